@@ -1,0 +1,226 @@
+"""CPU oracle loader (ctypes).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  The product (orb_slam2_e_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Keypoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int), ("class_id", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "fem_oracle.c", "orb_pattern_data.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.oracle_orb_create.restype = C.c_void_p
+        L.oracle_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_orb_destroy.argtypes = [C.c_void_p]
+        L.oracle_orb_set_blur_taps.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_fastAtan2.restype = C.c_float
+        L.oracle_fastAtan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_cvRound.argtypes = [C.c_float]
+        L.oracle_orb_scale_factor.restype = C.c_float
+        L.oracle_orb_scale_factor.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_orb_features_per_level.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_orb_umax.restype = C.POINTER(C.c_int)
+        L.oracle_orb_umax.argtypes = [C.c_void_p]
+        for name in ("oracle_orb_level_padded", "oracle_orb_level_blurred", "oracle_orb_level_cands",
+                     "oracle_orb_level_kps"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        for name in ("oracle_orb_level_ncands", "oracle_orb_level_nkps"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        L.oracle_orb_level_dims.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_grid_build.restype = C.c_void_p
+        L.oracle_grid_build.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.oracle_grid_free.argtypes = [C.c_void_p]
+        L.oracle_grid_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                                   C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_match_filter.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbOracle:
+    """Mirror of ORBextractor (ORBextractor.h:46-112) on the CPU restatement."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.oracle_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_orb_destroy(self.h)
+            self.h = None
+
+    def set_blur_taps(self, taps):
+        t = np.asarray(taps, dtype=np.int32)
+        assert t.shape == (7,)
+        self.L.oracle_orb_set_blur_taps(self.h, _p(t))
+
+    def features_per_level(self):
+        return [self.L.oracle_orb_features_per_level(self.h, l) for l in range(self.nlevels)]
+
+    def scale_factors(self):
+        return [self.L.oracle_orb_scale_factor(self.h, l) for l in range(self.nlevels)]
+
+    def umax(self):
+        p = self.L.oracle_orb_umax(self.h)
+        return [p[i] for i in range(16)]
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        rc = self.L.oracle_orb_extract(self.h, _p(img), w, h, w, _p(kps), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"oracle_orb_extract rc={rc}")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_dims(self, l):
+        w, h, s = C.c_int(), C.c_int(), C.c_int()
+        self.L.oracle_orb_level_dims(self.h, l, C.byref(w), C.byref(h), C.byref(s))
+        return w.value, h.value, s.value
+
+    def level_padded(self, l):
+        w, h, s = self.level_dims(l)
+        p = self.L.oracle_orb_level_padded(self.h, l)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h + 38, s)).copy()
+
+    def level_image(self, l):
+        return self.level_padded(l)[19:-19, 19:-19]
+
+    def level_blurred(self, l):
+        w, h, _ = self.level_dims(l)
+        p = self.L.oracle_orb_level_blurred(self.h, l)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h, w)).copy()
+
+    def level_cands(self, l):
+        n = self.L.oracle_orb_level_ncands(self.h, l)
+        p = self.L.oracle_orb_level_cands(self.h, l)
+        if n == 0:
+            return np.zeros(0, dtype=CAND_DTYPE)
+        buf = (C.c_char * (n * CAND_DTYPE.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=CAND_DTYPE).copy()
+
+    def level_kps(self, l):
+        n = self.L.oracle_orb_level_nkps(self.h, l)
+        p = self.L.oracle_orb_level_kps(self.h, l)
+        if n == 0:
+            return np.zeros(0, dtype=KP_DTYPE)
+        buf = (C.c_char * (n * KP_DTYPE.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=KP_DTYPE).copy()
+
+
+def octree_distribute(cands, min_x, max_x, min_y, max_y, N):
+    L = lib()
+    c = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+    out = np.zeros(len(c) + 8, dtype=np.int32)
+    n = L.oracle_octree_distribute(_p(c), len(c), min_x, max_x, min_y, max_y, N, _p(out), len(out))
+    if n < 0:
+        raise ValueError("nIni < 1")
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    L = lib()
+    a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+    return L.oracle_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_matrix(A, B):
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.uint8); B = np.ascontiguousarray(B, dtype=np.uint8)
+    out = np.zeros((len(A), len(B)), dtype=np.uint16)
+    L.oracle_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(out))
+    return out
+
+
+def match_bruteforce(A, B):
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.uint8); B = np.ascontiguousarray(B, dtype=np.uint8)
+    best = np.zeros(len(A), np.int32); second = np.zeros(len(A), np.int32); idx = np.zeros(len(A), np.int32)
+    L.oracle_match_bruteforce(_p(A), len(A), _p(B), len(B), _p(best), _p(second), _p(idx))
+    return best, second, idx
+
+
+def match_candidates(A, B, cand_off, cand_idx):
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.uint8); B = np.ascontiguousarray(B, dtype=np.uint8)
+    off = np.ascontiguousarray(cand_off, np.int32); ci = np.ascontiguousarray(cand_idx, np.int32)
+    best = np.zeros(len(A), np.int32); second = np.zeros(len(A), np.int32); idx = np.zeros(len(A), np.int32)
+    L.oracle_match_candidates(_p(A), len(A), _p(B), _p(off), _p(ci), _p(best), _p(second), _p(idx))
+    return best, second, idx
+
+
+def match_filter(best, second, idx, th, nnratio):
+    L = lib()
+    m = np.zeros(len(best), np.int32)
+    n = L.oracle_match_filter(len(best), _p(np.ascontiguousarray(best, np.int32)),
+                              _p(np.ascontiguousarray(second, np.int32)),
+                              _p(np.ascontiguousarray(idx, np.int32)), th, nnratio, _p(m))
+    return m, n
+
+
+def three_maxima(sizes):
+    L = lib()
+    s = np.ascontiguousarray(sizes, np.int32)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    L.oracle_three_maxima(_p(s), len(s), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+class Grid:
+    """Frame grid (Frame.cc:245-260,342-407) on the CPU restatement."""
+
+    def __init__(self, xy, octave, min_x, min_y, max_x, max_y):
+        self.L = lib()
+        self.xy = np.ascontiguousarray(xy, np.float32)
+        self.octave = np.ascontiguousarray(octave, np.int32)
+        self.h = self.L.oracle_grid_build(_p(self.xy), len(self.xy), min_x, min_y, max_x, max_y)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_grid_free(self.h)
+            self.h = None
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(len(self.xy) + 1, np.int32)
+        n = self.L.oracle_grid_features_in_area(self.h, _p(self.xy), _p(self.octave), x, y, r,
+                                                min_level, max_level, _p(out), len(out))
+        return out[:n].copy()

@@ -1,0 +1,191 @@
+/*
+ * oracle/match_oracle.c -- CPU restatement of the ORBmatcher data plane.
+ *
+ * TEST INFRASTRUCTURE ONLY (see orb_oracle.c header).  PARITY UNPINNED: the
+ * reference holds no tests/golden vectors; pinned by known-answer tests only.
+ *
+ * Follows src/ORBmatcher.cc: DescriptorDistance :1848-1864 (SWAR popcount, literal),
+ * the best / second-best selection loop common to every Search* function
+ * (e.g. :645-672, :96-118: strict '<' so the first-seen candidate wins ties,
+ * second updated with 'else if'), the TH_LOW / nnratio acceptance test
+ * (:674-676: bestDist<=TH_LOW && bestDist<(float)bestDist2*mfNNratio),
+ * ComputeThreeMaxima :1802-1843, and Frame::GetFeaturesInArea (src/Frame.cc:342-395)
+ * with AssignFeaturesToGrid/PosInGrid (:245-260,:397-407).
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ORBmatcher::DescriptorDistance, ORBmatcher.cc:1848-1864 */
+int oracle_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0, i;
+    for (i = 0; i < 8; i++) {
+        uint32_t pa, pb, v;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+void oracle_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint16_t *out)
+{
+    int i, j;
+    for (i = 0; i < nA; i++)
+        for (j = 0; j < nB; j++)
+            out[(size_t)i * nB + j] = (uint16_t)oracle_descriptor_distance(A + 32 * (size_t)i, B + 32 * (size_t)j);
+}
+
+/* Per query row: best, second-best and arg-best over ALL of B in index order
+ * (SURVEY 8d config-2 task).  Empty B: best=second=INT_MAX, idx=-1. */
+void oracle_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB,
+                             int *best, int *second, int *idx)
+{
+    int i, j;
+    for (i = 0; i < nA; i++) {
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1;
+        for (j = 0; j < nB; j++) {
+            int dist = oracle_descriptor_distance(A + 32 * (size_t)i, B + 32 * (size_t)j);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = j; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        best[i] = bestDist; second[i] = bestDist2; idx[i] = bestIdx;
+    }
+}
+
+/* Same selection over a gated candidate list per query (CSR: cand_off[nA+1],
+ * cand_idx[] in GetFeaturesInArea / BoW-member order). */
+void oracle_match_candidates(const uint8_t *A, int nA, const uint8_t *B,
+                             const int *cand_off, const int *cand_idx,
+                             int *best, int *second, int *idx)
+{
+    int i, k;
+    for (i = 0; i < nA; i++) {
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1;
+        for (k = cand_off[i]; k < cand_off[i + 1]; k++) {
+            int j = cand_idx[k];
+            int dist = oracle_descriptor_distance(A + 32 * (size_t)i, B + 32 * (size_t)j);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = j; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        best[i] = bestDist; second[i] = bestDist2; idx[i] = bestIdx;
+    }
+}
+
+/* Acceptance test: bestDist<=th && bestDist<(float)bestDist2*nnratio.
+ * match12[i] = idx or -1; returns the number of accepted rows. */
+int oracle_match_filter(int nA, const int *best, const int *second, const int *idx,
+                        int th, float nnratio, int *match12)
+{
+    int i, n = 0;
+    for (i = 0; i < nA; i++) {
+        match12[i] = -1;
+        if (idx[i] >= 0 && best[i] <= th && (float)best[i] < (float)second[i] * nnratio) {
+            match12[i] = idx[i];
+            n++;
+        }
+    }
+    return n;
+}
+
+/* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1802-1843 (histogram sizes in). */
+void oracle_three_maxima(const int *histo_size, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0, i;
+    *ind1 = *ind2 = *ind3 = -1;
+    for (i = 0; i < L; i++) {
+        const int s = histo_size[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* ---- Frame grid: AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea ------- */
+#define FRAME_GRID_ROWS 48 /* include/Frame.h:37 */
+#define FRAME_GRID_COLS 64 /* include/Frame.h:38 */
+
+typedef struct {
+    float minX, minY, maxX, maxY, invW, invH;
+    int *cell_off;   /* [COLS*ROWS+1], cells indexed col*ROWS+row */
+    int *cell_items; /* keypoint indices, insertion order inside a cell */
+    int n;
+} oracle_grid;
+
+/* Frame::PosInGrid, Frame.cc:397-407 */
+static int pos_in_grid(const oracle_grid *g, float x, float y, int *px, int *py)
+{
+    *px = (int)roundf((x - g->minX) * g->invW);
+    *py = (int)roundf((y - g->minY) * g->invH);
+    if (*px < 0 || *px >= FRAME_GRID_COLS || *py < 0 || *py >= FRAME_GRID_ROWS) return 0;
+    return 1;
+}
+
+/* Frame::AssignFeaturesToGrid, Frame.cc:245-260; bounds as Frame ctor sets them
+ * (mfGridElementWidthInv = COLS/(maxX-minX), Frame.cc:221-222). */
+oracle_grid *oracle_grid_build(const float *xy, int n, float minX, float minY, float maxX, float maxY)
+{
+    oracle_grid *g = (oracle_grid *)calloc(1, sizeof(oracle_grid));
+    const int NC = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    int i, *cnt, *cell;
+    g->minX = minX; g->minY = minY; g->maxX = maxX; g->maxY = maxY; g->n = n;
+    g->invW = (float)FRAME_GRID_COLS / (maxX - minX);
+    g->invH = (float)FRAME_GRID_ROWS / (maxY - minY);
+    g->cell_off = (int *)calloc(NC + 1, sizeof(int));
+    g->cell_items = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    cell = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    cnt = (int *)calloc(NC, sizeof(int));
+    for (i = 0; i < n; i++) {
+        int px, py;
+        cell[i] = pos_in_grid(g, xy[2 * i], xy[2 * i + 1], &px, &py) ? px * FRAME_GRID_ROWS + py : -1;
+        if (cell[i] >= 0) g->cell_off[cell[i] + 1]++;
+    }
+    for (i = 0; i < NC; i++) g->cell_off[i + 1] += g->cell_off[i];
+    for (i = 0; i < n; i++)
+        if (cell[i] >= 0) g->cell_items[g->cell_off[cell[i]] + cnt[cell[i]]++] = i;
+    free(cnt); free(cell);
+    return g;
+}
+void oracle_grid_free(oracle_grid *g) { if (g) { free(g->cell_off); free(g->cell_items); free(g); } }
+
+/* Frame::GetFeaturesInArea, Frame.cc:342-395.  Result order: column-major
+ * cells, insertion order inside a cell.  Returns the count (<= cap written). */
+int oracle_grid_features_in_area(const oracle_grid *g, const float *xy, const int *octave,
+                                 float x, float y, float r, int minLevel, int maxLevel,
+                                 int *out, int cap)
+{
+    int n = 0, ix, iy, k;
+    const int nMinCellX = (int)fmaxf(0.f, floorf((x - g->minX - r) * g->invW));
+    int nMaxCellX, nMinCellY, nMaxCellY, bCheckLevels;
+    if (nMinCellX >= FRAME_GRID_COLS) return 0;
+    nMaxCellX = (int)fminf((float)FRAME_GRID_COLS - 1, ceilf((x - g->minX + r) * g->invW));
+    if (nMaxCellX < 0) return 0;
+    nMinCellY = (int)fmaxf(0.f, floorf((y - g->minY - r) * g->invH));
+    if (nMinCellY >= FRAME_GRID_ROWS) return 0;
+    nMaxCellY = (int)fminf((float)FRAME_GRID_ROWS - 1, ceilf((y - g->minY + r) * g->invH));
+    if (nMaxCellY < 0) return 0;
+    bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * FRAME_GRID_ROWS + iy;
+            for (k = g->cell_off[c]; k < g->cell_off[c + 1]; k++) {
+                const int j = g->cell_items[k];
+                float distx, disty;
+                if (bCheckLevels) {
+                    if (octave[j] < minLevel) continue;
+                    if (maxLevel >= 0 && octave[j] > maxLevel) continue;
+                }
+                distx = xy[2 * j] - x; disty = xy[2 * j + 1] - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) { if (n < cap) out[n] = j; n++; }
+            }
+        }
+    return n;
+}
