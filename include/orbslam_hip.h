@@ -1,0 +1,150 @@
+/*
+ * orbslam_hip.h -- C ABI of the MI355X-native front-end hot path of ORB_SLAM2_E.
+ *
+ * One shared library (liborbslam_hip.so), plain pointers and sizes, int status
+ * codes, never throws.  Each entry point names the reference interface it
+ * replaces (paths relative to the ORB_SLAM2_E tree).  INTEGRATION.md shows the
+ * reference-side C++ binding (ORBextractor / ORBmatcher / FEA2 shells).
+ *
+ * Conventions
+ *   - `*_dev` pointers are device (HBM) addresses, everything else is host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - Status: 0 = ORBX_OK, negative = error (see enum).  No CPU fallback exists:
+ *     without a usable HIP device every compute call returns ORBX_ERR_NO_DEVICE.
+ */
+#ifndef ORBSLAM_HIP_H
+#define ORBSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ORBX_OK = 0,
+    ORBX_ERR_ARG = -1,        /* null pointer, bad size, image too small for the 30-px cell grid */
+    ORBX_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure at init */
+    ORBX_ERR_HIP = -3,        /* a HIP call failed; orbx_last_error() has the text */
+    ORBX_ERR_CAPACITY = -4,   /* caller buffer or configured capacity too small */
+    ORBX_ERR_UNSUPPORTED = -5 /* parameter outside the supported range */
+};
+
+const char *orbx_last_error(void);
+/* ABI version of this header (major*100+minor). */
+int orbx_abi_version(void);
+
+/* ------------------------------------------------------------------ extractor
+ * Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:46-112,
+ * src/ORBextractor.cc:410-470 ctor, :1051-1113 operator()).                   */
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct orbx_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbx_keypoint;
+
+typedef struct orbx_params {
+    int32_t nfeatures;     /* ORBextractor ctor arg 1 */
+    float scale_factor;    /* arg 2 */
+    int32_t nlevels;       /* arg 3 (1..16) */
+    int32_t ini_th_fast;   /* arg 4 */
+    int32_t min_th_fast;   /* arg 5 */
+    int32_t blur_variant;  /* 0: 7-tap 8.8 kernel {18,34,48,56,48,34,18} (sum 256, canonical);
+                              1: {18,34,49,55,49,34,18} (taps rounded individually) */
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) */
+int orbx_create(const orbx_params *params, orbx_extractor **out);
+int orbx_destroy(orbx_extractor *ex);
+
+/* Getters: ORBextractor.h:61-84 (GetLevels, GetScaleFactors, GetInverseScaleFactors,
+ * GetScaleSigmaSquares, GetInverseScaleSigmaSquares) + mnFeaturesPerLevel (:97). */
+int orbx_get_levels(const orbx_extractor *ex);
+int orbx_get_scale_factors(const orbx_extractor *ex, float *out_nlevels);
+int orbx_get_inv_scale_factors(const orbx_extractor *ex, float *out_nlevels);
+int orbx_get_level_sigma2(const orbx_extractor *ex, float *out_nlevels);
+int orbx_get_inv_level_sigma2(const orbx_extractor *ex, float *out_nlevels);
+int orbx_get_features_per_level(const orbx_extractor *ex, int32_t *out_nlevels);
+/* Upper bound on keypoints per frame: nfeatures + 3*nlevels. */
+int orbx_keypoint_capacity(const orbx_extractor *ex);
+
+/* Size the device workspace for `batch` frames of width x height (idempotent;
+ * called implicitly by the extract calls). */
+int orbx_reserve(orbx_extractor *ex, int width, int height, int batch);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) for ONE host image
+ * (CV_8UC1, `stride` bytes per row).  Writes up to `cap` keypoints / 32-byte
+ * descriptor rows; *n = count.  An empty image (NULL / 0 size) returns ORBX_OK
+ * with outputs untouched and *n = 0 (ORBextractor.cc:1054-1055). */
+int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride,
+                 orbx_keypoint *kps, uint8_t *desc, int cap, int *n);
+
+/* Batch form: `batch` frames, frame f at images + f*frame_stride.  images_dev may
+ * be a device pointer (is_device=1: inputs already resident in HBM) or host.
+ * Results stay on the device until orbx_download / orbx_result_dev. Asynchronous
+ * on `stream`. */
+int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
+                       int width, int height, int stride, size_t frame_stride, int batch, void *stream);
+/* Copy frame f's result of the last batch to host (synchronises the stream). */
+int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *desc, int cap, int *n);
+/* Device-side result arrays of the last batch: kps[batch][capacity],
+ * desc[batch][capacity][32], counts[batch] (int32). */
+int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps_dev, const uint8_t **desc_dev,
+                    const int32_t **counts_dev, int *capacity);
+
+/* mvImagePyramid[level] of frame f of the last call (ORBextractor.h:86; read by
+ * Frame::ComputeStereoMatches, src/Frame.cc:534,624,636,641): copies the level
+ * image (without border) into out[height][out_stride]. */
+int orbx_level_size(const orbx_extractor *ex, int level, int *width, int *height);
+int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride);
+/* Same with the 19-px REFLECT_101 border: out[(h+38)][out_stride], width w+38. */
+int orbx_pyramid_level_padded(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride);
+
+/* Staged outputs for parity tests (no reference counterpart; they expose the
+ * intermediate values the reference keeps in locals):
+ *   blurred level image (GaussianBlur output, ORBextractor.cc:1093-1094),
+ *   FAST candidates per level = vToDistributeKeys (:826-834) as (x,y,response) triples,
+ *   per-level keypoints after DistributeOctTree + orientation (:842-860). */
+int orbx_debug_blurred_level(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride);
+int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, float *xyr, int cap, int *n);
+int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *kps, int cap, int *n);
+
+/* -------------------------------------------------------------------- matcher
+ * Data plane of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:37-111).            */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1848-1864) for all pairs:
+ * out[nA][nB] uint16.  Host pointers; runs on the device. */
+int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint16_t *out);
+
+/* Best / second-best / arg-best per query row over all of B, first index wins
+ * ties -- the selection loop shared by every ORBmatcher::Search* (e.g.
+ * ORBmatcher.cc:645-672).  best/second = INT32_MAX and idx = -1 when nB == 0. */
+int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB,
+                          int32_t *best, int32_t *second, int32_t *idx);
+/* Same over gated candidate lists (CSR: cand_off[nA+1], cand_idx[] in
+ * GetFeaturesInArea / BoW-member order). */
+int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB,
+                          const int32_t *cand_off, const int32_t *cand_idx,
+                          int32_t *best, int32_t *second, int32_t *idx);
+/* Acceptance test of ORBmatcher.cc:674-676: best<=th && best<(float)second*nnratio.
+ * match12[i] = idx or -1; *nmatches = accepted rows.  Host arrays. */
+int orbm_match_filter(int nA, const int32_t *best, const int32_t *second, const int32_t *idx,
+                      int th, float nnratio, int32_t *match12, int *nmatches);
+
+/* Batched device form used by the frames/s pipeline: descriptor sets
+ * desc_dev[nsets][cap][32] with counts_dev[nsets]; pair p matches set qa[p]
+ * (queries) against set qb[p].  Outputs (device): best/second/idx/match12
+ * [npairs][cap] int32, nmatch[npairs].  Asynchronous on `stream`. */
+int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int cap,
+                         const int32_t *pair_a_dev, const int32_t *pair_b_dev, int npairs,
+                         int th, float nnratio,
+                         int32_t *best_dev, int32_t *second_dev, int32_t *idx_dev,
+                         int32_t *match12_dev, int32_t *nmatch_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBSLAM_HIP_H */

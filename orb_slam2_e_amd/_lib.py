@@ -1,0 +1,43 @@
+"""Build + load liborbslam_hip.so (the C-ABI of include/*.h) through ctypes.
+
+There is no CPU fallback: if the library is missing it is built with hipcc, and
+if it cannot be loaded the import fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liborbslam_hip.so")
+_LIB = None
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"orbslam_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", csrc] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("liborbslam_hip.so was not produced by the build")
+    return SO_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            build()
+        _LIB = C.CDLL(SO_PATH)
+        _LIB.orbx_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise OrbxError(rc, lib().orbx_last_error().decode())
+    return rc

@@ -1,0 +1,1114 @@
+// orbx_extract.hip -- ORB extractor (FAST pyramid + octree + rBRIEF) for gfx950.
+//
+// Replaces ORB_SLAM2::ORBextractor (src/ORBextractor.cc, include/ORBextractor.h).
+// One batch = B independent frames; every stage is one launch over all frames
+// (and, where there is no dependency, all pyramid levels):
+//
+//   k_pyr_level0    copyMakeBorder of the input            (:1135)
+//   k_pyr_resize    resize level l from l-1 + border       (:1128-1131)   x (nlevels-1)
+//   k_fast_cells    per 30-px cell FAST-9/16 score + NMS + threshold fallback (:789-837)
+//   k_octree        DistributeOctTree as scan-based rounds (:539-763)
+//   k_blur          GaussianBlur 7x7 sigma 2               (:1093-1094)
+//   k_describe      IC_Angle + steered BRIEF + output      (:77-147, :845-860, :1103-1111)
+//
+// HBM layout: per frame one pyramid block; level l is a padded image of
+// (h_l + 38) rows x stride_l bytes, inner pixel (x, y) at off_l + (y+19)*stride_l + 32 + x
+// (19-px REFLECT_101 border as in mvImagePyramid; 32-byte left pad keeps inner
+// rows dword/16-B aligned).  All integer work is bit-exact by construction; the
+// float steps (fastAtan2, rBRIEF rotation) use fixed IEEE op sequences (orbx_math.h,
+// built with -ffp-contract=off).
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "common.h"
+#include "orbx_math.h"
+
+namespace {
+
+constexpr int EDGE = 19;  // EDGE_THRESHOLD, ORBextractor.cc:74
+constexpr int PADX = 32;  // left pad (bytes) of every pyramid row
+constexpr int MAXL = 16;
+constexpr int MIN_BORDER = EDGE - 3; // minBorderX/Y, ORBextractor.cc:773
+constexpr int OCT_T = 256;           // threads of k_octree
+constexpr int OCT_MAXN = 1023;       // largest per-level feature quota supported
+
+struct LevelInfo {
+    int w, h, stride, off; // inner size, row stride (bytes), offset of the padded block in a frame
+    int W, H;              // octree box = FAST region (maxBorder - minBorder)
+    int N;                 // mnFeaturesPerLevel[l]
+    int ncells, cell_base; // cell slots [cell_base, cell_base + ncells) of a frame
+    int key_base;          // first key slot of this level in a frame's key workspace
+    int sel_base;          // first slot of this level in a frame's selected-keypoint array
+    int nIni;
+    float hX;
+    float scale; // mvScaleFactor[l]
+    int patch;   // scaledPatchSize = int(31 * scale)
+    int xtab, ytab;
+};
+
+struct CellInfo {
+    short level, x0, y0, cw, ch, dx, dy, pad; // sub-image origin/size in level coords; pt offset
+    int cand_off;                             // first candidate slot of the cell in a frame
+    int cap;
+};
+
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// ------------------------------------------------------------------ pyramid
+// Level 0: copyMakeBorder(image, temp, 19,19,19,19, BORDER_REFLECT_101), ORBextractor.cc:1135.
+__global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ img, int img_stride,
+                                                   size_t img_frame_stride, uint8_t *__restrict__ pyr,
+                                                   size_t frame_bytes, LevelInfo lv)
+{
+    const int xw = blockIdx.x * 64 + threadIdx.x;
+    if (xw * 4 >= lv.stride) return;
+    const int row = blockIdx.y, f = blockIdx.z;
+    const int sy = reflect101(row - EDGE, lv.h);
+    const uint8_t *src = img + (size_t)f * img_frame_stride + (size_t)sy * img_stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int px = xw * 4 + b - PADX;
+        uint32_t v = 0;
+        if (px >= -EDGE && px < lv.w + EDGE) v = src[reflect101(px, lv.w)];
+        out |= v << (8 * b);
+    }
+    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + lv.off + (size_t)row * lv.stride + xw * 4) = out;
+}
+
+// Level l from level l-1: cv::resize INTER_LINEAR 8U fixed point
+// + REFLECT_101 border (recomputed, not copied).  xt[dx] = {sx, a0 | a1<<16},
+// yt[dy] = {sy0, sy1, b0, b1}: OpenCV's coefficient tables, built on the host.
+__global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
+                                                   LevelInfo dst, const int2 *__restrict__ xt,
+                                                   const int4 *__restrict__ yt)
+{
+    const int xw = blockIdx.x * 64 + threadIdx.x;
+    if (xw * 4 >= dst.stride) return;
+    const int row = blockIdx.y, f = blockIdx.z;
+    const int dy = reflect101(row - EDGE, dst.h);
+    const int4 yy = yt[dy];
+    const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
+    const uint8_t *S0 = base + (size_t)(yy.x + EDGE) * src.stride;
+    const uint8_t *S1 = base + (size_t)(yy.y + EDGE) * src.stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int px = xw * 4 + b - PADX;
+        uint32_t v = 0;
+        if (px >= -EDGE && px < dst.w + EDGE) {
+            const int2 xx = xt[reflect101(px, dst.w)];
+            const int a0 = xx.y & 0xffff, a1 = xx.y >> 16;
+            const int r0 = S0[xx.x] * a0 + S0[xx.x + 1] * a1;
+            const int r1 = S1[xx.x] * a0 + S1[xx.x + 1] * a1;
+            v = (uint32_t)((((yy.z * (r0 >> 4)) >> 16) + ((yy.w * (r1 >> 4)) >> 16) + 2) >> 2);
+            v = v > 255u ? 255u : v;
+        }
+        out |= v << (8 * b);
+    }
+    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (size_t)row * dst.stride + xw * 4) = out;
+}
+
+// --------------------------------------------------------------------- FAST
+__device__ __forceinline__ bool has9(unsigned m)
+{
+    m |= m << 16;
+    unsigned x = m & (m >> 1);
+    x &= x >> 2;
+    x &= x >> 4;
+    x &= m >> 8;
+    return (x & 0xffffu) != 0;
+}
+
+// cv::FAST score of one pixel: 0 if it is not a FAST-9/16 corner at threshold
+// `th`, else cornerScore<16> = (largest arc-minimum of |v - p_k| over the 16
+// 9-arcs) - 1, which does not depend on th.
+__device__ __forceinline__ int fast_score(const uint8_t *t, int ts, int th)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * ts];       d[1] = v - t[3 * ts + 1];   d[2] = v - t[2 * ts + 2];   d[3] = v - t[ts + 3];
+    d[4] = v - t[3];            d[5] = v - t[-ts + 3];      d[6] = v - t[-2 * ts + 2];  d[7] = v - t[-3 * ts + 1];
+    d[8] = v - t[-3 * ts];      d[9] = v - t[-3 * ts - 1];  d[10] = v - t[-2 * ts - 2]; d[11] = v - t[-ts - 3];
+    d[12] = v - t[-3];          d[13] = v - t[ts - 3];      d[14] = v - t[2 * ts - 2];  d[15] = v - t[3 * ts - 1];
+    unsigned dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        dark |= (unsigned)(d[k] > th) << k;
+        bright |= (unsigned)(d[k] < -th) << k;
+    }
+    const bool isd = has9(dark), isb = has9(bright);
+    if (!(isd || isb)) return 0;
+    int e[16], m[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = isd ? d[k] : -d[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = min(e[k], e[(k + 1) & 15]);
+    int m4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m4[k] = min(m[k], m[(k + 2) & 15]);
+    int best = -256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int m9 = min(min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]);
+        best = max(best, m9);
+    }
+    return best - 1;
+}
+
+// One wave per 30-px cell (ORBextractor.cc:789-837): cv::FAST(cell, iniThFAST, nms=true),
+// rerun with minThFAST only if the cell came back empty; candidates are written
+// in FAST raster order, coordinates relative to (minBorderX, minBorderY).
+// Packed candidate: y<<20 | x<<8 | score.
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_bytes,
+                                                   const LevelInfo *__restrict__ L,
+                                                   const CellInfo *__restrict__ cells, int *__restrict__ cell_count,
+                                                   int cells_per_frame, uint32_t *__restrict__ cands,
+                                                   size_t cands_per_frame, int iniTh, int minTh, int TS,
+                                                   int tile_bytes, int SS)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint8_t *tile = smem;
+    uint8_t *sc = smem + tile_bytes;
+    const int c = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const CellInfo ci = cells[c];
+    const LevelInfo lv = L[ci.level];
+    const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
+    int total = 0;
+    if (zw > 0 && zh > 0) {
+        const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + ci.x0;
+        for (int y = 0; y < ch; ++y)
+            for (int x = lane; x < cw; x += 64) tile[y * TS + x] = img[(size_t)y * lv.stride + x];
+        for (int i = lane; i < (zh + 2) * SS; i += 64) sc[i] = 0;
+        __syncthreads();
+        const int npx = zw * zh;
+        {
+            int x = lane, y = 0;
+            while (x >= zw) { x -= zw; ++y; }
+            for (int p = lane; p < npx; p += 64) {
+                sc[(y + 1) * SS + x + 1] = (uint8_t)fast_score(tile + (y + 3) * TS + x + 3, TS, minTh);
+                x += 64;
+                while (x >= zw) { x -= zw; ++y; }
+            }
+        }
+        __syncthreads();
+        // 3x3 strict non-max suppression; the local-maximum flag does not depend on
+        // the threshold (a neighbour below it is < the centre anyway).
+        unsigned long long mx = 0, hi = 0;
+        int nhi = 0;
+        {
+            int x = lane, y = 0, it = 0;
+            while (x >= zw) { x -= zw; ++y; }
+            for (int p0 = 0; p0 < npx; p0 += 64, ++it) {
+                bool ismax = false, ishi = false;
+                if (p0 + lane < npx) {
+                    const uint8_t *q = sc + (y + 1) * SS + x + 1;
+                    const int s = q[0];
+                    ismax = s > 0 && s > q[-1] && s > q[1] && s > q[-SS - 1] && s > q[-SS] && s > q[-SS + 1] &&
+                            s > q[SS - 1] && s > q[SS] && s > q[SS + 1];
+                    ishi = ismax && s >= iniTh;
+                }
+                mx |= (unsigned long long)ismax << it;
+                hi |= (unsigned long long)ishi << it;
+                nhi += __popcll(__ballot(ishi));
+                x += 64;
+                while (x >= zw) { x -= zw; ++y; }
+            }
+        }
+        const unsigned long long sel = nhi > 0 ? hi : mx;
+        uint32_t *out = cands + (size_t)f * cands_per_frame + ci.cand_off;
+        {
+            int x = lane, y = 0, it = 0;
+            while (x >= zw) { x -= zw; ++y; }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (int p0 = 0; p0 < npx; p0 += 64, ++it) {
+                const bool flag = (sel >> it) & 1ull;
+                const unsigned long long b = __ballot(flag);
+                if (flag) {
+                    const int pos = total + __popcll(b & lt);
+                    const uint32_t s = sc[(y + 1) * SS + x + 1];
+                    if (pos < ci.cap)
+                        out[pos] = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | s;
+                }
+                total += __popcll(b);
+                x += 64;
+                while (x >= zw) { x -= zw; ++y; }
+            }
+        }
+    }
+    if (lane == 0) cell_count[(size_t)f * cells_per_frame + c] = total;
+}
+
+// ------------------------------------------------------------------- octree
+// Exclusive scan of a[0..n) in place by the whole block; returns the total.
+__device__ int block_excl_scan(int *a, int n, int *part)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    const int per = (n + OCT_T - 1) / OCT_T;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += a[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < OCT_T; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int total = part[OCT_T - 1];
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = b; i < e; ++i) {
+        const int v = a[i];
+        a[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+// Children of node box (x0,x1,y0,y1): ExtractorNode::DivideNode, ORBextractor.cc:481-509.
+__device__ __forceinline__ void child_box(int x0, int x1, int y0, int y1, int q, int &cx0, int &cx1, int &cy0, int &cy1)
+{
+    const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2);
+    const int my = y0 + (int)ceilf((float)(y1 - y0) / 2);
+    cx0 = (q & 1) ? mx : x0;
+    cx1 = (q & 1) ? x1 : mx;
+    cy0 = (q & 2) ? my : y0;
+    cy1 = (q & 2) ? y1 : my;
+}
+
+// DistributeOctTree (ORBextractor.cc:539-763) for one (level, frame) per block.
+// Each pass of the reference's list surgery is one "round": which nodes split,
+// where their children land in the list, and where the untouched nodes move are
+// all prefix sums (tests/octree_model.py is the same formulation in Python and is
+// checked against the literal list-based oracle).  Equal-size ties in the
+// largest-first phase use creation order.
+__global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ L, const CellInfo *__restrict__ cells,
+                                                  const int *__restrict__ cell_count, int cells_per_frame,
+                                                  const uint32_t *__restrict__ cands, size_t cands_per_frame,
+                                                  uint32_t *__restrict__ kpos_all, unsigned short *__restrict__ knode_all,
+                                                  uint8_t *__restrict__ kq_all, size_t keys_per_frame,
+                                                  uint32_t *__restrict__ sel_all, int sel_per_frame,
+                                                  int *__restrict__ level_count, int *__restrict__ level_ncand,
+                                                  int nlevels, int NC, int maxcells)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *p = reinterpret_cast<int *>(smem);
+    int *part = p;          p += OCT_T;
+    int *s_cell = p;        p += maxcells + 1;
+    int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
+    int *by[2] = {p, p + NC};  p += 2 * NC; // y0 | y1<<16
+    int *cnt[2] = {p, p + NC}; p += 2 * NC;
+    int *seq[2] = {p, p + NC}; p += 2 * NC;
+    int *cc = p;            p += 4 * NC;
+    int *nne = p;           p += NC;
+    int *eexp = p;          p += NC;
+    int *rnk = p;           p += NC;
+    int *order = p;         p += NC;
+    int *split = p;         p += NC;
+    int *bstart = p;        p += NC;
+    int *ebase = p;         p += NC;
+    int *a1 = p;            p += NC;
+    int *a2 = p;            p += NC;
+    int *a3 = p;            p += NC;
+    __shared__ int s_nproc;
+
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelInfo lv = L[l];
+    const int N = lv.N;
+    uint32_t *kpos = kpos_all + (size_t)f * keys_per_frame + lv.key_base;
+    unsigned short *knode = knode_all + (size_t)f * keys_per_frame + lv.key_base;
+    uint8_t *kq = kq_all + (size_t)f * keys_per_frame + lv.key_base;
+
+    // gather the level's candidates in cell row-major order (vToDistributeKeys)
+    for (int c = tid; c < lv.ncells; c += OCT_T) {
+        const int n = cell_count[(size_t)f * cells_per_frame + lv.cell_base + c];
+        const int cap = cells[lv.cell_base + c].cap;
+        s_cell[c] = n < cap ? n : cap;
+    }
+    if (tid == 0) s_cell[lv.ncells] = 0;
+    const int M = block_excl_scan(s_cell, lv.ncells, part);
+    if (tid == 0) s_cell[lv.ncells] = M;
+    for (int i = tid; i < NC; i += OCT_T) cnt[0][i] = 0;
+    __syncthreads();
+    for (int k = tid; k < M; k += OCT_T) {
+        int lo = 0, hiC = lv.ncells; // largest c with s_cell[c] <= k
+        while (hiC - lo > 1) {
+            const int mid = (lo + hiC) >> 1;
+            if (s_cell[mid] <= k) lo = mid; else hiC = mid;
+        }
+        const uint32_t pk = cands[(size_t)f * cands_per_frame + cells[lv.cell_base + lo].cand_off + (k - s_cell[lo])];
+        kpos[k] = pk;
+        const float x = (float)((pk >> 8) & 0xfffu);
+        const int root = (int)(x / lv.hX); // vpIniNodes[kp.pt.x/hX], :569
+        knode[k] = (unsigned short)root;
+        atomicAdd(&cnt[0][root], 1);
+    }
+    __syncthreads();
+    // roots (:552-563), empty ones erased (:574-585)
+    for (int i = tid; i < lv.nIni; i += OCT_T) a1[i] = cnt[0][i] > 0 ? 1 : 0;
+    int S = block_excl_scan(a1, lv.nIni, part);
+    for (int i = tid; i < lv.nIni; i += OCT_T) {
+        if (cnt[0][i] > 0) {
+            const int x0 = (int)(lv.hX * (float)i), x1 = (int)(lv.hX * (float)(i + 1));
+            const int pos = a1[i];
+            bx[1][pos] = x0 | (x1 << 16);
+            by[1][pos] = 0 | (lv.H << 16);
+            cnt[1][pos] = cnt[0][i];
+            seq[1][pos] = 0;
+        }
+    }
+    for (int k = tid; k < M; k += OCT_T) knode[k] = (unsigned short)a1[knode[k]];
+    __syncthreads();
+    int cur = 1, mode = 1;
+
+    while (true) {
+        int *cx = bx[cur], *cy = by[cur], *cn = cnt[cur], *cs = seq[cur];
+        for (int s = tid; s < S; s += OCT_T) {
+            a1[s] = cn[s] > 1 ? 1 : 0;
+            cc[4 * s] = cc[4 * s + 1] = cc[4 * s + 2] = cc[4 * s + 3] = 0;
+            split[s] = 0;
+        }
+        const int E = block_excl_scan(a1, S, part); // a1[s] = candidate index in list order
+        if (E == 0) break;
+        // children counts of every expandable node (DivideNode, :511-526)
+        for (int k = tid; k < M; k += OCT_T) {
+            const int s = knode[k];
+            if (cn[s] > 1) {
+                const uint32_t pk = kpos[k];
+                const float x = (float)((pk >> 8) & 0xfffu), y = (float)(pk >> 20);
+                const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
+                const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2);
+                const int my = y0 + (int)ceilf((float)(y1 - y0) / 2);
+                const int q = (x < (float)mx ? 0 : 1) + (y < (float)my ? 0 : 2);
+                kq[k] = (uint8_t)q;
+                atomicAdd(&cc[4 * s + q], 1);
+            }
+        }
+        __syncthreads();
+        for (int s = tid; s < S; s += OCT_T) {
+            int a = 0, b = 0;
+            if (cn[s] > 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a += cc[4 * s + q] > 0;
+                    b += cc[4 * s + q] > 1;
+                }
+            }
+            nne[s] = a;
+            eexp[s] = b;
+        }
+        __syncthreads();
+        int nproc = E;
+        if (mode == 1) {
+            // every expandable node splits, in list order (:606-665)
+            for (int s = tid; s < S; s += OCT_T)
+                if (cn[s] > 1) { rnk[s] = a1[s]; order[a1[s]] = s; }
+        } else {
+            // largest first, later-created first among equals (:684-732)
+            for (int s = tid; s < S; s += OCT_T) {
+                if (cn[s] > 1) {
+                    int r = 0;
+                    const int c0 = cn[s], q0 = cs[s];
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int c2 = cn[s2];
+                        r += (c2 > 1) && (c2 > c0 || (c2 == c0 && cs[s2] > q0));
+                    }
+                    rnk[s] = r;
+                    order[r] = s;
+                }
+            }
+            if (tid == 0) s_nproc = E;
+            __syncthreads();
+            for (int r = tid; r < E; r += OCT_T) a2[r] = nne[order[r]] - 1;
+            block_excl_scan(a2, E, part);
+            for (int r = tid; r < E; r += OCT_T)
+                if (S + a2[r] + nne[order[r]] - 1 >= N) atomicMin(&s_nproc, r + 1);
+            __syncthreads();
+            nproc = s_nproc;
+        }
+        __syncthreads();
+        for (int r = tid; r < nproc; r += OCT_T) {
+            a2[r] = nne[order[r]];
+            a3[r] = eexp[order[r]];
+        }
+        const int F = block_excl_scan(a2, nproc, part);
+        const int Etot = block_excl_scan(a3, nproc, part);
+        for (int r = tid; r < nproc; r += OCT_T) {
+            const int s = order[r];
+            split[s] = 1;
+            bstart[s] = F - (a2[r] + nne[s]); // children pushed to the front, last processed first
+            ebase[s] = a3[r];
+        }
+        __syncthreads();
+        for (int s = tid; s < S; s += OCT_T) a1[s] = split[s] ? 0 : 1;
+        const int nns = block_excl_scan(a1, S, part); // a1[s] = rank among nodes that stay
+        const int S2 = F + nns;
+        int *nx = bx[cur ^ 1], *ny = by[cur ^ 1], *nn = cnt[cur ^ 1], *ns = seq[cur ^ 1];
+        for (int s = tid; s < S; s += OCT_T) {
+            if (split[s]) {
+                const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
+                int e = ebase[s];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cc[4 * s + q];
+                    if (c > 0) {
+                        int after = 0;
+                        for (int q2 = q + 1; q2 < 4; ++q2) after += cc[4 * s + q2] > 0;
+                        const int pos = bstart[s] + after; // list shows n4,n3,n2,n1
+                        int c0, c1, d0, d1;
+                        child_box(x0, x1, y0, y1, q, c0, c1, d0, d1);
+                        nx[pos] = c0 | (c1 << 16);
+                        ny[pos] = d0 | (d1 << 16);
+                        nn[pos] = c;
+                        ns[pos] = c > 1 ? e++ : 0;
+                    }
+                }
+            } else {
+                const int pos = F + a1[s];
+                nx[pos] = cx[s]; ny[pos] = cy[s]; nn[pos] = cn[s]; ns[pos] = cs[s];
+            }
+        }
+        for (int k = tid; k < M; k += OCT_T) {
+            const int s = knode[k];
+            int pos;
+            if (split[s]) {
+                const int q = kq[k];
+                int after = 0;
+                for (int q2 = q + 1; q2 < 4; ++q2) after += cc[4 * s + q2] > 0;
+                pos = bstart[s] + after;
+            } else {
+                pos = F + a1[s];
+            }
+            knode[k] = (unsigned short)pos;
+        }
+        __syncthreads();
+        const int prevS = S;
+        S = S2;
+        cur ^= 1;
+        if (S >= N || S == prevS) break;          // :669-672, :734-735
+        if (mode == 1 && S + 3 * Etot > N) mode = 2; // :673
+    }
+    __syncthreads();
+    // best response per leaf, first candidate wins ties (:741-760)
+    int *best = a2;
+    for (int s = tid; s < S; s += OCT_T) best[s] = 0;
+    __syncthreads();
+    for (int k = tid; k < M; k += OCT_T)
+        atomicMax(reinterpret_cast<unsigned *>(&best[knode[k]]), ((kpos[k] & 0xffu) << 24) | (0xffffffu - (unsigned)k));
+    __syncthreads();
+    uint32_t *sel = sel_all + (size_t)f * sel_per_frame + lv.sel_base;
+    for (int s = tid; s < S; s += OCT_T) sel[s] = kpos[0xffffffu - ((unsigned)best[s] & 0xffffffu)];
+    if (tid == 0) {
+        level_count[f * nlevels + l] = S;
+        level_ncand[f * nlevels + l] = M;
+    }
+}
+
+// --------------------------------------------------------------------- blur
+struct BlurTile { short level, x0, y0, pad; };
+
+// GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point:
+// horizontal 7 taps exact in u16, vertical 7 taps exact in u32, (v + 2^15) >> 16.
+// The padded pyramid already holds the reflected border, so no index clamping.
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                              size_t frame_bytes, const LevelInfo *__restrict__ L,
+                                              const BlurTile *__restrict__ tiles, int t0, int t1, int t2, int t3)
+{
+    __shared__ uint8_t in[22][72];
+    __shared__ unsigned short hz[22][64];
+    const BlurTile bt = tiles[blockIdx.x];
+    const LevelInfo lv = L[bt.level];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const size_t base = (size_t)f * frame_bytes + lv.off + PADX;
+    for (int i = tid; i < 22 * 70; i += 256) {
+        const int r = i / 70, c = i - r * 70;
+        const int x = bt.x0 - 3 + c, y = bt.y0 - 3 + r;
+        uint8_t v = 0;
+        if (x < lv.w + 3 && y < lv.h + 3) v = pyr[base + (size_t)(y + EDGE) * lv.stride + x];
+        in[r][c] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 22 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t *q = &in[r][c];
+        hz[r][c] = (unsigned short)(t0 * (q[0] + q[6]) + t1 * (q[1] + q[5]) + t2 * (q[2] + q[4]) + t3 * q[3]);
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = (tid & 15) * 4;
+    const int x = bt.x0 + tx, y = bt.y0 + ty;
+    if (x < lv.w && y < lv.h) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t s = (uint32_t)t0 * (hz[ty][tx + b] + hz[ty + 6][tx + b]) +
+                               (uint32_t)t1 * (hz[ty + 1][tx + b] + hz[ty + 5][tx + b]) +
+                               (uint32_t)t2 * (hz[ty + 2][tx + b] + hz[ty + 4][tx + b]) +
+                               (uint32_t)t3 * hz[ty + 3][tx + b];
+            uint32_t v = (s + (1u << 15)) >> 16;
+            v = v > 255u ? 255u : v;
+            out |= v << (8 * b);
+        }
+        *reinterpret_cast<uint32_t *>(blur + base + (size_t)(y + EDGE) * lv.stride + x) = out;
+    }
+}
+
+// ----------------------------------------------------- orientation + rBRIEF
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// One wave per keypoint: IC_Angle (:77-104) on the unblurred level, then
+// computeOrbDescriptor (:108-147) on the blurred one, then the output record
+// (:845-855 octave/size, :1103-1109 pt *= scale).
+__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
+                                                  size_t frame_bytes, const LevelInfo *__restrict__ L, int nlevels,
+                                                  const uint32_t *__restrict__ sel_all, int sel_per_frame,
+                                                  const int *__restrict__ level_count,
+                                                  orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                  int *__restrict__ counts, int cap)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kidx = blockIdx.x * 4 + wv, f = blockIdx.y;
+    int level = -1, first = 0, total = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int c = level_count[f * nlevels + l];
+        if (level < 0 && kidx < total + c) { level = l; first = total; }
+        total += c;
+    }
+    if (kidx == 0 && lane == 0) counts[f] = total < cap ? total : cap;
+    if (level < 0 || kidx >= cap) return;
+    const LevelInfo lv = L[level];
+    const uint32_t pk = sel_all[(size_t)f * sel_per_frame + lv.sel_base + (kidx - first)];
+    const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
+    const size_t center = (size_t)f * frame_bytes + lv.off + (size_t)(y + EDGE) * lv.stride + PADX + x;
+
+    // intensity centroid over the radius-15 disc
+    // umax[|v|] = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3} (:454-469), 4 bits each
+    const unsigned long long umax_nib = 0x3689ABCDDEEEFFFFull;
+    int m10 = 0, m01 = 0;
+    {
+        const uint8_t *c0 = pyr + center;
+        const int u = (lane & 31) - 15, half = lane >> 5;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int v = -15 + it * 2 + half;
+            const int av = v < 0 ? -v : v;
+            if (v <= 15 && (lane & 31) < 31) {
+                const int au = u < 0 ? -u : u;
+                if (au <= (int)((umax_nib >> (4 * av)) & 15ull)) {
+                    const int val = c0[v * lv.stride + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = orbx_fast_atan2((float)m01, (float)m10);
+
+    // steered BRIEF: lane i evaluates tests 4i..4i+3
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    orbx_sincos_f32(angle * factorPI, &b, &a); // a = cos, b = sin
+    const uint8_t *cb = blur + center;
+    unsigned nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const signed char *pp = c_pattern + 16 * lane + 4 * t;
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const int t0 = cb[orbx_cvround(x0 * b + y0 * a) * lv.stride + orbx_cvround(x0 * a - y0 * b)];
+        const int t1 = cb[orbx_cvround(x1 * b + y1 * a) * lv.stride + orbx_cvround(x1 * a - y1 * b)];
+        nib |= (unsigned)(t0 < t1) << t;
+    }
+    unsigned byte = nib | (__shfl_down(nib, 1) << 4);                     // even lanes
+    unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
+    const size_t o = (size_t)f * cap + kidx;
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
+    if (lane == 0) {
+        orbx_keypoint kp;
+        kp.x = (float)x;
+        kp.y = (float)y;
+        if (level != 0) { kp.x *= lv.scale; kp.y *= lv.scale; }
+        kp.size = (float)lv.patch;
+        kp.angle = angle;
+        kp.response = (float)(pk & 0xffu);
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[o] = kp;
+    }
+}
+
+} // namespace
+
+// ======================================================================= host
+struct orbx_extractor {
+    orbx_params prm;
+    int nlevels;
+    float scale[MAXL], inv_scale[MAXL], sigma2[MAXL], inv_sigma2[MAXL];
+    int nfeat[MAXL];
+    int taps[4];
+    int kcap; // nfeatures + 3*nlevels
+
+    // geometry of the reserved workspace
+    int width = 0, height = 0, batch = 0;
+    LevelInfo lv[MAXL];
+    std::vector<CellInfo> cells;
+    std::vector<BlurTile> tiles;
+    size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
+    int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
+    int TS = 0, tile_bytes = 0, SS = 0, fast_lds = 0, oct_lds = 0;
+
+    hipStream_t stream = nullptr;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_in = nullptr;
+    size_t in_bytes = 0;
+    LevelInfo *d_lv = nullptr;
+    CellInfo *d_cells = nullptr;
+    BlurTile *d_tiles = nullptr;
+    int2 *d_xt = nullptr;
+    int4 *d_yt = nullptr;
+    int *d_cell_count = nullptr, *d_level_count = nullptr, *d_level_ncand = nullptr, *d_counts = nullptr;
+    uint32_t *d_cands = nullptr, *d_kpos = nullptr, *d_sel = nullptr;
+    unsigned short *d_knode = nullptr;
+    uint8_t *d_kq = nullptr, *d_desc = nullptr;
+    orbx_keypoint *d_kps = nullptr;
+    int last_batch = 0;
+};
+
+namespace {
+
+void free_workspace(orbx_extractor *ex)
+{
+    void *ptrs[] = {ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_xt, ex->d_yt, ex->d_cell_count,
+                    ex->d_level_count, ex->d_level_ncand, ex->d_counts, ex->d_cands, ex->d_kpos, ex->d_sel,
+                    ex->d_knode, ex->d_kq, ex->d_desc, ex->d_kps};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    ex->d_pyr = ex->d_blur = nullptr; ex->d_lv = nullptr; ex->d_cells = nullptr; ex->d_tiles = nullptr;
+    ex->d_xt = nullptr; ex->d_yt = nullptr; ex->d_cell_count = ex->d_level_count = ex->d_level_ncand = ex->d_counts = nullptr;
+    ex->d_cands = ex->d_kpos = ex->d_sel = nullptr; ex->d_knode = nullptr; ex->d_kq = ex->d_desc = nullptr; ex->d_kps = nullptr;
+    ex->width = ex->height = ex->batch = 0;
+}
+
+inline int cv_round_f(float v) { return (int)lrintf(v); }
+
+// OpenCV resize coefficient tables for one axis.
+void resize_axis(int dn, int sn, std::vector<int> &ofs, std::vector<int> &c0, std::vector<int> &c1)
+{
+    const double inv_scale = (double)dn / sn, scale = 1. / inv_scale;
+    ofs.resize(dn); c0.resize(dn); c1.resize(dn);
+    for (int d = 0; d < dn; ++d) {
+        float fv = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(fv);
+        fv -= s;
+        ofs[d] = s;
+        const int a0 = cv_round_f((1.f - fv) * 2048.f), a1 = cv_round_f(fv * 2048.f);
+        c0[d] = a0 > 32767 ? 32767 : a0;
+        c1[d] = a1 > 32767 ? 32767 : a1;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *orbx_last_error(void) { return orbx::last_error().c_str(); }
+int orbx_abi_version(void) { return 100; }
+
+int orbx_create(const orbx_params *prm, orbx_extractor **out)
+{
+    if (!prm || !out) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
+    if (prm->nlevels < 1 || prm->nlevels > MAXL || prm->nfeatures < 0 || !(prm->scale_factor > 1.0f))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad extractor parameters");
+    orbx_extractor *ex = new orbx_extractor();
+    ex->prm = *prm;
+    const int nl = ex->nlevels = prm->nlevels;
+    // ORBextractor::ORBextractor, ORBextractor.cc:415-446
+    ex->scale[0] = 1.0f; ex->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        ex->scale[i] = ex->scale[i - 1] * prm->scale_factor;
+        ex->sigma2[i] = ex->scale[i] * ex->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        ex->inv_scale[i] = 1.0f / ex->scale[i];
+        ex->inv_sigma2[i] = 1.0f / ex->sigma2[i];
+    }
+    const float factor = 1.0f / prm->scale_factor;
+    float nDesired = prm->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        ex->nfeat[l] = cv_round_f(nDesired);
+        sum += ex->nfeat[l];
+        nDesired *= factor;
+    }
+    ex->nfeat[nl - 1] = prm->nfeatures - sum > 0 ? prm->nfeatures - sum : 0;
+    for (int l = 0; l < nl; l++)
+        if (ex->nfeat[l] > OCT_MAXN) {
+            delete ex;
+            ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "per-level feature quota above 1023 is not supported");
+        }
+    if (prm->blur_variant == 1) { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 49; ex->taps[3] = 55; }
+    else { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 48; ex->taps[3] = 56; }
+    ex->kcap = prm->nfeatures + 3 * nl;
+    *out = ex;
+    return ORBX_OK;
+}
+
+int orbx_destroy(orbx_extractor *ex)
+{
+    if (!ex) return ORBX_OK;
+    free_workspace(ex);
+    if (ex->d_in) (void)hipFree(ex->d_in);
+    if (ex->stream) (void)hipStreamDestroy(ex->stream);
+    delete ex;
+    return ORBX_OK;
+}
+
+int orbx_get_levels(const orbx_extractor *ex) { return ex ? ex->nlevels : ORBX_ERR_ARG; }
+#define ORBX_GETTER(name, field, type)                                   \
+    int name(const orbx_extractor *ex, type *out)                        \
+    {                                                                    \
+        if (!ex || !out) ORBX_FAIL(ORBX_ERR_ARG, "null argument");       \
+        for (int i = 0; i < ex->nlevels; i++) out[i] = ex->field[i];     \
+        return ORBX_OK;                                                  \
+    }
+ORBX_GETTER(orbx_get_scale_factors, scale, float)
+ORBX_GETTER(orbx_get_inv_scale_factors, inv_scale, float)
+ORBX_GETTER(orbx_get_level_sigma2, sigma2, float)
+ORBX_GETTER(orbx_get_inv_level_sigma2, inv_sigma2, float)
+ORBX_GETTER(orbx_get_features_per_level, nfeat, int32_t)
+int orbx_keypoint_capacity(const orbx_extractor *ex) { return ex ? ex->kcap : ORBX_ERR_ARG; }
+
+int orbx_level_size(const orbx_extractor *ex, int level, int *w, int *h)
+{
+    if (!ex || level < 0 || level >= ex->nlevels || !ex->width) ORBX_FAIL(ORBX_ERR_ARG, "bad level / nothing reserved");
+    if (w) *w = ex->lv[level].w;
+    if (h) *h = ex->lv[level].h;
+    return ORBX_OK;
+}
+
+int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
+{
+    if (!ex || width <= 0 || height <= 0 || batch <= 0) ORBX_FAIL(ORBX_ERR_ARG, "bad reserve arguments");
+    ORBX_NEED_DEVICE();
+    if (ex->width == width && ex->height == height && ex->batch >= batch) return ORBX_OK;
+    if (!ex->stream) ORBX_HIP(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    free_workspace(ex);
+
+    const int nl = ex->nlevels;
+    std::vector<int2> xt;
+    std::vector<int4> yt;
+    ex->cells.clear(); ex->tiles.clear();
+    size_t off = 0, cand_off = 0, key_off = 0;
+    int sel_off = 0, maxcw = 0, maxch = 0;
+    ex->maxcells = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelInfo &lv = ex->lv[l];
+        memset(&lv, 0, sizeof(lv));
+        // ComputePyramid, ORBextractor.cc:1119-1121
+        lv.w = cv_round_f((float)width * ex->inv_scale[l]);
+        lv.h = cv_round_f((float)height * ex->inv_scale[l]);
+        if (lv.w > 4000 || lv.h > 4000) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "image larger than 4000 px");
+        lv.stride = (PADX + lv.w + EDGE + 63) & ~63;
+        lv.off = (int)off;
+        off += (size_t)lv.stride * (lv.h + 2 * EDGE);
+        off = (off + 255) & ~(size_t)255;
+        lv.scale = ex->scale[l];
+        lv.patch = (int)(31 * ex->scale[l]); // :845
+        lv.N = ex->nfeat[l];
+        // ComputeKeyPointsOctTree grid, :773-787
+        const int maxBorderX = lv.w - EDGE + 3, maxBorderY = lv.h - EDGE + 3;
+        const float fw = (float)(maxBorderX - MIN_BORDER), fh = (float)(maxBorderY - MIN_BORDER);
+        const int nCols = (int)(fw / 30.f), nRows = (int)(fh / 30.f);
+        if (nCols < 1 || nRows < 1) ORBX_FAIL(ORBX_ERR_ARG, "image too small for the 30-px FAST cell grid at some level");
+        const int wCell = (int)ceilf(fw / nCols), hCell = (int)ceilf(fh / nRows);
+        lv.W = maxBorderX - MIN_BORDER;
+        lv.H = maxBorderY - MIN_BORDER;
+        lv.nIni = (int)roundf((float)lv.W / lv.H); // :543
+        if (lv.nIni < 1) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "aspect ratio below 0.5 (reference divides by zero)");
+        lv.hX = (float)lv.W / lv.nIni;
+        lv.cell_base = (int)ex->cells.size();
+        lv.key_base = (int)key_off;
+        for (int i = 0; i < nRows; i++) { // :789-806
+            const float iniY = (float)(MIN_BORDER + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBorderY - 3) continue;
+            if (maxY > maxBorderY) maxY = (float)maxBorderY;
+            for (int j = 0; j < nCols; j++) {
+                const float iniX = (float)(MIN_BORDER + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBorderX - 6) continue;
+                if (maxX > maxBorderX) maxX = (float)maxBorderX;
+                CellInfo c;
+                memset(&c, 0, sizeof(c));
+                c.level = (short)l;
+                c.x0 = (short)(int)iniX; c.y0 = (short)(int)iniY;
+                c.cw = (short)((int)maxX - (int)iniX); c.ch = (short)((int)maxY - (int)iniY);
+                c.dx = (short)(j * wCell); c.dy = (short)(i * hCell);
+                const int zw = c.cw - 6, zh = c.ch - 6;
+                c.cap = (zw > 0 && zh > 0) ? ((zw + 1) / 2) * ((zh + 1) / 2) : 0; // 3x3 strict NMS bound
+                if (zw * zh > 4096) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than 4096 px");
+                c.cand_off = (int)cand_off;
+                cand_off += c.cap;
+                key_off += c.cap;
+                if (c.cw > maxcw) maxcw = c.cw;
+                if (c.ch > maxch) maxch = c.ch;
+                ex->cells.push_back(c);
+            }
+        }
+        lv.ncells = (int)ex->cells.size() - lv.cell_base;
+        if (lv.ncells > ex->maxcells) ex->maxcells = lv.ncells;
+        lv.sel_base = sel_off;
+        sel_off += lv.N + 4;
+        // blur tiles
+        for (int y0 = 0; y0 < lv.h; y0 += 16)
+            for (int x0 = 0; x0 < lv.w; x0 += 64) {
+                BlurTile t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0;
+                ex->tiles.push_back(t);
+            }
+        // resize tables from level l-1
+        lv.xtab = (int)xt.size(); lv.ytab = (int)yt.size();
+        if (l > 0) {
+            const LevelInfo &sv = ex->lv[l - 1];
+            std::vector<int> o, c0, c1;
+            resize_axis(lv.w, sv.w, o, c0, c1);
+            for (int d = 0; d < lv.w; d++) {
+                int s = o[d], a0 = c0[d], a1 = c1[d];
+                if (s < 0) { s = 0; a0 = 2048; a1 = 0; }              // fx = 0, sx = 0
+                if (s >= sv.w - 1) { s = sv.w - 1; a0 = 2048; a1 = 0; } // fx = 0, sx = w-1
+                xt.push_back(make_int2(s, a0 | (a1 << 16)));
+            }
+            resize_axis(lv.h, sv.h, o, c0, c1);
+            for (int d = 0; d < lv.h; d++) {
+                const int s = o[d];
+                const int s0 = s < 0 ? 0 : (s < sv.h ? s : sv.h - 1);
+                const int s1 = s + 1 < 0 ? 0 : (s + 1 < sv.h ? s + 1 : sv.h - 1);
+                yt.push_back(make_int4(s0, s1, c0[d], c1[d]));
+            }
+        }
+    }
+    ex->frame_bytes = off;
+    ex->cands_per_frame = cand_off;
+    ex->keys_per_frame = key_off;
+    ex->cells_per_frame = (int)ex->cells.size();
+    ex->sel_per_frame = sel_off;
+    int maxN = 0;
+    for (int l = 0; l < nl; l++) {
+        if (ex->lv[l].N > maxN) maxN = ex->lv[l].N;
+        if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
+    }
+    ex->NC = maxN + 8;
+    ex->TS = (maxcw + 3) & ~3;
+    ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
+    ex->SS = maxcw - 6 + 2;
+    ex->fast_lds = ex->tile_bytes + ex->SS * (maxch - 6 + 2) + 16;
+    ex->oct_lds = (int)sizeof(int) * (OCT_T + ex->maxcells + 1 + 22 * ex->NC) + 64;
+    if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
+
+    const size_t B = (size_t)batch;
+    ORBX_HIP(hipMalloc(&ex->d_pyr, ex->frame_bytes * B));
+    ORBX_HIP(hipMalloc(&ex->d_blur, ex->frame_bytes * B));
+    ORBX_HIP(hipMemset(ex->d_blur, 0, ex->frame_bytes * B));
+    ORBX_HIP(hipMalloc(&ex->d_lv, sizeof(LevelInfo) * MAXL));
+    ORBX_HIP(hipMalloc(&ex->d_cells, sizeof(CellInfo) * ex->cells.size()));
+    ORBX_HIP(hipMalloc(&ex->d_tiles, sizeof(BlurTile) * ex->tiles.size()));
+    ORBX_HIP(hipMalloc(&ex->d_xt, sizeof(int2) * (xt.size() + 1)));
+    ORBX_HIP(hipMalloc(&ex->d_yt, sizeof(int4) * (yt.size() + 1)));
+    ORBX_HIP(hipMalloc(&ex->d_cell_count, sizeof(int) * ex->cells_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_level_count, sizeof(int) * MAXL * B));
+    ORBX_HIP(hipMalloc(&ex->d_level_ncand, sizeof(int) * MAXL * B));
+    ORBX_HIP(hipMalloc(&ex->d_counts, sizeof(int) * B));
+    ORBX_HIP(hipMalloc(&ex->d_cands, sizeof(uint32_t) * ex->cands_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_kpos, sizeof(uint32_t) * ex->keys_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_knode, sizeof(unsigned short) * ex->keys_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_kq, ex->keys_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_sel, sizeof(uint32_t) * ex->sel_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B));
+    ORBX_HIP(hipMalloc(&ex->d_desc, (size_t)32 * ex->kcap * B));
+    ORBX_HIP(hipMemcpy(ex->d_lv, ex->lv, sizeof(LevelInfo) * MAXL, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(ex->d_cells, ex->cells.data(), sizeof(CellInfo) * ex->cells.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(ex->d_tiles, ex->tiles.data(), sizeof(BlurTile) * ex->tiles.size(), hipMemcpyHostToDevice));
+    if (!xt.empty()) ORBX_HIP(hipMemcpy(ex->d_xt, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
+    if (!yt.empty()) ORBX_HIP(hipMemcpy(ex->d_yt, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
+    if (ex->oct_lds > 48 * 1024)
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, ex->oct_lds));
+    ex->width = width; ex->height = height; ex->batch = batch;
+    return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device, int width, int height, int stride,
+                       size_t frame_stride, int batch, void *stream_)
+{
+    if (!ex || !images || width <= 0 || height <= 0 || batch <= 0 || stride < width)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad extract arguments");
+    ORBX_NEED_DEVICE();
+    int rc = orbx_reserve(ex, width, height, batch);
+    if (rc != ORBX_OK) return rc;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ex->stream;
+    const uint8_t *d_img = images;
+    if (!is_device) {
+        const size_t need = frame_stride * (size_t)(batch - 1) + (size_t)stride * height;
+        if (need > ex->in_bytes) {
+            if (ex->d_in) ORBX_HIP(hipFree(ex->d_in));
+            ex->d_in = nullptr;
+            ORBX_HIP(hipMalloc(&ex->d_in, need));
+            ex->in_bytes = need;
+        }
+        ORBX_HIP(hipMemcpyAsync(ex->d_in, images, need, hipMemcpyHostToDevice, st));
+        d_img = ex->d_in;
+    }
+    const int nl = ex->nlevels;
+    {
+        const LevelInfo &l0 = ex->lv[0];
+        dim3 g((l0.stride / 4 + 63) / 64, l0.h + 2 * EDGE, batch);
+        hipLaunchKernelGGL(k_pyr_level0, g, dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr, ex->frame_bytes, l0);
+    }
+    for (int l = 1; l < nl; l++) {
+        const LevelInfo &lv = ex->lv[l];
+        dim3 g((lv.stride / 4 + 63) / 64, lv.h + 2 * EDGE, batch);
+        hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
+                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab);
+    }
+    hipLaunchKernelGGL(k_fast_cells, dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
+                       ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
+                       ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->TS, ex->tile_bytes, ex->SS);
+    hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
+                       ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
+                       ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
+                       ex->d_level_ncand, nl, ex->NC, ex->maxcells);
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)ex->tiles.size(), batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
+                       ex->frame_bytes, ex->d_lv, ex->d_tiles, ex->taps[0], ex->taps[1], ex->taps[2], ex->taps[3]);
+    hipLaunchKernelGGL(k_describe, dim3((ex->kcap + 3) / 4, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
+                       ex->frame_bytes, ex->d_lv, nl, ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps,
+                       ex->d_desc, ex->d_counts, ex->kcap);
+    ORBX_HIP(hipGetLastError());
+    ex->last_batch = batch;
+    return ORBX_OK;
+}
+
+int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    if (!ex || frame < 0 || frame >= ex->last_batch || !n) ORBX_FAIL(ORBX_ERR_ARG, "bad download arguments");
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipDeviceSynchronize());
+    int cnt = 0;
+    ORBX_HIP(hipMemcpy(&cnt, ex->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "keypoint buffer too small");
+    if (cnt > 0) {
+        if (kps) ORBX_HIP(hipMemcpy(kps, ex->d_kps + (size_t)frame * ex->kcap, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost));
+        if (desc) ORBX_HIP(hipMemcpy(desc, ex->d_desc + (size_t)frame * ex->kcap * 32, (size_t)32 * cnt, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride, orbx_keypoint *kps,
+                 uint8_t *desc, int cap, int *n)
+{
+    if (!ex || !n) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
+    if (!image || width <= 0 || height <= 0) { *n = 0; return ORBX_OK; } // empty image: outputs untouched (:1054)
+    int rc = orbx_extract_batch(ex, image, 0, width, height, stride, (size_t)stride * height, 1, nullptr);
+    if (rc != ORBX_OK) return rc;
+    return orbx_download(ex, 0, kps, desc, cap, n);
+}
+
+int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps, const uint8_t **desc, const int32_t **counts, int *capacity)
+{
+    if (!ex || !ex->d_kps) ORBX_FAIL(ORBX_ERR_ARG, "no results");
+    if (kps) *kps = ex->d_kps;
+    if (desc) *desc = ex->d_desc;
+    if (counts) *counts = ex->d_counts;
+    if (capacity) *capacity = ex->kcap;
+    return ORBX_OK;
+}
+
+static int copy_level(orbx_extractor *ex, const uint8_t *buf, int frame, int level, uint8_t *out, int out_stride, int padded)
+{
+    if (!ex || !out || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipDeviceSynchronize());
+    const LevelInfo &lv = ex->lv[level];
+    const int w = padded ? lv.w + 2 * EDGE : lv.w, h = padded ? lv.h + 2 * EDGE : lv.h;
+    if (out_stride < w) ORBX_FAIL(ORBX_ERR_ARG, "out_stride too small");
+    const uint8_t *src = buf + (size_t)frame * ex->frame_bytes + lv.off +
+                         (padded ? (size_t)(PADX - EDGE) : (size_t)EDGE * lv.stride + PADX);
+    ORBX_HIP(hipMemcpy2D(out, out_stride, src, lv.stride, w, h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride)
+{ return copy_level(ex, ex ? ex->d_pyr : nullptr, frame, level, out, out_stride, 0); }
+int orbx_pyramid_level_padded(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride)
+{ return copy_level(ex, ex ? ex->d_pyr : nullptr, frame, level, out, out_stride, 1); }
+int orbx_debug_blurred_level(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride)
+{ return copy_level(ex, ex ? ex->d_blur : nullptr, frame, level, out, out_stride, 0); }
+
+int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, float *xyr, int cap, int *n)
+{
+    if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels || !n)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipDeviceSynchronize());
+    int M = 0;
+    ORBX_HIP(hipMemcpy(&M, ex->d_level_ncand + frame * ex->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n = M;
+    if (M > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "candidate buffer too small");
+    std::vector<uint32_t> pk(M > 0 ? M : 1);
+    if (M > 0)
+        ORBX_HIP(hipMemcpy(pk.data(), ex->d_kpos + (size_t)frame * ex->keys_per_frame + ex->lv[level].key_base,
+                           sizeof(uint32_t) * M, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; i++) {
+        xyr[3 * i] = (float)((pk[i] >> 8) & 0xfffu);
+        xyr[3 * i + 1] = (float)(pk[i] >> 20);
+        xyr[3 * i + 2] = (float)(pk[i] & 0xffu);
+    }
+    return ORBX_OK;
+}
+
+int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *kps, int cap, int *n)
+{
+    if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels || !n)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipDeviceSynchronize());
+    std::vector<int> lc(ex->nlevels);
+    ORBX_HIP(hipMemcpy(lc.data(), ex->d_level_count + frame * ex->nlevels, sizeof(int) * ex->nlevels, hipMemcpyDeviceToHost));
+    int first = 0;
+    for (int l = 0; l < level; l++) first += lc[l];
+    const int cnt = lc[level];
+    *n = cnt;
+    if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "keypoint buffer too small");
+    if (cnt == 0) return ORBX_OK;
+    std::vector<uint32_t> pk(cnt);
+    ORBX_HIP(hipMemcpy(pk.data(), ex->d_sel + (size_t)frame * ex->sel_per_frame + ex->lv[level].sel_base,
+                       sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(kps, ex->d_kps + (size_t)frame * ex->kcap + first, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; i++) { // level coordinates, before pt *= scale
+        kps[i].x = (float)((pk[i] >> 8) & 0xfffu) + MIN_BORDER;
+        kps[i].y = (float)(pk[i] >> 20) + MIN_BORDER;
+    }
+    return ORBX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,73 @@
+// orbx_math.h -- exact-arithmetic helpers shared by the HIP kernels.
+//
+// Every function here is a fixed sequence of IEEE-754 operations (no FMA
+// contraction: the library is built with -ffp-contract=off), so the device
+// result is a pure function of the inputs and can be checked on the host by
+// compiling this header with g++ (tests/test_math_host.py does that).
+#ifndef ORBX_MATH_H
+#define ORBX_MATH_H
+
+#if defined(__HIPCC__)
+#define ORBX_HD __host__ __device__ __forceinline__
+#else
+#define ORBX_HD static inline
+#endif
+
+#include <math.h>
+
+// cvRound(float): round-half-to-even.
+ORBX_HD int orbx_cvround(float v) { return (int)rintf(v); }
+
+// cv::fastAtan2(y, x) in degrees, OpenCV 3.4 scalar path;
+// called by IC_Angle, src/ORBextractor.cc:103.
+ORBX_HD float orbx_fast_atan2(float y, float x)
+{
+    const float s = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float eps = 2.2204460492503131e-16f; // (float)DBL_EPSILON
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// sin/cos of a float angle in [0, 2*pi], evaluated in double with a fixed
+// operation sequence (Cody-Waite reduction by pi/2 + degree-13/12 minimax
+// kernels) and rounded to float.  Replaces `(float)cos(angle)`, `(float)sin(angle)`
+// of computeOrbDescriptor (src/ORBextractor.cc:112-113).  The host test checks
+// it against libm's correctly-rounded-in-practice (float)cos((double)x).
+ORBX_HD void orbx_sincos_f32(float xf, float *sn, float *cs)
+{
+    const double x = (double)xf;
+    const double fn = rint(x * 6.36619772367581382433e-01); // 2/pi
+    const int n = (int)fn;
+    const double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double s = r + (r * z) * ps;
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double c = 1.0 - (0.5 * z - (z * z) * pc);
+    double so, co;
+    switch (n & 3) {
+    case 0: so = s; co = c; break;
+    case 1: so = c; co = -s; break;
+    case 2: so = -s; co = -c; break;
+    default: so = -c; co = s; break;
+    }
+    *sn = (float)so;
+    *cs = (float)co;
+}
+
+#endif // ORBX_MATH_H

@@ -1,0 +1,145 @@
+"""Host-side mirror of ORB_SLAM2::ORBextractor over the C-ABI (ctypes).
+
+Same constructor arguments, getters and call semantics as the reference class
+(include/ORBextractor.h:46-112, src/ORBextractor.cc:1051-1113); images and results
+are numpy arrays instead of cv::Mat / std::vector<cv::KeyPoint>.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class _Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_variant", C.c_int32)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ORBextractor:
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, blur_variant=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        prm = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, blur_variant)
+        check(self._L.orbx_create(C.byref(prm), C.byref(self._h)))
+        self.nlevels = nlevels
+        self.capacity = self._L.orbx_keypoint_capacity(self._h)
+        self._shape = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.orbx_destroy(h)
+            self._h = None
+
+    # ---- getters (ORBextractor.h:61-84)
+    def GetLevels(self):
+        return self._L.orbx_get_levels(self._h)
+
+    def _vec(self, fn, dtype):
+        out = np.zeros(self.nlevels, dtype=dtype)
+        check(fn(self._h, _p(out)))
+        return out
+
+    def GetScaleFactor(self):
+        return float(self.GetScaleFactors()[1]) if self.nlevels > 1 else 1.0
+
+    def GetScaleFactors(self):
+        return self._vec(self._L.orbx_get_scale_factors, np.float32)
+
+    def GetInverseScaleFactors(self):
+        return self._vec(self._L.orbx_get_inv_scale_factors, np.float32)
+
+    def GetScaleSigmaSquares(self):
+        return self._vec(self._L.orbx_get_level_sigma2, np.float32)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._vec(self._L.orbx_get_inv_level_sigma2, np.float32)
+
+    def features_per_level(self):
+        return self._vec(self._L.orbx_get_features_per_level, np.int32)
+
+    # ---- operator()
+    def __call__(self, image, mask=None):
+        """Returns (keypoints[KP_DTYPE], descriptors[n,32] uint8).  The mask is
+        ignored, as in the reference (ORBextractor.cc:1051: _mask unused)."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (ORBextractor.cc:1058)"
+        image = np.ascontiguousarray(image)
+        h, w = image.shape
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = C.c_int(0)
+        check(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc),
+                                   self.capacity, C.byref(n)))
+        self._shape = (h, w)
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- batch API
+    def extract_batch(self, images):
+        """images: [B,H,W] uint8 numpy array (host)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, h, w = images.shape
+        check(self._L.orbx_extract_batch(self._h, _p(images), 0, w, h, w, C.c_size_t(w * h), B, None))
+        self._shape = (h, w)
+
+    def extract_batch_device(self, dev_ptr, B, h, w, stream=None):
+        """dev_ptr: device address of [B,H,W] uint8 (e.g. torch tensor .data_ptr())."""
+        check(self._L.orbx_extract_batch(self._h, C.c_void_p(dev_ptr), 1, w, h, w, C.c_size_t(w * h), B,
+                                         C.c_void_p(stream) if stream else None))
+        self._shape = (h, w)
+
+    def download(self, frame):
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = C.c_int(0)
+        check(self._L.orbx_download(self._h, frame, _p(kps), _p(desc), self.capacity, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def result_dev(self):
+        kps, desc, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        check(self._L.orbx_result_dev(self._h, C.byref(kps), C.byref(desc), C.byref(cnt), C.byref(cap)))
+        return kps.value, desc.value, cnt.value, cap.value
+
+    # ---- mvImagePyramid and staged outputs
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        check(self._L.orbx_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def pyramid_level(self, frame, level, padded=False):
+        w, h = self.level_size(level)
+        if padded:
+            w, h = w + 38, h + 38
+        out = np.zeros((h, w), np.uint8)
+        fn = self._L.orbx_pyramid_level_padded if padded else self._L.orbx_pyramid_level
+        check(fn(self._h, frame, level, _p(out), w))
+        return out
+
+    def blurred_level(self, frame, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        check(self._L.orbx_debug_blurred_level(self._h, frame, level, _p(out), w))
+        return out
+
+    def level_candidates(self, frame, level):
+        w, h = self.level_size(level)
+        cap = w * h // 4 + 16
+        out = np.zeros((cap, 3), np.float32)
+        n = C.c_int(0)
+        check(self._L.orbx_debug_level_candidates(self._h, frame, level, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def level_keypoints(self, frame, level):
+        out = np.zeros(self.capacity, KP_DTYPE)
+        n = C.c_int(0)
+        check(self._L.orbx_debug_level_keypoints(self._h, frame, level, _p(out), self.capacity, C.byref(n)))
+        return out[:n.value].copy()

@@ -1,0 +1,73 @@
+"""Host-side mirror of the ORBmatcher data plane over the C-ABI (ctypes).
+
+Constants and semantics follow include/ORBmatcher.h:37-111 and
+src/ORBmatcher.cc:37-40 (TH_HIGH=95, TH_LOW=45, TH_RELOC=60, HISTO_LENGTH=30).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ORBmatcher:
+    # src/ORBmatcher.cc:37-40
+    TH_HIGH = 95
+    TH_LOW = 45
+    TH_RELOC = 60
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio = np.float32(nnratio)
+        self.mbCheckOrientation = checkOri
+        self._L = lib()
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """ORBmatcher::DescriptorDistance for one pair (runs the device kernel)."""
+        return int(ORBmatcher.hamming_matrix(np.reshape(a, (1, 32)), np.reshape(b, (1, 32)))[0, 0])
+
+    @staticmethod
+    def hamming_matrix(A, B):
+        L = lib()
+        A = np.ascontiguousarray(A, np.uint8); B = np.ascontiguousarray(B, np.uint8)
+        out = np.zeros((len(A), len(B)), np.uint16)
+        check(L.orbm_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(out)))
+        return out
+
+    def match_bruteforce(self, A, B):
+        A = np.ascontiguousarray(A, np.uint8); B = np.ascontiguousarray(B, np.uint8)
+        nA = len(A)
+        best = np.zeros(nA, np.int32); second = np.zeros(nA, np.int32); idx = np.zeros(nA, np.int32)
+        check(self._L.orbm_match_bruteforce(_p(A), nA, _p(B), len(B), _p(best), _p(second), _p(idx)))
+        return best, second, idx
+
+    def match_candidates(self, A, B, cand_off, cand_idx):
+        A = np.ascontiguousarray(A, np.uint8); B = np.ascontiguousarray(B, np.uint8)
+        off = np.ascontiguousarray(cand_off, np.int32); ci = np.ascontiguousarray(cand_idx, np.int32)
+        nA = len(A)
+        best = np.zeros(nA, np.int32); second = np.zeros(nA, np.int32); idx = np.zeros(nA, np.int32)
+        check(self._L.orbm_match_candidates(_p(A), nA, _p(B), len(B), _p(off), _p(ci), _p(best), _p(second), _p(idx)))
+        return best, second, idx
+
+    def filter(self, best, second, idx, th=None):
+        th = self.TH_LOW if th is None else th
+        m = np.zeros(len(best), np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_match_filter(len(best), _p(np.ascontiguousarray(best, np.int32)),
+                                        _p(np.ascontiguousarray(second, np.int32)),
+                                        _p(np.ascontiguousarray(idx, np.int32)), th, C.c_float(self.mfNNratio),
+                                        _p(m), C.byref(n)))
+        return m, n.value
+
+    def match_batch_device(self, desc_dev, counts_dev, cap, pair_a_dev, pair_b_dev, npairs,
+                           best_dev, second_dev, idx_dev, match12_dev, nmatch_dev, th=None, stream=None):
+        th = self.TH_LOW if th is None else th
+        vp = lambda v: C.c_void_p(v) if v else None
+        check(self._L.orbm_match_batch_dev(vp(desc_dev), vp(counts_dev), cap, vp(pair_a_dev), vp(pair_b_dev), npairs,
+                                           th, C.c_float(self.mfNNratio), vp(best_dev), vp(second_dev), vp(idx_dev),
+                                           vp(match12_dev), vp(nmatch_dev), vp(stream)))

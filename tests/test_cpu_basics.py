@@ -1,0 +1,200 @@
+"""CPU-only checks: oracle known answers, host logic, C-ABI surface."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from octree_model import octree_rounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ oracle KATs
+def test_constructor_tables_match_survey_appendix_d():
+    o = oracle.OrbOracle(2000, 1.2, 8, 20, 7)
+    assert o.features_per_level() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert o.umax() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    assert o.features_per_level() == [217, 181, 151, 126, 105, 87, 73, 60]
+
+
+def test_level_sizes_match_survey_appendix_d():
+    o = oracle.OrbOracle(2000, 1.2, 8, 20, 7)
+    o.extract(np.zeros((480, 640), np.uint8))
+    dims = [o.level_dims(l)[:2] for l in range(8)]
+    assert dims == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+
+
+def test_cvround_half_to_even_and_atan2():
+    L = oracle.lib()
+    assert [L.oracle_cvRound(C.c_float(v)) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999)] == [0, 2, 2, 0, -2, 2]
+    assert L.oracle_fastAtan2(0.0, 0.0) == 0.0
+    for y, x, deg in [(0, 1, 0), (1, 0, 90), (0, -1, 180), (-1, 0, 270), (1, 1, 45), (-1, -1, 225)]:
+        assert abs(L.oracle_fastAtan2(float(y), float(x)) - deg) < 0.02  # polynomial: ~0.01 deg accuracy
+
+
+def test_descriptor_distance_known_answers():
+    z = np.zeros(32, np.uint8); f = np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, z) == 0
+    assert oracle.descriptor_distance(z, f) == 256
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.integers(0, 256, 32, dtype=np.uint8); b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert oracle.descriptor_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+def test_fast_score_definition_on_synthetic_corner():
+    # bright 9-arc of +50 on a flat patch -> score 49; 8-arc -> not a corner
+    L = oracle.lib()
+    L.oracle_fast_corner_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.oracle_fast_is_corner.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    dx = [0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1]
+    dy = [3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3]
+    for arc, want in [(9, True), (8, False), (12, True)]:
+        img = np.full((7, 7), 100, np.uint8)
+        for k in range(arc):
+            img[3 + dy[(k + 5) % 16], 3 + dx[(k + 5) % 16]] = 150
+        p = img.ctypes.data + 3 * 7 + 3
+        assert bool(L.oracle_fast_is_corner(p, 7, 20)) == want
+        if want:
+            assert L.oracle_fast_corner_score(p, 7, 20) == 49
+
+
+def test_gauss_taps_sum_and_flat_image():
+    L = oracle.lib()
+    src = np.full((20, 30), 200, np.uint8); dst = np.zeros_like(src)
+    taps = np.array([18, 34, 48, 56, 48, 34, 18], np.int32)
+    assert taps.sum() == 256
+    L.oracle_gauss7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_gauss7(src.ctypes.data, 30, 20, 30, dst.ctypes.data, 30, taps.ctypes.data)
+    assert (dst == 200).all()
+
+
+def test_resize_identity_and_flat():
+    L = oracle.lib()
+    L.oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (40, 60), dtype=np.uint8)
+    dst = np.zeros_like(src)
+    L.oracle_resize_linear(src.ctypes.data, 60, 40, 60, dst.ctypes.data, 60, 40, 60)
+    assert np.array_equal(src, dst)
+    flat = np.full((40, 60), 93, np.uint8); out = np.zeros((33, 50), np.uint8)
+    L.oracle_resize_linear(flat.ctypes.data, 60, 40, 60, out.ctypes.data, 50, 33, 50)
+    assert (out == 93).all()
+
+
+def test_extract_is_deterministic_and_within_caps():
+    from orb_slam2_e_amd.synth import synth_frame
+    o = oracle.OrbOracle(2000, 1.2, 8, 20, 7)
+    k1, d1 = o.extract(synth_frame(0)); k2, d2 = o.extract(synth_frame(0))
+    assert np.array_equal(d1, d2) and len(k1) <= 2000 + 24
+    for l in range(8):
+        n = len(o.level_kps(l))
+        assert n <= o.features_per_level()[l] + 3
+        assert n >= o.features_per_level()[l]              # synthetic frames reach the quota (8d)
+    assert ((k1["angle"] >= 0) & (k1["angle"] <= 360)).all()
+
+
+# ------------------------------------------------ octree round formulation model
+def test_octree_round_formulation_equals_list_oracle():
+    rng = np.random.default_rng(0)
+    modes = 0
+    for trial in range(120):
+        W = int(rng.integers(40, 1300)); H = int(rng.integers(40, 500))
+        if round(W / H) < 1:
+            continue
+        n = int(rng.integers(0, 900))
+        pos = rng.choice(W * H, size=min(n, W * H), replace=False)
+        xs = (pos % W).astype(np.float32); ys = (pos // W).astype(np.float32)
+        if trial % 3 == 0 and n > 10:
+            xs = (xs % max(W // 4, 1)).astype(np.float32)
+            _, ui = np.unique(np.stack([xs, ys], 1), axis=0, return_index=True); ui.sort()
+            xs, ys = xs[ui], ys[ui]
+        resp = rng.integers(7, 60, size=len(xs)).astype(np.float32)
+        N = int(rng.integers(0, 400))
+        c = np.zeros(len(xs), dtype=oracle.CAND_DTYPE); c["x"] = xs; c["y"] = ys; c["response"] = resp
+        ref = oracle.octree_distribute(c, 16, 16 + W, 16, 16 + H, N)
+        got = octree_rounds(xs, ys, resp, 16, 16 + W, 16, 16 + H, N)
+        assert np.array_equal(ref, got), f"trial {trial}"
+        modes += 1
+    assert modes > 50
+
+
+def test_octree_returns_at_most_N_plus_3_and_one_per_leaf():
+    rng = np.random.default_rng(2)
+    pos = rng.choice(600 * 440, size=3000, replace=False)
+    c = np.zeros(3000, dtype=oracle.CAND_DTYPE)
+    c["x"] = pos % 600; c["y"] = pos // 600; c["response"] = rng.integers(7, 200, 3000)
+    for N in (1, 50, 434, 2999, 5000):
+        out = oracle.octree_distribute(c, 16, 616, 16, 456, N)
+        assert len(out) <= max(N + 3, 1) and len(set(out.tolist())) == len(out)
+        if N >= 3000:
+            assert len(out) == 3000
+
+
+# --------------------------------------------------------- matcher host helpers
+def test_three_maxima():
+    assert oracle.three_maxima([0] * 30) == (-1, -1, -1)
+    s = [0] * 30; s[3] = 100; s[7] = 50; s[9] = 5
+    assert oracle.three_maxima(s) == (3, 7, -1)
+    s[9] = 20
+    assert oracle.three_maxima(s) == (3, 7, 9)
+
+
+def test_grid_features_in_area_order_and_radius():
+    rng = np.random.default_rng(4)
+    xy = np.stack([rng.uniform(0, 640, 2000), rng.uniform(0, 480, 2000)], 1).astype(np.float32)
+    octv = rng.integers(0, 8, 2000).astype(np.int32)
+    g = oracle.Grid(xy, octv, 0.0, 0.0, 640.0, 480.0)
+    got = g.features_in_area(320.0, 240.0, 50.0)
+    brute = [i for i in range(2000) if abs(xy[i, 0] - 320) < 50 and abs(xy[i, 1] - 240) < 50]
+    assert sorted(got.tolist()) == brute
+    got_l = g.features_in_area(320.0, 240.0, 50.0, 2, 3)
+    assert sorted(got_l.tolist()) == [i for i in brute if 2 <= octv[i] <= 3]
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def _declared_symbols():
+    syms = []
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            syms += re.findall(r"\b((?:orbx|orbm|fem)_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(syms))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from orb_slam2_e_amd import _lib
+    so = _lib.SO_PATH if os.path.exists(_lib.SO_PATH) else _lib.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    exported = set(re.findall(r" T ((?:orbx|orbm|fem)_[a-z0-9_]+)", out))
+    missing = [s for s in _declared_symbols() if s not in exported]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    L = C.CDLL(so)
+    assert L.orbx_abi_version() >= 100
+
+
+def test_no_device_fails_loudly_not_silently():
+    """Without a GPU the compute entry points must return ORBX_ERR_NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from orb_slam2_e_amd import ORBextractor, OrbxError
+    ex = ORBextractor(2000, 1.2, 8, 20, 7)
+    assert list(ex.features_per_level()) == [434, 362, 302, 251, 209, 175, 145, 122]
+    with pytest.raises(OrbxError) as e:
+        ex(np.zeros((480, 640), np.uint8))
+    assert e.value.code == -2
+
+
+def test_product_never_references_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "orb_slam2_e_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in txt and "oracle/" not in txt and "liboracle" not in txt, fn
