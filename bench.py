@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the ORB extract + Hamming match hot path on MI355X.
+
+Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W`;
+for N>1 launched by torch.distributed.run, one rank per GPU.  A *step* is one pass
+of the hot path over one batch: 64 synthetic 640x480 frames per GPU ->
+ORBextractor (2000 features, 8 levels, FAST 20/7) -> 2000x2000 brute-force
+Hamming match of every frame against its successor in the batch (+ TH_LOW / 0.6
+ratio filter) -> gather of the fixed-size result records on rank 0 (N>1 only).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`roofline`: dominant kernel's algorithmic bytes / its mean launch time, timed
+with HIP events on the launch stream inside the timed region.  `cpu_baseline`:
+the CPU oracle (single thread) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, BATCH = 640, 480, 64
+PARAMS = (2000, 1.2, 8, 20, 7)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# SURVEY 8(d) algorithmic bytes per 640x480 frame, by stage
+PYR_PX = 950532
+ALG_BYTES = {
+    "k_pyr_level0": 307200 + 307200,            # read L0 input + write level 0
+    "k_pyr_resize": (PYR_PX - 307200) * 2,      # read level l-1 (approx. its own size class) + write level l, levels 1..7
+    "k_fast_cells": PYR_PX,                     # FAST read of the pyramid
+    "k_octree": 0,
+    "k_blur": 2 * PYR_PX,                       # blur read + write
+    "k_describe": 2000 * 749 + 2000 * 512 + 2000 * 60,
+    "k_match_sets": 144000,                     # 2 x 2000 x 32 B read + 2000 x 8 B written
+}
+FRAME_BYTES = 6751328  # whole extract path per frame
+
+
+def cpu_baseline(nframes=12):
+    """Oracle (CPU restatement, one thread) on a bounded sample of the workload."""
+    import oracle
+    from orb_slam2_e_amd.synth import synth_frame
+    imgs = [synth_frame(k) for k in range(nframes)]
+    o = oracle.OrbOracle(*PARAMS)
+    o.extract(imgs[0])  # warm
+    t0 = time.perf_counter()
+    descs = [o.extract(im)[1] for im in imgs]
+    for i in range(nframes):
+        b, s, ix = oracle.match_bruteforce(descs[i], descs[(i + 1) % nframes])
+        oracle.match_filter(b, s, ix, 45, 0.6)
+    dt = time.perf_counter() - t0
+    return {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{nframes} synthetic 640x480 frames: oracle extract + 2000x2000 match each, 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from orb_slam2_e_amd import ORBextractor, ORBmatcher
+    from orb_slam2_e_amd._lib import lib
+    from orb_slam2_e_amd.synth import synth_frames
+
+    # ---- inputs resident in HBM (weak scaling: each rank owns its own 64 frames)
+    frames = synth_frames(BATCH, W, H, start=rank * BATCH)
+    d_frames = torch.from_numpy(frames).to(dev)
+    ex = ORBextractor(*PARAMS)
+    m = ORBmatcher(0.6)
+    L = lib()
+    cap = ex.capacity
+    qa = torch.arange(BATCH, dtype=torch.int32, device=dev)
+    qb = ((qa + 1) % BATCH).to(torch.int32)
+    best = torch.empty((BATCH, cap), dtype=torch.int32, device=dev)
+    second = torch.empty_like(best); idx = torch.empty_like(best); match12 = torch.empty_like(best)
+    nmatch = torch.zeros(BATCH, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, stream)  # sizes the workspace
+    kps_p, desc_p, cnt_p, _ = ex.result_dev()
+    # fixed-size records {kps[CAP], desc[CAP][32], counts, match12[CAP], nmatch} -> one send buffer
+    n_kps, n_desc, n_cnt, n_m12 = cap * 28 * BATCH, cap * 32 * BATCH, 4 * BATCH, cap * 4 * BATCH
+    rec_bytes = n_kps + n_desc + n_cnt + n_m12 + n_cnt
+    counts_t = torch.zeros(BATCH, dtype=torch.int32, device=dev)
+    send = recv = None
+    if world > 1 and not args.no_gather:
+        send = torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
+        recv = [torch.empty(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def pack_records():
+        p0 = send.data_ptr()
+        L.orbx_copy_results_dev(ex._h, C.c_void_p(p0), C.c_void_p(p0 + n_kps), C.c_void_p(p0 + n_kps + n_desc),
+                                C.c_void_p(stream))
+        o = n_kps + n_desc + n_cnt
+        send[o:o + n_m12].copy_(match12.view(torch.uint8).reshape(-1), non_blocking=True)
+        send[o + n_m12:].copy_(nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
+
+    def step():
+        ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, stream)
+        m.match_batch_device(desc_p, cnt_p, cap, qa.data_ptr(), qb.data_ptr(), BATCH, best.data_ptr(),
+                             second.data_ptr(), idx.data_ptr(), match12.data_ptr(), nmatch.data_ptr(), stream=stream)
+        if send is not None:
+            pack_records()
+            dist.gather(send, recv, dst=0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    L.orbx_profile_enable(ex._h, 1)
+    L.orbm_profile_enable(1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel times (HIP events on the launch stream, recorded in the timed region)
+    names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); ln = (C.c_int64 * 16)(); nk = C.c_int(0)
+    L.orbx_profile_read(ex._h, 16, names, ms, ln, C.byref(nk))
+    kern = {names[i].decode(): (ms[i], ln[i]) for i in range(nk.value)}
+    mm, ml = C.c_double(0), C.c_int64(0)
+    L.orbm_profile_read(C.byref(mm), C.byref(ml))
+    kern["k_match_sets"] = (mm.value, ml.value)
+    L.orbx_profile_enable(ex._h, 0)
+    L.orbm_profile_enable(0)
+
+    if rank == 0:
+        total_frames = world * BATCH * args.steps
+        value = total_frames / dt
+        per_step_ms = {k: v[0] / args.steps for k, v in kern.items()}
+        dom = max(per_step_ms, key=per_step_ms.get)
+        launches_per_step = max(kern[dom][1] // max(args.steps, 1), 1)
+        avg_launch_ms = kern[dom][0] / max(kern[dom][1], 1)
+        alg = ALG_BYTES[dom] * BATCH / launches_per_step  # algorithmic bytes per launch
+        achieved = alg / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        L.orbx_copy_results_dev(ex._h, None, None, C.c_void_p(counts_t.data_ptr()), C.c_void_p(stream))
+        torch.cuda.synchronize()
+        counts = counts_t
+        out = {
+            "metric": "frames/s ORB extract+match (640x480, 2000 feat)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1xMI355X: batch of 64 synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
+                                   "+ 2000x2000 brute-force Hamming match per frame",
+                       "frames_per_gpu": BATCH, "global_batch": world * BATCH,
+                       "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0" if world > 1 else "single GPU",
+                       "mean_keypoints_per_frame": float(counts.float().mean().item()),
+                       "mean_matches_per_frame": float(nmatch.float().mean().item())},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_launch_ms, "alg_bytes_per_launch": alg},
+            "pipeline_hbm_frac": value / world * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms_per_step": per_step_ms,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,12 @@ int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *de
 int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps_dev, const uint8_t **desc_dev,
                     const int32_t **counts_dev, int *capacity);
 
+/* Asynchronous device-to-device export of the last batch's result arrays into
+ * caller-owned device buffers (same shapes as orbx_result_dev); any pointer may be
+ * NULL.  Used to stage the fixed-size records of the multi-GPU gather. */
+int orbx_copy_results_dev(orbx_extractor *ex, orbx_keypoint *kps_dst_dev, uint8_t *desc_dst_dev,
+                          int32_t *counts_dst_dev, void *stream);
+
 /* mvImagePyramid[level] of frame f of the last call (ORBextractor.h:86; read by
  * Frame::ComputeStereoMatches, src/Frame.cc:534,624,636,641): copies the level
  * image (without border) into out[height][out_stride]. */
@@ -111,6 +117,13 @@ int orbx_pyramid_level_padded(orbx_extractor *ex, int frame, int level, uint8_t 
 int orbx_debug_blurred_level(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride);
 int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, float *xyr, int cap, int *n);
 int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *kps, int cap, int *n);
+
+/* Per-kernel timing with HIP events on the launch stream (no reference
+ * counterpart; feeds bench.py's roofline object).  Read returns, per kernel kind,
+ * its name, accumulated milliseconds and launch count since enable. */
+int orbx_profile_enable(orbx_extractor *ex, int on);
+int orbx_profile_read(orbx_extractor *ex, int max_kinds, const char **names, double *total_ms,
+                      int64_t *launches, int *nkinds);
 
 /* -------------------------------------------------------------------- matcher
  * Data plane of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:37-111).            */
@@ -143,6 +156,10 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
                          int th, float nnratio,
                          int32_t *best_dev, int32_t *second_dev, int32_t *idx_dev,
                          int32_t *match12_dev, int32_t *nmatch_dev, void *stream);
+
+/* HIP-event timing of k_match_sets launched through orbm_match_batch_dev. */
+int orbm_profile_enable(int on);
+int orbm_profile_read(double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

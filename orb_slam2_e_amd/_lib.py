@@ -27,11 +27,25 @@ def build(force=False):
     return SO_PATH
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  The loader
+    de-duplicates by SONAME only if torch's copy is loaded first, so import torch
+    before dlopen()ing our library: one HIP runtime per process, and torch streams /
+    device pointers are then valid inside the C-ABI calls."""
+    if os.environ.get("ORBX_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(SO_PATH):
             build()
+        _one_hip_runtime()
         _LIB = C.CDLL(SO_PATH)
         _LIB.orbx_last_error.restype = C.c_char_p
     return _LIB

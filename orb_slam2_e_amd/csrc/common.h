@@ -39,6 +39,62 @@ inline bool device_ok()
     return state == 1;
 }
 
+// Optional per-kernel timing with HIP events recorded on the launch stream
+// (bench.py's roofline leg).  begin() marks the start of a launch sequence,
+// mark(kind) closes the interval since the previous event and charges it to
+// `kind`.  flush() synchronises and accumulates.
+struct KernelProfiler {
+    static constexpr int MAXK = 16, MAXEV = 4096;
+    bool on = false;
+    const char *names[MAXK] = {nullptr};
+    double ms[MAXK] = {0};
+    long launches[MAXK] = {0};
+    hipEvent_t ev[MAXEV];
+    int kind[MAXEV];
+    int n = 0, created = 0;
+
+    hipEvent_t next()
+    {
+        if (n == created) { (void)hipEventCreate(&ev[created]); ++created; }
+        return ev[n];
+    }
+    void begin(hipStream_t st)
+    {
+        if (!on) return;
+        if (n + 32 >= MAXEV) flush();
+        hipEvent_t e = next();
+        kind[n++] = -1;
+        (void)hipEventRecord(e, st);
+    }
+    void mark(int k, hipStream_t st)
+    {
+        if (!on) return;
+        hipEvent_t e = next();
+        kind[n++] = k;
+        (void)hipEventRecord(e, st);
+    }
+    void flush()
+    {
+        if (n == 0) return;
+        (void)hipEventSynchronize(ev[n - 1]);
+        for (int i = 1; i < n; ++i) {
+            if (kind[i] < 0) continue;
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev[i - 1], ev[i]) == hipSuccess) { ms[kind[i]] += t; launches[kind[i]]++; }
+        }
+        n = 0;
+    }
+    void reset()
+    {
+        flush();
+        for (int i = 0; i < MAXK; ++i) { ms[i] = 0; launches[i] = 0; }
+    }
+    ~KernelProfiler()
+    {
+        for (int i = 0; i < created; ++i) (void)hipEventDestroy(ev[i]);
+    }
+};
+
 } // namespace orbx
 
 #define ORBX_FAIL(code, msg) return orbx::set_error((code), (msg), __FILE__, __LINE__)

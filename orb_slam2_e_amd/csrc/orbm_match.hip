@@ -102,6 +102,8 @@ __global__ __launch_bounds__(MT) void k_hamming_matrix(const uint4 *__restrict__
     out[(size_t)i * nB + j] = (unsigned short)hamming256(A[2 * i], A[2 * i + 1], B[2 * j], B[2 * j + 1]);
 }
 
+orbx::KernelProfiler g_prof;
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -120,8 +122,10 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
     ORBX_NEED_DEVICE();
     hipStream_t st = (hipStream_t)stream;
     if (nmatch_dev) ORBX_HIP(hipMemsetAsync(nmatch_dev, 0, sizeof(int) * npairs, st));
+    g_prof.begin(st);
     hipLaunchKernelGGL(k_match_sets, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, st, desc_dev, counts_dev, cap,
                        pair_a_dev, pair_b_dev, th, nnratio, best_dev, second_dev, idx_dev, match12_dev, nmatch_dev);
+    g_prof.mark(0, st);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
@@ -197,6 +201,22 @@ int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipDeviceSynchronize());
     ORBX_HIP(hipMemcpy(out, o.p, sizeof(uint16_t) * (size_t)nA * nB, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbm_profile_enable(int on)
+{
+    g_prof.names[0] = "k_match_sets";
+    g_prof.reset();
+    g_prof.on = on != 0;
+    return ORBX_OK;
+}
+
+int orbm_profile_read(double *total_ms, int64_t *launches)
+{
+    g_prof.flush();
+    if (total_ms) *total_ms = g_prof.ms[0];
+    if (launches) *launches = g_prof.launches[0];
     return ORBX_OK;
 }
 

@@ -691,6 +691,7 @@ struct orbx_extractor {
     uint8_t *d_kq = nullptr, *d_desc = nullptr;
     orbx_keypoint *d_kps = nullptr;
     int last_batch = 0;
+    orbx::KernelProfiler prof;
 };
 
 namespace {
@@ -978,31 +979,65 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         d_img = ex->d_in;
     }
     const int nl = ex->nlevels;
+    orbx::KernelProfiler &pf = ex->prof;
+    pf.begin(st);
     {
         const LevelInfo &l0 = ex->lv[0];
         dim3 g((l0.stride / 4 + 63) / 64, l0.h + 2 * EDGE, batch);
         hipLaunchKernelGGL(k_pyr_level0, g, dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr, ex->frame_bytes, l0);
+        pf.mark(0, st);
     }
     for (int l = 1; l < nl; l++) {
         const LevelInfo &lv = ex->lv[l];
         dim3 g((lv.stride / 4 + 63) / 64, lv.h + 2 * EDGE, batch);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
                            ex->d_xt + lv.xtab, ex->d_yt + lv.ytab);
+        pf.mark(1, st);
     }
     hipLaunchKernelGGL(k_fast_cells, dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
                        ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
                        ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->TS, ex->tile_bytes, ex->SS);
+    pf.mark(2, st);
     hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
                        ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
                        ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
                        ex->d_level_ncand, nl, ex->NC, ex->maxcells);
+    pf.mark(3, st);
     hipLaunchKernelGGL(k_blur, dim3((unsigned)ex->tiles.size(), batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
                        ex->frame_bytes, ex->d_lv, ex->d_tiles, ex->taps[0], ex->taps[1], ex->taps[2], ex->taps[3]);
+    pf.mark(4, st);
     hipLaunchKernelGGL(k_describe, dim3((ex->kcap + 3) / 4, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
                        ex->frame_bytes, ex->d_lv, nl, ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps,
                        ex->d_desc, ex->d_counts, ex->kcap);
+    pf.mark(5, st);
     ORBX_HIP(hipGetLastError());
     ex->last_batch = batch;
+    return ORBX_OK;
+}
+
+int orbx_profile_enable(orbx_extractor *ex, int on)
+{
+    if (!ex) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
+    static const char *names[6] = {"k_pyr_level0", "k_pyr_resize", "k_fast_cells", "k_octree", "k_blur", "k_describe"};
+    for (int i = 0; i < 6; ++i) ex->prof.names[i] = names[i];
+    ex->prof.reset();
+    ex->prof.on = on != 0;
+    return ORBX_OK;
+}
+
+int orbx_profile_read(orbx_extractor *ex, int max_kinds, const char **names, double *total_ms, int64_t *launches, int *nkinds)
+{
+    if (!ex || !nkinds) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
+    ex->prof.flush();
+    int n = 0;
+    for (int i = 0; i < orbx::KernelProfiler::MAXK && n < max_kinds; ++i) {
+        if (!ex->prof.names[i]) continue;
+        if (names) names[n] = ex->prof.names[i];
+        if (total_ms) total_ms[n] = ex->prof.ms[i];
+        if (launches) launches[n] = ex->prof.launches[i];
+        ++n;
+    }
+    *nkinds = n;
     return ORBX_OK;
 }
 
@@ -1039,6 +1074,17 @@ int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps, const uint8_t
     if (desc) *desc = ex->d_desc;
     if (counts) *counts = ex->d_counts;
     if (capacity) *capacity = ex->kcap;
+    return ORBX_OK;
+}
+
+int orbx_copy_results_dev(orbx_extractor *ex, orbx_keypoint *kps_dst, uint8_t *desc_dst, int32_t *counts_dst, void *stream_)
+{
+    if (!ex || !ex->d_kps || ex->last_batch <= 0) ORBX_FAIL(ORBX_ERR_ARG, "no results");
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ex->stream;
+    const size_t B = (size_t)ex->last_batch;
+    if (kps_dst) ORBX_HIP(hipMemcpyAsync(kps_dst, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B, hipMemcpyDeviceToDevice, st));
+    if (desc_dst) ORBX_HIP(hipMemcpyAsync(desc_dst, ex->d_desc, (size_t)32 * ex->kcap * B, hipMemcpyDeviceToDevice, st));
+    if (counts_dst) ORBX_HIP(hipMemcpyAsync(counts_dst, ex->d_counts, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
     return ORBX_OK;
 }
 
