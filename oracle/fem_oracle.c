@@ -1,1 +1,343 @@
-/* placeholder, filled in below */
+/*
+ * oracle/fem_oracle.c -- CPU restatement of the FEM core of FEA2 (ORB_SLAM2_E fork).
+ *
+ * TEST INFRASTRUCTURE ONLY (see orb_oracle.c header).  PARITY UNPINNED: the
+ * reference has no tests/golden vectors for this path and FEA2.cc cannot be built
+ * here (needs PCL + Eigen).  Pinned by first-principles known-answer tests only
+ * (symmetry, rigid-translation null space, patch tests).
+ *
+ * Follows Thirdparty/g2o/g2o/FEA/src/FEA2.cc: ctor :48-73 (Lame matrix, Gauss
+ * points), SetSecondLayer :1184-1219, ComputeKeiC3D8 :1244-1309, ComputeKeiC3D6
+ * :1312-1376 (literal, including the signed Jacobian and the three sign
+ * deviations in the inverse Jacobian), MatrixAssemblyC3D8/6
+ * :1379-1624 (dense, element order), ImposeDirichletEncastre_K/_a :1628-1658
+ * (the id-1 quirk, App. C5), ComputeDisplacement :1799-1808, ComputeForces
+ * :1811-1816, ComputeStrainEnergy :1877-1894, NormalizeStrainEnergy :1897-1902.
+ * The linear tetrahedron and the CG solve have NO reference counterpart (the
+ * reference's only solve is a dead dense inverse, :1661-1691): for them this
+ * file is the definition.
+ *
+ * All arithmetic in float exactly as written in the reference (-ffp-contract=off),
+ * CG in double.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* FEA2::FEA2, FEA2.cc:53-62 */
+void oracle_fem_material(unsigned int E, float nu, float *lambda_out, float *G_out, float *D /*36*/)
+{
+    float lambda = (nu * E) / ((1 + nu) * (1 - 2 * nu));
+    float G = E / (2 * (1 + nu));
+    int i;
+    for (i = 0; i < 36; i++) D[i] = 0.0f;
+    D[0] = D[7] = D[14] = lambda + 2 * G;
+    D[1] = D[2] = D[6] = D[8] = D[12] = D[13] = lambda;
+    D[21] = D[28] = D[35] = G;
+    if (lambda_out) *lambda_out = lambda;
+    if (G_out) *G_out = G;
+}
+
+/* Gauss points, FEA2.cc:64-72 */
+void oracle_fem_gauss(float fg, float *gs /*24*/)
+{
+    const float s[8][3] = {{-1, -1, -1}, {+1, -1, -1}, {+1, +1, -1}, {-1, +1, -1},
+                           {-1, -1, +1}, {+1, -1, +1}, {+1, +1, +1}, {-1, +1, +1}};
+    int i, j;
+    for (i = 0; i < 8; i++)
+        for (j = 0; j < 3; j++) gs[3 * i + j] = s[i][j] < 0 ? -fg : +fg;
+}
+
+/* Shared tail of ComputeKeiC3D8/C3D6: Jacobian, "inverse", B, BtD, BtDB*Jac.
+ * dN[a][n] = dN_n/d(xi|eta|zeta), nn nodes. */
+static void ke_accumulate(int nn, const float dNdxi[], const float dNdeta[], const float dNdzeta[],
+                          const float *P /*nn x 3*/, const float *D, float *Ke)
+{
+    const int nd = 3 * nn;
+    float J_00 = 0, J_01 = 0, J_02 = 0, J_10 = 0, J_11 = 0, J_12 = 0, J_20 = 0, J_21 = 0, J_22 = 0, Jac;
+    float J1_00, J1_01, J1_02, J1_10, J1_11, J1_12, J1_20, J1_21, J1_22;
+    float dNdx[8], dNdy[8], dNdz[8];
+    float B[6][24], BtD[24][6];
+    int n, i, j;
+    /* left-to-right sums as written (:1263-1271); first term assigned, rest added */
+    for (n = 0; n < nn; n++) {
+        if (n == 0) {
+            J_00 = dNdxi[0] * P[0];   J_01 = dNdxi[0] * P[1];   J_02 = dNdxi[0] * P[2];
+            J_10 = dNdeta[0] * P[0];  J_11 = dNdeta[0] * P[1];  J_12 = dNdeta[0] * P[2];
+            J_20 = dNdzeta[0] * P[0]; J_21 = dNdzeta[0] * P[1]; J_22 = dNdzeta[0] * P[2];
+        } else {
+            J_00 = J_00 + dNdxi[n] * P[3 * n];   J_01 = J_01 + dNdxi[n] * P[3 * n + 1];   J_02 = J_02 + dNdxi[n] * P[3 * n + 2];
+            J_10 = J_10 + dNdeta[n] * P[3 * n];  J_11 = J_11 + dNdeta[n] * P[3 * n + 1];  J_12 = J_12 + dNdeta[n] * P[3 * n + 2];
+            J_20 = J_20 + dNdzeta[n] * P[3 * n]; J_21 = J_21 + dNdzeta[n] * P[3 * n + 1]; J_22 = J_22 + dNdzeta[n] * P[3 * n + 2];
+        }
+    }
+    Jac = J_00 * J_11 * J_22 + J_01 * J_12 * J_20 + J_10 * J_21 * J_02 - J_20 * J_11 * J_02 - J_10 * J_01 * J_22 - J_21 * J_12 * J_00;
+    J1_00 = (+1) * ((J_11 * J_22) - (J_21 * J_12)) / Jac; J1_01 = (-1) * ((J_01 * J_22) - (J_21 * J_02)) / Jac; J1_02 = (-1) * ((J_01 * J_12) - (J_11 * J_02)) / Jac;
+    J1_10 = (-1) * ((J_10 * J_22) - (J_20 * J_12)) / Jac; J1_11 = (-1) * ((J_00 * J_22) - (J_20 * J_02)) / Jac; J1_12 = (-1) * ((J_00 * J_12) - (J_10 * J_02)) / Jac;
+    J1_20 = (+1) * ((J_10 * J_21) - (J_20 * J_11)) / Jac; J1_21 = (-1) * ((J_00 * J_21) - (J_20 * J_01)) / Jac; J1_22 = (-1) * ((J_00 * J_11) - (J_10 * J_01)) / Jac;
+    for (n = 0; n < nn; n++) {
+        dNdx[n] = J1_00 * dNdxi[n] + J1_01 * dNdeta[n] + J1_02 * dNdzeta[n];
+        dNdy[n] = J1_10 * dNdxi[n] + J1_11 * dNdeta[n] + J1_12 * dNdzeta[n];
+        dNdz[n] = J1_20 * dNdxi[n] + J1_21 * dNdeta[n] + J1_22 * dNdzeta[n];
+    }
+    for (n = 0; n < nn; n++) { /* B as laid out at :1288-1293 */
+        const int c = 3 * n;
+        B[0][c] = dNdx[n]; B[0][c + 1] = 0.0f;    B[0][c + 2] = 0.0f;
+        B[1][c] = 0.0f;    B[1][c + 1] = dNdy[n]; B[1][c + 2] = 0.0f;
+        B[2][c] = 0.0f;    B[2][c + 1] = 0.0f;    B[2][c + 2] = dNdz[n];
+        B[3][c] = dNdy[n]; B[3][c + 1] = dNdx[n]; B[3][c + 2] = 0.0f;
+        B[4][c] = dNdz[n]; B[4][c + 1] = 0.0f;    B[4][c + 2] = dNdx[n];
+        B[5][c] = 0.0f;    B[5][c + 1] = dNdz[n]; B[5][c + 2] = dNdy[n];
+    }
+    for (i = 0; i < nd; i++)
+        for (j = 0; j < 6; j++)
+            BtD[i][j] = B[0][i] * D[0 * 6 + j] + B[1][i] * D[1 * 6 + j] + B[2][i] * D[2 * 6 + j] + B[3][i] * D[3 * 6 + j] + B[4][i] * D[4 * 6 + j] + B[5][i] * D[5 * 6 + j];
+    for (i = 0; i < nd; i++)
+        for (j = 0; j < nd; j++) {
+            float aux = BtD[i][0] * B[0][j] + BtD[i][1] * B[1][j] + BtD[i][2] * B[2][j] + BtD[i][3] * B[3][j] + BtD[i][4] * B[4][j] + BtD[i][5] * B[5][j];
+            Ke[i * nd + j] += aux * Jac;
+        }
+}
+
+/* FEA2::ComputeKeiC3D8, FEA2.cc:1244-1309 */
+void oracle_fem_ke_c3d8(const float *P /*8x3*/, const float *D, const float *gs, float *Ke /*24x24*/)
+{
+    int ops;
+    memset(Ke, 0, sizeof(float) * 24 * 24);
+    for (ops = 0; ops < 8; ops++) {
+        float xi = gs[3 * ops], eta = gs[3 * ops + 1], zeta = gs[3 * ops + 2];
+        float a[8], b[8], c[8];
+        a[0] = -0.125 * ((1 - eta) * (1 - zeta)); b[0] = -0.125 * ((1 - xi) * (1 - zeta)); c[0] = -0.125 * ((1 - xi) * (1 - eta));
+        a[1] = +0.125 * ((1 - eta) * (1 - zeta)); b[1] = -0.125 * ((1 + xi) * (1 - zeta)); c[1] = -0.125 * ((1 + xi) * (1 - eta));
+        a[2] = +0.125 * ((1 + eta) * (1 - zeta)); b[2] = +0.125 * ((1 + xi) * (1 - zeta)); c[2] = -0.125 * ((1 + xi) * (1 + eta));
+        a[3] = -0.125 * ((1 + eta) * (1 - zeta)); b[3] = +0.125 * ((1 - xi) * (1 - zeta)); c[3] = -0.125 * ((1 - xi) * (1 + eta));
+        a[4] = -0.125 * ((1 - eta) * (1 + zeta)); b[4] = -0.125 * ((1 - xi) * (1 + zeta)); c[4] = +0.125 * ((1 - xi) * (1 - eta));
+        a[5] = +0.125 * ((1 - eta) * (1 + zeta)); b[5] = -0.125 * ((1 + xi) * (1 + zeta)); c[5] = +0.125 * ((1 + xi) * (1 - eta));
+        a[6] = +0.125 * ((1 + eta) * (1 + zeta)); b[6] = +0.125 * ((1 + xi) * (1 + zeta)); c[6] = +0.125 * ((1 + xi) * (1 + eta));
+        a[7] = -0.125 * ((1 + eta) * (1 + zeta)); b[7] = +0.125 * ((1 - xi) * (1 + zeta)); c[7] = +0.125 * ((1 - xi) * (1 + eta));
+        ke_accumulate(8, a, b, c, P, D, Ke);
+    }
+}
+
+/* FEA2::ComputeKeiC3D6, FEA2.cc:1312-1376 (prism, same 8 hex Gauss points: App. C4) */
+void oracle_fem_ke_c3d6(const float *P /*6x3*/, const float *D, const float *gs, float *Ke /*18x18*/)
+{
+    int ops;
+    memset(Ke, 0, sizeof(float) * 18 * 18);
+    for (ops = 0; ops < 8; ops++) {
+        float xi = gs[3 * ops], eta = gs[3 * ops + 1], zeta = gs[3 * ops + 2];
+        float a[6], b[6], c[6];
+        a[0] = -(1 + zeta) / 2; b[0] = -(1 + zeta) / 2; c[0] = (1 - xi - eta) / 2;
+        a[1] = (1 + zeta) / 2;  b[1] = 0.0;             c[1] = xi / 2;
+        a[2] = 0.0;             b[2] = (1 + zeta) / 2;  c[2] = eta / 2;
+        a[3] = -(1 - zeta) / 2; b[3] = -(1 - zeta) / 2; c[3] = -(1 - xi - eta) / 2;
+        a[4] = (1 - zeta) / 2;  b[4] = 0.0;             c[4] = -xi / 2;
+        a[5] = 0.0;             b[5] = (1 - zeta) / 2;  c[5] = -eta / 2;
+        ke_accumulate(6, a, b, c, P, D, Ke);
+    }
+}
+
+/* Linear tetrahedron (no reference counterpart): constant strain,
+ * K_e = (B^T D B) * V with V = |det[p1-p0,p2-p0,p3-p0]| / 6, float arithmetic in
+ * the same BtD -> BtDB order as the reference elements. */
+void oracle_fem_ke_tet4(const float *P /*4x3*/, const float *D, float *Ke /*12x12*/)
+{
+    float e1x = P[3] - P[0], e1y = P[4] - P[1], e1z = P[5] - P[2];
+    float e2x = P[6] - P[0], e2y = P[7] - P[1], e2z = P[8] - P[2];
+    float e3x = P[9] - P[0], e3y = P[10] - P[1], e3z = P[11] - P[2];
+    /* cofactors: gradients of N1..N3 are rows of inv([e1;e2;e3]) transposed */
+    float c1x = e2y * e3z - e2z * e3y, c1y = e2z * e3x - e2x * e3z, c1z = e2x * e3y - e2y * e3x;
+    float c2x = e3y * e1z - e3z * e1y, c2y = e3z * e1x - e3x * e1z, c2z = e3x * e1y - e3y * e1x;
+    float c3x = e1y * e2z - e1z * e2y, c3y = e1z * e2x - e1x * e2z, c3z = e1x * e2y - e1y * e2x;
+    float det = e1x * c1x + e1y * c1y + e1z * c1z;
+    float V = fabsf(det) / 6;
+    float gx[4], gy[4], gz[4], B[6][12], BtD[12][6];
+    int n, i, j;
+    gx[1] = c1x / det; gy[1] = c1y / det; gz[1] = c1z / det;
+    gx[2] = c2x / det; gy[2] = c2y / det; gz[2] = c2z / det;
+    gx[3] = c3x / det; gy[3] = c3y / det; gz[3] = c3z / det;
+    gx[0] = -(gx[1] + gx[2] + gx[3]); gy[0] = -(gy[1] + gy[2] + gy[3]); gz[0] = -(gz[1] + gz[2] + gz[3]);
+    for (n = 0; n < 4; n++) {
+        const int c = 3 * n;
+        B[0][c] = gx[n]; B[0][c + 1] = 0.0f;  B[0][c + 2] = 0.0f;
+        B[1][c] = 0.0f;  B[1][c + 1] = gy[n]; B[1][c + 2] = 0.0f;
+        B[2][c] = 0.0f;  B[2][c + 1] = 0.0f;  B[2][c + 2] = gz[n];
+        B[3][c] = gy[n]; B[3][c + 1] = gx[n]; B[3][c + 2] = 0.0f;
+        B[4][c] = gz[n]; B[4][c + 1] = 0.0f;  B[4][c + 2] = gx[n];
+        B[5][c] = 0.0f;  B[5][c + 1] = gz[n]; B[5][c + 2] = gy[n];
+    }
+    for (i = 0; i < 12; i++)
+        for (j = 0; j < 6; j++)
+            BtD[i][j] = B[0][i] * D[j] + B[1][i] * D[6 + j] + B[2][i] * D[12 + j] + B[3][i] * D[18 + j] + B[4][i] * D[24 + j] + B[5][i] * D[30 + j];
+    for (i = 0; i < 12; i++)
+        for (j = 0; j < 12; j++) {
+            float aux = BtD[i][0] * B[0][j] + BtD[i][1] * B[1][j] + BtD[i][2] * B[2][j] + BtD[i][3] * B[3][j] + BtD[i][4] * B[4][j] + BtD[i][5] * B[5][j];
+            Ke[i * 12 + j] = aux * V;
+        }
+}
+
+/* SetSecondLayer, FEA2.cc:1184-1219: bottom = top - (h,h,h); nodes = top || bottom. */
+void oracle_fem_second_layer(const float *top, int nTop, float h, float *nodes /*2*nTop*3*/)
+{
+    int i;
+    memcpy(nodes, top, sizeof(float) * 3 * nTop);
+    for (i = 0; i < 3 * nTop; i++) nodes[3 * nTop + i] = top[i] - h;
+}
+
+static int nodes_per_elem(int eltype) { return eltype == 1 ? 8 : (eltype == 2 ? 6 : 4); }
+
+void oracle_fem_ke(int eltype, const float *P, const float *D, const float *gs, float *Ke)
+{
+    if (eltype == 1) oracle_fem_ke_c3d8(P, D, gs, Ke);
+    else if (eltype == 2) oracle_fem_ke_c3d6(P, D, gs, Ke);
+    else oracle_fem_ke_tet4(P, D, Ke);
+}
+
+/* MatrixAssemblyC3D8/C3D6, FEA2.cc:1379-1624: dense K (n = 3*nn), scatter-add in
+ * element order.  eltype: 1 = C3D8 (nElType 1), 2 = C3D6 (nElType 2), 4 = tet4.
+ * elems holds all element node ids (the reference forms them as top ids ||
+ * top ids + nTop, :1392-1399/:1518-1523; the caller does that). */
+void oracle_fem_assemble_dense(int eltype, const float *nodes, int nn, const int *elems, int ne,
+                               const float *D, const float *gs, float *K)
+{
+    const int npe = nodes_per_elem(eltype), nd = 3 * npe, n = 3 * nn;
+    float P[24], Ke[24 * 24];
+    int e, a, ni, nj, m, q;
+    memset(K, 0, sizeof(float) * (size_t)n * n);
+    for (e = 0; e < ne; e++) {
+        const int *en = elems + (size_t)e * npe;
+        for (a = 0; a < npe; a++) { P[3 * a] = nodes[3 * en[a]]; P[3 * a + 1] = nodes[3 * en[a] + 1]; P[3 * a + 2] = nodes[3 * en[a] + 2]; }
+        oracle_fem_ke(eltype, P, D, gs, Ke);
+        for (ni = 0; ni < npe; ni++)
+            for (nj = 0; nj < npe; nj++)
+                for (m = 0; m < 3; m++)
+                    for (q = 0; q < 3; q++) {
+                        const int r = en[ni] * 3 + m, c = en[nj] * 3 + q;
+                        if (r >= n || c >= n) continue;
+                        K[(size_t)r * n + c] += Ke[(3 * ni + m) * nd + 3 * nj + q];
+                    }
+    }
+}
+
+/* ImposeDirichletEncastre_K, FEA2.cc:1628-1645: K[d][d]=Klarge for d = 3*(id-1)+{0,1,2}. */
+void oracle_fem_dirichlet_K(float *K, int n, const int *ids, int nids, float Klarge)
+{
+    int i, k;
+    for (i = 0; i < nids; i++)
+        for (k = 0; k < 3; k++) {
+            const int d = 3 * (ids[i] - 1) + k;
+            K[(size_t)d * n + d] = Klarge;
+        }
+}
+
+/* ComputeDisplacement + ImposeDirichletEncastre_a, FEA2.cc:1799-1808,1648-1658 */
+void oracle_fem_displacement(const float *uf, const float *u0, int n, const int *ids, int nids, float Klarge, float *a)
+{
+    int i, k;
+    for (i = 0; i < n; i++) a[i] = uf[i] - u0[i];
+    for (i = 0; i < nids; i++)
+        for (k = 0; k < 3; k++) a[3 * (ids[i] - 1) + k] = 1 / Klarge;
+}
+
+/* ComputeForces f = K*a (dense, float; row sums taken left to right -- Eigen's
+ * own summation order is not specified, hence a tolerance on this one). */
+void oracle_fem_matvec_dense(const float *K, int n, const float *a, float *f)
+{
+    int i, j;
+    for (i = 0; i < n; i++) {
+        float s = 0.0f;
+        for (j = 0; j < n; j++) s += K[(size_t)i * n + j] * a[j];
+        f[i] = s;
+    }
+}
+
+/* ComputeStrainEnergy sE = |a^T f| (:1877-1894) and NormalizeStrainEnergy
+ * nsE = sE / int(Ksize/3) (:1897-1902). */
+float oracle_fem_strain_energy(const float *a, const float *f, int n, float *nsE)
+{
+    float sE = 0.0f;
+    int i;
+    for (i = 0; i < n; i++) sE += a[i] * f[i];
+    if (sE < 0.0) sE = -sE;
+    if (nsE) *nsE = sE / (n / 3);
+    return sE;
+}
+
+/* Dense -> CSR (pattern = non-zero entries plus the diagonal). Returns nnz. */
+int oracle_fem_dense_to_csr(const float *K, int n, int *rowptr, int *col, float *val, int cap)
+{
+    int i, j, nnz = 0;
+    for (i = 0; i < n; i++) {
+        rowptr[i] = nnz;
+        for (j = 0; j < n; j++)
+            if (K[(size_t)i * n + j] != 0.0f || i == j) {
+                if (nnz < cap) { col[nnz] = j; val[nnz] = K[(size_t)i * n + j]; }
+                nnz++;
+            }
+    }
+    rowptr[n] = nnz;
+    return nnz;
+}
+
+/* Exact Dirichlet elimination on CSR (used by the SPD tet benchmark, SURVEY
+ * App. C tail): rows/cols of constrained dofs -> identity. */
+void oracle_fem_csr_eliminate(int n, const int *rowptr, const int *col, float *val, const uint8_t *fixed)
+{
+    int i, k;
+    for (i = 0; i < n; i++)
+        for (k = rowptr[i]; k < rowptr[i + 1]; k++)
+            if (fixed[i] || fixed[col[k]]) val[k] = (col[k] == i) ? 1.0f : 0.0f;
+}
+
+/* Jacobi-preconditioned CG in double on a float CSR matrix (no reference
+ * counterpart: this is the definition).  x0 = 0.  Stops after `iters`
+ * iterations or when ||r|| <= tol*||b||.  Returns iterations done. */
+int oracle_fem_cg(int n, const int *rowptr, const int *col, const float *val, const double *b, double *x,
+                  int iters, double tol, double *relres)
+{
+    double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n);
+    double *p = (double *)malloc(sizeof(double) * n), *Ap = (double *)malloc(sizeof(double) * n);
+    double *dinv = (double *)malloc(sizeof(double) * n);
+    double rz = 0, bb = 0, rr;
+    int i, k, it = 0;
+    for (i = 0; i < n; i++) {
+        double d = 1.0;
+        for (k = rowptr[i]; k < rowptr[i + 1]; k++) if (col[k] == i) d = (double)val[k];
+        dinv[i] = 1.0 / d;
+        x[i] = 0; r[i] = b[i]; z[i] = r[i] * dinv[i]; p[i] = z[i];
+        rz += r[i] * z[i]; bb += b[i] * b[i];
+    }
+    rr = bb;
+    while (it < iters && !(sqrt(rr) <= tol * sqrt(bb))) {
+        double pAp = 0, alpha, beta, rz2 = 0;
+        for (i = 0; i < n; i++) {
+            double s = 0;
+            for (k = rowptr[i]; k < rowptr[i + 1]; k++) s += (double)val[k] * p[col[k]];
+            Ap[i] = s; pAp += p[i] * s;
+        }
+        alpha = rz / pAp;
+        rr = 0;
+        for (i = 0; i < n; i++) {
+            x[i] += alpha * p[i]; r[i] -= alpha * Ap[i];
+            z[i] = r[i] * dinv[i]; rz2 += r[i] * z[i]; rr += r[i] * r[i];
+        }
+        beta = rz2 / rz; rz = rz2;
+        for (i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
+        it++;
+    }
+    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0;
+    free(r); free(z); free(p); free(Ap); free(dinv);
+    return it;
+}
+
+/* CSR y = A*x in double (float values), for residual checks. */
+void oracle_fem_csr_matvec(int n, const int *rowptr, const int *col, const float *val, const double *x, double *y)
+{
+    int i, k;
+    for (i = 0; i < n; i++) {
+        double s = 0;
+        for (k = rowptr[i]; k < rowptr[i + 1]; k++) s += (double)val[k] * x[col[k]];
+        y[i] = s;
+    }
+}
