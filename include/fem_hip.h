@@ -1,0 +1,103 @@
+/*
+ * fem_hip.h -- C ABI of the FEM core that the ORB_SLAM2_E fork injects into
+ * Optimizer::PoseOptimizationNR (src/Optimizer.cc:478-834) through class FEA2
+ * (Thirdparty/g2o/g2o/FEA/{include/FEA2.h,src/FEA2.cc}).
+ *
+ * Scope: element stiffness K_e (C3D8 / C3D6 exactly as the reference computes
+ * them, plus a linear tetrahedron), global assembly (CSR instead of the
+ * reference's dense vector<vector<float>>), penalty Dirichlet, f = K*a, strain
+ * energy, and a Jacobi-preconditioned CG solve that fills the slot of the
+ * reference's dead dense inverse (FEA2.cc:1661-1691).  The PCL meshing front half
+ * of FEA2 (FEA2.cc:124-1181) is out of scope: meshes come in as node / element
+ * arrays.  Same conventions as orbslam_hip.h (int status, host pointers unless
+ * named *_dev, no CPU fallback).
+ *
+ * A fem_model holds `nmesh` independent meshes that share one topology (element
+ * connectivity) but have their own node coordinates, hence their own matrices:
+ * the batch is one block-diagonal CSR matrix resident in HBM.
+ */
+#ifndef FEM_HIP_H
+#define FEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    FEM_C3D8 = 1, /* nElType 1: 8-node hexahedron, FEA2::ComputeKeiC3D8 (FEA2.cc:1244-1309) */
+    FEM_C3D6 = 2, /* nElType 2: 6-node prism,      FEA2::ComputeKeiC3D6 (FEA2.cc:1312-1376) */
+    FEM_TET4 = 4  /* 4-node linear tetrahedron (no reference counterpart)        */
+};
+
+typedef struct fem_model fem_model;
+
+/* FEA2::SetSecondLayer (FEA2.cc:1184-1219): nodes_out[2*ntop][3] = top || top-(h,h,h).
+ * Pure host helper (3*ntop subtractions). */
+int fem_second_layer(const float *top, int ntop, float h, float *nodes_out);
+
+/* FEA2::FEA2(frameId, E, nu, h, fg, nElType, debug) (FEA2.cc:48-73) + the mesh.
+ * nodes[nmesh][nn][3] float, elems[ne][npe] int32 node ids (npe = 8 / 6 / 4).
+ * E is unsigned as in FEA2.h:236.  Builds the CSR pattern on the host once. */
+int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t *elems, int ne,
+               unsigned int E, float nu, float fg, fem_model **out);
+int fem_destroy(fem_model *m);
+
+/* Sizes: meshes, dofs per mesh (Ksize = 3*nn), scalar non-zeros per mesh. */
+int fem_sizes(const fem_model *m, int *nmesh, int *ndof, int64_t *nnz);
+/* lambda, G, D[36] as the constructor computes them in float (FEA2.cc:53-62). */
+int fem_material(const fem_model *m, float *lambda, float *G, float *D36);
+
+/* MatrixAssemblyC3D8 / MatrixAssemblyC3D6 (FEA2.cc:1379-1624): K_e for every
+ * element of every mesh, then the global K; each entry sums its element
+ * contributions in element order, so it equals the reference's dense scatter-add
+ * bit for bit (given the same float K_e). */
+int fem_assemble(fem_model *m);
+
+/* ImposeDirichletEncastre_K (FEA2.cc:1628-1645): K[d][d] = klarge for
+ * d = 3*(ids[i]-1)+{0,1,2} -- the reference's off-by-one is kept. */
+int fem_dirichlet_penalty(fem_model *m, const int32_t *ids, int nids, float klarge);
+/* Exact elimination (rows/cols of the listed dofs -> identity); used for the SPD
+ * tetrahedral benchmark, not by the reference. */
+int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs);
+
+/* Parity accessors. */
+int fem_get_ke(fem_model *m, int mesh, int elem, float *ke /* (3*npe)^2 */);
+int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr /*ndof+1*/, int32_t *col /*nnz*/, float *val /*nnz*/);
+
+/* ComputeDisplacement + ImposeDirichletEncastre_a (FEA2.cc:1799-1808,1648-1658):
+ * a = uf - u0, then a[3*(id-1)+k] = 1/klarge.  Arrays [nmesh][ndof]. */
+int fem_displacement(fem_model *m, const float *uf, const float *u0, const int32_t *ids, int nids,
+                     float klarge, float *a);
+/* ComputeForces (FEA2.cc:1811-1816 -> MultiplyMatricesEigen :1694-1729): f = K*a
+ * in float, each row summed left to right.  a, f: [nmesh][ndof]. */
+int fem_matvec(fem_model *m, const float *a, float *f);
+/* ComputeStrainEnergy + NormalizeStrainEnergy (FEA2.cc:1877-1902):
+ * sE[mesh] = |a^T K a|, nsE = sE / int(Ksize/3).  Either output may be NULL. */
+int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE);
+
+/* Jacobi-preconditioned conjugate gradients, double vectors on the float matrix:
+ * K x = b per mesh, x0 = 0.  Runs until `iters` iterations, or earlier when every
+ * mesh has ||r|| <= tol*||b|| (checked every 25 iterations; tol <= 0 disables).
+ * b, x: [nmesh][ndof] double.  iters_done / relres[nmesh] may be NULL. */
+int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int *iters_done, double *relres);
+
+/* Resident variants for timing: upload the right-hand side and reset the solver
+ * state; run n iterations asynchronously on `stream` (no host sync, no
+ * convergence test); read the iterate back. */
+int fem_cg_setup(fem_model *m, const double *b);
+int fem_cg_iterate(fem_model *m, int n, void *stream);
+int fem_cg_result(fem_model *m, double *x, double *relres);
+/* n launches of the CG SpMV kernel alone (Ap = K*p on the resident vectors). */
+int fem_spmv_repeat(fem_model *m, int n, void *stream);
+
+/* HIP-event timing per kernel kind (k_fem_ke, k_fem_assemble, k_fem_spmv,
+ * k_fem_cg_update, k_fem_cg_dir), as orbx_profile_*. */
+int fem_profile_enable(fem_model *m, int on);
+int fem_profile_read(fem_model *m, int max_kinds, const char **names, double *total_ms, int64_t *launches, int *nkinds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEM_HIP_H */

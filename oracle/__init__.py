@@ -224,3 +224,122 @@ class Grid:
         n = self.L.oracle_grid_features_in_area(self.h, _p(self.xy), _p(self.octave), x, y, r,
                                                 min_level, max_level, _p(out), len(out))
         return out[:n].copy()
+
+
+# ------------------------------------------------------------------------- FEM
+_NPE = {1: 8, 2: 6, 4: 4}
+
+
+def fem_material(E, nu):
+    L = lib()
+    L.oracle_fem_material.argtypes = [C.c_uint, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    lam, G = C.c_float(), C.c_float()
+    D = np.zeros(36, np.float32)
+    L.oracle_fem_material(int(E), nu, C.byref(lam), C.byref(G), _p(D))
+    return lam.value, G.value, D
+
+
+def fem_gauss(fg):
+    L = lib()
+    L.oracle_fem_gauss.argtypes = [C.c_float, C.c_void_p]
+    gs = np.zeros(24, np.float32)
+    L.oracle_fem_gauss(fg, _p(gs))
+    return gs
+
+
+def fem_ke(eltype, P, E=3500, nu=0.495, fg=0.577350269):
+    L = lib()
+    P = np.ascontiguousarray(P, np.float32)
+    nd = 3 * _NPE[eltype]
+    Ke = np.zeros((nd, nd), np.float32)
+    _, _, D = fem_material(E, nu)
+    L.oracle_fem_ke(eltype, _p(P), _p(D), _p(fem_gauss(fg)), _p(Ke))
+    return Ke
+
+
+def fem_second_layer(top, h):
+    L = lib()
+    L.oracle_fem_second_layer.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    top = np.ascontiguousarray(top, np.float32)
+    out = np.zeros((2 * len(top), 3), np.float32)
+    L.oracle_fem_second_layer(_p(top), len(top), h, _p(out))
+    return out
+
+
+def fem_assemble_dense(eltype, nodes, elems, E=3500, nu=0.495, fg=0.577350269):
+    L = lib()
+    nodes = np.ascontiguousarray(nodes, np.float32); elems = np.ascontiguousarray(elems, np.int32)
+    n = 3 * len(nodes)
+    K = np.zeros((n, n), np.float32)
+    _, _, D = fem_material(E, nu)
+    L.oracle_fem_assemble_dense(eltype, _p(nodes), len(nodes), _p(elems), len(elems), _p(D), _p(fem_gauss(fg)), _p(K))
+    return K
+
+
+def fem_dirichlet_K(K, ids, Klarge=100000000.0):
+    L = lib()
+    L.oracle_fem_dirichlet_K.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float]
+    ids = np.ascontiguousarray(ids, np.int32)
+    L.oracle_fem_dirichlet_K(_p(K), len(K), _p(ids), len(ids), Klarge)
+    return K
+
+
+def fem_displacement(uf, u0, ids, Klarge=100000000.0):
+    L = lib()
+    L.oracle_fem_displacement.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    uf = np.ascontiguousarray(uf, np.float32); u0 = np.ascontiguousarray(u0, np.float32)
+    ids = np.ascontiguousarray(ids, np.int32)
+    a = np.zeros_like(uf)
+    L.oracle_fem_displacement(_p(uf), _p(u0), len(uf), _p(ids), len(ids), Klarge, _p(a))
+    return a
+
+
+def fem_matvec_dense(K, a):
+    L = lib()
+    a = np.ascontiguousarray(a, np.float32)
+    f = np.zeros_like(a)
+    L.oracle_fem_matvec_dense(_p(K), len(K), _p(a), _p(f))
+    return f
+
+
+def fem_strain_energy(a, f):
+    L = lib()
+    L.oracle_fem_strain_energy.restype = C.c_float
+    nsE = C.c_float()
+    a = np.ascontiguousarray(a, np.float32); f = np.ascontiguousarray(f, np.float32)
+    sE = L.oracle_fem_strain_energy(_p(a), _p(f), len(a), C.byref(nsE))
+    return sE, nsE.value
+
+
+def fem_dense_to_csr(K):
+    L = lib()
+    n = len(K)
+    cap = int(np.count_nonzero(K)) + n
+    rp = np.zeros(n + 1, np.int32); col = np.zeros(cap, np.int32); val = np.zeros(cap, np.float32)
+    nnz = L.oracle_fem_dense_to_csr(_p(K), n, _p(rp), _p(col), _p(val), cap)
+    return rp, col[:nnz].copy(), val[:nnz].copy()
+
+
+def fem_csr_eliminate(rp, col, val, fixed_mask):
+    L = lib()
+    fm = np.ascontiguousarray(fixed_mask, np.uint8)
+    L.oracle_fem_csr_eliminate(len(rp) - 1, _p(rp), _p(col), _p(val), _p(fm))
+    return val
+
+
+def fem_cg(rp, col, val, b, iters, tol=0.0):
+    L = lib()
+    L.oracle_fem_cg.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_double, C.c_void_p]
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros_like(b); rel = C.c_double()
+    it = L.oracle_fem_cg(len(b), _p(rp), _p(col), _p(val), _p(b), _p(x), iters, tol, C.byref(rel))
+    return x, it, rel.value
+
+
+def fem_csr_matvec(rp, col, val, x):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x)
+    L.oracle_fem_csr_matvec(len(x), _p(rp), _p(col), _p(val), _p(x), _p(y))
+    return y

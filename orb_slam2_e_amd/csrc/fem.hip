@@ -1,0 +1,810 @@
+// fem.hip -- FEM stiffness assembly, K*a, strain energy and CG for gfx950.
+//
+// Replaces the numeric core of FEA2 (Thirdparty/g2o/g2o/FEA/src/FEA2.cc):
+//   k_fem_ke        ComputeKeiC3D8 / ComputeKeiC3D6 (:1244-1376) + a linear tet
+//   k_fem_assemble  MatrixAssemblyC3D8/6 (:1379-1624) into CSR, gather form: every
+//                   matrix entry sums its element contributions in element order,
+//                   so no atomics and the result equals the dense scatter-add
+//   k_fem_matvec    ComputeForces f = K*a (:1811-1816), float, row order
+//   k_fem_energy    ComputeStrainEnergy |a^T f| (:1877-1894)
+//   k_fem_spmv / k_fem_cg_update / k_fem_cg_dir: Jacobi-PCG on the resident
+//                   block-diagonal batch (the slot of the dead dense inverse, :1661-1691)
+//
+// HBM layout for a batch of M meshes with n dofs and nnz non-zeros each:
+// vals[M][nnz] f32, cols[M][nnz] i32 (global column = mesh*n + local), one shared
+// rowptr[n+1]; CG vectors x, r, p, Ap [M][n] f64.  SpMV streams vals+cols once per
+// iteration (HBM-bound); reductions are fixed-order (chunk partials
+// summed in index order), so results are run-to-run reproducible.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/fem_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int RPB = 128; // rows per block in the CG kernels
+constexpr int LPR = 8;   // lanes per row in the SpMV
+constexpr int CGT = 256; // threads per block in the CG kernels
+
+struct FemConst {
+    float D[36];
+    float gs[24];
+};
+
+__device__ __forceinline__ float bmat(int m, int comp, float gx, float gy, float gz)
+{
+    // B rows as laid out at FEA2.cc:1288-1293 for one node's 3 columns
+    switch (m) {
+    case 0: return comp == 0 ? gx : 0.0f;
+    case 1: return comp == 1 ? gy : 0.0f;
+    case 2: return comp == 2 ? gz : 0.0f;
+    case 3: return comp == 0 ? gy : (comp == 1 ? gx : 0.0f);
+    case 4: return comp == 0 ? gz : (comp == 2 ? gx : 0.0f);
+    default: return comp == 1 ? gz : (comp == 2 ? gy : 0.0f);
+    }
+}
+
+// One 64-lane workgroup per element.  Lanes 0..NGP-1 evaluate one Gauss point
+// each (Jacobian, the reference's "inverse", physical shape gradients) in the
+// literal float operation order; then all lanes form B^T D B * Jac entries,
+// accumulating over Gauss points in order.
+template <int NPE, int ELT>
+__global__ __launch_bounds__(64) void k_fem_ke(const float *__restrict__ nodes, int nn, const int *__restrict__ elems,
+                                               int ne, FemConst fc, float *__restrict__ ke_all)
+{
+    constexpr int ND = 3 * NPE;
+    constexpr int NGP = ELT == FEM_TET4 ? 1 : 8;
+    __shared__ float P[NPE * 3];
+    __shared__ float G[NGP][3][NPE];
+    __shared__ float JAC[NGP];
+    const int e = blockIdx.x, mesh = blockIdx.y, lane = threadIdx.x;
+    if (lane < NPE * 3) {
+        const int node = elems[e * NPE + lane / 3];
+        P[lane] = nodes[((size_t)mesh * nn + node) * 3 + lane % 3];
+    }
+    __syncthreads();
+    if (lane < NGP) {
+        if constexpr (ELT == FEM_TET4) {
+            const float e1x = P[3] - P[0], e1y = P[4] - P[1], e1z = P[5] - P[2];
+            const float e2x = P[6] - P[0], e2y = P[7] - P[1], e2z = P[8] - P[2];
+            const float e3x = P[9] - P[0], e3y = P[10] - P[1], e3z = P[11] - P[2];
+            const float c1x = e2y * e3z - e2z * e3y, c1y = e2z * e3x - e2x * e3z, c1z = e2x * e3y - e2y * e3x;
+            const float c2x = e3y * e1z - e3z * e1y, c2y = e3z * e1x - e3x * e1z, c2z = e3x * e1y - e3y * e1x;
+            const float c3x = e1y * e2z - e1z * e2y, c3y = e1z * e2x - e1x * e2z, c3z = e1x * e2y - e1y * e2x;
+            const float det = e1x * c1x + e1y * c1y + e1z * c1z;
+            float gx[4], gy[4], gz[4];
+            gx[1] = c1x / det; gy[1] = c1y / det; gz[1] = c1z / det;
+            gx[2] = c2x / det; gy[2] = c2y / det; gz[2] = c2z / det;
+            gx[3] = c3x / det; gy[3] = c3y / det; gz[3] = c3z / det;
+            gx[0] = -(gx[1] + gx[2] + gx[3]); gy[0] = -(gy[1] + gy[2] + gy[3]); gz[0] = -(gz[1] + gz[2] + gz[3]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { G[0][0][n % NPE] = gx[n]; G[0][1][n % NPE] = gy[n]; G[0][2][n % NPE] = gz[n]; }
+            JAC[0] = fabsf(det) / 6;
+        } else {
+            const float xi = fc.gs[3 * lane], eta = fc.gs[3 * lane + 1], zeta = fc.gs[3 * lane + 2];
+            float a[NPE], b[NPE], c[NPE];
+            if constexpr (ELT == FEM_C3D8) { // FEA2.cc:1254-1261
+                a[0 % NPE] = -0.125f * ((1 - eta) * (1 - zeta)); b[0 % NPE] = -0.125f * ((1 - xi) * (1 - zeta)); c[0 % NPE] = -0.125f * ((1 - xi) * (1 - eta));
+                a[1 % NPE] = +0.125f * ((1 - eta) * (1 - zeta)); b[1 % NPE] = -0.125f * ((1 + xi) * (1 - zeta)); c[1 % NPE] = -0.125f * ((1 + xi) * (1 - eta));
+                a[2 % NPE] = +0.125f * ((1 + eta) * (1 - zeta)); b[2 % NPE] = +0.125f * ((1 + xi) * (1 - zeta)); c[2 % NPE] = -0.125f * ((1 + xi) * (1 + eta));
+                a[3 % NPE] = -0.125f * ((1 + eta) * (1 - zeta)); b[3 % NPE] = +0.125f * ((1 - xi) * (1 - zeta)); c[3 % NPE] = -0.125f * ((1 - xi) * (1 + eta));
+                a[4 % NPE] = -0.125f * ((1 - eta) * (1 + zeta)); b[4 % NPE] = -0.125f * ((1 - xi) * (1 + zeta)); c[4 % NPE] = +0.125f * ((1 - xi) * (1 - eta));
+                a[5 % NPE] = +0.125f * ((1 - eta) * (1 + zeta)); b[5 % NPE] = -0.125f * ((1 + xi) * (1 + zeta)); c[5 % NPE] = +0.125f * ((1 + xi) * (1 - eta));
+                a[6 % NPE] = +0.125f * ((1 + eta) * (1 + zeta)); b[6 % NPE] = +0.125f * ((1 + xi) * (1 + zeta)); c[6 % NPE] = +0.125f * ((1 + xi) * (1 + eta));
+                a[7 % NPE] = -0.125f * ((1 + eta) * (1 + zeta)); b[7 % NPE] = +0.125f * ((1 - xi) * (1 + zeta)); c[7 % NPE] = +0.125f * ((1 - xi) * (1 + eta));
+            } else { // C3D6, FEA2.cc:1322-1327
+                a[0] = -(1 + zeta) / 2; b[0] = -(1 + zeta) / 2; c[0] = (1 - xi - eta) / 2;
+                a[1] = (1 + zeta) / 2;  b[1] = 0.0f;            c[1] = xi / 2;
+                a[2] = 0.0f;            b[2] = (1 + zeta) / 2;  c[2] = eta / 2;
+                a[3] = -(1 - zeta) / 2; b[3] = -(1 - zeta) / 2; c[3] = -(1 - xi - eta) / 2;
+                a[4 % NPE] = (1 - zeta) / 2;  b[4 % NPE] = 0.0f;            c[4 % NPE] = -xi / 2;
+                a[5 % NPE] = 0.0f;            b[5 % NPE] = (1 - zeta) / 2;  c[5 % NPE] = -eta / 2;
+            }
+            float J_00 = a[0] * P[0], J_01 = a[0] * P[1], J_02 = a[0] * P[2];
+            float J_10 = b[0] * P[0], J_11 = b[0] * P[1], J_12 = b[0] * P[2];
+            float J_20 = c[0] * P[0], J_21 = c[0] * P[1], J_22 = c[0] * P[2];
+#pragma unroll
+            for (int n = 1; n < NPE; ++n) {
+                J_00 = J_00 + a[n] * P[3 * n]; J_01 = J_01 + a[n] * P[3 * n + 1]; J_02 = J_02 + a[n] * P[3 * n + 2];
+                J_10 = J_10 + b[n] * P[3 * n]; J_11 = J_11 + b[n] * P[3 * n + 1]; J_12 = J_12 + b[n] * P[3 * n + 2];
+                J_20 = J_20 + c[n] * P[3 * n]; J_21 = J_21 + c[n] * P[3 * n + 1]; J_22 = J_22 + c[n] * P[3 * n + 2];
+            }
+            // signed determinant and the reference's inverse with its three sign deviations
+            const float Jac = J_00 * J_11 * J_22 + J_01 * J_12 * J_20 + J_10 * J_21 * J_02 - J_20 * J_11 * J_02 - J_10 * J_01 * J_22 - J_21 * J_12 * J_00;
+            const float J1_00 = (+1) * ((J_11 * J_22) - (J_21 * J_12)) / Jac, J1_01 = (-1) * ((J_01 * J_22) - (J_21 * J_02)) / Jac, J1_02 = (-1) * ((J_01 * J_12) - (J_11 * J_02)) / Jac;
+            const float J1_10 = (-1) * ((J_10 * J_22) - (J_20 * J_12)) / Jac, J1_11 = (-1) * ((J_00 * J_22) - (J_20 * J_02)) / Jac, J1_12 = (-1) * ((J_00 * J_12) - (J_10 * J_02)) / Jac;
+            const float J1_20 = (+1) * ((J_10 * J_21) - (J_20 * J_11)) / Jac, J1_21 = (-1) * ((J_00 * J_21) - (J_20 * J_01)) / Jac, J1_22 = (-1) * ((J_00 * J_11) - (J_10 * J_01)) / Jac;
+#pragma unroll
+            for (int n = 0; n < NPE; ++n) {
+                G[lane % NGP][0][n] = J1_00 * a[n] + J1_01 * b[n] + J1_02 * c[n];
+                G[lane % NGP][1][n] = J1_10 * a[n] + J1_11 * b[n] + J1_12 * c[n];
+                G[lane % NGP][2][n] = J1_20 * a[n] + J1_21 * b[n] + J1_22 * c[n];
+            }
+            JAC[lane % NGP] = Jac;
+        }
+    }
+    __syncthreads();
+    float *ke = ke_all + ((size_t)mesh * ne + e) * ND * ND;
+    for (int idx = lane; idx < ND * ND; idx += 64) {
+        const int i = idx / ND, j = idx - i * ND;
+        const int ni = i / 3, ci = i - 3 * ni, nj = j / 3, cj = j - 3 * nj;
+        float acc = 0.0f;
+        for (int gp = 0; gp < NGP; ++gp) {
+            const float gxi = G[gp][0][ni], gyi = G[gp][1][ni], gzi = G[gp][2][ni];
+            const float gxj = G[gp][0][nj], gyj = G[gp][1][nj], gzj = G[gp][2][nj];
+            float Bi[6], Bj[6], BtD[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { Bi[m] = bmat(m, ci, gxi, gyi, gzi); Bj[m] = bmat(m, cj, gxj, gyj, gzj); }
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                BtD[k] = Bi[0] * fc.D[k] + Bi[1] * fc.D[6 + k] + Bi[2] * fc.D[12 + k] + Bi[3] * fc.D[18 + k] + Bi[4] * fc.D[24 + k] + Bi[5] * fc.D[30 + k];
+            const float aux = BtD[0] * Bj[0] + BtD[1] * Bj[1] + BtD[2] * Bj[2] + BtD[3] * Bj[3] + BtD[4] * Bj[4] + BtD[5] * Bj[5];
+            acc += aux * JAC[gp];
+        }
+        ke[idx] = acc;
+    }
+}
+
+// One thread per scalar entry of a 3x3 block: sums the block's element
+// contributions in (element, local i, local j) order = the reference's loop order.
+__global__ __launch_bounds__(256) void k_fem_assemble(const float *__restrict__ ke_all, int ne, int nd, int nblk,
+                                                      const int *__restrict__ blk_row, const int *__restrict__ bptr,
+                                                      const int *__restrict__ cptr, const int *__restrict__ contrib,
+                                                      const int *__restrict__ rowptr, float *__restrict__ vals,
+                                                      int *__restrict__ cols, const int *__restrict__ lcol,
+                                                      size_t nnz, int ndof)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, mesh = blockIdx.y;
+    if (t >= nblk * 9) return;
+    const int b = t / 9, mn = t - 9 * b, m = mn / 3, n = mn - 3 * m;
+    const int I = blk_row[b];
+    const float *ke = ke_all + (size_t)mesh * ne * nd * nd;
+    float v = 0.0f;
+    for (int c = cptr[b]; c < cptr[b + 1]; ++c) {
+        const int pk = contrib[c];
+        const int e = pk >> 6, li = (pk >> 3) & 7, lj = pk & 7;
+        v += ke[((size_t)e * nd + 3 * li + m) * nd + 3 * lj + n];
+    }
+    const int k = rowptr[3 * I + m] + 3 * (b - bptr[I]) + n;
+    vals[(size_t)mesh * nnz + k] = v;
+    cols[(size_t)mesh * nnz + k] = mesh * ndof + lcol[k];
+}
+
+__global__ void k_fem_penalty(float *__restrict__ vals, size_t nnz, const int *__restrict__ diag_idx,
+                              const int *__restrict__ ids, int nids, float klarge)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y;
+    if (t >= nids * 3) return;
+    const int d = 3 * (ids[t / 3] - 1) + t % 3; // FEA2.cc:1630: mp0 = 3*(vD[i][0] - 1)
+    vals[(size_t)mesh * nnz + diag_idx[d]] = klarge;
+}
+
+__global__ void k_fem_eliminate(float *__restrict__ vals, const int *__restrict__ lcol, const int *__restrict__ rowptr,
+                                size_t nnz, int ndof, const uint8_t *__restrict__ fixed)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y;
+    if (r >= ndof) return;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (fixed[r] || fixed[lcol[k]]) vals[(size_t)mesh * nnz + k] = lcol[k] == r ? 1.0f : 0.0f;
+}
+
+// f = K*a in float, one thread per row, ascending column order (= the dense row
+// sum of MultiplyMatricesEigen with exact zeros skipped).
+__global__ void k_fem_matvec(const float *__restrict__ vals, const int *__restrict__ lcol,
+                             const int *__restrict__ rowptr, size_t nnz, int ndof, const float *__restrict__ a,
+                             float *__restrict__ f)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y;
+    if (r >= ndof) return;
+    const float *v = vals + (size_t)mesh * nnz;
+    const float *am = a + (size_t)mesh * ndof;
+    float s = 0.0f;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s += v[k] * am[lcol[k]];
+    f[(size_t)mesh * ndof + r] = s;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+
+// sE = |a^T f|, nsE = sE / int(Ksize/3): one block per mesh.
+__global__ __launch_bounds__(256) void k_fem_energy(const float *__restrict__ a, const float *__restrict__ f, int ndof,
+                                                    float *__restrict__ sE, float *__restrict__ nsE)
+{
+    __shared__ double sh[4];
+    const int mesh = blockIdx.x;
+    double s = 0;
+    for (int i = threadIdx.x; i < ndof; i += 256) s += (double)a[(size_t)mesh * ndof + i] * (double)f[(size_t)mesh * ndof + i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        float e = (float)s;
+        if (e < 0.0f) e = -e;
+        if (sE) sE[mesh] = e;
+        if (nsE) nsE[mesh] = e / (float)(ndof / 3);
+    }
+}
+
+__global__ void k_fem_displacement(const float *__restrict__ uf, const float *__restrict__ u0, float *__restrict__ a, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) a[i] = uf[i] - u0[i];
+}
+__global__ void k_fem_displacement_dir(float *__restrict__ a, int ndof, const int *__restrict__ ids, int nids, float klarge)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y;
+    if (t < nids * 3) a[(size_t)mesh * ndof + 3 * (ids[t / 3] - 1) + t % 3] = 1 / klarge;
+}
+
+// ------------------------------------------------------------------------ CG
+struct CgScal { double rz[2]; double bb; double rr; };
+
+// x = 0, r = b, p = z = r/diag; partial r.z and b.b per chunk.
+__global__ __launch_bounds__(CGT) void k_fem_cg_init(const float *__restrict__ vals, const int *__restrict__ diag_idx,
+                                                     size_t nnz, int ndof, int nchunk, const double *__restrict__ b,
+                                                     double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+                                                     double *__restrict__ dinv, double *__restrict__ part_a,
+                                                     double *__restrict__ part_b)
+{
+    __shared__ double sh[CGT / 64];
+    const int mesh = blockIdx.y, chunk = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < RPB; i += CGT) {
+        const int row = chunk * RPB + i;
+        if (row < ndof) {
+            const size_t g = (size_t)mesh * ndof + row;
+            const double d = (double)vals[(size_t)mesh * nnz + diag_idx[row]];
+            const double di = 1.0 / d, bi = b[g];
+            dinv[g] = di; x[g] = 0; r[g] = bi; p[g] = bi * di;
+            s1 += bi * (bi * di); s2 += bi * bi;
+        }
+    }
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { part_a[mesh * nchunk + chunk] = s1; part_b[mesh * nchunk + chunk] = s2; }
+}
+__global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, const double *__restrict__ part_b, CgScal *__restrict__ sc)
+{
+    const int mesh = blockIdx.x;
+    double a = 0, b = 0;
+    for (int c = 0; c < nchunk; ++c) { a += part_a[mesh * nchunk + c]; b += part_b[mesh * nchunk + c]; }
+    sc[mesh].rz[0] = a; sc[mesh].rz[1] = a; sc[mesh].bb = b; sc[mesh].rr = b;
+}
+
+// Ap = K p for RPB rows; LPR lanes stride one row's non-zeros (coalesced 32-B
+// segments of vals and cols), fixed-order shuffle reduction; partial p.Ap.
+__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ cols,
+                                                  const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
+                                                  const double *__restrict__ p, double *__restrict__ Ap,
+                                                  double *__restrict__ part_pAp)
+{
+    __shared__ double sh[CGT / 64];
+    const int mesh = blockIdx.y, chunk = blockIdx.x;
+    const int sub = threadIdx.x / LPR, sl = threadIdx.x % LPR;
+    const float *v = vals + (size_t)mesh * nnz;
+    const int *cidx = cols + (size_t)mesh * nnz;
+    double acc = 0;
+#pragma unroll
+    for (int pass = 0; pass < RPB / (CGT / LPR); ++pass) {
+        const int row = chunk * RPB + pass * (CGT / LPR) + sub;
+        double s = 0;
+        if (row < ndof) {
+            const int k1 = rowptr[row + 1];
+            for (int k = rowptr[row] + sl; k < k1; k += LPR) s += (double)v[k] * p[cidx[k]];
+        }
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (row < ndof && sl == 0) {
+            const size_t g = (size_t)mesh * ndof + row;
+            Ap[g] = s;
+            acc += p[g] * s;
+        }
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part_pAp[mesh * nchunk + chunk] = acc;
+}
+
+// alpha = rz/pAp; x += alpha p; r -= alpha Ap; partial r.(r/diag) and r.r.
+__global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int cur, const CgScal *__restrict__ sc,
+                                                       const double *__restrict__ part_pAp, const double *__restrict__ p,
+                                                       const double *__restrict__ Ap, const double *__restrict__ dinv,
+                                                       double *__restrict__ x, double *__restrict__ r,
+                                                       double *__restrict__ part_rz, double *__restrict__ part_rr)
+{
+    __shared__ double sh[CGT / 64];
+    const int mesh = blockIdx.y, chunk = blockIdx.x;
+    double pAp = 0;
+    for (int c = 0; c < nchunk; ++c) pAp += part_pAp[mesh * nchunk + c];
+    const double alpha = sc[mesh].rz[cur] / pAp;
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < RPB; i += CGT) {
+        const int row = chunk * RPB + i;
+        if (row < ndof) {
+            const size_t g = (size_t)mesh * ndof + row;
+            x[g] += alpha * p[g];
+            const double ri = r[g] - alpha * Ap[g];
+            r[g] = ri;
+            s1 += ri * (ri * dinv[g]);
+            s2 += ri * ri;
+        }
+    }
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { part_rz[mesh * nchunk + chunk] = s1; part_rr[mesh * nchunk + chunk] = s2; }
+}
+
+// beta = rz_new/rz; p = r/diag + beta p; chunk 0 publishes rz_new for the next iteration.
+__global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cur, CgScal *__restrict__ sc,
+                                                    const double *__restrict__ part_rz, const double *__restrict__ part_rr,
+                                                    const double *__restrict__ r, const double *__restrict__ dinv,
+                                                    double *__restrict__ p)
+{
+    const int mesh = blockIdx.y, chunk = blockIdx.x;
+    double rz2 = 0, rr = 0;
+    for (int c = 0; c < nchunk; ++c) { rz2 += part_rz[mesh * nchunk + c]; rr += part_rr[mesh * nchunk + c]; }
+    const double beta = rz2 / sc[mesh].rz[cur];
+    for (int i = threadIdx.x; i < RPB; i += CGT) {
+        const int row = chunk * RPB + i;
+        if (row < ndof) {
+            const size_t g = (size_t)mesh * ndof + row;
+            p[g] = r[g] * dinv[g] + beta * p[g];
+        }
+    }
+    if (chunk == 0 && threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
+}
+
+template <typename T> int dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+
+} // namespace
+
+struct fem_model {
+    int eltype, npe, nd, nmesh, nn, ne, ndof, nblk, nchunk;
+    size_t nnz;
+    unsigned int E;
+    float nu, fg, lambda, G;
+    FemConst fc;
+    std::vector<int> h_rowptr, h_lcol, h_diag;
+    bool assembled = false, cg_ready = false;
+    int cg_it = 0;
+    // device
+    float *d_nodes = nullptr, *d_ke = nullptr, *d_vals = nullptr, *d_a = nullptr, *d_f = nullptr, *d_u = nullptr, *d_e = nullptr;
+    int *d_elems = nullptr, *d_blk_row = nullptr, *d_bptr = nullptr, *d_cptr = nullptr, *d_contrib = nullptr;
+    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_cols = nullptr, *d_diag = nullptr;
+    double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
+    double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
+    CgScal *d_sc = nullptr;
+    hipStream_t stream = nullptr;
+    orbx::KernelProfiler prof;
+};
+
+namespace {
+
+void fem_free(fem_model *m)
+{
+    void *ptrs[] = {m->d_nodes, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_elems, m->d_blk_row, m->d_bptr,
+                    m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_cols, m->d_diag, m->d_b, m->d_x, m->d_r,
+                    m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+}
+
+int ensure_vecs(fem_model *m)
+{
+    const size_t N = (size_t)m->nmesh * m->ndof;
+    if (!m->d_a && (dalloc(&m->d_a, N) || dalloc(&m->d_f, N) || dalloc(&m->d_u, N) || dalloc(&m->d_e, 2 * (size_t)m->nmesh)))
+        return -1;
+    return 0;
+}
+
+int ensure_cg(fem_model *m)
+{
+    const size_t N = (size_t)m->nmesh * m->ndof, C = (size_t)m->nmesh * m->nchunk;
+    if (m->d_b) return 0;
+    if (dalloc(&m->d_b, N) || dalloc(&m->d_x, N) || dalloc(&m->d_r, N) || dalloc(&m->d_p, N) || dalloc(&m->d_Ap, N) ||
+        dalloc(&m->d_dinv, N) || dalloc(&m->d_part[0], C) || dalloc(&m->d_part[1], C) || dalloc(&m->d_part[2], C) ||
+        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nmesh))
+        return -1;
+    return 0;
+}
+
+void launch_iter(fem_model *m, hipStream_t st)
+{
+    const dim3 g(m->nchunk, m->nmesh);
+    const int cur = m->cg_it & 1;
+    m->prof.begin(st);
+    hipLaunchKernelGGL(k_fem_spmv, g, dim3(CGT), 0, st, m->d_vals, m->d_cols, m->d_rowptr, m->nnz, m->ndof, m->nchunk,
+                       m->d_p, m->d_Ap, m->d_part[0]);
+    m->prof.mark(2, st);
+    hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, cur, m->d_sc, m->d_part[0], m->d_p,
+                       m->d_Ap, m->d_dinv, m->d_x, m->d_r, m->d_part[1], m->d_part[2]);
+    m->prof.mark(3, st);
+    hipLaunchKernelGGL(k_fem_cg_dir, g, dim3(CGT), 0, st, m->ndof, m->nchunk, cur, m->d_sc, m->d_part[1], m->d_part[2],
+                       m->d_r, m->d_dinv, m->d_p);
+    m->prof.mark(4, st);
+    m->cg_it++;
+}
+
+} // namespace
+
+extern "C" {
+
+int fem_second_layer(const float *top, int ntop, float h, float *nodes_out)
+{
+    if (!top || !nodes_out || ntop < 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    for (int i = 0; i < 3 * ntop; ++i) {
+        nodes_out[i] = top[i];
+        nodes_out[3 * ntop + i] = top[i] - h; // FEA2.cc:1189-1191: world xyz, not along normals
+    }
+    return ORBX_OK;
+}
+
+int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t *elems, int ne, unsigned int E, float nu,
+               float fg, fem_model **out)
+{
+    if (!nodes || !elems || !out || nmesh < 1 || nn < 1 || ne < 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    const int npe = eltype == FEM_C3D8 ? 8 : eltype == FEM_C3D6 ? 6 : eltype == FEM_TET4 ? 4 : 0;
+    if (!npe) ORBX_FAIL(ORBX_ERR_ARG, "unknown element type");
+    if (3 * nn <= 3) ORBX_FAIL(ORBX_ERR_ARG, "Ksize<=3 (FEA2.cc:1386: assembly refuses)");
+    for (int i = 0; i < ne * npe; ++i)
+        if (elems[i] < 0 || elems[i] >= nn) ORBX_FAIL(ORBX_ERR_ARG, "element node id out of range");
+    if ((long long)ne >= (1ll << 25)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "too many elements");
+    if ((long long)nmesh * 3 * nn >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 dofs");
+    ORBX_NEED_DEVICE();
+    fem_model *m = new fem_model();
+    m->eltype = eltype; m->npe = npe; m->nd = 3 * npe; m->nmesh = nmesh; m->nn = nn; m->ne = ne; m->ndof = 3 * nn;
+    m->E = E; m->nu = nu; m->fg = fg;
+    // FEA2::FEA2, FEA2.cc:53-72 (float arithmetic, E unsigned)
+    m->lambda = (nu * E) / ((1 + nu) * (1 - 2 * nu));
+    m->G = E / (2 * (1 + nu));
+    for (int i = 0; i < 36; ++i) m->fc.D[i] = 0.0f;
+    m->fc.D[0] = m->fc.D[7] = m->fc.D[14] = m->lambda + 2 * m->G;
+    m->fc.D[1] = m->fc.D[2] = m->fc.D[6] = m->fc.D[8] = m->fc.D[12] = m->fc.D[13] = m->lambda;
+    m->fc.D[21] = m->fc.D[28] = m->fc.D[35] = m->G;
+    static const int sg[8][3] = {{-1, -1, -1}, {+1, -1, -1}, {+1, +1, -1}, {-1, +1, -1}, {-1, -1, +1}, {+1, -1, +1}, {+1, +1, +1}, {-1, +1, +1}};
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 3; ++j) m->fc.gs[3 * i + j] = sg[i][j] < 0 ? -fg : +fg;
+
+    // ---- symbolic phase (host, once per topology): block pattern + contribution lists
+    std::vector<std::vector<int>> adj(nn);
+    for (int i = 0; i < nn; ++i) adj[i].push_back(i);
+    for (int e = 0; e < ne; ++e)
+        for (int a = 0; a < npe; ++a)
+            for (int b = 0; b < npe; ++b) adj[elems[e * npe + a]].push_back(elems[e * npe + b]);
+    std::vector<int> bptr(nn + 1, 0), bcol, blk_row;
+    for (int i = 0; i < nn; ++i) {
+        std::sort(adj[i].begin(), adj[i].end());
+        adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+        bptr[i + 1] = bptr[i] + (int)adj[i].size();
+        for (int j : adj[i]) { bcol.push_back(j); blk_row.push_back(i); }
+    }
+    const int nblk = m->nblk = (int)bcol.size();
+    std::vector<int> cptr(nblk + 1, 0);
+    auto blk_of = [&](int I, int J) {
+        return bptr[I] + (int)(std::lower_bound(adj[I].begin(), adj[I].end(), J) - adj[I].begin());
+    };
+    for (int e = 0; e < ne; ++e)
+        for (int a = 0; a < npe; ++a)
+            for (int b = 0; b < npe; ++b) cptr[blk_of(elems[e * npe + a], elems[e * npe + b]) + 1]++;
+    for (int b = 0; b < nblk; ++b) cptr[b + 1] += cptr[b];
+    std::vector<int> contrib(cptr[nblk]), fill(cptr.begin(), cptr.end() - 1);
+    for (int e = 0; e < ne; ++e) // ascending (e, li, lj) inside every block = the reference's scatter order
+        for (int a = 0; a < npe; ++a)
+            for (int b = 0; b < npe; ++b) contrib[fill[blk_of(elems[e * npe + a], elems[e * npe + b])]++] = (e << 6) | (a << 3) | b;
+    m->nnz = (size_t)9 * nblk;
+    m->h_rowptr.assign(m->ndof + 1, 0);
+    m->h_lcol.assign(m->nnz, 0);
+    m->h_diag.assign(m->ndof, 0);
+    for (int I = 0; I < nn; ++I) {
+        const int nb = bptr[I + 1] - bptr[I];
+        for (int r = 0; r < 3; ++r) {
+            const int row = 3 * I + r, start = 9 * bptr[I] + r * 3 * nb;
+            m->h_rowptr[row] = start;
+            for (int jb = 0; jb < nb; ++jb)
+                for (int c = 0; c < 3; ++c) {
+                    const int col = 3 * bcol[bptr[I] + jb] + c;
+                    m->h_lcol[start + 3 * jb + c] = col;
+                    if (col == row) m->h_diag[row] = start + 3 * jb + c;
+                }
+        }
+    }
+    m->h_rowptr[m->ndof] = (int)m->nnz;
+    m->nchunk = (m->ndof + RPB - 1) / RPB;
+
+    const size_t M = (size_t)nmesh;
+    int bad = 0;
+    bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke, M * ne * m->nd * m->nd);
+    bad |= dalloc(&m->d_vals, M * m->nnz) | dalloc(&m->d_cols, M * m->nnz) | dalloc(&m->d_blk_row, (size_t)nblk);
+    bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, contrib.size());
+    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnz) | dalloc(&m->d_diag, (size_t)m->ndof);
+    if (bad || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        fem_free(m); delete m;
+        ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
+    }
+    ORBX_HIP(hipMemcpy(m->d_nodes, nodes, sizeof(float) * M * nn * 3, hipMemcpyHostToDevice));
+    if (ne) ORBX_HIP(hipMemcpy(m->d_elems, elems, sizeof(int) * (size_t)ne * npe, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_blk_row, blk_row.data(), sizeof(int) * nblk, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_bptr, bptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_cptr, cptr.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice));
+    if (!contrib.empty()) ORBX_HIP(hipMemcpy(m->d_contrib, contrib.data(), sizeof(int) * contrib.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
+    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
+    for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
+    *out = m;
+    return ORBX_OK;
+}
+
+int fem_destroy(fem_model *m)
+{
+    if (!m) return ORBX_OK;
+    fem_free(m);
+    delete m;
+    return ORBX_OK;
+}
+
+int fem_sizes(const fem_model *m, int *nmesh, int *ndof, int64_t *nnz)
+{
+    if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
+    if (nmesh) *nmesh = m->nmesh;
+    if (ndof) *ndof = m->ndof;
+    if (nnz) *nnz = (int64_t)m->nnz;
+    return ORBX_OK;
+}
+
+int fem_material(const fem_model *m, float *lambda, float *G, float *D36)
+{
+    if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
+    if (lambda) *lambda = m->lambda;
+    if (G) *G = m->G;
+    if (D36) memcpy(D36, m->fc.D, sizeof(float) * 36);
+    return ORBX_OK;
+}
+
+int fem_assemble(fem_model *m)
+{
+    if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
+    hipStream_t st = m->stream;
+    m->prof.begin(st);
+    if (m->ne > 0) {
+        const dim3 g(m->ne, m->nmesh);
+        if (m->eltype == FEM_C3D8)
+            hipLaunchKernelGGL((k_fem_ke<8, FEM_C3D8>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
+        else if (m->eltype == FEM_C3D6)
+            hipLaunchKernelGGL((k_fem_ke<6, FEM_C3D6>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
+        else
+            hipLaunchKernelGGL((k_fem_ke<4, FEM_TET4>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
+    }
+    m->prof.mark(0, st);
+    hipLaunchKernelGGL(k_fem_assemble, dim3((m->nblk * 9 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_ke, m->ne, m->nd,
+                       m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->d_cols,
+                       m->d_lcol, m->nnz, m->ndof);
+    m->prof.mark(1, st);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipStreamSynchronize(st));
+    m->assembled = true;
+    m->cg_ready = false;
+    return ORBX_OK;
+}
+
+int fem_dirichlet_penalty(fem_model *m, const int32_t *ids, int nids, float klarge)
+{
+    if (!m || !m->assembled || nids < 0 || (nids && !ids)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    for (int i = 0; i < nids; ++i)
+        if (ids[i] - 1 < 0 || ids[i] - 1 >= m->nn) ORBX_FAIL(ORBX_ERR_ARG, "Dirichlet id out of range (reference would write out of bounds)");
+    if (nids == 0) return ORBX_OK;
+    int *d_ids = nullptr;
+    if (dalloc(&d_ids, (size_t)nids)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemcpy(d_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fem_penalty, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->nnz,
+                       m->d_diag, d_ids, nids, klarge);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    (void)hipFree(d_ids);
+    m->cg_ready = false;
+    return ORBX_OK;
+}
+
+int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
+{
+    if (!m || !m->assembled || ndofs < 0 || (ndofs && !dofs)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    std::vector<uint8_t> fixed(m->ndof, 0);
+    for (int i = 0; i < ndofs; ++i) {
+        if (dofs[i] < 0 || dofs[i] >= m->ndof) ORBX_FAIL(ORBX_ERR_ARG, "dof out of range");
+        fixed[dofs[i]] = 1;
+    }
+    uint8_t *d_fixed = nullptr;
+    if (dalloc(&d_fixed, (size_t)m->ndof)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemcpy(d_fixed, fixed.data(), m->ndof, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fem_eliminate, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals,
+                       m->d_lcol, m->d_rowptr, m->nnz, m->ndof, d_fixed);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    (void)hipFree(d_fixed);
+    m->cg_ready = false;
+    return ORBX_OK;
+}
+
+int fem_get_ke(fem_model *m, int mesh, int elem, float *ke)
+{
+    if (!m || !m->assembled || !ke || mesh < 0 || mesh >= m->nmesh || elem < 0 || elem >= m->ne)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    ORBX_HIP(hipMemcpy(ke, m->d_ke + ((size_t)mesh * m->ne + elem) * m->nd * m->nd, sizeof(float) * m->nd * m->nd, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr, int32_t *col, float *val)
+{
+    if (!m || !m->assembled || mesh < 0 || mesh >= m->nmesh) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (rowptr) memcpy(rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1));
+    if (col) memcpy(col, m->h_lcol.data(), sizeof(int) * m->nnz);
+    if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + (size_t)mesh * m->nnz, sizeof(float) * m->nnz, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int fem_displacement(fem_model *m, const float *uf, const float *u0, const int32_t *ids, int nids, float klarge, float *a)
+{
+    if (!m || !uf || !u0 || !a || nids < 0 || (nids && !ids)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    for (int i = 0; i < nids; ++i)
+        if (ids[i] - 1 < 0 || ids[i] - 1 >= m->nn) ORBX_FAIL(ORBX_ERR_ARG, "Dirichlet id out of range");
+    if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    const size_t N = (size_t)m->nmesh * m->ndof;
+    ORBX_HIP(hipMemcpy(m->d_a, uf, sizeof(float) * N, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_u, u0, sizeof(float) * N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fem_displacement, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, m->stream, m->d_a, m->d_u, m->d_f, N);
+    if (nids) {
+        int *d_ids = nullptr;
+        if (dalloc(&d_ids, (size_t)nids)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+        ORBX_HIP(hipMemcpy(d_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_fem_displacement_dir, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_f,
+                           m->ndof, d_ids, nids, klarge);
+        ORBX_HIP(hipStreamSynchronize(m->stream));
+        (void)hipFree(d_ids);
+    }
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    ORBX_HIP(hipMemcpy(a, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int fem_matvec(fem_model *m, const float *a, float *f)
+{
+    if (!m || !m->assembled || !a || !f) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    const size_t N = (size_t)m->nmesh * m->ndof;
+    ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
+                       m->d_rowptr, m->nnz, m->ndof, m->d_a, m->d_f);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    ORBX_HIP(hipMemcpy(f, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE)
+{
+    if (!m || !m->assembled || !a) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    const size_t N = (size_t)m->nmesh * m->ndof;
+    ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
+                       m->d_rowptr, m->nnz, m->ndof, m->d_a, m->d_f);
+    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
+    if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nmesh, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int fem_cg_setup(fem_model *m, const double *b)
+{
+    if (!m || !m->assembled || !b) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (ensure_cg(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    const size_t N = (size_t)m->nmesh * m->ndof;
+    ORBX_HIP(hipMemcpy(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fem_cg_init, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnz,
+                       m->ndof, m->nchunk, m->d_b, m->d_x, m->d_r, m->d_p, m->d_dinv, m->d_part[0], m->d_part[1]);
+    hipLaunchKernelGGL(k_fem_cg_init2, dim3(m->nmesh), dim3(1), 0, m->stream, m->nchunk, m->d_part[0], m->d_part[1], m->d_sc);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    m->cg_it = 0;
+    m->cg_ready = true;
+    return ORBX_OK;
+}
+
+int fem_cg_iterate(fem_model *m, int n, void *stream)
+{
+    if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    for (int i = 0; i < n; ++i) launch_iter(m, st);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+int fem_spmv_repeat(fem_model *m, int n, void *stream)
+{
+    if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    for (int i = 0; i < n; ++i) {
+        m->prof.begin(st);
+        hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, st, m->d_vals, m->d_cols, m->d_rowptr, m->nnz,
+                           m->ndof, m->nchunk, m->d_p, m->d_Ap, m->d_part[0]);
+        m->prof.mark(2, st);
+    }
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+int fem_cg_result(fem_model *m, double *x, double *relres)
+{
+    if (!m || !m->cg_ready) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
+    ORBX_HIP(hipDeviceSynchronize());
+    if (x) ORBX_HIP(hipMemcpy(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost));
+    if (relres) {
+        std::vector<CgScal> sc(m->nmesh);
+        ORBX_HIP(hipMemcpy(sc.data(), m->d_sc, sizeof(CgScal) * m->nmesh, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m->nmesh; ++i) relres[i] = sc[i].bb > 0 ? sqrt(sc[i].rr / sc[i].bb) : 0.0;
+    }
+    return ORBX_OK;
+}
+
+int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int *iters_done, double *relres)
+{
+    if (!x || iters < 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    int rc = fem_cg_setup(m, b);
+    if (rc != ORBX_OK) return rc;
+    std::vector<CgScal> sc(m->nmesh);
+    int done = 0;
+    while (done < iters) {
+        if (tol > 0) { // convergence test on the device-side scalars, every 25 iterations
+            ORBX_HIP(hipStreamSynchronize(m->stream));
+            ORBX_HIP(hipMemcpy(sc.data(), m->d_sc, sizeof(CgScal) * m->nmesh, hipMemcpyDeviceToHost));
+            bool all = true;
+            for (int i = 0; i < m->nmesh; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb));
+            if (all) break;
+        }
+        const int n = iters - done < 25 ? iters - done : 25;
+        for (int i = 0; i < n; ++i) launch_iter(m, m->stream);
+        done += n;
+    }
+    ORBX_HIP(hipGetLastError());
+    if (iters_done) *iters_done = done;
+    return fem_cg_result(m, x, relres);
+}
+
+int fem_profile_enable(fem_model *m, int on)
+{
+    if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
+    m->prof.reset();
+    m->prof.on = on != 0;
+    return ORBX_OK;
+}
+
+int fem_profile_read(fem_model *m, int max_kinds, const char **names, double *total_ms, int64_t *launches, int *nkinds)
+{
+    if (!m || !nkinds) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
+    m->prof.flush();
+    int n = 0;
+    for (int i = 0; i < orbx::KernelProfiler::MAXK && n < max_kinds; ++i) {
+        if (!m->prof.names[i]) continue;
+        if (names) names[n] = m->prof.names[i];
+        if (total_ms) total_ms[n] = m->prof.ms[i];
+        if (launches) launches[n] = m->prof.launches[i];
+        ++n;
+    }
+    *nkinds = n;
+    return ORBX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,168 @@
+"""Host-side mirror of the FEM core of FEA2 over the C-ABI (ctypes).
+
+Names follow Thirdparty/g2o/g2o/FEA/include/FEA2.h: the constructor takes the
+material constants of FEA2::FEA2 (E unsigned, nu, h, fg, nElType) and the methods
+are the reference's (SetSecondLayer, MatrixAssembly, ImposeDirichletEncastre_K,
+ComputeDisplacement, ComputeForces, ComputeStrainEnergy, NormalizeStrainEnergy),
+plus the CG solve that fills the slot of the dead InvertMatrixEigen path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+FEM_C3D8, FEM_C3D6, FEM_TET4 = 1, 2, 4
+_NPE = {FEM_C3D8: 8, FEM_C3D6: 6, FEM_TET4: 4}
+_BOUND = False
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _bind(L):
+    global _BOUND
+    if _BOUND:
+        return
+    L.fem_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_float,
+                             C.c_float, C.c_void_p]
+    L.fem_second_layer.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.fem_dirichlet_penalty.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    L.fem_dirichlet_eliminate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.fem_displacement.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.fem_cg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    L.fem_cg_iterate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.fem_spmv_repeat.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    for n in ("fem_destroy", "fem_assemble"):
+        getattr(L, n).argtypes = [C.c_void_p]
+    _BOUND = True
+
+
+def second_layer(top, h):
+    """FEA2::SetSecondLayer: nodes = top || top - (h,h,h)."""
+    L = lib(); _bind(L)
+    top = np.ascontiguousarray(top, np.float32)
+    out = np.zeros((2 * len(top), 3), np.float32)
+    check(L.fem_second_layer(_p(top), len(top), h, _p(out)))
+    return out
+
+
+def extrude_elems(faces, ntop):
+    """Element node ids as MatrixAssemblyC3D8/6 forms them (FEA2.cc:1392-1399,
+    :1518-1523): top ids || top ids + nTop."""
+    faces = np.asarray(faces, np.int32)
+    return np.ascontiguousarray(np.concatenate([faces, faces + ntop], axis=1), np.int32)
+
+
+class FEA2:
+    def __init__(self, nodes, elems, nElType, E=3500, nu=0.495, fg=0.577350269):
+        """nodes: [nn,3] or [nmesh,nn,3] float32; elems: [ne,npe] int32."""
+        self._L = lib(); _bind(self._L)
+        nodes = np.ascontiguousarray(nodes, np.float32)
+        if nodes.ndim == 2:
+            nodes = nodes[None]
+        self.nmesh, self.nn = nodes.shape[0], nodes.shape[1]
+        elems = np.ascontiguousarray(elems, np.int32).reshape(-1, _NPE[nElType])
+        self.ne, self.npe, self.nElType = len(elems), _NPE[nElType], nElType
+        self._h = C.c_void_p()
+        check(self._L.fem_create(nElType, _p(nodes), self.nmesh, self.nn, _p(elems), self.ne, int(E), nu, fg,
+                                 C.byref(self._h)))
+        nm, nd, nnz = C.c_int(), C.c_int(), C.c_int64()
+        check(self._L.fem_sizes(self._h, C.byref(nm), C.byref(nd), C.byref(nnz)))
+        self.Ksize, self.nnz = nd.value, nnz.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.fem_destroy(h)
+            self._h = None
+
+    def material(self):
+        lam, G = C.c_float(), C.c_float()
+        D = np.zeros(36, np.float32)
+        check(self._L.fem_material(self._h, C.byref(lam), C.byref(G), _p(D)))
+        return lam.value, G.value, D.reshape(6, 6)
+
+    def MatrixAssembly(self):
+        check(self._L.fem_assemble(self._h))
+
+    def ImposeDirichletEncastre_K(self, ids, Klarge=100000000.0):
+        ids = np.ascontiguousarray(ids, np.int32)
+        check(self._L.fem_dirichlet_penalty(self._h, _p(ids), len(ids), Klarge))
+
+    def eliminate_dofs(self, dofs):
+        dofs = np.ascontiguousarray(dofs, np.int32)
+        check(self._L.fem_dirichlet_eliminate(self._h, _p(dofs), len(dofs)))
+
+    def Kei(self, elem, mesh=0):
+        nd = 3 * self.npe
+        out = np.zeros((nd, nd), np.float32)
+        check(self._L.fem_get_ke(self._h, mesh, elem, _p(out)))
+        return out
+
+    def csr(self, mesh=0):
+        rp = np.zeros(self.Ksize + 1, np.int32); col = np.zeros(self.nnz, np.int32); val = np.zeros(self.nnz, np.float32)
+        check(self._L.fem_get_csr(self._h, mesh, _p(rp), _p(col), _p(val)))
+        return rp, col, val
+
+    def K_dense(self, mesh=0):
+        rp, col, val = self.csr(mesh)
+        K = np.zeros((self.Ksize, self.Ksize), np.float32)
+        rows = np.repeat(np.arange(self.Ksize), np.diff(rp))
+        K[rows, col] = val
+        return K
+
+    def _vec(self, a, dtype):
+        a = np.ascontiguousarray(a, dtype).reshape(self.nmesh, self.Ksize)
+        return a
+
+    def ComputeDisplacement(self, uf, u0, ids, Klarge=100000000.0):
+        uf = self._vec(uf, np.float32); u0 = self._vec(u0, np.float32)
+        ids = np.ascontiguousarray(ids, np.int32)
+        a = np.zeros_like(uf)
+        check(self._L.fem_displacement(self._h, _p(uf), _p(u0), _p(ids), len(ids), Klarge, _p(a)))
+        return a
+
+    def ComputeForces(self, a):
+        a = self._vec(a, np.float32)
+        f = np.zeros_like(a)
+        check(self._L.fem_matvec(self._h, _p(a), _p(f)))
+        return f
+
+    def ComputeStrainEnergy(self, a):
+        """Returns (sE, nsE) per mesh: |a^T K a| and sE / int(Ksize/3)."""
+        a = self._vec(a, np.float32)
+        sE = np.zeros(self.nmesh, np.float32); nsE = np.zeros(self.nmesh, np.float32)
+        check(self._L.fem_strain_energy(self._h, _p(a), _p(sE), _p(nsE)))
+        return sE, nsE
+
+    def solve_cg(self, b, iters=200, tol=0.0):
+        b = self._vec(b, np.float64)
+        x = np.zeros_like(b); rel = np.zeros(self.nmesh, np.float64); done = C.c_int(0)
+        check(self._L.fem_cg(self._h, _p(b), _p(x), iters, tol, C.byref(done), _p(rel)))
+        return x, done.value, rel
+
+    # resident / timing API
+    def cg_setup(self, b):
+        b = self._vec(b, np.float64)
+        check(self._L.fem_cg_setup(self._h, _p(b)))
+
+    def cg_iterate(self, n, stream=None):
+        check(self._L.fem_cg_iterate(self._h, n, C.c_void_p(stream) if stream else None))
+
+    def spmv_repeat(self, n, stream=None):
+        check(self._L.fem_spmv_repeat(self._h, n, C.c_void_p(stream) if stream else None))
+
+    def cg_result(self):
+        x = np.zeros((self.nmesh, self.Ksize), np.float64); rel = np.zeros(self.nmesh, np.float64)
+        check(self._L.fem_cg_result(self._h, _p(x), _p(rel)))
+        return x, rel
+
+    def profile(self, on):
+        check(self._L.fem_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); ln = (C.c_int64 * 16)(); nk = C.c_int(0)
+        check(self._L.fem_profile_read(self._h, 16, names, ms, ln, C.byref(nk)))
+        return {names[i].decode(): (ms[i], ln[i]) for i in range(nk.value)}

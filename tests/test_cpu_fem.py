@@ -1,0 +1,141 @@
+"""CPU-only known-answer tests pinning the FEM oracle from first principles
+(the reference holds no golden vectors: SURVEY F2)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+UNIT_HEX = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1],
+                     [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float32)
+
+
+def test_material_constants_match_survey():
+    lam, G, D = oracle.fem_material(3500, 0.495)
+    assert abs(lam - 115886.398438) < 0.02 and abs(G - 1170.568604) < 1e-3
+    D = D.reshape(6, 6)
+    assert D[0, 0] == np.float32(lam) + 2 * np.float32(G) and D[3, 3] == np.float32(G) and D[0, 3] == 0
+
+
+@pytest.mark.parametrize("eltype,P", [
+    (1, UNIT_HEX * np.float32(0.5)),
+    (1, UNIT_HEX * np.array([0.7, 0.4, 0.9], np.float32) + np.float32(0.3)),
+    (2, np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1], [0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)),
+    (4, np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)),
+    (4, np.array([[0.1, 0, 0.2], [1.3, 0.1, 0], [0, 0.9, 0.1], [0.2, 0.3, 1.1]], np.float32)),
+])
+def test_ke_symmetric_and_translation_nullspace(eltype, P):
+    Ke = oracle.fem_ke(eltype, P).astype(np.float64)
+    scale = np.abs(Ke).max()
+    assert np.abs(Ke - Ke.T).max() < 2e-5 * scale
+    for d in range(3):                       # rigid translation produces no force
+        t = np.zeros(Ke.shape[0]); t[d::3] = 1
+        assert np.abs(Ke @ t).max() < 1e-4 * scale
+
+
+def test_tet4_is_spd_on_its_range_and_scales_with_size():
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    K1 = oracle.fem_ke(4, P).astype(np.float64)
+    w = np.linalg.eigvalsh((K1 + K1.T) / 2)
+    assert (w > -1e-6 * w.max()).all() and (w > 1e-6 * w.max()).sum() == 6     # 12 dofs - 6 rigid modes
+    K2 = oracle.fem_ke(4, P * np.float32(2)).astype(np.float64)
+    assert np.allclose(K2, 2 * K1, rtol=1e-5)                                   # K ~ length in 3-D
+
+
+def test_tet4_orientation_independent():
+    P = np.array([[0.1, 0, 0.2], [1.3, 0.1, 0], [0, 0.9, 0.1], [0.2, 0.3, 1.1]], np.float32)
+    K = oracle.fem_ke(4, P).astype(np.float64)
+    Pm = P[[0, 2, 1, 3]]                                                        # mirrored numbering
+    Km = oracle.fem_ke(4, Pm).astype(np.float64)
+    perm = np.concatenate([[3 * i, 3 * i + 1, 3 * i + 2] for i in (0, 2, 1, 3)])
+    assert np.allclose(Km, K[np.ix_(perm, perm)], rtol=1e-4, atol=1e-3)
+
+
+def test_c3d8_equals_mirrored_textbook_on_axis_aligned_box():
+    """On an axis-aligned box J is diagonal, so of the reference's three sign
+    deviations J1_02 vanishes while J1_11 and J1_22 negate the
+    y- and z-gradients: K_ref = S K_textbook S with S = diag(1,-1,-1) per node.
+    Checked against an independent float64 textbook hexahedron."""
+    P = (UNIT_HEX * np.array([0.7, 0.4, 0.9], np.float32)).astype(np.float32)
+    lam, G, D = oracle.fem_material(3500, 0.495)
+    D = D.reshape(6, 6).astype(np.float64)
+    g = 0.577350269
+    sg = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+    K = np.zeros((24, 24))
+    for xi, eta, zeta in sg * g:
+        dN = np.array([[sx * (1 + sy * eta) * (1 + sz * zeta), sy * (1 + sx * xi) * (1 + sz * zeta),
+                        sz * (1 + sx * xi) * (1 + sy * eta)] for sx, sy, sz in sg]) / 8
+        J = dN.T @ P.astype(np.float64)
+        dNx = dN @ np.linalg.inv(J).T
+        B = np.zeros((6, 24))
+        for n in range(8):
+            gx, gy, gz = dNx[n]
+            B[:, 3 * n:3 * n + 3] = [[gx, 0, 0], [0, gy, 0], [0, 0, gz], [gy, gx, 0], [gz, 0, gx], [0, gz, gy]]
+        K += B.T @ D @ B * np.linalg.det(J)
+    Ke = oracle.fem_ke(1, P).astype(np.float64)
+    S = np.tile([1.0, -1.0, -1.0], 8)
+    assert np.abs(Ke - S[:, None] * K * S[None, :]).max() < 1e-5 * np.abs(K).max()
+    assert np.abs(Ke - K).max() > 0.1 * np.abs(K).max()          # and it is NOT the textbook matrix
+
+
+def test_second_layer_and_dirichlet_off_by_one():
+    top = np.arange(12, dtype=np.float32).reshape(4, 3)
+    nodes = oracle.fem_second_layer(top, 0.5)
+    assert np.array_equal(nodes[:4], top) and np.array_equal(nodes[4:], top - np.float32(0.5))
+    K = np.zeros((24, 24), np.float32)
+    oracle.fem_dirichlet_K(K, [4, 5, 6, 7])                      # vvDir = nTop + i (FEA2.cc:1198)
+    d = np.diag(K)
+    assert (d[9:21] == 1e8).all() and (d[:9] == 0).all() and (d[21:] == 0).all()   # pins nodes 3..6 (App. C5)
+
+
+def clean_tris(top, tris):
+    """Drop triangles with coincident vertices (the raw GP3 dumps contain
+    duplicated points and repeated indices; the reference's K_e divides by a zero
+    Jacobian for them and yields NaN)."""
+    p = top[tris]
+    ok = ~((p[:, 0] == p[:, 1]).all(1) | (p[:, 0] == p[:, 2]).all(1) | (p[:, 1] == p[:, 2]).all(1))
+    return tris[ok]
+
+
+def test_raw_fixture_degenerate_triangles_give_nan_like_the_reference_would():
+    m = np.load(os.path.join(GOLD, "fem_mesh_median.npz"))
+    top, tris = m["points"], m["triangles"]
+    assert 0 < len(tris) - len(clean_tris(top, tris)) <= 4
+    nodes = oracle.fem_second_layer(top, 0.5)
+    bad = tris[109]                                               # (21, 71, 21): repeated index
+    Ke = oracle.fem_ke(2, nodes[np.concatenate([bad, bad + len(top)])])
+    assert np.isnan(Ke).any()
+
+
+def test_dense_assembly_fixture_symmetric_and_energy_nonnegative_abs():
+    m = np.load(os.path.join(GOLD, "fem_mesh_median.npz"))
+    top, tris = m["points"], m["triangles"]
+    tris = clean_tris(top, tris)
+    nodes = oracle.fem_second_layer(top, 0.5)
+    elems = np.concatenate([tris, tris + len(top)], 1).astype(np.int32)
+    K = oracle.fem_assemble_dense(2, nodes, elems)
+    assert K.shape == (570, 570)                                 # SURVEY: Ksize = 6 * pts = 570 (median)
+    assert np.abs(K - K.T).max() <= 1e-3 * np.abs(K).max()
+    rng = np.random.default_rng(0)
+    a = rng.normal(0, 1e-3, 570).astype(np.float32)
+    f = oracle.fem_matvec_dense(K, a)
+    sE, nsE = oracle.fem_strain_energy(a, f)
+    assert sE >= 0 and abs(nsE - sE / 190) <= 1e-6 * max(sE, 1)
+
+
+def test_cg_solves_spd_tet_problem():
+    from orb_slam2_e_amd.synth import synth_tet_mesh
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=3)
+    K = oracle.fem_assemble_dense(4, nodes, tets)
+    rp, col, val = oracle.fem_dense_to_csr(K)
+    mask = np.zeros(len(K), np.uint8); mask[fixed] = 1
+    oracle.fem_csr_eliminate(rp, col, val, mask)
+    b = load.copy(); b[fixed] = 0
+    x, it, rel = oracle.fem_cg(rp, col, val, b, 5000, 1e-12)
+    assert rel <= 1e-12 and it < 5000
+    r = b - oracle.fem_csr_matvec(rp, col, val, x)
+    assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b)
+    assert x[2::3].max() > 0 and np.abs(x[fixed]).max() == 0     # pulled up, clamped at z=0
