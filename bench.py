@@ -59,6 +59,66 @@ def cpu_baseline(nframes=12):
             "sample": f"{nframes} synthetic 640x480 frames: oracle extract + 2000x2000 match each, 1 thread, {dt:.1f} s"}
 
 
+def fem_bench(rank, world, dist, torch, dev, nmesh=256, iters=200, cpu=True):
+    """Config 3 (10,368-tet / 6,591-dof mesh, E=3500, nu=0.495): assemble K + 200
+    CG iterations, single mesh and a batch of `nmesh` distinct matrices per GPU."""
+    from orb_slam2_e_amd.fem import FEA2, FEM_TET4
+    from orb_slam2_e_amd.synth import synth_tet_batch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    out = {}
+    for label, nm in (("single", 1), ("batch", nmesh)):
+        nodes, tets, fixed, load = synth_tet_batch(nm, 12, seed=11 + 7919 * rank)
+        fea = FEA2(nodes, tets, FEM_TET4)
+        fea.profile(True)
+        t0 = time.perf_counter(); fea.MatrixAssembly(); t_asm = time.perf_counter() - t0
+        fea.eliminate_dofs(fixed)
+        b = np.tile(load, (nm, 1)); b[:, fixed] = 0
+        fea.cg_setup(b)
+        fea.cg_iterate(5); fea.cg_result()            # warm
+        fea.cg_setup(b)
+        fea.profile(True)
+        barrier()
+        t0 = time.perf_counter()
+        fea.cg_iterate(iters)
+        x, rel = fea.cg_result()                       # synchronises
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        prof = fea.profile_read()
+        n, nnz = fea.Ksize, fea.nnz
+        spmv_ms = prof["k_fem_spmv"][0] / max(prof["k_fem_spmv"][1], 1)
+        spmv_bytes = nm * (nnz * 8 + (n + 1) * 4 + 2 * n * 8)      # SURVEY 8d: nnz(val+4)+(n+1)4+2n*val', f32 K, f64 x/y
+        iter_bytes = spmv_bytes + nm * (2 * 2 + 3 * 3) * n * 8
+        out[label] = {"meshes_per_gpu": nm, "n_dof": n, "nnz": nnz, "cg_iters": iters,
+                      "cg_mesh_iters_per_s": world * nm * iters / dt, "ms_per_iter": dt / iters * 1e3,
+                      "assemble_ms": t_asm * 1e3, "relres_after": float(rel.max()),
+                      "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes,
+                      "spmv_GBps": spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+                      "cg_iter_GBps": iter_bytes * iters / dt / 1e9,
+                      "kernel_ms_per_iter": {k: v[0] / iters for k, v in prof.items() if v[1]}}
+        if label == "single" and cpu and rank == 0:
+            import oracle
+            rp, col, val = fea.csr()
+            t0 = time.perf_counter()
+            oracle.fem_cg(rp, col, val, b[0], iters, 0.0)
+            out["cpu_baseline"] = {"value": iters / (time.perf_counter() - t0), "unit": "CG iters/s", "cores": 1,
+                                   "kind": "port", "sample": f"oracle Jacobi-PCG, {iters} iterations on the single 6,591-dof mesh"}
+        del fea
+    bt = out["batch"]
+    out["roofline"] = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +126,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-fem", action="store_true")
+    ap.add_argument("--fem-meshes", type=int, default=256)
     args = ap.parse_args()
 
     import torch
@@ -159,6 +221,10 @@ def main():
     L.orbx_profile_enable(ex._h, 0)
     L.orbm_profile_enable(0)
 
+    fem = None
+    if not args.no_fem:
+        fem = fem_bench(rank, world, dist, torch, dev, nmesh=args.fem_meshes, cpu=not args.no_cpu_baseline)
+
     if rank == 0:
         total_frames = world * BATCH * args.steps
         value = total_frames / dt
@@ -188,6 +254,8 @@ def main():
             "pipeline_hbm_frac": value / world * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
             "kernel_ms_per_step": per_step_ms,
         }
+        if fem is not None:
+            out["fem"] = fem
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

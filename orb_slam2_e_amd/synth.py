@@ -46,44 +46,47 @@ def synth_descriptors(n=2000, seed=7, flip_p=0.08, n_replace=200):
     return A, np.ascontiguousarray(B), perm
 
 
+def _tet_grid(ncell):
+    n1 = ncell + 1
+    g = np.arange(n1, dtype=np.float64)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    nodes = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    # Kuhn split: 6 tets per cube along the main diagonal (0,0,0)-(1,1,1)
+    perms = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
+    I, J, K = np.meshgrid(np.arange(ncell), np.arange(ncell), np.arange(ncell), indexing="ij")
+    base = np.stack([I.ravel(), J.ravel(), K.ravel()], 1)                    # [ncell^3, 3]
+    tets = np.zeros((len(base), 6, 4), np.int64)
+    for t, pm in enumerate(perms):
+        cur = base.copy()
+        tets[:, t, 0] = (cur[:, 0] * n1 + cur[:, 1]) * n1 + cur[:, 2]
+        for v, ax in enumerate(pm):
+            cur = cur.copy(); cur[:, ax] += 1
+            tets[:, t, v + 1] = (cur[:, 0] * n1 + cur[:, 1]) * n1 + cur[:, 2]
+    tets = tets.reshape(-1, 4)
+    p = nodes[tets]
+    det = np.einsum("ij,ij->i", p[:, 1] - p[:, 0], np.cross(p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]))
+    neg = det < 0
+    tets[neg, 2], tets[neg, 3] = tets[neg, 3].copy(), tets[neg, 2].copy()
+    return nodes, tets
+
+
 def synth_tet_mesh(ncell=12, seed=11, jitter=0.1):
     """Config-3 mesh: ncell^3 unit cubes, each split into 6 tets (Kuhn),
     node jitter U[-jitter,jitter]*spacing on interior nodes; 12 -> 10,368 tets,
     2,197 nodes, 6,591 dofs.  Returns nodes[nn,3] f32, tets[ne,4] i32 (positively
     oriented), fixed dofs (z=0 face), load vector (unit traction on z=max face)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    n1 = ncell + 1
-    g = np.arange(n1, dtype=np.float64)
-    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
-    nodes = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    nodes, tets = _tet_grid(ncell)
     interior = ((nodes > 0) & (nodes < ncell)).all(1)
-    nodes[interior] += rng.uniform(-jitter, jitter, size=(int(interior.sum()), 3))
-    nid = lambda i, j, k: (i * n1 + j) * n1 + k
-    # Kuhn split: 6 tets per cube along the main diagonal (0,0,0)-(1,1,1)
-    perms = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
-    tets = []
-    for i in range(ncell):
-        for j in range(ncell):
-            for k in range(ncell):
-                base = np.array([i, j, k])
-                for pm in perms:
-                    v = [base.copy()]
-                    cur = base.copy()
-                    for ax in pm:
-                        cur = cur.copy(); cur[ax] += 1
-                        v.append(cur)
-                    tets.append([nid(*p) for p in v])
-    tets = np.array(tets, np.int64)
-    p = nodes[tets]
-    det = np.einsum("ij,ij->i", p[:, 1] - p[:, 0], np.cross(p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]))
-    neg = det < 0
-    tets[neg, 2], tets[neg, 3] = tets[neg, 3].copy(), tets[neg, 2].copy()
+    ij = nodes[:, :2].copy()
+    ztop = nodes[:, 2] == ncell
     fixed_nodes = np.where(nodes[:, 2] == 0)[0]
+    nodes[interior] += rng.uniform(-jitter, jitter, size=(int(interior.sum()), 3))
     fixed = (3 * fixed_nodes[:, None] + np.arange(3)[None]).ravel()
     load = np.zeros(3 * len(nodes))
-    top = np.where(nodes[:, 2] == ncell)[0]
-    ij = nodes[top, :2]
-    wgt = np.where((ij[:, 0] == 0) | (ij[:, 0] == ncell), 0.5, 1.0) * np.where((ij[:, 1] == 0) | (ij[:, 1] == ncell), 0.5, 1.0)
+    top = np.where(ztop)[0]
+    wgt = np.where((ij[top, 0] == 0) | (ij[top, 0] == ncell), 0.5, 1.0) * \
+        np.where((ij[top, 1] == 0) | (ij[top, 1] == ncell), 0.5, 1.0)
     load[3 * top + 2] = wgt  # unit traction x tributary area
     return nodes.astype(np.float32), tets.astype(np.int32), fixed.astype(np.int32), load
 
