@@ -1,0 +1,223 @@
+// orbslam_hip.hpp -- C++ host classes over the C-ABI (header only).
+//
+// Same names, constructor arguments, getters and call semantics as the
+// reference's classes (include/ORBextractor.h:46-112, include/ORBmatcher.h:37-111,
+// Thirdparty/g2o/g2o/FEA/include/FEA2.h:94-304), with plain views instead of
+// cv::Mat / std::vector<cv::KeyPoint> so the header needs no OpenCV.
+// INTEGRATION.md shows the few lines that bind these to the cv:: signatures so
+// that Tracking.cc / Frame.cc link unchanged.  Like the reference, nothing here
+// throws; `status()` reports the last C-ABI status code.
+#ifndef ORBSLAM_HIP_HPP
+#define ORBSLAM_HIP_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "fem_hip.h"
+#include "orbslam_hip.h"
+
+namespace orbslam_hip {
+
+// A CV_8UC1 image view: what cv::Mat::data / cols / rows / step carry.
+struct ImageView {
+    const uint8_t *data = nullptr;
+    int cols = 0, rows = 0, step = 0;
+    bool empty() const { return !data || cols <= 0 || rows <= 0; }
+};
+
+// One pyramid level on the host (mvImagePyramid[level]).
+struct HostImage {
+    std::vector<uint8_t> pixels;
+    int cols = 0, rows = 0;
+    ImageView view() const { return ImageView{pixels.data(), cols, rows, cols}; }
+};
+
+typedef orbx_keypoint KeyPoint; // 28-byte cv::KeyPoint layout
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 }; // ORBextractor.h:50
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+    {
+        orbx_params p = {nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, 0};
+        mStatus = orbx_create(&p, &mHandle);
+        if (mStatus == ORBX_OK) {
+            mnLevels = nlevels;
+            mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
+            mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+            orbx_get_scale_factors(mHandle, mvScaleFactor.data());
+            orbx_get_inv_scale_factors(mHandle, mvInvScaleFactor.data());
+            orbx_get_level_sigma2(mHandle, mvLevelSigma2.data());
+            orbx_get_inv_level_sigma2(mHandle, mvInvLevelSigma2.data());
+            mvImagePyramid.resize(nlevels);
+        }
+    }
+    ~ORBextractor() { orbx_destroy(mHandle); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+
+    // Compute the ORB features and descriptors on an image; the mask is ignored
+    // (ORBextractor.cc:1051-1113).  descriptors: n rows of 32 bytes.
+    void operator()(const ImageView &image, const ImageView & /*mask*/, std::vector<KeyPoint> &keypoints,
+                    std::vector<uint8_t> &descriptors)
+    {
+        if (image.empty()) return; // :1054-1055: outputs untouched
+        const int cap = orbx_keypoint_capacity(mHandle);
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        mStatus = orbx_extract(mHandle, image.data, image.cols, image.rows, image.step, keypoints.data(),
+                               descriptors.data(), cap, &n);
+        if (mStatus != ORBX_OK) n = 0;
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32); // n == 0: descriptors.release() (:1072-1073)
+        mPyramidStale = true;
+    }
+
+    int GetLevels() const { return mnLevels; }
+    float GetScaleFactor() const { return mnLevels > 1 ? mvScaleFactor[1] : 1.0f; }
+    std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() const { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() const { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return mvInvLevelSigma2; }
+
+    // Public in the reference (ORBextractor.h:86) and read by
+    // Frame::ComputeStereoMatches: call SyncImagePyramid() before reading it.
+    std::vector<HostImage> mvImagePyramid;
+    void SyncImagePyramid()
+    {
+        if (!mPyramidStale) return;
+        for (int l = 0; l < mnLevels; ++l) {
+            int w = 0, h = 0;
+            if (orbx_level_size(mHandle, l, &w, &h) != ORBX_OK) return;
+            HostImage &im = mvImagePyramid[l];
+            im.cols = w; im.rows = h; im.pixels.resize((size_t)w * h);
+            mStatus = orbx_pyramid_level(mHandle, 0, l, im.pixels.data(), w);
+        }
+        mPyramidStale = false;
+    }
+
+    int status() const { return mStatus; }
+    orbx_extractor *handle() { return mHandle; }
+
+private:
+    orbx_extractor *mHandle = nullptr;
+    int mnLevels = 0, mStatus = ORBX_OK;
+    bool mPyramidStale = true;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+class ORBmatcher {
+public:
+    static const int TH_LOW = 45, TH_HIGH = 95, TH_RELOC = 60, HISTO_LENGTH = 30; // ORBmatcher.cc:37-40
+
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    // ORBmatcher::DescriptorDistance(a, b), a/b = 32-byte rows.
+    static int DescriptorDistance(const uint8_t *a, const uint8_t *b)
+    {
+        uint16_t d = 0;
+        return orbm_hamming_matrix(a, 1, b, 1, &d) == ORBX_OK ? (int)d : -1;
+    }
+
+    // The selection loop of every Search* function over gated candidates
+    // (candidate order = GetFeaturesInArea / BoW-member order), then the
+    // acceptance test bestDist<=th && bestDist<bestDist2*mfNNratio.
+    // Returns the number of accepted matches; vnMatches12[i] = index in B or -1.
+    int MatchCandidates(const uint8_t *A, int nA, const uint8_t *B, int nB, const std::vector<int32_t> &candOff,
+                        const std::vector<int32_t> &candIdx, int th, std::vector<int32_t> &vnMatches12,
+                        std::vector<int32_t> *bestDist = nullptr)
+    {
+        std::vector<int32_t> best(nA), second(nA), idx(nA);
+        vnMatches12.assign(nA, -1);
+        if (orbm_match_candidates(A, nA, B, nB, candOff.data(), candIdx.data(), best.data(), second.data(), idx.data()) != ORBX_OK)
+            return 0;
+        int n = 0;
+        orbm_match_filter(nA, best.data(), second.data(), idx.data(), th, mfNNratio, vnMatches12.data(), &n);
+        if (bestDist) *bestDist = best;
+        return n;
+    }
+
+    int MatchBruteForce(const uint8_t *A, int nA, const uint8_t *B, int nB, int th, std::vector<int32_t> &vnMatches12)
+    {
+        std::vector<int32_t> best(nA), second(nA), idx(nA);
+        vnMatches12.assign(nA, -1);
+        if (orbm_match_bruteforce(A, nA, B, nB, best.data(), second.data(), idx.data()) != ORBX_OK) return 0;
+        int n = 0;
+        orbm_match_filter(nA, best.data(), second.data(), idx.data(), th, mfNNratio, vnMatches12.data(), &n);
+        return n;
+    }
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+// Numeric core of FEA2: the members and methods g2o and Optimizer touch
+// (FEA2.h: K-size, vva, vvf, sE, nsE; Set/Compute* calls at
+// optimization_algorithm_levenberg.cpp:159-199).
+class FEA2 {
+public:
+    FEA2(unsigned int input_E, float input_nu, float input_h, float input_fg1, int input_nElType)
+        : E(input_E), nu(input_nu), h(input_h), fg(input_fg1), nElType(input_nElType) {}
+    ~FEA2() { fem_destroy(mModel); }
+    FEA2(const FEA2 &) = delete;
+    FEA2 &operator=(const FEA2 &) = delete;
+
+    // SetSecondLayer + Set_u0 + MatrixAssemblyC3D8/6 + ImposeDirichletEncastre_K
+    // (the numeric half of FEA2::Compute(1), FEA2.cc:92-103) for a top-layer mesh:
+    // faces = triangles (nElType 2) or quads (nElType 1).
+    bool Compute(const std::vector<float> &topXYZ, const std::vector<int32_t> &faces)
+    {
+        const int nTop = (int)topXYZ.size() / 3, nv = nElType == 1 ? 4 : 3, nf = (int)faces.size() / nv;
+        std::vector<float> nodes((size_t)6 * nTop);
+        fem_second_layer(topXYZ.data(), nTop, h, nodes.data());
+        u0 = nodes;
+        std::vector<int32_t> elems((size_t)nf * 2 * nv);
+        for (int f = 0; f < nf; ++f)
+            for (int k = 0; k < nv; ++k) {
+                elems[(size_t)f * 2 * nv + k] = faces[(size_t)f * nv + k];
+                elems[(size_t)f * 2 * nv + nv + k] = faces[(size_t)f * nv + k] + nTop; // FEA2.cc:1392-1399
+            }
+        fem_destroy(mModel);
+        mModel = nullptr;
+        mStatus = fem_create(nElType == 1 ? FEM_C3D8 : FEM_C3D6, nodes.data(), 1, 2 * nTop, elems.data(), nf, E, nu, fg, &mModel);
+        if (mStatus != ORBX_OK) return false; // Ksize<=3: assembly refuses (:1386)
+        Ksize = 6 * nTop;
+        vDir.resize(nTop);
+        for (int i = 0; i < nTop; ++i) vDir[i] = nTop + i; // vvDir_t, :1198
+        if ((mStatus = fem_assemble(mModel)) != ORBX_OK) return false;
+        mStatus = fem_dirichlet_penalty(mModel, vDir.data(), nTop, 100000000.0f);
+        return mStatus == ORBX_OK;
+    }
+
+    // Set_uf (top layer moved, bottom layer kept) + ComputeDisplacement (:1732-1808)
+    void ComputeDisplacement(const std::vector<float> &topXYZ_new)
+    {
+        std::vector<float> uf = u0;
+        std::memcpy(uf.data(), topXYZ_new.data(), sizeof(float) * topXYZ_new.size());
+        vva.resize(Ksize);
+        mStatus = fem_displacement(mModel, uf.data(), u0.data(), vDir.data(), (int)vDir.size(), 100000000.0f, vva.data());
+    }
+    void ComputeForces() { vvf.resize(Ksize); mStatus = fem_matvec(mModel, vva.data(), vvf.data()); }
+    float ComputeStrainEnergy() { mStatus = fem_strain_energy(mModel, vva.data(), &sE, &nsE); return sE; }
+    float NormalizeStrainEnergy() const { return nsE; }
+
+    unsigned int E;
+    float nu, h, fg;
+    int nElType, Ksize = 0;
+    float sE = 0.f, nsE = 0.f;
+    std::vector<float> u0, vva, vvf;
+    std::vector<int32_t> vDir;
+    int status() const { return mStatus; }
+    fem_model *model() { return mModel; }
+
+private:
+    fem_model *mModel = nullptr;
+    int mStatus = ORBX_OK;
+};
+
+} // namespace orbslam_hip
+#endif // ORBSLAM_HIP_HPP

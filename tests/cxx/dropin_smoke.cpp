@@ -1,0 +1,80 @@
+// C++ host-side smoke test of include/orbslam_hip.hpp (built and run by
+// tests/test_cxx_host.py).  argv[1] = "nodevice": expect ORBX_ERR_NO_DEVICE.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "orbslam_hip.hpp"
+
+using namespace orbslam_hip;
+
+static int popcount_row(const uint8_t *a, const uint8_t *b)
+{
+    int d = 0;
+    for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+}
+
+int main(int argc, char **argv)
+{
+    const bool nodevice = argc > 1 && !strcmp(argv[1], "nodevice");
+    const int W = 640, H = 480;
+    std::vector<uint8_t> img((size_t)W * H);
+    unsigned s = 12345;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            s = s * 1664525u + 1013904223u;
+            const int checker = (((x / 24) + (y / 24)) & 1) ? 200 : 60;
+            img[(size_t)y * W + x] = (uint8_t)(checker + (int)((s >> 24) % 9) - 4);
+        }
+    ORBextractor ex(1000, 1.2f, 8, 20, 7);
+    if (ex.status() != ORBX_OK || ex.GetLevels() != 8 || ex.GetScaleFactors().size() != 8) { printf("FAIL ctor\n"); return 1; }
+    std::vector<KeyPoint> kps, kps2;
+    std::vector<uint8_t> desc, desc2;
+    ex(ImageView{img.data(), W, H, W}, ImageView{}, kps, desc);
+    if (nodevice) {
+        if (ex.status() != ORBX_ERR_NO_DEVICE || !kps.empty()) { printf("FAIL expected ORBX_ERR_NO_DEVICE, got %d\n", ex.status()); return 1; }
+        printf("OK nodevice: %s\n", orbx_last_error());
+        return 0;
+    }
+    if (ex.status() != ORBX_OK || kps.size() < 500 || desc.size() != kps.size() * 32) { printf("FAIL extract %d n=%zu\n", ex.status(), kps.size()); return 1; }
+    ex(ImageView{img.data(), W, H, W}, ImageView{}, kps2, desc2);
+    if (kps2.size() != kps.size() || memcmp(desc.data(), desc2.data(), desc.size())) { printf("FAIL determinism\n"); return 1; }
+    ex(ImageView{}, ImageView{}, kps2, desc2); // empty image: outputs untouched
+    if (kps2.size() != kps.size()) { printf("FAIL empty-image semantics\n"); return 1; }
+    ex.SyncImagePyramid();
+    if (ex.mvImagePyramid[0].cols != W || ex.mvImagePyramid[1].cols != 533 ||
+        memcmp(ex.mvImagePyramid[0].pixels.data(), img.data(), img.size())) { printf("FAIL pyramid\n"); return 1; }
+
+    ORBmatcher m(0.6f, true);
+    for (int i = 0; i < 10; ++i)
+        if (ORBmatcher::DescriptorDistance(&desc[32 * i], &desc[32 * (i + 7)]) != popcount_row(&desc[32 * i], &desc[32 * (i + 7)])) { printf("FAIL distance\n"); return 1; }
+    std::vector<int32_t> m12;
+    const int n = (int)kps.size();
+    const int nm = m.MatchBruteForce(desc.data(), n, desc.data(), n, ORBmatcher::TH_LOW, m12);
+    int self = 0;
+    for (int i = 0; i < n; ++i) self += m12[i] == i;
+    if (nm <= 0 || self < nm * 9 / 10) { printf("FAIL self-match nm=%d self=%d\n", nm, self); return 1; }
+
+    // FEA2: 3x3 patch of triangles, prism elements
+    std::vector<float> top;
+    std::vector<int32_t> tris;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { top.push_back((float)i); top.push_back((float)j); top.push_back(0.1f * i * j); }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int a = i * 4 + j, b = a + 4, c = a + 5, d = a + 1;
+            tris.insert(tris.end(), {a, b, c, a, c, d});
+        }
+    FEA2 fea(3500, 0.495f, 0.5f, 0.577350269f, 2);
+    if (!fea.Compute(top, tris) || fea.Ksize != 96) { printf("FAIL fea compute %d\n", fea.status()); return 1; }
+    std::vector<float> moved = top;
+    for (size_t i = 2; i < moved.size(); i += 3) moved[i] += 0.01f;
+    fea.ComputeDisplacement(moved);
+    fea.ComputeForces();
+    const float sE = fea.ComputeStrainEnergy();
+    if (!(sE > 0.f) || !(fea.NormalizeStrainEnergy() == sE / 32)) { printf("FAIL energy %g %g\n", sE, fea.NormalizeStrainEnergy()); return 1; }
+    printf("OK %d keypoints, %d self matches, sE=%g\n", n, nm, sE);
+    return 0;
+}
