@@ -4,10 +4,7 @@
 // DescriptorDistance (:1848-1864) as XOR + v_bcnt popcount on 256-bit rows, and
 // the best / second-best / arg-best selection every Search* function shares
 // (strict '<': first-seen candidate wins ties; second updated with 'else if').
-// This is bit-twiddling, not a contraction: no MFMA.  One query row per lane;
-// the B-side tile is staged in LDS and read as wave-uniform (broadcast) 128-bit
-// words, so LDS traffic is conflict-free and HBM sees each descriptor once per
-// workgroup.
+// This is bit-twiddling, not a contraction: no MFMA.
 #include <limits.h>
 #include <stdint.h>
 
@@ -15,8 +12,7 @@
 
 namespace {
 
-constexpr int MT = 256;   // threads per block = query rows per block
-constexpr int TILE = 256; // B descriptors staged per step (8 KiB)
+constexpr int MT = 256; // threads per block of the small helper kernels
 
 __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
 {
@@ -24,6 +20,7 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+// Sequential form used by the gated variant (candidate lists are short).
 __device__ __forceinline__ void select_update(int dist, int j, int &best, int &second, int &idx)
 {
     // if(dist<bestDist){bestDist2=bestDist;bestDist=dist;bestIdx=j;} else if(dist<bestDist2) bestDist2=dist;
@@ -34,47 +31,104 @@ __device__ __forceinline__ void select_update(int dist, int j, int &best, int &s
 }
 
 // Pair p: queries = set qa[p], candidates = all of set qb[p] in index order.
-__global__ __launch_bounds__(MT) void k_match_sets(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
-                                                   int cap, const int *__restrict__ qa, const int *__restrict__ qb,
-                                                   int th, float nnratio, int *__restrict__ best_o,
-                                                   int *__restrict__ second_o, int *__restrict__ idx_o,
-                                                   int *__restrict__ match12, int *__restrict__ nmatch)
+// Workgroup = 4 waves x 128 query rows: every lane keeps TWO query rows in VGPRs
+// (rows i and i+64 of the block), every wave scans one quarter of the candidates.
+// A wave stages its candidates 64 at a time in a private LDS buffer (one 32-byte
+// row per lane, double buffered, no workgroup barrier) and reads them back as
+// wave-uniform 128-bit broadcasts, each feeding two Hamming distances.  Per pair:
+// 8 v_xor + 8 v_bcnt + key pack + min/max.  key = dist<<16 | j keeps "strict <,
+// first index wins": the smallest key is the best match, the second smallest key
+// carries the second-best distance (= what the if / else-if chain of
+// ORBmatcher.cc:664-672 leaves in bestDist2).  The four partial (smallest, second
+// smallest) pairs are merged through LDS at the end.
+constexpr int MSEG = 4;   // waves per workgroup = candidate segments
+constexpr int MQ = 2;     // query rows per lane
+
+__device__ __forceinline__ void key_update(unsigned key, unsigned &k1, unsigned &k2)
 {
-    __shared__ uint4 tile[TILE * 2];
-    const int p = blockIdx.y, tid = threadIdx.x;
+    const unsigned hi = k1 > key ? k1 : key; // k1 <= k2 always: median(k1, key, k2) = new second smallest
+    k2 = k2 < hi ? k2 : hi;
+    k1 = k1 < key ? k1 : key;
+}
+
+__global__ __launch_bounds__(64 * MSEG) void k_match_sets(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
+                                                          int cap, const int *__restrict__ qa, const int *__restrict__ qb,
+                                                          int th, float nnratio, int *__restrict__ best_o,
+                                                          int *__restrict__ second_o, int *__restrict__ idx_o,
+                                                          int *__restrict__ match12, int *__restrict__ nmatch)
+{
+    __shared__ uint4 stage[MSEG][2][64 * 2];
+    __shared__ unsigned sk[MSEG][MQ][2][64];
+    const int p = blockIdx.y, lane = threadIdx.x, seg = threadIdx.y;
     const int sa = qa ? qa[p] : 0, sb = qb ? qb[p] : 1;
     const int nA = counts[sa] < cap ? counts[sa] : cap, nB = counts[sb] < cap ? counts[sb] : cap;
-    if (blockIdx.x * MT >= nA) return;
-    const int i = blockIdx.x * MT + tid;
+    const int row0 = blockIdx.x * 64 * MQ;
+    if (row0 >= nA) return;
     const uint4 *A = reinterpret_cast<const uint4 *>(desc + (size_t)sa * cap * 32);
     const uint4 *B = reinterpret_cast<const uint4 *>(desc + (size_t)sb * cap * 32);
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-    if (i < nA) { a0 = A[2 * i]; a1 = A[2 * i + 1]; }
-    int best = INT_MAX, second = INT_MAX, idx = -1;
-    for (int j0 = 0; j0 < nB; j0 += TILE) {
-        const int nt = nB - j0 < TILE ? nB - j0 : TILE;
-        __syncthreads();
-        for (int k = tid; k < nt * 2; k += MT) tile[k] = B[2 * j0 + k];
-        __syncthreads();
+    uint4 a[MQ][2];
+    unsigned k1[MQ], k2[MQ];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const int i = row0 + q * 64 + lane;
+        a[q][0] = a[q][1] = make_uint4(0, 0, 0, 0);
+        if (i < nA) { a[q][0] = A[2 * i]; a[q][1] = A[2 * i + 1]; }
+        k1[q] = k2[q] = 0xffffffffu;
+    }
+    const int per = (nB + MSEG - 1) / MSEG;
+    const int j0 = seg * per, j1 = j0 + per < nB ? j0 + per : nB;
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+    if (j0 + lane < j1) { n0 = B[2 * (j0 + lane)]; n1 = B[2 * (j0 + lane) + 1]; }
+    stage[seg][0][2 * lane] = n0;
+    stage[seg][0][2 * lane + 1] = n1;
+    int buf = 0;
+    for (int c0 = j0; c0 < j1; c0 += 64, buf ^= 1) {
+        const int nxt = c0 + 64 + lane;
+        if (nxt < j1) { n0 = B[2 * nxt]; n1 = B[2 * nxt + 1]; } // in flight during the scan below
+        const int nc = j1 - c0 < 64 ? j1 - c0 : 64;
+        const uint4 *t = stage[seg][buf];
 #pragma unroll 4
-        for (int j = 0; j < nt; ++j) {
-            const int dist = hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]);
-            select_update(dist, j0 + j, best, second, idx);
+        for (int j = 0; j < nc; ++j) {
+            const uint4 b0 = t[2 * j], b1 = t[2 * j + 1];
+#pragma unroll
+            for (int q = 0; q < MQ; ++q)
+                key_update(((unsigned)hamming256(a[q][0], a[q][1], b0, b1) << 16) | (unsigned)(c0 + j), k1[q], k2[q]);
         }
+        stage[seg][buf ^ 1][2 * lane] = n0;
+        stage[seg][buf ^ 1][2 * lane + 1] = n1;
     }
-    if (i < nA) {
-        const size_t o = (size_t)p * cap + i;
-        if (best_o) best_o[o] = best;
-        if (second_o) second_o[o] = second;
-        if (idx_o) idx_o[o] = idx;
-        // ORBmatcher.cc:674-676: bestDist<=TH && bestDist<(float)bestDist2*mfNNratio
-        const bool ok = idx >= 0 && best <= th && (float)best < (float)second * nnratio;
-        if (match12) match12[o] = ok ? idx : -1;
-        if (nmatch) {
-            const unsigned long long b = __ballot(ok);
-            if ((tid & 63) == 0 && b) atomicAdd(&nmatch[p], __popcll(b));
+    // merge the per-segment (smallest, second smallest) pairs; keys are unique
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) { sk[seg][q][0][lane] = k1[q]; sk[seg][q][1][lane] = k2[q]; }
+    __syncthreads();
+    if (seg != 0) return;
+    int nok = 0;
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        unsigned m1 = k1[q], m2 = k2[q];
+#pragma unroll
+        for (int g = 1; g < MSEG; ++g) {
+            const unsigned o1 = sk[g][q][0][lane], o2 = sk[g][q][1][lane];
+            const unsigned hi = m1 > o1 ? m1 : o1, lo2 = m2 < o2 ? m2 : o2;
+            m1 = m1 < o1 ? m1 : o1;
+            m2 = hi < lo2 ? hi : lo2;
         }
+        const int i = row0 + q * 64 + lane;
+        bool ok = false;
+        if (i < nA) {
+            const int best = nB > 0 ? (int)(m1 >> 16) : INT_MAX, idx = nB > 0 ? (int)(m1 & 0xffffu) : -1;
+            const int second = nB > 1 ? (int)(m2 >> 16) : INT_MAX;
+            const size_t o = (size_t)p * cap + i;
+            if (best_o) best_o[o] = best;
+            if (second_o) second_o[o] = second;
+            if (idx_o) idx_o[o] = idx;
+            // ORBmatcher.cc:674-676: bestDist<=TH && bestDist<(float)bestDist2*mfNNratio
+            ok = idx >= 0 && best <= th && (float)best < (float)second * nnratio;
+            if (match12) match12[o] = ok ? idx : -1;
+        }
+        nok += __popcll(__ballot(ok));
     }
+    if (nmatch && lane == 0 && nok) atomicAdd(&nmatch[p], nok);
 }
 
 // Gated variant: per-query candidate list (CSR), candidate order preserved.
@@ -123,7 +177,7 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
     hipStream_t st = (hipStream_t)stream;
     if (nmatch_dev) ORBX_HIP(hipMemsetAsync(nmatch_dev, 0, sizeof(int) * npairs, st));
     g_prof.begin(st);
-    hipLaunchKernelGGL(k_match_sets, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, st, desc_dev, counts_dev, cap,
+    hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), npairs), dim3(64, MSEG), 0, st, desc_dev, counts_dev, cap,
                        pair_a_dev, pair_b_dev, th, nnratio, best_dev, second_dev, idx_dev, match12_dev, nmatch_dev);
     g_prof.mark(0, st);
     ORBX_HIP(hipGetLastError());
@@ -144,7 +198,7 @@ int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB, in
     if (nB) ORBX_HIP(hipMemcpy((uint8_t *)d.p + (size_t)cap * 32, B, (size_t)nB * 32, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(c.p, cnt, sizeof(cnt), hipMemcpyHostToDevice));
     int *ob = (int *)o.p;
-    hipLaunchKernelGGL(k_match_sets, dim3((cap + MT - 1) / MT, 1), dim3(MT), 0, 0, (const uint8_t *)d.p, (const int *)c.p,
+    hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), 1), dim3(64, MSEG), 0, 0, (const uint8_t *)d.p, (const int *)c.p,
                        cap, (const int *)nullptr, (const int *)nullptr, 0, 0.f, ob, ob + cap, ob + 2 * cap,
                        (int *)nullptr, (int *)nullptr);
     ORBX_HIP(hipGetLastError());

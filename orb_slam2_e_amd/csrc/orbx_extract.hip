@@ -122,130 +122,152 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
 }
 
 // --------------------------------------------------------------------- FAST
-__device__ __forceinline__ bool has9(unsigned m)
-{
-    m |= m << 16;
-    unsigned x = m & (m >> 1);
-    x &= x >> 2;
-    x &= x >> 4;
-    x &= m >> 8;
-    return (x & 0xffffu) != 0;
-}
-
-// cv::FAST score of one pixel: 0 if it is not a FAST-9/16 corner at threshold
-// `th`, else cornerScore<16> = (largest arc-minimum of |v - p_k| over the 16
-// 9-arcs) - 1, which does not depend on th.
-__device__ __forceinline__ int fast_score(const uint8_t *t, int ts, int th)
+// Differences v - p_k on the 16-pixel Bresenham circle of radius 3 (OpenCV
+// makeOffsets order), t = centre pointer into the LDS tile, ts = tile stride.
+__device__ __forceinline__ void fast_diffs(const uint8_t *t, int ts, int d[16])
 {
     const int v = t[0];
-    int d[16];
     d[0] = v - t[3 * ts];       d[1] = v - t[3 * ts + 1];   d[2] = v - t[2 * ts + 2];   d[3] = v - t[ts + 3];
     d[4] = v - t[3];            d[5] = v - t[-ts + 3];      d[6] = v - t[-2 * ts + 2];  d[7] = v - t[-3 * ts + 1];
     d[8] = v - t[-3 * ts];      d[9] = v - t[-3 * ts - 1];  d[10] = v - t[-2 * ts - 2]; d[11] = v - t[-ts - 3];
     d[12] = v - t[-3];          d[13] = v - t[ts - 3];      d[14] = v - t[2 * ts - 2];  d[15] = v - t[3 * ts - 1];
-    unsigned dark = 0, bright = 0;
+}
+
+// Necessary condition for a 9-arc (OpenCV's opposite-pair pre-test): a 9-arc
+// contains one pixel of every opposite pair (k, k+8).  Returns 1 = dark arc
+// possible, 2 = bright arc possible, 0 = neither (both set cannot be a corner:
+// a 9-arc holds both pixels of one pair).
+__device__ __forceinline__ int fast_pretest(const int d[16], int th)
+{
+    int lo = max(d[0], d[8]), hi = min(d[0], d[8]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        dark |= (unsigned)(d[k] > th) << k;
-        bright |= (unsigned)(d[k] < -th) << k;
+    for (int k = 1; k < 8; ++k) {
+        lo = min(lo, max(d[k], d[k + 8]));
+        hi = max(hi, min(d[k], d[k + 8]));
     }
-    const bool isd = has9(dark), isb = has9(bright);
-    if (!(isd || isb)) return 0;
-    int e[16], m[16];
+    const int pd = lo > th, pb = hi < -th;
+    return (pd ^ pb) ? (pd ? 1 : 2) : 0;
+}
+
+// cornerScore<16>: (largest arc-minimum of e_k over the 16 circular 9-arcs) - 1
+// where e = d (dark) or -d (bright); it is a corner at threshold th iff that
+// arc-minimum exceeds th, and the score does not depend on th.
+__device__ __forceinline__ int fast_arc_score(const int d[16], int sgn, int th)
+{
+    int e[16], m2[16], m4[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) e[k] = isd ? d[k] : -d[k];
+    for (int k = 0; k < 16; ++k) e[k] = d[k] * sgn;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m[k] = min(e[k], e[(k + 1) & 15]);
-    int m4[16];
+    for (int k = 0; k < 16; ++k) m2[k] = min(e[k], e[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = min(m[k], m[(k + 2) & 15]);
+    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
     int best = -256;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int m9 = min(min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]);
-        best = max(best, m9);
-    }
-    return best - 1;
+    for (int k = 0; k < 16; ++k) best = max(best, min(min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
+    return best > th ? best - 1 : 0;
 }
 
 // One wave per 30-px cell (ORBextractor.cc:789-837): cv::FAST(cell, iniThFAST, nms=true),
 // rerun with minThFAST only if the cell came back empty; candidates are written
 // in FAST raster order, coordinates relative to (minBorderX, minBorderY).
 // Packed candidate: y<<20 | x<<8 | score.
+//
+// Phases: (1) cell tile -> LDS as dwords; (2) every pixel: 16 differences + the
+// opposite-pair pre-test, survivors (a few %) compacted in raster order into an
+// LDS queue; (3) survivors only: arc score -> score map; (4) survivors with a
+// score: 3x3 strict NMS (the local-maximum flag does not depend on the threshold:
+// a neighbour below it is smaller than the centre anyway); (5) ordered emission.
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_bytes,
                                                    const LevelInfo *__restrict__ L,
                                                    const CellInfo *__restrict__ cells, int *__restrict__ cell_count,
                                                    int cells_per_frame, uint32_t *__restrict__ cands,
                                                    size_t cands_per_frame, int iniTh, int minTh, int TS,
-                                                   int tile_bytes, int SS)
+                                                   int tile_bytes, int SS, int sc_bytes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *tile = smem;
     uint8_t *sc = smem + tile_bytes;
+    unsigned short *queue = reinterpret_cast<unsigned short *>(smem + tile_bytes + sc_bytes);
     const int c = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const CellInfo ci = cells[c];
     const LevelInfo lv = L[ci.level];
     const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
     int total = 0;
     if (zw > 0 && zh > 0) {
-        const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + ci.x0;
-        for (int y = 0; y < ch; ++y)
-            for (int x = lane; x < cw; x += 64) tile[y * TS + x] = img[(size_t)y * lv.stride + x];
-        for (int i = lane; i < (zh + 2) * SS; i += 64) sc[i] = 0;
+        // (1) tile: aligned dword loads; pixel (x, y) of the cell lives at tile[y*TS + x + xoff]
+        const int xoff = ci.x0 & 3, ndw = (cw + xoff + 3) >> 2;
+        const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + (ci.x0 - xoff);
+        for (int i = lane; i < ch * ndw; i += 64) {
+            const int y = i / ndw, xw = i - y * ndw;
+            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = *reinterpret_cast<const uint32_t *>(img + (size_t)y * lv.stride + 4 * xw);
+        }
+        for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
         __syncthreads();
+        const uint8_t *t0 = tile + 3 * TS + 3 + xoff; // zone pixel (0,0)
         const int npx = zw * zh;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        // (2) pre-test, survivors -> queue entries y<<6 | x | polarity<<12
+        int nq = 0;
         {
             int x = lane, y = 0;
             while (x >= zw) { x -= zw; ++y; }
-            for (int p = lane; p < npx; p += 64) {
-                sc[(y + 1) * SS + x + 1] = (uint8_t)fast_score(tile + (y + 3) * TS + x + 3, TS, minTh);
+            for (int p0 = 0; p0 < npx; p0 += 64) {
+                int pol = 0;
+                if (p0 + lane < npx) {
+                    int d[16];
+                    fast_diffs(t0 + y * TS + x, TS, d);
+                    pol = fast_pretest(d, minTh);
+                }
+                const unsigned long long b = __ballot(pol != 0);
+                if (pol) queue[nq + __popcll(b & lt)] = (unsigned short)((y << 6) | x | (pol << 12));
+                nq += __popcll(b);
                 x += 64;
                 while (x >= zw) { x -= zw; ++y; }
             }
         }
         __syncthreads();
-        // 3x3 strict non-max suppression; the local-maximum flag does not depend on
-        // the threshold (a neighbour below it is < the centre anyway).
-        unsigned long long mx = 0, hi = 0;
-        int nhi = 0;
-        {
-            int x = lane, y = 0, it = 0;
-            while (x >= zw) { x -= zw; ++y; }
-            for (int p0 = 0; p0 < npx; p0 += 64, ++it) {
-                bool ismax = false, ishi = false;
-                if (p0 + lane < npx) {
-                    const uint8_t *q = sc + (y + 1) * SS + x + 1;
-                    const int s = q[0];
-                    ismax = s > 0 && s > q[-1] && s > q[1] && s > q[-SS - 1] && s > q[-SS] && s > q[-SS + 1] &&
-                            s > q[SS - 1] && s > q[SS] && s > q[SS + 1];
-                    ishi = ismax && s >= iniTh;
-                }
-                mx |= (unsigned long long)ismax << it;
-                hi |= (unsigned long long)ishi << it;
-                nhi += __popcll(__ballot(ishi));
-                x += 64;
-                while (x >= zw) { x -= zw; ++y; }
+        // (3) arc score of the survivors
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            if (q0 + lane < nq) {
+                const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                int d[16];
+                fast_diffs(t0 + y * TS + x, TS, d);
+                sc[(y + 1) * SS + x + 1] = (uint8_t)fast_arc_score(d, (e >> 12) == 1 ? 1 : -1, minTh);
             }
         }
+        __syncthreads();
+        // (4) 3x3 strict non-max suppression on the survivors
+        unsigned long long mx = 0, hi = 0;
+        int nhi = 0, it = 0;
+        for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
+            bool ismax = false, ishi = false;
+            if (q0 + lane < nq) {
+                const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                const uint8_t *q = sc + (y + 1) * SS + x + 1;
+                const int s = q[0];
+                ismax = s > 0 && s > q[-1] && s > q[1] && s > q[-SS - 1] && s > q[-SS] && s > q[-SS + 1] &&
+                        s > q[SS - 1] && s > q[SS] && s > q[SS + 1];
+                ishi = ismax && s >= iniTh;
+            }
+            mx |= (unsigned long long)ismax << it;
+            hi |= (unsigned long long)ishi << it;
+            nhi += __popcll(__ballot(ishi));
+        }
+        // (5) emission in queue (= raster) order; iniThFAST keypoints if any, else minThFAST (:820-824)
         const unsigned long long sel = nhi > 0 ? hi : mx;
         uint32_t *out = cands + (size_t)f * cands_per_frame + ci.cand_off;
-        {
-            int x = lane, y = 0, it = 0;
-            while (x >= zw) { x -= zw; ++y; }
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int p0 = 0; p0 < npx; p0 += 64, ++it) {
-                const bool flag = (sel >> it) & 1ull;
-                const unsigned long long b = __ballot(flag);
-                if (flag) {
-                    const int pos = total + __popcll(b & lt);
-                    const uint32_t s = sc[(y + 1) * SS + x + 1];
-                    if (pos < ci.cap)
-                        out[pos] = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | s;
-                }
-                total += __popcll(b);
-                x += 64;
-                while (x >= zw) { x -= zw; ++y; }
+        it = 0;
+        for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
+            const bool flag = (sel >> it) & 1ull;
+            const unsigned long long b = __ballot(flag);
+            if (flag) {
+                const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                const int pos = total + __popcll(b & lt);
+                const uint32_t s = sc[(y + 1) * SS + x + 1];
+                if (pos < ci.cap)
+                    out[pos] = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | s;
             }
+            total += __popcll(b);
         }
     }
     if (lane == 0) cell_count[(size_t)f * cells_per_frame + c] = total;
@@ -525,43 +547,61 @@ struct BlurTile { short level, x0, y0, pad; };
 // GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point:
 // horizontal 7 taps exact in u16, vertical 7 taps exact in u32, (v + 2^15) >> 16.
 // The padded pyramid already holds the reflected border, so no index clamping.
+// Tile = 64 x 32 outputs per 256-thread workgroup; the (72 x 38)-byte input
+// window is fetched as aligned dwords (x0 is a multiple of 64, rows start 32-B
+// aligned), each work item filters 4 adjacent pixels.
+constexpr int BLUR_TW = 64, BLUR_TH = 32;
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               size_t frame_bytes, const LevelInfo *__restrict__ L,
                                               const BlurTile *__restrict__ tiles, int t0, int t1, int t2, int t3)
 {
-    __shared__ uint8_t in[22][72];
-    __shared__ unsigned short hz[22][64];
+    constexpr int IW = BLUR_TW / 4 + 2, IH = BLUR_TH + 6; // 18 dwords x 38 rows
+    __shared__ uint32_t in[IH][IW + 1];
+    __shared__ uint32_t hz[IH][BLUR_TW / 2 + 1];           // u16 pairs
     const BlurTile bt = tiles[blockIdx.x];
     const LevelInfo lv = L[bt.level];
     const int f = blockIdx.y, tid = threadIdx.x;
     const size_t base = (size_t)f * frame_bytes + lv.off + PADX;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        const int r = i / 70, c = i - r * 70;
-        const int x = bt.x0 - 3 + c, y = bt.y0 - 3 + r;
-        uint8_t v = 0;
-        if (x < lv.w + 3 && y < lv.h + 3) v = pyr[base + (size_t)(y + EDGE) * lv.stride + x];
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int x = bt.x0 - 4 + 4 * c, y = bt.y0 - 3 + r;
+        uint32_t v = 0;
+        if (x <= lv.w + EDGE - 4 && y < lv.h + EDGE) v = *reinterpret_cast<const uint32_t *>(pyr + base + (ptrdiff_t)(y + EDGE) * lv.stride + x);
         in[r][c] = v;
     }
     __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t *q = &in[r][c];
-        hz[r][c] = (unsigned short)(t0 * (q[0] + q[6]) + t1 * (q[1] + q[5]) + t2 * (q[2] + q[4]) + t3 * q[3]);
+    for (int i = tid; i < IH * (BLUR_TW / 4); i += 256) {
+        const int r = i / (BLUR_TW / 4), q = i - r * (BLUR_TW / 4);
+        const uint32_t w0 = in[r][q], w1 = in[r][q + 1], w2 = in[r][q + 2];
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 255u; b[4 + k] = (w1 >> (8 * k)) & 255u; b[8 + k] = (w2 >> (8 * k)) & 255u; }
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) // pixel 4q+k sits at byte 4+k of the 12-byte window
+            o[k] = t0 * (b[k + 1] + b[k + 7]) + t1 * (b[k + 2] + b[k + 6]) + t2 * (b[k + 3] + b[k + 5]) + t3 * b[k + 4];
+        hz[r][2 * q] = o[0] | (o[1] << 16);
+        hz[r][2 * q + 1] = o[2] | (o[3] << 16);
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = (tid & 15) * 4;
-    const int x = bt.x0 + tx, y = bt.y0 + ty;
-    if (x < lv.w && y < lv.h) {
+    for (int i = tid; i < BLUR_TH * (BLUR_TW / 4); i += 256) {
+        const int r = i / (BLUR_TW / 4), q = i - r * (BLUR_TW / 4);
+        const int x = bt.x0 + 4 * q, y = bt.y0 + r;
+        if (x >= lv.w || y >= lv.h) continue;
+        uint32_t a[7][2];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { a[j][0] = hz[r + j][2 * q]; a[j][1] = hz[r + j][2 * q + 1]; }
         uint32_t out = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t s = (uint32_t)t0 * (hz[ty][tx + b] + hz[ty + 6][tx + b]) +
-                               (uint32_t)t1 * (hz[ty + 1][tx + b] + hz[ty + 5][tx + b]) +
-                               (uint32_t)t2 * (hz[ty + 2][tx + b] + hz[ty + 4][tx + b]) +
-                               (uint32_t)t3 * hz[ty + 3][tx + b];
+        for (int k = 0; k < 4; ++k) {
+            const int wi = k >> 1, sh = (k & 1) * 16;
+            const uint32_t s = (uint32_t)t0 * (((a[0][wi] >> sh) & 0xffffu) + ((a[6][wi] >> sh) & 0xffffu)) +
+                               (uint32_t)t1 * (((a[1][wi] >> sh) & 0xffffu) + ((a[5][wi] >> sh) & 0xffffu)) +
+                               (uint32_t)t2 * (((a[2][wi] >> sh) & 0xffffu) + ((a[4][wi] >> sh) & 0xffffu)) +
+                               (uint32_t)t3 * ((a[3][wi] >> sh) & 0xffffu);
             uint32_t v = (s + (1u << 15)) >> 16;
             v = v > 255u ? 255u : v;
-            out |= v << (8 * b);
+            out |= v << (8 * k);
         }
         *reinterpret_cast<uint32_t *>(blur + base + (size_t)(y + EDGE) * lv.stride + x) = out;
     }
@@ -675,7 +715,7 @@ struct orbx_extractor {
     std::vector<BlurTile> tiles;
     size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
     int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
-    int TS = 0, tile_bytes = 0, SS = 0, fast_lds = 0, oct_lds = 0;
+    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, oct_lds = 0;
 
     hipStream_t stream = nullptr;
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_in = nullptr;
@@ -867,7 +907,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 c.dx = (short)(j * wCell); c.dy = (short)(i * hCell);
                 const int zw = c.cw - 6, zh = c.ch - 6;
                 c.cap = (zw > 0 && zh > 0) ? ((zw + 1) / 2) * ((zh + 1) / 2) : 0; // 3x3 strict NMS bound
-                if (zw * zh > 4096) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than 4096 px");
+                if (zw > 63 || zh > 63) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than 63 px");
                 c.cand_off = (int)cand_off;
                 cand_off += c.cap;
                 key_off += c.cap;
@@ -881,8 +921,8 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         lv.sel_base = sel_off;
         sel_off += lv.N + 4;
         // blur tiles
-        for (int y0 = 0; y0 < lv.h; y0 += 16)
-            for (int x0 = 0; x0 < lv.w; x0 += 64) {
+        for (int y0 = 0; y0 < lv.h; y0 += BLUR_TH)
+            for (int x0 = 0; x0 < lv.w; x0 += BLUR_TW) {
                 BlurTile t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0;
                 ex->tiles.push_back(t);
             }
@@ -918,10 +958,11 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
     }
     ex->NC = maxN + 8;
-    ex->TS = (maxcw + 3) & ~3;
+    ex->TS = (maxcw + 3 + 3) & ~3; // + up to 3 bytes of alignment shift
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
     ex->SS = maxcw - 6 + 2;
-    ex->fast_lds = ex->tile_bytes + ex->SS * (maxch - 6 + 2) + 16;
+    ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
+    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 16;
     ex->oct_lds = (int)sizeof(int) * (OCT_T + ex->maxcells + 1 + 22 * ex->NC) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
@@ -996,7 +1037,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     }
     hipLaunchKernelGGL(k_fast_cells, dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
                        ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                       ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->TS, ex->tile_bytes, ex->SS);
+                       ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->TS, ex->tile_bytes, ex->SS, ex->sc_bytes);
     pf.mark(2, st);
     hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
                        ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
