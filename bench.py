@@ -80,9 +80,11 @@ def fem_bench(rank, world, dist, torch, dev, nmesh=256, iters=200, cpu=True):
         fea.eliminate_dofs(fixed)
         b = np.tile(load, (nm, 1)); b[:, fixed] = 0
         fea.cg_setup(b)
-        fea.cg_iterate(5); fea.cg_result()            # warm
-        fea.cg_setup(b)
         fea.profile(True)
+        fea.cg_iterate(20); fea.cg_result()           # warm + per-kernel split (untimed pass, all kinds)
+        split = {k: v[0] / max(v[1], 1) for k, v in fea.profile_read().items() if v[1]}
+        fea.cg_setup(b)
+        fea.profile(4)                                # timed region: events around k_fem_spmv only
         barrier()
         t0 = time.perf_counter()
         fea.cg_iterate(iters)
@@ -104,7 +106,7 @@ def fem_bench(rank, world, dist, torch, dev, nmesh=256, iters=200, cpu=True):
                       "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes,
                       "spmv_GBps": spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
                       "cg_iter_GBps": iter_bytes * iters / dt / 1e9,
-                      "kernel_ms_per_iter": {k: v[0] / iters for k, v in prof.items() if v[1]}}
+                      "kernel_ms_per_launch_untimed_pass": split}
         if label == "single" and cpu and rank == 0:
             import oracle
             rp, col, val = fea.csr()
@@ -126,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2, help="independent contexts/streams the steps rotate over")
     ap.add_argument("--no-fem", action="store_true")
     ap.add_argument("--fem-meshes", type=int, default=256)
     args = ap.parse_args()
@@ -151,43 +154,57 @@ def main():
     # ---- inputs resident in HBM (weak scaling: each rank owns its own 64 frames)
     frames = synth_frames(BATCH, W, H, start=rank * BATCH)
     d_frames = torch.from_numpy(frames).to(dev)
-    ex = ORBextractor(*PARAMS)
     m = ORBmatcher(0.6)
     L = lib()
-    cap = ex.capacity
     qa = torch.arange(BATCH, dtype=torch.int32, device=dev)
     qb = ((qa + 1) % BATCH).to(torch.int32)
-    best = torch.empty((BATCH, cap), dtype=torch.int32, device=dev)
-    second = torch.empty_like(best); idx = torch.empty_like(best); match12 = torch.empty_like(best)
-    nmatch = torch.zeros(BATCH, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
 
-    ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, stream)  # sizes the workspace
-    kps_p, desc_p, cnt_p, _ = ex.result_dev()
+    # `--pipeline P` independent contexts (extractor workspace + result buffers + HIP stream): step k runs
+    # on context k % P, so the latency-bound stages of one batch (pyramid, octree) overlap the VALU-bound
+    # stages of the next (FAST, match).  Every step still does the full work on its own buffers.
+    class Ctx:
+        pass
+    ctxs = []
+    for i in range(max(1, args.pipeline)):
+        c = Ctx()
+        c.ex = ORBextractor(*PARAMS)
+        c.tstream = torch.cuda.Stream(device=dev) if args.pipeline > 1 else torch.cuda.current_stream()
+        c.stream = c.tstream.cuda_stream
+        cap = c.ex.capacity
+        c.best = torch.empty((BATCH, cap), dtype=torch.int32, device=dev)
+        c.second = torch.empty_like(c.best); c.idx = torch.empty_like(c.best); c.match12 = torch.empty_like(c.best)
+        c.nmatch = torch.zeros(BATCH, dtype=torch.int32, device=dev)
+        c.ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, c.stream)  # sizes the workspace
+        c.kps_p, c.desc_p, c.cnt_p, _ = c.ex.result_dev()
+        ctxs.append(c)
+    torch.cuda.synchronize()
     # fixed-size records {kps[CAP], desc[CAP][32], counts, match12[CAP], nmatch} -> one send buffer
     n_kps, n_desc, n_cnt, n_m12 = cap * 28 * BATCH, cap * 32 * BATCH, 4 * BATCH, cap * 4 * BATCH
     rec_bytes = n_kps + n_desc + n_cnt + n_m12 + n_cnt
     counts_t = torch.zeros(BATCH, dtype=torch.int32, device=dev)
-    send = recv = None
-    if world > 1 and not args.no_gather:
-        send = torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
-        recv = [torch.empty(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    do_gather = world > 1 and not args.no_gather
+    for c in ctxs:
+        c.send = torch.empty(rec_bytes, dtype=torch.uint8, device=dev) if do_gather else None
+        c.recv = [torch.empty(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if (do_gather and rank == 0) else None
 
-    def pack_records():
-        p0 = send.data_ptr()
-        L.orbx_copy_results_dev(ex._h, C.c_void_p(p0), C.c_void_p(p0 + n_kps), C.c_void_p(p0 + n_kps + n_desc),
-                                C.c_void_p(stream))
+    def pack_records(c):
+        p0 = c.send.data_ptr()
+        L.orbx_copy_results_dev(c.ex._h, C.c_void_p(p0), C.c_void_p(p0 + n_kps), C.c_void_p(p0 + n_kps + n_desc),
+                                C.c_void_p(c.stream))
         o = n_kps + n_desc + n_cnt
-        send[o:o + n_m12].copy_(match12.view(torch.uint8).reshape(-1), non_blocking=True)
-        send[o + n_m12:].copy_(nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
+        c.send[o:o + n_m12].copy_(c.match12.view(torch.uint8).reshape(-1), non_blocking=True)
+        c.send[o + n_m12:].copy_(c.nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
 
-    def step():
-        ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, stream)
-        m.match_batch_device(desc_p, cnt_p, cap, qa.data_ptr(), qb.data_ptr(), BATCH, best.data_ptr(),
-                             second.data_ptr(), idx.data_ptr(), match12.data_ptr(), nmatch.data_ptr(), stream=stream)
-        if send is not None:
-            pack_records()
-            dist.gather(send, recv, dst=0)
+    def step(k):
+        c = ctxs[k % len(ctxs)]
+        with torch.cuda.stream(c.tstream):
+            c.ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, c.stream)
+            m.match_batch_device(c.desc_p, c.cnt_p, cap, qa.data_ptr(), qb.data_ptr(), BATCH, c.best.data_ptr(),
+                                 c.second.data_ptr(), c.idx.data_ptr(), c.match12.data_ptr(), c.nmatch.data_ptr(),
+                                 stream=c.stream)
+            if do_gather:
+                pack_records(c)
+                dist.gather(c.send, c.recv, dst=0)
 
     def sync():
         torch.cuda.synchronize()
@@ -195,15 +212,43 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     sync()
-    L.orbx_profile_enable(ex._h, 1)
+
+    def read_profiles():
+        kern = {}
+        for c in ctxs:
+            names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); ln = (C.c_int64 * 16)(); nk = C.c_int(0)
+            L.orbx_profile_read(c.ex._h, 16, names, ms, ln, C.byref(nk))
+            for i in range(nk.value):
+                a, b = kern.get(names[i].decode(), (0.0, 0))
+                kern[names[i].decode()] = (a + ms[i], b + ln[i])
+        mm, ml = C.c_double(0), C.c_int64(0)
+        L.orbm_profile_read(C.byref(mm), C.byref(ml))
+        kern["k_match_sets"] = (mm.value, ml.value)
+        return kern
+
+    # untimed pass with events around every kernel: the per-kernel split and the dominant kernel
+    KINDS = ["k_pyr_level0", "k_pyr_resize", "k_fast_cells", "k_octree", "k_blur", "k_describe"]
+    for c in ctxs:
+        L.orbx_profile_enable(c.ex._h, -1)
     L.orbm_profile_enable(1)
+    nprof = 2 * len(ctxs)
+    for k in range(nprof):
+        step(k)
+    sync()
+    kern_all = read_profiles()
+    split_ms = {k: v[0] / nprof for k, v in kern_all.items()}
+    dom = max(split_ms, key=split_ms.get)
+    # timed region: events around the dominant kernel only (each event costs dispatch-gap time)
+    for c in ctxs:
+        L.orbx_profile_enable(c.ex._h, (1 << KINDS.index(dom)) if dom in KINDS else 0)
+    L.orbm_profile_enable(1 if dom == "k_match_sets" else 0)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -211,15 +256,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel times (HIP events on the launch stream, recorded in the timed region)
-    names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); ln = (C.c_int64 * 16)(); nk = C.c_int(0)
-    L.orbx_profile_read(ex._h, 16, names, ms, ln, C.byref(nk))
-    kern = {names[i].decode(): (ms[i], ln[i]) for i in range(nk.value)}
-    mm, ml = C.c_double(0), C.c_int64(0)
-    L.orbm_profile_read(C.byref(mm), C.byref(ml))
-    kern["k_match_sets"] = (mm.value, ml.value)
-    L.orbx_profile_enable(ex._h, 0)
+    # ---- dominant kernel's launch times (HIP events on the launch stream, recorded in the timed region)
+    kern = read_profiles()
+    for c in ctxs:
+        L.orbx_profile_enable(c.ex._h, 0)
     L.orbm_profile_enable(0)
+    ex, nmatch, stream = ctxs[0].ex, ctxs[0].nmatch, ctxs[0].stream
 
     fem = None
     if not args.no_fem:
@@ -228,8 +270,6 @@ def main():
     if rank == 0:
         total_frames = world * BATCH * args.steps
         value = total_frames / dt
-        per_step_ms = {k: v[0] / args.steps for k, v in kern.items()}
-        dom = max(per_step_ms, key=per_step_ms.get)
         launches_per_step = max(kern[dom][1] // max(args.steps, 1), 1)
         avg_launch_ms = kern[dom][0] / max(kern[dom][1], 1)
         alg = ALG_BYTES[dom] * BATCH / launches_per_step  # algorithmic bytes per launch
@@ -244,7 +284,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of 64 synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
                                    "+ 2000x2000 brute-force Hamming match per frame",
-                       "frames_per_gpu": BATCH, "global_batch": world * BATCH,
+                       "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
                        "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0" if world > 1 else "single GPU",
                        "mean_keypoints_per_frame": float(counts.float().mean().item()),
                        "mean_matches_per_frame": float(nmatch.float().mean().item())},
@@ -252,7 +292,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_launch_ms, "alg_bytes_per_launch": alg},
             "pipeline_hbm_frac": value / world * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
-            "kernel_ms_per_step": per_step_ms,
+            "kernel_ms_per_step_untimed_pass": split_ms,
         }
         if fem is not None:
             out["fem"] = fem

@@ -119,8 +119,11 @@ int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, float 
 int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *kps, int cap, int *n);
 
 /* Per-kernel timing with HIP events on the launch stream (no reference
- * counterpart; feeds bench.py's roofline object).  Read returns, per kernel kind,
- * its name, accumulated milliseconds and launch count since enable. */
+ * counterpart; feeds bench.py's roofline object).  `on`: 0 = off, < 0 = every
+ * kernel kind, > 0 = bit mask of kinds (bit i = i-th name returned by read): each
+ * recorded event widens the dispatch gap by a few microseconds, so a timed run
+ * enables only the kernel it reports.  Read returns, per kernel kind, its name,
+ * accumulated milliseconds and launch count since enable. */
 int orbx_profile_enable(orbx_extractor *ex, int on);
 int orbx_profile_read(orbx_extractor *ex, int max_kinds, const char **names, double *total_ms,
                       int64_t *launches, int *nkinds);

@@ -40,47 +40,45 @@ inline bool device_ok()
 }
 
 // Optional per-kernel timing with HIP events recorded on the launch stream
-// (bench.py's roofline leg).  begin() marks the start of a launch sequence,
-// mark(kind) closes the interval since the previous event and charges it to
-// `kind`.  flush() synchronises and accumulates.
+// (bench.py's roofline leg).  start(kind)/stop(kind) bracket one launch and only
+// record when `kind` is in `mask`: every recorded event costs a few microseconds
+// of dispatch gap, so the timed region enables just the kernel it reports.
+// flush() synchronises and accumulates.
 struct KernelProfiler {
     static constexpr int MAXK = 16, MAXEV = 4096;
-    bool on = false;
+    unsigned mask = 0;
     const char *names[MAXK] = {nullptr};
     double ms[MAXK] = {0};
     long launches[MAXK] = {0};
     hipEvent_t ev[MAXEV];
-    int kind[MAXEV];
+    int kind[MAXEV]; // start: kind, stop: kind | 0x100
     int n = 0, created = 0;
 
-    hipEvent_t next()
+    void rec(int tag, hipStream_t st)
     {
         if (n == created) { (void)hipEventCreate(&ev[created]); ++created; }
-        return ev[n];
+        kind[n] = tag;
+        (void)hipEventRecord(ev[n++], st);
     }
-    void begin(hipStream_t st)
+    void start(int k, hipStream_t st)
     {
-        if (!on) return;
-        if (n + 32 >= MAXEV) flush();
-        hipEvent_t e = next();
-        kind[n++] = -1;
-        (void)hipEventRecord(e, st);
+        if (!((mask >> k) & 1u)) return;
+        if (n + 4 >= MAXEV) flush();
+        rec(k, st);
     }
-    void mark(int k, hipStream_t st)
+    void stop(int k, hipStream_t st)
     {
-        if (!on) return;
-        hipEvent_t e = next();
-        kind[n++] = k;
-        (void)hipEventRecord(e, st);
+        if ((mask >> k) & 1u) rec(k | 0x100, st);
     }
     void flush()
     {
         if (n == 0) return;
         (void)hipEventSynchronize(ev[n - 1]);
         for (int i = 1; i < n; ++i) {
-            if (kind[i] < 0) continue;
+            if (!(kind[i] & 0x100) || kind[i - 1] != (kind[i] & 0xff)) continue;
             float t = 0.f;
-            if (hipEventElapsedTime(&t, ev[i - 1], ev[i]) == hipSuccess) { ms[kind[i]] += t; launches[kind[i]]++; }
+            const int k = kind[i] & 0xff;
+            if (hipEventElapsedTime(&t, ev[i - 1], ev[i]) == hipSuccess) { ms[k] += t; launches[k]++; }
         }
         n = 0;
     }

@@ -426,16 +426,18 @@ void launch_iter(fem_model *m, hipStream_t st)
 {
     const dim3 g(m->nchunk, m->nmesh);
     const int cur = m->cg_it & 1;
-    m->prof.begin(st);
+    m->prof.start(2, st);
     hipLaunchKernelGGL(k_fem_spmv, g, dim3(CGT), 0, st, m->d_vals, m->d_cols, m->d_rowptr, m->nnz, m->ndof, m->nchunk,
                        m->d_p, m->d_Ap, m->d_part[0]);
-    m->prof.mark(2, st);
+    m->prof.stop(2, st);
+    m->prof.start(3, st);
     hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, cur, m->d_sc, m->d_part[0], m->d_p,
                        m->d_Ap, m->d_dinv, m->d_x, m->d_r, m->d_part[1], m->d_part[2]);
-    m->prof.mark(3, st);
+    m->prof.stop(3, st);
+    m->prof.start(4, st);
     hipLaunchKernelGGL(k_fem_cg_dir, g, dim3(CGT), 0, st, m->ndof, m->nchunk, cur, m->d_sc, m->d_part[1], m->d_part[2],
                        m->d_r, m->d_dinv, m->d_p);
-    m->prof.mark(4, st);
+    m->prof.stop(4, st);
     m->cg_it++;
 }
 
@@ -580,7 +582,7 @@ int fem_assemble(fem_model *m)
 {
     if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
     hipStream_t st = m->stream;
-    m->prof.begin(st);
+    m->prof.start(0, st);
     if (m->ne > 0) {
         const dim3 g(m->ne, m->nmesh);
         if (m->eltype == FEM_C3D8)
@@ -590,11 +592,12 @@ int fem_assemble(fem_model *m)
         else
             hipLaunchKernelGGL((k_fem_ke<4, FEM_TET4>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
     }
-    m->prof.mark(0, st);
+    m->prof.stop(0, st);
+    m->prof.start(1, st);
     hipLaunchKernelGGL(k_fem_assemble, dim3((m->nblk * 9 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_ke, m->ne, m->nd,
                        m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->d_cols,
                        m->d_lcol, m->nnz, m->ndof);
-    m->prof.mark(1, st);
+    m->prof.stop(1, st);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(st));
     m->assembled = true;
@@ -737,10 +740,10 @@ int fem_spmv_repeat(fem_model *m, int n, void *stream)
     if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     for (int i = 0; i < n; ++i) {
-        m->prof.begin(st);
+        m->prof.start(2, st);
         hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, st, m->d_vals, m->d_cols, m->d_rowptr, m->nnz,
                            m->ndof, m->nchunk, m->d_p, m->d_Ap, m->d_part[0]);
-        m->prof.mark(2, st);
+        m->prof.stop(2, st);
     }
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -787,7 +790,7 @@ int fem_profile_enable(fem_model *m, int on)
 {
     if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
     m->prof.reset();
-    m->prof.on = on != 0;
+    m->prof.mask = on < 0 ? 0xffffu : (unsigned)on;
     return ORBX_OK;
 }
 

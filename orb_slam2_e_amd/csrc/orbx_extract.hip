@@ -67,58 +67,97 @@ __device__ __forceinline__ int reflect101(int p, int n)
 }
 
 // ------------------------------------------------------------------ pyramid
+// Both pyramid kernels are latency-bound (two dependent global loads per output),
+// so every thread produces 4 pixels (one dword store) in PYR_ROWS rows and keeps
+// all of their loads in flight at once.  The 19-px REFLECT_101 border is
+// recomputed through the reflected coordinate instead of copied afterwards.
+constexpr int PYR_ROWS = 4;
+
 // Level 0: copyMakeBorder(image, temp, 19,19,19,19, BORDER_REFLECT_101), ORBextractor.cc:1135.
 __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ img, int img_stride,
                                                    size_t img_frame_stride, uint8_t *__restrict__ pyr,
-                                                   size_t frame_bytes, LevelInfo lv)
+                                                   size_t frame_bytes, LevelInfo lv, int aligned)
 {
     const int xw = blockIdx.x * 64 + threadIdx.x;
     if (xw * 4 >= lv.stride) return;
-    const int row = blockIdx.y, f = blockIdx.z;
-    const int sy = reflect101(row - EDGE, lv.h);
-    const uint8_t *src = img + (size_t)f * img_frame_stride + (size_t)sy * img_stride;
-    uint32_t out = 0;
+    const int f = blockIdx.z, px0 = xw * 4 - PADX;
+    const bool inner = aligned && px0 >= 0 && px0 + 4 <= lv.w;
+    int sx[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int px = xw * 4 + b - PADX;
-        uint32_t v = 0;
-        if (px >= -EDGE && px < lv.w + EDGE) v = src[reflect101(px, lv.w)];
-        out |= v << (8 * b);
+    for (int b = 0; b < 4; ++b) sx[b] = (px0 + b >= -EDGE && px0 + b < lv.w + EDGE) ? reflect101(px0 + b, lv.w) : -1;
+    uint32_t out[PYR_ROWS];
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; ++r) {
+        const int row = blockIdx.y * PYR_ROWS + r;
+        out[r] = 0;
+        if (row < lv.h + 2 * EDGE) {
+            const uint8_t *src = img + (size_t)f * img_frame_stride + (size_t)reflect101(row - EDGE, lv.h) * img_stride;
+            if (inner) {
+                out[r] = *reinterpret_cast<const uint32_t *>(src + px0);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (sx[b] >= 0) out[r] |= (uint32_t)src[sx[b]] << (8 * b);
+            }
+        }
     }
-    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + lv.off + (size_t)row * lv.stride + xw * 4) = out;
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; ++r) {
+        const int row = blockIdx.y * PYR_ROWS + r;
+        if (row < lv.h + 2 * EDGE)
+            *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + lv.off + (size_t)row * lv.stride + xw * 4) = out[r];
+    }
 }
 
 // Level l from level l-1: cv::resize INTER_LINEAR 8U fixed point
-// + REFLECT_101 border (recomputed, not copied).  xt[dx] = {sx, a0 | a1<<16},
-// yt[dy] = {sy0, sy1, b0, b1}: OpenCV's coefficient tables, built on the host.
+// + REFLECT_101 border.  xt[dx] = {sx, a0 | a1<<16}, yt[dy] = {sy0, sy1, b0, b1}:
+// OpenCV's coefficient tables, built on the host.
 __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
                                                    LevelInfo dst, const int2 *__restrict__ xt,
                                                    const int4 *__restrict__ yt)
 {
     const int xw = blockIdx.x * 64 + threadIdx.x;
     if (xw * 4 >= dst.stride) return;
-    const int row = blockIdx.y, f = blockIdx.z;
-    const int dy = reflect101(row - EDGE, dst.h);
-    const int4 yy = yt[dy];
-    const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
-    const uint8_t *S0 = base + (size_t)(yy.x + EDGE) * src.stride;
-    const uint8_t *S1 = base + (size_t)(yy.y + EDGE) * src.stride;
-    uint32_t out = 0;
+    const int f = blockIdx.z, px0 = xw * 4 - PADX;
+    int sxs[4], a0[4], a1[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int px = xw * 4 + b - PADX;
-        uint32_t v = 0;
-        if (px >= -EDGE && px < dst.w + EDGE) {
-            const int2 xx = xt[reflect101(px, dst.w)];
-            const int a0 = xx.y & 0xffff, a1 = xx.y >> 16;
-            const int r0 = S0[xx.x] * a0 + S0[xx.x + 1] * a1;
-            const int r1 = S1[xx.x] * a0 + S1[xx.x + 1] * a1;
-            v = (uint32_t)((((yy.z * (r0 >> 4)) >> 16) + ((yy.w * (r1 >> 4)) >> 16) + 2) >> 2);
-            v = v > 255u ? 255u : v;
+        sxs[b] = -1; a0[b] = a1[b] = 0;
+        if (px0 + b >= -EDGE && px0 + b < dst.w + EDGE) {
+            const int2 xx = xt[reflect101(px0 + b, dst.w)];
+            sxs[b] = xx.x; a0[b] = xx.y & 0xffff; a1[b] = xx.y >> 16;
         }
-        out |= v << (8 * b);
     }
-    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (size_t)row * dst.stride + xw * 4) = out;
+    int4 yy[PYR_ROWS];
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; ++r) {
+        const int row = blockIdx.y * PYR_ROWS + r;
+        yy[r] = yt[reflect101((row < dst.h + 2 * EDGE ? row : 0) - EDGE, dst.h)];
+    }
+    const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
+    uint32_t out[PYR_ROWS];
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; ++r) {
+        const uint8_t *S0 = base + (size_t)(yy[r].x + EDGE) * src.stride;
+        const uint8_t *S1 = base + (size_t)(yy[r].y + EDGE) * src.stride;
+        out[r] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (sxs[b] >= 0) {
+                const int r0 = S0[sxs[b]] * a0[b] + S0[sxs[b] + 1] * a1[b];
+                const int r1 = S1[sxs[b]] * a0[b] + S1[sxs[b] + 1] * a1[b];
+                uint32_t v = (uint32_t)((((yy[r].z * (r0 >> 4)) >> 16) + ((yy[r].w * (r1 >> 4)) >> 16) + 2) >> 2);
+                v = v > 255u ? 255u : v;
+                out[r] |= v << (8 * b);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; ++r) {
+        const int row = blockIdx.y * PYR_ROWS + r;
+        if (row < dst.h + 2 * EDGE)
+            *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (size_t)row * dst.stride + xw * 4) = out[r];
+    }
 }
 
 // --------------------------------------------------------------------- FAST
@@ -177,12 +216,15 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int sgn, int th)
 // LDS queue; (3) survivors only: arc score -> score map; (4) survivors with a
 // score: 3x3 strict NMS (the local-maximum flag does not depend on the threshold:
 // a neighbour below it is smaller than the centre anyway); (5) ordered emission.
+// TS / SS (tile and score-map strides) are compile-time so that the 16 circle
+// offsets fold into ds_read immediates.
+template <int TS, int SS>
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_bytes,
                                                    const LevelInfo *__restrict__ L,
                                                    const CellInfo *__restrict__ cells, int *__restrict__ cell_count,
                                                    int cells_per_frame, uint32_t *__restrict__ cands,
-                                                   size_t cands_per_frame, int iniTh, int minTh, int TS,
-                                                   int tile_bytes, int SS, int sc_bytes)
+                                                   size_t cands_per_frame, int iniTh, int minTh,
+                                                   int tile_bytes, int sc_bytes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *tile = smem;
@@ -274,32 +316,46 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 }
 
 // ------------------------------------------------------------------- octree
-// Exclusive scan of a[0..n) in place by the whole block; returns the total.
-__device__ int block_excl_scan(int *a, int n, int *part)
+// Exclusive scan of a[0..n) (and, if b != nullptr, of b[0..n)) in place by the
+// whole 256-thread block; totals returned through ta / tb.  Each thread owns a
+// contiguous chunk, wave-level shuffle scan, one cross-wave hop through LDS:
+// three barriers in all.
+__device__ void block_excl_scan2(int *a, int *b, int n, int *part, int &ta, int &tb)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     __syncthreads();
     const int per = (n + OCT_T - 1) / OCT_T;
-    const int b = min(tid * per, n), e = min(b + per, n);
-    int sum = 0;
-    for (int i = b; i < e; ++i) sum += a[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < OCT_T; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int sa = 0, sb = 0;
+    for (int i = lo; i < hi; ++i) { sa += a[i]; if (b) sb += b[i]; }
+    int ia = sa, ib = sb; // inclusive over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int va = __shfl_up(ia, off), vb = __shfl_up(ib, off);
+        if (lane >= off) { ia += va; ib += vb; }
     }
-    const int total = part[OCT_T - 1];
-    int run = tid ? part[tid - 1] : 0;
-    for (int i = b; i < e; ++i) {
-        const int v = a[i];
-        a[i] = run;
-        run += v;
-    }
+    if (lane == 63) { part[w] = ia; part[4 + w] = ib; }
     __syncthreads();
-    return total;
+    int ba = 0, bb = 0, ga = 0, gb = 0;
+#pragma unroll
+    for (int i = 0; i < OCT_T / 64; ++i) {
+        if (i < w) { ba += part[i]; bb += part[4 + i]; }
+        ga += part[i]; gb += part[4 + i];
+    }
+    int ra = ba + ia - sa, rb = bb + ib - sb;
+    for (int i = lo; i < hi; ++i) {
+        const int va = a[i];
+        a[i] = ra; ra += va;
+        if (b) { const int vb = b[i]; b[i] = rb; rb += vb; }
+    }
+    ta = ga; tb = gb;
+    __syncthreads();
+}
+__device__ int block_excl_scan(int *a, int n, int *part)
+{
+    int ta, tb;
+    block_excl_scan2(a, nullptr, n, part, ta, tb);
+    return ta;
 }
 
 // Children of node box (x0,x1,y0,y1): ExtractorNode::DivideNode, ORBextractor.cc:481-509.
@@ -319,6 +375,8 @@ __device__ __forceinline__ void child_box(int x0, int x1, int y0, int y1, int q,
 // all prefix sums (tests/octree_model.py is the same formulation in Python and is
 // checked against the literal list-based oracle).  Equal-size ties in the
 // largest-first phase use creation order.
+// Keys (candidates) live in LDS when the level has at most `kcap` of them, else in
+// the per-frame HBM workspace (flat pointers serve both).
 __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ L, const CellInfo *__restrict__ cells,
                                                   const int *__restrict__ cell_count, int cells_per_frame,
                                                   const uint32_t *__restrict__ cands, size_t cands_per_frame,
@@ -326,11 +384,11 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
                                                   uint8_t *__restrict__ kq_all, size_t keys_per_frame,
                                                   uint32_t *__restrict__ sel_all, int sel_per_frame,
                                                   int *__restrict__ level_count, int *__restrict__ level_ncand,
-                                                  int nlevels, int NC, int maxcells)
+                                                  int nlevels, int NC, int maxcells, int kcap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     int *p = reinterpret_cast<int *>(smem);
-    int *part = p;          p += OCT_T;
+    int *part = p;          p += 8;
     int *s_cell = p;        p += maxcells + 1;
     int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
     int *by[2] = {p, p + NC};  p += 2 * NC; // y0 | y1<<16
@@ -339,22 +397,21 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     int *cc = p;            p += 4 * NC;
     int *nne = p;           p += NC;
     int *eexp = p;          p += NC;
-    int *rnk = p;           p += NC;
     int *order = p;         p += NC;
     int *split = p;         p += NC;
     int *bstart = p;        p += NC;
     int *ebase = p;         p += NC;
     int *a1 = p;            p += NC;
     int *a2 = p;            p += NC;
-    int *a3 = p;            p += NC;
+    p += NC; // spare
+    uint32_t *l_kpos = reinterpret_cast<uint32_t *>(p);                     p += kcap;
+    unsigned short *l_knode = reinterpret_cast<unsigned short *>(p);        p += (kcap + 1) / 2;
+    uint8_t *l_kq = reinterpret_cast<uint8_t *>(p);
     __shared__ int s_nproc;
 
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelInfo lv = L[l];
     const int N = lv.N;
-    uint32_t *kpos = kpos_all + (size_t)f * keys_per_frame + lv.key_base;
-    unsigned short *knode = knode_all + (size_t)f * keys_per_frame + lv.key_base;
-    uint8_t *kq = kq_all + (size_t)f * keys_per_frame + lv.key_base;
 
     // gather the level's candidates in cell row-major order (vToDistributeKeys)
     for (int c = tid; c < lv.ncells; c += OCT_T) {
@@ -362,9 +419,13 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         const int cap = cells[lv.cell_base + c].cap;
         s_cell[c] = n < cap ? n : cap;
     }
-    if (tid == 0) s_cell[lv.ncells] = 0;
     const int M = block_excl_scan(s_cell, lv.ncells, part);
     if (tid == 0) s_cell[lv.ncells] = M;
+    const bool in_lds = M <= kcap;
+    uint32_t *kpos = in_lds ? l_kpos : kpos_all + (size_t)f * keys_per_frame + lv.key_base;
+    unsigned short *knode = in_lds ? l_knode : knode_all + (size_t)f * keys_per_frame + lv.key_base;
+    uint8_t *kq = in_lds ? l_kq : kq_all + (size_t)f * keys_per_frame + lv.key_base;
+    uint32_t *kpos_out = kpos_all + (size_t)f * keys_per_frame + lv.key_base; // candidates stay readable for staged tests
     for (int i = tid; i < NC; i += OCT_T) cnt[0][i] = 0;
     __syncthreads();
     for (int k = tid; k < M; k += OCT_T) {
@@ -375,6 +436,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
         const uint32_t pk = cands[(size_t)f * cands_per_frame + cells[lv.cell_base + lo].cand_off + (k - s_cell[lo])];
         kpos[k] = pk;
+        if (in_lds) kpos_out[k] = pk;
         const float x = (float)((pk >> 8) & 0xfffu);
         const int root = (int)(x / lv.hX); // vpIniNodes[kp.pt.x/hX], :569
         knode[k] = (unsigned short)root;
@@ -401,12 +463,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     while (true) {
         int *cx = bx[cur], *cy = by[cur], *cn = cnt[cur], *cs = seq[cur];
         for (int s = tid; s < S; s += OCT_T) {
-            a1[s] = cn[s] > 1 ? 1 : 0;
             cc[4 * s] = cc[4 * s + 1] = cc[4 * s + 2] = cc[4 * s + 3] = 0;
             split[s] = 0;
         }
-        const int E = block_excl_scan(a1, S, part); // a1[s] = candidate index in list order
-        if (E == 0) break;
+        __syncthreads();
         // children counts of every expandable node (DivideNode, :511-526)
         for (int k = tid; k < M; k += OCT_T) {
             const int s = knode[k];
@@ -422,9 +482,11 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             }
         }
         __syncthreads();
+        // per node: non-empty / expandable children; scanned together with the candidate flag
         for (int s = tid; s < S; s += OCT_T) {
             int a = 0, b = 0;
-            if (cn[s] > 1) {
+            const bool cand = cn[s] > 1;
+            if (cand) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     a += cc[4 * s + q] > 0;
@@ -433,13 +495,26 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             }
             nne[s] = a;
             eexp[s] = b;
+            a1[s] = cand ? 1 : 0;      // -> candidate index in list order
+            a2[s] = a | (b << 16);     // -> prefix of (non-empty, expandable) children in list order
         }
-        __syncthreads();
-        int nproc = E;
+        int E, PE;
+        block_excl_scan2(a1, a2, S, part, E, PE);
+        if (E == 0) break;
+        int F, Etot, nns;
         if (mode == 1) {
             // every expandable node splits, in list order (:606-665)
-            for (int s = tid; s < S; s += OCT_T)
-                if (cn[s] > 1) { rnk[s] = a1[s]; order[a1[s]] = s; }
+            F = PE & 0xffff; Etot = PE >> 16;
+            for (int s = tid; s < S; s += OCT_T) {
+                if (cn[s] > 1) {
+                    split[s] = 1;
+                    bstart[s] = F - ((a2[s] & 0xffff) + nne[s]); // children pushed to the front, last processed first
+                    ebase[s] = a2[s] >> 16;
+                }
+                a1[s] = s - a1[s]; // rank among the nodes that stay
+            }
+            nns = S - E;
+            __syncthreads();
         } else {
             // largest first, later-created first among equals (:684-732)
             for (int s = tid; s < S; s += OCT_T) {
@@ -450,35 +525,32 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
                         const int c2 = cn[s2];
                         r += (c2 > 1) && (c2 > c0 || (c2 == c0 && cs[s2] > q0));
                     }
-                    rnk[s] = r;
                     order[r] = s;
                 }
             }
             if (tid == 0) s_nproc = E;
             __syncthreads();
-            for (int r = tid; r < E; r += OCT_T) a2[r] = nne[order[r]] - 1;
-            block_excl_scan(a2, E, part);
-            for (int r = tid; r < E; r += OCT_T)
-                if (S + a2[r] + nne[order[r]] - 1 >= N) atomicMin(&s_nproc, r + 1);
+            for (int r = tid; r < E; r += OCT_T) a2[r] = nne[order[r]] | (eexp[order[r]] << 16);
+            int dummy;
+            block_excl_scan2(a2, nullptr, E, part, PE, dummy);
+            for (int r = tid; r < E; r += OCT_T) // stop at the first split that reaches N leaves (:730-731)
+                if (S + (a2[r] & 0xffff) - r + nne[order[r]] - 1 >= N) atomicMin(&s_nproc, r + 1);
             __syncthreads();
-            nproc = s_nproc;
+            const int nproc = s_nproc;
+            // totals over the processed prefix
+            const int lastr = nproc - 1, lasts = order[lastr];
+            F = (a2[lastr] & 0xffff) + nne[lasts];
+            Etot = (a2[lastr] >> 16) + eexp[lasts];
+            for (int r = tid; r < nproc; r += OCT_T) {
+                const int s = order[r];
+                split[s] = 1;
+                bstart[s] = F - ((a2[r] & 0xffff) + nne[s]);
+                ebase[s] = a2[r] >> 16;
+            }
+            __syncthreads();
+            for (int s = tid; s < S; s += OCT_T) a1[s] = split[s] ? 0 : 1;
+            nns = block_excl_scan(a1, S, part); // a1[s] = rank among the nodes that stay
         }
-        __syncthreads();
-        for (int r = tid; r < nproc; r += OCT_T) {
-            a2[r] = nne[order[r]];
-            a3[r] = eexp[order[r]];
-        }
-        const int F = block_excl_scan(a2, nproc, part);
-        const int Etot = block_excl_scan(a3, nproc, part);
-        for (int r = tid; r < nproc; r += OCT_T) {
-            const int s = order[r];
-            split[s] = 1;
-            bstart[s] = F - (a2[r] + nne[s]); // children pushed to the front, last processed first
-            ebase[s] = a3[r];
-        }
-        __syncthreads();
-        for (int s = tid; s < S; s += OCT_T) a1[s] = split[s] ? 0 : 1;
-        const int nns = block_excl_scan(a1, S, part); // a1[s] = rank among nodes that stay
         const int S2 = F + nns;
         int *nx = bx[cur ^ 1], *ny = by[cur ^ 1], *nn = cnt[cur ^ 1], *ns = seq[cur ^ 1];
         for (int s = tid; s < S; s += OCT_T) {
@@ -543,6 +615,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 
 // --------------------------------------------------------------------- blur
 struct BlurTile { short level, x0, y0, pad; };
+
 
 // GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point:
 // horizontal 7 taps exact in u16, vertical 7 taps exact in u32, (v + 2^15) >> 16.
@@ -615,9 +688,14 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// One wave per keypoint: IC_Angle (:77-104) on the unblurred level, then
-// computeOrbDescriptor (:108-147) on the blurred one, then the output record
-// (:845-855 octave/size, :1103-1109 pt *= scale).
+// 16 keypoints per 256-thread workgroup (4 per wave).  Phase 0: one lane per
+// keypoint finds its level and pixel; phase 1: IC_Angle moments (:77-104) on the
+// unblurred level, one wave per keypoint at a time; phase 2: one lane per
+// keypoint evaluates fastAtan2 and the exact sin/cos ONCE (they are wave-uniform
+// values -- evaluating them in every lane of a keypoint's wave would cost 64x the
+// instructions); phase 3: computeOrbDescriptor (:108-147) on the blurred level
+// and the output record (:845-855 octave/size, :1103-1109 pt *= scale).
+constexpr int DESC_KPB = 16;
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                   size_t frame_bytes, const LevelInfo *__restrict__ L, int nlevels,
                                                   const uint32_t *__restrict__ sel_all, int sel_per_frame,
@@ -625,27 +703,41 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                   int *__restrict__ counts, int cap)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int kidx = blockIdx.x * 4 + wv, f = blockIdx.y;
-    int level = -1, first = 0, total = 0;
-    for (int l = 0; l < nlevels; ++l) {
-        const int c = level_count[f * nlevels + l];
-        if (level < 0 && kidx < total + c) { level = l; first = total; }
-        total += c;
+    __shared__ unsigned long long s_center[DESC_KPB];
+    __shared__ int s_stride[DESC_KPB], s_level[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
+    __shared__ uint32_t s_pk[DESC_KPB];
+    __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
+    __shared__ uint32_t s_patch[4][37 * 12];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.y, kbase = blockIdx.x * DESC_KPB;
+    if (tid < DESC_KPB) {
+        const int kidx = kbase + tid;
+        int level = -1, first = 0, total = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            const int c = level_count[f * nlevels + l];
+            if (level < 0 && kidx < total + c) { level = l; first = total; }
+            total += c;
+        }
+        if (kidx == 0) counts[f] = total < cap ? total : cap;
+        if (kidx >= cap) level = -1;
+        s_level[tid] = level;
+        if (level >= 0) {
+            const uint32_t pk = sel_all[(size_t)f * sel_per_frame + L[level].sel_base + (kidx - first)];
+            const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
+            s_pk[tid] = pk;
+            s_stride[tid] = L[level].stride;
+            s_center[tid] = (unsigned long long)f * frame_bytes + L[level].off + (size_t)(y + EDGE) * L[level].stride + PADX + x;
+        }
     }
-    if (kidx == 0 && lane == 0) counts[f] = total < cap ? total : cap;
-    if (level < 0 || kidx >= cap) return;
-    const LevelInfo lv = L[level];
-    const uint32_t pk = sel_all[(size_t)f * sel_per_frame + lv.sel_base + (kidx - first)];
-    const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
-    const size_t center = (size_t)f * frame_bytes + lv.off + (size_t)(y + EDGE) * lv.stride + PADX + x;
-
-    // intensity centroid over the radius-15 disc
+    __syncthreads();
     // umax[|v|] = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3} (:454-469), 4 bits each
     const unsigned long long umax_nib = 0x3689ABCDDEEEFFFFull;
-    int m10 = 0, m01 = 0;
-    {
-        const uint8_t *c0 = pyr + center;
+    for (int j = 0; j < DESC_KPB / 4; ++j) {
+        const int kp = wv * (DESC_KPB / 4) + j;
+        if (s_level[kp] < 0) continue;
+        const uint8_t *c0 = pyr + s_center[kp];
+        const int stride = s_stride[kp];
+        int m10 = 0, m01 = 0;
         const int u = (lane & 31) - 15, half = lane >> 5;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -654,46 +746,76 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             if (v <= 15 && (lane & 31) < 31) {
                 const int au = u < 0 ? -u : u;
                 if (au <= (int)((umax_nib >> (4 * av)) & 15ull)) {
-                    const int val = c0[v * lv.stride + u];
+                    const int val = c0[v * stride + u];
                     m10 += u * val;
                     m01 += v * val;
                 }
             }
         }
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
+        if (lane == 0) { s_m10[kp] = m10; s_m01[kp] = m01; }
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = orbx_fast_atan2((float)m01, (float)m10);
-
-    // steered BRIEF: lane i evaluates tests 4i..4i+3
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    orbx_sincos_f32(angle * factorPI, &b, &a); // a = cos, b = sin
-    const uint8_t *cb = blur + center;
-    unsigned nib = 0;
+    __syncthreads();
+    if (tid < DESC_KPB && s_level[tid] >= 0) {
+        const float angle = orbx_fast_atan2((float)s_m01[tid], (float)s_m10[tid]);
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        float a, b;
+        orbx_sincos_f32(angle * factorPI, &b, &a); // a = cos, b = sin
+        s_angle[tid] = angle; s_cos[tid] = a; s_sin[tid] = b;
+    }
+    __syncthreads();
+    // steered BRIEF: lane i evaluates tests 4i..4i+3 of its wave's current keypoint.
+    // The 37x37 blurred patch (|offset| <= 18) is staged in LDS with aligned dword
+    // loads first: the 512 sample points are scattered over ~37 rows, and gathering
+    // them straight from global memory costs ~30 cache-line requests per load.
+    float px[8], py[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const signed char *pp = c_pattern + 16 * lane + 4 * t;
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-        const int t0 = cb[orbx_cvround(x0 * b + y0 * a) * lv.stride + orbx_cvround(x0 * a - y0 * b)];
-        const int t1 = cb[orbx_cvround(x1 * b + y1 * a) * lv.stride + orbx_cvround(x1 * a - y1 * b)];
-        nib |= (unsigned)(t0 < t1) << t;
+        px[2 * t] = (float)pp[0]; py[2 * t] = (float)pp[1]; px[2 * t + 1] = (float)pp[2]; py[2 * t + 1] = (float)pp[3];
     }
-    unsigned byte = nib | (__shfl_down(nib, 1) << 4);                     // even lanes
-    unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
-    const size_t o = (size_t)f * cap + kidx;
-    if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
-    if (lane == 0) {
-        orbx_keypoint kp;
-        kp.x = (float)x;
-        kp.y = (float)y;
-        if (level != 0) { kp.x *= lv.scale; kp.y *= lv.scale; }
-        kp.size = (float)lv.patch;
-        kp.angle = angle;
-        kp.response = (float)(pk & 0xffu);
-        kp.octave = level;
-        kp.class_id = -1;
-        kps[o] = kp;
+    constexpr int PR = 18, PW = 12; // patch radius, dwords per staged row (48 bytes)
+    uint32_t *patch = s_patch[wv];
+    for (int j = 0; j < DESC_KPB / 4; ++j) {
+        const int kp = wv * (DESC_KPB / 4) + j;
+        const int level = s_level[kp];
+        if (level < 0) continue;
+        const float a = s_cos[kp], b = s_sin[kp];
+        const int stride = s_stride[kp];
+        const unsigned long long c = s_center[kp];
+        const int shift = (int)((c - PR) & 3ull);                // bytes between the aligned start and x-18
+        const uint8_t *row0 = blur + (c - PR - shift) - (ptrdiff_t)PR * stride;
+        for (int i = lane; i < (2 * PR + 1) * PW; i += 64) {
+            const int r = i / PW, w = i - r * PW;
+            patch[i] = *reinterpret_cast<const uint32_t *>(row0 + (ptrdiff_t)r * stride + 4 * w);
+        }
+        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR + shift; // patch centre
+        unsigned nib = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int t0 = pc[orbx_cvround(px[2 * t] * b + py[2 * t] * a) * (PW * 4) + orbx_cvround(px[2 * t] * a - py[2 * t] * b)];
+            const int t1 = pc[orbx_cvround(px[2 * t + 1] * b + py[2 * t + 1] * a) * (PW * 4) + orbx_cvround(px[2 * t + 1] * a - py[2 * t + 1] * b)];
+            nib |= (unsigned)(t0 < t1) << t;
+        }
+        const unsigned byte = nib | (__shfl_down(nib, 1) << 4); // even lanes
+        const unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
+        const size_t o = (size_t)f * cap + kbase + kp;
+        if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
+        if (lane == 0) {
+            const LevelInfo lv = L[level];
+            const uint32_t pk = s_pk[kp];
+            orbx_keypoint k;
+            k.x = (float)((int)((pk >> 8) & 0xfffu) + MIN_BORDER);
+            k.y = (float)((int)(pk >> 20) + MIN_BORDER);
+            if (level != 0) { k.x *= lv.scale; k.y *= lv.scale; }
+            k.size = (float)lv.patch;
+            k.angle = s_angle[kp];
+            k.response = (float)(pk & 0xffu);
+            k.octave = level;
+            k.class_id = -1;
+            kps[o] = k;
+        }
     }
 }
 
@@ -715,7 +837,7 @@ struct orbx_extractor {
     std::vector<BlurTile> tiles;
     size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
     int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
-    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, oct_lds = 0;
+    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, oct_lds = 0, oct_kcap = 0;
 
     hipStream_t stream = nullptr;
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_in = nullptr;
@@ -958,12 +1080,12 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
     }
     ex->NC = maxN + 8;
-    ex->TS = (maxcw + 3 + 3) & ~3; // + up to 3 bytes of alignment shift
+    ex->TS = ex->SS = (maxcw + 3 <= 64) ? 64 : 80; // + up to 3 bytes of alignment shift; zone <= 63
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
-    ex->SS = maxcw - 6 + 2;
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 16;
-    ex->oct_lds = (int)sizeof(int) * (OCT_T + ex->maxcells + 1 + 22 * ex->NC) + 64;
+    ex->oct_kcap = 4096;
+    ex->oct_lds = (int)sizeof(int) * (8 + ex->maxcells + 1 + 21 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     const size_t B = (size_t)batch;
@@ -973,6 +1095,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ORBX_HIP(hipMalloc(&ex->d_lv, sizeof(LevelInfo) * MAXL));
     ORBX_HIP(hipMalloc(&ex->d_cells, sizeof(CellInfo) * ex->cells.size()));
     ORBX_HIP(hipMalloc(&ex->d_tiles, sizeof(BlurTile) * ex->tiles.size()));
+
     ORBX_HIP(hipMalloc(&ex->d_xt, sizeof(int2) * (xt.size() + 1)));
     ORBX_HIP(hipMalloc(&ex->d_yt, sizeof(int4) * (yt.size() + 1)));
     ORBX_HIP(hipMalloc(&ex->d_cell_count, sizeof(int) * ex->cells_per_frame * B));
@@ -1021,36 +1144,47 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     }
     const int nl = ex->nlevels;
     orbx::KernelProfiler &pf = ex->prof;
-    pf.begin(st);
     {
         const LevelInfo &l0 = ex->lv[0];
-        dim3 g((l0.stride / 4 + 63) / 64, l0.h + 2 * EDGE, batch);
-        hipLaunchKernelGGL(k_pyr_level0, g, dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr, ex->frame_bytes, l0);
-        pf.mark(0, st);
+        const int aligned = (((uintptr_t)d_img | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
+        dim3 g((l0.stride / 4 + 63) / 64, (l0.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+        pf.start(0, st);
+        hipLaunchKernelGGL(k_pyr_level0, g, dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr, ex->frame_bytes, l0, aligned);
+        pf.stop(0, st);
     }
     for (int l = 1; l < nl; l++) {
         const LevelInfo &lv = ex->lv[l];
-        dim3 g((lv.stride / 4 + 63) / 64, lv.h + 2 * EDGE, batch);
+        dim3 g((lv.stride / 4 + 63) / 64, (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+        pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
                            ex->d_xt + lv.xtab, ex->d_yt + lv.ytab);
-        pf.mark(1, st);
+        pf.stop(1, st);
     }
-    hipLaunchKernelGGL(k_fast_cells, dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
-                       ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                       ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->TS, ex->tile_bytes, ex->SS, ex->sc_bytes);
-    pf.mark(2, st);
+    pf.start(2, st);
+    if (ex->TS == 64)
+        hipLaunchKernelGGL((k_fast_cells<64, 64>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
+                           ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
+                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes);
+    else
+        hipLaunchKernelGGL((k_fast_cells<80, 80>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
+                           ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
+                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes);
+    pf.stop(2, st);
+    pf.start(3, st);
     hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
                        ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
                        ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
-                       ex->d_level_ncand, nl, ex->NC, ex->maxcells);
-    pf.mark(3, st);
+                       ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap);
+    pf.stop(3, st);
+    pf.start(4, st);
     hipLaunchKernelGGL(k_blur, dim3((unsigned)ex->tiles.size(), batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
                        ex->frame_bytes, ex->d_lv, ex->d_tiles, ex->taps[0], ex->taps[1], ex->taps[2], ex->taps[3]);
-    pf.mark(4, st);
-    hipLaunchKernelGGL(k_describe, dim3((ex->kcap + 3) / 4, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
+    pf.stop(4, st);
+    pf.start(5, st);
+    hipLaunchKernelGGL(k_describe, dim3((ex->kcap + DESC_KPB - 1) / DESC_KPB, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
                        ex->frame_bytes, ex->d_lv, nl, ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps,
                        ex->d_desc, ex->d_counts, ex->kcap);
-    pf.mark(5, st);
+    pf.stop(5, st);
     ORBX_HIP(hipGetLastError());
     ex->last_batch = batch;
     return ORBX_OK;
@@ -1062,7 +1196,7 @@ int orbx_profile_enable(orbx_extractor *ex, int on)
     static const char *names[6] = {"k_pyr_level0", "k_pyr_resize", "k_fast_cells", "k_octree", "k_blur", "k_describe"};
     for (int i = 0; i < 6; ++i) ex->prof.names[i] = names[i];
     ex->prof.reset();
-    ex->prof.on = on != 0;
+    ex->prof.mask = on < 0 ? 0xffffu : (unsigned)on;
     return ORBX_OK;
 }
 

@@ -160,7 +160,9 @@ class FEA2:
         return x, rel
 
     def profile(self, on):
-        check(self._L.fem_profile_enable(self._h, 1 if on else 0))
+        """on: False/0 = off, True = every kernel kind, int = bit mask of kinds
+        (k_fem_ke 1, k_fem_assemble 2, k_fem_spmv 4, k_fem_cg_update 8, k_fem_cg_dir 16)."""
+        check(self._L.fem_profile_enable(self._h, -1 if on is True else int(on)))
 
     def profile_read(self):
         names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); ln = (C.c_int64 * 16)(); nk = C.c_int(0)
