@@ -109,6 +109,15 @@ int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, uint8_t *out, i
 /* Same with the 19-px REFLECT_101 border: out[(h+38)][out_stride], width w+38. */
 int orbx_pyramid_level_padded(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:527-701) for every frame of the last
+ * batch extracted on `left` and `right` (two distinct handles with the same
+ * parameters, Frame.cc:78-81): row-band Hamming match (+-1 octave, disparity in
+ * [0, mbf/mb]), 11x11 L1 sub-pixel refinement on the keypoint's pyramid level,
+ * median cut.  Results stay on the device in the left handle; download returns
+ * mvuRight[n] / mvDepth[n] (-1 where unmatched) for one frame. */
+int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, float mbf, void *stream);
+int orbx_stereo_download(orbx_extractor *left, int frame, float *uRight, float *depth, int cap, int *n);
+
 /* Staged outputs for parity tests (no reference counterpart; they expose the
  * intermediate values the reference keeps in locals):
  *   blurred level image (GaussianBlur output, ORBextractor.cc:1093-1094),

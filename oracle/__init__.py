@@ -25,7 +25,7 @@ CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "fem_oracle.c", "orb_pattern_data.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "fem_oracle.c", "stereo_oracle.c", "orb_pattern_data.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -343,3 +343,28 @@ def fem_csr_matvec(rp, col, val, x):
     y = np.zeros_like(x)
     L.oracle_fem_csr_matvec(len(x), _p(rp), _p(col), _p(val), _p(x), _p(y))
     return y
+
+
+def stereo_matches(oL, oR, kL, dL, kR, dR, mb, mbf):
+    """Frame::ComputeStereoMatches on the CPU restatement; oL / oR are OrbOracle
+    objects that just extracted the left / right image (their pyramids are read)."""
+    L = lib()
+    nl = oL.nlevels
+    pl = [oL.level_padded(l) for l in range(nl)]
+    pr = [oR.level_padded(l) for l in range(nl)]
+    PP = C.c_void_p * nl
+    strides = np.array([p.shape[1] for p in pl], np.int32)
+    cols = np.array([oL.level_dims(l)[0] for l in range(nl)], np.int32)
+    pL = PP(*[p.ctypes.data + 19 * p.shape[1] + 19 for p in pl])
+    pR = PP(*[p.ctypes.data + 19 * p.shape[1] + 19 for p in pr])
+    sf = np.array(oL.scale_factors(), np.float32)
+    isf = (np.float32(1.0) / sf).astype(np.float32)
+    kL = np.ascontiguousarray(kL); kR = np.ascontiguousarray(kR)
+    dL = np.ascontiguousarray(dL, np.uint8); dR = np.ascontiguousarray(dR, np.uint8)
+    u = np.zeros(len(kL), np.float32); d = np.zeros(len(kL), np.float32)
+    L.oracle_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    nd = L.oracle_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), pL, pR, _p(strides), _p(cols),
+                                 oL.level_dims(0)[1], _p(sf), _p(isf), mb, mbf, _p(u), _p(d))
+    return u, d, nd

@@ -24,36 +24,12 @@
 #include <vector>
 
 #include "common.h"
+#include "orbx_internal.h"
 #include "orbx_math.h"
 
+using namespace orbx_detail;
+
 namespace {
-
-constexpr int EDGE = 19;  // EDGE_THRESHOLD, ORBextractor.cc:74
-constexpr int PADX = 32;  // left pad (bytes) of every pyramid row
-constexpr int MAXL = 16;
-constexpr int MIN_BORDER = EDGE - 3; // minBorderX/Y, ORBextractor.cc:773
-constexpr int OCT_T = 256;           // threads of k_octree
-constexpr int OCT_MAXN = 1023;       // largest per-level feature quota supported
-
-struct LevelInfo {
-    int w, h, stride, off; // inner size, row stride (bytes), offset of the padded block in a frame
-    int W, H;              // octree box = FAST region (maxBorder - minBorder)
-    int N;                 // mnFeaturesPerLevel[l]
-    int ncells, cell_base; // cell slots [cell_base, cell_base + ncells) of a frame
-    int key_base;          // first key slot of this level in a frame's key workspace
-    int sel_base;          // first slot of this level in a frame's selected-keypoint array
-    int nIni;
-    float hX;
-    float scale; // mvScaleFactor[l]
-    int patch;   // scaledPatchSize = int(31 * scale)
-    int xtab, ytab;
-};
-
-struct CellInfo {
-    short level, x0, y0, cw, ch, dx, dy, pad; // sub-image origin/size in level coords; pt offset
-    int cand_off;                             // first candidate slot of the cell in a frame
-    int cap;
-};
 
 __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
@@ -614,7 +590,6 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 }
 
 // --------------------------------------------------------------------- blur
-struct BlurTile { short level, x0, y0, pad; };
 
 
 // GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point:
@@ -822,39 +797,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 } // namespace
 
 // ======================================================================= host
-struct orbx_extractor {
-    orbx_params prm;
-    int nlevels;
-    float scale[MAXL], inv_scale[MAXL], sigma2[MAXL], inv_sigma2[MAXL];
-    int nfeat[MAXL];
-    int taps[4];
-    int kcap; // nfeatures + 3*nlevels
-
-    // geometry of the reserved workspace
-    int width = 0, height = 0, batch = 0;
-    LevelInfo lv[MAXL];
-    std::vector<CellInfo> cells;
-    std::vector<BlurTile> tiles;
-    size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
-    int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
-    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, oct_lds = 0, oct_kcap = 0;
-
-    hipStream_t stream = nullptr;
-    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_in = nullptr;
-    size_t in_bytes = 0;
-    LevelInfo *d_lv = nullptr;
-    CellInfo *d_cells = nullptr;
-    BlurTile *d_tiles = nullptr;
-    int2 *d_xt = nullptr;
-    int4 *d_yt = nullptr;
-    int *d_cell_count = nullptr, *d_level_count = nullptr, *d_level_ncand = nullptr, *d_counts = nullptr;
-    uint32_t *d_cands = nullptr, *d_kpos = nullptr, *d_sel = nullptr;
-    unsigned short *d_knode = nullptr;
-    uint8_t *d_kq = nullptr, *d_desc = nullptr;
-    orbx_keypoint *d_kps = nullptr;
-    int last_batch = 0;
-    orbx::KernelProfiler prof;
-};
 
 namespace {
 
@@ -940,6 +882,9 @@ int orbx_destroy(orbx_extractor *ex)
     if (!ex) return ORBX_OK;
     free_workspace(ex);
     if (ex->d_in) (void)hipFree(ex->d_in);
+    void *stp[] = {ex->d_st_key, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
+    for (void *q : stp)
+        if (q) (void)hipFree(q);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
     return ORBX_OK;

@@ -1,0 +1,84 @@
+// orbx_internal.h -- extractor state shared by the translation units that work
+// on an orbx_extractor's device-resident results (orbx_extract.hip, orbx_stereo.hip).
+#ifndef ORBX_INTERNAL_H
+#define ORBX_INTERNAL_H
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace orbx_detail {
+
+constexpr int EDGE = 19;  // EDGE_THRESHOLD, ORBextractor.cc:74
+constexpr int PADX = 32;  // left pad (bytes) of every pyramid row
+constexpr int MAXL = 16;
+constexpr int MIN_BORDER = EDGE - 3; // minBorderX/Y, ORBextractor.cc:773
+constexpr int OCT_T = 256;           // threads of k_octree
+constexpr int OCT_MAXN = 1023;       // largest per-level feature quota supported
+
+struct LevelInfo {
+    int w, h, stride, off; // inner size, row stride (bytes), offset of the padded block in a frame
+    int W, H;              // octree box = FAST region (maxBorder - minBorder)
+    int N;                 // mnFeaturesPerLevel[l]
+    int ncells, cell_base; // cell slots [cell_base, cell_base + ncells) of a frame
+    int key_base;          // first key slot of this level in a frame's key workspace
+    int sel_base;          // first slot of this level in a frame's selected-keypoint array
+    int nIni;
+    float hX;
+    float scale; // mvScaleFactor[l]
+    int patch;   // scaledPatchSize = int(31 * scale)
+    int xtab, ytab;
+};
+
+struct CellInfo {
+    short level, x0, y0, cw, ch, dx, dy, pad; // sub-image origin/size in level coords; pt offset
+    int cand_off;                             // first candidate slot of the cell in a frame
+    int cap;
+};
+
+struct BlurTile { short level, x0, y0, pad; };
+
+} // namespace orbx_detail
+
+struct orbx_extractor {
+    orbx_params prm;
+    int nlevels;
+    float scale[orbx_detail::MAXL], inv_scale[orbx_detail::MAXL], sigma2[orbx_detail::MAXL], inv_sigma2[orbx_detail::MAXL];
+    int nfeat[orbx_detail::MAXL];
+    int taps[4];
+    int kcap; // nfeatures + 3*nlevels
+
+    // geometry of the reserved workspace
+    int width = 0, height = 0, batch = 0;
+    orbx_detail::LevelInfo lv[orbx_detail::MAXL];
+    std::vector<orbx_detail::CellInfo> cells;
+    std::vector<orbx_detail::BlurTile> tiles;
+    size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
+    int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
+    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, oct_lds = 0, oct_kcap = 0;
+
+    hipStream_t stream = nullptr;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_in = nullptr;
+    size_t in_bytes = 0;
+    orbx_detail::LevelInfo *d_lv = nullptr;
+    orbx_detail::CellInfo *d_cells = nullptr;
+    orbx_detail::BlurTile *d_tiles = nullptr;
+    int2 *d_xt = nullptr;
+    int4 *d_yt = nullptr;
+    int *d_cell_count = nullptr, *d_level_count = nullptr, *d_level_ncand = nullptr, *d_counts = nullptr;
+    uint32_t *d_cands = nullptr, *d_kpos = nullptr, *d_sel = nullptr;
+    unsigned short *d_knode = nullptr;
+    uint8_t *d_kq = nullptr, *d_desc = nullptr;
+    orbx_keypoint *d_kps = nullptr;
+    int last_batch = 0;
+    // stereo (orbx_stereo.hip): results live in the LEFT handle
+    unsigned *d_st_key = nullptr;
+    float *d_uright = nullptr, *d_depth = nullptr, *d_st_scale = nullptr;
+    int *d_st_sad = nullptr, *d_st_nvalid = nullptr;
+    int st_batch = 0;
+    orbx::KernelProfiler prof;
+};
+
+#endif // ORBX_INTERNAL_H

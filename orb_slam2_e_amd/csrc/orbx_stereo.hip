@@ -1,0 +1,269 @@
+// orbx_stereo.hip -- Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the
+// device-resident results of a left and a right orbx_extractor.
+//
+//   k_stereo_hamming  row-band / octave / disparity gating + best Hamming match (:537-610)
+//   k_stereo_refine   11x11 L1 correlation over 11 shifts on the left keypoint's
+//                     pyramid level, parabola sub-pixel fit, depth (:612-683)
+//   k_stereo_median   median cut 1.5*1.4*median of the correlation distances (:687-700)
+//
+// Candidate order only matters through "strict <, first index wins", which the
+// packed key (dist<<16 | iR) minimum reproduces.  The L1 distances are sums of
+// integer-valued floats (exact), so everything up to the parabola is integer work.
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "orbx_internal.h"
+
+using namespace orbx_detail;
+
+namespace {
+
+constexpr int ST_T = 256;   // right keypoints staged per step
+struct RightKp { short minr, maxr; int octave; float x; };
+
+__device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// One lane per left keypoint; right keypoints staged through LDS 256 at a time.
+__global__ __launch_bounds__(ST_T) void k_stereo_hamming(const orbx_keypoint *__restrict__ kpL, const uint8_t *__restrict__ dL,
+                                                         const int *__restrict__ cntL, const orbx_keypoint *__restrict__ kpR,
+                                                         const uint8_t *__restrict__ dR, const int *__restrict__ cntR,
+                                                         int cap, const float *__restrict__ scaleFactors, int nRows,
+                                                         float maxD, unsigned *__restrict__ best_key)
+{
+    __shared__ RightKp s_kp[ST_T];
+    __shared__ uint4 s_d[ST_T * 2];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int N = min(cntL[f], cap), Nr = min(cntR[f], cap);
+    if (blockIdx.x * ST_T >= N) return;
+    const int iL = blockIdx.x * ST_T + tid;
+    const bool act = iL < N;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    int levelL = 0, row = -100000;
+    float minU = 0.f, maxU = -1.f;
+    if (act) {
+        const orbx_keypoint k = kpL[(size_t)f * cap + iL];
+        const uint4 *A = reinterpret_cast<const uint4 *>(dL + ((size_t)f * cap + iL) * 32);
+        a0 = A[0]; a1 = A[1];
+        levelL = k.octave;
+        row = (int)k.y;              // vRowIndices[vL], :569
+        minU = k.x - maxD;           // :574
+        maxU = k.x - 0.0f;           // :575 (minD = 0)
+        if (row < 0 || row >= nRows || maxU < 0) row = -100000; // no candidates (:571-578)
+    }
+    unsigned key = 95u << 16;        // bestDist = TH_HIGH, bestIdxR = 0 (:580-581)
+    for (int j0 = 0; j0 < Nr; j0 += ST_T) {
+        __syncthreads();
+        if (j0 + tid < Nr) {
+            const orbx_keypoint k = kpR[(size_t)f * cap + j0 + tid];
+            const float r = 2.0f * scaleFactors[k.octave]; // :546
+            RightKp rk;
+            rk.maxr = (short)(int)ceilf(k.y + r);
+            rk.minr = (short)(int)floorf(k.y - r);
+            rk.octave = k.octave; rk.x = k.x;
+            s_kp[tid] = rk;
+            const uint4 *B = reinterpret_cast<const uint4 *>(dR + ((size_t)f * cap + j0 + tid) * 32);
+            s_d[2 * tid] = B[0]; s_d[2 * tid + 1] = B[1];
+        }
+        __syncthreads();
+        const int nt = min(ST_T, Nr - j0);
+        for (int j = 0; j < nt; ++j) {
+            const RightKp rk = s_kp[j];
+            const bool ok = row >= rk.minr && row <= rk.maxr && rk.octave >= levelL - 1 && rk.octave <= levelL + 1 &&
+                            rk.x >= minU && rk.x <= maxU;
+            if (ok) {
+                const unsigned k2 = ((unsigned)hamming256(a0, a1, s_d[2 * j], s_d[2 * j + 1]) << 16) | (unsigned)(j0 + j);
+                key = k2 < key ? k2 : key; // dist<bestDist in iR order == min over (dist, iR), :598-602
+            }
+        }
+    }
+    if (act) best_key[(size_t)f * cap + iL] = key;
+}
+
+// One wave per left keypoint that found a descriptor match below thOrbDist.
+__global__ __launch_bounds__(256) void k_stereo_refine(const orbx_keypoint *__restrict__ kpL, const int *__restrict__ cntL,
+                                                       const orbx_keypoint *__restrict__ kpR, int cap,
+                                                       const unsigned *__restrict__ best_key,
+                                                       const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
+                                                       size_t frame_bytes, const LevelInfo *__restrict__ L,
+                                                       const float *__restrict__ scaleFactors, const float *__restrict__ invScaleFactors,
+                                                       float maxD, float mbf, float *__restrict__ uRight, float *__restrict__ depth,
+                                                       int *__restrict__ sad)
+{
+    __shared__ uint8_t s_l[4][11 * 11];
+    __shared__ uint8_t s_r[4][11 * 21];
+    const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iL = blockIdx.x * 4 + wv;
+    const int N = min(cntL[f], cap);
+    if (iL >= cap) return;
+    const size_t o = (size_t)f * cap + iL;
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    const int thOrbDist = (95 + 45) / 2; // (TH_HIGH + TH_LOW) / 2, :532
+    if (iL < N) {
+        const unsigned key = best_key[o];
+        if ((int)(key >> 16) < thOrbDist) { // wave-uniform
+            const orbx_keypoint kl = kpL[o];
+            const int level = kl.octave;
+            const float uL = kl.x;
+            const float uR0 = kpR[(size_t)f * cap + (key & 0xffffu)].x;
+            const float sf = invScaleFactors[level];
+            const float scaleduL = roundf(kl.x * sf), scaledvL = roundf(kl.y * sf), scaleduR0 = roundf(uR0 * sf);
+            const LevelInfo lv = L[level];
+            const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
+            if (!(iniu < 0 || endu >= (float)lv.w)) {
+                const int xl = (int)scaleduL, yl = (int)scaledvL, xr = (int)scaleduR0;
+                const size_t base = (size_t)f * frame_bytes + lv.off + (size_t)(yl - 5 + EDGE) * lv.stride + PADX;
+                for (int i = lane; i < 121; i += 64) {
+                    const int dy = i / 11, dx = i - 11 * dy;
+                    s_l[wv][i] = pyrL[base + (size_t)dy * lv.stride + xl - 5 + dx];
+                }
+                for (int i = lane; i < 231; i += 64) {
+                    const int dy = i / 21, dx = i - 21 * dy;
+                    s_r[wv][i] = pyrR[base + (size_t)dy * lv.stride + xr - 10 + dx];
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                // lanes 0..10: L1 distance for incR = lane - 5 (IL, IR minus their centre pixels, :625-645)
+                float dist = 0.0f;
+                if (lane < 11) {
+                    const int cL = s_l[wv][5 * 11 + 5], cR = s_r[wv][5 * 21 + 5 + lane];
+                    int acc = 0;
+                    for (int dy = 0; dy < 11; ++dy)
+                        for (int dx = 0; dx < 11; ++dx) {
+                            const int a = (int)s_l[wv][dy * 11 + dx] - cL, b = (int)s_r[wv][dy * 21 + lane + dx] - cR;
+                            const int d = a - b;
+                            acc += d < 0 ? -d : d;
+                        }
+                    dist = (float)acc;
+                }
+                float vd[11];
+#pragma unroll
+                for (int k = 0; k < 11; ++k) vd[k] = __shfl(dist, k);
+                int bestDist = INT_MAX, bestincR = 0;
+#pragma unroll
+                for (int k = 0; k < 11; ++k)
+                    if (vd[k] < (float)bestDist) { bestDist = (int)vd[k]; bestincR = k - 5; }
+                if (!(bestincR == -5 || bestincR == 5)) {
+                    float d1 = vd[0], d2 = vd[0], d3 = vd[0];
+#pragma unroll
+                    for (int k = 1; k < 10; ++k)
+                        if (k - 5 == bestincR) { d1 = vd[k - 1]; d2 = vd[k]; d3 = vd[k + 1]; }
+                    const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2)); // :666
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = scaleFactors[level] * ((float)scaleduR0 + (float)bestincR + deltaR);
+                        float disparity = uL - bestuR;
+                        if (disparity >= 0.0f && disparity < maxD) {
+                            if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+                            out_d = mbf / disparity;
+                            out_u = bestuR;
+                            out_sad = bestDist;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uRight[o] = out_u; depth[o] = out_d; sad[o] = out_sad; }
+}
+
+// Median cut (:687-700): median = the (nd/2)-th smallest correlation distance,
+// everything >= 1.5f*1.4f*median is discarded.  One block per frame; k-th smallest
+// by bisection on the value.
+__global__ __launch_bounds__(256) void k_stereo_median(const int *__restrict__ cntL, int cap, const int *__restrict__ sad,
+                                                       float *__restrict__ uRight, float *__restrict__ depth, int *__restrict__ nvalid)
+{
+    __shared__ int s_cnt[4];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int N = min(cntL[f], cap);
+    const int *sd = sad + (size_t)f * cap;
+    auto block_count = [&](int limit) { // #valid with sad <= limit
+        int c = 0;
+        for (int i = tid; i < N; i += 256) c += sd[i] >= 0 && sd[i] <= limit;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        __syncthreads();
+        if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+        __syncthreads();
+        return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    };
+    const int nd = block_count(INT_MAX);
+    if (tid == 0 && nvalid) nvalid[f] = nd;
+    if (nd == 0) return;
+    const int k = nd / 2; // vDistIdx[vDistIdx.size()/2]
+    int lo = 0, hi = 1 << 20; // smallest v with count(sad <= v) >= k+1
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (block_count(mid) >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    const float median = (float)lo;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = tid; i < N; i += 256)
+        if (sd[i] >= 0 && !((float)sd[i] < thDist)) { uRight[(size_t)f * cap + i] = -1.0f; depth[(size_t)f * cap + i] = -1.0f; }
+}
+
+} // namespace
+
+extern "C" {
+
+int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, float mbf, void *stream_)
+{
+    if (!left || !right || !left->d_kps || !right->d_kps) ORBX_FAIL(ORBX_ERR_ARG, "extract on both handles first");
+    if (left->last_batch != right->last_batch || left->width != right->width || left->height != right->height ||
+        left->nlevels != right->nlevels || left->kcap != right->kcap || left->frame_bytes != right->frame_bytes)
+        ORBX_FAIL(ORBX_ERR_ARG, "left / right extractors differ in geometry or batch");
+    if (!(mb > 0.f) || !(mbf > 0.f)) ORBX_FAIL(ORBX_ERR_ARG, "bad baseline");
+    ORBX_NEED_DEVICE();
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : left->stream;
+    const int B = left->last_batch, cap = left->kcap;
+    if (!left->d_st_key || left->st_batch < B) {
+        if (left->d_st_key) { (void)hipFree(left->d_st_key); (void)hipFree(left->d_uright); (void)hipFree(left->d_depth); (void)hipFree(left->d_st_sad); (void)hipFree(left->d_st_scale); (void)hipFree(left->d_st_nvalid); }
+        ORBX_HIP(hipMalloc(&left->d_st_key, sizeof(unsigned) * (size_t)cap * left->batch));
+        ORBX_HIP(hipMalloc(&left->d_uright, sizeof(float) * (size_t)cap * left->batch));
+        ORBX_HIP(hipMalloc(&left->d_depth, sizeof(float) * (size_t)cap * left->batch));
+        ORBX_HIP(hipMalloc(&left->d_st_sad, sizeof(int) * (size_t)cap * left->batch));
+        ORBX_HIP(hipMalloc(&left->d_st_nvalid, sizeof(int) * (size_t)left->batch));
+        ORBX_HIP(hipMalloc(&left->d_st_scale, sizeof(float) * 2 * MAXL));
+        float sc[2 * MAXL];
+        for (int i = 0; i < MAXL; ++i) { sc[i] = left->scale[i]; sc[MAXL + i] = left->inv_scale[i]; }
+        ORBX_HIP(hipMemcpy(left->d_st_scale, sc, sizeof(sc), hipMemcpyHostToDevice));
+        left->st_batch = left->batch;
+    }
+    // streams: results of both extractors must be complete before matching
+    if (st != left->stream) ORBX_HIP(hipStreamSynchronize(left->stream));
+    if (st != right->stream) ORBX_HIP(hipStreamSynchronize(right->stream));
+    const float maxD = mbf / mb; // :557-559
+    const int nRows = left->lv[0].h;
+    hipLaunchKernelGGL(k_stereo_hamming, dim3((cap + ST_T - 1) / ST_T, B), dim3(ST_T), 0, st, left->d_kps, left->d_desc,
+                       left->d_counts, right->d_kps, right->d_desc, right->d_counts, cap, left->d_st_scale, nRows, maxD,
+                       left->d_st_key);
+    hipLaunchKernelGGL(k_stereo_refine, dim3((cap + 3) / 4, B), dim3(256), 0, st, left->d_kps, left->d_counts, right->d_kps,
+                       cap, left->d_st_key, left->d_pyr, right->d_pyr, left->frame_bytes, left->d_lv, left->d_st_scale,
+                       left->d_st_scale + MAXL, maxD, mbf, left->d_uright, left->d_depth, left->d_st_sad);
+    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(256), 0, st, left->d_counts, cap, left->d_st_sad, left->d_uright,
+                       left->d_depth, left->d_st_nvalid);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_stereo_download(orbx_extractor *left, int frame, float *uRight, float *depth, int cap, int *n)
+{
+    if (!left || !left->d_uright || frame < 0 || frame >= left->last_batch || !n) ORBX_FAIL(ORBX_ERR_ARG, "no stereo results");
+    ORBX_HIP(hipDeviceSynchronize());
+    int cnt = 0;
+    ORBX_HIP(hipMemcpy(&cnt, left->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "buffer too small");
+    if (cnt > 0) {
+        if (uRight) ORBX_HIP(hipMemcpy(uRight, left->d_uright + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+        if (depth) ORBX_HIP(hipMemcpy(depth, left->d_depth + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+} // extern "C"

@@ -143,3 +143,16 @@ class ORBextractor:
         n = C.c_int(0)
         check(self._L.orbx_debug_level_keypoints(self._h, frame, level, _p(out), self.capacity, C.byref(n)))
         return out[:n.value].copy()
+
+
+def ComputeStereoMatches(left, right, mb, mbf, frame=0):
+    """Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the last results of two
+    ORBextractor objects (left / right images extracted with the same parameters).
+    Returns (mvuRight, mvDepth) for `frame`; -1 where unmatched."""
+    L = left._L
+    L.orbx_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    check(L.orbx_stereo_match(left._h, right._h, mb, mbf, None))
+    u = np.zeros(left.capacity, np.float32); d = np.zeros(left.capacity, np.float32)
+    n = C.c_int(0)
+    check(L.orbx_stereo_download(left._h, frame, _p(u), _p(d), left.capacity, C.byref(n)))
+    return u[:n.value].copy(), d[:n.value].copy()

@@ -96,3 +96,17 @@ def synth_tet_batch(nmesh, ncell=12, seed=11):
     base, tets, fixed, load = synth_tet_mesh(ncell, seed)
     nodes = np.stack([synth_tet_mesh(ncell, seed + 1000 * m)[0] for m in range(nmesh)]) if nmesh > 1 else base[None]
     return nodes, tets, fixed, load
+
+
+def synth_stereo_pair(k=0, w=1242, h=375, dmin=2.0, dmax=60.0):
+    """Config-5 input: KITTI-shaped pair; right = left warped by a smooth
+    synthetic disparity field in [dmin, dmax] px (right(x) = left(x + d(x, y)), bilinear)."""
+    left = synth_frame(500 + k, w, h)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = dmin + (dmax - dmin) * (0.5 + 0.25 * np.sin(xx / 97.0 + 0.3 * k) + 0.25 * np.cos(yy / 61.0))
+    xs = np.clip(xx + d, 0, w - 1.001)
+    x0 = np.floor(xs).astype(np.int64); fx = xs - x0
+    rows = np.arange(h)[:, None]
+    L = left.astype(np.float64)
+    right = (1 - fx) * L[rows, x0] + fx * L[rows, x0 + 1]
+    return left, np.clip(np.rint(right), 0, 255).astype(np.uint8)

@@ -1,0 +1,49 @@
+"""GPU parity: Frame::ComputeStereoMatches (config 5, 1242x375 KITTI-shaped pair)
+through the C-ABI vs the CPU oracle.  mvuRight / mvDepth bit-exact (float bits)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from orb_slam2_e_amd import ComputeStereoMatches, ORBextractor
+from orb_slam2_e_amd.synth import synth_stereo_pair
+
+PARAMS = (2000, 1.2, 8, 20, 7)           # Examples/Stereo/KITTI00-02.yaml:38-51
+FX, BF = 718.856, 386.1448               # KITTI00-02.yaml:8,25
+
+
+def _run(k, shape=(375, 1242)):
+    left, right = synth_stereo_pair(k, w=shape[1], h=shape[0])
+    oL, oR = oracle.OrbOracle(*PARAMS), oracle.OrbOracle(*PARAMS)
+    kL, dL = oL.extract(left); kR, dR = oR.extract(right)
+    mb = np.float32(BF) / np.float32(FX)
+    ou, od, nd = oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(BF))
+    eL, eR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+    gkL, gdL = eL(left); gkR, gdR = eR(right)
+    assert np.array_equal(gdL, dL) and np.array_equal(gdR, dR)
+    gu, gd = ComputeStereoMatches(eL, eR, mb, np.float32(BF))
+    return ou, od, nd, gu, gd
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_stereo_matches_bit_exact(k):
+    ou, od, nd, gu, gd = _run(k)
+    assert nd > 200                                  # the synthetic pair really matches
+    assert (ou >= 0).sum() > 150
+    assert np.array_equal(gu.view(np.uint32), ou.view(np.uint32))
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_stereo_depth_consistent_with_disparity():
+    ou, od, nd, gu, gd = _run(2)
+    ok = gu >= 0
+    assert ok.sum() > 100
+    # depth = mbf / (uL - uR) within float rounding; disparities inside the synthetic range
+    assert np.all(gd[ok] > 0) and np.all(gd[ok] <= BF / 0.009)
+
+
+def test_stereo_small_image():
+    ou, od, nd, gu, gd = _run(3, shape=(240, 640))
+    assert np.array_equal(gu.view(np.uint32), ou.view(np.uint32))
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
