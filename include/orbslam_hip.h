@@ -154,6 +154,22 @@ int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB,
 int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB,
                           const int32_t *cand_off, const int32_t *cand_idx,
                           int32_t *best, int32_t *second, int32_t *idx);
+/* Inner loop of ORBmatcher::SearchForTriangulation (ORBmatcher.cc:892-990) with
+ * CheckDistEpipolarLine (:341-358): per keypoint of KF1 (skipped if it owns a
+ * MapPoint, or is mono while only_stereo), scan its BoW-node candidates of KF2 in
+ * member order (CSR lists built by the host-side FeatureVector co-iteration):
+ * dist <= TH_LOW && dist <= bestDist (non-strict), epipole distance^2 >=
+ * 100*scaleFactor[octave2] unless one side is stereo, epipolar line d^2 <
+ * 3.84*sigma2[octave2].  F12 row-major 3x3 float (LocalMapping::ComputeF12),
+ * (ex, ey) the epipole in image 2.  match12[i] = index in KF2 or -1; best_dist[i].
+ * The rotation histogram and the pair list stay on the host (ORBmatcher.cc:992-1023). */
+int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbx_keypoint *kps2,
+                             const uint8_t *desc2, int n2, const int32_t *cand_off, const int32_t *cand_idx,
+                             const uint8_t *has_mappoint1, const uint8_t *has_mappoint2, const uint8_t *stereo1,
+                             const uint8_t *stereo2, int only_stereo, const float *F12, float ex, float ey,
+                             const float *scale_factors2, const float *level_sigma2, int nlevels, int32_t *match12,
+                             int32_t *best_dist);
+
 /* Acceptance test of ORBmatcher.cc:674-676: best<=th && best<(float)second*nnratio.
  * match12[i] = idx or -1; *nmatches = accepted rows.  Host arrays. */
 int orbm_match_filter(int nA, const int32_t *best, const int32_t *second, const int32_t *idx,

@@ -368,3 +368,22 @@ def stereo_matches(oL, oR, kL, dL, kR, dR, mb, mbf):
     nd = L.oracle_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), pL, pR, _p(strides), _p(cols),
                                  oL.level_dims(0)[1], _p(sf), _p(isf), mb, mbf, _p(u), _p(d))
     return u, d, nd
+
+
+def match_triangulation(kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, has_mp2, stereo1, stereo2,
+                        F12, ex, ey, scale_factors2, level_sigma2, only_stereo=False):
+    L = lib()
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    off = np.ascontiguousarray(cand_off, np.int32); ci = np.ascontiguousarray(cand_idx, np.int32)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    m1, m2, s1, s2 = u8(has_mp1), u8(has_mp2), u8(stereo1), u8(stereo2)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
+    m12 = np.zeros(len(kps1), np.int32); bd = np.zeros(len(kps1), np.int32)
+    L.oracle_match_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_match_triangulation(_p(kps1), _p(d1), len(kps1), _p(kps2), _p(d2), _p(off), _p(ci), _p(m1), _p(m2), _p(s1),
+                                 _p(s2), 1 if only_stereo else 0, _p(F), ex, ey, _p(sc), _p(sg), _p(m12), _p(bd))
+    return m12, bd

@@ -189,3 +189,52 @@ int oracle_grid_features_in_area(const oracle_grid *g, const float *xy, const in
         }
     return n;
 }
+
+/* ---- SearchForTriangulation inner loop, ORBmatcher.cc:892-990 + CheckDistEpipolarLine
+ * :341-358.  The BoW-node co-iteration (host, DBoW2) is given as per-query candidate
+ * lists in member order.  Note vbMatched2 is never set in the reference, so queries
+ * are independent; `dist>bestDist` (non-strict) lets a later equal candidate win. */
+typedef struct { float x, y, size, angle, response; int octave, class_id; } tri_kp;
+
+static int check_dist_epipolar_line(const tri_kp *kp1, const tri_kp *kp2, const float *F12, const float *levelSigma2)
+{
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    float dsqr;
+    if (den == 0) return 0;
+    dsqr = num * num / den;
+    return dsqr < 3.84 * levelSigma2[kp2->octave];
+}
+
+void oracle_match_triangulation(const tri_kp *kps1, const uint8_t *d1, int n1, const tri_kp *kps2, const uint8_t *d2,
+                                const int *cand_off, const int *cand_idx, const uint8_t *hasmp1, const uint8_t *hasmp2,
+                                const uint8_t *stereo1, const uint8_t *stereo2, int bOnlyStereo, const float *F12,
+                                float ex, float ey, const float *scaleFactors2, const float *levelSigma2,
+                                int *match12, int *bestdist)
+{
+    const int TH_LOW = 45;
+    int i, k;
+    for (i = 0; i < n1; i++) {
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        match12[i] = -1; bestdist[i] = TH_LOW;
+        if (hasmp1[i]) continue;
+        if (bOnlyStereo && !stereo1[i]) continue;
+        for (k = cand_off[i]; k < cand_off[i + 1]; k++) {
+            const int idx2 = cand_idx[k];
+            int dist;
+            if (hasmp2[idx2]) continue;
+            if (bOnlyStereo && !stereo2[idx2]) continue;
+            dist = oracle_descriptor_distance(d1 + 32 * (size_t)i, d2 + 32 * (size_t)idx2);
+            if (dist > TH_LOW || dist > bestDist) continue;
+            if (!stereo1[i] && !stereo2[idx2]) {
+                const float distex = ex - kps2[idx2].x, distey = ey - kps2[idx2].y;
+                if (distex * distex + distey * distey < 100 * scaleFactors2[kps2[idx2].octave]) continue;
+            }
+            if (check_dist_epipolar_line(&kps1[i], &kps2[idx2], F12, levelSigma2)) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        match12[i] = bestIdx2; bestdist[i] = bestDist;
+    }
+}

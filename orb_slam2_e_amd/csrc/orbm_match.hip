@@ -172,6 +172,59 @@ __global__ __launch_bounds__(MT) void k_match_cands(const uint4 *__restrict__ A,
     best_o[i] = best; second_o[i] = second; idx_o[i] = idx;
 }
 
+// SearchForTriangulation inner loop (ORBmatcher.cc:892-990) + CheckDistEpipolarLine
+// (:341-358): one query per lane over its BoW-node candidate list, in member order.
+// `dist>bestDist` is non-strict in the reference, so a later candidate with an equal
+// distance replaces the earlier one; vbMatched2 is never set there, so queries are
+// independent.
+struct TriParams { float F12[9]; float ex, ey; int only_stereo; };
+__device__ __forceinline__ int popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+__global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__restrict__ kps1, const uint4 *__restrict__ A, int nA,
+                                                     const orbx_keypoint *__restrict__ kps2, const uint4 *__restrict__ B,
+                                                     const int *__restrict__ off, const int *__restrict__ cidx,
+                                                     const uint8_t *__restrict__ hasmp1, const uint8_t *__restrict__ hasmp2,
+                                                     const uint8_t *__restrict__ stereo1, const uint8_t *__restrict__ stereo2,
+                                                     TriParams tp, const float *__restrict__ scale2, const float *__restrict__ sigma2,
+                                                     int *__restrict__ match12, int *__restrict__ bestdist)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i >= nA) return;
+    int bestDist = 45, bestIdx2 = -1; // TH_LOW
+    if (!hasmp1[i] && !(tp.only_stereo && !stereo1[i])) {
+        const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
+        const orbx_keypoint kp1 = kps1[i];
+        // epipolar line in the second image l = x1' F12 = [a b c]
+        const float a = kp1.x * tp.F12[0] + kp1.y * tp.F12[3] + tp.F12[6];
+        const float b = kp1.x * tp.F12[1] + kp1.y * tp.F12[4] + tp.F12[7];
+        const float c = kp1.x * tp.F12[2] + kp1.y * tp.F12[5] + tp.F12[8];
+        const float den = a * a + b * b;
+        const bool st1 = stereo1[i] != 0;
+        for (int k = off[i]; k < off[i + 1]; ++k) {
+            const int j = cidx[k];
+            if (hasmp2[j]) continue;
+            const bool st2 = stereo2[j] != 0;
+            if (tp.only_stereo && !st2) continue;
+            const int dist = popc256(a0, a1, B[2 * j], B[2 * j + 1]);
+            if (dist > 45 || dist > bestDist) continue;
+            const orbx_keypoint kp2 = kps2[j];
+            if (!st1 && !st2) {
+                const float distex = tp.ex - kp2.x, distey = tp.ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * scale2[kp2.octave]) continue;
+            }
+            const float num = a * kp2.x + b * kp2.y + c;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if ((double)dsqr < 3.84 * (double)sigma2[kp2.octave]) { bestIdx2 = j; bestDist = dist; }
+        }
+    }
+    match12[i] = bestIdx2;
+    bestdist[i] = bestDist;
+}
+
 __global__ __launch_bounds__(MT) void k_hamming_matrix(const uint4 *__restrict__ A, int nA, const uint4 *__restrict__ B,
                                                        int nB, unsigned short *__restrict__ out)
 {
@@ -261,6 +314,62 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB, co
     ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(second, ob + nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(idx, ob + 2 * nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbx_keypoint *kps2,
+                             const uint8_t *desc2, int n2, const int32_t *cand_off, const int32_t *cand_idx,
+                             const uint8_t *has_mappoint1, const uint8_t *has_mappoint2, const uint8_t *stereo1,
+                             const uint8_t *stereo2, int only_stereo, const float *F12, float ex, float ey,
+                             const float *scale_factors2, const float *level_sigma2, int nlevels, int32_t *match12,
+                             int32_t *best_dist)
+{
+    if (n1 < 0 || n2 < 0 || nlevels < 1 || (n1 && (!kps1 || !desc1 || !has_mappoint1 || !stereo1 || !match12 || !best_dist)) ||
+        !cand_off || !F12 || !scale_factors2 || !level_sigma2)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (n1 == 0) return ORBX_OK;
+    const int nc = cand_off[n1];
+    if (nc < 0 || (nc && (!cand_idx || !kps2 || !desc2 || !has_mappoint2 || !stereo2))) ORBX_FAIL(ORBX_ERR_ARG, "bad candidate lists");
+    for (int k = 0; k < nc; ++k)
+        if (cand_idx[k] < 0 || cand_idx[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "candidate index out of range");
+    for (int i = 0; i < n1; ++i)
+        if (cand_off[i] > cand_off[i + 1] || cand_off[i] < 0) ORBX_FAIL(ORBX_ERR_ARG, "candidate offsets not monotone");
+    for (int j = 0; j < n2; ++j)
+        if (kps2[j].octave < 0 || kps2[j].octave >= nlevels) ORBX_FAIL(ORBX_ERR_ARG, "octave out of range");
+    DevBuf k1, a, k2, b, doff, dci, m1, m2, s1, s2, sc, sg, o;
+    const size_t N2 = n2 ? n2 : 1;
+    if (k1.alloc(sizeof(orbx_keypoint) * n1) || a.alloc((size_t)32 * n1) || k2.alloc(sizeof(orbx_keypoint) * N2) ||
+        b.alloc((size_t)32 * N2) || doff.alloc(sizeof(int) * (n1 + 1)) || dci.alloc(sizeof(int) * nc) || m1.alloc(n1) ||
+        m2.alloc(N2) || s1.alloc(n1) || s2.alloc(N2) || sc.alloc(sizeof(float) * nlevels) || sg.alloc(sizeof(float) * nlevels) ||
+        o.alloc(sizeof(int) * 2 * (size_t)n1))
+        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemcpy(k1.p, kps1, sizeof(orbx_keypoint) * n1, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(a.p, desc1, (size_t)32 * n1, hipMemcpyHostToDevice));
+    if (n2) {
+        ORBX_HIP(hipMemcpy(k2.p, kps2, sizeof(orbx_keypoint) * n2, hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(b.p, desc2, (size_t)32 * n2, hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(m2.p, has_mappoint2, n2, hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(s2.p, stereo2, n2, hipMemcpyHostToDevice));
+    }
+    ORBX_HIP(hipMemcpy(doff.p, cand_off, sizeof(int) * (n1 + 1), hipMemcpyHostToDevice));
+    if (nc) ORBX_HIP(hipMemcpy(dci.p, cand_idx, sizeof(int) * nc, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m1.p, has_mappoint1, n1, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(s1.p, stereo1, n1, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(sc.p, scale_factors2, sizeof(float) * nlevels, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(sg.p, level_sigma2, sizeof(float) * nlevels, hipMemcpyHostToDevice));
+    TriParams tp;
+    for (int i = 0; i < 9; ++i) tp.F12[i] = F12[i];
+    tp.ex = ex; tp.ey = ey; tp.only_stereo = only_stereo ? 1 : 0;
+    int *ob = (int *)o.p;
+    hipLaunchKernelGGL(k_match_triang, dim3((n1 + MT - 1) / MT), dim3(MT), 0, 0, (const orbx_keypoint *)k1.p, (const uint4 *)a.p,
+                       n1, (const orbx_keypoint *)k2.p, (const uint4 *)b.p, (const int *)doff.p, (const int *)dci.p,
+                       (const uint8_t *)m1.p, (const uint8_t *)m2.p, (const uint8_t *)s1.p, (const uint8_t *)s2.p, tp,
+                       (const float *)sc.p, (const float *)sg.p, ob, ob + n1);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(match12, ob, sizeof(int) * n1, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(best_dist, ob + n1, sizeof(int) * n1, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

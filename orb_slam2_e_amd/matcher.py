@@ -71,3 +71,25 @@ class ORBmatcher:
         check(self._L.orbm_match_batch_dev(vp(desc_dev), vp(counts_dev), cap, vp(pair_a_dev), vp(pair_b_dev), npairs,
                                            th, C.c_float(self.mfNNratio), vp(best_dev), vp(second_dev), vp(idx_dev),
                                            vp(match12_dev), vp(nmatch_dev), vp(stream)))
+
+    def match_triangulation(self, kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, has_mp2, stereo1, stereo2,
+                            F12, ex, ey, scale_factors2, level_sigma2, bOnlyStereo=False):
+        """Inner loop of ORBmatcher::SearchForTriangulation (ORBmatcher.cc:892-990).
+        Returns (vMatches12, bestDist); rotation histogram / pair list stay on the host."""
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        off = np.ascontiguousarray(cand_off, np.int32); ci = np.ascontiguousarray(cand_idx, np.int32)
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        m1, m2, s1, s2 = u8(has_mp1), u8(has_mp2), u8(stereo1), u8(stereo2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
+        n1 = len(kps1)
+        m12 = np.zeros(n1, np.int32); bd = np.zeros(n1, np.int32)
+        self._L.orbm_match_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                                     C.c_int, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_match_triangulation(_p(kps1), _p(d1), n1, _p(kps2), _p(d2), len(kps2), _p(off), _p(ci), _p(m1),
+                                               _p(m2), _p(s1), _p(s2), 1 if bOnlyStereo else 0, _p(F), ex, ey, _p(sc),
+                                               _p(sg), len(sc), _p(m12), _p(bd)))
+        return m12, bd
