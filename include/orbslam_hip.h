@@ -154,6 +154,25 @@ int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB,
 int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB,
                           const int32_t *cand_off, const int32_t *cand_idx,
                           int32_t *best, int32_t *second, int32_t *idx);
+/* Frame::GetFeaturesInArea(u, v, r, minLevel, maxLevel) (src/Frame.cc:342-395, on
+ * the 64x48 grid of Frame::AssignFeaturesToGrid :245-260) fused with the best /
+ * second-best-with-levels loop that the SearchByProjection family runs over its
+ * result (ORBmatcher.cc:69-118; same shape at :166-205, :1600-1640, :1730-1770).
+ * kps = mvKeysUn, (min_x..max_y) = mnMinX..mnMaxY; skip[j] != 0 excludes keypoint j
+ * (already holds an observed MapPoint, :87-89); uright (may be NULL) enables the
+ * stereo check |xr - uRight[j]| <= r of :91-96.  init_dist: 256 or INT32_MAX.
+ * Outputs per query: best / second distance, their octaves, arg-best (-1 if none).
+ * Callers whose loop assigns matches as it goes (e.g. :126 F.mvpMapPoints[bestIdx]=pMP)
+ * resolve the rare conflicts in a host post-pass. */
+typedef struct orbm_window_query {
+    float u, v, r, xr;
+    int32_t min_level, max_level;
+} orbm_window_query;
+int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps,
+                       const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
+                       float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
+                       int32_t *second_level, int32_t *idx);
+
 /* Inner loop of ORBmatcher::SearchForTriangulation (ORBmatcher.cc:892-990) with
  * CheckDistEpipolarLine (:341-358): per keypoint of KF1 (skipped if it owns a
  * MapPoint, or is mono while only_stereo), scan its BoW-node candidates of KF2 in

@@ -387,3 +387,22 @@ def match_triangulation(kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, h
     L.oracle_match_triangulation(_p(kps1), _p(d1), len(kps1), _p(kps2), _p(d2), _p(off), _p(ci), _p(m1), _p(m2), _p(s1),
                                  _p(s2), 1 if only_stereo else 0, _p(F), ex, ey, _p(sc), _p(sg), _p(m12), _p(bd))
     return m12, bd
+
+
+WQ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("xr", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+
+
+def search_window(queries, qdesc, kps, desc, bounds, skip=None, uright=None, init_dist=256):
+    L = lib()
+    q = np.ascontiguousarray(queries, WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    xy = np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1), np.float32)
+    octv = np.ascontiguousarray(kps["octave"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    g = Grid(xy, octv, *[float(b) for b in bounds])
+    outs = [np.zeros(len(q), np.int32) for _ in range(5)]
+    sk = np.ascontiguousarray(skip, np.uint8) if skip is not None else None
+    ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+    L.oracle_search_window.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.oracle_search_window(g.h, _p(xy), _p(octv), _p(d), _p(sk) if sk is not None else None,
+                           _p(ur) if ur is not None else None, _p(q), _p(qd), len(q), init_dist, *[_p(o) for o in outs])
+    return tuple(outs)

@@ -238,3 +238,36 @@ void oracle_match_triangulation(const tri_kp *kps1, const uint8_t *d1, int n1, c
         match12[i] = bestIdx2; bestdist[i] = bestDist;
     }
 }
+
+/* ---- windowed search: GetFeaturesInArea + the best/second-with-levels loop of
+ * SearchByProjection(Frame&, vector<MapPoint*>&, th), ORBmatcher.cc:69-118.
+ * q = {u, v, r, xr, minLevel, maxLevel}; skip[idx] stands for "already holds an
+ * observed MapPoint" (:87-89); uright may be NULL (mono), else the stereo check of
+ * :91-96 applies.  init_dist = 256 (:79-81) or INT_MAX (SearchForInitialization). */
+typedef struct { float u, v, r, xr; int min_level, max_level; } oracle_wquery;
+
+void oracle_search_window(const oracle_grid *g, const float *xy, const int *octave, const uint8_t *desc,
+                          const uint8_t *skip, const float *uright, const oracle_wquery *q, const uint8_t *qdesc, int nq,
+                          int init_dist, int *best, int *best_level, int *second, int *second_level, int *idx)
+{
+    int *cand = (int *)malloc(sizeof(int) * (g->n + 1));
+    int i, k;
+    for (i = 0; i < nq; i++) {
+        const int nc = oracle_grid_features_in_area(g, xy, octave, q[i].u, q[i].v, q[i].r, q[i].min_level, q[i].max_level, cand, g->n + 1);
+        int bestDist = init_dist, bestLevel = -1, bestDist2 = init_dist, bestLevel2 = -1, bestIdx = -1;
+        for (k = 0; k < nc; k++) {
+            const int j = cand[k];
+            int dist;
+            if (skip && skip[j]) continue;
+            if (uright && uright[j] > 0) {
+                const float er = fabsf(q[i].xr - uright[j]);
+                if (er > q[i].r) continue;
+            }
+            dist = oracle_descriptor_distance(qdesc + 32 * (size_t)i, desc + 32 * (size_t)j);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = octave[j]; bestIdx = j; }
+            else if (dist < bestDist2) { bestLevel2 = octave[j]; bestDist2 = dist; }
+        }
+        best[i] = bestDist; best_level[i] = bestLevel; second[i] = bestDist2; second_level[i] = bestLevel2; idx[i] = bestIdx;
+    }
+    free(cand);
+}

@@ -8,6 +8,10 @@
 #include <limits.h>
 #include <stdint.h>
 
+#include <math.h>
+
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -33,6 +37,12 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
     d = bcnt_acc(a1.z ^ b1.z, d);
     d = bcnt_acc(a1.w ^ b1.w, d);
     return (int)d;
+}
+
+__device__ __forceinline__ int popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
 // Sequential form used by the gated variant (candidate lists are short).
@@ -172,17 +182,70 @@ __global__ __launch_bounds__(MT) void k_match_cands(const uint4 *__restrict__ A,
     best_o[i] = best; second_o[i] = second; idx_o[i] = idx;
 }
 
+// Windowed search = Frame::GetFeaturesInArea (src/Frame.cc:342-395) fused with the
+// best / second-best-with-levels loop of SearchByProjection (ORBmatcher.cc:69-118).
+// One query per lane scans every keypoint of the frame (staged through LDS); the
+// window test |dx|<r && |dy|<r on an in-grid keypoint is equivalent to membership
+// in the visited grid cells (round() in PosInGrid vs floor/ceil of the cell range),
+// and the visiting order (cells column-major, insertion order inside) only matters
+// for equal distances, so it is folded into the key: dist<<28 | cell<<16 | index.
+constexpr int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64; // include/Frame.h:37-38
+struct WinKp { float x, y, uright; int octave; unsigned order; }; // order = cell<<16 | idx, 0xffffffff = not in the grid / skipped
+struct WinQuery { float u, v, r, xr; int min_level, max_level; };
+
+__global__ __launch_bounds__(MT) void k_search_window(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
+                                                      const WinKp *__restrict__ kp, const uint4 *__restrict__ B, int n,
+                                                      int has_uright, int init_dist, int *__restrict__ best_o,
+                                                      int *__restrict__ bl_o, int *__restrict__ second_o, int *__restrict__ sl_o,
+                                                      int *__restrict__ idx_o)
+{
+    __shared__ WinKp s_kp[MT];
+    __shared__ uint4 s_d[MT * 2];
+    const int i = blockIdx.x * MT + threadIdx.x, tid = threadIdx.x;
+    const bool act = i < nq;
+    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1};
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (act) { w = q[i]; a0 = A[2 * i]; a1 = A[2 * i + 1]; }
+    const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    for (int j0 = 0; j0 < n; j0 += MT) {
+        __syncthreads();
+        if (j0 + tid < n) { s_kp[tid] = kp[j0 + tid]; s_d[2 * tid] = B[2 * (j0 + tid)]; s_d[2 * tid + 1] = B[2 * (j0 + tid) + 1]; }
+        __syncthreads();
+        const int nt = min(MT, n - j0);
+        for (int j = 0; j < nt; ++j) {
+            const WinKp k = s_kp[j];
+            bool ok = act && k.order != 0xffffffffu;
+            if (check_levels) ok = ok && !(k.octave < w.min_level) && !(w.max_level >= 0 && k.octave > w.max_level);
+            const float distx = k.x - w.u, disty = k.y - w.v;
+            ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
+            if (has_uright && k.uright > 0) ok = ok && !(fabsf(w.xr - k.uright) > w.r);
+            const int dist = ok ? popc256(a0, a1, s_d[2 * j], s_d[2 * j + 1]) : 0;
+            if (ok && dist < init_dist) { // dist<bestDist / dist<bestDist2 can only fire below the initial value
+                const unsigned long long key = ((unsigned long long)dist << 28) | k.order;
+                const unsigned long long hi = k1 > key ? k1 : key;
+                k2 = k2 < hi ? k2 : hi;
+                k1 = k1 < key ? k1 : key;
+            }
+        }
+    }
+    if (act) {
+        int best = init_dist, second = init_dist, idx = -1;
+        // keys only enter when dist < init (256: always; INT_MAX: always)
+        if (k1 != ~0ull) { best = (int)(k1 >> 28); idx = (int)(k1 & 0xffffu); }
+        if (k2 != ~0ull) second = (int)(k2 >> 28);
+        best_o[i] = best; second_o[i] = second; idx_o[i] = idx;
+        bl_o[i] = k1 != ~0ull ? (int)(k1 & 0xffffu) : -1;      // resolved to octaves on the host side of the ABI
+        sl_o[i] = k2 != ~0ull ? (int)(k2 & 0xffffu) : -1;
+    }
+}
+
 // SearchForTriangulation inner loop (ORBmatcher.cc:892-990) + CheckDistEpipolarLine
 // (:341-358): one query per lane over its BoW-node candidate list, in member order.
 // `dist>bestDist` is non-strict in the reference, so a later candidate with an equal
 // distance replaces the earlier one; vbMatched2 is never set there, so queries are
 // independent.
 struct TriParams { float F12[9]; float ex, ey; int only_stereo; };
-__device__ __forceinline__ int popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
-{
-    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
-           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-}
 __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__restrict__ kps1, const uint4 *__restrict__ A, int nA,
                                                      const orbx_keypoint *__restrict__ kps2, const uint4 *__restrict__ B,
                                                      const int *__restrict__ off, const int *__restrict__ cidx,
@@ -314,6 +377,55 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB, co
     ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(second, ob + nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(idx, ob + 2 * nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps,
+                       const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
+                       float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
+                       int32_t *second_level, int32_t *idx)
+{
+    if (nq < 0 || n < 0 || n > 65535 || (nq && (!queries || !qdesc || !best || !best_level || !second || !second_level || !idx)) ||
+        (n && (!kps || !desc)) || !(max_x > min_x) || !(max_y > min_y))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (nq == 0) return ORBX_OK;
+    // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:245-260,397-407), on the host: n float ops
+    const float invW = (float)FRAME_GRID_COLS / (max_x - min_x), invH = (float)FRAME_GRID_ROWS / (max_y - min_y);
+    std::vector<WinKp> wk(n ? n : 1);
+    for (int j = 0; j < n; ++j) {
+        const int px = (int)roundf((kps[j].x - min_x) * invW), py = (int)roundf((kps[j].y - min_y) * invH);
+        const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
+        wk[j].x = kps[j].x; wk[j].y = kps[j].y; wk[j].octave = kps[j].octave;
+        wk[j].uright = uright ? uright[j] : -1.0f;
+        wk[j].order = (in && !(skip && skip[j])) ? ((unsigned)(px * FRAME_GRID_ROWS + py) << 16) | (unsigned)j : 0xffffffffu;
+    }
+    DevBuf dq, da, dk, db, o;
+    if (dq.alloc(sizeof(WinQuery) * nq) || da.alloc((size_t)32 * nq) || dk.alloc(sizeof(WinKp) * wk.size()) ||
+        db.alloc((size_t)32 * (n ? n : 1)) || o.alloc(sizeof(int) * 5 * (size_t)nq))
+        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    static_assert(sizeof(WinQuery) == sizeof(orbm_window_query), "query layout");
+    ORBX_HIP(hipMemcpy(dq.p, queries, sizeof(WinQuery) * nq, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(da.p, qdesc, (size_t)32 * nq, hipMemcpyHostToDevice));
+    if (n) {
+        ORBX_HIP(hipMemcpy(dk.p, wk.data(), sizeof(WinKp) * n, hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(db.p, desc, (size_t)32 * n, hipMemcpyHostToDevice));
+    }
+    int *ob = (int *)o.p;
+    hipLaunchKernelGGL(k_search_window, dim3((nq + MT - 1) / MT), dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq,
+                       (const WinKp *)dk.p, (const uint4 *)db.p, n, uright ? 1 : 0, init_dist, ob, ob + nq, ob + 2 * nq,
+                       ob + 3 * nq, ob + 4 * nq);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nq, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(best_level, ob + nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(second, ob + 2 * nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(second_level, ob + 3 * nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(idx, ob + 4 * nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nq; ++i) { // keypoint index -> octave (bestLevel / bestLevel2, ORBmatcher.cc:102-111)
+        if (best_level[i] >= 0) best_level[i] = kps[best_level[i]].octave;
+        if (second_level[i] >= 0) second_level[i] = kps[second_level[i]].octave;
+    }
     return ORBX_OK;
 }
 

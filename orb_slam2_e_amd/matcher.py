@@ -93,3 +93,22 @@ class ORBmatcher:
                                                _p(m2), _p(s1), _p(s2), 1 if bOnlyStereo else 0, _p(F), ex, ey, _p(sc),
                                                _p(sg), len(sc), _p(m12), _p(bd)))
         return m12, bd
+
+    WQ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("xr", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+
+    def search_window(self, queries, qdesc, kps, desc, bounds, skip=None, uright=None, init_dist=256):
+        """GetFeaturesInArea + best/second-with-levels (ORBmatcher.cc:69-118).
+        queries: array of WQ_DTYPE; bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY).
+        Returns best, best_level, second, second_level, idx."""
+        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+        kps = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+        nq = len(q)
+        outs = [np.zeros(nq, np.int32) for _ in range(5)]
+        sk = np.ascontiguousarray(skip, np.uint8) if skip is not None else None
+        ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+        self._L.orbm_search_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 5
+        check(self._L.orbm_search_window(_p(q), _p(qd), nq, _p(kps), _p(d), len(kps), _p(sk) if sk is not None else None,
+                                         _p(ur) if ur is not None else None, *[float(b) for b in bounds], init_dist,
+                                         *[_p(o) for o in outs]))
+        return tuple(outs)

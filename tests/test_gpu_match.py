@@ -101,3 +101,32 @@ def test_search_for_triangulation_inner_loop(seed, only_stereo):
     ref = oracle.match_triangulation(*args, only_stereo=os_)
     assert (ref[0] >= 0).sum() > (20 if os_ else 100)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("seed,stereo,init", [(0, False, 256), (1, True, 256), (2, False, 2**31 - 1)])
+def test_search_window_equals_grid_then_selection(seed, stereo, init):
+    """orbm_search_window vs GetFeaturesInArea (grid order) + the SearchByProjection loop."""
+    from orb_slam2_e_amd import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    n, nq = 2000, 1500
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(-5, 645, n); kps["y"] = rng.uniform(-5, 485, n)   # some fall outside the grid
+    kps["octave"] = rng.integers(0, 8, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    desc[rng.choice(n, 300, replace=False)] = desc[0]                        # many equal distances: order matters
+    src = rng.integers(0, n, nq)
+    q = np.zeros(nq, ORBmatcher.WQ_DTYPE)
+    q["u"] = kps["x"][src] + rng.normal(0, 3, nq); q["v"] = kps["y"][src] + rng.normal(0, 3, nq)
+    q["r"] = rng.choice([3.0, 4.5, 15.0, 40.0], nq) * (1.2 ** kps["octave"][src])
+    lvl = kps["octave"][src]
+    q["min_level"] = np.where(rng.random(nq) < 0.2, -1, lvl - 1); q["max_level"] = np.where(rng.random(nq) < 0.2, -1, lvl)
+    q["xr"] = q["u"] - rng.uniform(0, 30, nq)
+    qd = desc[src] ^ np.packbits(rng.random((nq, 256)) < 0.05, axis=1, bitorder="little")
+    skip = (rng.random(n) < 0.1).astype(np.uint8)
+    ur = np.where(rng.random(n) < 0.5, kps["x"] - rng.uniform(0, 30, n), -1).astype(np.float32) if stereo else None
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    got = ORBmatcher().search_window(q, qd, kps, desc, bounds, skip, ur, init)
+    ref = oracle.search_window(q, qd, kps, desc, bounds, skip, ur, init)
+    assert (ref[4] >= 0).sum() > nq // 2
+    for g, r, name in zip(got, ref, ("best", "best_level", "second", "second_level", "idx")):
+        assert np.array_equal(g, r), name
