@@ -172,23 +172,26 @@ void oracle_gauss7(const uint8_t *src, int w, int h, int sstride,
                    uint8_t *dst, int dstride, const int *taps)
 {
     uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)w * h);
+    int *rx = (int *)malloc(sizeof(int) * (w + 6)), *ry = (int *)malloc(sizeof(int) * (h + 6));
     int x, y, k;
-    for (y = 0; y < h; y++)
+    for (x = -3; x < w + 3; x++) rx[x + 3] = reflect101(x, w);
+    for (y = -3; y < h + 3; y++) ry[y + 3] = reflect101(y, h);
+    for (y = 0; y < h; y++) {
+        const uint8_t *row = src + (size_t)y * sstride;
         for (x = 0; x < w; x++) {
             uint32_t s = 0;
-            for (k = -3; k <= 3; k++)
-                s += (uint32_t)taps[k + 3] * src[(size_t)y * sstride + reflect101(x + k, w)];
+            for (k = 0; k < 7; k++) s += (uint32_t)taps[k] * row[rx[x + k]];
             tmp[(size_t)y * w + x] = s;
         }
+    }
     for (y = 0; y < h; y++)
         for (x = 0; x < w; x++) {
             uint32_t s = 0;
-            for (k = -3; k <= 3; k++)
-                s += (uint32_t)taps[k + 3] * tmp[(size_t)reflect101(y + k, h) * w + x];
+            for (k = 0; k < 7; k++) s += (uint32_t)taps[k] * tmp[(size_t)ry[y + k] * w + x];
             s = (s + (1u << 15)) >> 16;
             dst[(size_t)y * dstride + x] = (uint8_t)(s > 255 ? 255 : s);
         }
-    free(tmp);
+    free(tmp); free(rx); free(ry);
 }
 
 /* 16-pixel Bresenham circle of radius 3 (OpenCV makeOffsets, patternSize 16). */
@@ -253,28 +256,40 @@ int oracle_fast_is_corner(const uint8_t *p, int stride, int threshold)
 }
 
 /* cv::FAST(img, kps, threshold, nonmaxSuppression=true) on a cw x ch sub-image.
- * Output (x, y, score) in raster order; returns count (<= cap written). */
+ * Output (x, y, score) in raster order; returns count (<= cap written).
+ * Like OpenCV's FAST_t<16>, a pixel first passes the opposite-pair pre-test
+ * (d = (tab[p0]|tab[p8]) & (tab[p2]|tab[p10]) & ...: a 9-arc contains one pixel of
+ * every opposite pair) before the 25-step segment test runs. */
 int oracle_fast_detect(const uint8_t *img, int cw, int ch, int stride, int threshold,
                        oracle_cand *out, int cap)
 {
-    int n = 0, x, y;
-    uint8_t *score;
+    int n = 0, x, y, k;
+    uint8_t *score, *iscorner;
     if (cw < 7 || ch < 7) return 0;
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;
     score = (uint8_t *)calloc((size_t)cw * ch, 1);
+    iscorner = (uint8_t *)calloc((size_t)cw * ch, 1);
     for (y = 3; y < ch - 3; y++)
         for (x = 3; x < cw - 3; x++) {
             const uint8_t *p = img + (size_t)y * stride + x;
-            if (oracle_fast_is_corner(p, stride, threshold))
+            const int v = p[0], lo = v - threshold, hi = v + threshold;
+            int d = 3; /* bit 0: darker arc still possible, bit 1: brighter arc still possible */
+            for (k = 0; k < 8 && d; k++) {
+                const int a = p[fast_dy[k] * stride + fast_dx[k]], b = p[fast_dy[k + 8] * stride + fast_dx[k + 8]];
+                d &= ((a < lo || b < lo) ? 1 : 0) | ((a > hi || b > hi) ? 2 : 0);
+            }
+            if (!d) continue;
+            if (oracle_fast_is_corner(p, stride, threshold)) {
+                iscorner[(size_t)y * cw + x] = 1;
                 score[(size_t)y * cw + x] = (uint8_t)oracle_fast_corner_score(p, stride, threshold);
+            }
         }
     for (y = 3; y < ch - 3; y++)
         for (x = 3; x < cw - 3; x++) {
-            const uint8_t *p = img + (size_t)y * stride + x;
             int s;
             const uint8_t *r0, *r1, *r2;
-            if (!oracle_fast_is_corner(p, stride, threshold)) continue;
+            if (!iscorner[(size_t)y * cw + x]) continue;
             s = score[(size_t)y * cw + x];
             r0 = score + (size_t)(y - 1) * cw + x;
             r1 = score + (size_t)y * cw + x;
@@ -285,7 +300,7 @@ int oracle_fast_detect(const uint8_t *img, int cw, int ch, int stride, int thres
                 n++;
             }
         }
-    free(score);
+    free(score); free(iscorner);
     return n;
 }
 

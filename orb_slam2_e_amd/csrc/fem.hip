@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int RPB = 128; // rows per block in the CG kernels
+constexpr int RPB = 256; // rows per block in the CG vector kernels
 constexpr int LPR = 8;   // lanes per row in the SpMV
 constexpr int CGT = 256; // threads per block in the CG kernels
 
@@ -284,42 +284,76 @@ __global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, co
     sc[mesh].rz[0] = a; sc[mesh].rz[1] = a; sc[mesh].bb = b; sc[mesh].rr = b;
 }
 
-// Ap = K p for RPB rows; LPR lanes stride one row's non-zeros (coalesced 32-B
-// segments of vals and cols), fixed-order shuffle reduction; partial p.Ap.
+// Ap = K p, CSR-stream form: a workgroup owns SPB consecutive rows = one contiguous
+// run of non-zeros.  Phase 1 streams vals/cols of that run with fully coalesced,
+// 3-deep independent 16-byte loads (1 KiB per wave instruction), gathers
+// p[col] (L1/L2-resident: 52 KB per mesh) and parks the f64 products in LDS.  Phase 2
+// sums each row from LDS with 8 lanes + fixed-order shuffles, writes Ap and the
+// partial p.Ap.  HBM sees every matrix byte exactly once.
+constexpr int SPB = 64; // rows per SpMV workgroup
+constexpr int SPU4 = 3;  // independent 16-byte (val, col) load pairs in flight per lane
 __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ cols,
                                                   const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
                                                   double *__restrict__ part_pAp)
 {
+    extern __shared__ __align__(16) double prod[];
     __shared__ double sh[CGT / 64];
-    const int mesh = blockIdx.y, chunk = blockIdx.x;
-    const int sub = threadIdx.x / LPR, sl = threadIdx.x % LPR;
+    const int mesh = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int r0 = chunk * SPB, r1 = min(r0 + SPB, ndof);
+    const int k0 = rowptr[r0], k1 = rowptr[r1];
     const float *v = vals + (size_t)mesh * nnz;
     const int *cidx = cols + (size_t)mesh * nnz;
+    // aligned 16-byte streams: start at k0 rounded down to a multiple of 4 (the per-mesh
+    // stride is a multiple of 4), elements outside [k0, k1) are dropped at the LDS write
+    const int ka = k0 & ~3;
+    for (int k = ka + 4 * tid; k < k1; k += SPU4 * 4 * CGT) {
+        float4 va[SPU4]; int4 ca[SPU4];
+#pragma unroll
+        for (int u = 0; u < SPU4; ++u) { // clamped index: unconditional loads, all in flight together
+            const int kk = min(k + u * 4 * CGT, (k1 - 1) & ~3);
+            va[u] = *reinterpret_cast<const float4 *>(v + kk);
+            ca[u] = *reinterpret_cast<const int4 *>(cidx + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < SPU4; ++u) {
+            const int kk = k + u * 4 * CGT;
+            const float vv[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+            const int cc[4] = {ca[u].x, ca[u].y, ca[u].z, ca[u].w};
+            double pa[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pa[e] = (kk + e >= k0 && kk + e < k1) ? p[cc[e]] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kk + e >= k0 && kk + e < k1) prod[kk + e - k0] = (double)vv[e] * pa[e];
+        }
+    }
+    __syncthreads();
+    const int sub = tid / LPR, sl = tid % LPR;
     double acc = 0;
 #pragma unroll
-    for (int pass = 0; pass < RPB / (CGT / LPR); ++pass) {
-        const int row = chunk * RPB + pass * (CGT / LPR) + sub;
+    for (int pass = 0; pass < SPB / (CGT / LPR); ++pass) {
+        const int row = r0 + pass * (CGT / LPR) + sub;
         double s = 0;
-        if (row < ndof) {
-            const int k1 = rowptr[row + 1];
-            for (int k = rowptr[row] + sl; k < k1; k += LPR) s += (double)v[k] * p[cidx[k]];
+        if (row < r1) {
+            const int e = rowptr[row + 1] - k0;
+            for (int k = rowptr[row] - k0 + sl; k < e; k += LPR) s += prod[k];
         }
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 1);
-        if (row < ndof && sl == 0) {
+        if (row < r1 && sl == 0) {
             const size_t g = (size_t)mesh * ndof + row;
             Ap[g] = s;
             acc += p[g] * s;
         }
     }
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part_pAp[mesh * nchunk + chunk] = acc;
+    if (tid == 0) part_pAp[mesh * nchunk + chunk] = acc;
 }
 
 // alpha = rz/pAp; x += alpha p; r -= alpha Ap; partial r.(r/diag) and r.r.
-__global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int cur, const CgScal *__restrict__ sc,
+__global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int nchunk_s, int cur, const CgScal *__restrict__ sc,
                                                        const double *__restrict__ part_pAp, const double *__restrict__ p,
                                                        const double *__restrict__ Ap, const double *__restrict__ dinv,
                                                        double *__restrict__ x, double *__restrict__ r,
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int
     __shared__ double sh[CGT / 64];
     const int mesh = blockIdx.y, chunk = blockIdx.x;
     double pAp = 0;
-    for (int c = 0; c < nchunk; ++c) pAp += part_pAp[mesh * nchunk + c];
+    for (int c = 0; c < nchunk_s; ++c) pAp += part_pAp[mesh * nchunk_s + c];
     const double alpha = sc[mesh].rz[cur] / pAp;
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < RPB; i += CGT) {
@@ -372,8 +406,8 @@ template <typename T> int dalloc(T **p, size_t n) { return hipMalloc((void **)p,
 } // namespace
 
 struct fem_model {
-    int eltype, npe, nd, nmesh, nn, ne, ndof, nblk, nchunk;
-    size_t nnz;
+    int eltype, npe, nd, nmesh, nn, ne, ndof, nblk, nchunk, nchunk_s, spmv_lds;
+    size_t nnz, nnzs; // non-zeros per mesh; per-mesh stride of vals/cols (multiple of 4: 16-B aligned streams)
     unsigned int E;
     float nu, fg, lambda, G;
     FemConst fc;
@@ -413,7 +447,7 @@ int ensure_vecs(fem_model *m)
 
 int ensure_cg(fem_model *m)
 {
-    const size_t N = (size_t)m->nmesh * m->ndof, C = (size_t)m->nmesh * m->nchunk;
+    const size_t N = (size_t)m->nmesh * m->ndof, C = (size_t)m->nmesh * (m->nchunk > m->nchunk_s ? m->nchunk : m->nchunk_s);
     if (m->d_b) return 0;
     if (dalloc(&m->d_b, N) || dalloc(&m->d_x, N) || dalloc(&m->d_r, N) || dalloc(&m->d_p, N) || dalloc(&m->d_Ap, N) ||
         dalloc(&m->d_dinv, N) || dalloc(&m->d_part[0], C) || dalloc(&m->d_part[1], C) || dalloc(&m->d_part[2], C) ||
@@ -427,11 +461,11 @@ void launch_iter(fem_model *m, hipStream_t st)
     const dim3 g(m->nchunk, m->nmesh);
     const int cur = m->cg_it & 1;
     m->prof.start(2, st);
-    hipLaunchKernelGGL(k_fem_spmv, g, dim3(CGT), 0, st, m->d_vals, m->d_cols, m->d_rowptr, m->nnz, m->ndof, m->nchunk,
-                       m->d_p, m->d_Ap, m->d_part[0]);
+    hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st, m->d_vals, m->d_cols, m->d_rowptr,
+                       m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
     m->prof.stop(2, st);
     m->prof.start(3, st);
-    hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, cur, m->d_sc, m->d_part[0], m->d_p,
+    hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
                        m->d_Ap, m->d_dinv, m->d_x, m->d_r, m->d_part[1], m->d_part[2]);
     m->prof.stop(3, st);
     m->prof.start(4, st);
@@ -508,6 +542,7 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
         for (int a = 0; a < npe; ++a)
             for (int b = 0; b < npe; ++b) contrib[fill[blk_of(elems[e * npe + a], elems[e * npe + b])]++] = (e << 6) | (a << 3) | b;
     m->nnz = (size_t)9 * nblk;
+    m->nnzs = (m->nnz + 3) & ~(size_t)3;
     m->h_rowptr.assign(m->ndof + 1, 0);
     m->h_lcol.assign(m->nnz, 0);
     m->h_diag.assign(m->ndof, 0);
@@ -526,11 +561,19 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     }
     m->h_rowptr[m->ndof] = (int)m->nnz;
     m->nchunk = (m->ndof + RPB - 1) / RPB;
+    m->nchunk_s = (m->ndof + SPB - 1) / SPB;
+    int maxrun = 0;
+    for (int r0 = 0; r0 < m->ndof; r0 += SPB) {
+        const int r1 = r0 + SPB < m->ndof ? r0 + SPB : m->ndof;
+        maxrun = std::max(maxrun, m->h_rowptr[r1] - m->h_rowptr[r0]);
+    }
+    m->spmv_lds = maxrun * (int)sizeof(double);
+    if (m->spmv_lds > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
 
     const size_t M = (size_t)nmesh;
     int bad = 0;
     bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke, M * ne * m->nd * m->nd);
-    bad |= dalloc(&m->d_vals, M * m->nnz) | dalloc(&m->d_cols, M * m->nnz) | dalloc(&m->d_blk_row, (size_t)nblk);
+    bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_cols, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
     bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, contrib.size());
     bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnz) | dalloc(&m->d_diag, (size_t)m->ndof);
     if (bad || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -548,6 +591,8 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
+    if (m->spmv_lds > 48 * 1024)
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_spmv), hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
     *out = m;
     return ORBX_OK;
 }
@@ -596,7 +641,7 @@ int fem_assemble(fem_model *m)
     m->prof.start(1, st);
     hipLaunchKernelGGL(k_fem_assemble, dim3((m->nblk * 9 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_ke, m->ne, m->nd,
                        m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->d_cols,
-                       m->d_lcol, m->nnz, m->ndof);
+                       m->d_lcol, m->nnzs, m->ndof);
     m->prof.stop(1, st);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(st));
@@ -614,7 +659,7 @@ int fem_dirichlet_penalty(fem_model *m, const int32_t *ids, int nids, float klar
     int *d_ids = nullptr;
     if (dalloc(&d_ids, (size_t)nids)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     ORBX_HIP(hipMemcpy(d_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fem_penalty, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->nnz,
+    hipLaunchKernelGGL(k_fem_penalty, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->nnzs,
                        m->d_diag, d_ids, nids, klarge);
     ORBX_HIP(hipStreamSynchronize(m->stream));
     (void)hipFree(d_ids);
@@ -634,7 +679,7 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
     if (dalloc(&d_fixed, (size_t)m->ndof)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     ORBX_HIP(hipMemcpy(d_fixed, fixed.data(), m->ndof, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fem_eliminate, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals,
-                       m->d_lcol, m->d_rowptr, m->nnz, m->ndof, d_fixed);
+                       m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, d_fixed);
     ORBX_HIP(hipStreamSynchronize(m->stream));
     (void)hipFree(d_fixed);
     m->cg_ready = false;
@@ -654,7 +699,7 @@ int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr, int32_t *col, float *va
     if (!m || !m->assembled || mesh < 0 || mesh >= m->nmesh) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
     if (rowptr) memcpy(rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1));
     if (col) memcpy(col, m->h_lcol.data(), sizeof(int) * m->nnz);
-    if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + (size_t)mesh * m->nnz, sizeof(float) * m->nnz, hipMemcpyDeviceToHost));
+    if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + (size_t)mesh * m->nnzs, sizeof(float) * m->nnz, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 
@@ -689,7 +734,7 @@ int fem_matvec(fem_model *m, const float *a, float *f)
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
-                       m->d_rowptr, m->nnz, m->ndof, m->d_a, m->d_f);
+                       m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     ORBX_HIP(hipStreamSynchronize(m->stream));
     ORBX_HIP(hipMemcpy(f, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
     return ORBX_OK;
@@ -702,7 +747,7 @@ int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE)
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
-                       m->d_rowptr, m->nnz, m->ndof, m->d_a, m->d_f);
+                       m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
     ORBX_HIP(hipStreamSynchronize(m->stream));
     if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
@@ -716,7 +761,7 @@ int fem_cg_setup(fem_model *m, const double *b)
     if (ensure_cg(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fem_cg_init, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnz,
+    hipLaunchKernelGGL(k_fem_cg_init, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnzs,
                        m->ndof, m->nchunk, m->d_b, m->d_x, m->d_r, m->d_p, m->d_dinv, m->d_part[0], m->d_part[1]);
     hipLaunchKernelGGL(k_fem_cg_init2, dim3(m->nmesh), dim3(1), 0, m->stream, m->nchunk, m->d_part[0], m->d_part[1], m->d_sc);
     ORBX_HIP(hipGetLastError());
@@ -741,8 +786,8 @@ int fem_spmv_repeat(fem_model *m, int n, void *stream)
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     for (int i = 0; i < n; ++i) {
         m->prof.start(2, st);
-        hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, st, m->d_vals, m->d_cols, m->d_rowptr, m->nnz,
-                           m->ndof, m->nchunk, m->d_p, m->d_Ap, m->d_part[0]);
+        hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st, m->d_vals, m->d_cols, m->d_rowptr,
+                           m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
         m->prof.stop(2, st);
     }
     ORBX_HIP(hipGetLastError());
