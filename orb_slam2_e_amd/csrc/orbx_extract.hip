@@ -707,11 +707,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __syncthreads();
     // umax[|v|] = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3} (:454-469), 4 bits each
     const unsigned long long umax_nib = 0x3689ABCDDEEEFFFFull;
+    uint32_t *patch = s_patch[wv];
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         if (s_level[kp] < 0) continue;
-        const uint8_t *c0 = pyr + s_center[kp];
+        // stage the 31x31 window (|offset| <= 15) of the unblurred level with aligned dword loads
+        constexpr int OR = 15, OW = 10; // radius, dwords per staged row (40 bytes >= 31 + 3)
+        const unsigned long long c = s_center[kp];
         const int stride = s_stride[kp];
+        const int shift = (int)((c - OR) & 3ull);
+        const uint8_t *row0 = pyr + (c - OR - shift) - (ptrdiff_t)OR * stride;
+        for (int i = lane; i < (2 * OR + 1) * OW; i += 64) {
+            const int r = i / OW, w = i - r * OW;
+            patch[i] = *reinterpret_cast<const uint32_t *>(row0 + (ptrdiff_t)r * stride + 4 * w);
+        }
+        const uint8_t *c0 = reinterpret_cast<const uint8_t *>(patch) + OR * (OW * 4) + OR + shift;
         int m10 = 0, m01 = 0;
         const int u = (lane & 31) - 15, half = lane >> 5;
 #pragma unroll
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             if (v <= 15 && (lane & 31) < 31) {
                 const int au = u < 0 ? -u : u;
                 if (au <= (int)((umax_nib >> (4 * av)) & 15ull)) {
-                    const int val = c0[v * stride + u];
+                    const int val = c0[v * (OW * 4) + u];
                     m10 += u * val;
                     m01 += v * val;
                 }
@@ -751,7 +761,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         px[2 * t] = (float)pp[0]; py[2 * t] = (float)pp[1]; px[2 * t + 1] = (float)pp[2]; py[2 * t + 1] = (float)pp[3];
     }
     constexpr int PR = 18, PW = 12; // patch radius, dwords per staged row (48 bytes)
-    uint32_t *patch = s_patch[wv];
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         const int level = s_level[kp];
