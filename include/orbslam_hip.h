@@ -90,6 +90,9 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
                        int width, int height, int stride, size_t frame_stride, int batch, void *stream);
 /* Copy frame f's result of the last batch to host (synchronises the stream). */
 int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *desc, int cap, int *n);
+/* Whole last batch to host in three copies: kps[batch][capacity],
+ * desc[batch][capacity][32], counts[batch]; any pointer may be NULL. */
+int orbx_download_batch(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts);
 /* Device-side result arrays of the last batch: kps[batch][capacity],
  * desc[batch][capacity][32], counts[batch] (int32). */
 int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps_dev, const uint8_t **desc_dev,

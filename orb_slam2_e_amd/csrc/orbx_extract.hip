@@ -120,9 +120,10 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (sxs[b] >= 0) {
-                const int r0 = S0[sxs[b]] * a0[b] + S0[sxs[b] + 1] * a1[b];
-                const int r1 = S1[sxs[b]] * a0[b] + S1[sxs[b] + 1] * a1[b];
-                uint32_t v = (uint32_t)((((yy[r].z * (r0 >> 4)) >> 16) + ((yy[r].w * (r1 >> 4)) >> 16) + 2) >> 2);
+                // every factor is below 2^24 and every product below 2^31: 24-bit multiplies are exact here
+                const int r0 = __mul24(S0[sxs[b]], a0[b]) + __mul24(S0[sxs[b] + 1], a1[b]);
+                const int r1 = __mul24(S1[sxs[b]], a0[b]) + __mul24(S1[sxs[b] + 1], a1[b]);
+                uint32_t v = (uint32_t)((((__mul24(yy[r].z, r0 >> 4)) >> 16) + ((__mul24(yy[r].w, r1 >> 4)) >> 16) + 2) >> 2);
                 v = v > 255u ? 255u : v;
                 out[r] |= v << (8 * b);
             }
@@ -215,9 +216,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         // (1) tile: aligned dword loads; pixel (x, y) of the cell lives at tile[y*TS + x + xoff]
         const int xoff = ci.x0 & 3, ndw = (cw + xoff + 3) >> 2;
         const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + (ci.x0 - xoff);
+        const float inv_ndw = 1.0f / (float)ndw; // i / ndw via float: (i + 0.5) / ndw is >= 0.025 away from any integer
         for (int i = lane; i < ch * ndw; i += 64) {
-            const int y = i / ndw, xw = i - y * ndw;
-            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = *reinterpret_cast<const uint32_t *>(img + (size_t)y * lv.stride + 4 * xw);
+            const int y = (int)(((float)i + 0.5f) * inv_ndw), xw = i - y * ndw;
+            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = *reinterpret_cast<const uint32_t *>(img + __mul24(y, lv.stride) + 4 * xw);
         }
         for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
         __syncthreads();
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) // pixel 4q+k sits at byte 4+k of the 12-byte window
-            o[k] = t0 * (b[k + 1] + b[k + 7]) + t1 * (b[k + 2] + b[k + 6]) + t2 * (b[k + 3] + b[k + 5]) + t3 * b[k + 4];
+            o[k] = __umul24(t0, b[k + 1] + b[k + 7]) + __umul24(t1, b[k + 2] + b[k + 6]) + __umul24(t2, b[k + 3] + b[k + 5]) + __umul24(t3, b[k + 4]);
         hz[r][2 * q] = o[0] | (o[1] << 16);
         hz[r][2 * q + 1] = o[2] | (o[3] << 16);
     }
@@ -643,10 +645,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int wi = k >> 1, sh = (k & 1) * 16;
-            const uint32_t s = (uint32_t)t0 * (((a[0][wi] >> sh) & 0xffffu) + ((a[6][wi] >> sh) & 0xffffu)) +
-                               (uint32_t)t1 * (((a[1][wi] >> sh) & 0xffffu) + ((a[5][wi] >> sh) & 0xffffu)) +
-                               (uint32_t)t2 * (((a[2][wi] >> sh) & 0xffffu) + ((a[4][wi] >> sh) & 0xffffu)) +
-                               (uint32_t)t3 * ((a[3][wi] >> sh) & 0xffffu);
+            // all factors < 2^24: v_mul_u32_u24 / v_mad_u32_u24 (full rate) instead of v_mul_lo_u32 (quarter rate)
+            const uint32_t s = __umul24(t0, ((a[0][wi] >> sh) & 0xffffu) + ((a[6][wi] >> sh) & 0xffffu)) +
+                               __umul24(t1, ((a[1][wi] >> sh) & 0xffffu) + ((a[5][wi] >> sh) & 0xffffu)) +
+                               __umul24(t2, ((a[2][wi] >> sh) & 0xffffu) + ((a[4][wi] >> sh) & 0xffffu)) +
+                               __umul24(t3, (a[3][wi] >> sh) & 0xffffu);
             uint32_t v = (s + (1u << 15)) >> 16;
             v = v > 255u ? 255u : v;
             out |= v << (8 * k);
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ int s_stride[DESC_KPB], s_level[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
     __shared__ uint32_t s_pk[DESC_KPB];
     __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
-    __shared__ uint32_t s_patch[4][37 * 12];
+    __shared__ uint32_t s_patch[4][37 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int f = blockIdx.y, kbase = blockIdx.x * DESC_KPB;
     if (tid < DESC_KPB) {
@@ -712,14 +715,14 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int kp = wv * (DESC_KPB / 4) + j;
         if (s_level[kp] < 0) continue;
         // stage the 31x31 window (|offset| <= 15) of the unblurred level with aligned dword loads
-        constexpr int OR = 15, OW = 10; // radius, dwords per staged row (40 bytes >= 31 + 3)
+        constexpr int OR = 15, OW = 16, OWN = 10; // radius, LDS row pitch in dwords, dwords needed (40 bytes >= 31 + 3)
         const unsigned long long c = s_center[kp];
         const int stride = s_stride[kp];
         const int shift = (int)((c - OR) & 3ull);
         const uint8_t *row0 = pyr + (c - OR - shift) - (ptrdiff_t)OR * stride;
         for (int i = lane; i < (2 * OR + 1) * OW; i += 64) {
-            const int r = i / OW, w = i - r * OW;
-            patch[i] = *reinterpret_cast<const uint32_t *>(row0 + (ptrdiff_t)r * stride + 4 * w);
+            const int r = i >> 4, w = i & 15;
+            if (w < OWN) patch[i] = *reinterpret_cast<const uint32_t *>(row0 + __mul24(r, stride) + 4 * w);
         }
         const uint8_t *c0 = reinterpret_cast<const uint8_t *>(patch) + OR * (OW * 4) + OR + shift;
         int m10 = 0, m01 = 0;
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const signed char *pp = c_pattern + 16 * lane + 4 * t;
         px[2 * t] = (float)pp[0]; py[2 * t] = (float)pp[1]; px[2 * t + 1] = (float)pp[2]; py[2 * t + 1] = (float)pp[3];
     }
-    constexpr int PR = 18, PW = 12; // patch radius, dwords per staged row (48 bytes)
+    constexpr int PR = 18, PW = 16, PWN = 12; // patch radius, LDS row pitch in dwords, dwords needed (48 bytes >= 37 + 3)
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         const int level = s_level[kp];
@@ -771,8 +774,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int shift = (int)((c - PR) & 3ull);                // bytes between the aligned start and x-18
         const uint8_t *row0 = blur + (c - PR - shift) - (ptrdiff_t)PR * stride;
         for (int i = lane; i < (2 * PR + 1) * PW; i += 64) {
-            const int r = i / PW, w = i - r * PW;
-            patch[i] = *reinterpret_cast<const uint32_t *>(row0 + (ptrdiff_t)r * stride + 4 * w);
+            const int r = i >> 4, w = i & 15;
+            if (w < PWN) patch[i] = *reinterpret_cast<const uint32_t *>(row0 + __mul24(r, stride) + 4 * w);
         }
         const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR + shift; // patch centre
         unsigned nib = 0;
@@ -1183,6 +1186,18 @@ int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *de
         if (kps) ORBX_HIP(hipMemcpy(kps, ex->d_kps + (size_t)frame * ex->kcap, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost));
         if (desc) ORBX_HIP(hipMemcpy(desc, ex->d_desc + (size_t)frame * ex->kcap * 32, (size_t)32 * cnt, hipMemcpyDeviceToHost));
     }
+    return ORBX_OK;
+}
+
+int orbx_download_batch(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts)
+{
+    if (!ex || ex->last_batch <= 0 || !ex->d_kps) ORBX_FAIL(ORBX_ERR_ARG, "no results");
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipDeviceSynchronize());
+    const size_t B = (size_t)ex->last_batch;
+    if (counts) ORBX_HIP(hipMemcpy(counts, ex->d_counts, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (kps) ORBX_HIP(hipMemcpy(kps, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B, hipMemcpyDeviceToHost));
+    if (desc) ORBX_HIP(hipMemcpy(desc, ex->d_desc, (size_t)32 * ex->kcap * B, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

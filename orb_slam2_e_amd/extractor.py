@@ -90,12 +90,14 @@ class ORBextractor:
         B, h, w = images.shape
         check(self._L.orbx_extract_batch(self._h, _p(images), 0, w, h, w, C.c_size_t(w * h), B, None))
         self._shape = (h, w)
+        self._last_B = B
 
     def extract_batch_device(self, dev_ptr, B, h, w, stream=None):
         """dev_ptr: device address of [B,H,W] uint8 (e.g. torch tensor .data_ptr())."""
         check(self._L.orbx_extract_batch(self._h, C.c_void_p(dev_ptr), 1, w, h, w, C.c_size_t(w * h), B,
                                          C.c_void_p(stream) if stream else None))
         self._shape = (h, w)
+        self._last_B = B
 
     def download(self, frame):
         kps = np.zeros(self.capacity, KP_DTYPE)
@@ -103,6 +105,14 @@ class ORBextractor:
         n = C.c_int(0)
         check(self._L.orbx_download(self._h, frame, _p(kps), _p(desc), self.capacity, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def download_batch(self):
+        """All frames of the last batch: (kps[B,cap], desc[B,cap,32], counts[B])."""
+        B = self._last_B
+        kps = np.zeros((B, self.capacity), KP_DTYPE); desc = np.zeros((B, self.capacity, 32), np.uint8)
+        cnt = np.zeros(B, np.int32)
+        check(self._L.orbx_download_batch(self._h, _p(kps), _p(desc), _p(cnt)))
+        return kps, desc, cnt
 
     def result_dev(self):
         kps, desc, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()

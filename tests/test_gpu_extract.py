@@ -153,3 +153,15 @@ def test_blur_variant_1():
     kps, desc = ex(img)
     _kp_equal(kps, okps)
     assert np.array_equal(desc, odesc)
+
+
+def test_download_batch_equals_per_frame_download():
+    imgs = np.stack([synth_frame(20 + k) for k in range(3)])
+    ex = ORBextractor(*PARAMS)
+    ex.extract_batch(imgs)
+    kps, desc, cnt = ex.download_batch()
+    for f in range(3):
+        k1, d1 = ex.download(f)
+        assert cnt[f] == len(k1)
+        _kp_equal(kps[f, :cnt[f]], k1)
+        assert np.array_equal(desc[f, :cnt[f]], d1)
