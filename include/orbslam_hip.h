@@ -176,6 +176,28 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
                        float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
                        int32_t *second_level, int32_t *idx);
 
+/* The fork's whole-map relocalisation search, ORBmatcher::SearchByProjection(Frame&,
+ * Map*, double Rcw[3][3], double tcw[3], ...) (src/ORBmatcher.cc:134-222): for
+ * EVERY map point isInFrustum (:262-330, with ComputeDistance :224-260; mixed
+ * float / double arithmetic reproduced operation by operation), level prediction
+ * by lower_bound on the scale factors, window r = RadiusByViewingCos * th *
+ * scale[level], GetFeaturesInArea(u, v, r, level-1, level), best / second with
+ * levels over keypoints that hold no MapPoint, bestDist <= th_reloc and the
+ * same-level ratio test.  matched_mp[j] = index of the (last) map point assigned
+ * to keypoint j or -1 (vMatchedMPs); *nmatches as the reference counts them.
+ * cam: intrinsics, GetImageBounds() ints, grid bounds mnMinX..mnMaxY.  proj
+ * (optional, [m][4]): u, v, viewCos, level per map point (level -1 = culled). */
+typedef struct orbm_camera {
+    float fx, fy, cx, cy;
+    int32_t min_x, max_x, min_y, max_y;
+    float grid_min_x, grid_min_y, grid_max_x, grid_max_y;
+} orbm_camera;
+int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *has_mappoint,
+                                  const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
+                                  const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw,
+                                  const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels,
+                                  float th, float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj);
+
 /* Inner loop of ORBmatcher::SearchForTriangulation (ORBmatcher.cc:892-990) with
  * CheckDistEpipolarLine (:341-358): per keypoint of KF1 (skipped if it owns a
  * MapPoint, or is mono while only_stereo), scan its BoW-node candidates of KF2 in

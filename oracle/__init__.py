@@ -406,3 +406,29 @@ def search_window(queries, qdesc, kps, desc, bounds, skip=None, uright=None, ini
     L.oracle_search_window(g.h, _p(xy), _p(octv), _p(d), _p(sk) if sk is not None else None,
                            _p(ur) if ur is not None else None, _p(q), _p(qd), len(q), init_dist, *[_p(o) for o in outs])
     return tuple(outs)
+
+
+CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
+                      ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
+
+
+def search_by_projection_map(kps, desc, has_mp, mp_pos, mp_normal, mp_min_dist, mp_max_dist, mp_desc, Rcw, tcw, cam,
+                             scale_factors, th=1.0, nnratio=0.6, th_reloc=60):
+    L = lib()
+    xy = np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1), np.float32)
+    octv = np.ascontiguousarray(kps["octave"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint8); hm = np.ascontiguousarray(has_mp, np.uint8)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pos, nrm, mn, mx = f32(mp_pos), f32(mp_normal), f32(mp_min_dist), f32(mp_max_dist)
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    R = np.ascontiguousarray(Rcw, np.float64).reshape(9); t = np.ascontiguousarray(tcw, np.float64).reshape(3)
+    cam = np.ascontiguousarray(cam, CAM_DTYPE).reshape(1)
+    sc = f32(scale_factors)
+    matched = np.zeros(len(xy), np.int32); proj = np.zeros((len(pos), 4), np.float32)
+    L.oracle_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    nm = L.oracle_search_by_projection_map(_p(xy), _p(octv), _p(d), len(xy), _p(hm), _p(pos), _p(nrm), _p(mn), _p(mx), _p(md),
+                                           len(pos), _p(R), _p(t), _p(cam), _p(sc), len(sc), th, nnratio, th_reloc,
+                                           _p(matched), _p(proj))
+    return matched, nm, proj

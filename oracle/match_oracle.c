@@ -271,3 +271,92 @@ void oracle_search_window(const oracle_grid *g, const float *xy, const int *octa
     }
     free(cand);
 }
+
+/* ---- the fork's whole-map SearchByProjection(Frame&, Map*, Rcw, tcw, ...),
+ * ORBmatcher.cc:134-222, with isInFrustum :262-330, ComputeDistance :224-260 and
+ * RadiusByViewingCos :332-338, literally (mixed float / double arithmetic kept).
+ * F.mvpMapPoints is only read, so map points are independent; a keypoint chosen by
+ * several map points keeps the last one (vMatchedMPs[bestIdx] = pMP). */
+typedef struct { float fx, fy, cx, cy; int bminx, bmaxx, bminy, bmaxy; float gminx, gminy, gmaxx, gmaxy; } oracle_cam;
+
+static int oracle_in_frustum(const float *P, const float *Pn, float minDistance, float maxDistance,
+                             const oracle_cam *cam, double mRcw[3][3], double mtcw[3], float viewingCosLimit,
+                             const float *scaleFactors, int nLevels, float *pu, float *pv, int *plevel, float *pcos)
+{
+    float ptX = P[0], ptY = P[1], ptZ = P[2];
+    double Pt[3], Rt[3][3], Rtt[3], PO[3], normSum, norm;
+    float PcX, PcY, PcZ, invz, u, v, dist, viewCos, ratio;
+    int i, nPredictedLevel;
+    Pt[0] = ptX; Pt[1] = ptY; Pt[2] = ptZ;
+    PcX = mRcw[0][0] * ptX + mRcw[0][1] * ptY + mRcw[0][2] * ptZ + mtcw[0];
+    PcY = mRcw[1][0] * ptX + mRcw[1][1] * ptY + mRcw[1][2] * ptZ + mtcw[1];
+    PcZ = mRcw[2][0] * ptX + mRcw[2][1] * ptY + mRcw[2][2] * ptZ + mtcw[2];
+    if (PcZ < 0.0) return 0;
+    invz = 1.0 / PcZ;
+    u = cam->fx * PcX * invz + cam->cx;
+    v = cam->fy * PcY * invz + cam->cy;
+    if (u < cam->bminx || u > cam->bmaxx) return 0;
+    if (v < cam->bminy || v > cam->bmaxy) return 0;
+    /* ComputeDistance */
+    Rt[0][0] = (-1) * mRcw[0][0]; Rt[1][0] = (-1) * mRcw[0][1]; Rt[2][0] = (-1) * mRcw[0][2];
+    Rt[0][1] = (-1) * mRcw[1][0]; Rt[1][1] = (-1) * mRcw[1][1]; Rt[2][1] = (-1) * mRcw[1][2];
+    Rt[0][2] = (-1) * mRcw[2][0]; Rt[1][2] = (-1) * mRcw[2][1]; Rt[2][2] = (-1) * mRcw[2][2];
+    for (i = 0; i < 3; i++) Rtt[i] = Rt[i][0] * mtcw[0] + Rt[i][1] * mtcw[1] + Rt[i][2] * mtcw[2];
+    for (i = 0; i < 3; i++) PO[i] = Pt[i] - Rtt[i];
+    normSum = PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2];
+    norm = sqrt(normSum);
+    dist = norm;
+    if (dist < (0.9 * minDistance) || dist > (maxDistance / 0.9)) return 0;
+    viewCos = PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2];
+    viewCos = viewCos / dist;
+    if (viewCos < viewingCosLimit) return 0;
+    ratio = dist / minDistance;
+    for (nPredictedLevel = 0; nPredictedLevel < nLevels && scaleFactors[nPredictedLevel] < ratio; nPredictedLevel++) {} /* lower_bound */
+    if (nPredictedLevel >= nLevels) nPredictedLevel = nLevels - 1;
+    *pu = u; *pv = v; *plevel = nPredictedLevel; *pcos = viewCos;
+    return 1;
+}
+
+int oracle_search_by_projection_map(const float *kxy, const int *koct, const uint8_t *kdesc, int n, const uint8_t *has_mp,
+                                    const float *mp_pos, const float *mp_normal, const float *mp_mind, const float *mp_maxd,
+                                    const uint8_t *mp_desc, int m, const double *Rcw, const double *tcw, const oracle_cam *cam,
+                                    const float *scaleFactors, int nLevels, float th, float nnratio, int th_reloc,
+                                    int *matched_mp, float *proj /* [m][4] u,v,viewCos,level (level<0: not in frustum) */)
+{
+    oracle_grid *g = oracle_grid_build(kxy, n, cam->gminx, cam->gminy, cam->gmaxx, cam->gmaxy);
+    int *cand = (int *)malloc(sizeof(int) * (n + 1));
+    double R[3][3], t[3];
+    int i, k, nmatches = 0;
+    const int bFactor = th != 1.0;
+    for (i = 0; i < 9; i++) R[i / 3][i % 3] = Rcw[i];
+    for (i = 0; i < 3; i++) t[i] = tcw[i];
+    for (i = 0; i < n; i++) matched_mp[i] = -1;
+    for (i = 0; i < m; i++) {
+        float u, v, viewCos, r;
+        int level, nc, bestDist = INT_MAX, bestLevel = -1, bestDist2 = INT_MAX, bestLevel2 = -1, bestIdx = -1;
+        if (proj) { proj[4 * i] = proj[4 * i + 1] = proj[4 * i + 2] = 0; proj[4 * i + 3] = -1; }
+        if (!oracle_in_frustum(mp_pos + 3 * i, mp_normal + 3 * i, mp_mind[i], mp_maxd[i], cam, R, t, 0.5f, scaleFactors, nLevels,
+                               &u, &v, &level, &viewCos))
+            continue;
+        if (proj) { proj[4 * i] = u; proj[4 * i + 1] = v; proj[4 * i + 2] = viewCos; proj[4 * i + 3] = (float)level; }
+        r = viewCos > 0.998 ? 3.0 : 4.5;
+        if (bFactor) r *= th;
+        nc = oracle_grid_features_in_area(g, kxy, koct, u, v, r * scaleFactors[level], level - 1, level, cand, n + 1);
+        for (k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            int dist;
+            if (has_mp[idx]) continue;
+            dist = oracle_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = koct[idx]; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = koct[idx]; bestDist2 = dist; }
+        }
+        if (bestDist <= th_reloc) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            matched_mp[bestIdx] = i;
+            nmatches++;
+        }
+    }
+    free(cand);
+    oracle_grid_free(g);
+    return nmatches;
+}

@@ -240,6 +240,76 @@ __global__ __launch_bounds__(MT) void k_search_window(const WinQuery *__restrict
     }
 }
 
+// The fork's whole-map relocalisation search (ORBmatcher.cc:134-222): isInFrustum
+// (:262-330) + ComputeDistance (:224-260) per map point in the reference's mixed
+// float / double arithmetic (fixed op order, no contraction), producing the
+// GetFeaturesInArea query of :162-163; k_search_window does the search; then the
+// TH_RELOC / same-level ratio acceptance (:205-216) with "last map point wins".
+struct MapCam { float fx, fy, cx, cy; int bminx, bmaxx, bminy, bmaxy; double R[9], t[3]; float th; int nlevels; };
+
+__global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ pos, const float *__restrict__ nrm,
+                                                    const float *__restrict__ mind, const float *__restrict__ maxd, int m,
+                                                    MapCam cam, const float *__restrict__ scale, WinQuery *__restrict__ q,
+                                                    float *__restrict__ proj)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i >= m) return;
+    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
+    float out[4] = {0.f, 0.f, 0.f, -1.f};
+    const float ptX = pos[3 * i], ptY = pos[3 * i + 1], ptZ = pos[3 * i + 2];
+    const double *R = cam.R, *t = cam.t;
+    const float PcX = (float)(R[0] * ptX + R[1] * ptY + R[2] * ptZ + t[0]);
+    const float PcY = (float)(R[3] * ptX + R[4] * ptY + R[5] * ptZ + t[1]);
+    const float PcZ = (float)(R[6] * ptX + R[7] * ptY + R[8] * ptZ + t[2]);
+    bool ok = !(PcZ < 0.0f);
+    const float invz = (float)(1.0 / (double)PcZ);
+    const float u = cam.fx * PcX * invz + cam.cx;
+    const float v = cam.fy * PcY * invz + cam.cy;
+    ok = ok && !(u < (float)cam.bminx || u > (float)cam.bmaxx) && !(v < (float)cam.bminy || v > (float)cam.bmaxy);
+    // ComputeDistance: PO = Pt - (-R^T) t, norm in double
+    double PO[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double rtt = ((-1) * R[a]) * t[0] + ((-1) * R[3 + a]) * t[1] + ((-1) * R[6 + a]) * t[2];
+        PO[a] = (double)(a == 0 ? ptX : a == 1 ? ptY : ptZ) - rtt;
+    }
+    const double normSum = PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2];
+    const float dist = (float)sqrt(normSum);
+    const float minDistance = mind[i], maxDistance = maxd[i];
+    ok = ok && !((double)dist < (0.9 * (double)minDistance) || (double)dist > ((double)maxDistance / 0.9));
+    float viewCos = (float)(PO[0] * nrm[3 * i] + PO[1] * nrm[3 * i + 1] + PO[2] * nrm[3 * i + 2]);
+    viewCos = viewCos / dist;
+    ok = ok && !(viewCos < 0.5f);
+    const float ratio = dist / minDistance;
+    int level = 0;
+    while (level < cam.nlevels && scale[level] < ratio) ++level; // lower_bound(mvScaleFactors, ratio)
+    if (level >= cam.nlevels) level = cam.nlevels - 1;
+    if (ok) {
+        float r = (double)viewCos > 0.998 ? 3.0f : 4.5f; // RadiusByViewingCos
+        if ((double)cam.th != 1.0) r *= cam.th;
+        w.u = u; w.v = v; w.r = r * scale[level]; w.min_level = level - 1; w.max_level = level;
+        out[0] = u; out[1] = v; out[2] = viewCos; out[3] = (float)level;
+    }
+    q[i] = w;
+    if (proj) { proj[4 * i] = out[0]; proj[4 * i + 1] = out[1]; proj[4 * i + 2] = out[2]; proj[4 * i + 3] = out[3]; }
+}
+
+__global__ __launch_bounds__(MT) void k_reloc_accept(const int *__restrict__ best, const int *__restrict__ bidx,
+                                                     const int *__restrict__ second, const int *__restrict__ sidx,
+                                                     const WinKp *__restrict__ kp, int m, int th_reloc, float nnratio,
+                                                     int *__restrict__ matched, int *__restrict__ nmatches)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    bool acc = false;
+    if (i < m && bidx[i] >= 0 && best[i] <= th_reloc) {
+        const int bl = kp[bidx[i]].octave, sl = sidx[i] >= 0 ? kp[sidx[i]].octave : -1;
+        acc = !(bl == sl && (float)best[i] > nnratio * (float)second[i]);
+        if (acc) atomicMax(&matched[bidx[i]], i); // vMatchedMPs[bestIdx] = pMP: the last map point wins
+    }
+    const unsigned long long b = __ballot(acc);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nmatches, __popcll(b));
+}
+
 // SearchForTriangulation inner loop (ORBmatcher.cc:892-990) + CheckDistEpipolarLine
 // (:341-358): one query per lane over its BoW-node candidate list, in member order.
 // `dist>bestDist` is non-strict in the reference, so a later candidate with an equal
@@ -426,6 +496,67 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
         if (best_level[i] >= 0) best_level[i] = kps[best_level[i]].octave;
         if (second_level[i] >= 0) second_level[i] = kps[second_level[i]].octave;
     }
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *has_mappoint,
+                                  const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
+                                  const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw,
+                                  const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels,
+                                  float th, float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj)
+{
+    if (n < 0 || m < 0 || n > 65535 || nlevels < 1 || nlevels > 64 || !cam || !Rcw || !tcw || !scale_factors || !matched_mp ||
+        (n && (!kps || !desc)) || (m && (!mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !mp_desc)) ||
+        !(cam->grid_max_x > cam->grid_min_x) || !(cam->grid_max_y > cam->grid_min_y))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    for (int j = 0; j < n; ++j) matched_mp[j] = -1;
+    if (nmatches) *nmatches = 0;
+    if (n == 0 || m == 0) return ORBX_OK;
+    const float invW = (float)FRAME_GRID_COLS / (cam->grid_max_x - cam->grid_min_x), invH = (float)FRAME_GRID_ROWS / (cam->grid_max_y - cam->grid_min_y);
+    std::vector<WinKp> wk(n);
+    for (int j = 0; j < n; ++j) {
+        const int px = (int)roundf((kps[j].x - cam->grid_min_x) * invW), py = (int)roundf((kps[j].y - cam->grid_min_y) * invH);
+        const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
+        wk[j].x = kps[j].x; wk[j].y = kps[j].y; wk[j].octave = kps[j].octave; wk[j].uright = -1.0f;
+        wk[j].order = (in && !(has_mappoint && has_mappoint[j])) ? ((unsigned)(px * FRAME_GRID_ROWS + py) << 16) | (unsigned)j : 0xffffffffu;
+    }
+    DevBuf dpos, dnrm, dmin, dmax, dmd, dk, dd, dsc, dq, o, dm, dn, dproj;
+    if (dpos.alloc(sizeof(float) * 3 * m) || dnrm.alloc(sizeof(float) * 3 * m) || dmin.alloc(sizeof(float) * m) ||
+        dmax.alloc(sizeof(float) * m) || dmd.alloc((size_t)32 * m) || dk.alloc(sizeof(WinKp) * n) || dd.alloc((size_t)32 * n) ||
+        dsc.alloc(sizeof(float) * nlevels) || dq.alloc(sizeof(WinQuery) * m) || o.alloc(sizeof(int) * 5 * (size_t)m) ||
+        dm.alloc(sizeof(int) * n) || dn.alloc(sizeof(int)) || dproj.alloc(sizeof(float) * 4 * m))
+        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemcpy(dpos.p, mp_pos, sizeof(float) * 3 * m, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dnrm.p, mp_normal, sizeof(float) * 3 * m, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dmin.p, mp_min_dist, sizeof(float) * m, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dmax.p, mp_max_dist, sizeof(float) * m, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dmd.p, mp_desc, (size_t)32 * m, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dk.p, wk.data(), sizeof(WinKp) * n, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dd.p, desc, (size_t)32 * n, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(dsc.p, scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemset(dm.p, 0xff, sizeof(int) * n));
+    ORBX_HIP(hipMemset(dn.p, 0, sizeof(int)));
+    MapCam mc;
+    mc.fx = cam->fx; mc.fy = cam->fy; mc.cx = cam->cx; mc.cy = cam->cy;
+    mc.bminx = cam->min_x; mc.bmaxx = cam->max_x; mc.bminy = cam->min_y; mc.bmaxy = cam->max_y;
+    for (int i = 0; i < 9; ++i) mc.R[i] = Rcw[i];
+    for (int i = 0; i < 3; ++i) mc.t[i] = tcw[i];
+    mc.th = th; mc.nlevels = nlevels;
+    int *ob = (int *)o.p;
+    const dim3 g((m + MT - 1) / MT);
+    hipLaunchKernelGGL(k_map_frustum, g, dim3(MT), 0, 0, (const float *)dpos.p, (const float *)dnrm.p, (const float *)dmin.p,
+                       (const float *)dmax.p, m, mc, (const float *)dsc.p, (WinQuery *)dq.p, (float *)dproj.p);
+    hipLaunchKernelGGL(k_search_window, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)dmd.p, m, (const WinKp *)dk.p,
+                       (const uint4 *)dd.p, n, 0, INT_MAX, ob, ob + m, ob + 2 * m, ob + 3 * m, ob + 4 * m);
+    // k_search_window leaves the key's keypoint index in best_level / second_level
+    hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, 0, ob, ob + m, ob + 2 * m, ob + 3 * m, (const WinKp *)dk.p, m, th_reloc,
+                       nnratio, (int *)dm.p, (int *)dn.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(matched_mp, dm.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP(hipMemcpy(nmatches, dn.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (proj) ORBX_HIP(hipMemcpy(proj, dproj.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

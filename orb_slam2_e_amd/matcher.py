@@ -112,3 +112,29 @@ class ORBmatcher:
                                          _p(ur) if ur is not None else None, *[float(b) for b in bounds], init_dist,
                                          *[_p(o) for o in outs]))
         return tuple(outs)
+
+    CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
+                          ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
+
+    def SearchByProjectionMap(self, kps, desc, has_mp, mp_pos, mp_normal, mp_min_dist, mp_max_dist, mp_desc, Rcw, tcw, cam,
+                              scale_factors, th=1.0):
+        """The fork's SearchByProjection(Frame&, Map*, Rcw, tcw, ...) (ORBmatcher.cc:134-222).
+        Returns (vMatchedMPs as indices or -1, nmatches, proj[m,4])."""
+        kps = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+        hm = np.ascontiguousarray(has_mp, np.uint8)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, nrm, mn, mx = f32(mp_pos), f32(mp_normal), f32(mp_min_dist), f32(mp_max_dist)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        R = np.ascontiguousarray(Rcw, np.float64).reshape(9); t = np.ascontiguousarray(tcw, np.float64).reshape(3)
+        cam = np.ascontiguousarray(cam, self.CAM_DTYPE).reshape(1)
+        sc = f32(scale_factors)
+        n, m = len(kps), len(pos)
+        matched = np.zeros(n, np.int32); proj = np.zeros((m, 4), np.float32); nm = C.c_int(0)
+        self._L.orbm_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_search_by_projection_map(_p(kps), _p(d), n, _p(hm), _p(pos), _p(nrm), _p(mn), _p(mx), _p(md), m,
+                                                    _p(R), _p(t), _p(cam), _p(sc), len(sc), th, C.c_float(self.mfNNratio),
+                                                    self.TH_RELOC, _p(matched), C.byref(nm), _p(proj)))
+        return matched, nm.value, proj

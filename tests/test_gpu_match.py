@@ -130,3 +130,49 @@ def test_search_window_equals_grid_then_selection(seed, stereo, init):
     assert (ref[4] >= 0).sum() > nq // 2
     for g, r, name in zip(got, ref, ("best", "best_level", "second", "second_level", "idx")):
         assert np.array_equal(g, r), name
+
+
+@pytest.mark.parametrize("seed,th", [(0, 1.0), (1, 3.0)])
+def test_whole_map_search_by_projection(seed, th):
+    """The fork's relocalisation search over EVERY map point (ORBmatcher.cc:134-222):
+    frustum test in mixed float/double, window search, TH_RELOC + ratio, last map point wins."""
+    from orb_slam2_e_amd import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    m, n = 5000, 2000
+    fx = fy = 520.0; cx, cy = 320.0, 240.0
+    ang = 0.1 * (seed + 1)
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    tcw = np.array([0.2, -0.1, 0.3])
+    pos = np.stack([rng.uniform(-6, 6, m), rng.uniform(-4, 4, m), rng.uniform(-2, 12, m)], 1).astype(np.float32)
+    Ow = -Rcw.T @ tcw
+    view = pos - Ow
+    dist = np.linalg.norm(view, axis=1)
+    nrm = (view / dist[:, None] + rng.normal(0, 0.4, (m, 3))).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    maxd = (dist * rng.uniform(0.7, 3.0, m) / 1.2).astype(np.float32)   # GetMaxDistanceInvariance() = 1.2f*mfMaxDistance
+    mind = (dist / rng.uniform(0.9, 4.5, m) / 0.8).astype(np.float32)
+    mind_inv = (np.float32(0.8) * mind).astype(np.float32); maxd_inv = (np.float32(1.2) * maxd).astype(np.float32)
+    mp_desc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    # frame keypoints: projections of a subset of the map points + clutter
+    Pc = (Rcw @ pos.T).T + tcw
+    uv = np.stack([fx * Pc[:, 0] / Pc[:, 2] + cx, fy * Pc[:, 1] / Pc[:, 2] + cy], 1)
+    vis = np.where((Pc[:, 2] > 0.5) & (uv[:, 0] > 5) & (uv[:, 0] < 635) & (uv[:, 1] > 5) & (uv[:, 1] < 475))[0]
+    pick = rng.choice(vis, min(n - 400, len(vis)), replace=False)
+    kps = np.zeros(n, KP_DTYPE); desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = len(pick)
+    kps["x"][:k] = uv[pick, 0] + rng.normal(0, 1.0, k); kps["y"][:k] = uv[pick, 1] + rng.normal(0, 1.0, k)
+    kps["x"][k:] = rng.uniform(0, 640, n - k); kps["y"][k:] = rng.uniform(0, 480, n - k)
+    kps["octave"] = rng.integers(0, 8, n)
+    desc[:k] = mp_desc[pick] ^ np.packbits(rng.random((k, 256)) < 0.07, axis=1, bitorder="little")
+    desc[k:k + 100] = desc[:100]                         # duplicated descriptors: several map points claim one keypoint / ties
+    has_mp = rng.random(n) < 0.15
+    cam = np.zeros(1, ORBmatcher.CAM_DTYPE)
+    cam["fx"], cam["fy"], cam["cx"], cam["cy"] = fx, fy, cx, cy
+    cam["min_x"], cam["max_x"], cam["min_y"], cam["max_y"] = 0, 640, 0, 480
+    cam["gminx"], cam["gminy"], cam["gmaxx"], cam["gmaxy"] = 0, 0, 640, 480
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    got = ORBmatcher(0.6).SearchByProjectionMap(kps, desc, has_mp, pos, nrm, mind_inv, maxd_inv, mp_desc, Rcw, tcw, cam, sf, th)
+    ref = oracle.search_by_projection_map(kps, desc, has_mp, pos, nrm, mind_inv, maxd_inv, mp_desc, Rcw, tcw, cam, sf, th)
+    assert (ref[2][:, 3] >= 0).sum() > 300 and ref[1] > 50          # many map points in the frustum, many matches
+    assert np.array_equal(got[2].view(np.uint32), ref[2].view(np.uint32))   # u, v, viewCos, level: float bits
+    assert got[1] == ref[1] and np.array_equal(got[0], ref[0])
