@@ -77,6 +77,20 @@ int fem_matvec(fem_model *m, const float *a, float *f);
  * sE[mesh] = |a^T K a|, nsE = sE / int(Ksize/3).  Either output may be NULL. */
 int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE);
 
+/* The LM hook (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:159-175)
+ * with K, u0, the Dirichlet list and the derived-node table resident on the device
+ * (no per-trial copy of K).  setup: u0[Ksize] (FEA2::Set_u0), the
+ * Dirichlet ids of ImposeDirichletEncastre_a, npoints = number of optimiser vertices
+ * (pFEA2->vVertices), derived[nder][4] = {count 2|3, i0, i1, i2} = vNewPointsBase
+ * (mid-edge / barycentre nodes recomputed by FEA2::Set_uf, FEA2.cc:1746-1775);
+ * npoints + nder = top-layer nodes.  energy: points[nmesh][npoints][3] are the
+ * vertex estimates in double (GetPointCoordinates casts them to float); runs Set_uf,
+ * ComputeDisplacement, ComputeForces, ComputeStrainEnergy, NormalizeStrainEnergy and
+ * returns sE / nsE per mesh (a_out, optional: the displacement vector). */
+int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids, float klarge, int npoints,
+                    const int32_t *derived, int nder);
+int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE, float *nsE);
+
 /* Jacobi-preconditioned conjugate gradients, double vectors on the float matrix:
  * K x = b per mesh, x0 = 0.  Runs until `iters` iterations, or earlier when every
  * mesh has ||r|| <= tol*||b|| (checked every 25 iterations; tol <= 0 disables).

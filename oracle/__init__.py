@@ -432,3 +432,15 @@ def search_by_projection_map(kps, desc, has_mp, mp_pos, mp_normal, mp_min_dist, 
                                            len(pos), _p(R), _p(t), _p(cam), _p(sc), len(sc), th, nnratio, th_reloc,
                                            _p(matched), _p(proj))
     return matched, nm, proj
+
+
+def fem_trial_displacement(points, derived, u0, ids, Klarge=100000000.0):
+    L = lib()
+    pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    der = np.ascontiguousarray(derived if derived is not None else np.zeros((0, 4)), np.int32).reshape(-1, 4)
+    u0 = np.ascontiguousarray(u0, np.float32); ids = np.ascontiguousarray(ids, np.int32)
+    a = np.zeros(len(u0), np.float32)
+    L.oracle_fem_trial_displacement.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_float, C.c_void_p]
+    L.oracle_fem_trial_displacement(_p(pts), len(pts), _p(der), len(der), _p(u0), _p(ids), len(ids), Klarge, _p(a))
+    return a

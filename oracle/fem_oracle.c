@@ -341,3 +341,29 @@ void oracle_fem_csr_matvec(int n, const int *rowptr, const int *col, const float
         y[i] = s;
     }
 }
+
+/* The LM hook's per-trial sequence, optimization_algorithm_levenberg.cpp:159-175:
+ * GetPointCoordinates (:293-311, double -> float), FEA2::Set_uf (FEA2.cc:1732-1796,
+ * incl. the recomputed mid-edge / barycentre nodes of vNewPointsBase), ComputeDisplacement
+ * (:1799-1808), then the caller runs ComputeForces / ComputeStrainEnergy on `a`.
+ * derived[d] = {count (2|3), i0, i1, i2}; nTop = npoints + nder; u0 = [top || bottom]. */
+void oracle_fem_trial_displacement(const double *points, int npoints, const int *derived, int nder, const float *u0,
+                                   const int *ids, int nids, float Klarge, float *a)
+{
+    const int nTop = npoints + nder, n = 6 * nTop;
+    float *top = (float *)malloc(sizeof(float) * 3 * (nTop > 0 ? nTop : 1));
+    int i, k, d;
+    for (i = 0; i < npoints; i++)
+        for (k = 0; k < 3; k++) top[3 * i + k] = (float)points[3 * i + k];
+    for (d = 0; d < nder; d++) {
+        const int *e = derived + 4 * d;
+        float *mi = top + 3 * (npoints + d);
+        if (e[0] == 2) for (k = 0; k < 3; k++) mi[k] = (top[3 * e[1] + k] + top[3 * e[2] + k]) / 2;
+        else for (k = 0; k < 3; k++) mi[k] = (top[3 * e[1] + k] + top[3 * e[2] + k] + top[3 * e[3] + k]) / 3;
+    }
+    for (i = 0; i < 3 * nTop; i++) a[i] = top[i] - u0[i];          /* uf - u0, top layer */
+    for (i = 3 * nTop; i < n; i++) a[i] = u0[i] - u0[i];           /* bottom layer: uf keeps vMPsXYZN_t2 */
+    for (i = 0; i < nids; i++)
+        for (k = 0; k < 3; k++) a[3 * (ids[i] - 1) + k] = 1 / Klarge;
+    free(top);
+}

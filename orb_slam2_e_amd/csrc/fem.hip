@@ -249,6 +249,45 @@ __global__ void k_fem_displacement_dir(float *__restrict__ a, int ndof, const in
     if (t < nids * 3) a[(size_t)mesh * ndof + 3 * (ids[t / 3] - 1) + t % 3] = 1 / klarge;
 }
 
+// LM-hook trial (optimization_algorithm_levenberg.cpp:159-175): GetPointCoordinates
+// (double -> float), Set_uf with the recomputed mid-edge / barycentre nodes
+// (FEA2.cc:1732-1796), ComputeDisplacement (:1799-1808).  K, u0, the Dirichlet list and
+// the derived-node table stay resident; only the optimiser's points come in.
+__global__ __launch_bounds__(256) void k_fem_trial_top(const double *__restrict__ points, int npoints,
+                                                       const int *__restrict__ derived, int nder, int sequential,
+                                                       float *__restrict__ top)
+{
+    const int mesh = blockIdx.y, nTop = npoints + nder;
+    float *t = top + (size_t)mesh * nTop * 3;
+    const double *p = points + (size_t)mesh * npoints * 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * npoints; i += gridDim.x * 256) t[i] = (float)p[i];
+    if (nder == 0 || blockIdx.x != 0) return;
+    __syncthreads(); // block 0 wrote... only its own share: derived nodes need all points -> grid has ONE block when nder > 0
+    if (sequential) {
+        if (threadIdx.x == 0)
+            for (int d = 0; d < nder; ++d) {
+                const int *e = derived + 4 * d;
+                for (int k = 0; k < 3; ++k)
+                    t[3 * (npoints + d) + k] = e[0] == 2 ? (t[3 * e[1] + k] + t[3 * e[2] + k]) / 2
+                                                         : (t[3 * e[1] + k] + t[3 * e[2] + k] + t[3 * e[3] + k]) / 3;
+            }
+    } else {
+        for (int i = threadIdx.x; i < 3 * nder; i += 256) {
+            const int d = i / 3, k = i - 3 * d;
+            const int *e = derived + 4 * d;
+            t[3 * (npoints + d) + k] = e[0] == 2 ? (t[3 * e[1] + k] + t[3 * e[2] + k]) / 2
+                                                 : (t[3 * e[1] + k] + t[3 * e[2] + k] + t[3 * e[3] + k]) / 3;
+        }
+    }
+}
+__global__ void k_fem_trial_a(const float *__restrict__ top, const float *__restrict__ u0, int nTop, float *__restrict__ a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y, ndof = 6 * nTop;
+    if (i >= ndof) return;
+    const float u = u0[i];
+    a[(size_t)mesh * ndof + i] = (i < 3 * nTop ? top[(size_t)mesh * 3 * nTop + i] : u) - u;
+}
+
 // ------------------------------------------------------------------------ CG
 struct CgScal { double rz[2]; double bb; double rr; };
 
@@ -412,7 +451,12 @@ struct fem_model {
     float nu, fg, lambda, G;
     FemConst fc;
     std::vector<int> h_rowptr, h_lcol, h_diag;
-    bool assembled = false, cg_ready = false;
+    bool assembled = false, cg_ready = false, trial_ready = false;
+    int tr_npoints = 0, tr_nder = 0, tr_nids = 0, tr_seq = 0;
+    float tr_klarge = 0.f;
+    double *d_tr_points = nullptr;
+    float *d_tr_top = nullptr, *d_tr_u0 = nullptr;
+    int *d_tr_derived = nullptr, *d_tr_ids = nullptr;
     int cg_it = 0;
     // device
     float *d_nodes = nullptr, *d_ke = nullptr, *d_vals = nullptr, *d_a = nullptr, *d_f = nullptr, *d_u = nullptr, *d_e = nullptr;
@@ -432,7 +476,8 @@ void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_nodes, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_elems, m->d_blk_row, m->d_bptr,
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_cols, m->d_diag, m->d_b, m->d_x, m->d_r,
-                    m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc};
+                    m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
+                    m->d_tr_derived, m->d_tr_ids};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (m->cg_graph) (void)hipGraphExecDestroy(m->cg_graph);
@@ -752,6 +797,63 @@ int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE)
                        m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
     ORBX_HIP(hipStreamSynchronize(m->stream));
+    if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
+    if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nmesh, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids, float klarge, int npoints,
+                    const int32_t *derived, int nder)
+{
+    if (!m || !m->assembled || !u0 || nids < 0 || (nids && !ids) || npoints < 0 || nder < 0 || (nder && !derived))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    const int nTop = npoints + nder;
+    if (6 * nTop != m->ndof) ORBX_FAIL(ORBX_ERR_ARG, "npoints + nder must equal the number of top-layer nodes (Ksize / 6)");
+    for (int i = 0; i < nids; ++i)
+        if (ids[i] - 1 < 0 || ids[i] - 1 >= m->nn) ORBX_FAIL(ORBX_ERR_ARG, "Dirichlet id out of range");
+    int seq = 0;
+    for (int d = 0; d < nder; ++d) {
+        const int c = derived[4 * d];
+        if (c != 2 && c != 3) ORBX_FAIL(ORBX_ERR_ARG, "derived node needs 2 or 3 base points (FEA2.cc:1749,1761)");
+        for (int k = 1; k <= c; ++k) {
+            if (derived[4 * d + k] < 0 || derived[4 * d + k] >= npoints + d) ORBX_FAIL(ORBX_ERR_ARG, "derived base index out of range");
+            if (derived[4 * d + k] >= npoints) seq = 1; // built on an earlier derived node: keep the reference's order
+        }
+    }
+    void *old[] = {m->d_tr_points, m->d_tr_top, m->d_tr_u0, m->d_tr_derived, m->d_tr_ids};
+    for (void *q : old)
+        if (q) (void)hipFree(q);
+    m->d_tr_points = nullptr; m->d_tr_top = m->d_tr_u0 = nullptr; m->d_tr_derived = m->d_tr_ids = nullptr;
+    if (ensure_vecs(m) || dalloc(&m->d_tr_points, (size_t)m->nmesh * npoints * 3) || dalloc(&m->d_tr_top, (size_t)m->nmesh * nTop * 3) ||
+        dalloc(&m->d_tr_u0, (size_t)m->ndof) || dalloc(&m->d_tr_derived, (size_t)4 * nder) || dalloc(&m->d_tr_ids, (size_t)nids))
+        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemcpy(m->d_tr_u0, u0, sizeof(float) * m->ndof, hipMemcpyHostToDevice));
+    if (nder) ORBX_HIP(hipMemcpy(m->d_tr_derived, derived, sizeof(int) * 4 * nder, hipMemcpyHostToDevice));
+    if (nids) ORBX_HIP(hipMemcpy(m->d_tr_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
+    m->tr_npoints = npoints; m->tr_nder = nder; m->tr_nids = nids; m->tr_seq = seq; m->tr_klarge = klarge;
+    m->trial_ready = true;
+    return ORBX_OK;
+}
+
+int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE, float *nsE)
+{
+    if (!m || !m->trial_ready || !points) ORBX_FAIL(ORBX_ERR_ARG, "call fem_trial_setup first");
+    hipStream_t st = m->stream;
+    const int nTop = m->tr_npoints + m->tr_nder;
+    ORBX_HIP(hipMemcpyAsync(m->d_tr_points, points, sizeof(double) * (size_t)m->nmesh * m->tr_npoints * 3, hipMemcpyHostToDevice, st));
+    const int gx = m->tr_nder ? 1 : (3 * m->tr_npoints + 255) / 256;
+    hipLaunchKernelGGL(k_fem_trial_top, dim3(gx > 0 ? gx : 1, m->nmesh), dim3(256), 0, st, m->d_tr_points, m->tr_npoints,
+                       m->d_tr_derived, m->tr_nder, m->tr_seq, m->d_tr_top);
+    hipLaunchKernelGGL(k_fem_trial_a, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_tr_top, m->d_tr_u0, nTop, m->d_a);
+    if (m->tr_nids)
+        hipLaunchKernelGGL(k_fem_displacement_dir, dim3((m->tr_nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_a, m->ndof,
+                           m->d_tr_ids, m->tr_nids, m->tr_klarge);
+    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
+                       m->nnzs, m->ndof, m->d_a, m->d_f);
+    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipStreamSynchronize(st));
+    if (a_out) ORBX_HIP(hipMemcpy(a_out, m->d_a, sizeof(float) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost));
     if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
     if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nmesh, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
     return ORBX_OK;

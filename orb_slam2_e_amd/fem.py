@@ -137,6 +137,24 @@ class FEA2:
         check(self._L.fem_strain_energy(self._h, _p(a), _p(sE), _p(nsE)))
         return sE, nsE
 
+    def trial_setup(self, u0, ids, npoints, derived=None, Klarge=100000000.0):
+        """Resident LM hook state (levenberg.cpp:159-175): u0, Dirichlet ids, vNewPointsBase."""
+        u0 = np.ascontiguousarray(u0, np.float32).reshape(self.Ksize)
+        ids = np.ascontiguousarray(ids, np.int32)
+        der = np.ascontiguousarray(derived if derived is not None else np.zeros((0, 4)), np.int32).reshape(-1, 4)
+        self._npoints = npoints
+        self._L.fem_trial_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
+        check(self._L.fem_trial_setup(self._h, _p(u0), _p(ids), len(ids), Klarge, npoints, _p(der), len(der)))
+
+    def trial_energy(self, points):
+        """Set_uf + ComputeDisplacement + ComputeForces + ComputeStrainEnergy + NormalizeStrainEnergy
+        for the optimiser's current vertex estimates (double).  Returns (a, sE, nsE)."""
+        pts = np.ascontiguousarray(points, np.float64).reshape(self.nmesh, self._npoints, 3)
+        a = np.zeros((self.nmesh, self.Ksize), np.float32)
+        sE = np.zeros(self.nmesh, np.float32); nsE = np.zeros(self.nmesh, np.float32)
+        check(self._L.fem_trial_energy(self._h, _p(pts), _p(a), _p(sE), _p(nsE)))
+        return a, sE, nsE
+
     def solve_cg(self, b, iters=200, tol=0.0):
         b = self._vec(b, np.float64)
         x = np.zeros_like(b); rel = np.zeros(self.nmesh, np.float64); done = C.c_int(0)

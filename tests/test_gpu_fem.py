@@ -183,3 +183,43 @@ def test_config3_full_size_properties():
     x, it, rel = fea.solve_cg(b, iters=20000, tol=1e-10)
     assert rel[0] <= 1e-10
     assert np.linalg.norm(b - A @ x[0]) <= 1e-8 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("with_derived", [False, True])
+def test_lm_hook_trial_energy_resident(with_derived):
+    """levenberg.cpp:159-175 in one call with K / u0 / tables resident: a bit-exact,
+    f = K*a bit-exact (checked through sE), nsE within 1e-5 relative."""
+    top, tris = _fixture("p90")
+    tris = _clean(top, tris)
+    rng = np.random.default_rng(3)
+    if with_derived:
+        # optimiser owns the first npts points; the rest are recomputed as mid-edges / barycentres,
+        # some of them on top of earlier derived nodes (sequential dependency as in vNewPointsBase)
+        npts = len(top) - 40
+        der = []
+        for d in range(40):
+            hi = npts + d if d % 5 == 4 else npts
+            if d % 2 == 0:
+                i0, i1 = rng.integers(0, hi, 2); der.append([2, i0, i1, 0])
+            else:
+                i0, i1, i2 = rng.integers(0, hi, 3); der.append([3, i0, i1, i2])
+        der = np.array(der, np.int32)
+    else:
+        npts, der = len(top), None
+    nodes = second_layer(top, 0.5)
+    elems = extrude_elems(tris, len(top))
+    fea = FEA2(nodes, elems, FEM_C3D6)
+    fea.MatrixAssembly()
+    ids = np.arange(len(top), 2 * len(top), dtype=np.int32)
+    fea.ImposeDirichletEncastre_K(ids)
+    u0 = nodes.ravel()
+    fea.trial_setup(u0, ids, npts, der)
+    K = fea.K_dense()
+    for trial in range(3):
+        pts = top[:npts].astype(np.float64) + rng.normal(0, 0.004, (npts, 3))
+        a, sE, nsE = fea.trial_energy(pts)
+        oa = oracle.fem_trial_displacement(pts, der, u0, ids)
+        assert np.array_equal(a[0], oa)
+        of = oracle.fem_matvec_dense(K, oa)
+        osE, onsE = oracle.fem_strain_energy(oa, of)
+        assert abs(sE[0] - osE) <= RTOL * abs(osE) and abs(nsE[0] - onsE) <= RTOL * abs(onsE)
