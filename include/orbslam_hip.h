@@ -214,6 +214,26 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
                              const float *scale_factors2, const float *level_sigma2, int nlevels, int32_t *match12,
                              int32_t *best_dist);
 
+/* DBoW2 vocabulary-tree descent = the Hamming-heavy half of Frame::ComputeBoW
+ * (src/Frame.cc:410-417 -> TemplatedVocabulary::transform, Thirdparty/DBoW2/DBoW2/
+ * TemplatedVocabulary.h:1127-1160 batch, :1218-1262 descent; FORB::distance,
+ * FORB.cpp:81-101).  The tree is given flat: children of node i =
+ * child_ids[child_off[i] .. child_off[i+1]) (node 0 = root), node_desc[nnodes][32],
+ * node_word[i] = word id of a leaf (-1 inside), node_weight[i] = its idf weight;
+ * L = tree depth (m_L).  transform returns, per feature, the word id, the node at
+ * level L - levelsup (the FeatureVector key) and the word weight; BowVector /
+ * FeatureVector (std::map insertions, addWeight in feature order, L1 normalise)
+ * stay on the host.  The batch form reads descriptor sets resident in HBM
+ * (orbx_result_dev layout) and leaves its outputs there. */
+typedef struct orbm_vocabulary orbm_vocabulary;
+int orbm_vocab_create(const int32_t *child_off, const int32_t *child_ids, const uint8_t *node_desc, const int32_t *node_word,
+                      const double *node_weight, int nnodes, int L, orbm_vocabulary **out);
+int orbm_vocab_destroy(orbm_vocabulary *v);
+int orbm_bow_transform(orbm_vocabulary *v, const uint8_t *features, int n, int levelsup, int32_t *word_id, int32_t *node_id,
+                       double *weight);
+int orbm_bow_transform_batch_dev(orbm_vocabulary *v, const uint8_t *desc_dev, const int32_t *counts_dev, int cap, int nsets,
+                                 int levelsup, int32_t *word_id_dev, int32_t *node_id_dev, void *stream);
+
 /* Acceptance test of ORBmatcher.cc:674-676: best<=th && best<(float)second*nnratio.
  * match12[i] = idx or -1; *nmatches = accepted rows.  Host arrays. */
 int orbm_match_filter(int nA, const int32_t *best, const int32_t *second, const int32_t *idx,

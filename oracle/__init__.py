@@ -444,3 +444,15 @@ def fem_trial_displacement(points, derived, u0, ids, Klarge=100000000.0):
                                                 C.c_float, C.c_void_p]
     L.oracle_fem_trial_displacement(_p(pts), len(pts), _p(der), len(der), _p(u0), _p(ids), len(ids), Klarge, _p(a))
     return a
+
+
+def bow_descend(child_off, child_ids, node_desc, node_word, node_weight, L, features, levelsup):
+    Lb = lib()
+    off = np.ascontiguousarray(child_off, np.int32); ids = np.ascontiguousarray(child_ids, np.int32)
+    nd = np.ascontiguousarray(node_desc, np.uint8); nw = np.ascontiguousarray(node_word, np.int32)
+    wt = np.ascontiguousarray(node_weight, np.float64); f = np.ascontiguousarray(features, np.uint8)
+    n = len(f)
+    word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); w = np.zeros(n, np.float64)
+    Lb.oracle_bow_transform.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3
+    Lb.oracle_bow_transform(_p(off), _p(ids), _p(nd), _p(nw), _p(wt), L, levelsup, _p(f), n, _p(word), _p(node), _p(w))
+    return word, node, w

@@ -360,3 +360,33 @@ int oracle_search_by_projection_map(const float *kxy, const int *koct, const uin
     oracle_grid_free(g);
     return nmatches;
 }
+
+/* ---- DBoW2 vocabulary-tree descent: TemplatedVocabulary::transform(feature, id,
+ * weight, nid, levelsup), Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1262,
+ * with FORB::distance (FORB.cpp:81-101 = the same SWAR popcount).  Tree as flat
+ * arrays: children of node i = child_ids[child_off[i] .. child_off[i+1]); leaves
+ * have no children, a word id and a weight.  First child wins ties (strict d<best_d). */
+void oracle_bow_transform(const int *child_off, const int *child_ids, const uint8_t *node_desc, const int *node_word,
+                          const double *node_weight, int L, int levelsup, const uint8_t *feat, int n,
+                          int *word_id, int *node_id, double *weight)
+{
+    const int nid_level = L - levelsup;
+    int f;
+    for (f = 0; f < n; f++) {
+        int final_id = 0, current_level = 0, nid = 0, k;
+        do {
+            const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
+            double best_d;
+            ++current_level;
+            final_id = child_ids[c0];
+            best_d = oracle_descriptor_distance(feat + 32 * (size_t)f, node_desc + 32 * (size_t)final_id);
+            for (k = c0 + 1; k < c1; k++) {
+                const int id = child_ids[k];
+                const double d = oracle_descriptor_distance(feat + 32 * (size_t)f, node_desc + 32 * (size_t)id);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (child_off[final_id + 1] > child_off[final_id]);
+        word_id[f] = node_word[final_id]; node_id[f] = nid; weight[f] = node_weight[final_id];
+    }
+}

@@ -10,6 +10,7 @@
 
 #include <math.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -358,6 +359,37 @@ __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__rest
     bestdist[i] = bestDist;
 }
 
+// DBoW2 vocabulary-tree descent (TemplatedVocabulary.h:1218-1262): one feature per
+// lane, at every level the Hamming distance to all children of the current node,
+// strict '<' so the first child wins ties; records the node at level L - levelsup
+// (the FeatureVector key) and the leaf's word id.
+__global__ __launch_bounds__(MT) void k_bow_transform(const int *__restrict__ child_off, const int *__restrict__ child_ids,
+                                                      const uint4 *__restrict__ node_desc, const int *__restrict__ node_word,
+                                                      int nid_level, const uint4 *__restrict__ feat, const int *__restrict__ counts,
+                                                      int cap, int n_single, int *__restrict__ word_id, int *__restrict__ node_id)
+{
+    const int set = blockIdx.y, i = blockIdx.x * MT + threadIdx.x;
+    const int n = counts ? min(counts[set], cap) : n_single;
+    if (i >= n) return;
+    const size_t o = (size_t)set * cap + i;
+    const uint4 a0 = feat[2 * o], a1 = feat[2 * o + 1];
+    int final_id = 0, level = 0, nid = 0;
+    do {
+        const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
+        ++level;
+        final_id = child_ids[c0];
+        int best = popc256(a0, a1, node_desc[2 * final_id], node_desc[2 * final_id + 1]);
+        for (int k = c0 + 1; k < c1; ++k) {
+            const int id = child_ids[k];
+            const int d = popc256(a0, a1, node_desc[2 * id], node_desc[2 * id + 1]);
+            if (d < best) { best = d; final_id = id; }
+        }
+        if (level == nid_level) nid = final_id;
+    } while (child_off[final_id + 1] > child_off[final_id]);
+    word_id[o] = node_word[final_id];
+    node_id[o] = nid;
+}
+
 __global__ __launch_bounds__(MT) void k_hamming_matrix(const uint4 *__restrict__ A, int nA, const uint4 *__restrict__ B,
                                                        int nB, unsigned short *__restrict__ out)
 {
@@ -447,6 +479,105 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB, co
     ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(second, ob + nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(idx, ob + 2 * nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+struct orbm_vocabulary {
+    int nnodes = 0, L = 0;
+    int *d_off = nullptr, *d_ids = nullptr, *d_word = nullptr;
+    uint8_t *d_desc = nullptr;
+    std::vector<double> weight; // per word id (host: the BowVector is assembled by the caller)
+    std::vector<int> word_of_node;
+};
+
+int orbm_vocab_create(const int32_t *child_off, const int32_t *child_ids, const uint8_t *node_desc, const int32_t *node_word,
+                      const double *node_weight, int nnodes, int L, orbm_vocabulary **out)
+{
+    if (!child_off || !child_ids || !node_desc || !node_word || !node_weight || nnodes < 2 || L < 1 || !out)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad vocabulary");
+    const int nch = child_off[nnodes];
+    if (child_off[0] != 0 || nch != nnodes - 1) ORBX_FAIL(ORBX_ERR_ARG, "vocabulary is not a tree rooted at node 0");
+    for (int i = 0; i < nnodes; ++i)
+        if (child_off[i] > child_off[i + 1]) ORBX_FAIL(ORBX_ERR_ARG, "child offsets not monotone");
+    for (int k = 0; k < nch; ++k)
+        if (child_ids[k] <= 0 || child_ids[k] >= nnodes) ORBX_FAIL(ORBX_ERR_ARG, "child id out of range");
+    if (child_off[1] == 0) ORBX_FAIL(ORBX_ERR_ARG, "root has no children");
+    // depth check: every descent must end (children have larger depth); guards the device loop
+    std::vector<int> depth(nnodes, -1);
+    depth[0] = 0;
+    std::vector<int> stack(1, 0);
+    int visited = 0;
+    while (!stack.empty()) {
+        const int u = stack.back(); stack.pop_back(); ++visited;
+        for (int k = child_off[u]; k < child_off[u + 1]; ++k) {
+            if (depth[child_ids[k]] >= 0) ORBX_FAIL(ORBX_ERR_ARG, "node has two parents");
+            depth[child_ids[k]] = depth[u] + 1;
+            stack.push_back(child_ids[k]);
+        }
+    }
+    if (visited != nnodes) ORBX_FAIL(ORBX_ERR_ARG, "unreachable nodes in the vocabulary");
+    ORBX_NEED_DEVICE();
+    orbm_vocabulary *v = new orbm_vocabulary();
+    v->nnodes = nnodes; v->L = L;
+    if (hipMalloc(&v->d_off, sizeof(int) * (nnodes + 1)) != hipSuccess || hipMalloc(&v->d_ids, sizeof(int) * (nch ? nch : 1)) != hipSuccess ||
+        hipMalloc(&v->d_word, sizeof(int) * nnodes) != hipSuccess || hipMalloc(&v->d_desc, (size_t)32 * nnodes) != hipSuccess) {
+        delete v;
+        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    }
+    ORBX_HIP(hipMemcpy(v->d_off, child_off, sizeof(int) * (nnodes + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(v->d_ids, child_ids, sizeof(int) * nch, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(v->d_word, node_word, sizeof(int) * nnodes, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(v->d_desc, node_desc, (size_t)32 * nnodes, hipMemcpyHostToDevice));
+    v->word_of_node.assign(node_word, node_word + nnodes);
+    int nwords = 0;
+    for (int i = 0; i < nnodes; ++i) nwords = std::max(nwords, node_word[i] + 1);
+    v->weight.assign(nwords, 0.0);
+    for (int i = 0; i < nnodes; ++i)
+        if (node_word[i] >= 0) v->weight[node_word[i]] = node_weight[i];
+    *out = v;
+    return ORBX_OK;
+}
+
+int orbm_vocab_destroy(orbm_vocabulary *v)
+{
+    if (!v) return ORBX_OK;
+    (void)hipFree(v->d_off); (void)hipFree(v->d_ids); (void)hipFree(v->d_word); (void)hipFree(v->d_desc);
+    delete v;
+    return ORBX_OK;
+}
+
+int orbm_bow_transform(orbm_vocabulary *v, const uint8_t *features, int n, int levelsup, int32_t *word_id, int32_t *node_id,
+                       double *weight)
+{
+    if (!v || n < 0 || (n && (!features || !word_id || !node_id))) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (n == 0) return ORBX_OK;
+    DevBuf df, o;
+    if (df.alloc((size_t)32 * n) || o.alloc(sizeof(int) * 2 * (size_t)n)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemcpy(df.p, features, (size_t)32 * n, hipMemcpyHostToDevice));
+    int *ob = (int *)o.p;
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + MT - 1) / MT, 1), dim3(MT), 0, 0, v->d_off, v->d_ids, (const uint4 *)v->d_desc,
+                       v->d_word, v->L - levelsup, (const uint4 *)df.p, (const int *)nullptr, n, n, ob, ob + n);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(word_id, ob, sizeof(int) * n, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(node_id, ob + n, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (weight)
+        for (int i = 0; i < n; ++i) weight[i] = word_id[i] >= 0 ? v->weight[word_id[i]] : 0.0;
+    if (v->L - levelsup <= 0)
+        for (int i = 0; i < n; ++i) node_id[i] = 0; // root (TemplatedVocabulary.h:1230)
+    return ORBX_OK;
+}
+
+int orbm_bow_transform_batch_dev(orbm_vocabulary *v, const uint8_t *desc_dev, const int32_t *counts_dev, int cap, int nsets,
+                                 int levelsup, int32_t *word_id_dev, int32_t *node_id_dev, void *stream)
+{
+    if (!v || !desc_dev || !counts_dev || cap <= 0 || nsets <= 0 || !word_id_dev || !node_id_dev) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    hipLaunchKernelGGL(k_bow_transform, dim3((cap + MT - 1) / MT, nsets), dim3(MT), 0, (hipStream_t)stream, v->d_off, v->d_ids,
+                       (const uint4 *)v->d_desc, v->d_word, v->L - levelsup, (const uint4 *)desc_dev, counts_dev, cap, 0,
+                       word_id_dev, node_id_dev);
+    ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
 
