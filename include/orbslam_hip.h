@@ -214,6 +214,14 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
                              const float *scale_factors2, const float *level_sigma2, int nlevels, int32_t *match12,
                              int32_t *best_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:305-370) for a batch of m
+ * map points: the observed descriptors of point i are rows off[i]..off[i+1) of desc
+ * (bad keyframes already filtered by the caller, :325-331); best[i] = index (within
+ * the point's rows) of the descriptor with the least median Hamming distance to the
+ * others, first on ties, median = sorted row [int(0.5*(N-1))]; -1 if the point has
+ * none.  At most 128 observations per point. */
+int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m, int32_t *best);
+
 /* DBoW2 vocabulary-tree descent = the Hamming-heavy half of Frame::ComputeBoW
  * (src/Frame.cc:410-417 -> TemplatedVocabulary::transform, Thirdparty/DBoW2/DBoW2/
  * TemplatedVocabulary.h:1127-1160 batch, :1218-1262 descent; FORB::distance,

@@ -456,3 +456,11 @@ def bow_descend(child_off, child_ids, node_desc, node_word, node_weight, L, feat
     Lb.oracle_bow_transform.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3
     Lb.oracle_bow_transform(_p(off), _p(ids), _p(nd), _p(nw), _p(wt), L, levelsup, _p(f), n, _p(word), _p(node), _p(w))
     return word, node, w
+
+
+def distinctive_descriptors(desc, off):
+    L = lib()
+    d = np.ascontiguousarray(desc, np.uint8); o = np.ascontiguousarray(off, np.int32)
+    best = np.zeros(len(o) - 1, np.int32)
+    L.oracle_distinctive_descriptors(_p(d), _p(o), len(o) - 1, _p(best))
+    return best

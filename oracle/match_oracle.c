@@ -390,3 +390,30 @@ void oracle_bow_transform(const int *child_off, const int *child_ids, const uint
         word_id[f] = node_word[final_id]; node_id[f] = nid; weight[f] = node_weight[final_id];
     }
 }
+
+/* ---- MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:305-370, for a batch
+ * of map points: observed descriptors of point i = rows off[i]..off[i+1); the
+ * descriptor with the least median distance to the others wins (first on ties),
+ * median = sorted row [int(0.5*(N-1))].  best[i] = row index within the point, -1 if N==0. */
+static int int_cmp(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+void oracle_distinctive_descriptors(const uint8_t *desc, const int *off, int m, int *best)
+{
+    int i, a, b;
+    for (i = 0; i < m; i++) {
+        const int N = off[i + 1] - off[i];
+        const uint8_t *d = desc + 32 * (size_t)off[i];
+        int BestMedian = INT_MAX, BestIdx = 0;
+        int *row;
+        if (N <= 0) { best[i] = -1; continue; }
+        row = (int *)malloc(sizeof(int) * N);
+        for (a = 0; a < N; a++) {
+            int median;
+            for (b = 0; b < N; b++) row[b] = a == b ? 0 : oracle_descriptor_distance(d + 32 * (size_t)a, d + 32 * (size_t)b);
+            qsort(row, N, sizeof(int), int_cmp);
+            median = row[(int)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = a; }
+        }
+        free(row);
+        best[i] = BestIdx;
+    }
+}

@@ -359,6 +359,44 @@ __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__rest
     bestdist[i] = bestDist;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:305-370), one wave per map
+// point: N x N Hamming matrix in LDS, per-row median (element int(0.5*(N-1)) of the
+// sorted row) by bisection on the value, arg-min with first-wins through a
+// (median<<16 | row) key.
+constexpr int DD_MAXN = 128;
+__global__ __launch_bounds__(64) void k_distinctive(const uint4 *__restrict__ desc, const int *__restrict__ off,
+                                                    int *__restrict__ best)
+{
+    __shared__ uint4 s_d[DD_MAXN * 2];
+    __shared__ unsigned short s_m[DD_MAXN * DD_MAXN];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int o = off[i], N = off[i + 1] - o;
+    if (N <= 0) { if (lane == 0) best[i] = -1; return; }
+    for (int k = lane; k < 2 * N; k += 64) s_d[k] = desc[2 * (size_t)o + k];
+    __syncthreads();
+    for (int p = lane; p < N * N; p += 64) {
+        const int a = p / N, b = p - a * N;
+        s_m[p] = a == b ? 0 : (unsigned short)popc256(s_d[2 * a], s_d[2 * a + 1], s_d[2 * b], s_d[2 * b + 1]);
+    }
+    __syncthreads();
+    const int kth = (int)(0.5 * (N - 1));
+    unsigned key = 0xffffffffu;
+    for (int a = lane; a < N; a += 64) {
+        int lo = 0, hi = 256; // smallest v with #(row <= v) >= kth+1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int b = 0; b < N; ++b) c += s_m[a * N + b] <= mid;
+            if (c >= kth + 1) hi = mid; else lo = mid + 1;
+        }
+        const unsigned k2 = ((unsigned)lo << 16) | (unsigned)a;
+        key = k2 < key ? k2 : key;
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned other = __shfl_xor(key, sft); key = other < key ? other : key; }
+    if (lane == 0) best[i] = (int)(key & 0xffffu);
+}
+
 // DBoW2 vocabulary-tree descent (TemplatedVocabulary.h:1218-1262): one feature per
 // lane, at every level the Hamming distance to all children of the current node,
 // strict '<' so the first child wins ties; records the node at level L - levelsup
@@ -479,6 +517,28 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB, co
     ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(second, ob + nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(idx, ob + 2 * nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m, int32_t *best)
+{
+    if (m < 0 || (m && (!off || !best))) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (m == 0) return ORBX_OK;
+    const int total = off[m];
+    if (off[0] != 0 || total < 0 || (total && !desc)) ORBX_FAIL(ORBX_ERR_ARG, "bad offsets");
+    for (int i = 0; i < m; ++i) {
+        if (off[i] > off[i + 1]) ORBX_FAIL(ORBX_ERR_ARG, "offsets not monotone");
+        if (off[i + 1] - off[i] > DD_MAXN) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 128 observations of one map point");
+    }
+    DevBuf dd, doff, o;
+    if (dd.alloc((size_t)32 * total) || doff.alloc(sizeof(int) * (m + 1)) || o.alloc(sizeof(int) * m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    if (total) ORBX_HIP(hipMemcpy(dd.p, desc, (size_t)32 * total, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(doff.p, off, sizeof(int) * (m + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_distinctive, dim3(m), dim3(64), 0, 0, (const uint4 *)dd.p, (const int *)doff.p, (int *)o.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(best, o.p, sizeof(int) * m, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

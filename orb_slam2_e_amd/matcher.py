@@ -138,3 +138,12 @@ class ORBmatcher:
                                                     _p(R), _p(t), _p(cam), _p(sc), len(sc), th, C.c_float(self.mfNNratio),
                                                     self.TH_RELOC, _p(matched), C.byref(nm), _p(proj)))
         return matched, nm.value, proj
+
+    @staticmethod
+    def distinctive_descriptors(desc, off):
+        """MapPoint::ComputeDistinctiveDescriptors for a batch (MapPoint.cc:305-370)."""
+        L = lib()
+        d = np.ascontiguousarray(desc, np.uint8); o = np.ascontiguousarray(off, np.int32)
+        best = np.zeros(len(o) - 1, np.int32)
+        check(L.orbm_distinctive_descriptors(_p(d), _p(o), len(o) - 1, _p(best)))
+        return best

@@ -176,3 +176,15 @@ def test_whole_map_search_by_projection(seed, th):
     assert (ref[2][:, 3] >= 0).sum() > 300 and ref[1] > 50          # many map points in the frustum, many matches
     assert np.array_equal(got[2].view(np.uint32), ref[2].view(np.uint32))   # u, v, viewCos, level: float bits
     assert got[1] == ref[1] and np.array_equal(got[0], ref[0])
+
+
+def test_distinctive_descriptors_batch():
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([[0, 1, 2, 3, 128], rng.integers(1, 60, 400)])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = rng.integers(0, 256, (len(sizes), 32), dtype=np.uint8)
+    desc = np.concatenate([base[i] ^ np.packbits(rng.random((n, 256)) < 0.1, axis=1, bitorder="little") for i, n in enumerate(sizes) if n > 0])
+    desc[off[10]:off[10] + 2] = desc[off[10] + 2]               # identical rows: first index wins the tie
+    got = ORBmatcher.distinctive_descriptors(desc, off)
+    ref = oracle.distinctive_descriptors(desc, off)
+    assert got[0] == -1 and np.array_equal(got, ref)
