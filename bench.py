@@ -124,7 +124,14 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, cpu=Tru
         del fea
     bt = out["batch"]
     out["roofline"] = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None}
+                       "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                       "avg_launch_ms": bt["spmv_avg_launch_ms"], "alg_bytes_per_launch": bt["spmv_alg_bytes_per_launch"]}
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tfile) and nmesh == 256:      # PMC passes were taken on the 256-mesh batch
+        tr = json.load(open(tfile)).get("k_fem_spmv")
+        if tr:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
     return out
 
 
