@@ -137,6 +137,23 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     }
 }
 
+// XCD-aware (frame, item) mapping for grids of (nitems, nframes) workgroups (speed only,
+// never correctness): workgroups are dealt round-robin over the 8 XCDs in dispatch
+// order (x fastest), each XCD has its own L2; handing every XCD whole frames lets the
+// halos / patches of one frame hit in one L2 instead of being fetched by all eight.
+__device__ __forceinline__ void xcd_frame_item(int &frame, int &item)
+{
+    const int nb = gridDim.x, B = gridDim.y, id = blockIdx.x + nb * blockIdx.y;
+    if ((B & 7) == 0) {
+        const int x = id & 7, s = id >> 3;
+        frame = (s / nb) * 8 + x;
+        item = s % nb;
+    } else {
+        frame = blockIdx.y;
+        item = blockIdx.x;
+    }
+}
+
 // --------------------------------------------------------------------- FAST
 // Differences v - p_k on the 16-pixel Bresenham circle of radius 3 (OpenCV
 // makeOffsets order), t = centre pointer into the LDS tile, ts = tile stride.
@@ -207,7 +224,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     uint8_t *tile = smem;
     uint8_t *sc = smem + tile_bytes;
     unsigned short *queue = reinterpret_cast<unsigned short *>(smem + tile_bytes + sc_bytes);
-    const int c = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    int c, f;
+    xcd_frame_item(f, c);
+    const int lane = threadIdx.x;
     const CellInfo ci = cells[c];
     const LevelInfo lv = L[ci.level];
     const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
@@ -608,9 +627,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     constexpr int IW = BLUR_TW / 4 + 2, IH = BLUR_TH + 6; // 18 dwords x 38 rows
     __shared__ uint32_t in[IH][IW + 1];
     __shared__ uint32_t hz[IH][BLUR_TW / 2 + 1];           // u16 pairs
-    const BlurTile bt = tiles[blockIdx.x];
+    int f, ti;
+    xcd_frame_item(f, ti);
+    const BlurTile bt = tiles[ti];
     const LevelInfo lv = L[bt.level];
-    const int f = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const size_t base = (size_t)f * frame_bytes + lv.off + PADX;
     for (int i = tid; i < IH * IW; i += 256) {
         const int r = i / IW, c = i - r * IW;
@@ -687,7 +708,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
     __shared__ uint32_t s_patch[4][37 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int f = blockIdx.y, kbase = blockIdx.x * DESC_KPB;
+    int f, kbase;
+    xcd_frame_item(f, kbase);
+    kbase *= DESC_KPB;
     if (tid < DESC_KPB) {
         const int kidx = kbase + tid;
         int level = -1, first = 0, total = 0;
