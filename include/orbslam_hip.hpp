@@ -109,6 +109,22 @@ private:
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 
+// Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the results the two
+// extractors still hold on the device after operator() ran on the left / right image.
+inline int ComputeStereoMatches(ORBextractor &left, ORBextractor &right, float mb, float mbf,
+                                std::vector<float> &mvuRight, std::vector<float> &mvDepth)
+{
+    const int cap = orbx_keypoint_capacity(left.handle());
+    mvuRight.assign(cap, -1.0f);
+    mvDepth.assign(cap, -1.0f);
+    int n = 0;
+    int rc = orbx_stereo_match(left.handle(), right.handle(), mb, mbf, nullptr);
+    if (rc == ORBX_OK) rc = orbx_stereo_download(left.handle(), 0, mvuRight.data(), mvDepth.data(), cap, &n);
+    mvuRight.resize(rc == ORBX_OK ? n : 0);
+    mvDepth.resize(rc == ORBX_OK ? n : 0);
+    return rc;
+}
+
 class ORBmatcher {
 public:
     static const int TH_LOW = 45, TH_HIGH = 95, TH_RELOC = 60, HISTO_LENGTH = 30; // ORBmatcher.cc:37-40
@@ -183,6 +199,7 @@ public:
             }
         fem_destroy(mModel);
         mModel = nullptr;
+        mTrialReady = false;
         mStatus = fem_create(nElType == 1 ? FEM_C3D8 : FEM_C3D6, nodes.data(), 1, 2 * nTop, elems.data(), nf, E, nu, fg, &mModel);
         if (mStatus != ORBX_OK) return false; // Ksize<=3: assembly refuses (:1386)
         Ksize = 6 * nTop;
@@ -205,6 +222,18 @@ public:
     float ComputeStrainEnergy() { mStatus = fem_strain_energy(mModel, vva.data(), &sE, &nsE); return sE; }
     float NormalizeStrainEnergy() const { return nsE; }
 
+    // The whole per-trial sequence of the LM hook (optimization_algorithm_levenberg.cpp:159-175)
+    // in one call, K / u0 / Dirichlet list resident: vertex estimates in, nsE out.
+    float TrialEnergy(const std::vector<double> &vertexXYZ)
+    {
+        if (!mTrialReady) {
+            mStatus = fem_trial_setup(mModel, u0.data(), vDir.data(), (int)vDir.size(), 100000000.0f, (int)vertexXYZ.size() / 3, nullptr, 0);
+            mTrialReady = mStatus == ORBX_OK;
+        }
+        if (mTrialReady) mStatus = fem_trial_energy(mModel, vertexXYZ.data(), nullptr, &sE, &nsE);
+        return nsE;
+    }
+
     unsigned int E;
     float nu, h, fg;
     int nElType, Ksize = 0;
@@ -217,6 +246,7 @@ public:
 private:
     fem_model *mModel = nullptr;
     int mStatus = ORBX_OK;
+    bool mTrialReady = false;
 };
 
 } // namespace orbslam_hip

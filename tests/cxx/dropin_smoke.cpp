@@ -75,6 +75,34 @@ int main(int argc, char **argv)
     fea.ComputeForces();
     const float sE = fea.ComputeStrainEnergy();
     if (!(sE > 0.f) || !(fea.NormalizeStrainEnergy() == sE / 32)) { printf("FAIL energy %g %g\n", sE, fea.NormalizeStrainEnergy()); return 1; }
-    printf("OK %d keypoints, %d self matches, sE=%g\n", n, nm, sE);
+    std::vector<double> vest(moved.begin(), moved.end());
+    const float nsE2 = fea.TrialEnergy(vest);
+    if (fea.status() != ORBX_OK || !(nsE2 == fea.NormalizeStrainEnergy()) || !(nsE2 > 0.f)) { printf("FAIL trial energy %g\n", nsE2); return 1; }
+    {
+        const float rel = (nsE2 - sE / 32) / (sE / 32);
+        if (rel > 1e-5f || rel < -1e-5f) { printf("FAIL trial energy differs from the stepwise path %g %g\n", nsE2, sE / 32); return 1; }
+    }
+
+    // stereo: right = left shifted by 7 px with its own noise (identical images would give an all-zero
+    // correlation distance, a zero median and hence no survivors of the median cut, Frame.cc:687-700)
+    std::vector<uint8_t> imgR((size_t)W * H);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            s = s * 1664525u + 1013904223u;
+            const int xs = x + 7 < W ? x + 7 : W - 1;
+            const int checker = (((xs / 24) + (y / 24)) & 1) ? 200 : 60;
+            imgR[(size_t)y * W + x] = (uint8_t)(checker + (int)((s >> 24) % 9) - 4);
+        }
+    ORBextractor exR(1000, 1.2f, 8, 20, 7);
+    std::vector<KeyPoint> kr; std::vector<uint8_t> dr;
+    exR(ImageView{imgR.data(), W, H, W}, ImageView{}, kr, dr);
+    std::vector<float> uR, depth;
+    if (ComputeStereoMatches(ex, exR, 0.5f, 400.f, uR, depth) != ORBX_OK || uR.size() != kps.size()) { printf("FAIL stereo\n"); return 1; }
+    int nst = 0;
+    for (size_t i = 0; i < uR.size(); ++i) nst += uR[i] >= 0;
+    if (nst < 20) { printf("FAIL stereo matches %d\n", nst); return 1; }
+    for (size_t i = 0; i < uR.size(); ++i)
+        if (uR[i] >= 0 && !(depth[i] > 0.f)) { printf("FAIL stereo depth\n"); return 1; }
+    printf("OK %d keypoints, %d self matches, %d stereo matches, sE=%g\n", n, nm, nst, sE);
     return 0;
 }
