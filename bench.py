@@ -42,7 +42,7 @@ ALG_BYTES = {
 FRAME_BYTES = 6751328  # whole extract path per frame
 
 
-def cpu_baseline(nframes=160, ndistinct=16):
+def cpu_baseline(min_seconds=12.0, ndistinct=16):
     """Oracle (CPU restatement, one thread) on a bounded sample of the workload
     (about 10-20 s of CPU work)."""
     import oracle
@@ -52,12 +52,14 @@ def cpu_baseline(nframes=160, ndistinct=16):
     o.extract(imgs[0])  # warm
     t0 = time.perf_counter()
     prev = None
-    for i in range(nframes):
-        desc = o.extract(imgs[i % ndistinct])[1]
+    nframes = 0
+    while time.perf_counter() - t0 < min_seconds:
+        desc = o.extract(imgs[nframes % ndistinct])[1]
         if prev is not None:
             b, s, ix = oracle.match_bruteforce(prev, desc)
             oracle.match_filter(b, s, ix, 45, 0.6)
         prev = desc
+        nframes += 1
     dt = time.perf_counter() - t0
     return {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{nframes} synthetic 640x480 frames ({ndistinct} distinct): oracle extract + 2000x2000 match "

@@ -221,6 +221,18 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return t;
 }
 
+// Sum of n per-workgroup partials in a fixed order, the same value in every lane: lane l
+// adds part[l], part[l+64], ... and a xor butterfly joins the 64 lane sums.  (A serial
+// loop over the partials was 5 of the 8 us of k_fem_cg_update on one 6.6k-dof mesh.)
+__device__ __forceinline__ double chunk_sum(const double *__restrict__ part, int n)
+{
+    double v = 0;
+    for (int c = threadIdx.x & 63; c < n; c += 64) v += part[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 // sE = |a^T f|, nsE = sE / int(Ksize/3): one block per mesh.
 __global__ __launch_bounds__(256) void k_fem_energy(const float *__restrict__ a, const float *__restrict__ f, int ndof,
                                                     float *__restrict__ sE, float *__restrict__ nsE)
@@ -329,8 +341,10 @@ __global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, co
 // p[col] (L1/L2-resident: 52 KB per mesh) and parks the f64 products in LDS.  Phase 2
 // sums each row from LDS with 8 lanes + fixed-order shuffles, writes Ap and the
 // partial p.Ap.  HBM sees every matrix byte exactly once.
-constexpr int SPB = 64; // rows per SpMV workgroup
+// SPB = rows per workgroup: 64 for batches (fewest row-pointer reads per byte streamed),
+// 32 when the whole launch would otherwise be under ~2 workgroups per CU (one small mesh).
 constexpr int SPU4 = 3;  // independent 16-byte (val, col) load pairs in flight per lane
+template <int SPB>
 __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ cols,
                                                   const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
@@ -400,8 +414,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int
 {
     __shared__ double sh[CGT / 64];
     const int mesh = blockIdx.y, chunk = blockIdx.x;
-    double pAp = 0;
-    for (int c = 0; c < nchunk_s; ++c) pAp += part_pAp[mesh * nchunk_s + c];
+    const double pAp = chunk_sum(part_pAp + (size_t)mesh * nchunk_s, nchunk_s);
     const double alpha = sc[mesh].rz[cur] / pAp;
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < RPB; i += CGT) {
@@ -427,8 +440,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
                                                     double *__restrict__ p)
 {
     const int mesh = blockIdx.y, chunk = blockIdx.x;
-    double rz2 = 0, rr = 0;
-    for (int c = 0; c < nchunk; ++c) { rz2 += part_rz[mesh * nchunk + c]; rr += part_rr[mesh * nchunk + c]; }
+    const double rz2 = chunk_sum(part_rz + (size_t)mesh * nchunk, nchunk), rr = chunk_sum(part_rr + (size_t)mesh * nchunk, nchunk);
     const double beta = rz2 / sc[mesh].rz[cur];
     for (int i = threadIdx.x; i < RPB; i += CGT) {
         const int row = chunk * RPB + i;
@@ -445,7 +457,7 @@ template <typename T> int dalloc(T **p, size_t n) { return hipMalloc((void **)p,
 } // namespace
 
 struct fem_model {
-    int eltype, npe, nd, nmesh, nn, ne, ndof, nblk, nchunk, nchunk_s, spmv_lds;
+    int eltype, npe, nd, nmesh, nn, ne, ndof, nblk, nchunk, nchunk_s, spmv_lds, spb;
     size_t nnz, nnzs; // non-zeros per mesh; per-mesh stride of vals/cols (multiple of 4: 16-B aligned streams)
     unsigned int E;
     float nu, fg, lambda, G;
@@ -508,8 +520,8 @@ void launch_iter(fem_model *m, hipStream_t st)
     const dim3 g(m->nchunk, m->nmesh);
     const int cur = m->cg_it & 1;
     m->prof.start(2, st);
-    hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st, m->d_vals, m->d_cols, m->d_rowptr,
-                       m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
+    hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st,
+                       m->d_vals, m->d_cols, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
     m->prof.stop(2, st);
     m->prof.start(3, st);
     hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
@@ -608,6 +620,8 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     }
     m->h_rowptr[m->ndof] = (int)m->nnz;
     m->nchunk = (m->ndof + RPB - 1) / RPB;
+    m->spb = (size_t)nmesh * ((m->ndof + 63) / 64) < 512 ? 32 : 64;
+    const int SPB = m->spb;
     m->nchunk_s = (m->ndof + SPB - 1) / SPB;
     int maxrun = 0;
     for (int r0 = 0; r0 < m->ndof; r0 += SPB) {
@@ -639,7 +653,8 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
     if (m->spmv_lds > 48 * 1024)
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_spmv), hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
+        ORBX_HIP(hipFuncSetAttribute(m->spb == 32 ? reinterpret_cast<const void *>(k_fem_spmv<32>) : reinterpret_cast<const void *>(k_fem_spmv<64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
     *out = m;
     return ORBX_OK;
 }
@@ -913,8 +928,8 @@ int fem_spmv_repeat(fem_model *m, int n, void *stream)
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     for (int i = 0; i < n; ++i) {
         m->prof.start(2, st);
-        hipLaunchKernelGGL(k_fem_spmv, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st, m->d_vals, m->d_cols, m->d_rowptr,
-                           m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
+        hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st,
+                           m->d_vals, m->d_cols, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
         m->prof.stop(2, st);
     }
     ORBX_HIP(hipGetLastError());
