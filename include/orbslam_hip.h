@@ -176,6 +176,44 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
                        float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
                        int32_t *second_level, int32_t *idx);
 
+/* The SearchByProjection family as whole loops: the selection of orbm_search_window plus
+ * what the reference does between queries and after them,
+ *   SearchByProjection(Frame&, vector<MapPoint*>&, th)          src/ORBmatcher.cc:46-132
+ *       th_accept = TH_HIGH, ratio_same_level = 1 (:121), check_orientation = 0
+ *   SearchByProjection(CurrentFrame, LastFrame, th, bMono)      :1529-1671   TH_HIGH, 0, mbCheckOrientation
+ *   SearchByProjection(CurrentFrame, KeyFrame*, found, th, d)   :1673-1800   ORBdist, 0, mbCheckOrientation
+ *   SearchByProjection(KeyFrame*, Scw, points, matched, th)     :491-604     TH_LOW,  0, 0
+ * Query i = one map point that passed the caller's projection / frustum tests, in the
+ * caller's loop order: its window and level range (as orbm_search_window), xr = u - bf/z,
+ * its descriptor (MapPoint::GetDescriptor), qangle[i] = angle of its source keypoint (only
+ * read when check_orientation), qtakes[i] != 0 when the pointer it leaves in
+ * mvpMapPoints[best] makes later queries skip that keypoint (Observations() > 0 in the
+ * first two forms; NULL = always, the last two).  occupied[j] != 0: keypoint j is skipped
+ * from the start.  Each query sees the assignments of the queries before it, exactly as
+ * the sequential loop (:87-89, :1603-1605, :1741-1742, :574-575).  Then the 30-bin rotation
+ * histogram, ComputeThreeMaxima (:1802-1843) and the rejection of the other bins.
+ * match_kp[j] = query whose point ends in slot j, -1 = slot untouched, -2 = slot set to
+ * NULL by the rotation check; match_q[i] = keypoint chosen by query i when it was accepted
+ * (before the rotation check) or -1; *nmatches as the reference counts it.
+ * Limits: at most 8192 keypoints inside the grid, 65536 queries. */
+int orbm_search_projection(const orbm_window_query *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes,
+                           int nq, const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *occupied,
+                           const float *uright, float min_x, float min_y, float max_x, float max_y, int th_accept, float nnratio,
+                           int ratio_same_level, int check_orientation, int32_t *match_kp, int32_t *match_q, int *nmatches);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+ * (src/ORBmatcher.cc:606-721), whole: level-0 keypoints of F1, window around
+ * vbPrevMatched[i1] on level 0 of F2 (grid bounds = F2's mnMinX..mnMaxY), candidates whose
+ * vMatchedDistance is not above the new distance are skipped (:645-646), best <= TH_LOW and
+ * best < second * nnratio, a better match steals the keypoint (:678-682), rotation
+ * histogram over every accepted match (stolen ones included, as the reference pushes
+ * them), ComputeThreeMaxima, rejection, vbPrevMatched update (:715-718).  kps1 / kps2 =
+ * mvKeysUn.  matches12[n1] = vnMatches12; prev_matched[n1][2] in/out. */
+int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbx_keypoint *kps2,
+                                   const uint8_t *desc2, int n2, float *prev_matched, float min_x, float min_y, float max_x,
+                                   float max_y, int window_size, float nnratio, int check_orientation, int32_t *matches12,
+                                   int *nmatches);
+
 /* The fork's whole-map relocalisation search, ORBmatcher::SearchByProjection(Frame&,
  * Map*, double Rcw[3][3], double tcw[3], ...) (src/ORBmatcher.cc:134-222): for
  * EVERY map point isInFrustum (:262-330, with ComputeDistance :224-260; mixed

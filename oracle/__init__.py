@@ -408,6 +408,42 @@ def search_window(queries, qdesc, kps, desc, bounds, skip=None, uright=None, ini
     return tuple(outs)
 
 
+def search_projection_seq(queries, qdesc, qangle, qtakes, kps, desc, bounds, occupied=None, uright=None, th_accept=95,
+                          nnratio=0.6, ratio_same_level=False, check_orientation=True):
+    """SearchByProjection family with in-loop assignment + rotation check -> (match_kp, match_q, nmatches)."""
+    L = lib()
+    q = np.ascontiguousarray(queries, WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    qa = np.ascontiguousarray(qangle, np.float32); qt = np.ascontiguousarray(qtakes, np.uint8)
+    xy = np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1), np.float32)
+    octv = np.ascontiguousarray(kps["octave"], np.int32); ang = np.ascontiguousarray(kps["angle"], np.float32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    g = Grid(xy, octv, *[float(b) for b in bounds])
+    oc = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else None
+    ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+    mk = np.zeros(len(xy), np.int32); mq = np.zeros(len(q), np.int32)
+    L.oracle_search_projection_seq.argtypes = [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    nm = L.oracle_search_projection_seq(g.h, _p(xy), _p(octv), _p(ang), _p(d), _p(oc) if oc is not None else None,
+                                        _p(ur) if ur is not None else None, _p(q), _p(qd), _p(qa), _p(qt), len(q), th_accept,
+                                        nnratio, int(ratio_same_level), int(check_orientation), _p(mk), _p(mq))
+    return mk, mq, nm
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, prev, bounds, window=100, nnratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchForInitialization -> (vnMatches12, updated vbPrevMatched, nmatches)."""
+    L = lib()
+    f = lambda k: (np.ascontiguousarray(np.stack([k["x"], k["y"]], 1), np.float32), np.ascontiguousarray(k["octave"], np.int32),
+                   np.ascontiguousarray(k["angle"], np.float32))
+    xy1, o1, a1 = f(kps1); xy2, o2, a2 = f(kps2)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    g2 = Grid(xy2, o2, *[float(b) for b in bounds])
+    pv = np.array(prev, np.float32, copy=True).reshape(-1, 2)
+    m12 = np.zeros(len(xy1), np.int32)
+    L.oracle_search_for_initialization.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    nm = L.oracle_search_for_initialization(_p(xy1), _p(o1), _p(a1), _p(d1), len(xy1), g2.h, _p(xy2), _p(o2), _p(a2), _p(d2),
+                                            _p(pv), int(window), nnratio, int(check_orientation), _p(m12))
+    return m12, pv, nm
+
+
 CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
                       ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
 

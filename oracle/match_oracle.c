@@ -272,6 +272,141 @@ void oracle_search_window(const oracle_grid *g, const float *xy, const int *octa
     free(cand);
 }
 
+/* ---- Whole search loops, with the reference's in-loop bookkeeping (the coupling between
+ * queries that oracle_search_window leaves out) and the rotation-consistency check.
+ *
+ * Rotation histogram as every Search* builds it (e.g. ORBmatcher.cc:1642-1650):
+ * rot = angle1 - angle2 (+360 if negative), bin = round(rot * 1/HISTO_LENGTH), 30 -> 0.
+ * (With factor = 1/30 and 30 bins only bins 0..12 are ever hit: SURVEY M12.) */
+#define HISTO_LENGTH 30 /* ORBmatcher.cc:40 */
+static int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    int bin;
+    if (rot < 0.0) rot += 360.0f;
+    bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+/* The SearchByProjection family over already projected queries:
+ *   (Frame, vector<MapPoint*>, th)            ORBmatcher.cc:46-132    th_accept = TH_HIGH, ratio_same_level = 1, no rotation check
+ *   (CurrentFrame, LastFrame, th, mono)       :1529-1671              TH_HIGH, best only, rotation check
+ *   (CurrentFrame, KeyFrame, found, th, dist) :1673-1800              ORBdist, best only, rotation check
+ *   (KeyFrame, Scw, points, matched, th)      :491-604                TH_LOW,  best only, no rotation check
+ * Query i = one map point that passed the caller's projection / frustum tests (in the
+ * caller's loop order): window (u, v, r), level range, xr = u - bf/z for the stereo check,
+ * its descriptor, the angle of its source keypoint and takes[i] = whether the pointer it
+ * leaves in mvpMapPoints[best] makes later queries skip that keypoint (Observations()>0 for
+ * the first two forms, always for the last two).  occupied[j] = keypoint j is skipped from
+ * the start.  Outputs: match_kp[j] = query whose point ends in slot j, -1 = slot untouched,
+ * -2 = set to NULL by the rotation check; match_q[i] = keypoint chosen by query i when its
+ * match was accepted (before the rotation check), else -1.  Returns nmatches as counted
+ * by the reference (:124-127, :1634-1637 ++, :1664 --). */
+int oracle_search_projection_seq(const oracle_grid *g, const float *xy, const int *octave, const float *angle,
+                                 const uint8_t *desc, const uint8_t *occupied, const float *uright,
+                                 const oracle_wquery *q, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes,
+                                 int nq, int th_accept, float nnratio, int ratio_same_level, int check_orientation,
+                                 int *match_kp, int *match_q)
+{
+    const int n = g->n;
+    int *cand = (int *)malloc(sizeof(int) * (n + 1));
+    uint8_t *blocked = (uint8_t *)malloc(n + 1);
+    int *qbin = (int *)malloc(sizeof(int) * (nq + 1));
+    int hist[HISTO_LENGTH] = {0};
+    int i, k, nmatches = 0;
+    for (k = 0; k < n; k++) { blocked[k] = occupied ? occupied[k] : 0; match_kp[k] = -1; }
+    for (i = 0; i < nq; i++) {
+        const int nc = oracle_grid_features_in_area(g, xy, octave, q[i].u, q[i].v, q[i].r, q[i].min_level, q[i].max_level, cand, n + 1);
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        match_q[i] = -1; qbin[i] = -1;
+        for (k = 0; k < nc; k++) {
+            const int j = cand[k];
+            int dist;
+            if (blocked[j]) continue;
+            if (uright && uright[j] > 0) {
+                const float er = fabsf(q[i].xr - uright[j]);
+                if (er > q[i].r) continue;
+            }
+            dist = oracle_descriptor_distance(qdesc + 32 * (size_t)i, desc + 32 * (size_t)j);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = octave[j]; bestIdx = j; }
+            else if (dist < bestDist2) { bestLevel2 = octave[j]; bestDist2 = dist; }
+        }
+        if (bestDist <= th_accept) {
+            if (ratio_same_level && bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue; /* :121-122 */
+            match_kp[bestIdx] = i; /* F.mvpMapPoints[bestIdx] = pMP */
+            match_q[i] = bestIdx;
+            if (qtakes[i]) blocked[bestIdx] = 1;
+            nmatches++;
+            if (check_orientation) { qbin[i] = rot_bin(qangle[i], angle[bestIdx]); hist[qbin[i]]++; }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (i = 0; i < nq; i++) /* rotHist holds keypoint indices: every entry of a rejected bin clears its slot */
+            if (qbin[i] >= 0 && qbin[i] != ind1 && qbin[i] != ind2 && qbin[i] != ind3) { match_kp[match_q[i]] = -2; nmatches--; }
+    }
+    free(cand); free(blocked); free(qbin);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchForInitialization, ORBmatcher.cc:606-721.  prev[i1] = vbPrevMatched[i1]
+ * (in/out, updated at :715-718), kps1/kps2 = mvKeysUn of F1/F2 (x, y, octave, angle),
+ * g2 = grid of F2.  vnMatches12[n1] out.  Returns nmatches. */
+int oracle_search_for_initialization(const float *xy1, const int *octave1, const float *angle1, const uint8_t *desc1, int n1,
+                                     const oracle_grid *g2, const float *xy2, const int *octave2, const float *angle2,
+                                     const uint8_t *desc2, float *prev, int windowSize, float nnratio, int check_orientation,
+                                     int *vnMatches12)
+{
+    const int n2 = g2->n, TH_LOW = 45; /* ORBmatcher.cc:38 */
+    int *cand = (int *)malloc(sizeof(int) * (n2 + 1));
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (n2 + 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (n2 + 1));
+    int *qbin = (int *)malloc(sizeof(int) * (n1 + 1));
+    int hist[HISTO_LENGTH] = {0};
+    int i1, k, nmatches = 0;
+    (void)xy1;
+    for (k = 0; k < n2; k++) { vMatchedDistance[k] = INT_MAX; vnMatches21[k] = -1; }
+    for (i1 = 0; i1 < n1; i1++) { vnMatches12[i1] = -1; qbin[i1] = -1; }
+    for (i1 = 0; i1 < n1; i1++) {
+        int nc, bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        const int level1 = octave1[i1];
+        if (level1 > 0) continue;
+        nc = oracle_grid_features_in_area(g2, xy2, octave2, prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1, cand, n2 + 1);
+        for (k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            const int dist = oracle_descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) { qbin[i1] = rot_bin(angle1[i1], angle2[bestIdx2]); hist[qbin[i1]]++; }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (i1 = 0; i1 < n1; i1++)
+            if (qbin[i1] >= 0 && qbin[i1] != ind1 && qbin[i1] != ind2 && qbin[i1] != ind3 && vnMatches12[i1] >= 0) {
+                vnMatches12[i1] = -1; nmatches--;
+            }
+    }
+    for (i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) { prev[2 * i1] = xy2[2 * vnMatches12[i1]]; prev[2 * i1 + 1] = xy2[2 * vnMatches12[i1] + 1]; }
+    free(cand); free(vMatchedDistance); free(vnMatches21); free(qbin);
+    return nmatches;
+}
+
 /* ---- the fork's whole-map SearchByProjection(Frame&, Map*, Rcw, tcw, ...),
  * ORBmatcher.cc:134-222, with isInFrustum :262-330, ComputeDistance :224-260 and
  * RadiusByViewingCos :332-338, literally (mixed float / double arithmetic kept).

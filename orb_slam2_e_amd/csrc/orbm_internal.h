@@ -1,0 +1,52 @@
+// orbm_internal.h -- pieces shared by the matcher translation units (orbm_match.hip,
+// orbm_search.hip): the Frame grid constants, the keypoint / query records of the
+// windowed searches and small host / device helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/orbslam_hip.h"
+
+namespace orbm_detail {
+
+constexpr int MT = 256; // threads per block of the small helper kernels
+constexpr int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64; // include/Frame.h:37-38
+
+// order = grid cell << 16 | keypoint index: ascending order = the order in which
+// Frame::GetFeaturesInArea (src/Frame.cc:342-395) lists its result (column-major cells,
+// insertion order inside a cell); 0xffffffff = not in the grid / skipped.
+struct WinKp { float x, y, uright; int octave; unsigned order; };
+struct WinQuery { float u, v, r, xr; int min_level, max_level; };
+static_assert(sizeof(WinQuery) == sizeof(orbm_window_query), "query layout");
+
+__device__ __forceinline__ int popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:245-260,397-407), on the host: n float ops.
+inline void build_winkp(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
+                        float max_x, float max_y, std::vector<WinKp> &wk)
+{
+    const float invW = (float)FRAME_GRID_COLS / (max_x - min_x), invH = (float)FRAME_GRID_ROWS / (max_y - min_y);
+    wk.resize(n ? n : 1);
+    for (int j = 0; j < n; ++j) {
+        const int px = (int)roundf((kps[j].x - min_x) * invW), py = (int)roundf((kps[j].y - min_y) * invH);
+        const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
+        wk[j].x = kps[j].x; wk[j].y = kps[j].y; wk[j].octave = kps[j].octave;
+        wk[j].uright = uright ? uright[j] : -1.0f;
+        wk[j].order = (in && !(skip && skip[j])) ? ((unsigned)(px * FRAME_GRID_ROWS + py) << 16) | (unsigned)j : 0xffffffffu;
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
+};
+
+} // namespace orbm_detail

@@ -14,10 +14,11 @@
 #include <vector>
 
 #include "common.h"
+#include "orbm_internal.h"
+
+using namespace orbm_detail;
 
 namespace {
-
-constexpr int MT = 256; // threads per block of the small helper kernels
 
 // v_bcnt_u32_b32 d, s0, s1 = popcount(s0) + s1: one accumulating chain, 8 xor + 8 bcnt
 // per 256-bit pair (left to the compiler the sum becomes 8 bcnt + 3-4 v_add3).
@@ -38,12 +39,6 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
     d = bcnt_acc(a1.z ^ b1.z, d);
     d = bcnt_acc(a1.w ^ b1.w, d);
     return (int)d;
-}
-
-__device__ __forceinline__ int popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
-{
-    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
-           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
 // Sequential form used by the gated variant (candidate lists are short).
@@ -190,9 +185,6 @@ __global__ __launch_bounds__(MT) void k_match_cands(const uint4 *__restrict__ A,
 // in the visited grid cells (round() in PosInGrid vs floor/ceil of the cell range),
 // and the visiting order (cells column-major, insertion order inside) only matters
 // for equal distances, so it is folded into the key: dist<<28 | cell<<16 | index.
-constexpr int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64; // include/Frame.h:37-38
-struct WinKp { float x, y, uright; int octave; unsigned order; }; // order = cell<<16 | idx, 0xffffffff = not in the grid / skipped
-struct WinQuery { float u, v, r, xr; int min_level, max_level; };
 
 __global__ __launch_bounds__(MT) void k_search_window(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
                                                       const WinKp *__restrict__ kp, const uint4 *__restrict__ B, int n,
@@ -438,12 +430,6 @@ __global__ __launch_bounds__(MT) void k_hamming_matrix(const uint4 *__restrict__
 
 orbx::KernelProfiler g_prof;
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
-};
-
 } // namespace
 
 extern "C" {
@@ -651,16 +637,8 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
         ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
     if (nq == 0) return ORBX_OK;
-    // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:245-260,397-407), on the host: n float ops
-    const float invW = (float)FRAME_GRID_COLS / (max_x - min_x), invH = (float)FRAME_GRID_ROWS / (max_y - min_y);
-    std::vector<WinKp> wk(n ? n : 1);
-    for (int j = 0; j < n; ++j) {
-        const int px = (int)roundf((kps[j].x - min_x) * invW), py = (int)roundf((kps[j].y - min_y) * invH);
-        const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
-        wk[j].x = kps[j].x; wk[j].y = kps[j].y; wk[j].octave = kps[j].octave;
-        wk[j].uright = uright ? uright[j] : -1.0f;
-        wk[j].order = (in && !(skip && skip[j])) ? ((unsigned)(px * FRAME_GRID_ROWS + py) << 16) | (unsigned)j : 0xffffffffu;
-    }
+    std::vector<WinKp> wk;
+    build_winkp(kps, n, skip, uright, min_x, min_y, max_x, max_y, wk);
     DevBuf dq, da, dk, db, o;
     if (dq.alloc(sizeof(WinQuery) * nq) || da.alloc((size_t)32 * nq) || dk.alloc(sizeof(WinKp) * wk.size()) ||
         db.alloc((size_t)32 * (n ? n : 1)) || o.alloc(sizeof(int) * 5 * (size_t)nq))

@@ -166,20 +166,75 @@ __device__ __forceinline__ void fast_diffs(const uint8_t *t, int ts, int d[16])
     d[12] = v - t[-3];          d[13] = v - t[ts - 3];      d[14] = v - t[2 * ts - 2];  d[15] = v - t[3 * ts - 1];
 }
 
-// Necessary condition for a 9-arc (OpenCV's opposite-pair pre-test): a 9-arc
-// contains one pixel of every opposite pair (k, k+8).  Returns 1 = dark arc
-// possible, 2 = bright arc possible, 0 = neither (both set cannot be a corner:
-// a 9-arc holds both pixels of one pair).
-__device__ __forceinline__ int fast_pretest(const int d[16], int th)
+// Necessary condition for a 9-arc (OpenCV's opposite-pair pre-test): a 9-arc contains
+// one pixel of every opposite pair (k, k+8), so with d_k = v - p_k a dark arc needs
+// min_k max(d_k, d_k+8) > th and a bright one max_k min(d_k, d_k+8) < -th (both at
+// once cannot be a corner: a 9-arc holds both pixels of one pair).
+// Evaluated for 4 horizontally adjacent pixels per lane, on packed u16 pairs
+// (v_perm_b32 / v_pk_min_u16 / v_pk_max_u16; there is no byte-wise min/max).  With
+// d_k = v - p_k:  min_k max(d_k, d_k+8) > th  <=>  v > max_k min(p_k, p_k+8) + th  (dark)
+//                max_k min(d_k, d_k+8) < -th <=>  min_k max(p_k, p_k+8) > v + th  (bright)
+// so the differences are never formed.  p = dword-aligned address of the 4 centre pixels
+// in the LDS tile; the 7 rows x 12 bytes around it are read as dwords and the circle
+// pixels of lanes-pixels (0,2) / (1,3) are pulled out as (even, odd) u16 pairs.
+// Returns one byte per pixel: 1 = dark arc possible, 2 = bright, 0 = neither.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t pk1(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+template <int DX>
+__device__ __forceinline__ void fast_pick(const uint32_t r[3], u16x2 &E, u16x2 &O)
 {
-    int lo = max(d[0], d[8]), hi = min(d[0], d[8]);
+    constexpr int s = 4 + DX;                  // byte of pixel 0 in the 12-byte window r[0] | r[1] | r[2]
+    constexpr int base = (DX < 0) ? s : s - 4; // ... inside the 8-byte pair handed to v_perm
+    const uint32_t hi = (DX < 0) ? r[1] : r[2], lo = (DX < 0) ? r[0] : r[1];
+    constexpr uint32_t selE = base | 0x0c00u | ((base + 2) << 16) | 0x0c000000u;       // {b, 0, b+2, 0}
+    constexpr uint32_t selO = (base + 1) | 0x0c00u | ((base + 3) << 16) | 0x0c000000u; // {b+1, 0, b+3, 0}
+    E = pk2(__builtin_amdgcn_perm(hi, lo, selE));
+    O = pk2(__builtin_amdgcn_perm(hi, lo, selO));
+}
+template <int TS>
+__device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2)
+{
+    uint32_t r[7][3];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        lo = min(lo, max(d[k], d[k + 8]));
-        hi = max(hi, min(d[k], d[k + 8]));
+    for (int dy = -3; dy <= 3; ++dy) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p + dy * TS);
+        r[dy + 3][0] = q[-1]; r[dy + 3][1] = q[0]; r[dy + 3][2] = q[1];
     }
-    const int pd = lo > th, pb = hi < -th;
-    return (pd ^ pb) ? (pd ? 1 : 2) : 0;
+    u16x2 aE, aO, bE, bO, loE, loO, hiE, hiO;
+#define ORBX_PAIR(DYA, DXA, FIRST)                                                               \
+    fast_pick<DXA>(r[3 + (DYA)], aE, aO);                                                        \
+    fast_pick<-(DXA)>(r[3 - (DYA)], bE, bO);                                                     \
+    if (FIRST) {                                                                                 \
+        loE = __builtin_elementwise_min(aE, bE); loO = __builtin_elementwise_min(aO, bO);        \
+        hiE = __builtin_elementwise_max(aE, bE); hiO = __builtin_elementwise_max(aO, bO);        \
+    } else {                                                                                     \
+        loE = __builtin_elementwise_max(loE, __builtin_elementwise_min(aE, bE));                 \
+        loO = __builtin_elementwise_max(loO, __builtin_elementwise_min(aO, bO));                 \
+        hiE = __builtin_elementwise_min(hiE, __builtin_elementwise_max(aE, bE));                 \
+        hiO = __builtin_elementwise_min(hiO, __builtin_elementwise_max(aO, bO));                 \
+    }
+    ORBX_PAIR(3, 0, true)   // circle pixels 0 / 8
+    ORBX_PAIR(3, 1, false)  // 1 / 9
+    ORBX_PAIR(2, 2, false)  // 2 / 10
+    ORBX_PAIR(1, 3, false)  // 3 / 11
+    ORBX_PAIR(0, 3, false)  // 4 / 12
+    ORBX_PAIR(-1, 3, false) // 5 / 13
+    ORBX_PAIR(-2, 2, false) // 6 / 14
+    ORBX_PAIR(-3, 1, false) // 7 / 15
+#undef ORBX_PAIR
+    u16x2 vE, vO;
+    fast_pick<0>(r[3], vE, vO);
+    const u16x2 t = pk2(th2), one = pk2(0x00010001u);
+    // saturating differences: non-zero half = condition holds
+    const u16x2 dE = __builtin_elementwise_min(__builtin_elementwise_sub_sat(vE, loE + t), one);
+    const u16x2 dO = __builtin_elementwise_min(__builtin_elementwise_sub_sat(vO, loO + t), one);
+    const u16x2 gE = __builtin_elementwise_min(__builtin_elementwise_sub_sat(hiE, vE + t), one);
+    const u16x2 gO = __builtin_elementwise_min(__builtin_elementwise_sub_sat(hiO, vO + t), one);
+    // bytes 0..3 = pixels 0..3: dark | bright << 1; both set cannot be a corner -> 0
+    uint32_t code = (pk1(dE) | (pk1(gE) << 1)) | ((pk1(dO) | (pk1(gO) << 1)) << 8);
+    code &= ~((code & (code >> 1) & 0x01010101u) * 3u);
+    return code;
 }
 
 // cornerScore<16>: (largest arc-minimum of e_k over the 16 circular 9-arcs) - 1
@@ -205,9 +260,9 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int sgn, int th)
 // in FAST raster order, coordinates relative to (minBorderX, minBorderY).
 // Packed candidate: y<<20 | x<<8 | score.
 //
-// Phases: (1) cell tile -> LDS as dwords; (2) every pixel: 16 differences + the
-// opposite-pair pre-test, survivors (a few %) compacted in raster order into an
-// LDS queue; (3) survivors only: arc score -> score map; (4) survivors with a
+// Phases: (1) cell tile -> LDS as dwords; (2) every pixel: the opposite-pair pre-test,
+// 4 adjacent pixels per lane on packed u16 (fast_pretest4), survivors (a few %)
+// compacted in raster order into an LDS queue; (3) survivors only: arc score -> score map; (4) survivors with a
 // score: 3x3 strict NMS (the local-maximum flag does not depend on the threshold:
 // a neighbour below it is smaller than the centre anyway); (5) ordered emission.
 // TS / SS (tile and score-map strides) are compile-time so that the 16 circle
@@ -232,36 +287,55 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
     int total = 0;
     if (zw > 0 && zh > 0) {
-        // (1) tile: aligned dword loads; pixel (x, y) of the cell lives at tile[y*TS + x + xoff]
+        // (1) tile: aligned dword loads; pixel (x, y) of the cell lives at tile[y*TS + 4 + x + xoff]
+        // (4 spare bytes on the left: the packed pre-test reads one dword either side of its group)
         const int xoff = ci.x0 & 3, ndw = (cw + xoff + 3) >> 2;
         const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + (ci.x0 - xoff);
         const float inv_ndw = 1.0f / (float)ndw; // i / ndw via float: (i + 0.5) / ndw is >= 0.025 away from any integer
         for (int i = lane; i < ch * ndw; i += 64) {
             const int y = (int)(((float)i + 0.5f) * inv_ndw), xw = i - y * ndw;
-            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = *reinterpret_cast<const uint32_t *>(img + __mul24(y, lv.stride) + 4 * xw);
+            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 + 4 * xw) = *reinterpret_cast<const uint32_t *>(img + __mul24(y, lv.stride) + 4 * xw);
         }
         for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
         __syncthreads();
-        const uint8_t *t0 = tile + 3 * TS + 3 + xoff; // zone pixel (0,0)
-        const int npx = zw * zh;
+        const int zc0 = 7 + xoff;                     // tile column of zone pixel 0
+        const uint8_t *t0 = tile + 3 * TS + zc0;      // zone pixel (0,0)
         const unsigned long long lt = (1ull << lane) - 1ull;
-        // (2) pre-test, survivors -> queue entries y<<6 | x | polarity<<12
+        // (2) pre-test, survivors -> queue entries y<<6 | x | polarity<<12.  A group = the 4
+        // pixels of one tile dword; groups overlapping the zone row, in raster order.
         int nq = 0;
         {
-            int x = lane, y = 0;
-            while (x >= zw) { x -= zw; ++y; }
-            for (int p0 = 0; p0 < npx; p0 += 64) {
-                int pol = 0;
-                if (p0 + lane < npx) {
-                    int d[16];
-                    fast_diffs(t0 + y * TS + x, TS, d);
-                    pol = fast_pretest(d, minTh);
+            const int g0 = zc0 >> 2, ngx = ((zc0 + zw - 1) >> 2) - g0 + 1, ngrp = ngx * zh;
+            const uint32_t th2 = (uint32_t)minTh | ((uint32_t)minTh << 16);
+            const int qstep = 64 / ngx, rstep = 64 - qstep * ngx; // lane + 64 -> (gx + rstep, y + qstep), one carry
+            int y = lane / ngx, gx = lane - y * ngx;
+            unsigned short *const dump = queue + zw * zh;         // one spare slot per lane for rejected pixels
+            for (int p0 = 0; p0 < ngrp; p0 += 64) {
+                uint32_t code = 0;
+                const int xs = 4 * (g0 + gx) - zc0;   // zone x of the group's pixel 0 (-3 .. zw-1)
+                if (p0 + lane < ngrp) {
+                    code = fast_pretest4<TS>(tile + (y + 3) * TS + 4 * (g0 + gx), th2);
+                    const int jlo = max(0, -xs), jhi = min(4, zw - xs); // pixels jlo..jhi-1 are in the zone
+                    code &= (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (4 - jhi)));
                 }
-                const unsigned long long b = __ballot(pol != 0);
-                if (pol) queue[nq + __popcll(b & lt)] = (unsigned short)((y << 6) | x | (pol << 12));
-                nq += __popcll(b);
-                x += 64;
-                while (x >= zw) { x -= zw; ++y; }
+                if (__ballot(code != 0)) {
+                    // survivors of this lane: bytes 0..3 are 0/1/2 -> one bit per pixel, n = how many
+                    const uint32_t nz = (code | (code >> 1)) & 0x01010101u;
+                    const int n = __popc(nz);
+                    const unsigned long long c0 = __ballot(n & 1), c1 = __ballot(n & 2), c2 = __ballot(n & 4);
+                    int pos = nq + __popcll(c0 & lt) + 2 * __popcll(c1 & lt) + 4 * __popcll(c2 & lt);
+                    const int ent = (y << 6) + xs;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { // branch-free: rejected pixels go to the lane's dump slot
+                        const int pol = (code >> (8 * j)) & 3;
+                        unsigned short *dst = pol ? queue + pos : dump + lane;
+                        *dst = (unsigned short)((ent + j) | (pol << 12));
+                        pos += pol != 0;
+                    }
+                    nq += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
+                }
+                gx += rstep; y += qstep;
+                if (gx >= ngx) { gx -= ngx; ++y; }
             }
         }
         __syncthreads();
@@ -1060,10 +1134,13 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
     }
     ex->NC = maxN + 8;
-    ex->TS = ex->SS = (maxcw + 3 <= 64) ? 64 : 80; // + up to 3 bytes of alignment shift; zone <= 63
+    // tile row = 4 spare bytes + up to 3 of alignment shift + the cell + the packed pre-test's
+    // right-hand dword; zone <= 63 (6-bit queue coordinates)
+    if (maxcw + 11 > 80 || maxch > 69) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than the LDS tile");
+    ex->TS = ex->SS = (maxcw + 11 <= 64) ? 64 : 80;
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
-    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 16;
+    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
     ex->oct_kcap = 4096;
     ex->oct_lds = (int)sizeof(int) * (8 + ex->maxcells + 1 + 21 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");

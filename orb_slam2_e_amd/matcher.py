@@ -113,6 +113,44 @@ class ORBmatcher:
                                          *[_p(o) for o in outs]))
         return tuple(outs)
 
+    def search_projection(self, queries, qdesc, qangle, qtakes, kps, desc, bounds, occupied=None, uright=None, th_accept=None,
+                          ratio_same_level=False):
+        """The SearchByProjection family as a whole loop (ORBmatcher.cc:46-132, :491-604, :1529-1800): in-loop
+        assignment, acceptance, rotation check (self.mbCheckOrientation).  Returns (match_kp, match_q, nmatches):
+        match_kp[j] = query assigned to keypoint j (-1 untouched, -2 cleared by the rotation check)."""
+        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+        qa = np.ascontiguousarray(qangle, np.float32) if qangle is not None else None
+        qt = np.ascontiguousarray(qtakes, np.uint8) if qtakes is not None else None
+        kps = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+        oc = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else None
+        ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+        nq, n = len(q), len(kps)
+        mk = np.zeros(n, np.int32); mq = np.zeros(nq, np.int32); nm = C.c_int(0)
+        opt = lambda a: _p(a) if a is not None else None
+        self._L.orbm_search_projection.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_search_projection(_p(q), _p(qd), opt(qa), opt(qt), nq, _p(kps), _p(d), n, opt(oc), opt(ur),
+                                             *[float(b) for b in bounds], self.TH_HIGH if th_accept is None else int(th_accept),
+                                             C.c_float(self.mfNNratio), int(ratio_same_level), int(self.mbCheckOrientation),
+                                             _p(mk), _p(mq), C.byref(nm)))
+        return mk, mq, nm.value
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, vbPrevMatched, bounds, windowSize=10):
+        """ORBmatcher::SearchForInitialization (ORBmatcher.cc:606-721).  kps = mvKeysUn of F1 / F2, bounds = F2's
+        grid bounds.  Returns (vnMatches12, updated vbPrevMatched, nmatches)."""
+        k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        pv = np.array(vbPrevMatched, np.float32, copy=True).reshape(-1, 2)
+        m12 = np.zeros(len(k1), np.int32); nm = C.c_int(0)
+        self._L.orbm_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int,
+                                                           C.c_void_p, C.c_void_p]
+        check(self._L.orbm_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(pv),
+                                                     *[float(b) for b in bounds], int(windowSize), C.c_float(self.mfNNratio),
+                                                     int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
+        return m12, pv, nm.value
+
     CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
                           ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
 

@@ -168,6 +168,42 @@ def _declared_symbols():
     return sorted(set(syms))
 
 
+def test_sequential_search_oracle_known_answers():
+    """Hand-made cases for the in-loop bookkeeping of SearchByProjection (ORBmatcher.cc:87-89,124-127,
+    1652-1668) and SearchForInitialization (:645-646, :678-682)."""
+    from orb_slam2_e_amd.extractor import KP_DTYPE
+    kps = np.zeros(3, KP_DTYPE); kps["x"] = [100, 104, 300]; kps["y"] = [100, 100, 300]
+    desc = np.zeros((3, 32), np.uint8); desc[1, 0] = 0x0f; desc[2] = 255
+    q = np.zeros(2, oracle.WQ_DTYPE); q["u"] = 101; q["v"] = 100; q["r"] = 10; q["min_level"] = -1; q["max_level"] = -1
+    qd = np.zeros((2, 32), np.uint8); qa = np.zeros(2, np.float32); b = (0, 0, 640, 480)
+    # both queries prefer keypoint 0; if the first one's point blocks it, the second falls back to keypoint 1
+    mk, mq, nm = oracle.search_projection_seq(q, qd, qa, np.array([1, 1], np.uint8), kps, desc, b, check_orientation=False)
+    assert mk.tolist() == [0, 1, -1] and mq.tolist() == [0, 1] and nm == 2
+    # a point without observations does not block: the later query overwrites the slot, both are counted
+    mk, mq, nm = oracle.search_projection_seq(q, qd, qa, np.array([0, 1], np.uint8), kps, desc, b, check_orientation=False)
+    assert mk.tolist() == [1, -1, -1] and mq.tolist() == [0, 0] and nm == 2
+    # rotation check: 12 matches rotated by ~30 deg (bin 1) and one by ~120 deg (bin 4 < 10 % of the maximum -> rejected)
+    n = 13
+    kps = np.zeros(n, KP_DTYPE); kps["x"] = 50 + 40 * np.arange(n); kps["y"] = 200
+    desc = np.eye(n, 32, dtype=np.uint8)
+    q = np.zeros(n, oracle.WQ_DTYPE); q["u"] = kps["x"]; q["v"] = 200; q["r"] = 5; q["min_level"] = -1; q["max_level"] = -1
+    qa = np.full(n, 30.0, np.float32); qa[7] = 120.0
+    mk, mq, nm = oracle.search_projection_seq(q, desc, qa, np.ones(n, np.uint8), kps, desc, b)
+    assert nm == 12 and mk[7] == -2 and (np.delete(mk, 7) == np.delete(np.arange(n), 7)).all() and mq[7] == 7
+    # SearchForInitialization: two F1 keypoints want the same F2 keypoint; the closer (later) one steals it
+    k1 = np.zeros(3, KP_DTYPE); k1["x"] = [100, 101, 400]; k1["y"] = [100, 100, 300]; k1["octave"] = [0, 0, 1]
+    k2 = np.zeros(2, KP_DTYPE); k2["x"] = [100, 400]; k2["y"] = [100, 300]
+    d1 = np.zeros((3, 32), np.uint8); d1[0, 0] = 0x03
+    d2 = np.zeros((2, 32), np.uint8)
+    prev = np.stack([k1["x"], k1["y"]], 1)
+    m12, pv, nm = oracle.search_for_initialization(k1, d1, k2, d2, prev, b, 20, 0.9, False)
+    assert m12.tolist() == [-1, 0, -1] and nm == 1           # i1=0 matched at distance 2, then i1=1 (distance 0) stole it;
+    assert pv[1].tolist() == [100.0, 100.0]                  # the octave-1 keypoint is never a query (:622-624)
+    # the other order: the first holds distance 0, the later one (distance 2) is gated out by vMatchedDistance
+    m12, pv, nm = oracle.search_for_initialization(k1[[1, 0, 2]], d1[[1, 0, 2]], k2, d2, prev, b, 20, 0.9, False)
+    assert m12.tolist() == [0, -1, -1] and nm == 1
+
+
 def test_library_builds_and_exports_every_declared_symbol():
     from orb_slam2_e_amd import _lib
     so = _lib.SO_PATH if os.path.exists(_lib.SO_PATH) else _lib.build()
