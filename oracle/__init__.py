@@ -444,6 +444,36 @@ def search_for_initialization(kps1, desc1, kps2, desc2, prev, bounds, window=100
     return m12, pv, nm
 
 
+def feature_vector(node_id, keep=None):
+    """DBoW2::FeatureVector as arrays: (nodes ascending, off, items in feature order)."""
+    node_id = np.asarray(node_id)
+    idx = np.arange(len(node_id)) if keep is None else np.nonzero(keep)[0]
+    order = idx[np.argsort(node_id[idx], kind="stable")]
+    nodes, start = np.unique(node_id[order], return_index=True)
+    off = np.append(start, len(order)).astype(np.int32)
+    return nodes.astype(np.int32), off, order.astype(np.int32)
+
+
+def search_by_bow(fv1, valid1, desc1, angle1, fv2, valid2, desc2, angle2, kf_kf=False, nnratio=0.6, check_orientation=True):
+    """ORBmatcher::SearchByBoW (both forms) -> (match12, match21, nmatches)."""
+    L = lib()
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    n1, n2 = len(desc1), len(desc2)
+    nodes1, off1, it1 = [i32(a) for a in fv1]; nodes2, off2, it2 = [i32(a) for a in fv2]
+    v1 = np.ascontiguousarray(valid1, np.uint8)
+    v2 = np.ascontiguousarray(valid2, np.uint8) if valid2 is not None else np.ones(n2, np.uint8)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    a1 = np.ascontiguousarray(angle1, np.float32); a2 = np.ascontiguousarray(angle2, np.float32)
+    m12 = np.zeros(n1, np.int32); m21 = np.zeros(n2, np.int32)
+    L.oracle_search_by_bow.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    nm = L.oracle_search_by_bow(int(kf_kf), _p(nodes1), _p(off1), _p(it1), len(nodes1), _p(v1), _p(d1), _p(a1), n1,
+                                _p(nodes2), _p(off2), _p(it2), len(nodes2), _p(v2), _p(d2), _p(a2), n2, nnratio,
+                                int(check_orientation), _p(m12), _p(m21))
+    return m12, m21, nm
+
+
 CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
                       ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
 

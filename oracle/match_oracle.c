@@ -407,6 +407,68 @@ int oracle_search_for_initialization(const float *xy1, const int *octave1, const
     return nmatches;
 }
 
+/* ORBmatcher::SearchByBoW, both forms: (KeyFrame*, Frame&, matches) ORBmatcher.cc:360-489
+ * (kf_kf = 0) and (KeyFrame*, KeyFrame*, matches12) :723-856 (kf_kf = 1).  A
+ * DBoW2::FeatureVector is given as its std::map in key order: nodes[nn] ascending,
+ * members of node k = items[off[k] .. off[k+1]) in insertion (= feature) order.
+ * valid1[i] = "feature i of the first keyframe owns a good MapPoint" (:395-399, :763-767);
+ * valid2 (kf_kf only) the same for the second (:782-786).  match12[n1] = feature of
+ * the second set or -1; match21[n2] = feature of the first or -1.  kf_kf = 0 accepts
+ * bestDist1 <= TH_LOW (:429), kf_kf = 1 bestDist1 < TH_LOW (:799).  Returns nmatches. */
+int oracle_search_by_bow(int kf_kf, const int *nodes1, const int *off1, const int *items1, int nn1, const uint8_t *valid1,
+                         const uint8_t *desc1, const float *angle1, int n1, const int *nodes2, const int *off2, const int *items2,
+                         int nn2, const uint8_t *valid2, const uint8_t *desc2, const float *angle2, int n2, float nnratio,
+                         int check_orientation, int *match12, int *match21)
+{
+    const int TH_LOW = 45; /* ORBmatcher.cc:38 */
+    int hist[HISTO_LENGTH] = {0};
+    int *bin1 = (int *)malloc(sizeof(int) * (n1 + 1));
+    int a = 0, b = 0, i, nmatches = 0;
+    for (i = 0; i < n1; i++) { match12[i] = -1; bin1[i] = -1; }
+    for (i = 0; i < n2; i++) match21[i] = -1;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            int k1, k2;
+            for (k1 = off1[a]; k1 < off1[a + 1]; k1++) {
+                const int idx1 = items1[k1];
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                if (!valid1[idx1]) continue;
+                for (k2 = off2[b]; k2 < off2[b + 1]; k2++) {
+                    const int idx2 = items2[k2];
+                    int dist;
+                    if (match21[idx2] >= 0) continue;          /* vpMapPointMatches[realIdxF] / vbMatched2[idx2] */
+                    if (kf_kf && !valid2[idx2]) continue;
+                    dist = oracle_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (kf_kf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        match12[idx1] = bestIdx2; match21[bestIdx2] = idx1;
+                        if (check_orientation) { bin1[idx1] = rot_bin(angle1[idx1], angle2[bestIdx2]); hist[bin1[idx1]]++; }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) a++;          /* lower_bound */
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (i = 0; i < n1; i++)
+            if (bin1[i] >= 0 && bin1[i] != ind1 && bin1[i] != ind2 && bin1[i] != ind3) {
+                match21[match12[i]] = -1; match12[i] = -1; nmatches--;
+            }
+    }
+    free(bin1);
+    return nmatches;
+}
+
 /* ---- the fork's whole-map SearchByProjection(Frame&, Map*, Rcw, tcw, ...),
  * ORBmatcher.cc:134-222, with isInFrustum :262-330, ComputeDistance :224-260 and
  * RadiusByViewingCos :332-338, literally (mixed float / double arithmetic kept).

@@ -36,6 +36,7 @@ namespace {
 constexpr int SEQ_CAP = 8192;      // candidate entries staged in LDS per batch of queries
 constexpr int SEQ_MAXN = 8192;     // keypoints per frame the resolver's LDS state holds
 constexpr int HISTO_LENGTH = 30;   // ORBmatcher.cc:40
+enum { ACCEPT_BEST = 0, ACCEPT_RATIO_SAME_LEVEL = 1, ACCEPT_RATIO = 2 };
 
 // Sorted keypoint record: position sp in this array = rank in GetFeaturesInArea order.
 struct SeqKp { float x, y, uright; int octave; };
@@ -91,6 +92,22 @@ __global__ __launch_bounds__(MT) void k_win_list(const WinQuery *__restrict__ q,
     if (!FILL && act) cnt[i] = c;
 }
 
+// Entries for explicit candidate lists (BoW-node members in member order): one lane per
+// query, entry = dist << 20 | candidate index; a distance of 256 can never be selected.
+__global__ __launch_bounds__(MT) void k_list_fill(const uint4 *__restrict__ A, int nq, const uint4 *__restrict__ B,
+                                                  const int *__restrict__ off, const int *__restrict__ cand,
+                                                  unsigned *__restrict__ ent)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i >= nq) return;
+    const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
+    for (int k = off[i]; k < off[i + 1]; ++k) {
+        const int j = cand[k];
+        const int dist = popc256(a0, a1, B[2 * j], B[2 * j + 1]);
+        ent[k] = dist < 256 ? ((unsigned)dist << 20) | (unsigned)j : 0xffffffffu;
+    }
+}
+
 // Exclusive scan of cnt[0..n) into off[0..n], one block (n is a few thousand).
 __global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt, int n, int *__restrict__ off)
 {
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt,
 // acc_sp[i] = candidate chosen by query i when it was accepted (else -1).
 template <int MODE>
 __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent, const int *__restrict__ off, int nq, int ns,
-                                                const uint8_t *__restrict__ takes, int th, float nnratio, int ratio_same_level,
+                                                const uint8_t *__restrict__ takes, int th, float nnratio, int accept_mode,
                                                 int *__restrict__ acc_sp, int *__restrict__ out_a, int *__restrict__ nmatches)
 {
     extern __shared__ __align__(16) unsigned sm[];
@@ -176,7 +193,8 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
             if (MODE == 0) {
                 // initial bestDist2 = 256 when there is no second candidate (:79-81)
                 const int sec = sp2 >= 0 ? second : 256;
-                if (acc && ratio_same_level && l1 == l2 && (float)best > nnratio * (float)sec) acc = false;
+                if (accept_mode == ACCEPT_RATIO_SAME_LEVEL && l1 == l2 && (float)best > nnratio * (float)sec) acc = false; // :121
+                if (accept_mode == ACCEPT_RATIO && !((float)best < nnratio * (float)sec)) acc = false;                    // :431, :801
             } else {
                 acc = acc && (float)best < (float)second * nnratio; // INT_MAX when alone (:637-638,674-676)
             }
@@ -309,8 +327,9 @@ void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint
 
 // Shared driver.  mode 0: projection family; mode 1: SearchForInitialization.
 int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes, int nq,
-                   const SortedFrame &sf, int n, int has_uright, int th, float nnratio, int ratio_same_level, int check,
-                   int32_t *match_kp, int32_t *match_q, int *nmatches)
+                   const SortedFrame &sf, int n, int has_uright, int th, float nnratio, int accept_mode, int check,
+                   int32_t *match_kp, int32_t *match_q, int *nmatches, const int32_t *cand_off = nullptr,
+                   const int32_t *cand_idx = nullptr)
 {
     const int ns = (int)sf.kp.size();
     if (ns > SEQ_MAXN || nq > 65536) ORBX_FAIL(ORBX_ERR_CAPACITY, "frame too large for the sequential resolver");
@@ -325,9 +344,9 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         dstate.alloc(sizeof(int) * std::max(ns, nq)) || dmq.alloc(sizeof(int) * nq) || dmk.alloc(sizeof(int) * (n ? n : 1)) ||
         dnm.alloc(sizeof(int)))
         ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(dq.p, queries, sizeof(WinQuery) * nq, hipMemcpyHostToDevice));
+    if (queries) ORBX_HIP(hipMemcpy(dq.p, queries, sizeof(WinQuery) * nq, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(da.p, qdesc, (size_t)32 * nq, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dk.p, sf.kp.data(), sizeof(SeqKp) * ns, hipMemcpyHostToDevice));
+    if (queries) ORBX_HIP(hipMemcpy(dk.p, sf.kp.data(), sizeof(SeqKp) * ns, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(db.p, sf.desc.data(), (size_t)32 * ns, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(dang.p, sf.angle.data(), sizeof(float) * ns, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(dperm.p, sf.perm.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
@@ -338,21 +357,34 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     ORBX_HIP(hipMemset(dmk.p, 0xff, sizeof(int) * (n ? n : 1))); // -1: slot untouched
     const int init_dist = mode == 0 ? 256 : INT_MAX;
     const dim3 g((nq + MT - 1) / MT);
-    hipLaunchKernelGGL(k_win_list<0>, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq, (const SeqKp *)dk.p,
-                       (const uint4 *)db.p, ns, has_uright, init_dist, (int *)dcnt.p, (const int *)nullptr, (unsigned *)nullptr);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, 0, (const int *)dcnt.p, nq, (int *)doff.p);
-    ORBX_HIP(hipGetLastError());
-    int total = 0;
-    ORBX_HIP(hipMemcpy(&total, (int *)doff.p + nq, sizeof(int), hipMemcpyDeviceToHost));
-    if (dent.alloc(sizeof(unsigned) * (size_t)(total ? total : 1))) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    hipLaunchKernelGGL(k_win_list<1>, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq, (const SeqKp *)dk.p,
-                       (const uint4 *)db.p, ns, has_uright, init_dist, (int *)nullptr, (const int *)doff.p, (unsigned *)dent.p);
+    if (cand_off) { // explicit candidate lists
+        DevBuf dcand;
+        const int total = cand_off[nq];
+        if (dcand.alloc(sizeof(int) * (size_t)(total ? total : 1)) || dent.alloc(sizeof(unsigned) * (size_t)(total ? total : 1)))
+            ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+        ORBX_HIP(hipMemcpy(doff.p, cand_off, sizeof(int) * (nq + 1), hipMemcpyHostToDevice));
+        if (total) ORBX_HIP(hipMemcpy(dcand.p, cand_idx, sizeof(int) * total, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, 0, (const uint4 *)da.p, nq, (const uint4 *)db.p, (const int *)doff.p,
+                           (const int *)dcand.p, (unsigned *)dent.p);
+        ORBX_HIP(hipGetLastError());
+        ORBX_HIP(hipDeviceSynchronize()); // dcand is released at the end of this scope
+    } else {
+        hipLaunchKernelGGL(k_win_list<0>, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq, (const SeqKp *)dk.p,
+                           (const uint4 *)db.p, ns, has_uright, init_dist, (int *)dcnt.p, (const int *)nullptr, (unsigned *)nullptr);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, 0, (const int *)dcnt.p, nq, (int *)doff.p);
+        ORBX_HIP(hipGetLastError());
+        int total = 0;
+        ORBX_HIP(hipMemcpy(&total, (int *)doff.p + nq, sizeof(int), hipMemcpyDeviceToHost));
+        if (dent.alloc(sizeof(unsigned) * (size_t)(total ? total : 1))) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+        hipLaunchKernelGGL(k_win_list<1>, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq, (const SeqKp *)dk.p,
+                           (const uint4 *)db.p, ns, has_uright, init_dist, (int *)nullptr, (const int *)doff.p, (unsigned *)dent.p);
+    }
     const size_t lds = sizeof(unsigned) * SEQ_CAP + sizeof(int) * (2 * (size_t)ns + (mode == 1 ? nq : 0)) + 16;
     if (lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_CAPACITY, "resolver state exceeds LDS");
     if (mode == 0) {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_resolve<0>, dim3(1), dim3(64), lds, 0, (const unsigned *)dent.p, (const int *)doff.p, nq, ns,
-                           (const uint8_t *)dtk.p, th, nnratio, ratio_same_level, (int *)dacc.p, (int *)dstate.p, (int *)dnm.p);
+                           (const uint8_t *)dtk.p, th, nnratio, accept_mode, (int *)dacc.p, (int *)dstate.p, (int *)dnm.p);
         hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, 0, (const int *)dacc.p, (const int *)dstate.p, nq, ns,
                            (const float *)dqang.p, (const float *)dang.p, (const int *)dperm.p, check, (int *)dmq.p, (int *)dmk.p,
                            (int *)dnm.p);
@@ -388,7 +420,8 @@ int orbm_search_projection(const orbm_window_query *queries, const uint8_t *qdes
     SortedFrame sf;
     sort_frame(kps, desc, n, occupied, uright, min_x, min_y, max_x, max_y, sf);
     return run_sequential(0, reinterpret_cast<const WinQuery *>(queries), qdesc, qangle, qtakes, nq, sf, n, uright ? 1 : 0,
-                          th_accept, nnratio, ratio_same_level, check_orientation, match_kp, match_q, nmatches);
+                          th_accept, nnratio, ratio_same_level ? ACCEPT_RATIO_SAME_LEVEL : ACCEPT_BEST, check_orientation, match_kp,
+                          match_q, nmatches);
 }
 
 int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbx_keypoint *kps2,
@@ -416,6 +449,39 @@ int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *des
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < n1; ++i) // :715-718
         if (matches12[i] >= 0) { prev_matched[2 * i] = kps2[matches12[i]].x; prev_matched[2 * i + 1] = kps2[matches12[i]].y; }
+    return ORBX_OK;
+}
+
+int orbm_search_by_bow(const uint8_t *desc1, const float *angle1, int n1, const int32_t *qidx, int nq, const uint8_t *desc2,
+                       const float *angle2, int n2, const int32_t *cand_off, const int32_t *cand_idx, int th, int strict_th,
+                       float nnratio, int check_orientation, int32_t *match12, int32_t *match21, int *nmatches)
+{
+    if (n1 < 0 || n2 < 0 || nq < 0 || (n1 && (!desc1 || !match12)) || (n2 && !desc2) || (nq && (!qidx || !cand_off)) || !nmatches ||
+        (check_orientation && nq && (!angle1 || !angle2)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    for (int i = 0; i < nq; ++i)
+        if (qidx[i] < 0 || qidx[i] >= n1 || cand_off[i + 1] < cand_off[i]) ORBX_FAIL(ORBX_ERR_ARG, "bad query list");
+    if (nq && cand_off[0] != 0) ORBX_FAIL(ORBX_ERR_ARG, "bad query list");
+    for (int k = 0; nq && k < cand_off[nq]; ++k)
+        if (!cand_idx || cand_idx[k] < 0 || cand_idx[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "candidate index out of range");
+    ORBX_NEED_DEVICE();
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    if (match21) for (int j = 0; j < n2; ++j) match21[j] = -1;
+    *nmatches = 0;
+    if (nq == 0 || n2 == 0) return ORBX_OK;
+    SortedFrame sf; // the second set as it is: position = feature index
+    sf.kp.resize(n2); sf.perm.resize(n2); sf.angle.resize(n2); sf.desc.assign(desc2, desc2 + (size_t)32 * n2);
+    for (int j = 0; j < n2; ++j) { sf.perm[j] = j; sf.angle[j] = angle2 ? angle2[j] : 0.f; }
+    std::vector<uint8_t> qd((size_t)32 * nq);
+    std::vector<float> qa(nq);
+    for (int i = 0; i < nq; ++i) { memcpy(&qd[32 * (size_t)i], desc1 + 32 * (size_t)qidx[i], 32); qa[i] = angle1 ? angle1[qidx[i]] : 0.f; }
+    std::vector<int32_t> mk(n2), mq(nq);
+    // bestDist1 < TH_LOW (:799) == bestDist1 <= TH_LOW - 1
+    const int rc = run_sequential(0, nullptr, qd.data(), qa.data(), nullptr, nq, sf, n2, 0, strict_th ? th - 1 : th, nnratio,
+                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, cand_off, cand_idx);
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < nq; ++i) // every accepted query blocks its candidate, so slot mq[i] still names i unless rejected
+        if (mq[i] >= 0 && mk[mq[i]] == i) { match12[qidx[i]] = mq[i]; if (match21) match21[mq[i]] = qidx[i]; }
     return ORBX_OK;
 }
 

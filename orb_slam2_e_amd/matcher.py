@@ -151,6 +151,25 @@ class ORBmatcher:
                                                      int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
         return m12, pv, nm.value
 
+    def SearchByBoW(self, fv1, valid1, desc1, angle1, fv2, valid2, desc2, angle2, kf_kf=False):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:360-489; kf_kf=False) or
+        SearchByBoW(KeyFrame*, KeyFrame*, ...) (:723-856; kf_kf=True).  fv = feature_vector_arrays(...) of each
+        side, valid = "owns a good MapPoint" masks (valid2 only for the KeyFrame form), angle = mvKeysUn angles.
+        Returns (match12, match21, nmatches)."""
+        from .vocabulary import bow_query_lists
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        a1 = np.ascontiguousarray(angle1, np.float32); a2 = np.ascontiguousarray(angle2, np.float32)
+        qidx, off, cand = bow_query_lists(fv1, np.asarray(valid1), fv2, np.asarray(valid2) if kf_kf else None)
+        n1, n2 = len(d1), len(d2)
+        m12 = np.zeros(n1, np.int32); m21 = np.zeros(n2, np.int32); nm = C.c_int(0)
+        self._L.orbm_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        check(self._L.orbm_search_by_bow(_p(d1), _p(a1), n1, _p(qidx), len(qidx), _p(d2), _p(a2), n2, _p(off), _p(cand),
+                                         self.TH_LOW, int(kf_kf), C.c_float(self.mfNNratio), int(self.mbCheckOrientation),
+                                         _p(m12), _p(m21), C.byref(nm)))
+        return m12, m21, nm.value
+
     CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
                           ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
 

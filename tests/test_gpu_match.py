@@ -285,3 +285,38 @@ def test_search_for_initialization(seed, ratio, ori, window):
     ref = oracle.search_for_initialization(k1, d1, k2, d2, prev, bounds, window, ratio, ori)
     assert ref[2] > 100
     assert got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def _bow_case(seed, n1=2000, n2=2100, nnodes=90):
+    rng = np.random.default_rng(seed)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    d1[rng.choice(n1, 500, replace=False)] = d1[:5][rng.integers(0, 5, 500)]      # look-alikes: the "already matched" skip matters
+    node1 = rng.integers(0, nnodes, n1) * 7 + 3
+    node1[d1[:, 0] % 5 == 0] = 3                                                   # one crowded node
+    src = rng.integers(0, n1, n2)
+    d2 = d1[src] ^ np.packbits(rng.random((n2, 256)) < 0.03, axis=1, bitorder="little")
+    node2 = node1[src].copy()
+    move = rng.random(n2) < 0.1
+    node2[move] = rng.integers(0, nnodes + 20, move.sum()) * 7 + 3                # some land in other (or unseen) nodes
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    a2 = ((a1[src] - rng.choice([15.0, 100.0, 260.0], n2, p=[0.75, 0.2, 0.05]) + rng.normal(0, 2, n2)) % 360).astype(np.float32)
+    valid1 = (rng.random(n1) < 0.8).astype(np.uint8); valid2 = (rng.random(n2) < 0.85).astype(np.uint8)
+    keep1 = rng.random(n1) < 0.97; keep2 = rng.random(n2) < 0.97                   # stop words never enter the FeatureVector
+    return d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2
+
+
+@pytest.mark.parametrize("seed,kf_kf,ori,ratio", [(0, False, True, 0.7), (1, True, True, 0.75), (2, False, False, 0.6), (3, True, False, 0.9)])
+def test_search_by_bow_whole_loop(seed, kf_kf, ori, ratio):
+    """orbm_search_by_bow (+ the host co-iteration) vs the literal SearchByBoW loops."""
+    from orb_slam2_e_amd.vocabulary import feature_vector_arrays
+    d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = _bow_case(seed)
+    fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
+    got = ORBmatcher(ratio, ori).SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, kf_kf)
+    ref = oracle.search_by_bow(oracle.feature_vector(node1, keep1), valid1, d1, a1, oracle.feature_vector(node2, keep2),
+                               valid2 if kf_kf else None, d2, a2, kf_kf, ratio, ori)
+    assert ref[2] > 300
+    assert got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    # the skip of already matched features is exercised: some query's unconstrained best was taken before it
+    best = oracle.match_bruteforce(d1, d2)[2]
+    taken = sum(1 for i in np.nonzero(ref[0] >= 0)[0] if ref[0][i] != best[i])
+    assert taken > 0
