@@ -215,22 +215,24 @@ int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *des
                                    int *nmatches);
 
 /* ORBmatcher::SearchByBoW, both forms, as a whole loop:
- *   SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)   src/ORBmatcher.cc:360-489  th = TH_LOW, strict_th = 0 (:429)
- *   SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)      :723-856                   th = TH_LOW, strict_th = 1 (:799)
- * The host walks the two DBoW2::FeatureVectors (the lower_bound co-iteration of :384-456)
- * and hands over the loop as lists: qidx[nq] = features of the first keyframe in the order
- * the reference visits them (common nodes ascending, members in order, those without a
- * good MapPoint left out, :395-399); candidates of query i = cand_idx[cand_off[i] ..
- * cand_off[i+1]) = members of the same node in the second set, in member order (for the
- * KeyFrame form without the features that own no good MapPoint, :782-786).  A candidate
- * matched by an earlier query is skipped (:415-416, :784), best/second from 256,
- * best <= th (< th if strict_th) and (float)best < nnratio * (float)second, rotation
- * histogram + ComputeThreeMaxima + rejection.  match12[n1] = feature of the second set
- * or -1; match21[n2] (may be NULL) the inverse; *nmatches as the reference returns it.
+ *   SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)   src/ORBmatcher.cc:360-489  valid2 = NULL, th = TH_LOW, strict_th = 0 (:429)
+ *   SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)      :723-856                   valid2 given, th = TH_LOW, strict_th = 1 (:799)
+ * A DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>) is passed flat, in map order:
+ * nodes[nn] ascending, members of node k = items[off[k] .. off[k+1]) in insertion order.
+ * valid1[i] != 0: feature i of the first keyframe owns a good MapPoint (:395-399, :763-767);
+ * valid2 likewise for the second keyframe (:782-786).  The lower_bound co-iteration of
+ * :384-456 runs on the host; then, in the reference's visiting order, every feature of the
+ * first set selects best / second (from 256) over the members of its node in the second
+ * set that no earlier feature has matched (:415-416, :784), accepts on best <= th (< th if
+ * strict_th) and (float)best < nnratio * (float)second; rotation histogram +
+ * ComputeThreeMaxima + rejection.  match12[n1] = feature of the second set or -1;
+ * match21[n2] (may be NULL) the inverse; *nmatches as the reference returns it.
  * At most 8192 features in the second set. */
-int orbm_search_by_bow(const uint8_t *desc1, const float *angle1, int n1, const int32_t *qidx, int nq, const uint8_t *desc2,
-                       const float *angle2, int n2, const int32_t *cand_off, const int32_t *cand_idx, int th, int strict_th,
-                       float nnratio, int check_orientation, int32_t *match12, int32_t *match21, int *nmatches);
+int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1, const uint8_t *valid1,
+                       const uint8_t *desc1, const float *angle1, int n1, const int32_t *nodes2, const int32_t *off2,
+                       const int32_t *items2, int nn2, const uint8_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
+                       int th, int strict_th, float nnratio, int check_orientation, int32_t *match12, int32_t *match21,
+                       int *nmatches);
 
 /* The fork's whole-map relocalisation search, ORBmatcher::SearchByProjection(Frame&,
  * Map*, double Rcw[3][3], double tcw[3], ...) (src/ORBmatcher.cc:134-222): for

@@ -43,6 +43,31 @@ inline void build_winkp(const orbx_keypoint *kps, int n, const uint8_t *skip, co
     }
 }
 
+// Per-call scratch without per-call hipMalloc: a pool of workspaces (device arena, pinned
+// host staging arena, a growable device buffer for candidate entries, a stream).  A call
+// leases one, carves its arrays out of the arenas (staged inputs sit at the same offsets
+// in both, so ONE copy uploads them) and releases the lease on return.  Concurrent
+// callers (Tracking / LocalMapping / LoopClosing threads) get different workspaces.
+// Workspaces live until process exit.
+struct Workspace {
+    char *dev = nullptr, *pin = nullptr;
+    unsigned *ent = nullptr;
+    size_t dev_cap = 0, pin_cap = 0, ent_cap = 0, used = 0;
+    hipStream_t st = nullptr;
+    int reserve(size_t dev_bytes, size_t pin_bytes); // discards the contents
+    int reserve_entries(size_t n);
+    size_t carve(size_t bytes) { const size_t o = used; used += (bytes + 255) & ~(size_t)255; return o; }
+    template <typename T> T *d(size_t off) const { return reinterpret_cast<T *>(dev + off); }
+    template <typename T> T *h(size_t off) const { return reinterpret_cast<T *>(pin + off); }
+};
+Workspace *workspace_acquire();
+void workspace_release(Workspace *w);
+struct WorkspaceLease {
+    Workspace *w;
+    WorkspaceLease() : w(workspace_acquire()) {}
+    ~WorkspaceLease() { workspace_release(w); }
+};
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }

@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -431,6 +432,58 @@ __global__ __launch_bounds__(MT) void k_hamming_matrix(const uint4 *__restrict__
 orbx::KernelProfiler g_prof;
 
 } // namespace
+
+namespace orbm_detail {
+
+static std::mutex g_ws_mutex;
+static std::vector<Workspace *> g_ws_free;
+
+int Workspace::reserve(size_t dev_bytes, size_t pin_bytes)
+{
+    used = 0;
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return -1; }
+    if (dev_bytes > dev_cap) {
+        if (dev) (void)hipFree(dev);
+        dev = nullptr; dev_cap = 0;
+        const size_t want = std::max(dev_bytes + dev_bytes / 2, (size_t)1 << 20);
+        if (hipMalloc((void **)&dev, want) != hipSuccess) { dev = nullptr; return -1; }
+        dev_cap = want;
+    }
+    if (pin_bytes > pin_cap) {
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr; pin_cap = 0;
+        const size_t want = std::max(pin_bytes + pin_bytes / 2, (size_t)1 << 20);
+        if (hipHostMalloc((void **)&pin, want, hipHostMallocDefault) != hipSuccess) { pin = nullptr; return -1; }
+        pin_cap = want;
+    }
+    return 0;
+}
+
+int Workspace::reserve_entries(size_t n)
+{
+    if (n <= ent_cap) return 0;
+    if (ent) (void)hipFree(ent);
+    ent = nullptr; ent_cap = 0;
+    const size_t want = std::max(n + n / 2, (size_t)1 << 18);
+    if (hipMalloc((void **)&ent, want * sizeof(unsigned)) != hipSuccess) { ent = nullptr; return -1; }
+    ent_cap = want;
+    return 0;
+}
+
+Workspace *workspace_acquire()
+{
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    if (!g_ws_free.empty()) { Workspace *w = g_ws_free.back(); g_ws_free.pop_back(); return w; }
+    return new Workspace();
+}
+
+void workspace_release(Workspace *w)
+{
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    g_ws_free.push_back(w);
+}
+
+} // namespace orbm_detail
 
 extern "C" {
 

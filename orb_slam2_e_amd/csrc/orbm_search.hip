@@ -8,13 +8,14 @@
 //
 // These loops are sequential in the reference: a query sees what earlier queries left in
 // mvpMapPoints / vMatchedDistance.  Here
-//   1. the frame's keypoints are sorted by (grid cell, index), so a scan in array order
-//      visits candidates exactly in Frame::GetFeaturesInArea order (src/Frame.cc:342-395);
-//   2. k_win_count / k_win_fill build, fully in parallel, every query's candidate list with
-//      its Hamming distances (the expensive part: window tests + 256-bit distances);
+//   1. the frame's keypoints are sorted by (grid cell, index): a window's candidates are a
+//      few contiguous runs of that array, in Frame::GetFeaturesInArea order (src/Frame.cc:342-395);
+//   2. k_win_wave (count, then fill; one wave per query) builds every query's candidate list
+//      with its Hamming distances, k_topk keeps each list's 8 best sorted -- the expensive
+//      part, fully parallel;
 //   3. k_resolve walks the queries in order, 64 at a time: every lane selects best / second
 //      for its query against the committed state; a lane whose best or second candidate
-//      was claimed by an earlier lane of the same batch is a conflict; lanes below the
+//      is claimed by an earlier lane of the same batch is a conflict; lanes below the
 //      first conflict commit, the rest select again.  A lane's selection can only change
 //      when an earlier query claims its best or second candidate, so the committed
 //      results are the sequential loop's results;
@@ -33,7 +34,6 @@ using namespace orbm_detail;
 
 namespace {
 
-constexpr int SEQ_CAP = 8192;      // candidate entries staged in LDS per batch of queries
 constexpr int SEQ_MAXN = 8192;     // keypoints per frame the resolver's LDS state holds
 constexpr int HISTO_LENGTH = 30;   // ORBmatcher.cc:40
 enum { ACCEPT_BEST = 0, ACCEPT_RATIO_SAME_LEVEL = 1, ACCEPT_RATIO = 2 };
@@ -41,70 +41,110 @@ enum { ACCEPT_BEST = 0, ACCEPT_RATIO_SAME_LEVEL = 1, ACCEPT_RATIO = 2 };
 // Sorted keypoint record: position sp in this array = rank in GetFeaturesInArea order.
 struct SeqKp { float x, y, uright; int octave; };
 
-// One lane per query, the sorted keypoints streamed through LDS.  FILL = 0: count the
-// candidates of each query (window + level + stereo tests of Frame.cc:365-390 and
-// ORBmatcher.cc:91-96); FILL = 1: also the distances, entry = dist << 20 | octave << 16 | sp.
-template <int FILL>
-__global__ __launch_bounds__(MT) void k_win_list(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
-                                                 const SeqKp *__restrict__ kp, const uint4 *__restrict__ B, int ns, int has_uright,
-                                                 int init_dist, int *__restrict__ cnt, const int *__restrict__ off,
-                                                 unsigned *__restrict__ ent)
+constexpr int TOPK = 8; // best candidates per query kept sorted for the resolver
+
+struct GridParams { float min_x, min_y, inv_w, inv_h; };
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-    __shared__ SeqKp s_kp[MT];
-    __shared__ uint4 s_d[FILL ? MT * 2 : 1];
-    const int i = blockIdx.x * MT + threadIdx.x, tid = threadIdx.x;
-    const bool act = i < nq;
-    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1};
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-    if (act) {
-        w = q[i];
-        if (FILL) { a0 = A[2 * i]; a1 = A[2 * i + 1]; }
-    }
-    const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
-    int c = 0;
-    unsigned *out = FILL && act ? ent + off[i] : nullptr;
-    for (int j0 = 0; j0 < ns; j0 += MT) {
-        __syncthreads();
-        if (j0 + tid < ns) {
-            s_kp[tid] = kp[j0 + tid];
-            if (FILL) { s_d[2 * tid] = B[2 * (j0 + tid)]; s_d[2 * tid + 1] = B[2 * (j0 + tid) + 1]; }
-        }
-        __syncthreads();
-        const int nt = min(MT, ns - j0);
-        for (int j = 0; j < nt; ++j) {
-            const SeqKp k = s_kp[j];
-            bool ok = act;
-            if (check_levels) ok = ok && !(k.octave < w.min_level) && !(w.max_level >= 0 && k.octave > w.max_level);
-            const float distx = k.x - w.u, disty = k.y - w.v;
-            ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
-            if (has_uright && k.uright > 0) ok = ok && !(fabsf(w.xr - k.uright) > w.r);
-            if (FILL) {
-                if (ok) {
-                    const int dist = popc256(a0, a1, s_d[2 * j], s_d[2 * j + 1]);
-                    // dist<bestDist / dist<bestDist2 can only fire below the initial value; dropped
-                    // entries keep their slot (count pass is distance-free) as "never selectable"
-                    out[c] = dist < init_dist ? ((unsigned)dist << 20) | ((unsigned)k.octave << 16) | (unsigned)(j0 + j) : 0xffffffffu;
-                }
-            }
-            c += ok;
-        }
-    }
-    if (!FILL && act) cnt[i] = c;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
 }
 
-// Entries for explicit candidate lists (BoW-node members in member order): one lane per
-// query, entry = dist << 20 | candidate index; a distance of 256 can never be selected.
+// One WAVE per query (4 per block).  Frame::GetFeaturesInArea (src/Frame.cc:342-395): the
+// cell range of the window in the reference's float arithmetic, then, column by column,
+// the keypoints of rows [nMinCellY, nMaxCellY] -- one contiguous run of the (cell, index)
+// sorted array -- tested 64 at a time: level range, |dx| < r && |dy| < r, and the stereo
+// check of ORBmatcher.cc:91-96.  FILL = 0 counts the survivors; FILL = 1 writes them in
+// that order with their distances: entry = dist << 20 | octave << 16 | sp (0xffffffff for
+// a distance that can never be selected).
+template <int FILL>
+__global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
+                                                 const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
+                                                 const int *__restrict__ cell_off, GridParams gp, int has_uright, int init_dist,
+                                                 int *__restrict__ cnt, const int *__restrict__ off, unsigned *__restrict__ ent)
+{
+    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const WinQuery w = q[i];
+    int c = 0;
+    const int nMinCellX = (int)fmaxf(0.f, floorf((w.u - gp.min_x - w.r) * gp.inv_w));
+    const int nMaxCellX = (int)fminf((float)FRAME_GRID_COLS - 1, ceilf((w.u - gp.min_x + w.r) * gp.inv_w));
+    const int nMinCellY = (int)fmaxf(0.f, floorf((w.v - gp.min_y - w.r) * gp.inv_h));
+    const int nMaxCellY = (int)fminf((float)FRAME_GRID_ROWS - 1, ceilf((w.v - gp.min_y + w.r) * gp.inv_h));
+    const bool none = !(w.r >= 0.f) || nMinCellX >= FRAME_GRID_COLS || nMaxCellX < 0 || nMinCellY >= FRAME_GRID_ROWS || nMaxCellY < 0;
+    if (!none) {
+        const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (FILL) { a0 = A[2 * i]; a1 = A[2 * i + 1]; }
+        unsigned *out = FILL ? ent + off[i] : nullptr;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int k0 = cell_off[ix * FRAME_GRID_ROWS + nMinCellY], k1 = cell_off[ix * FRAME_GRID_ROWS + nMaxCellY + 1];
+            for (int kb = k0; kb < k1; kb += 64) {
+                const int k = kb + lane;
+                bool ok = k < k1;
+                SeqKp p = {0.f, 0.f, 0.f, 0};
+                if (ok) p = kp[k];
+                if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
+                const float distx = p.x - w.u, disty = p.y - w.v;
+                ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
+                if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
+                const unsigned long long bal = __ballot(ok);
+                if (FILL && ok) {
+                    const int dist = popc256(a0, a1, B[2 * k], B[2 * k + 1]);
+                    out[c + __popcll(bal & lt)] = dist < init_dist ? ((unsigned)dist << 20) | ((unsigned)p.octave << 16) | (unsigned)k : 0xffffffffu;
+                }
+                c += __popcll(bal);
+            }
+        }
+    }
+    if (!FILL && lane == 0) cnt[i] = c;
+}
+
+// Entries for explicit candidate lists (BoW-node members in member order), one wave per
+// query: entry = dist << 20 | candidate index; a distance of 256 can never be selected.
 __global__ __launch_bounds__(MT) void k_list_fill(const uint4 *__restrict__ A, int nq, const uint4 *__restrict__ B,
                                                   const int *__restrict__ off, const int *__restrict__ cand,
                                                   unsigned *__restrict__ ent)
 {
-    const int i = blockIdx.x * MT + threadIdx.x;
+    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nq) return;
     const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
-    for (int k = off[i]; k < off[i + 1]; ++k) {
+    for (int k = off[i] + lane; k < off[i + 1]; k += 64) {
         const int j = cand[k];
         const int dist = popc256(a0, a1, B[2 * j], B[2 * j + 1]);
         ent[k] = dist < 256 ? ((unsigned)dist << 20) | (unsigned)j : 0xffffffffu;
+    }
+}
+
+// The TOPK entries of every list with the smallest (distance, position) keys, in that
+// order -- all the sequential resolver normally needs.  One wave per query.
+__global__ __launch_bounds__(MT) void k_topk(const unsigned *__restrict__ ent, const int *__restrict__ off, int nq,
+                                             unsigned *__restrict__ top)
+{
+    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const int b = off[i], len = off[i + 1] - b;
+    unsigned prev = 0;
+    bool done = false;
+    for (int r = 0; r < TOPK; ++r) {
+        unsigned g = 0xffffffffu;
+        if (!done) {
+            unsigned m = 0xffffffffu;
+            for (int p = lane; p < len; p += 64) {
+                const unsigned en = ent[b + p];
+                if (en != 0xffffffffu) {
+                    const unsigned key = ((en >> 20) << 16) | (unsigned)p;
+                    if (r == 0 || key > prev) m = min(m, key);
+                }
+            }
+            g = wave_min_u32(m);
+            done = g == 0xffffffffu;
+            prev = g;
+        }
+        if (lane == 0) top[(size_t)i * TOPK + r] = done ? 0xffffffffu : ent[b + (g & 0xffffu)];
     }
 }
 
@@ -128,67 +168,79 @@ __global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt,
 }
 
 // The sequential loop, 64 queries per batch (see the file header).  MODE 0 = projection
-// family: state = blocked[sp] ("mvpMapPoints[sp] holds a point later queries must skip"),
+// family / BoW: state = blocked[sp] ("the slot holds a point later queries must skip"),
 // match_kp[sp] = last query assigned to the slot.  MODE 1 = SearchForInitialization:
 // state = vMatchedDistance[sp], vnMatches21[sp], vnMatches12[i].
+// A lane selects the first two eligible entries of its query's TOPK list (sorted by
+// distance, then list position = the reference's strict-'<' first-wins order); only when
+// fewer than it needs remain there and the list is longer does it scan the whole list.
+// Conflicts go through a claim table: every accepted lane whose match blocks its slot
+// claims it with its lane number (minimum wins); a lane whose best or second slot is
+// claimed by a lower lane has to select again after that lane has committed.
 // acc_sp[i] = candidate chosen by query i when it was accepted (else -1).
 template <int MODE>
-__global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent, const int *__restrict__ off, int nq, int ns,
-                                                const uint8_t *__restrict__ takes, int th, float nnratio, int accept_mode,
-                                                int *__restrict__ acc_sp, int *__restrict__ out_a, int *__restrict__ nmatches)
+__global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent, const unsigned *__restrict__ top,
+                                                const int *__restrict__ off, int nq, int ns, const uint8_t *__restrict__ takes, int th,
+                                                float nnratio, int accept_mode, int *__restrict__ acc_sp, int *__restrict__ out_a,
+                                                int *__restrict__ nmatches)
 {
-    extern __shared__ __align__(16) unsigned sm[];
-    unsigned *s_ent = sm;
-    int *s_a = reinterpret_cast<int *>(sm + SEQ_CAP);                // MODE 0: match_kp[ns]   MODE 1: vMatchedDistance[ns]
-    int *s_b = s_a + ns;                                             // MODE 0: blocked bytes  MODE 1: vnMatches21[ns]
-    int *s_c = s_b + ns;                                             // MODE 1: vnMatches12[nq]
-    uint8_t *s_blk = reinterpret_cast<uint8_t *>(s_b);
+    extern __shared__ __align__(16) int sm[];
+    int *s_a = sm;            // MODE 0: match_kp[ns]   MODE 1: vMatchedDistance[ns]
+    int *s_b = s_a + ns;      // MODE 0: blocked[ns]    MODE 1: vnMatches21[ns]
+    int *s_claim = s_b + ns;  // lane that claims the slot in this pass, 64 = none
+    int *s_c = s_claim + ns;  // MODE 1: vnMatches12[nq]
     const int lane = threadIdx.x;
-    for (int j = lane; j < ns; j += 64) {
-        s_a[j] = MODE == 0 ? -1 : INT_MAX;
-        if (MODE == 1) s_b[j] = -1;
-    }
-    if (MODE == 0) for (int j = lane; j < (ns + 3) / 4; j += 64) s_b[j] = 0;
+    for (int j = lane; j < ns; j += 64) { s_a[j] = MODE == 0 ? -1 : INT_MAX; s_b[j] = MODE == 0 ? 0 : -1; s_claim[j] = 64; }
     if (MODE == 1) for (int j = lane; j < nq; j += 64) s_c[j] = -1;
     __syncthreads();
+    const bool need2 = MODE == 1 || accept_mode != ACCEPT_BEST;
     int nm = 0;
-    for (int i0 = 0; i0 < nq;) {
-        // batch = the leading queries whose entries fit the staging buffer (at least one)
-        const int lo = off[i0];
-        const bool in = i0 + lane < nq;
-        const int b_g = in ? off[i0 + lane] : 0, e_g = in ? off[i0 + lane + 1] : 0;
-        const unsigned long long fits = __ballot(in && e_g - lo <= SEQ_CAP);
-        int nb = fits == ~0ull ? 64 : __ffsll((long long)~fits) - 1;
-        const unsigned *src = s_ent;
-        int base = lo;
-        if (nb == 0) { nb = 1; src = ent; base = 0; }               // one oversized list: read it from HBM
-        else {
-            const int hi = __shfl(e_g, nb - 1);
-            for (int k = lo + lane; k < hi; k += 64) s_ent[k - lo] = ent[k];
-        }
-        __syncthreads();
-        const int i = i0 + lane, b = b_g - base, e = e_g - base;
-        unsigned long long pending = nb == 64 ? ~0ull : (1ull << nb) - 1ull;
-        const int tk = (MODE == 0 && lane < nb) ? takes[i] : 1;
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < nq;
+        const int b = in ? off[i] : 0, e = in ? off[i + 1] : 0;
+        uint4 t0 = make_uint4(~0u, ~0u, ~0u, ~0u), t1 = t0;
+        if (in) { t0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i]; t1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1]; }
+        const unsigned tp[TOPK] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const int tk = (MODE == 0 && in) ? takes[i] : 1;
+        unsigned long long pending = __ballot(in);
+        bool dirty = true;
+        int sp1 = -1, sp2 = -1, best = INT_MAX, second = INT_MAX, l1 = -1, l2 = -1;
         while (pending) {
             const bool mine = (pending >> lane) & 1ull;
-            unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
-            if (mine) {
-                for (int k = b; k < e; ++k) {
-                    const unsigned en = src[k];
-                    const int sp = en & 0xffffu, dist = (int)(en >> 20);
-                    const bool ok = en != 0xffffffffu && (MODE == 0 ? s_blk[sp] == 0 : s_a[sp] > dist);
-                    if (ok) {
-                        const unsigned key = ((unsigned)dist << 16) | (unsigned)(k - b);
-                        const unsigned hi = max(k1, key);
-                        k2 = min(k2, hi);
-                        k1 = min(k1, key);
+            if (mine && dirty) {
+                sp1 = sp2 = -1; best = second = INT_MAX; l1 = l2 = -1;
+                int found = 0;
+#pragma unroll
+                for (int r = 0; r < TOPK; ++r) {
+                    const unsigned en = tp[r];
+                    if (en != 0xffffffffu && found < 2) {
+                        const int sp = en & 0xffffu, dist = (int)(en >> 20);
+                        if (MODE == 0 ? s_b[sp] == 0 : s_a[sp] > dist) {
+                            if (found == 0) { sp1 = sp; best = dist; l1 = (en >> 16) & 15; }
+                            else { sp2 = sp; second = dist; l2 = (en >> 16) & 15; }
+                            ++found;
+                        }
                     }
                 }
+                if (found < (need2 ? 2 : 1) && e - b > TOPK) { // the short list ran dry: the whole list
+                    unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
+                    for (int k = b; k < e; ++k) {
+                        const unsigned en = ent[k];
+                        const int sp = en & 0xffffu, dist = (int)(en >> 20);
+                        if (en != 0xffffffffu && (MODE == 0 ? s_b[sp] == 0 : s_a[sp] > dist)) {
+                            const unsigned key = ((unsigned)dist << 16) | (unsigned)(k - b);
+                            const unsigned hi = max(k1, key);
+                            k2 = min(k2, hi);
+                            k1 = min(k1, key);
+                        }
+                    }
+                    sp1 = sp2 = -1; best = second = INT_MAX; l1 = l2 = -1;
+                    if (k1 != 0xffffffffu) { const unsigned en = ent[b + (k1 & 0xffffu)]; sp1 = en & 0xffffu; l1 = (en >> 16) & 15; best = (int)(k1 >> 16); }
+                    if (k2 != 0xffffffffu) { const unsigned en = ent[b + (k2 & 0xffffu)]; sp2 = en & 0xffffu; l2 = (en >> 16) & 15; second = (int)(k2 >> 16); }
+                }
+                if (!need2) sp2 = -1;
             }
-            int sp1 = -1, sp2 = -1, best = INT_MAX, second = INT_MAX, l1 = -1, l2 = -1;
-            if (k1 != 0xffffffffu) { const unsigned en = src[b + (k1 & 0xffffu)]; sp1 = en & 0xffffu; l1 = (en >> 16) & 15; best = (int)(k1 >> 16); }
-            if (k2 != 0xffffffffu) { const unsigned en = src[b + (k2 & 0xffffu)]; sp2 = en & 0xffffu; l2 = (en >> 16) & 15; second = (int)(k2 >> 16); }
             bool acc = mine && sp1 >= 0 && best <= th;
             if (MODE == 0) {
                 // initial bestDist2 = 256 when there is no second candidate (:79-81)
@@ -198,13 +250,13 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
             } else {
                 acc = acc && (float)best < (float)second * nnratio; // INT_MAX when alone (:637-638,674-676)
             }
-            // conflicts: an earlier accepted lane of this batch claims my best or second candidate
-            bool conflict = false;
-            for (unsigned long long m = __ballot(acc && tk); m; m &= m - 1ull) {
-                const int l = __ffsll((long long)m) - 1;
-                const int x = __shfl(sp1, l);
-                conflict = conflict || (mine && lane > l && (x == sp1 || x == sp2));
-            }
+            // claims of this pass
+            const bool claims = acc && tk;
+            if (claims) atomicMin(&s_claim[sp1], lane);
+            __syncthreads();
+            const bool conflict = mine && ((sp1 >= 0 && s_claim[sp1] < lane) || (sp2 >= 0 && s_claim[sp2] < lane));
+            __syncthreads();
+            if (claims) s_claim[sp1] = 64;
             const unsigned long long cm = __ballot(conflict);
             const int lc = cm ? __ffsll((long long)cm) - 1 : 64;
             const bool commit = mine && lane < lc;
@@ -214,7 +266,7 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
                 if (acc) {
                     if (MODE == 0) {
                         atomicMax(&s_a[sp1], i);               // the last query assigned to the slot stays
-                        if (tk) s_blk[sp1] = 1;
+                        if (tk) s_b[sp1] = 1;
                     } else {                                   // accepted candidates of one pass are distinct
                         old = s_b[sp1];
                         if (old >= 0) s_c[old] = -1;           // steal (:678-682)
@@ -224,9 +276,9 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
             }
             nm += __popcll(__ballot(commit && acc)) - __popcll(__ballot(old >= 0));
             pending &= ~((lc == 64 ? ~0ull : (1ull << lc) - 1ull));
+            dirty = conflict;
             __syncthreads();
         }
-        i0 += nb;
     }
     __syncthreads();
     if (MODE == 0) for (int j = lane; j < ns; j += 64) out_a[j] = s_a[j];   // match_kp by sorted position
@@ -297,6 +349,8 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
 
 struct SortedFrame {
     std::vector<SeqKp> kp;
+    std::vector<int> cell_off; // [COLS*ROWS + 1] runs of the sorted array per grid cell (col * ROWS + row)
+    GridParams gp = {0.f, 0.f, 0.f, 0.f};
     std::vector<int> perm;
     std::vector<float> angle;
     std::vector<uint8_t> desc;
@@ -314,6 +368,10 @@ void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint
         if (wk[j].order != 0xffffffffu) order.push_back(wk[j].order);
     std::sort(order.begin(), order.end());
     const size_t ns = order.size();
+    sf.gp = {min_x, min_y, (float)FRAME_GRID_COLS / (max_x - min_x), (float)FRAME_GRID_ROWS / (max_y - min_y)}; // Frame.cc:95-96
+    sf.cell_off.assign(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1, 0);
+    for (size_t k = 0; k < ns; ++k) sf.cell_off[(order[k] >> 16) + 1]++;
+    for (int c = 0; c < FRAME_GRID_COLS * FRAME_GRID_ROWS; ++c) sf.cell_off[c + 1] += sf.cell_off[c];
     sf.kp.resize(ns ? ns : 1); sf.perm.resize(ns ? ns : 1); sf.angle.resize(ns ? ns : 1); sf.desc.resize(32 * (ns ? ns : 1));
     for (size_t s = 0; s < ns; ++s) {
         const int j = (int)(order[s] & 0xffffu);
@@ -325,82 +383,108 @@ void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint
     sf.kp.resize(ns); sf.perm.resize(ns); sf.angle.resize(ns); sf.desc.resize(32 * ns);
 }
 
-// Shared driver.  mode 0: projection family; mode 1: SearchForInitialization.
+// Shared driver.  mode 0: projection family / BoW lists; mode 1: SearchForInitialization.
+// Inputs are staged in the workspace's pinned arena and uploaded with one copy; results
+// come back with one copy.  Everything runs on the workspace's stream.
 int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes, int nq,
                    const SortedFrame &sf, int n, int has_uright, int th, float nnratio, int accept_mode, int check,
                    int32_t *match_kp, int32_t *match_q, int *nmatches, const int32_t *cand_off = nullptr,
                    const int32_t *cand_idx = nullptr)
 {
-    const int ns = (int)sf.kp.size();
+    const int ns = (int)sf.perm.size();
     if (ns > SEQ_MAXN || nq > 65536) ORBX_FAIL(ORBX_ERR_CAPACITY, "frame too large for the sequential resolver");
     for (int j = 0; j < n && mode == 0; ++j) match_kp[j] = -1;
     for (int i = 0; i < nq; ++i) match_q[i] = -1;
     *nmatches = 0;
     if (nq == 0 || ns == 0) return ORBX_OK;
-    DevBuf dq, da, dk, db, dang, dqang, dperm, dtk, dcnt, doff, dacc, dstate, dmq, dmk, dnm, dent;
-    if (dq.alloc(sizeof(WinQuery) * nq) || da.alloc((size_t)32 * nq) || dk.alloc(sizeof(SeqKp) * ns) || db.alloc((size_t)32 * ns) ||
-        dang.alloc(sizeof(float) * ns) || dqang.alloc(sizeof(float) * nq) || dperm.alloc(sizeof(int) * ns) || dtk.alloc(nq) ||
-        dcnt.alloc(sizeof(int) * nq) || doff.alloc(sizeof(int) * (nq + 1)) || dacc.alloc(sizeof(int) * nq) ||
-        dstate.alloc(sizeof(int) * std::max(ns, nq)) || dmq.alloc(sizeof(int) * nq) || dmk.alloc(sizeof(int) * (n ? n : 1)) ||
-        dnm.alloc(sizeof(int)))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    if (queries) ORBX_HIP(hipMemcpy(dq.p, queries, sizeof(WinQuery) * nq, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(da.p, qdesc, (size_t)32 * nq, hipMemcpyHostToDevice));
-    if (queries) ORBX_HIP(hipMemcpy(dk.p, sf.kp.data(), sizeof(SeqKp) * ns, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(db.p, sf.desc.data(), (size_t)32 * ns, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dang.p, sf.angle.data(), sizeof(float) * ns, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dperm.p, sf.perm.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
-    if (qangle) ORBX_HIP(hipMemcpy(dqang.p, qangle, sizeof(float) * nq, hipMemcpyHostToDevice));
-    else ORBX_HIP(hipMemset(dqang.p, 0, sizeof(float) * nq));
-    if (qtakes) ORBX_HIP(hipMemcpy(dtk.p, qtakes, nq, hipMemcpyHostToDevice));
-    else ORBX_HIP(hipMemset(dtk.p, 1, nq));
-    ORBX_HIP(hipMemset(dmk.p, 0xff, sizeof(int) * (n ? n : 1))); // -1: slot untouched
+    const size_t lds = sizeof(int) * (3 * (size_t)ns + (mode == 1 ? nq : 0)) + 16;
+    if (lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_CAPACITY, "resolver state exceeds LDS");
+    const int ncand = cand_off ? cand_off[nq] : 0;
+
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    // staged inputs (same offsets on both sides), then device-only arrays, then the result block
+    const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * ns),
+                 o_b = w.carve((size_t)32 * ns), o_kang = w.carve(sizeof(float) * ns), o_qang = w.carve(sizeof(float) * nq),
+                 o_perm = w.carve(sizeof(int) * ns), o_tk = w.carve(nq), o_off = w.carve(sizeof(int) * (nq + 1)),
+                 o_cand = w.carve(sizeof(int) * (size_t)(ncand ? ncand : 1)),
+                 o_cell = w.carve(sizeof(int) * (FRAME_GRID_COLS * FRAME_GRID_ROWS + 1));
+    const size_t staged = w.used;
+    const size_t o_top = w.carve(sizeof(unsigned) * TOPK * (size_t)nq), o_cnt = w.carve(sizeof(int) * nq), o_acc = w.carve(sizeof(int) * nq),
+                 o_state = w.carve(sizeof(int) * (size_t)std::max(ns, nq));
+    const size_t o_res = w.used;
+    const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(sizeof(int));
+    const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
+    if (w.reserve(total_bytes, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    hipStream_t st = w.st;
+
+    if (queries) {
+        memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
+        memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
+        memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
+    }
+    memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
+    memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
+    memcpy(w.h<char>(o_kang), sf.angle.data(), sizeof(float) * ns);
+    if (qangle) memcpy(w.h<char>(o_qang), qangle, sizeof(float) * nq); else memset(w.h<char>(o_qang), 0, sizeof(float) * nq);
+    memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
+    if (qtakes) memcpy(w.h<char>(o_tk), qtakes, nq); else memset(w.h<char>(o_tk), 1, nq);
+    if (cand_off) {
+        memcpy(w.h<char>(o_off), cand_off, sizeof(int) * (nq + 1));
+        if (ncand) memcpy(w.h<char>(o_cand), cand_idx, sizeof(int) * ncand);
+    }
+    ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * (size_t)(n ? n : 1), st)); // -1: slot untouched
+
+    const WinQuery *dq = w.d<WinQuery>(o_q);
+    const uint4 *da = w.d<uint4>(o_a), *db = w.d<uint4>(o_b);
+    const SeqKp *dk = w.d<SeqKp>(o_k);
+    int *doff = w.d<int>(o_off), *dnm = w.d<int>(o_nm);
     const int init_dist = mode == 0 ? 256 : INT_MAX;
-    const dim3 g((nq + MT - 1) / MT);
+    const dim3 g((nq + MT / 64 - 1) / (MT / 64)); // one wave per query
+    unsigned *dtop = w.d<unsigned>(o_top);
     if (cand_off) { // explicit candidate lists
-        DevBuf dcand;
-        const int total = cand_off[nq];
-        if (dcand.alloc(sizeof(int) * (size_t)(total ? total : 1)) || dent.alloc(sizeof(unsigned) * (size_t)(total ? total : 1)))
-            ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-        ORBX_HIP(hipMemcpy(doff.p, cand_off, sizeof(int) * (nq + 1), hipMemcpyHostToDevice));
-        if (total) ORBX_HIP(hipMemcpy(dcand.p, cand_idx, sizeof(int) * total, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, 0, (const uint4 *)da.p, nq, (const uint4 *)db.p, (const int *)doff.p,
-                           (const int *)dcand.p, (unsigned *)dent.p);
-        ORBX_HIP(hipGetLastError());
-        ORBX_HIP(hipDeviceSynchronize()); // dcand is released at the end of this scope
+        if (w.reserve_entries((size_t)ncand)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, st, da, nq, db, (const int *)doff, (const int *)w.d<int>(o_cand), w.ent);
     } else {
-        hipLaunchKernelGGL(k_win_list<0>, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq, (const SeqKp *)dk.p,
-                           (const uint4 *)db.p, ns, has_uright, init_dist, (int *)dcnt.p, (const int *)nullptr, (unsigned *)nullptr);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, 0, (const int *)dcnt.p, nq, (int *)doff.p);
+        hipLaunchKernelGGL(k_win_wave<0>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+                           init_dist, w.d<int>(o_cnt), (const int *)nullptr, (unsigned *)nullptr);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_cnt), nq, doff);
         ORBX_HIP(hipGetLastError());
         int total = 0;
-        ORBX_HIP(hipMemcpy(&total, (int *)doff.p + nq, sizeof(int), hipMemcpyDeviceToHost));
-        if (dent.alloc(sizeof(unsigned) * (size_t)(total ? total : 1))) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-        hipLaunchKernelGGL(k_win_list<1>, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq, (const SeqKp *)dk.p,
-                           (const uint4 *)db.p, ns, has_uright, init_dist, (int *)nullptr, (const int *)doff.p, (unsigned *)dent.p);
+        ORBX_HIP(hipMemcpyAsync(&total, doff + nq, sizeof(int), hipMemcpyDeviceToHost, st));
+        ORBX_HIP(hipStreamSynchronize(st));
+        if (w.reserve_entries((size_t)total)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        hipLaunchKernelGGL(k_win_wave<1>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+                           init_dist, (int *)nullptr, (const int *)doff, w.ent);
     }
-    const size_t lds = sizeof(unsigned) * SEQ_CAP + sizeof(int) * (2 * (size_t)ns + (mode == 1 ? nq : 0)) + 16;
-    if (lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_CAPACITY, "resolver state exceeds LDS");
+    hipLaunchKernelGGL(k_topk, g, dim3(MT), 0, st, (const unsigned *)w.ent, (const int *)doff, nq, dtop);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) { // the largest request either instantiation can make
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr_set = true;
+    }
     if (mode == 0) {
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_resolve<0>, dim3(1), dim3(64), lds, 0, (const unsigned *)dent.p, (const int *)doff.p, nq, ns,
-                           (const uint8_t *)dtk.p, th, nnratio, accept_mode, (int *)dacc.p, (int *)dstate.p, (int *)dnm.p);
-        hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, 0, (const int *)dacc.p, (const int *)dstate.p, nq, ns,
-                           (const float *)dqang.p, (const float *)dang.p, (const int *)dperm.p, check, (int *)dmq.p, (int *)dmk.p,
-                           (int *)dnm.p);
+        hipLaunchKernelGGL(k_resolve<0>, dim3(1), dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, (const int *)doff, nq, ns,
+                           (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, w.d<int>(o_acc), w.d<int>(o_state), dnm);
+        hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
+                           (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
+                           w.d<int>(o_mq), w.d<int>(o_mk), dnm);
     } else {
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_resolve<1>, dim3(1), dim3(64), lds, 0, (const unsigned *)dent.p, (const int *)doff.p, nq, ns,
-                           (const uint8_t *)dtk.p, th, nnratio, 0, (int *)dacc.p, (int *)dstate.p, (int *)dnm.p);
-        hipLaunchKernelGGL(k_rotation<1>, dim3(1), dim3(MT), 0, 0, (const int *)dacc.p, (const int *)dstate.p, nq, ns,
-                           (const float *)dqang.p, (const float *)dang.p, (const int *)dperm.p, check, (int *)dmq.p, (int *)dmk.p,
-                           (int *)dnm.p);
+        hipLaunchKernelGGL(k_resolve<1>, dim3(1), dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, (const int *)doff, nq, ns,
+                           (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, 0, w.d<int>(o_acc), w.d<int>(o_state), dnm);
+        hipLaunchKernelGGL(k_rotation<1>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
+                           (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
+                           w.d<int>(o_mq), w.d<int>(o_mk), dnm);
     }
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(match_q, dmq.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    if (mode == 0 && n) ORBX_HIP(hipMemcpy(match_kp, dmk.p, sizeof(int) * n, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(nmatches, dnm.p, sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
+    if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
+    memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
     return ORBX_OK;
 }
 
@@ -452,25 +536,52 @@ int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *des
     return ORBX_OK;
 }
 
-int orbm_search_by_bow(const uint8_t *desc1, const float *angle1, int n1, const int32_t *qidx, int nq, const uint8_t *desc2,
-                       const float *angle2, int n2, const int32_t *cand_off, const int32_t *cand_idx, int th, int strict_th,
-                       float nnratio, int check_orientation, int32_t *match12, int32_t *match21, int *nmatches)
+int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1, const uint8_t *valid1,
+                       const uint8_t *desc1, const float *angle1, int n1, const int32_t *nodes2, const int32_t *off2,
+                       const int32_t *items2, int nn2, const uint8_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
+                       int th, int strict_th, float nnratio, int check_orientation, int32_t *match12, int32_t *match21,
+                       int *nmatches)
 {
-    if (n1 < 0 || n2 < 0 || nq < 0 || (n1 && (!desc1 || !match12)) || (n2 && !desc2) || (nq && (!qidx || !cand_off)) || !nmatches ||
-        (check_orientation && nq && (!angle1 || !angle2)))
+    if (n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || (n1 && (!desc1 || !match12 || !valid1)) || (n2 && !desc2) ||
+        (nn1 && (!nodes1 || !off1 || !items1)) || (nn2 && (!nodes2 || !off2 || !items2)) || !nmatches ||
+        (check_orientation && n1 && n2 && (!angle1 || !angle2)))
         ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
-    for (int i = 0; i < nq; ++i)
-        if (qidx[i] < 0 || qidx[i] >= n1 || cand_off[i + 1] < cand_off[i]) ORBX_FAIL(ORBX_ERR_ARG, "bad query list");
-    if (nq && cand_off[0] != 0) ORBX_FAIL(ORBX_ERR_ARG, "bad query list");
-    for (int k = 0; nq && k < cand_off[nq]; ++k)
-        if (!cand_idx || cand_idx[k] < 0 || cand_idx[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "candidate index out of range");
+    for (int k = 0; k < (nn1 ? off1[nn1] : 0); ++k)
+        if (items1[k] < 0 || items1[k] >= n1) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
+    for (int k = 0; k < (nn2 ? off2[nn2] : 0); ++k)
+        if (items2[k] < 0 || items2[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
     ORBX_NEED_DEVICE();
     for (int i = 0; i < n1; ++i) match12[i] = -1;
     if (match21) for (int j = 0; j < n2; ++j) match21[j] = -1;
     *nmatches = 0;
+    // the co-iteration of :384-456 / :745-828 (equal keys: visit; else lower_bound on the other map), as lists
+    std::vector<int32_t> qidx, cand_off(1, 0), cand;
+    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
+        if (nodes1[a] == nodes2[b]) {
+            const size_t c0 = cand.size();
+            for (int k = off2[b]; k < off2[b + 1]; ++k)
+                if (!valid2 || valid2[items2[k]]) cand.push_back(items2[k]);
+            const size_t len = cand.size() - c0;
+            bool first = true;
+            for (int k = off1[a]; k < off1[a + 1]; ++k) {
+                if (!valid1[items1[k]]) continue;
+                if (!first) cand.insert(cand.end(), cand.begin() + c0, cand.begin() + c0 + len); // every query of the node: same members
+                first = false;
+                qidx.push_back(items1[k]);
+                cand_off.push_back((int32_t)cand.size());
+            }
+            if (first) cand.resize(c0);
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) ++a;
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) ++b;
+        }
+    }
+    const int nq = (int)qidx.size();
     if (nq == 0 || n2 == 0) return ORBX_OK;
     SortedFrame sf; // the second set as it is: position = feature index
-    sf.kp.resize(n2); sf.perm.resize(n2); sf.angle.resize(n2); sf.desc.assign(desc2, desc2 + (size_t)32 * n2);
+    sf.perm.resize(n2); sf.angle.resize(n2); sf.desc.assign(desc2, desc2 + (size_t)32 * n2);
     for (int j = 0; j < n2; ++j) { sf.perm[j] = j; sf.angle[j] = angle2 ? angle2[j] : 0.f; }
     std::vector<uint8_t> qd((size_t)32 * nq);
     std::vector<float> qa(nq);
@@ -478,7 +589,7 @@ int orbm_search_by_bow(const uint8_t *desc1, const float *angle1, int n1, const 
     std::vector<int32_t> mk(n2), mq(nq);
     // bestDist1 < TH_LOW (:799) == bestDist1 <= TH_LOW - 1
     const int rc = run_sequential(0, nullptr, qd.data(), qa.data(), nullptr, nq, sf, n2, 0, strict_th ? th - 1 : th, nnratio,
-                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, cand_off, cand_idx);
+                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, cand_off.data(), cand.data());
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < nq; ++i) // every accepted query blocks its candidate, so slot mq[i] still names i unless rejected
         if (mq[i] >= 0 && mk[mq[i]] == i) { match12[qidx[i]] = mq[i]; if (match21) match21[mq[i]] = qidx[i]; }

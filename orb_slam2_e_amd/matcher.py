@@ -156,18 +156,21 @@ class ORBmatcher:
         SearchByBoW(KeyFrame*, KeyFrame*, ...) (:723-856; kf_kf=True).  fv = feature_vector_arrays(...) of each
         side, valid = "owns a good MapPoint" masks (valid2 only for the KeyFrame form), angle = mvKeysUn angles.
         Returns (match12, match21, nmatches)."""
-        from .vocabulary import bow_query_lists
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
         d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
         a1 = np.ascontiguousarray(angle1, np.float32); a2 = np.ascontiguousarray(angle2, np.float32)
-        qidx, off, cand = bow_query_lists(fv1, np.asarray(valid1), fv2, np.asarray(valid2) if kf_kf else None)
+        nodes1, off1, it1 = [i32(a) for a in fv1]; nodes2, off2, it2 = [i32(a) for a in fv2]
+        v1 = np.ascontiguousarray(valid1, np.uint8)
+        v2 = np.ascontiguousarray(valid2, np.uint8) if kf_kf else None
         n1, n2 = len(d1), len(d2)
         m12 = np.zeros(n1, np.int32); m21 = np.zeros(n2, np.int32); nm = C.c_int(0)
-        self._L.orbm_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
-                                               C.c_void_p]
-        check(self._L.orbm_search_by_bow(_p(d1), _p(a1), n1, _p(qidx), len(qidx), _p(d2), _p(a2), n2, _p(off), _p(cand),
-                                         self.TH_LOW, int(kf_kf), C.c_float(self.mfNNratio), int(self.mbCheckOrientation),
-                                         _p(m12), _p(m21), C.byref(nm)))
+        self._L.orbm_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_search_by_bow(_p(nodes1), _p(off1), _p(it1), len(nodes1), _p(v1), _p(d1), _p(a1), n1,
+                                         _p(nodes2), _p(off2), _p(it2), len(nodes2), _p(v2) if v2 is not None else None, _p(d2),
+                                         _p(a2), n2, self.TH_LOW, int(kf_kf), C.c_float(self.mfNNratio),
+                                         int(self.mbCheckOrientation), _p(m12), _p(m21), C.byref(nm)))
         return m12, m21, nm.value
 
     CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),

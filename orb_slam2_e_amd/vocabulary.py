@@ -68,21 +68,3 @@ def feature_vector_arrays(node_id, keep=None):
     order = idx[np.argsort(node_id[idx], kind="stable")]
     nodes, start = np.unique(node_id[order], return_index=True)
     return nodes.astype(np.int32), np.append(start, len(order)).astype(np.int32), order.astype(np.int32)
-
-
-def bow_query_lists(fv1, valid1, fv2, valid2=None):
-    """The loop structure of ORBmatcher::SearchByBoW (ORBmatcher.cc:384-456 / :745-828) as lists: the features of
-    the first keyframe in visiting order and, per query, the members of the same node in the second set.
-    Returns (qidx, cand_off, cand_idx)."""
-    nodes1, off1, it1 = fv1
-    nodes2, off2, it2 = fv2
-    common, i1, i2 = np.intersect1d(nodes1, nodes2, assume_unique=True, return_indices=True)   # ascending = map order
-    qidx, cand_off, cand = [], [0], []
-    for a, b in zip(i1, i2):
-        m2 = it2[off2[b]:off2[b + 1]]
-        if valid2 is not None:
-            m2 = m2[np.asarray(valid2)[m2] != 0]
-        for f in it1[off1[a]:off1[a + 1]]:
-            if valid1[f]:
-                qidx.append(f); cand.extend(m2.tolist()); cand_off.append(len(cand))
-    return np.asarray(qidx, np.int32), np.asarray(cand_off, np.int32), np.asarray(cand, np.int32)

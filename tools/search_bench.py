@@ -1,0 +1,29 @@
+"""Wall time of the whole-loop matcher entry points (host arrays in, host arrays out, so H2D/D2H and the
+per-call device allocations are inside) against the CPU oracle on the same inputs."""
+import sys, time
+import numpy as np
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import oracle
+from orb_slam2_e_amd import ORBmatcher
+from orb_slam2_e_amd.vocabulary import feature_vector_arrays
+from test_gpu_match import _projection_case, _bow_case
+
+
+def t(f, reps=20):
+    f(); t0 = time.perf_counter()
+    for _ in range(reps): f()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+q, qd, qa, takes, kps, desc, bounds, occ, ur = _projection_case(0, n=2000, nq=2000, hot=2000)
+m = ORBmatcher(0.6, True)
+print("SearchByProjection loop  2000 queries x 2000 kps: gpu %.3f ms  oracle %.3f ms" % (
+    t(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95)),
+    t(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True), 5)))
+d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = _bow_case(0)
+fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
+ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, keep2)
+print("SearchByBoW loop 2000 x 2100, 90 nodes: gpu %.3f ms   oracle %.3f ms" % (
+    t(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False)),
+    t(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True), 5)))
