@@ -10,6 +10,7 @@
 #ifndef ORBSLAM_HIP_HPP
 #define ORBSLAM_HIP_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -166,9 +167,105 @@ public:
         return n;
     }
 
+    // What the whole-loop searches read of a Frame / KeyFrame (src/Frame.h): mvKeysUn, mDescriptors (N x 32),
+    // mvuRight (may be null: monocular), the grid bounds mnMinX..mnMaxY.
+    struct FrameView {
+        const orbx_keypoint *mvKeysUn = nullptr;
+        const uint8_t *mDescriptors = nullptr;
+        int N = 0;
+        const float *mvuRight = nullptr;
+        float mnMinX = 0.f, mnMinY = 0.f, mnMaxX = 0.f, mnMaxY = 0.f;
+    };
+    // One projected map point of the SearchByProjection loops: window (u, v, r), level range, xr = u - bf/z,
+    // MapPoint::GetDescriptor(), the angle of its source keypoint, and whether the pointer it leaves in
+    // mvpMapPoints makes later points skip that keypoint (Observations() > 0, or always).
+    struct ProjectedPoint {
+        orbm_window_query window;
+        const uint8_t *descriptor;
+        float angle;
+        bool blocksSlot;
+    };
+
+    // ORBmatcher::SearchByProjection loops (ORBmatcher.cc:46-132, :491-604, :1529-1671, :1673-1800) over points
+    // the caller has projected, in the caller's order.  occupied[j]: keypoint j is skipped from the start.
+    // slotOwner[j] = point that ends in mvpMapPoints[j] (-1 untouched, -2 set to NULL by the rotation check).
+    int SearchByProjection(const FrameView &F, const std::vector<ProjectedPoint> &points, const std::vector<uint8_t> &occupied,
+                           int thAccept, bool ratioOnSameLevel, std::vector<int32_t> &slotOwner)
+    {
+        const int nq = (int)points.size();
+        std::vector<orbm_window_query> q(nq);
+        std::vector<uint8_t> qd((size_t)32 * nq), tk(nq);
+        std::vector<float> qa(nq);
+        for (int i = 0; i < nq; ++i) {
+            q[i] = points[i].window; qa[i] = points[i].angle; tk[i] = points[i].blocksSlot;
+            std::copy(points[i].descriptor, points[i].descriptor + 32, &qd[(size_t)32 * i]);
+        }
+        slotOwner.assign(F.N, -1);
+        std::vector<int32_t> mq(nq);
+        int nm = 0;
+        mStatus = orbm_search_projection(q.data(), qd.data(), qa.data(), tk.data(), nq, F.mvKeysUn, F.mDescriptors, F.N,
+                                         occupied.empty() ? nullptr : occupied.data(), F.mvuRight, F.mnMinX, F.mnMinY, F.mnMaxX,
+                                         F.mnMaxY, thAccept, mfNNratio, ratioOnSameLevel, mbCheckOrientation, slotOwner.data(),
+                                         mq.data(), &nm);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+
+    // ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:606-721);
+    // vbPrevMatched as x0, y0, x1, y1, ...
+    int SearchForInitialization(const FrameView &F1, const FrameView &F2, std::vector<float> &vbPrevMatched,
+                                std::vector<int32_t> &vnMatches12, int windowSize = 10)
+    {
+        vnMatches12.assign(F1.N, -1);
+        int nm = 0;
+        mStatus = orbm_search_for_initialization(F1.mvKeysUn, F1.mDescriptors, F1.N, F2.mvKeysUn, F2.mDescriptors, F2.N,
+                                                 vbPrevMatched.data(), F2.mnMinX, F2.mnMinY, F2.mnMaxX, F2.mnMaxY, windowSize,
+                                                 mfNNratio, mbCheckOrientation, vnMatches12.data(), &nm);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+
+    // DBoW2::FeatureVector flattened in std::map order.
+    struct FeatureVector {
+        std::vector<int32_t> nodes, off, items;
+        // from the per-feature node ids of orbm_bow_transform; keep[i] == 0: feature i is not in the vector
+        static FeatureVector FromNodeIds(const std::vector<int32_t> &nodeId, const std::vector<uint8_t> *keep = nullptr)
+        {
+            std::vector<int32_t> idx;
+            for (int32_t i = 0; i < (int32_t)nodeId.size(); ++i)
+                if (!keep || (*keep)[i]) idx.push_back(i);
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return nodeId[a] < nodeId[b]; });
+            FeatureVector fv;
+            for (size_t k = 0; k < idx.size(); ++k) {
+                if (k == 0 || nodeId[idx[k]] != nodeId[idx[k - 1]]) { fv.nodes.push_back(nodeId[idx[k]]); fv.off.push_back((int32_t)k); }
+                fv.items.push_back(idx[k]);
+            }
+            fv.off.push_back((int32_t)idx.size());
+            return fv;
+        }
+    };
+
+    // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:360-489; valid2 == nullptr) and
+    // SearchByBoW(KeyFrame*, KeyFrame*, ...) (:723-856).  valid = "owns a good MapPoint".
+    int SearchByBoW(const FeatureVector &fv1, const std::vector<uint8_t> &valid1, const FrameView &KF1, const FeatureVector &fv2,
+                    const std::vector<uint8_t> *valid2, const FrameView &F2, std::vector<int32_t> &vnMatches12)
+    {
+        std::vector<float> a1(KF1.N), a2(F2.N);
+        for (int i = 0; i < KF1.N; ++i) a1[i] = KF1.mvKeysUn[i].angle;
+        for (int i = 0; i < F2.N; ++i) a2[i] = F2.mvKeysUn[i].angle;
+        vnMatches12.assign(KF1.N, -1);
+        int nm = 0;
+        mStatus = orbm_search_by_bow(fv1.nodes.data(), fv1.off.data(), fv1.items.data(), (int)fv1.nodes.size(), valid1.data(),
+                                     KF1.mDescriptors, a1.data(), KF1.N, fv2.nodes.data(), fv2.off.data(), fv2.items.data(),
+                                     (int)fv2.nodes.size(), valid2 ? valid2->data() : nullptr, F2.mDescriptors, a2.data(), F2.N,
+                                     TH_LOW, valid2 ? 1 : 0, mfNNratio, mbCheckOrientation, vnMatches12.data(), nullptr, &nm);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+
+    int status() const { return mStatus; }
+
 protected:
     float mfNNratio;
     bool mbCheckOrientation;
+    int mStatus = ORBX_OK;
 };
 
 // Numeric core of FEA2: the members and methods g2o and Optimizer touch

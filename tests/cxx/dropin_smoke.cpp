@@ -103,6 +103,46 @@ int main(int argc, char **argv)
     if (nst < 20) { printf("FAIL stereo matches %d\n", nst); return 1; }
     for (size_t i = 0; i < uR.size(); ++i)
         if (uR[i] >= 0 && !(depth[i] > 0.f)) { printf("FAIL stereo depth\n"); return 1; }
+    // whole-loop searches on the frame against itself: every keypoint must find itself
+    ORBmatcher::FrameView F;
+    F.mvKeysUn = kps.data(); F.mDescriptors = desc.data(); F.N = n; F.mnMinX = 0.f; F.mnMinY = 0.f; F.mnMaxX = (float)W; F.mnMaxY = (float)H;
+    {
+        std::vector<float> prev((size_t)2 * n);
+        int level0 = 0;
+        for (int i = 0; i < n; ++i) { prev[2 * i] = kps[i].x; prev[2 * i + 1] = kps[i].y; level0 += kps[i].octave == 0; }
+        std::vector<int32_t> m12i;
+        ORBmatcher mi(0.9f, true);
+        const int ni = mi.SearchForInitialization(F, F, prev, m12i, 100);
+        int selfi = 0;
+        for (int i = 0; i < n; ++i) selfi += m12i[i] == i;
+        if (mi.status() != ORBX_OK || ni != selfi || selfi < level0 / 2) { printf("FAIL SearchForInitialization %d %d %d\n", ni, selfi, level0); return 1; }
+        for (int i = 0; i < n; ++i)
+            if (kps[i].octave > 0 && m12i[i] >= 0) { printf("FAIL SearchForInitialization level\n"); return 1; }
+    }
+    {
+        std::vector<ORBmatcher::ProjectedPoint> pts(n);
+        for (int i = 0; i < n; ++i) {
+            pts[i].window = {kps[i].x, kps[i].y, 7.0f * 1.2f, 0.f, kps[i].octave - 1, kps[i].octave + 1};
+            pts[i].descriptor = &desc[(size_t)32 * i]; pts[i].angle = kps[i].angle; pts[i].blocksSlot = true;
+        }
+        std::vector<int32_t> owner;
+        const int np = m.SearchByProjection(F, pts, std::vector<uint8_t>(), ORBmatcher::TH_HIGH, false, owner);
+        int selfp = 0;
+        for (int i = 0; i < n; ++i) selfp += owner[i] == i;
+        if (m.status() != ORBX_OK || np != n || selfp != n) { printf("FAIL SearchByProjection %d %d of %d\n", np, selfp, n); return 1; }
+    }
+    {
+        std::vector<int32_t> node(n);
+        for (int i = 0; i < n; ++i) node[i] = (desc[(size_t)32 * i] & 31) * 3 + 1;   // a stand-in vocabulary node per feature
+        const ORBmatcher::FeatureVector fv = ORBmatcher::FeatureVector::FromNodeIds(node);
+        std::vector<uint8_t> valid(n, 1);
+        std::vector<int32_t> m12b;
+        ORBmatcher mb(0.9f, true);
+        const int nb = mb.SearchByBoW(fv, valid, F, fv, nullptr, F, m12b);
+        int selfb = 0;
+        for (int i = 0; i < n; ++i) selfb += m12b[i] == i;
+        if (mb.status() != ORBX_OK || nb != selfb || selfb < n * 8 / 10) { printf("FAIL SearchByBoW %d %d of %d\n", nb, selfb, n); return 1; }
+    }
     printf("OK %d keypoints, %d self matches, %d stereo matches, sE=%g\n", n, nm, nst, sE);
     return 0;
 }
