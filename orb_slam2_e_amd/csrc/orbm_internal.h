@@ -52,7 +52,7 @@ inline void build_winkp(const orbx_keypoint *kps, int n, const uint8_t *skip, co
 struct Workspace {
     char *dev = nullptr, *pin = nullptr;
     unsigned *ent = nullptr;
-    size_t dev_cap = 0, pin_cap = 0, ent_cap = 0, used = 0;
+    size_t dev_cap = 0, pin_cap = 0, ent_cap = 0, used = 0, want = 0;
     hipStream_t st = nullptr;
     int reserve(size_t dev_bytes, size_t pin_bytes); // discards the contents
     int reserve_entries(size_t n);
@@ -68,10 +68,31 @@ struct WorkspaceLease {
     ~WorkspaceLease() { workspace_release(w); }
 };
 
+// Scope of one host-array call that takes its device arrays one by one (DevBuf): they are
+// bumped out of a leased workspace's arena; what does not fit falls back to hipMalloc for
+// this call and makes the arena grow before the next one, so the steady state allocates
+// nothing.
+struct DevScope {
+    WorkspaceLease lease;
+    std::vector<void *> overflow;
+    size_t asked = 0;
+    DevScope *prev;
+    DevScope();
+    ~DevScope();
+    void *alloc(size_t n);
+};
+extern thread_local DevScope *tls_dev_scope;
+
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
+    bool owned = false;
+    ~DevBuf() { if (p && owned) (void)hipFree(p); }
+    int alloc(size_t n)
+    {
+        if (tls_dev_scope) { p = tls_dev_scope->alloc(n ? n : 1); return p ? 0 : -1; }
+        owned = true;
+        return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1;
+    }
 };
 
 } // namespace orbm_detail

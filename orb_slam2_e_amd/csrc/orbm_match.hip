@@ -179,131 +179,6 @@ __global__ __launch_bounds__(MT) void k_match_cands(const uint4 *__restrict__ A,
     best_o[i] = best; second_o[i] = second; idx_o[i] = idx;
 }
 
-// Windowed search = Frame::GetFeaturesInArea (src/Frame.cc:342-395) fused with the
-// best / second-best-with-levels loop of SearchByProjection (ORBmatcher.cc:69-118).
-// One query per lane scans every keypoint of the frame (staged through LDS); the
-// window test |dx|<r && |dy|<r on an in-grid keypoint is equivalent to membership
-// in the visited grid cells (round() in PosInGrid vs floor/ceil of the cell range),
-// and the visiting order (cells column-major, insertion order inside) only matters
-// for equal distances, so it is folded into the key: dist<<28 | cell<<16 | index.
-
-__global__ __launch_bounds__(MT) void k_search_window(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
-                                                      const WinKp *__restrict__ kp, const uint4 *__restrict__ B, int n,
-                                                      int has_uright, int init_dist, int *__restrict__ best_o,
-                                                      int *__restrict__ bl_o, int *__restrict__ second_o, int *__restrict__ sl_o,
-                                                      int *__restrict__ idx_o)
-{
-    __shared__ WinKp s_kp[MT];
-    __shared__ uint4 s_d[MT * 2];
-    const int i = blockIdx.x * MT + threadIdx.x, tid = threadIdx.x;
-    const bool act = i < nq;
-    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1};
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-    if (act) { w = q[i]; a0 = A[2 * i]; a1 = A[2 * i + 1]; }
-    const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
-    unsigned long long k1 = ~0ull, k2 = ~0ull;
-    for (int j0 = 0; j0 < n; j0 += MT) {
-        __syncthreads();
-        if (j0 + tid < n) { s_kp[tid] = kp[j0 + tid]; s_d[2 * tid] = B[2 * (j0 + tid)]; s_d[2 * tid + 1] = B[2 * (j0 + tid) + 1]; }
-        __syncthreads();
-        const int nt = min(MT, n - j0);
-        for (int j = 0; j < nt; ++j) {
-            const WinKp k = s_kp[j];
-            bool ok = act && k.order != 0xffffffffu;
-            if (check_levels) ok = ok && !(k.octave < w.min_level) && !(w.max_level >= 0 && k.octave > w.max_level);
-            const float distx = k.x - w.u, disty = k.y - w.v;
-            ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
-            if (has_uright && k.uright > 0) ok = ok && !(fabsf(w.xr - k.uright) > w.r);
-            const int dist = ok ? popc256(a0, a1, s_d[2 * j], s_d[2 * j + 1]) : 0;
-            if (ok && dist < init_dist) { // dist<bestDist / dist<bestDist2 can only fire below the initial value
-                const unsigned long long key = ((unsigned long long)dist << 28) | k.order;
-                const unsigned long long hi = k1 > key ? k1 : key;
-                k2 = k2 < hi ? k2 : hi;
-                k1 = k1 < key ? k1 : key;
-            }
-        }
-    }
-    if (act) {
-        int best = init_dist, second = init_dist, idx = -1;
-        // keys only enter when dist < init (256: always; INT_MAX: always)
-        if (k1 != ~0ull) { best = (int)(k1 >> 28); idx = (int)(k1 & 0xffffu); }
-        if (k2 != ~0ull) second = (int)(k2 >> 28);
-        best_o[i] = best; second_o[i] = second; idx_o[i] = idx;
-        bl_o[i] = k1 != ~0ull ? (int)(k1 & 0xffffu) : -1;      // resolved to octaves on the host side of the ABI
-        sl_o[i] = k2 != ~0ull ? (int)(k2 & 0xffffu) : -1;
-    }
-}
-
-// The fork's whole-map relocalisation search (ORBmatcher.cc:134-222): isInFrustum
-// (:262-330) + ComputeDistance (:224-260) per map point in the reference's mixed
-// float / double arithmetic (fixed op order, no contraction), producing the
-// GetFeaturesInArea query of :162-163; k_search_window does the search; then the
-// TH_RELOC / same-level ratio acceptance (:205-216) with "last map point wins".
-struct MapCam { float fx, fy, cx, cy; int bminx, bmaxx, bminy, bmaxy; double R[9], t[3]; float th; int nlevels; };
-
-__global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ pos, const float *__restrict__ nrm,
-                                                    const float *__restrict__ mind, const float *__restrict__ maxd, int m,
-                                                    MapCam cam, const float *__restrict__ scale, WinQuery *__restrict__ q,
-                                                    float *__restrict__ proj)
-{
-    const int i = blockIdx.x * MT + threadIdx.x;
-    if (i >= m) return;
-    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
-    float out[4] = {0.f, 0.f, 0.f, -1.f};
-    const float ptX = pos[3 * i], ptY = pos[3 * i + 1], ptZ = pos[3 * i + 2];
-    const double *R = cam.R, *t = cam.t;
-    const float PcX = (float)(R[0] * ptX + R[1] * ptY + R[2] * ptZ + t[0]);
-    const float PcY = (float)(R[3] * ptX + R[4] * ptY + R[5] * ptZ + t[1]);
-    const float PcZ = (float)(R[6] * ptX + R[7] * ptY + R[8] * ptZ + t[2]);
-    bool ok = !(PcZ < 0.0f);
-    const float invz = (float)(1.0 / (double)PcZ);
-    const float u = cam.fx * PcX * invz + cam.cx;
-    const float v = cam.fy * PcY * invz + cam.cy;
-    ok = ok && !(u < (float)cam.bminx || u > (float)cam.bmaxx) && !(v < (float)cam.bminy || v > (float)cam.bmaxy);
-    // ComputeDistance: PO = Pt - (-R^T) t, norm in double
-    double PO[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double rtt = ((-1) * R[a]) * t[0] + ((-1) * R[3 + a]) * t[1] + ((-1) * R[6 + a]) * t[2];
-        PO[a] = (double)(a == 0 ? ptX : a == 1 ? ptY : ptZ) - rtt;
-    }
-    const double normSum = PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2];
-    const float dist = (float)sqrt(normSum);
-    const float minDistance = mind[i], maxDistance = maxd[i];
-    ok = ok && !((double)dist < (0.9 * (double)minDistance) || (double)dist > ((double)maxDistance / 0.9));
-    float viewCos = (float)(PO[0] * nrm[3 * i] + PO[1] * nrm[3 * i + 1] + PO[2] * nrm[3 * i + 2]);
-    viewCos = viewCos / dist;
-    ok = ok && !(viewCos < 0.5f);
-    const float ratio = dist / minDistance;
-    int level = 0;
-    while (level < cam.nlevels && scale[level] < ratio) ++level; // lower_bound(mvScaleFactors, ratio)
-    if (level >= cam.nlevels) level = cam.nlevels - 1;
-    if (ok) {
-        float r = (double)viewCos > 0.998 ? 3.0f : 4.5f; // RadiusByViewingCos
-        if ((double)cam.th != 1.0) r *= cam.th;
-        w.u = u; w.v = v; w.r = r * scale[level]; w.min_level = level - 1; w.max_level = level;
-        out[0] = u; out[1] = v; out[2] = viewCos; out[3] = (float)level;
-    }
-    q[i] = w;
-    if (proj) { proj[4 * i] = out[0]; proj[4 * i + 1] = out[1]; proj[4 * i + 2] = out[2]; proj[4 * i + 3] = out[3]; }
-}
-
-__global__ __launch_bounds__(MT) void k_reloc_accept(const int *__restrict__ best, const int *__restrict__ bidx,
-                                                     const int *__restrict__ second, const int *__restrict__ sidx,
-                                                     const WinKp *__restrict__ kp, int m, int th_reloc, float nnratio,
-                                                     int *__restrict__ matched, int *__restrict__ nmatches)
-{
-    const int i = blockIdx.x * MT + threadIdx.x;
-    bool acc = false;
-    if (i < m && bidx[i] >= 0 && best[i] <= th_reloc) {
-        const int bl = kp[bidx[i]].octave, sl = sidx[i] >= 0 ? kp[sidx[i]].octave : -1;
-        acc = !(bl == sl && (float)best[i] > nnratio * (float)second[i]);
-        if (acc) atomicMax(&matched[bidx[i]], i); // vMatchedMPs[bestIdx] = pMP: the last map point wins
-    }
-    const unsigned long long b = __ballot(acc);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nmatches, __popcll(b));
-}
-
 // SearchForTriangulation inner loop (ORBmatcher.cc:892-990) + CheckDistEpipolarLine
 // (:341-358): one query per lane over its BoW-node candidate list, in member order.
 // `dist>bestDist` is non-strict in the reference, so a later candidate with an equal
@@ -470,6 +345,36 @@ int Workspace::reserve_entries(size_t n)
     return 0;
 }
 
+thread_local DevScope *tls_dev_scope = nullptr;
+
+DevScope::DevScope() : prev(tls_dev_scope)
+{
+    Workspace &w = *lease.w;
+    if (w.want > w.dev_cap) (void)w.reserve(w.want, 0);
+    w.used = 0;
+    tls_dev_scope = this;
+}
+
+DevScope::~DevScope()
+{
+    for (void *q : overflow) (void)hipFree(q);
+    Workspace &w = *lease.w;
+    w.want = std::max(w.want, asked);
+    tls_dev_scope = prev;
+}
+
+void *DevScope::alloc(size_t n)
+{
+    Workspace &w = *lease.w;
+    const size_t bytes = (n + 255) & ~(size_t)255;
+    asked += bytes;
+    if (w.dev && w.used + bytes <= w.dev_cap) { void *q = w.dev + w.used; w.used += bytes; return q; }
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+    overflow.push_back(q);
+    return q;
+}
+
 Workspace *workspace_acquire()
 {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
@@ -509,6 +414,7 @@ int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB, in
     ORBX_NEED_DEVICE();
     if (nA == 0) return ORBX_OK;
     const int cap = nA > nB ? nA : nB;
+    DevScope scope;
     DevBuf d, c, o;
     if (d.alloc((size_t)2 * cap * 32) || c.alloc(2 * sizeof(int)) || o.alloc((size_t)3 * cap * sizeof(int)))
         ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
@@ -540,6 +446,7 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB, co
         if (cand_idx[k] < 0 || cand_idx[k] >= nB) ORBX_FAIL(ORBX_ERR_ARG, "candidate index out of range");
     for (int i = 0; i < nA; ++i)
         if (cand_off[i] > cand_off[i + 1] || cand_off[i] < 0) ORBX_FAIL(ORBX_ERR_ARG, "candidate offsets not monotone");
+    DevScope scope;
     DevBuf da, db, doff, dci, o;
     if (da.alloc((size_t)nA * 32) || db.alloc((size_t)nB * 32) || doff.alloc(sizeof(int) * (nA + 1)) ||
         dci.alloc(sizeof(int) * nc) || o.alloc(sizeof(int) * 3 * (size_t)nA))
@@ -570,6 +477,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m,
         if (off[i] > off[i + 1]) ORBX_FAIL(ORBX_ERR_ARG, "offsets not monotone");
         if (off[i + 1] - off[i] > DD_MAXN) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 128 observations of one map point");
     }
+    DevScope scope;
     DevBuf dd, doff, o;
     if (dd.alloc((size_t)32 * total) || doff.alloc(sizeof(int) * (m + 1)) || o.alloc(sizeof(int) * m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     if (total) ORBX_HIP(hipMemcpy(dd.p, desc, (size_t)32 * total, hipMemcpyHostToDevice));
@@ -651,6 +559,7 @@ int orbm_bow_transform(orbm_vocabulary *v, const uint8_t *features, int n, int l
     if (!v || n < 0 || (n && (!features || !word_id || !node_id))) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
     if (n == 0) return ORBX_OK;
+    DevScope scope;
     DevBuf df, o;
     if (df.alloc((size_t)32 * n) || o.alloc(sizeof(int) * 2 * (size_t)n)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     ORBX_HIP(hipMemcpy(df.p, features, (size_t)32 * n, hipMemcpyHostToDevice));
@@ -680,108 +589,6 @@ int orbm_bow_transform_batch_dev(orbm_vocabulary *v, const uint8_t *desc_dev, co
     return ORBX_OK;
 }
 
-int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps,
-                       const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
-                       float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
-                       int32_t *second_level, int32_t *idx)
-{
-    if (nq < 0 || n < 0 || n > 65535 || (nq && (!queries || !qdesc || !best || !best_level || !second || !second_level || !idx)) ||
-        (n && (!kps || !desc)) || !(max_x > min_x) || !(max_y > min_y))
-        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
-    ORBX_NEED_DEVICE();
-    if (nq == 0) return ORBX_OK;
-    std::vector<WinKp> wk;
-    build_winkp(kps, n, skip, uright, min_x, min_y, max_x, max_y, wk);
-    DevBuf dq, da, dk, db, o;
-    if (dq.alloc(sizeof(WinQuery) * nq) || da.alloc((size_t)32 * nq) || dk.alloc(sizeof(WinKp) * wk.size()) ||
-        db.alloc((size_t)32 * (n ? n : 1)) || o.alloc(sizeof(int) * 5 * (size_t)nq))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    static_assert(sizeof(WinQuery) == sizeof(orbm_window_query), "query layout");
-    ORBX_HIP(hipMemcpy(dq.p, queries, sizeof(WinQuery) * nq, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(da.p, qdesc, (size_t)32 * nq, hipMemcpyHostToDevice));
-    if (n) {
-        ORBX_HIP(hipMemcpy(dk.p, wk.data(), sizeof(WinKp) * n, hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(db.p, desc, (size_t)32 * n, hipMemcpyHostToDevice));
-    }
-    int *ob = (int *)o.p;
-    hipLaunchKernelGGL(k_search_window, dim3((nq + MT - 1) / MT), dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)da.p, nq,
-                       (const WinKp *)dk.p, (const uint4 *)db.p, n, uright ? 1 : 0, init_dist, ob, ob + nq, ob + 2 * nq,
-                       ob + 3 * nq, ob + 4 * nq);
-    ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(best_level, ob + nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(second, ob + 2 * nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(second_level, ob + 3 * nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(idx, ob + 4 * nq, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    for (int i = 0; i < nq; ++i) { // keypoint index -> octave (bestLevel / bestLevel2, ORBmatcher.cc:102-111)
-        if (best_level[i] >= 0) best_level[i] = kps[best_level[i]].octave;
-        if (second_level[i] >= 0) second_level[i] = kps[second_level[i]].octave;
-    }
-    return ORBX_OK;
-}
-
-int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *has_mappoint,
-                                  const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
-                                  const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw,
-                                  const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels,
-                                  float th, float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj)
-{
-    if (n < 0 || m < 0 || n > 65535 || nlevels < 1 || nlevels > 64 || !cam || !Rcw || !tcw || !scale_factors || !matched_mp ||
-        (n && (!kps || !desc)) || (m && (!mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !mp_desc)) ||
-        !(cam->grid_max_x > cam->grid_min_x) || !(cam->grid_max_y > cam->grid_min_y))
-        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
-    ORBX_NEED_DEVICE();
-    for (int j = 0; j < n; ++j) matched_mp[j] = -1;
-    if (nmatches) *nmatches = 0;
-    if (n == 0 || m == 0) return ORBX_OK;
-    const float invW = (float)FRAME_GRID_COLS / (cam->grid_max_x - cam->grid_min_x), invH = (float)FRAME_GRID_ROWS / (cam->grid_max_y - cam->grid_min_y);
-    std::vector<WinKp> wk(n);
-    for (int j = 0; j < n; ++j) {
-        const int px = (int)roundf((kps[j].x - cam->grid_min_x) * invW), py = (int)roundf((kps[j].y - cam->grid_min_y) * invH);
-        const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
-        wk[j].x = kps[j].x; wk[j].y = kps[j].y; wk[j].octave = kps[j].octave; wk[j].uright = -1.0f;
-        wk[j].order = (in && !(has_mappoint && has_mappoint[j])) ? ((unsigned)(px * FRAME_GRID_ROWS + py) << 16) | (unsigned)j : 0xffffffffu;
-    }
-    DevBuf dpos, dnrm, dmin, dmax, dmd, dk, dd, dsc, dq, o, dm, dn, dproj;
-    if (dpos.alloc(sizeof(float) * 3 * m) || dnrm.alloc(sizeof(float) * 3 * m) || dmin.alloc(sizeof(float) * m) ||
-        dmax.alloc(sizeof(float) * m) || dmd.alloc((size_t)32 * m) || dk.alloc(sizeof(WinKp) * n) || dd.alloc((size_t)32 * n) ||
-        dsc.alloc(sizeof(float) * nlevels) || dq.alloc(sizeof(WinQuery) * m) || o.alloc(sizeof(int) * 5 * (size_t)m) ||
-        dm.alloc(sizeof(int) * n) || dn.alloc(sizeof(int)) || dproj.alloc(sizeof(float) * 4 * m))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(dpos.p, mp_pos, sizeof(float) * 3 * m, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dnrm.p, mp_normal, sizeof(float) * 3 * m, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dmin.p, mp_min_dist, sizeof(float) * m, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dmax.p, mp_max_dist, sizeof(float) * m, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dmd.p, mp_desc, (size_t)32 * m, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dk.p, wk.data(), sizeof(WinKp) * n, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dd.p, desc, (size_t)32 * n, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(dsc.p, scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemset(dm.p, 0xff, sizeof(int) * n));
-    ORBX_HIP(hipMemset(dn.p, 0, sizeof(int)));
-    MapCam mc;
-    mc.fx = cam->fx; mc.fy = cam->fy; mc.cx = cam->cx; mc.cy = cam->cy;
-    mc.bminx = cam->min_x; mc.bmaxx = cam->max_x; mc.bminy = cam->min_y; mc.bmaxy = cam->max_y;
-    for (int i = 0; i < 9; ++i) mc.R[i] = Rcw[i];
-    for (int i = 0; i < 3; ++i) mc.t[i] = tcw[i];
-    mc.th = th; mc.nlevels = nlevels;
-    int *ob = (int *)o.p;
-    const dim3 g((m + MT - 1) / MT);
-    hipLaunchKernelGGL(k_map_frustum, g, dim3(MT), 0, 0, (const float *)dpos.p, (const float *)dnrm.p, (const float *)dmin.p,
-                       (const float *)dmax.p, m, mc, (const float *)dsc.p, (WinQuery *)dq.p, (float *)dproj.p);
-    hipLaunchKernelGGL(k_search_window, g, dim3(MT), 0, 0, (const WinQuery *)dq.p, (const uint4 *)dmd.p, m, (const WinKp *)dk.p,
-                       (const uint4 *)dd.p, n, 0, INT_MAX, ob, ob + m, ob + 2 * m, ob + 3 * m, ob + 4 * m);
-    // k_search_window leaves the key's keypoint index in best_level / second_level
-    hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, 0, ob, ob + m, ob + 2 * m, ob + 3 * m, (const WinKp *)dk.p, m, th_reloc,
-                       nnratio, (int *)dm.p, (int *)dn.p);
-    ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(matched_mp, dm.p, sizeof(int) * n, hipMemcpyDeviceToHost));
-    if (nmatches) ORBX_HIP(hipMemcpy(nmatches, dn.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (proj) ORBX_HIP(hipMemcpy(proj, dproj.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost));
-    return ORBX_OK;
-}
-
 int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbx_keypoint *kps2,
                              const uint8_t *desc2, int n2, const int32_t *cand_off, const int32_t *cand_idx,
                              const uint8_t *has_mappoint1, const uint8_t *has_mappoint2, const uint8_t *stereo1,
@@ -802,6 +609,7 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
         if (cand_off[i] > cand_off[i + 1] || cand_off[i] < 0) ORBX_FAIL(ORBX_ERR_ARG, "candidate offsets not monotone");
     for (int j = 0; j < n2; ++j)
         if (kps2[j].octave < 0 || kps2[j].octave >= nlevels) ORBX_FAIL(ORBX_ERR_ARG, "octave out of range");
+    DevScope scope;
     DevBuf k1, a, k2, b, doff, dci, m1, m2, s1, s2, sc, sg, o;
     const size_t N2 = n2 ? n2 : 1;
     if (k1.alloc(sizeof(orbx_keypoint) * n1) || a.alloc((size_t)32 * n1) || k2.alloc(sizeof(orbx_keypoint) * N2) ||
@@ -843,6 +651,7 @@ int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint
     if (nA < 0 || nB < 0 || (nA && !A) || (nB && !B) || ((nA && nB) && !out)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
     if (nA == 0 || nB == 0) return ORBX_OK;
+    DevScope scope;
     DevBuf da, db, o;
     if (da.alloc((size_t)nA * 32) || db.alloc((size_t)nB * 32) || o.alloc(sizeof(uint16_t) * (size_t)nA * nB))
         ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");

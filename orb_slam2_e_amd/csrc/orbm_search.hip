@@ -286,6 +286,145 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
     if (lane == 0) *nmatches = nm;
 }
 
+// Window search without coupling between queries = Frame::GetFeaturesInArea (src/Frame.cc:342-395)
+// fused with the best / second-best-with-levels loop of SearchByProjection (ORBmatcher.cc:69-118).
+// One wave per query walks the window's runs of the sorted keypoint array as k_win_wave does; every
+// lane keeps the two smallest keys dist << 16 | position-in-visiting-order of its candidates (strict
+// '<', first wins = smallest key; bestDist2 = second smallest), two wave reductions pick the winners.
+// Outputs: best / second distance (init_dist when absent), their octaves (-1), arg-best as a
+// keypoint index (-1).
+__global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
+                                                 const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
+                                                 const int *__restrict__ cell_off, const int *__restrict__ perm, GridParams gp,
+                                                 int has_uright, int init_dist, int *__restrict__ best_o, int *__restrict__ bl_o,
+                                                 int *__restrict__ second_o, int *__restrict__ sl_o, int *__restrict__ idx_o)
+{
+    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const WinQuery w = q[i];
+    unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, e1 = 0, e2 = 0; // e = octave << 16 | sorted position
+    int c = 0;
+    const int nMinCellX = (int)fmaxf(0.f, floorf((w.u - gp.min_x - w.r) * gp.inv_w));
+    const int nMaxCellX = (int)fminf((float)FRAME_GRID_COLS - 1, ceilf((w.u - gp.min_x + w.r) * gp.inv_w));
+    const int nMinCellY = (int)fmaxf(0.f, floorf((w.v - gp.min_y - w.r) * gp.inv_h));
+    const int nMaxCellY = (int)fminf((float)FRAME_GRID_ROWS - 1, ceilf((w.v - gp.min_y + w.r) * gp.inv_h));
+    const bool none = !(w.r >= 0.f) || nMinCellX >= FRAME_GRID_COLS || nMaxCellX < 0 || nMinCellY >= FRAME_GRID_ROWS || nMaxCellY < 0;
+    if (!none) {
+        const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
+        const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int r0 = cell_off[ix * FRAME_GRID_ROWS + nMinCellY], r1 = cell_off[ix * FRAME_GRID_ROWS + nMaxCellY + 1];
+            for (int kb = r0; kb < r1; kb += 64) {
+                const int k = kb + lane;
+                bool ok = k < r1;
+                SeqKp p = {0.f, 0.f, 0.f, 0};
+                if (ok) p = kp[k];
+                if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
+                const float distx = p.x - w.u, disty = p.y - w.v;
+                ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
+                if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
+                const unsigned long long bal = __ballot(ok);
+                if (ok) {
+                    const int dist = popc256(a0, a1, B[2 * k], B[2 * k + 1]);
+                    if (dist < init_dist) { // dist<bestDist / dist<bestDist2 can only fire below the initial value
+                        const unsigned key = ((unsigned)dist << 16) | (unsigned)(c + __popcll(bal & lt));
+                        const unsigned en = ((unsigned)p.octave << 16) | (unsigned)k;
+                        if (key < k1) { k2 = k1; e2 = e1; k1 = key; e1 = en; }
+                        else if (key < k2) { k2 = key; e2 = en; }
+                    }
+                }
+                c += __popcll(bal);
+            }
+        }
+    }
+    // smallest key of the wave, then the smallest of what is left (keys are unique)
+    const unsigned g1 = wave_min_u32(k1);
+    const bool own1 = g1 != 0xffffffffu && k1 == g1;
+    const unsigned long long b1 = __ballot(own1);
+    const unsigned c2 = own1 ? k2 : k1;
+    const unsigned g2 = wave_min_u32(c2);
+    const unsigned long long b2 = __ballot(g2 != 0xffffffffu && c2 == g2);
+    const unsigned w1 = b1 ? (unsigned)__shfl((int)e1, __ffsll((long long)b1) - 1) : 0u;
+    const unsigned w2 = b2 ? (unsigned)__shfl((int)(own1 ? e2 : e1), __ffsll((long long)b2) - 1) : 0u;
+    if (lane == 0) {
+        best_o[i] = b1 ? (int)(g1 >> 16) : init_dist;
+        idx_o[i] = b1 ? perm[w1 & 0xffffu] : -1;
+        bl_o[i] = b1 ? (int)(w1 >> 16) : -1;
+        second_o[i] = b2 ? (int)(g2 >> 16) : init_dist;
+        sl_o[i] = b2 ? (int)(w2 >> 16) : -1;
+    }
+}
+
+// The fork's whole-map relocalisation search (ORBmatcher.cc:134-222): isInFrustum
+// (:262-330) + ComputeDistance (:224-260) per map point in the reference's mixed
+// float / double arithmetic (fixed op order, no contraction), producing the
+// GetFeaturesInArea query of :162-163; k_win_best does the search; then the
+// TH_RELOC / same-level ratio acceptance (:205-216) with "last map point wins".
+struct MapCam { float fx, fy, cx, cy; int bminx, bmaxx, bminy, bmaxy; double R[9], t[3]; float th; int nlevels; };
+
+__global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ pos, const float *__restrict__ nrm,
+                                                    const float *__restrict__ mind, const float *__restrict__ maxd, int m,
+                                                    MapCam cam, const float *__restrict__ scale, WinQuery *__restrict__ q,
+                                                    float *__restrict__ proj)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i >= m) return;
+    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
+    float out[4] = {0.f, 0.f, 0.f, -1.f};
+    const float ptX = pos[3 * i], ptY = pos[3 * i + 1], ptZ = pos[3 * i + 2];
+    const double *R = cam.R, *t = cam.t;
+    const float PcX = (float)(R[0] * ptX + R[1] * ptY + R[2] * ptZ + t[0]);
+    const float PcY = (float)(R[3] * ptX + R[4] * ptY + R[5] * ptZ + t[1]);
+    const float PcZ = (float)(R[6] * ptX + R[7] * ptY + R[8] * ptZ + t[2]);
+    bool ok = !(PcZ < 0.0f);
+    const float invz = (float)(1.0 / (double)PcZ);
+    const float u = cam.fx * PcX * invz + cam.cx;
+    const float v = cam.fy * PcY * invz + cam.cy;
+    ok = ok && !(u < (float)cam.bminx || u > (float)cam.bmaxx) && !(v < (float)cam.bminy || v > (float)cam.bmaxy);
+    // ComputeDistance: PO = Pt - (-R^T) t, norm in double
+    double PO[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double rtt = ((-1) * R[a]) * t[0] + ((-1) * R[3 + a]) * t[1] + ((-1) * R[6 + a]) * t[2];
+        PO[a] = (double)(a == 0 ? ptX : a == 1 ? ptY : ptZ) - rtt;
+    }
+    const double normSum = PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2];
+    const float dist = (float)sqrt(normSum);
+    const float minDistance = mind[i], maxDistance = maxd[i];
+    ok = ok && !((double)dist < (0.9 * (double)minDistance) || (double)dist > ((double)maxDistance / 0.9));
+    float viewCos = (float)(PO[0] * nrm[3 * i] + PO[1] * nrm[3 * i + 1] + PO[2] * nrm[3 * i + 2]);
+    viewCos = viewCos / dist;
+    ok = ok && !(viewCos < 0.5f);
+    const float ratio = dist / minDistance;
+    int level = 0;
+    while (level < cam.nlevels && scale[level] < ratio) ++level; // lower_bound(mvScaleFactors, ratio)
+    if (level >= cam.nlevels) level = cam.nlevels - 1;
+    if (ok) {
+        float r = (double)viewCos > 0.998 ? 3.0f : 4.5f; // RadiusByViewingCos
+        if ((double)cam.th != 1.0) r *= cam.th;
+        w.u = u; w.v = v; w.r = r * scale[level]; w.min_level = level - 1; w.max_level = level;
+        out[0] = u; out[1] = v; out[2] = viewCos; out[3] = (float)level;
+    }
+    q[i] = w;
+    if (proj) { proj[4 * i] = out[0]; proj[4 * i + 1] = out[1]; proj[4 * i + 2] = out[2]; proj[4 * i + 3] = out[3]; }
+}
+
+__global__ __launch_bounds__(MT) void k_reloc_accept(const int *__restrict__ best, const int *__restrict__ bidx,
+                                                     const int *__restrict__ second, const int *__restrict__ blevel,
+                                                     const int *__restrict__ slevel, int m, int th_reloc, float nnratio,
+                                                     int *__restrict__ matched, int *__restrict__ nmatches)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    bool acc = false;
+    if (i < m && bidx[i] >= 0 && best[i] <= th_reloc) {
+        acc = !(blevel[i] == slevel[i] && (float)best[i] > nnratio * (float)second[i]);
+        if (acc) atomicMax(&matched[bidx[i]], i); // vMatchedMPs[bestIdx] = pMP: the last map point wins
+    }
+    const unsigned long long b = __ballot(acc);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nmatches, __popcll(b));
+}
+
 // Rotation histogram + ComputeThreeMaxima (:1802-1843) + rejection, and the translation of
 // sorted positions back to keypoint indices.  One block.
 // MODE 0: match_kp[perm[sp]] = query (or -1 untouched / -2 cleared), match_q[i] = keypoint.
@@ -491,6 +630,122 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
 } // namespace
 
 extern "C" {
+
+int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps,
+                       const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
+                       float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
+                       int32_t *second_level, int32_t *idx)
+{
+    if (nq < 0 || n < 0 || n > 65535 || (nq && (!queries || !qdesc || !best || !best_level || !second || !second_level || !idx)) ||
+        (n && (!kps || !desc)) || !(max_x > min_x) || !(max_y > min_y))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (nq == 0) return ORBX_OK;
+    SortedFrame sf;
+    sort_frame(kps, desc, n, skip, uright, min_x, min_y, max_x, max_y, sf);
+    const int ns = (int)sf.perm.size();
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * (ns ? ns : 1)),
+                 o_b = w.carve((size_t)32 * (ns ? ns : 1)), o_perm = w.carve(sizeof(int) * (ns ? ns : 1)),
+                 o_cell = w.carve(sizeof(int) * sf.cell_off.size());
+    const size_t staged = w.used;
+    const size_t o_res = w.carve(sizeof(int) * 5 * (size_t)nq);
+    if (w.reserve(w.used, std::max(staged, sizeof(int) * 5 * (size_t)nq))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
+    memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
+    if (ns) {
+        memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
+        memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
+        memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
+    }
+    memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
+    ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, w.st));
+    int *ob = w.d<int>(o_res);
+    hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, w.st, (const WinQuery *)w.d<WinQuery>(o_q),
+                       (const uint4 *)w.d<uint4>(o_a), nq, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
+                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, uright ? 1 : 0, init_dist, ob, ob + nq,
+                       ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(w.pin, ob, sizeof(int) * 5 * (size_t)nq, hipMemcpyDeviceToHost, w.st));
+    ORBX_HIP(hipStreamSynchronize(w.st));
+    const int *r = w.h<int>(0);
+    memcpy(best, r, sizeof(int) * nq); memcpy(best_level, r + nq, sizeof(int) * nq);
+    memcpy(second, r + 2 * nq, sizeof(int) * nq); memcpy(second_level, r + 3 * nq, sizeof(int) * nq);
+    memcpy(idx, r + 4 * nq, sizeof(int) * nq);
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *has_mappoint,
+                                  const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
+                                  const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw,
+                                  const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels,
+                                  float th, float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj)
+{
+    if (n < 0 || m < 0 || n > 65535 || nlevels < 1 || nlevels > 64 || !cam || !Rcw || !tcw || !scale_factors || !matched_mp ||
+        (n && (!kps || !desc)) || (m && (!mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !mp_desc)) ||
+        !(cam->grid_max_x > cam->grid_min_x) || !(cam->grid_max_y > cam->grid_min_y))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    for (int j = 0; j < n; ++j) matched_mp[j] = -1;
+    if (nmatches) *nmatches = 0;
+    if (n == 0 || m == 0) return ORBX_OK;
+    SortedFrame sf;
+    sort_frame(kps, desc, n, has_mappoint, nullptr, cam->grid_min_x, cam->grid_min_y, cam->grid_max_x, cam->grid_max_y, sf);
+    const int ns = (int)sf.perm.size();
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    const size_t o_pos = w.carve(sizeof(float) * 3 * m), o_nrm = w.carve(sizeof(float) * 3 * m), o_min = w.carve(sizeof(float) * m),
+                 o_max = w.carve(sizeof(float) * m), o_md = w.carve((size_t)32 * m), o_k = w.carve(sizeof(SeqKp) * (ns ? ns : 1)),
+                 o_b = w.carve((size_t)32 * (ns ? ns : 1)), o_perm = w.carve(sizeof(int) * (ns ? ns : 1)),
+                 o_cell = w.carve(sizeof(int) * sf.cell_off.size()), o_sc = w.carve(sizeof(float) * nlevels);
+    const size_t staged = w.used;
+    const size_t o_q = w.carve(sizeof(WinQuery) * m), o_o = w.carve(sizeof(int) * 5 * (size_t)m);
+    const size_t o_res = w.used;
+    const size_t o_mk = w.carve(sizeof(int) * n), o_nm = w.carve(sizeof(int)), o_proj = w.carve(sizeof(float) * 4 * m);
+    const size_t res_bytes = w.used - o_res;
+    if (w.reserve(w.used, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    memcpy(w.h<char>(o_pos), mp_pos, sizeof(float) * 3 * m); memcpy(w.h<char>(o_nrm), mp_normal, sizeof(float) * 3 * m);
+    memcpy(w.h<char>(o_min), mp_min_dist, sizeof(float) * m); memcpy(w.h<char>(o_max), mp_max_dist, sizeof(float) * m);
+    memcpy(w.h<char>(o_md), mp_desc, (size_t)32 * m);
+    if (ns) {
+        memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
+        memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
+        memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
+    }
+    memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
+    memcpy(w.h<char>(o_sc), scale_factors, sizeof(float) * nlevels);
+    hipStream_t st = w.st;
+    ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * n, st));
+    ORBX_HIP(hipMemsetAsync(w.d<char>(o_nm), 0, sizeof(int), st));
+    MapCam mc;
+    mc.fx = cam->fx; mc.fy = cam->fy; mc.cx = cam->cx; mc.cy = cam->cy;
+    mc.bminx = cam->min_x; mc.bmaxx = cam->max_x; mc.bminy = cam->min_y; mc.bmaxy = cam->max_y;
+    for (int i = 0; i < 9; ++i) mc.R[i] = Rcw[i];
+    for (int i = 0; i < 3; ++i) mc.t[i] = tcw[i];
+    mc.th = th; mc.nlevels = nlevels;
+    int *ob = w.d<int>(o_o);
+    const dim3 g((m + MT - 1) / MT);
+    hipLaunchKernelGGL(k_map_frustum, g, dim3(MT), 0, st, (const float *)w.d<float>(o_pos), (const float *)w.d<float>(o_nrm),
+                       (const float *)w.d<float>(o_min), (const float *)w.d<float>(o_max), m, mc, (const float *)w.d<float>(o_sc),
+                       w.d<WinQuery>(o_q), w.d<float>(o_proj));
+    hipLaunchKernelGGL(k_win_best, dim3((m + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, st, (const WinQuery *)w.d<WinQuery>(o_q),
+                       (const uint4 *)w.d<uint4>(o_md), m, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
+                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, 0, INT_MAX, ob, ob + m, ob + 2 * m,
+                       ob + 3 * m, ob + 4 * m);
+    hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, st, (const int *)ob, (const int *)(ob + 4 * m), (const int *)(ob + 2 * m),
+                       (const int *)(ob + m), (const int *)(ob + 3 * m), m, th_reloc, nnratio, w.d<int>(o_mk), w.d<int>(o_nm));
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(matched_mp, w.pin + (o_mk - o_res), sizeof(int) * n);
+    if (nmatches) memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
+    if (proj) memcpy(proj, w.pin + (o_proj - o_res), sizeof(float) * 4 * m);
+    return ORBX_OK;
+}
 
 int orbm_search_projection(const orbm_window_query *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes,
                            int nq, const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *occupied,

@@ -27,3 +27,7 @@ ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, 
 print("SearchByBoW loop 2000 x 2100, 90 nodes: gpu %.3f ms   oracle %.3f ms" % (
     t(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False)),
     t(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True), 5)))
+print("search_window (no coupling) same inputs: gpu %.3f ms  oracle %.3f ms" % (
+    t(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur)), t(lambda: oracle.search_window(q, qd, kps, desc, bounds, occ, ur), 5)))
+print("match_bruteforce 2000x2100 (host arrays): gpu %.3f ms  oracle %.3f ms" % (
+    t(lambda: m.match_bruteforce(d1, d2)), t(lambda: oracle.match_bruteforce(d1, d2), 3)))
