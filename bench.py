@@ -137,6 +137,33 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, cpu=Tru
     return out
 
 
+def matcher_loops_bench(cpu=True):
+    """Tracking-time matching: one call = one whole ORBmatcher loop, host arrays in and out
+    (PCIe and the per-call host work included), against the oracle's literal loop on the same inputs."""
+    from orb_slam2_e_amd.matcher import ORBmatcher
+    from orb_slam2_e_amd.synth import synth_bow_case, synth_projection_case
+    from orb_slam2_e_amd.vocabulary import feature_vector_arrays
+
+    def ms(f, reps):
+        f(); t0 = time.perf_counter()
+        for _ in range(reps): f()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(0, n=2000, nq=2000, hot=2000)
+    d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
+    fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
+    m = ORBmatcher(0.6, True)
+    out = {"search_by_projection_2000x2000_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
+           "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
+           "search_window_2000x2000_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
+    if cpu:
+        import oracle
+        ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, keep2)
+        out["oracle_search_by_projection_ms"] = ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True), 5)
+        out["oracle_search_by_bow_ms"] = ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True), 5)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,6 +372,8 @@ def main():
             out["host_io"] = host_io
         if fem is not None:
             out["fem"] = fem
+        if not args.no_fem:
+            out["matcher_loops"] = matcher_loops_bench(cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -110,3 +110,48 @@ def synth_stereo_pair(k=0, w=1242, h=375, dmin=2.0, dmax=60.0):
     L = left.astype(np.float64)
     right = (1 - fx) * L[rows, x0] + fx * L[rows, x0 + 1]
     return left, np.clip(np.rint(right), 0, 255).astype(np.uint8)
+
+
+def synth_projection_case(seed, n=2000, nq=3000, hot=400, stereo=False):
+    """Many queries aim at few keypoints, so the in-loop assignment matters."""
+    from .extractor import KP_DTYPE
+    from .matcher import ORBmatcher
+    rng = np.random.default_rng(seed)
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(-5, 645, n); kps["y"] = rng.uniform(-5, 485, n)
+    kps["octave"] = rng.integers(0, 8, n); kps["angle"] = rng.uniform(0, 360, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    desc[rng.choice(n, 200, replace=False)] = desc[1]
+    src = rng.choice(rng.choice(n, hot, replace=False), nq)
+    q = np.zeros(nq, ORBmatcher.WQ_DTYPE)
+    q["u"] = kps["x"][src] + rng.normal(0, 2, nq); q["v"] = kps["y"][src] + rng.normal(0, 2, nq)
+    q["r"] = rng.choice([7.0, 15.0, 30.0], nq) * (1.2 ** kps["octave"][src])
+    lvl = kps["octave"][src]
+    q["min_level"] = lvl - 1; q["max_level"] = lvl + rng.integers(0, 2, nq)
+    q["xr"] = q["u"] - rng.uniform(0, 30, nq)
+    qd = desc[src] ^ np.packbits(rng.random((nq, 256)) < 0.04, axis=1, bitorder="little")
+    # rotation: most matches agree on one of three rotations, the rest are scattered
+    qa = (kps["angle"][src] + rng.choice([10.0, 95.0, 200.0, 300.0, 333.0], nq, p=[0.5, 0.25, 0.15, 0.05, 0.05])
+          + rng.normal(0, 2, nq)) % 360
+    takes = (rng.random(nq) < 0.8).astype(np.uint8)
+    occ = (rng.random(n) < 0.05).astype(np.uint8)
+    ur = np.where(rng.random(n) < 0.5, kps["x"] - rng.uniform(0, 30, n), -1).astype(np.float32) if stereo else None
+    return q, qd, qa.astype(np.float32), takes, kps, desc, (0.0, 0.0, 640.0, 480.0), occ, ur
+
+
+def synth_bow_case(seed, n1=2000, n2=2100, nnodes=90):
+    rng = np.random.default_rng(seed)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    d1[rng.choice(n1, 500, replace=False)] = d1[:5][rng.integers(0, 5, 500)]      # look-alikes: the "already matched" skip matters
+    node1 = rng.integers(0, nnodes, n1) * 7 + 3
+    node1[d1[:, 0] % 5 == 0] = 3                                                   # one crowded node
+    src = rng.integers(0, n1, n2)
+    d2 = d1[src] ^ np.packbits(rng.random((n2, 256)) < 0.03, axis=1, bitorder="little")
+    node2 = node1[src].copy()
+    move = rng.random(n2) < 0.1
+    node2[move] = rng.integers(0, nnodes + 20, move.sum()) * 7 + 3                # some land in other (or unseen) nodes
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    a2 = ((a1[src] - rng.choice([15.0, 100.0, 260.0], n2, p=[0.75, 0.2, 0.05]) + rng.normal(0, 2, n2)) % 360).astype(np.float32)
+    valid1 = (rng.random(n1) < 0.8).astype(np.uint8); valid2 = (rng.random(n2) < 0.85).astype(np.uint8)
+    keep1 = rng.random(n1) < 0.97; keep2 = rng.random(n2) < 0.97                   # stop words never enter the FeatureVector
+    return d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from a tools/prof.sh output directory (separate rocprofv3 --pmc FETCH_SIZE and
+--pmc WRITE_SIZE passes), as MI355X_MICROARCH.md prescribes: both counters are reported in KiB; on gfx950
+FETCH_SIZE shows exactly half of the bytes of a wide coalesced streaming read (16 B per lane), so it is
+doubled for the kernels whose reads are such streams (k_fem_spmv); other access widths are uncalibrated and
+kept raw.  Only the largest dispatches of each kernel (= the batch case) are averaged.
+usage: prof_traffic.py gpurun_out/<dir> profiles/rNN_traffic.json "<source note>" """
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+STREAM16 = {"k_fem_spmv"}          # 16-byte-per-lane streaming reads: FETCH_SIZE x2
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].split("<")[0]
+
+
+def mean_largest(d, sub, counter):
+    vals = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                vals[short(r["Kernel_Name"])][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return {k: sum(v[max(v)]) / len(v[max(v)]) * 1024.0 for k, v in vals.items()}
+
+
+d, out, note = sys.argv[1], sys.argv[2], sys.argv[3]
+fetch, write = mean_largest(d, "pmc3", "FETCH_SIZE"), mean_largest(d, "pmc4", "WRITE_SIZE")
+res = {}
+for k in sorted(fetch):
+    if not k.startswith(("k_", "orb")):
+        continue
+    f, w = fetch[k], write.get(k, 0.0)
+    x2 = k in STREAM16
+    res[k] = {"hbm_bytes_per_launch": (2 * f if x2 else f) + w, "fetch_size_bytes_raw": f, "write_size_bytes": w,
+              "fetch_correction": "x2 (16-B/lane streaming loads, gfx950)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
+              "source": note}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in res.items()}, indent=1))

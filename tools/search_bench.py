@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import oracle
 from orb_slam2_e_amd import ORBmatcher
 from orb_slam2_e_amd.vocabulary import feature_vector_arrays
-from test_gpu_match import _projection_case, _bow_case
+from orb_slam2_e_amd.synth import synth_projection_case as _projection_case, synth_bow_case as _bow_case
 
 
 def t(f, reps=20):
