@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 W, H, BATCH = 640, 480, 64
 PARAMS = (2000, 1.2, 8, 20, 7)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Integer VALU issue rate: one wave64 instruction per 4 clocks per SIMD (tools/ubench/valu.hip), 1024 SIMDs, 2.4 GHz
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0
 # SURVEY 8(d) algorithmic bytes per 640x480 frame, by stage
 PYR_PX = 950532
 ALG_BYTES = {
@@ -368,6 +370,13 @@ def main():
             if dom in tr:
                 out["roofline"]["traffic"] = tr[dom]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr[dom]["source"]
+                if tr[dom].get("valu_wave_insts_per_launch"):
+                    # the kernels that dominate this path are bound by integer VALU issue, not by HBM:
+                    # the same launch time priced against the instruction count of the committed PMC pass
+                    ginst = tr[dom]["valu_wave_insts_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+                    out["roofline"]["valu"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64-instr/s",
+                                               "frac": ginst / VALU_PEAK_GINST,
+                                               "wave_insts_per_launch": tr[dom]["valu_wave_insts_per_launch"]}
         if host_io is not None:
             out["host_io"] = host_io
         if fem is not None:

@@ -3,7 +3,8 @@
 --pmc WRITE_SIZE passes), as MI355X_MICROARCH.md prescribes: both counters are reported in KiB; on gfx950
 FETCH_SIZE shows exactly half of the bytes of a wide coalesced streaming read (16 B per lane), so it is
 doubled for the kernels whose reads are such streams (k_fem_spmv); other access widths are uncalibrated and
-kept raw.  Only the largest dispatches of each kernel (= the batch case) are averaged.
+kept raw.  SQ_INSTS_VALU (wave-level VALU instructions, whole chip) is copied alongside for the kernels that are
+VALU-bound rather than HBM-bound.  Only the largest dispatches of each kernel (= the batch case) are averaged.
 usage: prof_traffic.py gpurun_out/<dir> profiles/rNN_traffic.json "<source note>" """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -27,6 +28,7 @@ def mean_largest(d, sub, counter):
 
 d, out, note = sys.argv[1], sys.argv[2], sys.argv[3]
 fetch, write = mean_largest(d, "pmc3", "FETCH_SIZE"), mean_largest(d, "pmc4", "WRITE_SIZE")
+valu = {k: v / 1024.0 for k, v in mean_largest(d, "pmc1", "SQ_INSTS_VALU").items()}   # a count, not KiB
 res = {}
 for k in sorted(fetch):
     if not k.startswith(("k_", "orb")):
@@ -35,6 +37,6 @@ for k in sorted(fetch):
     x2 = k in STREAM16
     res[k] = {"hbm_bytes_per_launch": (2 * f if x2 else f) + w, "fetch_size_bytes_raw": f, "write_size_bytes": w,
               "fetch_correction": "x2 (16-B/lane streaming loads, gfx950)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
-              "source": note}
+              "valu_wave_insts_per_launch": valu.get(k), "source": note}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in res.items()}, indent=1))
