@@ -68,8 +68,10 @@ constexpr int MQ = 2;     // query rows per lane
 
 __device__ __forceinline__ void key_update(unsigned key, unsigned &k1, unsigned &k2)
 {
-    const unsigned hi = k1 > key ? k1 : key; // k1 <= k2 always: median(k1, key, k2) = new second smallest
-    k2 = k2 < hi ? k2 : hi;
+    // k1 <= k2 always: median(k1, key, k2) = new second smallest (one v_med3_u32 instead of max + min)
+    unsigned m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k1), "v"(key), "v"(k2));
+    k2 = m;
     k1 = k1 < key ? k1 : key;
 }
 

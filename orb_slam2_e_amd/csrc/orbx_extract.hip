@@ -768,6 +768,35 @@ __device__ __forceinline__ int wave_sum(int v)
 // values -- evaluating them in every lane of a keypoint's wave would cost 64x the
 // instructions); phase 3: computeOrbDescriptor (:108-147) on the blurred level
 // and the output record (:845-855 octave/size, :1103-1109 pt *= scale).
+// IC_Angle weights for v_dot4_u32_u8: the 31x31 window is read as 31 rows x 8 dwords
+// starting at (x-15, y-15); dword d = row*8 + w holds u = 4w-15 .. 4w-12.  S weight = 1
+// inside the circular patch (|u| <= umax[|v|], ORBextractor.cc:454-469), T weight = u+15
+// there (m10 = sum(T) - 15*sum(S) keeps the weights unsigned).
+struct MomentWeights { uint32_t s[248], t[248]; };
+constexpr MomentWeights make_moment_weights()
+{
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    MomentWeights m{};
+    for (int d = 0; d < 248; ++d) {
+        const int v = d / 8 - 15, av = v < 0 ? -v : v;
+        uint32_t ws = 0, wt = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * (d % 8) + k - 15, au = u < 0 ? -u : u;
+            if (au <= umax[av]) { ws |= 1u << (8 * k); wt |= (uint32_t)(u + 15) << (8 * k); }
+        }
+        m.s[d] = ws; m.t[d] = wt;
+    }
+    return m;
+}
+__device__ const MomentWeights c_momw = make_moment_weights();
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4); // global_load_dword at any byte address (gfx950 amdhsa: unaligned access mode)
+    return v;
+}
+
 constexpr int DESC_KPB = 16;
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                   size_t frame_bytes, const LevelInfo *__restrict__ L, int nlevels,
@@ -780,7 +809,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ int s_stride[DESC_KPB], s_level[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
     __shared__ uint32_t s_pk[DESC_KPB];
     __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
-    __shared__ uint32_t s_patch[4][37 * 16];
+    __shared__ uint32_t s_patch[4][37 * 10 + 14];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int f, kbase;
     xcd_frame_item(f, kbase);
@@ -805,37 +834,33 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
     }
     __syncthreads();
-    // umax[|v|] = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3} (:454-469), 4 bits each
-    const unsigned long long umax_nib = 0x3689ABCDDEEEFFFFull;
+    // IC_Angle (:77-104): every lane owns 4 dwords of the 31x31 window (fixed per lane, so are
+    // their weights) and reads them straight from the unblurred level; two dot4 per dword.
     uint32_t *patch = s_patch[wv];
+    uint32_t wS[4], wT[4];
+    int vrow[4], doff[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int d = lane + 64 * jj;
+        const bool in = d < 248;
+        wS[jj] = in ? c_momw.s[d] : 0u; wT[jj] = in ? c_momw.t[d] : 0u;
+        vrow[jj] = (in ? d : 0) >> 3; doff[jj] = 4 * (d & 7);
+    }
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         if (s_level[kp] < 0) continue;
-        // stage the 31x31 window (|offset| <= 15) of the unblurred level with aligned dword loads
-        constexpr int OR = 15, OW = 16, OWN = 10; // radius, LDS row pitch in dwords, dwords needed (40 bytes >= 31 + 3)
-        const unsigned long long c = s_center[kp];
         const int stride = s_stride[kp];
-        const int shift = (int)((c - OR) & 3ull);
-        const uint8_t *row0 = pyr + (c - OR - shift) - (ptrdiff_t)OR * stride;
-        for (int i = lane; i < (2 * OR + 1) * OW; i += 64) {
-            const int r = i >> 4, w = i & 15;
-            if (w < OWN) patch[i] = *reinterpret_cast<const uint32_t *>(row0 + __mul24(r, stride) + 4 * w);
-        }
-        const uint8_t *c0 = reinterpret_cast<const uint8_t *>(patch) + OR * (OW * 4) + OR + shift;
-        int m10 = 0, m01 = 0;
-        const int u = (lane & 31) - 15, half = lane >> 5;
+        const uint8_t *win = pyr + s_center[kp] - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
+        uint32_t px[4];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int v = -15 + it * 2 + half;
-            const int av = v < 0 ? -v : v;
-            if (v <= 15 && (lane & 31) < 31) {
-                const int au = u < 0 ? -u : u;
-                if (au <= (int)((umax_nib >> (4 * av)) & 15ull)) {
-                    const int val = c0[v * (OW * 4) + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
-            }
+        for (int jj = 0; jj < 4; ++jj) px[jj] = load_u32_unaligned(win + __mul24(vrow[jj], stride) + doff[jj]);
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int sS = (int)__builtin_amdgcn_udot4(px[jj], wS[jj], 0u, false);
+            const int sT = (int)__builtin_amdgcn_udot4(px[jj], wT[jj], 0u, false);
+            m10 += sT - 15 * sS;
+            m01 += (vrow[jj] - 15) * sS;
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
@@ -851,30 +876,35 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     }
     __syncthreads();
     // steered BRIEF: lane i evaluates tests 4i..4i+3 of its wave's current keypoint.
-    // The 37x37 blurred patch (|offset| <= 18) is staged in LDS with aligned dword
-    // loads first: the 512 sample points are scattered over ~37 rows, and gathering
-    // them straight from global memory costs ~30 cache-line requests per load.
+    // The 37x37 blurred patch (|offset| <= 18) is staged in LDS first, as 37 rows of 10
+    // dwords starting at (x-18, y-18) (dword loads at byte addresses): the 512 sample
+    // points are scattered over ~37 rows, and gathering them straight from global memory
+    // costs ~30 cache-line requests per load.
     float px[8], py[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const signed char *pp = c_pattern + 16 * lane + 4 * t;
         px[2 * t] = (float)pp[0]; py[2 * t] = (float)pp[1]; px[2 * t + 1] = (float)pp[2]; py[2 * t + 1] = (float)pp[3];
     }
-    constexpr int PR = 18, PW = 16, PWN = 12; // patch radius, LDS row pitch in dwords, dwords needed (48 bytes >= 37 + 3)
+    constexpr int PR = 18, PW = 10; // patch radius; row = 10 dwords = bytes x-18 .. x+21
+    int prow[6], pcol[6];
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) { // dword jj*64 + lane of the 37 x 10 window: fixed per lane
+        const int d = lane + 64 * jj;
+        prow[jj] = d < (2 * PR + 1) * PW ? d / PW : -1;
+        pcol[jj] = 4 * (d % PW);
+    }
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         const int level = s_level[kp];
         if (level < 0) continue;
         const float a = s_cos[kp], b = s_sin[kp];
         const int stride = s_stride[kp];
-        const unsigned long long c = s_center[kp];
-        const int shift = (int)((c - PR) & 3ull);                // bytes between the aligned start and x-18
-        const uint8_t *row0 = blur + (c - PR - shift) - (ptrdiff_t)PR * stride;
-        for (int i = lane; i < (2 * PR + 1) * PW; i += 64) {
-            const int r = i >> 4, w = i & 15;
-            if (w < PWN) patch[i] = *reinterpret_cast<const uint32_t *>(row0 + __mul24(r, stride) + 4 * w);
-        }
-        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR + shift; // patch centre
+        const uint8_t *win = blur + s_center[kp] - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj)
+            if (prow[jj] >= 0) patch[lane + 64 * jj] = load_u32_unaligned(win + __mul24(prow[jj], stride) + pcol[jj]);
+        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR; // patch centre
         unsigned nib = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
