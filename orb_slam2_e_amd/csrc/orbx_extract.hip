@@ -690,17 +690,27 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 // GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point:
 // horizontal 7 taps exact in u16, vertical 7 taps exact in u32, (v + 2^15) >> 16.
 // The padded pyramid already holds the reflected border, so no index clamping.
-// Tile = 64 x 32 outputs per 256-thread workgroup; the (72 x 38)-byte input
-// window is fetched as aligned dwords (x0 is a multiple of 64, rows start 32-B
-// aligned), each work item filters 4 adjacent pixels.
-constexpr int BLUR_TW = 64, BLUR_TH = 32;
+// Tile = 64 x BLUR_TH outputs per 256-thread workgroup; the (72 x (BLUR_TH+6))-byte input
+// window is fetched as aligned dwords (x0 is a multiple of 64, rows start 32-B aligned).
+// Both passes are integer dot products (no MFMA: v_dot4_u32_u8 / v_dot2_u32_u16 are plain
+// VALU ops): horizontally the 7 taps of 4 adjacent pixels are at most three dot4 of the
+// three input dwords with shifted tap vectors; the u16 row sums are stored as VERTICAL
+// pairs (row 2p | row 2p+1 << 16), so that the 7 vertical taps of output rows 2p and 2p+1
+// are four dot2 each over the same four pair-dwords.
+constexpr int BLUR_TW = 64, BLUR_TH = 58;
+typedef unsigned short blur_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t w, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_u16x2, a), __builtin_bit_cast(blur_u16x2, w), c, false);
+}
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               size_t frame_bytes, const LevelInfo *__restrict__ L,
                                               const BlurTile *__restrict__ tiles, int t0, int t1, int t2, int t3)
 {
-    constexpr int IW = BLUR_TW / 4 + 2, IH = BLUR_TH + 6; // 18 dwords x 38 rows
+    constexpr int IW = BLUR_TW / 4 + 2, IH = BLUR_TH + 6, NP = IH / 2; // 18 dwords x 64 rows = 32 row pairs
+    static_assert(IH % 2 == 0, "row pairs");
     __shared__ uint32_t in[IH][IW + 1];
-    __shared__ uint32_t hz[IH][BLUR_TW / 2 + 1];           // u16 pairs
+    __shared__ __align__(16) uint32_t hz[NP][BLUR_TW + 4]; // hz[p][x] = H(row 2p, x) | H(row 2p+1, x) << 16
     int f, ti;
     xcd_frame_item(f, ti);
     const BlurTile bt = tiles[ti];
@@ -714,42 +724,66 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         if (x <= lv.w + EDGE - 4 && y < lv.h + EDGE) v = *reinterpret_cast<const uint32_t *>(pyr + base + (ptrdiff_t)(y + EDGE) * lv.stride + x);
         in[r][c] = v;
     }
+    // tap vectors: taps t0 t1 t2 t3 t2 t1 t0 sit on window bytes k+1 .. k+7 for output pixel k
+    // (pixel 4q+k = byte 4+k of the 12-byte window w0 | w1 | w2)
+    const uint32_t T[7] = {(uint32_t)t0, (uint32_t)t1, (uint32_t)t2, (uint32_t)t3, (uint32_t)t2, (uint32_t)t1, (uint32_t)t0};
+    uint32_t W[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int tap = 4 * d + bb - (k + 1);
+                if (tap >= 0 && tap < 7) w |= T[tap] << (8 * bb);
+            }
+            W[k][d] = w;
+        }
     __syncthreads();
-    for (int i = tid; i < IH * (BLUR_TW / 4); i += 256) {
-        const int r = i / (BLUR_TW / 4), q = i - r * (BLUR_TW / 4);
-        const uint32_t w0 = in[r][q], w1 = in[r][q + 1], w2 = in[r][q + 2];
-        uint32_t b[12];
+    for (int i = tid; i < NP * (BLUR_TW / 4); i += 256) {
+        const int p = i / (BLUR_TW / 4), q = i - p * (BLUR_TW / 4);
+        uint32_t o[2][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 255u; b[4 + k] = (w1 >> (8 * k)) & 255u; b[8 + k] = (w2 >> (8 * k)) & 255u; }
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) // pixel 4q+k sits at byte 4+k of the 12-byte window
-            o[k] = __umul24(t0, b[k + 1] + b[k + 7]) + __umul24(t1, b[k + 2] + b[k + 6]) + __umul24(t2, b[k + 3] + b[k + 5]) + __umul24(t3, b[k + 4]);
-        hz[r][2 * q] = o[0] | (o[1] << 16);
-        hz[r][2 * q + 1] = o[2] | (o[3] << 16);
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t w0 = in[2 * p + h][q], w1 = in[2 * p + h][q + 1], w2 = in[2 * p + h][q + 2];
+            o[h][0] = __builtin_amdgcn_udot4(w1, W[0][1], __builtin_amdgcn_udot4(w0, W[0][0], 0u, false), false);
+            o[h][1] = __builtin_amdgcn_udot4(w2, W[1][2], __builtin_amdgcn_udot4(w1, W[1][1], __builtin_amdgcn_udot4(w0, W[1][0], 0u, false), false), false);
+            o[h][2] = __builtin_amdgcn_udot4(w2, W[2][2], __builtin_amdgcn_udot4(w1, W[2][1], __builtin_amdgcn_udot4(w0, W[2][0], 0u, false), false), false);
+            o[h][3] = __builtin_amdgcn_udot4(w2, W[3][2], __builtin_amdgcn_udot4(w1, W[3][1], 0u, false), false);
+        }
+        uint4 v;
+        v.x = o[0][0] | (o[1][0] << 16); v.y = o[0][1] | (o[1][1] << 16); v.z = o[0][2] | (o[1][2] << 16); v.w = o[0][3] | (o[1][3] << 16);
+        *reinterpret_cast<uint4 *>(&hz[p][4 * q]) = v;
     }
     __syncthreads();
-    for (int i = tid; i < BLUR_TH * (BLUR_TW / 4); i += 256) {
-        const int r = i / (BLUR_TW / 4), q = i - r * (BLUR_TW / 4);
-        const int x = bt.x0 + 4 * q, y = bt.y0 + r;
+    // vertical: output rows 2p, 2p+1 (tile-relative) read H rows 2p .. 2p+7 = pairs p .. p+3
+    const uint32_t ve0 = (uint32_t)t0 | ((uint32_t)t1 << 16), ve1 = (uint32_t)t2 | ((uint32_t)t3 << 16),
+                   ve2 = (uint32_t)t2 | ((uint32_t)t1 << 16), ve3 = (uint32_t)t0;                         // even row: taps on rows 0..6
+    const uint32_t vo0 = (uint32_t)t0 << 16, vo1 = (uint32_t)t1 | ((uint32_t)t2 << 16),
+                   vo2 = (uint32_t)t3 | ((uint32_t)t2 << 16), vo3 = (uint32_t)t1 | ((uint32_t)t0 << 16); // odd row: rows 1..7
+    for (int i = tid; i < (BLUR_TH / 2) * (BLUR_TW / 4); i += 256) {
+        const int p = i / (BLUR_TW / 4), q = i - p * (BLUR_TW / 4);
+        const int x = bt.x0 + 4 * q, y = bt.y0 + 2 * p;
         if (x >= lv.w || y >= lv.h) continue;
-        uint32_t a[7][2];
+        uint32_t a[4][4];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) { a[j][0] = hz[r + j][2 * q]; a[j][1] = hz[r + j][2 * q + 1]; }
-        uint32_t out = 0;
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&hz[p + j][4 * q]);
+            a[j][0] = v.x; a[j][1] = v.y; a[j][2] = v.z; a[j][3] = v.w;
+        }
+        uint32_t oe = 0, oo = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int wi = k >> 1, sh = (k & 1) * 16;
-            // all factors < 2^24: v_mul_u32_u24 / v_mad_u32_u24 (full rate) instead of v_mul_lo_u32 (quarter rate)
-            const uint32_t s = __umul24(t0, ((a[0][wi] >> sh) & 0xffffu) + ((a[6][wi] >> sh) & 0xffffu)) +
-                               __umul24(t1, ((a[1][wi] >> sh) & 0xffffu) + ((a[5][wi] >> sh) & 0xffffu)) +
-                               __umul24(t2, ((a[2][wi] >> sh) & 0xffffu) + ((a[4][wi] >> sh) & 0xffffu)) +
-                               __umul24(t3, (a[3][wi] >> sh) & 0xffffu);
-            uint32_t v = (s + (1u << 15)) >> 16;
-            v = v > 255u ? 255u : v;
-            out |= v << (8 * k);
+            uint32_t se = blur_dot2(a[3][k], ve3, blur_dot2(a[2][k], ve2, blur_dot2(a[1][k], ve1, blur_dot2(a[0][k], ve0, 1u << 15))));
+            uint32_t so = blur_dot2(a[3][k], vo3, blur_dot2(a[2][k], vo2, blur_dot2(a[1][k], vo1, blur_dot2(a[0][k], vo0, 1u << 15))));
+            se >>= 16; so >>= 16;
+            se = se > 255u ? 255u : se; so = so > 255u ? 255u : so;
+            oe |= se << (8 * k); oo |= so << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(blur + base + (size_t)(y + EDGE) * lv.stride + x) = out;
+        uint8_t *dst = blur + base + (size_t)(y + EDGE) * lv.stride + x;
+        *reinterpret_cast<uint32_t *>(dst) = oe;
+        if (y + 1 < lv.h) *reinterpret_cast<uint32_t *>(dst + lv.stride) = oo;
     }
 }
 
