@@ -154,6 +154,15 @@ __device__ __forceinline__ void xcd_frame_item(int &frame, int &item)
     }
 }
 
+// Dword load at any byte address: gfx950 under amdhsa runs in unaligned-access mode (the compiler itself turns an
+// align-1 4-byte copy into one global_load_dword).
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // --------------------------------------------------------------------- FAST
 // Differences v - p_k on the 16-pixel Bresenham circle of radius 3 (OpenCV
 // makeOffsets order), t = centre pointer into the LDS tile, ts = tile stride.
@@ -287,25 +296,26 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
     int total = 0;
     if (zw > 0 && zh > 0) {
-        // (1) tile: aligned dword loads; pixel (x, y) of the cell lives at tile[y*TS + 4 + x + xoff]
-        // (4 spare bytes on the left: the packed pre-test reads one dword either side of its group)
-        const int xoff = ci.x0 & 3, ndw = (cw + xoff + 3) >> 2;
-        const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + (ci.x0 - xoff);
+        // (1) tile: pixel (x, y) of the cell lives at tile[y*TS + 5 + x], so that zone pixel 0 (cell pixel 3) sits
+        // on the dword boundary at column 8 whatever the cell's position: the pre-test's 4-pixel groups then cover a
+        // zone row with ceil(zw/4) groups.  Dword loads at byte addresses (see load_u32_unaligned).
+        const int ndw = (cw + 5 + 3) >> 2;
+        const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + (ci.x0 - 5);
         const float inv_ndw = 1.0f / (float)ndw; // i / ndw via float: (i + 0.5) / ndw is >= 0.025 away from any integer
         for (int i = lane; i < ch * ndw; i += 64) {
             const int y = (int)(((float)i + 0.5f) * inv_ndw), xw = i - y * ndw;
-            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 + 4 * xw) = *reinterpret_cast<const uint32_t *>(img + __mul24(y, lv.stride) + 4 * xw);
+            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = load_u32_unaligned(img + __mul24(y, lv.stride) + 4 * xw);
         }
         for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
         __syncthreads();
-        const int zc0 = 7 + xoff;                     // tile column of zone pixel 0
+        constexpr int zc0 = 8;                        // tile column of zone pixel 0
         const uint8_t *t0 = tile + 3 * TS + zc0;      // zone pixel (0,0)
         const unsigned long long lt = (1ull << lane) - 1ull;
         // (2) pre-test, survivors -> queue entries y<<6 | x | polarity<<12.  A group = the 4
         // pixels of one tile dword; groups overlapping the zone row, in raster order.
         int nq = 0;
         {
-            const int g0 = zc0 >> 2, ngx = ((zc0 + zw - 1) >> 2) - g0 + 1, ngrp = ngx * zh;
+            const int g0 = zc0 >> 2, ngx = (zw + 3) >> 2, ngrp = ngx * zh;
             const uint32_t th2 = (uint32_t)minTh | ((uint32_t)minTh << 16);
             const int qstep = 64 / ngx, rstep = 64 - qstep * ngx; // lane + 64 -> (gx + rstep, y + qstep), one carry
             int y = lane / ngx, gx = lane - y * ngx;
@@ -824,13 +834,6 @@ constexpr MomentWeights make_moment_weights()
 }
 __device__ const MomentWeights c_momw = make_moment_weights();
 
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
-{
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4); // global_load_dword at any byte address (gfx950 amdhsa: unaligned access mode)
-    return v;
-}
-
 constexpr int DESC_KPB = 16;
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                   size_t frame_bytes, const LevelInfo *__restrict__ L, int nlevels,
@@ -1198,10 +1201,10 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
     }
     ex->NC = maxN + 8;
-    // tile row = 4 spare bytes + up to 3 of alignment shift + the cell + the packed pre-test's
-    // right-hand dword; zone <= 63 (6-bit queue coordinates)
-    if (maxcw + 11 > 80 || maxch > 69) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than the LDS tile");
-    ex->TS = ex->SS = (maxcw + 11 <= 64) ? 64 : 80;
+    // tile row = 5 spare bytes + the cell + the packed pre-test's right-hand dword; zone <= 63 (6-bit queue
+    // coordinates)
+    if (maxcw + 12 > 80 || maxch > 69) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than the LDS tile");
+    ex->TS = ex->SS = (maxcw + 12 <= 64) ? 64 : 80;
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
