@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2, help="independent contexts/streams the steps rotate over")
+    ap.add_argument("--pipeline", type=int, default=3, help="independent contexts/streams the steps rotate over")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--host-io", action="store_true", help="also time the PCIe-inclusive path (host images in, host results out)")
     ap.add_argument("--no-fem", action="store_true")
