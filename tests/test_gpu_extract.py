@@ -104,6 +104,10 @@ def test_too_small_image_is_an_error():
     ((375, 1242), (2000, 1.2, 8, 20, 7)),     # KITTI-shaped: 4 octree roots at level 0
     ((300, 400), (500, 1.5, 4, 30, 10)),
     ((480, 640), (4000, 1.2, 8, 20, 7)),      # mpIniORBextractor uses 2*nFeatures
+    ((480, 752), (1000, 1.2, 8, 20, 7)),      # EuRoC-shaped
+    ((487, 645), (1500, 1.2, 8, 20, 7)),      # odd sizes: every cell / row start at another byte alignment
+    ((251, 333), (700, 1.3, 5, 15, 5)),
+    ((376, 1241), (2000, 1.2, 8, 12, 7)),     # KITTI 00-02 size (Examples/Stereo/KITTI00-02.yaml), odd width
 ])
 def test_other_shapes_and_params(shape, params):
     img = synth_frame(3, w=shape[1], h=shape[0])
@@ -127,6 +131,24 @@ def test_sparse_image_threshold_fallback_and_short_levels():
     ex = ORBextractor(*PARAMS)
     kps, desc = ex(img)
     assert 0 < len(okps) < 2000
+    _kp_equal(kps, okps)
+    assert np.array_equal(desc, odesc)
+
+
+def test_dense_texture_every_cell_full():
+    # white noise: almost every pixel passes the pre-test, cells emit their maximum number of candidates
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    img[100:200, 100:300] = rng.integers(90, 110, (100, 200), dtype=np.uint8)   # and one low-contrast region
+    o = oracle.OrbOracle(*PARAMS)
+    okps, odesc = o.extract(img)
+    ex = ORBextractor(*PARAMS)
+    kps, desc = ex(img)
+    for l in range(8):
+        ref = o.level_cands(l)
+        got = ex.level_candidates(0, l)
+        assert len(got) == len(ref) and len(ref) > 100, f"level {l}: {len(got)} vs {len(ref)} candidates"
+        assert np.array_equal(got[:, 0], ref["x"]) and np.array_equal(got[:, 1], ref["y"]) and np.array_equal(got[:, 2], ref["response"])
     _kp_equal(kps, okps)
     assert np.array_equal(desc, odesc)
 
