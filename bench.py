@@ -166,6 +166,43 @@ def matcher_loops_bench(cpu=True):
     return out
 
 
+def stereo_bench(cpu=True):
+    """Config 5: one 1242x375 KITTI-shaped pair through the drop-in calls -- left and right ORBextractor::operator()
+    (host image in, keypoints / descriptors out) and Frame::ComputeStereoMatches on the two resident pyramids."""
+    from orb_slam2_e_amd import ComputeStereoMatches, ORBextractor
+    from orb_slam2_e_amd.synth import synth_stereo_pair
+    fx, bf = 718.856, 386.1448                      # Examples/Stereo/KITTI00-02.yaml:8,25
+    mb = np.float32(bf) / np.float32(fx)
+    left, right = synth_stereo_pair(0)
+    eL, eR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+
+    def frame():
+        eL(left); eR(right)
+        return ComputeStereoMatches(eL, eR, mb, np.float32(bf))
+
+    u, d = frame()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps): frame()
+    t_all = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps): ComputeStereoMatches(eL, eR, mb, np.float32(bf))
+    t_st = (time.perf_counter() - t0) / reps
+    out = {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "compute_stereo_matches_ms": t_st * 1e3,
+           "stereo_pairs_per_s": 1.0 / t_all, "matched": int((u >= 0).sum())}
+    if cpu:
+        import oracle
+        oL, oR = oracle.OrbOracle(*PARAMS), oracle.OrbOracle(*PARAMS)
+        t0 = time.perf_counter()
+        kL, dL = oL.extract(left); kR, dR = oR.extract(right)
+        t1 = time.perf_counter()
+        oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(bf))
+        t2 = time.perf_counter()
+        out["oracle_stereo_frame_ms"] = (t2 - t0) * 1e3
+        out["oracle_compute_stereo_matches_ms"] = (t2 - t1) * 1e3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,6 +420,7 @@ def main():
             out["fem"] = fem
         if not args.no_fem:
             out["matcher_loops"] = matcher_loops_bench(cpu=not args.no_cpu_baseline)
+            out["stereo"] = stereo_bench(cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1058,7 +1058,7 @@ int orbx_destroy(orbx_extractor *ex)
     if (!ex) return ORBX_OK;
     free_workspace(ex);
     if (ex->d_in) (void)hipFree(ex->d_in);
-    void *stp[] = {ex->d_st_key, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
+    void *stp[] = {ex->d_st_key, ex->d_st_rk, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
     for (void *q : stp)
         if (q) (void)hipFree(q);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);

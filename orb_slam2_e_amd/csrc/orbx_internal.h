@@ -75,6 +75,7 @@ struct orbx_extractor {
     int last_batch = 0;
     // stereo (orbx_stereo.hip): results live in the LEFT handle
     unsigned *d_st_key = nullptr;
+    void *d_st_rk = nullptr; // row bands of the right keypoints (orbx_stereo.hip)
     float *d_uright = nullptr, *d_depth = nullptr, *d_st_scale = nullptr;
     int *d_st_sad = nullptr, *d_st_nvalid = nullptr;
     int st_batch = 0;

@@ -1,7 +1,8 @@
 // orbx_stereo.hip -- Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the
 // device-resident results of a left and a right orbx_extractor.
 //
-//   k_stereo_hamming  row-band / octave / disparity gating + best Hamming match (:537-610)
+//   k_stereo_prep     row band of every right keypoint (:537-554)
+//   k_stereo_hamming  row-band / octave / disparity gating + best Hamming match (:556-610)
 //   k_stereo_refine   11x11 L1 correlation over 11 shifts on the left keypoint's
 //                     pyramid level, parabola sub-pixel fit, depth (:612-683)
 //   k_stereo_median   median cut 1.5*1.4*median of the correlation distances (:687-700)
@@ -20,7 +21,7 @@ using namespace orbx_detail;
 
 namespace {
 
-constexpr int ST_T = 256;   // right keypoints staged per step
+constexpr int ST_T = 256;
 struct RightKp { short minr, maxr; int octave; float x; };
 
 __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
@@ -29,60 +30,54 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// One lane per left keypoint; right keypoints staged through LDS 256 at a time.
-__global__ __launch_bounds__(ST_T) void k_stereo_hamming(const orbx_keypoint *__restrict__ kpL, const uint8_t *__restrict__ dL,
-                                                         const int *__restrict__ cntL, const orbx_keypoint *__restrict__ kpR,
-                                                         const uint8_t *__restrict__ dR, const int *__restrict__ cntR,
-                                                         int cap, const float *__restrict__ scaleFactors, int nRows,
-                                                         float maxD, unsigned *__restrict__ best_key)
+// Row band of every right keypoint (vRowIndices, :537-554): r = 2 * scale[octave], rows floor(y - r) .. ceil(y + r).
+__global__ __launch_bounds__(ST_T) void k_stereo_prep(const orbx_keypoint *__restrict__ kpR, const int *__restrict__ cntR, int cap,
+                                                      const float *__restrict__ scaleFactors, RightKp *__restrict__ rk)
 {
-    __shared__ RightKp s_kp[ST_T];
-    __shared__ uint4 s_d[ST_T * 2];
-    const int f = blockIdx.y, tid = threadIdx.x;
+    const int f = blockIdx.y, j = blockIdx.x * ST_T + threadIdx.x;
+    if (j >= min(cntR[f], cap)) return;
+    const orbx_keypoint k = kpR[(size_t)f * cap + j];
+    const float r = 2.0f * scaleFactors[k.octave]; // :546
+    RightKp o;
+    o.maxr = (short)(int)ceilf(k.y + r);
+    o.minr = (short)(int)floorf(k.y - r);
+    o.octave = k.octave; o.x = k.x;
+    rk[(size_t)f * cap + j] = o;
+}
+
+// One wave per left keypoint (4 per workgroup): the lanes stride over the right keypoints' row bands; the few
+// that pass the row / octave / disparity gates get a Hamming distance; wave minimum of dist << 16 | iR.
+__global__ __launch_bounds__(ST_T) void k_stereo_hamming(const orbx_keypoint *__restrict__ kpL, const uint8_t *__restrict__ dL,
+                                                         const int *__restrict__ cntL, const RightKp *__restrict__ rkR,
+                                                         const uint8_t *__restrict__ dR, const int *__restrict__ cntR,
+                                                         int cap, int nRows, float maxD, unsigned *__restrict__ best_key)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * (ST_T / 64) + (threadIdx.x >> 6);
     const int N = min(cntL[f], cap), Nr = min(cntR[f], cap);
-    if (blockIdx.x * ST_T >= N) return;
-    const int iL = blockIdx.x * ST_T + tid;
-    const bool act = iL < N;
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-    int levelL = 0, row = -100000;
-    float minU = 0.f, maxU = -1.f;
-    if (act) {
-        const orbx_keypoint k = kpL[(size_t)f * cap + iL];
-        const uint4 *A = reinterpret_cast<const uint4 *>(dL + ((size_t)f * cap + iL) * 32);
-        a0 = A[0]; a1 = A[1];
-        levelL = k.octave;
-        row = (int)k.y;              // vRowIndices[vL], :569
-        minU = k.x - maxD;           // :574
-        maxU = k.x - 0.0f;           // :575 (minD = 0)
-        if (row < 0 || row >= nRows || maxU < 0) row = -100000; // no candidates (:571-578)
-    }
-    unsigned key = 95u << 16;        // bestDist = TH_HIGH, bestIdxR = 0 (:580-581)
-    for (int j0 = 0; j0 < Nr; j0 += ST_T) {
-        __syncthreads();
-        if (j0 + tid < Nr) {
-            const orbx_keypoint k = kpR[(size_t)f * cap + j0 + tid];
-            const float r = 2.0f * scaleFactors[k.octave]; // :546
-            RightKp rk;
-            rk.maxr = (short)(int)ceilf(k.y + r);
-            rk.minr = (short)(int)floorf(k.y - r);
-            rk.octave = k.octave; rk.x = k.x;
-            s_kp[tid] = rk;
-            const uint4 *B = reinterpret_cast<const uint4 *>(dR + ((size_t)f * cap + j0 + tid) * 32);
-            s_d[2 * tid] = B[0]; s_d[2 * tid + 1] = B[1];
-        }
-        __syncthreads();
-        const int nt = min(ST_T, Nr - j0);
-        for (int j = 0; j < nt; ++j) {
-            const RightKp rk = s_kp[j];
-            const bool ok = row >= rk.minr && row <= rk.maxr && rk.octave >= levelL - 1 && rk.octave <= levelL + 1 &&
-                            rk.x >= minU && rk.x <= maxU;
-            if (ok) {
-                const unsigned k2 = ((unsigned)hamming256(a0, a1, s_d[2 * j], s_d[2 * j + 1]) << 16) | (unsigned)(j0 + j);
+    if (iL >= N) return;
+    const orbx_keypoint k = kpL[(size_t)f * cap + iL];
+    const uint4 *A = reinterpret_cast<const uint4 *>(dL + ((size_t)f * cap + iL) * 32);
+    const uint4 a0 = A[0], a1 = A[1];
+    const int levelL = k.octave;
+    int row = (int)k.y;                    // vRowIndices[vL], :569
+    const float minU = k.x - maxD;         // :574
+    const float maxU = k.x - 0.0f;         // :575 (minD = 0)
+    unsigned key = 95u << 16;              // bestDist = TH_HIGH, bestIdxR = 0 (:580-581)
+    if (!(row < 0 || row >= nRows || maxU < 0)) { // else no candidates (:571-578)
+        const RightKp *rk = rkR + (size_t)f * cap;
+        for (int j = lane; j < Nr; j += 64) {
+            const RightKp r = rk[j];
+            if (row >= r.minr && row <= r.maxr && r.octave >= levelL - 1 && r.octave <= levelL + 1 && r.x >= minU && r.x <= maxU) {
+                const uint4 *Bp = reinterpret_cast<const uint4 *>(dR + ((size_t)f * cap + j) * 32);
+                const unsigned k2 = ((unsigned)hamming256(a0, a1, Bp[0], Bp[1]) << 16) | (unsigned)j;
                 key = k2 < key ? k2 : key; // dist<bestDist in iR order == min over (dist, iR), :598-602
             }
         }
     }
-    if (act) best_key[(size_t)f * cap + iL] = key;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    if (lane == 0) best_key[(size_t)f * cap + iL] = key;
 }
 
 // One wave per left keypoint that found a descriptor match below thOrbDist.
@@ -222,8 +217,9 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
     hipStream_t st = stream_ ? (hipStream_t)stream_ : left->stream;
     const int B = left->last_batch, cap = left->kcap;
     if (!left->d_st_key || left->st_batch < B) {
-        if (left->d_st_key) { (void)hipFree(left->d_st_key); (void)hipFree(left->d_uright); (void)hipFree(left->d_depth); (void)hipFree(left->d_st_sad); (void)hipFree(left->d_st_scale); (void)hipFree(left->d_st_nvalid); }
+        if (left->d_st_key) { (void)hipFree(left->d_st_rk); (void)hipFree(left->d_st_key); (void)hipFree(left->d_uright); (void)hipFree(left->d_depth); (void)hipFree(left->d_st_sad); (void)hipFree(left->d_st_scale); (void)hipFree(left->d_st_nvalid); }
         ORBX_HIP(hipMalloc(&left->d_st_key, sizeof(unsigned) * (size_t)cap * left->batch));
+        ORBX_HIP(hipMalloc(&left->d_st_rk, sizeof(RightKp) * (size_t)cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_uright, sizeof(float) * (size_t)cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_depth, sizeof(float) * (size_t)cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_st_sad, sizeof(int) * (size_t)cap * left->batch));
@@ -239,8 +235,10 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
     if (st != right->stream) ORBX_HIP(hipStreamSynchronize(right->stream));
     const float maxD = mbf / mb; // :557-559
     const int nRows = left->lv[0].h;
-    hipLaunchKernelGGL(k_stereo_hamming, dim3((cap + ST_T - 1) / ST_T, B), dim3(ST_T), 0, st, left->d_kps, left->d_desc,
-                       left->d_counts, right->d_kps, right->d_desc, right->d_counts, cap, left->d_st_scale, nRows, maxD,
+    hipLaunchKernelGGL(k_stereo_prep, dim3((cap + ST_T - 1) / ST_T, B), dim3(ST_T), 0, st, right->d_kps, right->d_counts, cap,
+                       left->d_st_scale, (RightKp *)left->d_st_rk);
+    hipLaunchKernelGGL(k_stereo_hamming, dim3((cap + ST_T / 64 - 1) / (ST_T / 64), B), dim3(ST_T), 0, st, left->d_kps, left->d_desc,
+                       left->d_counts, (const RightKp *)left->d_st_rk, right->d_desc, right->d_counts, cap, nRows, maxD,
                        left->d_st_key);
     hipLaunchKernelGGL(k_stereo_refine, dim3((cap + 3) / 4, B), dim3(256), 0, st, left->d_kps, left->d_counts, right->d_kps,
                        cap, left->d_st_key, left->d_pyr, right->d_pyr, left->frame_bytes, left->d_lv, left->d_st_scale,
