@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <vector>
 
@@ -52,7 +53,7 @@ inline void build_winkp(const orbx_keypoint *kps, int n, const uint8_t *skip, co
 struct Workspace {
     char *dev = nullptr, *pin = nullptr;
     unsigned *ent = nullptr;
-    size_t dev_cap = 0, pin_cap = 0, ent_cap = 0, used = 0, want = 0;
+    size_t dev_cap = 0, pin_cap = 0, ent_cap = 0, used = 0;
     hipStream_t st = nullptr;
     int reserve(size_t dev_bytes, size_t pin_bytes); // discards the contents
     int reserve_entries(size_t n);
@@ -68,30 +69,44 @@ struct WorkspaceLease {
     ~WorkspaceLease() { workspace_release(w); }
 };
 
-// Scope of one host-array call that takes its device arrays one by one (DevBuf): they are
-// bumped out of a leased workspace's arena; what does not fit falls back to hipMalloc for
-// this call and makes the arena grow before the next one, so the steady state allocates
-// nothing.
-struct DevScope {
+// One host-array call: declare inputs (staged in pinned memory, uploaded with ONE copy), device scratch and outputs
+// (downloaded with ONE copy), in that order; everything runs on the leased workspace's stream.
+struct StagedCall {
     WorkspaceLease lease;
-    std::vector<void *> overflow;
-    size_t asked = 0;
-    DevScope *prev;
-    DevScope();
-    ~DevScope();
-    void *alloc(size_t n);
-};
-extern thread_local DevScope *tls_dev_scope;
-
-struct DevBuf {
-    void *p = nullptr;
-    bool owned = false;
-    ~DevBuf() { if (p && owned) (void)hipFree(p); }
-    int alloc(size_t n)
+    Workspace &w;
+    struct In { size_t off; const void *src; size_t bytes; };
+    std::vector<In> ins;
+    size_t staged = 0, res_off = 0, res_bytes = 0;
+    StagedCall() : w(*lease.w) { w.used = 0; }
+    size_t in(const void *src, size_t bytes)
     {
-        if (tls_dev_scope) { p = tls_dev_scope->alloc(n ? n : 1); return p ? 0 : -1; }
-        owned = true;
-        return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1;
+        const size_t o = w.carve(bytes ? bytes : 1);
+        if (src && bytes) ins.push_back({o, src, bytes});
+        staged = w.used;
+        return o;
+    }
+    void in_at(size_t off, const void *src, size_t bytes) { if (src && bytes) ins.push_back({off, src, bytes}); } // inside an in(nullptr, n) block
+    size_t scratch(size_t bytes) { return w.carve(bytes ? bytes : 1); }
+    size_t out(size_t bytes)
+    {
+        if (!res_bytes) res_off = w.used;
+        const size_t o = w.carve(bytes ? bytes : 1);
+        res_bytes = w.used - res_off;
+        return o;
+    }
+    hipStream_t stream() const { return w.st; }
+    template <typename T> T *d(size_t off) const { return reinterpret_cast<T *>(w.dev + off); }
+    template <typename T> const T *r(size_t off) const { return reinterpret_cast<const T *>(w.pin + (off - res_off)); }
+    int upload() // after the last in / scratch / out
+    {
+        if (w.reserve(w.used, staged > res_bytes ? staged : res_bytes)) return -1;
+        for (const In &i : ins) memcpy(w.pin + i.off, i.src, i.bytes);
+        return staged && hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, w.st) != hipSuccess ? -1 : 0;
+    }
+    int download()
+    {
+        if (res_bytes && hipMemcpyAsync(w.pin, w.dev + res_off, res_bytes, hipMemcpyDeviceToHost, w.st) != hipSuccess) return -1;
+        return hipStreamSynchronize(w.st) == hipSuccess ? 0 : -1;
     }
 };
 

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(MT) void k_bow_transform(const int *__restrict__ ch
                                                       int nid_level, const uint4 *__restrict__ feat, const int *__restrict__ counts,
                                                       int cap, int n_single, int *__restrict__ word_id, int *__restrict__ node_id)
 {
-    const int set = blockIdx.y, i = blockIdx.x * MT + threadIdx.x;
+    // 16 lanes per feature: at every level the children of the current node are scored 16 at a time, one per lane,
+    // and the group minimum of dist << 16 | position picks the first closest child (strict d < best_d, :1246-1254)
+    const int set = blockIdx.y, i = blockIdx.x * (MT / 16) + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     const int n = counts ? min(counts[set], cap) : n_single;
     if (i >= n) return;
     const size_t o = (size_t)set * cap + i;
@@ -285,17 +287,24 @@ __global__ __launch_bounds__(MT) void k_bow_transform(const int *__restrict__ ch
     do {
         const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
         ++level;
-        final_id = child_ids[c0];
-        int best = popc256(a0, a1, node_desc[2 * final_id], node_desc[2 * final_id + 1]);
-        for (int k = c0 + 1; k < c1; ++k) {
-            const int id = child_ids[k];
-            const int d = popc256(a0, a1, node_desc[2 * id], node_desc[2 * id + 1]);
-            if (d < best) { best = d; final_id = id; }
+        unsigned key = 0xffffffffu;
+        for (int kb = c0; kb < c1; kb += 16) {
+            const int k = kb + sub;
+            if (k < c1) {
+                const int id = child_ids[k];
+                const unsigned d = (unsigned)popc256(a0, a1, node_desc[2 * id], node_desc[2 * id + 1]);
+                key = min(key, (d << 16) | (unsigned)(k - c0));
+            }
         }
+#pragma unroll
+        for (int w = 8; w; w >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, w, 16));
+        final_id = child_ids[c0 + (int)(key & 0xffffu)];
         if (level == nid_level) nid = final_id;
     } while (child_off[final_id + 1] > child_off[final_id]);
-    word_id[o] = node_word[final_id];
-    node_id[o] = nid;
+    if (sub == 0) {
+        word_id[o] = node_word[final_id];
+        node_id[o] = nid;
+    }
 }
 
 __global__ __launch_bounds__(MT) void k_hamming_matrix(const uint4 *__restrict__ A, int nA, const uint4 *__restrict__ B,
@@ -347,36 +356,6 @@ int Workspace::reserve_entries(size_t n)
     return 0;
 }
 
-thread_local DevScope *tls_dev_scope = nullptr;
-
-DevScope::DevScope() : prev(tls_dev_scope)
-{
-    Workspace &w = *lease.w;
-    if (w.want > w.dev_cap) (void)w.reserve(w.want, 0);
-    w.used = 0;
-    tls_dev_scope = this;
-}
-
-DevScope::~DevScope()
-{
-    for (void *q : overflow) (void)hipFree(q);
-    Workspace &w = *lease.w;
-    w.want = std::max(w.want, asked);
-    tls_dev_scope = prev;
-}
-
-void *DevScope::alloc(size_t n)
-{
-    Workspace &w = *lease.w;
-    const size_t bytes = (n + 255) & ~(size_t)255;
-    asked += bytes;
-    if (w.dev && w.used + bytes <= w.dev_cap) { void *q = w.dev + w.used; w.used += bytes; return q; }
-    void *q = nullptr;
-    if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
-    overflow.push_back(q);
-    return q;
-}
-
 Workspace *workspace_acquire()
 {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
@@ -416,23 +395,22 @@ int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB, in
     ORBX_NEED_DEVICE();
     if (nA == 0) return ORBX_OK;
     const int cap = nA > nB ? nA : nB;
-    DevScope scope;
-    DevBuf d, c, o;
-    if (d.alloc((size_t)2 * cap * 32) || c.alloc(2 * sizeof(int)) || o.alloc((size_t)3 * cap * sizeof(int)))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const int cnt[2] = {nA, nB};
-    ORBX_HIP(hipMemcpy(d.p, A, (size_t)nA * 32, hipMemcpyHostToDevice));
-    if (nB) ORBX_HIP(hipMemcpy((uint8_t *)d.p + (size_t)cap * 32, B, (size_t)nB * 32, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(c.p, cnt, sizeof(cnt), hipMemcpyHostToDevice));
-    int *ob = (int *)o.p;
-    hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), 1), dim3(64, MSEG), 0, 0, (const uint8_t *)d.p, (const int *)c.p,
-                       cap, (const int *)nullptr, (const int *)nullptr, 0, 0.f, ob, ob + cap, ob + 2 * cap,
+    StagedCall sc;
+    const size_t o_a = sc.in(nullptr, (size_t)2 * cap * 32); // two sets of `cap` rows
+    sc.in_at(o_a, A, (size_t)nA * 32);
+    sc.in_at(o_a + (size_t)cap * 32, B, (size_t)nB * 32);
+    const size_t o_c = sc.in(cnt, sizeof(cnt));
+    const size_t o_o = sc.out(sizeof(int) * 3 * (size_t)cap);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    int *ob = sc.d<int>(o_o);
+    hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), 1), dim3(64, MSEG), 0, sc.stream(), sc.d<const uint8_t>(o_a),
+                       sc.d<const int>(o_c), cap, (const int *)nullptr, (const int *)nullptr, 0, 0.f, ob, ob + cap, ob + 2 * cap,
                        (int *)nullptr, (int *)nullptr);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nA, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(second, ob + cap, sizeof(int) * nA, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(idx, ob + 2 * cap, sizeof(int) * nA, hipMemcpyDeviceToHost));
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    const int *r = sc.r<int>(o_o);
+    memcpy(best, r, sizeof(int) * nA); memcpy(second, r + cap, sizeof(int) * nA); memcpy(idx, r + 2 * cap, sizeof(int) * nA);
     return ORBX_OK;
 }
 
@@ -448,23 +426,17 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB, co
         if (cand_idx[k] < 0 || cand_idx[k] >= nB) ORBX_FAIL(ORBX_ERR_ARG, "candidate index out of range");
     for (int i = 0; i < nA; ++i)
         if (cand_off[i] > cand_off[i + 1] || cand_off[i] < 0) ORBX_FAIL(ORBX_ERR_ARG, "candidate offsets not monotone");
-    DevScope scope;
-    DevBuf da, db, doff, dci, o;
-    if (da.alloc((size_t)nA * 32) || db.alloc((size_t)nB * 32) || doff.alloc(sizeof(int) * (nA + 1)) ||
-        dci.alloc(sizeof(int) * nc) || o.alloc(sizeof(int) * 3 * (size_t)nA))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(da.p, A, (size_t)nA * 32, hipMemcpyHostToDevice));
-    if (nB) ORBX_HIP(hipMemcpy(db.p, B, (size_t)nB * 32, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(doff.p, cand_off, sizeof(int) * (nA + 1), hipMemcpyHostToDevice));
-    if (nc) ORBX_HIP(hipMemcpy(dci.p, cand_idx, sizeof(int) * nc, hipMemcpyHostToDevice));
-    int *ob = (int *)o.p;
-    hipLaunchKernelGGL(k_match_cands, dim3((nA + MT - 1) / MT), dim3(MT), 0, 0, (const uint4 *)da.p, nA,
-                       (const uint4 *)db.p, (const int *)doff.p, (const int *)dci.p, ob, ob + nA, ob + 2 * nA);
+    StagedCall sc;
+    const size_t o_a = sc.in(A, (size_t)nA * 32), o_b = sc.in(B, (size_t)nB * 32), o_off = sc.in(cand_off, sizeof(int) * (nA + 1)),
+                 o_ci = sc.in(cand_idx, sizeof(int) * (size_t)nc), o_o = sc.out(sizeof(int) * 3 * (size_t)nA);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    int *ob = sc.d<int>(o_o);
+    hipLaunchKernelGGL(k_match_cands, dim3((nA + MT - 1) / MT), dim3(MT), 0, sc.stream(), sc.d<const uint4>(o_a), nA,
+                       sc.d<const uint4>(o_b), sc.d<const int>(o_off), sc.d<const int>(o_ci), ob, ob + nA, ob + 2 * nA);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(best, ob, sizeof(int) * nA, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(second, ob + nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(idx, ob + 2 * nA, sizeof(int) * nA, hipMemcpyDeviceToHost));
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    const int *r = sc.r<int>(o_o);
+    memcpy(best, r, sizeof(int) * nA); memcpy(second, r + nA, sizeof(int) * nA); memcpy(idx, r + 2 * nA, sizeof(int) * nA);
     return ORBX_OK;
 }
 
@@ -479,15 +451,13 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m,
         if (off[i] > off[i + 1]) ORBX_FAIL(ORBX_ERR_ARG, "offsets not monotone");
         if (off[i + 1] - off[i] > DD_MAXN) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 128 observations of one map point");
     }
-    DevScope scope;
-    DevBuf dd, doff, o;
-    if (dd.alloc((size_t)32 * total) || doff.alloc(sizeof(int) * (m + 1)) || o.alloc(sizeof(int) * m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    if (total) ORBX_HIP(hipMemcpy(dd.p, desc, (size_t)32 * total, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(doff.p, off, sizeof(int) * (m + 1), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_distinctive, dim3(m), dim3(64), 0, 0, (const uint4 *)dd.p, (const int *)doff.p, (int *)o.p);
+    StagedCall sc;
+    const size_t o_d = sc.in(desc, (size_t)32 * total), o_off = sc.in(off, sizeof(int) * (m + 1)), o_o = sc.out(sizeof(int) * m);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    hipLaunchKernelGGL(k_distinctive, dim3(m), dim3(64), 0, sc.stream(), sc.d<const uint4>(o_d), sc.d<const int>(o_off), sc.d<int>(o_o));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(best, o.p, sizeof(int) * m, hipMemcpyDeviceToHost));
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    memcpy(best, sc.r<int>(o_o), sizeof(int) * m);
     return ORBX_OK;
 }
 
@@ -561,17 +531,16 @@ int orbm_bow_transform(orbm_vocabulary *v, const uint8_t *features, int n, int l
     if (!v || n < 0 || (n && (!features || !word_id || !node_id))) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
     if (n == 0) return ORBX_OK;
-    DevScope scope;
-    DevBuf df, o;
-    if (df.alloc((size_t)32 * n) || o.alloc(sizeof(int) * 2 * (size_t)n)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(df.p, features, (size_t)32 * n, hipMemcpyHostToDevice));
-    int *ob = (int *)o.p;
-    hipLaunchKernelGGL(k_bow_transform, dim3((n + MT - 1) / MT, 1), dim3(MT), 0, 0, v->d_off, v->d_ids, (const uint4 *)v->d_desc,
-                       v->d_word, v->L - levelsup, (const uint4 *)df.p, (const int *)nullptr, n, n, ob, ob + n);
+    StagedCall sc;
+    const size_t o_f = sc.in(features, (size_t)32 * n), o_o = sc.out(sizeof(int) * 2 * (size_t)n);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    int *ob = sc.d<int>(o_o);
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + MT / 16 - 1) / (MT / 16), 1), dim3(MT), 0, sc.stream(), v->d_off, v->d_ids,
+                       (const uint4 *)v->d_desc, v->d_word, v->L - levelsup, sc.d<const uint4>(o_f), (const int *)nullptr, n, n, ob, ob + n);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(word_id, ob, sizeof(int) * n, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(node_id, ob + n, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    memcpy(word_id, sc.r<int>(o_o), sizeof(int) * n);
+    memcpy(node_id, sc.r<int>(o_o) + n, sizeof(int) * n);
     if (weight)
         for (int i = 0; i < n; ++i) weight[i] = word_id[i] >= 0 ? v->weight[word_id[i]] : 0.0;
     if (v->L - levelsup <= 0)
@@ -584,7 +553,7 @@ int orbm_bow_transform_batch_dev(orbm_vocabulary *v, const uint8_t *desc_dev, co
 {
     if (!v || !desc_dev || !counts_dev || cap <= 0 || nsets <= 0 || !word_id_dev || !node_id_dev) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
-    hipLaunchKernelGGL(k_bow_transform, dim3((cap + MT - 1) / MT, nsets), dim3(MT), 0, (hipStream_t)stream, v->d_off, v->d_ids,
+    hipLaunchKernelGGL(k_bow_transform, dim3((cap + MT / 16 - 1) / (MT / 16), nsets), dim3(MT), 0, (hipStream_t)stream, v->d_off, v->d_ids,
                        (const uint4 *)v->d_desc, v->d_word, v->L - levelsup, (const uint4 *)desc_dev, counts_dev, cap, 0,
                        word_id_dev, node_id_dev);
     ORBX_HIP(hipGetLastError());
@@ -611,40 +580,26 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
         if (cand_off[i] > cand_off[i + 1] || cand_off[i] < 0) ORBX_FAIL(ORBX_ERR_ARG, "candidate offsets not monotone");
     for (int j = 0; j < n2; ++j)
         if (kps2[j].octave < 0 || kps2[j].octave >= nlevels) ORBX_FAIL(ORBX_ERR_ARG, "octave out of range");
-    DevScope scope;
-    DevBuf k1, a, k2, b, doff, dci, m1, m2, s1, s2, sc, sg, o;
-    const size_t N2 = n2 ? n2 : 1;
-    if (k1.alloc(sizeof(orbx_keypoint) * n1) || a.alloc((size_t)32 * n1) || k2.alloc(sizeof(orbx_keypoint) * N2) ||
-        b.alloc((size_t)32 * N2) || doff.alloc(sizeof(int) * (n1 + 1)) || dci.alloc(sizeof(int) * nc) || m1.alloc(n1) ||
-        m2.alloc(N2) || s1.alloc(n1) || s2.alloc(N2) || sc.alloc(sizeof(float) * nlevels) || sg.alloc(sizeof(float) * nlevels) ||
-        o.alloc(sizeof(int) * 2 * (size_t)n1))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(k1.p, kps1, sizeof(orbx_keypoint) * n1, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(a.p, desc1, (size_t)32 * n1, hipMemcpyHostToDevice));
-    if (n2) {
-        ORBX_HIP(hipMemcpy(k2.p, kps2, sizeof(orbx_keypoint) * n2, hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(b.p, desc2, (size_t)32 * n2, hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(m2.p, has_mappoint2, n2, hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(s2.p, stereo2, n2, hipMemcpyHostToDevice));
-    }
-    ORBX_HIP(hipMemcpy(doff.p, cand_off, sizeof(int) * (n1 + 1), hipMemcpyHostToDevice));
-    if (nc) ORBX_HIP(hipMemcpy(dci.p, cand_idx, sizeof(int) * nc, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m1.p, has_mappoint1, n1, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(s1.p, stereo1, n1, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(sc.p, scale_factors2, sizeof(float) * nlevels, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(sg.p, level_sigma2, sizeof(float) * nlevels, hipMemcpyHostToDevice));
+    StagedCall sc;
+    const size_t o_k1 = sc.in(kps1, sizeof(orbx_keypoint) * n1), o_a = sc.in(desc1, (size_t)32 * n1),
+                 o_k2 = sc.in(kps2, sizeof(orbx_keypoint) * (size_t)n2), o_b = sc.in(desc2, (size_t)32 * n2),
+                 o_off = sc.in(cand_off, sizeof(int) * (n1 + 1)), o_ci = sc.in(cand_idx, sizeof(int) * (size_t)nc),
+                 o_m1 = sc.in(has_mappoint1, n1), o_m2 = sc.in(has_mappoint2, n2), o_s1 = sc.in(stereo1, n1), o_s2 = sc.in(stereo2, n2),
+                 o_sc = sc.in(scale_factors2, sizeof(float) * nlevels), o_sg = sc.in(level_sigma2, sizeof(float) * nlevels),
+                 o_o = sc.out(sizeof(int) * 2 * (size_t)n1);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
     TriParams tp;
     for (int i = 0; i < 9; ++i) tp.F12[i] = F12[i];
     tp.ex = ex; tp.ey = ey; tp.only_stereo = only_stereo ? 1 : 0;
-    int *ob = (int *)o.p;
-    hipLaunchKernelGGL(k_match_triang, dim3((n1 + MT - 1) / MT), dim3(MT), 0, 0, (const orbx_keypoint *)k1.p, (const uint4 *)a.p,
-                       n1, (const orbx_keypoint *)k2.p, (const uint4 *)b.p, (const int *)doff.p, (const int *)dci.p,
-                       (const uint8_t *)m1.p, (const uint8_t *)m2.p, (const uint8_t *)s1.p, (const uint8_t *)s2.p, tp,
-                       (const float *)sc.p, (const float *)sg.p, ob, ob + n1);
+    int *ob = sc.d<int>(o_o);
+    hipLaunchKernelGGL(k_match_triang, dim3((n1 + MT - 1) / MT), dim3(MT), 0, sc.stream(), sc.d<const orbx_keypoint>(o_k1),
+                       sc.d<const uint4>(o_a), n1, sc.d<const orbx_keypoint>(o_k2), sc.d<const uint4>(o_b), sc.d<const int>(o_off),
+                       sc.d<const int>(o_ci), sc.d<const uint8_t>(o_m1), sc.d<const uint8_t>(o_m2), sc.d<const uint8_t>(o_s1),
+                       sc.d<const uint8_t>(o_s2), tp, sc.d<const float>(o_sc), sc.d<const float>(o_sg), ob, ob + n1);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(match12, ob, sizeof(int) * n1, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(best_dist, ob + n1, sizeof(int) * n1, hipMemcpyDeviceToHost));
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    memcpy(match12, sc.r<int>(o_o), sizeof(int) * n1);
+    memcpy(best_dist, sc.r<int>(o_o) + n1, sizeof(int) * n1);
     return ORBX_OK;
 }
 
@@ -653,17 +608,14 @@ int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint
     if (nA < 0 || nB < 0 || (nA && !A) || (nB && !B) || ((nA && nB) && !out)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
     if (nA == 0 || nB == 0) return ORBX_OK;
-    DevScope scope;
-    DevBuf da, db, o;
-    if (da.alloc((size_t)nA * 32) || db.alloc((size_t)nB * 32) || o.alloc(sizeof(uint16_t) * (size_t)nA * nB))
-        ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(da.p, A, (size_t)nA * 32, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(db.p, B, (size_t)nB * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + MT - 1) / MT, nA), dim3(MT), 0, 0, (const uint4 *)da.p, nA,
-                       (const uint4 *)db.p, nB, (unsigned short *)o.p);
+    StagedCall sc;
+    const size_t o_a = sc.in(A, (size_t)nA * 32), o_b = sc.in(B, (size_t)nB * 32), o_o = sc.out(sizeof(uint16_t) * (size_t)nA * nB);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + MT - 1) / MT, nA), dim3(MT), 0, sc.stream(), sc.d<const uint4>(o_a), nA,
+                       sc.d<const uint4>(o_b), nB, sc.d<unsigned short>(o_o));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(out, o.p, sizeof(uint16_t) * (size_t)nA * nB, hipMemcpyDeviceToHost));
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    memcpy(out, sc.r<uint16_t>(o_o), sizeof(uint16_t) * (size_t)nA * nB);
     return ORBX_OK;
 }
 
