@@ -20,6 +20,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/fem_hip.h"
@@ -452,7 +454,63 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
     if (chunk == 0 && threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
 }
 
-template <typename T> int dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+// FEA2 is a stack object per PoseOptimizationNR call (Optimizer.cc:480): a model is created and destroyed every
+// frame with nearly the same sizes.  Device blocks, pinned blocks and streams are therefore recycled through
+// small process-wide caches (size classes = powers of two, blocks above 64 MiB are not kept), so a steady-state
+// fem_create / fem_destroy pair performs no hipMalloc / hipFree / hipStreamCreate.
+struct BlockCache {
+    std::mutex mu;
+    std::unordered_map<size_t, std::vector<void *>> free_;
+    std::unordered_map<void *, size_t> cls_of;
+    bool pinned;
+    explicit BlockCache(bool pin) : pinned(pin) {}
+    static size_t cls(size_t bytes) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+    void *get(size_t bytes)
+    {
+        const size_t c = cls(bytes ? bytes : 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_.find(c);
+            if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; }
+        }
+        void *p = nullptr;
+        const hipError_t e = pinned ? hipHostMalloc(&p, c, hipHostMallocDefault) : hipMalloc(&p, c);
+        if (e != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        cls_of[p] = c;
+        return p;
+    }
+    void put(void *p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t c = cls_of[p];
+        if (c > ((size_t)64 << 20)) { cls_of.erase(p); if (pinned) (void)hipHostFree(p); else (void)hipFree(p); return; }
+        free_[c].push_back(p);
+    }
+};
+BlockCache g_dev_cache(false), g_pin_cache(true);
+std::mutex g_stream_mu;
+std::vector<hipStream_t> g_stream_free;
+
+hipStream_t stream_get()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        if (!g_stream_free.empty()) { hipStream_t s = g_stream_free.back(); g_stream_free.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
+}
+void stream_put(hipStream_t s)
+{
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_free.push_back(s);
+}
+
+template <typename T> int dalloc(T **p, size_t n) { *p = static_cast<T *>(g_dev_cache.get((n ? n : 1) * sizeof(T))); return *p ? 0 : -1; }
+inline void dfree(void *p) { g_dev_cache.put(p); }
 
 } // namespace
 
@@ -467,6 +525,8 @@ struct fem_model {
     int tr_npoints = 0, tr_nder = 0, tr_nids = 0, tr_seq = 0;
     float tr_klarge = 0.f;
     double *d_tr_points = nullptr;
+    char *h_tr_pin = nullptr; // pinned staging of the LM hook: points in, a / sE / nsE out (pageable copies above a few KB pin on the fly)
+    size_t h_tr_pin_bytes = 0;
     float *d_tr_top = nullptr, *d_tr_u0 = nullptr;
     int *d_tr_derived = nullptr, *d_tr_ids = nullptr;
     int cg_it = 0;
@@ -490,10 +550,12 @@ void fem_free(fem_model *m)
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_cols, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
                     m->d_tr_derived, m->d_tr_ids};
+    if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) dfree(q);
+    g_pin_cache.put(m->h_tr_pin);
     if (m->cg_graph) (void)hipGraphExecDestroy(m->cg_graph);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    stream_put(m->stream);
 }
 
 int ensure_vecs(fem_model *m)
@@ -637,7 +699,7 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_cols, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
     bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, contrib.size());
     bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnz) | dalloc(&m->d_diag, (size_t)m->ndof);
-    if (bad || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (bad || !(m->stream = stream_get())) {
         fem_free(m); delete m;
         ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
     }
@@ -724,7 +786,7 @@ int fem_dirichlet_penalty(fem_model *m, const int32_t *ids, int nids, float klar
     hipLaunchKernelGGL(k_fem_penalty, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->nnzs,
                        m->d_diag, d_ids, nids, klarge);
     ORBX_HIP(hipStreamSynchronize(m->stream));
-    (void)hipFree(d_ids);
+    dfree(d_ids);
     m->cg_ready = false;
     return ORBX_OK;
 }
@@ -743,7 +805,7 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
     hipLaunchKernelGGL(k_fem_eliminate, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals,
                        m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, d_fixed);
     ORBX_HIP(hipStreamSynchronize(m->stream));
-    (void)hipFree(d_fixed);
+    dfree(d_fixed);
     m->cg_ready = false;
     return ORBX_OK;
 }
@@ -782,7 +844,7 @@ int fem_displacement(fem_model *m, const float *uf, const float *u0, const int32
         hipLaunchKernelGGL(k_fem_displacement_dir, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_f,
                            m->ndof, d_ids, nids, klarge);
         ORBX_HIP(hipStreamSynchronize(m->stream));
-        (void)hipFree(d_ids);
+        dfree(d_ids);
     }
     ORBX_HIP(hipStreamSynchronize(m->stream));
     ORBX_HIP(hipMemcpy(a, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
@@ -837,7 +899,7 @@ int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids,
     }
     void *old[] = {m->d_tr_points, m->d_tr_top, m->d_tr_u0, m->d_tr_derived, m->d_tr_ids};
     for (void *q : old)
-        if (q) (void)hipFree(q);
+        if (q) dfree(q);
     m->d_tr_points = nullptr; m->d_tr_top = m->d_tr_u0 = nullptr; m->d_tr_derived = m->d_tr_ids = nullptr;
     if (ensure_vecs(m) || dalloc(&m->d_tr_points, (size_t)m->nmesh * npoints * 3) || dalloc(&m->d_tr_top, (size_t)m->nmesh * nTop * 3) ||
         dalloc(&m->d_tr_u0, (size_t)m->ndof) || dalloc(&m->d_tr_derived, (size_t)4 * nder) || dalloc(&m->d_tr_ids, (size_t)nids))
@@ -846,6 +908,14 @@ int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids,
     if (nder) ORBX_HIP(hipMemcpy(m->d_tr_derived, derived, sizeof(int) * 4 * nder, hipMemcpyHostToDevice));
     if (nids) ORBX_HIP(hipMemcpy(m->d_tr_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
     m->tr_npoints = npoints; m->tr_nder = nder; m->tr_nids = nids; m->tr_seq = seq; m->tr_klarge = klarge;
+    const size_t pin_bytes = sizeof(double) * (size_t)m->nmesh * npoints * 3 + sizeof(float) * (size_t)m->nmesh * (m->ndof + 2);
+    if (pin_bytes > m->h_tr_pin_bytes) {
+        g_pin_cache.put(m->h_tr_pin);
+        m->h_tr_pin_bytes = 0;
+        m->h_tr_pin = static_cast<char *>(g_pin_cache.get(pin_bytes));
+        if (!m->h_tr_pin) ORBX_FAIL(ORBX_ERR_HIP, "pinned allocation failed");
+        m->h_tr_pin_bytes = pin_bytes;
+    }
     m->trial_ready = true;
     return ORBX_OK;
 }
@@ -855,7 +925,11 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
     if (!m || !m->trial_ready || !points) ORBX_FAIL(ORBX_ERR_ARG, "call fem_trial_setup first");
     hipStream_t st = m->stream;
     const int nTop = m->tr_npoints + m->tr_nder;
-    ORBX_HIP(hipMemcpyAsync(m->d_tr_points, points, sizeof(double) * (size_t)m->nmesh * m->tr_npoints * 3, hipMemcpyHostToDevice, st));
+    const size_t pbytes = sizeof(double) * (size_t)m->nmesh * m->tr_npoints * 3, abytes = sizeof(float) * (size_t)m->nmesh * m->ndof;
+    double *h_points = reinterpret_cast<double *>(m->h_tr_pin);
+    float *h_a = reinterpret_cast<float *>(m->h_tr_pin + pbytes), *h_e = h_a + (size_t)m->nmesh * m->ndof;
+    memcpy(h_points, points, pbytes);
+    ORBX_HIP(hipMemcpyAsync(m->d_tr_points, h_points, pbytes, hipMemcpyHostToDevice, st));
     const int gx = m->tr_nder ? 1 : (3 * m->tr_npoints + 255) / 256;
     hipLaunchKernelGGL(k_fem_trial_top, dim3(gx > 0 ? gx : 1, m->nmesh), dim3(256), 0, st, m->d_tr_points, m->tr_npoints,
                        m->d_tr_derived, m->tr_nder, m->tr_seq, m->d_tr_top);
@@ -867,10 +941,12 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
                        m->nnzs, m->ndof, m->d_a, m->d_f);
     hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
     ORBX_HIP(hipGetLastError());
+    if (a_out) ORBX_HIP(hipMemcpyAsync(h_a, m->d_a, abytes, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(h_e, m->d_e, sizeof(float) * 2 * m->nmesh, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));
-    if (a_out) ORBX_HIP(hipMemcpy(a_out, m->d_a, sizeof(float) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost));
-    if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
-    if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nmesh, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
+    if (a_out) memcpy(a_out, h_a, abytes);
+    if (sE) memcpy(sE, h_e, sizeof(float) * m->nmesh);
+    if (nsE) memcpy(nsE, h_e + m->nmesh, sizeof(float) * m->nmesh);
     return ORBX_OK;
 }
 
