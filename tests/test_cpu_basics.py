@@ -204,6 +204,32 @@ def test_sequential_search_oracle_known_answers():
     assert m12.tolist() == [0, -1, -1] and nm == 1
 
 
+def test_sequential_search_oracle_reduces_to_the_uncoupled_search():
+    """Cross-check between two independently written oracle paths: without blocking points and without the
+    rotation check, the whole-loop projection search is the per-query window search + its acceptance test."""
+    from orb_slam2_e_amd.synth import synth_projection_case, synth_bow_case
+    q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(4, n=1200, nq=900, hot=300, stereo=True)
+    mk, mq, nm = oracle.search_projection_seq(q, qd, qa, np.zeros(len(q), np.uint8), kps, desc, bounds, occ, ur, 95, 0.8, True, False)
+    best, bl, second, sl, idx = oracle.search_window(q, qd, kps, desc, bounds, occ, ur, 256)
+    acc = (idx >= 0) & (best <= 95) & ~((bl == sl) & (best.astype(np.float32) > np.float32(0.8) * second.astype(np.float32)))
+    assert np.array_equal(mq, np.where(acc, idx, -1)) and nm == acc.sum() and acc.sum() > 100
+    last = np.full(len(kps), -1, np.int32)
+    for i in np.nonzero(acc)[0]: last[idx[i]] = i            # the last query assigned to a slot stays
+    assert np.array_equal(mk, last)
+    # SearchByBoW with one feature per node on either side = an independent pair test per node
+    rng = np.random.default_rng(2)
+    n = 400
+    d1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d2 = d1 ^ np.packbits(rng.random((n, 256)) < rng.choice([0.02, 0.3], n)[:, None], axis=1, bitorder="little")
+    node = rng.permutation(n) * 3 + 1
+    a = np.zeros(n, np.float32)
+    m12, m21, nm = oracle.search_by_bow(oracle.feature_vector(node), np.ones(n, np.uint8), d1, a, oracle.feature_vector(node), None, d2, a,
+                                        False, 0.6, False)
+    dist = np.array([oracle.descriptor_distance(d1[i], d2[i]) for i in range(n)])
+    ok = (dist <= 45) & (dist.astype(np.float32) < np.float32(0.6) * np.float32(256))
+    assert np.array_equal(m12, np.where(ok, np.arange(n), -1)) and nm == ok.sum() and 50 < ok.sum() < n
+
+
 def test_library_builds_and_exports_every_declared_symbol():
     from orb_slam2_e_amd import _lib
     so = _lib.SO_PATH if os.path.exists(_lib.SO_PATH) else _lib.build()
