@@ -470,7 +470,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     extern __shared__ __align__(16) unsigned char smem[];
     int *p = reinterpret_cast<int *>(smem);
     int *part = p;          p += 8;
-    int *s_cell = p;        p += maxcells + 1;
+    int *s_cell = p;        p += (maxcells + 1 + 3) & ~3;
     int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
     int *by[2] = {p, p + NC};  p += 2 * NC; // y0 | y1<<16
     int *cnt[2] = {p, p + NC}; p += 2 * NC;
@@ -509,19 +509,34 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     uint32_t *kpos_out = kpos_all + (size_t)f * keys_per_frame + lv.key_base; // candidates stay readable for staged tests
     for (int i = tid; i < NC; i += OCT_T) cnt[0][i] = 0;
     __syncthreads();
-    for (int k = tid; k < M; k += OCT_T) {
-        int lo = 0, hiC = lv.ncells; // largest c with s_cell[c] <= k
-        while (hiC - lo > 1) {
-            const int mid = (lo + hiC) >> 1;
-            if (s_cell[mid] <= k) lo = mid; else hiC = mid;
+    for (int k0 = tid; k0 < M; k0 += 4 * OCT_T) { // four candidates per thread in flight: the loads are a dependent chain each
+        uint32_t pk4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * OCT_T;
+            pk4[u] = 0;
+            if (k < M) {
+                int lo = 0, hiC = lv.ncells; // largest c with s_cell[c] <= k
+                while (hiC - lo > 1) {
+                    const int mid = (lo + hiC) >> 1;
+                    if (s_cell[mid] <= k) lo = mid; else hiC = mid;
+                }
+                pk4[u] = cands[(size_t)f * cands_per_frame + cells[lv.cell_base + lo].cand_off + (k - s_cell[lo])];
+            }
         }
-        const uint32_t pk = cands[(size_t)f * cands_per_frame + cells[lv.cell_base + lo].cand_off + (k - s_cell[lo])];
-        kpos[k] = pk;
-        if (in_lds) kpos_out[k] = pk;
-        const float x = (float)((pk >> 8) & 0xfffu);
-        const int root = (int)(x / lv.hX); // vpIniNodes[kp.pt.x/hX], :569
-        knode[k] = (unsigned short)root;
-        atomicAdd(&cnt[0][root], 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * OCT_T;
+            if (k < M) {
+                const uint32_t pk = pk4[u];
+                kpos[k] = pk;
+                if (in_lds) kpos_out[k] = pk;
+                const float x = (float)((pk >> 8) & 0xfffu);
+                const int root = (int)(x / lv.hX); // vpIniNodes[kp.pt.x/hX], :569
+                knode[k] = (unsigned short)root;
+                atomicAdd(&cnt[0][root], 1);
+            }
+        }
     }
     __syncthreads();
     // roots (:552-563), empty ones erased (:574-585)
@@ -597,18 +612,24 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             nns = S - E;
             __syncthreads();
         } else {
-            // largest first, later-created first among equals (:684-732)
+            // largest first, later-created first among equals (:684-732): rank = number of expandable nodes with a
+            // larger (size, creation seq) key.  Keys (size << 11 | seq, 0 for the others) are packed first so that
+            // the S x S comparison reads one LDS dword per four nodes (it was 45 % of the kernel as a scalar loop).
+            int *okey = ebase; // free until the splits are numbered below
+            for (int s = tid; s < ((S + 3) & ~3); s += OCT_T) okey[s] = (s < S && cn[s] > 1) ? (cn[s] << 11) | cs[s] : 0;
+            __syncthreads();
             for (int s = tid; s < S; s += OCT_T) {
-                if (cn[s] > 1) {
+                const int k0 = okey[s];
+                if (k0) {
                     int r = 0;
-                    const int c0 = cn[s], q0 = cs[s];
-                    for (int s2 = 0; s2 < S; ++s2) {
-                        const int c2 = cn[s2];
-                        r += (c2 > 1) && (c2 > c0 || (c2 == c0 && cs[s2] > q0));
+                    for (int s2 = 0; s2 < S; s2 += 4) {
+                        const int4 k4 = *reinterpret_cast<const int4 *>(okey + s2);
+                        r += (k4.x > k0) + (k4.y > k0) + (k4.z > k0) + (k4.w > k0);
                     }
                     order[r] = s;
                 }
             }
+            __syncthreads(); // okey (= ebase) is rewritten below
             if (tid == 0) s_nproc = E;
             __syncthreads();
             for (int r = tid; r < E; r += OCT_T) a2[r] = nne[order[r]] | (eexp[order[r]] << 16);
@@ -1200,7 +1221,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         if (ex->lv[l].N > maxN) maxN = ex->lv[l].N;
         if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
     }
-    ex->NC = maxN + 8;
+    ex->NC = (maxN + 8 + 3) & ~3; // multiple of 4: the node arrays stay 16-byte aligned (int4 reads in k_octree)
     // tile row = 5 spare bytes + the cell + the packed pre-test's right-hand dword; zone <= 63 (6-bit queue
     // coordinates)
     if (maxcw + 12 > 80 || maxch > 69) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than the LDS tile");
@@ -1209,7 +1230,8 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
     ex->oct_kcap = 4096;
-    ex->oct_lds = (int)sizeof(int) * (8 + ex->maxcells + 1 + 21 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
+    if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
+    ex->oct_lds = (int)sizeof(int) * (8 + ((ex->maxcells + 1 + 3) & ~3) + 21 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     const size_t B = (size_t)batch;
