@@ -98,9 +98,10 @@ int orbx_download_batch(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, i
 int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps_dev, const uint8_t **desc_dev,
                     const int32_t **counts_dev, int *capacity);
 
-/* Asynchronous device-to-device export of the last batch's result arrays into
- * caller-owned device buffers (same shapes as orbx_result_dev); any pointer may be
- * NULL.  Used to stage the fixed-size records of the multi-GPU gather. */
+/* Asynchronous export of the last batch's result arrays into caller-owned buffers
+ * (same shapes as orbx_result_dev) -- device memory, or pinned host memory for a
+ * download that overlaps the next batch; any pointer may be NULL.  Used to stage the
+ * fixed-size records of the multi-GPU gather. */
 int orbx_copy_results_dev(orbx_extractor *ex, orbx_keypoint *kps_dst_dev, uint8_t *desc_dst_dev,
                           int32_t *counts_dst_dev, void *stream);
 

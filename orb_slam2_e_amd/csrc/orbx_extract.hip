@@ -1415,9 +1415,9 @@ int orbx_copy_results_dev(orbx_extractor *ex, orbx_keypoint *kps_dst, uint8_t *d
     if (!ex || !ex->d_kps || ex->last_batch <= 0) ORBX_FAIL(ORBX_ERR_ARG, "no results");
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ex->stream;
     const size_t B = (size_t)ex->last_batch;
-    if (kps_dst) ORBX_HIP(hipMemcpyAsync(kps_dst, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B, hipMemcpyDeviceToDevice, st));
-    if (desc_dst) ORBX_HIP(hipMemcpyAsync(desc_dst, ex->d_desc, (size_t)32 * ex->kcap * B, hipMemcpyDeviceToDevice, st));
-    if (counts_dst) ORBX_HIP(hipMemcpyAsync(counts_dst, ex->d_counts, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    if (kps_dst) ORBX_HIP(hipMemcpyAsync(kps_dst, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B, hipMemcpyDefault, st));
+    if (desc_dst) ORBX_HIP(hipMemcpyAsync(desc_dst, ex->d_desc, (size_t)32 * ex->kcap * B, hipMemcpyDefault, st));
+    if (counts_dst) ORBX_HIP(hipMemcpyAsync(counts_dst, ex->d_counts, sizeof(int) * B, hipMemcpyDefault, st));
     return ORBX_OK;
 }
 
