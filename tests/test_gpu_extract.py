@@ -187,3 +187,34 @@ def test_download_batch_equals_per_frame_download():
         assert cnt[f] == len(k1)
         _kp_equal(kps[f, :cnt[f]], k1)
         assert np.array_equal(desc[f, :cnt[f]], d1)
+
+
+def test_random_sizes_parameters_and_contents():
+    """Differential sweep (tools/fuzz_extract.py runs the same loop for hundreds of cases): random image sizes,
+    pyramid depths / scale factors / quotas / thresholds and four kinds of content."""
+    rng = np.random.default_rng(2026)
+    done = 0
+    while done < 40:
+        w = int(rng.integers(220, 900)); h = int(rng.integers(180, 700))
+        nlev = int(rng.integers(3, 9)); sf = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0]))
+        nfeat = int(rng.integers(100, 2500)); ini = int(rng.integers(8, 40)); mn = int(rng.integers(3, ini + 1))
+        kind = rng.integers(0, 4)
+        if kind == 0: img = synth_frame(int(rng.integers(0, 10000)), w, h)
+        elif kind == 1: img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 2: img = (synth_frame(int(rng.integers(0, 10000)), w, h) // 4 + 100).astype(np.uint8)
+        else:
+            img = np.full((h, w), 90, np.uint8)
+            for _ in range(int(rng.integers(1, 60))):
+                x, y = rng.integers(0, w - 20), rng.integers(0, h - 20)
+                img[y:y + rng.integers(3, 20), x:x + rng.integers(3, 20)] = rng.integers(0, 256)
+        params = (nfeat, sf, nlev, ini, mn)
+        try:
+            ex = ORBextractor(*params)
+            kps, desc = ex(img)
+        except Exception as e:                      # sizes the reference cannot run either, or the documented capacity limits
+            assert "error -5" in str(e) or "error -1" in str(e), str(e)
+            continue
+        okps, odesc = oracle.OrbOracle(*params).extract(img)
+        _kp_equal(kps, okps)
+        assert np.array_equal(desc, odesc), (params, w, h, kind)
+        done += 1
