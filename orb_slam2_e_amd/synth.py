@@ -121,7 +121,7 @@ def synth_projection_case(seed, n=2000, nq=3000, hot=400, stereo=False):
     kps["x"] = rng.uniform(-5, 645, n); kps["y"] = rng.uniform(-5, 485, n)
     kps["octave"] = rng.integers(0, 8, n); kps["angle"] = rng.uniform(0, 360, n)
     desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-    desc[rng.choice(n, 200, replace=False)] = desc[1]
+    desc[rng.choice(n, min(200, n // 2), replace=False)] = desc[min(1, n - 1)]
     src = rng.choice(rng.choice(n, hot, replace=False), nq)
     q = np.zeros(nq, ORBmatcher.WQ_DTYPE)
     q["u"] = kps["x"][src] + rng.normal(0, 2, nq); q["v"] = kps["y"][src] + rng.normal(0, 2, nq)
@@ -142,7 +142,8 @@ def synth_projection_case(seed, n=2000, nq=3000, hot=400, stereo=False):
 def synth_bow_case(seed, n1=2000, n2=2100, nnodes=90):
     rng = np.random.default_rng(seed)
     d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
-    d1[rng.choice(n1, 500, replace=False)] = d1[:5][rng.integers(0, 5, 500)]      # look-alikes: the "already matched" skip matters
+    nl = min(500, n1 // 4)
+    d1[rng.choice(n1, nl, replace=False)] = d1[:5][rng.integers(0, 5, nl)]      # look-alikes: the "already matched" skip matters
     node1 = rng.integers(0, nnodes, n1) * 7 + 3
     node1[d1[:, 0] % 5 == 0] = 3                                                   # one crowded node
     src = rng.integers(0, n1, n2)

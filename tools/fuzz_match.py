@@ -1,0 +1,42 @@
+"""Differential fuzz of the whole-loop matcher entry points vs the literal oracle loops."""
+import sys
+import numpy as np
+import oracle
+from orb_slam2_e_amd import ORBmatcher
+from orb_slam2_e_amd.synth import synth_projection_case, synth_bow_case
+from orb_slam2_e_amd.vocabulary import feature_vector_arrays
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n):
+    nk = int(rng.integers(1, 3000)); nq = int(rng.integers(1, 4000)); hot = int(rng.integers(1, nk + 1))
+    stereo = bool(rng.integers(0, 2)); ori = bool(rng.integers(0, 2)); rl = bool(rng.integers(0, 2))
+    th = int(rng.choice([45, 60, 95, 255])); ratio = float(rng.choice([0.6, 0.75, 0.9]))
+    q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(int(rng.integers(0, 1 << 30)), n=nk, nq=nq, hot=hot, stereo=stereo)
+    m = ORBmatcher(ratio, ori)
+    got = m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, th, rl)
+    ref = oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, th, ratio, rl, ori)
+    if not (got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])):
+        bad += 1; print("MISMATCH projection", case, nk, nq, hot, stereo, ori, rl, th, ratio, flush=True)
+    n1 = int(rng.integers(1, 2500)); n2 = int(rng.integers(1, 2500)); nn = int(rng.integers(1, 200))
+    d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(int(rng.integers(0, 1 << 30)), n1=n1, n2=n2, nnodes=nn)
+    kf = bool(rng.integers(0, 2))
+    fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
+    got = m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, kf)
+    ref = oracle.search_by_bow(oracle.feature_vector(node1, keep1), valid1, d1, a1, oracle.feature_vector(node2, keep2),
+                               valid2 if kf else None, d2, a2, kf, ratio, ori)
+    if not (got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])):
+        bad += 1; print("MISMATCH bow", case, n1, n2, nn, kf, ori, ratio, flush=True)
+    # SearchForInitialization on the projection case's keypoints against a jittered copy
+    k2 = kps.copy(); k2["x"] += rng.normal(0, 4, nk).astype(np.float32); k2["y"] += rng.normal(0, 4, nk).astype(np.float32)
+    k1 = kps.copy(); k1["octave"] = np.where(rng.random(nk) < 0.6, 0, k1["octave"]); k2["octave"] = k1["octave"]
+    dd2 = desc ^ np.packbits(rng.random((nk, 256)) < 0.03, axis=1, bitorder="little")
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    w = int(rng.choice([10, 30, 100]))
+    got = m.SearchForInitialization(k1, desc, k2, dd2, prev, bounds, w)
+    ref = oracle.search_for_initialization(k1, desc, k2, dd2, prev, bounds, w, ratio, ori)
+    if not (got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])):
+        bad += 1; print("MISMATCH init", case, nk, w, ori, ratio, flush=True)
+print("cases", n, "mismatches", bad)
+sys.exit(1 if bad else 0)
