@@ -1,7 +1,8 @@
 """Wall time of the per-frame host-array entry points at the sizes one frame produces (B = 1)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from orb_slam2_e_amd import ORBmatcher
 from orb_slam2_e_amd.vocabulary import ORBVocabulary
 from orb_slam2_e_amd.synth import synth_descriptors

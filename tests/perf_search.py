@@ -3,7 +3,7 @@ per-call device allocations are inside) against the CPU oracle on the same input
 import sys, time
 import numpy as np
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import oracle
 from orb_slam2_e_amd import ORBmatcher
 from orb_slam2_e_amd.vocabulary import feature_vector_arrays

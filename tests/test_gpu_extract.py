@@ -190,7 +190,7 @@ def test_download_batch_equals_per_frame_download():
 
 
 def test_random_sizes_parameters_and_contents():
-    """Differential sweep (tools/fuzz_extract.py runs the same loop for hundreds of cases): random image sizes,
+    """Differential sweep (tests/fuzz_extract.py runs the same loop for hundreds of cases): random image sizes,
     pyramid depths / scale factors / quotas / thresholds and four kinds of content."""
     rng = np.random.default_rng(2026)
     done = 0
