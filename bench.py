@@ -161,8 +161,10 @@ def matcher_loops_bench(cpu=True):
     if cpu:
         import oracle
         ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, keep2)
-        out["oracle_search_by_projection_ms"] = ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True), 5)
-        out["oracle_search_by_bow_ms"] = ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True), 5)
+        out["cpu_baseline"] = {
+            "kind": "port", "cores": 1, "unit": "ms per call", "sample": "the same inputs, 5 calls each",
+            "search_by_projection_2000x2000_ms": ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True), 5),
+            "search_by_bow_2000x2100_ms": ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True), 5)}
     return out
 
 
@@ -198,8 +200,8 @@ def stereo_bench(cpu=True):
         t1 = time.perf_counter()
         oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(bf))
         t2 = time.perf_counter()
-        out["oracle_stereo_frame_ms"] = (t2 - t0) * 1e3
-        out["oracle_compute_stereo_matches_ms"] = (t2 - t1) * 1e3
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "ms per pair", "sample": "the same pair, once",
+                               "stereo_frame_ms": (t2 - t0) * 1e3, "compute_stereo_matches_ms": (t2 - t1) * 1e3}
     return out
 
 
