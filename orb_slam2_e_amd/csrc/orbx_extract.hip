@@ -474,17 +474,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
     int *by[2] = {p, p + NC};  p += 2 * NC; // y0 | y1<<16
     int *cnt[2] = {p, p + NC}; p += 2 * NC;
-    int *seq[2] = {p, p + NC}; p += 2 * NC;
+    // narrow per-node fields share dwords (NC is a multiple of 4): 16 NC dwords of node state in all
+    unsigned short *seq[2] = {reinterpret_cast<unsigned short *>(p), reinterpret_cast<unsigned short *>(p) + NC}; p += NC; // < NC
     int *cc = p;            p += 4 * NC;
-    int *nne = p;           p += NC;
-    int *eexp = p;          p += NC;
-    int *order = p;         p += NC;
-    int *split = p;         p += NC;
-    int *bstart = p;        p += NC;
+    uint8_t *nne = reinterpret_cast<uint8_t *>(p), *eexp = nne + NC, *split = nne + 2 * NC; p += NC; // 0..4, 0..4, flag
+    unsigned short *order = reinterpret_cast<unsigned short *>(p), *bstart = order + NC;      p += NC; // node / list positions
     int *ebase = p;         p += NC;
     int *a1 = p;            p += NC;
     int *a2 = p;            p += NC;
-    p += NC; // spare
     uint32_t *l_kpos = reinterpret_cast<uint32_t *>(p);                     p += kcap;
     unsigned short *l_knode = reinterpret_cast<unsigned short *>(p);        p += (kcap + 1) / 2;
     uint8_t *l_kq = reinterpret_cast<uint8_t *>(p);
@@ -557,7 +554,8 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     int cur = 1, mode = 1;
 
     while (true) {
-        int *cx = bx[cur], *cy = by[cur], *cn = cnt[cur], *cs = seq[cur];
+        int *cx = bx[cur], *cy = by[cur], *cn = cnt[cur];
+        unsigned short *cs = seq[cur];
         for (int s = tid; s < S; s += OCT_T) {
             cc[4 * s] = cc[4 * s + 1] = cc[4 * s + 2] = cc[4 * s + 3] = 0;
             split[s] = 0;
@@ -613,20 +611,20 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             __syncthreads();
         } else {
             // largest first, later-created first among equals (:684-732): rank = number of expandable nodes with a
-            // larger (size, creation seq) key.  Keys (size << 11 | seq, 0 for the others) are packed first so that
+            // larger (size, creation seq) key.  Keys (size << 12 | seq, 0 for the others) are packed first so that
             // the S x S comparison reads one LDS dword per four nodes (it was 45 % of the kernel as a scalar loop).
-            int *okey = ebase; // free until the splits are numbered below
-            for (int s = tid; s < ((S + 3) & ~3); s += OCT_T) okey[s] = (s < S && cn[s] > 1) ? (cn[s] << 11) | cs[s] : 0;
+            unsigned *okey = reinterpret_cast<unsigned *>(ebase); // free until the splits are numbered below
+            for (int s = tid; s < ((S + 3) & ~3); s += OCT_T) okey[s] = (s < S && cn[s] > 1) ? ((unsigned)cn[s] << 12) | cs[s] : 0u;
             __syncthreads();
             for (int s = tid; s < S; s += OCT_T) {
-                const int k0 = okey[s];
+                const unsigned k0 = okey[s];
                 if (k0) {
                     int r = 0;
                     for (int s2 = 0; s2 < S; s2 += 4) {
-                        const int4 k4 = *reinterpret_cast<const int4 *>(okey + s2);
+                        const uint4 k4 = *reinterpret_cast<const uint4 *>(okey + s2);
                         r += (k4.x > k0) + (k4.y > k0) + (k4.z > k0) + (k4.w > k0);
                     }
-                    order[r] = s;
+                    order[r] = (unsigned short)s;
                 }
             }
             __syncthreads(); // okey (= ebase) is rewritten below
@@ -654,7 +652,8 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             nns = block_excl_scan(a1, S, part); // a1[s] = rank among the nodes that stay
         }
         const int S2 = F + nns;
-        int *nx = bx[cur ^ 1], *ny = by[cur ^ 1], *nn = cnt[cur ^ 1], *ns = seq[cur ^ 1];
+        int *nx = bx[cur ^ 1], *ny = by[cur ^ 1], *nn = cnt[cur ^ 1];
+        unsigned short *ns = seq[cur ^ 1];
         for (int s = tid; s < S; s += OCT_T) {
             if (split[s]) {
                 const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
@@ -1065,7 +1064,7 @@ int orbx_create(const orbx_params *prm, orbx_extractor **out)
     for (int l = 0; l < nl; l++)
         if (ex->nfeat[l] > OCT_MAXN) {
             delete ex;
-            ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "per-level feature quota above 1023 is not supported");
+            ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "per-level feature quota above 2047 is not supported");
         }
     if (prm->blur_variant == 1) { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 49; ex->taps[3] = 55; }
     else { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 48; ex->taps[3] = 56; }
@@ -1229,9 +1228,9 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
-    ex->oct_kcap = 4096;
+    ex->oct_kcap = ex->NC > 1100 ? 3072 : 4096; // keys of a level live in LDS up to this many, else in HBM
     if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
-    ex->oct_lds = (int)sizeof(int) * (8 + ((ex->maxcells + 1 + 3) & ~3) + 21 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
+    ex->oct_lds = (int)sizeof(int) * (8 + ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     const size_t B = (size_t)batch;

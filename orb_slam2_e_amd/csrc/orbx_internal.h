@@ -16,7 +16,7 @@ constexpr int PADX = 32;  // left pad (bytes) of every pyramid row
 constexpr int MAXL = 16;
 constexpr int MIN_BORDER = EDGE - 3; // minBorderX/Y, ORBextractor.cc:773
 constexpr int OCT_T = 256;           // threads of k_octree
-constexpr int OCT_MAXN = 1023;       // largest per-level feature quota supported
+constexpr int OCT_MAXN = 2047;       // largest per-level feature quota supported (node state of k_octree in LDS)
 
 struct LevelInfo {
     int w, h, stride, off; // inner size, row stride (bytes), offset of the padded block in a frame

@@ -34,7 +34,7 @@ for case in range(n):
         kps, desc = ex(img)
     except Exception as e:
         # geometry the reference cannot run either (cell grid / nIni = 0) must be rejected by both
-        if "error -5" in str(e):      # documented capacity limit (per-level quota above 1023, cell larger than the LDS tile)
+        if "error -5" in str(e):      # documented capacity limit (per-level quota above 2047, cell larger than the LDS tile)
             skipped += 1; continue
         try:
             o.extract(img); print("MISMATCH: gpu rejects, oracle runs", params, w, h, e); bad += 1

@@ -108,6 +108,8 @@ def test_too_small_image_is_an_error():
     ((487, 645), (1500, 1.2, 8, 20, 7)),      # odd sizes: every cell / row start at another byte alignment
     ((251, 333), (700, 1.3, 5, 15, 5)),
     ((376, 1241), (2000, 1.2, 8, 12, 7)),     # KITTI 00-02 size (Examples/Stereo/KITTI00-02.yaml), odd width
+    ((480, 640), (5000, 1.2, 8, 20, 7)),      # level-0 quota 1085: node state beyond 1024 leaves
+    ((600, 800), (3000, 1.5, 3, 15, 5)),      # level-0 quota 1421
 ])
 def test_other_shapes_and_params(shape, params):
     img = synth_frame(3, w=shape[1], h=shape[0])
