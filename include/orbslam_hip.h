@@ -177,6 +177,17 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
                        float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
                        int32_t *second_level, int32_t *idx);
 
+/* Candidate loop of ORBmatcher::Fuse (src/ORBmatcher.cc:1092-1146; Sim3 form :1245-1276): per map point that passed
+ * the caller's projection / distance / viewing-angle tests, the window (u, v, r), levels [min_level, max_level] =
+ * [l-1, l], xr = ur; a keypoint is scored only if its reprojection error passes e2 * inv_level_sigma2[level] <= 7.8
+ * (stereo keypoint, uright[j] >= 0: ex, ey, er) or <= 5.99 (mono: ex, ey) -- inv_level_sigma2 = NULL switches the
+ * gate off (the Sim3 form has none).  best[i] = smallest distance (256 if none), idx[i] = its keypoint (-1).  The map
+ * update that follows in the reference (:1149-1170: Replace / AddObservation, nFused) reads only these two values
+ * and stays on the host, in the reference's order. */
+int orbm_search_fuse(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps, const uint8_t *desc,
+                     int n, const float *uright, const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float max_x,
+                     float max_y, int32_t *best, int32_t *idx);
+
 /* The SearchByProjection family as whole loops: the selection of orbm_search_window plus
  * what the reference does between queries and after them,
  *   SearchByProjection(Frame&, vector<MapPoint*>&, th)          src/ORBmatcher.cc:46-132

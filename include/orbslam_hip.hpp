@@ -223,6 +223,49 @@ public:
         return mStatus == ORBX_OK ? nm : 0;
     }
 
+    // Candidate loop of ORBmatcher::Fuse (ORBmatcher.cc:1092-1146): best keypoint per projected map point under the
+    // reprojection-error gate; invLevelSigma2 == nullptr: no gate (the Sim3 form).  The map update stays with the caller.
+    int FuseCandidates(const FrameView &KF, const std::vector<ProjectedPoint> &points, const float *invLevelSigma2, int nLevels,
+                       std::vector<int32_t> &bestDist, std::vector<int32_t> &bestIdx)
+    {
+        const int nq = (int)points.size();
+        std::vector<orbm_window_query> q(nq);
+        std::vector<uint8_t> qd((size_t)32 * nq);
+        for (int i = 0; i < nq; ++i) { q[i] = points[i].window; std::copy(points[i].descriptor, points[i].descriptor + 32, &qd[(size_t)32 * i]); }
+        bestDist.assign(nq, 256); bestIdx.assign(nq, -1);
+        mStatus = orbm_search_fuse(q.data(), qd.data(), nq, KF.mvKeysUn, KF.mDescriptors, KF.N, KF.mvuRight, invLevelSigma2, nLevels,
+                                   KF.mnMinX, KF.mnMinY, KF.mnMaxX, KF.mnMaxY, bestDist.data(), bestIdx.data());
+        return mStatus;
+    }
+
+    // ORBmatcher::SearchBySim3 (ORBmatcher.cc:1303-1527) over projected points: points12[i1] = map point i1 of KF1 seen
+    // in KF2 (window.r < 0: skipped), points21 the other way; levels [l-1, l], <= TH_HIGH, then the agreement check.
+    int SearchBySim3(const FrameView &KF1, const FrameView &KF2, const std::vector<ProjectedPoint> &points12,
+                     const std::vector<ProjectedPoint> &points21, std::vector<int32_t> &vnMatches12)
+    {
+        auto one_way = [&](const FrameView &dst, const std::vector<ProjectedPoint> &pts, std::vector<int32_t> &m) {
+            const int nq = (int)pts.size();
+            std::vector<orbm_window_query> q(nq);
+            std::vector<uint8_t> qd((size_t)32 * nq);
+            for (int i = 0; i < nq; ++i) { q[i] = pts[i].window; std::copy(pts[i].descriptor, pts[i].descriptor + 32, &qd[(size_t)32 * i]); }
+            std::vector<int32_t> best(nq), bl(nq), second(nq), sl(nq), idx(nq);
+            mStatus = orbm_search_window(q.data(), qd.data(), nq, dst.mvKeysUn, dst.mDescriptors, dst.N, nullptr, nullptr, dst.mnMinX,
+                                         dst.mnMinY, dst.mnMaxX, dst.mnMaxY, INT32_MAX, best.data(), bl.data(), second.data(), sl.data(),
+                                         idx.data());
+            m.assign(nq, -1);
+            for (int i = 0; i < nq && mStatus == ORBX_OK; ++i)
+                if (idx[i] >= 0 && best[i] <= TH_HIGH) m[i] = idx[i];
+        };
+        std::vector<int32_t> m1, m2;
+        one_way(KF2, points12, m1);
+        if (mStatus == ORBX_OK) one_way(KF1, points21, m2);
+        vnMatches12.assign(points12.size(), -1);
+        int nFound = 0;
+        for (size_t i1 = 0; i1 < m1.size() && mStatus == ORBX_OK; ++i1)
+            if (m1[i1] >= 0 && m1[i1] < (int32_t)m2.size() && m2[m1[i1]] == (int32_t)i1) { vnMatches12[i1] = m1[i1]; ++nFound; }
+        return nFound;
+    }
+
     // DBoW2::FeatureVector flattened in std::map order.
     struct FeatureVector {
         std::vector<int32_t> nodes, off, items;

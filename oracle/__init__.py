@@ -474,6 +474,38 @@ def search_by_bow(fv1, valid1, desc1, angle1, fv2, valid2, desc2, angle2, kf_kf=
     return m12, m21, nm
 
 
+def search_fuse(queries, qdesc, kps, desc, bounds, uright=None, inv_level_sigma2=None):
+    """Candidate loop of ORBmatcher::Fuse -> (bestDist, bestIdx); inv_level_sigma2=None: no reprojection gate (Sim3 form)."""
+    L = lib()
+    q = np.ascontiguousarray(queries, WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    xy = np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1), np.float32)
+    octv = np.ascontiguousarray(kps["octave"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    g = Grid(xy, octv, *[float(b) for b in bounds])
+    ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+    sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if inv_level_sigma2 is not None else None
+    best = np.zeros(len(q), np.int32); idx = np.zeros(len(q), np.int32)
+    L.oracle_search_fuse.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_search_fuse(g.h, _p(xy), _p(octv), _p(d), _p(ur) if ur is not None else None, _p(sg) if sg is not None else None,
+                         int(sg is not None), _p(q), _p(qd), len(q), _p(best), _p(idx))
+    return best, idx
+
+
+def search_by_sim3(q12, qdesc1, kps2, desc2, q21, qdesc2, kps1, desc1, bounds, th_high=95):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1303-1527) over projected points: q12[i1] = window of map point i1 of
+    KF1 in KF2 (r < 0 when the point is skipped: no MapPoint, bad, already matched, outside the image / distance
+    range), q21 likewise.  Each direction: levels [l-1, l], best from INT_MAX, accepted at <= TH_HIGH (:1426-1429);
+    then the agreement check (:1509-1524).  Returns (match12 = index in KF2 or -1, nFound)."""
+    b1, _, _, _, i1 = search_window(q12, qdesc1, kps2, desc2, bounds, None, None, 2**31 - 1)
+    b2, _, _, _, i2 = search_window(q21, qdesc2, kps1, desc1, bounds, None, None, 2**31 - 1)
+    m1 = np.where((i1 >= 0) & (b1 <= th_high), i1, -1); m2 = np.where((i2 >= 0) & (b2 <= th_high), i2, -1)
+    out = np.full(len(m1), -1, np.int32)
+    for a in range(len(m1)):
+        if m1[a] >= 0 and m2[m1[a]] == a:
+            out[a] = m1[a]
+    return out, int((out >= 0).sum())
+
+
 CAM_DTYPE = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("min_x", "<i4"), ("max_x", "<i4"),
                       ("min_y", "<i4"), ("max_y", "<i4"), ("gminx", "<f4"), ("gminy", "<f4"), ("gmaxx", "<f4"), ("gmaxy", "<f4")])
 

@@ -469,6 +469,46 @@ int oracle_search_by_bow(int kf_kf, const int *nodes1, const int *off1, const in
     return nmatches;
 }
 
+/* Candidate loop of ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th), ORBmatcher.cc:1092-1146 (the same loop
+ * at :1245-1276 in the Sim3 form, there without the reprojection gate): keypoints of the window whose level is in
+ * [l-1, l]; reprojection error gate e2 * invLevelSigma2[level] > 7.8 (stereo keypoint, mvuRight >= 0: ex, ey, er)
+ * or > 5.99 (mono: ex, ey); best distance from 256, strict '<'.  q = {u, v, radius, ur, l-1, l}.  The map update
+ * that follows (:1149-1170) reads only bestDist / bestIdx, so the points are independent. */
+void oracle_search_fuse(const oracle_grid *g, const float *xy, const int *octave, const uint8_t *desc, const float *uright,
+                        const float *invLevelSigma2, int use_gate, const oracle_wquery *q, const uint8_t *qdesc, int nq,
+                        int *best, int *idx)
+{
+    int *cand = (int *)malloc(sizeof(int) * (g->n + 1));
+    int i, k;
+    for (i = 0; i < nq; i++) {
+        /* KeyFrame::GetFeaturesInArea(u, v, radius) has no level filter; the loop applies it (:1106-1107) */
+        const int nc = oracle_grid_features_in_area(g, xy, octave, q[i].u, q[i].v, q[i].r, -1, -1, cand, g->n + 1);
+        int bestDist = 256, bestIdx = -1;
+        for (k = 0; k < nc; k++) {
+            const int j = cand[k];
+            const int kpLevel = octave[j];
+            int dist;
+            if (kpLevel < q[i].min_level || kpLevel > q[i].max_level) continue;
+            if (use_gate) {
+                const float kpx = xy[2 * j], kpy = xy[2 * j + 1];
+                const float ex = q[i].u - kpx, ey = q[i].v - kpy;
+                if (uright && uright[j] >= 0) {
+                    const float er = q[i].xr - uright[j];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            dist = oracle_descriptor_distance(qdesc + 32 * (size_t)i, desc + 32 * (size_t)j);
+            if (dist < bestDist) { bestDist = dist; bestIdx = j; }
+        }
+        best[i] = bestDist; idx[i] = bestIdx;
+    }
+    free(cand);
+}
+
 /* ---- the fork's whole-map SearchByProjection(Frame&, Map*, Rcw, tcw, ...),
  * ORBmatcher.cc:134-222, with isInFrustum :262-330, ComputeDistance :224-260 and
  * RadiusByViewingCos :332-338, literally (mixed float / double arithmetic kept).

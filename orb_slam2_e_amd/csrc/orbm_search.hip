@@ -296,8 +296,9 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
 __global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
                                                  const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
                                                  const int *__restrict__ cell_off, const int *__restrict__ perm, GridParams gp,
-                                                 int has_uright, int init_dist, int *__restrict__ best_o, int *__restrict__ bl_o,
-                                                 int *__restrict__ second_o, int *__restrict__ sl_o, int *__restrict__ idx_o)
+                                                 int has_uright, int init_dist, const float *__restrict__ inv_sigma2, int fuse_gate,
+                                                 int *__restrict__ best_o, int *__restrict__ bl_o, int *__restrict__ second_o,
+                                                 int *__restrict__ sl_o, int *__restrict__ idx_o)
 {
     const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nq) return;
@@ -323,9 +324,23 @@ __global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q,
                 if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
                 const float distx = p.x - w.u, disty = p.y - w.v;
                 ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
-                if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
+                bool use = ok; // in the visiting order (position) every keypoint of the window counts; `use`: it is scored
+                if (fuse_gate == 0) {
+                    if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
+                    use = ok;
+                } else if (ok && inv_sigma2) { // reprojection-error gate of ORBmatcher::Fuse (:1109-1132)
+                    const float ex = w.u - p.x, ey = w.v - p.y;
+                    if (has_uright && p.uright >= 0) {
+                        const float er = w.xr - p.uright;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        use = !((double)(e2 * inv_sigma2[p.octave]) > 7.8);
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        use = !((double)(e2 * inv_sigma2[p.octave]) > 5.99);
+                    }
+                }
                 const unsigned long long bal = __ballot(ok);
-                if (ok) {
+                if (use) {
                     const int dist = popc256(a0, a1, B[2 * k], B[2 * k + 1]);
                     if (dist < init_dist) { // dist<bestDist / dist<bestDist2 can only fire below the initial value
                         const unsigned key = ((unsigned)dist << 16) | (unsigned)(c + __popcll(bal & lt));
@@ -665,7 +680,7 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
     int *ob = w.d<int>(o_res);
     hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, w.st, (const WinQuery *)w.d<WinQuery>(o_q),
                        (const uint4 *)w.d<uint4>(o_a), nq, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
-                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, uright ? 1 : 0, init_dist, ob, ob + nq,
+                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, uright ? 1 : 0, init_dist, (const float *)nullptr, 0, ob, ob + nq,
                        ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(w.pin, ob, sizeof(int) * 5 * (size_t)nq, hipMemcpyDeviceToHost, w.st));
@@ -734,7 +749,7 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
                        w.d<WinQuery>(o_q), w.d<float>(o_proj));
     hipLaunchKernelGGL(k_win_best, dim3((m + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, st, (const WinQuery *)w.d<WinQuery>(o_q),
                        (const uint4 *)w.d<uint4>(o_md), m, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
-                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, 0, INT_MAX, ob, ob + m, ob + 2 * m,
+                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, 0, INT_MAX, (const float *)nullptr, 0, ob, ob + m, ob + 2 * m,
                        ob + 3 * m, ob + 4 * m);
     hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, st, (const int *)ob, (const int *)(ob + 4 * m), (const int *)(ob + 2 * m),
                        (const int *)(ob + m), (const int *)(ob + 3 * m), m, th_reloc, nnratio, w.d<int>(o_mk), w.d<int>(o_nm));
@@ -744,6 +759,40 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
     memcpy(matched_mp, w.pin + (o_mk - o_res), sizeof(int) * n);
     if (nmatches) memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
     if (proj) memcpy(proj, w.pin + (o_proj - o_res), sizeof(float) * 4 * m);
+    return ORBX_OK;
+}
+
+int orbm_search_fuse(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps, const uint8_t *desc,
+                     int n, const float *uright, const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float max_x,
+                     float max_y, int32_t *best, int32_t *idx)
+{
+    if (nq < 0 || n < 0 || n > 65535 || (nq && (!queries || !qdesc || !best || !idx)) || (n && (!kps || !desc)) ||
+        (inv_level_sigma2 && (nlevels < 1 || nlevels > 64)) || !(max_x > min_x) || !(max_y > min_y))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    for (int j = 0; j < n && inv_level_sigma2; ++j)
+        if (kps[j].octave < 0 || kps[j].octave >= nlevels) ORBX_FAIL(ORBX_ERR_ARG, "octave out of range");
+    ORBX_NEED_DEVICE();
+    if (nq == 0) return ORBX_OK;
+    SortedFrame sf;
+    sort_frame(kps, desc, n, nullptr, uright, min_x, min_y, max_x, max_y, sf);
+    if (!uright) for (SeqKp &k : sf.kp) k.uright = -1.0f;
+    const int ns = (int)sf.perm.size();
+    StagedCall sc;
+    const size_t o_q = sc.in(queries, sizeof(WinQuery) * nq), o_a = sc.in(qdesc, (size_t)32 * nq),
+                 o_k = sc.in(sf.kp.data(), sizeof(SeqKp) * ns), o_b = sc.in(sf.desc.data(), (size_t)32 * ns),
+                 o_perm = sc.in(sf.perm.data(), sizeof(int) * ns), o_cell = sc.in(sf.cell_off.data(), sizeof(int) * sf.cell_off.size()),
+                 o_sg = sc.in(inv_level_sigma2, sizeof(float) * (inv_level_sigma2 ? nlevels : 0)), o_o = sc.out(sizeof(int) * 5 * (size_t)nq);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    int *ob = sc.d<int>(o_o);
+    hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, sc.stream(), sc.d<const WinQuery>(o_q),
+                       sc.d<const uint4>(o_a), nq, sc.d<const SeqKp>(o_k), sc.d<const uint4>(o_b), sc.d<const int>(o_cell),
+                       sc.d<const int>(o_perm), sf.gp, uright ? 1 : 0, 256, inv_level_sigma2 ? sc.d<const float>(o_sg) : (const float *)nullptr,
+                       1, ob, ob + nq, ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
+    ORBX_HIP(hipGetLastError());
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    const int *r = sc.r<int>(o_o);
+    memcpy(best, r, sizeof(int) * nq);
+    memcpy(idx, r + 4 * nq, sizeof(int) * nq);
     return ORBX_OK;
 }
 

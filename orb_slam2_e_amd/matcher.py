@@ -136,6 +136,33 @@ class ORBmatcher:
                                              _p(mk), _p(mq), C.byref(nm)))
         return mk, mq, nm.value
 
+    def search_fuse(self, queries, qdesc, kps, desc, bounds, uright=None, inv_level_sigma2=None):
+        """Candidate loop of ORBmatcher::Fuse (ORBmatcher.cc:1092-1146) -> (bestDist, bestIdx) per projected point."""
+        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+        kps = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+        ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+        sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if inv_level_sigma2 is not None else None
+        best = np.zeros(len(q), np.int32); idx = np.zeros(len(q), np.int32)
+        self._L.orbm_search_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_search_fuse(_p(q), _p(qd), len(q), _p(kps), _p(d), len(kps), _p(ur) if ur is not None else None,
+                                       _p(sg) if sg is not None else None, len(sg) if sg is not None else 0,
+                                       *[float(b) for b in bounds], _p(best), _p(idx)))
+        return best, idx
+
+    def SearchBySim3(self, q12, qdesc1, kps2, desc2, q21, qdesc2, kps1, desc1, bounds):
+        """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1303-1527) over projected points (r < 0 = skipped point): two
+        independent window searches (levels [l-1, l], <= TH_HIGH) and the agreement check (:1509-1524).
+        Returns (match12, nFound)."""
+        b1, _, _, _, i1 = self.search_window(q12, qdesc1, kps2, desc2, bounds, None, None, 2**31 - 1)
+        b2, _, _, _, i2 = self.search_window(q21, qdesc2, kps1, desc1, bounds, None, None, 2**31 - 1)
+        m1 = np.where((i1 >= 0) & (b1 <= self.TH_HIGH), i1, -1); m2 = np.where((i2 >= 0) & (b2 <= self.TH_HIGH), i2, -1)
+        ok = m1 >= 0
+        agree = np.zeros(len(m1), bool)
+        agree[ok] = m2[m1[ok]] == np.nonzero(ok)[0]
+        out = np.where(agree, m1, -1).astype(np.int32)
+        return out, int(agree.sum())
+
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, vbPrevMatched, bounds, windowSize=10):
         """ORBmatcher::SearchForInitialization (ORBmatcher.cc:606-721).  kps = mvKeysUn of F1 / F2, bounds = F2's
         grid bounds.  Returns (vnMatches12, updated vbPrevMatched, nmatches)."""

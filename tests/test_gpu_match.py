@@ -306,3 +306,47 @@ def test_matcher_calls_are_reentrant_across_threads():
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("seed,stereo,gate", [(0, False, True), (1, True, True), (2, True, False)])
+def test_fuse_candidate_loop(seed, stereo, gate):
+    """orbm_search_fuse vs the literal candidate loop of ORBmatcher::Fuse (reprojection gate 5.99 / 7.8)."""
+    q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(seed, n=2500, nq=2500, hot=2500, stereo=stereo)
+    q["r"] = 3.0 * 1.2 ** (q["max_level"].clip(0, 7))             # th * scale[level]: a few px, as Fuse uses it
+    q["min_level"] = q["max_level"] - 1
+    if ur is not None:
+        ur = np.where(ur < 0, -1.0, ur).astype(np.float32)
+        q["xr"] = np.where(ur[np.arange(len(q)) % len(kps)] >= 0, q["u"] - (kps["x"] - ur)[np.arange(len(q)) % len(kps)], q["xr"])
+    sg = (1.0 / (1.2 ** np.arange(8)) ** 2).astype(np.float32) if gate else None
+    got = ORBmatcher().search_fuse(q, qd, kps, desc, bounds, ur, sg)
+    ref = oracle.search_fuse(q, qd, kps, desc, bounds, ur, sg)
+    assert (ref[1] >= 0).sum() > 300
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    if gate:  # the gate removes candidates the plain window search would take
+        free = oracle.search_fuse(q, qd, kps, desc, bounds, ur, None)
+        assert not np.array_equal(free[1], ref[1])
+
+
+def test_search_by_sim3_agreement():
+    """SearchBySim3 = two window searches + the mutual-agreement check, against the oracle composition."""
+    from orb_slam2_e_amd import KP_DTYPE
+    rng = np.random.default_rng(4)
+    n = 1800
+    k1 = np.zeros(n, KP_DTYPE); k1["x"] = rng.uniform(10, 630, n); k1["y"] = rng.uniform(10, 470, n); k1["octave"] = rng.integers(0, 8, n)
+    perm = rng.permutation(n)
+    k2 = k1[perm].copy(); k2["x"] += rng.normal(0, 2, n); k2["y"] += rng.normal(0, 2, n)
+    d1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d1[rng.choice(n, 300, replace=False)] = d1[0]                   # look-alikes break the agreement for some
+    d2 = d1[perm] ^ np.packbits(rng.random((n, 256)) < 0.04, axis=1, bitorder="little")
+    inv = np.argsort(perm)
+    def queries(src_k, dst_k, dst_of_src):
+        q = np.zeros(n, ORBmatcher.WQ_DTYPE)
+        q["u"] = dst_k["x"][dst_of_src] + rng.normal(0, 1.5, n); q["v"] = dst_k["y"][dst_of_src] + rng.normal(0, 1.5, n)
+        q["r"] = np.where(rng.random(n) < 0.1, -1.0, 7.5 * 1.2 ** src_k["octave"])   # 10 % skipped points
+        q["max_level"] = src_k["octave"] + rng.integers(0, 2, n); q["min_level"] = q["max_level"] - 1
+        return q
+    q12 = queries(k1, k2, inv); q21 = queries(k2, k1, perm)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    got = ORBmatcher().SearchBySim3(q12, d1, k2, d2, q21, d2, k1, d1, bounds)
+    ref = oracle.search_by_sim3(q12, d1, k2, d2, q21, d2, k1, d1, bounds)
+    assert ref[1] > 500 and got[1] == ref[1] and np.array_equal(got[0], ref[0])
