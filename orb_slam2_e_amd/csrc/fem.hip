@@ -11,9 +11,9 @@
 //                   block-diagonal batch (the slot of the dead dense inverse, :1661-1691)
 //
 // HBM layout for a batch of M meshes with n dofs and nnz non-zeros each:
-// vals[M][nnz] f32, cols[M][nnz] i32 (global column = mesh*n + local), one shared
-// rowptr[n+1]; CG vectors x, r, p, Ap [M][n] f64.  SpMV streams vals+cols once per
-// iteration (HBM-bound); reductions are fixed-order (chunk partials
+// vals[M][nnz] f32 per mesh; ONE column-index array lcol[nnz] i32 and ONE rowptr[n+1] for the
+// whole batch (shared topology: they stay in L2); CG vectors x, r, p, Ap [M][n] f64.  SpMV streams
+// the values from HBM once per iteration; reductions are fixed-order (chunk partials
 // summed in index order), so results are run-to-run reproducible.
 #include <math.h>
 #include <stdint.h>
@@ -157,9 +157,7 @@ __global__ __launch_bounds__(64) void k_fem_ke(const float *__restrict__ nodes, 
 __global__ __launch_bounds__(256) void k_fem_assemble(const float *__restrict__ ke_all, int ne, int nd, int nblk,
                                                       const int *__restrict__ blk_row, const int *__restrict__ bptr,
                                                       const int *__restrict__ cptr, const int *__restrict__ contrib,
-                                                      const int *__restrict__ rowptr, float *__restrict__ vals,
-                                                      int *__restrict__ cols, const int *__restrict__ lcol,
-                                                      size_t nnz, int ndof)
+                                                      const int *__restrict__ rowptr, float *__restrict__ vals, size_t nnz)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, mesh = blockIdx.y;
     if (t >= nblk * 9) return;
@@ -174,7 +172,6 @@ __global__ __launch_bounds__(256) void k_fem_assemble(const float *__restrict__ 
     }
     const int k = rowptr[3 * I + m] + 3 * (b - bptr[I]) + n;
     vals[(size_t)mesh * nnz + k] = v;
-    cols[(size_t)mesh * nnz + k] = mesh * ndof + lcol[k];
 }
 
 __global__ void k_fem_penalty(float *__restrict__ vals, size_t nnz, const int *__restrict__ diag_idx,
@@ -347,7 +344,7 @@ __global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, co
 // 32 when the whole launch would otherwise be under ~2 workgroups per CU (one small mesh).
 constexpr int SPU4 = 3;  // independent 16-byte (val, col) load pairs in flight per lane
 template <int SPB>
-__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ cols,
+__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ lcol,
                                                   const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
                                                   double *__restrict__ part_pAp)
@@ -358,7 +355,8 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
     const int r0 = chunk * SPB, r1 = min(r0 + SPB, ndof);
     const int k0 = rowptr[r0], k1 = rowptr[r1];
     const float *v = vals + (size_t)mesh * nnz;
-    const int *cidx = cols + (size_t)mesh * nnz;
+    const int *cidx = lcol; // one column-index array for all meshes (shared topology): it stays in L2, HBM streams the values only
+    const double *pm = p + (size_t)mesh * ndof;
     // aligned 16-byte streams: start at k0 rounded down to a multiple of 4 (the per-mesh
     // stride is a multiple of 4), elements outside [k0, k1) are dropped at the LDS write
     const int ka = k0 & ~3;
@@ -377,7 +375,7 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
             const int cc[4] = {ca[u].x, ca[u].y, ca[u].z, ca[u].w};
             double pa[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pa[e] = (kk + e >= k0 && kk + e < k1) ? p[cc[e]] : 0.0;
+            for (int e = 0; e < 4; ++e) pa[e] = (kk + e >= k0 && kk + e < k1) ? pm[cc[e]] : 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (kk + e >= k0 && kk + e < k1) prod[kk + e - k0] = (double)vv[e] * pa[e];
@@ -533,7 +531,7 @@ struct fem_model {
     // device
     float *d_nodes = nullptr, *d_ke = nullptr, *d_vals = nullptr, *d_a = nullptr, *d_f = nullptr, *d_u = nullptr, *d_e = nullptr;
     int *d_elems = nullptr, *d_blk_row = nullptr, *d_bptr = nullptr, *d_cptr = nullptr, *d_contrib = nullptr;
-    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_cols = nullptr, *d_diag = nullptr;
+    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr;
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -547,7 +545,7 @@ namespace {
 void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_nodes, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_elems, m->d_blk_row, m->d_bptr,
-                    m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_cols, m->d_diag, m->d_b, m->d_x, m->d_r,
+                    m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
                     m->d_tr_derived, m->d_tr_ids};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
@@ -583,7 +581,7 @@ void launch_iter(fem_model *m, hipStream_t st)
     const int cur = m->cg_it & 1;
     m->prof.start(2, st);
     hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st,
-                       m->d_vals, m->d_cols, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
+                       m->d_vals, m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
     m->prof.stop(2, st);
     m->prof.start(3, st);
     hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
@@ -690,15 +688,15 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
         const int r1 = r0 + SPB < m->ndof ? r0 + SPB : m->ndof;
         maxrun = std::max(maxrun, m->h_rowptr[r1] - m->h_rowptr[r0]);
     }
+    if (maxrun * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
     m->spmv_lds = maxrun * (int)sizeof(double);
-    if (m->spmv_lds > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
 
     const size_t M = (size_t)nmesh;
     int bad = 0;
     bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke, M * ne * m->nd * m->nd);
-    bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_cols, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
+    bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
     bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, contrib.size());
-    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnz) | dalloc(&m->d_diag, (size_t)m->ndof);
+    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof);
     if (bad || !(m->stream = stream_get())) {
         fem_free(m); delete m;
         ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
@@ -764,8 +762,7 @@ int fem_assemble(fem_model *m)
     m->prof.stop(0, st);
     m->prof.start(1, st);
     hipLaunchKernelGGL(k_fem_assemble, dim3((m->nblk * 9 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_ke, m->ne, m->nd,
-                       m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->d_cols,
-                       m->d_lcol, m->nnzs, m->ndof);
+                       m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->nnzs);
     m->prof.stop(1, st);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(st));
@@ -1005,7 +1002,7 @@ int fem_spmv_repeat(fem_model *m, int n, void *stream)
     for (int i = 0; i < n; ++i) {
         m->prof.start(2, st);
         hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st,
-                           m->d_vals, m->d_cols, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
+                           m->d_vals, m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
         m->prof.stop(2, st);
     }
     ORBX_HIP(hipGetLastError());
