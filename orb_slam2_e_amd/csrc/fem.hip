@@ -343,6 +343,14 @@ __global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, co
 // SPB = rows per workgroup: 64 for batches (fewest row-pointer reads per byte streamed),
 // 32 when the whole launch would otherwise be under ~2 workgroups per CU (one small mesh).
 constexpr int SPU4 = 3;  // independent 16-byte (val, col) load pairs in flight per lane
+template <int N> __device__ __forceinline__ double dpp_shl_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x100 + N, 0xf, 0xf, true);         // row_shl:N, 0 beyond the row
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x100 + N, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 template <int SPB>
 __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ lcol,
                                                   const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
@@ -357,28 +365,26 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
     const float *v = vals + (size_t)mesh * nnz;
     const int *cidx = lcol; // one column-index array for all meshes (shared topology): it stays in L2, HBM streams the values only
     const double *pm = p + (size_t)mesh * ndof;
-    // aligned 16-byte streams: start at k0 rounded down to a multiple of 4 (the per-mesh
-    // stride is a multiple of 4), elements outside [k0, k1) are dropped at the LDS write
-    const int ka = k0 & ~3;
+    // aligned 16-byte streams: start at ka = k0 rounded down to a multiple of 4 (the per-mesh stride is a multiple of
+    // 4).  No per-element predicate: every quad is loaded, gathered, multiplied and parked at prod[k - ka]; the up to 3
+    // entries before k0 and after k1 are neighbours' non-zeros (valid columns; the padding tail of lcol is zeroed) whose
+    // products phase 2 never reads; lanes beyond the end repeat the last quad (same values to the same slots).
+    const int ka = k0 & ~3, klast = (k1 - 1) & ~3;
     for (int k = ka + 4 * tid; k < k1; k += SPU4 * 4 * CGT) {
         float4 va[SPU4]; int4 ca[SPU4];
+        int kk[SPU4];
 #pragma unroll
         for (int u = 0; u < SPU4; ++u) { // clamped index: unconditional loads, all in flight together
-            const int kk = min(k + u * 4 * CGT, (k1 - 1) & ~3);
-            va[u] = *reinterpret_cast<const float4 *>(v + kk);
-            ca[u] = *reinterpret_cast<const int4 *>(cidx + kk);
+            kk[u] = min(k + u * 4 * CGT, klast);
+            va[u] = *reinterpret_cast<const float4 *>(v + kk[u]);
+            ca[u] = *reinterpret_cast<const int4 *>(cidx + kk[u]);
         }
 #pragma unroll
         for (int u = 0; u < SPU4; ++u) {
-            const int kk = k + u * 4 * CGT;
-            const float vv[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
-            const int cc[4] = {ca[u].x, ca[u].y, ca[u].z, ca[u].w};
-            double pa[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pa[e] = (kk + e >= k0 && kk + e < k1) ? pm[cc[e]] : 0.0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (kk + e >= k0 && kk + e < k1) prod[kk + e - k0] = (double)vv[e] * pa[e];
+            const double p0 = pm[ca[u].x], p1 = pm[ca[u].y], p2 = pm[ca[u].z], p3 = pm[ca[u].w];
+            double2 *dst = reinterpret_cast<double2 *>(prod + (kk[u] - ka));
+            dst[0] = make_double2((double)va[u].x * p0, (double)va[u].y * p1);
+            dst[1] = make_double2((double)va[u].z * p2, (double)va[u].w * p3);
         }
     }
     __syncthreads();
@@ -389,12 +395,13 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
         const int row = r0 + pass * (CGT / LPR) + sub;
         double s = 0;
         if (row < r1) {
-            const int e = rowptr[row + 1] - k0;
-            for (int k = rowptr[row] - k0 + sl; k < e; k += LPR) s += prod[k];
+            const int e = rowptr[row + 1] - ka;
+            for (int k = rowptr[row] - ka + sl; k < e; k += LPR) s += prod[k];
         }
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 1);
+        // sum of the 8 lanes of a row into its lane 0: DPP row_shl (lane i reads lane i+n of its 16-lane row), fixed order
+        s += dpp_shl_f64<4>(s);
+        s += dpp_shl_f64<2>(s);
+        s += dpp_shl_f64<1>(s);
         if (row < r1 && sl == 0) {
             const size_t g = (size_t)mesh * ndof + row;
             Ap[g] = s;
@@ -689,7 +696,7 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
         maxrun = std::max(maxrun, m->h_rowptr[r1] - m->h_rowptr[r0]);
     }
     if (maxrun * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
-    m->spmv_lds = maxrun * (int)sizeof(double);
+    m->spmv_lds = (maxrun + 8) * (int)sizeof(double); // + the quads' slack either side of a row block
 
     const size_t M = (size_t)nmesh;
     int bad = 0;
@@ -708,6 +715,7 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     ORBX_HIP(hipMemcpy(m->d_cptr, cptr.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice));
     if (!contrib.empty()) ORBX_HIP(hipMemcpy(m->d_contrib, contrib.data(), sizeof(int) * contrib.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
     ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
