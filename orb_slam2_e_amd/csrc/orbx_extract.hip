@@ -59,8 +59,13 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
     const int f = blockIdx.z, px0 = xw * 4 - PADX;
     const bool inner = aligned && px0 >= 0 && px0 + 4 <= lv.w;
     int sx[4];
+    uint32_t keep = 0; // bytes inside [-EDGE, w+EDGE); the others (row padding) read a clamped column and are masked to 0
 #pragma unroll
-    for (int b = 0; b < 4; ++b) sx[b] = (px0 + b >= -EDGE && px0 + b < lv.w + EDGE) ? reflect101(px0 + b, lv.w) : -1;
+    for (int b = 0; b < 4; ++b) {
+        const int px = px0 + b;
+        sx[b] = reflect101(min(max(px, -EDGE), lv.w + EDGE - 1), lv.w);
+        keep |= (px >= -EDGE && px < lv.w + EDGE) ? 0xffu << (8 * b) : 0u;
+    }
     uint32_t out[PYR_ROWS];
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
@@ -72,8 +77,8 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
                 out[r] = *reinterpret_cast<const uint32_t *>(src + px0);
             } else {
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (sx[b] >= 0) out[r] |= (uint32_t)src[sx[b]] << (8 * b);
+                for (int b = 0; b < 4; ++b) out[r] |= (uint32_t)src[sx[b]] << (8 * b);
+                out[r] &= keep;
             }
         }
     }
@@ -95,14 +100,17 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     const int xw = blockIdx.x * 64 + threadIdx.x;
     if (xw * 4 >= dst.stride) return;
     const int f = blockIdx.z, px0 = xw * 4 - PADX;
+    // no per-pixel branches: pixels outside [-EDGE, w+EDGE) (row padding) take the column of a clamped coordinate and
+    // are masked out of the stored dword
     int sxs[4], a0[4], a1[4];
+    uint32_t keep = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        sxs[b] = -1; a0[b] = a1[b] = 0;
-        if (px0 + b >= -EDGE && px0 + b < dst.w + EDGE) {
-            const int2 xx = xt[reflect101(px0 + b, dst.w)];
-            sxs[b] = xx.x; a0[b] = xx.y & 0xffff; a1[b] = xx.y >> 16;
-        }
+        const int px = px0 + b;
+        const bool in = px >= -EDGE && px < dst.w + EDGE;
+        const int2 xx = xt[reflect101(min(max(px, -EDGE), dst.w + EDGE - 1), dst.w)];
+        sxs[b] = xx.x; a0[b] = xx.y & 0xffff; a1[b] = xx.y >> 16;
+        keep |= in ? 0xffu << (8 * b) : 0u;
     }
     int4 yy[PYR_ROWS];
 #pragma unroll
@@ -119,15 +127,14 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
         out[r] = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (sxs[b] >= 0) {
-                // every factor is below 2^24 and every product below 2^31: 24-bit multiplies are exact here
-                const int r0 = __mul24(S0[sxs[b]], a0[b]) + __mul24(S0[sxs[b] + 1], a1[b]);
-                const int r1 = __mul24(S1[sxs[b]], a0[b]) + __mul24(S1[sxs[b] + 1], a1[b]);
-                uint32_t v = (uint32_t)((((__mul24(yy[r].z, r0 >> 4)) >> 16) + ((__mul24(yy[r].w, r1 >> 4)) >> 16) + 2) >> 2);
-                v = v > 255u ? 255u : v;
-                out[r] |= v << (8 * b);
-            }
+            // every factor is below 2^24 and every product below 2^31: 24-bit multiplies are exact here
+            const int r0 = __mul24(S0[sxs[b]], a0[b]) + __mul24(S0[sxs[b] + 1], a1[b]);
+            const int r1 = __mul24(S1[sxs[b]], a0[b]) + __mul24(S1[sxs[b] + 1], a1[b]);
+            uint32_t v = (uint32_t)((((__mul24(yy[r].z, r0 >> 4)) >> 16) + ((__mul24(yy[r].w, r1 >> 4)) >> 16) + 2) >> 2);
+            v = v > 255u ? 255u : v;
+            out[r] |= v << (8 * b);
         }
+        out[r] &= keep;
     }
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
