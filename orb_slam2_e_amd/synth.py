@@ -143,7 +143,7 @@ def synth_bow_case(seed, n1=2000, n2=2100, nnodes=90):
     rng = np.random.default_rng(seed)
     d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
     nl = min(500, n1 // 4)
-    d1[rng.choice(n1, nl, replace=False)] = d1[:5][rng.integers(0, 5, nl)]      # look-alikes: the "already matched" skip matters
+    d1[rng.choice(n1, nl, replace=False)] = d1[:min(5, n1)][rng.integers(0, 5, nl) % min(5, n1)]      # look-alikes: the "already matched" skip matters
     node1 = rng.integers(0, nnodes, n1) * 7 + 3
     node1[d1[:, 0] % 5 == 0] = 3                                                   # one crowded node
     src = rng.integers(0, n1, n2)
