@@ -1,0 +1,58 @@
+"""Differential fuzz of the FEM assembly / K*a path (random surface meshes, C3D6 / C3D8 / tet4, random material)
+and of ComputeStereoMatches (random pair sizes) against the oracle."""
+import sys
+import numpy as np
+import oracle
+from orb_slam2_e_amd import ComputeStereoMatches, ORBextractor
+from orb_slam2_e_amd.fem import FEA2, FEM_C3D6, FEM_C3D8, FEM_TET4, second_layer, extrude_elems
+from orb_slam2_e_amd.synth import synth_stereo_pair
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n):
+    kind = int(rng.integers(0, 3))
+    g = int(rng.integers(3, 12))
+    X, Y = np.meshgrid(np.arange(g, dtype=np.float32), np.arange(g, dtype=np.float32), indexing="ij")
+    top = np.stack([X.ravel() + rng.normal(0, 0.15, g * g), Y.ravel() + rng.normal(0, 0.15, g * g), rng.normal(0, 0.3, g * g)], 1).astype(np.float32)
+    nid = lambda i, j: i * g + j
+    E = int(rng.integers(100, 100000)); nu = float(rng.uniform(0.05, 0.499))
+    if kind == 0:
+        faces = np.array([[nid(i, j), nid(i + 1, j), nid(i + 1, j + 1)] for i in range(g - 1) for j in range(g - 1)] +
+                         [[nid(i, j), nid(i + 1, j + 1), nid(i, j + 1)] for i in range(g - 1) for j in range(g - 1)], np.int32)
+        et, code = FEM_C3D6, 2
+    else:
+        faces = np.array([[nid(i, j), nid(i + 1, j), nid(i + 1, j + 1), nid(i, j + 1)] for i in range(g - 1) for j in range(g - 1)], np.int32)
+        if kind == 2:                                  # a few degenerate quads (repeated node), as tri2quad leaves them
+            k = rng.choice(len(faces), max(1, len(faces) // 6), replace=False); faces[k, 3] = faces[k, 0]
+        et, code = FEM_C3D8, 1
+    faces = faces[rng.permutation(len(faces))]
+    nodes = second_layer(top, float(rng.uniform(0.2, 1.0)))
+    elems = extrude_elems(faces, len(top))
+    fea = FEA2(nodes, elems, et, E=E, nu=nu)
+    fea.MatrixAssembly()
+    K = oracle.fem_assemble_dense(code, nodes, elems, E, nu) if "E" in oracle.fem_assemble_dense.__code__.co_varnames else None
+    if K is None:
+        print("oracle.fem_assemble_dense has no material arguments"); sys.exit(2)
+    ok = np.array_equal(fea.K_dense(), K, equal_nan=True)
+    a = rng.normal(0, 1e-2, 3 * len(nodes)).astype(np.float32)
+    if ok and not np.isnan(K).any():
+        ok = np.array_equal(fea.ComputeForces(a)[0], oracle.fem_matvec_dense(K, a))
+    if not ok:
+        bad += 1; print("MISMATCH fem", case, kind, g, E, nu, flush=True)
+P = (1500, 1.2, 8, 20, 7)
+for case in range(max(4, n // 8)):
+    w = int(rng.integers(400, 1300)); h = int(rng.integers(200, 500))
+    left, right = synth_stereo_pair(int(rng.integers(0, 1000)), w=w, h=h, dmin=float(rng.uniform(0, 5)), dmax=float(rng.uniform(20, 90)))
+    oL, oR = oracle.OrbOracle(*P), oracle.OrbOracle(*P)
+    kL, dL = oL.extract(left); kR, dR = oR.extract(right)
+    fx, bf = float(rng.uniform(300, 900)), float(rng.uniform(100, 500))
+    mb = np.float32(bf) / np.float32(fx)
+    ou, od, nd = oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(bf))
+    eL, eR = ORBextractor(*P), ORBextractor(*P)
+    eL(left); eR(right)
+    gu, gd = ComputeStereoMatches(eL, eR, mb, np.float32(bf))
+    if not (np.array_equal(gu.view(np.uint32), ou.view(np.uint32)) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))):
+        bad += 1; print("MISMATCH stereo", case, w, h, fx, bf, flush=True)
+print("cases", n, "mismatches", bad)
+sys.exit(1 if bad else 0)
