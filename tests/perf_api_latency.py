@@ -11,7 +11,8 @@ from test_gpu_match import _triangulation_case
 
 
 def t(f, reps=30):
-    f(); t0 = time.perf_counter()
+    for _ in range(10): f()          # the card drops to a low power state while the host times the oracle
+    t0 = time.perf_counter()
     for _ in range(reps): f()
     return (time.perf_counter() - t0) / reps * 1e3
 
