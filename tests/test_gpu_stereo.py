@@ -47,3 +47,32 @@ def test_stereo_small_image():
     ou, od, nd, gu, gd = _run(3, shape=(240, 640))
     assert np.array_equal(gu.view(np.uint32), ou.view(np.uint32))
     assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_left_and_right_extractors_on_two_threads():
+    """Frame::Frame (stereo) runs the two extractors on two std::threads (src/Frame.cc:78-81): distinct handles
+    must be usable concurrently and give what they give sequentially."""
+    import threading
+    left, right = synth_stereo_pair(4)
+    seq = []
+    for img in (left, right):
+        e = ORBextractor(*PARAMS); seq.append(e(img))
+    eL, eR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+    out, errors = {}, []
+
+    def run(name, e, img):
+        try:
+            for _ in range(8):
+                out[name] = e(img)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    ts = [threading.Thread(target=run, args=("L", eL, left)), threading.Thread(target=run, args=("R", eR, right))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors
+    for name, ref in (("L", seq[0]), ("R", seq[1])):
+        assert np.array_equal(out[name][1], ref[1]) and np.array_equal(out[name][0]["x"], ref[0]["x"])
+    mb = np.float32(BF) / np.float32(FX)
+    gu, gd = ComputeStereoMatches(eL, eR, mb, np.float32(BF))
+    assert (gu >= 0).sum() > 100
