@@ -1088,6 +1088,7 @@ int orbx_destroy(orbx_extractor *ex)
     void *stp[] = {ex->d_st_key, ex->d_st_rk, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
     for (void *q : stp)
         if (q) (void)hipFree(q);
+    if (ex->h_pin) (void)hipHostFree(ex->h_pin);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
     return ORBX_OK;
@@ -1401,9 +1402,43 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
 {
     if (!ex || !n) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
     if (!image || width <= 0 || height <= 0) { *n = 0; return ORBX_OK; } // empty image: outputs untouched (:1054)
-    int rc = orbx_extract_batch(ex, image, 0, width, height, stride, (size_t)stride * height, 1, nullptr);
+    // ORBextractor::operator() on one host image is latency-bound: stage the image and the results through pinned
+    // buffers so that the call is one H2D, the kernel chain, one D2H and a single stream synchronisation
+    const size_t in_bytes = (size_t)stride * height;
+    int rc = orbx_reserve(ex, width, height, 1);
     if (rc != ORBX_OK) return rc;
-    return orbx_download(ex, 0, kps, desc, cap, n);
+    const size_t out_bytes = 16 + (sizeof(orbx_keypoint) + 32) * (size_t)ex->kcap;
+    if (in_bytes + out_bytes > ex->pin_bytes) {
+        if (ex->h_pin) (void)hipHostFree(ex->h_pin);
+        ex->h_pin = nullptr; ex->pin_bytes = 0;
+        ORBX_HIP(hipHostMalloc((void **)&ex->h_pin, in_bytes + out_bytes, hipHostMallocDefault));
+        ex->pin_bytes = in_bytes + out_bytes;
+    }
+    if (in_bytes > ex->in_bytes) {
+        if (ex->d_in) ORBX_HIP(hipFree(ex->d_in));
+        ex->d_in = nullptr;
+        ORBX_HIP(hipMalloc(&ex->d_in, in_bytes));
+        ex->in_bytes = in_bytes;
+    }
+    hipStream_t st = ex->stream;
+    memcpy(ex->h_pin, image, in_bytes);
+    ORBX_HIP(hipMemcpyAsync(ex->d_in, ex->h_pin, in_bytes, hipMemcpyHostToDevice, st));
+    rc = orbx_extract_batch(ex, ex->d_in, 1, width, height, stride, in_bytes, 1, st);
+    if (rc != ORBX_OK) return rc;
+    uint8_t *o = ex->h_pin + in_bytes;
+    ORBX_HIP(hipMemcpyAsync(o, ex->d_counts, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(o + 16, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(o + 16 + sizeof(orbx_keypoint) * ex->kcap, ex->d_desc, (size_t)32 * ex->kcap, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    int cnt = 0;
+    memcpy(&cnt, o, sizeof(int));
+    *n = cnt;
+    if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "keypoint buffer too small");
+    if (cnt > 0) {
+        if (kps) memcpy(kps, o + 16, sizeof(orbx_keypoint) * cnt);
+        if (desc) memcpy(desc, o + 16 + sizeof(orbx_keypoint) * ex->kcap, (size_t)32 * cnt);
+    }
+    return ORBX_OK;
 }
 
 int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps, const uint8_t **desc, const int32_t **counts, int *capacity)

@@ -74,6 +74,8 @@ struct orbx_extractor {
     orbx_keypoint *d_kps = nullptr;
     int last_batch = 0;
     // stereo (orbx_stereo.hip): results live in the LEFT handle
+    uint8_t *h_pin = nullptr;                // pinned staging of the single-image call: image in, count + keypoints + descriptors out
+    size_t pin_bytes = 0;
     unsigned *d_st_key = nullptr;
     void *d_st_rk = nullptr; // row bands of the right keypoints (orbx_stereo.hip)
     float *d_uright = nullptr, *d_depth = nullptr, *d_st_scale = nullptr;
