@@ -478,6 +478,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     int *p = reinterpret_cast<int *>(smem);
     int *part = p;          p += 8;
     int *s_cell = p;        p += (maxcells + 1 + 3) & ~3;
+    int *s_coff = p;        p += (maxcells + 1 + 3) & ~3; // each cell's slot in the candidate buffer
     int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
     int *by[2] = {p, p + NC};  p += 2 * NC; // y0 | y1<<16
     int *cnt[2] = {p, p + NC}; p += 2 * NC;
@@ -499,10 +500,12 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     const int N = lv.N;
 
     // gather the level's candidates in cell row-major order (vToDistributeKeys)
+    // (cand_off goes to LDS too, so that the gather below has one dependent global load per candidate, not two)
     for (int c = tid; c < lv.ncells; c += OCT_T) {
         const int n = cell_count[(size_t)f * cells_per_frame + lv.cell_base + c];
-        const int cap = cells[lv.cell_base + c].cap;
-        s_cell[c] = n < cap ? n : cap;
+        const CellInfo ci = cells[lv.cell_base + c];
+        s_cell[c] = n < ci.cap ? n : ci.cap;
+        s_coff[c] = ci.cand_off;
     }
     const int M = block_excl_scan(s_cell, lv.ncells, part);
     if (tid == 0) s_cell[lv.ncells] = M;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
                     const int mid = (lo + hiC) >> 1;
                     if (s_cell[mid] <= k) lo = mid; else hiC = mid;
                 }
-                pk4[u] = cands[(size_t)f * cands_per_frame + cells[lv.cell_base + lo].cand_off + (k - s_cell[lo])];
+                pk4[u] = cands[(size_t)f * cands_per_frame + s_coff[lo] + (k - s_cell[lo])];
             }
         }
 #pragma unroll
@@ -1238,7 +1241,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
     ex->oct_kcap = ex->NC > 1100 ? 3072 : 4096; // keys of a level live in LDS up to this many, else in HBM
     if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
-    ex->oct_lds = (int)sizeof(int) * (8 + ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
+    ex->oct_lds = (int)sizeof(int) * (8 + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     const size_t B = (size_t)batch;
