@@ -11,8 +11,12 @@
 #define ORBSLAM_HIP_HPP
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "fem_hip.h"
@@ -124,6 +128,11 @@ inline int ComputeStereoMatches(ORBextractor &left, ORBextractor &right, float m
     mvuRight.resize(rc == ORBX_OK ? n : 0);
     mvDepth.resize(rc == ORBX_OK ? n : 0);
     return rc;
+}
+
+namespace DBoW2 {
+typedef std::map<unsigned int, double> BowVector;                          // DBoW2/BowVector.h:57
+typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;    // DBoW2/FeatureVector.h:23
 }
 
 class ORBmatcher {
@@ -284,6 +293,17 @@ public:
             fv.off.push_back((int32_t)idx.size());
             return fv;
         }
+        // from the map ORBVocabulary::transform fills (Frame::mFeatVec / KeyFrame::mFeatVec)
+        static FeatureVector FromMap(const DBoW2::FeatureVector &m)
+        {
+            FeatureVector fv;
+            for (const auto &e : m) {
+                fv.nodes.push_back((int32_t)e.first); fv.off.push_back((int32_t)fv.items.size());
+                for (unsigned int i : e.second) fv.items.push_back((int32_t)i);
+            }
+            fv.off.push_back((int32_t)fv.items.size());
+            return fv;
+        }
     };
 
     // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:360-489; valid2 == nullptr) and
@@ -309,6 +329,101 @@ protected:
     float mfNNratio;
     bool mbCheckOrientation;
     int mStatus = ORBX_OK;
+};
+
+// ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:31) as the
+// front end uses it: loadFromTextFile (System.cc:69) and transform (Frame.cc:410-417).  The tree lives in HBM
+// behind orbm_vocab_create; the descent of all features of a frame is one device call, the two std::map
+// results are filled here in feature order like TemplatedVocabulary.h:1127-1160.
+class ORBVocabulary {
+    typedef DBoW2::BowVector BowVector;
+    typedef DBoW2::FeatureVector FeatureVector;
+
+
+public:
+    ORBVocabulary() {}
+    ~ORBVocabulary() { clear(); }
+    ORBVocabulary(const ORBVocabulary &) = delete;
+    ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+
+    // Text layout of TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1420): header `k L scoring
+    // weighting`, then per node `parent isLeaf d0..d31 weight`; node ids are line numbers, word ids count the leaves.
+    bool loadFromTextFile(const std::string &filename) {
+        clear();
+        FILE *f = std::fopen(filename.c_str(), "r");
+        if (!f) return false;
+        int k = 0, L = 0, n1 = 0, n2 = 0;
+        bool ok = std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) == 4 && !(k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3);
+        std::vector<int32_t> parent(1, 0), word(1, -1);
+        std::vector<uint8_t> desc(32, 0);
+        std::vector<double> weight(1, 0.0);
+        int nwords = 0;
+        while (ok) {
+            int pid, leaf;
+            if (std::fscanf(f, "%d %d", &pid, &leaf) != 2) break;            // end of file
+            const int id = (int)parent.size();
+            if (pid < 0 || pid >= id) { ok = false; break; }
+            unsigned b[32];
+            for (int i = 0; i < 32 && ok; ++i) ok = std::fscanf(f, "%u", &b[i]) == 1 && b[i] < 256;
+            double w = 0;
+            ok = ok && std::fscanf(f, "%lf", &w) == 1;
+            if (!ok) break;
+            parent.push_back(pid); word.push_back(leaf > 0 ? nwords++ : -1); weight.push_back(w);
+            for (int i = 0; i < 32; ++i) desc.push_back((uint8_t)b[i]);
+        }
+        std::fclose(f);
+        if (!ok) return false;
+        const int n = (int)parent.size();
+        std::vector<int32_t> off(n + 1, 0), ids(n - 1), fill(n, 0);
+        for (int i = 1; i < n; ++i) ++off[parent[i] + 1];
+        for (int i = 0; i < n; ++i) off[i + 1] += off[i];
+        for (int i = 1; i < n; ++i) ids[off[parent[i]] + fill[parent[i]]++] = i;   // children in order of appearance
+        m_k = k; m_L = L; m_scoring = n1; m_weighting = n2; m_nwords = nwords; m_nnodes = n;
+        mStatus = orbm_vocab_create(off.data(), ids.data(), desc.data(), word.data(), weight.data(), n, L, &mVoc);
+        return mStatus == ORBX_OK;
+    }
+
+    bool empty() const { return m_nwords == 0; }
+    unsigned int size() const { return (unsigned int)m_nwords; }
+    int getBranchingFactor() const { return m_k; }
+    int getDepthLevels() const { return m_L; }
+
+    // features: n x 32 bytes (Converter::toDescriptorVector of mDescriptors is this, row by row).
+    void transform(const uint8_t *features, int n, BowVector &v, FeatureVector &fv, int levelsup) {
+        v.clear(); fv.clear();
+        if (!mVoc || n <= 0) return;
+        mWord.resize(n); mNode.resize(n); mW.resize(n);
+        mStatus = orbm_bow_transform(mVoc, features, n, levelsup, mWord.data(), mNode.data(), mW.data());
+        if (mStatus != ORBX_OK) return;
+        const bool tf = m_weighting == 0 || m_weighting == 1;                // TF_IDF / TF accumulate, IDF / BINARY keep the first
+        for (int i = 0; i < n; ++i)
+            if (mW[i] > 0) {                                                 // not stopped
+                if (tf) v[(unsigned)mWord[i]] += mW[i];                      // BowVector::addWeight
+                else v.insert(BowVector::value_type((unsigned)mWord[i], mW[i]));   // BowVector::addIfNotExist
+                fv[(unsigned)mNode[i]].push_back((unsigned)i);               // FeatureVector::addFeature
+            }
+        const bool must = m_scoring != 5;                                    // every scoring but DOT_PRODUCT normalises (ScoringObject.h:74-89)
+        if (tf && !v.empty() && !must) {
+            const double nd = (double)v.size();
+            for (auto &e : v) e.second /= nd;
+        }
+        if (must) {                                                          // BowVector::normalize: L2 for L2_NORM, else L1
+            double norm = 0;
+            if (m_scoring == 1) { for (auto &e : v) norm += e.second * e.second; norm = std::sqrt(norm); }
+            else for (auto &e : v) norm += std::fabs(e.second);
+            if (norm > 0) for (auto &e : v) e.second /= norm;
+        }
+    }
+
+    orbm_vocabulary *handle() const { return mVoc; }
+    int status() const { return mStatus; }
+
+private:
+    void clear() { if (mVoc) orbm_vocab_destroy(mVoc); mVoc = nullptr; m_nwords = m_nnodes = 0; }
+    orbm_vocabulary *mVoc = nullptr;
+    int m_k = 0, m_L = 0, m_scoring = 0, m_weighting = 0, m_nwords = 0, m_nnodes = 0, mStatus = ORBX_OK;
+    std::vector<int32_t> mWord, mNode;
+    std::vector<double> mW;
 };
 
 // Numeric core of FEA2: the members and methods g2o and Optimizer touch

@@ -15,8 +15,9 @@ def _p(a):
 
 
 class ORBVocabulary:
-    def __init__(self, child_off, child_ids, node_desc, node_word, node_weight, L):
+    def __init__(self, child_off, child_ids, node_desc, node_word, node_weight, L, scoring=0, weighting=0):
         self._L = lib()
+        self.m_scoring, self.m_weighting = scoring, weighting
         self.child_off = np.ascontiguousarray(child_off, np.int32); self.child_ids = np.ascontiguousarray(child_ids, np.int32)
         self.node_desc = np.ascontiguousarray(node_desc, np.uint8); self.node_word = np.ascontiguousarray(node_word, np.int32)
         self.node_weight = np.ascontiguousarray(node_weight, np.float64)
@@ -42,21 +43,81 @@ class ORBVocabulary:
     def transform(self, features, levelsup=4):
         """Returns (BowVector: {word id: value}, FeatureVector: {node id: [feature indices]})."""
         word, node, w = self.descend(features, levelsup)
-        return assemble_bow(word, node, w)
+        return assemble_bow(word, node, w, self.m_scoring, self.m_weighting)
+
+    @classmethod
+    def loadFromTextFile(cls, path):
+        """ORBvoc.txt -> device tree (System.cc:69 mpVocabulary->loadFromTextFile)."""
+        arrays, (k, scoring, weighting) = load_vocabulary_text(path)
+        v = cls(*arrays, scoring=scoring, weighting=weighting)
+        v.m_k = k
+        return v
 
 
-def assemble_bow(word, node, w):
+def load_vocabulary_text(path):
+    """ORBvoc.txt reader = TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420):
+    first line `k L scoring weighting`, then one node per line `parent isLeaf d0 .. d31 weight`; node ids are line
+    numbers (the root is node 0 and has no line), children keep their order of appearance, word ids number the leaves
+    in file order.  Returns the flat arrays ORBVocabulary / orbm_vocab_create take:
+    (child_off, child_ids, node_desc, node_word, node_weight, L) plus (k, scoring, weighting)."""
+    with open(path) as f:
+        head = f.readline().split()
+        k, L, scoring, weighting = (int(x) for x in head[:4])
+        if k < 0 or k > 20 or L < 1 or L > 10 or scoring < 0 or scoring > 5 or weighting < 0 or weighting > 3:
+            raise ValueError("not a DBoW2 text vocabulary")           # the reference's check (:1359)
+        rows = np.loadtxt(f, dtype=np.float64, ndmin=2)
+    n = len(rows) + 1
+    parent = rows[:, 0].astype(np.int64); leaf = rows[:, 1] > 0
+    if rows.shape[1] != 35 or (parent < 0).any() or (parent >= np.arange(1, n)).any():
+        raise ValueError("malformed vocabulary line")
+    desc = np.zeros((n, 32), np.uint8); desc[1:] = rows[:, 2:34].astype(np.uint8)
+    weight = np.zeros(n, np.float64); weight[1:] = rows[:, 34]
+    word = np.full(n, -1, np.int32); word[1:][leaf] = np.arange(int(leaf.sum()), dtype=np.int32)
+    order = np.argsort(parent, kind="stable")                        # children grouped by parent, in order of appearance
+    child_ids = (order + 1).astype(np.int32)
+    child_off = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(parent, minlength=n), out=child_off[1:])
+    return (child_off, child_ids, desc, word, weight, L), (k, scoring, weighting)
+
+
+def save_vocabulary_text(path, child_off, child_ids, node_desc, node_word, node_weight, k, L, scoring=0, weighting=0):
+    """Writer in the layout of TemplatedVocabulary::saveToTextFile (:1425-1450), for tests: nodes must be numbered so
+    that every parent precedes its children (breadth-first ids as DBoW2 creates them)."""
+    n = len(node_word)
+    parent = np.zeros(n, np.int64)
+    for i in range(n):
+        parent[child_ids[child_off[i]:child_off[i + 1]]] = i
+    with open(path, "w") as f:
+        f.write(f"{k} {L}  {scoring} {weighting}\n")
+        for i in range(1, n):
+            f.write(f"{parent[i]} {1 if node_word[i] >= 0 else 0} " + " ".join(str(int(b)) for b in node_desc[i]) + f" {float(node_weight[i])!r}\n")
+
+
+def assemble_bow(word, node, w, scoring=0, weighting=0):
+    """scoring / weighting: DBoW2 ScoringType / WeightingType numbers (BowVector.h:36-53); ORBvoc is L1_NORM, TF_IDF = 0, 0."""
     bow, fv = {}, {}
+    tf = weighting in (0, 1)
     for i in range(len(word)):
         if w[i] > 0:                                   # not stopped
-            bow[int(word[i])] = bow.get(int(word[i]), 0.0) + float(w[i])      # BowVector::addWeight
+            if tf:
+                bow[int(word[i])] = bow.get(int(word[i]), 0.0) + float(w[i])  # BowVector::addWeight
+            else:
+                bow.setdefault(int(word[i]), float(w[i]))                     # BowVector::addIfNotExist
             fv.setdefault(int(node[i]), []).append(i)                         # FeatureVector::addFeature
-    norm = 0.0
-    for k in sorted(bow):                              # BowVector::normalize(L1), std::map order
-        norm += abs(bow[k])
-    if norm > 0.0:
+    must = scoring != 5                                # all but DOT_PRODUCT normalise (ScoringObject.h:74-89)
+    if tf and bow and not must:
+        nd = float(len(bow))
         for k in bow:
-            bow[k] /= norm
+            bow[k] /= nd
+    if must:
+        norm = 0.0
+        for k in sorted(bow):                          # BowVector::normalize, std::map order
+            norm += bow[k] * bow[k] if scoring == 1 else abs(bow[k])
+        if scoring == 1:
+            norm = float(np.sqrt(norm))
+        if norm > 0.0:
+            for k in bow:
+                bow[k] /= norm
     return bow, fv
 
 

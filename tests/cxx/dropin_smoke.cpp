@@ -143,6 +143,49 @@ int main(int argc, char **argv)
         for (int i = 0; i < n; ++i) selfb += m12b[i] == i;
         if (mb.status() != ORBX_OK || nb != selfb || selfb < n * 8 / 10) { printf("FAIL SearchByBoW %d %d of %d\n", nb, selfb, n); return 1; }
     }
+    {
+        // ORBVocabulary: write a k=4, L=2 tree in the ORBvoc.txt layout whose leaves are the first 16 descriptors,
+        // load it, transform the frame: every one of those 16 features must land on its own word.
+        const char *path = argc > 2 ? argv[2] : "/tmp/dropin_voc.txt";
+        FILE *f = fopen(path, "w");
+        if (!f || n < 16) { printf("FAIL vocabulary file\n"); return 1; }
+        fprintf(f, "4 2  0 0\n");
+        for (int c = 0; c < 4; ++c) {                                        // nodes 1..4: inner nodes, descriptor = first leaf below
+            fprintf(f, "0 0 ");
+            for (int b = 0; b < 32; ++b) fprintf(f, "%d ", desc[(size_t)32 * (4 * c) + b]);
+            fprintf(f, "0\n");
+        }
+        for (int l = 0; l < 16; ++l) {                                       // nodes 5..20: leaves = words 0..15
+            fprintf(f, "%d 1 ", 1 + l / 4);
+            for (int b = 0; b < 32; ++b) fprintf(f, "%d ", desc[(size_t)32 * l + b]);
+            fprintf(f, "%.17g\n", 1.0 + 0.25 * l);
+        }
+        fclose(f);
+        ORBVocabulary voc;
+        if (!voc.loadFromTextFile(path) || voc.size() != 16 || voc.getBranchingFactor() != 4 || voc.getDepthLevels() != 2) {
+            printf("FAIL loadFromTextFile %d\n", voc.status()); return 1;
+        }
+        DBoW2::BowVector bv;
+        DBoW2::FeatureVector fvm;
+        voc.transform(desc.data(), n, bv, fvm, 1);
+        double sum = 0; size_t nfeat = 0;
+        for (const auto &e : bv) sum += e.second;
+        for (const auto &e : fvm) { nfeat += e.second.size(); if (e.first < 1 || e.first > 4) { printf("FAIL node id %u\n", e.first); return 1; } }
+        const ORBmatcher::FeatureVector flat = ORBmatcher::FeatureVector::FromMap(fvm);
+        if (voc.status() != ORBX_OK || bv.empty() || sum < 1 - 1e-9 || sum > 1 + 1e-9 || (int)nfeat != n || (int)flat.items.size() != n) {
+            printf("FAIL transform %d sum %g nfeat %zu\n", voc.status(), sum, nfeat); return 1;
+        }
+        // the inner nodes carry the descriptor of their first leaf, so feature 4c (distance 0 to node 1+c) reaches word 4c
+        std::vector<int32_t> word(n), node(n); std::vector<double> w(n);
+        orbm_bow_transform(voc.handle(), desc.data(), n, 1, word.data(), node.data(), w.data());
+        for (int c = 0; c < 4; ++c) {
+            bool dup = false;                                                // an identical descriptor earlier in the tree wins the tie
+            for (int l = 0; l < 4 * c; ++l) dup = dup || popcount_row(&desc[(size_t)32 * l], &desc[(size_t)32 * 4 * c]) == 0;
+            if (!dup && (word[4 * c] != 4 * c || node[4 * c] != 1 + c || w[4 * c] != 1.0 + 0.25 * 4 * c)) {
+                printf("FAIL descent of feature %d: word %d node %d\n", 4 * c, word[4 * c], node[4 * c]); return 1;
+            }
+        }
+    }
     printf("OK %d keypoints, %d self matches, %d stereo matches, sE=%g\n", n, nm, nst, sE);
     return 0;
 }

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import oracle
-from orb_slam2_e_amd.vocabulary import ORBVocabulary, assemble_bow
+from orb_slam2_e_amd.vocabulary import ORBVocabulary, assemble_bow, load_vocabulary_text, save_vocabulary_text
 
 
 def _synthetic_vocabulary(k=10, L=4, seed=0):
@@ -66,3 +66,51 @@ def test_bow_descent_and_vectors(levelsup):
     gb, gf = voc.transform(feats, levelsup)
     rb, rf = assemble_bow(*ref)
     assert gb == rb and gf == rf and abs(sum(gb.values()) - 1.0) < 1e-12 and len(gb) > 500
+
+
+def _irregular_vocabulary(seed=5, L=5):
+    """A tree as k-means can leave it: between 1 and 7 children per node, leaves at every depth 1..L, node ids in
+    creation (breadth-first) order, as parent-array so the text writer can emit it."""
+    rng = np.random.default_rng(seed)
+    parent, depth, desc = [0], [0], [np.zeros(32, np.uint8)]
+    frontier = [0]
+    for d in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            for _ in range(int(rng.integers(1, 8))):
+                parent.append(p); depth.append(d)
+                desc.append(desc[p] ^ np.packbits(rng.random(256) < 0.5 ** d, bitorder="little"))
+                nxt.append(len(parent) - 1)
+        frontier = [i for i in nxt if d < L and rng.random() < 0.8]      # the others stay leaves at depth d
+        if not frontier and d < L:
+            frontier = nxt[:1]
+    n = len(parent)
+    parent = np.array(parent)
+    inner = np.zeros(n, bool); inner[parent[1:]] = True
+    word = np.full(n, -1, np.int32); word[~inner] = np.arange(int((~inner).sum()))
+    weight = np.where(inner, 0.0, rng.uniform(0.1, 9.0, n)); weight[np.where(~inner)[0][::17]] = 0.0
+    order = np.argsort(parent[1:], kind="stable") + 1
+    off = np.zeros(n + 1, np.int32); np.cumsum(np.bincount(parent[1:], minlength=n), out=off[1:])
+    return off, order.astype(np.int32), np.stack(desc), word, weight, L
+
+
+@pytest.mark.parametrize("levelsup", [4, 1])
+@pytest.mark.parametrize("scoring,weighting", [(0, 0), (1, 0), (5, 1), (0, 2), (5, 3)])
+def test_vocabulary_loaded_from_text_file(tmp_path, levelsup, scoring, weighting):
+    """ORBvoc.txt route: write an irregular tree in the saveToTextFile layout, load it (System.cc:69), and the
+    descent + BowVector / FeatureVector must equal the oracle's on the arrays the file was written from."""
+    off, ids, desc, word, weight, L = _irregular_vocabulary()
+    path = str(tmp_path / "voc.txt")
+    save_vocabulary_text(path, off, ids, desc, word, weight, 7, L, scoring, weighting)
+    voc = ORBVocabulary.loadFromTextFile(path)
+    assert voc.m_L == L and voc.m_k == 7 and (voc.m_scoring, voc.m_weighting) == (scoring, weighting)
+    assert np.array_equal(voc.child_off, off) and np.array_equal(voc.child_ids, ids) and np.array_equal(voc.node_word, word)
+    assert np.array_equal(voc.node_desc[1:], desc[1:]) and np.array_equal(voc.node_weight, weight)
+    rng = np.random.default_rng(2)
+    leaves = np.where(word >= 0)[0]
+    feats = desc[rng.choice(leaves, 1500)] ^ np.packbits(rng.random((1500, 256)) < 0.05, axis=1, bitorder="little")
+    got = voc.descend(feats, levelsup)
+    ref = oracle.bow_descend(off, ids, desc, word, weight, L, feats, levelsup)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    assert voc.transform(feats, levelsup) == assemble_bow(*ref, scoring, weighting)
