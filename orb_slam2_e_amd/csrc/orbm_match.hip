@@ -4,7 +4,8 @@
 // DescriptorDistance (:1848-1864) as XOR + v_bcnt popcount on 256-bit rows, and
 // the best / second-best / arg-best selection every Search* function shares
 // (strict '<': first-seen candidate wins ties; second updated with 'else if').
-// This is bit-twiddling, not a contraction: no MFMA.
+// The gated searches are bit-twiddling on short candidate lists (no MFMA); the all-pairs
+// matcher is a contraction over the descriptor bits and runs on the matrix cores (k_match_sets_mfma).
 #include <limits.h>
 #include <stdint.h>
 
@@ -161,6 +162,141 @@ __global__ __launch_bounds__(64 * MSEG) void k_match_sets(const uint8_t *__restr
         }
         nok += __popcll(__ballot(ok));
     }
+    if (nmatch && lane == 0 && nok) atomicAdd(&nmatch[p], nok);
+}
+
+// ---- The all-pairs matcher on the matrix cores ---------------------------------------------------------
+// A 2000 x 2000 Hamming matrix is a contraction over the 256 descriptor bits: with train bit t sent to
+// (1 - 2t) and query bit q to -(1 - 2q) / 2, sum_k a_k b_k = hamming - 128, and +-1 / +-0.5 are exact FP4
+// (E2M1) values, so v_mfma_f32_32x32x64_f8f6f4 computes 32 x 32 distances from four K = 64 steps at the FP4
+// rate (8 x the K of the bf16 form per cycle) with exact small-integer f32 sums.  The accumulator is seeded
+// with 128 + j * 2^-15 (j = train index of the row), so every output element IS the selection key
+// dist + j / 32768: at most 9 + 15 significant bits, exact in f32, positive, and ordered like its bit
+// pattern -- the (smallest, second smallest) update of k_match_sets runs on it unchanged, two VALU
+// instructions per pair instead of 8 xor + 8 bcnt + pack + 2.  The K order inside a step is whatever the
+// hardware uses: both operands are expanded by the same function of (lane half, step), and a dot product
+// does not care.  Train rows sit on M (the 16 accumulator registers of a lane), queries on N (the lane),
+// so a lane folds its registers into the running pair of its own query with no cross-lane traffic.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int XQ = 4;                          // 32-query tiles per wave; also the number of waves of a workgroup
+constexpr unsigned XKEY_INF = 0x7f000000u;     // above every key (keys < 257)
+constexpr float XIDX = 1.0f / 32768.0f;
+constexpr int XMAXN = 32768;                   // j * 2^-15 < 1
+constexpr unsigned FP4_TRAIN = 0xAAA22A22u;    // byte v = two E2M1 codes for bits (v & 1, v >> 1): 0 -> +1 (0x2), 1 -> -1 (0xA)
+constexpr unsigned FP4_QUERY = 0x11199199u;    // 0 -> -0.5 (0x9), 1 -> +0.5 (0x1)
+
+// 32 descriptor bits -> 32 FP4 codes: the 2-bit fields of the four bytes select table bytes (v_perm_b32).
+template <unsigned TBL> __device__ __forceinline__ v8i expand_fp4(unsigned x)
+{
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    r[0] = (int)__builtin_amdgcn_perm(0u, TBL, x & 0x03030303u);
+    r[1] = (int)__builtin_amdgcn_perm(0u, TBL, (x >> 2) & 0x03030303u);
+    r[2] = (int)__builtin_amdgcn_perm(0u, TBL, (x >> 4) & 0x03030303u);
+    r[3] = (int)__builtin_amdgcn_perm(0u, TBL, (x >> 6) & 0x03030303u);
+    return r;
+}
+
+// key_update for keys that come straight out of an MFMA: no inline asm here -- the compiler's hazard recogniser
+// does not see asm operands, and a VALU read of a fresh MFMA result needs software wait states.  The keys are
+// positive finite floats, so v_med3_f32 orders them like v_med3_u32.
+__device__ __forceinline__ void key_update_f(float key, unsigned &k1, unsigned &k2)
+{
+    k2 = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(k1), key, __uint_as_float(k2)));
+    const unsigned u = __float_as_uint(key);
+    k1 = k1 < u ? k1 : u;
+}
+
+__device__ __forceinline__ void merge_pairs(unsigned &m1, unsigned &m2, unsigned o1, unsigned o2)
+{
+    const unsigned hi = m1 > o1 ? m1 : o1, lo2 = m2 < o2 ? m2 : o2;
+    m1 = m1 < o1 ? m1 : o1;
+    m2 = hi < lo2 ? hi : lo2;
+}
+
+// Workgroup = 4 waves x (XQ * 32 = 128 queries); wave `seg` scans the train tiles seg, seg + 4, ... .
+__global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
+                                                          int cap, const int *__restrict__ qa, const int *__restrict__ qb,
+                                                          int th, float nnratio, int *__restrict__ best_o,
+                                                          int *__restrict__ second_o, int *__restrict__ idx_o,
+                                                          int *__restrict__ match12, int *__restrict__ nmatch)
+{
+    __shared__ unsigned sk[4][XQ][2][32];
+    const int p = blockIdx.y, lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int sa = qa ? qa[p] : 0, sb = qb ? qb[p] : 1;
+    const int nA = counts[sa] < cap ? counts[sa] : cap, nB = counts[sb] < cap ? counts[sb] : cap;
+    const int row0 = blockIdx.x * 32 * XQ;
+    if (row0 >= nA) return;
+    const uint4 *A = reinterpret_cast<const uint4 *>(desc + (size_t)sa * cap * 32);
+    const uint4 *B = reinterpret_cast<const uint4 *>(desc + (size_t)sb * cap * 32);
+    const int r = lane & 31, h = lane >> 5;            // operand row / column, and which 128-bit half of it this lane feeds
+    v8i bq[XQ][4];
+    unsigned k1[XQ], k2[XQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        const int i = min(row0 + q * 32 + r, nA - 1);
+        const uint4 x = A[2 * i + h];
+        bq[q][0] = expand_fp4<FP4_QUERY>(x.x); bq[q][1] = expand_fp4<FP4_QUERY>(x.y);
+        bq[q][2] = expand_fp4<FP4_QUERY>(x.z); bq[q][3] = expand_fp4<FP4_QUERY>(x.w);
+        k1[q] = k2[q] = XKEY_INF;
+    }
+    // accumulator register g of this lane is train row (g & 3) + 8 * (g >> 2) + 4 * h of the tile
+    v16f c;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) c[g] = 128.0f + (float)(seg * 32 + (g & 3) + 8 * (g >> 2) + 4 * h) * XIDX;
+    const int ntile = (nB + 31) >> 5;
+    uint4 nx = make_uint4(0, 0, 0, 0);
+    if (seg < ntile) nx = B[2 * min(seg * 32 + r, nB - 1) + h];
+    for (int t = seg; t < ntile; t += 4) {
+        const uint4 x = nx;
+        if (t + 4 < ntile) nx = B[2 * min((t + 4) * 32 + r, nB - 1) + h];      // in flight during this tile
+        const v8i a0 = expand_fp4<FP4_TRAIN>(x.x), a1 = expand_fp4<FP4_TRAIN>(x.y), a2 = expand_fp4<FP4_TRAIN>(x.z),
+                  a3 = expand_fp4<FP4_TRAIN>(x.w);
+        v16f cc = c;
+        if (t * 32 + 32 > nB) {                                                // rows past the set never win
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (t * 32 + (g & 3) + 8 * (g >> 2) + 4 * h >= nB) cc[g] = __uint_as_float(XKEY_INF);
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bq[q][0], cc, 4, 4, 0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[q][1], acc, 4, 4, 0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a2, bq[q][2], acc, 4, 4, 0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a3, bq[q][3], acc, 4, 4, 0, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) key_update_f(acc[g], k1[q], k2[q]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) c[g] += 128.0f * XIDX;                    // four tiles further
+    }
+    // fold the two lane halves (rows 4h.. of every tile), then the four waves
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        merge_pairs(k1[q], k2[q], (unsigned)__shfl_xor((int)k1[q], 32), (unsigned)__shfl_xor((int)k2[q], 32));
+        if (h == 0) { sk[seg][q][0][r] = k1[q]; sk[seg][q][1][r] = k2[q]; }
+    }
+    __syncthreads();
+    // wave `seg` finishes query tile `seg`
+    bool ok = false;
+    const int i = row0 + seg * 32 + r;
+    if (h == 0 && i < nA) {
+        unsigned m1 = sk[0][seg][0][r], m2 = sk[0][seg][1][r];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) merge_pairs(m1, m2, sk[g][seg][0][r], sk[g][seg][1][r]);
+        const float f1 = __uint_as_float(m1), f2 = __uint_as_float(m2);
+        const int d1 = (int)f1;
+        const int best = nB > 0 ? d1 : INT_MAX, idx = nB > 0 ? (int)((f1 - (float)d1) * 32768.0f) : -1;
+        const int second = nB > 1 ? (int)f2 : INT_MAX;
+        const size_t o = (size_t)p * cap + i;
+        if (best_o) best_o[o] = best;
+        if (second_o) second_o[o] = second;
+        if (idx_o) idx_o[o] = idx;
+        ok = idx >= 0 && best <= th && (float)best < (float)second * nnratio;     // ORBmatcher.cc:674-676
+        if (match12) match12[o] = ok ? idx : -1;
+    }
+    const int nok = __popcll(__ballot(ok));
     if (nmatch && lane == 0 && nok) atomicAdd(&nmatch[p], nok);
 }
 
@@ -371,6 +507,18 @@ void workspace_release(Workspace *w)
 
 } // namespace orbm_detail
 
+// All-pairs launch: matrix-core kernel while the train index fits the key's 15 fraction bits.
+static void launch_match_sets(hipStream_t st, const uint8_t *desc, const int *counts, int cap, const int *qa, const int *qb, int npairs,
+                              int th, float nnratio, int *best, int *second, int *idx, int *match12, int *nmatch)
+{
+    if (cap <= XMAXN)
+        hipLaunchKernelGGL(k_match_sets_mfma, dim3((cap + 32 * XQ - 1) / (32 * XQ), npairs), dim3(256), 0, st, desc, counts, cap, qa, qb,
+                           th, nnratio, best, second, idx, match12, nmatch);
+    else
+        hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), npairs), dim3(64, MSEG), 0, st, desc, counts, cap, qa, qb,
+                           th, nnratio, best, second, idx, match12, nmatch);
+}
+
 extern "C" {
 
 int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int cap, const int32_t *pair_a_dev,
@@ -382,8 +530,8 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
     hipStream_t st = (hipStream_t)stream;
     if (nmatch_dev) ORBX_HIP(hipMemsetAsync(nmatch_dev, 0, sizeof(int) * npairs, st));
     g_prof.start(0, st);
-    hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), npairs), dim3(64, MSEG), 0, st, desc_dev, counts_dev, cap,
-                       pair_a_dev, pair_b_dev, th, nnratio, best_dev, second_dev, idx_dev, match12_dev, nmatch_dev);
+    launch_match_sets(st, desc_dev, counts_dev, cap, pair_a_dev, pair_b_dev, npairs, th, nnratio, best_dev, second_dev, idx_dev,
+                      match12_dev, nmatch_dev);
     g_prof.stop(0, st);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -404,9 +552,8 @@ int orbm_match_bruteforce(const uint8_t *A, int nA, const uint8_t *B, int nB, in
     const size_t o_o = sc.out(sizeof(int) * 3 * (size_t)cap);
     if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
     int *ob = sc.d<int>(o_o);
-    hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), 1), dim3(64, MSEG), 0, sc.stream(), sc.d<const uint8_t>(o_a),
-                       sc.d<const int>(o_c), cap, (const int *)nullptr, (const int *)nullptr, 0, 0.f, ob, ob + cap, ob + 2 * cap,
-                       (int *)nullptr, (int *)nullptr);
+    launch_match_sets(sc.stream(), sc.d<const uint8_t>(o_a), sc.d<const int>(o_c), cap, nullptr, nullptr, 1, 0, 0.f, ob, ob + cap,
+                      ob + 2 * cap, nullptr, nullptr);
     ORBX_HIP(hipGetLastError());
     if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
     const int *r = sc.r<int>(o_o);
