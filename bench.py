@@ -30,6 +30,8 @@ PARAMS = (2000, 1.2, 8, 20, 7)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Integer VALU issue rate: one wave64 instruction per 4 clocks per SIMD (tools/ubench/valu.hip), 1024 SIMDs, 2.4 GHz
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0
+# MI355X_MICROARCH.md, Matrix cores: FP4 (v_mfma_f32_32x32x64_f8f6f4) dense peak; the all-pairs matcher runs on it
+MFMA_FP4_PEAK_TFLOPS = 10000.0
 # SURVEY 8(d) algorithmic bytes per 640x480 frame, by stage
 PYR_PX = 950532
 ALG_BYTES = {
@@ -39,7 +41,7 @@ ALG_BYTES = {
     "k_octree": 0,
     "k_blur": 2 * PYR_PX,                       # blur read + write
     "k_describe": 2000 * 749 + 2000 * 512 + 2000 * 60,
-    "k_match_sets": 144000,                     # 2 x 2000 x 32 B read + 2000 x 8 B written
+    "k_match_sets_mfma": 144000,                # 2 x 2000 x 32 B read + 2000 x 8 B written
 }
 FRAME_BYTES = 6751328  # whole extract path per frame
 
@@ -320,7 +322,7 @@ def main():
                 kern[names[i].decode()] = (a + ms[i], b + ln[i])
         mm, ml = C.c_double(0), C.c_int64(0)
         L.orbm_profile_read(C.byref(mm), C.byref(ml))
-        kern["k_match_sets"] = (mm.value, ml.value)
+        kern["k_match_sets_mfma"] = (mm.value, ml.value)
         return kern
 
     # untimed pass with events around every kernel: the per-kernel split and the dominant kernel
@@ -341,7 +343,7 @@ def main():
     # timed region: events around the dominant kernel only (each event costs dispatch-gap time)
     for c in ctxs:
         L.orbx_profile_enable(c.ex._h, (1 << KINDS.index(dom)) if dom in KINDS else 0)
-    L.orbm_profile_enable(1 if dom == "k_match_sets" else 0)
+    L.orbm_profile_enable(1 if dom == "k_match_sets_mfma" else 0)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -437,6 +439,19 @@ def main():
             "pipeline_hbm_frac": value / world * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
             "kernel_ms_per_step_untimed_pass": split_ms,
         }
+        # the all-pairs matcher is the one contraction on the path: 2 x 256 FP4 multiply-adds per descriptor pair
+        nk = counts.double().clamp(max=cap).cpu()
+        pair_flops = 512.0 * float((nk[qa.cpu().long()] * nk[qb.cpu().long()]).sum())
+        mm_ms = split_ms.get("k_match_sets_mfma", 0.0)
+        if mm_ms > 0:
+            out["matcher_mfma"] = {"kernel": "k_match_sets_mfma", "bound": "mfma", "achieved": pair_flops / (mm_ms * 1e-3) / 1e12,
+                                   "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pair_flops / (mm_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                                   "flops_per_launch": pair_flops, "launch_ms_untimed_pass": mm_ms,
+                                   "note": "FP4 MFMA computes the selection keys; the top-2 fold (2 VALU instructions per pair) bounds it"}
+        if dom == "k_match_sets_mfma":
+            tf = pair_flops / (avg_launch_ms * 1e-3) / 1e12
+            out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf / MFMA_FP4_PEAK_TFLOPS, "flops_per_launch": pair_flops})
         tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tfile):   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
             tr = json.load(open(tfile))

@@ -327,7 +327,7 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
                          int32_t *best_dev, int32_t *second_dev, int32_t *idx_dev,
                          int32_t *match12_dev, int32_t *nmatch_dev, void *stream);
 
-/* HIP-event timing of k_match_sets launched through orbm_match_batch_dev. */
+/* HIP-event timing of the all-pairs kernel (k_match_sets_mfma) launched through orbm_match_batch_dev. */
 int orbm_profile_enable(int on);
 int orbm_profile_read(double *total_ms, int64_t *launches);
 

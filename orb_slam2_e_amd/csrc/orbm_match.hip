@@ -215,6 +215,22 @@ __device__ __forceinline__ void merge_pairs(unsigned &m1, unsigned &m2, unsigned
     m2 = hi < lo2 ? hi : lo2;
 }
 
+// One 32-row train tile against the XQ query tiles of the wave: expand, 4 x XQ MFMAs, fold the keys.
+__device__ __forceinline__ void mfma_tile(const uint4 &x, const v16f &c, const v8i (&bq)[XQ][4], unsigned (&k1)[XQ], unsigned (&k2)[XQ])
+{
+    const v8i a0 = expand_fp4<FP4_TRAIN>(x.x), a1 = expand_fp4<FP4_TRAIN>(x.y), a2 = expand_fp4<FP4_TRAIN>(x.z),
+              a3 = expand_fp4<FP4_TRAIN>(x.w);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bq[q][0], c, 4, 4, 0, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[q][1], acc, 4, 4, 0, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a2, bq[q][2], acc, 4, 4, 0, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a3, bq[q][3], acc, 4, 4, 0, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) key_update_f(acc[g], k1[q], k2[q]);
+    }
+}
+
 // Workgroup = 4 waves x (XQ * 32 = 128 queries); wave `seg` scans the train tiles seg, seg + 4, ... .
 __global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
                                                           int cap, const int *__restrict__ qa, const int *__restrict__ qb,
@@ -223,7 +239,7 @@ __global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restri
                                                           int *__restrict__ match12, int *__restrict__ nmatch)
 {
     __shared__ unsigned sk[4][XQ][2][32];
-    const int p = blockIdx.y, lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int p = blockIdx.y, lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sa = qa ? qa[p] : 0, sb = qb ? qb[p] : 1;
     const int nA = counts[sa] < cap ? counts[sa] : cap, nB = counts[sb] < cap ? counts[sb] : cap;
     const int row0 = blockIdx.x * 32 * XQ;
@@ -245,31 +261,24 @@ __global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restri
     v16f c;
 #pragma unroll
     for (int g = 0; g < 16; ++g) c[g] = 128.0f + (float)(seg * 32 + (g & 3) + 8 * (g >> 2) + 4 * h) * XIDX;
-    const int ntile = (nB + 31) >> 5;
+    // full tiles first (no row test anywhere in that loop), then the one ragged tile, which belongs to one wave
+    const int nfull = nB >> 5;
     uint4 nx = make_uint4(0, 0, 0, 0);
-    if (seg < ntile) nx = B[2 * min(seg * 32 + r, nB - 1) + h];
-    for (int t = seg; t < ntile; t += 4) {
+    if (seg < nfull) nx = B[2 * (seg * 32 + r) + h];
+    for (int t = seg; t < nfull; t += 4) {
         const uint4 x = nx;
-        if (t + 4 < ntile) nx = B[2 * min((t + 4) * 32 + r, nB - 1) + h];      // in flight during this tile
-        const v8i a0 = expand_fp4<FP4_TRAIN>(x.x), a1 = expand_fp4<FP4_TRAIN>(x.y), a2 = expand_fp4<FP4_TRAIN>(x.z),
-                  a3 = expand_fp4<FP4_TRAIN>(x.w);
-        v16f cc = c;
-        if (t * 32 + 32 > nB) {                                                // rows past the set never win
-#pragma unroll
-            for (int g = 0; g < 16; ++g)
-                if (t * 32 + (g & 3) + 8 * (g >> 2) + 4 * h >= nB) cc[g] = __uint_as_float(XKEY_INF);
-        }
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bq[q][0], cc, 4, 4, 0, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[q][1], acc, 4, 4, 0, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a2, bq[q][2], acc, 4, 4, 0, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a3, bq[q][3], acc, 4, 4, 0, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) key_update_f(acc[g], k1[q], k2[q]);
-        }
+        if (t + 4 < nfull) nx = B[2 * ((t + 4) * 32 + r) + h];                  // in flight during this tile
+        mfma_tile(x, c, bq, k1, k2);
 #pragma unroll
         for (int g = 0; g < 16; ++g) c[g] += 128.0f * XIDX;                    // four tiles further
+    }
+    if ((nB & 31) && (nfull & 3) == seg) {
+        // c of this wave stands at tile seg + 4 * (its full tiles) = nfull
+        const uint4 x = B[2 * min(nfull * 32 + r, nB - 1) + h];
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            if (nfull * 32 + (g & 3) + 8 * (g >> 2) + 4 * h >= nB) c[g] = __uint_as_float(XKEY_INF);   // rows past the set never win
+        mfma_tile(x, c, bq, k1, k2);
     }
     // fold the two lane halves (rows 4h.. of every tile), then the four waves
 #pragma unroll
@@ -768,7 +777,7 @@ int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint
 
 int orbm_profile_enable(int on)
 {
-    g_prof.names[0] = "k_match_sets";
+    g_prof.names[0] = "k_match_sets_mfma";
     g_prof.reset();
     g_prof.mask = on ? 1u : 0u;
     return ORBX_OK;

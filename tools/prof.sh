@@ -11,3 +11,5 @@ rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_IN
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc4.log 2>&1
 find $OUT -name "*.csv" | head -20
+# matrix-core pass (the all-pairs matcher): optional, a missing counter must not lose the passes above
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 --output-format csv -d $OUT/pmc5 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc5.log 2>&1 || true
