@@ -46,6 +46,30 @@ def test_ties_first_index_wins():
     assert list(got[0]) == [1] * 4 and list(got[1]) == [1] * 4 and list(got[2]) == [0] * 4
 
 
+@pytest.mark.parametrize("nA,nB", [(3, 31), (33, 32), (129, 33), (64, 95), (130, 127), (7, 129), (40, 32768), (40, 32769)])
+def test_bruteforce_tile_edges_and_extreme_distances(nA, nB):
+    """The matrix-core kernel's corners: ragged / exactly full 32-row train tiles, a ragged query tile, the largest
+    train set whose index fits the key (32768; one more row takes the popcount kernel), distances 0 and 256
+    (complemented rows), duplicated rows (first index wins) and far-apart duplicates of the best row."""
+    rng = np.random.default_rng(nA * 100003 + nB)
+    A = rng.integers(0, 256, (nA, 32), dtype=np.uint8)
+    B = rng.integers(0, 256, (nB, 32), dtype=np.uint8)
+    B[nB - 1] = A[0]                 # distance 0 in the last (ragged) row
+    B[nB // 2] = A[0]                # ... and earlier: the earlier one must win, second = 0
+    if nA > 1:
+        B[nB // 3] = ~A[1]           # distance 256 somewhere
+    if nA > 2:
+        A[2] = 0
+        B[:] = np.where(rng.random((nB, 1)) < 0.5, 0xFF, B)     # half the train rows all ones: 256 from the zero query
+    got = ORBmatcher().match_bruteforce(A, B)
+    ref = oracle.match_bruteforce(A, B)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    Z = np.zeros((5, 32), np.uint8); F = np.full((nB, 32), 0xFF, np.uint8)          # every distance 256
+    got = ORBmatcher().match_bruteforce(Z, F)
+    assert list(got[0]) == [256] * 5 and list(got[2]) == [0] * 5 and list(got[1]) == [256 if nB > 1 else 2**31 - 1] * 5
+
+
 def test_candidate_lists():
     rng = np.random.default_rng(11)
     A, B, _ = synth_descriptors(500, seed=9)
