@@ -727,103 +727,99 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 // --------------------------------------------------------------------- blur
 
 
-// GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point:
-// horizontal 7 taps exact in u16, vertical 7 taps exact in u32, (v + 2^15) >> 16.
-// The padded pyramid already holds the reflected border, so no index clamping.
-// Tile = 64 x BLUR_TH outputs per 256-thread workgroup; the (72 x (BLUR_TH+6))-byte input
-// window is fetched as aligned dwords (x0 is a multiple of 64, rows start 32-B aligned).
-// Both passes are integer dot products (no MFMA: v_dot4_u32_u8 / v_dot2_u32_u16 are plain
-// VALU ops): horizontally the 7 taps of 4 adjacent pixels are at most three dot4 of the
-// three input dwords with shifted tap vectors; the u16 row sums are stored as VERTICAL
-// pairs (row 2p | row 2p+1 << 16), so that the 7 vertical taps of output rows 2p and 2p+1
-// are four dot2 each over the same four pair-dwords.
-constexpr int BLUR_TW = 64, BLUR_TH = 58;
-typedef unsigned short blur_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t w, uint32_t c)
-{
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_u16x2, a), __builtin_bit_cast(blur_u16x2, w), c, false);
-}
+// GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point: horizontal 7 taps exact in
+// u16, vertical 7 taps exact in u32, min((v + 2^15) >> 16, 255).  The padded pyramid already holds the
+// reflected border, so no index clamping.
+//
+// Both passes are products with a banded Toeplitz matrix of the taps, in exact integers on the i8 matrix
+// cores (v_mfma_i32_32x32x32_i8): one wave blurs one 32 x 32 input tile,
+//   H''[y'][x] = sum_k (P[y'][k] - 128) T[k - x - 1] + 128          (A = pixel rows as loaded, B = Toeplitz)
+//   V^T[x][y]  = sum_y' H[y'][x] T[y' - y]                            (A = the accumulator of the first product)
+// H'' fits 16 signed bits for tap sums up to 257 and goes into the second product as two i8 planes
+// (H'' >> 8 and (H'' & 255) - 128, eight v_perm_b32 + xor per 16 values); the constant terms of both offsets
+// ride in the accumulator seeds.  The first result has its column on the lane and its rows in the lane's 16
+// registers, which is exactly an A (or B) operand of the next MFMA -- no LDS, no lane movement -- and since a
+// dot product pairs operand bytes by position, the Toeplitz fragments (a 2-KB table built on the host) are
+// simply written in the order in which the lane holds its rows; the hardware's K order never enters.  Taking
+// the accumulator as A transposes the result: a lane ends with 16 x-consecutive outputs of ONE row, four per
+// dword store.  A tile yields 24 x 26 valid outputs (7 taps of support inside 32 inputs, dword-aligned in x).
+constexpr int BLUR_TW = 24, BLUR_TH = 26;
+typedef int blur_v4i __attribute__((ext_vector_type(4)));
+typedef int blur_v16i __attribute__((ext_vector_type(16)));
+// A wave blurs a strip of BLUR_TPW x-adjacent tiles (96 x 26 outputs) and stages it in LDS, so that the rows
+// leave as 16-byte pieces of 96 contiguous bytes instead of 4-byte pieces in 32 different lines.
+constexpr int BLUR_TPW = 4, BLUR_SW = BLUR_TPW * BLUR_TW, BLUR_LROW = 112;   // strip width; LDS row stride (7 x 16 B)
+// WIDE: tap sum 257 (blur_variant 1): H' = sum (P - 128) T needs a +128 bias to fit 16 signed bits, and the
+// result can exceed 255.  Otherwise the first product starts from 0 and nothing saturates.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               size_t frame_bytes, const LevelInfo *__restrict__ L,
-                                              const BlurTile *__restrict__ tiles, int t0, int t1, int t2, int t3)
+                                              const BlurTile *__restrict__ tiles, int ntiles,
+                                              const uint4 *__restrict__ frag, int seed2)
 {
-    constexpr int IW = BLUR_TW / 4 + 2, IH = BLUR_TH + 6, NP = IH / 2; // 18 dwords x 64 rows = 32 row pairs
-    static_assert(IH % 2 == 0, "row pairs");
-    __shared__ uint32_t in[IH][IW + 1];
-    __shared__ __align__(16) uint32_t hz[NP][BLUR_TW + 4]; // hz[p][x] = H(row 2p, x) | H(row 2p+1, x) << 16
-    int f, ti;
-    xcd_frame_item(f, ti);
+    __shared__ __align__(16) uint8_t stage[4][BLUR_TH * BLUR_LROW];
+    int f, wg;
+    xcd_frame_item(f, wg);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ti = wg * 4 + wave;
+    if (ti >= ntiles) return;
+    const int r = lane & 31, h = lane >> 5;
+    const uint4 f1 = frag[2 * lane], f2 = frag[2 * lane + 1];
+    const blur_v4i b1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w}, b2 = {(int)f2.x, (int)f2.y, (int)f2.z, (int)f2.w};
+    blur_v16i c1, c2, z;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { c1[g] = WIDE ? 128 : 0; c2[g] = seed2; z[g] = 0; }
     const BlurTile bt = tiles[ti];
     const LevelInfo lv = L[bt.level];
-    const int tid = threadIdx.x;
     const size_t base = (size_t)f * frame_bytes + lv.off + PADX;
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int x = bt.x0 - 4 + 4 * c, y = bt.y0 - 3 + r;
-        uint32_t v = 0;
-        if (x <= lv.w + EDGE - 4 && y < lv.h + EDGE) v = *reinterpret_cast<const uint32_t *>(pyr + base + (ptrdiff_t)(y + EDGE) * lv.stride + x);
-        in[r][c] = v;
-    }
-    // tap vectors: taps t0 t1 t2 t3 t2 t1 t0 sit on window bytes k+1 .. k+7 for output pixel k
-    // (pixel 4q+k = byte 4+k of the 12-byte window w0 | w1 | w2)
-    const uint32_t T[7] = {(uint32_t)t0, (uint32_t)t1, (uint32_t)t2, (uint32_t)t3, (uint32_t)t2, (uint32_t)t1, (uint32_t)t0};
-    uint32_t W[4][3];
+    uint8_t *const st = stage[wave];
+    // input rows y0-3 .. y0+28 (rows past the padded level are clamped: they only reach outputs that are not stored)
+    const uint8_t *src = pyr + base + (ptrdiff_t)(min(bt.y0 - 3 + r, lv.h + EDGE - 1) + EDGE) * lv.stride;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < BLUR_TPW; ++k) {
+        const int x0 = bt.x0 + BLUR_TW * k;
+        if (x0 >= lv.w) break;
+        // input columns x0-4 .. x0+27; a 16-byte chunk past the padded row is clamped like the rows
+        const uint4 p = *reinterpret_cast<const uint4 *>(src + min(x0 - 4 + 16 * h, lv.w + EDGE - 16));
+        const blur_v4i a1 = {(int)(p.x ^ 0x80808080u), (int)(p.y ^ 0x80808080u), (int)(p.z ^ 0x80808080u), (int)(p.w ^ 0x80808080u)};
+        const blur_v16i H = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c1, 0, 0, 0);
+        blur_v4i ah, al;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            uint32_t w = 0;
+        for (int d = 0; d < 4; ++d) {
+            // [b0(g), b0(g+1), b1(g), b1(g+1)] of two registers, then the low / high byte planes of four
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)H[4 * d + 1], (uint32_t)H[4 * d], 0x05010400u);
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)H[4 * d + 3], (uint32_t)H[4 * d + 2], 0x05010400u);
+            al[d] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+            ah[d] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+        }
+        const blur_v16i VL = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b2, c2, 0, 0, 0);
+        const blur_v16i VH = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b2, z, 0, 0, 0);
+        // lane = output row r; registers 4q .. 4q+3 = columns 8q + 4h + (0..3) of the tile
+        if (r < BLUR_TH) {
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const int tap = 4 * d + bb - (k + 1);
-                if (tap >= 0 && tap < 7) w |= T[tap] << (8 * bb);
+            for (int q = 0; q < 3; ++q) {
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = ((uint32_t)VH[4 * q + e] << 8) + (uint32_t)VL[4 * q + e];   // v + 2^15: the result is byte 2
+                    if (WIDE) o[e] = o[e] < 0x00ffffffu ? o[e] : 0x00ffffffu;
+                }
+                *reinterpret_cast<uint32_t *>(st + r * BLUR_LROW + BLUR_TW * k + 8 * q + 4 * h) =
+                    __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
             }
-            W[k][d] = w;
         }
-    __syncthreads();
-    for (int i = tid; i < NP * (BLUR_TW / 4); i += 256) {
-        const int p = i / (BLUR_TW / 4), q = i - p * (BLUR_TW / 4);
-        uint32_t o[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t w0 = in[2 * p + h][q], w1 = in[2 * p + h][q + 1], w2 = in[2 * p + h][q + 2];
-            o[h][0] = __builtin_amdgcn_udot4(w1, W[0][1], __builtin_amdgcn_udot4(w0, W[0][0], 0u, false), false);
-            o[h][1] = __builtin_amdgcn_udot4(w2, W[1][2], __builtin_amdgcn_udot4(w1, W[1][1], __builtin_amdgcn_udot4(w0, W[1][0], 0u, false), false), false);
-            o[h][2] = __builtin_amdgcn_udot4(w2, W[2][2], __builtin_amdgcn_udot4(w1, W[2][1], __builtin_amdgcn_udot4(w0, W[2][0], 0u, false), false), false);
-            o[h][3] = __builtin_amdgcn_udot4(w2, W[3][2], __builtin_amdgcn_udot4(w1, W[3][1], 0u, false), false);
-        }
-        uint4 v;
-        v.x = o[0][0] | (o[1][0] << 16); v.y = o[0][1] | (o[1][1] << 16); v.z = o[0][2] | (o[1][2] << 16); v.w = o[0][3] | (o[1][3] << 16);
-        *reinterpret_cast<uint4 *>(&hz[p][4 * q]) = v;
     }
-    __syncthreads();
-    // vertical: output rows 2p, 2p+1 (tile-relative) read H rows 2p .. 2p+7 = pairs p .. p+3
-    const uint32_t ve0 = (uint32_t)t0 | ((uint32_t)t1 << 16), ve1 = (uint32_t)t2 | ((uint32_t)t3 << 16),
-                   ve2 = (uint32_t)t2 | ((uint32_t)t1 << 16), ve3 = (uint32_t)t0;                         // even row: taps on rows 0..6
-    const uint32_t vo0 = (uint32_t)t0 << 16, vo1 = (uint32_t)t1 | ((uint32_t)t2 << 16),
-                   vo2 = (uint32_t)t3 | ((uint32_t)t2 << 16), vo3 = (uint32_t)t1 | ((uint32_t)t0 << 16); // odd row: rows 1..7
-    for (int i = tid; i < (BLUR_TH / 2) * (BLUR_TW / 4); i += 256) {
-        const int p = i / (BLUR_TW / 4), q = i - p * (BLUR_TW / 4);
-        const int x = bt.x0 + 4 * q, y = bt.y0 + 2 * p;
-        if (x >= lv.w || y >= lv.h) continue;
-        uint32_t a[4][4];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // rows out as 16-byte pieces: 6 per row
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&hz[p + j][4 * q]);
-            a[j][0] = v.x; a[j][1] = v.y; a[j][2] = v.z; a[j][3] = v.w;
-        }
-        uint32_t oe = 0, oo = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t se = blur_dot2(a[3][k], ve3, blur_dot2(a[2][k], ve2, blur_dot2(a[1][k], ve1, blur_dot2(a[0][k], ve0, 1u << 15))));
-            uint32_t so = blur_dot2(a[3][k], vo3, blur_dot2(a[2][k], vo2, blur_dot2(a[1][k], vo1, blur_dot2(a[0][k], vo0, 1u << 15))));
-            se >>= 16; so >>= 16;
-            se = se > 255u ? 255u : se; so = so > 255u ? 255u : so;
-            oe |= se << (8 * k); oo |= so << (8 * k);
-        }
-        uint8_t *dst = blur + base + (size_t)(y + EDGE) * lv.stride + x;
-        *reinterpret_cast<uint32_t *>(dst) = oe;
-        if (y + 1 < lv.h) *reinterpret_cast<uint32_t *>(dst + lv.stride) = oo;
+    for (int s = 0; s < (BLUR_TH * (BLUR_SW / 16) + 63) / 64; ++s) {
+        const int i = lane + 64 * s, row = i / (BLUR_SW / 16), c = i - row * (BLUR_SW / 16);
+        const int x = bt.x0 + 16 * c, y = bt.y0 + row;
+        if (row < BLUR_TH && y < lv.h && x < lv.w)
+            *reinterpret_cast<uint4 *>(blur + base + (size_t)(y + EDGE) * lv.stride + x) =
+                *reinterpret_cast<const uint4 *>(st + row * BLUR_LROW + 16 * c);
     }
 }
 
@@ -1008,12 +1004,12 @@ namespace {
 
 void free_workspace(orbx_extractor *ex)
 {
-    void *ptrs[] = {ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_xt, ex->d_yt, ex->d_cell_count,
+    void *ptrs[] = {ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_blur_frag, ex->d_xt, ex->d_yt, ex->d_cell_count,
                     ex->d_level_count, ex->d_level_ncand, ex->d_counts, ex->d_cands, ex->d_kpos, ex->d_sel,
                     ex->d_knode, ex->d_kq, ex->d_desc, ex->d_kps};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    ex->d_pyr = ex->d_blur = nullptr; ex->d_lv = nullptr; ex->d_cells = nullptr; ex->d_tiles = nullptr;
+    ex->d_pyr = ex->d_blur = nullptr; ex->d_lv = nullptr; ex->d_cells = nullptr; ex->d_tiles = nullptr; ex->d_blur_frag = nullptr;
     ex->d_xt = nullptr; ex->d_yt = nullptr; ex->d_cell_count = ex->d_level_count = ex->d_level_ncand = ex->d_counts = nullptr;
     ex->d_cands = ex->d_kpos = ex->d_sel = nullptr; ex->d_knode = nullptr; ex->d_kq = ex->d_desc = nullptr; ex->d_kps = nullptr;
     ex->width = ex->height = ex->batch = 0;
@@ -1196,7 +1192,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         sel_off += lv.N + 4;
         // blur tiles
         for (int y0 = 0; y0 < lv.h; y0 += BLUR_TH)
-            for (int x0 = 0; x0 < lv.w; x0 += BLUR_TW) {
+            for (int x0 = 0; x0 < lv.w; x0 += BLUR_SW) {
                 BlurTile t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0;
                 ex->tiles.push_back(t);
             }
@@ -1268,6 +1264,21 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ORBX_HIP(hipMemcpy(ex->d_lv, ex->lv, sizeof(LevelInfo) * MAXL, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_cells, ex->cells.data(), sizeof(CellInfo) * ex->cells.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_tiles, ex->tiles.data(), sizeof(BlurTile) * ex->tiles.size(), hipMemcpyHostToDevice));
+    {
+        // Toeplitz fragments of k_blur, per lane (r = lane & 31, h = lane >> 5), byte j of the 16-byte operand:
+        // first product: input column 16h + j feeds output column r with tap (16h + j) - r - 1;
+        // second product: the lane's j-th row is rho = (j & 3) + 8 (j >> 2) + 4h and feeds output row r with tap rho - r
+        const int T[7] = {ex->taps[0], ex->taps[1], ex->taps[2], ex->taps[3], ex->taps[2], ex->taps[1], ex->taps[0]};
+        uint8_t fr[64][2][16];
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+                const int r = lane & 31, h = lane >> 5, d1 = 16 * h + j - r - 1, d2 = (j & 3) + 8 * (j >> 2) + 4 * h - r;
+                fr[lane][0][j] = (uint8_t)(d1 >= 0 && d1 < 7 ? T[d1] : 0);
+                fr[lane][1][j] = (uint8_t)(d2 >= 0 && d2 < 7 ? T[d2] : 0);
+            }
+        ORBX_HIP(hipMalloc(&ex->d_blur_frag, sizeof(fr)));
+        ORBX_HIP(hipMemcpy(ex->d_blur_frag, fr, sizeof(fr), hipMemcpyHostToDevice));
+    }
     if (!xt.empty()) ORBX_HIP(hipMemcpy(ex->d_xt, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
     if (!yt.empty()) ORBX_HIP(hipMemcpy(ex->d_yt, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
     if (ex->oct_lds > 48 * 1024)
@@ -1333,8 +1344,18 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
                        ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap);
     pf.stop(3, st);
     pf.start(4, st);
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)ex->tiles.size(), batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
-                       ex->frame_bytes, ex->d_lv, ex->d_tiles, ex->taps[0], ex->taps[1], ex->taps[2], ex->taps[3]);
+    {
+        // with H'' = sum (P - 128) T + bias = 256 hi + lo' + 128:  H = H'' - bias + 128 S, so
+        // V + 2^15 = 256 sum(T hi) + sum(T lo') + S (128 - bias + 128 S) + 2^15     (S = tap sum, bias = 128 iff S > 256)
+        const int S = 2 * (ex->taps[0] + ex->taps[1] + ex->taps[2]) + ex->taps[3], nt = (int)ex->tiles.size();
+        const dim3 grid((unsigned)((nt + 3) / 4), batch);
+        if (S > 256)
+            hipLaunchKernelGGL(k_blur<true>, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->d_lv, ex->d_tiles, nt,
+                               ex->d_blur_frag, 128 * S * S + 32768);
+        else
+            hipLaunchKernelGGL(k_blur<false>, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->d_lv, ex->d_tiles, nt,
+                               ex->d_blur_frag, S * (128 + 128 * S) + 32768);
+    }
     pf.stop(4, st);
     pf.start(5, st);
     hipLaunchKernelGGL(k_describe, dim3((ex->kcap + DESC_KPB - 1) / DESC_KPB, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,

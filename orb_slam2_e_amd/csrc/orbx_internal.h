@@ -65,6 +65,7 @@ struct orbx_extractor {
     orbx_detail::LevelInfo *d_lv = nullptr;
     orbx_detail::CellInfo *d_cells = nullptr;
     orbx_detail::BlurTile *d_tiles = nullptr;
+    uint4 *d_blur_frag = nullptr; // Toeplitz operand fragments of k_blur, 2 x 16 bytes per lane
     int2 *d_xt = nullptr;
     int4 *d_yt = nullptr;
     int *d_cell_count = nullptr, *d_level_count = nullptr, *d_level_ncand = nullptr, *d_counts = nullptr;
