@@ -824,11 +824,17 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 }
 
 // ----------------------------------------------------- orientation + rBRIEF
+// Sum over the wave, returned wave-uniform: four row_shr steps leave each 16-lane row's total in its last lane,
+// row_bcast:15 / row_bcast:31 carry it across the rows into lane 63 (six DPP adds, no LDS traffic).
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // 16 keypoints per 256-thread workgroup (4 per wave).  Phase 0: one lane per
@@ -943,11 +949,17 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     // dwords starting at (x-18, y-18) (dword loads at byte addresses): the 512 sample
     // points are scattered over ~37 rows, and gathering them straight from global memory
     // costs ~30 cache-line requests per load.
-    float px[8], py[8];
+    // Rotation on packed f32 (v_pk_mul_f32 / v_pk_add_f32, the same IEEE operations as the scalar form):
+    // (x', y') = (px a - py b, px b + py a) = (px, px) * (a, b) + (-py, py) * (b, a); adding 1.5 * 2^23 rounds both to
+    // the nearest-even integer (= cvRound) and leaves 0x4B400000 + value in the bits, which feed the address
+    // multiply-add directly (its 24-bit multiplicand is 0x400000 + y').
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 PX[8], PY[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const signed char *pp = c_pattern + 16 * lane + 4 * t;
-        px[2 * t] = (float)pp[0]; py[2 * t] = (float)pp[1]; px[2 * t + 1] = (float)pp[2]; py[2 * t + 1] = (float)pp[3];
+        PX[2 * t] = f32x2{(float)pp[0], (float)pp[0]}; PY[2 * t] = f32x2{-(float)pp[1], (float)pp[1]};
+        PX[2 * t + 1] = f32x2{(float)pp[2], (float)pp[2]}; PY[2 * t + 1] = f32x2{-(float)pp[3], (float)pp[3]};
     }
     constexpr int PR = 18, PW = 10; // patch radius; row = 10 dwords = bytes x-18 .. x+21
     int prow[6], pcol[6];
@@ -967,14 +979,18 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj)
             if (prow[jj] >= 0) patch[lane + 64 * jj] = load_u32_unaligned(win + __mul24(prow[jj], stride) + pcol[jj]);
-        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR; // patch centre
-        unsigned nib = 0;
+        // patch centre, minus what the magic-number bits add: (0x400000 * 40 + 0x4B400000) mod 2^32
+        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR;
+        const f32x2 ab = {a, b}, ba = {b, a}, magic = {12582912.0f, 12582912.0f};
+        unsigned nib = 0, tv[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int t0 = pc[orbx_cvround(px[2 * t] * b + py[2 * t] * a) * (PW * 4) + orbx_cvround(px[2 * t] * a - py[2 * t] * b)];
-            const int t1 = pc[orbx_cvround(px[2 * t + 1] * b + py[2 * t + 1] * a) * (PW * 4) + orbx_cvround(px[2 * t + 1] * a - py[2 * t + 1] * b)];
-            nib |= (unsigned)(t0 < t1) << t;
+        for (int t = 0; t < 8; ++t) {
+            const f32x2 w = (PX[t] * ab + PY[t] * ba) + magic;
+            const unsigned off = __umul24(__float_as_uint(w.y), PW * 4) + __float_as_uint(w.x) - (0x400000u * (PW * 4) + 0x4B400000u);
+            tv[t] = pc[(int)off];
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) nib |= (unsigned)(tv[2 * t] < tv[2 * t + 1]) << t;
         const unsigned byte = nib | (__shfl_down(nib, 1) << 4); // even lanes
         const unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
         const size_t o = (size_t)f * cap + kbase + kp;
