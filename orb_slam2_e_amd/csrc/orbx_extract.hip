@@ -93,25 +93,36 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
 // Level l from level l-1: cv::resize INTER_LINEAR 8U fixed point
 // + REFLECT_101 border.  xt[dx] = {sx, a0 | a1<<16}, yt[dy] = {sy0, sy1, b0, b1}:
 // OpenCV's coefficient tables, built on the host.
+//
+// Workgroups 0 .. nxi-1 hold the interior dword groups (4 pixels with 0 <= x < w, no reflection): the source
+// columns of such a group are non-decreasing and span at most 8 bytes (the host checks it per level), so each
+// source row is ONE unaligned 8-byte load and a pixel's pair (S[sx], S[sx+1]) is one v_perm_b32 into two u16
+// halves, times (a0, a1) one v_dot2_u32_u16.  The last workgroup holds the groups that touch the border or the
+// row padding and takes them pixel by pixel through the reflected coordinate (nxi = 0: every group does).
+__device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, int b0, int b1)
+{
+    // every factor is below 2^24 and every product below 2^31: 24-bit multiplies are exact here
+    const uint32_t v = (uint32_t)((((__mul24(b0, r0 >> 4)) >> 16) + ((__mul24(b1, r1 >> 4)) >> 16) + 2) >> 2);
+    return v > 255u ? 255u : v;
+}
+typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
                                                    LevelInfo dst, const int2 *__restrict__ xt,
-                                                   const int4 *__restrict__ yt)
+                                                   const int4 *__restrict__ yt, int nxi)
 {
-    const int xw = blockIdx.x * 64 + threadIdx.x;
-    if (xw * 4 >= dst.stride) return;
-    const int f = blockIdx.z, px0 = xw * 4 - PADX;
-    // no per-pixel branches: pixels outside [-EDGE, w+EDGE) (row padding) take the column of a clamped coordinate and
-    // are masked out of the stored dword
-    int sxs[4], a0[4], a1[4];
-    uint32_t keep = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int px = px0 + b;
-        const bool in = px >= -EDGE && px < dst.w + EDGE;
-        const int2 xx = xt[reflect101(min(max(px, -EDGE), dst.w + EDGE - 1), dst.w)];
-        sxs[b] = xx.x; a0[b] = xx.y & 0xffff; a1[b] = xx.y >> 16;
-        keep |= in ? 0xffu << (8 * b) : 0u;
+    const int f = blockIdx.z, tid = threadIdx.x, ngi = dst.w >> 2; // interior groups: pixels 4i .. 4i+3 < w
+    const bool fast = (int)blockIdx.x < nxi;
+    int xw;
+    if (fast) {
+        const int i = blockIdx.x * 64 + tid;
+        if (i >= ngi) return;
+        xw = PADX / 4 + i;
+    } else if (nxi > 0) {
+        xw = tid < PADX / 4 ? tid : ngi + tid; // left padding + border, then everything right of the last interior group
+    } else {
+        xw = blockIdx.x * 64 + tid;
     }
+    if (xw * 4 >= dst.stride) return;
     int4 yy[PYR_ROWS];
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
@@ -120,27 +131,65 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     }
     const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
     uint32_t out[PYR_ROWS];
+    if (fast) {
+        const int px0 = xw * 4 - PADX;
+        const int4 xa = *reinterpret_cast<const int4 *>(xt + px0), xb = *reinterpret_cast<const int4 *>(xt + px0 + 2);
+        const int sx0 = xa.x;
+        const uint32_t coef[4] = {(uint32_t)xa.y, (uint32_t)xa.w, (uint32_t)xb.y, (uint32_t)xb.w};
+        // selector {byte o, 0, byte o+1, 0} of the 8-byte window, o = sx - sx0
+        const uint32_t sel[4] = {0x0c010c00u, 0x0c010c00u + (uint32_t)(xa.z - sx0) * 0x00010001u,
+                                 0x0c010c00u + (uint32_t)(xb.x - sx0) * 0x00010001u, 0x0c010c00u + (uint32_t)(xb.z - sx0) * 0x00010001u};
+        uint2 w0[PYR_ROWS], w1[PYR_ROWS];
 #pragma unroll
-    for (int r = 0; r < PYR_ROWS; ++r) {
-        const uint8_t *S0 = base + (size_t)(yy[r].x + EDGE) * src.stride;
-        const uint8_t *S1 = base + (size_t)(yy[r].y + EDGE) * src.stride;
-        out[r] = 0;
+        for (int r = 0; r < PYR_ROWS; ++r) {
+            __builtin_memcpy(&w0[r], base + (uint32_t)((yy[r].x + EDGE) * src.stride + sx0), 8);
+            __builtin_memcpy(&w1[r], base + (uint32_t)((yy[r].y + EDGE) * src.stride + sx0), 8);
+        }
+#pragma unroll
+        for (int r = 0; r < PYR_ROWS; ++r) {
+            out[r] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w0[r].y, w0[r].x, sel[b])),
+                                                           __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w1[r].y, w1[r].x, sel[b])),
+                                                           __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                out[r] |= resize_vertical(r0, r1, yy[r].z, yy[r].w) << (8 * b);
+            }
+        }
+    } else {
+        // no per-pixel branches: pixels outside [-EDGE, w+EDGE) (row padding) take the column of a clamped coordinate and
+        // are masked out of the stored dword
+        const int px0 = xw * 4 - PADX;
+        int sxs[4], a0[4], a1[4];
+        uint32_t keep = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            // every factor is below 2^24 and every product below 2^31: 24-bit multiplies are exact here
-            const int r0 = __mul24(S0[sxs[b]], a0[b]) + __mul24(S0[sxs[b] + 1], a1[b]);
-            const int r1 = __mul24(S1[sxs[b]], a0[b]) + __mul24(S1[sxs[b] + 1], a1[b]);
-            uint32_t v = (uint32_t)((((__mul24(yy[r].z, r0 >> 4)) >> 16) + ((__mul24(yy[r].w, r1 >> 4)) >> 16) + 2) >> 2);
-            v = v > 255u ? 255u : v;
-            out[r] |= v << (8 * b);
+            const int px = px0 + b;
+            const bool in = px >= -EDGE && px < dst.w + EDGE;
+            const int2 xx = xt[reflect101(min(max(px, -EDGE), dst.w + EDGE - 1), dst.w)];
+            sxs[b] = xx.x; a0[b] = xx.y & 0xffff; a1[b] = xx.y >> 16;
+            keep |= in ? 0xffu << (8 * b) : 0u;
         }
-        out[r] &= keep;
+#pragma unroll
+        for (int r = 0; r < PYR_ROWS; ++r) {
+            const uint8_t *S0 = base + (size_t)(yy[r].x + EDGE) * src.stride;
+            const uint8_t *S1 = base + (size_t)(yy[r].y + EDGE) * src.stride;
+            out[r] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int r0 = __mul24(S0[sxs[b]], a0[b]) + __mul24(S0[sxs[b] + 1], a1[b]);
+                const int r1 = __mul24(S1[sxs[b]], a0[b]) + __mul24(S1[sxs[b] + 1], a1[b]);
+                out[r] |= resize_vertical(r0, r1, yy[r].z, yy[r].w) << (8 * b);
+            }
+            out[r] &= keep;
+        }
     }
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
         const int row = blockIdx.y * PYR_ROWS + r;
         if (row < dst.h + 2 * EDGE)
-            *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (size_t)row * dst.stride + xw * 4) = out[r];
+            *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (uint32_t)(row * dst.stride + xw * 4)) = out[r];
     }
 }
 
@@ -824,6 +873,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 }
 
 // ----------------------------------------------------- orientation + rBRIEF
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+
 // Sum over the wave, returned wave-uniform: four row_shr steps leave each 16-lane row's total in its last lane,
 // row_bcast:15 / row_bcast:31 carry it across the rows into lane 63 (six DPP adds, no LDS traffic).
 __device__ __forceinline__ int wave_sum(int v)
@@ -918,11 +973,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         if (s_level[kp] < 0) continue;
-        const int stride = s_stride[kp];
-        const uint8_t *win = pyr + s_center[kp] - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
+        // wave-uniform values read from LDS: tell the compiler, so the loads take a scalar base + 32-bit lane offset
+        const int stride = __builtin_amdgcn_readfirstlane(s_stride[kp]);
+        const uint8_t *win = pyr + uniform_u64(s_center[kp]) - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
         uint32_t px[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) px[jj] = load_u32_unaligned(win + __mul24(vrow[jj], stride) + doff[jj]);
+        for (int jj = 0; jj < 4; ++jj) px[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(vrow[jj], stride) + doff[jj]));
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -974,11 +1030,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int level = s_level[kp];
         if (level < 0) continue;
         const float a = s_cos[kp], b = s_sin[kp];
-        const int stride = s_stride[kp];
-        const uint8_t *win = blur + s_center[kp] - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
+        const int stride = __builtin_amdgcn_readfirstlane(s_stride[kp]);
+        const uint8_t *win = blur + uniform_u64(s_center[kp]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj)
-            if (prow[jj] >= 0) patch[lane + 64 * jj] = load_u32_unaligned(win + __mul24(prow[jj], stride) + pcol[jj]);
+            if (prow[jj] >= 0) patch[lane + 64 * jj] = load_u32_unaligned(win + (uint32_t)(__mul24(prow[jj], stride) + pcol[jj]));
         // patch centre, minus what the magic-number bits add: (0x400000 * 40 + 0x4B400000) mod 2^32
         const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR;
         const f32x2 ab = {a, b}, ba = {b, a}, magic = {12582912.0f, 12582912.0f};
@@ -1213,6 +1269,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 ex->tiles.push_back(t);
             }
         // resize tables from level l-1
+        if (xt.size() & 1) xt.push_back(make_int2(0, 0));   // every level's table 16-byte aligned (int4 reads in k_pyr_resize)
         lv.xtab = (int)xt.size(); lv.ytab = (int)yt.size();
         if (l > 0) {
             const LevelInfo &sv = ex->lv[l - 1];
@@ -1224,6 +1281,15 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 if (s >= sv.w - 1) { s = sv.w - 1; a0 = 2048; a1 = 0; } // fx = 0, sx = w-1
                 xt.push_back(make_int2(s, a0 | (a1 << 16)));
             }
+            // interior dword groups read their source columns as one 8-byte window: sx non-decreasing, span <= 8 bytes
+            bool window_ok = true;
+            for (int d = 0; d + 3 < lv.w; d += 4) {
+                const int2 *g = &xt[lv.xtab + d];
+                for (int k = 1; k < 4; ++k) window_ok = window_ok && g[k].x >= g[k - 1].x;
+                window_ok = window_ok && g[3].x + 1 - g[0].x <= 7;
+            }
+            const int border_groups = PADX / 4 + lv.stride / 4 - PADX / 4 - (lv.w >> 2);
+            ex->resize_nxi[l] = (window_ok && border_groups <= 64) ? ((lv.w >> 2) + 63) / 64 : 0;
             resize_axis(lv.h, sv.h, o, c0, c1);
             for (int d = 0; d < lv.h; d++) {
                 const int s = o[d];
@@ -1337,10 +1403,11 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     }
     for (int l = 1; l < nl; l++) {
         const LevelInfo &lv = ex->lv[l];
-        dim3 g((lv.stride / 4 + 63) / 64, (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+        const int nxi = ex->resize_nxi[l];
+        dim3 g(nxi > 0 ? nxi + 1 : (lv.stride / 4 + 63) / 64, (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
         pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
-                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab);
+                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nxi);
         pf.stop(1, st);
     }
     pf.start(2, st);

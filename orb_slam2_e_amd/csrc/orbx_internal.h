@@ -48,6 +48,7 @@ struct orbx_extractor {
     float scale[orbx_detail::MAXL], inv_scale[orbx_detail::MAXL], sigma2[orbx_detail::MAXL], inv_sigma2[orbx_detail::MAXL];
     int nfeat[orbx_detail::MAXL];
     int taps[4];
+    int resize_nxi[orbx_detail::MAXL] = {}; // interior workgroups per row group of k_pyr_resize (0: no fast path at this level)
     int kcap; // nfeatures + 3*nlevels
 
     // geometry of the reserved workspace
