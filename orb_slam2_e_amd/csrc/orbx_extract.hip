@@ -958,8 +958,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
     }
     __syncthreads();
+    if (s_level[0] < 0) return; // keypoint slots fill from 0: nothing in this block
     // IC_Angle (:77-104): every lane owns 4 dwords of the 31x31 window (fixed per lane, so are
     // their weights) and reads them straight from the unblurred level; two dot4 per dword.
+    // No branches on "slot in use": an unused slot reads the window of slot 0 (in use, see above) and its results are
+    // dropped, so the loads of all four keypoints of a wave are in flight together.
     uint32_t *patch = s_patch[wv];
     uint32_t wS[4], wT[4];
     int vrow[4], doff[4];
@@ -970,26 +973,32 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         wS[jj] = in ? c_momw.s[d] : 0u; wT[jj] = in ? c_momw.t[d] : 0u;
         vrow[jj] = (in ? d : 0) >> 3; doff[jj] = 4 * (d & 7);
     }
-    for (int j = 0; j < DESC_KPB / 4; ++j) {
-        const int kp = wv * (DESC_KPB / 4) + j;
-        if (s_level[kp] < 0) continue;
-        // wave-uniform values read from LDS: tell the compiler, so the loads take a scalar base + 32-bit lane offset
-        const int stride = __builtin_amdgcn_readfirstlane(s_stride[kp]);
-        const uint8_t *win = pyr + uniform_u64(s_center[kp]) - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
-        uint32_t px[4];
+    {
+        uint32_t px[DESC_KPB / 4][4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) px[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(vrow[jj], stride) + doff[jj]));
-        int m10 = 0, m01 = 0;
+        for (int j = 0; j < DESC_KPB / 4; ++j) {
+            const int kp = wv * (DESC_KPB / 4) + j, kpv = s_level[kp] >= 0 ? kp : 0;
+            // wave-uniform values read from LDS: tell the compiler, so the loads take a scalar base + 32-bit lane offset
+            const int stride = __builtin_amdgcn_readfirstlane(s_stride[kpv]);
+            const uint8_t *win = pyr + uniform_u64(s_center[kpv]) - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int sS = (int)__builtin_amdgcn_udot4(px[jj], wS[jj], 0u, false);
-            const int sT = (int)__builtin_amdgcn_udot4(px[jj], wT[jj], 0u, false);
-            m10 += sT - 15 * sS;
-            m01 += (vrow[jj] - 15) * sS;
+            for (int jj = 0; jj < 4; ++jj) px[j][jj] = load_u32_unaligned(win + (uint32_t)(__mul24(vrow[jj], stride) + doff[jj]));
         }
-        m10 = wave_sum(m10);
-        m01 = wave_sum(m01);
-        if (lane == 0) { s_m10[kp] = m10; s_m01[kp] = m01; }
+#pragma unroll
+        for (int j = 0; j < DESC_KPB / 4; ++j) {
+            const int kp = wv * (DESC_KPB / 4) + j;
+            int m10 = 0, m01 = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int sS = (int)__builtin_amdgcn_udot4(px[j][jj], wS[jj], 0u, false);
+                const int sT = (int)__builtin_amdgcn_udot4(px[j][jj], wT[jj], 0u, false);
+                m10 += sT - 15 * sS;
+                m01 += (vrow[jj] - 15) * sS;
+            }
+            m10 = wave_sum(m10);
+            m01 = wave_sum(m01);
+            if (lane == 0) { s_m10[kp] = m10; s_m01[kp] = m01; }
+        }
     }
     __syncthreads();
     if (tid < DESC_KPB && s_level[tid] >= 0) {
@@ -1025,16 +1034,31 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         prow[jj] = d < (2 * PR + 1) * PW ? d / PW : -1;
         pcol[jj] = 4 * (d % PW);
     }
+    // the six patch dwords of keypoint j+1 are loaded while keypoint j is evaluated (unused slots read slot 0's patch)
+    uint32_t nxt[6];
+    {
+        const int kpv = s_level[wv * (DESC_KPB / 4)] >= 0 ? wv * (DESC_KPB / 4) : 0;
+        const int stride = __builtin_amdgcn_readfirstlane(s_stride[kpv]);
+        const uint8_t *win = blur + uniform_u64(s_center[kpv]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) nxt[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(max(prow[jj], 0), stride) + pcol[jj]));
+    }
+#pragma unroll
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
         const int level = s_level[kp];
-        if (level < 0) continue;
         const float a = s_cos[kp], b = s_sin[kp];
-        const int stride = __builtin_amdgcn_readfirstlane(s_stride[kp]);
-        const uint8_t *win = blur + uniform_u64(s_center[kp]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj)
-            if (prow[jj] >= 0) patch[lane + 64 * jj] = load_u32_unaligned(win + (uint32_t)(__mul24(prow[jj], stride) + pcol[jj]));
+            if (prow[jj] >= 0) patch[lane + 64 * jj] = nxt[jj];
+        if (j + 1 < DESC_KPB / 4) {
+            const int kpv = s_level[kp + 1] >= 0 ? kp + 1 : 0;
+            const int stride = __builtin_amdgcn_readfirstlane(s_stride[kpv]);
+            const uint8_t *win = blur + uniform_u64(s_center[kpv]) - PR - (ptrdiff_t)PR * stride;
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) nxt[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(max(prow[jj], 0), stride) + pcol[jj]));
+        }
+        if (level < 0) continue;
         // patch centre, minus what the magic-number bits add: (0x400000 * 40 + 0x4B400000) mod 2^32
         const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR;
         const f32x2 ab = {a, b}, ba = {b, a}, magic = {12582912.0f, 12582912.0f};
