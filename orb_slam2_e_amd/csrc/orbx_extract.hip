@@ -798,6 +798,7 @@ typedef int blur_v16i __attribute__((ext_vector_type(16)));
 // A wave blurs a strip of BLUR_TPW x-adjacent tiles (96 x 26 outputs) and stages it in LDS, so that the rows
 // leave as 16-byte pieces of 96 contiguous bytes instead of 4-byte pieces in 32 different lines.
 constexpr int BLUR_TPW = 4, BLUR_SW = BLUR_TPW * BLUR_TW, BLUR_LROW = 112;   // strip width; LDS row stride (7 x 16 B)
+constexpr int BLUR_IROW = 144;                                                 // LDS row stride of the 128-byte input window
 // WIDE: tap sum 257 (blur_variant 1): H' = sum (P - 128) T needs a +128 bias to fit 16 signed bits, and the
 // result can exceed 255.  Otherwise the first product starts from 0 and nothing saturates.
 template <bool WIDE>
@@ -807,6 +808,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
                                               const uint4 *__restrict__ frag, int seed2)
 {
     __shared__ __align__(16) uint8_t stage[4][BLUR_TH * BLUR_LROW];
+    __shared__ __align__(16) uint8_t win[4][32 * BLUR_IROW];
     int f, wg;
     xcd_frame_item(f, wg);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -821,15 +823,27 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const BlurTile bt = tiles[ti];
     const LevelInfo lv = L[bt.level];
     const size_t base = (size_t)f * frame_bytes + lv.off + PADX;
-    uint8_t *const st = stage[wave];
-    // input rows y0-3 .. y0+28 (rows past the padded level are clamped: they only reach outputs that are not stored)
-    const uint8_t *src = pyr + base + (ptrdiff_t)(min(bt.y0 - 3 + r, lv.h + EDGE - 1) + EDGE) * lv.stride;
+    uint8_t *const st = stage[wave], *const wn = win[wave];
+    // input window: rows y0-3 .. y0+28, columns x0-16 .. x0+111 as 8 aligned 16-byte pieces per row (whole 128-byte
+    // lines per row instead of 32 bytes of 32 different lines per load).  Rows past the padded level and pieces past
+    // the padded row are clamped: they only reach outputs that are not stored.
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int i = lane + 64 * s4, row = i >> 3, pc = i & 7;
+        const int yin = min(bt.y0 - 3 + row, lv.h + EDGE - 1), xo = min(PADX + bt.x0 - 16 + 16 * pc, lv.stride - 16);
+        *reinterpret_cast<uint4 *>(wn + row * BLUR_IROW + 16 * pc) =
+            *reinterpret_cast<const uint4 *>(pyr + (base - PADX) + (uint32_t)((yin + EDGE) * lv.stride + xo));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int k = 0; k < BLUR_TPW; ++k) {
         const int x0 = bt.x0 + BLUR_TW * k;
         if (x0 >= lv.w) break;
-        // input columns x0-4 .. x0+27; a 16-byte chunk past the padded row is clamped like the rows
-        const uint4 p = *reinterpret_cast<const uint4 *>(src + min(x0 - 4 + 16 * h, lv.w + EDGE - 16));
+        // tile k: input columns x0-4 .. x0+27 = window bytes 12 + 24k ..; this lane's 16 of them
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(wn + r * BLUR_IROW + 12 + BLUR_TW * k + 16 * h);
+        const uint4 p = make_uint4(q[0], q[1], q[2], q[3]);
         const blur_v4i a1 = {(int)(p.x ^ 0x80808080u), (int)(p.y ^ 0x80808080u), (int)(p.z ^ 0x80808080u), (int)(p.w ^ 0x80808080u)};
         const blur_v16i H = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, c1, 0, 0, 0);
         blur_v4i ah, al;
