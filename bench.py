@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--host-io", action="store_true", help="also time the PCIe-inclusive path (host images in, host results out)")
     ap.add_argument("--no-fem", action="store_true")
+    ap.add_argument("--match-kernel", choices=["auto", "popcount"], default="auto",
+                    help="all-pairs matcher: auto = FP4 matrix-core kernel (default), popcount = XOR + v_bcnt kernel; same results")
     ap.add_argument("--fem-meshes", type=int, default=256)
     args = ap.parse_args()
 
@@ -249,6 +251,8 @@ def main():
     d_frames = torch.from_numpy(frames).to(dev)
     m = ORBmatcher(0.6)
     L = lib()
+    if args.match_kernel == "popcount":
+        ORBmatcher.set_allpairs_kernel(ORBmatcher.ALLPAIRS_POPCOUNT)
     qa = torch.arange(BATCH, dtype=torch.int32, device=dev)
     qb = ((qa + 1) % BATCH).to(torch.int32)
 
@@ -430,6 +434,7 @@ def main():
             "config": {"workload": "1xMI355X: batch of 64 synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
                                    "+ 2000x2000 brute-force Hamming match per frame",
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
+                       "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma (FP4 matrix cores)",
                        "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0" if world > 1 else "single GPU",
                        "mean_keypoints_per_frame": float(counts.float().mean().item()),
                        "mean_matches_per_frame": float(nmatch.float().mean().item())},
@@ -443,12 +448,12 @@ def main():
         nk = counts.double().clamp(max=cap).cpu()
         pair_flops = 512.0 * float((nk[qa.cpu().long()] * nk[qb.cpu().long()]).sum())
         mm_ms = split_ms.get("k_match_sets_mfma", 0.0)
-        if mm_ms > 0:
+        if mm_ms > 0 and args.match_kernel != "popcount":
             out["matcher_mfma"] = {"kernel": "k_match_sets_mfma", "bound": "mfma", "achieved": pair_flops / (mm_ms * 1e-3) / 1e12,
                                    "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pair_flops / (mm_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                                    "flops_per_launch": pair_flops, "launch_ms_untimed_pass": mm_ms,
                                    "note": "FP4 MFMA computes the selection keys; the top-2 fold (2 VALU instructions per pair) bounds it"}
-        if dom == "k_match_sets_mfma":
+        if dom == "k_match_sets_mfma" and args.match_kernel != "popcount":
             tf = pair_flops / (avg_launch_ms * 1e-3) / 1e12
             out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf / MFMA_FP4_PEAK_TFLOPS, "flops_per_launch": pair_flops})

@@ -327,7 +327,15 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
                          int32_t *best_dev, int32_t *second_dev, int32_t *idx_dev,
                          int32_t *match12_dev, int32_t *nmatch_dev, void *stream);
 
-/* HIP-event timing of the all-pairs kernel (k_match_sets_mfma) launched through orbm_match_batch_dev. */
+/* Which kernel the all-pairs matchers (orbm_match_batch_dev, orbm_match_bruteforce) launch.  Both produce the same
+ * integers.  ORBM_ALLPAIRS_AUTO (default): the matrix-core kernel (FP4 MFMA computes the selection keys, 3.5x
+ * faster at 2000 x 2000) for sets up to 32768 rows, the XOR + popcount kernel above that; ORBM_ALLPAIRS_POPCOUNT:
+ * always the wavefront popcount + LDS-reduction kernel BASELINE.json's north_star describes; ORBM_ALLPAIRS_MFMA:
+ * as AUTO.  Process-wide; returns the previous setting, or a negative status for an unknown value. */
+enum { ORBM_ALLPAIRS_AUTO = 0, ORBM_ALLPAIRS_POPCOUNT = 1, ORBM_ALLPAIRS_MFMA = 2 };
+int orbm_set_allpairs_kernel(int kind);
+
+/* HIP-event timing of the all-pairs kernel launched through orbm_match_batch_dev. */
 int orbm_profile_enable(int on);
 int orbm_profile_read(double *total_ms, int64_t *launches);
 

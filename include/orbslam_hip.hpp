@@ -166,6 +166,9 @@ public:
         return n;
     }
 
+    // Which kernel MatchBruteForce (and orbm_match_batch_dev) launch: ORBM_ALLPAIRS_AUTO / _POPCOUNT / _MFMA; same results.
+    static int SetAllPairsKernel(int kind) { return orbm_set_allpairs_kernel(kind); }
+
     int MatchBruteForce(const uint8_t *A, int nA, const uint8_t *B, int nB, int th, std::vector<int32_t> &vnMatches12)
     {
         std::vector<int32_t> best(nA), second(nA), idx(nA);

@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -516,11 +517,14 @@ void workspace_release(Workspace *w)
 
 } // namespace orbm_detail
 
-// All-pairs launch: matrix-core kernel while the train index fits the key's 15 fraction bits.
+static std::atomic<int> g_allpairs_kind{ORBM_ALLPAIRS_AUTO};
+
+// All-pairs launch: matrix-core kernel while the train index fits the key's 15 fraction bits (unless the caller
+// asked for the popcount kernel, orbm_set_allpairs_kernel).
 static void launch_match_sets(hipStream_t st, const uint8_t *desc, const int *counts, int cap, const int *qa, const int *qb, int npairs,
                               int th, float nnratio, int *best, int *second, int *idx, int *match12, int *nmatch)
 {
-    if (cap <= XMAXN)
+    if (cap <= XMAXN && g_allpairs_kind.load(std::memory_order_relaxed) != ORBM_ALLPAIRS_POPCOUNT)
         hipLaunchKernelGGL(k_match_sets_mfma, dim3((cap + 32 * XQ - 1) / (32 * XQ), npairs), dim3(256), 0, st, desc, counts, cap, qa, qb,
                            th, nnratio, best, second, idx, match12, nmatch);
     else
@@ -773,6 +777,12 @@ int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint
     if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
     memcpy(out, sc.r<uint16_t>(o_o), sizeof(uint16_t) * (size_t)nA * nB);
     return ORBX_OK;
+}
+
+int orbm_set_allpairs_kernel(int kind)
+{
+    if (kind != ORBM_ALLPAIRS_AUTO && kind != ORBM_ALLPAIRS_POPCOUNT && kind != ORBM_ALLPAIRS_MFMA) return ORBX_ERR_ARG;
+    return g_allpairs_kind.exchange(kind);
 }
 
 int orbm_profile_enable(int on)

@@ -39,6 +39,16 @@ class ORBmatcher:
         check(L.orbm_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(out)))
         return out
 
+    ALLPAIRS_AUTO, ALLPAIRS_POPCOUNT, ALLPAIRS_MFMA = 0, 1, 2
+
+    @staticmethod
+    def set_allpairs_kernel(kind):
+        """orbm_set_allpairs_kernel: which kernel the all-pairs matchers launch (process-wide); returns the previous one."""
+        prev = lib().orbm_set_allpairs_kernel(int(kind))
+        if prev < 0:
+            raise ValueError("unknown all-pairs kernel kind")
+        return prev
+
     def match_bruteforce(self, A, B):
         A = np.ascontiguousarray(A, np.uint8); B = np.ascontiguousarray(B, np.uint8)
         nA = len(A)

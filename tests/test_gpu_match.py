@@ -23,8 +23,16 @@ def test_known_answers():
     assert ORBmatcher.DescriptorDistance(z, one) == 1
 
 
+@pytest.fixture(params=["matrix cores", "popcount"])
+def allpairs_kernel(request):
+    """Both all-pairs kernels behind orbm_match_bruteforce / orbm_match_batch_dev must give the same integers."""
+    prev = ORBmatcher.set_allpairs_kernel(ORBmatcher.ALLPAIRS_POPCOUNT if request.param == "popcount" else ORBmatcher.ALLPAIRS_AUTO)
+    yield request.param
+    ORBmatcher.set_allpairs_kernel(prev)
+
+
 @pytest.mark.parametrize("nA,nB", [(2000, 2000), (1, 1), (257, 3), (5, 1000), (2024, 2024), (100, 0)])
-def test_bruteforce_config2(nA, nB):
+def test_bruteforce_config2(nA, nB, allpairs_kernel):
     A, B, _ = synth_descriptors(max(nA, nB, 1), seed=7)
     A, B = A[:nA], B[:nB]
     m = ORBmatcher(0.6)
@@ -47,7 +55,7 @@ def test_ties_first_index_wins():
 
 
 @pytest.mark.parametrize("nA,nB", [(3, 31), (33, 32), (129, 33), (64, 95), (130, 127), (7, 129), (40, 32768), (40, 32769)])
-def test_bruteforce_tile_edges_and_extreme_distances(nA, nB):
+def test_bruteforce_tile_edges_and_extreme_distances(nA, nB, allpairs_kernel):
     """The matrix-core kernel's corners: ragged / exactly full 32-row train tiles, a ragged query tile, the largest
     train set whose index fits the key (32768; one more row takes the popcount kernel), distances 0 and 256
     (complemented rows), duplicated rows (first index wins) and far-apart duplicates of the best row."""
