@@ -431,8 +431,9 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1xMI355X: batch of 64 synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
-                                   "+ 2000x2000 brute-force Hamming match per frame",
+            "config": {"workload": (f"{world}xMI355X: {world * BATCH}-frame batch sharded {BATCH}/GPU, " if world > 1 else
+                                    f"1xMI355X: batch of {BATCH} ") + "synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
+                                   "+ 2000x2000 brute-force Hamming match per frame" + (", RCCL gather on rank 0" if world > 1 else ""),
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
                        "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma (FP4 matrix cores)",
                        "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0" if world > 1 else "single GPU",
