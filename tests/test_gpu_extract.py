@@ -121,6 +121,29 @@ def test_other_shapes_and_params(shape, params):
     assert np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("shape,params", [
+    ((760, 700), (400, 2.5, 3, 20, 7)),     # scale 2.5: a dword group's source columns span > 8 bytes -> no resize fast path
+    ((410, 333), (600, 3.0, 2, 15, 5)),
+    ((97 * 4 + 1, 251), (500, 1.2, 6, 20, 7)),   # w = 4k + 1: a partial interior group next to the border at every level
+    ((96 * 3, 26 * 7), (500, 1.2, 4, 20, 7)),    # level 0 exactly 3 x 7 blur strips
+    ((96 * 3 + 1, 26 * 7 + 1), (500, 1.2, 4, 20, 7)),   # ... and one pixel more in both directions
+    ((463, 431), (300, 1.44, 4, 12, 4)),
+])
+def test_pyramid_and_blur_paths(shape, params):
+    """Every level of the padded pyramid and of the blurred pyramid, bit for bit, on shapes that hit the resize
+    kernel's interior / border split (and its fallback) and the blur's strip and tile edges."""
+    w, h = shape
+    img = synth_frame(5, w, h)
+    o = oracle.OrbOracle(*params)
+    o.extract(img)
+    ex = ORBextractor(*params)
+    ex(img)
+    for l in range(params[2]):
+        lw, lh, _ = o.level_dims(l)
+        assert np.array_equal(ex.pyramid_level(0, l, padded=True), o.level_padded(l)[:, :lw + 38]), f"padded level {l}"
+        assert np.array_equal(ex.blurred_level(0, l), o.level_blurred(l)), f"blurred level {l}"
+
+
 def test_sparse_image_threshold_fallback_and_short_levels():
     # few weak corners: exercises the minThFAST fallback and levels below quota
     rng = np.random.default_rng(5)
