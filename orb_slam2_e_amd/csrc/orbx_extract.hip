@@ -424,8 +424,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
                 const uint8_t *q = sc + (y + 1) * SS + x + 1;
                 const int s = q[0];
-                ismax = s > 0 && s > q[-1] && s > q[1] && s > q[-SS - 1] && s > q[-SS] && s > q[-SS + 1] &&
-                        s > q[SS - 1] && s > q[SS] && s > q[SS + 1];
+                // strictly above all eight neighbours (scores are >= 0, so this also says s > 0); no short-circuit
+                // branches: eight LDS bytes, three v_max3, one compare
+                const int m = max(max(max(q[-1], q[1]), max(q[-SS - 1], q[-SS])), max(max(q[-SS + 1], q[SS - 1]), max(q[SS], q[SS + 1])));
+                ismax = s > m;
                 ishi = ismax && s >= iniTh;
             }
             mx |= (unsigned long long)ismax << it;
