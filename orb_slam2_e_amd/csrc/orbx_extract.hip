@@ -409,9 +409,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         for (int q0 = 0; q0 < nq; q0 += 64) {
             if (q0 + lane < nq) {
                 const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                // e_k = sgn (v - p_k) as one multiply-add per circle pixel: sgn v - sgn p_k
+                const uint8_t *t = t0 + y * TS + x;
+                const int sgn = (e >> 12) == 1 ? 1 : -1, sv = sgn * (int)t[0], ns = -sgn;
                 int d[16];
-                fast_diffs(t0 + y * TS + x, TS, d);
-                sc[(y + 1) * SS + x + 1] = (uint8_t)fast_arc_score(d, (e >> 12) == 1 ? 1 : -1, minTh);
+                d[0] = __mul24(t[3 * TS], ns) + sv;       d[1] = __mul24(t[3 * TS + 1], ns) + sv;   d[2] = __mul24(t[2 * TS + 2], ns) + sv;
+                d[3] = __mul24(t[TS + 3], ns) + sv;       d[4] = __mul24(t[3], ns) + sv;            d[5] = __mul24(t[-TS + 3], ns) + sv;
+                d[6] = __mul24(t[-2 * TS + 2], ns) + sv;  d[7] = __mul24(t[-3 * TS + 1], ns) + sv;  d[8] = __mul24(t[-3 * TS], ns) + sv;
+                d[9] = __mul24(t[-3 * TS - 1], ns) + sv;  d[10] = __mul24(t[-2 * TS - 2], ns) + sv; d[11] = __mul24(t[-TS - 3], ns) + sv;
+                d[12] = __mul24(t[-3], ns) + sv;          d[13] = __mul24(t[TS - 3], ns) + sv;      d[14] = __mul24(t[2 * TS - 2], ns) + sv;
+                d[15] = __mul24(t[3 * TS - 1], ns) + sv;
+                sc[(y + 1) * SS + x + 1] = (uint8_t)fast_arc_score(d, 1, minTh);
             }
         }
         __syncthreads();
