@@ -481,13 +481,13 @@ __device__ void block_excl_scan2(int *a, int *b, int n, int *part, int &ta, int 
         const int va = __shfl_up(ia, off), vb = __shfl_up(ib, off);
         if (lane >= off) { ia += va; ib += vb; }
     }
-    if (lane == 63) { part[w] = ia; part[4 + w] = ib; }
+    if (lane == 63) { part[w] = ia; part[OCT_T / 64 + w] = ib; }
     __syncthreads();
     int ba = 0, bb = 0, ga = 0, gb = 0;
 #pragma unroll
     for (int i = 0; i < OCT_T / 64; ++i) {
-        if (i < w) { ba += part[i]; bb += part[4 + i]; }
-        ga += part[i]; gb += part[4 + i];
+        if (i < w) { ba += part[i]; bb += part[OCT_T / 64 + i]; }
+        ga += part[i]; gb += part[OCT_T / 64 + i];
     }
     int ra = ba + ia - sa, rb = bb + ib - sb;
     for (int i = lo; i < hi; ++i) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 {
     extern __shared__ __align__(16) unsigned char smem[];
     int *p = reinterpret_cast<int *>(smem);
-    int *part = p;          p += 8;
+    int *part = p;          p += 2 * (OCT_T / 64);
     int *s_cell = p;        p += (maxcells + 1 + 3) & ~3;
     int *s_coff = p;        p += (maxcells + 1 + 3) & ~3; // each cell's slot in the candidate buffer
     int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
@@ -1367,7 +1367,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
     ex->oct_kcap = ex->NC > 1100 ? 3072 : 4096; // keys of a level live in LDS up to this many, else in HBM
     if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
-    ex->oct_lds = (int)sizeof(int) * (8 + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
+    ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     const size_t B = (size_t)batch;
