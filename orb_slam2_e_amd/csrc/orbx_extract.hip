@@ -257,6 +257,20 @@ __device__ __forceinline__ void fast_pick(const uint32_t r[3], u16x2 &E, u16x2 &
     E = pk2(__builtin_amdgcn_perm(hi, lo, selE));
     O = pk2(__builtin_amdgcn_perm(hi, lo, selO));
 }
+// Both u16 halves: a > b ? 1 : 0, as v_pk_sub_u16 with clamp + v_pk_min_u16.  Written in asm because the compiler
+// rewrites min(sub_sat(a, b), 1) into two 16-bit compares, two selects and a v_perm (six instructions instead of two);
+// the operands come from VALU instructions, so there is no software-visible hazard to pad.
+__device__ __forceinline__ uint32_t pk_gt01(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(0x00010001u));
+    return d;
+}
+// number of set bits of a wave mask below this lane
+__device__ __forceinline__ int mask_rank(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 template <int TS>
 __device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2)
 {
@@ -290,14 +304,12 @@ __device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2
 #undef ORBX_PAIR
     u16x2 vE, vO;
     fast_pick<0>(r[3], vE, vO);
-    const u16x2 t = pk2(th2), one = pk2(0x00010001u);
-    // saturating differences: non-zero half = condition holds
-    const u16x2 dE = __builtin_elementwise_min(__builtin_elementwise_sub_sat(vE, loE + t), one);
-    const u16x2 dO = __builtin_elementwise_min(__builtin_elementwise_sub_sat(vO, loO + t), one);
-    const u16x2 gE = __builtin_elementwise_min(__builtin_elementwise_sub_sat(hiE, vE + t), one);
-    const u16x2 gO = __builtin_elementwise_min(__builtin_elementwise_sub_sat(hiO, vO + t), one);
+    const u16x2 t = pk2(th2);
+    // per half "a > b" as 0 / 1: saturating difference clamped to 1
+    const uint32_t dE = pk_gt01(pk1(vE), pk1(loE + t)), dO = pk_gt01(pk1(vO), pk1(loO + t));
+    const uint32_t gE = pk_gt01(pk1(hiE), pk1(vE + t)), gO = pk_gt01(pk1(hiO), pk1(vO + t));
     // bytes 0..3 = pixels 0..3: dark | bright << 1; both set cannot be a corner -> 0
-    uint32_t code = (pk1(dE) | (pk1(gE) << 1)) | ((pk1(dO) | (pk1(gO) << 1)) << 8);
+    uint32_t code = (dE | (gE << 1)) | ((dO | (gO << 1)) << 8);
     code &= ~((code & (code >> 1) & 0x01010101u) * 3u);
     return code;
 }
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     const uint32_t nz = (code | (code >> 1)) & 0x01010101u;
                     const int n = __popc(nz);
                     const unsigned long long c0 = __ballot(n & 1), c1 = __ballot(n & 2), c2 = __ballot(n & 4);
-                    int pos = nq + __popcll(c0 & lt) + 2 * __popcll(c1 & lt) + 4 * __popcll(c2 & lt);
+                    int pos = nq + mask_rank(c0) + 2 * mask_rank(c1) + 4 * mask_rank(c2);
                     const int ent = (y << 6) + xs;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { // branch-free: rejected pixels go to the lane's dump slot
