@@ -1107,8 +1107,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) nib |= (unsigned)(tv[2 * t] < tv[2 * t + 1]) << t;
-        const unsigned byte = nib | (__shfl_down(nib, 1) << 4); // even lanes
-        const unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
+        // lanes 8j .. 8j+7 hold the eight nibbles of dword j: DPP row_shl (lane i reads lane i+n of its 16-lane row)
+        const unsigned byte = nib | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xf, 0xf, true) << 4); // even lanes
+        const unsigned w = byte | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x102, 0xf, 0xf, true) << 8) |
+                           ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x104, 0xf, 0xf, true) << 16) |
+                           ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x106, 0xf, 0xf, true) << 24);
         const size_t o = (size_t)f * cap + kbase + kp;
         if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
         if (lane == 0) {
