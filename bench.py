@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: steps of a context whose records travel in one RCCL gather (default: every step; larger values "
+                         "= fewer, larger collectives, each gather costing two cross-stream dependencies; partial buckets are "
+                         "flushed before every barrier).  Not measurable on the one-GPU development box: tune against SCALE_rNN.json")
     ap.add_argument("--pipeline", type=int, default=3, help="independent contexts/streams the steps rotate over")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--host-io", action="store_true", help="also time the PCIe-inclusive path (host images in, host results out)")
@@ -280,17 +284,31 @@ def main():
     rec_bytes = n_kps + n_desc + n_cnt + n_m12 + n_cnt
     counts_t = torch.zeros(BATCH, dtype=torch.int32, device=dev)
     do_gather = world > 1 and not args.no_gather
+    GE = max(1, args.gather_every)
     for c in ctxs:
-        c.send = torch.empty(rec_bytes, dtype=torch.uint8, device=dev) if do_gather else None
-        c.recv = [torch.empty(rec_bytes, dtype=torch.uint8, device=cdev) for _ in range(world)] if (do_gather and rank == 0) else None
+        c.nfill = 0   # records waiting in c.send
+        c.send = torch.empty(GE * rec_bytes, dtype=torch.uint8, device=dev) if do_gather else None
+        c.recv = [torch.empty(GE * rec_bytes, dtype=torch.uint8, device=cdev) for _ in range(world)] if (do_gather and rank == 0) else None
 
     def pack_records(c):
-        p0 = c.send.data_ptr()
+        base = c.nfill * rec_bytes
+        p0 = c.send.data_ptr() + base
         L.orbx_copy_results_dev(c.ex._h, C.c_void_p(p0), C.c_void_p(p0 + n_kps), C.c_void_p(p0 + n_kps + n_desc),
                                 C.c_void_p(c.stream))
-        o = n_kps + n_desc + n_cnt
+        o = base + n_kps + n_desc + n_cnt
         c.send[o:o + n_m12].copy_(c.match12.view(torch.uint8).reshape(-1), non_blocking=True)
-        c.send[o + n_m12:].copy_(c.nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
+        c.send[o + n_m12:o + n_m12 + n_cnt].copy_(c.nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
+        c.nfill += 1
+
+    def gather_bucket(c):
+        """The records of the last c.nfill steps of this context -> rank 0 (every rank holds the same number)."""
+        n = c.nfill * rec_bytes
+        if not do_gather or n == 0:
+            return
+        with torch.cuda.stream(c.tstream):
+            recv = [r[:n] for r in c.recv] if rank == 0 else None
+            dist.gather(c.send[:n].cpu() if rehearse else c.send[:n], recv, dst=0)
+        c.nfill = 0
 
     def step(k):
         c = ctxs[k % len(ctxs)]
@@ -301,12 +319,12 @@ def main():
                                  stream=c.stream)
             if do_gather:
                 pack_records(c)
-                if rehearse:
-                    dist.gather(c.send.cpu(), c.recv, dst=0)
-                else:
-                    dist.gather(c.send, c.recv, dst=0)
+                if c.nfill == GE:
+                    gather_bucket(c)
 
     def sync():
+        for c in ctxs:
+            gather_bucket(c)   # partial buckets: every step's records are on rank 0 before the barrier
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -436,7 +454,7 @@ def main():
                                    "+ 2000x2000 brute-force Hamming match per frame" + (", RCCL gather on rank 0" if world > 1 else ""),
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
                        "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma (FP4 matrix cores)",
-                       "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0" if world > 1 else "single GPU",
+                       "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0 ({GE} steps per RCCL gather)" if world > 1 else "single GPU",
                        "mean_keypoints_per_frame": float(counts.float().mean().item()),
                        "mean_matches_per_frame": float(nmatch.float().mean().item())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
