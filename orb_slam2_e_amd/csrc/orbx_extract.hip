@@ -99,10 +99,13 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
 // source row is ONE unaligned 8-byte load and a pixel's pair (S[sx], S[sx+1]) is one v_perm_b32 into two u16
 // halves, times (a0, a1) one v_dot2_u32_u16.  The last workgroup holds the groups that touch the border or the
 // row padding and takes them pixel by pixel through the reflected coordinate (nxi = 0: every group does).
-__device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, int b0, int b1)
+// (b (r >> 4)) >> 16 = floor((b 2^12) (r & ~15) / 2^32): both factors are below 2^24 (b <= 2048, r <= 255 * 2048), so
+// it is one v_mul_hi_u32_u24 after the mask instead of shift, multiply, shift.  bs = b << 12.
+__device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, uint32_t bs0, uint32_t bs1)
 {
-    // every factor is below 2^24 and every product below 2^31: 24-bit multiplies are exact here
-    const uint32_t v = (uint32_t)((((__mul24(b0, r0 >> 4)) >> 16) + ((__mul24(b1, r1 >> 4)) >> 16) + 2) >> 2);
+    const uint32_t t0 = (uint32_t)(((unsigned long long)(bs0 & 0xffffffu) * ((uint32_t)r0 & 0xfffff0u)) >> 32);
+    const uint32_t t1 = (uint32_t)(((unsigned long long)(bs1 & 0xffffffu) * ((uint32_t)r1 & 0xfffff0u)) >> 32);
+    const uint32_t v = (t0 + t1 + 2) >> 2;
     return v > 255u ? 255u : v;
 }
 typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
                                                            __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
                 const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w1[r].y, w1[r].x, sel[b])),
                                                            __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
-                out[r] |= resize_vertical(r0, r1, yy[r].z, yy[r].w) << (8 * b);
+                out[r] |= resize_vertical(r0, r1, (uint32_t)yy[r].z << 12, (uint32_t)yy[r].w << 12) << (8 * b);
             }
         }
     } else {
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
             for (int b = 0; b < 4; ++b) {
                 const int r0 = __mul24(S0[sxs[b]], a0[b]) + __mul24(S0[sxs[b] + 1], a1[b]);
                 const int r1 = __mul24(S1[sxs[b]], a0[b]) + __mul24(S1[sxs[b] + 1], a1[b]);
-                out[r] |= resize_vertical(r0, r1, yy[r].z, yy[r].w) << (8 * b);
+                out[r] |= resize_vertical(r0, r1, (uint32_t)yy[r].z << 12, (uint32_t)yy[r].w << 12) << (8 * b);
             }
             out[r] &= keep;
         }
