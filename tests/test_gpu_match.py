@@ -78,6 +78,36 @@ def test_bruteforce_tile_edges_and_extreme_distances(nA, nB, allpairs_kernel):
     assert list(got[0]) == [256] * 5 and list(got[2]) == [0] * 5 and list(got[1]) == [256 if nB > 1 else 2**31 - 1] * 5
 
 
+def test_match_batch_dev_ragged_sets_and_pairs(allpairs_kernel):
+    """orbm_match_batch_dev on descriptor sets resident in HBM: ragged counts (0, 1, a partial tile, cap), arbitrary
+    (query set, train set) pairs incl. a set against itself, the fused acceptance test and the per-pair match count."""
+    import torch
+    rng = np.random.default_rng(5)
+    cap, counts = 300, [300, 0, 1, 37, 256, 129]
+    nsets = len(counts)
+    desc = rng.integers(0, 256, (nsets, cap, 32), dtype=np.uint8)
+    desc[4, :100] = desc[0, 100:200]                       # exact matches between sets 0 and 4
+    desc[5, :60] = desc[0, :60] ^ np.packbits(rng.random((60, 256)) < 0.05, axis=1, bitorder="little")   # near matches
+    pa = np.array([0, 4, 5, 3, 2, 1, 0, 0, 5], np.int32)   # queries
+    pb = np.array([4, 0, 0, 5, 0, 0, 1, 0, 2], np.int32)   # train
+    d = torch.from_numpy(desc).cuda(); c = torch.tensor(counts, dtype=torch.int32).cuda()
+    ta, tb = torch.from_numpy(pa).cuda(), torch.from_numpy(pb).cuda()
+    out = [torch.full((len(pa), cap), -7, dtype=torch.int32).cuda() for _ in range(4)]
+    nm = torch.full((len(pa),), -7, dtype=torch.int32).cuda()
+    m = ORBmatcher(0.6)
+    m.match_batch_device(d.data_ptr(), c.data_ptr(), cap, ta.data_ptr(), tb.data_ptr(), len(pa), out[0].data_ptr(), out[1].data_ptr(),
+                         out[2].data_ptr(), out[3].data_ptr(), nm.data_ptr(), th=50)
+    torch.cuda.synchronize()
+    best, second, idx, m12 = (o.cpu().numpy() for o in out)
+    for p in range(len(pa)):
+        nA, nB = counts[pa[p]], counts[pb[p]]
+        rb, rs, ri = oracle.match_bruteforce(desc[pa[p], :nA], desc[pb[p], :nB])
+        rm, rn = oracle.match_filter(rb, rs, ri, 50, 0.6)
+        assert np.array_equal(best[p, :nA], rb) and np.array_equal(second[p, :nA], rs) and np.array_equal(idx[p, :nA], ri), f"pair {p}"
+        assert np.array_equal(m12[p, :nA], rm) and int(nm[p]) == rn, f"pair {p}: acceptance"
+        assert (best[p, nA:] == -7).all() and (m12[p, nA:] == -7).all(), f"pair {p}: rows past the query count untouched"
+
+
 def test_candidate_lists():
     rng = np.random.default_rng(11)
     A, B, _ = synth_descriptors(500, seed=9)
