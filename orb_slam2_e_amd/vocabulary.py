@@ -40,6 +40,13 @@ class ORBVocabulary:
         check(self._L.orbm_bow_transform(self._h, _p(f), n, levelsup, _p(word), _p(node), _p(w)))
         return word, node, w
 
+    def descend_batch_device(self, desc_dev, counts_dev, cap, nsets, levelsup, word_id_dev, node_id_dev, stream=None):
+        """orbm_bow_transform_batch_dev: descriptor sets resident in HBM ([nsets][cap][32] bytes, counts[nsets]) ->
+        word / node ids [nsets][cap] int32 on the device (rows past a set's count are not written).  Asynchronous."""
+        vp = lambda v: C.c_void_p(v) if v else None
+        check(self._L.orbm_bow_transform_batch_dev(self._h, vp(desc_dev), vp(counts_dev), cap, nsets, levelsup, vp(word_id_dev),
+                                                   vp(node_id_dev), vp(stream)))
+
     def transform(self, features, levelsup=4):
         """Returns (BowVector: {word id: value}, FeatureVector: {node id: [feature indices]})."""
         word, node, w = self.descend(features, levelsup)

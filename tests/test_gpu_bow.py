@@ -114,3 +114,24 @@ def test_vocabulary_loaded_from_text_file(tmp_path, levelsup, scoring, weighting
     for g, r in zip(got, ref):
         assert np.array_equal(g, r)
     assert voc.transform(feats, levelsup) == assemble_bow(*ref, scoring, weighting)
+
+
+@pytest.mark.parametrize("levelsup", [4, 0])
+def test_bow_batch_on_resident_descriptor_sets(levelsup):
+    """orbm_bow_transform_batch_dev: the extractor's result layout ([sets][cap][32], counts) in HBM, ids left there."""
+    import torch
+    off, ids, desc, word, weight, L = _synthetic_vocabulary()
+    voc = ORBVocabulary(off, ids, desc, word, weight, L)
+    rng = np.random.default_rng(3)
+    cap, counts = 500, [500, 0, 1, 17, 333]
+    leaves = np.where(word >= 0)[0]
+    sets = desc[rng.choice(leaves, (len(counts), cap))] ^ np.packbits(rng.random((len(counts), cap, 256)) < 0.04, axis=2, bitorder="little")
+    d = torch.from_numpy(np.ascontiguousarray(sets)).cuda(); c = torch.tensor(counts, dtype=torch.int32).cuda()
+    w = torch.full((len(counts), cap), -9, dtype=torch.int32).cuda(); n = torch.full_like(w, -9)
+    voc.descend_batch_device(d.data_ptr(), c.data_ptr(), cap, len(counts), levelsup, w.data_ptr(), n.data_ptr())
+    torch.cuda.synchronize()
+    w, n = w.cpu().numpy(), n.cpu().numpy()
+    for s_, cnt in enumerate(counts):
+        rw, rn, _ = oracle.bow_descend(off, ids, desc, word, weight, L, sets[s_, :cnt], levelsup)
+        assert np.array_equal(w[s_, :cnt], rw) and np.array_equal(n[s_, :cnt], rn), f"set {s_}"
+        assert (w[s_, cnt:] == -9).all() and (n[s_, cnt:] == -9).all()
