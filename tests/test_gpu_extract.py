@@ -243,3 +243,21 @@ def test_random_sizes_parameters_and_contents():
         _kp_equal(kps, okps)
         assert np.array_equal(desc, odesc), (params, w, h, kind)
         done += 1
+
+
+def test_reserve_sizes_the_workspace_up_front():
+    """orbx_reserve: the workspace for (width, height, batch) is built before the first frame; bad sizes are an error and a
+    later extraction at the reserved size gives the usual result."""
+    from orb_slam2_e_amd._lib import lib
+    ex = ORBextractor(*PARAMS)
+    L = lib()
+    assert L.orbx_reserve(ex._h, 640, 480, 2) == 0
+    assert L.orbx_reserve(ex._h, 640, 480, 1) == 0          # a smaller batch fits the same workspace
+    assert L.orbx_reserve(ex._h, 0, 480, 1) != 0 and L.orbx_reserve(ex._h, 640, 480, 0) != 0
+    assert L.orbx_reserve(None, 640, 480, 1) != 0
+    img = synth_frame(1)
+    o = oracle.OrbOracle(*PARAMS)
+    okps, odesc = o.extract(img)
+    kps, desc = ex(img)
+    _kp_equal(kps, okps)
+    assert np.array_equal(desc, odesc)
