@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "fem_hip.h"
@@ -324,6 +325,100 @@ public:
                                      (int)fv2.nodes.size(), valid2 ? valid2->data() : nullptr, F2.mDescriptors, a2.data(), F2.N,
                                      TH_LOW, valid2 ? 1 : 0, mfNNratio, mbCheckOrientation, vnMatches12.data(), nullptr, &nm);
         return mStatus == ORBX_OK ? nm : 0;
+    }
+
+    // ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024).  The FeatureVector co-iteration builds the candidate
+    // list of every keypoint of KF1 (the members of the same vocabulary node in KF2, in member order), the device
+    // runs the loop with its epipolar gates, the rotation histogram and the pair list are finished here.
+    // hasMP / stereo: "pKF->GetMapPoint(idx) exists" and "mvuRight[idx] >= 0", one byte per keypoint.
+    int SearchForTriangulation(const FrameView &KF1, const FeatureVector &fv1, const std::vector<uint8_t> &hasMP1,
+                               const std::vector<uint8_t> &stereo1, const FrameView &KF2, const FeatureVector &fv2,
+                               const std::vector<uint8_t> &hasMP2, const std::vector<uint8_t> &stereo2, const float F12[9],
+                               float ex, float ey, bool bOnlyStereo, const std::vector<float> &scaleFactors2,
+                               const std::vector<float> &levelSigma2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs)
+    {
+        vMatchedPairs.clear();
+        std::vector<int32_t> node_of(KF1.N, -1);       // position in fv2.nodes of keypoint i's node, if both frames have it
+        for (size_t a = 0, b = 0; a < fv1.nodes.size() && b < fv2.nodes.size();) {
+            if (fv1.nodes[a] == fv2.nodes[b]) {
+                for (int32_t k = fv1.off[a]; k < fv1.off[a + 1]; ++k) node_of[fv1.items[k]] = (int32_t)b;
+                ++a; ++b;
+            } else if (fv1.nodes[a] < fv2.nodes[b]) ++a;
+            else ++b;
+        }
+        std::vector<int32_t> off(KF1.N + 1, 0), idx;
+        for (int i = 0; i < KF1.N; ++i) {
+            if (node_of[i] >= 0) idx.insert(idx.end(), fv2.items.begin() + fv2.off[node_of[i]], fv2.items.begin() + fv2.off[node_of[i] + 1]);
+            off[i + 1] = (int32_t)idx.size();
+        }
+        std::vector<int32_t> m12(KF1.N, -1), bd(KF1.N, 0);
+        mStatus = orbm_match_triangulation(KF1.mvKeysUn, KF1.mDescriptors, KF1.N, KF2.mvKeysUn, KF2.mDescriptors, KF2.N, off.data(),
+                                           idx.data(), hasMP1.data(), hasMP2.data(), stereo1.data(), stereo2.data(), bOnlyStereo ? 1 : 0,
+                                           F12, ex, ey, scaleFactors2.data(), levelSigma2.data(), (int)scaleFactors2.size(), m12.data(),
+                                           bd.data());
+        if (mStatus != ORBX_OK) return 0;
+        int nmatches = 0;
+        for (int i = 0; i < KF1.N; ++i) nmatches += m12[i] >= 0;
+        if (mbCheckOrientation) {                      // :965-976, :992-1011
+            std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+            const float factor = 1.0f / HISTO_LENGTH;
+            for (int i = 0; i < KF1.N; ++i) {
+                if (m12[i] < 0) continue;
+                float rot = KF1.mvKeysUn[i].angle - KF2.mvKeysUn[m12[i]].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(i);
+            }
+            int ind1, ind2, ind3;
+            ComputeThreeMaxima(rotHist, ind1, ind2, ind3);
+            for (int b = 0; b < HISTO_LENGTH; ++b) {
+                if (b == ind1 || b == ind2 || b == ind3) continue;
+                for (int i : rotHist[b]) { m12[i] = -1; --nmatches; }
+            }
+        }
+        for (int i = 0; i < KF1.N; ++i)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+        return nmatches;
+    }
+
+    // ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1802-1843) on the bin sizes.
+    static void ComputeThreeMaxima(const std::vector<std::vector<int>> &histo, int &ind1, int &ind2, int &ind3)
+    {
+        int max1 = 0, max2 = 0, max3 = 0;
+        ind1 = ind2 = ind3 = -1;
+        for (int i = 0; i < (int)histo.size(); ++i) {
+            const int s = (int)histo[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) ind3 = -1;
+    }
+
+    // The fork's SearchByProjection(Frame&, Map*, Rcw, tcw, ...) over every map point (ORBmatcher.cc:134-222): isInFrustum,
+    // level prediction, windowed search and acceptance on the device.  mp*: one entry per map point (position and normal
+    // xyz, distance invariance limits, MapPoint::GetDescriptor()); vMatchedMPs[j] = map point index for keypoint j or -1.
+    int SearchByProjection(const FrameView &F, const std::vector<uint8_t> &hasMapPoint, const float *mpPos, const float *mpNormal,
+                           const float *mpMinDistance, const float *mpMaxDistance, const uint8_t *mpDescriptors, int nMapPoints,
+                           const double Rcw[9], const double tcw[3], const orbm_camera &cam, const std::vector<float> &scaleFactors,
+                           float th, std::vector<int32_t> &vMatchedMPs)
+    {
+        vMatchedMPs.assign(F.N, -1);
+        int nm = 0;
+        mStatus = orbm_search_by_projection_map(F.mvKeysUn, F.mDescriptors, F.N, hasMapPoint.data(), mpPos, mpNormal, mpMinDistance,
+                                                mpMaxDistance, mpDescriptors, nMapPoints, Rcw, tcw, &cam, scaleFactors.data(),
+                                                (int)scaleFactors.size(), th, mfNNratio, TH_RELOC, vMatchedMPs.data(), &nm, nullptr);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+
+    // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:305-370) for many map points at once: the observed descriptors of
+    // point i are rows off[i] .. off[i+1) of desc; best[i] = the row (within the point) with the least median distance.
+    static int ComputeDistinctiveDescriptors(const uint8_t *desc, const std::vector<int32_t> &off, std::vector<int32_t> &best)
+    {
+        best.assign(off.empty() ? 0 : off.size() - 1, -1);
+        return best.empty() ? ORBX_OK : orbm_distinctive_descriptors(desc, off.data(), (int)best.size(), best.data());
     }
 
     int status() const { return mStatus; }

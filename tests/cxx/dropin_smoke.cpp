@@ -144,6 +144,33 @@ int main(int argc, char **argv)
         if (mb.status() != ORBX_OK || nb != selfb || selfb < n * 8 / 10) { printf("FAIL SearchByBoW %d %d of %d\n", nb, selfb, n); return 1; }
     }
     {
+        // SearchForTriangulation of the frame against itself with a skew-symmetric F12 = [t]x (x^T [t]x x = 0: every keypoint
+        // lies on its own epipolar line; the epipole t is far outside the image), mono keypoints: candidates = members of the
+        // same node, so every keypoint must pair with a keypoint of its own node at distance 0 -- itself, or an identical
+        // descriptor on the same line after it (ties: the later candidate wins, :950).
+        std::vector<int32_t> node(n);
+        for (int i = 0; i < n; ++i) node[i] = (desc[(size_t)32 * i] & 15) + 1;
+        const ORBmatcher::FeatureVector fv = ORBmatcher::FeatureVector::FromNodeIds(node);
+        std::vector<uint8_t> none(n, 0);
+        const float t3[3] = {1.0f, 0.5f, -1.0e-4f};
+        const float F12[9] = {0, -t3[2], t3[1], t3[2], 0, -t3[0], -t3[1], t3[0], 0};
+        std::vector<float> sf(8), sg(8);
+        for (int l = 0; l < 8; ++l) { sf[l] = l ? sf[l - 1] * 1.2f : 1.0f; sg[l] = sf[l] * sf[l]; }
+        std::vector<std::pair<size_t, size_t>> pairs;
+        ORBmatcher mt(0.6f, false);
+        const int nt = mt.SearchForTriangulation(F, fv, none, none, F, fv, none, none, F12, t3[0] / t3[2], t3[1] / t3[2], false, sf, sg, pairs);
+        int good = 0;
+        for (const auto &pr : pairs) good += node[pr.first] == node[pr.second] && popcount_row(&desc[32 * pr.first], &desc[32 * pr.second]) == 0;
+        if (mt.status() != ORBX_OK || nt != n || (int)pairs.size() != n || good != n) { printf("FAIL SearchForTriangulation %d %zu %d of %d\n", nt, pairs.size(), good, n); return 1; }
+        // ComputeDistinctiveDescriptors: three copies of a descriptor and one outlier -> one of the copies (the first)
+        std::vector<uint8_t> obs(4 * 32);
+        for (int r = 0; r < 4; ++r) memcpy(&obs[32 * r], &desc[(size_t)32 * (r == 1 ? 7 : 3)], 32);
+        std::vector<int32_t> offs = {0, 4}, best;
+        if (ORBmatcher::ComputeDistinctiveDescriptors(obs.data(), offs, best) != ORBX_OK || best.size() != 1 || best[0] != 0) {
+            printf("FAIL ComputeDistinctiveDescriptors %d\n", best.empty() ? -99 : best[0]); return 1;
+        }
+    }
+    {
         // ORBVocabulary: write a k=4, L=2 tree in the ORBvoc.txt layout whose leaves are the first 16 descriptors,
         // load it, transform the frame: every one of those 16 features must land on its own word.
         const char *path = argc > 2 ? argv[2] : "/tmp/dropin_voc.txt";
