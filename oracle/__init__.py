@@ -389,6 +389,30 @@ def match_triangulation(kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, h
     return m12, bd
 
 
+def search_for_triangulation(kps1, desc1, fv1, has_mp1, stereo1, kps2, desc2, fv2, has_mp2, stereo2, F12, ex, ey,
+                             scale_factors2, level_sigma2, only_stereo=False, check_orientation=True):
+    """ORBmatcher::SearchForTriangulation as a whole (ORBmatcher.cc:858-1024) -> (match12, nmatches)."""
+    L = lib()
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    n1_, o1, it1 = (i32(a) for a in fv1); n2_, o2, it2 = (i32(a) for a in fv2)
+    m1, m2, s1, s2 = u8(has_mp1), u8(has_mp2), u8(stereo1), u8(stereo2)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
+    m12 = np.zeros(len(kps1), np.int32)
+    L.oracle_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_search_for_triangulation.restype = C.c_int
+    nm = L.oracle_search_for_triangulation(_p(kps1), _p(d1), len(kps1), _p(kps2), _p(d2), _p(n1_), _p(o1), _p(it1), len(n1_),
+                                           _p(n2_), _p(o2), _p(it2), len(n2_), _p(m1), _p(m2), _p(s1), _p(s2), 1 if only_stereo else 0,
+                                           _p(F), ex, ey, _p(sc), _p(sg), 1 if check_orientation else 0, _p(m12))
+    return m12, nm
+
+
 WQ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("xr", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
 
 

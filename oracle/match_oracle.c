@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define HISTO_LENGTH 30 /* ORBmatcher.cc:40 */
+
 /* ORBmatcher::DescriptorDistance, ORBmatcher.cc:1848-1864 */
 int oracle_descriptor_distance(const uint8_t *a, const uint8_t *b)
 {
@@ -239,6 +241,73 @@ void oracle_match_triangulation(const tri_kp *kps1, const uint8_t *d1, int n1, c
     }
 }
 
+/* ---- ORBmatcher::SearchForTriangulation as a whole, ORBmatcher.cc:858-1024: FeatureVector co-iteration (:889-985;
+ * std::map iteration with lower_bound = a merge of the two ascending node lists), the inner loop above per member
+ * of a shared node, the rotation histogram (:965-976), ComputeThreeMaxima and the rejection of the other bins
+ * (:992-1011).  FeatureVectors as (nodes ascending, off, items in member order).  match12[n1] = index in KF2 or -1
+ * (= vMatchedPairs); returns nmatches. */
+int oracle_search_for_triangulation(const tri_kp *kps1, const uint8_t *d1, int n1, const tri_kp *kps2, const uint8_t *d2,
+                                    const int *nodes1, const int *off1, const int *items1, int nn1, const int *nodes2,
+                                    const int *off2, const int *items2, int nn2, const uint8_t *hasmp1,
+                                    const uint8_t *hasmp2, const uint8_t *stereo1, const uint8_t *stereo2, int bOnlyStereo,
+                                    const float *F12, float ex, float ey, const float *scaleFactors2,
+                                    const float *levelSigma2, int check_orientation, int *match12)
+{
+    const int TH_LOW = 45;
+    const float factor = 1.0f / HISTO_LENGTH;
+    int *bin_of = (int *)malloc(sizeof(int) * (n1 + 1));
+    int hist[HISTO_LENGTH] = {0};
+    int a = 0, b = 0, i, nmatches = 0;
+    for (i = 0; i < n1; i++) { match12[i] = -1; bin_of[i] = -1; }
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            int i1, i2;
+            for (i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const int idx1 = items1[i1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                if (hasmp1[idx1]) continue;
+                if (bOnlyStereo && !stereo1[idx1]) continue;
+                for (i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const int idx2 = items2[i2];
+                    int dist;
+                    if (hasmp2[idx2]) continue;       /* vbMatched2 is never set in the reference */
+                    if (bOnlyStereo && !stereo2[idx2]) continue;
+                    dist = oracle_descriptor_distance(d1 + 32 * (size_t)idx1, d2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    if (!stereo1[idx1] && !stereo2[idx2]) {
+                        const float distex = ex - kps2[idx2].x, distey = ey - kps2[idx2].y;
+                        if (distex * distex + distey * distey < 100 * scaleFactors2[kps2[idx2].octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(&kps1[idx1], &kps2[idx2], F12, levelSigma2)) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = kps1[idx1].angle - kps2[bestIdx2].angle;
+                        int bin;
+                        if (rot < 0.0) rot += 360.0f;
+                        bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        bin_of[idx1] = bin;
+                        hist[bin]++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) a++; /* lower_bound(f2it->first) on an ascending list */
+        else b++;
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (i = 0; i < n1; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind1 && bin_of[i] != ind2 && bin_of[i] != ind3) { match12[i] = -1; nmatches--; }
+    }
+    free(bin_of);
+    return nmatches;
+}
+
 /* ---- windowed search: GetFeaturesInArea + the best/second-with-levels loop of
  * SearchByProjection(Frame&, vector<MapPoint*>&, th), ORBmatcher.cc:69-118.
  * q = {u, v, r, xr, minLevel, maxLevel}; skip[idx] stands for "already holds an
@@ -278,7 +347,6 @@ void oracle_search_window(const oracle_grid *g, const float *xy, const int *octa
  * Rotation histogram as every Search* builds it (e.g. ORBmatcher.cc:1642-1650):
  * rot = angle1 - angle2 (+360 if negative), bin = round(rot * 1/HISTO_LENGTH), 30 -> 0.
  * (With factor = 1/30 and 30 bins only bins 0..12 are ever hit: SURVEY M12.) */
-#define HISTO_LENGTH 30 /* ORBmatcher.cc:40 */
 static int rot_bin(float a1, float a2)
 {
     const float factor = 1.0f / HISTO_LENGTH;

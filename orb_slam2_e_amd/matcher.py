@@ -104,6 +104,51 @@ class ORBmatcher:
                                                _p(sg), len(sc), _p(m12), _p(bd)))
         return m12, bd
 
+    def SearchForTriangulation(self, kps1, desc1, fv1, has_mp1, stereo1, kps2, desc2, fv2, has_mp2, stereo2, F12, ex, ey,
+                               scale_factors2, level_sigma2, bOnlyStereo=False):
+        """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024): FeatureVector co-iteration into per-keypoint
+        candidate lists (host), the gated loop on the device, rotation histogram + ComputeThreeMaxima + pair list (host).
+        fv = (nodes ascending, off, items).  Returns (vMatchedPairs as an (m, 2) array, nmatches, vMatches12)."""
+        n1 = len(kps1)
+        nodes1, off1, items1 = (np.asarray(a) for a in fv1); nodes2, off2, items2 = (np.asarray(a) for a in fv2)
+        pos2 = {int(nd): k for k, nd in enumerate(nodes2)}
+        lists = [None] * n1
+        for k, nd in enumerate(nodes1):
+            b = pos2.get(int(nd))
+            if b is not None:
+                members2 = items2[off2[b]:off2[b + 1]]
+                for i in items1[off1[k]:off1[k + 1]]:
+                    lists[int(i)] = members2
+        cand_off = np.zeros(n1 + 1, np.int32)
+        cand_off[1:] = np.cumsum([0 if l is None else len(l) for l in lists])
+        cand_idx = np.concatenate([l for l in lists if l is not None]).astype(np.int32) if cand_off[-1] else np.zeros(0, np.int32)
+        m12, _ = self.match_triangulation(kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, has_mp2, stereo1, stereo2, F12, ex, ey,
+                                          scale_factors2, level_sigma2, bOnlyStereo)
+        if self.mbCheckOrientation:
+            hit = np.nonzero(m12 >= 0)[0]
+            rot = np.asarray(kps1["angle"], np.float32)[hit] - np.asarray(kps2["angle"], np.float32)[m12[hit]]
+            rot = np.where(rot < 0, rot + np.float32(360.0), rot).astype(np.float32)
+            v = rot * np.float32(1.0 / self.HISTO_LENGTH)
+            bins = (np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))).astype(np.int64)       # round(): half away from zero
+            bins[bins == self.HISTO_LENGTH] = 0
+            hist = np.bincount(bins, minlength=self.HISTO_LENGTH)
+            keep = self.ComputeThreeMaxima(hist)
+            m12[hit[~np.isin(bins, keep)]] = -1
+        i1 = np.nonzero(m12 >= 0)[0]
+        return np.stack([i1, m12[i1]], 1), len(i1), m12
+
+    @staticmethod
+    def ComputeThreeMaxima(hist):
+        """ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1802-1843) on the bin sizes -> the bins that stay."""
+        max1 = max2 = max3 = 0; ind1 = ind2 = ind3 = -1
+        for i, s in enumerate(int(x) for x in hist):
+            if s > max1: max3, max2, max1, ind3, ind2, ind1 = max2, max1, s, ind2, ind1, i
+            elif s > max2: max3, max2, ind3, ind2 = max2, s, ind2, i
+            elif s > max3: max3, ind3 = s, i
+        if max2 < np.float32(0.1) * np.float32(max1): ind2 = ind3 = -1
+        elif max3 < np.float32(0.1) * np.float32(max1): ind3 = -1
+        return [i for i in (ind1, ind2, ind3) if i >= 0]
+
     WQ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("xr", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
 
     def search_window(self, queries, qdesc, kps, desc, bounds, skip=None, uright=None, init_dist=256):

@@ -300,3 +300,44 @@ def test_vocabulary_text_format(tmp_path):
     assert assemble_bow(wid, nid, ww, 5, 0)[0] == {3: 2.0, 9: 0.5}                     # DOT_PRODUCT: / number of words
     b = assemble_bow(wid, nid, ww, 1, 0)[0]
     assert abs(b[3] - 4 / np.sqrt(17)) < 1e-15 and abs(b[9] - 1 / np.sqrt(17)) < 1e-15  # L2
+
+
+def test_search_for_triangulation_oracle_cross_check():
+    """Two restatements of ORBmatcher::SearchForTriangulation must agree: the literal whole function (node merge, loop,
+    rotation histogram) and the inner-loop oracle over explicit candidate lists followed by an independent histogram."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_match import _triangulation_case
+    for seed, only_stereo in ((0, False), (1, True)):
+        (k1, d1, k2, d2, _, _, mp1, mp2, s1, s2, F12, ex, ey, sf, sg), _ = _triangulation_case(seed, only_stereo)
+        rng = np.random.default_rng(seed)
+        n = len(k1)
+        node1 = rng.integers(0, 30, n) * 2
+        node2 = np.where(rng.random(n) < 0.9, node1, rng.integers(0, 35, n) * 2)
+        k1["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        k2["angle"] = np.where(rng.random(n) < 0.8, (k1["angle"] + rng.normal(0, 4, n)) % 360, rng.uniform(0, 360, n)).astype(np.float32)
+        fv1, fv2 = oracle.feature_vector(node1), oracle.feature_vector(node2, rng.random(n) < 0.9)
+        whole, nwhole = oracle.search_for_triangulation(k1, d1, fv1, mp1, s1, k2, d2, fv2, mp2, s2, F12, ex, ey, sf, sg, only_stereo, True)
+        # explicit candidate lists: members of the same node of KF2, member order
+        members2 = {int(nd): fv2[2][fv2[1][k]:fv2[1][k + 1]] for k, nd in enumerate(fv2[0])}
+        in1 = np.zeros(n, bool); in1[fv1[2]] = True
+        off = [0]; idx = []
+        for i in range(n):
+            if in1[i]: idx += list(members2.get(int(node1[i]), []))
+            off.append(len(idx))
+        m12, _ = oracle.match_triangulation(k1, d1, k2, d2, off, idx, mp1, mp2, s1, s2, F12, ex, ey, sf, sg, only_stereo)
+        hist = [[] for _ in range(30)]
+        for i in np.nonzero(m12 >= 0)[0]:
+            rot = np.float32(k1["angle"][i]) - np.float32(k2["angle"][m12[i]])
+            if rot < 0: rot = np.float32(rot + np.float32(360.0))
+            b = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + np.float32(0.5)))
+            hist[0 if b == 30 else b].append(i)
+        sizes = sorted(((len(h), -b) for b, h in enumerate(hist)), reverse=True)      # largest first, lower bin first on ties
+        keep = [-sizes[0][1]]
+        if sizes[1][0] >= np.float32(0.1) * np.float32(sizes[0][0]):
+            keep.append(-sizes[1][1])
+            if sizes[2][0] >= np.float32(0.1) * np.float32(sizes[0][0]): keep.append(-sizes[2][1])
+        for b, h in enumerate(hist):
+            if b not in keep:
+                m12[h] = -1
+        assert nwhole == int((m12 >= 0).sum()) and np.array_equal(whole, m12) and nwhole > 10

@@ -166,6 +166,29 @@ def test_search_for_triangulation_inner_loop(seed, only_stereo):
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
+@pytest.mark.parametrize("seed,only_stereo,ori", [(0, False, True), (1, True, True), (2, False, False), (3, False, True)])
+def test_search_for_triangulation_whole_function(seed, only_stereo, ori):
+    """The whole SearchForTriangulation: FeatureVector co-iteration, gated loop, rotation histogram, pair list."""
+    (k1, d1, k2, d2, _, _, mp1, mp2, s1, s2, F12, ex, ey, sf, sg), _ = _triangulation_case(seed, only_stereo)
+    rng = np.random.default_rng(100 + seed)
+    n = len(k1)
+    node1 = rng.integers(0, 45, n) * 3 + 7
+    node2 = np.where(rng.random(n) < 0.9, node1, rng.integers(0, 50, n) * 3 + 7)       # most true matches share a node
+    node2[node2 == node1[0]] += 1 if seed == 3 else 0                                    # a node present on one side only
+    k1["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k2["angle"] = np.where(rng.random(n) < 0.8, (k1["angle"] + rng.normal(0, 4, n)) % 360, rng.uniform(0, 360, n)).astype(np.float32)
+    keep1 = rng.random(n) < 0.95; keep2 = rng.random(n) < 0.95                          # stopped words are in no node
+    fv1, fv2 = oracle.feature_vector(node1, keep1), oracle.feature_vector(node2, keep2)
+    m = ORBmatcher(0.6, ori)
+    pairs, nm, m12 = m.SearchForTriangulation(k1, d1, fv1, mp1, s1, k2, d2, fv2, mp2, s2, F12, ex, ey, sf, sg, only_stereo)
+    r12, rn = oracle.search_for_triangulation(k1, d1, fv1, mp1, s1, k2, d2, fv2, mp2, s2, F12, ex, ey, sf, sg, only_stereo, ori)
+    assert rn > (10 if only_stereo else 60)
+    assert nm == rn and np.array_equal(m12, r12)
+    assert np.array_equal(pairs[:, 0], np.nonzero(r12 >= 0)[0]) and np.array_equal(pairs[:, 1], r12[r12 >= 0])
+    if ori:
+        assert rn < (oracle.search_for_triangulation(k1, d1, fv1, mp1, s1, k2, d2, fv2, mp2, s2, F12, ex, ey, sf, sg, only_stereo, False)[1])
+
+
 @pytest.mark.parametrize("seed,stereo,init", [(0, False, 256), (1, True, 256), (2, False, 2**31 - 1)])
 def test_search_window_equals_grid_then_selection(seed, stereo, init):
     """orbm_search_window vs GetFeaturesInArea (grid order) + the SearchByProjection loop."""
