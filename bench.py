@@ -44,36 +44,56 @@ ALG_BYTES = {
     "k_match_sets_mfma": 144000,                # 2 x 2000 x 32 B read + 2000 x 8 B written
 }
 FRAME_BYTES = 6751328  # whole extract path per frame
+KERNEL_KINDS = ["k_pyr_level0", "k_pyr_resize", "k_fast_cells", "k_octree", "k_blur", "k_describe"]  # orbx_profile_enable bit order
 
 
-def cpu_baseline(min_seconds=12.0, ndistinct=16):
-    """Oracle (CPU restatement, one thread) on a bounded sample of the workload
-    (about 10-20 s of CPU work)."""
+def cpu_baseline_child(legs, fem_csr=None, timeout=600):
+    """SURVEY 8(d) CPU-baseline protocol in a child process (oracle/cpu_bench.py): the oracle built -O3 -march=native
+    -ffp-contract=off on this host, one thread pinned to one core, 3 warm-ups, medians of >= 20 runs, plus the
+    all-cores figure (one pinned worker per core).  The child never touches the GPU; this process only waits."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--legs", ",".join(legs)]
+    if fem_csr:
+        cmd += ["--fem-csr", fem_csr]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    if r.returncode != 0:
+        return {"error": r.stderr[-400:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def verify_against_oracle(frames, kps, desc, counts, best, second, idx, match12, nmatch, pair_b):
+    """The checker, outside the timed region: every frame's keypoints (float bits) and descriptors and every pair's
+    best / second / arg-best / accepted match / match count against the CPU oracle (ORBextractor.cc:1051-1113,
+    ORBmatcher.cc:645-676 selection + TH_LOW / ratio acceptance).  Returns (ok, first mismatch or None)."""
     import oracle
-    from orb_slam2_e_amd.synth import synth_frame
-    imgs = [synth_frame(k) for k in range(ndistinct)]
     o = oracle.OrbOracle(*PARAMS)
-    o.extract(imgs[0])  # warm
-    t0 = time.perf_counter()
-    prev = None
-    nframes = 0
-    while time.perf_counter() - t0 < min_seconds:
-        desc = o.extract(imgs[nframes % ndistinct])[1]
-        if prev is not None:
-            b, s, ix = oracle.match_bruteforce(prev, desc)
-            oracle.match_filter(b, s, ix, 45, 0.6)
-        prev = desc
-        nframes += 1
-    dt = time.perf_counter() - t0
-    return {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{nframes} synthetic 640x480 frames ({ndistinct} distinct): oracle extract + 2000x2000 match "
-                      f"against the previous frame, 1 thread, {dt:.1f} s"}
+    B = len(frames)
+    od = []
+    for f in range(B):
+        okps, odesc = o.extract(frames[f])
+        n = int(counts[f])
+        if n != len(okps):
+            return False, f"frame {f}: {n} keypoints, oracle {len(okps)}"
+        if not np.array_equal(kps[f, :n].view(np.uint8), okps.view(np.uint8)) or not np.array_equal(desc[f, :n], odesc):
+            return False, f"frame {f}: keypoints / descriptors differ"
+        od.append(odesc)
+    for f in range(B):
+        g = int(pair_b[f])
+        rb, rs, ri = oracle.match_bruteforce(od[f], od[g])
+        rm, rn = oracle.match_filter(rb, rs, ri, 45, 0.6)
+        n = len(od[f])
+        if not (np.array_equal(best[f, :n], rb) and np.array_equal(second[f, :n], rs) and np.array_equal(idx[f, :n], ri)
+                and np.array_equal(match12[f, :n], rm) and int(nmatch[f]) == rn):
+            return False, f"pair ({f}, {g}): match result differs"
+    return True, None
 
 
-def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, cpu=True):
+def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out=None):
     """Config 3 (10,368-tet / 6,591-dof mesh, E=3500, nu=0.495): assemble K + 200
-    CG iterations, single mesh and a batch of `nmesh` distinct matrices per GPU."""
+    CG iterations, single mesh and a batch of `nmesh` distinct matrices per GPU; for N > 1 the nodal
+    displacements of every rank's meshes are gathered on rank 0 inside the timed region."""
     from orb_slam2_e_amd.fem import FEA2, FEM_TET4
+    from orb_slam2_e_amd.shard import gather_displacements, max_over_ranks
     from orb_slam2_e_amd.synth import synth_tet_batch
 
     def barrier():
@@ -100,12 +120,9 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, cpu=Tru
         t0 = time.perf_counter()
         fea.cg_iterate(iters)
         x, rel = fea.cg_result()                       # synchronises
+        xall = gather_displacements(x, rank, world, cdev)   # N > 1: [world * nm, ndof] on rank 0
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(time.perf_counter() - t0, world, cdev)
         prof = fea.profile_read()
         n, nnz = fea.Ksize, fea.nnz
         spmv_ms = prof["k_fem_spmv"][0] / max(prof["k_fem_spmv"][1], 1) if prof["k_fem_spmv"][1] else split.get("k_fem_spmv", 0.0)
@@ -117,33 +134,47 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, cpu=Tru
                       "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes,
                       "spmv_GBps": spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
                       "cg_iter_GBps": iter_bytes * iters / dt / 1e9,
+                      "displacements_gathered": None if xall is None else list(xall.shape),
                       "kernel_ms_per_launch_untimed_pass": split}
-        if label == "single" and cpu and rank == 0:
-            import oracle
+        if label == "single" and rank == 0:
             rp, col, val = fea.csr()
-            t0 = time.perf_counter(); reps = 0
-            while time.perf_counter() - t0 < 10.0:
-                oracle.fem_cg(rp, col, val, b[0], iters, 0.0); reps += 1
-            dtc = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": reps * iters / dtc, "unit": "CG iters/s", "cores": 1, "kind": "port",
-                                   "sample": f"oracle Jacobi-PCG, {reps} x {iters} iterations on the single 6,591-dof mesh, {dtc:.1f} s"}
+            # the checker, outside the timed region: the 200-iteration iterate against the oracle's CG on the exported CSR
+            import oracle
+            ox, _, _ = oracle.fem_cg(rp, col, val, b[0], iters, 0.0)
+            dev_rel = float(np.abs(x[0] - ox).max() / np.abs(ox).max())
+            out[label]["max_rel_dev_vs_oracle"] = dev_rel
+            out["verified"] = bool(dev_rel <= 1e-5)
+            if csr_out:
+                np.savez(csr_out, rp=rp, col=col, val=val, b=b[0])
         del fea
     bt = out["batch"]
     out["roofline"] = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None,
                        "avg_launch_ms": bt["spmv_avg_launch_ms"], "alg_bytes_per_launch": bt["spmv_alg_bytes_per_launch"]}
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile) and nmesh == 256:      # PMC passes were taken on the 256-mesh batch
-        tr = json.load(open(tfile)).get("k_fem_spmv")
-        if tr:
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
+    tr = load_traffic().get("k_fem_spmv") if nmesh == 256 else None     # PMC passes were taken on the 256-mesh batch
+    if tr:
+        out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = tr["source"]
+        if bt["spmv_avg_launch_ms"] > 0:
+            # what HBM really delivers: the shared column-index array is served from L2, so the counter traffic is below
+            # SURVEY's algorithmic bytes; this is the honest HBM fraction of the same launch
+            out["roofline"]["frac_of_counter_traffic"] = tr["hbm_bytes_per_launch"] / (bt["spmv_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 
 
-def matcher_loops_bench(cpu=True):
+def load_traffic():
+    """HBM bytes / VALU instruction counts per launch from the committed PMC passes (newest round first)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            return json.load(open(f))
+    return {}
+
+
+def matcher_loops_bench():
     """Tracking-time matching: one call = one whole ORBmatcher loop, host arrays in and out
-    (PCIe and the per-call host work included), against the oracle's literal loop on the same inputs."""
+    (PCIe and the per-call host work included); the oracle's literal loops on the same inputs are timed by
+    oracle/cpu_bench.py."""
     from orb_slam2_e_amd.matcher import ORBmatcher
     from orb_slam2_e_amd.synth import synth_bow_case, synth_projection_case
     from orb_slam2_e_amd.vocabulary import feature_vector_arrays
@@ -158,20 +189,12 @@ def matcher_loops_bench(cpu=True):
     d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
     fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
     m = ORBmatcher(0.6, True)
-    out = {"search_by_projection_2000x2000_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
-           "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
-           "search_window_2000x2000_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
-    if cpu:
-        import oracle
-        ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, keep2)
-        out["cpu_baseline"] = {
-            "kind": "port", "cores": 1, "unit": "ms per call", "sample": "the same inputs, 5 calls each",
-            "search_by_projection_2000x2000_ms": ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True), 5),
-            "search_by_bow_2000x2100_ms": ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True), 5)}
-    return out
+    return {"search_by_projection_2000x2000_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
+            "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
+            "search_window_2000x2000_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
 
 
-def stereo_bench(cpu=True):
+def stereo_bench():
     """Config 5: one 1242x375 KITTI-shaped pair through the drop-in calls -- left and right ORBextractor::operator()
     (host image in, keypoints / descriptors out) and Frame::ComputeStereoMatches on the two resident pyramids."""
     from orb_slam2_e_amd import ComputeStereoMatches, ORBextractor
@@ -193,19 +216,8 @@ def stereo_bench(cpu=True):
     t0 = time.perf_counter()
     for _ in range(reps): ComputeStereoMatches(eL, eR, mb, np.float32(bf))
     t_st = (time.perf_counter() - t0) / reps
-    out = {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "compute_stereo_matches_ms": t_st * 1e3,
-           "stereo_pairs_per_s": 1.0 / t_all, "matched": int((u >= 0).sum())}
-    if cpu:
-        import oracle
-        oL, oR = oracle.OrbOracle(*PARAMS), oracle.OrbOracle(*PARAMS)
-        t0 = time.perf_counter()
-        kL, dL = oL.extract(left); kR, dR = oR.extract(right)
-        t1 = time.perf_counter()
-        oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(bf))
-        t2 = time.perf_counter()
-        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "ms per pair", "sample": "the same pair, once",
-                               "stereo_frame_ms": (t2 - t0) * 1e3, "compute_stereo_matches_ms": (t2 - t1) * 1e3}
-    return out
+    return {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "compute_stereo_matches_ms": t_st * 1e3,
+            "stereo_pairs_per_s": 1.0 / t_all, "matched": int((u >= 0).sum())}
 
 
 def main():
@@ -214,6 +226,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of one step's results (outside the timed region)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1: steps of a context whose records travel in one RCCL gather (default: every step; larger values "
@@ -221,8 +234,8 @@ def main():
                          "flushed before every barrier).  Not measurable on the one-GPU development box: tune against SCALE_rNN.json")
     ap.add_argument("--pipeline", type=int, default=3, help="independent contexts/streams the steps rotate over")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on one GPU")
-    ap.add_argument("--host-io", action="store_true", help="also time the PCIe-inclusive path (host images in, host results out)")
-    ap.add_argument("--no-fem", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive leg (host images in, host results out)")
+    ap.add_argument("--no-fem", action="store_true", help="skip the FEM, matcher-loop and stereo legs")
     ap.add_argument("--match-kernel", choices=["auto", "popcount"], default="auto",
                     help="all-pairs matcher: auto = FP4 matrix-core kernel (default), popcount = XOR + v_bcnt kernel; same results")
     ap.add_argument("--fem-meshes", type=int, default=256)
@@ -248,10 +261,11 @@ def main():
 
     from orb_slam2_e_amd import ORBextractor, ORBmatcher
     from orb_slam2_e_amd._lib import lib
-    from orb_slam2_e_amd.synth import synth_frames
+    from orb_slam2_e_amd.shard import RecordLayout, ShardedPipeline, max_over_ranks
+    from orb_slam2_e_amd.synth import synth_sequence
 
-    # ---- inputs resident in HBM (weak scaling: each rank owns its own 64 frames)
-    frames = synth_frames(BATCH, W, H, start=rank * BATCH)
+    # ---- inputs resident in HBM (weak scaling: each rank owns its own 64 frames = one camera pan over its own scene)
+    frames = synth_sequence(BATCH, W, H, start=rank * BATCH)
     d_frames = torch.from_numpy(frames).to(dev)
     m = ORBmatcher(0.6)
     L = lib()
@@ -263,68 +277,58 @@ def main():
     # `--pipeline P` independent contexts (extractor workspace + result buffers + HIP stream): step k runs
     # on context k % P, so the latency-bound stages of one batch (pyramid, octree) overlap the VALU-bound
     # stages of the next (FAST, match).  Every step still does the full work on its own buffers.
-    class Ctx:
+    class Work:
         pass
-    ctxs = []
-    for i in range(max(1, args.pipeline)):
-        c = Ctx()
-        c.ex = ORBextractor(*PARAMS)
-        c.tstream = torch.cuda.Stream(device=dev) if args.pipeline > 1 else torch.cuda.current_stream()
-        c.stream = c.tstream.cuda_stream
-        cap = c.ex.capacity
-        c.best = torch.empty((BATCH, cap), dtype=torch.int32, device=dev)
-        c.second = torch.empty_like(c.best); c.idx = torch.empty_like(c.best); c.match12 = torch.empty_like(c.best)
-        c.nmatch = torch.zeros(BATCH, dtype=torch.int32, device=dev)
-        c.ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, c.stream)  # sizes the workspace
-        c.kps_p, c.desc_p, c.cnt_p, _ = c.ex.result_dev()
-        ctxs.append(c)
+
+    def make_context(c):
+        u = Work()
+        u.ex = ORBextractor(*PARAMS)
+        u.tstream = torch.cuda.Stream(device=dev) if args.pipeline > 1 else torch.cuda.current_stream()
+        u.stream = u.tstream.cuda_stream
+        cap = u.ex.capacity
+        u.best = torch.empty((BATCH, cap), dtype=torch.int32, device=dev)
+        u.second = torch.empty_like(u.best); u.idx = torch.empty_like(u.best); u.match12 = torch.empty_like(u.best)
+        u.nmatch = torch.zeros(BATCH, dtype=torch.int32, device=dev)
+        u.ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, u.stream)  # sizes the workspace
+        u.kps_p, u.desc_p, u.cnt_p, _ = u.ex.result_dev()
+        return u
+
+    def compute(c, k):
+        u = c.user
+        u.ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, u.stream)
+        m.match_batch_device(u.desc_p, u.cnt_p, cap, qa.data_ptr(), qb.data_ptr(), BATCH, u.best.data_ptr(),
+                             u.second.data_ptr(), u.idx.data_ptr(), u.match12.data_ptr(), u.nmatch.data_ptr(),
+                             stream=u.stream)
+
+    def pack(c, dst):
+        """fixed-size record {kps[CAP], desc[CAP][32], counts, match12[CAP], nmatch} of this step -> dst (device)"""
+        u = c.user
+        p0 = dst.data_ptr()
+        L.orbx_copy_results_dev(u.ex._h, C.c_void_p(p0 + lay.o_kps), C.c_void_p(p0 + lay.o_desc), C.c_void_p(p0 + lay.o_cnt),
+                                C.c_void_p(u.stream))
+        dst[lay.o_m12:lay.o_nm].copy_(u.match12.view(torch.uint8).reshape(-1), non_blocking=True)
+        dst[lay.o_nm:lay.rec_bytes].copy_(u.nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
+
+    cap = PARAMS[0] + 3 * PARAMS[2]
+    lay = RecordLayout(BATCH, cap)
+    captured = {}
+
+    def on_receive(k, r, rec):
+        if captured.get("want") == k:
+            captured[r] = rec.cpu().clone()
+
+    pipe = ShardedPipeline(rank, world, lay.rec_bytes, max(1, args.pipeline), args.gather_every, compute, pack,
+                           make_context=make_context, stream_ctx=lambda c: torch.cuda.stream(c.user.tstream),
+                           on_receive=on_receive, send_device=dev, coll_device=cdev, enable_gather=not args.no_gather)
+    ctxs = [c.user for c in pipe.ctxs]
+    assert ctxs[0].ex.capacity == cap
+    GE = pipe.GE
     torch.cuda.synchronize()
-    # fixed-size records {kps[CAP], desc[CAP][32], counts, match12[CAP], nmatch} -> one send buffer
-    n_kps, n_desc, n_cnt, n_m12 = cap * 28 * BATCH, cap * 32 * BATCH, 4 * BATCH, cap * 4 * BATCH
-    rec_bytes = n_kps + n_desc + n_cnt + n_m12 + n_cnt
     counts_t = torch.zeros(BATCH, dtype=torch.int32, device=dev)
-    do_gather = world > 1 and not args.no_gather
-    GE = max(1, args.gather_every)
-    for c in ctxs:
-        c.nfill = 0   # records waiting in c.send
-        c.send = torch.empty(GE * rec_bytes, dtype=torch.uint8, device=dev) if do_gather else None
-        c.recv = [torch.empty(GE * rec_bytes, dtype=torch.uint8, device=cdev) for _ in range(world)] if (do_gather and rank == 0) else None
-
-    def pack_records(c):
-        base = c.nfill * rec_bytes
-        p0 = c.send.data_ptr() + base
-        L.orbx_copy_results_dev(c.ex._h, C.c_void_p(p0), C.c_void_p(p0 + n_kps), C.c_void_p(p0 + n_kps + n_desc),
-                                C.c_void_p(c.stream))
-        o = base + n_kps + n_desc + n_cnt
-        c.send[o:o + n_m12].copy_(c.match12.view(torch.uint8).reshape(-1), non_blocking=True)
-        c.send[o + n_m12:o + n_m12 + n_cnt].copy_(c.nmatch.view(torch.uint8).reshape(-1), non_blocking=True)
-        c.nfill += 1
-
-    def gather_bucket(c):
-        """The records of the last c.nfill steps of this context -> rank 0 (every rank holds the same number)."""
-        n = c.nfill * rec_bytes
-        if not do_gather or n == 0:
-            return
-        with torch.cuda.stream(c.tstream):
-            recv = [r[:n] for r in c.recv] if rank == 0 else None
-            dist.gather(c.send[:n].cpu() if rehearse else c.send[:n], recv, dst=0)
-        c.nfill = 0
-
-    def step(k):
-        c = ctxs[k % len(ctxs)]
-        with torch.cuda.stream(c.tstream):
-            c.ex.extract_batch_device(d_frames.data_ptr(), BATCH, H, W, c.stream)
-            m.match_batch_device(c.desc_p, c.cnt_p, cap, qa.data_ptr(), qb.data_ptr(), BATCH, c.best.data_ptr(),
-                                 c.second.data_ptr(), c.idx.data_ptr(), c.match12.data_ptr(), c.nmatch.data_ptr(),
-                                 stream=c.stream)
-            if do_gather:
-                pack_records(c)
-                if c.nfill == GE:
-                    gather_bucket(c)
+    step = pipe.step
 
     def sync():
-        for c in ctxs:
-            gather_bucket(c)   # partial buckets: every step's records are on rank 0 before the barrier
+        pipe.flush()           # partial buckets: every step's records are on rank 0 before the barrier
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -348,7 +352,7 @@ def main():
         return kern
 
     # untimed pass with events around every kernel: the per-kernel split and the dominant kernel
-    KINDS = ["k_pyr_level0", "k_pyr_resize", "k_fast_cells", "k_octree", "k_blur", "k_describe"]
+    KINDS = [n for n in KERNEL_KINDS]
     for c in ctxs:
         L.orbx_profile_enable(c.ex._h, -1)
     L.orbm_profile_enable(1)
@@ -360,7 +364,7 @@ def main():
     kern_all = read_profiles()
     split_ms = {k: v[0] / nprof for k, v in kern_all.items()}
     # a start/stop event pair inflates each measured launch by ~10-20 us (rocprof traces in profiles/); rank the
-    # kinds by time net of 15 us per launch so that the 7-launch resize chain is not picked for its event overhead
+    # kinds by time net of 15 us per launch so that a multi-launch chain is not picked for its event overhead
     dom = max(split_ms, key=lambda k: split_ms[k] - 0.015 * kern_all[k][1] / nprof)
     # timed region: events around the dominant kernel only (each event costs dispatch-gap time)
     for c in ctxs:
@@ -371,11 +375,7 @@ def main():
     for k in range(args.steps):
         step(k)
     sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, world, cdev)
 
     # ---- dominant kernel's launch times (HIP events on the launch stream, recorded in the timed region)
     kern = read_profiles()
@@ -384,8 +384,40 @@ def main():
     L.orbm_profile_enable(0)
     ex, nmatch, stream = ctxs[0].ex, ctxs[0].nmatch, ctxs[0].stream
 
+    # ---- the checker (outside the timed region): one more step on context 0, its results against the CPU oracle on
+    # every rank; for N > 1 rank 0 also compares the records it received with the senders' own bytes (checksums)
+    verified, verify_note = None, None
+    if not args.no_verify:
+        import hashlib
+        captured["want"] = args.steps
+        step(args.steps)                        # args.steps % P need not be 0: any context does the full work
+        sync()
+        u = pipe.ctxs[args.steps % len(pipe.ctxs)].user
+        rec = torch.empty(lay.rec_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(u.tstream):
+            pack(pipe.ctxs[args.steps % len(pipe.ctxs)], rec)
+        torch.cuda.synchronize()
+        rec_h = rec.cpu().numpy()
+        R = lay.unpack(rec_h)
+        best, second, idx = (t.cpu().numpy() for t in (u.best, u.second, u.idx))
+        ok, why = verify_against_oracle(frames, R["kps"], R["desc"], R["counts"], best, second, idx, R["match12"], R["nmatch"],
+                                        qb.cpu().numpy())
+        digest = hashlib.sha256(rec_h.tobytes()).hexdigest()
+        if world > 1:
+            oks = [None] * world
+            dist.all_gather_object(oks, (bool(ok), why, digest))
+            ok = all(o[0] for o in oks)
+            why = next((f"rank {r}: {o[1]}" for r, o in enumerate(oks) if not o[0]), None)
+            if rank == 0 and pipe.do_gather:
+                for r in range(world):
+                    got = captured.get(r)
+                    if got is None or hashlib.sha256(got.numpy().tobytes()).hexdigest() != oks[r][2]:
+                        ok, why = False, f"record gathered from rank {r} differs from what that rank produced"
+                        break
+        verified, verify_note = bool(ok), why
+
     host_io = None
-    if args.host_io and rank == 0:
+    if not args.no_host_io and rank == 0:
         # PCIe-inclusive rate: 64 host frames in, every frame's keypoints / descriptors / counts out.  (a) the plain
         # synchronous calls on pageable memory; (b) what a batch front-end does: pinned buffers, the upload, the kernels
         # and the download of a batch queued on one stream per context, contexts rotating.
@@ -428,11 +460,14 @@ def main():
             bw[name] = 5 * (64 << 20) / (time.perf_counter() - t0) / 1e9
         host_io = {"pcie_pinned_copy_GBps": bw, "frames_per_s_extract_only_sync_pageable": rate_sync, "frames_per_s_extract_only_pinned_pipelined": rate_pipe,
                    "bytes_per_frame": W * H + cap * 60 + 4,
-                   "note": "64 host u8 frames in over PCIe, all keypoints+descriptors+counts out; no match"}
+                   "note": "64 host u8 frames in over PCIe, all keypoints+descriptors+counts out; no match; never `value`"}
+        for c in ctxs:
+            del c.pin_in, c.d_in, c.pin_kps, c.pin_desc, c.pin_cnt
 
     fem = None
+    fem_csr = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"orbx_bench_fem_csr_{os.getpid()}.npz")
     if not args.no_fem:
-        fem = fem_bench(rank, world, dist, torch, dev, cdev, nmesh=args.fem_meshes, cpu=not args.no_cpu_baseline)
+        fem = fem_bench(rank, world, dist, torch, dev, cdev, nmesh=args.fem_meshes, csr_out=fem_csr)
 
     if rank == 0:
         total_frames = world * BATCH * args.steps
@@ -449,9 +484,12 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "verified": verified,
             "config": {"workload": (f"{world}xMI355X: {world * BATCH}-frame batch sharded {BATCH}/GPU, " if world > 1 else
                                     f"1xMI355X: batch of {BATCH} ") + "synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
                                    "+ 2000x2000 brute-force Hamming match per frame" + (", RCCL gather on rank 0" if world > 1 else ""),
+                       "frames": "synth_sequence: each GPU's 64 frames are one camera pan (2, 1) px per frame over its own scene of "
+                                 "rectangles and discs + per-frame noise; frame i is matched against frame i+1 mod 64",
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
                        "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma (FP4 matrix cores)",
                        "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0 ({GE} steps per RCCL gather)" if world > 1 else "single GPU",
@@ -463,6 +501,11 @@ def main():
             "pipeline_hbm_frac": value / world * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
             "kernel_ms_per_step_untimed_pass": split_ms,
         }
+        if verified is not None:
+            out["verified_what"] = ("one step's keypoints (float bits), descriptors, best/second/arg-best, accepted matches and match counts "
+                                    "of all frames of every rank == CPU oracle, outside the timed region" +
+                                    ("; gathered records == the senders' bytes (sha256)" if world > 1 and pipe.do_gather else "") +
+                                    (f"; FAILED: {verify_note}" if not verified else ""))
         # the all-pairs matcher is the one contraction on the path: 2 x 256 FP4 multiply-adds per descriptor pair
         nk = counts.double().clamp(max=cap).cpu()
         pair_flops = 512.0 * float((nk[qa.cpu().long()] * nk[qb.cpu().long()]).sum())
@@ -476,28 +519,35 @@ def main():
             tf = pair_flops / (avg_launch_ms * 1e-3) / 1e12
             out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf / MFMA_FP4_PEAK_TFLOPS, "flops_per_launch": pair_flops})
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tfile):   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-            tr = json.load(open(tfile))
-            if dom in tr:
-                out["roofline"]["traffic"] = tr[dom]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = tr[dom]["source"]
-                if tr[dom].get("valu_wave_insts_per_launch"):
-                    # the kernels that dominate this path are bound by integer VALU issue, not by HBM:
-                    # the same launch time priced against the instruction count of the committed PMC pass
-                    ginst = tr[dom]["valu_wave_insts_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
-                    out["roofline"]["valu"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64-instr/s",
-                                               "frac": ginst / VALU_PEAK_GINST,
-                                               "wave_insts_per_launch": tr[dom]["valu_wave_insts_per_launch"]}
+        tr = load_traffic()   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        if dom in tr:
+            out["roofline"]["traffic"] = tr[dom]["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr[dom]["source"]
+            if tr[dom].get("valu_wave_insts_per_launch"):
+                # the kernels that dominate this path are bound by integer VALU issue, not by HBM:
+                # the same launch time priced against the instruction count of the committed PMC pass
+                ginst = tr[dom]["valu_wave_insts_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+                out["roofline"]["valu"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64-instr/s",
+                                           "frac": ginst / VALU_PEAK_GINST,
+                                           "wave_insts_per_launch": tr[dom]["valu_wave_insts_per_launch"]}
         if host_io is not None:
             out["host_io"] = host_io
         if fem is not None:
             out["fem"] = fem
+            if verified is not None and "verified" in fem:
+                out["verified"] = bool(verified and fem["verified"])
         if not args.no_fem:
-            out["matcher_loops"] = matcher_loops_bench(cpu=not args.no_cpu_baseline)
-            out["stereo"] = stereo_bench(cpu=not args.no_cpu_baseline)
+            out["matcher_loops"] = matcher_loops_bench()
+            out["stereo"] = stereo_bench()
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            legs = ["extract"] + ([] if args.no_fem else ["fem", "stereo", "loops"])
+            cb = cpu_baseline_child(legs, fem_csr if os.path.exists(fem_csr) else None)
+            out["cpu_baseline"] = cb.get("extract_match", cb)
+            if "fem" in cb and fem is not None: out["fem"]["cpu_baseline"] = cb["fem"]
+            if "stereo" in cb and "stereo" in out: out["stereo"]["cpu_baseline"] = cb["stereo"]
+            if "matcher_loops" in cb and "matcher_loops" in out: out["matcher_loops"]["cpu_baseline"] = cb["matcher_loops"]
+        if os.path.exists(fem_csr):
+            os.unlink(fem_csr)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

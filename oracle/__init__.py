@@ -24,10 +24,14 @@ CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "fem_oracle.c", "stereo_oracle.c", "orb_pattern_data.h")]
+    """liboracle.so (the checker); with ORACLE_NATIVE=1 in the environment liboracle_native.so instead, the same sources
+    built -O3 -march=native on this machine (bench.py's cpu_baseline leg, oracle/cpu_bench.py)."""
+    name = "liboracle_native.so" if os.environ.get("ORACLE_NATIVE") == "1" else "liboracle.so"
+    so = os.path.join(_HERE, name)
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "fem_oracle.c", "stereo_oracle.c", "orb_pattern_data.h",
+                                             "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
 
 

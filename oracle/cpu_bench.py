@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""CPU baseline of bench.py (SURVEY 8d protocol).  TEST / MEASUREMENT INFRASTRUCTURE, never part of the product.
+
+Runs the oracle (kind "port": the CPU restatement of the reference's algorithm, built -O3 -march=native
+-ffp-contract=off on THIS machine as liboracle_native.so) on a bounded sample of the bench workload:
+  * single thread pinned to one core (sched_setaffinity = taskset -c), 3 warm-ups, median of >= 20 runs of
+    extract (one 640x480 frame), match (2000x2000 Hamming + best/second + TH_LOW / ratio filter) and the
+    frames/s of extract + match against the previous frame;
+  * all host cores: one worker process per core, each pinned, one frame per worker at a time.
+Prints one JSON object.  Started by bench.py as a child process (it never touches the GPU).
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+os.environ["ORACLE_NATIVE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PARAMS = (2000, 1.2, 8, 20, 7)
+
+
+def _pin(cpu):
+    try:
+        os.sched_setaffinity(0, {cpu})
+        return True
+    except OSError:
+        return False
+
+
+def _extract_match(o, oracle, imgs, prev):
+    kps, desc = o.extract(imgs)
+    if prev is not None:
+        b, s, ix = oracle.match_bruteforce(prev, desc)
+        oracle.match_filter(b, s, ix, 45, 0.6)
+    return desc
+
+
+def _worker(cpu, frames, reps, q, barrier):
+    import oracle
+    _pin(cpu)
+    o = oracle.OrbOracle(*PARAMS)
+    prev = _extract_match(o, oracle, frames[0], None)
+    barrier.wait()
+    t0 = time.perf_counter()
+    n = 0
+    for r in range(reps):
+        for f in frames:
+            prev = _extract_match(o, oracle, f, prev)
+            n += 1
+    q.put((n, t0, time.perf_counter()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--all-cores-frames", type=int, default=16, help="frames per worker in the all-cores pass")
+    ap.add_argument("--legs", default="extract", help="comma list of extract, fem, stereo, loops")
+    ap.add_argument("--fem-csr", default=None, help=".npz with rp, col, val, b of the single config-3 mesh (written by bench.py)")
+    ap.add_argument("--fem-iters", type=int, default=200)
+    args = ap.parse_args()
+    legs = args.legs.split(",")
+    result = {}
+    if "extract" in legs:
+        result["extract_match"] = extract_leg(args)
+    if "fem" in legs and args.fem_csr:
+        result["fem"] = fem_leg(args)
+    if "stereo" in legs:
+        result["stereo"] = stereo_leg(args)
+    if "loops" in legs:
+        result["matcher_loops"] = loops_leg(args)
+    print(json.dumps(result), flush=True)
+
+
+def _median_ms(f, runs=20, warmup=3):
+    for _ in range(warmup): f()
+    t = []
+    for _ in range(runs):
+        t0 = time.perf_counter(); f(); t.append(time.perf_counter() - t0)
+    return float(np.median(t)) * 1e3
+
+
+PROTOCOL = "one thread pinned to one core, 3 warm-ups, median of 20 runs, -O3 -march=native -ffp-contract=off"
+
+
+def fem_leg(args):
+    import oracle
+    _pin(sorted(os.sched_getaffinity(0))[0])
+    z = np.load(args.fem_csr)
+    rp, col, val, b = z["rp"], z["col"], z["val"], z["b"]
+    ms = _median_ms(lambda: oracle.fem_cg(rp, col, val, b, args.fem_iters, 0.0))
+    return {"value": args.fem_iters / (ms * 1e-3), "unit": "CG iters/s", "cores": 1, "kind": "port",
+            "sample": f"oracle Jacobi-PCG, {args.fem_iters} iterations on the single {len(b)}-dof mesh (nnz {len(val)}); " + PROTOCOL}
+
+
+def stereo_leg(args):
+    import oracle
+    from orb_slam2_e_amd.synth import synth_stereo_pair
+    _pin(sorted(os.sched_getaffinity(0))[0])
+    fx, bf = 718.856, 386.1448
+    mb = np.float32(bf) / np.float32(fx)
+    left, right = synth_stereo_pair(0)
+    oL, oR = oracle.OrbOracle(*PARAMS), oracle.OrbOracle(*PARAMS)
+    st = {}
+
+    def frame():
+        st["kL"], st["dL"] = oL.extract(left); st["kR"], st["dR"] = oR.extract(right)
+        oracle.stereo_matches(oL, oR, st["kL"], st["dL"], st["kR"], st["dR"], mb, np.float32(bf))
+    all_ms = _median_ms(frame)
+    sm_ms = _median_ms(lambda: oracle.stereo_matches(oL, oR, st["kL"], st["dL"], st["kR"], st["dR"], mb, np.float32(bf)))
+    return {"kind": "port", "cores": 1, "unit": "ms per pair", "sample": "the same 1242x375 pair; " + PROTOCOL,
+            "stereo_frame_ms": all_ms, "compute_stereo_matches_ms": sm_ms}
+
+
+def loops_leg(args):
+    import oracle
+    from orb_slam2_e_amd.synth import synth_bow_case, synth_projection_case
+    _pin(sorted(os.sched_getaffinity(0))[0])
+    q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(0, n=2000, nq=2000, hot=2000)
+    d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
+    ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, keep2)
+    return {"kind": "port", "cores": 1, "unit": "ms per call", "sample": "the same inputs; " + PROTOCOL,
+            "search_by_projection_2000x2000_ms": _median_ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True)),
+            "search_by_bow_2000x2100_ms": _median_ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True))}
+
+
+def extract_leg(args):
+    import oracle
+    from orb_slam2_e_amd.synth import synth_sequence
+    cpus = sorted(os.sched_getaffinity(0))
+    pinned = _pin(cpus[0])
+    nd = min(max(args.runs, 2), 64)
+    frames = synth_sequence(nd)
+    o = oracle.OrbOracle(*PARAMS)
+    descs = [None] * nd
+    for i in range(args.warmup):
+        descs[i % nd] = o.extract(frames[i % nd])[1]
+    t_ex, t_m = [], []
+    prev = descs[(args.warmup - 1) % nd] if args.warmup else None
+    for i in range(args.runs):
+        t0 = time.perf_counter()
+        d = o.extract(frames[i % nd])[1]
+        t1 = time.perf_counter()
+        if prev is not None:
+            b, s, ix = oracle.match_bruteforce(prev, d)
+            oracle.match_filter(b, s, ix, 45, 0.6)
+            t_m.append(time.perf_counter() - t1)
+        t_ex.append(t1 - t0)
+        prev = d
+    ex_ms, m_ms = float(np.median(t_ex)) * 1e3, float(np.median(t_m)) * 1e3
+    out = {"value": 1e3 / (ex_ms + m_ms), "unit": "frames/s", "cores": 1, "kind": "port",
+           "extract_ms_median": ex_ms, "match_ms_median": m_ms, "runs": args.runs, "warmup": args.warmup,
+           "pinned_to_cpu": cpus[0] if pinned else None,
+           "flags": "-O3 -march=native -ffp-contract=off (oracle/Makefile: liboracle_native.so, built on this host)",
+           "sample": f"{args.runs} frames of the bench sequence (640x480, 2000 features, 8 levels), one thread pinned to one core, "
+                     f"{args.warmup} warm-ups; value = 1 / (median extract + median 2000x2000 match + filter)"}
+    # all host cores: one pinned worker per core, one frame at a time per worker
+    if pinned:
+        os.sched_setaffinity(0, set(cpus))
+    nproc = len(cpus)
+    ctx = mp.get_context("fork")
+    q, barrier = ctx.Queue(), ctx.Barrier(nproc)
+    per = max(1, args.all_cores_frames)
+    procs = [ctx.Process(target=_worker, args=(cpus[w], frames[(w * per) % nd:(w * per) % nd + per], 1, q, barrier)) for w in range(nproc)]
+    for p in procs: p.start()
+    res = [q.get() for _ in procs]
+    for p in procs: p.join()
+    total = sum(r[0] for r in res)
+    wall = max(r[2] for r in res) - min(r[1] for r in res)
+    out["all_cores"] = {"value": total / wall, "unit": "frames/s", "cores": nproc, "nproc": os.cpu_count(),
+                        "sample": f"{total} frames, one pinned worker process per core ({nproc} cores available to this process, "
+                                  f"os.cpu_count() = {os.cpu_count()}), extract + match each, {wall:.2f} s wall"}
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -543,6 +543,7 @@ struct fem_model {
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
     hipGraphExec_t cg_graph = nullptr; // GRAPH_ITERS CG iterations captured once (launch-bound single-mesh case)
     orbx::KernelProfiler prof;
 };
@@ -975,6 +976,7 @@ int fem_cg_iterate(fem_model *m, int n, void *stream)
 {
     if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    m->cg_stream = st;
     int i = 0;
     // Small batches are launch-bound (3 short kernels per iteration): replay a captured
     // hipGraph of GRAPH_ITERS iterations.  Graph nodes carry no timing events, so this
@@ -1020,11 +1022,13 @@ int fem_spmv_repeat(fem_model *m, int n, void *stream)
 int fem_cg_result(fem_model *m, double *x, double *relres)
 {
     if (!m || !m->cg_ready) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
-    ORBX_HIP(hipDeviceSynchronize());
-    if (x) ORBX_HIP(hipMemcpy(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost));
+    // the copies wait for the stream the iterations ran on, not for the whole device
+    hipStream_t st = m->cg_stream ? m->cg_stream : m->stream;
+    std::vector<CgScal> sc(relres ? m->nmesh : 0);
+    if (x) ORBX_HIP(hipMemcpyAsync(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost, st));
+    if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nmesh, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     if (relres) {
-        std::vector<CgScal> sc(m->nmesh);
-        ORBX_HIP(hipMemcpy(sc.data(), m->d_sc, sizeof(CgScal) * m->nmesh, hipMemcpyDeviceToHost));
         for (int i = 0; i < m->nmesh; ++i) relres[i] = sc[i].bb > 0 ? sqrt(sc[i].rr / sc[i].bb) : 0.0;
     }
     return ORBX_OK;

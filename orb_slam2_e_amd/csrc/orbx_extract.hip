@@ -1513,6 +1513,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     pf.stop(5, st);
     ORBX_HIP(hipGetLastError());
     ex->last_batch = batch;
+    ex->last_stream = st;
     return ORBX_OK;
 }
 
@@ -1545,15 +1546,18 @@ int orbx_profile_read(orbx_extractor *ex, int max_kinds, const char **names, dou
 int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *desc, int cap, int *n)
 {
     if (!ex || frame < 0 || frame >= ex->last_batch || !n) ORBX_FAIL(ORBX_ERR_ARG, "bad download arguments");
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    ORBX_HIP(hipDeviceSynchronize());
+    // copies queued behind the batch on ITS stream and one wait for that stream: the other SLAM threads' streams
+    // (LocalMapping, LoopClosing) are not stalled, as a device-wide synchronisation would
+    hipStream_t st = ex->last_stream;
     int cnt = 0;
-    ORBX_HIP(hipMemcpy(&cnt, ex->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpyAsync(&cnt, ex->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     *n = cnt;
     if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "keypoint buffer too small");
     if (cnt > 0) {
-        if (kps) ORBX_HIP(hipMemcpy(kps, ex->d_kps + (size_t)frame * ex->kcap, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost));
-        if (desc) ORBX_HIP(hipMemcpy(desc, ex->d_desc + (size_t)frame * ex->kcap * 32, (size_t)32 * cnt, hipMemcpyDeviceToHost));
+        if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps + (size_t)frame * ex->kcap, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost, st));
+        if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc + (size_t)frame * ex->kcap * 32, (size_t)32 * cnt, hipMemcpyDeviceToHost, st));
+        ORBX_HIP(hipStreamSynchronize(st));
     }
     return ORBX_OK;
 }
@@ -1561,12 +1565,12 @@ int orbx_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *de
 int orbx_download_batch(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts)
 {
     if (!ex || ex->last_batch <= 0 || !ex->d_kps) ORBX_FAIL(ORBX_ERR_ARG, "no results");
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    ORBX_HIP(hipDeviceSynchronize());
+    hipStream_t st = ex->last_stream;
     const size_t B = (size_t)ex->last_batch;
-    if (counts) ORBX_HIP(hipMemcpy(counts, ex->d_counts, sizeof(int) * B, hipMemcpyDeviceToHost));
-    if (kps) ORBX_HIP(hipMemcpy(kps, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B, hipMemcpyDeviceToHost));
-    if (desc) ORBX_HIP(hipMemcpy(desc, ex->d_desc, (size_t)32 * ex->kcap * B, hipMemcpyDeviceToHost));
+    if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_counts, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B, hipMemcpyDeviceToHost, st));
+    if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc, (size_t)32 * ex->kcap * B, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     return ORBX_OK;
 }
 
@@ -1639,14 +1643,13 @@ static int copy_level(orbx_extractor *ex, const uint8_t *buf, int frame, int lev
 {
     if (!ex || !out || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels)
         ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    ORBX_HIP(hipDeviceSynchronize());
     const LevelInfo &lv = ex->lv[level];
     const int w = padded ? lv.w + 2 * EDGE : lv.w, h = padded ? lv.h + 2 * EDGE : lv.h;
     if (out_stride < w) ORBX_FAIL(ORBX_ERR_ARG, "out_stride too small");
     const uint8_t *src = buf + (size_t)frame * ex->frame_bytes + lv.off +
                          (padded ? (size_t)(PADX - EDGE) : (size_t)EDGE * lv.stride + PADX);
-    ORBX_HIP(hipMemcpy2D(out, out_stride, src, lv.stride, w, h, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy2DAsync(out, out_stride, src, lv.stride, w, h, hipMemcpyDeviceToHost, ex->last_stream));
+    ORBX_HIP(hipStreamSynchronize(ex->last_stream));
     return ORBX_OK;
 }
 
@@ -1661,16 +1664,18 @@ int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, float 
 {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels || !n)
         ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    ORBX_HIP(hipDeviceSynchronize());
+    hipStream_t st = ex->last_stream;
     int M = 0;
-    ORBX_HIP(hipMemcpy(&M, ex->d_level_ncand + frame * ex->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpyAsync(&M, ex->d_level_ncand + frame * ex->nlevels + level, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     *n = M;
     if (M > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "candidate buffer too small");
     std::vector<uint32_t> pk(M > 0 ? M : 1);
-    if (M > 0)
-        ORBX_HIP(hipMemcpy(pk.data(), ex->d_kpos + (size_t)frame * ex->keys_per_frame + ex->lv[level].key_base,
-                           sizeof(uint32_t) * M, hipMemcpyDeviceToHost));
+    if (M > 0) {
+        ORBX_HIP(hipMemcpyAsync(pk.data(), ex->d_kpos + (size_t)frame * ex->keys_per_frame + ex->lv[level].key_base,
+                                sizeof(uint32_t) * M, hipMemcpyDeviceToHost, st));
+        ORBX_HIP(hipStreamSynchronize(st));
+    }
     for (int i = 0; i < M; i++) {
         xyr[3 * i] = (float)((pk[i] >> 8) & 0xfffu);
         xyr[3 * i + 1] = (float)(pk[i] >> 20);
@@ -1683,10 +1688,10 @@ int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_ke
 {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels || !n)
         ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    ORBX_HIP(hipDeviceSynchronize());
+    hipStream_t st = ex->last_stream;
     std::vector<int> lc(ex->nlevels);
-    ORBX_HIP(hipMemcpy(lc.data(), ex->d_level_count + frame * ex->nlevels, sizeof(int) * ex->nlevels, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpyAsync(lc.data(), ex->d_level_count + frame * ex->nlevels, sizeof(int) * ex->nlevels, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     int first = 0;
     for (int l = 0; l < level; l++) first += lc[l];
     const int cnt = lc[level];
@@ -1694,9 +1699,10 @@ int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_ke
     if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "keypoint buffer too small");
     if (cnt == 0) return ORBX_OK;
     std::vector<uint32_t> pk(cnt);
-    ORBX_HIP(hipMemcpy(pk.data(), ex->d_sel + (size_t)frame * ex->sel_per_frame + ex->lv[level].sel_base,
-                       sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(kps, ex->d_kps + (size_t)frame * ex->kcap + first, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpyAsync(pk.data(), ex->d_sel + (size_t)frame * ex->sel_per_frame + ex->lv[level].sel_base,
+                            sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps + (size_t)frame * ex->kcap + first, sizeof(orbx_keypoint) * cnt, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < cnt; i++) { // level coordinates, before pt *= scale
         kps[i].x = (float)((pk[i] >> 8) & 0xfffu) + MIN_BORDER;
         kps[i].y = (float)(pk[i] >> 20) + MIN_BORDER;

@@ -61,6 +61,8 @@ struct orbx_extractor {
     int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, oct_lds = 0, oct_kcap = 0;
 
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr; // the stream the last batch was queued on (the handle's own or the caller's): downloads wait for it only
+    hipStream_t st_stream = nullptr;   // ... and the last stereo match
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_in = nullptr;
     size_t in_bytes = 0;
     orbx_detail::LevelInfo *d_lv = nullptr;

@@ -231,8 +231,9 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
         left->st_batch = left->batch;
     }
     // streams: results of both extractors must be complete before matching
-    if (st != left->stream) ORBX_HIP(hipStreamSynchronize(left->stream));
-    if (st != right->stream) ORBX_HIP(hipStreamSynchronize(right->stream));
+    if (st != left->last_stream) ORBX_HIP(hipStreamSynchronize(left->last_stream));
+    if (st != right->last_stream) ORBX_HIP(hipStreamSynchronize(right->last_stream));
+    left->st_stream = st;
     const float maxD = mbf / mb; // :557-559
     const int nRows = left->lv[0].h;
     hipLaunchKernelGGL(k_stereo_prep, dim3((cap + ST_T - 1) / ST_T, B), dim3(ST_T), 0, st, right->d_kps, right->d_counts, cap,
@@ -252,14 +253,16 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
 int orbx_stereo_download(orbx_extractor *left, int frame, float *uRight, float *depth, int cap, int *n)
 {
     if (!left || !left->d_uright || frame < 0 || frame >= left->last_batch || !n) ORBX_FAIL(ORBX_ERR_ARG, "no stereo results");
-    ORBX_HIP(hipDeviceSynchronize());
+    hipStream_t st = left->st_stream;   // the copies wait for the stereo match's stream only
     int cnt = 0;
-    ORBX_HIP(hipMemcpy(&cnt, left->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpyAsync(&cnt, left->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     *n = cnt;
     if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "buffer too small");
     if (cnt > 0) {
-        if (uRight) ORBX_HIP(hipMemcpy(uRight, left->d_uright + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost));
-        if (depth) ORBX_HIP(hipMemcpy(depth, left->d_depth + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+        if (uRight) ORBX_HIP(hipMemcpyAsync(uRight, left->d_uright + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+        if (depth) ORBX_HIP(hipMemcpyAsync(depth, left->d_depth + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
+        ORBX_HIP(hipStreamSynchronize(st));
     }
     return ORBX_OK;
 }

@@ -5,18 +5,16 @@ numpy-only; identical on the build container and the GPU box (same numpy).
 import numpy as np
 
 
-def synth_frame(k, w=640, h=480):
-    """Frame k (seed 1000+k): mid-grey 128 + 300 filled rectangles (side 8-80,
-    intensity U[0,255]) + 200 filled discs (radius 4-30) + noise U[-6,6], clamped."""
-    rng = np.random.Generator(np.random.PCG64(1000 + k))
+def _scene(rng, w, h, nrect, ndisc):
+    """Mid-grey 128 + nrect filled rectangles (side 8-80, intensity U[0,255]) + ndisc filled discs (radius 4-30)."""
     img = np.full((h, w), 128, dtype=np.int16)
-    for _ in range(300):
+    for _ in range(nrect):
         sw, sh = rng.integers(8, 81, size=2)
         x0 = rng.integers(-sw // 2, w - sw // 2)
         y0 = rng.integers(-sh // 2, h - sh // 2)
         img[max(y0, 0):max(y0 + sh, 0), max(x0, 0):max(x0 + sw, 0)] = rng.integers(0, 256)
     yy, xx = np.mgrid[0:h, 0:w]
-    for _ in range(200):
+    for _ in range(ndisc):
         r = int(rng.integers(4, 31))
         cx = int(rng.integers(0, w)); cy = int(rng.integers(0, h))
         v = int(rng.integers(0, 256))
@@ -24,8 +22,44 @@ def synth_frame(k, w=640, h=480):
         x0, x1 = max(cx - r, 0), min(cx + r + 1, w)
         m = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= r * r
         img[y0:y1, x0:x1][m] = v
+    return img
+
+
+def synth_frame(k, w=640, h=480):
+    """Frame k (seed 1000+k): mid-grey 128 + 300 filled rectangles (side 8-80,
+    intensity U[0,255]) + 200 filled discs (radius 4-30) + noise U[-6,6], clamped."""
+    rng = np.random.Generator(np.random.PCG64(1000 + k))
+    img = _scene(rng, w, h, 300, 200)
     img += rng.integers(-6, 7, size=(h, w), dtype=np.int16)
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+SEQ_LEN = 64          # frames of one camera pan = one GPU's shard of the batch
+SEQ_STEP = (2, 1)     # pan per frame, px
+
+
+def synth_sequence(n, w=640, h=480, start=0):
+    """Frames start .. start+n-1 of the bench workload: consecutive frames see the SAME scene under a camera pan, so
+    that matching frame i against frame i+1 finds hundreds of true correspondences (independent scenes give none).
+    Frames [64 q, 64 q + 64) are one pan over scene q (seed 1000 + 64 q, the content statistics of synth_frame on a
+    canvas large enough for the pan): frame j of the pan is the w x h window at (2 j, j) plus its own noise
+    U[-6,6] (its own generator, seed 500000 + frame number), clamped."""
+    out = np.empty((n, h, w), np.uint8)
+    canvas, cq = None, -1
+    for i in range(n):
+        k = start + i
+        q, j = divmod(k, SEQ_LEN)
+        if q != cq:
+            cw, chh = w + SEQ_STEP[0] * (SEQ_LEN - 1), h + SEQ_STEP[1] * (SEQ_LEN - 1)
+            area = (cw * chh) / float(w * h)
+            canvas = _scene(np.random.Generator(np.random.PCG64(1000 + SEQ_LEN * q)), cw, chh,
+                            int(round(300 * area)), int(round(200 * area)))
+            cq = q
+        rng = np.random.Generator(np.random.PCG64(500000 + k))
+        x0, y0 = SEQ_STEP[0] * j, SEQ_STEP[1] * j
+        img = canvas[y0:y0 + h, x0:x0 + w] + rng.integers(-6, 7, size=(h, w), dtype=np.int16)
+        out[i] = np.clip(img, 0, 255).astype(np.uint8)
+    return out
 
 
 def synth_frames(n, w=640, h=480, start=0):

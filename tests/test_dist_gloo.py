@@ -1,58 +1,176 @@
-"""World-size-2 gloo test (CPU) of the N>1 host logic of bench.py: frames sharded
-contiguously per rank, fixed-size records gathered on rank 0, MAX-over-ranks timing.
-The compute leg is replaced by the CPU oracle here (checker role only)."""
+"""World-size-2 gloo tests (CPU tensors) of the N > 1 host logic that bench.py runs (orb_slam2_e_amd/shard.py):
+frames sharded contiguously per rank, fixed-size records in the bench's own layout, steps rotating over contexts,
+the bucketed gather (`--gather-every`, partial buckets flushed before the barrier), MAX-over-ranks timing and the FEM
+displacement gather.  The compute leg is a stand-in here: the CPU oracle (checker role only) or a byte pattern."""
 import os
+import pickle
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FR = 2          # frames per rank
-CAP = 1000 + 24
+NFEAT, NLEV = 500, 6
+CAP = NFEAT + 3 * NLEV
+W, H = 320, 240
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _init(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _oracle_record(lay, frames):
+    """One step's record of `frames` (this rank's shard) in the bench layout, computed by the oracle."""
     import oracle
-    from orb_slam2_e_amd.synth import synth_frame
-    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
-    rec = np.zeros((FR, 4 + CAP * 32), np.uint8)            # {count, desc[CAP][32]} fixed-size record
-    for i in range(FR):
-        f = rank * FR + i                                    # rank r owns frames [FR*r, FR*r+FR)
-        _, desc = o.extract(synth_frame(f, 320, 240))
-        rec[i, :4] = np.frombuffer(np.int32(len(desc)).tobytes(), np.uint8)
-        rec[i, 4:4 + 32 * len(desc)] = desc.ravel()
-    send = torch.from_numpy(rec.ravel())
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, recv, dst=0)
-    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    o = oracle.OrbOracle(NFEAT, 1.2, NLEV, 20, 7)
+    rec = np.zeros(lay.rec_bytes, np.uint8)
+    R = lay.unpack(rec)
+    descs = []
+    for i, f in enumerate(frames):
+        kps, desc = o.extract(f)
+        n = len(kps)
+        R["kps"][i, :n] = kps; R["desc"][i, :n] = desc; R["counts"][i] = n
+        descs.append(desc)
+    for i in range(len(frames)):
+        b, s, ix = oracle.match_bruteforce(descs[i], descs[(i + 1) % len(frames)])
+        m12, nm = oracle.match_filter(b, s, ix, 45, 0.6)
+        R["match12"][i, :len(m12)] = m12; R["nmatch"][i] = nm
+    return rec
+
+
+def _worker_records(rank, world, port, out):
+    _init(rank, world, port)
+    from orb_slam2_e_amd.shard import RecordLayout, ShardedPipeline, max_over_ranks
+    from orb_slam2_e_amd.synth import synth_sequence
+    lay = RecordLayout(FR, CAP)
+    frames = synth_sequence(FR, W, H, start=rank * FR)        # rank r owns frames [FR r, FR r + FR)
+    got = {}
+    state = {}
+
+    def compute(c, k):
+        state["rec"] = torch.from_numpy(_oracle_record(lay, frames))
+
+    def pack(c, dst):
+        dst.copy_(state["rec"])
+
+    pipe = ShardedPipeline(rank, world, lay.rec_bytes, 1, 1, compute, pack,
+                           on_receive=lambda k, r, rec: got.__setitem__((k, r), rec.numpy().copy()))
+    pipe.step(0)
+    pipe.flush()
+    t = max_over_ranks(0.1 * (rank + 1), world)
+    assert abs(t - 0.1 * world) < 1e-12
+    dist.barrier()
     if rank == 0:
-        allrec = torch.stack(recv).numpy().reshape(world * FR, -1)
-        np.save(out, allrec)
-        assert abs(float(t) - 0.1 * world) < 1e-12
+        with open(out, "wb") as f:
+            pickle.dump(got, f)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_record_layout(tmp_path):
+    """Records in bench.py's layout, gathered on rank 0 in global frame order, equal the oracle's results."""
+    out = str(tmp_path / "gathered.pkl")
+    mp.spawn(_worker_records, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = pickle.load(open(out, "rb"))
+    sys.path.insert(0, ROOT)
+    import oracle
+    from orb_slam2_e_amd.shard import RecordLayout
+    from orb_slam2_e_amd.synth import synth_sequence
+    lay = RecordLayout(FR, CAP)
+    assert sorted(got) == [(0, 0), (0, 1)]
+    o = oracle.OrbOracle(NFEAT, 1.2, NLEV, 20, 7)
+    frames = synth_sequence(2 * FR, W, H)
+    for r in range(2):
+        R = lay.unpack(got[(0, r)])
+        descs = []
+        for i in range(FR):
+            kps, desc = o.extract(frames[r * FR + i])
+            n = int(R["counts"][i])
+            assert n == len(kps) and n > 100
+            assert np.array_equal(R["kps"][i, :n].view(np.uint8), kps.view(np.uint8)) and np.array_equal(R["desc"][i, :n], desc)
+            descs.append(desc)
+        for i in range(FR):
+            b, s, ix = oracle.match_bruteforce(descs[i], descs[(i + 1) % FR])
+            m12, nm = oracle.match_filter(b, s, ix, 45, 0.6)
+            assert int(R["nmatch"][i]) == nm and nm > 20 and np.array_equal(R["match12"][i, :len(m12)], m12)
+
+
+def _pattern(rank, k, n):
+    return ((np.arange(n, dtype=np.int64) * 31 + 7919 * k + 104729 * rank) % 251).astype(np.uint8)
+
+
+def _worker_buckets(rank, world, port, out, nctx, ge, nsteps):
+    _init(rank, world, port)
+    from orb_slam2_e_amd.shard import ShardedPipeline
+    rec_bytes = 1000
+    got = []
+    state = {}
+    used = []
+
+    def compute(c, k):
+        used.append(c.index)
+        state[c.index] = torch.from_numpy(_pattern(rank, k, rec_bytes))
+
+    def pack(c, dst):
+        dst.copy_(state[c.index])
+
+    pipe = ShardedPipeline(rank, world, rec_bytes, nctx, ge, compute, pack, make_context=lambda c: {"i": c.index},
+                           on_receive=lambda k, r, rec: got.append((k, r, rec.numpy().copy())))
+    for k in range(nsteps):
+        pipe.step(k)
+    assert used == [k % nctx for k in range(nsteps)]
+    before_flush = len(got)
+    pipe.flush()
+    dist.barrier()
+    if rank == 0:
+        with open(out, "wb") as f:
+            pickle.dump((got, pipe.gathers, before_flush), f)
+    else:
+        assert not got
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nctx,ge,nsteps,full,partial", [(1, 3, 4, 1, 1), (2, 3, 7, 2, 1), (3, 1, 5, 5, 0), (2, 4, 3, 0, 2)])
+def test_bucketed_gather(tmp_path, nctx, ge, nsteps, full, partial):
+    """`--gather-every ge`: a context's records travel in buckets of ge steps, partial buckets leave on flush();
+    every (step, rank) record arrives exactly once with the right bytes."""
+    out = str(tmp_path / "b.pkl")
+    mp.spawn(_worker_buckets, args=(2, _free_port(), out, nctx, ge, nsteps), nprocs=2, join=True)
+    got, gathers, before_flush = pickle.load(open(out, "rb"))
+    assert gathers == full + partial
+    assert before_flush == 2 * ge * full          # what arrived before the flush came in full buckets
+    assert sorted((k, r) for k, r, _ in got) == [(k, r) for k in range(nsteps) for r in range(2)]
+    for k, r, rec in got:
+        assert np.array_equal(rec, _pattern(r, k, 1000)), (k, r)
+
+
+def _worker_fem(rank, world, port, out):
+    _init(rank, world, port)
+    from orb_slam2_e_amd.shard import gather_displacements
+    x = np.arange(3 * 11, dtype=np.float64).reshape(3, 11) + 1000.0 * rank
+    allx = gather_displacements(x, rank, world)
+    assert (allx is None) == (rank != 0)
+    if rank == 0:
+        np.save(out, allx)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_gather(tmp_path):
-    out = str(tmp_path / "gathered.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    allrec = np.load(out)
-    import oracle
-    from orb_slam2_e_amd.synth import synth_frame
-    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
-    for f in range(2 * FR):                                  # gathered order = global frame order
-        _, desc = o.extract(synth_frame(f, 320, 240))
-        n = int(np.frombuffer(allrec[f, :4].tobytes(), np.int32)[0])
-        assert n == len(desc) and np.array_equal(allrec[f, 4:4 + 32 * n].reshape(n, 32), desc)
+def test_fem_displacement_gather(tmp_path):
+    out = str(tmp_path / "x.npy")
+    mp.spawn(_worker_fem, args=(2, _free_port(), out), nprocs=2, join=True)
+    allx = np.load(out)
+    ref = np.concatenate([np.arange(33, dtype=np.float64).reshape(3, 11) + 1000.0 * r for r in range(2)])
+    assert np.array_equal(allx, ref)
+    from orb_slam2_e_amd.shard import gather_displacements
+    assert np.array_equal(gather_displacements(ref, 0, 1), ref)     # N = 1: no collective
