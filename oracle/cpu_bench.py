@@ -33,6 +33,24 @@ def _pin(cpu):
         return False
 
 
+def _usable_cores(cpus):
+    """Cores this process may really use at once: its affinity mask, cut down to the cgroup CPU quota where one is
+    readable, else to 16 (a one-GPU box hands out one GPU's share of the host, 16 cores, whatever the mask says);
+    ORBX_CPU_WORKERS overrides.  Returns (n, how)."""
+    n = len(cpus)
+    if os.environ.get("ORBX_CPU_WORKERS"):
+        return min(n, max(1, int(os.environ["ORBX_CPU_WORKERS"]))), "ORBX_CPU_WORKERS"
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            q = parse(open(path).read())
+            if q:
+                return min(n, max(1, int(q))), "cgroup CPU quota"
+        except (OSError, ValueError, IndexError):
+            pass
+    return (n, "affinity mask") if n <= 16 else (16, "affinity mask has %d cores, no cgroup quota readable: one GPU's share of 16 used" % n)
+
+
 def _extract_match(o, oracle, imgs, prev):
     kps, desc = o.extract(imgs)
     if prev is not None:
@@ -163,18 +181,19 @@ def extract_leg(args):
     # all host cores: one pinned worker per core, one frame at a time per worker
     if pinned:
         os.sched_setaffinity(0, set(cpus))
-    nproc = len(cpus)
+    nproc, how = _usable_cores(cpus)
+    cpus = cpus[:nproc]
     ctx = mp.get_context("fork")
     q, barrier = ctx.Queue(), ctx.Barrier(nproc)
     per = max(1, args.all_cores_frames)
-    procs = [ctx.Process(target=_worker, args=(cpus[w], frames[(w * per) % nd:(w * per) % nd + per], 1, q, barrier)) for w in range(nproc)]
+    procs = [ctx.Process(target=_worker, args=(cpus[w], frames[(w * per + np.arange(per)) % nd], 1, q, barrier)) for w in range(nproc)]
     for p in procs: p.start()
     res = [q.get() for _ in procs]
     for p in procs: p.join()
     total = sum(r[0] for r in res)
     wall = max(r[2] for r in res) - min(r[1] for r in res)
     out["all_cores"] = {"value": total / wall, "unit": "frames/s", "cores": nproc, "nproc": os.cpu_count(),
-                        "sample": f"{total} frames, one pinned worker process per core ({nproc} cores available to this process, "
+                        "sample": f"{total} frames, one pinned worker process per usable core ({nproc}, from: {how}; "
                                   f"os.cpu_count() = {os.cpu_count()}), extract + match each, {wall:.2f} s wall"}
     return out
 

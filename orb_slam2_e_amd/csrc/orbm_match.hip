@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * MSEG) void k_match_sets(const uint8_t *__restr
     __shared__ unsigned sk[MSEG][MQ][2][64];
     const int p = blockIdx.y, lane = threadIdx.x, seg = threadIdx.y;
     const int sa = qa ? qa[p] : 0, sb = qb ? qb[p] : 1;
-    const int nA = counts[sa] < cap ? counts[sa] : cap, nB = counts[sb] < cap ? counts[sb] : cap;
+    const int nA = min(max(counts[sa], 0), cap), nB = min(max(counts[sb], 0), cap); // a count outside [0, cap] is a caller's bug; never index with it
     const int row0 = blockIdx.x * 64 * MQ;
     if (row0 >= nA) return;
     const uint4 *A = reinterpret_cast<const uint4 *>(desc + (size_t)sa * cap * 32);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restri
     __shared__ unsigned sk[4][XQ][2][32];
     const int p = blockIdx.y, lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sa = qa ? qa[p] : 0, sb = qb ? qb[p] : 1;
-    const int nA = counts[sa] < cap ? counts[sa] : cap, nB = counts[sb] < cap ? counts[sb] : cap;
+    const int nA = min(max(counts[sa], 0), cap), nB = min(max(counts[sb], 0), cap); // a count outside [0, cap] is a caller's bug; never index with it
     const int row0 = blockIdx.x * 32 * XQ;
     if (row0 >= nA) return;
     const uint4 *A = reinterpret_cast<const uint4 *>(desc + (size_t)sa * cap * 32);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(MT) void k_bow_transform(const int *__restrict__ ch
     // 16 lanes per feature: at every level the children of the current node are scored 16 at a time, one per lane,
     // and the group minimum of dist << 16 | position picks the first closest child (strict d < best_d, :1246-1254)
     const int set = blockIdx.y, i = blockIdx.x * (MT / 16) + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    const int n = counts ? min(counts[set], cap) : n_single;
+    const int n = counts ? min(max(counts[set], 0), cap) : n_single;
     if (i >= n) return;
     const size_t o = (size_t)set * cap + i;
     const uint4 a0 = feat[2 * o], a1 = feat[2 * o + 1];

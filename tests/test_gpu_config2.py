@@ -29,7 +29,8 @@ def test_batch64_extract_and_match_equal_oracle(kernel):
         qb = ((qa + 1) % B).to(torch.int32)
         out = [torch.full((B, cap), -7, dtype=torch.int32).cuda() for _ in range(4)]
         nm = torch.zeros(B, dtype=torch.int32).cuda()
-        st = torch.cuda.current_stream().cuda_stream
+        ts = torch.cuda.Stream()            # extraction and matching queued on ONE stream, as in bench.py (a null stream
+        st = ts.cuda_stream                 # handle would mean "the handle's own stream" to the extractor only)
         for _ in range(2):          # twice on the same workspace: nothing may survive from the first pass
             ex.extract_batch_device(d_frames.data_ptr(), B, H, W, st)
             kps_p, desc_p, cnt_p, _ = ex.result_dev()
