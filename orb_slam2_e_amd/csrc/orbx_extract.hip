@@ -274,7 +274,11 @@ __device__ __forceinline__ int mask_rank(unsigned long long m)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-template <int TS>
+// PAIRS: bit k = opposite pair (k, k+8) takes part.  Returns bytes 0..3 = pixels 0..3: dark possible | bright possible << 1
+// over the chosen pairs.  With all eight pairs both bits at once cannot be a corner (see above); with a subset either
+// polarity is still open, so the codes of two subsets are ANDed first and the rule applied to the result
+// (fast_resolve).  Rows whose pairs are not chosen are never loaded (the loads fold away at compile time).
+template <int TS, unsigned PAIRS>
 __device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2)
 {
     uint32_t r[7][3];
@@ -284,26 +288,29 @@ __device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2
         r[dy + 3][0] = q[-1]; r[dy + 3][1] = q[0]; r[dy + 3][2] = q[1];
     }
     u16x2 aE, aO, bE, bO, loE, loO, hiE, hiO;
-#define ORBX_PAIR(DYA, DXA, FIRST)                                                               \
-    fast_pick<DXA>(r[3 + (DYA)], aE, aO);                                                        \
-    fast_pick<-(DXA)>(r[3 - (DYA)], bE, bO);                                                     \
-    if (FIRST) {                                                                                 \
-        loE = __builtin_elementwise_min(aE, bE); loO = __builtin_elementwise_min(aO, bO);        \
-        hiE = __builtin_elementwise_max(aE, bE); hiO = __builtin_elementwise_max(aO, bO);        \
-    } else {                                                                                     \
-        loE = __builtin_elementwise_max(loE, __builtin_elementwise_min(aE, bE));                 \
-        loO = __builtin_elementwise_max(loO, __builtin_elementwise_min(aO, bO));                 \
-        hiE = __builtin_elementwise_min(hiE, __builtin_elementwise_max(aE, bE));                 \
-        hiO = __builtin_elementwise_min(hiO, __builtin_elementwise_max(aO, bO));                 \
+    constexpr int FIRSTK = __builtin_ctz(PAIRS);
+#define ORBX_PAIR(K, DYA, DXA)                                                                       \
+    if constexpr ((PAIRS >> (K)) & 1u) {                                                             \
+        fast_pick<DXA>(r[3 + (DYA)], aE, aO);                                                        \
+        fast_pick<-(DXA)>(r[3 - (DYA)], bE, bO);                                                     \
+        if constexpr ((K) == FIRSTK) {                                                               \
+            loE = __builtin_elementwise_min(aE, bE); loO = __builtin_elementwise_min(aO, bO);        \
+            hiE = __builtin_elementwise_max(aE, bE); hiO = __builtin_elementwise_max(aO, bO);        \
+        } else {                                                                                     \
+            loE = __builtin_elementwise_max(loE, __builtin_elementwise_min(aE, bE));                 \
+            loO = __builtin_elementwise_max(loO, __builtin_elementwise_min(aO, bO));                 \
+            hiE = __builtin_elementwise_min(hiE, __builtin_elementwise_max(aE, bE));                 \
+            hiO = __builtin_elementwise_min(hiO, __builtin_elementwise_max(aO, bO));                 \
+        }                                                                                            \
     }
-    ORBX_PAIR(3, 0, true)   // circle pixels 0 / 8
-    ORBX_PAIR(3, 1, false)  // 1 / 9
-    ORBX_PAIR(2, 2, false)  // 2 / 10
-    ORBX_PAIR(1, 3, false)  // 3 / 11
-    ORBX_PAIR(0, 3, false)  // 4 / 12
-    ORBX_PAIR(-1, 3, false) // 5 / 13
-    ORBX_PAIR(-2, 2, false) // 6 / 14
-    ORBX_PAIR(-3, 1, false) // 7 / 15
+    ORBX_PAIR(0, 3, 0)   // circle pixels 0 / 8
+    ORBX_PAIR(1, 3, 1)   // 1 / 9
+    ORBX_PAIR(2, 2, 2)   // 2 / 10
+    ORBX_PAIR(3, 1, 3)   // 3 / 11
+    ORBX_PAIR(4, 0, 3)   // 4 / 12
+    ORBX_PAIR(5, -1, 3)  // 5 / 13
+    ORBX_PAIR(6, -2, 2)  // 6 / 14
+    ORBX_PAIR(7, -3, 1)  // 7 / 15
 #undef ORBX_PAIR
     u16x2 vE, vO;
     fast_pick<0>(r[3], vE, vO);
@@ -311,11 +318,11 @@ __device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2
     // per half "a > b" as 0 / 1: saturating difference clamped to 1
     const uint32_t dE = pk_gt01(pk1(vE), pk1(loE + t)), dO = pk_gt01(pk1(vO), pk1(loO + t));
     const uint32_t gE = pk_gt01(pk1(hiE), pk1(vE + t)), gO = pk_gt01(pk1(hiO), pk1(vO + t));
-    // bytes 0..3 = pixels 0..3: dark | bright << 1; both set cannot be a corner -> 0
-    uint32_t code = (dE | (gE << 1)) | ((dO | (gO << 1)) << 8);
-    code &= ~((code & (code >> 1) & 0x01010101u) * 3u);
-    return code;
+    return (dE | (gE << 1)) | ((dO | (gO << 1)) << 8);
 }
+// dark and bright both possible over all eight pairs cannot be a corner -> 0
+__device__ __forceinline__ uint32_t fast_resolve(uint32_t code) { return code & ~((code & (code >> 1) & 0x01010101u) * 3u); }
+constexpr unsigned FAST_PAIRS_A = 0x11u, FAST_PAIRS_B = 0xeeu;   // compass pairs 0/8 and 4/12 first, the other six on what is left
 
 // cornerScore<16>: (largest arc-minimum of e_k over the 16 circular 9-arcs) - 1
 // where e = d (dark) or -d (bright); it is a corner at threshold th iff that
@@ -340,11 +347,18 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int sgn, int th)
 // in FAST raster order, coordinates relative to (minBorderX, minBorderY).
 // Packed candidate: y<<20 | x<<8 | score.
 //
-// Phases: (1) cell tile -> LDS as dwords; (2) every pixel: the opposite-pair pre-test,
-// 4 adjacent pixels per lane on packed u16 (fast_pretest4), survivors (a few %)
-// compacted in raster order into an LDS queue; (3) survivors only: arc score -> score map; (4) survivors with a
-// score: 3x3 strict NMS (the local-maximum flag does not depend on the threshold:
-// a neighbour below it is smaller than the centre anyway); (5) ordered emission.
+// Phases: (1) cell tile -> LDS as dwords; then, as the reference does, one pass at iniThFAST and -- only if that
+// pass emits nothing (a wave-uniform branch; on textured frames almost every cell has a corner at iniThFAST) -- a
+// second one at minThFAST:
+// (2a) every pixel, 4 adjacent pixels per lane on packed u16: the opposite-pair pre-test on the two compass
+// pairs only (0/8 and 4/12: the vertical pair needs no byte shuffling across dwords); the 4-pixel groups that still
+// hold a possible corner (18 % of them at level 0, 67 % at level 7 on the synthetic frames) are compacted in raster
+// order into an LDS group queue; (2b) the other six pairs on the queued groups only, survivors (4 % ... 28 % of the
+// pixels) compacted in raster order into the pixel queue; (3) survivors only: arc score -> score map (0 below
+// the pass's threshold, which is all the non-max test needs: a neighbour that is no corner at this threshold scores
+// less than any corner); (4) 3x3 strict NMS; (5) ordered emission.
+// The score map is not cleared between the passes: what pass 1 wrote are the true scores of pixels that pass 2
+// visits again (its survivor set contains pass 1's) and rewrites with the same values.
 // TS / SS (tile and score-map strides) are compile-time so that the 16 circle
 // offsets fold into ds_read immediates.
 template <int TS, int SS>
@@ -353,12 +367,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                                                    const CellInfo *__restrict__ cells, int *__restrict__ cell_count,
                                                    int cells_per_frame, uint32_t *__restrict__ cands,
                                                    size_t cands_per_frame, int iniTh, int minTh,
-                                                   int tile_bytes, int sc_bytes)
+                                                   int tile_bytes, int sc_bytes, int queue_bytes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *tile = smem;
     uint8_t *sc = smem + tile_bytes;
     unsigned short *queue = reinterpret_cast<unsigned short *>(smem + tile_bytes + sc_bytes);
+    uint32_t *gqueue = reinterpret_cast<uint32_t *>(smem + tile_bytes + sc_bytes + queue_bytes);
     int c, f;
     xcd_frame_item(f, c);
     const int lane = threadIdx.x;
@@ -382,22 +397,44 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         constexpr int zc0 = 8;                        // tile column of zone pixel 0
         const uint8_t *t0 = tile + 3 * TS + zc0;      // zone pixel (0,0)
         const unsigned long long lt = (1ull << lane) - 1ull;
-        // (2) pre-test, survivors -> queue entries y<<6 | x | polarity<<12.  A group = the 4
-        // pixels of one tile dword; groups overlapping the zone row, in raster order.
-        int nq = 0;
-        {
-            const int g0 = zc0 >> 2, ngx = (zw + 3) >> 2, ngrp = ngx * zh;
-            const uint32_t th2 = (uint32_t)minTh | ((uint32_t)minTh << 16);
-            const int qstep = 64 / ngx, rstep = 64 - qstep * ngx; // lane + 64 -> (gx + rstep, y + qstep), one carry
-            int y = lane / ngx, gx = lane - y * ngx;
-            unsigned short *const dump = queue + zw * zh;         // one spare slot per lane for rejected pixels
-            for (int p0 = 0; p0 < ngrp; p0 += 64) {
+        const int g0 = zc0 >> 2, ngx = (zw + 3) >> 2, ngrp = ngx * zh;
+        const int qstep = 64 / ngx, rstep = 64 - qstep * ngx; // lane + 64 -> (gx + rstep, y + qstep), one carry
+        unsigned short *const dump = queue + zw * zh;         // one spare slot per lane for rejected pixels
+        uint32_t *out = cands + (size_t)f * cands_per_frame + ci.cand_off;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int th = pass ? minTh : iniTh;
+            const uint32_t th2 = (uint32_t)th | ((uint32_t)th << 16);
+            // (2a) compass pairs on every group; group queue entry = code | y << 2 | gx << 10 (the code uses bits 0-1 of
+            // every byte).  A group = the 4 pixels of one tile dword; groups overlapping the zone row, in raster order.
+            int ngq = 0;
+            {
+                int y = lane / ngx, gx = lane - y * ngx;
+                for (int p0 = 0; p0 < ngrp; p0 += 64) {
+                    uint32_t code = 0;
+                    if (p0 + lane < ngrp) {
+                        const int xs = 4 * (g0 + gx) - zc0;   // zone x of the group's pixel 0 (-3 .. zw-1)
+                        code = fast_pretest4<TS, FAST_PAIRS_A>(tile + (y + 3) * TS + 4 * (g0 + gx), th2);
+                        const int jlo = max(0, -xs), jhi = min(4, zw - xs); // pixels jlo..jhi-1 are in the zone
+                        code &= (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (4 - jhi)));
+                    }
+                    const unsigned long long b = __ballot(code != 0);
+                    if (code) gqueue[ngq + mask_rank(b)] = code | ((uint32_t)y << 2) | ((uint32_t)gx << 10);
+                    ngq += __popcll(b);
+                    gx += rstep; y += qstep;
+                    if (gx >= ngx) { gx -= ngx; ++y; }
+                }
+            }
+            __syncthreads();
+            // (2b) the other six pairs on the queued groups, survivors -> queue entries y<<6 | x | polarity<<12
+            int nq = 0;
+            for (int q0 = 0; q0 < ngq; q0 += 64) {
                 uint32_t code = 0;
-                const int xs = 4 * (g0 + gx) - zc0;   // zone x of the group's pixel 0 (-3 .. zw-1)
-                if (p0 + lane < ngrp) {
-                    code = fast_pretest4<TS>(tile + (y + 3) * TS + 4 * (g0 + gx), th2);
-                    const int jlo = max(0, -xs), jhi = min(4, zw - xs); // pixels jlo..jhi-1 are in the zone
-                    code &= (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (4 - jhi)));
+                int ent = 0;
+                if (q0 + lane < ngq) {
+                    const uint32_t e = gqueue[q0 + lane];
+                    const int y = (e >> 2) & 63, gx = (e >> 10) & 63;
+                    code = fast_resolve(fast_pretest4<TS, FAST_PAIRS_B>(tile + (y + 3) * TS + 4 * (g0 + gx), th2) & e & 0x03030303u);
+                    ent = (y << 6) + 4 * (g0 + gx) - zc0;
                 }
                 if (__ballot(code != 0)) {
                     // survivors of this lane: bytes 0..3 are 0/1/2 -> one bit per pixel, n = how many
@@ -405,7 +442,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     const int n = __popc(nz);
                     const unsigned long long c0 = __ballot(n & 1), c1 = __ballot(n & 2), c2 = __ballot(n & 4);
                     int pos = nq + mask_rank(c0) + 2 * mask_rank(c1) + 4 * mask_rank(c2);
-                    const int ent = (y << 6) + xs;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { // branch-free: rejected pixels go to the lane's dump slot
                         const int pol = (code >> (8 * j)) & 3;
@@ -415,63 +451,58 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     }
                     nq += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
                 }
-                gx += rstep; y += qstep;
-                if (gx >= ngx) { gx -= ngx; ++y; }
             }
-        }
-        __syncthreads();
-        // (3) arc score of the survivors
-        for (int q0 = 0; q0 < nq; q0 += 64) {
-            if (q0 + lane < nq) {
-                const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
-                // e_k = sgn (v - p_k) as one multiply-add per circle pixel: sgn v - sgn p_k
-                const uint8_t *t = t0 + y * TS + x;
-                const int sgn = (e >> 12) == 1 ? 1 : -1, sv = sgn * (int)t[0], ns = -sgn;
-                int d[16];
-                d[0] = __mul24(t[3 * TS], ns) + sv;       d[1] = __mul24(t[3 * TS + 1], ns) + sv;   d[2] = __mul24(t[2 * TS + 2], ns) + sv;
-                d[3] = __mul24(t[TS + 3], ns) + sv;       d[4] = __mul24(t[3], ns) + sv;            d[5] = __mul24(t[-TS + 3], ns) + sv;
-                d[6] = __mul24(t[-2 * TS + 2], ns) + sv;  d[7] = __mul24(t[-3 * TS + 1], ns) + sv;  d[8] = __mul24(t[-3 * TS], ns) + sv;
-                d[9] = __mul24(t[-3 * TS - 1], ns) + sv;  d[10] = __mul24(t[-2 * TS - 2], ns) + sv; d[11] = __mul24(t[-TS - 3], ns) + sv;
-                d[12] = __mul24(t[-3], ns) + sv;          d[13] = __mul24(t[TS - 3], ns) + sv;      d[14] = __mul24(t[2 * TS - 2], ns) + sv;
-                d[15] = __mul24(t[3 * TS - 1], ns) + sv;
-                sc[(y + 1) * SS + x + 1] = (uint8_t)fast_arc_score(d, 1, minTh);
+            __syncthreads();
+            // (3) arc score of the survivors
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                if (q0 + lane < nq) {
+                    const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                    // e_k = sgn (v - p_k) as one multiply-add per circle pixel: sgn v - sgn p_k
+                    const uint8_t *t = t0 + y * TS + x;
+                    const int sgn = (e >> 12) == 1 ? 1 : -1, sv = sgn * (int)t[0], ns = -sgn;
+                    int d[16];
+                    d[0] = __mul24(t[3 * TS], ns) + sv;       d[1] = __mul24(t[3 * TS + 1], ns) + sv;   d[2] = __mul24(t[2 * TS + 2], ns) + sv;
+                    d[3] = __mul24(t[TS + 3], ns) + sv;       d[4] = __mul24(t[3], ns) + sv;            d[5] = __mul24(t[-TS + 3], ns) + sv;
+                    d[6] = __mul24(t[-2 * TS + 2], ns) + sv;  d[7] = __mul24(t[-3 * TS + 1], ns) + sv;  d[8] = __mul24(t[-3 * TS], ns) + sv;
+                    d[9] = __mul24(t[-3 * TS - 1], ns) + sv;  d[10] = __mul24(t[-2 * TS - 2], ns) + sv; d[11] = __mul24(t[-TS - 3], ns) + sv;
+                    d[12] = __mul24(t[-3], ns) + sv;          d[13] = __mul24(t[TS - 3], ns) + sv;      d[14] = __mul24(t[2 * TS - 2], ns) + sv;
+                    d[15] = __mul24(t[3 * TS - 1], ns) + sv;
+                    sc[(y + 1) * SS + x + 1] = (uint8_t)fast_arc_score(d, 1, th);
+                }
             }
-        }
-        __syncthreads();
-        // (4) 3x3 strict non-max suppression on the survivors
-        unsigned long long mx = 0, hi = 0;
-        int nhi = 0, it = 0;
-        for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
-            bool ismax = false, ishi = false;
-            if (q0 + lane < nq) {
-                const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
-                const uint8_t *q = sc + (y + 1) * SS + x + 1;
-                const int s = q[0];
-                // strictly above all eight neighbours (scores are >= 0, so this also says s > 0); no short-circuit
-                // branches: eight LDS bytes, three v_max3, one compare
-                const int m = max(max(max(q[-1], q[1]), max(q[-SS - 1], q[-SS])), max(max(q[-SS + 1], q[SS - 1]), max(q[SS], q[SS + 1])));
-                ismax = s > m;
-                ishi = ismax && s >= iniTh;
+            __syncthreads();
+            // (4) 3x3 strict non-max suppression on the survivors
+            unsigned long long mx = 0;
+            int it = 0;
+            for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
+                bool ismax = false;
+                if (q0 + lane < nq) {
+                    const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                    const uint8_t *q = sc + (y + 1) * SS + x + 1;
+                    const int s = q[0];
+                    // strictly above all eight neighbours (scores are >= 0, so this also says s > 0); no short-circuit
+                    // branches: eight LDS bytes, three v_max3, one compare
+                    const int m = max(max(max(q[-1], q[1]), max(q[-SS - 1], q[-SS])), max(max(q[-SS + 1], q[SS - 1]), max(q[SS], q[SS + 1])));
+                    ismax = s > m;
+                }
+                mx |= (unsigned long long)ismax << it;
             }
-            mx |= (unsigned long long)ismax << it;
-            hi |= (unsigned long long)ishi << it;
-            nhi += __popcll(__ballot(ishi));
-        }
-        // (5) emission in queue (= raster) order; iniThFAST keypoints if any, else minThFAST (:820-824)
-        const unsigned long long sel = nhi > 0 ? hi : mx;
-        uint32_t *out = cands + (size_t)f * cands_per_frame + ci.cand_off;
-        it = 0;
-        for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
-            const bool flag = (sel >> it) & 1ull;
-            const unsigned long long b = __ballot(flag);
-            if (flag) {
-                const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
-                const int pos = total + __popcll(b & lt);
-                const uint32_t s = sc[(y + 1) * SS + x + 1];
-                if (pos < ci.cap)
-                    out[pos] = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | s;
+            // (5) emission in queue (= raster) order
+            it = 0;
+            for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
+                const bool flag = (mx >> it) & 1ull;
+                const unsigned long long b = __ballot(flag);
+                if (flag) {
+                    const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
+                    const int pos = total + __popcll(b & lt);
+                    const uint32_t s = sc[(y + 1) * SS + x + 1];
+                    if (pos < ci.cap)
+                        out[pos] = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | s;
+                }
+                total += __popcll(b);
             }
-            total += __popcll(b);
+            if (total > 0 || minTh == iniTh) break; // empty at iniThFAST: once more at minThFAST (:820-824)
+            __syncthreads();                        // the queues are rewritten
         }
     }
     if (lane == 0) cell_count[(size_t)f * cells_per_frame + c] = total;
@@ -1382,7 +1413,8 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->TS = ex->SS = (maxcw + 12 <= 64) ? 64 : 80;
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
-    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + 2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 16; // + the pre-test's dump slots
+    ex->queue_bytes = (2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 15) & ~15;                       // pixel queue + the pre-test's dump slots
+    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + ex->queue_bytes + 4 * (((maxcw - 6 + 3) >> 2) * (maxch - 6)); // + group queue
     ex->oct_kcap = ex->NC > 1100 ? 3072 : 4096; // keys of a level live in LDS up to this many, else in HBM
     if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
@@ -1480,11 +1512,11 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     if (ex->TS == 64)
         hipLaunchKernelGGL((k_fast_cells<64, 64>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
                            ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes);
+                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
     else
         hipLaunchKernelGGL((k_fast_cells<80, 80>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
                            ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes);
+                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
     pf.stop(2, st);
     pf.start(3, st);
     hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
