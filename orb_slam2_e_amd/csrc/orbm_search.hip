@@ -19,8 +19,13 @@
 //      first conflict commit, the rest select again.  A lane's selection can only change
 //      when an earlier query claims its best or second candidate, so the committed
 //      results are the sequential loop's results;
+//      Queries whose candidate sets cannot meet are independent of each other: the BoW searches hand
+//      k_resolve one SEGMENT per vocabulary node (a feature belongs to one node, ORBmatcher.cc:384-456),
+//      one workgroup per segment, so the nodes resolve side by side instead of one after the other;
 //   4. k_rotation builds the 30-bin rotation histogram, ORBmatcher::ComputeThreeMaxima
 //      (:1802-1843) and rejects the matches outside the three main bins.
+// The host never waits in the middle of a call: the entry buffer is sized from a running estimate and the
+// real total comes back with the results (a call that outgrew it is repeated once with the right size).
 #include <limits.h>
 #include <stdint.h>
 
@@ -52,81 +57,11 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return v;
 }
 
-// One WAVE per query (4 per block).  Frame::GetFeaturesInArea (src/Frame.cc:342-395): the
-// cell range of the window in the reference's float arithmetic, then, column by column,
-// the keypoints of rows [nMinCellY, nMaxCellY] -- one contiguous run of the (cell, index)
-// sorted array -- tested 64 at a time: level range, |dx| < r && |dy| < r, and the stereo
-// check of ORBmatcher.cc:91-96.  FILL = 0 counts the survivors; FILL = 1 writes them in
-// that order with their distances: entry = dist << 20 | octave << 16 | sp (0xffffffff for
-// a distance that can never be selected).
-template <int FILL>
-__global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
-                                                 const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
-                                                 const int *__restrict__ cell_off, GridParams gp, int has_uright, int init_dist,
-                                                 int *__restrict__ cnt, const int *__restrict__ off, unsigned *__restrict__ ent)
+// The TOPK entries of a list with the smallest (distance, position) keys, in that
+// order -- all the sequential resolver normally needs.  Run by the wave that has just written the list
+// (its own stores are visible to it after the workgroup-scope fence).
+__device__ __forceinline__ void wave_topk(const unsigned *__restrict__ ent, int b, int len, int lane, unsigned *__restrict__ top_i)
 {
-    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= nq) return;
-    const WinQuery w = q[i];
-    int c = 0;
-    const int nMinCellX = (int)fmaxf(0.f, floorf((w.u - gp.min_x - w.r) * gp.inv_w));
-    const int nMaxCellX = (int)fminf((float)FRAME_GRID_COLS - 1, ceilf((w.u - gp.min_x + w.r) * gp.inv_w));
-    const int nMinCellY = (int)fmaxf(0.f, floorf((w.v - gp.min_y - w.r) * gp.inv_h));
-    const int nMaxCellY = (int)fminf((float)FRAME_GRID_ROWS - 1, ceilf((w.v - gp.min_y + w.r) * gp.inv_h));
-    const bool none = !(w.r >= 0.f) || nMinCellX >= FRAME_GRID_COLS || nMaxCellX < 0 || nMinCellY >= FRAME_GRID_ROWS || nMaxCellY < 0;
-    if (!none) {
-        const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-        if (FILL) { a0 = A[2 * i]; a1 = A[2 * i + 1]; }
-        unsigned *out = FILL ? ent + off[i] : nullptr;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
-            const int k0 = cell_off[ix * FRAME_GRID_ROWS + nMinCellY], k1 = cell_off[ix * FRAME_GRID_ROWS + nMaxCellY + 1];
-            for (int kb = k0; kb < k1; kb += 64) {
-                const int k = kb + lane;
-                bool ok = k < k1;
-                SeqKp p = {0.f, 0.f, 0.f, 0};
-                if (ok) p = kp[k];
-                if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
-                const float distx = p.x - w.u, disty = p.y - w.v;
-                ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
-                if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
-                const unsigned long long bal = __ballot(ok);
-                if (FILL && ok) {
-                    const int dist = popc256(a0, a1, B[2 * k], B[2 * k + 1]);
-                    out[c + __popcll(bal & lt)] = dist < init_dist ? ((unsigned)dist << 20) | ((unsigned)p.octave << 16) | (unsigned)k : 0xffffffffu;
-                }
-                c += __popcll(bal);
-            }
-        }
-    }
-    if (!FILL && lane == 0) cnt[i] = c;
-}
-
-// Entries for explicit candidate lists (BoW-node members in member order), one wave per
-// query: entry = dist << 20 | candidate index; a distance of 256 can never be selected.
-__global__ __launch_bounds__(MT) void k_list_fill(const uint4 *__restrict__ A, int nq, const uint4 *__restrict__ B,
-                                                  const int *__restrict__ off, const int *__restrict__ cand,
-                                                  unsigned *__restrict__ ent)
-{
-    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= nq) return;
-    const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
-    for (int k = off[i] + lane; k < off[i + 1]; k += 64) {
-        const int j = cand[k];
-        const int dist = popc256(a0, a1, B[2 * j], B[2 * j + 1]);
-        ent[k] = dist < 256 ? ((unsigned)dist << 20) | (unsigned)j : 0xffffffffu;
-    }
-}
-
-// The TOPK entries of every list with the smallest (distance, position) keys, in that
-// order -- all the sequential resolver normally needs.  One wave per query.
-__global__ __launch_bounds__(MT) void k_topk(const unsigned *__restrict__ ent, const int *__restrict__ off, int nq,
-                                             unsigned *__restrict__ top)
-{
-    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= nq) return;
-    const int b = off[i], len = off[i + 1] - b;
     unsigned prev = 0;
     bool done = false;
     for (int r = 0; r < TOPK; ++r) {
@@ -144,12 +79,97 @@ __global__ __launch_bounds__(MT) void k_topk(const unsigned *__restrict__ ent, c
             done = g == 0xffffffffu;
             prev = g;
         }
-        if (lane == 0) top[(size_t)i * TOPK + r] = done ? 0xffffffffu : ent[b + (g & 0xffffu)];
+        if (lane == 0) top_i[r] = done ? 0xffffffffu : ent[b + (g & 0xffffu)];
     }
 }
 
+// One WAVE per query (4 per block).  Frame::GetFeaturesInArea (src/Frame.cc:342-395): the
+// cell range of the window in the reference's float arithmetic, then, column by column,
+// the keypoints of rows [nMinCellY, nMaxCellY] -- one contiguous run of the (cell, index)
+// sorted array -- tested 64 at a time: level range, |dx| < r && |dy| < r, and the stereo
+// check of ORBmatcher.cc:91-96.  FILL = 2 (the usual path) writes the survivors of query i into its own region of
+// `stride` entries and the region's bounds into lbeg / lend, and raises *overflow if a list does not fit (the host
+// then repeats the call on the exact path); FILL = 0 counts the survivors; FILL = 1 writes them in
+// that order with their distances: entry = dist << 20 | octave << 16 | sp (0xffffffff for
+// a distance that can never be selected).
+template <int FILL>
+__global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
+                                                 const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
+                                                 const int *__restrict__ cell_off, GridParams gp, int has_uright, int init_dist,
+                                                 int *__restrict__ cnt, const int *__restrict__ off, unsigned *__restrict__ ent,
+                                                 int stride, int *__restrict__ lbeg, int *__restrict__ lend,
+                                                 int *__restrict__ overflow, unsigned *__restrict__ top)
+{
+    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const int obase = FILL == 2 ? i * stride : (FILL == 1 ? off[i] : 0), ocap = FILL == 2 ? stride : INT_MAX;
+    const WinQuery w = q[i];
+    int c = 0;
+    const int nMinCellX = (int)fmaxf(0.f, floorf((w.u - gp.min_x - w.r) * gp.inv_w));
+    const int nMaxCellX = (int)fminf((float)FRAME_GRID_COLS - 1, ceilf((w.u - gp.min_x + w.r) * gp.inv_w));
+    const int nMinCellY = (int)fmaxf(0.f, floorf((w.v - gp.min_y - w.r) * gp.inv_h));
+    const int nMaxCellY = (int)fminf((float)FRAME_GRID_ROWS - 1, ceilf((w.v - gp.min_y + w.r) * gp.inv_h));
+    const bool none = !(w.r >= 0.f) || nMinCellX >= FRAME_GRID_COLS || nMaxCellX < 0 || nMinCellY >= FRAME_GRID_ROWS || nMaxCellY < 0;
+    if (!none) {
+        const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (FILL) { a0 = A[2 * i]; a1 = A[2 * i + 1]; }
+        unsigned *out = FILL ? ent + obase : nullptr;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int k0 = cell_off[ix * FRAME_GRID_ROWS + nMinCellY], k1 = cell_off[ix * FRAME_GRID_ROWS + nMaxCellY + 1];
+            for (int kb = k0; kb < k1; kb += 64) {
+                const int k = kb + lane;
+                bool ok = k < k1;
+                SeqKp p = {0.f, 0.f, 0.f, 0};
+                if (ok) p = kp[k];
+                if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
+                const float distx = p.x - w.u, disty = p.y - w.v;
+                ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
+                if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
+                const unsigned long long bal = __ballot(ok);
+                if (FILL && ok && c + __popcll(bal & lt) < ocap) {
+                    const int dist = popc256(a0, a1, B[2 * k], B[2 * k + 1]);
+                    out[c + __popcll(bal & lt)] = dist < init_dist ? ((unsigned)dist << 20) | ((unsigned)p.octave << 16) | (unsigned)k : 0xffffffffu;
+                }
+                c += __popcll(bal);
+            }
+        }
+    }
+    if (!FILL && lane == 0) cnt[i] = c;
+    if (FILL) {
+        if (FILL == 2 && lane == 0) {
+            lbeg[i] = obase; lend[i] = obase + min(c, ocap);
+            if (c > ocap) atomicOr(overflow, 1);
+        }
+        __threadfence_block();
+        wave_topk(ent, obase, min(c, ocap), lane, top + (size_t)i * TOPK);
+    }
+}
+
+// Entries for explicit candidate lists (BoW-node members in member order), one wave per
+// query: entry = dist << 20 | candidate index; a distance of 256 can never be selected.  Query i's candidates are
+// cand[cbeg[i] .. cbeg[i] + off[i+1] - off[i]): the queries of one node share one copy of the node's member list.
+__global__ __launch_bounds__(MT) void k_list_fill(const uint4 *__restrict__ A, int nq, const uint4 *__restrict__ B,
+                                                  const int *__restrict__ off, const int *__restrict__ cbeg,
+                                                  const int *__restrict__ cand, unsigned *__restrict__ ent,
+                                                  unsigned *__restrict__ top)
+{
+    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
+    const int shift = cbeg[i] - off[i];
+    for (int k = off[i] + lane; k < off[i + 1]; k += 64) {
+        const int j = cand[k + shift];
+        const int dist = popc256(a0, a1, B[2 * j], B[2 * j + 1]);
+        ent[k] = dist < 256 ? ((unsigned)dist << 20) | (unsigned)j : 0xffffffffu;
+    }
+    __threadfence_block();
+    wave_topk(ent, off[i], off[i + 1] - off[i], lane, top + (size_t)i * TOPK);
+}
+
 // Exclusive scan of cnt[0..n) into off[0..n], one block (n is a few thousand).
-__global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt, int n, int *__restrict__ off)
+__global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt, int n, int *__restrict__ off, int *__restrict__ total_out)
 {
     __shared__ int part[MT];
     const int tid = threadIdx.x, per = (n + MT - 1) / MT, lo = min(tid * per, n), hi = min(lo + per, n);
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt,
         int r = 0;
         for (int i = 0; i < MT; ++i) { const int v = part[i]; part[i] = r; r += v; }
         off[n] = r;
+        *total_out = r;
     }
     __syncthreads();
     int r = part[tid];
@@ -178,12 +199,16 @@ __global__ __launch_bounds__(MT) void k_scan_counts(const int *__restrict__ cnt,
 // claims it with its lane number (minimum wins); a lane whose best or second slot is
 // claimed by a lower lane has to select again after that lane has committed.
 // acc_sp[i] = candidate chosen by query i when it was accepted (else -1).
+// seg != nullptr: workgroup s resolves the queries [seg[s], seg[s+1]) -- segments whose candidate sets are disjoint
+// (BoW nodes) -- on its own copy of the state and writes back only the slots it touched (out_a is preset to -1, the
+// match count is added up); seg == nullptr: one workgroup, all queries.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent, const unsigned *__restrict__ top,
-                                                const int *__restrict__ off, int nq, int ns, const uint8_t *__restrict__ takes, int th,
+                                                const int *__restrict__ lbeg, const int *__restrict__ lend, int nq_all, int ns, const uint8_t *__restrict__ takes, int th,
                                                 float nnratio, int accept_mode, int *__restrict__ acc_sp, int *__restrict__ out_a,
-                                                int *__restrict__ nmatches)
+                                                int *__restrict__ nmatches, const int *__restrict__ seg)
 {
+    const int q_begin = seg ? seg[blockIdx.x] : 0, nq = seg ? seg[blockIdx.x + 1] : nq_all;
     extern __shared__ __align__(16) int sm[];
     int *s_a = sm;            // MODE 0: match_kp[ns]   MODE 1: vMatchedDistance[ns]
     int *s_b = s_a + ns;      // MODE 0: blocked[ns]    MODE 1: vnMatches21[ns]
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
     int *s_c = s_claim + ns;  // MODE 1: vnMatches12[nq]
     const int lane = threadIdx.x;
     for (int j = lane; j < ns; j += 64) { s_a[j] = MODE == 0 ? -1 : INT_MAX; s_b[j] = MODE == 0 ? 0 : -1; s_claim[j] = 64; }
-    if (MODE == 1) for (int j = lane; j < nq; j += 64) s_c[j] = -1;
+    if (MODE == 1) for (int j = lane; j < nq; j += 64) s_c[j] = -1;   // MODE 1 never runs in segments
     __syncthreads();
     const bool need2 = MODE == 1 || accept_mode != ACCEPT_BEST;
     int nm = 0;
@@ -202,13 +227,13 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
     auto fetch = [&](int i) {
         nb_ = ne_ = 0; ntk = 1; nt0 = nt1 = make_uint4(~0u, ~0u, ~0u, ~0u);
         if (i < nq) {
-            nb_ = off[i]; ne_ = off[i + 1];
+            nb_ = lbeg[i]; ne_ = lend[i];
             nt0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i]; nt1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1];
             if (MODE == 0) ntk = takes[i];
         }
     };
-    fetch(lane);
-    for (int i0 = 0; i0 < nq; i0 += 64) {
+    fetch(q_begin + lane);
+    for (int i0 = q_begin; i0 < nq; i0 += 64) {
         const int i = i0 + lane;
         const bool in = i < nq;
         const int b = nb_, e = ne_;
@@ -294,9 +319,13 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
         }
     }
     __syncthreads();
-    if (MODE == 0) for (int j = lane; j < ns; j += 64) out_a[j] = s_a[j];   // match_kp by sorted position
-    else for (int j = lane; j < nq; j += 64) out_a[j] = s_c[j];            // vnMatches12 by sorted position
-    if (lane == 0) *nmatches = nm;
+    if (MODE == 0) {
+        for (int j = lane; j < ns; j += 64)                                  // match_kp by sorted position
+            if (!seg || s_a[j] >= 0) out_a[j] = s_a[j];
+    } else {
+        for (int j = lane; j < nq; j += 64) out_a[j] = s_c[j];              // vnMatches12 by sorted position
+    }
+    if (lane == 0) { if (seg) atomicAdd(nmatches, nm); else *nmatches = nm; }
 }
 
 // Window search without coupling between queries = Frame::GetFeaturesInArea (src/Frame.cc:342-395)
@@ -469,16 +498,30 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
     if (tid == 0) removed = 0;
     __syncthreads();
     const float factor = 1.0f / HISTO_LENGTH;
+    auto bin_of = [&](int i, int sp) {
+        float rot = qangle[i] - kangle[sp];
+        if (rot < 0.0f) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        return bin == HISTO_LENGTH ? 0 : bin;
+    };
+    // the first RPT * MT queries keep (candidate, bin) in registers between the two passes: one dependent gather chain
+    // instead of two (the kernel is one block of pure latency)
+    constexpr int RPT = 12;
+    int spc[RPT], binc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = tid + r * MT;
+        spc[r] = i < nq ? acc_sp[i] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        binc[r] = -1;
+        if (check && spc[r] >= 0) { binc[r] = bin_of(tid + r * MT, spc[r]); atomicAdd(&hist[binc[r]], 1); }
+    }
     if (check)
-        for (int i = tid; i < nq; i += MT) {
+        for (int i = tid + RPT * MT; i < nq; i += MT) {
             const int sp = acc_sp[i];
-            if (sp >= 0) {
-                float rot = qangle[i] - kangle[sp];
-                if (rot < 0.0f) rot += 360.0f;
-                int bin = (int)roundf(rot * factor);
-                if (bin == HISTO_LENGTH) bin = 0;
-                atomicAdd(&hist[bin], 1);
-            }
+            if (sp >= 0) atomicAdd(&hist[bin_of(i, sp)], 1);
         }
     __syncthreads();
     if (tid == 0) {
@@ -495,20 +538,20 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
     }
     if (MODE == 0) for (int j = tid; j < ns; j += MT) match_kp[perm[j]] = state[j];
     __syncthreads();
-    for (int i = tid; i < nq; i += MT) {
-        const int sp = acc_sp[i];
+    auto finish = [&](int i, int sp, int bin) {
         int out = MODE == 0 ? (sp >= 0 ? perm[sp] : -1) : (state[i] >= 0 ? perm[state[i]] : -1);
-        if (check && sp >= 0) {
-            float rot = qangle[i] - kangle[sp];
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            if (bin != keep[0] && bin != keep[1] && bin != keep[2]) {
-                if (MODE == 0) { match_kp[perm[sp]] = -2; atomicAdd(&removed, 1); }   // every entry of the bin: slot cleared, nmatches--
-                else if (state[i] >= 0) { out = -1; atomicAdd(&removed, 1); }         // only matches still standing (:704-708)
-            }
+        if (check && sp >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+            if (MODE == 0) { match_kp[perm[sp]] = -2; atomicAdd(&removed, 1); }   // every entry of the bin: slot cleared, nmatches--
+            else if (state[i] >= 0) { out = -1; atomicAdd(&removed, 1); }         // only matches still standing (:704-708)
         }
         match_q[i] = out;
+    };
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        if (tid + r * MT < nq) finish(tid + r * MT, spc[r], binc[r]);
+    for (int i = tid + RPT * MT; i < nq; i += MT) {
+        const int sp = acc_sp[i];
+        finish(i, sp, check && sp >= 0 ? bin_of(i, sp) : -1);
     }
     __syncthreads();
     if (tid == 0) *nmatches -= removed;
@@ -529,16 +572,19 @@ void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint
 {
     std::vector<WinKp> wk;
     build_winkp(kps, n, skip, uright, min_x, min_y, max_x, max_y, wk);
-    std::vector<unsigned> order;
-    order.reserve(n);
-    for (int j = 0; j < n; ++j)
-        if (wk[j].order != 0xffffffffu) order.push_back(wk[j].order);
-    std::sort(order.begin(), order.end());
-    const size_t ns = order.size();
+    // counting sort by grid cell; inside a cell ascending keypoint index (= insertion order, Frame.cc:245-260)
     sf.gp = {min_x, min_y, (float)FRAME_GRID_COLS / (max_x - min_x), (float)FRAME_GRID_ROWS / (max_y - min_y)}; // Frame.cc:95-96
     sf.cell_off.assign(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1, 0);
-    for (size_t k = 0; k < ns; ++k) sf.cell_off[(order[k] >> 16) + 1]++;
+    for (int j = 0; j < n; ++j)
+        if (wk[j].order != 0xffffffffu) sf.cell_off[(wk[j].order >> 16) + 1]++;
     for (int c = 0; c < FRAME_GRID_COLS * FRAME_GRID_ROWS; ++c) sf.cell_off[c + 1] += sf.cell_off[c];
+    const size_t ns = (size_t)sf.cell_off[FRAME_GRID_COLS * FRAME_GRID_ROWS];
+    std::vector<unsigned> order(ns ? ns : 1);
+    {
+        std::vector<int> fill(sf.cell_off.begin(), sf.cell_off.end() - 1);
+        for (int j = 0; j < n; ++j)
+            if (wk[j].order != 0xffffffffu) order[fill[wk[j].order >> 16]++] = wk[j].order;
+    }
     sf.kp.resize(ns ? ns : 1); sf.perm.resize(ns ? ns : 1); sf.angle.resize(ns ? ns : 1); sf.desc.resize(32 * (ns ? ns : 1));
     for (size_t s = 0; s < ns; ++s) {
         const int j = (int)(order[s] & 0xffffu);
@@ -556,7 +602,8 @@ void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint
 int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes, int nq,
                    const SortedFrame &sf, int n, int has_uright, int th, float nnratio, int accept_mode, int check,
                    int32_t *match_kp, int32_t *match_q, int *nmatches, const int32_t *cand_off = nullptr,
-                   const int32_t *cand_idx = nullptr)
+                   const int32_t *cand_beg = nullptr, const int32_t *cand_idx = nullptr, int ncand = 0,
+                   const int32_t *seg = nullptr, int nseg = 0)
 {
     const int ns = (int)sf.perm.size();
     if (ns > SEQ_MAXN || nq > 65536) ORBX_FAIL(ORBX_ERR_CAPACITY, "frame too large for the sequential resolver");
@@ -566,92 +613,124 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     if (nq == 0 || ns == 0) return ORBX_OK;
     const size_t lds = sizeof(int) * (3 * (size_t)ns + (mode == 1 ? nq : 0)) + 16;
     if (lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_CAPACITY, "resolver state exceeds LDS");
-    const int ncand = cand_off ? cand_off[nq] : 0;
+    if (mode != 0) { seg = nullptr; nseg = 0; }
 
     WorkspaceLease lease;
     Workspace &w = *lease.w;
-    w.used = 0;
-    // staged inputs (same offsets on both sides), then device-only arrays, then the result block
-    const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * ns),
-                 o_b = w.carve((size_t)32 * ns), o_kang = w.carve(sizeof(float) * ns), o_qang = w.carve(sizeof(float) * nq),
-                 o_perm = w.carve(sizeof(int) * ns), o_tk = w.carve(nq), o_off = w.carve(sizeof(int) * (nq + 1)),
-                 o_cand = w.carve(sizeof(int) * (size_t)(ncand ? ncand : 1)),
-                 o_cell = w.carve(sizeof(int) * (FRAME_GRID_COLS * FRAME_GRID_ROWS + 1));
-    const size_t staged = w.used;
-    const size_t o_top = w.carve(sizeof(unsigned) * TOPK * (size_t)nq), o_cnt = w.carve(sizeof(int) * nq), o_acc = w.carve(sizeof(int) * nq),
-                 o_state = w.carve(sizeof(int) * (size_t)std::max(ns, nq));
-    const size_t o_res = w.used;
-    const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(sizeof(int));
-    const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
-    if (w.reserve(total_bytes, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
-    hipStream_t st = w.st;
-
-    if (queries) {
-        memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
-        memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
-        memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
-    }
-    memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
-    memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
-    memcpy(w.h<char>(o_kang), sf.angle.data(), sizeof(float) * ns);
-    if (qangle) memcpy(w.h<char>(o_qang), qangle, sizeof(float) * nq); else memset(w.h<char>(o_qang), 0, sizeof(float) * nq);
-    memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
-    if (qtakes) memcpy(w.h<char>(o_tk), qtakes, nq); else memset(w.h<char>(o_tk), 1, nq);
-    if (cand_off) {
-        memcpy(w.h<char>(o_off), cand_off, sizeof(int) * (nq + 1));
-        if (ncand) memcpy(w.h<char>(o_cand), cand_idx, sizeof(int) * ncand);
-    }
-    ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
-    ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * (size_t)(n ? n : 1), st)); // -1: slot untouched
-
-    const WinQuery *dq = w.d<WinQuery>(o_q);
-    const uint4 *da = w.d<uint4>(o_a), *db = w.d<uint4>(o_b);
-    const SeqKp *dk = w.d<SeqKp>(o_k);
-    int *doff = w.d<int>(o_off), *dnm = w.d<int>(o_nm);
-    const int init_dist = mode == 0 ? 256 : INT_MAX;
-    const dim3 g((nq + MT / 64 - 1) / (MT / 64)); // one wave per query
-    unsigned *dtop = w.d<unsigned>(o_top);
-    if (cand_off) { // explicit candidate lists
-        if (w.reserve_entries((size_t)ncand)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
-        hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, st, da, nq, db, (const int *)doff, (const int *)w.d<int>(o_cand), w.ent);
-    } else {
-        hipLaunchKernelGGL(k_win_wave<0>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
-                           init_dist, w.d<int>(o_cnt), (const int *)nullptr, (unsigned *)nullptr);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_cnt), nq, doff);
-        ORBX_HIP(hipGetLastError());
-        int total = 0;
-        ORBX_HIP(hipMemcpyAsync(&total, doff + nq, sizeof(int), hipMemcpyDeviceToHost, st));
-        ORBX_HIP(hipStreamSynchronize(st));
-        if (w.reserve_entries((size_t)total)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
-        hipLaunchKernelGGL(k_win_wave<1>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
-                           init_dist, (int *)nullptr, (const int *)doff, w.ent);
-    }
-    hipLaunchKernelGGL(k_topk, g, dim3(MT), 0, st, (const unsigned *)w.ent, (const int *)doff, nq, dtop);
     static bool lds_attr_set = false;
     if (!lds_attr_set) { // the largest request either instantiation can make
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
-    if (mode == 0) {
-        hipLaunchKernelGGL(k_resolve<0>, dim3(1), dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, (const int *)doff, nq, ns,
-                           (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, w.d<int>(o_acc), w.d<int>(o_state), dnm);
-        hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
-                           (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
-                           w.d<int>(o_mq), w.d<int>(o_mk), dnm);
-    } else {
-        hipLaunchKernelGGL(k_resolve<1>, dim3(1), dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, (const int *)doff, nq, ns,
-                           (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, 0, w.d<int>(o_acc), w.d<int>(o_state), dnm);
-        hipLaunchKernelGGL(k_rotation<1>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
-                           (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
-                           w.d<int>(o_mq), w.d<int>(o_mk), dnm);
+    // Window lists: their lengths are known only on the device.  First attempt: every query fills its own region of
+    // WIN_STRIDE entries in one pass (no count, no scan, no host wait); if a list does not fit, the overflow flag comes
+    // back with the results and the call is repeated on the exact path (count, scan, fill), whose total also travels
+    // with the results -- the host never waits in the middle of a call.
+    constexpr int WIN_STRIDE = 256;
+    bool exact = false;
+    size_t ent_need = cand_off ? (size_t)cand_off[nq] : (size_t)nq * WIN_STRIDE;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        w.used = 0;
+        // staged inputs (same offsets on both sides), then device-only arrays, then the result block
+        const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * ns),
+                     o_b = w.carve((size_t)32 * ns), o_kang = w.carve(sizeof(float) * ns), o_qang = w.carve(sizeof(float) * nq),
+                     o_perm = w.carve(sizeof(int) * ns), o_tk = w.carve(nq), o_off = w.carve(sizeof(int) * (nq + 1)),
+                     o_cbeg = w.carve(sizeof(int) * (size_t)nq), o_cand = w.carve(sizeof(int) * (size_t)(ncand ? ncand : 1)),
+                     o_cell = w.carve(sizeof(int) * (FRAME_GRID_COLS * FRAME_GRID_ROWS + 1)),
+                     o_seg = w.carve(sizeof(int) * (size_t)(nseg + 1));
+        const size_t staged = w.used;
+        const size_t o_top = w.carve(sizeof(unsigned) * TOPK * (size_t)nq), o_cnt = w.carve(sizeof(int) * nq), o_acc = w.carve(sizeof(int) * nq),
+                     o_lend = w.carve(sizeof(int) * nq),
+                     o_state = w.carve(sizeof(int) * (size_t)std::max(ns, nq));
+        const size_t o_res = w.used;
+        const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(2 * sizeof(int));
+        const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
+        if (w.reserve(total_bytes, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        hipStream_t st = w.st;
+
+        if (queries) {
+            memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
+            memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
+            memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
+        }
+        memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
+        memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
+        memcpy(w.h<char>(o_kang), sf.angle.data(), sizeof(float) * ns);
+        if (qangle) memcpy(w.h<char>(o_qang), qangle, sizeof(float) * nq); else memset(w.h<char>(o_qang), 0, sizeof(float) * nq);
+        memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
+        if (qtakes) memcpy(w.h<char>(o_tk), qtakes, nq); else memset(w.h<char>(o_tk), 1, nq);
+        if (cand_off) {
+            memcpy(w.h<char>(o_off), cand_off, sizeof(int) * (nq + 1));
+            memcpy(w.h<char>(o_cbeg), cand_beg, sizeof(int) * (size_t)nq);
+            if (ncand) memcpy(w.h<char>(o_cand), cand_idx, sizeof(int) * ncand);
+        }
+        if (seg) memcpy(w.h<char>(o_seg), seg, sizeof(int) * (size_t)(nseg + 1));
+        ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
+        ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * (size_t)(n ? n : 1), st)); // -1: slot untouched
+        ORBX_HIP(hipMemsetAsync(w.d<char>(o_nm), 0, 2 * sizeof(int), st));
+        if (seg) ORBX_HIP(hipMemsetAsync(w.d<char>(o_state), 0xff, sizeof(int) * (size_t)ns, st));    // segments write back touched slots only
+
+        const WinQuery *dq = w.d<WinQuery>(o_q);
+        const uint4 *da = w.d<uint4>(o_a), *db = w.d<uint4>(o_b);
+        const SeqKp *dk = w.d<SeqKp>(o_k);
+        int *doff = w.d<int>(o_off), *dnm = w.d<int>(o_nm);
+        const int init_dist = mode == 0 ? 256 : INT_MAX;
+        const dim3 g((nq + MT / 64 - 1) / (MT / 64)); // one wave per query
+        unsigned *dtop = w.d<unsigned>(o_top);
+        const int *lbeg = doff, *lend = doff + 1; // CSR lists; the strided path has its own bounds
+        if (cand_off) { // explicit candidate lists
+            hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, st, da, nq, db, (const int *)doff, (const int *)w.d<int>(o_cbeg),
+                               (const int *)w.d<int>(o_cand), w.ent, dtop);
+        } else if (!exact) {
+            lbeg = w.d<int>(o_cnt); lend = w.d<int>(o_lend);
+            hipLaunchKernelGGL(k_win_wave<2>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+                               init_dist, (int *)nullptr, (const int *)nullptr, w.ent, WIN_STRIDE, w.d<int>(o_cnt), w.d<int>(o_lend), dnm + 1, dtop);
+        } else {
+            hipLaunchKernelGGL(k_win_wave<0>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+                               init_dist, w.d<int>(o_cnt), (const int *)nullptr, (unsigned *)nullptr, 0, (int *)nullptr, (int *)nullptr,
+                               (int *)nullptr, (unsigned *)nullptr);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_cnt), nq, doff, dnm + 1);
+            if (attempt == 1) { // the total is needed to size the buffer: the one host wait of this (rare) path
+                int total = 0;
+                ORBX_HIP(hipMemcpyAsync(&total, dnm + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                ORBX_HIP(hipStreamSynchronize(st));
+                ent_need = (size_t)total;
+                if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+            }
+            hipLaunchKernelGGL(k_win_wave<1>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+                               init_dist, (int *)nullptr, (const int *)doff, w.ent, 0, (int *)nullptr, (int *)nullptr, (int *)nullptr, dtop);
+        }
+        const int *dseg = seg ? w.d<int>(o_seg) : nullptr;
+        const dim3 gr(seg ? nseg : 1);
+        if (mode == 0) {
+            hipLaunchKernelGGL(k_resolve<0>, gr, dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend, nq, ns,
+                               (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, w.d<int>(o_acc), w.d<int>(o_state), dnm, dseg);
+            hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
+                               (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
+                               w.d<int>(o_mq), w.d<int>(o_mk), dnm);
+        } else {
+            hipLaunchKernelGGL(k_resolve<1>, gr, dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend, nq, ns,
+                               (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, 0, w.d<int>(o_acc), w.d<int>(o_state), dnm, dseg);
+            hipLaunchKernelGGL(k_rotation<1>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
+                               (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
+                               w.d<int>(o_mq), w.d<int>(o_mk), dnm);
+        }
+        ORBX_HIP(hipGetLastError());
+        ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));
+        ORBX_HIP(hipStreamSynchronize(st));
+        int flag = 0;
+        memcpy(&flag, w.pin + (o_nm - o_res) + sizeof(int), sizeof(int));
+        if (!cand_off && !exact && flag) { // a window list outgrew its region: once more on the exact path
+            exact = true;
+            continue;
+        }
+        memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
+        if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
+        memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
+        break;
     }
-    ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipStreamSynchronize(st));
-    memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
-    if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
-    memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
     return ORBX_OK;
 }
 
@@ -872,22 +951,26 @@ int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t
     if (match21) for (int j = 0; j < n2; ++j) match21[j] = -1;
     *nmatches = 0;
     // the co-iteration of :384-456 / :745-828 (equal keys: visit; else lower_bound on the other map), as lists
-    std::vector<int32_t> qidx, cand_off(1, 0), cand;
+    std::vector<int32_t> qidx, cand_off(1, 0), cand_beg, cand, seg(1, 0);
+    std::vector<uint8_t> seen(n2 ? n2 : 1, 0);
+    bool disjoint = true; // a feature sits in one node of a FeatureVector; arrays that break this resolve as one segment
     for (int a = 0, b = 0; a < nn1 && b < nn2;) {
         if (nodes1[a] == nodes2[b]) {
             const size_t c0 = cand.size();
+            for (int k = off2[b]; k < off2[b + 1]; ++k) { disjoint = disjoint && !seen[items2[k]]; seen[items2[k]] = 1; }
             for (int k = off2[b]; k < off2[b + 1]; ++k)
                 if (!valid2 || valid2[items2[k]]) cand.push_back(items2[k]);
-            const size_t len = cand.size() - c0;
-            bool first = true;
-            for (int k = off1[a]; k < off1[a + 1]; ++k) {
+            const int32_t len = (int32_t)(cand.size() - c0);
+            bool any = false;
+            for (int k = off1[a]; k < off1[a + 1]; ++k) { // every query of the node: the same members, one copy
                 if (!valid1[items1[k]]) continue;
-                if (!first) cand.insert(cand.end(), cand.begin() + c0, cand.begin() + c0 + len); // every query of the node: same members
-                first = false;
+                any = true;
                 qidx.push_back(items1[k]);
-                cand_off.push_back((int32_t)cand.size());
+                cand_beg.push_back((int32_t)c0);
+                cand_off.push_back(cand_off.back() + len);
             }
-            if (first) cand.resize(c0);
+            if (!any) cand.resize(c0);
+            else seg.push_back((int32_t)qidx.size());   // one segment per node
             ++a; ++b;
         } else if (nodes1[a] < nodes2[b]) {
             while (a < nn1 && nodes1[a] < nodes2[b]) ++a;
@@ -906,7 +989,8 @@ int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t
     std::vector<int32_t> mk(n2), mq(nq);
     // bestDist1 < TH_LOW (:799) == bestDist1 <= TH_LOW - 1
     const int rc = run_sequential(0, nullptr, qd.data(), qa.data(), nullptr, nq, sf, n2, 0, strict_th ? th - 1 : th, nnratio,
-                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, cand_off.data(), cand.data());
+                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, cand_off.data(), cand_beg.data(), cand.data(),
+                                  (int)cand.size(), disjoint ? seg.data() : nullptr, disjoint ? (int)seg.size() - 1 : 0);
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < nq; ++i) // every accepted query blocks its candidate, so slot mq[i] still names i unless rejected
         if (mq[i] >= 0 && mk[mq[i]] == i) { match12[qidx[i]] = mq[i]; if (match21) match21[mq[i]] = qidx[i]; }

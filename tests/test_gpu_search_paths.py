@@ -1,0 +1,38 @@
+"""The windowed whole-loop search takes one of two routes for its candidate lists: every query fills its own fixed
+region in one pass, or -- when some list outgrows its region -- the exact count / scan / fill route.  Both must give
+the sequential loop's result (ORBmatcher.cc:46-132); the crowded case forces the second route."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from orb_slam2_e_amd import ORBmatcher
+from orb_slam2_e_amd.extractor import KP_DTYPE
+
+
+@pytest.mark.parametrize("crowd", [40, 700])
+def test_projection_loop_small_and_overflowing_lists(crowd):
+    rng = np.random.default_rng(crowd)
+    n, nq = 1500, 900
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(0, 640, n); kps["y"] = rng.uniform(0, 480, n)
+    kps["x"][:crowd] = rng.uniform(300, 330, crowd); kps["y"][:crowd] = rng.uniform(200, 230, crowd)   # a crowd inside one window
+    kps["octave"] = rng.integers(0, 3, n); kps["angle"] = rng.uniform(0, 360, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    src = rng.integers(0, n, nq); src[:300] = rng.integers(0, crowd, 300)
+    q = np.zeros(nq, ORBmatcher.WQ_DTYPE)
+    q["u"] = kps["x"][src] + rng.normal(0, 1, nq); q["v"] = kps["y"][src] + rng.normal(0, 1, nq)
+    q["r"] = 40.0; q["min_level"] = 0; q["max_level"] = 2; q["xr"] = q["u"]
+    qd = desc[src] ^ np.packbits(rng.random((nq, 256)) < 0.05, axis=1, bitorder="little")
+    qa = ((kps["angle"][src] + 7.0) % 360).astype(np.float32)
+    takes = np.ones(nq, np.uint8)
+    occ = np.zeros(n, np.uint8)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    m = ORBmatcher(0.8, True)
+    for same_level in (False, True):
+        got = m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, None, 95, ratio_same_level=same_level)
+        ref = oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, None, 95, 0.8, same_level, True)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g, r)
+    assert got[2] > 100
