@@ -268,6 +268,32 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
                                   const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels,
                                   float th, float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj);
 
+/* Batch projection of map points (M15): replaces the per-point host loop in front of every SearchByProjection /
+ * Fuse form.  mode ORBM_PROJECT_FRUSTUM = Frame::isInFrustum (src/Frame.cc:284-340: positive depth, image bounds
+ * mnMinX..mnMaxY inclusive, distance in [0.9 min, max / 0.9], viewing cosine >= viewing_cos_limit) with
+ * MapPoint::PredictScale (src/MapPoint.cc:464-480) -> mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, and the
+ * window of SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:62-70: RadiusByViewingCos, * th
+ * unless th == 1, * mvScaleFactors[level], levels [l-1, l], xr = mTrackProjXR);
+ * ORBM_PROJECT_FUSE = the projection block of ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:1053-1094: KeyFrame::IsInImage, distance in [min, max], PO.Pn >= 0.5 dist, radius th *
+ * mvScaleFactors[level]); ORBM_PROJECT_FUSE_SIM3 = the Sim3 form (:1212-1250; the caller passes Rcw = sRcw / s,
+ * tcw = t / s, Ow = -Rcw' tcw as :1188-1192 computes them).
+ * mp_min_distance / mp_max_distance are MapPoint::mfMinDistance / mfMaxDistance (the 0.8 / 1.2 factors of
+ * Get{Min,Max}DistanceInvariance are applied here); Rcw row-major 3x3, tcw, Ow = camera centre, all float as the
+ * cv::Mat members are; cam->grid_* = mnMinX .. mnMaxY; log_scale_factor = mfLogScaleFactor.
+ * out[i].visible = 0 for a point the reference rejects (then level = -1 and queries[i].r < 0 = "no candidates", so
+ * the arrays feed orbm_search_projection / orbm_search_fuse as they are).  queries may be NULL. */
+enum { ORBM_PROJECT_FRUSTUM = 0, ORBM_PROJECT_FUSE = 1, ORBM_PROJECT_FUSE_SIM3 = 2 };
+typedef struct orbm_projected_point {
+    float u, v, ur, view_cos, dist; /* mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos, |P - Ow| */
+    int32_t level;                  /* mnTrackScaleLevel / nPredictedLevel, -1 if rejected */
+    int32_t visible;                /* mbTrackInView */
+} orbm_projected_point;
+int orbm_project_points(int mode, const float *mp_pos, const float *mp_normal, const float *mp_min_distance,
+                        const float *mp_max_distance, int m, const float *Rcw, const float *tcw, const float *Ow,
+                        const orbm_camera *cam, float mbf, float viewing_cos_limit, float log_scale_factor,
+                        const float *scale_factors, int nlevels, float th, orbm_projected_point *out, orbm_window_query *queries);
+
 /* Inner loop of ORBmatcher::SearchForTriangulation (ORBmatcher.cc:892-990) with
  * CheckDistEpipolarLine (:341-358): per keypoint of KF1 (skipped if it owns a
  * MapPoint, or is mono while only_stereo), scan its BoW-node candidates of KF2 in

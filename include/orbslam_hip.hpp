@@ -251,6 +251,128 @@ public:
         return mStatus;
     }
 
+    // What the projection kernels read of a Frame / KeyFrame pose (src/Frame.cc:270-282, KeyFrame::GetRotation ...):
+    // mRcw (row-major), mtcw, mOw as the float cv::Mat members hold them, the intrinsics, the grid bounds
+    // mnMinX .. mnMaxY (in cam.grid_*), mbf, mfLogScaleFactor, mvScaleFactors.
+    struct PoseView {
+        float Rcw[9], tcw[3], Ow[3];
+        orbm_camera cam;
+        float mbf = 0.f, mfLogScaleFactor = 0.f;
+        const float *mvScaleFactors = nullptr;
+        const float *mvInvLevelSigma2 = nullptr;
+        int mnScaleLevels = 0;
+    };
+    // Map points gathered by the caller from a vector<MapPoint*>: GetWorldPos(), GetNormal(), mfMinDistance,
+    // mfMaxDistance, GetDescriptor(), one entry per list position (entries of NULL pointers are never read back).
+    struct MapPointArrays {
+        const float *pos = nullptr, *normal = nullptr, *mfMinDistance = nullptr, *mfMaxDistance = nullptr;
+        const uint8_t *descriptors = nullptr;
+        int n = 0;
+    };
+
+    // Frame::isInFrustum + MapPoint::PredictScale for all points at once (Frame.cc:284-340, MapPoint.cc:464-480):
+    // out[i] = {mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos, dist, mnTrackScaleLevel, mbTrackInView}, windows[i] =
+    // the GetFeaturesInArea query of SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:62-70).
+    int ProjectInFrustum(const PoseView &F, const MapPointArrays &mps, float viewingCosLimit, float th,
+                         std::vector<orbm_projected_point> &out, std::vector<orbm_window_query> &windows)
+    {
+        out.resize(mps.n); windows.resize(mps.n);
+        mStatus = orbm_project_points(ORBM_PROJECT_FRUSTUM, mps.pos, mps.normal, mps.mfMinDistance, mps.mfMaxDistance, mps.n, F.Rcw,
+                                      F.tcw, F.Ow, &F.cam, F.mbf, viewingCosLimit, F.mfLogScaleFactor, F.mvScaleFactors,
+                                      F.mnScaleLevels, th, out.data(), windows.data());
+        return mStatus;
+    }
+
+    // ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) as a whole (ORBmatcher.cc:1026-1176): projection of every
+    // listed point (:1053-1094) and the gated candidate loop (:1092-1146) on the device, then the loop's skips (:1046-1053)
+    // and its map update (:1149-1170) on the host in the list's order -- the candidate search of a point does not depend
+    // on the map state, the skips and the update do.  `map` supplies the pointer-graph side through handles H (e.g.
+    // MapPoint*): H at(int i) (vpMapPoints[i], a null handle for NULL), bool null(H), bool isBad(H), bool
+    // isInKeyFrame(H), H slotOwner(int idx) (pKF->GetMapPoint), int observations(H), void replace(H dead, H heir)
+    // (dead->Replace(heir)), void add(H, int idx) (AddObservation + AddMapPoint).
+    template <class MapOps>
+    int Fuse(const FrameView &KF, const PoseView &pose, const MapPointArrays &mps, float th, MapOps &map)
+    {
+        std::vector<orbm_projected_point> proj;
+        std::vector<int32_t> best, idx;
+        if (fuseCandidates(KF, pose, mps, th, false, proj, best, idx) != ORBX_OK) return 0;
+        return fuseReplay(proj, best, idx, map);
+    }
+    // ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, vpReplacePoint) (ORBmatcher.cc:1178-1301):
+    // pose = the Sim3 decomposed as :1188-1192 do; `map` additionally needs recordReplace(int i, H) (vpReplacePoint[i] =).
+    template <class MapOps>
+    int FuseSim3(const FrameView &KF, const PoseView &pose, const MapPointArrays &mps, float th, MapOps &map)
+    {
+        std::vector<orbm_projected_point> proj;
+        std::vector<int32_t> best, idx;
+        if (fuseCandidates(KF, pose, mps, th, true, proj, best, idx) != ORBX_OK) return 0;
+        return fuseReplaySim3(proj, best, idx, map);
+    }
+    int fuseCandidates(const FrameView &KF, const PoseView &pose, const MapPointArrays &mps, float th, bool sim3,
+                       std::vector<orbm_projected_point> &proj, std::vector<int32_t> &best, std::vector<int32_t> &idx)
+    {
+        proj.resize(mps.n);
+        std::vector<orbm_window_query> q(mps.n);
+        mStatus = orbm_project_points(sim3 ? ORBM_PROJECT_FUSE_SIM3 : ORBM_PROJECT_FUSE, mps.pos, mps.normal, mps.mfMinDistance,
+                                      mps.mfMaxDistance, mps.n, pose.Rcw, pose.tcw, pose.Ow, &pose.cam, pose.mbf, 0.f,
+                                      pose.mfLogScaleFactor, pose.mvScaleFactors, pose.mnScaleLevels, th, proj.data(), q.data());
+        if (mStatus != ORBX_OK) return mStatus;
+        best.assign(mps.n, 256); idx.assign(mps.n, -1);
+        mStatus = orbm_search_fuse(q.data(), mps.descriptors, mps.n, KF.mvKeysUn, KF.mDescriptors, KF.N, KF.mvuRight,
+                                   sim3 ? nullptr : pose.mvInvLevelSigma2, pose.mnScaleLevels, KF.mnMinX, KF.mnMinY, KF.mnMaxX,
+                                   KF.mnMaxY, best.data(), idx.data());
+        return mStatus;
+    }
+
+    // Tail of the Fuse loop, ORBmatcher.cc:1046-1053 and :1149-1170, in list order.
+    template <class MapOps>
+    static int fuseReplay(const std::vector<orbm_projected_point> &proj, const std::vector<int32_t> &best,
+                          const std::vector<int32_t> &idx, MapOps &map)
+    {
+        int nFused = 0;
+        for (int i = 0; i < (int)proj.size(); ++i) {
+            auto pMP = map.at(i);
+            if (map.null(pMP)) continue;
+            if (map.isBad(pMP) || map.isInKeyFrame(pMP)) continue;
+            if (!proj[i].visible || idx[i] < 0) continue;      // projection tests failed / vIndices.empty() / no candidate
+            if (best[i] <= TH_LOW) {
+                auto pMPinKF = map.slotOwner(idx[i]);
+                if (!map.null(pMPinKF)) {
+                    if (!map.isBad(pMPinKF)) {
+                        if (map.observations(pMPinKF) > map.observations(pMP)) map.replace(pMP, pMPinKF);
+                        else map.replace(pMPinKF, pMP);
+                    }
+                } else {
+                    map.add(pMP, idx[i]);
+                }
+                ++nFused;
+            }
+        }
+        return nFused;
+    }
+
+    // Tail of the Sim3 form, ORBmatcher.cc:1194-1205 and :1279-1296: the skips read spAlreadyFound (a snapshot taken before
+    // the loop: isInKeyFrame must answer from that snapshot), a taken slot is only recorded (vpReplacePoint[iMP] =
+    // pMPinKF: map.recordReplace(i, pMPinKF)), a free one gets the point.
+    template <class MapOps>
+    static int fuseReplaySim3(const std::vector<orbm_projected_point> &proj, const std::vector<int32_t> &best,
+                              const std::vector<int32_t> &idx, MapOps &map)
+    {
+        int nFused = 0;
+        for (int i = 0; i < (int)proj.size(); ++i) {
+            auto pMP = map.at(i);
+            if (map.null(pMP) || map.isBad(pMP) || map.isInKeyFrame(pMP)) continue;
+            if (!proj[i].visible || idx[i] < 0) continue;
+            if (best[i] <= TH_LOW) {
+                auto pMPinKF = map.slotOwner(idx[i]);
+                if (!map.null(pMPinKF)) { if (!map.isBad(pMPinKF)) map.recordReplace(i, pMPinKF); }
+                else map.add(pMP, idx[i]);
+                ++nFused;
+            }
+        }
+        return nFused;
+    }
+
     // ORBmatcher::SearchBySim3 (ORBmatcher.cc:1303-1527) over projected points: points12[i1] = map point i1 of KF1 seen
     // in KF2 (window.r < 0: skipped), points21 the other way; levels [l-1, l], <= TH_HIGH, then the agreement check.
     int SearchBySim3(const FrameView &KF1, const FrameView &KF2, const std::vector<ProjectedPoint> &points12,

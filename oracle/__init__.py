@@ -590,3 +590,37 @@ def distinctive_descriptors(desc, off):
     best = np.zeros(len(o) - 1, np.int32)
     L.oracle_distinctive_descriptors(_p(d), _p(o), len(o) - 1, _p(best))
     return best
+
+
+PROJ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("view_cos", "<f4"), ("dist", "<f4"), ("level", "<i4"),
+                       ("visible", "<i4")])
+
+
+def project_points(mode, mp_pos, mp_normal, mp_min_distance, mp_max_distance, Rcw, tcw, Ow, cam4, bounds4, mbf,
+                   viewing_cos_limit, log_scale_factor, scale_factors, th):
+    """Frame::isInFrustum + PredictScale (mode 0) / the projection block of the two Fuse forms (1, 2), point by point."""
+    L = lib()
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pos, nrm, mn, mx = f32(mp_pos), f32(mp_normal), f32(mp_min_distance), f32(mp_max_distance)
+    R, t, O, c4, b4, sc = f32(Rcw).reshape(9), f32(tcw).reshape(3), f32(Ow).reshape(3), f32(cam4), f32(bounds4), f32(scale_factors)
+    m = len(pos)
+    out = np.zeros(m, PROJ_DTYPE); q = np.zeros(m, WQ_DTYPE)
+    L.oracle_project_points.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 3 + \
+                                       [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.oracle_project_points(int(mode), _p(pos), _p(nrm), _p(mn), _p(mx), m, _p(R), _p(t), _p(O), _p(c4), _p(b4), float(mbf),
+                            float(viewing_cos_limit), float(log_scale_factor), _p(sc), len(sc), float(th), _p(out), _p(q))
+    return out, q
+
+
+def fuse_replay(vpMapPoints, visible, best, idx, mp_obs, mp_bad, mp_in_kf, kf_mp, th_low=45):
+    """Tail of ORBmatcher::Fuse (ORBmatcher.cc:1046-1053, :1149-1170) on the toy map of oracle_fuse_replay; the state
+    arrays are updated in place.  Returns (nFused, ops[k,3])."""
+    L = lib()
+    lst = np.ascontiguousarray(vpMapPoints, np.int32); vis = np.ascontiguousarray(visible, np.int32)
+    b = np.ascontiguousarray(best, np.int32); ix = np.ascontiguousarray(idx, np.int32)
+    assert mp_obs.dtype == np.int32 and mp_bad.dtype == np.uint8 and mp_in_kf.dtype == np.int32 and kf_mp.dtype == np.int32
+    ops = np.zeros((len(lst) + 1, 3), np.int32); nops = C.c_int(0)
+    L.oracle_fuse_replay.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6
+    n = L.oracle_fuse_replay(_p(lst), len(lst), _p(vis), _p(b), _p(ix), int(th_low), _p(mp_obs), _p(mp_bad), _p(mp_in_kf),
+                             _p(kf_mp), _p(ops), C.byref(nops))
+    return n, ops[:nops.value].copy()

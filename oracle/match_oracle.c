@@ -722,3 +722,130 @@ void oracle_distinctive_descriptors(const uint8_t *desc, const int *off, int m, 
         best[i] = BestIdx;
     }
 }
+
+/* ---- Frame::isInFrustum (src/Frame.cc:284-340) with MapPoint::PredictScale (src/MapPoint.cc:464-480) and the projection
+ * blocks of the two ORBmatcher::Fuse forms (src/ORBmatcher.cc:1053-1094, :1212-1250), one point at a time as the reference
+ * does.  The cv::Mat arithmetic (OpenCV 3.4, CV_32F; not under /root/reference -- parity unpinned) is restated as:
+ * Rcw*P + tcw = gemm's 3x3 special case (row sum in float, left to right; result = float(double(sum) + double(t)));
+ * cv::norm = sqrt of the double sum of squares; Mat::dot = double sum of double products.  std::log / std::ceil on
+ * floats are the float overloads (using namespace std). */
+typedef struct { float u, v, ur, view_cos, dist; int level, visible; } oracle_projected;
+
+static int oracle_predict_scale(float mfMaxDistance, float currentDist, float logScaleFactor, int nScaleLevels)
+{
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)ceilf(logf(ratio) / logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nScaleLevels) nScale = nScaleLevels - 1;
+    return nScale;
+}
+
+static float oracle_radius_by_viewing_cos(float viewCos) { return viewCos > 0.998 ? 3.0f : 4.5f; } /* ORBmatcher.cc:332-338 */
+
+void oracle_project_points(int mode, const float *pos, const float *nrm, const float *mfMinDistance, const float *mfMaxDistance,
+                           int m, const float *Rcw, const float *tcw, const float *Ow, const float *cam4, const float *bounds4,
+                           float mbf, float viewingCosLimit, float logScaleFactor, const float *scaleFactors, int nLevels,
+                           float th, oracle_projected *out, oracle_wquery *q)
+{
+    const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const float mnMinX = bounds4[0], mnMinY = bounds4[1], mnMaxX = bounds4[2], mnMaxY = bounds4[3];
+    int i, k;
+    for (i = 0; i < m; i++) {
+        const float *P = pos + 3 * i, *Pn = nrm + 3 * i;
+        float Pc[3], PO[3], invz, u, v, ur, dist, viewCos = 0.f, r;
+        double dot;
+        int level;
+        oracle_projected o = {0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};
+        oracle_wquery w = {0.f, 0.f, -1.f, 0.f, 0, -1};
+        out[i] = o;
+        if (q) q[i] = w;
+        for (k = 0; k < 3; k++) {
+            const float s = Rcw[3 * k] * P[0] + Rcw[3 * k + 1] * P[1] + Rcw[3 * k + 2] * P[2];
+            Pc[k] = (float)((double)s + (double)tcw[k]);
+        }
+        if (Pc[2] < 0.0f) continue;
+        if (mode == 0) {
+            invz = 1.0f / Pc[2];
+            u = fx * Pc[0] * invz + cx;
+            v = fy * Pc[1] * invz + cy;
+            if (u < mnMinX || u > mnMaxX) continue;
+            if (v < mnMinY || v > mnMaxY) continue;
+        } else {
+            float x, y;
+            invz = mode == 1 ? 1 / Pc[2] : (float)(1.0 / Pc[2]);
+            x = Pc[0] * invz; y = Pc[1] * invz;
+            u = fx * x + cx; v = fy * y + cy;
+            if (!(u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY)) continue;
+        }
+        ur = u - mbf * invz;
+        {
+            const float maxDistance = 1.2f * mfMaxDistance[i], minDistance = 0.8f * mfMinDistance[i];
+            double ss = 0;
+            for (k = 0; k < 3; k++) PO[k] = P[k] - Ow[k];
+            for (k = 0; k < 3; k++) ss += (double)PO[k] * (double)PO[k];
+            dist = (float)sqrt(ss);
+            dot = 0;
+            for (k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn[k];
+            if (mode == 0) {
+                if (dist < 0.9 * minDistance || dist > maxDistance / 0.9) continue;
+                viewCos = (float)(dot / dist);
+                if (viewCos < viewingCosLimit) continue;
+            } else {
+                if (dist < minDistance || dist > maxDistance) continue;
+                if (dot < 0.5 * dist) continue;
+            }
+        }
+        level = oracle_predict_scale(mfMaxDistance[i], dist, logScaleFactor, nLevels);
+        o.u = u; o.v = v; o.ur = ur; o.view_cos = viewCos; o.dist = dist; o.level = level; o.visible = 1;
+        out[i] = o;
+        if (mode == 0) {
+            r = oracle_radius_by_viewing_cos(viewCos);
+            if (th != 1.0) r *= th;
+        } else {
+            r = th;
+        }
+        if (q) { w.u = u; w.v = v; w.r = r * scaleFactors[level]; w.xr = ur; w.min_level = level - 1; w.max_level = level; q[i] = w; }
+    }
+}
+
+/* ---- ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) as a whole, src/ORBmatcher.cc:1026-1176, on a toy map:
+ * map points are indices 0..nmp-1 with Observations() = mp_obs[], isBad() = mp_bad[], their slot in this key frame
+ * mp_in_kf[] (-1: IsInKeyFrame false); the key frame's mvpMapPoints = kf_mp[] (-1 = NULL).  vpMapPoints = list[] (-1 = NULL
+ * entries, duplicates allowed).  Replace(a by b) (MapPoint.cc:209-258, what this loop can observe of it): a becomes bad,
+ * b takes a's slot in this key frame unless b is already in it (then the slot is erased), b's observation count grows by
+ * one per key frame taken over.  best / idx come from the candidate loop (oracle_search_fuse on the projected windows).
+ * Returns nFused; ops[] receives the sequence of map operations {kind, mp, slot_or_other}: 0 = AddObservation + AddMapPoint,
+ * 1 = pMP->Replace(pMPinKF) (pMP dies), 2 = pMPinKF->Replace(pMP). */
+int oracle_fuse_replay(const int *list, int nlist, const int *visible, const int *best, const int *idx, int th_low,
+                       int *mp_obs, uint8_t *mp_bad, int *mp_in_kf, int *kf_mp, int *ops, int *nops)
+{
+    int i, nFused = 0, no = 0;
+    for (i = 0; i < nlist; i++) {
+        const int pMP = list[i];
+        if (pMP < 0) continue;
+        if (mp_bad[pMP] || mp_in_kf[pMP] >= 0) continue;
+        if (!visible[i] || idx[i] < 0) continue;          /* projection tests / vIndices.empty() / no candidate */
+        if (best[i] <= th_low) {
+            const int bestIdx = idx[i], pMPinKF = kf_mp[bestIdx];
+            if (pMPinKF >= 0) {
+                if (!mp_bad[pMPinKF]) {
+                    if (mp_obs[pMPinKF] > mp_obs[pMP]) { /* pMP->Replace(pMPinKF): pMP is in no slot of this key frame */
+                        mp_bad[pMP] = 1;
+                        ops[3 * no] = 1; ops[3 * no + 1] = pMP; ops[3 * no + 2] = pMPinKF; no++;
+                    } else {                              /* pMPinKF->Replace(pMP): pMP takes the slot */
+                        mp_bad[pMPinKF] = 1;
+                        mp_in_kf[pMPinKF] = -1;
+                        kf_mp[bestIdx] = pMP; mp_in_kf[pMP] = bestIdx; mp_obs[pMP] += 1;
+                        ops[3 * no] = 2; ops[3 * no + 1] = pMP; ops[3 * no + 2] = pMPinKF; no++;
+                    }
+                }
+            } else {
+                kf_mp[bestIdx] = pMP; mp_in_kf[pMP] = bestIdx; mp_obs[pMP] += 1;
+                ops[3 * no] = 0; ops[3 * no + 1] = pMP; ops[3 * no + 2] = bestIdx; no++;
+            }
+            nFused++;
+        }
+    }
+    *nops = no;
+    return nFused;
+}

@@ -467,6 +467,82 @@ __global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ po
     if (proj) { proj[4 * i] = out[0]; proj[4 * i + 1] = out[1]; proj[4 * i + 2] = out[2]; proj[4 * i + 3] = out[3]; }
 }
 
+// Batch projection of map points into a Frame / KeyFrame, in the reference's float / double order, op by op:
+//   mode 0  Frame::isInFrustum (src/Frame.cc:284-340) + MapPoint::PredictScale (src/MapPoint.cc:464-480) and the window
+//           of SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:62-70, RadiusByViewingCos :332-338)
+//   mode 1  the projection block of ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th) (:1053-1094)
+//   mode 2  the same block of the Sim3 form (:1212-1250): invz = 1.0 / z in double, no right coordinate
+// cv::Mat arithmetic restated (OpenCV 3.4, CV_32F; parity unpinned like the other OpenCV primitives):
+//   Rcw * P + tcw  : gemm's 3 x 3 special case -- the row sum a0 b0 + a1 b1 + a2 b2 in float, left to right, then
+//                    float(double(sum) + double(t));
+//   cv::norm(PO)   : sqrt of the double sum of squares, left to right, cast to float;
+//   PO.dot(Pn)     : double sum of double products, left to right.
+// std::log / std::ceil on a float argument are the float overloads (using namespace std): log as the correctly
+// rounded float of the double logarithm (what glibc's logf returns except in vanishingly rare cases).
+struct ProjectCam { float fx, fy, cx, cy, min_x, max_x, min_y, max_y, mbf, cos_limit, log_scale, th; float R[9], t[3], Ow[3]; int nlevels, mode; };
+
+__global__ __launch_bounds__(MT) void k_project_points(const float *__restrict__ pos, const float *__restrict__ nrm,
+                                                       const float *__restrict__ mind, const float *__restrict__ maxd, int m,
+                                                       ProjectCam cam, const float *__restrict__ scale,
+                                                       orbm_projected_point *__restrict__ out, WinQuery *__restrict__ q)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i >= m) return;
+    orbm_projected_point o = {0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};
+    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
+    const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+    const float *R = cam.R;
+    const float PcX = (float)((double)(R[0] * P0 + R[1] * P1 + R[2] * P2) + (double)cam.t[0]);
+    const float PcY = (float)((double)(R[3] * P0 + R[4] * P1 + R[5] * P2) + (double)cam.t[1]);
+    const float PcZ = (float)((double)(R[6] * P0 + R[7] * P1 + R[8] * P2) + (double)cam.t[2]);
+    bool ok = !(PcZ < 0.0f);
+    float invz, u, v;
+    if (cam.mode == 0) {
+        invz = 1.0f / PcZ;                                  // Frame.cc:302-304
+        u = cam.fx * PcX * invz + cam.cx;
+        v = cam.fy * PcY * invz + cam.cy;
+        ok = ok && !(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y);
+    } else {
+        invz = cam.mode == 1 ? 1 / PcZ : (float)(1.0 / (double)PcZ);   // ORBmatcher.cc:1060 / :1222
+        const float x = PcX * invz, y = PcY * invz;
+        u = cam.fx * x + cam.cx;
+        v = cam.fy * y + cam.cy;
+        ok = ok && (u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y); // KeyFrame::IsInImage
+    }
+    const float ur = u - cam.mbf * invz;
+    const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i]; // MapPoint.cc:430-440
+    const float PO0 = P0 - cam.Ow[0], PO1 = P1 - cam.Ow[1], PO2 = P2 - cam.Ow[2];
+    const float dist = (float)sqrt((double)PO0 * (double)PO0 + (double)PO1 * (double)PO1 + (double)PO2 * (double)PO2);
+    const double dot = (double)PO0 * (double)nrm[3 * i] + (double)PO1 * (double)nrm[3 * i + 1] + (double)PO2 * (double)nrm[3 * i + 2];
+    float viewCos = 0.f;
+    if (cam.mode == 0) {
+        ok = ok && !((double)dist < 0.9 * (double)minDistance || (double)dist > (double)maxDistance / 0.9);
+        viewCos = (float)(dot / (double)dist);
+        ok = ok && !(viewCos < cam.cos_limit);
+    } else {
+        ok = ok && !(dist < minDistance || dist > maxDistance);
+        ok = ok && !(dot < 0.5 * (double)dist);
+    }
+    // PredictScale: ratio = mfMaxDistance / dist; ceil(log(ratio) / mfLogScaleFactor), clamped
+    const float ratio = maxd[i] / dist;
+    const float lg = (float)log((double)ratio);
+    int level = (int)ceilf(lg / cam.log_scale);
+    if (level < 0) level = 0; else if (level >= cam.nlevels) level = cam.nlevels - 1;
+    if (ok) {
+        o.u = u; o.v = v; o.ur = ur; o.view_cos = viewCos; o.dist = dist; o.level = level; o.visible = 1;
+        float r;
+        if (cam.mode == 0) {
+            r = (double)viewCos > 0.998 ? 3.0f : 4.5f;      // RadiusByViewingCos
+            if ((double)cam.th != 1.0) r *= cam.th;
+        } else {
+            r = cam.th;
+        }
+        w.u = u; w.v = v; w.r = r * scale[level]; w.xr = ur; w.min_level = level - 1; w.max_level = level;
+    }
+    out[i] = o;
+    if (q) q[i] = w;
+}
+
 __global__ __launch_bounds__(MT) void k_reloc_accept(const int *__restrict__ best, const int *__restrict__ bidx,
                                                      const int *__restrict__ second, const int *__restrict__ blevel,
                                                      const int *__restrict__ slevel, int m, int th_reloc, float nnratio,
@@ -851,6 +927,40 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
     memcpy(matched_mp, w.pin + (o_mk - o_res), sizeof(int) * n);
     if (nmatches) memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
     if (proj) memcpy(proj, w.pin + (o_proj - o_res), sizeof(float) * 4 * m);
+    return ORBX_OK;
+}
+
+int orbm_project_points(int mode, const float *mp_pos, const float *mp_normal, const float *mp_min_distance,
+                        const float *mp_max_distance, int m, const float *Rcw, const float *tcw, const float *Ow,
+                        const orbm_camera *cam, float mbf, float viewing_cos_limit, float log_scale_factor,
+                        const float *scale_factors, int nlevels, float th, orbm_projected_point *out, orbm_window_query *queries)
+{
+    if (mode < 0 || mode > 2 || m < 0 || nlevels < 1 || nlevels > 64 || !cam || !Rcw || !tcw || !Ow || !scale_factors || !out ||
+        (m && (!mp_pos || !mp_normal || !mp_min_distance || !mp_max_distance)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (m == 0) return ORBX_OK;
+    StagedCall sc;
+    const size_t o_pos = sc.in(mp_pos, sizeof(float) * 3 * m), o_nrm = sc.in(mp_normal, sizeof(float) * 3 * m),
+                 o_min = sc.in(mp_min_distance, sizeof(float) * m), o_max = sc.in(mp_max_distance, sizeof(float) * m),
+                 o_sc = sc.in(scale_factors, sizeof(float) * nlevels);
+    const size_t o_out = sc.out(sizeof(orbm_projected_point) * (size_t)m), o_q = sc.out(sizeof(WinQuery) * (size_t)m);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    ProjectCam pc;
+    pc.fx = cam->fx; pc.fy = cam->fy; pc.cx = cam->cx; pc.cy = cam->cy;
+    // Frame::isInFrustum compares with the grid bounds mnMinX..mnMaxY (static floats), KeyFrame::IsInImage likewise
+    pc.min_x = cam->grid_min_x; pc.max_x = cam->grid_max_x; pc.min_y = cam->grid_min_y; pc.max_y = cam->grid_max_y;
+    pc.mbf = mbf; pc.cos_limit = viewing_cos_limit; pc.log_scale = log_scale_factor; pc.th = th;
+    for (int i = 0; i < 9; ++i) pc.R[i] = Rcw[i];
+    for (int i = 0; i < 3; ++i) { pc.t[i] = tcw[i]; pc.Ow[i] = Ow[i]; }
+    pc.nlevels = nlevels; pc.mode = mode;
+    hipLaunchKernelGGL(k_project_points, dim3((m + MT - 1) / MT), dim3(MT), 0, sc.stream(), sc.d<const float>(o_pos),
+                       sc.d<const float>(o_nrm), sc.d<const float>(o_min), sc.d<const float>(o_max), m, pc, sc.d<const float>(o_sc),
+                       sc.d<orbm_projected_point>(o_out), sc.d<WinQuery>(o_q));
+    ORBX_HIP(hipGetLastError());
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    memcpy(out, sc.r<orbm_projected_point>(o_out), sizeof(orbm_projected_point) * (size_t)m);
+    if (queries) memcpy(queries, sc.r<WinQuery>(o_q), sizeof(WinQuery) * (size_t)m);
     return ORBX_OK;
 }
 

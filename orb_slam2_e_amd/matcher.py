@@ -281,6 +281,64 @@ class ORBmatcher:
                                                     self.TH_RELOC, _p(matched), C.byref(nm), _p(proj)))
         return matched, nm.value, proj
 
+    PROJ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("view_cos", "<f4"), ("dist", "<f4"), ("level", "<i4"),
+                           ("visible", "<i4")])
+    PROJECT_FRUSTUM, PROJECT_FUSE, PROJECT_FUSE_SIM3 = 0, 1, 2
+
+    def project_points(self, mode, mp_pos, mp_normal, mp_min_distance, mp_max_distance, Rcw, tcw, Ow, cam, mbf, log_scale_factor,
+                       scale_factors, th=1.0, viewing_cos_limit=0.5):
+        """orbm_project_points: Frame::isInFrustum + MapPoint::PredictScale (Frame.cc:284-340, MapPoint.cc:464-480;
+        mode PROJECT_FRUSTUM) or the projection block of ORBmatcher::Fuse (ORBmatcher.cc:1053-1094 / :1212-1250) for all
+        map points at once.  Returns (projected[PROJ_DTYPE], window queries[WQ_DTYPE])."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, nrm, mn, mx = f32(mp_pos), f32(mp_normal), f32(mp_min_distance), f32(mp_max_distance)
+        R, t, O = f32(Rcw).reshape(9), f32(tcw).reshape(3), f32(Ow).reshape(3)
+        cam = np.ascontiguousarray(cam, self.CAM_DTYPE).reshape(1)
+        sc = f32(scale_factors)
+        m = len(pos)
+        out = np.zeros(m, self.PROJ_DTYPE); q = np.zeros(m, self.WQ_DTYPE)
+        self._L.orbm_project_points.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] * 3 + \
+                                               [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_project_points(int(mode), _p(pos), _p(nrm), _p(mn), _p(mx), m, _p(R), _p(t), _p(O), _p(cam), float(mbf),
+                                          float(viewing_cos_limit), float(log_scale_factor), _p(sc), len(sc), float(th), _p(out), _p(q)))
+        return out, q
+
+    def Fuse(self, kps, desc, uright, bounds, inv_level_sigma2, vpMapPoints, mp_pos, mp_normal, mp_min_distance, mp_max_distance,
+             mp_desc, Rcw, tcw, Ow, cam, mbf, log_scale_factor, scale_factors, th, map_ops, sim3=False):
+        """ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) as a whole (ORBmatcher.cc:1026-1176; sim3=True: the
+        projection and candidate loop of the Sim3 form, :1178-1301, whose map update differs -- see fuse_replay):
+        projection of every listed map point and the gated candidate loop on the device, then the reference's loop tail
+        on the host in list order.  vpMapPoints[i] = map point handle or -1 (NULL entry); mp_* arrays are indexed by i.
+        map_ops: is_bad(h), is_in_keyframe(h), slot_owner(idx) -> handle or -1, observations(h), replace(dead, heir),
+        add(h, idx).  Returns nFused."""
+        mode = self.PROJECT_FUSE_SIM3 if sim3 else self.PROJECT_FUSE
+        proj, q = self.project_points(mode, mp_pos, mp_normal, mp_min_distance, mp_max_distance, Rcw, tcw, Ow, cam, mbf,
+                                      log_scale_factor, scale_factors, th)
+        best, idx = self.search_fuse(q, mp_desc, kps, desc, bounds, uright, None if sim3 else inv_level_sigma2)
+        return self.fuse_replay(vpMapPoints, proj["visible"], best, idx, map_ops)
+
+    def fuse_replay(self, vpMapPoints, visible, best, idx, map_ops):
+        """The tail of the Fuse loop (ORBmatcher.cc:1046-1053 skips, :1149-1170 update) in the list's order: the candidate
+        search of a point does not depend on the map state, the skips and the update do."""
+        nFused = 0
+        for i, h in enumerate(vpMapPoints):
+            if h < 0 or map_ops.is_bad(h) or map_ops.is_in_keyframe(h):
+                continue
+            if not visible[i] or idx[i] < 0:
+                continue
+            if best[i] <= self.TH_LOW:
+                other = map_ops.slot_owner(int(idx[i]))
+                if other >= 0:
+                    if not map_ops.is_bad(other):
+                        if map_ops.observations(other) > map_ops.observations(h):
+                            map_ops.replace(h, other)       # pMP->Replace(pMPinKF)
+                        else:
+                            map_ops.replace(other, h)       # pMPinKF->Replace(pMP)
+                else:
+                    map_ops.add(h, int(idx[i]))             # AddObservation + AddMapPoint
+                nFused += 1
+        return nFused
+
     @staticmethod
     def distinctive_descriptors(desc, off):
         """MapPoint::ComputeDistinctiveDescriptors for a batch (MapPoint.cc:305-370)."""

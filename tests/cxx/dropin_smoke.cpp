@@ -1,5 +1,6 @@
 // C++ host-side smoke test of include/orbslam_hip.hpp (built and run by
 // tests/test_cxx_host.py).  argv[1] = "nodevice": expect ORBX_ERR_NO_DEVICE.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -211,6 +212,70 @@ int main(int argc, char **argv)
             if (!dup && (word[4 * c] != 4 * c || node[4 * c] != 1 + c || w[4 * c] != 1.0 + 0.25 * 4 * c)) {
                 printf("FAIL descent of feature %d: word %d node %d\n", 4 * c, word[4 * c], node[4 * c]); return 1;
             }
+        }
+    }
+    {
+        // ProjectInFrustum + Fuse as a whole through the C++ composition: an identity camera pose looking down +z, one map
+        // point per keypoint placed on that keypoint's ray (so point i projects onto keypoint i and carries its descriptor);
+        // a toy pointer graph: even slots already hold an older point with more observations (pMP->Replace(pMPinKF)),
+        // every fourth of the odd ones a weaker one (pMPinKF->Replace(pMP)), the rest are free (AddObservation).
+        ORBmatcher::FrameView F;
+        F.mvKeysUn = kps.data(); F.mDescriptors = desc.data(); F.N = n;
+        F.mnMinX = 0.f; F.mnMinY = 0.f; F.mnMaxX = (float)W; F.mnMaxY = (float)H;
+        std::vector<float> sf(8), isg(8);
+        for (int l = 0; l < 8; ++l) { sf[l] = l ? sf[l - 1] * 1.2f : 1.0f; isg[l] = 1.0f / (sf[l] * sf[l]); }
+        ORBmatcher::PoseView P;
+        const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        memcpy(P.Rcw, I9, sizeof(I9));
+        for (int k = 0; k < 3; ++k) { P.tcw[k] = 0.f; P.Ow[k] = 0.f; }
+        P.cam.fx = P.cam.fy = 500.f; P.cam.cx = 320.f; P.cam.cy = 240.f;
+        P.cam.min_x = 0; P.cam.min_y = 0; P.cam.max_x = W; P.cam.max_y = H;
+        P.cam.grid_min_x = 0.f; P.cam.grid_min_y = 0.f; P.cam.grid_max_x = (float)W; P.cam.grid_max_y = (float)H;
+        P.mbf = 40.f; P.mfLogScaleFactor = logf(1.2f); P.mvScaleFactors = sf.data(); P.mvInvLevelSigma2 = isg.data(); P.mnScaleLevels = 8;
+        std::vector<float> pos(3 * n), nrm(3 * n), mind(n), maxd(n);
+        for (int i = 0; i < n; ++i) {
+            const float z = 4.0f, x = (kps[i].x - 320.f) / 500.f * z, y = (kps[i].y - 240.f) / 500.f * z;
+            pos[3 * i] = x; pos[3 * i + 1] = y; pos[3 * i + 2] = z;
+            const float d = sqrtf(x * x + y * y + z * z);
+            nrm[3 * i] = x / d; nrm[3 * i + 1] = y / d; nrm[3 * i + 2] = z / d;    // PO.Pn = dist >= 0.5 dist
+            maxd[i] = d * powf(1.2f, (float)kps[i].octave) * 0.9999f;              // PredictScale = ceil(log(ratio) / log 1.2) -> the keypoint's octave
+            mind[i] = maxd[i] / 5.0f;
+        }
+        ORBmatcher::MapPointArrays mps;
+        mps.pos = pos.data(); mps.normal = nrm.data(); mps.mfMinDistance = mind.data(); mps.mfMaxDistance = maxd.data();
+        mps.descriptors = desc.data(); mps.n = n;
+        ORBmatcher mf(0.6f, true);
+        std::vector<orbm_projected_point> proj;
+        std::vector<orbm_window_query> win;
+        if (mf.ProjectInFrustum(P, mps, 0.5f, 1.0f, proj, win) != ORBX_OK) { printf("FAIL ProjectInFrustum %d\n", mf.status()); return 1; }
+        int vis = 0, lev = 0;
+        for (int i = 0; i < n; ++i) {
+            vis += proj[i].visible;
+            lev += proj[i].visible && proj[i].level == kps[i].octave && fabsf(proj[i].u - kps[i].x) < 1e-2f && fabsf(proj[i].v - kps[i].y) < 1e-2f;
+        }
+        if (vis < n * 9 / 10 || lev < vis * 9 / 10) { printf("FAIL ProjectInFrustum visible %d level/pixel ok %d of %d\n", vis, lev, n); return 1; }
+        struct Toy {
+            int n;
+            std::vector<int> slot, obs, inKF; std::vector<char> bad;     // handles: 0..n-1 listed points, n..2n-1 the key frame's own
+            int adds = 0, dies = 0, takes = 0;
+            typedef int H;
+            H at(int i) const { return i; }
+            bool null(H h) const { return h < 0; }
+            bool isBad(H h) const { return bad[h] != 0; }
+            bool isInKeyFrame(H h) const { return inKF[h] >= 0; }
+            H slotOwner(int idx) const { return slot[idx]; }
+            int observations(H h) const { return obs[h]; }
+            void replace(H dead, H heir) { bad[dead] = 1; if (inKF[dead] >= 0) { slot[inKF[dead]] = heir; inKF[heir] = inKF[dead]; inKF[dead] = -1; ++takes; } else ++dies; }
+            void add(H h, int idx) { slot[idx] = h; inKF[h] = idx; ++adds; }
+        } toy;
+        toy.n = n; toy.slot.assign(n, -1); toy.obs.assign(2 * n, 2); toy.inKF.assign(2 * n, -1); toy.bad.assign(2 * n, 0);
+        for (int j = 0; j < n; ++j) {
+            if (j % 2 == 0) { toy.slot[j] = n + j; toy.inKF[n + j] = j; toy.obs[n + j] = 5; }
+            else if (j % 4 == 1) { toy.slot[j] = n + j; toy.inKF[n + j] = j; toy.obs[n + j] = 1; }
+        }
+        const int nFused = mf.Fuse(F, P, mps, 3.0f, toy);
+        if (mf.status() != ORBX_OK || nFused < vis * 8 / 10 || nFused != toy.adds + toy.dies + toy.takes || toy.adds == 0 || toy.dies == 0 || toy.takes == 0) {
+            printf("FAIL Fuse %d: nFused %d adds %d dies %d takes %d\n", mf.status(), nFused, toy.adds, toy.dies, toy.takes); return 1;
         }
     }
     printf("OK %d keypoints, %d self matches, %d stereo matches, sE=%g\n", n, nm, nst, sE);
