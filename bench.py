@@ -102,14 +102,26 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
             dist.barrier()
             torch.cuda.synchronize()
 
+    from orb_slam2_e_amd.fem import FEA2Batch
+    from orb_slam2_e_amd.synth import synth_tet_batch_distinct
     out = {}
-    for label, nm in (("single", 1), ("batch", nmesh)):
-        nodes, tets, fixed, load = synth_tet_batch(nm, 12, seed=11 + 7919 * rank)
-        fea = FEA2(nodes, tets, FEM_TET4)
+    for label, nm in (("single", 1), ("batch", nmesh), ("batch_distinct_topologies", nmesh)):
+        t0 = time.perf_counter()
+        if label == "batch_distinct_topologies":
+            # every mesh its own topology and size (grids of 10..14 cells per side: 6,591 dofs on average), as the reference
+            # builds a new mesh on every call; one block-diagonal system in global numbering
+            nodes_l, tets_l, fixed_l, load_l = synth_tet_batch_distinct(nm, seed=11 + 7919 * rank)
+            fea = FEA2Batch(nodes_l, tets_l, FEM_TET4)
+            fixed = np.concatenate([fea.dof0[k] + fx for k, fx in enumerate(fixed_l)]).astype(np.int32)
+            b = np.concatenate(load_l)[None].copy(); b[:, fixed] = 0
+        else:
+            nodes, tets, fixed, load = synth_tet_batch(nm, 12, seed=11 + 7919 * rank)
+            fea = FEA2(nodes, tets, FEM_TET4)
+            b = np.tile(load, (nm, 1)); b[:, fixed] = 0
+        t_create = time.perf_counter() - t0
         fea.profile(True)
         t0 = time.perf_counter(); fea.MatrixAssembly(); t_asm = time.perf_counter() - t0
         fea.eliminate_dofs(fixed)
-        b = np.tile(load, (nm, 1)); b[:, fixed] = 0
         fea.cg_setup(b)
         fea.profile(True)
         fea.cg_iterate(20); fea.cg_result()           # warm + per-kernel split (untimed pass, all kinds)
@@ -125,10 +137,15 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         dt = max_over_ranks(time.perf_counter() - t0, world, cdev)
         prof = fea.profile_read()
         n, nnz = fea.Ksize, fea.nnz
+        distinct = label == "batch_distinct_topologies"
         spmv_ms = prof["k_fem_spmv"][0] / max(prof["k_fem_spmv"][1], 1) if prof["k_fem_spmv"][1] else split.get("k_fem_spmv", 0.0)
-        spmv_bytes = nm * (nnz * 8 + (n + 1) * 4 + 2 * n * 8)      # nnz(val+4)+(n+1)4+2n*val', f32 K, f64 x/y
-        iter_bytes = spmv_bytes + nm * (2 * 2 + 3 * 3) * n * 8
-        out[label] = {"meshes_per_gpu": nm, "n_dof": n, "nnz": nnz, "cg_iters": iters,
+        nblocks = 1 if distinct else nm                             # Ksize / nnz are totals for the concatenated batch
+        spmv_bytes = nblocks * (nnz * 8 + (n + 1) * 4 + 2 * n * 8)  # nnz(val+4)+(n+1)4+2n*val', f32 K, f64 x/y
+        iter_bytes = spmv_bytes + nblocks * (2 * 2 + 3 * 3) * n * 8
+        spb = 32 if nblocks * ((n + 63) // 64) < 512 and not distinct else 64
+        grid_threads = 256 * (sum((int(fea.dof0[k + 1] - fea.dof0[k]) + 63) // 64 for k in range(nm)) if distinct else nm * ((n + spb - 1) // spb))
+        out[label] = {"meshes_per_gpu": nm, "n_dof": n, "nnz": nnz, "cg_iters": iters, "create_ms": t_create * 1e3,
+                      "spmv_grid_threads": grid_threads,
                       "cg_mesh_iters_per_s": world * nm * iters / dt, "ms_per_iter": dt / iters * 1e3,
                       "assemble_ms": t_asm * 1e3, "relres_after": float(rel.max()),
                       "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes,
@@ -147,18 +164,23 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
             if csr_out:
                 np.savez(csr_out, rp=rp, col=col, val=val, b=b[0])
         del fea
-    bt = out["batch"]
-    out["roofline"] = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None,
-                       "avg_launch_ms": bt["spmv_avg_launch_ms"], "alg_bytes_per_launch": bt["spmv_alg_bytes_per_launch"]}
-    tr = load_traffic().get("k_fem_spmv") if nmesh == 256 else None     # PMC passes were taken on the 256-mesh batch
-    if tr:
-        out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-        out["roofline"]["traffic_source"] = tr["source"]
-        if bt["spmv_avg_launch_ms"] > 0:
-            # what HBM really delivers: the shared column-index array is served from L2, so the counter traffic is below
-            # SURVEY's algorithmic bytes; this is the honest HBM fraction of the same launch
-            out["roofline"]["frac_of_counter_traffic"] = tr["hbm_bytes_per_launch"] / (bt["spmv_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    traffic = load_traffic()
+    for key, label in (("roofline", "batch"), ("roofline_distinct_topologies", "batch_distinct_topologies")):
+        bt = out[label]
+        rf = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None,
+              "avg_launch_ms": bt["spmv_avg_launch_ms"], "alg_bytes_per_launch": bt["spmv_alg_bytes_per_launch"],
+              "batch": "one topology shared by all meshes (one column-index array, L2-resident)" if label == "batch" else
+                       "every mesh its own topology (its own column indices, streamed from HBM)"}
+        tr = traffic.get(f"k_fem_spmv@{bt['spmv_grid_threads']}") if nmesh == 256 else None   # PMC passes: the 256-mesh batches
+        if tr:
+            rf["traffic"] = tr["hbm_bytes_per_launch"]
+            rf["traffic_source"] = tr["source"]
+            if bt["spmv_avg_launch_ms"] > 0:
+                # what HBM really delivers (FETCH_SIZE x 2 + WRITE_SIZE of the PMC passes): with a shared topology the
+                # index array is served from L2, so the counter traffic is below SURVEY's algorithmic bytes
+                rf["frac_of_counter_traffic"] = tr["hbm_bytes_per_launch"] / (bt["spmv_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out[key] = rf
     return out
 
 

@@ -12,9 +12,17 @@
  * arrays.  Same conventions as orbslam_hip.h (int status, host pointers unless
  * named *_dev, no CPU fallback).
  *
- * A fem_model holds `nmesh` independent meshes that share one topology (element
- * connectivity) but have their own node coordinates, hence their own matrices:
- * the batch is one block-diagonal CSR matrix resident in HBM.
+ * A fem_model holds a batch of independent meshes as one block-diagonal CSR matrix
+ * resident in HBM, in one of two layouts:
+ *   fem_create        `nmesh` meshes that share one topology (element connectivity) but have
+ *                     their own node coordinates, hence their own matrices; ONE column-index /
+ *                     row-pointer array serves all of them.  Arrays are [nmesh][ndof].
+ *   fem_create_batch  meshes of different sizes and topologies -- the reference builds a new
+ *                     mesh on every call (src/Optimizer.cc:480, FEA2.cc:80-121) -- concatenated:
+ *                     node, element, dof and non-zero numbers are global over the batch (mesh k
+ *                     starts at the offsets fem_batch_offsets returns), vectors are one array of
+ *                     all dofs, Dirichlet ids / dofs are global numbers; per-mesh results (strain
+ *                     energy, CG residuals) come back one per mesh.
  */
 #ifndef FEM_HIP_H
 #define FEM_HIP_H
@@ -42,6 +50,16 @@ int fem_second_layer(const float *top, int ntop, float h, float *nodes_out);
  * E is unsigned as in FEA2.h:236.  Builds the CSR pattern on the host once. */
 int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t *elems, int ne,
                unsigned int E, float nu, float fg, fem_model **out);
+/* A batch of meshes with their own topologies: mesh k has mesh_nn[k] nodes and mesh_ne[k] elements;
+ * nodes[sum nn][3] and elems[sum ne][npe] are the meshes one after the other, element node ids local
+ * to their mesh.  fem_sizes then returns the number of meshes and the TOTAL dofs / non-zeros;
+ * fem_get_ke / fem_get_csr address a mesh's own elements, rows and columns.  The LM hook
+ * (fem_trial_*) is per single mesh and not available on such a model. */
+int fem_create_batch(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const float *nodes,
+                     const int32_t *elems, unsigned int E, float nu, float fg, fem_model **out);
+/* First node / element / non-zero of every mesh in the batch numbering, [nmesh + 1] each (any may be NULL);
+ * dof offset = 3 * node offset. */
+int fem_batch_offsets(const fem_model *m, int32_t *node0, int32_t *elem0, int32_t *nnz0);
 int fem_destroy(fem_model *m);
 
 /* Sizes: meshes, dofs per mesh (Ksize = 3*nn), scalar non-zeros per mesh. */

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -234,18 +235,20 @@ __device__ __forceinline__ double chunk_sum(const double *__restrict__ part, int
 
 // sE = |a^T f|, nsE = sE / int(Ksize/3): one block per mesh.
 __global__ __launch_bounds__(256) void k_fem_energy(const float *__restrict__ a, const float *__restrict__ f, int ndof,
-                                                    float *__restrict__ sE, float *__restrict__ nsE)
+                                                    float *__restrict__ sE, float *__restrict__ nsE, const int4 *__restrict__ minfo)
 {
     __shared__ double sh[4];
     const int mesh = blockIdx.x;
+    const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
+    const int nrows = minfo ? minfo[mesh].y : ndof;
     double s = 0;
-    for (int i = threadIdx.x; i < ndof; i += 256) s += (double)a[(size_t)mesh * ndof + i] * (double)f[(size_t)mesh * ndof + i];
+    for (int i = threadIdx.x; i < nrows; i += 256) s += (double)a[row0 + i] * (double)f[row0 + i];
     s = block_sum(s, sh);
     if (threadIdx.x == 0) {
         float e = (float)s;
         if (e < 0.0f) e = -e;
         if (sE) sE[mesh] = e;
-        if (nsE) nsE[mesh] = e / (float)(ndof / 3);
+        if (nsE) nsE[mesh] = e / (float)(nrows / 3);
     }
 }
 
@@ -302,21 +305,48 @@ __global__ void k_fem_trial_a(const float *__restrict__ top, const float *__rest
 // ------------------------------------------------------------------------ CG
 struct CgScal { double rz[2]; double bb; double rr; };
 
+// Two batch layouts.  Uniform (fem_create): nmesh meshes of one topology, mesh = blockIdx.y, chunk = blockIdx.x.
+// Segmented (fem_create_batch): meshes of different sizes and topologies concatenated into ONE block-diagonal
+// system (global row / column / non-zero numbering); a chunk never crosses a mesh, chunk -> mesh comes from
+// cmesh[], a mesh's row range and chunk range from minfo[mesh] = {row0, nrows, chunk0, nchunks}.  cmesh == nullptr
+// selects the uniform layout.
+struct Seg {
+    int mesh, chunk; // mesh (= index of its CgScal), chunk inside the mesh
+    int row0, nrows; // the mesh's rows in the batch vectors
+    int tab0;        // index of the mesh's first row in rowptr / diag_idx (0 in the uniform layout: shared tables)
+    int part0, nparts; // the mesh's slots in a per-chunk partial array
+    size_t voff;     // offset of the mesh's values (0 when segmented: global non-zero numbering)
+};
+__device__ __forceinline__ Seg seg_of(const int *__restrict__ cmesh, const int4 *__restrict__ minfo, int ndof, int nchunk, size_t nnz)
+{
+    Seg s;
+    if (cmesh) {
+        s.mesh = cmesh[blockIdx.x];
+        const int4 mi = minfo[s.mesh];
+        s.row0 = mi.x; s.nrows = mi.y; s.chunk = (int)blockIdx.x - mi.z; s.part0 = mi.z; s.nparts = mi.w; s.tab0 = mi.x; s.voff = 0;
+    } else {
+        s.mesh = blockIdx.y; s.chunk = blockIdx.x;
+        s.row0 = s.mesh * ndof; s.nrows = ndof; s.tab0 = 0; s.part0 = s.mesh * nchunk; s.nparts = nchunk; s.voff = (size_t)s.mesh * nnz;
+    }
+    return s;
+}
+
 // x = 0, r = b, p = z = r/diag; partial r.z and b.b per chunk.
 __global__ __launch_bounds__(CGT) void k_fem_cg_init(const float *__restrict__ vals, const int *__restrict__ diag_idx,
                                                      size_t nnz, int ndof, int nchunk, const double *__restrict__ b,
                                                      double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                      double *__restrict__ dinv, double *__restrict__ part_a,
-                                                     double *__restrict__ part_b)
+                                                     double *__restrict__ part_b, const int *__restrict__ cmesh,
+                                                     const int4 *__restrict__ minfo)
 {
     __shared__ double sh[CGT / 64];
-    const int mesh = blockIdx.y, chunk = blockIdx.x;
+    const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, nnz);
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < RPB; i += CGT) {
-        const int row = chunk * RPB + i;
-        if (row < ndof) {
-            const size_t g = (size_t)mesh * ndof + row;
-            const double d = (double)vals[(size_t)mesh * nnz + diag_idx[row]];
+        const int row = sg.chunk * RPB + i;
+        if (row < sg.nrows) {
+            const size_t g = (size_t)sg.row0 + row;
+            const double d = (double)vals[sg.voff + diag_idx[sg.tab0 + row]];
             const double di = 1.0 / d, bi = b[g];
             dinv[g] = di; x[g] = 0; r[g] = bi; p[g] = bi * di;
             s1 += bi * (bi * di); s2 += bi * bi;
@@ -324,13 +354,15 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_init(const float *__restrict__ v
     }
     s1 = block_sum(s1, sh);
     s2 = block_sum(s2, sh);
-    if (threadIdx.x == 0) { part_a[mesh * nchunk + chunk] = s1; part_b[mesh * nchunk + chunk] = s2; }
+    if (threadIdx.x == 0) { part_a[sg.part0 + sg.chunk] = s1; part_b[sg.part0 + sg.chunk] = s2; }
 }
-__global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, const double *__restrict__ part_b, CgScal *__restrict__ sc)
+__global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, const double *__restrict__ part_b, CgScal *__restrict__ sc,
+                               const int4 *__restrict__ minfo)
 {
     const int mesh = blockIdx.x;
+    const int p0 = minfo ? minfo[mesh].z : mesh * nchunk, np = minfo ? minfo[mesh].w : nchunk;
     double a = 0, b = 0;
-    for (int c = 0; c < nchunk; ++c) { a += part_a[mesh * nchunk + c]; b += part_b[mesh * nchunk + c]; }
+    for (int c = 0; c < np; ++c) { a += part_a[p0 + c]; b += part_b[p0 + c]; }
     sc[mesh].rz[0] = a; sc[mesh].rz[1] = a; sc[mesh].bb = b; sc[mesh].rr = b;
 }
 
@@ -355,16 +387,21 @@ template <int SPB>
 __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ lcol,
                                                   const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
-                                                  double *__restrict__ part_pAp)
+                                                  double *__restrict__ part_pAp, const int *__restrict__ cmesh,
+                                                  const int4 *__restrict__ minfo)
 {
     extern __shared__ __align__(16) double prod[];
     __shared__ double sh[CGT / 64];
-    const int mesh = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int r0 = chunk * SPB, r1 = min(r0 + SPB, ndof);
+    const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, nnz);
+    const int tid = threadIdx.x;
+    const int r0 = sg.tab0 + sg.chunk * SPB, r1 = min(r0 + SPB, sg.tab0 + sg.nrows); // rows as rowptr numbers them
     const int k0 = rowptr[r0], k1 = rowptr[r1];
-    const float *v = vals + (size_t)mesh * nnz;
-    const int *cidx = lcol; // one column-index array for all meshes (shared topology): it stays in L2, HBM streams the values only
-    const double *pm = p + (size_t)mesh * ndof;
+    const float *v = vals + sg.voff;
+    // uniform layout: one column-index array for all meshes (shared topology): it stays in L2, HBM streams the values only;
+    // segmented layout: every mesh has its own (global) column indices, streamed from HBM beside the values
+    const int *cidx = lcol;
+    const size_t vbase = (size_t)sg.row0 - sg.tab0;   // batch-vector index of rowptr's row 0: mesh * ndof, or 0
+    const double *pm = p + vbase;
     // aligned 16-byte streams: start at ka = k0 rounded down to a multiple of 4 (the per-mesh stride is a multiple of
     // 4).  No per-element predicate: every quad is loaded, gathered, multiplied and parked at prod[k - ka]; the up to 3
     // entries before k0 and after k1 are neighbours' non-zeros (valid columns; the padding tail of lcol is zeroed) whose
@@ -403,13 +440,13 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
         s += dpp_shl_f64<2>(s);
         s += dpp_shl_f64<1>(s);
         if (row < r1 && sl == 0) {
-            const size_t g = (size_t)mesh * ndof + row;
+            const size_t g = vbase + row;
             Ap[g] = s;
             acc += p[g] * s;
         }
     }
     acc = block_sum(acc, sh);
-    if (tid == 0) part_pAp[mesh * nchunk + chunk] = acc;
+    if (tid == 0) part_pAp[sg.part0 + sg.chunk] = acc;
 }
 
 // alpha = rz/pAp; x += alpha p; r -= alpha Ap; partial r.(r/diag) and r.r.
@@ -417,17 +454,20 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int
                                                        const double *__restrict__ part_pAp, const double *__restrict__ p,
                                                        const double *__restrict__ Ap, const double *__restrict__ dinv,
                                                        double *__restrict__ x, double *__restrict__ r,
-                                                       double *__restrict__ part_rz, double *__restrict__ part_rr)
+                                                       double *__restrict__ part_rz, double *__restrict__ part_rr,
+                                                       const int *__restrict__ cmesh, const int4 *__restrict__ minfo,
+                                                       const int4 *__restrict__ minfo_s)
 {
     __shared__ double sh[CGT / 64];
-    const int mesh = blockIdx.y, chunk = blockIdx.x;
-    const double pAp = chunk_sum(part_pAp + (size_t)mesh * nchunk_s, nchunk_s);
-    const double alpha = sc[mesh].rz[cur] / pAp;
+    const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, 0);
+    const int sp0 = minfo_s ? minfo_s[sg.mesh].z : sg.mesh * nchunk_s, snp = minfo_s ? minfo_s[sg.mesh].w : nchunk_s;
+    const double pAp = chunk_sum(part_pAp + sp0, snp);
+    const double alpha = sc[sg.mesh].rz[cur] / pAp;
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < RPB; i += CGT) {
-        const int row = chunk * RPB + i;
-        if (row < ndof) {
-            const size_t g = (size_t)mesh * ndof + row;
+        const int row = sg.chunk * RPB + i;
+        if (row < sg.nrows) {
+            const size_t g = (size_t)sg.row0 + row;
             x[g] += alpha * p[g];
             const double ri = r[g] - alpha * Ap[g];
             r[g] = ri;
@@ -437,26 +477,27 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int
     }
     s1 = block_sum(s1, sh);
     s2 = block_sum(s2, sh);
-    if (threadIdx.x == 0) { part_rz[mesh * nchunk + chunk] = s1; part_rr[mesh * nchunk + chunk] = s2; }
+    if (threadIdx.x == 0) { part_rz[sg.part0 + sg.chunk] = s1; part_rr[sg.part0 + sg.chunk] = s2; }
 }
 
 // beta = rz_new/rz; p = r/diag + beta p; chunk 0 publishes rz_new for the next iteration.
 __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cur, CgScal *__restrict__ sc,
                                                     const double *__restrict__ part_rz, const double *__restrict__ part_rr,
                                                     const double *__restrict__ r, const double *__restrict__ dinv,
-                                                    double *__restrict__ p)
+                                                    double *__restrict__ p, const int *__restrict__ cmesh,
+                                                    const int4 *__restrict__ minfo)
 {
-    const int mesh = blockIdx.y, chunk = blockIdx.x;
-    const double rz2 = chunk_sum(part_rz + (size_t)mesh * nchunk, nchunk), rr = chunk_sum(part_rr + (size_t)mesh * nchunk, nchunk);
-    const double beta = rz2 / sc[mesh].rz[cur];
+    const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, 0);
+    const double rz2 = chunk_sum(part_rz + sg.part0, sg.nparts), rr = chunk_sum(part_rr + sg.part0, sg.nparts);
+    const double beta = rz2 / sc[sg.mesh].rz[cur];
     for (int i = threadIdx.x; i < RPB; i += CGT) {
-        const int row = chunk * RPB + i;
-        if (row < ndof) {
-            const size_t g = (size_t)mesh * ndof + row;
+        const int row = sg.chunk * RPB + i;
+        if (row < sg.nrows) {
+            const size_t g = (size_t)sg.row0 + row;
             p[g] = r[g] * dinv[g] + beta * p[g];
         }
     }
-    if (chunk == 0 && threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
+    if (sg.chunk == 0 && threadIdx.x == 0) { sc[sg.mesh].rz[cur ^ 1] = rz2; sc[sg.mesh].rr = rr; }
 }
 
 // FEA2 is a stack object per PoseOptimizationNR call (Optimizer.cc:480): a model is created and destroyed every
@@ -526,6 +567,13 @@ struct fem_model {
     float nu, fg, lambda, G;
     FemConst fc;
     std::vector<int> h_rowptr, h_lcol, h_diag;
+    // segmented layout (fem_create_batch): nseg meshes of their own sizes concatenated; nmesh == 1 then and nn / ne / ndof /
+    // nnz are the totals.  Uniform layout: nseg == nmesh, no tables.
+    int nseg = 0, nchunk_tot = 0, nchunk_s_tot = 0;
+    std::vector<int> seg_node0, seg_elem0, seg_nnz0; // [nseg + 1]
+    int *d_cmesh = nullptr, *d_cmesh_s = nullptr;
+    int4 *d_minfo = nullptr, *d_minfo_s = nullptr;
+    bool segmented() const { return d_cmesh != nullptr; }
     bool assembled = false, cg_ready = false, trial_ready = false;
     int tr_npoints = 0, tr_nder = 0, tr_nids = 0, tr_seq = 0;
     float tr_klarge = 0.f;
@@ -555,7 +603,7 @@ void fem_free(fem_model *m)
     void *ptrs[] = {m->d_nodes, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_elems, m->d_blk_row, m->d_bptr,
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids};
+                    m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -567,39 +615,203 @@ void fem_free(fem_model *m)
 int ensure_vecs(fem_model *m)
 {
     const size_t N = (size_t)m->nmesh * m->ndof;
-    if (!m->d_a && (dalloc(&m->d_a, N) || dalloc(&m->d_f, N) || dalloc(&m->d_u, N) || dalloc(&m->d_e, 2 * (size_t)m->nmesh)))
+    if (!m->d_a && (dalloc(&m->d_a, N) || dalloc(&m->d_f, N) || dalloc(&m->d_u, N) || dalloc(&m->d_e, 2 * (size_t)m->nseg)))
         return -1;
     return 0;
 }
 
 int ensure_cg(fem_model *m)
 {
-    const size_t N = (size_t)m->nmesh * m->ndof, C = (size_t)m->nmesh * (m->nchunk > m->nchunk_s ? m->nchunk : m->nchunk_s);
+    const size_t N = (size_t)m->nmesh * m->ndof, C = (size_t)std::max(m->nchunk_tot, m->nchunk_s_tot);
     if (m->d_b) return 0;
     if (dalloc(&m->d_b, N) || dalloc(&m->d_x, N) || dalloc(&m->d_r, N) || dalloc(&m->d_p, N) || dalloc(&m->d_Ap, N) ||
         dalloc(&m->d_dinv, N) || dalloc(&m->d_part[0], C) || dalloc(&m->d_part[1], C) || dalloc(&m->d_part[2], C) ||
-        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nmesh))
+        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nseg))
         return -1;
     return 0;
 }
 
+// grids: uniform (chunks of one mesh, meshes) / segmented (all chunks, 1)
+inline dim3 grid_cg(const fem_model *m) { return m->segmented() ? dim3(m->nchunk_tot) : dim3(m->nchunk, m->nmesh); }
+inline dim3 grid_spmv(const fem_model *m) { return m->segmented() ? dim3(m->nchunk_s_tot) : dim3(m->nchunk_s, m->nmesh); }
+
+void launch_spmv(fem_model *m, hipStream_t st)
+{
+    hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, grid_spmv(m), dim3(CGT), m->spmv_lds, st,
+                       m->d_vals, m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
+                       (const int *)m->d_cmesh_s, (const int4 *)m->d_minfo_s);
+}
+
 void launch_iter(fem_model *m, hipStream_t st)
 {
-    const dim3 g(m->nchunk, m->nmesh);
+    const dim3 g = grid_cg(m);
     const int cur = m->cg_it & 1;
     m->prof.start(2, st);
-    hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st,
-                       m->d_vals, m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
+    launch_spmv(m, st);
     m->prof.stop(2, st);
     m->prof.start(3, st);
     hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
-                       m->d_Ap, m->d_dinv, m->d_x, m->d_r, m->d_part[1], m->d_part[2]);
+                       m->d_Ap, m->d_dinv, m->d_x, m->d_r, m->d_part[1], m->d_part[2], (const int *)m->d_cmesh,
+                       (const int4 *)m->d_minfo, (const int4 *)m->d_minfo_s);
     m->prof.stop(3, st);
     m->prof.start(4, st);
     hipLaunchKernelGGL(k_fem_cg_dir, g, dim3(CGT), 0, st, m->ndof, m->nchunk, cur, m->d_sc, m->d_part[1], m->d_part[2],
-                       m->d_r, m->d_dinv, m->d_p);
+                       m->d_r, m->d_dinv, m->d_p, (const int *)m->d_cmesh, (const int4 *)m->d_minfo);
     m->prof.stop(4, st);
     m->cg_it++;
+}
+
+// Symbolic phase of one mesh (host, once per topology): block pattern, contribution lists, CSR pattern.
+struct Symbolic {
+    std::vector<int> bptr, bcol, blk_row, cptr, contrib, rowptr, lcol, diag;
+    int nblk = 0;
+};
+void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
+{
+    std::vector<std::vector<int>> adj(nn);
+    for (int i = 0; i < nn; ++i) adj[i].push_back(i);
+    for (int e = 0; e < ne; ++e)
+        for (int a = 0; a < npe; ++a)
+            for (int b = 0; b < npe; ++b) adj[elems[e * npe + a]].push_back(elems[e * npe + b]);
+    y.bptr.assign(nn + 1, 0); y.bcol.clear(); y.blk_row.clear();
+    for (int i = 0; i < nn; ++i) {
+        std::sort(adj[i].begin(), adj[i].end());
+        adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+        y.bptr[i + 1] = y.bptr[i] + (int)adj[i].size();
+        for (int j : adj[i]) { y.bcol.push_back(j); y.blk_row.push_back(i); }
+    }
+    const int nblk = y.nblk = (int)y.bcol.size();
+    y.cptr.assign(nblk + 1, 0);
+    auto blk_of = [&](int I, int J) {
+        return y.bptr[I] + (int)(std::lower_bound(adj[I].begin(), adj[I].end(), J) - adj[I].begin());
+    };
+    for (int e = 0; e < ne; ++e)
+        for (int a = 0; a < npe; ++a)
+            for (int b = 0; b < npe; ++b) y.cptr[blk_of(elems[e * npe + a], elems[e * npe + b]) + 1]++;
+    for (int b = 0; b < nblk; ++b) y.cptr[b + 1] += y.cptr[b];
+    y.contrib.assign(y.cptr[nblk], 0);
+    std::vector<int> fill(y.cptr.begin(), y.cptr.end() - 1);
+    for (int e = 0; e < ne; ++e) // ascending (e, li, lj) inside every block = the reference's scatter order
+        for (int a = 0; a < npe; ++a)
+            for (int b = 0; b < npe; ++b) y.contrib[fill[blk_of(elems[e * npe + a], elems[e * npe + b])]++] = (e << 6) | (a << 3) | b;
+    const int ndof = 3 * nn;
+    y.rowptr.assign(ndof + 1, 0);
+    y.lcol.assign((size_t)9 * nblk, 0);
+    y.diag.assign(ndof, 0);
+    for (int I = 0; I < nn; ++I) {
+        const int nb = y.bptr[I + 1] - y.bptr[I];
+        for (int r = 0; r < 3; ++r) {
+            const int row = 3 * I + r, start = 9 * y.bptr[I] + r * 3 * nb;
+            y.rowptr[row] = start;
+            for (int jb = 0; jb < nb; ++jb)
+                for (int c = 0; c < 3; ++c) {
+                    const int col = 3 * y.bcol[y.bptr[I] + jb] + c;
+                    y.lcol[start + 3 * jb + c] = col;
+                    if (col == row) y.diag[row] = start + 3 * jb + c;
+                }
+        }
+    }
+    y.rowptr[ndof] = 9 * nblk;
+}
+
+// The rest of model construction: material constants, chunking, device arrays.  seg_nn == nullptr: uniform layout
+// (nmesh meshes of nn nodes sharing `y`); else the segmented layout over nseg meshes whose symbolic data `y` already
+// holds concatenated in global numbering (nmesh == 1, nn / ne = totals).
+int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, const int32_t *elems, int ne, unsigned int E, float nu,
+                 float fg, Symbolic &y, int nseg, const int *seg_nn, const int *seg_ne, fem_model **out)
+{
+    fem_model *m = new fem_model();
+    m->eltype = eltype; m->npe = npe; m->nd = 3 * npe; m->nmesh = nmesh; m->nn = nn; m->ne = ne; m->ndof = 3 * nn;
+    m->nseg = seg_nn ? nseg : nmesh;
+    m->E = E; m->nu = nu; m->fg = fg;
+    // FEA2::FEA2, FEA2.cc:53-72 (float arithmetic, E unsigned)
+    m->lambda = (nu * E) / ((1 + nu) * (1 - 2 * nu));
+    m->G = E / (2 * (1 + nu));
+    for (int i = 0; i < 36; ++i) m->fc.D[i] = 0.0f;
+    m->fc.D[0] = m->fc.D[7] = m->fc.D[14] = m->lambda + 2 * m->G;
+    m->fc.D[1] = m->fc.D[2] = m->fc.D[6] = m->fc.D[8] = m->fc.D[12] = m->fc.D[13] = m->lambda;
+    m->fc.D[21] = m->fc.D[28] = m->fc.D[35] = m->G;
+    static const int sg[8][3] = {{-1, -1, -1}, {+1, -1, -1}, {+1, +1, -1}, {-1, +1, -1}, {-1, -1, +1}, {+1, -1, +1}, {+1, +1, +1}, {-1, +1, +1}};
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 3; ++j) m->fc.gs[3 * i + j] = sg[i][j] < 0 ? -fg : +fg;
+
+    const int nblk = m->nblk = y.nblk;
+    m->nnz = (size_t)9 * nblk;
+    m->nnzs = (m->nnz + 3) & ~(size_t)3;
+    m->h_rowptr.swap(y.rowptr); m->h_lcol.swap(y.lcol); m->h_diag.swap(y.diag);
+    // chunking: CG vector kernels RPB rows per workgroup, SpMV SPB rows; a chunk never crosses a mesh
+    std::vector<int> cmesh, cmesh_s;
+    std::vector<int4> minfo, minfo_s;
+    size_t rows_of_blocks = 0;
+    if (seg_nn) for (int k = 0; k < nseg; ++k) rows_of_blocks += (size_t)(3 * seg_nn[k] + 63) / 64;
+    else rows_of_blocks = (size_t)nmesh * ((m->ndof + 63) / 64);
+    m->spb = rows_of_blocks < 512 ? 32 : 64;
+    const int SPB = m->spb;
+    m->nchunk = (m->ndof + RPB - 1) / RPB;
+    m->nchunk_s = (m->ndof + SPB - 1) / SPB;
+    m->nchunk_tot = m->nchunk * nmesh; m->nchunk_s_tot = m->nchunk_s * nmesh;
+    int maxrun = 0;
+    auto scan_runs = [&](int row0, int nrows) {
+        for (int r0 = row0; r0 < row0 + nrows; r0 += SPB) {
+            const int r1 = r0 + SPB < row0 + nrows ? r0 + SPB : row0 + nrows;
+            maxrun = std::max(maxrun, m->h_rowptr[r1] - m->h_rowptr[r0]);
+        }
+    };
+    if (seg_nn) {
+        m->seg_node0.assign(nseg + 1, 0); m->seg_elem0.assign(nseg + 1, 0); m->seg_nnz0.assign(nseg + 1, 0);
+        int c0 = 0, s0 = 0;
+        for (int k = 0; k < nseg; ++k) {
+            m->seg_node0[k + 1] = m->seg_node0[k] + seg_nn[k];
+            m->seg_elem0[k + 1] = m->seg_elem0[k] + seg_ne[k];
+            const int row0 = 3 * m->seg_node0[k], nrows = 3 * seg_nn[k];
+            m->seg_nnz0[k + 1] = m->h_rowptr[row0 + nrows];
+            const int nc = (nrows + RPB - 1) / RPB, ns = (nrows + SPB - 1) / SPB;
+            minfo.push_back(make_int4(row0, nrows, c0, nc)); minfo_s.push_back(make_int4(row0, nrows, s0, ns));
+            cmesh.insert(cmesh.end(), nc, k); cmesh_s.insert(cmesh_s.end(), ns, k);
+            c0 += nc; s0 += ns;
+            scan_runs(row0, nrows);
+        }
+        m->nchunk_tot = c0; m->nchunk_s_tot = s0;
+    } else {
+        scan_runs(0, m->ndof);
+    }
+    if (maxrun * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
+    m->spmv_lds = (maxrun + 8) * (int)sizeof(double); // + the quads' slack either side of a row block
+
+    const size_t M = (size_t)nmesh;
+    int bad = 0;
+    bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke, M * ne * m->nd * m->nd);
+    bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
+    bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, y.contrib.size());
+    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof);
+    if (seg_nn) bad |= dalloc(&m->d_cmesh, cmesh.size()) | dalloc(&m->d_cmesh_s, cmesh_s.size()) | dalloc(&m->d_minfo, (size_t)nseg) | dalloc(&m->d_minfo_s, (size_t)nseg);
+    if (bad || !(m->stream = stream_get())) {
+        fem_free(m); delete m;
+        ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
+    }
+    ORBX_HIP(hipMemcpy(m->d_nodes, nodes, sizeof(float) * M * nn * 3, hipMemcpyHostToDevice));
+    if (ne) ORBX_HIP(hipMemcpy(m->d_elems, elems, sizeof(int) * (size_t)ne * npe, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_blk_row, y.blk_row.data(), sizeof(int) * nblk, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_bptr, y.bptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_cptr, y.cptr.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice));
+    if (!y.contrib.empty()) ORBX_HIP(hipMemcpy(m->d_contrib, y.contrib.data(), sizeof(int) * y.contrib.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
+    ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
+    if (seg_nn) {
+        ORBX_HIP(hipMemcpy(m->d_cmesh, cmesh.data(), sizeof(int) * cmesh.size(), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(m->d_cmesh_s, cmesh_s.data(), sizeof(int) * cmesh_s.size(), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(m->d_minfo, minfo.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(m->d_minfo_s, minfo_s.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
+    }
+    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
+    for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
+    if (m->spmv_lds > 48 * 1024)
+        ORBX_HIP(hipFuncSetAttribute(m->spb == 32 ? reinterpret_cast<const void *>(k_fem_spmv<32>) : reinterpret_cast<const void *>(k_fem_spmv<64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
+    *out = m;
+    return ORBX_OK;
 }
 
 } // namespace
@@ -628,103 +840,74 @@ int fem_create(int eltype, const float *nodes, int nmesh, int nn, const int32_t 
     if ((long long)ne >= (1ll << 25)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "too many elements");
     if ((long long)nmesh * 3 * nn >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 dofs");
     ORBX_NEED_DEVICE();
-    fem_model *m = new fem_model();
-    m->eltype = eltype; m->npe = npe; m->nd = 3 * npe; m->nmesh = nmesh; m->nn = nn; m->ne = ne; m->ndof = 3 * nn;
-    m->E = E; m->nu = nu; m->fg = fg;
-    // FEA2::FEA2, FEA2.cc:53-72 (float arithmetic, E unsigned)
-    m->lambda = (nu * E) / ((1 + nu) * (1 - 2 * nu));
-    m->G = E / (2 * (1 + nu));
-    for (int i = 0; i < 36; ++i) m->fc.D[i] = 0.0f;
-    m->fc.D[0] = m->fc.D[7] = m->fc.D[14] = m->lambda + 2 * m->G;
-    m->fc.D[1] = m->fc.D[2] = m->fc.D[6] = m->fc.D[8] = m->fc.D[12] = m->fc.D[13] = m->lambda;
-    m->fc.D[21] = m->fc.D[28] = m->fc.D[35] = m->G;
-    static const int sg[8][3] = {{-1, -1, -1}, {+1, -1, -1}, {+1, +1, -1}, {-1, +1, -1}, {-1, -1, +1}, {+1, -1, +1}, {+1, +1, +1}, {-1, +1, +1}};
-    for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 3; ++j) m->fc.gs[3 * i + j] = sg[i][j] < 0 ? -fg : +fg;
+    Symbolic y;
+    build_symbolic(npe, nn, ne, elems, y);
+    return create_model(eltype, npe, nodes, nmesh, nn, elems, ne, E, nu, fg, y, 0, nullptr, nullptr, out);
+}
 
-    // ---- symbolic phase (host, once per topology): block pattern + contribution lists
-    std::vector<std::vector<int>> adj(nn);
-    for (int i = 0; i < nn; ++i) adj[i].push_back(i);
-    for (int e = 0; e < ne; ++e)
-        for (int a = 0; a < npe; ++a)
-            for (int b = 0; b < npe; ++b) adj[elems[e * npe + a]].push_back(elems[e * npe + b]);
-    std::vector<int> bptr(nn + 1, 0), bcol, blk_row;
-    for (int i = 0; i < nn; ++i) {
-        std::sort(adj[i].begin(), adj[i].end());
-        adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
-        bptr[i + 1] = bptr[i] + (int)adj[i].size();
-        for (int j : adj[i]) { bcol.push_back(j); blk_row.push_back(i); }
+int fem_create_batch(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const float *nodes, const int32_t *elems,
+                     unsigned int E, float nu, float fg, fem_model **out)
+{
+    if (!nodes || !elems || !out || !mesh_nn || !mesh_ne || nmesh < 1) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    const int npe = eltype == FEM_C3D8 ? 8 : eltype == FEM_C3D6 ? 6 : eltype == FEM_TET4 ? 4 : 0;
+    if (!npe) ORBX_FAIL(ORBX_ERR_ARG, "unknown element type");
+    std::vector<long long> node0(nmesh + 1, 0), elem0(nmesh + 1, 0);
+    for (int k = 0; k < nmesh; ++k) {
+        if (mesh_nn[k] < 2 || mesh_ne[k] < 0) ORBX_FAIL(ORBX_ERR_ARG, "mesh with fewer than two nodes (FEA2.cc:1386: assembly refuses Ksize <= 3)");
+        node0[k + 1] = node0[k] + mesh_nn[k]; elem0[k + 1] = elem0[k] + mesh_ne[k];
     }
-    const int nblk = m->nblk = (int)bcol.size();
-    std::vector<int> cptr(nblk + 1, 0);
-    auto blk_of = [&](int I, int J) {
-        return bptr[I] + (int)(std::lower_bound(adj[I].begin(), adj[I].end(), J) - adj[I].begin());
-    };
-    for (int e = 0; e < ne; ++e)
-        for (int a = 0; a < npe; ++a)
-            for (int b = 0; b < npe; ++b) cptr[blk_of(elems[e * npe + a], elems[e * npe + b]) + 1]++;
-    for (int b = 0; b < nblk; ++b) cptr[b + 1] += cptr[b];
-    std::vector<int> contrib(cptr[nblk]), fill(cptr.begin(), cptr.end() - 1);
-    for (int e = 0; e < ne; ++e) // ascending (e, li, lj) inside every block = the reference's scatter order
-        for (int a = 0; a < npe; ++a)
-            for (int b = 0; b < npe; ++b) contrib[fill[blk_of(elems[e * npe + a], elems[e * npe + b])]++] = (e << 6) | (a << 3) | b;
-    m->nnz = (size_t)9 * nblk;
-    m->nnzs = (m->nnz + 3) & ~(size_t)3;
-    m->h_rowptr.assign(m->ndof + 1, 0);
-    m->h_lcol.assign(m->nnz, 0);
-    m->h_diag.assign(m->ndof, 0);
-    for (int I = 0; I < nn; ++I) {
-        const int nb = bptr[I + 1] - bptr[I];
-        for (int r = 0; r < 3; ++r) {
-            const int row = 3 * I + r, start = 9 * bptr[I] + r * 3 * nb;
-            m->h_rowptr[row] = start;
-            for (int jb = 0; jb < nb; ++jb)
-                for (int c = 0; c < 3; ++c) {
-                    const int col = 3 * bcol[bptr[I] + jb] + c;
-                    m->h_lcol[start + 3 * jb + c] = col;
-                    if (col == row) m->h_diag[row] = start + 3 * jb + c;
-                }
-        }
+    const long long nn = node0[nmesh], ne = elem0[nmesh];
+    if (ne >= (1ll << 25)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "too many elements");
+    if (3 * nn >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 dofs");
+    for (int k = 0; k < nmesh; ++k)
+        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i)
+            if (elems[i] < 0 || elems[i] >= mesh_nn[k]) ORBX_FAIL(ORBX_ERR_ARG, "element node id out of range");
+    ORBX_NEED_DEVICE();
+    // symbolic phase per mesh (independent: a few host threads), then concatenation in global numbering
+    std::vector<Symbolic> ys(nmesh);
+    {
+        const int nthr = std::max(1, std::min(nmesh, std::min(16, (int)std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t)
+            pool.emplace_back([&, t]() {
+                for (int k = t; k < nmesh; k += nthr) build_symbolic(npe, mesh_nn[k], mesh_ne[k], elems + elem0[k] * npe, ys[k]);
+            });
+        for (std::thread &th : pool) th.join();
     }
-    m->h_rowptr[m->ndof] = (int)m->nnz;
-    m->nchunk = (m->ndof + RPB - 1) / RPB;
-    m->spb = (size_t)nmesh * ((m->ndof + 63) / 64) < 512 ? 32 : 64;
-    const int SPB = m->spb;
-    m->nchunk_s = (m->ndof + SPB - 1) / SPB;
-    int maxrun = 0;
-    for (int r0 = 0; r0 < m->ndof; r0 += SPB) {
-        const int r1 = r0 + SPB < m->ndof ? r0 + SPB : m->ndof;
-        maxrun = std::max(maxrun, m->h_rowptr[r1] - m->h_rowptr[r0]);
+    Symbolic y;
+    std::vector<int32_t> gelems((size_t)ne * npe);
+    y.bptr.assign(1, 0);
+    y.cptr.assign(1, 0);
+    y.rowptr.clear();
+    long long blk0 = 0;
+    for (int k = 0; k < nmesh; ++k) {
+        const Symbolic &z = ys[k];
+        const int nd0 = (int)node0[k], el0 = (int)elem0[k], nz0 = (int)(9 * blk0), c0 = y.cptr.back();
+        if (9 * (blk0 + z.nblk) >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 non-zeros");
+        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i) gelems[i] = elems[i] + nd0;
+        for (int v : z.blk_row) y.blk_row.push_back(v + nd0);
+        for (size_t i = 1; i < z.bptr.size(); ++i) y.bptr.push_back(z.bptr[i] + (int)blk0);
+        for (size_t i = 1; i < z.cptr.size(); ++i) y.cptr.push_back(z.cptr[i] + c0);
+        for (int v : z.contrib) y.contrib.push_back(v + (el0 << 6));
+        for (size_t i = 0; i + 1 < z.rowptr.size(); ++i) y.rowptr.push_back(z.rowptr[i] + nz0);
+        for (int v : z.lcol) y.lcol.push_back(v + 3 * nd0);
+        for (int v : z.diag) y.diag.push_back(v + nz0);
+        blk0 += z.nblk;
     }
-    if (maxrun * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
-    m->spmv_lds = (maxrun + 8) * (int)sizeof(double); // + the quads' slack either side of a row block
+    y.rowptr.push_back((int)(9 * blk0));
+    y.nblk = (int)blk0;
+    std::vector<int> snn(mesh_nn, mesh_nn + nmesh), sne(mesh_ne, mesh_ne + nmesh);
+    return create_model(eltype, npe, nodes, 1, (int)nn, gelems.data(), (int)ne, E, nu, fg, y, nmesh, snn.data(), sne.data(), out);
+}
 
-    const size_t M = (size_t)nmesh;
-    int bad = 0;
-    bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke, M * ne * m->nd * m->nd);
-    bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
-    bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, contrib.size());
-    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof);
-    if (bad || !(m->stream = stream_get())) {
-        fem_free(m); delete m;
-        ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
+int fem_batch_offsets(const fem_model *m, int32_t *node0, int32_t *elem0, int32_t *nnz0)
+{
+    if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
+    for (int k = 0; k <= m->nseg; ++k) {
+        if (node0) node0[k] = m->segmented() ? m->seg_node0[k] : k * m->nn;
+        if (elem0) elem0[k] = m->segmented() ? m->seg_elem0[k] : k * m->ne;
+        if (nnz0) nnz0[k] = m->segmented() ? m->seg_nnz0[k] : (int32_t)((size_t)k * m->nnz);
     }
-    ORBX_HIP(hipMemcpy(m->d_nodes, nodes, sizeof(float) * M * nn * 3, hipMemcpyHostToDevice));
-    if (ne) ORBX_HIP(hipMemcpy(m->d_elems, elems, sizeof(int) * (size_t)ne * npe, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_blk_row, blk_row.data(), sizeof(int) * nblk, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_bptr, bptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_cptr, cptr.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice));
-    if (!contrib.empty()) ORBX_HIP(hipMemcpy(m->d_contrib, contrib.data(), sizeof(int) * contrib.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
-    ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
-    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
-    for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
-    if (m->spmv_lds > 48 * 1024)
-        ORBX_HIP(hipFuncSetAttribute(m->spb == 32 ? reinterpret_cast<const void *>(k_fem_spmv<32>) : reinterpret_cast<const void *>(k_fem_spmv<64>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
-    *out = m;
     return ORBX_OK;
 }
 
@@ -739,7 +922,7 @@ int fem_destroy(fem_model *m)
 int fem_sizes(const fem_model *m, int *nmesh, int *ndof, int64_t *nnz)
 {
     if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
-    if (nmesh) *nmesh = m->nmesh;
+    if (nmesh) *nmesh = m->nseg;
     if (ndof) *ndof = m->ndof;
     if (nnz) *nnz = (int64_t)m->nnz;
     return ORBX_OK;
@@ -818,15 +1001,30 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
 
 int fem_get_ke(fem_model *m, int mesh, int elem, float *ke)
 {
-    if (!m || !m->assembled || !ke || mesh < 0 || mesh >= m->nmesh || elem < 0 || elem >= m->ne)
-        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
-    ORBX_HIP(hipMemcpy(ke, m->d_ke + ((size_t)mesh * m->ne + elem) * m->nd * m->nd, sizeof(float) * m->nd * m->nd, hipMemcpyDeviceToHost));
+    if (!m || !m->assembled || !ke || mesh < 0 || mesh >= m->nseg || elem < 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    size_t e;
+    if (m->segmented()) {
+        if (elem >= m->seg_elem0[mesh + 1] - m->seg_elem0[mesh]) ORBX_FAIL(ORBX_ERR_ARG, "element out of range");
+        e = (size_t)m->seg_elem0[mesh] + elem;
+    } else {
+        if (elem >= m->ne) ORBX_FAIL(ORBX_ERR_ARG, "element out of range");
+        e = (size_t)mesh * m->ne + elem;
+    }
+    ORBX_HIP(hipMemcpy(ke, m->d_ke + e * m->nd * m->nd, sizeof(float) * m->nd * m->nd, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 
 int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr, int32_t *col, float *val)
 {
-    if (!m || !m->assembled || mesh < 0 || mesh >= m->nmesh) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (!m || !m->assembled || mesh < 0 || mesh >= m->nseg) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (m->segmented()) { // the mesh's own CSR: local rows and columns
+        const int row0 = 3 * m->seg_node0[mesh], nrows = 3 * (m->seg_node0[mesh + 1] - m->seg_node0[mesh]);
+        const int k0 = m->seg_nnz0[mesh], k1 = m->seg_nnz0[mesh + 1];
+        if (rowptr) for (int r = 0; r <= nrows; ++r) rowptr[r] = m->h_rowptr[row0 + r] - k0;
+        if (col) for (int k = k0; k < k1; ++k) col[k - k0] = m->h_lcol[k] - row0;
+        if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + k0, sizeof(float) * (size_t)(k1 - k0), hipMemcpyDeviceToHost));
+        return ORBX_OK;
+    }
     if (rowptr) memcpy(rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1));
     if (col) memcpy(col, m->h_lcol.data(), sizeof(int) * m->nnz);
     if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + (size_t)mesh * m->nnzs, sizeof(float) * m->nnz, hipMemcpyDeviceToHost));
@@ -878,10 +1076,11 @@ int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE)
     ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
                        m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
-    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
+    hipLaunchKernelGGL(k_fem_energy, dim3(m->nseg), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nseg,
+                       (const int4 *)m->d_minfo);
     ORBX_HIP(hipStreamSynchronize(m->stream));
-    if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
-    if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nmesh, sizeof(float) * m->nmesh, hipMemcpyDeviceToHost));
+    if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nseg, hipMemcpyDeviceToHost));
+    if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nseg, sizeof(float) * m->nseg, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 
@@ -890,6 +1089,7 @@ int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids,
 {
     if (!m || !m->assembled || !u0 || nids < 0 || (nids && !ids) || npoints < 0 || nder < 0 || (nder && !derived))
         ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
+    if (m->segmented()) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "the LM hook works on one mesh per model (fem_create)");
     const int nTop = npoints + nder;
     if (6 * nTop != m->ndof) ORBX_FAIL(ORBX_ERR_ARG, "npoints + nder must equal the number of top-layer nodes (Ksize / 6)");
     for (int i = 0; i < nids; ++i)
@@ -945,7 +1145,8 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
                            m->d_tr_ids, m->tr_nids, m->tr_klarge);
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
                        m->nnzs, m->ndof, m->d_a, m->d_f);
-    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh);
+    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh,
+                       (const int4 *)nullptr);
     ORBX_HIP(hipGetLastError());
     if (a_out) ORBX_HIP(hipMemcpyAsync(h_a, m->d_a, abytes, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipMemcpyAsync(h_e, m->d_e, sizeof(float) * 2 * m->nmesh, hipMemcpyDeviceToHost, st));
@@ -962,9 +1163,11 @@ int fem_cg_setup(fem_model *m, const double *b)
     if (ensure_cg(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fem_cg_init, dim3(m->nchunk, m->nmesh), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnzs,
-                       m->ndof, m->nchunk, m->d_b, m->d_x, m->d_r, m->d_p, m->d_dinv, m->d_part[0], m->d_part[1]);
-    hipLaunchKernelGGL(k_fem_cg_init2, dim3(m->nmesh), dim3(1), 0, m->stream, m->nchunk, m->d_part[0], m->d_part[1], m->d_sc);
+    hipLaunchKernelGGL(k_fem_cg_init, grid_cg(m), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnzs,
+                       m->ndof, m->nchunk, m->d_b, m->d_x, m->d_r, m->d_p, m->d_dinv, m->d_part[0], m->d_part[1],
+                       (const int *)m->d_cmesh, (const int4 *)m->d_minfo);
+    hipLaunchKernelGGL(k_fem_cg_init2, dim3(m->nseg), dim3(1), 0, m->stream, m->nchunk, m->d_part[0], m->d_part[1], m->d_sc,
+                       (const int4 *)m->d_minfo);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(m->stream));
     m->cg_it = 0;
@@ -1011,8 +1214,7 @@ int fem_spmv_repeat(fem_model *m, int n, void *stream)
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     for (int i = 0; i < n; ++i) {
         m->prof.start(2, st);
-        hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, dim3(m->nchunk_s, m->nmesh), dim3(CGT), m->spmv_lds, st,
-                           m->d_vals, m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0]);
+        launch_spmv(m, st);
         m->prof.stop(2, st);
     }
     ORBX_HIP(hipGetLastError());
@@ -1024,12 +1226,12 @@ int fem_cg_result(fem_model *m, double *x, double *relres)
     if (!m || !m->cg_ready) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
     // the copies wait for the stream the iterations ran on, not for the whole device
     hipStream_t st = m->cg_stream ? m->cg_stream : m->stream;
-    std::vector<CgScal> sc(relres ? m->nmesh : 0);
+    std::vector<CgScal> sc(relres ? m->nseg : 0);
     if (x) ORBX_HIP(hipMemcpyAsync(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost, st));
-    if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nmesh, hipMemcpyDeviceToHost, st));
+    if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));
     if (relres) {
-        for (int i = 0; i < m->nmesh; ++i) relres[i] = sc[i].bb > 0 ? sqrt(sc[i].rr / sc[i].bb) : 0.0;
+        for (int i = 0; i < m->nseg; ++i) relres[i] = sc[i].bb > 0 ? sqrt(sc[i].rr / sc[i].bb) : 0.0;
     }
     return ORBX_OK;
 }
@@ -1039,14 +1241,14 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
     if (!x || iters < 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     int rc = fem_cg_setup(m, b);
     if (rc != ORBX_OK) return rc;
-    std::vector<CgScal> sc(m->nmesh);
+    std::vector<CgScal> sc(m->nseg);
     int done = 0;
     while (done < iters) {
         if (tol > 0) { // convergence test on the device-side scalars, every 25 iterations
             ORBX_HIP(hipStreamSynchronize(m->stream));
-            ORBX_HIP(hipMemcpy(sc.data(), m->d_sc, sizeof(CgScal) * m->nmesh, hipMemcpyDeviceToHost));
+            ORBX_HIP(hipMemcpy(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost));
             bool all = true;
-            for (int i = 0; i < m->nmesh; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb));
+            for (int i = 0; i < m->nseg; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb));
             if (all) break;
         }
         const int n = iters - done < 25 ? iters - done : 25;

@@ -78,6 +78,9 @@ class FEA2:
             self._L.fem_destroy(h)
             self._h = None
 
+    def _vec(self, a, dtype):
+        return np.ascontiguousarray(a, dtype).reshape(self.nmesh, self.Ksize)
+
     def material(self):
         lam, G = C.c_float(), C.c_float()
         D = np.zeros(36, np.float32)
@@ -112,10 +115,6 @@ class FEA2:
         rows = np.repeat(np.arange(self.Ksize), np.diff(rp))
         K[rows, col] = val
         return K
-
-    def _vec(self, a, dtype):
-        a = np.ascontiguousarray(a, dtype).reshape(self.nmesh, self.Ksize)
-        return a
 
     def ComputeDisplacement(self, uf, u0, ids, Klarge=100000000.0):
         uf = self._vec(uf, np.float32); u0 = self._vec(u0, np.float32)
@@ -186,3 +185,66 @@ class FEA2:
         names = (C.c_char_p * 16)(); ms = (C.c_double * 16)(); ln = (C.c_int64 * 16)(); nk = C.c_int(0)
         check(self._L.fem_profile_read(self._h, 16, names, ms, ln, C.byref(nk)))
         return {names[i].decode(): (ms[i], ln[i]) for i in range(nk.value)}
+
+
+class FEA2Batch(FEA2):
+    """A batch of meshes with their OWN topologies (fem_create_batch) -- the reference builds a new mesh on every
+    PoseOptimizationNR call (src/Optimizer.cc:480, FEA2.cc:80-121).  The batch is one block-diagonal system in global
+    numbering: vectors are one array of all dofs (mesh k owns dofs [dof0[k], dof0[k+1])), Dirichlet ids / dofs are global;
+    strain energies and CG residuals come back one per mesh.  Kei / csr / K_dense address a mesh's own elements, rows and
+    columns.  Methods are those of FEA2 (the LM hook excepted)."""
+
+    def __init__(self, nodes_list, elems_list, nElType, E=3500, nu=0.495, fg=0.577350269):
+        self._L = lib(); _bind(self._L)
+        self.npe, self.nElType = _NPE[nElType], nElType
+        nodes_list = [np.ascontiguousarray(n, np.float32).reshape(-1, 3) for n in nodes_list]
+        elems_list = [np.ascontiguousarray(e, np.int32).reshape(-1, self.npe) for e in elems_list]
+        self.nseg = len(nodes_list)
+        nn = np.array([len(n) for n in nodes_list], np.int32); ne = np.array([len(e) for e in elems_list], np.int32)
+        nodes = np.ascontiguousarray(np.concatenate(nodes_list), np.float32)
+        elems = np.ascontiguousarray(np.concatenate(elems_list), np.int32)
+        self._h = C.c_void_p()
+        self._L.fem_create_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_float,
+                                             C.c_float, C.c_void_p]
+        check(self._L.fem_create_batch(nElType, self.nseg, _p(nn), _p(ne), _p(nodes), _p(elems), int(E), nu, fg, C.byref(self._h)))
+        nm, nd, nnz = C.c_int(), C.c_int(), C.c_int64()
+        check(self._L.fem_sizes(self._h, C.byref(nm), C.byref(nd), C.byref(nnz)))
+        assert nm.value == self.nseg
+        self.Ksize, self.nnz = nd.value, nnz.value          # totals over the batch
+        self.nmesh = 1                                      # vectors: one array of all dofs
+        self.node0 = np.zeros(self.nseg + 1, np.int32); self.elem0 = np.zeros(self.nseg + 1, np.int32); self.nnz0 = np.zeros(self.nseg + 1, np.int32)
+        check(self._L.fem_batch_offsets(self._h, _p(self.node0), _p(self.elem0), _p(self.nnz0)))
+        self.dof0 = 3 * self.node0
+
+    def csr(self, mesh=0):
+        n = int(self.dof0[mesh + 1] - self.dof0[mesh]); nz = int(self.nnz0[mesh + 1] - self.nnz0[mesh])
+        rp = np.zeros(n + 1, np.int32); col = np.zeros(nz, np.int32); val = np.zeros(nz, np.float32)
+        check(self._L.fem_get_csr(self._h, mesh, _p(rp), _p(col), _p(val)))
+        return rp, col, val
+
+    def K_dense(self, mesh=0):
+        rp, col, val = self.csr(mesh)
+        n = len(rp) - 1
+        K = np.zeros((n, n), np.float32)
+        K[np.repeat(np.arange(n), np.diff(rp)), col] = val
+        return K
+
+    def ComputeStrainEnergy(self, a):
+        a = self._vec(a, np.float32)
+        sE = np.zeros(self.nseg, np.float32); nsE = np.zeros(self.nseg, np.float32)
+        check(self._L.fem_strain_energy(self._h, _p(a), _p(sE), _p(nsE)))
+        return sE, nsE
+
+    def solve_cg(self, b, iters=200, tol=0.0):
+        b = self._vec(b, np.float64)
+        x = np.zeros_like(b); rel = np.zeros(self.nseg, np.float64); done = C.c_int(0)
+        check(self._L.fem_cg(self._h, _p(b), _p(x), iters, tol, C.byref(done), _p(rel)))
+        return x, done.value, rel
+
+    def cg_result(self):
+        x = np.zeros((1, self.Ksize), np.float64); rel = np.zeros(self.nseg, np.float64)
+        check(self._L.fem_cg_result(self._h, _p(x), _p(rel)))
+        return x, rel
+
+    def trial_setup(self, *a, **k):
+        raise NotImplementedError("the LM hook works on one mesh per model")

@@ -81,21 +81,23 @@ def synth_descriptors(n=2000, seed=7, flip_p=0.08, n_replace=200):
 
 
 def _tet_grid(ncell):
-    n1 = ncell + 1
-    g = np.arange(n1, dtype=np.float64)
-    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    """ncell: one number (cube) or (nx, ny, nz) cells."""
+    nx, ny, nz = (ncell, ncell, ncell) if np.isscalar(ncell) else ncell
+    X, Y, Z = np.meshgrid(np.arange(nx + 1, dtype=np.float64), np.arange(ny + 1, dtype=np.float64),
+                          np.arange(nz + 1, dtype=np.float64), indexing="ij")
     nodes = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
     # Kuhn split: 6 tets per cube along the main diagonal (0,0,0)-(1,1,1)
     perms = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
-    I, J, K = np.meshgrid(np.arange(ncell), np.arange(ncell), np.arange(ncell), indexing="ij")
-    base = np.stack([I.ravel(), J.ravel(), K.ravel()], 1)                    # [ncell^3, 3]
+    I, J, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([I.ravel(), J.ravel(), K.ravel()], 1)                    # [cells, 3]
     tets = np.zeros((len(base), 6, 4), np.int64)
+    nid = lambda c: (c[:, 0] * (ny + 1) + c[:, 1]) * (nz + 1) + c[:, 2]
     for t, pm in enumerate(perms):
         cur = base.copy()
-        tets[:, t, 0] = (cur[:, 0] * n1 + cur[:, 1]) * n1 + cur[:, 2]
+        tets[:, t, 0] = nid(cur)
         for v, ax in enumerate(pm):
             cur = cur.copy(); cur[:, ax] += 1
-            tets[:, t, v + 1] = (cur[:, 0] * n1 + cur[:, 1]) * n1 + cur[:, 2]
+            tets[:, t, v + 1] = nid(cur)
     tets = tets.reshape(-1, 4)
     p = nodes[tets]
     det = np.einsum("ij,ij->i", p[:, 1] - p[:, 0], np.cross(p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]))
@@ -111,16 +113,17 @@ def synth_tet_mesh(ncell=12, seed=11, jitter=0.1):
     oriented), fixed dofs (z=0 face), load vector (unit traction on z=max face)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     nodes, tets = _tet_grid(ncell)
-    interior = ((nodes > 0) & (nodes < ncell)).all(1)
+    dims = np.array((ncell, ncell, ncell) if np.isscalar(ncell) else ncell, np.float64)
+    interior = ((nodes > 0) & (nodes < dims)).all(1)
     ij = nodes[:, :2].copy()
-    ztop = nodes[:, 2] == ncell
+    ztop = nodes[:, 2] == dims[2]
     fixed_nodes = np.where(nodes[:, 2] == 0)[0]
     nodes[interior] += rng.uniform(-jitter, jitter, size=(int(interior.sum()), 3))
     fixed = (3 * fixed_nodes[:, None] + np.arange(3)[None]).ravel()
     load = np.zeros(3 * len(nodes))
     top = np.where(ztop)[0]
-    wgt = np.where((ij[top, 0] == 0) | (ij[top, 0] == ncell), 0.5, 1.0) * \
-        np.where((ij[top, 1] == 0) | (ij[top, 1] == ncell), 0.5, 1.0)
+    wgt = np.where((ij[top, 0] == 0) | (ij[top, 0] == dims[0]), 0.5, 1.0) * \
+        np.where((ij[top, 1] == 0) | (ij[top, 1] == dims[1]), 0.5, 1.0)
     load[3 * top + 2] = wgt  # unit traction x tributary area
     return nodes.astype(np.float32), tets.astype(np.int32), fixed.astype(np.int32), load
 
@@ -130,6 +133,19 @@ def synth_tet_batch(nmesh, ncell=12, seed=11):
     base, tets, fixed, load = synth_tet_mesh(ncell, seed)
     nodes = np.stack([synth_tet_mesh(ncell, seed + 1000 * m)[0] for m in range(nmesh)]) if nmesh > 1 else base[None]
     return nodes, tets, fixed, load
+
+
+def synth_tet_batch_distinct(nmesh, seed=11, base=12, dims_seed=88):
+    """nmesh meshes with their OWN topologies: grids of (nx, ny, nz) cells, nx, ny, nz in base-2 .. base+2 drawn per mesh
+    (about the config-3 size on average; the sizes depend on dims_seed only, so every rank of a multi-GPU run holds the
+    same sizes), each with its own jitter (seed).  Returns lists (nodes, tets, fixed dofs, loads)."""
+    rng = np.random.Generator(np.random.PCG64(dims_seed))
+    out = ([], [], [], [])
+    for m in range(nmesh):
+        dims = tuple(int(v) for v in rng.integers(base - 2, base + 3, 3))
+        for lst, v in zip(out, synth_tet_mesh(dims, seed + 1000 * m)):
+            lst.append(v)
+    return out
 
 
 def synth_stereo_pair(k=0, w=1242, h=375, dmin=2.0, dmax=60.0):

@@ -246,3 +246,67 @@ def test_lm_hook_trial_energy_resident(with_derived):
         of = oracle.fem_matvec_dense(K, oa)
         osE, onsE = oracle.fem_strain_energy(oa, of)
         assert abs(sE[0] - osE) <= RTOL * abs(osE) and abs(nsE[0] - onsE) <= RTOL * abs(onsE)
+
+
+def test_batch_of_the_references_own_meshes_distinct_topologies():
+    """fem_create_batch: the reference's own surface meshes (four different topologies and sizes, Ksize 60 .. 7788) as ONE
+    batch of prism models -- K per mesh, K*a and the strain energies equal the single-mesh models' and the oracle's."""
+    from orb_slam2_e_amd.fem import FEA2Batch
+    names = ["min", "median", "p90", "large"]
+    nodes_l, elems_l = [], []
+    for name in names:
+        top, tris = _fixture(name)
+        tris = _clean(top, tris)
+        nodes_l.append(second_layer(top, 0.5)); elems_l.append(extrude_elems(tris, len(top)))
+    fb = FEA2Batch(nodes_l, elems_l, FEM_C3D6)
+    assert fb.nseg == 4 and fb.Ksize == sum(3 * len(n) for n in nodes_l)
+    fb.MatrixAssembly()
+    ids = np.concatenate([fb.node0[k] + np.arange(len(n) // 2, len(n), dtype=np.int32) for k, n in enumerate(nodes_l)]).astype(np.int32)
+    fb.ImposeDirichletEncastre_K(ids)            # global node ids, the reference's id - 1 quirk per mesh
+    rng = np.random.default_rng(1)
+    a = rng.normal(0, 1e-2, fb.Ksize).astype(np.float32)
+    f = fb.ComputeForces(a)[0]
+    sE, nsE = fb.ComputeStrainEnergy(a)
+    for k, (nodes, elems) in enumerate(zip(nodes_l, elems_l)):
+        K = oracle.fem_assemble_dense(2, nodes, elems)
+        lid = np.arange(len(nodes) // 2, len(nodes), dtype=np.int32)
+        K = oracle.fem_dirichlet_K(K, lid)      # global id - 1 = the mesh's own node (local id - 1): the quirk stays per mesh
+        assert np.array_equal(fb.K_dense(k), K, equal_nan=True), names[k]
+        d0, d1 = fb.dof0[k], fb.dof0[k + 1]
+        of = oracle.fem_matvec_dense(K, a[d0:d1])
+        assert np.array_equal(f[d0:d1], of, equal_nan=True), names[k]
+        osE, onsE = oracle.fem_strain_energy(a[d0:d1], of)
+        if np.isfinite(osE):
+            assert abs(sE[k] - osE) <= RTOL * abs(osE) and abs(nsE[k] - onsE) <= RTOL * abs(onsE)
+        ke = fb.Kei(len(elems) - 1, k)
+        assert np.array_equal(ke, oracle.fem_ke(2, nodes[elems[-1]]), equal_nan=True)
+
+
+def test_batch_of_distinct_tet_meshes_cg_per_mesh():
+    """Jacobi-PCG on a batch of tetrahedral meshes of different sizes and topologies: every mesh has its own alpha / beta
+    (segmented reductions) -- displacements per mesh against the oracle's CG on that mesh's exported CSR, 1e-5."""
+    from orb_slam2_e_amd.fem import FEA2Batch
+    from orb_slam2_e_amd.synth import synth_tet_batch_distinct
+    nodes_l, tets_l, fixed_l, load_l = synth_tet_batch_distinct(7, base=4)
+    assert len({len(n) for n in nodes_l}) > 3
+    fb = FEA2Batch(nodes_l, tets_l, FEM_TET4)
+    fb.MatrixAssembly()
+    fixed = np.concatenate([fb.dof0[k] + fx for k, fx in enumerate(fixed_l)]).astype(np.int32)
+    fb.eliminate_dofs(fixed)
+    b = np.concatenate(load_l); b[fixed] = 0
+    x200, done, rel200 = fb.solve_cg(b, iters=60, tol=0.0)
+    x, it, rel = fb.solve_cg(b, iters=20000, tol=1e-11)
+    assert done == 60 and (rel <= 1e-11).all() and len(rel) == 7
+    for k in range(7):
+        rp, col, val = fb.csr(k)
+        d0, d1 = fb.dof0[k], fb.dof0[k + 1]
+        K = oracle.fem_assemble_dense(4, nodes_l[k], tets_l[k])
+        orp, ocol, oval = oracle.fem_dense_to_csr(K)
+        mask = np.zeros(len(K), np.uint8); mask[fixed_l[k]] = 1
+        oracle.fem_csr_eliminate(orp, ocol, oval, mask)
+        Kd = np.zeros_like(K); Kd[np.repeat(np.arange(len(K)), np.diff(orp)), ocol] = oval
+        assert np.array_equal(fb.K_dense(k), Kd)
+        ox60, _, orel60 = oracle.fem_cg(rp, col, val, b[d0:d1], 60, 0.0)
+        assert np.abs(x200[0, d0:d1] - ox60).max() <= RTOL * np.abs(ox60).max() and abs(rel200[k] - orel60) <= 1e-6 * orel60 + 1e-12
+        ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], 20000, 1e-11)
+        assert np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max()

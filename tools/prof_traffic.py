@@ -17,13 +17,21 @@ def short(n):
     return n.split("(")[0].split("<")[0]
 
 
+PER_GRID = {"k_fem_spmv"}          # kernels whose launches of different grid sizes are different workloads: also keyed name@grid
+
+
 def mean_largest(d, sub, counter):
     vals = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 vals[short(r["Kernel_Name"])][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
-    return {k: sum(v[max(v)]) / len(v[max(v)]) * 1024.0 for k, v in vals.items()}
+    out = {k: sum(v[max(v)]) / len(v[max(v)]) * 1024.0 for k, v in vals.items()}
+    for k in PER_GRID & set(vals):
+        for g, x in vals[k].items():
+            if len(x) >= 5:
+                out[f"{k}@{g}"] = sum(x) / len(x) * 1024.0
+    return out
 
 
 d, out, note = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -34,7 +42,7 @@ for k in sorted(fetch):
     if not k.startswith(("k_", "orb")):
         continue
     f, w = fetch[k], write.get(k, 0.0)
-    x2 = k in STREAM16
+    x2 = k.split("@")[0] in STREAM16
     res[k] = {"hbm_bytes_per_launch": (2 * f if x2 else f) + w, "fetch_size_bytes_raw": f, "write_size_bytes": w,
               "fetch_correction": "x2 (16-B/lane streaming loads, gfx950)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
               "valu_wave_insts_per_launch": valu.get(k), "source": note}
