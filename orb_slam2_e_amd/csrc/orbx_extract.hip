@@ -94,11 +94,11 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
 // + REFLECT_101 border.  xt[dx] = {sx, a0 | a1<<16}, yt[dy] = {sy0, sy1, b0, b1}:
 // OpenCV's coefficient tables, built on the host.
 //
-// Workgroups 0 .. nxi-1 hold the interior dword groups (4 pixels with 0 <= x < w, no reflection): the source
-// columns of such a group are non-decreasing and span at most 8 bytes (the host checks it per level), so each
-// source row is ONE unaligned 8-byte load and a pixel's pair (S[sx], S[sx+1]) is one v_perm_b32 into two u16
-// halves, times (a0, a1) one v_dot2_u32_u16.  The last workgroup holds the groups that touch the border or the
-// row padding and takes them pixel by pixel through the reflected coordinate (nxi = 0: every group does).
+// Interior dword groups (4 pixels with 0 <= x < w, no reflection): the source columns of such a group are
+// non-decreasing and span at most 8 bytes (the host checks it per level), so each source row is ONE unaligned
+// 8-byte load and a pixel's pair (S[sx], S[sx+1]) is one v_perm_b32 into two u16 halves, times (a0, a1) one
+// v_dot2_u32_u16.  The groups that touch the border take their pixels one by one through the reflected
+// coordinate (nxf = 0: every group does).
 // (b (r >> 4)) >> 16 = floor((b 2^12) (r & ~15) / 2^32): both factors are below 2^24 (b <= 2048, r <= 255 * 2048), so
 // it is one v_mul_hi_u32_u24 after the mask instead of shift, multiply, shift.  bs = b << 12.
 __device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, uint32_t bs0, uint32_t bs1)
@@ -109,27 +109,38 @@ __device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, uint32_t bs0
     return v > 255u ? 255u : v;
 }
 typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
+// Thread -> work.  A row of level 1 has 133 interior groups + 11 border groups: one wave per 64 groups of a row left the
+// third and the border wave of every row 80-90 % empty (45-55 % of all lanes idle).  Now: workgroups 0 .. nff*nrg-1 are full
+// waves of 64 consecutive interior groups of ONE row group (contiguous 256-byte rows in and out: tiling these 16 x 4
+// instead was slower although it saved instructions -- the kernel lives on the memory pipe); the REST of every row
+// (the last ngi % 64 interior groups and the border groups, `ntail` in all) is gathered tw groups x 64/tw row groups per
+// wave and goes through the coordinate-by-coordinate path, which serves interior groups as well.  Dwords of pure row
+// padding (outside the 19-px border) are not written: the workspace is zeroed once.
 __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
                                                    LevelInfo dst, const int2 *__restrict__ xt,
-                                                   const int4 *__restrict__ yt, int nxi)
+                                                   const int4 *__restrict__ yt, int nff, int nrg, int ntail, int tw_shift, int ntw)
 {
-    const int f = blockIdx.z, tid = threadIdx.x, ngi = dst.w >> 2; // interior groups: pixels 4i .. 4i+3 < w
-    const bool fast = (int)blockIdx.x < nxi;
-    int xw;
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int xlo = (PADX - EDGE) >> 2, xhi = (PADX + dst.w + EDGE - 1) >> 2; // first / last dword that holds border or image bytes
+    const bool fast = (int)blockIdx.x < nff * nrg;
+    int xw, rowg;
     if (fast) {
-        const int i = blockIdx.x * 64 + tid;
-        if (i >= ngi) return;
-        xw = PADX / 4 + i;
-    } else if (nxi > 0) {
-        xw = tid < PADX / 4 ? tid : ngi + tid; // left padding + border, then everything right of the last interior group
+        rowg = (int)blockIdx.x / nff;
+        xw = PADX / 4 + ((int)blockIdx.x - rowg * nff) * 64 + tid;
     } else {
-        xw = blockIdx.x * 64 + tid;
+        // tail tile: 2^tw_shift groups x 64 >> tw_shift row groups; ntw > 1 (a tail wider than a wave) only with tw_shift = 6
+        const int tb = (int)blockIdx.x - nff * nrg, tr = tb / ntw;
+        const int col = ((tb - tr * ntw) << tw_shift) + (tid & ((1 << tw_shift) - 1));
+        rowg = (tr << (6 - tw_shift)) + (tid >> tw_shift);
+        if (col >= ntail) return;
+        const int nleft = PADX / 4 - xlo;                                  // border groups on the left
+        xw = col < nleft ? xlo + col : PADX / 4 + nff * 64 + (col - nleft); // left border, leftover interior, right border
     }
-    if (xw * 4 >= dst.stride) return;
+    if (xw > xhi || rowg * PYR_ROWS >= dst.h + 2 * EDGE) return;
     int4 yy[PYR_ROWS];
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
-        const int row = blockIdx.y * PYR_ROWS + r;
+        const int row = rowg * PYR_ROWS + r;
         yy[r] = yt[reflect101((row < dst.h + 2 * EDGE ? row : 0) - EDGE, dst.h)];
     }
     const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     }
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
-        const int row = blockIdx.y * PYR_ROWS + r;
+        const int row = rowg * PYR_ROWS + r;
         if (row < dst.h + 2 * EDGE)
             *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (uint32_t)(row * dst.stride + xw * 4)) = out[r];
     }
@@ -1385,8 +1396,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 for (int k = 1; k < 4; ++k) window_ok = window_ok && g[k].x >= g[k - 1].x;
                 window_ok = window_ok && g[3].x + 1 - g[0].x <= 7;
             }
-            const int border_groups = PADX / 4 + lv.stride / 4 - PADX / 4 - (lv.w >> 2);
-            ex->resize_nxi[l] = (window_ok && border_groups <= 64) ? ((lv.w >> 2) + 63) / 64 : 0;
+            ex->resize_nxi[l] = window_ok ? 1 : 0;   // the 8-byte-window fast path may serve this level's interior groups
             resize_axis(lv.h, sv.h, o, c0, c1);
             for (int d = 0; d < lv.h; d++) {
                 const int s = o[d];
@@ -1415,13 +1425,18 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
     ex->queue_bytes = (2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 15) & ~15;                       // pixel queue + the pre-test's dump slots
     ex->fast_lds = ex->tile_bytes + ex->sc_bytes + ex->queue_bytes + 4 * (((maxcw - 6 + 3) >> 2) * (maxch - 6)); // + group queue
-    ex->oct_kcap = ex->NC > 1100 ? 3072 : 4096; // keys of a level live in LDS up to this many, else in HBM
+    // Keys of a level live in LDS up to this many, else in HBM.  Small on purpose: while k_octree runs (60-80 us of serial
+    // rounds) its workgroups pin their LDS on every CU and keep the LDS-hungry kernels of the other pipeline contexts
+    // (FAST, blur) off it.  With room for 4096 keys (60 KB per workgroup) the kernel alone is 20 % faster and the
+    // 64-frame step 4-5 % slower than with 1536 (39 KB; levels 0-2 of a 640 x 480 frame then keep their keys in HBM).
+    ex->oct_kcap = 1536;
     if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     const size_t B = (size_t)batch;
     ORBX_HIP(hipMalloc(&ex->d_pyr, ex->frame_bytes * B));
+    ORBX_HIP(hipMemset(ex->d_pyr, 0, ex->frame_bytes * B)); // the row padding outside the 19-px border is never written by k_pyr_resize
     ORBX_HIP(hipMalloc(&ex->d_blur, ex->frame_bytes * B));
     ORBX_HIP(hipMemset(ex->d_blur, 0, ex->frame_bytes * B));
     ORBX_HIP(hipMalloc(&ex->d_lv, sizeof(LevelInfo) * MAXL));
@@ -1501,11 +1516,16 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     }
     for (int l = 1; l < nl; l++) {
         const LevelInfo &lv = ex->lv[l];
-        const int nxi = ex->resize_nxi[l];
-        dim3 g(nxi > 0 ? nxi + 1 : (lv.stride / 4 + 63) / 64, (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+        const int ngi = lv.w >> 2, xlo = (PADX - EDGE) >> 2, xhi = (PADX + lv.w + EDGE - 1) >> 2;
+        const int nff = ex->resize_nxi[l] ? ngi / 64 : 0;                          // full waves of interior groups per row group
+        const int ntail = (xhi - xlo + 1) - nff * 64;                              // what is left of a row: leftover interior + border groups
+        const int tw_shift = ntail <= 16 ? 4 : ntail <= 32 ? 5 : 6;                // tail tile: 16 x 4, 32 x 2 or 64 x 1 (groups x row groups)
+        const int nrg = (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, rpt = 64 >> tw_shift;
+        const int ntw = (ntail + (1 << tw_shift) - 1) >> tw_shift;                 // tail waves across a row (> 1 only when ntail > 64)
+        dim3 g(nff * nrg + ntw * ((nrg + rpt - 1) / rpt), 1, batch);
         pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
-                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nxi);
+                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nrg, ntail, tw_shift, ntw);
         pf.stop(1, st);
     }
     pf.start(2, st);
