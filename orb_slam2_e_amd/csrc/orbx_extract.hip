@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -368,8 +369,6 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int sgn, int th)
 // pixels) compacted in raster order into the pixel queue; (3) survivors only: arc score -> score map (0 below
 // the pass's threshold, which is all the non-max test needs: a neighbour that is no corner at this threshold scores
 // less than any corner); (4) 3x3 strict NMS; (5) ordered emission.
-// The score map is not cleared between the passes: what pass 1 wrote are the true scores of pixels that pass 2
-// visits again (its survivor set contains pass 1's) and rewrites with the same values.
 // TS / SS (tile and score-map strides) are compile-time so that the 16 circle
 // offsets fold into ds_read immediates.
 template <int TS, int SS>
@@ -382,9 +381,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *tile = smem;
+    // LDS per wave decides how many waves a CU holds (the kernel speeds up with occupancy well beyond 20 waves per CU, and what
+    // it leaves free is what the other pipeline contexts' kernels can use): the group queue is dead once stage (2b) has read
+    // it and the score map is born after that, so they share one region (sc_bytes = the larger of the two)
     uint8_t *sc = smem + tile_bytes;
+    uint32_t *gqueue = reinterpret_cast<uint32_t *>(smem + tile_bytes);
     unsigned short *queue = reinterpret_cast<unsigned short *>(smem + tile_bytes + sc_bytes);
-    uint32_t *gqueue = reinterpret_cast<uint32_t *>(smem + tile_bytes + sc_bytes + queue_bytes);
+    (void)queue_bytes;
     int c, f;
     xcd_frame_item(f, c);
     const int lane = threadIdx.x;
@@ -403,7 +406,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             const int y = (int)(((float)i + 0.5f) * inv_ndw), xw = i - y * ndw;
             *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = load_u32_unaligned(img + __mul24(y, lv.stride) + 4 * xw);
         }
-        for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
         __syncthreads();
         constexpr int zc0 = 8;                        // tile column of zone pixel 0
         const uint8_t *t0 = tile + 3 * TS + zc0;      // zone pixel (0,0)
@@ -463,6 +465,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     nq += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
                 }
             }
+            __syncthreads();
+            // the score map takes over the group queue's region: all zero, then (3) writes the survivors' scores
+            for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
             __syncthreads();
             // (3) arc score of the survivors
             for (int q0 = 0; q0 < nq; q0 += 64) {
@@ -1420,11 +1425,15 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     // tile row = 5 spare bytes + the cell + the packed pre-test's right-hand dword; zone <= 63 (6-bit queue
     // coordinates)
     if (maxcw + 12 > 80 || maxch > 69) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than the LDS tile");
-    ex->TS = ex->SS = (maxcw + 12 <= 64) ? 64 : 80;
+    // three instantiations by the widest cell: tile stride 52 / score-map stride 40 (cells up to 40 px: the 30-37 px cells of
+    // every usual image size), 64 / 64, 80 / 80
+    ex->TS = maxcw <= 40 ? 52 : (maxcw + 12 <= 64) ? 64 : 80;
+    ex->SS = maxcw <= 40 ? 40 : ex->TS;
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
-    ex->sc_bytes = (ex->SS * (maxch - 6 + 2) + 15) & ~15;
-    ex->queue_bytes = (2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 15) & ~15;                       // pixel queue + the pre-test's dump slots
-    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + ex->queue_bytes + 4 * (((maxcw - 6 + 3) >> 2) * (maxch - 6)); // + group queue
+    const int gq_bytes = 4 * (((maxcw - 6 + 3) >> 2) * (maxch - 6));                               // group queue
+    ex->sc_bytes = (std::max(ex->SS * (maxch - 6 + 2), gq_bytes) + 15) & ~15;                      // score map, sharing the group queue's region
+    ex->queue_bytes = (2 * (maxcw - 6) * (maxch - 6) + 2 * 64 + 15) & ~15;                         // pixel queue + the pre-test's dump slots
+    ex->fast_lds = ex->tile_bytes + ex->sc_bytes + ex->queue_bytes;
     // Keys of a level live in LDS up to this many, else in HBM.  Small on purpose: while k_octree runs (60-80 us of serial
     // rounds) its workgroups pin their LDS on every CU and keep the LDS-hungry kernels of the other pipeline contexts
     // (FAST, blur) off it.  With room for 4096 keys (60 KB per workgroup) the kernel alone is 20 % faster and the
@@ -1529,7 +1538,11 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         pf.stop(1, st);
     }
     pf.start(2, st);
-    if (ex->TS == 64)
+    if (ex->TS == 52)
+        hipLaunchKernelGGL((k_fast_cells<52, 40>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
+                           ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
+                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
+    else if (ex->TS == 64)
         hipLaunchKernelGGL((k_fast_cells<64, 64>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
                            ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
                            ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
