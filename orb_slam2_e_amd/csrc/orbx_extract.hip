@@ -978,6 +978,26 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// N independent wave sums, step by step across all of them: a DPP instruction needs its source two VALU slots old, and
+// with N chains interleaved those slots hold the other chains' steps instead of s_nop.
+template <int N> __device__ __forceinline__ void wave_sum_n(int (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x111, 0xf, 0xf, true);   // row_shr:1
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x112, 0xf, 0xf, true);   // row_shr:2
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x114, 0xf, 0xf, true);   // row_shr:4
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x118, 0xf, 0xf, true);   // row_shr:8
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_readlane(v[i], 63);
+}
+
 // 16 keypoints per 256-thread workgroup (4 per wave).  Phase 0: one lane per
 // keypoint finds its level and pixel; phase 1: IC_Angle moments (:77-104) on the
 // unblurred level, one wave per keypoint at a time; phase 2: one lane per
@@ -985,23 +1005,25 @@ __device__ __forceinline__ int wave_sum(int v)
 // values -- evaluating them in every lane of a keypoint's wave would cost 64x the
 // instructions); phase 3: computeOrbDescriptor (:108-147) on the blurred level
 // and the output record (:845-855 octave/size, :1103-1109 pt *= scale).
-// IC_Angle weights for v_dot4_u32_u8: the 31x31 window is read as 31 rows x 8 dwords
-// starting at (x-15, y-15); dword d = row*8 + w holds u = 4w-15 .. 4w-12.  S weight = 1
-// inside the circular patch (|u| <= umax[|v|], ORBextractor.cc:454-469), T weight = u+15
-// there (m10 = sum(T) - 15*sum(S) keeps the weights unsigned).
-struct MomentWeights { uint32_t s[248], t[248]; };
+// IC_Angle weights for v_dot4c_i32_i8: the 31x31 window is read as 31 rows x 8 dwords starting at (x-15, y-15); dword
+// d = row*8 + w holds u = 4w-15 .. 4w-12 of row v = row - 15.  Inside the circular patch (|u| <= umax[|v|],
+// ORBextractor.cc:454-469) the U weight of a byte is u and its V weight is v, outside both are 0.  The pixels enter as
+// p - 128 (one xor with 0x80808080 makes them signed bytes): the patch is symmetric in u and in v, so the weights of all
+// 248 dwords sum to zero and sum(u (p - 128)) = sum(u p) = m10 exactly, likewise m01 -- two accumulating dot products per
+// dword and nothing else.
+struct MomentWeights { uint32_t u[248], v[248]; };
 constexpr MomentWeights make_moment_weights()
 {
     constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     MomentWeights m{};
     for (int d = 0; d < 248; ++d) {
         const int v = d / 8 - 15, av = v < 0 ? -v : v;
-        uint32_t ws = 0, wt = 0;
+        uint32_t wu = 0, wv = 0;
         for (int k = 0; k < 4; ++k) {
             const int u = 4 * (d % 8) + k - 15, au = u < 0 ? -u : u;
-            if (au <= umax[av]) { ws |= 1u << (8 * k); wt |= (uint32_t)(u + 15) << (8 * k); }
+            if (au <= umax[av]) { wu |= (uint32_t)(u & 0xff) << (8 * k); wv |= (uint32_t)(v & 0xff) << (8 * k); }
         }
-        m.s[d] = ws; m.t[d] = wt;
+        m.u[d] = wu; m.v[d] = wv;
     }
     return m;
 }
@@ -1050,13 +1072,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     // No branches on "slot in use": an unused slot reads the window of slot 0 (in use, see above) and its results are
     // dropped, so the loads of all four keypoints of a wave are in flight together.
     uint32_t *patch = s_patch[wv];
-    uint32_t wS[4], wT[4];
+    int wU[4], wV[4];
     int vrow[4], doff[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const int d = lane + 64 * jj;
         const bool in = d < 248;
-        wS[jj] = in ? c_momw.s[d] : 0u; wT[jj] = in ? c_momw.t[d] : 0u;
+        wU[jj] = in ? (int)c_momw.u[d] : 0; wV[jj] = in ? (int)c_momw.v[d] : 0;
         vrow[jj] = (in ? d : 0) >> 3; doff[jj] = 4 * (d & 7);
     }
     {
@@ -1070,20 +1092,22 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) px[j][jj] = load_u32_unaligned(win + (uint32_t)(__mul24(vrow[jj], stride) + doff[jj]));
         }
+        int mom[2 * (DESC_KPB / 4)];   // m10, m01 of the wave's four keypoints: eight independent sums
 #pragma unroll
         for (int j = 0; j < DESC_KPB / 4; ++j) {
-            const int kp = wv * (DESC_KPB / 4) + j;
             int m10 = 0, m01 = 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int sS = (int)__builtin_amdgcn_udot4(px[j][jj], wS[jj], 0u, false);
-                const int sT = (int)__builtin_amdgcn_udot4(px[j][jj], wT[jj], 0u, false);
-                m10 += sT - 15 * sS;
-                m01 += (vrow[jj] - 15) * sS;
+                const int ps = (int)(px[j][jj] ^ 0x80808080u);
+                m10 = __builtin_amdgcn_sdot4(ps, wU[jj], m10, false);
+                m01 = __builtin_amdgcn_sdot4(ps, wV[jj], m01, false);
             }
-            m10 = wave_sum(m10);
-            m01 = wave_sum(m01);
-            if (lane == 0) { s_m10[kp] = m10; s_m01[kp] = m01; }
+            mom[2 * j] = m10; mom[2 * j + 1] = m01;
+        }
+        wave_sum_n<2 * (DESC_KPB / 4)>(mom);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < DESC_KPB / 4; ++j) { s_m10[wv * (DESC_KPB / 4) + j] = mom[2 * j]; s_m01[wv * (DESC_KPB / 4) + j] = mom[2 * j + 1]; }
         }
     }
     __syncthreads();
