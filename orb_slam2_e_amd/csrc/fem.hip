@@ -52,104 +52,167 @@ __device__ __forceinline__ float bmat(int m, int comp, float gx, float gy, float
     }
 }
 
-// One 64-lane workgroup per element.  Lanes 0..NGP-1 evaluate one Gauss point
-// each (Jacobian, the reference's "inverse", physical shape gradients) in the
-// literal float operation order; then all lanes form B^T D B * Jac entries,
-// accumulating over Gauss points in order.
+// One Gauss point of one element (one tetrahedron: its single point): Jacobian, the reference's "inverse", physical
+// shape gradients G[3][NPE] and the weight JAC, in the literal float operation order of ComputeKeiC3D8 / ComputeKeiC3D6
+// (FEA2.cc:1254-1277, :1322-1345).  P = the element's node coordinates [NPE][3].  GS = row stride of G.
+template <int NPE, int ELT, int GS>
+__device__ __forceinline__ void fem_gauss_point(const float *P, int gp, const FemConst &fc, float *G, float &jac)
+{
+    if constexpr (ELT == FEM_TET4) {
+        const float e1x = P[3] - P[0], e1y = P[4] - P[1], e1z = P[5] - P[2];
+        const float e2x = P[6] - P[0], e2y = P[7] - P[1], e2z = P[8] - P[2];
+        const float e3x = P[9] - P[0], e3y = P[10] - P[1], e3z = P[11] - P[2];
+        const float c1x = e2y * e3z - e2z * e3y, c1y = e2z * e3x - e2x * e3z, c1z = e2x * e3y - e2y * e3x;
+        const float c2x = e3y * e1z - e3z * e1y, c2y = e3z * e1x - e3x * e1z, c2z = e3x * e1y - e3y * e1x;
+        const float c3x = e1y * e2z - e1z * e2y, c3y = e1z * e2x - e1x * e2z, c3z = e1x * e2y - e1y * e2x;
+        const float det = e1x * c1x + e1y * c1y + e1z * c1z;
+        float gx[4], gy[4], gz[4];
+        gx[1] = c1x / det; gy[1] = c1y / det; gz[1] = c1z / det;
+        gx[2] = c2x / det; gy[2] = c2y / det; gz[2] = c2z / det;
+        gx[3] = c3x / det; gy[3] = c3y / det; gz[3] = c3z / det;
+        gx[0] = -(gx[1] + gx[2] + gx[3]); gy[0] = -(gy[1] + gy[2] + gy[3]); gz[0] = -(gz[1] + gz[2] + gz[3]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { G[n % NPE] = gx[n]; G[GS + n % NPE] = gy[n]; G[2 * GS + n % NPE] = gz[n]; }
+        jac = fabsf(det) / 6;
+    } else {
+        const float xi = fc.gs[3 * gp], eta = fc.gs[3 * gp + 1], zeta = fc.gs[3 * gp + 2];
+        float a[NPE], b[NPE], c[NPE];
+        if constexpr (ELT == FEM_C3D8) { // FEA2.cc:1254-1261
+            a[0 % NPE] = -0.125f * ((1 - eta) * (1 - zeta)); b[0 % NPE] = -0.125f * ((1 - xi) * (1 - zeta)); c[0 % NPE] = -0.125f * ((1 - xi) * (1 - eta));
+            a[1 % NPE] = +0.125f * ((1 - eta) * (1 - zeta)); b[1 % NPE] = -0.125f * ((1 + xi) * (1 - zeta)); c[1 % NPE] = -0.125f * ((1 + xi) * (1 - eta));
+            a[2 % NPE] = +0.125f * ((1 + eta) * (1 - zeta)); b[2 % NPE] = +0.125f * ((1 + xi) * (1 - zeta)); c[2 % NPE] = -0.125f * ((1 + xi) * (1 + eta));
+            a[3 % NPE] = -0.125f * ((1 + eta) * (1 - zeta)); b[3 % NPE] = +0.125f * ((1 - xi) * (1 - zeta)); c[3 % NPE] = -0.125f * ((1 - xi) * (1 + eta));
+            a[4 % NPE] = -0.125f * ((1 - eta) * (1 + zeta)); b[4 % NPE] = -0.125f * ((1 - xi) * (1 + zeta)); c[4 % NPE] = +0.125f * ((1 - xi) * (1 - eta));
+            a[5 % NPE] = +0.125f * ((1 - eta) * (1 + zeta)); b[5 % NPE] = -0.125f * ((1 + xi) * (1 + zeta)); c[5 % NPE] = +0.125f * ((1 + xi) * (1 - eta));
+            a[6 % NPE] = +0.125f * ((1 + eta) * (1 + zeta)); b[6 % NPE] = +0.125f * ((1 + xi) * (1 + zeta)); c[6 % NPE] = +0.125f * ((1 + xi) * (1 + eta));
+            a[7 % NPE] = -0.125f * ((1 + eta) * (1 + zeta)); b[7 % NPE] = +0.125f * ((1 - xi) * (1 + zeta)); c[7 % NPE] = +0.125f * ((1 - xi) * (1 + eta));
+        } else { // C3D6, FEA2.cc:1322-1327
+            a[0] = -(1 + zeta) / 2; b[0] = -(1 + zeta) / 2; c[0] = (1 - xi - eta) / 2;
+            a[1] = (1 + zeta) / 2;  b[1] = 0.0f;            c[1] = xi / 2;
+            a[2] = 0.0f;            b[2] = (1 + zeta) / 2;  c[2] = eta / 2;
+            a[3] = -(1 - zeta) / 2; b[3] = -(1 - zeta) / 2; c[3] = -(1 - xi - eta) / 2;
+            a[4 % NPE] = (1 - zeta) / 2;  b[4 % NPE] = 0.0f;            c[4 % NPE] = -xi / 2;
+            a[5 % NPE] = 0.0f;            b[5 % NPE] = (1 - zeta) / 2;  c[5 % NPE] = -eta / 2;
+        }
+        float J_00 = a[0] * P[0], J_01 = a[0] * P[1], J_02 = a[0] * P[2];
+        float J_10 = b[0] * P[0], J_11 = b[0] * P[1], J_12 = b[0] * P[2];
+        float J_20 = c[0] * P[0], J_21 = c[0] * P[1], J_22 = c[0] * P[2];
+#pragma unroll
+        for (int n = 1; n < NPE; ++n) {
+            J_00 = J_00 + a[n] * P[3 * n]; J_01 = J_01 + a[n] * P[3 * n + 1]; J_02 = J_02 + a[n] * P[3 * n + 2];
+            J_10 = J_10 + b[n] * P[3 * n]; J_11 = J_11 + b[n] * P[3 * n + 1]; J_12 = J_12 + b[n] * P[3 * n + 2];
+            J_20 = J_20 + c[n] * P[3 * n]; J_21 = J_21 + c[n] * P[3 * n + 1]; J_22 = J_22 + c[n] * P[3 * n + 2];
+        }
+        // signed determinant and the reference's inverse with its three sign deviations
+        const float Jac = J_00 * J_11 * J_22 + J_01 * J_12 * J_20 + J_10 * J_21 * J_02 - J_20 * J_11 * J_02 - J_10 * J_01 * J_22 - J_21 * J_12 * J_00;
+        const float J1_00 = (+1) * ((J_11 * J_22) - (J_21 * J_12)) / Jac, J1_01 = (-1) * ((J_01 * J_22) - (J_21 * J_02)) / Jac, J1_02 = (-1) * ((J_01 * J_12) - (J_11 * J_02)) / Jac;
+        const float J1_10 = (-1) * ((J_10 * J_22) - (J_20 * J_12)) / Jac, J1_11 = (-1) * ((J_00 * J_22) - (J_20 * J_02)) / Jac, J1_12 = (-1) * ((J_00 * J_12) - (J_10 * J_02)) / Jac;
+        const float J1_20 = (+1) * ((J_10 * J_21) - (J_20 * J_11)) / Jac, J1_21 = (-1) * ((J_00 * J_21) - (J_20 * J_01)) / Jac, J1_22 = (-1) * ((J_00 * J_11) - (J_10 * J_01)) / Jac;
+#pragma unroll
+        for (int n = 0; n < NPE; ++n) {
+            G[n] = J1_00 * a[n] + J1_01 * b[n] + J1_02 * c[n];
+            G[GS + n] = J1_10 * a[n] + J1_11 * b[n] + J1_12 * c[n];
+            G[2 * GS + n] = J1_20 * a[n] + J1_21 * b[n] + J1_22 * c[n];
+        }
+        jac = Jac;
+    }
+}
+
+// K_e[i][j] = sum over the Gauss points of (B^T D B)[i][j] * Jac, accumulated in Gauss-point order (FEA2.cc:1295-1306).
+// G: [NGP][3][NPE] (one element), JAC: [NGP].
+template <int NPE, int NGP>
+__device__ __forceinline__ float fem_ke_entry(const float *G, const float *JAC, const FemConst &fc, int i, int j)
+{
+    const int ni = i / 3, ci = i - 3 * ni, nj = j / 3, cj = j - 3 * nj;
+    float acc = 0.0f;
+    for (int gp = 0; gp < NGP; ++gp) {
+        const float *g = G + gp * 3 * NPE;
+        const float gxi = g[ni], gyi = g[NPE + ni], gzi = g[2 * NPE + ni];
+        const float gxj = g[nj], gyj = g[NPE + nj], gzj = g[2 * NPE + nj];
+        float Bi[6], Bj[6], BtD[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { Bi[m] = bmat(m, ci, gxi, gyi, gzi); Bj[m] = bmat(m, cj, gxj, gyj, gzj); }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            BtD[k] = Bi[0] * fc.D[k] + Bi[1] * fc.D[6 + k] + Bi[2] * fc.D[12 + k] + Bi[3] * fc.D[18 + k] + Bi[4] * fc.D[24 + k] + Bi[5] * fc.D[30 + k];
+        const float aux = BtD[0] * Bj[0] + BtD[1] * Bj[1] + BtD[2] * Bj[2] + BtD[3] * Bj[3] + BtD[4] * Bj[4] + BtD[5] * Bj[5];
+        acc += aux * JAC[gp];
+    }
+    return acc;
+}
+
+// One 64-lane workgroup per element (the K_e accessor and the two-kernel assembly): lanes 0..NGP-1 evaluate one Gauss
+// point each, then all lanes form the entries of K_e.
 template <int NPE, int ELT>
 __global__ __launch_bounds__(64) void k_fem_ke(const float *__restrict__ nodes, int nn, const int *__restrict__ elems,
-                                               int ne, FemConst fc, float *__restrict__ ke_all)
+                                               int ne, FemConst fc, float *__restrict__ ke_all, int e0, int mesh0)
 {
     constexpr int ND = 3 * NPE;
     constexpr int NGP = ELT == FEM_TET4 ? 1 : 8;
     __shared__ float P[NPE * 3];
-    __shared__ float G[NGP][3][NPE];
+    __shared__ float G[NGP * 3 * NPE];
     __shared__ float JAC[NGP];
-    const int e = blockIdx.x, mesh = blockIdx.y, lane = threadIdx.x;
+    const int e = e0 + blockIdx.x, mesh = mesh0 + blockIdx.y, lane = threadIdx.x; // K_e lands at ke_all[blockIdx.y][blockIdx.x]
     if (lane < NPE * 3) {
         const int node = elems[e * NPE + lane / 3];
         P[lane] = nodes[((size_t)mesh * nn + node) * 3 + lane % 3];
     }
     __syncthreads();
     if (lane < NGP) {
-        if constexpr (ELT == FEM_TET4) {
-            const float e1x = P[3] - P[0], e1y = P[4] - P[1], e1z = P[5] - P[2];
-            const float e2x = P[6] - P[0], e2y = P[7] - P[1], e2z = P[8] - P[2];
-            const float e3x = P[9] - P[0], e3y = P[10] - P[1], e3z = P[11] - P[2];
-            const float c1x = e2y * e3z - e2z * e3y, c1y = e2z * e3x - e2x * e3z, c1z = e2x * e3y - e2y * e3x;
-            const float c2x = e3y * e1z - e3z * e1y, c2y = e3z * e1x - e3x * e1z, c2z = e3x * e1y - e3y * e1x;
-            const float c3x = e1y * e2z - e1z * e2y, c3y = e1z * e2x - e1x * e2z, c3z = e1x * e2y - e1y * e2x;
-            const float det = e1x * c1x + e1y * c1y + e1z * c1z;
-            float gx[4], gy[4], gz[4];
-            gx[1] = c1x / det; gy[1] = c1y / det; gz[1] = c1z / det;
-            gx[2] = c2x / det; gy[2] = c2y / det; gz[2] = c2z / det;
-            gx[3] = c3x / det; gy[3] = c3y / det; gz[3] = c3z / det;
-            gx[0] = -(gx[1] + gx[2] + gx[3]); gy[0] = -(gy[1] + gy[2] + gy[3]); gz[0] = -(gz[1] + gz[2] + gz[3]);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) { G[0][0][n % NPE] = gx[n]; G[0][1][n % NPE] = gy[n]; G[0][2][n % NPE] = gz[n]; }
-            JAC[0] = fabsf(det) / 6;
-        } else {
-            const float xi = fc.gs[3 * lane], eta = fc.gs[3 * lane + 1], zeta = fc.gs[3 * lane + 2];
-            float a[NPE], b[NPE], c[NPE];
-            if constexpr (ELT == FEM_C3D8) { // FEA2.cc:1254-1261
-                a[0 % NPE] = -0.125f * ((1 - eta) * (1 - zeta)); b[0 % NPE] = -0.125f * ((1 - xi) * (1 - zeta)); c[0 % NPE] = -0.125f * ((1 - xi) * (1 - eta));
-                a[1 % NPE] = +0.125f * ((1 - eta) * (1 - zeta)); b[1 % NPE] = -0.125f * ((1 + xi) * (1 - zeta)); c[1 % NPE] = -0.125f * ((1 + xi) * (1 - eta));
-                a[2 % NPE] = +0.125f * ((1 + eta) * (1 - zeta)); b[2 % NPE] = +0.125f * ((1 + xi) * (1 - zeta)); c[2 % NPE] = -0.125f * ((1 + xi) * (1 + eta));
-                a[3 % NPE] = -0.125f * ((1 + eta) * (1 - zeta)); b[3 % NPE] = +0.125f * ((1 - xi) * (1 - zeta)); c[3 % NPE] = -0.125f * ((1 - xi) * (1 + eta));
-                a[4 % NPE] = -0.125f * ((1 - eta) * (1 + zeta)); b[4 % NPE] = -0.125f * ((1 - xi) * (1 + zeta)); c[4 % NPE] = +0.125f * ((1 - xi) * (1 - eta));
-                a[5 % NPE] = +0.125f * ((1 - eta) * (1 + zeta)); b[5 % NPE] = -0.125f * ((1 + xi) * (1 + zeta)); c[5 % NPE] = +0.125f * ((1 + xi) * (1 - eta));
-                a[6 % NPE] = +0.125f * ((1 + eta) * (1 + zeta)); b[6 % NPE] = +0.125f * ((1 + xi) * (1 + zeta)); c[6 % NPE] = +0.125f * ((1 + xi) * (1 + eta));
-                a[7 % NPE] = -0.125f * ((1 + eta) * (1 + zeta)); b[7 % NPE] = +0.125f * ((1 - xi) * (1 + zeta)); c[7 % NPE] = +0.125f * ((1 - xi) * (1 + eta));
-            } else { // C3D6, FEA2.cc:1322-1327
-                a[0] = -(1 + zeta) / 2; b[0] = -(1 + zeta) / 2; c[0] = (1 - xi - eta) / 2;
-                a[1] = (1 + zeta) / 2;  b[1] = 0.0f;            c[1] = xi / 2;
-                a[2] = 0.0f;            b[2] = (1 + zeta) / 2;  c[2] = eta / 2;
-                a[3] = -(1 - zeta) / 2; b[3] = -(1 - zeta) / 2; c[3] = -(1 - xi - eta) / 2;
-                a[4 % NPE] = (1 - zeta) / 2;  b[4 % NPE] = 0.0f;            c[4 % NPE] = -xi / 2;
-                a[5 % NPE] = 0.0f;            b[5 % NPE] = (1 - zeta) / 2;  c[5 % NPE] = -eta / 2;
-            }
-            float J_00 = a[0] * P[0], J_01 = a[0] * P[1], J_02 = a[0] * P[2];
-            float J_10 = b[0] * P[0], J_11 = b[0] * P[1], J_12 = b[0] * P[2];
-            float J_20 = c[0] * P[0], J_21 = c[0] * P[1], J_22 = c[0] * P[2];
-#pragma unroll
-            for (int n = 1; n < NPE; ++n) {
-                J_00 = J_00 + a[n] * P[3 * n]; J_01 = J_01 + a[n] * P[3 * n + 1]; J_02 = J_02 + a[n] * P[3 * n + 2];
-                J_10 = J_10 + b[n] * P[3 * n]; J_11 = J_11 + b[n] * P[3 * n + 1]; J_12 = J_12 + b[n] * P[3 * n + 2];
-                J_20 = J_20 + c[n] * P[3 * n]; J_21 = J_21 + c[n] * P[3 * n + 1]; J_22 = J_22 + c[n] * P[3 * n + 2];
-            }
-            // signed determinant and the reference's inverse with its three sign deviations
-            const float Jac = J_00 * J_11 * J_22 + J_01 * J_12 * J_20 + J_10 * J_21 * J_02 - J_20 * J_11 * J_02 - J_10 * J_01 * J_22 - J_21 * J_12 * J_00;
-            const float J1_00 = (+1) * ((J_11 * J_22) - (J_21 * J_12)) / Jac, J1_01 = (-1) * ((J_01 * J_22) - (J_21 * J_02)) / Jac, J1_02 = (-1) * ((J_01 * J_12) - (J_11 * J_02)) / Jac;
-            const float J1_10 = (-1) * ((J_10 * J_22) - (J_20 * J_12)) / Jac, J1_11 = (-1) * ((J_00 * J_22) - (J_20 * J_02)) / Jac, J1_12 = (-1) * ((J_00 * J_12) - (J_10 * J_02)) / Jac;
-            const float J1_20 = (+1) * ((J_10 * J_21) - (J_20 * J_11)) / Jac, J1_21 = (-1) * ((J_00 * J_21) - (J_20 * J_01)) / Jac, J1_22 = (-1) * ((J_00 * J_11) - (J_10 * J_01)) / Jac;
-#pragma unroll
-            for (int n = 0; n < NPE; ++n) {
-                G[lane % NGP][0][n] = J1_00 * a[n] + J1_01 * b[n] + J1_02 * c[n];
-                G[lane % NGP][1][n] = J1_10 * a[n] + J1_11 * b[n] + J1_12 * c[n];
-                G[lane % NGP][2][n] = J1_20 * a[n] + J1_21 * b[n] + J1_22 * c[n];
-            }
-            JAC[lane % NGP] = Jac;
-        }
+        float jac;
+        fem_gauss_point<NPE, ELT, NPE>(P, lane, fc, G + lane * 3 * NPE, jac);
+        JAC[lane] = jac;
     }
     __syncthreads();
-    float *ke = ke_all + ((size_t)mesh * ne + e) * ND * ND;
+    float *ke = ke_all + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ND * ND;
     for (int idx = lane; idx < ND * ND; idx += 64) {
         const int i = idx / ND, j = idx - i * ND;
-        const int ni = i / 3, ci = i - 3 * ni, nj = j / 3, cj = j - 3 * nj;
-        float acc = 0.0f;
-        for (int gp = 0; gp < NGP; ++gp) {
-            const float gxi = G[gp][0][ni], gyi = G[gp][1][ni], gzi = G[gp][2][ni];
-            const float gxj = G[gp][0][nj], gyj = G[gp][1][nj], gzj = G[gp][2][nj];
-            float Bi[6], Bj[6], BtD[6];
+        ke[idx] = fem_ke_entry<NPE, NGP>(G, JAC, fc, i, j);
+    }
+}
+
+// MatrixAssemblyC3D8 / C3D6 (FEA2.cc:1379-1624) with K_e never leaving the chip: one workgroup per node I = block row.
+// Phase 1: Gauss-point data (shape gradients, Jac) of every element that holds node I, one (element, Gauss point) per
+// thread, into LDS.  Phase 2: one thread per scalar of the row's 3x3 blocks walks its contribution list
+// (ascending (element, li, lj) = the reference's scatter order), forms each K_e entry from the cached gradients
+// exactly as k_fem_ke does and adds it up.  HBM sees the node coordinates, the lists and ONE write of the values
+// (instead of a write and a read of every K_e: 2.2x the algorithmic traffic).
+template <int NPE, int ELT>
+__global__ __launch_bounds__(256) void k_fem_assemble_fused(const float *__restrict__ nodes, int nn, const int *__restrict__ elems,
+                                                            FemConst fc, const int *__restrict__ bptr, const int *__restrict__ cptr,
+                                                            const int *__restrict__ contrib_loc, const int *__restrict__ nel_ptr,
+                                                            const int *__restrict__ nel, const int *__restrict__ rowptr,
+                                                            float *__restrict__ vals, size_t nnz)
+{
+    constexpr int NGP = ELT == FEM_TET4 ? 1 : 8;
+    constexpr int GSZ = NGP * 3 * NPE;                 // floats of gradients per element
+    extern __shared__ float s_fem[];                   // [nelI][GSZ] gradients, then [nelI][NGP] weights
+    const int I = blockIdx.x, mesh = blockIdx.y, tid = threadIdx.x;
+    const int e0 = nel_ptr[I], nelI = nel_ptr[I + 1] - e0;
+    float *G = s_fem, *JAC = s_fem + (size_t)nelI * GSZ;
+    for (int t = tid; t < nelI * NGP; t += 256) {
+        const int el = t / NGP, gp = t - el * NGP, e = nel[e0 + el];
+        float P[NPE * 3];
 #pragma unroll
-            for (int m = 0; m < 6; ++m) { Bi[m] = bmat(m, ci, gxi, gyi, gzi); Bj[m] = bmat(m, cj, gxj, gyj, gzj); }
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                BtD[k] = Bi[0] * fc.D[k] + Bi[1] * fc.D[6 + k] + Bi[2] * fc.D[12 + k] + Bi[3] * fc.D[18 + k] + Bi[4] * fc.D[24 + k] + Bi[5] * fc.D[30 + k];
-            const float aux = BtD[0] * Bj[0] + BtD[1] * Bj[1] + BtD[2] * Bj[2] + BtD[3] * Bj[3] + BtD[4] * Bj[4] + BtD[5] * Bj[5];
-            acc += aux * JAC[gp];
+        for (int n = 0; n < NPE; ++n) {
+            const float *q = nodes + ((size_t)mesh * nn + elems[e * NPE + n]) * 3;
+            P[3 * n] = q[0]; P[3 * n + 1] = q[1]; P[3 * n + 2] = q[2];
         }
-        ke[idx] = acc;
+        float jac;
+        fem_gauss_point<NPE, ELT, NPE>(P, gp, fc, G + (size_t)el * GSZ + gp * 3 * NPE, jac);
+        JAC[el * NGP + gp] = jac;
+    }
+    __syncthreads();
+    const int b0 = bptr[I], nb = bptr[I + 1] - b0;
+    for (int t = tid; t < nb * 9; t += 256) {
+        const int bl = t / 9, mn = t - 9 * bl, m = mn / 3, n = mn - 3 * m, b = b0 + bl;
+        float v = 0.0f;
+        for (int c = cptr[b]; c < cptr[b + 1]; ++c) {
+            const int pk = contrib_loc[c];
+            const int el = pk >> 6, li = (pk >> 3) & 7, lj = pk & 7;
+            v += fem_ke_entry<NPE, NGP>(G + (size_t)el * GSZ, JAC + el * NGP, fc, 3 * li + m, 3 * lj + n);
+        }
+        vals[(size_t)mesh * nnz + rowptr[3 * I + m] + 3 * bl + n] = v;
     }
 }
 
@@ -571,6 +634,9 @@ struct fem_model {
     // nnz are the totals.  Uniform layout: nseg == nmesh, no tables.
     int nseg = 0, nchunk_tot = 0, nchunk_s_tot = 0;
     std::vector<int> seg_node0, seg_elem0, seg_nnz0; // [nseg + 1]
+    int *d_nel_ptr = nullptr, *d_nel = nullptr, *d_contrib_loc = nullptr; // fused assembly: elements per node, contributions by local element
+    int fused_lds = 0;                                                      // LDS bytes of k_fem_assemble_fused (0: two-kernel assembly)
+    float *d_ke1 = nullptr;                                                 // one K_e for the accessor
     int *d_cmesh = nullptr, *d_cmesh_s = nullptr;
     int4 *d_minfo = nullptr, *d_minfo_s = nullptr;
     bool segmented() const { return d_cmesh != nullptr; }
@@ -603,7 +669,8 @@ void fem_free(fem_model *m)
     void *ptrs[] = {m->d_nodes, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_elems, m->d_blk_row, m->d_bptr,
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s};
+                    m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s, m->d_nel_ptr, m->d_nel, m->d_contrib_loc,
+                    m->d_ke1};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -664,7 +731,8 @@ void launch_iter(fem_model *m, hipStream_t st)
 // Symbolic phase of one mesh (host, once per topology): block pattern, contribution lists, CSR pattern.
 struct Symbolic {
     std::vector<int> bptr, bcol, blk_row, cptr, contrib, rowptr, lcol, diag;
-    int nblk = 0;
+    std::vector<int> nel_ptr, nel, contrib_loc; // elements holding each node (ascending); contrib with the element as its index in the row node's list
+    int nblk = 0, maxel = 0;
 };
 void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
 {
@@ -694,6 +762,30 @@ void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
     for (int e = 0; e < ne; ++e) // ascending (e, li, lj) inside every block = the reference's scatter order
         for (int a = 0; a < npe; ++a)
             for (int b = 0; b < npe; ++b) y.contrib[fill[blk_of(elems[e * npe + a], elems[e * npe + b])]++] = (e << 6) | (a << 3) | b;
+    // elements per node (ascending, once each) and the contributions re-indexed by them: what the fused assembly caches
+    y.nel_ptr.assign(nn + 1, 0); y.nel.clear(); y.maxel = 0;
+    {
+        std::vector<std::vector<int>> el(nn);
+        for (int e = 0; e < ne; ++e)
+            for (int a = 0; a < npe; ++a) {
+                std::vector<int> &v = el[elems[e * npe + a]];
+                if (v.empty() || v.back() != e) v.push_back(e);
+            }
+        for (int i = 0; i < nn; ++i) {
+            y.nel_ptr[i + 1] = y.nel_ptr[i] + (int)el[i].size();
+            y.nel.insert(y.nel.end(), el[i].begin(), el[i].end());
+            y.maxel = std::max(y.maxel, (int)el[i].size());
+        }
+        y.contrib_loc.resize(y.contrib.size());
+        for (int b = 0; b < nblk; ++b) {
+            const std::vector<int> &v = el[y.blk_row[b]];
+            for (int c = y.cptr[b]; c < y.cptr[b + 1]; ++c) {
+                const int e = y.contrib[c] >> 6;
+                const int loc = (int)(std::lower_bound(v.begin(), v.end(), e) - v.begin());
+                y.contrib_loc[c] = (loc << 6) | (y.contrib[c] & 63);
+            }
+        }
+    }
     const int ndof = 3 * nn;
     y.rowptr.assign(ndof + 1, 0);
     y.lcol.assign((size_t)9 * nblk, 0);
@@ -780,7 +872,14 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
 
     const size_t M = (size_t)nmesh;
     int bad = 0;
-    bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke, M * ne * m->nd * m->nd);
+    {   // K_e stays on the chip when the Gauss-point data of a node's elements fits LDS (it always does for real meshes)
+        const int ngp = eltype == FEM_TET4 ? 1 : 8;
+        const size_t lds = (size_t)y.maxel * (ngp * 3 * npe + ngp) * sizeof(float);
+        m->fused_lds = lds <= 64 * 1024 ? (int)std::max(lds, (size_t)16) : 0;
+    }
+    bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke1, (size_t)m->nd * m->nd);
+    if (!m->fused_lds) bad |= dalloc(&m->d_ke, M * ne * m->nd * m->nd);
+    else bad |= dalloc(&m->d_nel_ptr, (size_t)nn + 1) | dalloc(&m->d_nel, y.nel.size()) | dalloc(&m->d_contrib_loc, y.contrib_loc.size());
     bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
     bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, y.contrib.size());
     bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof);
@@ -795,6 +894,11 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     ORBX_HIP(hipMemcpy(m->d_bptr, y.bptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(m->d_cptr, y.cptr.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice));
     if (!y.contrib.empty()) ORBX_HIP(hipMemcpy(m->d_contrib, y.contrib.data(), sizeof(int) * y.contrib.size(), hipMemcpyHostToDevice));
+    if (m->fused_lds) {
+        ORBX_HIP(hipMemcpy(m->d_nel_ptr, y.nel_ptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
+        if (!y.nel.empty()) ORBX_HIP(hipMemcpy(m->d_nel, y.nel.data(), sizeof(int) * y.nel.size(), hipMemcpyHostToDevice));
+        if (!y.contrib_loc.empty()) ORBX_HIP(hipMemcpy(m->d_contrib_loc, y.contrib_loc.data(), sizeof(int) * y.contrib_loc.size(), hipMemcpyHostToDevice));
+    }
     ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
     ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
@@ -889,6 +993,14 @@ int fem_create_batch(int eltype, int nmesh, const int32_t *mesh_nn, const int32_
         for (size_t i = 1; i < z.bptr.size(); ++i) y.bptr.push_back(z.bptr[i] + (int)blk0);
         for (size_t i = 1; i < z.cptr.size(); ++i) y.cptr.push_back(z.cptr[i] + c0);
         for (int v : z.contrib) y.contrib.push_back(v + (el0 << 6));
+        y.contrib_loc.insert(y.contrib_loc.end(), z.contrib_loc.begin(), z.contrib_loc.end());   // local element numbers: unchanged
+        {
+            const int n0 = y.nel_ptr.empty() ? 0 : y.nel_ptr.back();
+            if (y.nel_ptr.empty()) y.nel_ptr.push_back(0);
+            for (size_t i = 1; i < z.nel_ptr.size(); ++i) y.nel_ptr.push_back(z.nel_ptr[i] + n0);
+            for (int v : z.nel) y.nel.push_back(v + el0);
+            y.maxel = std::max(y.maxel, z.maxel);
+        }
         for (size_t i = 0; i + 1 < z.rowptr.size(); ++i) y.rowptr.push_back(z.rowptr[i] + nz0);
         for (int v : z.lcol) y.lcol.push_back(v + 3 * nd0);
         for (int v : z.diag) y.diag.push_back(v + nz0);
@@ -941,21 +1053,42 @@ int fem_assemble(fem_model *m)
 {
     if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
     hipStream_t st = m->stream;
-    m->prof.start(0, st);
-    if (m->ne > 0) {
-        const dim3 g(m->ne, m->nmesh);
-        if (m->eltype == FEM_C3D8)
-            hipLaunchKernelGGL((k_fem_ke<8, FEM_C3D8>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
-        else if (m->eltype == FEM_C3D6)
-            hipLaunchKernelGGL((k_fem_ke<6, FEM_C3D6>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
-        else
-            hipLaunchKernelGGL((k_fem_ke<4, FEM_TET4>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke);
+    if (m->fused_lds) {
+        // K_e never leaves the chip: one workgroup per node forms and sums the contributions of its block row
+        m->prof.start(1, st);
+        const dim3 g(m->nn, m->nmesh);
+#define ORBX_FUSED(NPE, ELT)                                                                                                    \
+        do {                                                                                                                    \
+            if (m->fused_lds > 48 * 1024)                                                                                       \
+                ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_assemble_fused<NPE, ELT>),                    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, m->fused_lds));                        \
+            hipLaunchKernelGGL((k_fem_assemble_fused<NPE, ELT>), g, dim3(256), m->fused_lds, st, m->d_nodes, m->nn, m->d_elems,  \
+                               m->fc, m->d_bptr, m->d_cptr, m->d_contrib_loc, m->d_nel_ptr, m->d_nel, m->d_rowptr, m->d_vals,  \
+                               m->nnzs);                                                                                        \
+        } while (0)
+        if (m->eltype == FEM_C3D8) ORBX_FUSED(8, FEM_C3D8);
+        else if (m->eltype == FEM_C3D6) ORBX_FUSED(6, FEM_C3D6);
+        else ORBX_FUSED(4, FEM_TET4);
+#undef ORBX_FUSED
+        m->prof.stop(1, st);
+    } else {
+        // a node with so many elements that their Gauss-point data does not fit LDS: K_e through HBM
+        m->prof.start(0, st);
+        if (m->ne > 0) {
+            const dim3 g(m->ne, m->nmesh);
+            if (m->eltype == FEM_C3D8)
+                hipLaunchKernelGGL((k_fem_ke<8, FEM_C3D8>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke, 0, 0);
+            else if (m->eltype == FEM_C3D6)
+                hipLaunchKernelGGL((k_fem_ke<6, FEM_C3D6>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke, 0, 0);
+            else
+                hipLaunchKernelGGL((k_fem_ke<4, FEM_TET4>), g, dim3(64), 0, st, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke, 0, 0);
+        }
+        m->prof.stop(0, st);
+        m->prof.start(1, st);
+        hipLaunchKernelGGL(k_fem_assemble, dim3((m->nblk * 9 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_ke, m->ne, m->nd,
+                           m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->nnzs);
+        m->prof.stop(1, st);
     }
-    m->prof.stop(0, st);
-    m->prof.start(1, st);
-    hipLaunchKernelGGL(k_fem_assemble, dim3((m->nblk * 9 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_ke, m->ne, m->nd,
-                       m->nblk, m->d_blk_row, m->d_bptr, m->d_cptr, m->d_contrib, m->d_rowptr, m->d_vals, m->nnzs);
-    m->prof.stop(1, st);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(st));
     m->assembled = true;
@@ -1010,7 +1143,17 @@ int fem_get_ke(fem_model *m, int mesh, int elem, float *ke)
         if (elem >= m->ne) ORBX_FAIL(ORBX_ERR_ARG, "element out of range");
         e = (size_t)mesh * m->ne + elem;
     }
-    ORBX_HIP(hipMemcpy(ke, m->d_ke + e * m->nd * m->nd, sizeof(float) * m->nd * m->nd, hipMemcpyDeviceToHost));
+    // one element's K_e on demand (the assembly keeps K_e on the chip)
+    const int mesh0 = m->segmented() ? 0 : mesh, el = (int)(m->segmented() ? e : e - (size_t)mesh * m->ne);
+    if (m->eltype == FEM_C3D8)
+        hipLaunchKernelGGL((k_fem_ke<8, FEM_C3D8>), dim3(1), dim3(64), 0, m->stream, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke1, el, mesh0);
+    else if (m->eltype == FEM_C3D6)
+        hipLaunchKernelGGL((k_fem_ke<6, FEM_C3D6>), dim3(1), dim3(64), 0, m->stream, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke1, el, mesh0);
+    else
+        hipLaunchKernelGGL((k_fem_ke<4, FEM_TET4>), dim3(1), dim3(64), 0, m->stream, m->d_nodes, m->nn, m->d_elems, m->ne, m->fc, m->d_ke1, el, mesh0);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(ke, m->d_ke1, sizeof(float) * m->nd * m->nd, hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
 
