@@ -250,10 +250,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of one step's results (outside the timed region)")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--gather-every", type=int, default=1,
-                    help="N > 1: steps of a context whose records travel in one RCCL gather (default: every step; larger values "
-                         "= fewer, larger collectives, each gather costing two cross-stream dependencies; partial buckets are "
-                         "flushed before every barrier).  Not measurable on the one-GPU development box: tune against SCALE_rNN.json")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="N > 1: steps of a context whose records travel in one RCCL gather (default 4: every gather costs two "
+                         "cross-stream dependencies of tens of microseconds each on this stack -- a quarter of them per step; partial "
+                         "buckets are flushed before every barrier).  Not measurable on the one-GPU development box: tune against SCALE_rNN.json")
     ap.add_argument("--pipeline", type=int, default=3, help="independent contexts/streams the steps rotate over")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive leg (host images in, host results out)")
