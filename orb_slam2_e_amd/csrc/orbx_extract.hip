@@ -1247,7 +1247,7 @@ void resize_axis(int dn, int sn, std::vector<int> &ofs, std::vector<int> &c0, st
 extern "C" {
 
 const char *orbx_last_error(void) { return orbx::last_error().c_str(); }
-int orbx_abi_version(void) { return 100; }
+int orbx_abi_version(void) { return 110; } // 110: + orbm_project_points, fem_create_batch, fem_batch_offsets (additions only)
 
 int orbx_create(const orbx_params *prm, orbx_extractor **out)
 {

@@ -341,3 +341,31 @@ def test_search_for_triangulation_oracle_cross_check():
             if b not in keep:
                 m12[h] = -1
         assert nwhole == int((m12 >= 0).sum()) and np.array_equal(whole, m12) and nwhole > 10
+
+
+def test_round2_entry_points_fail_loudly_without_gpu():
+    """orbm_project_points and fem_create_batch: argument errors are reported as such; with valid arguments and no
+    device they return ORBX_ERR_NO_DEVICE -- nothing is computed on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from orb_slam2_e_amd import OrbxError
+    from orb_slam2_e_amd.fem import FEA2Batch, FEM_TET4
+    from orb_slam2_e_amd.matcher import ORBmatcher
+    m = ORBmatcher(0.8)
+    cam = np.zeros(1, ORBmatcher.CAM_DTYPE); cam["gmaxx"], cam["gmaxy"] = 640, 480
+    pos = np.ones((4, 3), np.float32)
+    with pytest.raises(OrbxError) as e:
+        m.project_points(0, pos, pos, np.ones(4), np.ones(4), np.eye(3), np.zeros(3), np.zeros(3), cam, 40.0, 0.18, [1.0, 1.2], 1.0)
+    assert e.value.code == -2
+    with pytest.raises(OrbxError) as e:          # mode out of range: an argument error, whatever the device
+        m.project_points(7, pos, pos, np.ones(4), np.ones(4), np.eye(3), np.zeros(3), np.zeros(3), cam, 40.0, 0.18, [1.0, 1.2], 1.0)
+    assert e.value.code == -1
+    nodes = [np.random.default_rng(0).random((5, 3)).astype(np.float32), np.random.default_rng(1).random((4, 3)).astype(np.float32)]
+    tets = [np.array([[0, 1, 2, 3], [1, 2, 3, 4]], np.int32), np.array([[0, 1, 2, 3]], np.int32)]
+    with pytest.raises(OrbxError) as e:
+        FEA2Batch(nodes, tets, FEM_TET4)
+    assert e.value.code == -2
+    with pytest.raises(OrbxError) as e:          # element node id outside its own mesh
+        FEA2Batch(nodes, [tets[0], np.array([[0, 1, 2, 4]], np.int32)], FEM_TET4)
+    assert e.value.code == -1
