@@ -235,17 +235,18 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 }
 
 // --------------------------------------------------------------------- FAST
-// Differences v - p_k on the 16-pixel Bresenham circle of radius 3 (OpenCV
-// makeOffsets order), t = centre pointer into the LDS tile, ts = tile stride.
-__device__ __forceinline__ void fast_diffs(const uint8_t *t, int ts, int d[16])
-{
-    const int v = t[0];
-    d[0] = v - t[3 * ts];       d[1] = v - t[3 * ts + 1];   d[2] = v - t[2 * ts + 2];   d[3] = v - t[ts + 3];
-    d[4] = v - t[3];            d[5] = v - t[-ts + 3];      d[6] = v - t[-2 * ts + 2];  d[7] = v - t[-3 * ts + 1];
-    d[8] = v - t[-3 * ts];      d[9] = v - t[-3 * ts - 1];  d[10] = v - t[-2 * ts - 2]; d[11] = v - t[-ts - 3];
-    d[12] = v - t[-3];          d[13] = v - t[ts - 3];      d[14] = v - t[2 * ts - 2];  d[15] = v - t[3 * ts - 1];
-}
-
+#ifdef ORBX_PHASE_TIMING
+// development aid (never in the product build): shader-clock time per kernel phase, one record per workgroup (plain
+// stores: atomics on shared counters serialise in one L2 channel and the measurement measures itself)
+__device__ unsigned long long g_phase_rec[2 * 65536 * 8];
+#define ORBX_PH_INIT(K) unsigned long long ph_t = clock64(); unsigned long long *const ph_rec = g_phase_rec + ((K) * 65536 + ((blockIdx.x + gridDim.x * blockIdx.y) & 65535u)) * 8
+#define ORBX_PH(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] = ph_n - ph_t; ph_t = ph_n; } } while (0)
+#else
+#define ORBX_PH_INIT(K) do {} while (0)
+#define ORBX_PH(i, cond) do {} while (0)
+#endif
+// Circle pixels p_k, k = 0..15: the 16-pixel Bresenham circle of radius 3 in OpenCV's makeOffsets order, starting at
+// (0, 3) and running through (3, 0), (0, -3), (-3, 0).
 // Necessary condition for a 9-arc (OpenCV's opposite-pair pre-test): a 9-arc contains
 // one pixel of every opposite pair (k, k+8), so with d_k = v - p_k a dark arc needs
 // min_k max(d_k, d_k+8) > th and a bright one max_k min(d_k, d_k+8) < -th (both at
@@ -337,21 +338,42 @@ __device__ __forceinline__ uint32_t fast_resolve(uint32_t code) { return code & 
 constexpr unsigned FAST_PAIRS_A = 0x11u, FAST_PAIRS_B = 0xeeu;   // compass pairs 0/8 and 4/12 first, the other six on what is left
 
 // cornerScore<16>: (largest arc-minimum of e_k over the 16 circular 9-arcs) - 1
-// where e = d (dark) or -d (bright); it is a corner at threshold th iff that
+// where e = d (dark) or -d (bright), d_k = v - p_k; it is a corner at threshold th iff that
 // arc-minimum exceeds th, and the score does not depend on th.
-__device__ __forceinline__ int fast_arc_score(const int d[16], int sgn, int th)
+// Computed on packed halves.  X[k] (k = 0..7) holds e_k in its low and e_(k+8) in its high 16 bits, every value
+// biased to 0x4100 + e: the bit patterns 0x4001..0x41ff are positive normal f16 numbers, and for those the float order IS
+// the integer order -- so gfx950's three-operand packed v_pk_minimum3_f16 / v_pk_maximum3_f16 serve as integer min3 /
+// max3 on two values at once (no NaN, no zero, no denormal among the operands; nothing is rounded: min / max only
+// select).  X[k+8] is X[k] with its halves swapped, which the op_sel modifiers do for free.  min over the 9-arc
+// starting at k = min3 of three 3-arcs; 16 + 4 instructions instead of 64.  Returns max_k min(e_k .. e_(k+8)) + 0x4100.
+template <int S1, int S2> __device__ __forceinline__ uint32_t pk_min3_h(uint32_t a, uint32_t b, uint32_t c)
 {
-    int e[16], m2[16], m4[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) e[k] = d[k] * sgn;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) m2[k] = min(e[k], e[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
-    int best = -256;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) best = max(best, min(min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
-    return best > th ? best - 1 : 0;
+    uint32_t d;
+    if constexpr (S1 && S2) asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else if constexpr (S2) asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max3_h(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t fast_arc_best_packed(const uint32_t X[8])
+{
+    uint32_t m3[8], m9[8];
+    m3[0] = pk_min3_h<0, 0>(X[0], X[1], X[2]); m3[1] = pk_min3_h<0, 0>(X[1], X[2], X[3]);
+    m3[2] = pk_min3_h<0, 0>(X[2], X[3], X[4]); m3[3] = pk_min3_h<0, 0>(X[3], X[4], X[5]);
+    m3[4] = pk_min3_h<0, 0>(X[4], X[5], X[6]); m3[5] = pk_min3_h<0, 0>(X[5], X[6], X[7]);
+    m3[6] = pk_min3_h<0, 1>(X[6], X[7], X[0]); m3[7] = pk_min3_h<1, 1>(X[7], X[0], X[1]);
+    m9[0] = pk_min3_h<0, 0>(m3[0], m3[3], m3[6]); m9[1] = pk_min3_h<0, 0>(m3[1], m3[4], m3[7]);
+    m9[2] = pk_min3_h<0, 1>(m3[2], m3[5], m3[0]); m9[3] = pk_min3_h<0, 1>(m3[3], m3[6], m3[1]);
+    m9[4] = pk_min3_h<0, 1>(m3[4], m3[7], m3[2]); m9[5] = pk_min3_h<1, 1>(m3[5], m3[0], m3[3]);
+    m9[6] = pk_min3_h<1, 1>(m3[6], m3[1], m3[4]); m9[7] = pk_min3_h<1, 1>(m3[7], m3[2], m3[5]);
+    const uint32_t a = pk_max3_h(m9[0], m9[1], m9[2]), b = pk_max3_h(m9[3], m9[4], m9[5]);
+    const uint32_t c = pk_max3_h(m9[6], m9[7], a), m = pk_max3_h(b, c, c);
+    return max(m & 0xffffu, m >> 16);
 }
 
 // One wave per 30-px cell (ORBextractor.cc:789-837): cv::FAST(cell, iniThFAST, nms=true),
@@ -391,27 +413,45 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     int c, f;
     xcd_frame_item(f, c);
     const int lane = threadIdx.x;
-    const CellInfo ci = cells[c];
-    const LevelInfo lv = L[ci.level];
+    ORBX_PH_INIT(0);
+    const CellInfo ci = cells[c];   // everything the wave needs about its cell: no second dependent table read
     const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
     int total = 0;
     if (zw > 0 && zh > 0) {
         // (1) tile: pixel (x, y) of the cell lives at tile[y*TS + 5 + x], so that zone pixel 0 (cell pixel 3) sits
         // on the dword boundary at column 8 whatever the cell's position: the pre-test's 4-pixel groups then cover a
         // zone row with ceil(zw/4) groups.  Dword loads at byte addresses (see load_u32_unaligned).
+        // LW lanes side by side on a tile row (ndw <= LW by the choice of TS), 64 / LW rows per step: a lane's column never
+        // changes.  All loads of a chunk of NB steps are issued before the first is stored, and none of them sits behind a
+        // branch (a lane without work in a step reads the cell's last row / last dword again): the wave spends ONE memory
+        // latency here, not one per step -- this phase was 44 % of a wave's life when every load was followed by its
+        // store.  44 rows = one chunk covers every cell of a 640 x 480 frame.
+        constexpr int LW = TS > 64 ? 32 : 16, RPI = 64 / LW, NB = TS > 64 ? 16 : 11;
         const int ndw = (cw + 5 + 3) >> 2;
-        const uint8_t *img = pyr + (size_t)f * frame_bytes + lv.off + (size_t)(ci.y0 + EDGE) * lv.stride + PADX + (ci.x0 - 5);
-        const float inv_ndw = 1.0f / (float)ndw; // i / ndw via float: (i + 0.5) / ndw is >= 0.025 away from any integer
-        for (int i = lane; i < ch * ndw; i += 64) {
-            const int y = (int)(((float)i + 0.5f) * inv_ndw), xw = i - y * ndw;
-            *reinterpret_cast<uint32_t *>(tile + y * TS + 4 * xw) = load_u32_unaligned(img + __mul24(y, lv.stride) + 4 * xw);
+        const uint8_t *img = pyr + (size_t)f * frame_bytes + ci.img_off;
+        {
+            const int xw = lane & (LW - 1), yr = lane / LW;
+            const uint32_t xoff = 4u * (uint32_t)min(xw, ndw - 1);
+            uint8_t *dst = tile + yr * TS + 4 * xw;
+            const int ylim = xw < ndw ? ch - yr : 0;      // rows y0 = 0, RPI, 2 RPI, ... < ylim are this lane's
+            for (int yb = 0; yb < ch; yb += NB * RPI) {
+                uint32_t v[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    v[i] = load_u32_unaligned(img + ((uint32_t)__mul24(min(yb + yr + i * RPI, ch - 1), ci.stride) + xoff));
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (yb + i * RPI < ylim) *reinterpret_cast<uint32_t *>(dst + i * RPI * TS) = v[i];
+                dst += NB * RPI * TS;
+            }
         }
         __syncthreads();
+        ORBX_PH(0, lane == 0);   // tile load
         constexpr int zc0 = 8;                        // tile column of zone pixel 0
         const uint8_t *t0 = tile + 3 * TS + zc0;      // zone pixel (0,0)
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const int g0 = zc0 >> 2, ngx = (zw + 3) >> 2, ngrp = ngx * zh;
-        const int qstep = 64 / ngx, rstep = 64 - qstep * ngx; // lane + 64 -> (gx + rstep, y + qstep), one carry
+        const int g0 = zc0 >> 2, ngx = ci.ngx, ngrp = ngx * zh;
+        const int qstep = ci.qstep, rstep = ci.rstep;         // lane + 64 -> (gx + rstep, y + qstep), one carry
         unsigned short *const dump = queue + zw * zh;         // one spare slot per lane for rejected pixels
         uint32_t *out = cands + (size_t)f * cands_per_frame + ci.cand_off;
         for (int pass = 0; pass < 2; ++pass) {
@@ -421,15 +461,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             // every byte).  A group = the 4 pixels of one tile dword; groups overlapping the zone row, in raster order.
             int ngq = 0;
             {
-                int y = lane / ngx, gx = lane - y * ngx;
+                int y = (lane * ci.inv_ngx) >> 16, gx = lane - y * ngx;
                 for (int p0 = 0; p0 < ngrp; p0 += 64) {
                     uint32_t code = 0;
-                    if (p0 + lane < ngrp) {
-                        const int xs = 4 * (g0 + gx) - zc0;   // zone x of the group's pixel 0 (-3 .. zw-1)
-                        code = fast_pretest4<TS, FAST_PAIRS_A>(tile + (y + 3) * TS + 4 * (g0 + gx), th2);
-                        const int jlo = max(0, -xs), jhi = min(4, zw - xs); // pixels jlo..jhi-1 are in the zone
-                        code &= (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (4 - jhi)));
-                    }
+                    // a row's last group may reach past the zone: those pixels are masked in (2b), on the queued groups only
+                    if (p0 + lane < ngrp) code = fast_pretest4<TS, FAST_PAIRS_A>(tile + (y + 3) * TS + 4 * (g0 + gx), th2);
                     const unsigned long long b = __ballot(code != 0);
                     if (code) gqueue[ngq + mask_rank(b)] = code | ((uint32_t)y << 2) | ((uint32_t)gx << 10);
                     ngq += __popcll(b);
@@ -438,6 +474,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 }
             }
             __syncthreads();
+            ORBX_PH(1, lane == 0);   // stage A
             // (2b) the other six pairs on the queued groups, survivors -> queue entries y<<6 | x | polarity<<12
             int nq = 0;
             for (int q0 = 0; q0 < ngq; q0 += 64) {
@@ -447,7 +484,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     const uint32_t e = gqueue[q0 + lane];
                     const int y = (e >> 2) & 63, gx = (e >> 10) & 63;
                     code = fast_resolve(fast_pretest4<TS, FAST_PAIRS_B>(tile + (y + 3) * TS + 4 * (g0 + gx), th2) & e & 0x03030303u);
-                    ent = (y << 6) + 4 * (g0 + gx) - zc0;
+                    ent = (y << 6) + 4 * (g0 + gx) - zc0;                  // zone x of the group's pixel 0: 4 gx
+                    code &= 0xffffffffu >> (8 * max(0, 4 * gx + 4 - zw));   // pixels at zone x >= zw are outside
                 }
                 if (__ballot(code != 0)) {
                     // survivors of this lane: bytes 0..3 are 0/1/2 -> one bit per pixel, n = how many
@@ -466,6 +504,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 }
             }
             __syncthreads();
+            ORBX_PH(2, lane == 0);   // stage B
             // the score map takes over the group queue's region: all zero, then (3) writes the survivors' scores
             for (int i = lane; i < ((zh + 2) * SS + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(sc)[i] = 0;
             __syncthreads();
@@ -473,20 +512,26 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             for (int q0 = 0; q0 < nq; q0 += 64) {
                 if (q0 + lane < nq) {
                     const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
-                    // e_k = sgn (v - p_k) as one multiply-add per circle pixel: sgn v - sgn p_k
+                    // e_k = v - p_k (dark) or p_k - v (bright) = (p_k ^ m) - (v ^ m) with m = 0xff / 0; pairs (k, k+8) packed
+                    // and biased in one xor-add each: halves (p ^ m) + (0x4100 - (v ^ m)) lie in 0x4001..0x41ff, no carry
                     const uint8_t *t = t0 + y * TS + x;
-                    const int sgn = (e >> 12) == 1 ? 1 : -1, sv = sgn * (int)t[0], ns = -sgn;
-                    int d[16];
-                    d[0] = __mul24(t[3 * TS], ns) + sv;       d[1] = __mul24(t[3 * TS + 1], ns) + sv;   d[2] = __mul24(t[2 * TS + 2], ns) + sv;
-                    d[3] = __mul24(t[TS + 3], ns) + sv;       d[4] = __mul24(t[3], ns) + sv;            d[5] = __mul24(t[-TS + 3], ns) + sv;
-                    d[6] = __mul24(t[-2 * TS + 2], ns) + sv;  d[7] = __mul24(t[-3 * TS + 1], ns) + sv;  d[8] = __mul24(t[-3 * TS], ns) + sv;
-                    d[9] = __mul24(t[-3 * TS - 1], ns) + sv;  d[10] = __mul24(t[-2 * TS - 2], ns) + sv; d[11] = __mul24(t[-TS - 3], ns) + sv;
-                    d[12] = __mul24(t[-3], ns) + sv;          d[13] = __mul24(t[TS - 3], ns) + sv;      d[14] = __mul24(t[2 * TS - 2], ns) + sv;
-                    d[15] = __mul24(t[3 * TS - 1], ns) + sv;
-                    sc[(y + 1) * SS + x + 1] = (uint8_t)fast_arc_score(d, 1, th);
+                    const uint32_t m1 = (e >> 12) == 1 ? 0xffu : 0u, m2 = m1 | (m1 << 16);
+                    const uint32_t c1 = 0x4100u - ((uint32_t)t[0] ^ m1), c2 = c1 | (c1 << 16);
+                    uint32_t X[8];
+                    X[0] = (((uint32_t)t[3 * TS] | ((uint32_t)t[-3 * TS] << 16)) ^ m2) + c2;
+                    X[1] = (((uint32_t)t[3 * TS + 1] | ((uint32_t)t[-3 * TS - 1] << 16)) ^ m2) + c2;
+                    X[2] = (((uint32_t)t[2 * TS + 2] | ((uint32_t)t[-2 * TS - 2] << 16)) ^ m2) + c2;
+                    X[3] = (((uint32_t)t[TS + 3] | ((uint32_t)t[-TS - 3] << 16)) ^ m2) + c2;
+                    X[4] = (((uint32_t)t[3] | ((uint32_t)t[-3] << 16)) ^ m2) + c2;
+                    X[5] = (((uint32_t)t[-TS + 3] | ((uint32_t)t[TS - 3] << 16)) ^ m2) + c2;
+                    X[6] = (((uint32_t)t[-2 * TS + 2] | ((uint32_t)t[2 * TS - 2] << 16)) ^ m2) + c2;
+                    X[7] = (((uint32_t)t[-3 * TS + 1] | ((uint32_t)t[3 * TS - 1] << 16)) ^ m2) + c2;
+                    const int best = (int)fast_arc_best_packed(X) - 0x4100;
+                    sc[(y + 1) * SS + x + 1] = (uint8_t)(best > th ? best - 1 : 0);
                 }
             }
             __syncthreads();
+            ORBX_PH(3, lane == 0);   // zero + arc score
             // (4) 3x3 strict non-max suppression on the survivors
             unsigned long long mx = 0;
             int it = 0;
@@ -517,11 +562,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 }
                 total += __popcll(b);
             }
+            ORBX_PH(4, lane == 0);   // NMS + emission
             if (total > 0 || minTh == iniTh) break; // empty at iniThFAST: once more at minThFAST (:820-824)
             __syncthreads();                        // the queues are rewritten
         }
     }
     if (lane == 0) cell_count[(size_t)f * cells_per_frame + c] = total;
+    ORBX_PH(5, lane == 0);       // epilogue
+    ORBX_PH(6, lane == 0);       // (count of waves x timer cost)
 }
 
 // ------------------------------------------------------------------- octree
@@ -1043,6 +1091,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
     __shared__ uint32_t s_patch[4][37 * 10 + 14];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    ORBX_PH_INIT(1);
     int f, kbase;
     xcd_frame_item(f, kbase);
     kbase *= DESC_KPB;
@@ -1066,6 +1115,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
     }
     __syncthreads();
+    ORBX_PH(8, tid == 0);    // keypoint lookup
     if (s_level[0] < 0) return; // keypoint slots fill from 0: nothing in this block
     // IC_Angle (:77-104): every lane owns 4 dwords of the 31x31 window (fixed per lane, so are
     // their weights) and reads them straight from the unblurred level; two dot4 per dword.
@@ -1111,6 +1161,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
     }
     __syncthreads();
+    ORBX_PH(9, tid == 0);    // moments
     if (tid < DESC_KPB && s_level[tid] >= 0) {
         const float angle = orbx_fast_atan2((float)s_m01[tid], (float)s_m10[tid]);
         const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -1119,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_angle[tid] = angle; s_cos[tid] = a; s_sin[tid] = b;
     }
     __syncthreads();
+    ORBX_PH(10, tid == 0);   // atan2 + sincos
     // steered BRIEF: lane i evaluates tests 4i..4i+3 of its wave's current keypoint.
     // The 37x37 blurred patch (|offset| <= 18) is staged in LDS first, as 37 rows of 10
     // dwords starting at (x-18, y-18) (dword loads at byte addresses): the 512 sample
@@ -1188,6 +1240,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
                            ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x106, 0xf, 0xf, true) << 24);
         const size_t o = (size_t)f * cap + kbase + kp;
         if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
+        ORBX_PH(11 + j, tid == 0);   // BRIEF of the wave's keypoint j (incl. waiting for its patch)
         if (lane == 0) {
             const LevelInfo lv = L[level];
             const uint32_t pk = s_pk[kp];
@@ -1203,6 +1256,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             kps[o] = k;
         }
     }
+    ORBX_PH(15, tid == 0);
 }
 
 } // namespace
@@ -1387,6 +1441,11 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 const int zw = c.cw - 6, zh = c.ch - 6;
                 c.cap = (zw > 0 && zh > 0) ? ((zw + 1) / 2) * ((zh + 1) / 2) : 0; // 3x3 strict NMS bound
                 if (zw > 63 || zh > 63) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than 63 px");
+                c.ngx = (short)(zw > 0 ? (zw + 3) >> 2 : 1);
+                c.qstep = (short)(64 / c.ngx); c.rstep = (short)(64 - c.qstep * c.ngx);
+                c.inv_ngx = (65536 + c.ngx - 1) / c.ngx;
+                c.stride = lv.stride;
+                c.img_off = lv.off + (c.y0 + EDGE) * lv.stride + PADX + (c.x0 - 5);
                 c.cand_off = (int)cand_off;
                 cand_off += c.cap;
                 key_off += c.cap;
@@ -1615,6 +1674,18 @@ int orbx_profile_enable(orbx_extractor *ex, int on)
     ex->prof.mask = on < 0 ? 0xffffu : (unsigned)on;
     return ORBX_OK;
 }
+
+#ifdef ORBX_PHASE_TIMING
+int orbx_debug_phases(unsigned long long *out, int reset)   // out: 2 x 65536 x 8 records (FAST, describe)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 2 * 65536 * 8) != hipSuccess) return -1;
+    if (reset) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 2 * 65536 * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int orbx_profile_read(orbx_extractor *ex, int max_kinds, const char **names, double *total_ms, int64_t *launches, int *nkinds)
 {
