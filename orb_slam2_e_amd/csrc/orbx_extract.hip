@@ -238,9 +238,10 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 #ifdef ORBX_PHASE_TIMING
 // development aid (never in the product build): shader-clock time per kernel phase, one record per workgroup (plain
 // stores: atomics on shared counters serialise in one L2 channel and the measurement measures itself)
-__device__ unsigned long long g_phase_rec[2 * 65536 * 8];
-#define ORBX_PH_INIT(K) unsigned long long ph_t = clock64(); unsigned long long *const ph_rec = g_phase_rec + ((K) * 65536 + ((blockIdx.x + gridDim.x * blockIdx.y) & 65535u)) * 8
-#define ORBX_PH(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] = ph_n - ph_t; ph_t = ph_n; } } while (0)
+__device__ unsigned long long g_phase_rec[2 * 65536 * 16];   // per workgroup: 8 phase times (shader clock), [13] = end and [15] = start in the 100 MHz wall clock, [14] = HW_ID
+#define ORBX_PH_INIT(K) unsigned long long ph_t = clock64(); unsigned long long *const ph_rec = g_phase_rec + ((K) * 65536 + ((blockIdx.x + gridDim.x * blockIdx.y) & 65535u)) * 16; \
+    if (threadIdx.x == 0) { ph_rec[15] = wall_clock64(); ph_rec[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+#define ORBX_PH(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] = ph_n - ph_t; ph_t = ph_n; ph_rec[13] = wall_clock64(); } } while (0)
 #else
 #define ORBX_PH_INIT(K) do {} while (0)
 #define ORBX_PH(i, cond) do {} while (0)
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     xcd_frame_item(f, c);
     const int lane = threadIdx.x;
     ORBX_PH_INIT(0);
-    const CellInfo ci = cells[c];   // everything the wave needs about its cell: no second dependent table read
+    const FastCell ci = cells[c];   // everything the wave needs about its cell: no second dependent table read
     const int cw = ci.cw, ch = ci.ch, zw = cw - 6, zh = ch - 6;
     int total = 0;
     if (zw > 0 && zh > 0) {
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         // changes.  All loads of a chunk of NB steps are issued before the first is stored, and none of them sits behind a
         // branch (a lane without work in a step reads the cell's last row / last dword again): the wave spends ONE memory
         // latency here, not one per step -- this phase was 44 % of a wave's life when every load was followed by its
-        // store.  44 rows = one chunk covers every cell of a 640 x 480 frame.
+        // store.  44 rows = one chunk covers every cell of a 640 x 480 frame.  (Several cells per wave with the next
+        // cell's tile in flight during the current one's work: kernel 3-20 % slower, the tail grows; dropped.)
         constexpr int LW = TS > 64 ? 32 : 16, RPI = 64 / LW, NB = TS > 64 ? 16 : 11;
         const int ndw = (cw + 5 + 3) >> 2;
         const uint8_t *img = pyr + (size_t)f * frame_bytes + ci.img_off;
@@ -1077,51 +1079,79 @@ constexpr MomentWeights make_moment_weights()
 }
 __device__ const MomentWeights c_momw = make_moment_weights();
 
-constexpr int DESC_KPB = 16;
+constexpr int DESC_KPB = 16, DESC_PD = 1;
+// Per-level constants of k_describe, passed by value (kernel-argument memory: scalar loads, nothing to wait for behind a
+// table pointer).  Workgroup `item` of a frame serves chunk item - chunk_base[level] of the level with
+// chunk_base[level] <= item < chunk_base[level + 1]: 16 consecutive entries of that level's selected-keypoint slots.
+struct DescLevels {
+    int off[MAXL], stride[MAXL], sel_base[MAXL], patch[MAXL], chunk_base[MAXL + 1];
+    float scale[MAXL];
+};
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
-                                                  size_t frame_bytes, const LevelInfo *__restrict__ L, int nlevels,
+                                                  size_t frame_bytes, const DescLevels D, int nlevels,
                                                   const uint32_t *__restrict__ sel_all, int sel_per_frame,
                                                   const int *__restrict__ level_count,
                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                   int *__restrict__ counts, int cap)
 {
-    __shared__ unsigned long long s_center[DESC_KPB];
-    __shared__ int s_stride[DESC_KPB], s_level[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
+    __shared__ uint32_t s_coff[DESC_KPB];   // patch centre, byte offset inside the frame's pyramid
+    __shared__ int s_valid[DESC_KPB], s_out[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
     __shared__ uint32_t s_pk[DESC_KPB];
     __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
     __shared__ uint32_t s_patch[4][37 * 10 + 14];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     ORBX_PH_INIT(1);
-    int f, kbase;
-    xcd_frame_item(f, kbase);
-    kbase *= DESC_KPB;
+    int f, item;
+    xcd_frame_item(f, item);
+    // the workgroup's level and chunk follow from its index alone, so the keypoint words and the level counts (which
+    // only decide validity and the OUTPUT position) are read side by side: one memory latency, not two
+    int level = 0;
+    for (int l = 1; l < nlevels; ++l) level += item >= D.chunk_base[l];
+    const int stride = D.stride[level];
     if (tid < DESC_KPB) {
-        const int kidx = kbase + tid;
-        int level = -1, first = 0, total = 0;
+        const int j = (item - D.chunk_base[level]) * DESC_KPB + tid;   // slot within the level
+        const uint32_t pk = sel_all[(size_t)f * sel_per_frame + D.sel_base[level] + j];   // (slots past the level's count: never used)
+        int first = 0, mine = 0, total = 0;
         for (int l = 0; l < nlevels; ++l) {
             const int c = level_count[f * nlevels + l];
-            if (level < 0 && kidx < total + c) { level = l; first = total; }
+            first += l < level ? c : 0;
+            mine = l == level ? c : mine;
             total += c;
         }
-        if (kidx == 0) counts[f] = total < cap ? total : cap;
-        if (kidx >= cap) level = -1;
-        s_level[tid] = level;
-        if (level >= 0) {
-            const uint32_t pk = sel_all[(size_t)f * sel_per_frame + L[level].sel_base + (kidx - first)];
-            const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
-            s_pk[tid] = pk;
-            s_stride[tid] = L[level].stride;
-            s_center[tid] = (unsigned long long)f * frame_bytes + L[level].off + (size_t)(y + EDGE) * L[level].stride + PADX + x;
-        }
+        if (item == 0 && tid == 0) counts[f] = total < cap ? total : cap;
+        const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
+        s_valid[tid] = j < mine && first + j < cap;
+        s_out[tid] = first + j;
+        s_pk[tid] = pk;
+        s_coff[tid] = (uint32_t)(D.off[level] + (y + EDGE) * stride + PADX + x);
     }
     __syncthreads();
     ORBX_PH(8, tid == 0);    // keypoint lookup
-    if (s_level[0] < 0) return; // keypoint slots fill from 0: nothing in this block
+    if (!s_valid[0]) return; // a level's slots fill from 0: nothing in this chunk
+    const uint8_t *const fpyr = pyr + (size_t)f * frame_bytes, *const fblur = blur + (size_t)f * frame_bytes;
     // IC_Angle (:77-104): every lane owns 4 dwords of the 31x31 window (fixed per lane, so are
     // their weights) and reads them straight from the unblurred level; two dot4 per dword.
     // No branches on "slot in use": an unused slot reads the window of slot 0 (in use, see above) and its results are
     // dropped, so the loads of all four keypoints of a wave are in flight together.
     uint32_t *patch = s_patch[wv];
+    // The 37x37 blurred window of steered BRIEF (|offset| <= 18) is staged in LDS as 37 rows of 10 dwords starting at
+    // (x-18, y-18); every lane owns six fixed dwords of it (dword jj*64 + lane).  The windows are loaded PD keypoints
+    // ahead of their use, the first ones together with the moment windows: they depend on the keypoint's position only
+    constexpr int PR = 18, PW = 10, PD = DESC_PD; // patch radius; row = 10 dwords = bytes x-18 .. x+21; prefetch distance
+    int prow[6], pcol[6];
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+        const int d = lane + 64 * jj;
+        prow[jj] = d < (2 * PR + 1) * PW ? d / PW : -1;
+        pcol[jj] = 4 * (d % PW);
+    }
+    uint32_t nxt[PD][6];
+    auto load_patch = [&](int j, uint32_t (&r)[6]) {   // unused slots read slot 0's window (no branch in front of a load)
+        const int kp = wv * (DESC_KPB / 4) + j, kpv = s_valid[kp] ? kp : 0;
+        const uint8_t *win = fblur + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_coff[kpv]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) r[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(max(prow[jj], 0), stride) + pcol[jj]));
+    };
     int wU[4], wV[4];
     int vrow[4], doff[4];
 #pragma unroll
@@ -1135,13 +1165,14 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         uint32_t px[DESC_KPB / 4][4];
 #pragma unroll
         for (int j = 0; j < DESC_KPB / 4; ++j) {
-            const int kp = wv * (DESC_KPB / 4) + j, kpv = s_level[kp] >= 0 ? kp : 0;
-            // wave-uniform values read from LDS: tell the compiler, so the loads take a scalar base + 32-bit lane offset
-            const int stride = __builtin_amdgcn_readfirstlane(s_stride[kpv]);
-            const uint8_t *win = pyr + uniform_u64(s_center[kpv]) - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
+            const int kp = wv * (DESC_KPB / 4) + j, kpv = s_valid[kp] ? kp : 0;
+            // wave-uniform value read from LDS: tell the compiler, so the loads take a scalar base + 32-bit lane offset
+            const uint8_t *win = fpyr + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_coff[kpv]) - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) px[j][jj] = load_u32_unaligned(win + (uint32_t)(__mul24(vrow[jj], stride) + doff[jj]));
         }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) load_patch(j, nxt[j]);
         int mom[2 * (DESC_KPB / 4)];   // m10, m01 of the wave's four keypoints: eight independent sums
 #pragma unroll
         for (int j = 0; j < DESC_KPB / 4; ++j) {
@@ -1162,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     }
     __syncthreads();
     ORBX_PH(9, tid == 0);    // moments
-    if (tid < DESC_KPB && s_level[tid] >= 0) {
+    if (tid < DESC_KPB && s_valid[tid]) {
         const float angle = orbx_fast_atan2((float)s_m01[tid], (float)s_m10[tid]);
         const float factorPI = (float)(3.14159265358979323846 / 180.f);
         float a, b;
@@ -1171,11 +1202,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     }
     __syncthreads();
     ORBX_PH(10, tid == 0);   // atan2 + sincos
-    // steered BRIEF: lane i evaluates tests 4i..4i+3 of its wave's current keypoint.
-    // The 37x37 blurred patch (|offset| <= 18) is staged in LDS first, as 37 rows of 10
-    // dwords starting at (x-18, y-18) (dword loads at byte addresses): the 512 sample
-    // points are scattered over ~37 rows, and gathering them straight from global memory
-    // costs ~30 cache-line requests per load.
+    // steered BRIEF: lane i evaluates tests 4i..4i+3 of its wave's current keypoint, sampling the staged window.
     // Rotation on packed f32 (v_pk_mul_f32 / v_pk_add_f32, the same IEEE operations as the scalar form):
     // (x', y') = (px a - py b, px b + py a) = (px, px) * (a, b) + (-py, py) * (b, a); adding 1.5 * 2^23 rounds both to
     // the nearest-even integer (= cvRound) and leaves 0x4B400000 + value in the bits, which feed the address
@@ -1188,39 +1215,15 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         PX[2 * t] = f32x2{(float)pp[0], (float)pp[0]}; PY[2 * t] = f32x2{-(float)pp[1], (float)pp[1]};
         PX[2 * t + 1] = f32x2{(float)pp[2], (float)pp[2]}; PY[2 * t + 1] = f32x2{-(float)pp[3], (float)pp[3]};
     }
-    constexpr int PR = 18, PW = 10; // patch radius; row = 10 dwords = bytes x-18 .. x+21
-    int prow[6], pcol[6];
-#pragma unroll
-    for (int jj = 0; jj < 6; ++jj) { // dword jj*64 + lane of the 37 x 10 window: fixed per lane
-        const int d = lane + 64 * jj;
-        prow[jj] = d < (2 * PR + 1) * PW ? d / PW : -1;
-        pcol[jj] = 4 * (d % PW);
-    }
-    // the six patch dwords of keypoint j+1 are loaded while keypoint j is evaluated (unused slots read slot 0's patch)
-    uint32_t nxt[6];
-    {
-        const int kpv = s_level[wv * (DESC_KPB / 4)] >= 0 ? wv * (DESC_KPB / 4) : 0;
-        const int stride = __builtin_amdgcn_readfirstlane(s_stride[kpv]);
-        const uint8_t *win = blur + uniform_u64(s_center[kpv]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
-#pragma unroll
-        for (int jj = 0; jj < 6; ++jj) nxt[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(max(prow[jj], 0), stride) + pcol[jj]));
-    }
 #pragma unroll
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
-        const int level = s_level[kp];
         const float a = s_cos[kp], b = s_sin[kp];
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj)
-            if (prow[jj] >= 0) patch[lane + 64 * jj] = nxt[jj];
-        if (j + 1 < DESC_KPB / 4) {
-            const int kpv = s_level[kp + 1] >= 0 ? kp + 1 : 0;
-            const int stride = __builtin_amdgcn_readfirstlane(s_stride[kpv]);
-            const uint8_t *win = blur + uniform_u64(s_center[kpv]) - PR - (ptrdiff_t)PR * stride;
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) nxt[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(max(prow[jj], 0), stride) + pcol[jj]));
-        }
-        if (level < 0) continue;
+            if (prow[jj] >= 0) patch[lane + 64 * jj] = nxt[j % PD][jj];
+        if (j + PD < DESC_KPB / 4) load_patch(j + PD, nxt[j % PD]);
+        if (!s_valid[kp]) continue;
         // patch centre, minus what the magic-number bits add: (0x400000 * 40 + 0x4B400000) mod 2^32
         const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR;
         const f32x2 ab = {a, b}, ba = {b, a}, magic = {12582912.0f, 12582912.0f};
@@ -1238,17 +1241,16 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const unsigned w = byte | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x102, 0xf, 0xf, true) << 8) |
                            ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x104, 0xf, 0xf, true) << 16) |
                            ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x106, 0xf, 0xf, true) << 24);
-        const size_t o = (size_t)f * cap + kbase + kp;
+        const size_t o = (size_t)f * cap + s_out[kp];
         if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
         ORBX_PH(11 + j, tid == 0);   // BRIEF of the wave's keypoint j (incl. waiting for its patch)
         if (lane == 0) {
-            const LevelInfo lv = L[level];
             const uint32_t pk = s_pk[kp];
             orbx_keypoint k;
             k.x = (float)((int)((pk >> 8) & 0xfffu) + MIN_BORDER);
             k.y = (float)((int)(pk >> 20) + MIN_BORDER);
-            if (level != 0) { k.x *= lv.scale; k.y *= lv.scale; }
-            k.size = (float)lv.patch;
+            if (level != 0) { k.x *= D.scale[level]; k.y *= D.scale[level]; }
+            k.size = (float)D.patch[level];
             k.angle = s_angle[kp];
             k.response = (float)(pk & 0xffu);
             k.octave = level;
@@ -1508,10 +1510,11 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     // tile row = 5 spare bytes + the cell + the packed pre-test's right-hand dword; zone <= 63 (6-bit queue
     // coordinates)
     if (maxcw + 12 > 80 || maxch > 69) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "FAST cell larger than the LDS tile");
-    // three instantiations by the widest cell: tile stride 52 / score-map stride 40 (cells up to 40 px: the 30-37 px cells of
-    // every usual image size), 64 / 64, 80 / 80
-    ex->TS = maxcw <= 40 ? 52 : (maxcw + 12 <= 64) ? 64 : 80;
-    ex->SS = maxcw <= 40 ? 40 : ex->TS;
+    // three instantiations by the widest cell: tile stride 52 / score-map stride 40 for cells up to 44 px (zone <= 38: its
+    // ten 4-pixel groups end at tile column 51 and its score row, with the two border columns, at 39) -- the 36-43 px
+    // cells of every usual image size; 64 / 64; 80 / 80.  LDS per wave sets how many waves a CU holds.
+    ex->TS = maxcw <= 44 ? 52 : (maxcw + 12 <= 64) ? 64 : 80;
+    ex->SS = maxcw <= 44 ? 40 : ex->TS;
     ex->tile_bytes = (ex->TS * maxch + 15) & ~15;
     const int gq_bytes = 4 * (((maxcw - 6 + 3) >> 2) * (maxch - 6));                               // group queue
     ex->sc_bytes = (std::max(ex->SS * (maxch - 6 + 2), gq_bytes) + 15) & ~15;                      // score map, sharing the group queue's region
@@ -1545,7 +1548,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ORBX_HIP(hipMalloc(&ex->d_kpos, sizeof(uint32_t) * ex->keys_per_frame * B));
     ORBX_HIP(hipMalloc(&ex->d_knode, sizeof(unsigned short) * ex->keys_per_frame * B));
     ORBX_HIP(hipMalloc(&ex->d_kq, ex->keys_per_frame * B));
-    ORBX_HIP(hipMalloc(&ex->d_sel, sizeof(uint32_t) * ex->sel_per_frame * B));
+    ORBX_HIP(hipMalloc(&ex->d_sel, sizeof(uint32_t) * ((size_t)ex->sel_per_frame * B + DESC_KPB)));   // k_describe reads whole chunks of 16 slots
     ORBX_HIP(hipMalloc(&ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B));
     ORBX_HIP(hipMalloc(&ex->d_desc, (size_t)32 * ex->kcap * B));
     ORBX_HIP(hipMemcpy(ex->d_lv, ex->lv, sizeof(LevelInfo) * MAXL, hipMemcpyHostToDevice));
@@ -1655,9 +1658,20 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     }
     pf.stop(4, st);
     pf.start(5, st);
-    hipLaunchKernelGGL(k_describe, dim3((ex->kcap + DESC_KPB - 1) / DESC_KPB, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur,
-                       ex->frame_bytes, ex->d_lv, nl, ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps,
-                       ex->d_desc, ex->d_counts, ex->kcap);
+    {
+        DescLevels D;
+        memset(&D, 0, sizeof(D));
+        int nchunks = 0;
+        for (int l = 0; l < nl; l++) {
+            const LevelInfo &lv = ex->lv[l];
+            D.off[l] = lv.off; D.stride[l] = lv.stride; D.sel_base[l] = lv.sel_base; D.patch[l] = lv.patch; D.scale[l] = lv.scale;
+            D.chunk_base[l] = nchunks;
+            nchunks += (lv.N + 4 + DESC_KPB - 1) / DESC_KPB;   // a level holds at most N + 3 keypoints (its slots: N + 4)
+        }
+        for (int l = nl; l <= MAXL; l++) D.chunk_base[l] = nchunks;
+        hipLaunchKernelGGL(k_describe, dim3(nchunks, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, D, nl,
+                           ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps, ex->d_desc, ex->d_counts, ex->kcap);
+    }
     pf.stop(5, st);
     ORBX_HIP(hipGetLastError());
     ex->last_batch = batch;
@@ -1676,12 +1690,12 @@ int orbx_profile_enable(orbx_extractor *ex, int on)
 }
 
 #ifdef ORBX_PHASE_TIMING
-int orbx_debug_phases(unsigned long long *out, int reset)   // out: 2 x 65536 x 8 records (FAST, describe)
+int orbx_debug_phases(unsigned long long *out, int reset)   // out: 2 x 65536 x 16 records (FAST, describe)
 {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 2 * 65536 * 8) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 2 * 65536 * 16) != hipSuccess) return -1;
     if (reset) {
         void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 2 * 65536 * 8) != hipSuccess) return -1;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 2 * 65536 * 16) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -32,9 +32,10 @@ struct LevelInfo {
     int xtab, ytab;
 };
 
-struct alignas(16) CellInfo {
-    // what k_fast_cells reads sits dword-aligned in the first 36 bytes (scalar loads; a 2-byte field at an odd dword
-    // offset would turn the whole read into vector loads and put a full memory latency in front of the tile loads)
+// What k_fast_cells reads of a cell: 36 bytes, every field dword-aligned within a 16-byte-aligned record, so that the
+// wave fetches it with scalar loads (a 2-byte field at an odd dword offset turns the read into vector loads and puts a
+// full memory latency in front of the tile loads).
+struct FastCell {
     short cw, ch, dx, dy;                     // sub-image size; pt offset of the cell (ORBextractor.cc:828-833)
     short ngx, qstep, rstep, level;           // 4-pixel groups per zone row and the group walk's steps (below); pyramid level
     int cand_off;                             // first candidate slot of the cell in a frame
@@ -43,6 +44,8 @@ struct alignas(16) CellInfo {
     // (y, gx) = (lane * inv_ngx >> 16, lane - y ngx), exact for lane < 64 and ngx <= 16 -- divisions done on the host, once
     int inv_ngx;
     int img_off, stride;                      // byte offset of tile pixel (0, 0) = level pixel (x0 - 5, y0) in a frame's pyramid; row pitch
+};
+struct alignas(16) CellInfo : FastCell {
     short x0, y0;                             // sub-image origin in level coordinates
     int pad;
 };

@@ -11,7 +11,7 @@ frames = synth_sequence(64)
 for _ in range(3):
     ex.extract_batch(frames)
 ex.download_batch()
-acc = np.zeros((2, 65536, 8), np.uint64)
+acc = np.zeros((2, 65536, 16), np.uint64)
 L.orbx_debug_phases.argtypes = [C.c_void_p, C.c_int]
 assert L.orbx_debug_phases(acc.ctypes.data, 1) == 0
 ex.extract_batch(frames)
@@ -19,10 +19,18 @@ ex.download_batch()
 assert L.orbx_debug_phases(acc.ctypes.data, 0) == 0
 for k, (title, names) in enumerate([("k_fast_cells, per wave", ["tile load", "stage A", "stage B", "zero + score", "nms + emit", "epilogue", "(timer)"]),
                                     ("k_describe, per workgroup (wave 0)", ["lookup", "moments", "atan/sincos", "brief kp0", "brief kp1", "brief kp2", "brief kp3", "tail"])]):
-    r = acc[k].astype(np.float64)
-    used = r.sum(axis=1) > 0
-    r = r[used]
+    full = acc[k]
+    used = full[:, :8].sum(axis=1) > 0
+    full = full[used]
+    r = full[:, :8].astype(np.float64)
     tot = r.sum(axis=1)
     print(title, "records", len(r), "mean total clk", round(tot.mean()), "median", round(np.median(tot)), "p90", round(np.percentile(tot, 90)))
     for i, n in enumerate(names):
         print("   %-14s mean %8.0f clk  %5.1f %%   median %8.0f" % (n, r[:, i].mean(), 100 * r[:, i].sum() / tot.sum(), np.median(r[:, i])))
+    # occupancy over the kernel's span (100 MHz wall clock, common to the whole device)
+    start = full[:, 15].astype(np.float64); end = full[:, 13].astype(np.float64)
+    s0, e0 = start.min(), end.max()
+    t = np.linspace(s0, e0, 21)
+    print("   span %.1f us, mean resident workgroups %.0f (%.2f per CU), at 5 %% steps: %s" % (
+        (e0 - s0) / 100, (end - start).sum() / (e0 - s0), (end - start).sum() / (e0 - s0) / 256, [int(((start <= x) & (end > x)).sum()) for x in t[1:-1]]))
+    print("   mean workgroup residence %.2f us" % ((end - start).mean() / 100))
