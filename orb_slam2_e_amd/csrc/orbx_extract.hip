@@ -50,6 +50,21 @@ __device__ __forceinline__ int reflect101(int p, int n)
 // recomputed through the reflected coordinate instead of copied afterwards.
 constexpr int PYR_ROWS = 4;
 
+#ifdef ORBX_PHASE_TIMING
+// development aid (never in the product build): shader-clock time per kernel phase, one record per workgroup (plain
+// stores: atomics on shared counters serialise in one L2 channel and the measurement measures itself)
+__device__ unsigned long long g_phase_rec[3 * 65536 * 16];   // per workgroup: 8 phase times (shader clock), [13] = end and [15] = start in the 100 MHz wall clock, [14] = HW_ID
+#define ORBX_PH_INIT(K) unsigned long long *const ph_rec = g_phase_rec + ((K) * 65536 + ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 65535u)) * 16; \
+    if (threadIdx.x == 0) { ph_rec[15] = wall_clock64(); ph_rec[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } \
+    __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64()   /* the wall clock's own latency stays outside the first phase */
+#define ORBX_PH(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] = ph_n - ph_t; ph_t = ph_n; } } while (0)
+#define ORBX_PH_END(cond) do { if (cond) ph_rec[13] = wall_clock64(); } while (0)   // s_memrealtime is slow: once, at the very end
+#else
+#define ORBX_PH_INIT(K) do {} while (0)
+#define ORBX_PH(i, cond) do {} while (0)
+#define ORBX_PH_END(cond) do {} while (0)
+#endif
+
 // Level 0: copyMakeBorder(image, temp, 19,19,19,19, BORDER_REFLECT_101), ORBextractor.cc:1135.
 __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ img, int img_stride,
                                                    size_t img_frame_stride, uint8_t *__restrict__ pyr,
@@ -119,18 +134,24 @@ typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
 // padding (outside the 19-px border) are not written: the workspace is zeroed once.
 __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
                                                    LevelInfo dst, const int2 *__restrict__ xt,
-                                                   const int4 *__restrict__ yt, int nff, int nrg, int ntail, int tw_shift, int ntw)
+                                                   const int4 *__restrict__ yt, int nff, int nrg, int ntail, int tw_shift, int ntw, int rpw)
 {
     const int f = blockIdx.z, tid = threadIdx.x;
+    ORBX_PH_INIT(2);
+#ifdef ORBX_PHASE_TIMING
+    if (tid == 0) ph_rec[12] = dst.w;
+#endif
     const int xlo = (PADX - EDGE) >> 2, xhi = (PADX + dst.w + EDGE - 1) >> 2; // first / last dword that holds border or image bytes
-    const bool fast = (int)blockIdx.x < nff * nrg;
+    const int nrgw = (nrg + rpw - 1) / rpw;   // a full wave takes rpw consecutive row groups, one after the other
+    const bool fast = (int)blockIdx.x < nff * nrgw;
     int xw, rowg;
     if (fast) {
-        rowg = (int)blockIdx.x / nff;
-        xw = PADX / 4 + ((int)blockIdx.x - rowg * nff) * 64 + tid;
+        const int rw = (int)blockIdx.x / nff;
+        xw = PADX / 4 + ((int)blockIdx.x - rw * nff) * 64 + tid;
+        rowg = rw * rpw;
     } else {
         // tail tile: 2^tw_shift groups x 64 >> tw_shift row groups; ntw > 1 (a tail wider than a wave) only with tw_shift = 6
-        const int tb = (int)blockIdx.x - nff * nrg, tr = tb / ntw;
+        const int tb = (int)blockIdx.x - nff * nrgw, tr = tb / ntw;
         const int col = ((tb - tr * ntw) << tw_shift) + (tid & ((1 << tw_shift) - 1));
         rowg = (tr << (6 - tw_shift)) + (tid >> tw_shift);
         if (col >= ntail) return;
@@ -138,15 +159,13 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
         xw = col < nleft ? xlo + col : PADX / 4 + nff * 64 + (col - nleft); // left border, leftover interior, right border
     }
     if (xw > xhi || rowg * PYR_ROWS >= dst.h + 2 * EDGE) return;
-    int4 yy[PYR_ROWS];
-#pragma unroll
-    for (int r = 0; r < PYR_ROWS; ++r) {
-        const int row = rowg * PYR_ROWS + r;
-        yy[r] = yt[reflect101((row < dst.h + 2 * EDGE ? row : 0) - EDGE, dst.h)];
-    }
     const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
     uint32_t out[PYR_ROWS];
     if (fast) {
+        // A full wave works on one row group at a time: the four row-table entries are wave-uniform and come through the
+        // scalar cache; the column table is read once and serves all rpw row groups of the wave.  The kernel's time is a
+        // wave's life (three dependent memory round trips, 4-6 us) times the number of wave generations, and a level's
+        // wave count is what the host sets through rpw so that one generation holds them all.
         const int px0 = xw * 4 - PADX;
         const int4 xa = *reinterpret_cast<const int4 *>(xt + px0), xb = *reinterpret_cast<const int4 *>(xt + px0 + 2);
         const int sx0 = xa.x;
@@ -154,25 +173,52 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
         // selector {byte o, 0, byte o+1, 0} of the 8-byte window, o = sx - sx0
         const uint32_t sel[4] = {0x0c010c00u, 0x0c010c00u + (uint32_t)(xa.z - sx0) * 0x00010001u,
                                  0x0c010c00u + (uint32_t)(xb.x - sx0) * 0x00010001u, 0x0c010c00u + (uint32_t)(xb.z - sx0) * 0x00010001u};
-        uint2 w0[PYR_ROWS], w1[PYR_ROWS];
+        const int rg0 = __builtin_amdgcn_readfirstlane(rowg);
+        for (int j = 0; j < rpw; ++j) {
+            const int rg = rg0 + j;
+            if (rg * PYR_ROWS >= dst.h + 2 * EDGE) break;
+            int4 yy[PYR_ROWS];
 #pragma unroll
-        for (int r = 0; r < PYR_ROWS; ++r) {
-            __builtin_memcpy(&w0[r], base + (uint32_t)((yy[r].x + EDGE) * src.stride + sx0), 8);
-            __builtin_memcpy(&w1[r], base + (uint32_t)((yy[r].y + EDGE) * src.stride + sx0), 8);
-        }
+            for (int r = 0; r < PYR_ROWS; ++r) {
+                const int row = rg * PYR_ROWS + r;
+                yy[r] = yt[reflect101((row < dst.h + 2 * EDGE ? row : 0) - EDGE, dst.h)];
+            }
+            uint2 w0[PYR_ROWS], w1[PYR_ROWS];
 #pragma unroll
-        for (int r = 0; r < PYR_ROWS; ++r) {
-            out[r] = 0;
+            for (int r = 0; r < PYR_ROWS; ++r) {
+                __builtin_memcpy(&w0[r], base + (uint32_t)((yy[r].x + EDGE) * src.stride + sx0), 8);
+                __builtin_memcpy(&w1[r], base + (uint32_t)((yy[r].y + EDGE) * src.stride + sx0), 8);
+            }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w0[r].y, w0[r].x, sel[b])),
-                                                           __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
-                const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w1[r].y, w1[r].x, sel[b])),
-                                                           __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
-                out[r] |= resize_vertical(r0, r1, (uint32_t)yy[r].z << 12, (uint32_t)yy[r].w << 12) << (8 * b);
+            for (int r = 0; r < PYR_ROWS; ++r) {
+                out[r] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w0[r].y, w0[r].x, sel[b])),
+                                                               __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                    const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w1[r].y, w1[r].x, sel[b])),
+                                                               __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                    out[r] |= resize_vertical(r0, r1, (uint32_t)yy[r].z << 12, (uint32_t)yy[r].w << 12) << (8 * b);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PYR_ROWS; ++r) {
+                const int row = rg * PYR_ROWS + r;
+                if (row < dst.h + 2 * EDGE)
+                    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (uint32_t)(row * dst.stride + xw * 4)) = out[r];
             }
         }
-    } else {
+        ORBX_PH(1, tid == 0);
+        ORBX_PH_END(tid == 0);
+        return;
+    }
+    {
+        int4 yy[PYR_ROWS];
+#pragma unroll
+        for (int r = 0; r < PYR_ROWS; ++r) {
+            const int row = rowg * PYR_ROWS + r;
+            yy[r] = yt[reflect101((row < dst.h + 2 * EDGE ? row : 0) - EDGE, dst.h)];
+        }
         // no per-pixel branches: pixels outside [-EDGE, w+EDGE) (row padding) take the column of a clamped coordinate and
         // are masked out of the stored dword
         const int px0 = xw * 4 - PADX;
@@ -200,12 +246,15 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
             out[r] &= keep;
         }
     }
+    ORBX_PH(1, tid == 0 && out[0] != 0x12345678u);   // column table, source rows, arithmetic
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; ++r) {
         const int row = rowg * PYR_ROWS + r;
         if (row < dst.h + 2 * EDGE)
             *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_bytes + dst.off + (uint32_t)(row * dst.stride + xw * 4)) = out[r];
     }
+    ORBX_PH(2, tid == 0);
+    ORBX_PH_END(tid == 0);
 }
 
 // XCD-aware (frame, item) mapping for grids of (nitems, nframes) workgroups (speed only,
@@ -235,17 +284,6 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 }
 
 // --------------------------------------------------------------------- FAST
-#ifdef ORBX_PHASE_TIMING
-// development aid (never in the product build): shader-clock time per kernel phase, one record per workgroup (plain
-// stores: atomics on shared counters serialise in one L2 channel and the measurement measures itself)
-__device__ unsigned long long g_phase_rec[2 * 65536 * 16];   // per workgroup: 8 phase times (shader clock), [13] = end and [15] = start in the 100 MHz wall clock, [14] = HW_ID
-#define ORBX_PH_INIT(K) unsigned long long ph_t = clock64(); unsigned long long *const ph_rec = g_phase_rec + ((K) * 65536 + ((blockIdx.x + gridDim.x * blockIdx.y) & 65535u)) * 16; \
-    if (threadIdx.x == 0) { ph_rec[15] = wall_clock64(); ph_rec[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
-#define ORBX_PH(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] = ph_n - ph_t; ph_t = ph_n; ph_rec[13] = wall_clock64(); } } while (0)
-#else
-#define ORBX_PH_INIT(K) do {} while (0)
-#define ORBX_PH(i, cond) do {} while (0)
-#endif
 // Circle pixels p_k, k = 0..15: the 16-pixel Bresenham circle of radius 3 in OpenCV's makeOffsets order, starting at
 // (0, 3) and running through (3, 0), (0, -3), (-3, 0).
 // Necessary condition for a 9-arc (OpenCV's opposite-pair pre-test): a 9-arc contains
@@ -572,6 +610,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     if (lane == 0) cell_count[(size_t)f * cells_per_frame + c] = total;
     ORBX_PH(5, lane == 0);       // epilogue
     ORBX_PH(6, lane == 0);       // (count of waves x timer cost)
+    ORBX_PH_END(lane == 0);
 }
 
 // ------------------------------------------------------------------- octree
@@ -1259,6 +1298,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
     }
     ORBX_PH(15, tid == 0);
+    ORBX_PH_END(tid == 0);
 }
 
 } // namespace
@@ -1535,6 +1575,12 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ORBX_HIP(hipMalloc(&ex->d_blur, ex->frame_bytes * B));
     ORBX_HIP(hipMemset(ex->d_blur, 0, ex->frame_bytes * B));
     ORBX_HIP(hipMalloc(&ex->d_lv, sizeof(LevelInfo) * MAXL));
+    {
+        int dev = 0, ncu = 0;
+        ORBX_HIP(hipGetDevice(&dev));
+        ORBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (ncu > 0) ex->resident_waves = 32 * ncu;
+    }
     ORBX_HIP(hipMalloc(&ex->d_cells, sizeof(CellInfo) * ex->cells.size()));
     ORBX_HIP(hipMalloc(&ex->d_tiles, sizeof(BlurTile) * ex->tiles.size()));
 
@@ -1617,10 +1663,16 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         const int tw_shift = ntail <= 16 ? 4 : ntail <= 32 ? 5 : 6;                // tail tile: 16 x 4, 32 x 2 or 64 x 1 (groups x row groups)
         const int nrg = (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, rpt = 64 >> tw_shift;
         const int ntw = (ntail + (1 << tw_shift) - 1) >> tw_shift;                 // tail waves across a row (> 1 only when ntail > 64)
-        dim3 g(nff * nrg + ntw * ((nrg + rpt - 1) / rpt), 1, batch);
+        // row groups per full wave: two when one would need a second generation of resident waves (the kernel holds 8 waves
+        // per SIMD) -- a second generation costs a whole wave's life, a longer wave only its extra rows.  Measured per 64-frame
+        // chain of seven launches: 1 -> 0.100, 2 -> 0.094, 3 -> 0.098, 4 -> 0.103 ms
+        const int ntailw = ntw * ((nrg + rpt - 1) / rpt);
+        int rpw = 1;
+        while (rpw < 2 && (size_t)(nff * ((nrg + rpw - 1) / rpw) + ntailw) * batch > (size_t)ex->resident_waves) ++rpw;
+        dim3 g(nff * ((nrg + rpw - 1) / rpw) + ntailw, 1, batch);
         pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
-                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nrg, ntail, tw_shift, ntw);
+                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nrg, ntail, tw_shift, ntw, rpw);
         pf.stop(1, st);
     }
     pf.start(2, st);
@@ -1692,10 +1744,10 @@ int orbx_profile_enable(orbx_extractor *ex, int on)
 #ifdef ORBX_PHASE_TIMING
 int orbx_debug_phases(unsigned long long *out, int reset)   // out: 2 x 65536 x 16 records (FAST, describe)
 {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 2 * 65536 * 16) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 3 * 65536 * 16) != hipSuccess) return -1;
     if (reset) {
         void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 2 * 65536 * 16) != hipSuccess) return -1;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 3 * 65536 * 16) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -60,6 +60,7 @@ struct orbx_extractor {
     float scale[orbx_detail::MAXL], inv_scale[orbx_detail::MAXL], sigma2[orbx_detail::MAXL], inv_sigma2[orbx_detail::MAXL];
     int nfeat[orbx_detail::MAXL];
     int taps[4];
+    int resident_waves = 8192;              // CUs x 32 wave slots of the device the handle was created on
     int resize_nxi[orbx_detail::MAXL] = {}; // interior workgroups per row group of k_pyr_resize (0: no fast path at this level)
     int kcap; // nfeatures + 3*nlevels
 

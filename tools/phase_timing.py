@@ -11,17 +11,24 @@ frames = synth_sequence(64)
 for _ in range(3):
     ex.extract_batch(frames)
 ex.download_batch()
-acc = np.zeros((2, 65536, 16), np.uint64)
+acc = np.zeros((3, 65536, 16), np.uint64)
 L.orbx_debug_phases.argtypes = [C.c_void_p, C.c_int]
 assert L.orbx_debug_phases(acc.ctypes.data, 1) == 0
 ex.extract_batch(frames)
 ex.download_batch()
 assert L.orbx_debug_phases(acc.ctypes.data, 0) == 0
 for k, (title, names) in enumerate([("k_fast_cells, per wave", ["tile load", "stage A", "stage B", "zero + score", "nms + emit", "epilogue", "(timer)"]),
-                                    ("k_describe, per workgroup (wave 0)", ["lookup", "moments", "atan/sincos", "brief kp0", "brief kp1", "brief kp2", "brief kp3", "tail"])]):
+                                    ("k_describe, per workgroup (wave 0)", ["lookup", "moments", "atan/sincos", "brief kp0", "brief kp1", "brief kp2", "brief kp3", "tail"]),
+                                    ("k_pyr_resize, per wave (records of the launches that wrote last; [12] = level width)", ["row table", "columns + rows + math", "store"])]):
     full = acc[k]
     used = full[:, :8].sum(axis=1) > 0
     full = full[used]
+    if k == 2:
+        for wv in np.unique(full[:, 12]):
+            g = full[full[:, 12] == wv]
+            o = np.argsort(g[:, 15]); q = len(g) // 4
+            print('      first-phase clk by start-time quartile:', [int(g[o[i * q:(i + 1) * q], 0].astype(float).mean()) for i in range(4)], 'start spread us', (g[:, 15].max() - g[:, 15].min()) / 100.0)
+            print('   level width', int(wv), 'records', len(g), 'mean clk', g[:, :3].astype(float).mean(axis=0).round(), 'span us', (g[:, 13].max() - g[:, 15].min()) / 100.0, 'mean residence us', (g[:, 13] - g[:, 15]).astype(float).mean() / 100)
     r = full[:, :8].astype(np.float64)
     tot = r.sum(axis=1)
     print(title, "records", len(r), "mean total clk", round(tot.mean()), "median", round(np.median(tot)), "p90", round(np.percentile(tot, 90)))
