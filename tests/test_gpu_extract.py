@@ -144,6 +144,33 @@ def test_pyramid_and_blur_paths(shape, params):
         assert np.array_equal(ex.blurred_level(0, l), o.level_blurred(l)), f"blurred level {l}"
 
 
+@pytest.mark.parametrize("shape,params", [
+    ((120, 86), (300, 1.2, 1, 20, 7)),      # one column of 57-px-wide cells: the 80-byte tile (32 lanes per tile row)
+    ((88, 130), (300, 1.2, 1, 20, 7)),      # one row of 59-px-tall cells: a second chunk of tile rows
+    ((88, 87), (200, 1.2, 1, 12, 5)),       # a single 58 x 59 cell
+    ((200, 150), (400, 1.2, 3, 20, 7)),     # 45-px cells: the 64-byte tile
+    ((140, 164), (400, 1.1, 2, 20, 7)),     # 44-px cells: the widest the 52-byte tile takes
+])
+def test_every_tile_class_of_the_fast_kernel(shape, params):
+    """k_fast_cells has three instantiations (tile row 52 / 64 / 80 bytes) chosen by the widest cell, and its tile loader
+    works in chunks of 44 (22) rows: small images with one or two cells per row reach the wide and tall cases."""
+    for seed, kind in ((5, 0), (6, 1)):
+        img = synth_frame(seed, w=shape[1], h=shape[0]) if kind == 0 else \
+            np.random.default_rng(seed).integers(0, 256, shape, dtype=np.uint8)
+        o = oracle.OrbOracle(*params)
+        okps, odesc = o.extract(img)
+        ex = ORBextractor(*params)
+        kps, desc = ex(img)
+        assert len(okps) > 0
+        _kp_equal(kps, okps)
+        assert np.array_equal(desc, odesc)
+        for l in range(params[2]):
+            ref, got = o.level_cands(l), ex.level_candidates(0, l)
+            assert len(got) == len(ref), f"level {l}: {len(got)} vs {len(ref)} candidates"
+            assert np.array_equal(got[:, 0], ref["x"]) and np.array_equal(got[:, 1], ref["y"])
+            assert np.array_equal(got[:, 2], ref["response"])
+
+
 def test_sparse_image_threshold_fallback_and_short_levels():
     # few weak corners: exercises the minThFAST fallback and levels below quota
     rng = np.random.default_rng(5)
