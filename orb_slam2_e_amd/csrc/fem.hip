@@ -563,6 +563,99 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
     if (sg.chunk == 0 && threadIdx.x == 0) { sc[sg.mesh].rz[cur ^ 1] = rz2; sc[sg.mesh].rr = rr; }
 }
 
+// Batches: the vector half of an iteration in one launch, one 1024-thread workgroup per mesh.  alpha and beta are per
+// mesh, so a mesh's workgroup needs nobody else: alpha = rz / pAp; x += alpha p; r -= alpha Ap; rz' = r.(r/diag) and
+// rr = r.r summed by the workgroup (thread-strided partials, wave butterflies, the waves in order: fixed order, no
+// atomics); beta = rz' / rz; p = r/diag + beta p.  Rows go through in blocks of CGS_U x 1024 with all loads of a block in
+// flight together (one memory round trip per block and phase).  A single mesh (the reference's own use, one mesh per
+// PoseOptimizationNR call) keeps the two launches above: there one workgroup is one CU's bandwidth, ~100 are the chip's.
+constexpr int CGS_T = 1024, CGS_U = 10, CGS_MIN_MESHES = 16;
+__global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int nchunk_s, int cur, CgScal *__restrict__ sc,
+                                                       const double *__restrict__ part_pAp, double *__restrict__ p,
+                                                       const double *__restrict__ Ap, const double *__restrict__ dinv,
+                                                       double *__restrict__ x, double *__restrict__ r,
+                                                       const int4 *__restrict__ minfo, const int4 *__restrict__ minfo_s)
+{
+    __shared__ double sh[CGS_T / 64];
+    const int mesh = blockIdx.x;
+    const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
+    const int nrows = minfo ? minfo[mesh].y : ndof;
+    const int sp0 = minfo_s ? minfo_s[mesh].z : mesh * nchunk_s, snp = minfo_s ? minfo_s[mesh].w : nchunk_s;
+    const double rz = sc[mesh].rz[cur];
+    const double alpha = rz / chunk_sum(part_pAp + sp0, snp);
+    double s1 = 0, s2 = 0;
+    if (nrows <= CGS_U * CGS_T) {
+        // the whole mesh in one block: p and r/diag stay in registers across the reduction -- 5 vector reads and 3 writes
+        double pv[CGS_U], zv[CGS_U];
+        {
+            double av[CGS_U], rv[CGS_U], xv[CGS_U], dv[CGS_U];
+#pragma unroll
+            for (int u = 0; u < CGS_U; ++u) {   // clamped index: unconditional loads, all in flight together
+                const size_t g = row0 + min(u * CGS_T + (int)threadIdx.x, nrows - 1);
+                pv[u] = p[g]; av[u] = Ap[g]; rv[u] = r[g]; xv[u] = x[g]; dv[u] = dinv[g];
+            }
+#pragma unroll
+            for (int u = 0; u < CGS_U; ++u) {
+                const int i = u * CGS_T + (int)threadIdx.x;
+                const double ri = rv[u] - alpha * av[u];
+                zv[u] = ri * dv[u];
+                if (i < nrows) {
+                    const size_t g = row0 + i;
+                    x[g] = xv[u] + alpha * pv[u];
+                    r[g] = ri;
+                    s1 += ri * zv[u];
+                    s2 += ri * ri;
+                }
+            }
+        }
+        const double rz2 = block_sum(s1, sh), rr = block_sum(s2, sh);
+        const double beta = rz2 / rz;
+#pragma unroll
+        for (int u = 0; u < CGS_U; ++u) {
+            const int i = u * CGS_T + (int)threadIdx.x;
+            if (i < nrows) p[row0 + i] = zv[u] + beta * pv[u];
+        }
+        if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
+        return;
+    }
+    for (int base = 0; base < nrows; base += CGS_U * CGS_T) {
+        double pv[CGS_U], av[CGS_U], rv[CGS_U], xv[CGS_U], dv[CGS_U];
+#pragma unroll
+        for (int u = 0; u < CGS_U; ++u) {
+            const size_t g = row0 + min(base + u * CGS_T + (int)threadIdx.x, nrows - 1);
+            pv[u] = p[g]; av[u] = Ap[g]; rv[u] = r[g]; xv[u] = x[g]; dv[u] = dinv[g];
+        }
+#pragma unroll
+        for (int u = 0; u < CGS_U; ++u) {
+            const int i = base + u * CGS_T + (int)threadIdx.x;
+            if (i < nrows) {
+                const size_t g = row0 + i;
+                x[g] = xv[u] + alpha * pv[u];
+                const double ri = rv[u] - alpha * av[u];
+                r[g] = ri;
+                s1 += ri * (ri * dv[u]);
+                s2 += ri * ri;
+            }
+        }
+    }
+    const double rz2 = block_sum(s1, sh), rr = block_sum(s2, sh);
+    const double beta = rz2 / rz;
+    for (int base = 0; base < nrows; base += CGS_U * CGS_T) {   // r[g]: this thread's own stores of the first phase
+        double pv[CGS_U], rv[CGS_U], dv[CGS_U];
+#pragma unroll
+        for (int u = 0; u < CGS_U; ++u) {
+            const size_t g = row0 + min(base + u * CGS_T + (int)threadIdx.x, nrows - 1);
+            pv[u] = p[g]; rv[u] = r[g]; dv[u] = dinv[g];
+        }
+#pragma unroll
+        for (int u = 0; u < CGS_U; ++u) {
+            const int i = base + u * CGS_T + (int)threadIdx.x;
+            if (i < nrows) p[row0 + i] = rv[u] * dv[u] + beta * pv[u];
+        }
+    }
+    if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
+}
+
 // FEA2 is a stack object per PoseOptimizationNR call (Optimizer.cc:480): a model is created and destroyed every
 // frame with nearly the same sizes.  Device blocks, pinned blocks and streams are therefore recycled through
 // small process-wide caches (size classes = powers of two, blocks above 64 MiB are not kept), so a steady-state
@@ -716,6 +809,14 @@ void launch_iter(fem_model *m, hipStream_t st)
     m->prof.start(2, st);
     launch_spmv(m, st);
     m->prof.stop(2, st);
+    if (m->nseg >= CGS_MIN_MESHES) {
+        m->prof.start(3, st);
+        hipLaunchKernelGGL(k_fem_cg_step, dim3(m->nseg), dim3(CGS_T), 0, st, m->ndof, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
+                           m->d_Ap, m->d_dinv, m->d_x, m->d_r, (const int4 *)m->d_minfo, (const int4 *)m->d_minfo_s);
+        m->prof.stop(3, st);
+        m->cg_it++;
+        return;
+    }
     m->prof.start(3, st);
     hipLaunchKernelGGL(k_fem_cg_update, g, dim3(CGT), 0, st, m->ndof, m->nchunk, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
                        m->d_Ap, m->d_dinv, m->d_x, m->d_r, m->d_part[1], m->d_part[2], (const int *)m->d_cmesh,
@@ -909,7 +1010,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         ORBX_HIP(hipMemcpy(m->d_minfo, minfo.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(m->d_minfo_s, minfo_s.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
     }
-    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
+    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};   // batches of 16+ meshes: slot 3 times k_fem_cg_step, which does both
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
     if (m->spmv_lds > 48 * 1024)
         ORBX_HIP(hipFuncSetAttribute(m->spb == 32 ? reinterpret_cast<const void *>(k_fem_spmv<32>) : reinterpret_cast<const void *>(k_fem_spmv<64>),
