@@ -437,7 +437,7 @@ __global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, co
 // partial p.Ap.  HBM sees every matrix byte exactly once.
 // SPB = rows per workgroup: 64 for batches (fewest row-pointer reads per byte streamed),
 // 32 when the whole launch would otherwise be under ~2 workgroups per CU (one small mesh).
-constexpr int SPU4 = 3;  // independent 16-byte (val, col) load pairs in flight per lane
+constexpr int SPU3 = 4;  // independent (values, index) triples in flight per lane
 template <int N> __device__ __forceinline__ double dpp_shl_f64(double v)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
@@ -447,7 +447,7 @@ template <int N> __device__ __forceinline__ double dpp_shl_f64(double v)
 }
 
 template <int SPB>
-__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ lcol,
+__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ tcol,
                                                   const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
                                                   double *__restrict__ part_pAp, const int *__restrict__ cmesh,
@@ -462,29 +462,30 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
     const float *v = vals + sg.voff;
     // uniform layout: one column-index array for all meshes (shared topology): it stays in L2, HBM streams the values only;
     // segmented layout: every mesh has its own (global) column indices, streamed from HBM beside the values
-    const int *cidx = lcol;
     const size_t vbase = (size_t)sg.row0 - sg.tab0;   // batch-vector index of rowptr's row 0: mesh * ndof, or 0
     const double *pm = p + vbase;
-    // aligned 16-byte streams: start at ka = k0 rounded down to a multiple of 4 (the per-mesh stride is a multiple of
-    // 4).  No per-element predicate: every quad is loaded, gathered, multiplied and parked at prod[k - ka]; the up to 3
-    // entries before k0 and after k1 are neighbours' non-zeros (valid columns; the padding tail of lcol is zeroed) whose
-    // products phase 2 never reads; lanes beyond the end repeat the last quad (same values to the same slots).
-    const int ka = k0 & ~3, klast = (k1 - 1) & ~3;
-    for (int k = ka + 4 * tid; k < k1; k += SPU4 * 4 * CGT) {
-        float4 va[SPU4]; int4 ca[SPU4];
-        int kk[SPU4];
+    // A row holds whole node blocks: its non-zeros come in triples with the columns 3c, 3c+1, 3c+2 (build_symbolic), and
+    // rowptr is a multiple of 3 everywhere.  A lane takes a triple: 12 bytes of values (one dwordx3; consecutive lanes read
+    // consecutive memory), ONE column index from the per-triple array tcol (a third of the index bytes) and three
+    // consecutive entries of p.  The kernel is bound by the gathers of p (one texture-addresser access per lane and load):
+    // per non-zero this is 2/3 of a gather and 1/3 of an index load instead of one each.  No predicate: lanes past the
+    // run repeat its last triple (same values to the same slots).
+    const int ka = k0, nt = (k1 - k0) / 3;
+    const int *tc = tcol + k0 / 3;
+    for (int t = tid; t < nt; t += SPU3 * CGT) {
+        float va[SPU3][3]; int ca[SPU3], tt[SPU3];
 #pragma unroll
-        for (int u = 0; u < SPU4; ++u) { // clamped index: unconditional loads, all in flight together
-            kk[u] = min(k + u * 4 * CGT, klast);
-            va[u] = *reinterpret_cast<const float4 *>(v + kk[u]);
-            ca[u] = *reinterpret_cast<const int4 *>(cidx + kk[u]);
+        for (int u = 0; u < SPU3; ++u) { // clamped index: unconditional loads, all in flight together
+            tt[u] = min(t + u * CGT, nt - 1);
+            __builtin_memcpy(va[u], v + k0 + 3 * tt[u], 12);
+            ca[u] = tc[tt[u]];
         }
 #pragma unroll
-        for (int u = 0; u < SPU4; ++u) {
-            const double p0 = pm[ca[u].x], p1 = pm[ca[u].y], p2 = pm[ca[u].z], p3 = pm[ca[u].w];
-            double2 *dst = reinterpret_cast<double2 *>(prod + (kk[u] - ka));
-            dst[0] = make_double2((double)va[u].x * p0, (double)va[u].y * p1);
-            dst[1] = make_double2((double)va[u].z * p2, (double)va[u].w * p3);
+        for (int u = 0; u < SPU3; ++u) {
+            const double *pp = pm + ca[u];
+            const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            double *dst = prod + 3 * tt[u];
+            dst[0] = (double)va[u][0] * p0; dst[1] = (double)va[u][1] * p1; dst[2] = (double)va[u][2] * p2;
         }
     }
     __syncthreads();
@@ -745,7 +746,7 @@ struct fem_model {
     // device
     float *d_nodes = nullptr, *d_ke = nullptr, *d_vals = nullptr, *d_a = nullptr, *d_f = nullptr, *d_u = nullptr, *d_e = nullptr;
     int *d_elems = nullptr, *d_blk_row = nullptr, *d_bptr = nullptr, *d_cptr = nullptr, *d_contrib = nullptr;
-    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr;
+    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr, *d_tcol = nullptr;
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -763,7 +764,7 @@ void fem_free(fem_model *m)
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
                     m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s, m->d_nel_ptr, m->d_nel, m->d_contrib_loc,
-                    m->d_ke1};
+                    m->d_ke1, m->d_tcol};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -798,7 +799,7 @@ inline dim3 grid_spmv(const fem_model *m) { return m->segmented() ? dim3(m->nchu
 void launch_spmv(fem_model *m, hipStream_t st)
 {
     hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, grid_spmv(m), dim3(CGT), m->spmv_lds, st,
-                       m->d_vals, m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
+                       m->d_vals, m->d_tcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
                        (const int *)m->d_cmesh_s, (const int4 *)m->d_minfo_s);
 }
 
@@ -983,7 +984,8 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     else bad |= dalloc(&m->d_nel_ptr, (size_t)nn + 1) | dalloc(&m->d_nel, y.nel.size()) | dalloc(&m->d_contrib_loc, y.contrib_loc.size());
     bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
     bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, y.contrib.size());
-    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof);
+    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof) |
+           dalloc(&m->d_tcol, (size_t)m->nnz / 3 + 1);
     if (seg_nn) bad |= dalloc(&m->d_cmesh, cmesh.size()) | dalloc(&m->d_cmesh_s, cmesh_s.size()) | dalloc(&m->d_minfo, (size_t)nseg) | dalloc(&m->d_minfo_s, (size_t)nseg);
     if (bad || !(m->stream = stream_get())) {
         fem_free(m); delete m;
@@ -1003,6 +1005,11 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
     ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
+    {   // first column of every non-zero triple (k_fem_spmv)
+        std::vector<int> tcol((size_t)m->nnz / 3);
+        for (size_t i = 0; i < tcol.size(); ++i) tcol[i] = m->h_lcol[3 * i];
+        ORBX_HIP(hipMemcpy(m->d_tcol, tcol.data(), sizeof(int) * tcol.size(), hipMemcpyHostToDevice));
+    }
     ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
     if (seg_nn) {
         ORBX_HIP(hipMemcpy(m->d_cmesh, cmesh.data(), sizeof(int) * cmesh.size(), hipMemcpyHostToDevice));
