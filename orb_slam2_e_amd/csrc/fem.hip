@@ -437,7 +437,7 @@ __global__ void k_fem_cg_init2(int nchunk, const double *__restrict__ part_a, co
 // partial p.Ap.  HBM sees every matrix byte exactly once.
 // SPB = rows per workgroup: 64 for batches (fewest row-pointer reads per byte streamed),
 // 32 when the whole launch would otherwise be under ~2 workgroups per CU (one small mesh).
-constexpr int SPU3 = 4;  // independent (values, index) triples in flight per lane
+constexpr int SPUB = 2;  // independent 3 x 3 blocks in flight per lane
 template <int N> __device__ __forceinline__ double dpp_shl_f64(double v)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
@@ -446,58 +446,77 @@ template <int N> __device__ __forceinline__ double dpp_shl_f64(double v)
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
+// The CG works on a block-major copy of the values (fem_cg_setup): the matrix is made of 3 x 3 node blocks
+// (build_symbolic: the rows 3I, 3I+1, 3I+2 hold the same columns, in triples 3c, 3c+1, 3c+2), block q of block row I
+// (q = bp[I] + j) keeps its nine values together, row-major, at 9 q.  One thread per row.
+__global__ __launch_bounds__(256) void k_fem_to_blocks(const float *__restrict__ vals, float *__restrict__ vals_b,
+                                                       const int *__restrict__ rowptr, const int *__restrict__ bp, int nrows, size_t nnz)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    const int I = row / 3, i = row - 3 * I, nb = bp[I + 1] - bp[I];
+    const float *src = vals + (size_t)blockIdx.y * nnz + rowptr[row];
+    float *dst = vals_b + (size_t)blockIdx.y * nnz + 9 * (size_t)bp[I] + 3 * i;
+    for (int j = 0; j < nb; ++j) {
+        dst[9 * j] = src[3 * j]; dst[9 * j + 1] = src[3 * j + 1]; dst[9 * j + 2] = src[3 * j + 2];
+    }
+}
+
+// Ap = K p on the block-major values, workgroup = SPB consecutive rows (a multiple of 3: whole block rows) of one mesh =
+// one contiguous run of blocks.  Phase 1, a lane per block: its first column (4 bytes), its nine values (36 contiguous
+// bytes, consecutive lanes read consecutive memory) and ONE gather of three consecutive entries of p for all nine
+// products; the block's three row sums are parked in LDS.  The kernel is bound by the texture addresser (76 % busy in
+// the row-major form, one access per lane and load whatever its width): per non-zero this is 2/9 of a gather, 3/9 of a
+// value load and 1/9 of an index load, where the row-major forms needed 1 + 1/4 + 1/4 (quads) or 2/3 + 1/3 + 1/3
+// (triples).  No predicate: lanes past the run repeat its last block (same values to the same slots).  Phase 2: 8 lanes
+// per row sum its blocks' partials from LDS, DPP `row_shl` reduce in a fixed order, fused p.Ap partial.
 template <int SPB>
-__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals, const int *__restrict__ tcol,
-                                                  const int *__restrict__ rowptr, size_t nnz, int ndof, int nchunk,
+__global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals_b, const int *__restrict__ bcol3,
+                                                  const int *__restrict__ bp, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
                                                   double *__restrict__ part_pAp, const int *__restrict__ cmesh,
                                                   const int4 *__restrict__ minfo)
 {
-    extern __shared__ __align__(16) double prod[];
+    extern __shared__ __align__(16) double part[];   // [blocks of the run][3]
     __shared__ double sh[CGT / 64];
     const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, nnz);
     const int tid = threadIdx.x;
-    const int r0 = sg.tab0 + sg.chunk * SPB, r1 = min(r0 + SPB, sg.tab0 + sg.nrows); // rows as rowptr numbers them
-    const int k0 = rowptr[r0], k1 = rowptr[r1];
-    const float *v = vals + sg.voff;
-    // uniform layout: one column-index array for all meshes (shared topology): it stays in L2, HBM streams the values only;
+    const int r0 = sg.tab0 + sg.chunk * SPB, r1 = min(r0 + SPB, sg.tab0 + sg.nrows); // rows as the tables number them
+    const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
+    // uniform layout: one index array for all meshes (shared topology): it stays in L2, HBM streams the values only;
     // segmented layout: every mesh has its own (global) column indices, streamed from HBM beside the values
-    const size_t vbase = (size_t)sg.row0 - sg.tab0;   // batch-vector index of rowptr's row 0: mesh * ndof, or 0
+    const float *v = vals_b + sg.voff + 9 * (size_t)q0;
+    const int *bc = bcol3 + q0;
+    const size_t vbase = (size_t)sg.row0 - sg.tab0;   // batch-vector index of the tables' row 0: mesh * ndof, or 0
     const double *pm = p + vbase;
-    // A row holds whole node blocks: its non-zeros come in triples with the columns 3c, 3c+1, 3c+2 (build_symbolic), and
-    // rowptr is a multiple of 3 everywhere.  A lane takes a triple: 12 bytes of values (one dwordx3; consecutive lanes read
-    // consecutive memory), ONE column index from the per-triple array tcol (a third of the index bytes) and three
-    // consecutive entries of p.  The kernel is bound by the gathers of p (one texture-addresser access per lane and load):
-    // per non-zero this is 2/3 of a gather and 1/3 of an index load instead of one each.  No predicate: lanes past the
-    // run repeat its last triple (same values to the same slots).
-    const int ka = k0, nt = (k1 - k0) / 3;
-    const int *tc = tcol + k0 / 3;
-    for (int t = tid; t < nt; t += SPU3 * CGT) {
-        float va[SPU3][3]; int ca[SPU3], tt[SPU3];
+    for (int q = tid; q < nq; q += SPUB * CGT) {
+        float va[SPUB][9]; int ca[SPUB], qq[SPUB];
 #pragma unroll
-        for (int u = 0; u < SPU3; ++u) { // clamped index: unconditional loads, all in flight together
-            tt[u] = min(t + u * CGT, nt - 1);
-            __builtin_memcpy(va[u], v + k0 + 3 * tt[u], 12);
-            ca[u] = tc[tt[u]];
+        for (int u = 0; u < SPUB; ++u) { // clamped index: unconditional loads, all in flight together
+            qq[u] = min(q + u * CGT, nq - 1);
+            __builtin_memcpy(va[u], v + 9 * qq[u], 36);
+            ca[u] = bc[qq[u]];
         }
 #pragma unroll
-        for (int u = 0; u < SPU3; ++u) {
+        for (int u = 0; u < SPUB; ++u) {
             const double *pp = pm + ca[u];
             const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
-            double *dst = prod + 3 * tt[u];
-            dst[0] = (double)va[u][0] * p0; dst[1] = (double)va[u][1] * p1; dst[2] = (double)va[u][2] * p2;
+            double *dst = part + 3 * qq[u];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                dst[i] = ((double)va[u][3 * i] * p0 + (double)va[u][3 * i + 1] * p1) + (double)va[u][3 * i + 2] * p2;
         }
     }
     __syncthreads();
     const int sub = tid / LPR, sl = tid % LPR;
     double acc = 0;
 #pragma unroll
-    for (int pass = 0; pass < SPB / (CGT / LPR); ++pass) {
+    for (int pass = 0; pass < (SPB + CGT / LPR - 1) / (CGT / LPR); ++pass) {
         const int row = r0 + pass * (CGT / LPR) + sub;
         double s = 0;
         if (row < r1) {
-            const int e = rowptr[row + 1] - ka;
-            for (int k = rowptr[row] - ka + sl; k < e; k += LPR) s += prod[k];
+            const int I = row / 3, i = row - 3 * I, b0 = bp[I] - q0, nb = bp[I + 1] - bp[I];
+            for (int j = sl; j < nb; j += LPR) s += part[3 * (b0 + j) + i];
         }
         // sum of the 8 lanes of a row into its lane 0: DPP row_shl (lane i reads lane i+n of its 16-lane row), fixed order
         s += dpp_shl_f64<4>(s);
@@ -723,7 +742,7 @@ struct fem_model {
     unsigned int E;
     float nu, fg, lambda, G;
     FemConst fc;
-    std::vector<int> h_rowptr, h_lcol, h_diag;
+    std::vector<int> h_rowptr, h_lcol, h_diag, h_bp;
     // segmented layout (fem_create_batch): nseg meshes of their own sizes concatenated; nmesh == 1 then and nn / ne / ndof /
     // nnz are the totals.  Uniform layout: nseg == nmesh, no tables.
     int nseg = 0, nchunk_tot = 0, nchunk_s_tot = 0;
@@ -746,7 +765,8 @@ struct fem_model {
     // device
     float *d_nodes = nullptr, *d_ke = nullptr, *d_vals = nullptr, *d_a = nullptr, *d_f = nullptr, *d_u = nullptr, *d_e = nullptr;
     int *d_elems = nullptr, *d_blk_row = nullptr, *d_bptr = nullptr, *d_cptr = nullptr, *d_contrib = nullptr;
-    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr, *d_tcol = nullptr;
+    int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr, *d_bcol3 = nullptr, *d_bp = nullptr;
+    float *d_vals_b = nullptr;   // block-major copy of d_vals for the CG (fem_cg_setup)
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -764,7 +784,7 @@ void fem_free(fem_model *m)
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
                     m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s, m->d_nel_ptr, m->d_nel, m->d_contrib_loc,
-                    m->d_ke1, m->d_tcol};
+                    m->d_ke1, m->d_bcol3, m->d_bp, m->d_vals_b};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -787,7 +807,7 @@ int ensure_cg(fem_model *m)
     if (m->d_b) return 0;
     if (dalloc(&m->d_b, N) || dalloc(&m->d_x, N) || dalloc(&m->d_r, N) || dalloc(&m->d_p, N) || dalloc(&m->d_Ap, N) ||
         dalloc(&m->d_dinv, N) || dalloc(&m->d_part[0], C) || dalloc(&m->d_part[1], C) || dalloc(&m->d_part[2], C) ||
-        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nseg))
+        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nseg) || dalloc(&m->d_vals_b, (size_t)m->nmesh * m->nnzs))
         return -1;
     return 0;
 }
@@ -798,8 +818,8 @@ inline dim3 grid_spmv(const fem_model *m) { return m->segmented() ? dim3(m->nchu
 
 void launch_spmv(fem_model *m, hipStream_t st)
 {
-    hipLaunchKernelGGL(m->spb == 32 ? k_fem_spmv<32> : k_fem_spmv<64>, grid_spmv(m), dim3(CGT), m->spmv_lds, st,
-                       m->d_vals, m->d_tcol, m->d_rowptr, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
+    hipLaunchKernelGGL(m->spb == 48 ? k_fem_spmv<48> : k_fem_spmv<96>, grid_spmv(m), dim3(CGT), m->spmv_lds, st,
+                       m->d_vals_b, m->d_bcol3, m->d_bp, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
                        (const int *)m->d_cmesh_s, (const int4 *)m->d_minfo_s);
 }
 
@@ -937,9 +957,9 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     std::vector<int> cmesh, cmesh_s;
     std::vector<int4> minfo, minfo_s;
     size_t rows_of_blocks = 0;
-    if (seg_nn) for (int k = 0; k < nseg; ++k) rows_of_blocks += (size_t)(3 * seg_nn[k] + 63) / 64;
-    else rows_of_blocks = (size_t)nmesh * ((m->ndof + 63) / 64);
-    m->spb = rows_of_blocks < 512 ? 32 : 64;
+    if (seg_nn) for (int k = 0; k < nseg; ++k) rows_of_blocks += (size_t)(3 * seg_nn[k] + 95) / 96;
+    else rows_of_blocks = (size_t)nmesh * ((m->ndof + 95) / 96);
+    m->spb = rows_of_blocks < 512 ? 48 : 96;   // multiples of 3: a workgroup's rows are whole node-block rows (k_fem_spmv)
     const int SPB = m->spb;
     m->nchunk = (m->ndof + RPB - 1) / RPB;
     m->nchunk_s = (m->ndof + SPB - 1) / SPB;
@@ -969,8 +989,9 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     } else {
         scan_runs(0, m->ndof);
     }
-    if (maxrun * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
-    m->spmv_lds = (maxrun + 8) * (int)sizeof(double); // + the quads' slack either side of a row block
+    // k_fem_spmv parks three row sums per 3 x 3 block of a workgroup's run: maxrun / 9 blocks
+    if (maxrun / 3 * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
+    m->spmv_lds = (maxrun / 3 + 8) * (int)sizeof(double);
 
     const size_t M = (size_t)nmesh;
     int bad = 0;
@@ -985,7 +1006,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
     bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, y.contrib.size());
     bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof) |
-           dalloc(&m->d_tcol, (size_t)m->nnz / 3 + 1);
+           dalloc(&m->d_bcol3, (size_t)m->nnz / 9 + 1) | dalloc(&m->d_bp, (size_t)m->ndof / 3 + 2);
     if (seg_nn) bad |= dalloc(&m->d_cmesh, cmesh.size()) | dalloc(&m->d_cmesh_s, cmesh_s.size()) | dalloc(&m->d_minfo, (size_t)nseg) | dalloc(&m->d_minfo_s, (size_t)nseg);
     if (bad || !(m->stream = stream_get())) {
         fem_free(m); delete m;
@@ -1005,10 +1026,20 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
     ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
-    {   // first column of every non-zero triple (k_fem_spmv)
-        std::vector<int> tcol((size_t)m->nnz / 3);
-        for (size_t i = 0; i < tcol.size(); ++i) tcol[i] = m->h_lcol[3 * i];
-        ORBX_HIP(hipMemcpy(m->d_tcol, tcol.data(), sizeof(int) * tcol.size(), hipMemcpyHostToDevice));
+    {   // node-block tables of k_fem_spmv: bp[I] = blocks before block row I, bcol3[q] = first column of block q
+        const int nbr = m->ndof / 3;
+        std::vector<int> bp((size_t)nbr + 1, 0), bcol3((size_t)m->nnz / 9);
+        size_t q = 0;
+        for (int I = 0; I < nbr; ++I) {
+            const int k0 = m->h_rowptr[3 * I], nb = (m->h_rowptr[3 * I + 1] - k0) / 3;
+            bp[I] = (int)q;
+            for (int j = 0; j < nb && q < bcol3.size(); ++j) bcol3[q++] = m->h_lcol[k0 + 3 * j];
+        }
+        bp[nbr] = (int)q;
+        if (q != bcol3.size()) { fem_free(m); delete m; ORBX_FAIL(ORBX_ERR_ARG, "matrix pattern is not made of 3 x 3 node blocks"); }
+        ORBX_HIP(hipMemcpy(m->d_bcol3, bcol3.data(), sizeof(int) * bcol3.size(), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(m->d_bp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice));
+        m->h_bp.swap(bp);
     }
     ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
     if (seg_nn) {
@@ -1020,7 +1051,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};   // batches of 16+ meshes: slot 3 times k_fem_cg_step, which does both
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
     if (m->spmv_lds > 48 * 1024)
-        ORBX_HIP(hipFuncSetAttribute(m->spb == 32 ? reinterpret_cast<const void *>(k_fem_spmv<32>) : reinterpret_cast<const void *>(k_fem_spmv<64>),
+        ORBX_HIP(hipFuncSetAttribute(m->spb == 48 ? reinterpret_cast<const void *>(k_fem_spmv<48>) : reinterpret_cast<const void *>(k_fem_spmv<96>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
     *out = m;
     return ORBX_OK;
@@ -1414,6 +1445,9 @@ int fem_cg_setup(fem_model *m, const double *b)
     if (ensure_cg(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice));
+    // the values as they stand now (assembled, penalties applied), block-major, for k_fem_spmv
+    hipLaunchKernelGGL(k_fem_to_blocks, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_vals_b, m->d_rowptr,
+                       m->d_bp, m->ndof, m->nnzs);
     hipLaunchKernelGGL(k_fem_cg_init, grid_cg(m), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnzs,
                        m->ndof, m->nchunk, m->d_b, m->d_x, m->d_r, m->d_p, m->d_dinv, m->d_part[0], m->d_part[1],
                        (const int *)m->d_cmesh, (const int4 *)m->d_minfo);
