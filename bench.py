@@ -142,13 +142,16 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         nblocks = 1 if distinct else nm                             # Ksize / nnz are totals for the concatenated batch
         spmv_bytes = nblocks * (nnz * 8 + (n + 1) * 4 + 2 * n * 8)  # nnz(val+4)+(n+1)4+2n*val', f32 K, f64 x/y
         iter_bytes = spmv_bytes + nblocks * (2 * 2 + 3 * 3) * n * 8
-        spb = 32 if nblocks * ((n + 63) // 64) < 512 and not distinct else 64
-        grid_threads = 256 * (sum((int(fea.dof0[k + 1] - fea.dof0[k]) + 63) // 64 for k in range(nm)) if distinct else nm * ((n + spb - 1) // spb))
+        spb = 48 if nblocks * ((n + 95) // 96) < 512 and not distinct else 96      # rows per SpMV workgroup (fem.hip: create_model)
+        grid_threads = 256 * (sum((int(fea.dof0[k + 1] - fea.dof0[k]) + 95) // 96 for k in range(nm)) if distinct else nm * ((n + spb - 1) // spb))
+        # what the kernel's 3 x 3 block form needs: values, ONE column index per block (nnz / 9), block-row table, x and y
+        # (shared topology: the index and block-row tables once -- every mesh reads them, L2 serves them)
+        block_bytes = nblocks * (nnz * 4 + 2 * n * 8) + (nnz // 9) * 4 + (n // 3 + 1) * 4
         out[label] = {"meshes_per_gpu": nm, "n_dof": n, "nnz": nnz, "cg_iters": iters, "create_ms": t_create * 1e3,
                       "spmv_grid_threads": grid_threads,
                       "cg_mesh_iters_per_s": world * nm * iters / dt, "ms_per_iter": dt / iters * 1e3,
                       "assemble_ms": t_asm * 1e3, "relres_after": float(rel.max()),
-                      "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes,
+                      "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes, "spmv_block_form_bytes_per_launch": block_bytes,
                       "spmv_GBps": spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
                       "cg_iter_GBps": iter_bytes * iters / dt / 1e9,
                       "displacements_gathered": None if xall is None else list(xall.shape),
@@ -170,6 +173,11 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         rf = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None,
               "avg_launch_ms": bt["spmv_avg_launch_ms"], "alg_bytes_per_launch": bt["spmv_alg_bytes_per_launch"],
+              "note": "achieved / frac charge SURVEY 8(d)'s CSR bytes (4 index bytes per non-zero); the kernel works on 3 x 3 node "
+                      "blocks and reads ONE index per nine values, so it needs block_form_bytes_per_launch only -- "
+                      "frac_block_form and frac_of_counter_traffic are what HBM is asked for and delivers",
+              "block_form_bytes_per_launch": bt["spmv_block_form_bytes_per_launch"],
+              "frac_block_form": (bt["spmv_block_form_bytes_per_launch"] / (bt["spmv_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if bt["spmv_avg_launch_ms"] > 0 else None,
               "batch": "one topology shared by all meshes (one column-index array, L2-resident)" if label == "batch" else
                        "every mesh its own topology (its own column indices, streamed from HBM)"}
         tr = traffic.get(f"k_fem_spmv@{bt['spmv_grid_threads']}") if nmesh == 256 else None   # PMC passes: the 256-mesh batches

@@ -9,7 +9,7 @@ usage: prof_traffic.py gpurun_out/<dir> profiles/rNN_traffic.json "<source note>
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-STREAM16 = {"k_fem_spmv"}          # 16-byte-per-lane streaming reads: FETCH_SIZE x2
+STREAM16 = {"k_fem_spmv"}          # wide streaming reads: FETCH_SIZE x2 (calibrated at 16 B per lane; 12 B per lane since the block form: upper bound)
 
 
 def short(n):
@@ -44,7 +44,7 @@ for k in sorted(fetch):
     f, w = fetch[k], write.get(k, 0.0)
     x2 = k.split("@")[0] in STREAM16
     res[k] = {"hbm_bytes_per_launch": (2 * f if x2 else f) + w, "fetch_size_bytes_raw": f, "write_size_bytes": w,
-              "fetch_correction": "x2 (16-B/lane streaming loads, gfx950)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
+              "fetch_correction": "x2 (gfx950 correction calibrated on 16-B/lane streaming loads; the block-form k_fem_spmv streams 12 B per lane, so this is an upper bound -- the raw value is kept beside it)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
               "valu_wave_insts_per_launch": valu.get(k), "source": note}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in res.items()}, indent=1))
