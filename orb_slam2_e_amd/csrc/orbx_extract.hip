@@ -1176,29 +1176,37 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     // The 37x37 blurred window of steered BRIEF (|offset| <= 18) is staged in LDS as 37 rows of 10 dwords starting at
     // (x-18, y-18); every lane owns six fixed dwords of it (dword jj*64 + lane).  The windows are loaded PD keypoints
     // ahead of their use, the first ones together with the moment windows: they depend on the keypoint's position only
-    constexpr int PR = 18, PW = 10, PD = DESC_PD; // patch radius; row = 10 dwords = bytes x-18 .. x+21; prefetch distance
-    int prow[6], pcol[6];
+    constexpr int PR = 18, PW = 10, PD = DESC_PD, NPL = 3; // patch radius; row = 10 dwords = bytes x-18 .. x+21; prefetch distance; loads per lane
+    // lane d (+ 64 jj) owns the 8-byte piece d % 5 of row d / 5: three 8-byte loads per window instead of six dwords
+    uint32_t poff[NPL]; int pslot[NPL];
 #pragma unroll
-    for (int jj = 0; jj < 6; ++jj) {
-        const int d = lane + 64 * jj;
-        prow[jj] = d < (2 * PR + 1) * PW ? d / PW : -1;
-        pcol[jj] = 4 * (d % PW);
+    for (int jj = 0; jj < NPL; ++jj) {
+        const int d = lane + 64 * jj, dd = min(d, (2 * PR + 1) * 5 - 1);   // pieces past the window repeat its last one
+        poff[jj] = (uint32_t)(__mul24(dd / 5, stride) + 8 * (dd % 5));
+        pslot[jj] = 2 * dd;
     }
-    uint32_t nxt[PD][6];
-    auto load_patch = [&](int j, uint32_t (&r)[6]) {   // unused slots read slot 0's window (no branch in front of a load)
+    uint2 nxt[PD][NPL];
+    auto load_patch = [&](int j, uint2 (&r)[NPL]) {   // unused slots read slot 0's window (no branch in front of a load)
         const int kp = wv * (DESC_KPB / 4) + j, kpv = s_valid[kp] ? kp : 0;
         const uint8_t *win = fblur + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_coff[kpv]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj) r[jj] = load_u32_unaligned(win + (uint32_t)(__mul24(max(prow[jj], 0), stride) + pcol[jj]));
+        for (int jj = 0; jj < NPL; ++jj) __builtin_memcpy(&r[jj], win + poff[jj], 8);
     };
+    // IC_Angle window, 31 rows x 32 bytes from (x-15, y-15): lane d (+ 64 jj) owns the 8-byte piece d % 4 of row d / 4 (dwords
+    // 2 (d % 4) and + 1 of that row): two 8-byte loads per keypoint instead of four dwords; pieces past row 30 re-read row 0 with
+    // weights 0
     int wU[4], wV[4];
-    int vrow[4], doff[4];
+    uint32_t moff[2];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int d = lane + 64 * jj;
-        const bool in = d < 248;
-        wU[jj] = in ? (int)c_momw.u[d] : 0; wV[jj] = in ? (int)c_momw.v[d] : 0;
-        vrow[jj] = (in ? d : 0) >> 3; doff[jj] = 4 * (d & 7);
+    for (int jj = 0; jj < 2; ++jj) {
+        const int d = lane + 64 * jj, row = d >> 2, piece = d & 3;
+        const bool in = row < 31;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int w = in ? 8 * row + 2 * piece + k : 0;
+            wU[2 * jj + k] = in ? (int)c_momw.u[w] : 0; wV[2 * jj + k] = in ? (int)c_momw.v[w] : 0;
+        }
+        moff[jj] = (uint32_t)(__mul24(in ? row : 0, stride) + 8 * piece);
     }
     {
         uint32_t px[DESC_KPB / 4][4];
@@ -1208,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             // wave-uniform value read from LDS: tell the compiler, so the loads take a scalar base + 32-bit lane offset
             const uint8_t *win = fpyr + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_coff[kpv]) - 15 - (ptrdiff_t)15 * stride; // (x-15, y-15)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) px[j][jj] = load_u32_unaligned(win + (uint32_t)(__mul24(vrow[jj], stride) + doff[jj]));
+            for (int jj = 0; jj < 2; ++jj) __builtin_memcpy(&px[j][2 * jj], win + moff[jj], 8);
         }
 #pragma unroll
         for (int j = 0; j < PD; ++j) load_patch(j, nxt[j]);
@@ -1259,8 +1267,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int kp = wv * (DESC_KPB / 4) + j;
         const float a = s_cos[kp], b = s_sin[kp];
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj)
-            if (prow[jj] >= 0) patch[lane + 64 * jj] = nxt[j % PD][jj];
+        for (int jj = 0; jj < NPL; ++jj) *reinterpret_cast<uint2 *>(patch + pslot[jj]) = nxt[j % PD][jj];
         if (j + PD < DESC_KPB / 4) load_patch(j + PD, nxt[j % PD]);
         if (!s_valid[kp]) continue;
         // patch centre, minus what the magic-number bits add: (0x400000 * 40 + 0x4B400000) mod 2^32
