@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     const int f = blockIdx.z, tid = threadIdx.x;
     ORBX_PH_INIT(2);
 #ifdef ORBX_PHASE_TIMING
-    if (tid == 0) ph_rec[12] = dst.w;
+    if (tid == 0) { ph_rec[12] = dst.w; ph_rec[11] = ((int)blockIdx.x < nff * ((nrg + rpw - 1) / rpw)) ? 1 : 0; }
 #endif
     const int xlo = (PADX - EDGE) >> 2, xhi = (PADX + dst.w + EDGE - 1) >> 2; // first / last dword that holds border or image bytes
     const int nrgw = (nrg + rpw - 1) / rpw;   // a full wave takes rpw consecutive row groups, one after the other

@@ -28,6 +28,9 @@ for k, (title, names) in enumerate([("k_fast_cells, per wave", ["tile load", "st
             g = full[full[:, 12] == wv]
             o = np.argsort(g[:, 15]); q = len(g) // 4
             print('      first-phase clk by start-time quartile:', [int(g[o[i * q:(i + 1) * q], 0].astype(float).mean()) for i in range(4)], 'start spread us', (g[:, 15].max() - g[:, 15].min()) / 100.0)
+            for fz in (1, 0):
+                gg = g[g[:, 11] == fz]
+                if len(gg): print('      %s waves: %d records, mean clk %s, mean residence %.2f us, last end - first start %.2f us' % ('full' if fz else 'tail', len(gg), gg[:, :3].astype(float).mean(axis=0).round(), (gg[:, 13] - gg[:, 15]).astype(float).mean() / 100, (gg[:, 13].max() - g[:, 15].min()) / 100.0))
             print('   level width', int(wv), 'records', len(g), 'mean clk', g[:, :3].astype(float).mean(axis=0).round(), 'span us', (g[:, 13].max() - g[:, 15].min()) / 100.0, 'mean residence us', (g[:, 13] - g[:, 15]).astype(float).mean() / 100)
     r = full[:, :8].astype(np.float64)
     tot = r.sum(axis=1)
