@@ -170,14 +170,16 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
     traffic = load_traffic()
     for key, label in (("roofline", "batch"), ("roofline_distinct_topologies", "batch_distinct_topologies")):
         bt = out[label]
-        rf = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": bt["spmv_GBps"], "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": bt["spmv_GBps"] / HBM_PEAK_GBS, "traffic": None,
-              "avg_launch_ms": bt["spmv_avg_launch_ms"], "alg_bytes_per_launch": bt["spmv_alg_bytes_per_launch"],
-              "note": "achieved / frac charge SURVEY 8(d)'s CSR bytes (4 index bytes per non-zero); the kernel works on 3 x 3 node "
-                      "blocks and reads ONE index per nine values, so it needs block_form_bytes_per_launch only -- "
-                      "frac_block_form and frac_of_counter_traffic are what HBM is asked for and delivers",
-              "block_form_bytes_per_launch": bt["spmv_block_form_bytes_per_launch"],
-              "frac_block_form": (bt["spmv_block_form_bytes_per_launch"] / (bt["spmv_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if bt["spmv_avg_launch_ms"] > 0 else None,
+        ms = bt["spmv_avg_launch_ms"]
+        blk_gbps = bt["spmv_block_form_bytes_per_launch"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rf = {"bound": "hbm", "kernel": "k_fem_spmv", "achieved": blk_gbps, "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": blk_gbps / HBM_PEAK_GBS, "traffic": None,
+              "avg_launch_ms": ms, "alg_bytes_per_launch": bt["spmv_block_form_bytes_per_launch"],
+              "note": "algorithmic bytes of the kernel's 3 x 3 node-block form: values, ONE column index per nine values, x and y. "
+                      "SURVEY 8(d)'s formula charges a CSR SpMV 4 index bytes per non-zero (survey_csr_bytes_per_launch); at this "
+                      "launch time that would read as frac_if_charged_survey_csr_bytes, bytes the kernel never moves",
+              "survey_csr_bytes_per_launch": bt["spmv_alg_bytes_per_launch"],
+              "frac_if_charged_survey_csr_bytes": bt["spmv_GBps"] / HBM_PEAK_GBS,
               "batch": "one topology shared by all meshes (one column-index array, L2-resident)" if label == "batch" else
                        "every mesh its own topology (its own column indices, streamed from HBM)"}
         tr = traffic.get(f"k_fem_spmv@{bt['spmv_grid_threads']}") if nmesh == 256 else None   # PMC passes: the 256-mesh batches
@@ -185,8 +187,8 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
             rf["traffic"] = tr["hbm_bytes_per_launch"]
             rf["traffic_source"] = tr["source"]
             if bt["spmv_avg_launch_ms"] > 0:
-                # what HBM really delivers (FETCH_SIZE x 2 + WRITE_SIZE of the PMC passes): with a shared topology the
-                # index array is served from L2, so the counter traffic is below SURVEY's algorithmic bytes
+                # what HBM delivers by the counters (FETCH_SIZE x 2 + WRITE_SIZE of the PMC passes; the x 2 is calibrated
+                # on 16-byte-per-lane streams, this kernel streams 12 bytes per lane: an upper bound)
                 rf["frac_of_counter_traffic"] = tr["hbm_bytes_per_launch"] / (bt["spmv_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         out[key] = rf
     return out
