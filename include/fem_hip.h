@@ -112,7 +112,11 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
 /* Jacobi-preconditioned conjugate gradients, double vectors on the float matrix:
  * K x = b per mesh, x0 = 0.  Runs until `iters` iterations, or earlier when every
  * mesh has ||r|| <= tol*||b|| (checked every 25 iterations; tol <= 0 disables).
- * b, x: [nmesh][ndof] double.  iters_done / relres[nmesh] may be NULL. */
+ * b, x: [nmesh][ndof] double.  iters_done / relres[nmesh] may be NULL.
+ * The solver works on a block-major copy of the matrix values (3 x 3 node blocks kept together), made from the values
+ * as they stand when fem_cg / fem_cg_setup is called: another 4 bytes per non-zero of device memory while a model has
+ * been solved with, and changes of K (assembly, penalties) after that call are seen by the next call, not by
+ * fem_cg_iterate. */
 int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int *iters_done, double *relres);
 
 /* Resident variants for timing: upload the right-hand side and reset the solver
