@@ -479,10 +479,12 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
 {
     extern __shared__ __align__(16) double part[];   // [blocks of the run][3]
     __shared__ double sh[CGT / 64];
+    __shared__ int s_bp[SPB / 3 + 1];                // the run's slice of bp: phase 2 reads it 16 times per row otherwise
     const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, nnz);
     const int tid = threadIdx.x;
     const int r0 = sg.tab0 + sg.chunk * SPB, r1 = min(r0 + SPB, sg.tab0 + sg.nrows); // rows as the tables number them
     const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
+    if (tid <= (r1 - r0) / 3) s_bp[tid] = bp[r0 / 3 + tid] - q0;
     // uniform layout: one index array for all meshes (shared topology): it stays in L2, HBM streams the values only;
     // segmented layout: every mesh has its own (global) column indices, streamed from HBM beside the values
     const float *v = vals_b + sg.voff + 9 * (size_t)q0;
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
         const int row = r0 + pass * (CGT / LPR) + sub;
         double s = 0;
         if (row < r1) {
-            const int I = row / 3, i = row - 3 * I, b0 = bp[I] - q0, nb = bp[I + 1] - bp[I];
+            const int I = (row - r0) / 3, i = row - r0 - 3 * I, b0 = s_bp[I], nb = s_bp[I + 1] - b0;
             for (int j = sl; j < nb; j += LPR) s += part[3 * (b0 + j) + i];
         }
         // sum of the 8 lanes of a row into its lane 0: DPP row_shl (lane i reads lane i+n of its 16-lane row), fixed order
