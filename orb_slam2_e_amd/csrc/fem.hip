@@ -470,7 +470,9 @@ __global__ __launch_bounds__(256) void k_fem_to_blocks(const float *__restrict__
 // value load and 1/9 of an index load, where the row-major forms needed 1 + 1/4 + 1/4 (quads) or 2/3 + 1/3 + 1/3
 // (triples).  No predicate: lanes past the run repeat its last block (same values to the same slots).  Phase 2: 8 lanes
 // per row sum its blocks' partials from LDS, DPP `row_shl` reduce in a fixed order, fused p.Ap partial.
-template <int SPB>
+// PAP: also emit the workgroup's partial of p.Ap (the chunked vector kernels of a single mesh want it; k_fem_cg_step, which
+// reads p and Ap anyway, forms p.Ap itself and spares this kernel a predicated gather of p and a workgroup reduction).
+template <int SPB, bool PAP>
 __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals_b, const int *__restrict__ bcol3,
                                                   const int *__restrict__ bp, size_t nnz, int ndof, int nchunk,
                                                   const double *__restrict__ p, double *__restrict__ Ap,
@@ -527,11 +529,13 @@ __global__ __launch_bounds__(CGT) void k_fem_spmv(const float *__restrict__ vals
         if (row < r1 && sl == 0) {
             const size_t g = vbase + row;
             Ap[g] = s;
-            acc += p[g] * s;
+            if (PAP) acc += p[g] * s;
         }
     }
-    acc = block_sum(acc, sh);
-    if (tid == 0) part_pAp[sg.part0 + sg.chunk] = acc;
+    if (PAP) {
+        acc = block_sum(acc, sh);
+        if (tid == 0) part_pAp[sg.part0 + sg.chunk] = acc;
+    }
 }
 
 // alpha = rz/pAp; x += alpha p; r -= alpha Ap; partial r.(r/diag) and r.r.
@@ -586,25 +590,22 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
 }
 
 // Batches: the vector half of an iteration in one launch, one 1024-thread workgroup per mesh.  alpha and beta are per
-// mesh, so a mesh's workgroup needs nobody else: alpha = rz / pAp; x += alpha p; r -= alpha Ap; rz' = r.(r/diag) and
+// mesh, so a mesh's workgroup needs nobody else: pAp = p.Ap; alpha = rz / pAp; x += alpha p; r -= alpha Ap; rz' = r.(r/diag) and
 // rr = r.r summed by the workgroup (thread-strided partials, wave butterflies, the waves in order: fixed order, no
 // atomics); beta = rz' / rz; p = r/diag + beta p.  Rows go through in blocks of CGS_U x 1024 with all loads of a block in
 // flight together (one memory round trip per block and phase).  A single mesh (the reference's own use, one mesh per
 // PoseOptimizationNR call) keeps the two launches above: there one workgroup is one CU's bandwidth, ~100 are the chip's.
 constexpr int CGS_T = 1024, CGS_U = 10, CGS_MIN_MESHES = 16;
-__global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int nchunk_s, int cur, CgScal *__restrict__ sc,
-                                                       const double *__restrict__ part_pAp, double *__restrict__ p,
+__global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal *__restrict__ sc, double *__restrict__ p,
                                                        const double *__restrict__ Ap, const double *__restrict__ dinv,
                                                        double *__restrict__ x, double *__restrict__ r,
-                                                       const int4 *__restrict__ minfo, const int4 *__restrict__ minfo_s)
+                                                       const int4 *__restrict__ minfo)
 {
     __shared__ double sh[CGS_T / 64];
     const int mesh = blockIdx.x;
     const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
     const int nrows = minfo ? minfo[mesh].y : ndof;
-    const int sp0 = minfo_s ? minfo_s[mesh].z : mesh * nchunk_s, snp = minfo_s ? minfo_s[mesh].w : nchunk_s;
     const double rz = sc[mesh].rz[cur];
-    const double alpha = rz / chunk_sum(part_pAp + sp0, snp);
     double s1 = 0, s2 = 0;
     if (nrows <= CGS_U * CGS_T) {
         // the whole mesh in one block: p and r/diag stay in registers across the reduction -- 5 vector reads and 3 writes
@@ -616,6 +617,11 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int nchunk_s, i
                 const size_t g = row0 + min(u * CGS_T + (int)threadIdx.x, nrows - 1);
                 pv[u] = p[g]; av[u] = Ap[g]; rv[u] = r[g]; xv[u] = x[g]; dv[u] = dinv[g];
             }
+            double s0 = 0;
+#pragma unroll
+            for (int u = 0; u < CGS_U; ++u)
+                if (u * CGS_T + (int)threadIdx.x < nrows) s0 += pv[u] * av[u];
+            const double alpha = rz / block_sum(s0, sh);   // p.Ap: the SpMV leaves it to us
 #pragma unroll
             for (int u = 0; u < CGS_U; ++u) {
                 const int i = u * CGS_T + (int)threadIdx.x;
@@ -640,6 +646,9 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int nchunk_s, i
         if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
         return;
     }
+    double s0 = 0;
+    for (int i = threadIdx.x; i < nrows; i += CGS_T) s0 += p[row0 + i] * Ap[row0 + i];
+    const double alpha = rz / block_sum(s0, sh);
     for (int base = 0; base < nrows; base += CGS_U * CGS_T) {
         double pv[CGS_U], av[CGS_U], rv[CGS_U], xv[CGS_U], dv[CGS_U];
 #pragma unroll
@@ -820,7 +829,9 @@ inline dim3 grid_spmv(const fem_model *m) { return m->segmented() ? dim3(m->nchu
 
 void launch_spmv(fem_model *m, hipStream_t st)
 {
-    hipLaunchKernelGGL(m->spb == 48 ? k_fem_spmv<48> : k_fem_spmv<96>, grid_spmv(m), dim3(CGT), m->spmv_lds, st,
+    const bool pap = m->nseg < CGS_MIN_MESHES;   // the per-mesh k_fem_cg_step forms p.Ap itself
+    hipLaunchKernelGGL(m->spb == 48 ? (pap ? k_fem_spmv<48, true> : k_fem_spmv<48, false>) : (pap ? k_fem_spmv<96, true> : k_fem_spmv<96, false>),
+                       grid_spmv(m), dim3(CGT), m->spmv_lds, st,
                        m->d_vals_b, m->d_bcol3, m->d_bp, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
                        (const int *)m->d_cmesh_s, (const int4 *)m->d_minfo_s);
 }
@@ -834,8 +845,8 @@ void launch_iter(fem_model *m, hipStream_t st)
     m->prof.stop(2, st);
     if (m->nseg >= CGS_MIN_MESHES) {
         m->prof.start(3, st);
-        hipLaunchKernelGGL(k_fem_cg_step, dim3(m->nseg), dim3(CGS_T), 0, st, m->ndof, m->nchunk_s, cur, m->d_sc, m->d_part[0], m->d_p,
-                           m->d_Ap, m->d_dinv, m->d_x, m->d_r, (const int4 *)m->d_minfo, (const int4 *)m->d_minfo_s);
+        hipLaunchKernelGGL(k_fem_cg_step, dim3(m->nseg), dim3(CGS_T), 0, st, m->ndof, cur, m->d_sc, m->d_p, m->d_Ap, m->d_dinv, m->d_x,
+                           m->d_r, (const int4 *)m->d_minfo);
         m->prof.stop(3, st);
         m->cg_it++;
         return;
@@ -1053,8 +1064,9 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};   // batches of 16+ meshes: slot 3 times k_fem_cg_step, which does both
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
     if (m->spmv_lds > 48 * 1024)
-        ORBX_HIP(hipFuncSetAttribute(m->spb == 48 ? reinterpret_cast<const void *>(k_fem_spmv<48>) : reinterpret_cast<const void *>(k_fem_spmv<96>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
+        for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
+                               reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
+            ORBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
     *out = m;
     return ORBX_OK;
 }
