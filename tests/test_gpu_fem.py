@@ -310,3 +310,45 @@ def test_batch_of_distinct_tet_meshes_cg_per_mesh():
         assert np.abs(x200[0, d0:d1] - ox60).max() <= RTOL * np.abs(ox60).max() and abs(rel200[k] - orel60) <= 1e-6 * orel60 + 1e-12
         ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], 20000, 1e-11)
         assert np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max()
+
+
+@pytest.mark.parametrize("nmesh,ncell,iters", [(20, 3, 40), (16, 15, 30)])
+def test_uniform_batch_above_the_fused_step_threshold(nmesh, ncell, iters):
+    """16 or more meshes take the batch form of an iteration (fem.hip: k_fem_spmv without the p.Ap partial, the whole vector
+    half as ONE per-mesh workgroup, k_fem_cg_step).  ncell = 15: 12,288 dofs per mesh, more than the 10,240 rows the step
+    kernel keeps in registers -- its block-by-block path.  Fixed iteration count against the oracle's CG on every (20 small)
+    or three (large) meshes' exported CSR, 1e-5."""
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=ncell)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    x, done, rel = fea.solve_cg(b, iters=iters, tol=0.0)
+    assert done == iters
+    for m in (range(nmesh) if ncell <= 4 else (0, 7, nmesh - 1)):
+        rp, col, val = fea.csr(m)
+        ox, _, orel = oracle.fem_cg(rp, col, val, b[m], iters, 0.0)
+        assert np.abs(x[m] - ox).max() <= RTOL * np.abs(ox).max(), m
+        assert abs(rel[m] - orel) <= 1e-6 * orel + 1e-12
+    assert not np.array_equal(x[0], x[1])
+
+
+def test_segmented_batch_above_the_fused_step_threshold():
+    """The same for 18 meshes of their own sizes and topologies (fem_create_batch): per-mesh alpha / beta inside the per-mesh
+    workgroups, every mesh against the oracle's CG on its exported CSR after 50 iterations."""
+    from orb_slam2_e_amd.fem import FEA2Batch
+    from orb_slam2_e_amd.synth import synth_tet_batch_distinct
+    nodes_l, tets_l, fixed_l, load_l = synth_tet_batch_distinct(18, base=5)
+    fb = FEA2Batch(nodes_l, tets_l, FEM_TET4)
+    fb.MatrixAssembly()
+    fixed = np.concatenate([fb.dof0[k] + fx for k, fx in enumerate(fixed_l)]).astype(np.int32)
+    fb.eliminate_dofs(fixed)
+    b = np.concatenate(load_l); b[fixed] = 0
+    x, done, rel = fb.solve_cg(b, iters=50, tol=0.0)
+    assert done == 50 and len(rel) == 18
+    for k in range(18):
+        rp, col, val = fb.csr(k)
+        d0, d1 = fb.dof0[k], fb.dof0[k + 1]
+        ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], 50, 0.0)
+        assert np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max(), k
+        assert abs(rel[k] - orel) <= 1e-6 * orel + 1e-12
