@@ -134,7 +134,7 @@ typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
 // padding (outside the 19-px border) are not written: the workspace is zeroed once.
 __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
                                                    LevelInfo dst, const int2 *__restrict__ xt,
-                                                   const int4 *__restrict__ yt, int nff, int nrg, int ntail, int tw_shift, int ntw, int rpw)
+                                                   const int4 *__restrict__ yt, int nff, int nint, int nrg, int ntail, int tw_shift, int ntw, int rpw)
 {
     const int f = blockIdx.z, tid = threadIdx.x;
     ORBX_PH_INIT(2);
@@ -147,7 +147,9 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     int xw, rowg;
     if (fast) {
         const int rw = (int)blockIdx.x / nff;
-        xw = PADX / 4 + ((int)blockIdx.x - rw * nff) * 64 + tid;
+        const int g = ((int)blockIdx.x - rw * nff) * 64 + tid;
+        if (g >= nint) return;   // the last wave of a row may be partly filled (nint = interior groups the full-wave path takes)
+        xw = PADX / 4 + g;
         rowg = rw * rpw;
     } else {
         // tail tile: 2^tw_shift groups x 64 >> tw_shift row groups; ntw > 1 (a tail wider than a wave) only with tw_shift = 6
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
         rowg = (tr << (6 - tw_shift)) + (tid >> tw_shift);
         if (col >= ntail) return;
         const int nleft = PADX / 4 - xlo;                                  // border groups on the left
-        xw = col < nleft ? xlo + col : PADX / 4 + nff * 64 + (col - nleft); // left border, leftover interior, right border
+        xw = col < nleft ? xlo + col : PADX / 4 + nint + (col - nleft);      // left border, leftover interior, right border
     }
     if (xw > xhi || rowg * PYR_ROWS >= dst.h + 2 * EDGE) return;
     const uint8_t *base = pyr + (size_t)f * frame_bytes + src.off + PADX;
@@ -1665,8 +1667,12 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     for (int l = 1; l < nl; l++) {
         const LevelInfo &lv = ex->lv[l];
         const int ngi = lv.w >> 2, xlo = (PADX - EDGE) >> 2, xhi = (PADX + lv.w + EDGE - 1) >> 2;
-        const int nff = ex->resize_nxi[l] ? ngi / 64 : 0;                          // full waves of interior groups per row group
-        const int ntail = (xhi - xlo + 1) - nff * 64;                              // what is left of a row: leftover interior + border groups
+        // waves of 64 consecutive interior groups of a row group (8-byte-window path); a last, partly filled one when at least
+        // 24 groups are left: the byte-by-byte path of the tail tiles costs 64 loads per lane (at levels 6-7 of a 640 x 480
+        // frame EVERY group went through it: fewer than 64 interior groups per row)
+        const int nff = ex->resize_nxi[l] ? (ngi % 64 >= 24 ? ngi / 64 + 1 : ngi / 64) : 0;
+        const int nint = std::min(nff * 64, ngi);                                  // interior groups the full-wave path takes
+        const int ntail = (xhi - xlo + 1) - nint;                                  // what is left of a row: leftover interior + border groups
         const int tw_shift = ntail <= 16 ? 4 : ntail <= 32 ? 5 : 6;                // tail tile: 16 x 4, 32 x 2 or 64 x 1 (groups x row groups)
         const int nrg = (lv.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, rpt = 64 >> tw_shift;
         const int ntw = (ntail + (1 << tw_shift) - 1) >> tw_shift;                 // tail waves across a row (> 1 only when ntail > 64)
@@ -1679,7 +1685,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         dim3 g(nff * ((nrg + rpw - 1) / rpw) + ntailw, 1, batch);
         pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
-                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nrg, ntail, tw_shift, ntw, rpw);
+                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nint, nrg, ntail, tw_shift, ntw, rpw);
         pf.stop(1, st);
     }
     pf.start(2, st);
