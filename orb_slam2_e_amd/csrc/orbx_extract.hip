@@ -1264,6 +1264,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         PX[2 * t] = f32x2{(float)pp[0], (float)pp[0]}; PY[2 * t] = f32x2{-(float)pp[1], (float)pp[1]};
         PX[2 * t + 1] = f32x2{(float)pp[2], (float)pp[2]}; PY[2 * t + 1] = f32x2{-(float)pp[3], (float)pp[3]};
     }
+    unsigned dacc = 0;   // lane 8j + m: dword m of the descriptor of the wave's keypoint j
 #pragma unroll
     for (int j = 0; j < DESC_KPB / 4; ++j) {
         const int kp = wv * (DESC_KPB / 4) + j;
@@ -1289,21 +1290,30 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const unsigned w = byte | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x102, 0xf, 0xf, true) << 8) |
                            ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x104, 0xf, 0xf, true) << 16) |
                            ((unsigned)__builtin_amdgcn_update_dpp(0, (int)byte, 0x106, 0xf, 0xf, true) << 24);
-        const size_t o = (size_t)f * cap + s_out[kp];
-        if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + o * 32)[lane >> 3] = w;
+        // lane 8m holds dword m of this keypoint's descriptor: hand it to lane 8j + m, where it waits for the wave's one store
+        const unsigned wv_ = (unsigned)__shfl((int)w, 8 * (lane & 7));
+        if ((lane >> 3) == j) dacc = wv_;
         ORBX_PH(11 + j, tid == 0);   // BRIEF of the wave's keypoint j (incl. waiting for its patch)
-        if (lane == 0) {
-            const uint32_t pk = s_pk[kp];
-            orbx_keypoint k;
-            k.x = (float)((int)((pk >> 8) & 0xfffu) + MIN_BORDER);
-            k.y = (float)((int)(pk >> 20) + MIN_BORDER);
-            if (level != 0) { k.x *= D.scale[level]; k.y *= D.scale[level]; }
-            k.size = (float)D.patch[level];
-            k.angle = s_angle[kp];
-            k.response = (float)(pk & 0xffu);
-            k.octave = level;
-            k.class_id = -1;
-            kps[o] = k;
+    }
+    // Output records of the wave's four keypoints, which sit side by side in the frame's arrays (a level's slots fill from
+    // 0, so the valid ones are a prefix): ONE store of 32 lanes x 4 bytes for the descriptors and ONE of 28 lanes x 4 bytes
+    // for the keypoint structs (7 dwords each: x, y, size, angle, response, octave, class_id), instead of a store per
+    // keypoint and per struct -- the stores go through the texture addresser like the loads, and the kernel is bound by it
+    {
+        const int kp0 = wv * (DESC_KPB / 4);
+        const size_t o0 = (size_t)f * cap + s_out[kp0];
+        if (lane < 32 && s_valid[kp0 + (lane >> 3)]) reinterpret_cast<uint32_t *>(desc + o0 * 32)[lane] = dacc;
+        if (lane < 28) {
+            const int jk = lane / 7, fld = lane - 7 * jk, kp = kp0 + jk;
+            if (s_valid[kp]) {
+                const uint32_t pk = s_pk[kp];
+                float x = (float)((int)((pk >> 8) & 0xfffu) + MIN_BORDER), y = (float)((int)(pk >> 20) + MIN_BORDER);
+                if (level != 0) { x *= D.scale[level]; y *= D.scale[level]; }   // :1103-1109
+                const uint32_t val = fld == 0 ? __float_as_uint(x) : fld == 1 ? __float_as_uint(y) :
+                                     fld == 2 ? __float_as_uint((float)D.patch[level]) : fld == 3 ? __float_as_uint(s_angle[kp]) :
+                                     fld == 4 ? __float_as_uint((float)(pk & 0xffu)) : fld == 5 ? (uint32_t)level : 0xffffffffu;
+                reinterpret_cast<uint32_t *>(kps + o0)[lane] = val;
+            }
         }
     }
     ORBX_PH(15, tid == 0);
