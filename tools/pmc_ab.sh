@@ -13,7 +13,7 @@ out, k, v = sys.argv[1:4]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if k in r['Kernel_Name'] and int(r['Grid_Size']) > 1000000:
+        if k in r['Kernel_Name'] and int(r["Grid_Size"]) > int(__import__("os").environ.get("MINGRID", "1000000")):
             a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
 print(v, {c: round(a[0] / a[1]) for c, a in sorted(acc.items())}, 'launches', max(a[1] for a in acc.values()) if acc else 0)
 PY
