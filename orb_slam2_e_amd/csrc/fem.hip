@@ -1061,8 +1061,9 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         ORBX_HIP(hipMemcpy(m->d_minfo, minfo.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(m->d_minfo_s, minfo_s.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
     }
-    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};   // batches of 16+ meshes: slot 3 times k_fem_cg_step, which does both
+    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
+    if (m->nseg >= CGS_MIN_MESHES) { m->prof.names[3] = "k_fem_cg_step"; m->prof.names[4] = nullptr; }   // one launch does both
     if (m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
                                reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
