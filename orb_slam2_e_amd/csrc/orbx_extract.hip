@@ -117,10 +117,18 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
 // coordinate (nxf = 0: every group does).
 // (b (r >> 4)) >> 16 = floor((b 2^12) (r & ~15) / 2^32): both factors are below 2^24 (b <= 2048, r <= 255 * 2048), so
 // it is one v_mul_hi_u32_u24 after the mask instead of shift, multiply, shift.  bs = b << 12.
+// (written as asm: from the masked 64-bit product the compiler makes v_mul_hi_u32, a quarter-rate instruction -- 64 of them were
+// a fifth of the kernel's VALU time)
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)   // (a[23:0] * b[23:0]) >> 32
+{
+    uint32_t d;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, uint32_t bs0, uint32_t bs1)
 {
-    const uint32_t t0 = (uint32_t)(((unsigned long long)(bs0 & 0xffffffu) * ((uint32_t)r0 & 0xfffff0u)) >> 32);
-    const uint32_t t1 = (uint32_t)(((unsigned long long)(bs1 & 0xffffffu) * ((uint32_t)r1 & 0xfffff0u)) >> 32);
+    const uint32_t t0 = mulhi_u24(bs0, (uint32_t)r0 & 0xfffff0u);
+    const uint32_t t1 = mulhi_u24(bs1, (uint32_t)r1 & 0xfffff0u);
     const uint32_t v = (t0 + t1 + 2) >> 2;
     return v > 255u ? 255u : v;
 }
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 for (int p0 = 0; p0 < ngrp; p0 += 64) {
                     uint32_t code = 0;
                     // a row's last group may reach past the zone: those pixels are masked in (2b), on the queued groups only
-                    if (p0 + lane < ngrp) code = fast_pretest4<TS, FAST_PAIRS_A>(tile + (y + 3) * TS + 4 * (g0 + gx), th2);
+                    if (p0 + lane < ngrp) code = fast_pretest4<TS, FAST_PAIRS_A>(tile + __mul24(y + 3, TS) + 4 * (g0 + gx), th2);
                     const unsigned long long b = __ballot(code != 0);
                     if (code) gqueue[ngq + mask_rank(b)] = code | ((uint32_t)y << 2) | ((uint32_t)gx << 10);
                     ngq += __popcll(b);
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 if (q0 + lane < ngq) {
                     const uint32_t e = gqueue[q0 + lane];
                     const int y = (e >> 2) & 63, gx = (e >> 10) & 63;
-                    code = fast_resolve(fast_pretest4<TS, FAST_PAIRS_B>(tile + (y + 3) * TS + 4 * (g0 + gx), th2) & e & 0x03030303u);
+                    code = fast_resolve(fast_pretest4<TS, FAST_PAIRS_B>(tile + __mul24(y + 3, TS) + 4 * (g0 + gx), th2) & e & 0x03030303u);
                     ent = (y << 6) + 4 * (g0 + gx) - zc0;                  // zone x of the group's pixel 0: 4 gx
                     code &= 0xffffffffu >> (8 * max(0, 4 * gx + 4 - zw));   // pixels at zone x >= zw are outside
                 }
