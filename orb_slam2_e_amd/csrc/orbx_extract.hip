@@ -1157,16 +1157,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     int level = 0;
     for (int l = 1; l < nlevels; ++l) level += item >= D.chunk_base[l];
     const int stride = D.stride[level];
-    if (tid < DESC_KPB) {
-        const int j = (item - D.chunk_base[level]) * DESC_KPB + tid;   // slot within the level
-        const uint32_t pk = sel_all[(size_t)f * sel_per_frame + D.sel_base[level] + j];   // (slots past the level's count: never used)
-        int first = 0, mine = 0, total = 0;
+    // the level counts of the frame: wave-uniform addresses, so they come through the scalar cache (as per-lane loads of
+    // 16 lanes they were 8 of a workgroup's ~100 texture-addresser instructions)
+    int first = 0, mine = 0, total = 0;
+    {
+        const int *lc = level_count + __builtin_amdgcn_readfirstlane(f) * nlevels;
         for (int l = 0; l < nlevels; ++l) {
-            const int c = level_count[f * nlevels + l];
+            const int c = lc[l];
             first += l < level ? c : 0;
             mine = l == level ? c : mine;
             total += c;
         }
+    }
+    if (tid < DESC_KPB) {
+        const int j = (item - D.chunk_base[level]) * DESC_KPB + tid;   // slot within the level
+        const uint32_t pk = sel_all[(size_t)f * sel_per_frame + D.sel_base[level] + j];   // (slots past the level's count: never used)
         if (item == 0 && tid == 0) counts[f] = total < cap ? total : cap;
         const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
         s_valid[tid] = j < mine && first + j < cap;
