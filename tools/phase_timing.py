@@ -1,5 +1,11 @@
-"""Development aid: shader-clock time per phase of k_fast_cells / k_describe, summed over waves (needs a library built with
--DORBX_PHASE_TIMING, e.g. orb_slam2_e_amd/lib_ph.so copied over liborbslam_hip.so on the GPU box; never the product build)."""
+"""Development aid: shader-clock time per phase of k_fast_cells / k_describe / k_pyr_resize per workgroup, and how many
+workgroups are resident over a launch (100-MHz wall clock).  Needs a library built with the markers switched on -- never the
+product build:
+    cd orb_slam2_e_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+        -mllvm -amdgpu-mfma-vgpr-form=1 -DORBX_PHASE_TIMING -c orbx_extract.hip -o /tmp/x.o && \
+        hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_ph.so /tmp/x.o orbx_stereo.o orbm_match.o orbm_search.o fem.o
+On the GPU box: cp orb_slam2_e_amd/lib_ph.so orb_slam2_e_amd/liborbslam_hip.so && PYTHONPATH=. python3 tools/phase_timing.py
+(the markers cost a few per cent and a register or two: compare kernels with tools/trace_ab.sh, not with this build)."""
 import ctypes as C, sys
 import numpy as np
 from orb_slam2_e_amd.extractor import ORBextractor
