@@ -106,6 +106,49 @@ __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ i
     }
 }
 
+// The same for images whose width is a multiple of 8 (and whose rows are dword-aligned), without a divergent wave: the
+// padded level is (h + 38) rows x pp = w / 8 interior pieces of 8 bytes -- every one a straight copy from a (reflected)
+// source row, numbered row-major and dealt out 64 x 4 per wave (8 bytes per lane and load: the texture addresser's sweet
+// spot) -- plus nb border dwords per row (the 19 px either side), which are put together byte by byte through the reflected
+// column by waves of their own.  The dword form above had the border lanes in the first and last wave of every row group:
+// both paths executed by two waves of three.  inv_pp / inv_nb = ceil(2^32 / pp), ceil(2^32 / nb): exact quotients.
+__global__ __launch_bounds__(64) void k_pyr_level0_lin(const uint8_t *__restrict__ img, int img_stride, size_t img_frame_stride,
+                                                       uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo lv, int pp,
+                                                       unsigned inv_pp, int nblk_int, int nb, unsigned inv_nb, int nleft)
+{
+    const int f = blockIdx.z, lane = threadIdx.x, rows = lv.h + 2 * EDGE;
+    const uint8_t *src = img + (size_t)f * img_frame_stride;
+    uint8_t *dst = pyr + (size_t)f * frame_bytes + lv.off;
+    if ((int)blockIdx.x < nblk_int) {
+        uint2 v[4];
+        int row[4], pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = min((int)blockIdx.x * 256 + u * 64 + lane, rows * pp - 1);   // past the end: the last piece again
+            row[u] = (int)(((unsigned long long)(unsigned)p * inv_pp) >> 32);
+            pc[u] = p - row[u] * pp;
+            __builtin_memcpy(&v[u], src + (uint32_t)(reflect101(row[u] - EDGE, lv.h) * img_stride + 8 * pc[u]), 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            *reinterpret_cast<uint2 *>(dst + (uint32_t)(row[u] * lv.stride + PADX + 8 * pc[u])) = v[u];
+    } else {
+        const int q = ((int)blockIdx.x - nblk_int) * 64 + lane;
+        if (q >= rows * nb) return;
+        const int row = (int)(((unsigned long long)(unsigned)q * inv_nb) >> 32), k = q - row * nb;
+        const int xw = k < nleft ? ((PADX - EDGE) >> 2) + k : ((PADX + lv.w) >> 2) + (k - nleft);   // dword of the padded row
+        const uint8_t *s = src + (uint32_t)(reflect101(row - EDGE, lv.h) * img_stride);
+        uint32_t out = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int px = xw * 4 - PADX + b;
+            const uint32_t val = s[reflect101(min(max(px, -EDGE), lv.w + EDGE - 1), lv.w)];
+            out |= (px >= -EDGE && px < lv.w + EDGE) ? val << (8 * b) : 0u;   // row padding stays 0
+        }
+        *reinterpret_cast<uint32_t *>(dst + (uint32_t)(row * lv.stride + xw * 4)) = out;
+    }
+}
+
 // Level l from level l-1: cv::resize INTER_LINEAR 8U fixed point
 // + REFLECT_101 border.  xt[dx] = {sx, a0 | a1<<16}, yt[dy] = {sy0, sy1, b0, b1}:
 // OpenCV's coefficient tables, built on the host.
@@ -1682,9 +1725,18 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     {
         const LevelInfo &l0 = ex->lv[0];
         const int aligned = (((uintptr_t)d_img | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
-        dim3 g((l0.stride / 4 + 63) / 64, (l0.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
         pf.start(0, st);
-        hipLaunchKernelGGL(k_pyr_level0, g, dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr, ex->frame_bytes, l0, aligned);
+        if (aligned && l0.w % 8 == 0 && l0.w >= 64) {
+            const int rows = l0.h + 2 * EDGE, pp = l0.w / 8, nleft = PADX / 4 - ((PADX - EDGE) >> 2);
+            const int nb = nleft + ((PADX + l0.w + EDGE - 1) >> 2) - ((PADX + l0.w) >> 2) + 1;
+            const int nblk_int = (rows * pp + 255) / 256, nblk_b = (rows * nb + 63) / 64;
+            hipLaunchKernelGGL(k_pyr_level0_lin, dim3(nblk_int + nblk_b, 1, batch), dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr,
+                               ex->frame_bytes, l0, pp, (unsigned)((0x100000000ull + pp - 1) / pp), nblk_int, nb,
+                               (unsigned)((0x100000000ull + nb - 1) / nb), nleft);
+        } else {
+            dim3 g((l0.stride / 4 + 63) / 64, (l0.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+            hipLaunchKernelGGL(k_pyr_level0, g, dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr, ex->frame_bytes, l0, aligned);
+        }
         pf.stop(0, st);
     }
     for (int l = 1; l < nl; l++) {
