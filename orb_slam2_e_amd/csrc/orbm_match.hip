@@ -181,7 +181,11 @@ __global__ __launch_bounds__(64 * MSEG) void k_match_sets(const uint8_t *__restr
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int XQ = 4;                          // 32-query tiles per wave; also the number of waves of a workgroup
+constexpr int XQ = 4;                          // 32-query tiles per wave
+// Waves per workgroup.  The kernel holds 3 waves per SIMD (156 VGPRs: the four query tiles' FP4 operands alone are 128), 12
+// per CU: workgroups of 3 waves make that 4 workgroups per CU = 1024 slots, exactly the 16 query blocks x 64 pairs of the
+// bench -- one full round.  With 4 waves per workgroup (3 per CU, 768 slots) the same grid took a full round and a third of one.
+constexpr int XW = 3;
 constexpr unsigned XKEY_INF = 0x7f000000u;     // above every key (keys < 257)
 constexpr float XIDX = 1.0f / 32768.0f;
 constexpr int XMAXN = 32768;                   // j * 2^-15 < 1
@@ -232,14 +236,14 @@ __device__ __forceinline__ void mfma_tile(const uint4 &x, const v16f &c, const v
     }
 }
 
-// Workgroup = 4 waves x (XQ * 32 = 128 queries); wave `seg` scans the train tiles seg, seg + 4, ... .
-__global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
+// Workgroup = XW waves x (XQ * 32 = 128 queries); wave `seg` scans the train tiles seg, seg + XW, ... .
+__global__ __launch_bounds__(64 * XW) void k_match_sets_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
                                                           int cap, const int *__restrict__ qa, const int *__restrict__ qb,
                                                           int th, float nnratio, int *__restrict__ best_o,
                                                           int *__restrict__ second_o, int *__restrict__ idx_o,
                                                           int *__restrict__ match12, int *__restrict__ nmatch)
 {
-    __shared__ unsigned sk[4][XQ][2][32];
+    __shared__ unsigned sk[XW][XQ][2][32];
     const int p = blockIdx.y, lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sa = qa ? qa[p] : 0, sb = qb ? qb[p] : 1;
     const int nA = min(max(counts[sa], 0), cap), nB = min(max(counts[sb], 0), cap); // a count outside [0, cap] is a caller's bug; never index with it
@@ -266,15 +270,15 @@ __global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restri
     const int nfull = nB >> 5;
     uint4 nx = make_uint4(0, 0, 0, 0);
     if (seg < nfull) nx = B[2 * (seg * 32 + r) + h];
-    for (int t = seg; t < nfull; t += 4) {
+    for (int t = seg; t < nfull; t += XW) {
         const uint4 x = nx;
-        if (t + 4 < nfull) nx = B[2 * ((t + 4) * 32 + r) + h];                  // in flight during this tile
+        if (t + XW < nfull) nx = B[2 * ((t + XW) * 32 + r) + h];                // in flight during this tile
         mfma_tile(x, c, bq, k1, k2);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) c[g] += 128.0f * XIDX;                    // four tiles further
+        for (int g = 0; g < 16; ++g) c[g] += (float)(32 * XW) * XIDX;          // XW tiles further
     }
-    if ((nB & 31) && (nfull & 3) == seg) {
-        // c of this wave stands at tile seg + 4 * (its full tiles) = nfull
+    if ((nB & 31) && (nfull % XW) == seg) {
+        // c of this wave stands at tile seg + XW * (its full tiles) = nfull
         const uint4 x = B[2 * min(nfull * 32 + r, nB - 1) + h];
 #pragma unroll
         for (int g = 0; g < 16; ++g)
@@ -288,13 +292,13 @@ __global__ __launch_bounds__(256) void k_match_sets_mfma(const uint8_t *__restri
         if (h == 0) { sk[seg][q][0][r] = k1[q]; sk[seg][q][1][r] = k2[q]; }
     }
     __syncthreads();
-    // wave `seg` finishes query tile `seg`
+    // waves 0 and 1 finish the 128 queries, 64 each: lane -> query tile 2 seg + h, row r
     bool ok = false;
-    const int i = row0 + seg * 32 + r;
-    if (h == 0 && i < nA) {
-        unsigned m1 = sk[0][seg][0][r], m2 = sk[0][seg][1][r];
+    const int qt = 2 * seg + h, i = row0 + qt * 32 + r;
+    if (seg < 2 && i < nA) {
+        unsigned m1 = sk[0][qt][0][r], m2 = sk[0][qt][1][r];
 #pragma unroll
-        for (int g = 1; g < 4; ++g) merge_pairs(m1, m2, sk[g][seg][0][r], sk[g][seg][1][r]);
+        for (int g = 1; g < XW; ++g) merge_pairs(m1, m2, sk[g][qt][0][r], sk[g][qt][1][r]);
         const float f1 = __uint_as_float(m1), f2 = __uint_as_float(m2);
         const int d1 = (int)f1;
         const int best = nB > 0 ? d1 : INT_MAX, idx = nB > 0 ? (int)((f1 - (float)d1) * 32768.0f) : -1;
@@ -525,7 +529,7 @@ static void launch_match_sets(hipStream_t st, const uint8_t *desc, const int *co
                               int th, float nnratio, int *best, int *second, int *idx, int *match12, int *nmatch)
 {
     if (cap <= XMAXN && g_allpairs_kind.load(std::memory_order_relaxed) != ORBM_ALLPAIRS_POPCOUNT)
-        hipLaunchKernelGGL(k_match_sets_mfma, dim3((cap + 32 * XQ - 1) / (32 * XQ), npairs), dim3(256), 0, st, desc, counts, cap, qa, qb,
+        hipLaunchKernelGGL(k_match_sets_mfma, dim3((cap + 32 * XQ - 1) / (32 * XQ), npairs), dim3(64 * XW), 0, st, desc, counts, cap, qa, qb,
                            th, nnratio, best, second, idx, match12, nmatch);
     else
         hipLaunchKernelGGL(k_match_sets, dim3((cap + 64 * MQ - 1) / (64 * MQ), npairs), dim3(64, MSEG), 0, st, desc, counts, cap, qa, qb,
