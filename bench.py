@@ -583,6 +583,14 @@ def main():
                 out["roofline"]["valu"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64-instr/s",
                                            "frac": ginst / VALU_PEAK_GINST,
                                            "wave_insts_per_launch": tr[dom]["valu_wave_insts_per_launch"]}
+        # avg_launch_ms is the kernel's launch-to-end time IN the pipelined run, where it shares the chip with the other two
+        # contexts' kernels; the same two fractions for the kernel running by itself (the untimed one-context pass; its event
+        # pair adds ~3 us to the time, so these are lower bounds)
+        alone_ms = split_ms.get(dom, 0.0) / max(1, kern_all[dom][1] // nprof) if dom in kern_all else 0.0
+        if alone_ms > 0 and out["roofline"]["bound"] == "hbm":
+            out["roofline"]["alone"] = {"launch_ms": alone_ms, "frac": alg / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if dom in tr and tr[dom].get("valu_wave_insts_per_launch"):
+                out["roofline"]["alone"]["valu_frac"] = tr[dom]["valu_wave_insts_per_launch"] / (alone_ms * 1e-3) / 1e9 / VALU_PEAK_GINST
         if host_io is not None:
             out["host_io"] = host_io
         if fem is not None:
