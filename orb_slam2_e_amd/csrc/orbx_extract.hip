@@ -53,16 +53,18 @@ constexpr int PYR_ROWS = 4;
 #ifdef ORBX_PHASE_TIMING
 // development aid (never in the product build): shader-clock time per kernel phase, one record per workgroup (plain
 // stores: atomics on shared counters serialise in one L2 channel and the measurement measures itself)
-__device__ unsigned long long g_phase_rec[3 * 65536 * 16];   // per workgroup: 8 phase times (shader clock), [13] = end and [15] = start in the 100 MHz wall clock, [14] = HW_ID
+__device__ unsigned long long g_phase_rec[4 * 65536 * 16];   // per workgroup: 8 phase times (shader clock), [13] = end and [15] = start in the 100 MHz wall clock, [14] = HW_ID
 #define ORBX_PH_INIT(K) unsigned long long *const ph_rec = g_phase_rec + ((K) * 65536 + ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 65535u)) * 16; \
     if (threadIdx.x == 0) { ph_rec[15] = wall_clock64(); ph_rec[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } \
     __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64()   /* the wall clock's own latency stays outside the first phase */
 #define ORBX_PH(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] = ph_n - ph_t; ph_t = ph_n; } } while (0)
 #define ORBX_PH_END(cond) do { if (cond) ph_rec[13] = wall_clock64(); } while (0)   // s_memrealtime is slow: once, at the very end
+#define ORBX_PHA(i, cond) do { if (cond) { const unsigned long long ph_n = clock64(); ph_rec[(i) & 7] += ph_n - ph_t; ph_t = ph_n; } } while (0)   // accumulating (loops)
 #else
 #define ORBX_PH_INIT(K) do {} while (0)
 #define ORBX_PH(i, cond) do {} while (0)
 #define ORBX_PH_END(cond) do {} while (0)
+#define ORBX_PHA(i, cond) do {} while (0)
 #endif
 
 // Level 0: copyMakeBorder(image, temp, 19,19,19,19, BORDER_REFLECT_101), ORBextractor.cc:1135.
@@ -759,6 +761,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     __shared__ int s_nproc;
 
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    ORBX_PH_INIT(3);
+#ifdef ORBX_PHASE_TIMING
+    if (tid == 0) { for (int i = 0; i < 8; ++i) ph_rec[i] = 0; ph_rec[12] = l; }
+#endif
     const LevelInfo lv = L[l];
     const int N = lv.N;
 
@@ -779,6 +785,39 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     uint32_t *kpos_out = kpos_all + (size_t)f * keys_per_frame + lv.key_base; // candidates stay readable for staged tests
     for (int i = tid; i < NC; i += OCT_T) cnt[0][i] = 0;
     __syncthreads();
+    // Up to OCT_KPT x 256 candidates (every level of a usual frame) the keys never leave the registers: thread t owns the keys
+    // t, t + 256, ...; a key's packed position never changes and its node is rewritten by its owner only.  A round's two passes
+    // over the keys were 60 % of a workgroup's life as loops over LDS / HBM arrays -- every iteration a chain of dependent
+    // reads (node of the key -> state of the node) on a workgroup of four waves; with the keys in registers all of a thread's
+    // node-state reads are in flight together.
+    const bool regs = M <= OCT_KPT * OCT_T;
+    uint32_t kp[OCT_KPT];
+    int kn[OCT_KPT], kqv[OCT_KPT];
+    if (regs) {
+#pragma unroll
+        for (int u = 0; u < OCT_KPT; ++u) {
+            const int k = tid + u * OCT_T;
+            kp[u] = 0; kn[u] = 0; kqv[u] = 0;
+            if (k < M) {
+                int lo = 0, hiC = lv.ncells; // largest c with s_cell[c] <= k
+                while (hiC - lo > 1) {
+                    const int mid = (lo + hiC) >> 1;
+                    if (s_cell[mid] <= k) lo = mid; else hiC = mid;
+                }
+                kp[u] = cands[(size_t)f * cands_per_frame + s_coff[lo] + (k - s_cell[lo])];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OCT_KPT; ++u) {
+            const int k = tid + u * OCT_T;
+            if (k < M) {
+                kpos_out[k] = kp[u];
+                const float x = (float)((kp[u] >> 8) & 0xfffu);
+                kn[u] = (int)(x / lv.hX); // vpIniNodes[kp.pt.x/hX], :569
+                atomicAdd(&cnt[0][kn[u]], 1);
+            }
+        }
+    } else
     for (int k0 = tid; k0 < M; k0 += 4 * OCT_T) { // four candidates per thread in flight: the loads are a dependent chain each
         uint32_t pk4[4];
 #pragma unroll
@@ -809,6 +848,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
     }
     __syncthreads();
+    ORBX_PHA(0, tid == 0);   // cells, scan, candidate gather
+#ifdef ORBX_PHASE_TIMING
+    if (tid == 0) ph_rec[11] = M;
+#endif
     // roots (:552-563), empty ones erased (:574-585)
     for (int i = tid; i < lv.nIni; i += OCT_T) a1[i] = cnt[0][i] > 0 ? 1 : 0;
     int S = block_excl_scan(a1, lv.nIni, part);
@@ -822,8 +865,13 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             seq[1][pos] = 0;
         }
     }
+    if (regs) {
+#pragma unroll
+        for (int u = 0; u < OCT_KPT; ++u) kn[u] = tid + u * OCT_T < M ? a1[kn[u]] : 0;
+    } else
     for (int k = tid; k < M; k += OCT_T) knode[k] = (unsigned short)a1[knode[k]];
     __syncthreads();
+    ORBX_PHA(1, tid == 0);   // roots
     int cur = 1, mode = 1;
 
     while (true) {
@@ -835,6 +883,20 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
         __syncthreads();
         // children counts of every expandable node (DivideNode, :511-526)
+        if (regs) {
+#pragma unroll
+            for (int u = 0; u < OCT_KPT; ++u) {
+                const int s = kn[u];
+                if (tid + u * OCT_T < M && cn[s] > 1) {
+                    const float x = (float)((kp[u] >> 8) & 0xfffu), y = (float)(kp[u] >> 20);
+                    const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
+                    const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2);
+                    const int my = y0 + (int)ceilf((float)(y1 - y0) / 2);
+                    kqv[u] = (x < (float)mx ? 0 : 1) + (y < (float)my ? 0 : 2);
+                    atomicAdd(&cc[4 * s + kqv[u]], 1);
+                }
+            }
+        } else
         for (int k = tid; k < M; k += OCT_T) {
             const int s = knode[k];
             if (cn[s] > 1) {
@@ -849,6 +911,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             }
         }
         __syncthreads();
+        ORBX_PHA(2, tid == 0);   // children counts (pass over the keys)
         // per node: non-empty / expandable children; scanned together with the candidate flag
         for (int s = tid; s < S; s += OCT_T) {
             int a = 0, b = 0;
@@ -867,6 +930,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
         int E, PE;
         block_excl_scan2(a1, a2, S, part, E, PE);
+        ORBX_PHA(3, tid == 0);   // node flags + scans
         if (E == 0) break;
         int F, Etot, nns;
         if (mode == 1) {
@@ -927,6 +991,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         const int S2 = F + nns;
         int *nx = bx[cur ^ 1], *ny = by[cur ^ 1], *nn = cnt[cur ^ 1];
         unsigned short *ns = seq[cur ^ 1];
+        ORBX_PHA(4, tid == 0);   // which nodes split (mode 1: all; mode 2: ranking, largest first)
         for (int s = tid; s < S; s += OCT_T) {
             if (split[s]) {
                 const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
@@ -951,6 +1016,21 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
                 nx[pos] = cx[s]; ny[pos] = cy[s]; nn[pos] = cn[s]; ns[pos] = cs[s];
             }
         }
+        if (regs) {
+#pragma unroll
+            for (int u = 0; u < OCT_KPT; ++u) {
+                const int s = kn[u];
+                int pos;
+                if (split[s]) {
+                    int after = 0;
+                    for (int q2 = kqv[u] + 1; q2 < 4; ++q2) after += cc[4 * s + q2] > 0;
+                    pos = bstart[s] + after;
+                } else {
+                    pos = F + a1[s];
+                }
+                kn[u] = tid + u * OCT_T < M ? pos : 0;
+            }
+        } else
         for (int k = tid; k < M; k += OCT_T) {
             const int s = knode[k];
             int pos;
@@ -965,6 +1045,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             knode[k] = (unsigned short)pos;
         }
         __syncthreads();
+        ORBX_PHA(5, tid == 0);   // new node list + keys to their new nodes (pass over the keys)
+#ifdef ORBX_PHASE_TIMING
+        if (tid == 0) ph_rec[7] += 1;
+#endif
         const int prevS = S;
         S = S2;
         cur ^= 1;
@@ -976,15 +1060,24 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     int *best = a2;
     for (int s = tid; s < S; s += OCT_T) best[s] = 0;
     __syncthreads();
+    if (regs) {
+#pragma unroll
+        for (int u = 0; u < OCT_KPT; ++u)
+            if (tid + u * OCT_T < M)
+                atomicMax(reinterpret_cast<unsigned *>(&best[kn[u]]), ((kp[u] & 0xffu) << 24) | (0xffffffu - (unsigned)(tid + u * OCT_T)));
+    } else
     for (int k = tid; k < M; k += OCT_T)
         atomicMax(reinterpret_cast<unsigned *>(&best[knode[k]]), ((kpos[k] & 0xffu) << 24) | (0xffffffu - (unsigned)k));
     __syncthreads();
     uint32_t *sel = sel_all + (size_t)f * sel_per_frame + lv.sel_base;
-    for (int s = tid; s < S; s += OCT_T) sel[s] = kpos[0xffffffu - ((unsigned)best[s] & 0xffffffu)];
+    const uint32_t *kfin = regs ? kpos_out : kpos;   // (register keys: the gather left the packed positions in the frame's workspace)
+    for (int s = tid; s < S; s += OCT_T) sel[s] = kfin[0xffffffu - ((unsigned)best[s] & 0xffffffu)];
     if (tid == 0) {
         level_count[f * nlevels + l] = S;
         level_ncand[f * nlevels + l] = M;
     }
+    ORBX_PHA(6, tid == 0);   // best response per leaf, output
+    ORBX_PH_END(tid == 0);
 }
 
 // --------------------------------------------------------------------- blur
@@ -1832,10 +1925,10 @@ int orbx_profile_enable(orbx_extractor *ex, int on)
 #ifdef ORBX_PHASE_TIMING
 int orbx_debug_phases(unsigned long long *out, int reset)   // out: 2 x 65536 x 16 records (FAST, describe)
 {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 3 * 65536 * 16) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 4 * 65536 * 16) != hipSuccess) return -1;
     if (reset) {
         void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 3 * 65536 * 16) != hipSuccess) return -1;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 4 * 65536 * 16) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -17,7 +17,7 @@ frames = synth_sequence(64)
 for _ in range(3):
     ex.extract_batch(frames)
 ex.download_batch()
-acc = np.zeros((3, 65536, 16), np.uint64)
+acc = np.zeros((4, 65536, 16), np.uint64)
 L.orbx_debug_phases.argtypes = [C.c_void_p, C.c_int]
 assert L.orbx_debug_phases(acc.ctypes.data, 1) == 0
 ex.extract_batch(frames)
@@ -25,10 +25,15 @@ ex.download_batch()
 assert L.orbx_debug_phases(acc.ctypes.data, 0) == 0
 for k, (title, names) in enumerate([("k_fast_cells, per wave", ["tile load", "stage A", "stage B", "zero + score", "nms + emit", "epilogue", "(timer)"]),
                                     ("k_describe, per workgroup (wave 0)", ["lookup", "moments", "atan/sincos", "brief kp0", "brief kp1", "brief kp2", "brief kp3", "tail"]),
-                                    ("k_pyr_resize, per wave (records of the launches that wrote last; [12] = level width)", ["row table", "columns + rows + math", "store"])]):
+                                    ("k_pyr_resize, per wave (records of the launches that wrote last; [12] = level width)", ["row table", "columns + rows + math", "store"]),
+                                    ("k_octree, per workgroup = (level, frame); [12] = level, [11] = candidates, [7] = rounds", ["cells + gather", "roots", "children counts", "node flags + scans", "who splits", "new list + keys", "best per leaf"])]):
     full = acc[k]
     used = full[:, :8].sum(axis=1) > 0
     full = full[used]
+    if k == 3:
+        for lvl in np.unique(full[:, 12]):
+            g = full[full[:, 12] == lvl]
+            print('   level', int(lvl), 'workgroups', len(g), 'candidates %.0f' % g[:, 11].astype(float).mean(), 'rounds %.1f' % g[:, 7].astype(float).mean(), 'mean clk per phase', g[:, :7].astype(float).mean(axis=0).round().astype(int).tolist(), 'residence %.1f us' % ((g[:, 13] - g[:, 15]).astype(float).mean() / 100))
     if k == 2:
         for wv in np.unique(full[:, 12]):
             g = full[full[:, 12] == wv]
