@@ -1732,6 +1732,8 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     // rounds) its workgroups pin their LDS on every CU and keep the LDS-hungry kernels of the other pipeline contexts
     // (FAST, blur) off it.  With room for 4096 keys (60 KB per workgroup) the kernel alone is 20 % faster and the
     // 64-frame step 4-5 % slower than with 1536 (39 KB; levels 0-2 of a 640 x 480 frame then keep their keys in HBM).
+    // (Since the keys of levels up to 2048 candidates live in registers, the LDS slots only serve larger levels' arrays -- but giving
+    // them up (kcap = 0, 28 KB per workgroup) made the step 1 % SLOWER: measured 0.266 against 0.263 ms; kept.)
     ex->oct_kcap = 1536;
     if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
