@@ -794,17 +794,29 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     uint32_t kp[OCT_KPT];
     int kn[OCT_KPT], kqv[OCT_KPT];
     if (regs) {
+        // cell of key k = largest c with s_cell[c] <= k: the bisections of a thread's keys run in lockstep, one LDS read of each
+        // in flight per step (one after the other they were 8 x 9 dependent reads)
+        // (OCT_KB keys at a time here and in the passes below: batching all eight took 187 VGPRs, and what the kernel holds on
+        // a CU for 60 us is what the other contexts' kernels cannot have -- the step lost 4 % to it)
 #pragma unroll
-        for (int u = 0; u < OCT_KPT; ++u) {
-            const int k = tid + u * OCT_T;
-            kp[u] = 0; kn[u] = 0; kqv[u] = 0;
-            if (k < M) {
-                int lo = 0, hiC = lv.ncells; // largest c with s_cell[c] <= k
-                while (hiC - lo > 1) {
-                    const int mid = (lo + hiC) >> 1;
-                    if (s_cell[mid] <= k) lo = mid; else hiC = mid;
+        for (int u = 0; u < OCT_KPT; ++u) { kp[u] = 0; kn[u] = 0; kqv[u] = 0; }
+#pragma unroll
+        for (int h = 0; h < OCT_KPT; h += OCT_KB) {
+            if (h * OCT_T >= M) break;
+            int lo[OCT_KB], hi[OCT_KB];
+#pragma unroll
+            for (int v = 0; v < OCT_KB; ++v) { lo[v] = 0; hi[v] = lv.ncells; }
+            for (int span = lv.ncells; span > 1; span = (span + 1) >> 1) {
+#pragma unroll
+                for (int v = 0; v < OCT_KB; ++v) {
+                    const int mid = (lo[v] + hi[v]) >> 1;
+                    if (hi[v] - lo[v] > 1) { if (s_cell[mid] <= min(tid + (h + v) * OCT_T, M - 1)) lo[v] = mid; else hi[v] = mid; }
                 }
-                kp[u] = cands[(size_t)f * cands_per_frame + s_coff[lo] + (k - s_cell[lo])];
+            }
+#pragma unroll
+            for (int v = 0; v < OCT_KB; ++v) {
+                const int k = tid + (h + v) * OCT_T;
+                if (k < M) kp[h + v] = cands[(size_t)f * cands_per_frame + s_coff[lo[v]] + (k - s_cell[lo[v]])];
             }
         }
 #pragma unroll
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     }
     if (regs) {
 #pragma unroll
-        for (int u = 0; u < OCT_KPT; ++u) kn[u] = tid + u * OCT_T < M ? a1[kn[u]] : 0;
+        for (int u = 0; u < OCT_KPT; ++u) { if (u * OCT_T >= M) break; kn[u] = tid + u * OCT_T < M ? a1[kn[u]] : 0; }
     } else
     for (int k = tid; k < M; k += OCT_T) knode[k] = (unsigned short)a1[knode[k]];
     __syncthreads();
@@ -885,15 +897,22 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         // children counts of every expandable node (DivideNode, :511-526)
         if (regs) {
 #pragma unroll
-            for (int u = 0; u < OCT_KPT; ++u) {
-                const int s = kn[u];
-                if (tid + u * OCT_T < M && cn[s] > 1) {
-                    const float x = (float)((kp[u] >> 8) & 0xfffu), y = (float)(kp[u] >> 20);
-                    const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
-                    const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2);
-                    const int my = y0 + (int)ceilf((float)(y1 - y0) / 2);
-                    kqv[u] = (x < (float)mx ? 0 : 1) + (y < (float)my ? 0 : 2);
-                    atomicAdd(&cc[4 * s + kqv[u]], 1);
+            for (int h = 0; h < OCT_KPT; h += OCT_KB) {
+                if (h * OCT_T >= M) break;
+                int ncn[OCT_KB], ncx[OCT_KB], ncy[OCT_KB];   // the node's state, read for OCT_KB of the thread's keys at once
+#pragma unroll
+                for (int v = 0; v < OCT_KB; ++v) { ncn[v] = cn[kn[h + v]]; ncx[v] = cx[kn[h + v]]; ncy[v] = cy[kn[h + v]]; }
+#pragma unroll
+                for (int v = 0; v < OCT_KB; ++v) {
+                    const int u = h + v;
+                    if (tid + u * OCT_T < M && ncn[v] > 1) {
+                        const float x = (float)((kp[u] >> 8) & 0xfffu), y = (float)(kp[u] >> 20);
+                        const int x0 = ncx[v] & 0xffff, x1 = ncx[v] >> 16, y0 = ncy[v] & 0xffff, y1 = ncy[v] >> 16;
+                        const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2);
+                        const int my = y0 + (int)ceilf((float)(y1 - y0) / 2);
+                        kqv[u] = (x < (float)mx ? 0 : 1) + (y < (float)my ? 0 : 2);
+                        atomicAdd(&cc[4 * kn[u] + kqv[u]], 1);
+                    }
                 }
             }
         } else
@@ -1018,17 +1037,22 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
         if (regs) {
 #pragma unroll
-            for (int u = 0; u < OCT_KPT; ++u) {
-                const int s = kn[u];
-                int pos;
-                if (split[s]) {
-                    int after = 0;
-                    for (int q2 = kqv[u] + 1; q2 < 4; ++q2) after += cc[4 * s + q2] > 0;
-                    pos = bstart[s] + after;
-                } else {
-                    pos = F + a1[s];
+            for (int h = 0; h < OCT_KPT; h += OCT_KB) {
+                if (h * OCT_T >= M) break;
+                int nsp[OCT_KB], nbs[OCT_KB], na1[OCT_KB];
+                int4 ncc[OCT_KB];
+#pragma unroll
+                for (int v = 0; v < OCT_KB; ++v) {
+                    const int s = kn[h + v];
+                    nsp[v] = split[s]; nbs[v] = bstart[s]; na1[v] = a1[s];
+                    ncc[v] = *reinterpret_cast<const int4 *>(cc + 4 * s);
                 }
-                kn[u] = tid + u * OCT_T < M ? pos : 0;
+#pragma unroll
+                for (int v = 0; v < OCT_KB; ++v) {
+                    const int u = h + v, q = kqv[u];
+                    const int after = (q < 1 && ncc[v].y > 0) + (q < 2 && ncc[v].z > 0) + (q < 3 && ncc[v].w > 0);   // later non-empty children
+                    kn[u] = tid + u * OCT_T < M ? (nsp[v] ? nbs[v] + after : F + na1[v]) : 0;
+                }
             }
         } else
         for (int k = tid; k < M; k += OCT_T) {

@@ -16,7 +16,7 @@ constexpr int PADX = 32;  // left pad (bytes) of every pyramid row
 constexpr int MAXL = 16;
 constexpr int MIN_BORDER = EDGE - 3; // minBorderX/Y, ORBextractor.cc:773
 constexpr int OCT_T = 256;           // threads of k_octree
-constexpr int OCT_KPT = 8;           // keys a k_octree thread keeps in registers (levels above OCT_KPT x OCT_T candidates: arrays)
+constexpr int OCT_KPT = 8, OCT_KB = 4; // keys a k_octree thread keeps in registers (levels above OCT_KPT x OCT_T candidates: arrays); keys per batch of LDS reads
 constexpr int OCT_MAXN = 2047;       // largest per-level feature quota supported (node state of k_octree in LDS)
 
 struct LevelInfo {
