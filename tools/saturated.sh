@@ -1,7 +1,8 @@
 #!/bin/bash
 # Development aid: each kernel's cost in the pipelined step.  tools/skip_hook.patch (never part of the product build) adds
 # an ORBX_SKIP bit mask to the launch sequence: 1 level0, 2 resize, 4 FAST, 8 octree, 16 blur, 32 describe, 64 match.
-# Locally:   git apply tools/skip_hook.patch && make -C orb_slam2_e_amd/csrc && cp orb_slam2_e_amd/liborbslam_hip.so \
+# Locally:   (python3 tools/make_skip_hook.py regenerates the patch when the sources have moved on)
+#            git apply tools/skip_hook.patch && make -C orb_slam2_e_amd/csrc && cp orb_slam2_e_amd/liborbslam_hip.so \
 #            orb_slam2_e_amd/lib_skip.so && git checkout orb_slam2_e_amd/csrc && make -C orb_slam2_e_amd/csrc
 # On the GPU box: tools/saturated.sh  -> ms per 64-frame step (a) with everything, (b) WITHOUT one kernel kind (its marginal
 # cost in the mix = all - without) and (c) with ONLY one kind on the 3 streams (its "saturated" time).
