@@ -292,10 +292,10 @@ __global__ __launch_bounds__(64 * XW) void k_match_sets_mfma(const uint8_t *__re
         if (h == 0) { sk[seg][q][0][r] = k1[q]; sk[seg][q][1][r] = k2[q]; }
     }
     __syncthreads();
-    // waves 0 and 1 finish the 128 queries, 64 each: lane -> query tile 2 seg + h, row r
+    // the first waves finish the workgroup's queries, 64 each: lane -> query tile 2 seg + h, row r
     bool ok = false;
     const int qt = 2 * seg + h, i = row0 + qt * 32 + r;
-    if (seg < 2 && i < nA) {
+    if (qt < XQ && i < nA) {
         unsigned m1 = sk[0][qt][0][r], m2 = sk[0][qt][1][r];
 #pragma unroll
         for (int g = 1; g < XW; ++g) merge_pairs(m1, m2, sk[g][qt][0][r], sk[g][qt][1][r]);
