@@ -249,12 +249,17 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
             if (mine && dirty) {
                 sp1 = sp2 = -1; best = second = INT_MAX; l1 = l2 = -1;
                 int found = 0;
+                // the state of all TOPK short-list slots is read at once (one after the other, each behind the test of the one
+                // before, they were up to eight dependent LDS round trips per pass on a workgroup of ONE wave)
+                int st[TOPK];
+#pragma unroll
+                for (int r = 0; r < TOPK; ++r) st[r] = MODE == 0 ? s_b[tp[r] == 0xffffffffu ? 0 : (tp[r] & 0xffffu)] : s_a[tp[r] == 0xffffffffu ? 0 : (tp[r] & 0xffffu)];
 #pragma unroll
                 for (int r = 0; r < TOPK; ++r) {
                     const unsigned en = tp[r];
                     if (en != 0xffffffffu && found < 2) {
                         const int sp = en & 0xffffu, dist = (int)(en >> 20);
-                        if (MODE == 0 ? s_b[sp] == 0 : s_a[sp] > dist) {
+                        if (MODE == 0 ? st[r] == 0 : st[r] > dist) {
                             if (found == 0) { sp1 = sp; best = dist; l1 = (en >> 16) & 15; }
                             else { sp2 = sp; second = dist; l2 = (en >> 16) & 15; }
                             ++found;
