@@ -140,7 +140,7 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
     if (FILL) {
         if (FILL == 2 && lane == 0) {
             lbeg[i] = obase; lend[i] = obase + min(c, ocap);
-            if (c > ocap) atomicOr(overflow, 1);
+            if (c > ocap) atomicAnd(overflow, 0);   // preset to -1 by the host's fill: 0 = some list did not fit
         }
         __threadfence_block();
         wave_topk(ent, obase, min(c, ocap), lane, top + (size_t)i * TOPK);
@@ -749,9 +749,14 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         }
         if (seg) memcpy(w.h<char>(o_seg), seg, sizeof(int) * (size_t)(nseg + 1));
         ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
-        ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * (size_t)(n ? n : 1), st)); // -1: slot untouched
-        ORBX_HIP(hipMemsetAsync(w.d<char>(o_nm), 0, 2 * sizeof(int), st));
-        if (seg) ORBX_HIP(hipMemsetAsync(w.d<char>(o_state), 0xff, sizeof(int) * (size_t)ns, st));    // segments write back touched slots only
+        // ONE fill for everything that needs a preset (a launch each was 3-4 us of a 0.1-ms call): match_kp = -1 (slot untouched);
+        // segments write back touched slots of the state only, so it is preset to -1 as well (the span in between, match_q, is
+        // rewritten in full anyway); and the two counters START AT -1: the match count is overwritten (one workgroup) or added
+        // to (segments: the host adds the 1 back), the overflow flag is CLEARED to 0 by a list that does not fit
+        {
+            const size_t f0 = seg ? o_state : o_mk;
+            ORBX_HIP(hipMemsetAsync(w.d<char>(f0), 0xff, o_nm + 2 * sizeof(int) - f0, st));
+        }
 
         const WinQuery *dq = w.d<WinQuery>(o_q);
         const uint4 *da = w.d<uint4>(o_a), *db = w.d<uint4>(o_b);
@@ -803,13 +808,14 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         ORBX_HIP(hipStreamSynchronize(st));
         int flag = 0;
         memcpy(&flag, w.pin + (o_nm - o_res) + sizeof(int), sizeof(int));
-        if (!cand_off && !exact && flag) { // a window list outgrew its region: once more on the exact path
+        if (!cand_off && !exact && flag == 0) { // a window list outgrew its region: once more on the exact path
             exact = true;
             continue;
         }
         memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
         if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
         memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
+        if (seg) *nmatches += 1;   // the segments added their counts to the preset -1
         break;
     }
     return ORBX_OK;
