@@ -187,7 +187,7 @@ typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
 // padding (outside the 19-px border) are not written: the workspace is zeroed once.
 __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo src,
                                                    LevelInfo dst, const int2 *__restrict__ xt,
-                                                   const int4 *__restrict__ yt, int nff, int nint, int nrg, int ntail, int tw_shift, int ntw, int rpw)
+                                                   const int4 *__restrict__ yt, int nff, int nint, int nrg, int ntail, int tw_shift, int ntw, int rpw, int tail_window)
 {
     const int f = blockIdx.z, tid = threadIdx.x;
     ORBX_PH_INIT(2);
@@ -287,6 +287,38 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
             sxs[b] = xx.x; a0[b] = xx.y & 0xffff; a1[b] = xx.y >> 16;
             keep |= in ? 0xffu << (8 * b) : 0u;
         }
+        if (tail_window) {
+            // The four pixels of a border group are reflections of interior pixels, so their source columns lie as close together as
+            // an interior group's (in mirrored order): one 8-byte window from the smallest of them serves all four, as in the
+            // full waves (the host checks the span per level) -- 8 loads per lane instead of 64 single bytes, which made a tail
+            // wave six times as expensive for the texture addresser as a full one.
+            const int smin = min(min(sxs[0], sxs[1]), min(sxs[2], sxs[3]));
+            uint32_t sel[4], coef[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                sel[b] = 0x0c010c00u + (uint32_t)(sxs[b] - smin) * 0x00010001u;   // {byte o, 0, byte o+1, 0}
+                coef[b] = (uint32_t)a0[b] | ((uint32_t)a1[b] << 16);
+            }
+            uint2 w0[PYR_ROWS], w1[PYR_ROWS];
+#pragma unroll
+            for (int r = 0; r < PYR_ROWS; ++r) {
+                __builtin_memcpy(&w0[r], base + (uint32_t)((yy[r].x + EDGE) * src.stride + smin), 8);
+                __builtin_memcpy(&w1[r], base + (uint32_t)((yy[r].y + EDGE) * src.stride + smin), 8);
+            }
+#pragma unroll
+            for (int r = 0; r < PYR_ROWS; ++r) {
+                out[r] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w0[r].y, w0[r].x, sel[b])),
+                                                               __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                    const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(w1[r].y, w1[r].x, sel[b])),
+                                                               __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                    out[r] |= resize_vertical(r0, r1, (uint32_t)yy[r].z << 12, (uint32_t)yy[r].w << 12) << (8 * b);
+                }
+                out[r] &= keep;
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; ++r) {
             const uint8_t *S0 = base + (size_t)(yy[r].x + EDGE) * src.stride;
@@ -1719,6 +1751,22 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 window_ok = window_ok && g[3].x + 1 - g[0].x <= 7;
             }
             ex->resize_nxi[l] = window_ok ? 1 : 0;   // the 8-byte-window fast path may serve this level's interior groups
+            {   // ... and the tail tiles' groups (border groups: reflected columns; row padding: clamped ones) if every dword group of
+                // the padded row keeps its four source columns within 7 bytes
+                bool ok = true;
+                for (int xw = (PADX - EDGE) >> 2; xw <= (PADX + lv.w + EDGE - 1) >> 2; ++xw) {
+                    int lo = 1 << 30, hi = -1;
+                    for (int b = 0; b < 4; ++b) {
+                        int px = xw * 4 - PADX + b;
+                        px = px < -EDGE ? -EDGE : px > lv.w + EDGE - 1 ? lv.w + EDGE - 1 : px;
+                        if (lv.w == 1) px = 0; else while (px < 0 || px >= lv.w) px = px < 0 ? -px : 2 * (lv.w - 1) - px;   // reflect101
+                        const int sx = xt[lv.xtab + px].x;
+                        lo = sx < lo ? sx : lo; hi = sx > hi ? sx : hi;
+                    }
+                    ok = ok && hi - lo <= 6;
+                }
+                ex->resize_tailwin[l] = ok ? 1 : 0;
+            }
             resize_axis(lv.h, sv.h, o, c0, c1);
             for (int d = 0; d < lv.h; d++) {
                 const int s = o[d];
@@ -1879,7 +1927,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         dim3 g(nff * ((nrg + rpw - 1) / rpw) + ntailw, 1, batch);
         pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
-                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nint, nrg, ntail, tw_shift, ntw, rpw);
+                           ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nint, nrg, ntail, tw_shift, ntw, rpw, ex->resize_tailwin[l]);
         pf.stop(1, st);
     }
     pf.start(2, st);
