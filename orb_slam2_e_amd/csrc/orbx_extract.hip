@@ -1178,14 +1178,15 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int ti = wg * 4 + wave;
     if (ti >= ntiles) return;
     const int r = lane & 31, h = lane >> 5;
-    const uint4 f1 = frag[2 * lane], f2 = frag[2 * lane + 1];
-    const blur_v4i b1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w}, b2 = {(int)f2.x, (int)f2.y, (int)f2.z, (int)f2.w};
     blur_v16i c1, c2, z;
 #pragma unroll
     for (int g = 0; g < 16; ++g) { c1[g] = WIDE ? 128 : 0; c2[g] = seed2; z[g] = 0; }
-    const BlurTile bt = tiles[ti];
-    const LevelInfo lv = L[bt.level];
-    const size_t base = (size_t)f * frame_bytes + lv.off + PADX;
+    const BlurTile bt = tiles[ti];   // wave-uniform index: a scalar load
+    struct { int w, h, stride; } lv = {bt.w, bt.h, bt.stride};
+    const size_t base = (size_t)f * frame_bytes + bt.off + PADX;
+    // the Toeplitz fragments (per-lane constants) are requested HERE, beside the window: left to the compiler they sank below the
+    // window's LDS stores, a memory round trip of their own in front of the first MFMA
+    uint4 f1 = frag[2 * lane], f2 = frag[2 * lane + 1];
     uint8_t *const st = stage[wave], *const wn = win[wave];
     // input window: rows y0-3 .. y0+28, columns x0-16 .. x0+111 as 8 aligned 16-byte pieces per row (whole 128-byte
     // lines per row instead of 32 bytes of 32 different lines per load).  Rows past the padded level and pieces past
@@ -1197,6 +1198,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         *reinterpret_cast<uint4 *>(wn + row * BLUR_IROW + 16 * pc) =
             *reinterpret_cast<const uint4 *>(pyr + (base - PADX) + (uint32_t)((yin + EDGE) * lv.stride + xo));
     }
+    asm volatile("" : "+v"(f1.x), "+v"(f1.y), "+v"(f1.z), "+v"(f1.w), "+v"(f2.x), "+v"(f2.y), "+v"(f2.z), "+v"(f2.w));   // pins the loads above this point
+    const blur_v4i b1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w}, b2 = {(int)f2.x, (int)f2.y, (int)f2.z, (int)f2.w};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1727,7 +1730,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         // blur tiles
         for (int y0 = 0; y0 < lv.h; y0 += BLUR_TH)
             for (int x0 = 0; x0 < lv.w; x0 += BLUR_SW) {
-                BlurTile t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0;
+                BlurTile t; t.x0 = (short)x0; t.y0 = (short)y0; t.w = (short)lv.w; t.h = (short)lv.h; t.off = lv.off; t.stride = lv.stride;
                 ex->tiles.push_back(t);
             }
         // resize tables from level l-1

@@ -51,7 +51,9 @@ struct alignas(16) CellInfo : FastCell {
     int pad;
 };
 
-struct BlurTile { short level, x0, y0, pad; };
+// a blur tile strip with what k_blur needs of its level: 16 bytes, one scalar load (a tile record pointing into the level
+// table was two dependent loads, the first a per-lane one, in front of the window loads)
+struct alignas(16) BlurTile { short x0, y0, w, h; int off, stride; };
 
 } // namespace orbx_detail
 
