@@ -687,6 +687,153 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
     if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
 }
 
+// Batches of meshes that fit a compute unit: ALL iterations of a mesh's CG in one launch, one 1024-thread workgroup per mesh
+// (one per CU: the batch of 256 fills the chip).  What an iteration needs besides the matrix stays on the CU: p and Ap in LDS
+// (16 bytes per dof), x, r and 1/diag in the registers of the thread that owns the row, the scalars in the workgroup.  HBM
+// then streams the block-major values and ONE column index per 3 x 3 block, once per iteration, and nothing else: no vector
+// traffic (a third of an iteration's bytes in the launch-per-phase form), no gathers through the texture addresser (p comes
+// from LDS), no launches, and the loads of the next iteration's first blocks are in flight while the workgroup reduces.
+// A wave takes chunks of <= CGR_CB blocks = whole block rows (host table: first block row, block rows, first block, blocks),
+// a lane a block; the three row sums of a block are parked in the wave's own LDS slice and summed per row by one lane, in
+// block order; no workgroup barrier inside the product.  Three barriers per iteration.
+constexpr int CGR_T = 512, CGR_W = CGR_T / 64, CGR_NB = 4, CGR_CB = 64 * CGR_NB, CGR_MAXROWS = 7168, CGR_U = CGR_MAXROWS / CGR_T, CGR_MIN_MESHES = 64;
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restrict__ vals_b, const int *__restrict__ bcol3,
+                                                           const int *__restrict__ bp, const int4 *__restrict__ rcd,
+                                                           const int *__restrict__ rcfirst, size_t nnzs, int ndof, int ldn,
+                                                           int niter, CgScal *__restrict__ sc, double *__restrict__ p,
+                                                           const double *__restrict__ dinv, double *__restrict__ x,
+                                                           double *__restrict__ r, const int4 *__restrict__ minfo)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mesh = blockIdx.x;
+    // uniform layout: shared tables numbered from 0, values at mesh * nnzs; segmented: global numbering throughout
+    const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
+    const int nrows = minfo ? minfo[mesh].y : ndof;
+    const int tabrow0 = minfo ? (int)row0 : 0;
+    const int c0 = rcfirst[minfo ? mesh : 0], c1 = rcfirst[minfo ? mesh + 1 : 1];
+    const float *vb = vals_b + (minfo ? (size_t)0 : (size_t)mesh * nnzs);
+    double *p_s = lds, *Ap_s = lds + ldn, *part = lds + 2 * ldn + wave * (3 * CGR_CB), *sh = lds + 2 * ldn + CGR_W * (3 * CGR_CB);
+    double xv[CGR_U], rv[CGR_U], dv[CGR_U];
+#pragma unroll
+    for (int u = 0; u < CGR_U; ++u) {
+        const int i = min(u * CGR_T + tid, nrows - 1);
+        xv[u] = x[row0 + i]; rv[u] = r[row0 + i]; dv[u] = dinv[row0 + i];
+        if (u * CGR_T + tid < nrows) p_s[i] = p[row0 + i];
+    }
+    double rz = sc[mesh].rz[0], rr = sc[mesh].rr;   // both rz slots hold the current value between launches of this kernel
+    // a chunk's loads: its descriptor (wave-uniform), per lane two blocks (clamped: lanes past the chunk repeat its last
+    // block) and the block-row pointer of block row `lane`
+    float nva[CGR_NB][9]; int nca[CGR_NB], nbpl; int4 nd;
+    auto issue = [&](int c) {
+        nd = rcd[c];
+#pragma unroll
+        for (int u = 0; u < CGR_NB; ++u) {
+            const int q = nd.z + min(lane + 64 * u, nd.w - 1);
+            __builtin_memcpy(nva[u], vb + 9 * (size_t)q, 36);
+            nca[u] = bcol3[q] - tabrow0;
+        }
+        nbpl = bp[nd.x + min(lane, nd.y)] - nd.z;
+    };
+    const bool any = c0 + wave < c1;
+    if (any) issue(c0 + wave);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        double pap = 0;
+        for (int c = c0 + wave; c < c1; c += CGR_W) {
+            float va[CGR_NB][9]; int ca[CGR_NB];
+            const int4 d = nd;
+            const int bpl = nbpl;
+#pragma unroll
+            for (int u = 0; u < CGR_NB; ++u) {
+                ca[u] = nca[u];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) va[u][k] = nva[u][k];
+            }
+            {   // the next chunk of this wave -- across the iteration boundary too: the matrix does not wait for p
+                const int cn = c + CGR_W < c1 ? c + CGR_W : c0 + wave;
+                if (c + CGR_W < c1 || it + 1 < niter) issue(cn);
+            }
+#pragma unroll
+            for (int u = 0; u < CGR_NB; ++u) {
+                const double *pp = p_s + ca[u];
+                const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                double *dst = part + 3 * min(lane + 64 * u, d.w - 1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    dst[i] = ((double)va[u][3 * i] * p0 + (double)va[u][3 * i + 1] * p1) + (double)va[u][3 * i + 2] * p2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // a lane per row of the chunk: its blocks' partials in block order (8 lanes per row with a shuffle tree, as k_fem_spmv
+            // does it, cost this kernel twice the instructions of the products themselves)
+            const int nr = 3 * d.y;
+            for (int rb = 0; rb < nr; rb += 64) {
+                const int row = rb + lane, I = (row * 171) >> 9, i = row - 3 * I;   // row / 3 for row < 512
+                const int b0 = __shfl(bpl, I), nb = __shfl(bpl, I + 1) - b0;
+                if (row < nr) {
+                    const double *q = part + 3 * b0 + i;
+                    double s = 0;
+#pragma unroll 4
+                    for (int j = 0; j < nb; ++j) s += q[3 * j];
+                    const int g = 3 * d.x - tabrow0 + row;   // the mesh's own row number
+                    Ap_s[g] = s;
+                    pap += p_s[g] * s;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        pap = wave_sum_f64(pap);
+        double *shi = sh + (it & 1) * (3 * CGR_W);     // two sets of slots: a set is rewritten two barriers after its last read
+        if (lane == 0) shi[wave] = pap;
+        __syncthreads();                                // Ap complete, partials of p.Ap visible
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < CGR_W; ++w) t += shi[w];
+        const double alpha = rz / t;
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int u = 0; u < CGR_U; ++u) {
+            const int i = u * CGR_T + tid, ic = min(i, nrows - 1);
+            const double ri = rv[u] - alpha * Ap_s[ic];
+            if (i < nrows) {
+                xv[u] += alpha * p_s[ic];
+                rv[u] = ri;
+                s1 += ri * (ri * dv[u]);
+                s2 += ri * ri;
+            }
+        }
+        s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+        if (lane == 0) { shi[CGR_W + wave] = s1; shi[2 * CGR_W + wave] = s2; }
+        __syncthreads();
+        double rz2 = 0; rr = 0;
+#pragma unroll
+        for (int w = 0; w < CGR_W; ++w) { rz2 += shi[CGR_W + w]; rr += shi[2 * CGR_W + w]; }
+        const double beta = rz2 / rz;
+        rz = rz2;
+#pragma unroll
+        for (int u = 0; u < CGR_U; ++u) {
+            const int i = u * CGR_T + tid;
+            if (i < nrows) p_s[i] = rv[u] * dv[u] + beta * p_s[i];   // r/diag: the same product as in the sum above
+        }
+        __syncthreads();                                // the new p is complete before anyone gathers from it
+    }
+#pragma unroll
+    for (int u = 0; u < CGR_U; ++u) {
+        const int i = u * CGR_T + tid;
+        if (i < nrows) { x[row0 + i] = xv[u]; r[row0 + i] = rv[u]; p[row0 + i] = p_s[i]; }
+    }
+    if (tid == 0) { sc[mesh].rz[0] = rz; sc[mesh].rz[1] = rz; sc[mesh].rr = rr; }
+}
+
 // FEA2 is a stack object per PoseOptimizationNR call (Optimizer.cc:480): a model is created and destroyed every
 // frame with nearly the same sizes.  Device blocks, pinned blocks and streams are therefore recycled through
 // small process-wide caches (size classes = powers of two, blocks above 64 MiB are not kept), so a steady-state
@@ -778,6 +925,9 @@ struct fem_model {
     int *d_elems = nullptr, *d_blk_row = nullptr, *d_bptr = nullptr, *d_cptr = nullptr, *d_contrib = nullptr;
     int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr, *d_bcol3 = nullptr, *d_bp = nullptr;
     float *d_vals_b = nullptr;   // block-major copy of d_vals for the CG (fem_cg_setup)
+    // k_fem_cg_resident: chunk table {first block row, block rows, first block, blocks} and each mesh's chunk range
+    int4 *d_rcd = nullptr; int *d_rcfirst = nullptr;
+    bool cg_resident = false; int cgr_lds = 0, cgr_ldn = 0;
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -795,7 +945,7 @@ void fem_free(fem_model *m)
                     m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
                     m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s, m->d_nel_ptr, m->d_nel, m->d_contrib_loc,
-                    m->d_ke1, m->d_bcol3, m->d_bp, m->d_vals_b};
+                    m->d_ke1, m->d_bcol3, m->d_bp, m->d_vals_b, m->d_rcd, m->d_rcfirst};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -861,6 +1011,22 @@ void launch_iter(fem_model *m, hipStream_t st)
                        m->d_r, m->d_dinv, m->d_p, (const int *)m->d_cmesh, (const int4 *)m->d_minfo);
     m->prof.stop(4, st);
     m->cg_it++;
+}
+
+// n iterations of the batch: one launch where a mesh fits a compute unit (k_fem_cg_resident), else launch by launch
+void run_iters(fem_model *m, int n, hipStream_t st)
+{
+    if (m->cg_resident) {
+        if (n <= 0) return;
+        m->prof.start(5, st);
+        hipLaunchKernelGGL(k_fem_cg_resident, dim3(m->nseg), dim3(CGR_T), m->cgr_lds, st, m->d_vals_b, m->d_bcol3, m->d_bp,
+                           (const int4 *)m->d_rcd, (const int *)m->d_rcfirst, m->nnzs, m->ndof, m->cgr_ldn, n, m->d_sc, m->d_p, m->d_dinv,
+                           m->d_x, m->d_r, (const int4 *)m->d_minfo);
+        m->prof.stop(5, st);
+        m->cg_it += 2 * ((n + 1) / 2);   // both rz slots are current after the launch: keep the parity of the other path even
+        return;
+    }
+    for (int i = 0; i < n; ++i) launch_iter(m, st);
 }
 
 // Symbolic phase of one mesh (host, once per topology): block pattern, contribution lists, CSR pattern.
@@ -1054,6 +1220,34 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         ORBX_HIP(hipMemcpy(m->d_bp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice));
         m->h_bp.swap(bp);
     }
+    {   // k_fem_cg_resident: whole batches of meshes small enough for one compute unit each
+        std::vector<int4> rcd; std::vector<int> rcfirst(1, 0);
+        bool ok = m->nseg >= CGR_MIN_MESHES;
+        int maxrows = 0;
+        auto chunks_of = [&](int I0, int nbr) {
+            for (int I = I0; I < I0 + nbr && ok;) {
+                const int q0 = m->h_bp[I];
+                int J = I;
+                while (J < I0 + nbr && m->h_bp[J + 1] - q0 <= CGR_CB && J - I < 63) ++J;
+                if (J == I) { ok = false; break; }       // a block row longer than a chunk
+                rcd.push_back(make_int4(I, J - I, q0, m->h_bp[J] - q0));
+                I = J;
+            }
+            rcfirst.push_back((int)rcd.size());
+            maxrows = std::max(maxrows, 3 * nbr);
+        };
+        if (seg_nn) for (int k = 0; k < nseg && ok; ++k) chunks_of(m->seg_node0[k], seg_nn[k]);
+        else if (ok) chunks_of(0, m->ndof / 3);
+        const size_t lds = ((size_t)2 * maxrows + CGR_W * 3 * CGR_CB + 6 * CGR_W) * sizeof(double);
+        ok = ok && maxrows > 0 && maxrows <= CGR_MAXROWS && lds <= 160 * 1024;
+        if (ok) {
+            if (dalloc(&m->d_rcd, rcd.size()) || dalloc(&m->d_rcfirst, rcfirst.size())) { fem_free(m); delete m; ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed"); }
+            ORBX_HIP(hipMemcpy(m->d_rcd, rcd.data(), sizeof(int4) * rcd.size(), hipMemcpyHostToDevice));
+            ORBX_HIP(hipMemcpy(m->d_rcfirst, rcfirst.data(), sizeof(int) * rcfirst.size(), hipMemcpyHostToDevice));
+            ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cg_resident), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            m->cg_resident = true; m->cgr_lds = (int)lds; m->cgr_ldn = maxrows;
+        }
+    }
     ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
     if (seg_nn) {
         ORBX_HIP(hipMemcpy(m->d_cmesh, cmesh.data(), sizeof(int) * cmesh.size(), hipMemcpyHostToDevice));
@@ -1064,6 +1258,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
     if (m->nseg >= CGS_MIN_MESHES) { m->prof.names[3] = "k_fem_cg_step"; m->prof.names[4] = nullptr; }   // one launch does both
+    if (m->cg_resident) m->prof.names[5] = "k_fem_cg_resident";
     if (m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
                                reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
@@ -1480,6 +1675,7 @@ int fem_cg_iterate(fem_model *m, int n, void *stream)
     if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     m->cg_stream = st;
+    if (m->cg_resident) { run_iters(m, n, st); ORBX_HIP(hipGetLastError()); return ORBX_OK; }
     int i = 0;
     // Small batches are launch-bound (3 short kernels per iteration): replay a captured
     // hipGraph of GRAPH_ITERS iterations.  Graph nodes carry no timing events, so this
@@ -1552,7 +1748,7 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
             if (all) break;
         }
         const int n = iters - done < 25 ? iters - done : 25;
-        for (int i = 0; i < n; ++i) launch_iter(m, m->stream);
+        run_iters(m, n, m->stream);
         done += n;
     }
     ORBX_HIP(hipGetLastError());
