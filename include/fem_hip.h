@@ -116,7 +116,9 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
  * The solver works on a block-major copy of the matrix values (3 x 3 node blocks kept together), made from the values
  * as they stand when fem_cg / fem_cg_setup is called: another 4 bytes per non-zero of device memory while a model has
  * been solved with, and changes of K (assembly, penalties) after that call are seen by the next call, not by
- * fem_cg_iterate. */
+ * fem_cg_iterate.  Batches of 64 or more meshes of at most 14,336 dofs each run one mesh per compute unit with the
+ * iteration vectors in LDS and registers (all iterations of a call in one launch); other models launch phase by
+ * phase.  Both sum in fixed orders: a given model, right-hand side and iteration count give the same bits every run. */
 int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int *iters_done, double *relres);
 
 /* Resident variants for timing: upload the right-hand side and reset the solver

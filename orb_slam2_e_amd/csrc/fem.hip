@@ -696,19 +696,23 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
 // A wave takes chunks of <= CGR_CB blocks = whole block rows (host table: first block row, block rows, first block, blocks),
 // a lane a block; the three row sums of a block are parked in the wave's own LDS slice and summed per row by one lane, in
 // block order; no workgroup barrier inside the product.  Three barriers per iteration.
-constexpr int CGR_T = 512, CGR_W = CGR_T / 64, CGR_NB = 4, CGR_CB = 64 * CGR_NB, CGR_MAXROWS = 7168, CGR_U = CGR_MAXROWS / CGR_T, CGR_MIN_MESHES = 64;
+// BIG: meshes of up to 14,336 dofs (8 bytes of LDS per dof for p): Ap and x live in the mesh's slice of the batch vectors instead
+// (written and read by the same compute unit: with 1/diag + 48 bytes per dof and iteration beside the matrix's ~175), r in registers.
+constexpr int CGR_T = 512, CGR_W = CGR_T / 64, CGR_NB = 4, CGR_CB = 64 * CGR_NB, CGR_MAXROWS = 7168, CGR_MAXROWS_BIG = 14336, CGR_MIN_MESHES = 64;
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+template <bool BIG>
 __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restrict__ vals_b, const int *__restrict__ bcol3,
                                                            const int *__restrict__ bp, const int4 *__restrict__ rcd,
                                                            const int *__restrict__ rcfirst, size_t nnzs, int ndof, int ldn,
                                                            int niter, CgScal *__restrict__ sc, double *__restrict__ p,
                                                            const double *__restrict__ dinv, double *__restrict__ x,
-                                                           double *__restrict__ r, const int4 *__restrict__ minfo)
+                                                           double *__restrict__ r, double *__restrict__ Apg,
+                                                           const int4 *__restrict__ minfo)
 {
     extern __shared__ __align__(16) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -719,12 +723,16 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
     const int tabrow0 = minfo ? (int)row0 : 0;
     const int c0 = rcfirst[minfo ? mesh : 0], c1 = rcfirst[minfo ? mesh + 1 : 1];
     const float *vb = vals_b + (minfo ? (size_t)0 : (size_t)mesh * nnzs);
-    double *p_s = lds, *Ap_s = lds + ldn, *part = lds + 2 * ldn + wave * (3 * CGR_CB), *sh = lds + 2 * ldn + CGR_W * (3 * CGR_CB);
-    double xv[CGR_U], rv[CGR_U], dv[CGR_U];
+    constexpr int CGR_U = (BIG ? CGR_MAXROWS_BIG : CGR_MAXROWS) / CGR_T, NV = BIG ? 1 : 2;   // NV: vectors in LDS
+    double *p_s = lds, *Ap_s = lds + ldn, *part = lds + NV * ldn + wave * (3 * CGR_CB), *sh = lds + NV * ldn + CGR_W * (3 * CGR_CB);
+    double *xg = x + row0, *ag = Apg + row0;
+    const double *dg = dinv + row0;
+    double xv[BIG ? 1 : CGR_U], rv[CGR_U], dv[BIG ? 1 : CGR_U];
 #pragma unroll
     for (int u = 0; u < CGR_U; ++u) {
         const int i = min(u * CGR_T + tid, nrows - 1);
-        xv[u] = x[row0 + i]; rv[u] = r[row0 + i]; dv[u] = dinv[row0 + i];
+        if (!BIG) { xv[u] = x[row0 + i]; dv[u] = dinv[row0 + i]; }
+        rv[u] = r[row0 + i];
         if (u * CGR_T + tid < nrows) p_s[i] = p[row0 + i];
     }
     double rz = sc[mesh].rz[0], rr = sc[mesh].rr;   // both rz slots hold the current value between launches of this kernel
@@ -775,6 +783,21 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
             // a lane per row of the chunk: its blocks' partials in block order (8 lanes per row with a shuffle tree, as k_fem_spmv
             // does it, cost this kernel twice the instructions of the products themselves)
             const int nr = 3 * d.y;
+            if constexpr (BIG) {
+                // Ap goes to the batch vector: ONE unconditional store per chunk (a BIG chunk has at most 21 block rows = one
+                // pass; lanes past its rows repeat the last row: same value to the same address).  A store behind a branch or in
+                // a loop would leave the compiler unable to count the memory operations issued after the next chunk's loads, and
+                // it would then wait for everything -- this store's completion included -- at the top of every chunk
+                const int row = min(lane, nr - 1), I = (row * 171) >> 9, i = row - 3 * I;
+                const int b0 = __shfl(bpl, I), nb = __shfl(bpl, I + 1) - b0;
+                const double *q = part + 3 * b0 + i;
+                double s = 0;
+#pragma unroll 4
+                for (int j = 0; j < nb; ++j) s += q[3 * j];
+                const int g = 3 * d.x - tabrow0 + row;
+                ag[g] = s;
+                pap += lane < nr ? p_s[g] * s : 0.0;
+            } else
             for (int rb = 0; rb < nr; rb += 64) {
                 const int row = rb + lane, I = (row * 171) >> 9, i = row - 3 * I;   // row / 3 for row < 512
                 const int b0 = __shfl(bpl, I), nb = __shfl(bpl, I + 1) - b0;
@@ -800,15 +823,45 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         for (int w = 0; w < CGR_W; ++w) t += shi[w];
         const double alpha = rz / t;
         double s1 = 0, s2 = 0;
+        double dd[BIG ? CGR_U : 1];
+        int tv = tid;
+        asm volatile("" : "+v"(tv));   // BIG: keeps 28 row indices, predicates and addresses from being hoisted out of the iteration loop into registers that do not exist
+        if constexpr (BIG) {
+            // fourteen rows at a time: their Ap, x and 1/diag requested together, the next fourteen only after these are used
+            // (the fence keeps the compiler from hoisting all 84 loads into registers it does not have); 1/diag stays in
+            // registers until the direction update below
 #pragma unroll
-        for (int u = 0; u < CGR_U; ++u) {
-            const int i = u * CGR_T + tid, ic = min(i, nrows - 1);
-            const double ri = rv[u] - alpha * Ap_s[ic];
-            if (i < nrows) {
-                xv[u] += alpha * p_s[ic];
-                rv[u] = ri;
-                s1 += ri * (ri * dv[u]);
-                s2 += ri * ri;
+            for (int sb = 0; sb < CGR_U; sb += 14) {
+                double av[14], xx[14];
+#pragma unroll
+                for (int v = 0; v < 14; ++v) {
+                    const int ic = min((sb + v) * CGR_T + tv, nrows - 1);
+                    av[v] = ag[ic]; xx[v] = xg[ic]; dd[sb + v] = dg[ic];
+                }
+#pragma unroll
+                for (int v = 0; v < 14; ++v) {
+                    const int u = sb + v, i = u * CGR_T + tv;
+                    const double ri = rv[u] - alpha * av[v];
+                    if (i < nrows) {
+                        xg[i] = xx[v] + alpha * p_s[i];
+                        rv[u] = ri;
+                        s1 += ri * (ri * dd[u]);
+                        s2 += ri * ri;
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CGR_U; ++u) {
+                const int i = u * CGR_T + tid, ic = min(i, nrows - 1);
+                const double ri = rv[u] - alpha * Ap_s[ic];
+                if (i < nrows) {
+                    xv[u] += alpha * p_s[ic];
+                    rv[u] = ri;
+                    s1 += ri * (ri * dv[u]);
+                    s2 += ri * ri;
+                }
             }
         }
         s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
@@ -819,17 +872,25 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         for (int w = 0; w < CGR_W; ++w) { rz2 += shi[CGR_W + w]; rr += shi[2 * CGR_W + w]; }
         const double beta = rz2 / rz;
         rz = rz2;
+        if constexpr (BIG) {
 #pragma unroll
-        for (int u = 0; u < CGR_U; ++u) {
-            const int i = u * CGR_T + tid;
-            if (i < nrows) p_s[i] = rv[u] * dv[u] + beta * p_s[i];   // r/diag: the same product as in the sum above
+            for (int u = 0; u < CGR_U; ++u) {
+                const int i = u * CGR_T + tv;
+                if (i < nrows) p_s[i] = rv[u] * dd[u] + beta * p_s[i];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CGR_U; ++u) {
+                const int i = u * CGR_T + tid;
+                if (i < nrows) p_s[i] = rv[u] * dv[u] + beta * p_s[i];   // r/diag: the same product as in the sum above
+            }
         }
         __syncthreads();                                // the new p is complete before anyone gathers from it
     }
 #pragma unroll
     for (int u = 0; u < CGR_U; ++u) {
         const int i = u * CGR_T + tid;
-        if (i < nrows) { x[row0 + i] = xv[u]; r[row0 + i] = rv[u]; p[row0 + i] = p_s[i]; }
+        if (i < nrows) { if (!BIG) x[row0 + i] = xv[u]; r[row0 + i] = rv[u]; p[row0 + i] = p_s[i]; }
     }
     if (tid == 0) { sc[mesh].rz[0] = rz; sc[mesh].rz[1] = rz; sc[mesh].rr = rr; }
 }
@@ -927,7 +988,7 @@ struct fem_model {
     float *d_vals_b = nullptr;   // block-major copy of d_vals for the CG (fem_cg_setup)
     // k_fem_cg_resident: chunk table {first block row, block rows, first block, blocks} and each mesh's chunk range
     int4 *d_rcd = nullptr; int *d_rcfirst = nullptr;
-    bool cg_resident = false; int cgr_lds = 0, cgr_ldn = 0;
+    bool cg_resident = false, cgr_big = false; int cgr_lds = 0, cgr_ldn = 0;
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -1019,9 +1080,9 @@ void run_iters(fem_model *m, int n, hipStream_t st)
     if (m->cg_resident) {
         if (n <= 0) return;
         m->prof.start(5, st);
-        hipLaunchKernelGGL(k_fem_cg_resident, dim3(m->nseg), dim3(CGR_T), m->cgr_lds, st, m->d_vals_b, m->d_bcol3, m->d_bp,
-                           (const int4 *)m->d_rcd, (const int *)m->d_rcfirst, m->nnzs, m->ndof, m->cgr_ldn, n, m->d_sc, m->d_p, m->d_dinv,
-                           m->d_x, m->d_r, (const int4 *)m->d_minfo);
+        hipLaunchKernelGGL(m->cgr_big ? k_fem_cg_resident<true> : k_fem_cg_resident<false>, dim3(m->nseg), dim3(CGR_T), m->cgr_lds, st,
+                           m->d_vals_b, m->d_bcol3, m->d_bp, (const int4 *)m->d_rcd, (const int *)m->d_rcfirst, m->nnzs, m->ndof,
+                           m->cgr_ldn, n, m->d_sc, m->d_p, m->d_dinv, m->d_x, m->d_r, m->d_Ap, (const int4 *)m->d_minfo);
         m->prof.stop(5, st);
         m->cg_it += 2 * ((n + 1) / 2);   // both rz slots are current after the launch: keep the parity of the other path even
         return;
@@ -1224,27 +1285,33 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         std::vector<int4> rcd; std::vector<int> rcfirst(1, 0);
         bool ok = m->nseg >= CGR_MIN_MESHES;
         int maxrows = 0;
+        if (seg_nn) for (int k = 0; k < nseg; ++k) maxrows = std::max(maxrows, 3 * seg_nn[k]);
+        else maxrows = m->ndof;
+        size_t lds = ((size_t)2 * maxrows + CGR_W * 3 * CGR_CB + 6 * CGR_W) * sizeof(double);
+        const bool big = maxrows > CGR_MAXROWS || lds > 160 * 1024;   // p alone in LDS
+        if (big) lds -= (size_t)maxrows * sizeof(double);
+        const int maxbr = big ? 21 : 63;   // block rows per chunk: the row pass of the big form is a single one
         auto chunks_of = [&](int I0, int nbr) {
             for (int I = I0; I < I0 + nbr && ok;) {
                 const int q0 = m->h_bp[I];
                 int J = I;
-                while (J < I0 + nbr && m->h_bp[J + 1] - q0 <= CGR_CB && J - I < 63) ++J;
+                while (J < I0 + nbr && m->h_bp[J + 1] - q0 <= CGR_CB && J - I < maxbr) ++J;
                 if (J == I) { ok = false; break; }       // a block row longer than a chunk
                 rcd.push_back(make_int4(I, J - I, q0, m->h_bp[J] - q0));
                 I = J;
             }
             rcfirst.push_back((int)rcd.size());
-            maxrows = std::max(maxrows, 3 * nbr);
         };
         if (seg_nn) for (int k = 0; k < nseg && ok; ++k) chunks_of(m->seg_node0[k], seg_nn[k]);
         else if (ok) chunks_of(0, m->ndof / 3);
-        const size_t lds = ((size_t)2 * maxrows + CGR_W * 3 * CGR_CB + 6 * CGR_W) * sizeof(double);
-        ok = ok && maxrows > 0 && maxrows <= CGR_MAXROWS && lds <= 160 * 1024;
+        ok = ok && maxrows > 0 && maxrows <= (big ? CGR_MAXROWS_BIG : CGR_MAXROWS) && lds <= 160 * 1024;
+        m->cgr_big = big;
         if (ok) {
             if (dalloc(&m->d_rcd, rcd.size()) || dalloc(&m->d_rcfirst, rcfirst.size())) { fem_free(m); delete m; ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed"); }
             ORBX_HIP(hipMemcpy(m->d_rcd, rcd.data(), sizeof(int4) * rcd.size(), hipMemcpyHostToDevice));
             ORBX_HIP(hipMemcpy(m->d_rcfirst, rcfirst.data(), sizeof(int) * rcfirst.size(), hipMemcpyHostToDevice));
-            ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cg_resident), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ORBX_HIP(hipFuncSetAttribute(big ? reinterpret_cast<const void *>(k_fem_cg_resident<true>) : reinterpret_cast<const void *>(k_fem_cg_resident<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             m->cg_resident = true; m->cgr_lds = (int)lds; m->cgr_ldn = maxrows;
         }
     }

@@ -354,12 +354,13 @@ def test_segmented_batch_above_the_fused_step_threshold():
         assert abs(rel[k] - orel) <= 1e-6 * orel + 1e-12
 
 
-@pytest.mark.parametrize("nmesh,ncell,iters", [(64, 3, 40), (70, 12, 30), (96, 5, 61)])
+@pytest.mark.parametrize("nmesh,ncell,iters", [(64, 3, 40), (70, 12, 30), (96, 5, 61), (64, 14, 25)])
 def test_uniform_batch_resident_on_the_compute_units(nmesh, ncell, iters):
     """64 or more meshes that fit a compute unit each (<= 7,168 dofs) run ALL iterations in one launch, one workgroup per
     mesh with p and Ap in LDS and x, r, 1/diag in registers (fem.hip: k_fem_cg_resident).  ncell = 12 is BASELINE config 3's
     mesh (6,591 dofs, 155 KB of LDS).  Fixed iteration count against the oracle's CG on the exported CSR, 1e-5; the odd
-    count and the split call check that the state handed from launch to launch (x, r, p, r.z) is complete."""
+    count and the split call check that the state handed from launch to launch (x, r, p, r.z) is complete.  ncell = 14:
+    10,125 dofs, the form with p alone in LDS and Ap / x in the batch vectors (k_fem_cg_resident<true>)."""
     nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=ncell)
     fea = FEA2(nodes, tets, FEM_TET4)
     fea.MatrixAssembly()
@@ -380,13 +381,14 @@ def test_uniform_batch_resident_on_the_compute_units(nmesh, ncell, iters):
     assert np.array_equal(x2, x) and np.array_equal(rel2, rel)
 
 
-def test_segmented_batch_resident_on_the_compute_units():
+@pytest.mark.parametrize("n,base", [(72, 5), (64, 12)])
+def test_segmented_batch_resident_on_the_compute_units(n, base):
     """The same for 72 meshes of their own sizes and topologies (fem_create_batch): global numbering in the tables, the
-    mesh's own numbering in LDS."""
+    mesh's own numbering in LDS.  base = 12: the bench's distinct batch (3,993 ... 10,125 dofs per mesh), whose largest
+    meshes need the form with p alone in LDS."""
     from orb_slam2_e_amd.fem import FEA2Batch
     from orb_slam2_e_amd.synth import synth_tet_batch_distinct
-    n = 72
-    nodes_l, tets_l, fixed_l, load_l = synth_tet_batch_distinct(n, base=5)
+    nodes_l, tets_l, fixed_l, load_l = synth_tet_batch_distinct(n, base=base)
     fb = FEA2Batch(nodes_l, tets_l, FEM_TET4)
     fb.MatrixAssembly()
     fixed = np.concatenate([fb.dof0[k] + fx for k, fx in enumerate(fixed_l)]).astype(np.int32)
@@ -394,7 +396,7 @@ def test_segmented_batch_resident_on_the_compute_units():
     b = np.concatenate(load_l); b[fixed] = 0
     x, done, rel = fb.solve_cg(b, iters=50, tol=0.0)
     assert done == 50 and len(rel) == n
-    for k in range(0, n, 5):
+    for k in range(0, n, 5 if base < 10 else 9):
         rp, col, val = fb.csr(k)
         d0, d1 = fb.dof0[k], fb.dof0[k + 1]
         ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], 50, 0.0)
