@@ -1,0 +1,52 @@
+"""Differential fuzz of the batched CG (uniform and segmented batches on both sides of the 16- and 64-mesh thresholds and of
+the 7,168-dof LDS limit of k_fem_cg_resident): fixed iteration counts against the oracle's CG on the exported CSR, 1e-5."""
+import sys
+import numpy as np
+import oracle
+from orb_slam2_e_amd.fem import FEA2, FEA2Batch, FEM_TET4
+from orb_slam2_e_amd.synth import synth_tet_mesh
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+RTOL = 1e-5
+bad = 0
+for case in range(n):
+    nm = int(rng.choice([1, 3, 15, 16, 40, 63, 64, 65, 100, 130]))
+    big = rng.random() < 0.3
+    lo, hi = (11, 15) if big else (2, 9)
+    iters = int(rng.integers(1, 60))
+    seg = rng.random() < 0.5
+    if seg:
+        dims = [tuple(int(v) for v in rng.integers(lo, hi + 1, 3)) for _ in range(nm)]
+        meshes = [synth_tet_mesh(d, 1000 * case + k) for k, d in enumerate(dims)]
+        fea = FEA2Batch([m[0] for m in meshes], [m[1] for m in meshes], FEM_TET4)
+        fixed = np.concatenate([fea.dof0[k] + m[2] for k, m in enumerate(meshes)]).astype(np.int32)
+        b = np.concatenate([m[3] for m in meshes]); b[fixed] = 0
+        fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
+        x, done, rel = fea.solve_cg(b, iters=iters, tol=0.0)
+        pick = sorted(set([0, nm - 1, int(rng.integers(0, nm))]))
+        ok = done == iters
+        for k in pick:
+            rp, col, val = fea.csr(k); d0, d1 = fea.dof0[k], fea.dof0[k + 1]
+            ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], iters, 0.0)
+            ok = ok and np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max() and abs(rel[k] - orel) <= 1e-6 * orel + 1e-12
+        desc = f"segmented nm={nm} dims {dims[0]}.. iters={iters}"
+    else:
+        d = tuple(int(v) for v in rng.integers(lo, hi + 1, 3))
+        base = synth_tet_mesh(d, 1000 * case)
+        nodes = np.stack([base[0] + rng.normal(0, 0.01, base[0].shape).astype(np.float32) for _ in range(nm)])
+        fea = FEA2(nodes, base[1], FEM_TET4)
+        b = np.tile(base[3], (nm, 1)) * rng.uniform(0.5, 2.0, (nm, 1)); b[:, base[2]] = 0
+        fea.MatrixAssembly(); fea.eliminate_dofs(base[2])
+        x, done, rel = fea.solve_cg(b, iters=iters, tol=0.0)
+        ok = done == iters
+        for k in sorted(set([0, nm - 1, int(rng.integers(0, nm))])):
+            rp, col, val = fea.csr(k)
+            ox, _, orel = oracle.fem_cg(rp, col, val, b[k], iters, 0.0)
+            ok = ok and np.abs(x[k] - ox).max() <= RTOL * np.abs(ox).max() and abs(rel[k] - orel) <= 1e-6 * orel + 1e-12
+        desc = f"uniform nm={nm} dims {d} iters={iters}"
+    if not ok:
+        bad += 1; print("MISMATCH cg", case, desc, flush=True)
+    del fea
+print("cases", n, "mismatches", bad)
+sys.exit(1 if bad else 0)
