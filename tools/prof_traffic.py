@@ -9,12 +9,17 @@ usage: prof_traffic.py gpurun_out/<dir> profiles/rNN_traffic.json "<source note>
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-STREAM16 = {"k_fem_spmv"}          # wide streaming reads: FETCH_SIZE x2 (calibrated at 16 B per lane; 12 B per lane since the block form: upper bound)
+STREAM16 = {"k_fem_spmv", "k_fem_cg_resident<false>", "k_fem_cg_resident<true>"}          # wide streaming reads: FETCH_SIZE x2 (calibrated at 16 B per lane; 12 B per lane since the block form: upper bound)
+
+
+KEEP_TEMPLATE = ("k_fem_cg_resident",)   # <false> / <true> are different workloads (Ap in LDS / through the batch vectors)
+LONGEST = ("k_fem_cg_resident",)         # one launch = n iterations: the dispatch with the largest counter value (bench: 200 iterations), not the mean
 
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    return n.split("(")[0].split("<")[0]
+    base = n.split("(")[0]
+    return base if base.split("<")[0] in KEEP_TEMPLATE else base.split("<")[0]
 
 
 PER_GRID = {"k_fem_spmv"}          # kernels whose launches of different grid sizes are different workloads: also keyed name@grid
@@ -26,7 +31,7 @@ def mean_largest(d, sub, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 vals[short(r["Kernel_Name"])][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
-    out = {k: sum(v[max(v)]) / len(v[max(v)]) * 1024.0 for k, v in vals.items()}
+    out = {k: (max(v[max(v)]) if k.split("<")[0] in LONGEST else sum(v[max(v)]) / len(v[max(v)])) * 1024.0 for k, v in vals.items()}
     for k in PER_GRID & set(vals):
         for g, x in vals[k].items():
             if len(x) >= 5:
@@ -44,7 +49,7 @@ for k in sorted(fetch):
     f, w = fetch[k], write.get(k, 0.0)
     x2 = k.split("@")[0] in STREAM16
     res[k] = {"hbm_bytes_per_launch": (2 * f if x2 else f) + w, "fetch_size_bytes_raw": f, "write_size_bytes": w,
-              "fetch_correction": "x2 (gfx950 correction calibrated on 16-B/lane streaming loads; the block-form k_fem_spmv streams 12 B per lane, so this is an upper bound -- the raw value is kept beside it)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
+              "fetch_correction": "x2 (gfx950 correction calibrated on 16-B/lane streaming loads; the block-form kernels stream 36 B per lane as 16 + 16 + 4, so this is an upper bound -- the raw value is kept beside it)" if x2 else "none (4-B/lane or byte loads: uncalibrated, raw value used)",
               "valu_wave_insts_per_launch": valu.get(k), "source": note}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in res.items()}, indent=1))
