@@ -351,7 +351,9 @@ def main():
     def make_context(c):
         u = Work()
         u.ex = ORBextractor(*PARAMS)
-        u.tstream = torch.cuda.Stream(device=dev) if args.pipeline > 1 else torch.cuda.current_stream()
+        # always a stream of its own, also for one context: handed the NULL stream the extractor and the matcher each fall back
+        # to their own streams, and the match of step k then runs beside the extraction of step k + 1
+        u.tstream = torch.cuda.Stream(device=dev)
         u.stream = u.tstream.cuda_stream
         cap = u.ex.capacity
         u.best = torch.empty((BATCH, cap), dtype=torch.int32, device=dev)
