@@ -346,7 +346,10 @@ int orbm_match_filter(int nA, const int32_t *best, const int32_t *second, const 
 /* Batched device form used by the frames/s pipeline: descriptor sets
  * desc_dev[nsets][cap][32] with counts_dev[nsets]; pair p matches set qa[p]
  * (queries) against set qb[p].  Outputs (device): best/second/idx/match12
- * [npairs][cap] int32, nmatch[npairs].  Asynchronous on `stream`. */
+ * [npairs][cap] int32, nmatch[npairs].  Asynchronous on `stream`.  When the sets come straight from
+ * orbx_extract_batch_dev, give both calls the SAME non-NULL stream (or synchronise between them): with NULL the
+ * extractor works on its handle's stream and this call on the default stream, and nothing orders the next
+ * extraction on that handle behind a match that still reads its descriptors. */
 int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int cap,
                          const int32_t *pair_a_dev, const int32_t *pair_b_dev, int npairs,
                          int th, float nnratio,
