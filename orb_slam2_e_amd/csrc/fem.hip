@@ -775,7 +775,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
                 double *dst = part + 3 * min(lane + 64 * u, d.w - 1);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    dst[i] = ((double)va[u][3 * i] * p0 + (double)va[u][3 * i + 1] * p1) + (double)va[u][3 * i + 2] * p2;
+                    dst[i] = __builtin_fma((double)va[u][3 * i + 2], p2, __builtin_fma((double)va[u][3 * i + 1], p1, (double)va[u][3 * i] * p0));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
