@@ -2,7 +2,9 @@
 """bench.py -- frames/s of the ORB extract + Hamming match hot path on MI355X.
 
 Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W`;
-for N>1 launched by torch.distributed.run, one rank per GPU.  A *step* is one pass
+one rank per GPU.  For N>1 either torch.distributed.run starts the ranks (WORLD_SIZE set; it must equal N) or, started
+plainly, this process becomes the parent of N rank processes before anything touches the GPU (orb_slam2_e_amd/launch.py),
+relays rank 0's line and fails if any rank fails.  A *step* is one pass
 of the hot path over one batch: 64 synthetic 640x480 frames per GPU ->
 ORBextractor (2000 features, 8 levels, FAST 20/7) -> 2000x2000 brute-force
 Hamming match of every frame against its successor in the batch (+ TH_LOW / 0.6
@@ -307,16 +309,29 @@ def main():
     ap.add_argument("--match-kernel", choices=["auto", "popcount"], default="auto",
                     help="all-pairs matcher: auto = FP4 matrix-core kernel (default), popcount = XOR + v_bcnt kernel; same results")
     ap.add_argument("--fem-meshes", type=int, default=256)
+    ap.add_argument("--launch-timeout", type=float, default=None, help="--gpus N > 1 started without a launcher: seconds the N ranks may run")
     args = ap.parse_args()
+
+    # N > 1 and not yet a rank of a launcher: this process becomes the parent of N ranks (fresh child processes running this same
+    # command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and relays rank 0's line.  Nothing above or in
+    # `launch` imports torch or touches the GPU.
+    from orb_slam2_e_amd import launch
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if launch.should_spawn(args.gpus):
+        sys.exit(launch.run_parent(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout))
+    world = launch.check_world(args.gpus)    # a launcher's WORLD_SIZE must be what --gpus says
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rehearse = args.dist_backend != "nccl"   # all ranks on GPU 0, collectives staged through the CPU (gloo)
     dev_index = 0 if (world == 1 or rehearse) else local_rank
+    if dev_index >= torch.cuda.device_count():   # (counting devices does not initialise the GPU)
+        raise SystemExit(f"bench: rank {rank} needs GPU {dev_index}, this node shows {torch.cuda.device_count()} "
+                         f"(--dist-backend gloo rehearses N > 1 with every rank on GPU 0)")
     torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -569,12 +584,16 @@ def main():
             "verified": verified,
             "config": {"workload": (f"{world}xMI355X: {world * BATCH}-frame batch sharded {BATCH}/GPU, " if world > 1 else
                                     f"1xMI355X: batch of {BATCH} ") + "synthetic 640x480 frames, ORB extract (2000 feat, 8 levels) "
-                                   "+ 2000x2000 brute-force Hamming match per frame" + (", RCCL gather on rank 0" if world > 1 else ""),
+                                   "+ 2000x2000 brute-force Hamming match per frame" +
+                                   ((", gloo gather on rank 0 staged through the host (REHEARSAL: all ranks share GPU 0)" if rehearse else
+                                     ", RCCL gather on rank 0") if world > 1 else ""),
                        "frames": "synth_sequence: each GPU's 64 frames are one camera pan (2, 1) px per frame over its own scene of "
                                  "rectangles and discs + per-frame noise; frame i is matched against frame i+1 mod 64",
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
                        "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma (FP4 matrix cores)",
-                       "parallelism": f"frames sharded {BATCH}/GPU, results gathered on rank 0 ({GE} steps per RCCL gather)" if world > 1 else "single GPU",
+                       "parallelism": (f"frames sharded {BATCH}/rank, results gathered on rank 0 ({GE} steps per "
+                                        f"{'gloo' if rehearse else 'RCCL'} gather)") if world > 1 else "single GPU",
+                       "dist_backend": (args.dist_backend if world > 1 else None),
                        "mean_keypoints_per_frame": float(counts.float().mean().item()),
                        "mean_matches_per_frame": float(nmatch.float().mean().item())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,118 @@
+"""`bench.py --gpus N` starts its own ranks (orb_slam2_e_amd/launch.py): spawn, relay of rank 0's line, exit codes.
+CPU only: stand-in rank scripts, plus bench.py itself up to the point where a rank finds no GPU."""
+import io
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from orb_slam2_e_amd import launch  # noqa: E402
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "rank.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_launch_module_needs_no_torch():
+    # the parent must not touch the GPU: the launcher may import the standard library only
+    code = ("import sys; sys.path.insert(0, %r); from orb_slam2_e_amd import launch; "
+            "assert 'torch' not in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def test_should_spawn_and_check_world():
+    assert not launch.should_spawn(1, {})
+    assert launch.should_spawn(2, {})
+    assert not launch.should_spawn(2, {"WORLD_SIZE": "2"})        # already a rank of some launcher
+    assert launch.check_world(1, {}) == 1
+    assert launch.check_world(4, {"WORLD_SIZE": "4"}) == 4
+    with pytest.raises(SystemExit):
+        launch.check_world(8, {"WORLD_SIZE": "1"})
+    with pytest.raises(SystemExit):
+        launch.check_world(1, {"WORLD_SIZE": "2"})
+    e = launch.rank_env(3, 8, 1234, {})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "1234")
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_spawn_relays_rank0_line_and_checks_n_gpus(tmp_path):
+    s = _script(tmp_path, """
+        import json, os, sys
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        print("noise from rank", r, file=sys.stderr)
+        if r == 0:
+            print("not json")
+            print(json.dumps({"n_gpus": w, "value": 1.5, "argv": sys.argv[1:]}))
+        else:
+            print("rank", r, "stdout")        # never reaches the parent's stdout
+        """)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.run_parent(s, ["--gpus", "3", "--steps", "7"], 3, timeout=60, out=out, err=err)
+    assert rc == 0, err.getvalue()
+    lines = out.getvalue().strip().splitlines()
+    res = json.loads(lines[-1])
+    assert res == {"n_gpus": 3, "value": 1.5, "argv": ["--gpus", "3", "--steps", "7"]}
+    assert all("stdout" not in l for l in lines)
+    e = err.getvalue()
+    assert "[rank 1] rank 1 stdout" in e and "[rank 2] noise from rank 2" in e
+
+
+def test_spawn_fails_when_a_rank_fails_and_stops_the_others(tmp_path):
+    s = _script(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(600)                        # the survivors would hang in a collective
+        """)
+    out, err = io.StringIO(), io.StringIO()
+    import time
+    t0 = time.monotonic()
+    rc = launch.run_parent(s, [], 3, timeout=120, out=out, err=err)
+    assert rc == 7 and time.monotonic() - t0 < 60
+    assert "rank 1 exited with 7" in err.getvalue()
+
+
+def test_spawn_fails_on_wrong_n_gpus_or_missing_line(tmp_path):
+    s = _script(tmp_path, """
+        import json, os
+        if os.environ["RANK"] == "0":
+            print(json.dumps({"n_gpus": 1}))     # a bench that ignored --gpus
+        """)
+    err = io.StringIO()
+    assert launch.run_parent(s, [], 2, timeout=60, out=io.StringIO(), err=err) == 4
+    assert "n_gpus = 1" in err.getvalue()
+    s2 = _script(tmp_path, "pass\n")
+    assert launch.run_parent(s2, [], 2, timeout=60, out=io.StringIO(), err=io.StringIO()) == 3
+
+
+def test_spawn_timeout(tmp_path):
+    s = _script(tmp_path, "import time; time.sleep(600)\n")
+    assert launch.run_parent(s, [], 2, timeout=1.0, out=io.StringIO(), err=io.StringIO()) == 124
+
+
+def test_bench_rejects_a_launcher_world_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_gpus2_spawns_two_ranks_and_fails_loudly_without_gpus():
+    # no GPU in this container: both ranks must get as far as the device check and the parent must report the failure
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-timeout", "300"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: this is the no-GPU failure path")
+    assert r.returncode != 0
+    assert "needs GPU" in r.stderr and "[rank " in r.stderr
+    assert not r.stdout.strip()
