@@ -316,13 +316,13 @@ int oracle_fem_cg(int n, const int *rowptr, const int *col, const float *val, co
             for (k = rowptr[i]; k < rowptr[i + 1]; k++) s += (double)val[k] * p[col[k]];
             Ap[i] = s; pAp += p[i] * s;
         }
-        alpha = rz / pAp;
+        alpha = pAp > 0.0 ? rz / pAp : 0.0;   /* a finished (or unloaded) system is frozen, not divided 0 / 0 */
         rr = 0;
         for (i = 0; i < n; i++) {
             x[i] += alpha * p[i]; r[i] -= alpha * Ap[i];
             z[i] = r[i] * dinv[i]; rz2 += r[i] * z[i]; rr += r[i] * r[i];
         }
-        beta = rz2 / rz; rz = rz2;
+        beta = rz > 0.0 ? rz2 / rz : 0.0; rz = rz2;
         for (i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
         it++;
     }

@@ -271,6 +271,12 @@ __global__ void k_fem_matvec(const float *__restrict__ vals, const int *__restri
     f[(size_t)mesh * ndof + r] = s;
 }
 
+// alpha = rz / p.Ap and beta = rz' / rz of a mesh that has nothing left to do (zero load, or a residual that reached exactly 0
+// while the other meshes of its batch go on iterating) would be 0 / 0: such a mesh is frozen instead -- the step and the
+// new direction are zero, x keeps its value.  Whenever the divisor is positive this is the plain quotient, bit for bit
+// (K is positive definite after the Dirichlet elimination, so p.Ap > 0 for p != 0).  The oracle's CG has the same guard.
+__device__ __forceinline__ double cg_ratio(double num, double den) { return den > 0.0 ? num / den : 0.0; }
+
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
 #pragma unroll
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_update(int ndof, int nchunk, int
     const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, 0);
     const int sp0 = minfo_s ? minfo_s[sg.mesh].z : sg.mesh * nchunk_s, snp = minfo_s ? minfo_s[sg.mesh].w : nchunk_s;
     const double pAp = chunk_sum(part_pAp + sp0, snp);
-    const double alpha = sc[sg.mesh].rz[cur] / pAp;
+    const double alpha = cg_ratio(sc[sg.mesh].rz[cur], pAp);
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < RPB; i += CGT) {
         const int row = sg.chunk * RPB + i;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
 {
     const Seg sg = seg_of(cmesh, minfo, ndof, nchunk, 0);
     const double rz2 = chunk_sum(part_rz + sg.part0, sg.nparts), rr = chunk_sum(part_rr + sg.part0, sg.nparts);
-    const double beta = rz2 / sc[sg.mesh].rz[cur];
+    const double beta = cg_ratio(rz2, sc[sg.mesh].rz[cur]);
     for (int i = threadIdx.x; i < RPB; i += CGT) {
         const int row = sg.chunk * RPB + i;
         if (row < sg.nrows) {
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
 #pragma unroll
             for (int u = 0; u < CGS_U; ++u)
                 if (u * CGS_T + (int)threadIdx.x < nrows) s0 += pv[u] * av[u];
-            const double alpha = rz / block_sum(s0, sh);   // p.Ap: the SpMV leaves it to us
+            const double alpha = cg_ratio(rz, block_sum(s0, sh));   // p.Ap: the SpMV leaves it to us
 #pragma unroll
             for (int u = 0; u < CGS_U; ++u) {
                 const int i = u * CGS_T + (int)threadIdx.x;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
             }
         }
         const double rz2 = block_sum(s1, sh), rr = block_sum(s2, sh);
-        const double beta = rz2 / rz;
+        const double beta = cg_ratio(rz2, rz);
 #pragma unroll
         for (int u = 0; u < CGS_U; ++u) {
             const int i = u * CGS_T + (int)threadIdx.x;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
     }
     double s0 = 0;
     for (int i = threadIdx.x; i < nrows; i += CGS_T) s0 += p[row0 + i] * Ap[row0 + i];
-    const double alpha = rz / block_sum(s0, sh);
+    const double alpha = cg_ratio(rz, block_sum(s0, sh));
     for (int base = 0; base < nrows; base += CGS_U * CGS_T) {
         double pv[CGS_U], av[CGS_U], rv[CGS_U], xv[CGS_U], dv[CGS_U];
 #pragma unroll
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
         }
     }
     const double rz2 = block_sum(s1, sh), rr = block_sum(s2, sh);
-    const double beta = rz2 / rz;
+    const double beta = cg_ratio(rz2, rz);
     for (int base = 0; base < nrows; base += CGS_U * CGS_T) {   // r[g]: this thread's own stores of the first phase
         double pv[CGS_U], rv[CGS_U], dv[CGS_U];
 #pragma unroll
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         double t = 0;
 #pragma unroll
         for (int w = 0; w < CGR_W; ++w) t += shi[w];
-        const double alpha = rz / t;
+        const double alpha = cg_ratio(rz, t);
         double s1 = 0, s2 = 0;
         double dd[BIG ? CGR_U : 1];
         int tv = tid;
@@ -870,7 +876,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         double rz2 = 0; rr = 0;
 #pragma unroll
         for (int w = 0; w < CGR_W; ++w) { rz2 += shi[CGR_W + w]; rr += shi[2 * CGR_W + w]; }
-        const double beta = rz2 / rz;
+        const double beta = cg_ratio(rz2, rz);
         rz = rz2;
         if constexpr (BIG) {
 #pragma unroll

@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "orbm_internal.h"
+#include "orbx_internal.h"
 
 using namespace orbm_detail;
 
@@ -545,11 +546,15 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
     if (!desc_dev || !counts_dev || cap <= 0 || npairs <= 0) ORBX_FAIL(ORBX_ERR_ARG, "bad match arguments");
     ORBX_NEED_DEVICE();
     hipStream_t st = (hipStream_t)stream;
+    // sets that are an extractor's resident results, produced on another stream (both calls handed NULL: the extractor then
+    // works on its handle's stream, this call on the default stream): ordered both ways by events; nothing on a common stream
+    orbx_extractor *producer = orbx_detail::order_after_producer(desc_dev, st);
     if (nmatch_dev) ORBX_HIP(hipMemsetAsync(nmatch_dev, 0, sizeof(int) * npairs, st));
     g_prof.start(0, st);
     launch_match_sets(st, desc_dev, counts_dev, cap, pair_a_dev, pair_b_dev, npairs, th, nnratio, best_dev, second_dev, idx_dev,
                       match12_dev, nmatch_dev);
     g_prof.stop(0, st);
+    orbx_detail::reader_done(producer, st);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1565,7 +1566,46 @@ void resize_axis(int dn, int sn, std::vector<int> &ofs, std::vector<int> &c0, st
     }
 }
 
+std::mutex g_reg_mu;
+std::vector<orbx_extractor *> g_reg;   // live handles (orbx_create .. orbx_destroy)
+
 } // namespace
+
+namespace orbx_detail {
+
+orbx_extractor *order_after_producer(const void *ptr, hipStream_t st)
+{
+    const uint8_t *q = (const uint8_t *)ptr;
+    orbx_extractor *hit = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (orbx_extractor *ex : g_reg) {
+            if (!ex->d_desc || !ex->batch) continue;
+            const size_t B = (size_t)ex->batch, cap = (size_t)ex->kcap;
+            const uint8_t *d = ex->d_desc, *k = (const uint8_t *)ex->d_kps, *c = (const uint8_t *)ex->d_counts;
+            if ((q >= d && q < d + B * cap * 32) || (q >= k && q < k + B * cap * sizeof(orbx_keypoint)) || (q >= c && q < c + B * sizeof(int))) {
+                hit = ex;
+                break;
+            }
+        }
+    }
+    if (!hit || !hit->last_batch || hit->last_stream == st) return nullptr;
+    if (!hit->order_ev && hipEventCreateWithFlags(&hit->order_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    // everything queued on the producer's stream so far -- its last batch was queued by an earlier call -- precedes `st`'s next work
+    if (hipEventRecord(hit->order_ev, hit->last_stream) != hipSuccess || hipStreamWaitEvent(st, hit->order_ev, 0) != hipSuccess) return nullptr;
+    return hit;
+}
+
+void reader_done(orbx_extractor *ex, hipStream_t st)
+{
+    if (!ex) return;
+    if (!ex->reader_ev && hipEventCreateWithFlags(&ex->reader_ev, hipEventDisableTiming) != hipSuccess) return;
+    if (hipEventRecord(ex->reader_ev, st) != hipSuccess) return;
+    ex->reader_stream = st;
+    ex->reader_pending = true;
+}
+
+} // namespace orbx_detail
 
 extern "C" {
 
@@ -1607,6 +1647,10 @@ int orbx_create(const orbx_params *prm, orbx_extractor **out)
     if (prm->blur_variant == 1) { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 49; ex->taps[3] = 55; }
     else { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 48; ex->taps[3] = 56; }
     ex->kcap = prm->nfeatures + 3 * nl;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_reg.push_back(ex);
+    }
     *out = ex;
     return ORBX_OK;
 }
@@ -1614,6 +1658,13 @@ int orbx_create(const orbx_params *prm, orbx_extractor **out)
 int orbx_destroy(orbx_extractor *ex)
 {
     if (!ex) return ORBX_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_reg.erase(std::remove(g_reg.begin(), g_reg.end(), ex), g_reg.end());
+    }
+    if (ex->reader_pending) (void)hipEventSynchronize(ex->reader_ev);   // a consumer on another stream may still read the results
+    if (ex->order_ev) (void)hipEventDestroy(ex->order_ev);
+    if (ex->reader_ev) (void)hipEventDestroy(ex->reader_ev);
     free_workspace(ex);
     if (ex->d_in) (void)hipFree(ex->d_in);
     void *stp[] = {ex->d_st_key, ex->d_st_rk, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
@@ -1878,6 +1929,10 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     int rc = orbx_reserve(ex, width, height, batch);
     if (rc != ORBX_OK) return rc;
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ex->stream;
+    if (ex->reader_pending) {   // a *_dev consumer on another stream still reads the last batch's results (order_after_producer)
+        if (ex->reader_stream != st) ORBX_HIP(hipStreamWaitEvent(st, ex->reader_ev, 0));
+        ex->reader_pending = false;
+    }
     const uint8_t *d_img = images;
     if (!is_device) {
         const size_t need = frame_stride * (size_t)(batch - 1) + (size_t)stride * height;

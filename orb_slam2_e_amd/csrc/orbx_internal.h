@@ -103,6 +103,20 @@ struct orbx_extractor {
     int *d_st_sad = nullptr, *d_st_nvalid = nullptr;
     int st_batch = 0;
     orbx::KernelProfiler prof;
+    // ordering of chained *_dev calls that were not given one common stream (orbx_detail::order_after_producer)
+    hipEvent_t order_ev = nullptr, reader_ev = nullptr;
+    hipStream_t reader_stream = nullptr;
+    bool reader_pending = false;
 };
+
+namespace orbx_detail {
+// A consumer of a handle's device-resident results (orbm_match_batch_dev) running on stream `st`: if `ptr` lies in the
+// result buffers of a live extractor whose last batch was queued on ANOTHER stream (e.g. both calls were handed the NULL
+// stream: the extractor then uses its handle's stream), `st` is made to wait for that batch.  Returns the producer (or
+// nullptr: unknown pointer or same stream -- nothing to order, nothing recorded); reader_done() afterwards makes the
+// producer's next batch wait for the consumer in turn.  Same-stream chains pay one table lookup and no event.
+orbx_extractor *order_after_producer(const void *ptr, hipStream_t st);
+void reader_done(orbx_extractor *ex, hipStream_t st);
+} // namespace orbx_detail
 
 #endif // ORBX_INTERNAL_H

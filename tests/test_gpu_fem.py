@@ -402,3 +402,43 @@ def test_segmented_batch_resident_on_the_compute_units(n, base):
         ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], 50, 0.0)
         assert np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max(), k
         assert abs(rel[k] - orel) <= 1e-6 * orel + 1e-12
+
+
+@pytest.mark.parametrize("nmesh", [1, 20, 64])
+def test_cg_freezes_a_mesh_without_load(nmesh):
+    """A mesh whose right-hand side is zero starts with r.z = p.Ap = 0: alpha = 0 / 0 would turn its displacements into NaN
+    (and the resident kernel never returns to the host in between).  Such a mesh is frozen (fem.hip: cg_ratio; the oracle's
+    CG has the same guard): x == 0, relres == 0, and every other mesh of the batch is what it is without the guard.  One
+    mesh (launch per phase), 20 (fused step), 64 (resident on the compute units)."""
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=3)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    dead = nmesh // 3
+    b[dead] = 0
+    x, done, rel = fea.solve_cg(b, iters=30, tol=0.0)
+    assert np.isfinite(x).all() and np.isfinite(rel).all()
+    assert not x[dead].any() and rel[dead] == 0
+    for m in sorted({0, dead, nmesh - 1}):
+        rp, col, val = fea.csr(m)
+        ox, _, orel = oracle.fem_cg(rp, col, val, b[m], 30, 0.0)
+        assert np.isfinite(ox).all()
+        assert np.abs(x[m] - ox).max() <= RTOL * max(np.abs(ox).max(), 1e-300), m
+
+
+@pytest.mark.parametrize("nmesh", [1, 64])
+def test_cg_far_past_convergence_stays_finite(nmesh):
+    """A tiny mesh (81 dofs) iterated 600 times -- ten times past the point where its residual stops shrinking: the iterate
+    must stay finite and at the solution (relres at rounding level), whatever r.z underflows to."""
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=2)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    x, done, rel = fea.solve_cg(b, iters=600, tol=0.0)
+    assert np.isfinite(x).all() and np.isfinite(rel).all()
+    assert rel.max() < 1e-9
+    rp, col, val = fea.csr(0)
+    r = b[0] - oracle.fem_csr_matvec(rp, col, val, x[0])
+    assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b[0])
