@@ -121,6 +121,9 @@ int orbx_pyramid_level_padded(orbx_extractor *ex, int frame, int level, uint8_t 
  * mvuRight[n] / mvDepth[n] (-1 where unmatched) for one frame. */
 int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, float mbf, void *stream);
 int orbx_stereo_download(orbx_extractor *left, int frame, float *uRight, float *depth, int cap, int *n);
+/* All frames of the last orbx_stereo_match at once: uRight / depth [batch][capacity] (rows past a frame's count are
+ * unspecified), counts[batch] = the left keypoint counts; any of the three may be NULL. */
+int orbx_stereo_download_batch(orbx_extractor *left, float *uRight, float *depth, int32_t *counts);
 
 /* Staged outputs for parity tests (no reference counterpart; they expose the
  * intermediate values the reference keeps in locals):

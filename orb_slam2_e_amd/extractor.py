@@ -155,6 +155,21 @@ class ORBextractor:
         return out[:n.value].copy()
 
 
+def stereo_match_batch(left, right, mb, mbf, stream=None):
+    """orbx_stereo_match on every frame of the last batch extracted on both handles (asynchronous on `stream`)."""
+    L = left._L
+    L.orbx_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    check(L.orbx_stereo_match(left._h, right._h, mb, mbf, C.c_void_p(stream) if stream else None))
+
+
+def stereo_download_batch(left):
+    """(mvuRight[B, cap], mvDepth[B, cap], counts[B]) of the last stereo_match_batch; rows past a frame's count unspecified."""
+    B = left._last_B
+    u = np.zeros((B, left.capacity), np.float32); d = np.zeros((B, left.capacity), np.float32); c = np.zeros(B, np.int32)
+    check(left._L.orbx_stereo_download_batch(left._h, _p(u), _p(d), _p(c)))
+    return u, d, c
+
+
 def ComputeStereoMatches(left, right, mb, mbf, frame=0):
     """Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the last results of two
     ORBextractor objects (left / right images extracted with the same parameters).

@@ -110,18 +110,7 @@ class ORBmatcher:
         candidate lists (host), the gated loop on the device, rotation histogram + ComputeThreeMaxima + pair list (host).
         fv = (nodes ascending, off, items).  Returns (vMatchedPairs as an (m, 2) array, nmatches, vMatches12)."""
         n1 = len(kps1)
-        nodes1, off1, items1 = (np.asarray(a) for a in fv1); nodes2, off2, items2 = (np.asarray(a) for a in fv2)
-        pos2 = {int(nd): k for k, nd in enumerate(nodes2)}
-        lists = [None] * n1
-        for k, nd in enumerate(nodes1):
-            b = pos2.get(int(nd))
-            if b is not None:
-                members2 = items2[off2[b]:off2[b + 1]]
-                for i in items1[off1[k]:off1[k + 1]]:
-                    lists[int(i)] = members2
-        cand_off = np.zeros(n1 + 1, np.int32)
-        cand_off[1:] = np.cumsum([0 if l is None else len(l) for l in lists])
-        cand_idx = np.concatenate([l for l in lists if l is not None]).astype(np.int32) if cand_off[-1] else np.zeros(0, np.int32)
+        cand_off, cand_idx = self.feature_vector_candidates(n1, fv1, fv2)
         m12, _ = self.match_triangulation(kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, has_mp2, stereo1, stereo2, F12, ex, ey,
                                           scale_factors2, level_sigma2, bOnlyStereo)
         if self.mbCheckOrientation:
@@ -136,6 +125,24 @@ class ORBmatcher:
             m12[hit[~np.isin(bins, keep)]] = -1
         i1 = np.nonzero(m12 >= 0)[0]
         return np.stack([i1, m12[i1]], 1), len(i1), m12
+
+    @staticmethod
+    def feature_vector_candidates(n1, fv1, fv2):
+        """The co-iteration of two FeatureVectors (ORBmatcher.cc:881-891, 1004-1012) as per-keypoint candidate lists: a
+        keypoint of frame 1 whose node also exists in frame 2 gets that node's members of frame 2, in their order.
+        fv = (nodes ascending, off, items).  Returns (cand_off[n1 + 1], cand_idx)."""
+        nodes1, off1, items1 = (np.asarray(a, np.int64) for a in fv1); nodes2, off2, items2 = (np.asarray(a, np.int64) for a in fv2)
+        _, ia, ib = np.intersect1d(nodes1, nodes2, assume_unique=True, return_indices=True)
+        len1 = off1[ia + 1] - off1[ia]; len2 = off2[ib + 1] - off2[ib]
+        tot1 = int(len1.sum())
+        seg = np.repeat(off1[ia], len1) + (np.arange(tot1) - np.repeat(np.cumsum(len1) - len1, len1))
+        members1 = items1[seg]                                      # keypoints of frame 1 that have candidates
+        cnt = np.zeros(n1, np.int64); start2 = np.zeros(n1, np.int64)
+        cnt[members1] = np.repeat(len2, len1); start2[members1] = np.repeat(off2[ib], len1)
+        cand_off = np.zeros(n1 + 1, np.int32); cand_off[1:] = np.cumsum(cnt)
+        tot = int(cand_off[-1])
+        pos = np.repeat(start2, cnt) + (np.arange(tot) - np.repeat(cand_off[:-1].astype(np.int64), cnt))
+        return cand_off, items2[pos].astype(np.int32)
 
     @staticmethod
     def ComputeThreeMaxima(hist):

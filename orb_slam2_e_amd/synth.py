@@ -162,6 +162,40 @@ def synth_stereo_pair(k=0, w=1242, h=375, dmin=2.0, dmax=60.0):
     return left, np.clip(np.rint(right), 0, 255).astype(np.uint8)
 
 
+def synth_keyframe_pair_case(kps1, desc1, kps2, desc2, seed=0, nwords=90, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157,
+                             baseline=0.5372, stereo1=None):
+    """Config 5's SearchForTriangulation input from a stereo pair's own keypoints: the left and the right image as two
+    keyframes one baseline apart (KITTI00-02.yaml:8-11,25: fx = fy = 718.856, bf = 386.1448 -> b = 0.5372 m).  FeatureVectors
+    from a flat stand-in vocabulary (node = the nearest of `nwords` descriptors drawn from keyframe 1: matching features
+    mostly share a node, as with DBoW2 at levelsup = 4); 30 % of the keypoints already hold a map point, stereo flags from
+    `stereo1` (e.g. mvuRight >= 0) / at random.  F12 = K^-T [t]x K^-1 for camera 2 = camera 1 moved by (b, 0, 1e-3 b): the
+    epipolar lines are the image rows to within a hundredth of a pixel and the epipole stays finite.
+    Returns (fv1, fv2, has_mp1, has_mp2, stereo1, stereo2, F12, ex, ey)."""
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    d1 = np.asarray(desc1, np.uint8); d2 = np.asarray(desc2, np.uint8)
+    words = d1[rng.choice(len(d1), nwords, replace=False)]
+    lut = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+    def nodes_of(d):
+        dist = lut[d[:, None, :] ^ words[None, :, :]].sum(2)
+        return (np.argmin(dist, 1) * 7 + 11).astype(np.int32), dist.min(1)
+
+    n1, m1 = nodes_of(d1); n2, m2 = nodes_of(d2)
+    from .vocabulary import feature_vector_arrays
+    fv1 = feature_vector_arrays(n1, rng.random(len(d1)) < 0.97)      # stopped words are in no node
+    fv2 = feature_vector_arrays(n2, rng.random(len(d2)) < 0.97)
+    has1 = rng.random(len(d1)) < 0.3; has2 = rng.random(len(d2)) < 0.3
+    s1 = np.asarray(stereo1, bool) if stereo1 is not None else rng.random(len(d1)) < 0.5
+    s2 = rng.random(len(d2)) < 0.5
+    t = np.array([baseline, 0.0, 1e-3 * baseline])                    # X2 = X1 - t
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F12 = (np.linalg.inv(K).T @ tx @ np.linalg.inv(K)).astype(np.float32)
+    C2 = -t
+    ex = np.float32(fx * C2[0] / C2[2] + cx); ey = np.float32(fy * C2[1] / C2[2] + cy)
+    return fv1, fv2, has1, has2, s1, s2, F12, ex, ey
+
+
 def synth_projection_case(seed, n=2000, nq=3000, hot=400, stereo=False):
     """Many queries aim at few keypoints, so the in-loop assignment matters."""
     from .extractor import KP_DTYPE

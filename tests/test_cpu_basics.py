@@ -369,3 +369,28 @@ def test_round2_entry_points_fail_loudly_without_gpu():
     with pytest.raises(OrbxError) as e:          # element node id outside its own mesh
         FEA2Batch(nodes, [tets[0], np.array([[0, 1, 2, 4]], np.int32)], FEM_TET4)
     assert e.value.code == -1
+
+
+def test_feature_vector_candidates_equal_the_literal_co_iteration():
+    """ORBmatcher.feature_vector_candidates (vectorised) against the literal two-iterator walk of ORBmatcher.cc:881-891."""
+    from orb_slam2_e_amd.matcher import ORBmatcher
+    rng = np.random.default_rng(3)
+    for trial in range(5):
+        n1, n2 = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        node1 = rng.integers(0, 40, n1) * 3; node2 = rng.integers(5, 45, n2) * 3
+        fv1 = oracle.feature_vector(node1, rng.random(n1) < 0.9); fv2 = oracle.feature_vector(node2, rng.random(n2) < 0.9)
+        off, idx = ORBmatcher.feature_vector_candidates(n1, fv1, fv2)
+        lists = [[] for _ in range(n1)]
+        a = b = 0
+        while a < len(fv1[0]) and b < len(fv2[0]):                 # f1it / f2it
+            if fv1[0][a] == fv2[0][b]:
+                for i in fv1[2][fv1[1][a]:fv1[1][a + 1]]:
+                    lists[int(i)] = list(fv2[2][fv2[1][b]:fv2[1][b + 1]])
+                a += 1; b += 1
+            elif fv1[0][a] < fv2[0][b]:
+                a += 1
+            else:
+                b += 1
+        assert off[0] == 0 and off[-1] == len(idx)
+        for i in range(n1):
+            assert list(idx[off[i]:off[i + 1]]) == lists[i], (trial, i)

@@ -442,3 +442,59 @@ def test_cg_far_past_convergence_stays_finite(nmesh):
     rp, col, val = fea.csr(0)
     r = b[0] - oracle.fem_csr_matvec(rp, col, val, x[0])
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b[0])
+
+
+def test_config3_full_size_assembly_bit_exact():
+    """BASELINE config 3's matrix itself: the 10,368-tet / 6,591-dof mesh assembled by the oracle's dense scatter
+    (FEA2.cc:1379-1624's order; 174 MB) against the device's K, every entry bit for bit, before and after the Dirichlet
+    elimination -- so that the CG tests' common input (the exported CSR) is the oracle's matrix and not only the device's."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    K = oracle.fem_assemble_dense(4, nodes, tets)
+    assert K.shape == (6591, 6591) and np.isfinite(K).all()
+    rp, col, val = fea.csr()
+    rows = np.repeat(np.arange(6591), np.diff(rp))
+    assert np.array_equal(K[rows, col], val)                    # every stored entry
+    mask = np.ones(K.shape, bool); mask[rows, col] = False
+    assert not K[mask].any()                                    # and nothing outside the pattern
+    del mask
+    # eliminated system: the oracle's CSR of its own K, rows / columns of the fixed dofs replaced by the identity
+    orp, ocol, oval = oracle.fem_dense_to_csr(K)
+    fm = np.zeros(6591, np.uint8); fm[fixed] = 1
+    oracle.fem_csr_eliminate(orp, ocol, oval, fm)
+    fea.eliminate_dofs(fixed)
+    Kd = fea.K_dense()
+    Ko = np.zeros_like(Kd)
+    Ko[np.repeat(np.arange(6591), np.diff(orp)), ocol] = oval
+    assert np.array_equal(Kd, Ko)
+    # and the oracle's CG on the ORACLE's matrix against the device's 200 iterations
+    b = load.copy(); b[fixed] = 0
+    x200, done, rel200 = fea.solve_cg(b, iters=200, tol=0.0)
+    ox200, _, _ = oracle.fem_cg(orp, ocol, oval, b, 200, 0.0)
+    assert np.abs(x200[0] - ox200).max() <= RTOL * np.abs(ox200).max()
+
+
+@pytest.mark.parametrize("ncell", [12, 15])
+def test_256_meshes_200_iterations_resident_vs_oracle(ncell):
+    """The bench's own FEM launches: 256 meshes x 200 CG iterations in k_fem_cg_resident (ncell = 12: config 3's mesh, p and
+    Ap in LDS; ncell = 15: 12,288 dofs, p alone in LDS -- the leg whose working set is beyond the Infinity Cache), nodal
+    displacements of the first, a middle and the last mesh against the oracle's CG at 1e-5."""
+    nm, iters = 256, 200
+    nodes, tets, fixed, load = synth_tet_batch(nm, ncell=ncell)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    b = np.tile(load, (nm, 1)); b[:, fixed] = 0
+    fea.profile(True)
+    fea.cg_setup(b)
+    fea.cg_iterate(iters)
+    x, rel = fea.cg_result()
+    prof = fea.profile_read()
+    assert prof["k_fem_cg_resident"][1] >= 1 and not prof["k_fem_spmv"][1]      # the resident kernel ran, nothing else
+    assert np.isfinite(x).all()
+    for m in (0, 131, nm - 1):
+        rp, col, val = fea.csr(m)
+        ox, _, orel = oracle.fem_cg(rp, col, val, b[m], iters, 0.0)
+        assert np.abs(x[m] - ox).max() <= RTOL * np.abs(ox).max(), m
+        assert abs(rel[m] - orel) <= 1e-6 * orel + 1e-12

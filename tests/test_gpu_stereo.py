@@ -76,3 +76,63 @@ def test_left_and_right_extractors_on_two_threads():
     mb = np.float32(BF) / np.float32(FX)
     gu, gd = ComputeStereoMatches(eL, eR, mb, np.float32(BF))
     assert (gu >= 0).sum() > 100
+
+
+def test_batched_stereo_eight_pairs_bit_exact():
+    """orbx_stereo_match "for every frame of the last batch": 8 KITTI-shaped pairs through extract_batch on two handles
+    and ONE stereo call; every frame's mvuRight / mvDepth float bits against the oracle run pair by pair
+    (Frame.cc:527-701).  The pairs differ (scene and disparity field), so a frame reading another frame's keypoints,
+    pyramid or median would show."""
+    from orb_slam2_e_amd import stereo_download_batch, stereo_match_batch
+    B = 8
+    pairs = [synth_stereo_pair(10 + k) for k in range(B)]
+    lefts = np.stack([p[0] for p in pairs]); rights = np.stack([p[1] for p in pairs])
+    eL, eR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+    eL.extract_batch(lefts); eR.extract_batch(rights)
+    mb = np.float32(BF) / np.float32(FX)
+    stereo_match_batch(eL, eR, mb, np.float32(BF))
+    U, D, cnt = stereo_download_batch(eL)
+    kpsL, descL, cntL = eL.download_batch()
+    assert np.array_equal(cnt, cntL)
+    matched = []
+    for f in range(B):
+        oL, oR = oracle.OrbOracle(*PARAMS), oracle.OrbOracle(*PARAMS)
+        kL, dL = oL.extract(lefts[f]); kR, dR = oR.extract(rights[f])
+        ou, od, nd = oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(BF))
+        n = int(cnt[f])
+        assert n == len(kL) and np.array_equal(descL[f, :n], dL)
+        assert np.array_equal(U[f, :n].view(np.uint32), ou.view(np.uint32)), f
+        assert np.array_equal(D[f, :n].view(np.uint32), od.view(np.uint32)), f
+        matched.append(int((ou >= 0).sum()))
+        # and the one-frame download of the same call
+        u1 = np.zeros(eL.capacity, np.float32); d1 = np.zeros(eL.capacity, np.float32)
+        import ctypes as C
+        n1 = C.c_int(0)
+        from orb_slam2_e_amd._lib import check
+        check(eL._L.orbx_stereo_download(eL._h, f, u1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p), eL.capacity, C.byref(n1)))
+        assert n1.value == n and np.array_equal(u1[:n].view(np.uint32), ou.view(np.uint32))
+    assert min(matched) > 100 and len(set(matched)) > 1
+
+
+def test_search_for_triangulation_on_the_pairs_own_keypoints():
+    """BASELINE config 5 names ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024) on the 1242x375 pair: the pair's
+    own ~2000 + ~2000 keypoints as two keyframes one KITTI baseline apart (synth_keyframe_pair_case), the whole function --
+    FeatureVector co-iteration, gated loop with CheckDistEpipolarLine, rotation histogram, pair list -- against the
+    oracle's literal loop, for the mono and the only-stereo form."""
+    from orb_slam2_e_amd import ORBmatcher
+    from orb_slam2_e_amd.synth import synth_keyframe_pair_case
+    left, right = synth_stereo_pair(0)
+    eL, eR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+    kL, dL = eL(left); kR, dR = eR(right)
+    assert len(kL) >= 1990 and len(kR) >= 1990
+    mb = np.float32(BF) / np.float32(FX)
+    gu, gd = ComputeStereoMatches(eL, eR, mb, np.float32(BF))
+    fv1, fv2, has1, has2, s1, s2, F12, ex, ey = synth_keyframe_pair_case(kL, dL, kR, dR, stereo1=gu >= 0)
+    sf = eR.GetScaleFactors(); sg = eR.GetScaleSigmaSquares()
+    for only_stereo in (False, True):
+        m = ORBmatcher(0.6, True)
+        pairs, nm, m12 = m.SearchForTriangulation(kL, dL, fv1, has1, s1, kR, dR, fv2, has2, s2, F12, ex, ey, sf, sg, only_stereo)
+        r12, rn = oracle.search_for_triangulation(kL, dL, fv1, has1, s1, kR, dR, fv2, has2, s2, F12, ex, ey, sf, sg, only_stereo, True)
+        assert rn > (50 if only_stereo else 200), rn
+        assert nm == rn and np.array_equal(m12, r12)
+        assert np.array_equal(pairs[:, 0], np.nonzero(r12 >= 0)[0]) and np.array_equal(pairs[:, 1], r12[r12 >= 0])
