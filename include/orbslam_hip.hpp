@@ -299,7 +299,9 @@ public:
         return fuseReplay(proj, best, idx, map);
     }
     // ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, vpReplacePoint) (ORBmatcher.cc:1178-1301):
-    // pose = the Sim3 decomposed as :1188-1192 do; `map` additionally needs recordReplace(int i, H) (vpReplacePoint[i] =).
+    // pose = the Sim3 decomposed as :1188-1192 do; `map` needs at / null / isBad / slotOwner / add as above, plus
+    // bool alreadyFound(H) (spAlreadyFound.count(pMP): the SNAPSHOT of pKF->GetMapPoints() from before the call) and
+    // void recordReplace(int i, H) (vpReplacePoint[i] = pMPinKF); it never replaces.
     template <class MapOps>
     int FuseSim3(const FrameView &KF, const PoseView &pose, const MapPointArrays &mps, float th, MapOps &map)
     {
@@ -351,9 +353,10 @@ public:
         return nFused;
     }
 
-    // Tail of the Sim3 form, ORBmatcher.cc:1194-1205 and :1279-1296: the skips read spAlreadyFound (a snapshot taken before
-    // the loop: isInKeyFrame must answer from that snapshot), a taken slot is only recorded (vpReplacePoint[iMP] =
-    // pMPinKF: map.recordReplace(i, pMPinKF)), a free one gets the point.
+    // Tail of the Sim3 form, ORBmatcher.cc:1194-1205 and :1279-1296: the skips read spAlreadyFound, a snapshot of
+    // pKF->GetMapPoints() taken before the loop -- map.alreadyFound(H) must answer from that snapshot, not from the
+    // state the loop is changing (a point the loop adds is processed again when the list repeats it); a taken slot is
+    // only recorded (vpReplacePoint[iMP] = pMPinKF: map.recordReplace(i, pMPinKF)), a free one gets the point.
     template <class MapOps>
     static int fuseReplaySim3(const std::vector<orbm_projected_point> &proj, const std::vector<int32_t> &best,
                               const std::vector<int32_t> &idx, MapOps &map)
@@ -361,7 +364,7 @@ public:
         int nFused = 0;
         for (int i = 0; i < (int)proj.size(); ++i) {
             auto pMP = map.at(i);
-            if (map.null(pMP) || map.isBad(pMP) || map.isInKeyFrame(pMP)) continue;
+            if (map.null(pMP) || map.isBad(pMP) || map.alreadyFound(pMP)) continue;
             if (!proj[i].visible || idx[i] < 0) continue;
             if (best[i] <= TH_LOW) {
                 auto pMPinKF = map.slotOwner(idx[i]);

@@ -624,3 +624,18 @@ def fuse_replay(vpMapPoints, visible, best, idx, mp_obs, mp_bad, mp_in_kf, kf_mp
     n = L.oracle_fuse_replay(_p(lst), len(lst), _p(vis), _p(b), _p(ix), int(th_low), _p(mp_obs), _p(mp_bad), _p(mp_in_kf),
                              _p(kf_mp), _p(ops), C.byref(nops))
     return n, ops[:nops.value].copy()
+
+
+def fuse_replay_sim3(vpPoints, visible, best, idx, mp_obs, mp_bad, mp_in_kf, kf_mp, vpReplacePoint, th_low=45):
+    """Tail of the Sim3 form of ORBmatcher::Fuse (ORBmatcher.cc:1194-1205, :1279-1296) on the toy map; mp_obs / mp_in_kf /
+    kf_mp / vpReplacePoint are updated in place.  Returns (nFused, ops[k,3])."""
+    L = lib()
+    lst = np.ascontiguousarray(vpPoints, np.int32); vis = np.ascontiguousarray(visible, np.int32)
+    b = np.ascontiguousarray(best, np.int32); ix = np.ascontiguousarray(idx, np.int32)
+    assert mp_obs.dtype == np.int32 and mp_bad.dtype == np.uint8 and mp_in_kf.dtype == np.int32 and kf_mp.dtype == np.int32
+    assert vpReplacePoint.dtype == np.int32 and len(vpReplacePoint) == len(lst)
+    ops = np.zeros((len(lst) + 1, 3), np.int32); nops = C.c_int(0)
+    L.oracle_fuse_replay_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 7
+    n = L.oracle_fuse_replay_sim3(_p(lst), len(lst), _p(vis), _p(b), _p(ix), int(th_low), len(mp_obs), len(kf_mp), _p(mp_obs),
+                                  _p(mp_bad), _p(mp_in_kf), _p(kf_mp), _p(vpReplacePoint), _p(ops), C.byref(nops))
+    return n, ops[:nops.value].copy()

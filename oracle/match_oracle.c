@@ -849,3 +849,44 @@ int oracle_fuse_replay(const int *list, int nlist, const int *visible, const int
     *nops = no;
     return nFused;
 }
+
+/* ---- The Sim3 form, ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, vpReplacePoint), src/ORBmatcher.cc:
+ * 1178-1301, tail on the same toy map.  What differs from the form above: the "already found" skip reads spAlreadyFound, a
+ * SNAPSHOT of KeyFrame::GetMapPoints() (src/KeyFrame.cc:274-287: the key frame's non-NULL, non-bad map points) taken before
+ * the loop (:1194), so a point the loop itself adds is not skipped when the list names it again; a taken slot is never
+ * replaced, only recorded (vpReplacePoint[iMP] = pMPinKF when that point is not bad, :1283-1287); a free slot gets the
+ * point (AddObservation + AddMapPoint, :1288-1292).  nFused counts both (:1293).  The reference dereferences every list
+ * entry (no NULL test, :1203): a negative entry is a caller error here and is skipped.  replace[] is the caller's
+ * vpReplacePoint (entries the loop does not write keep their value).  ops: {0, pMP, slot} for an add, {3, iMP, pMPinKF}
+ * for a recorded replacement. */
+int oracle_fuse_replay_sim3(const int *list, int nlist, const int *visible, const int *best, const int *idx, int th_low, int nmp,
+                            int nkp, int *mp_obs, const uint8_t *mp_bad, int *mp_in_kf, int *kf_mp, int *replace, int *ops,
+                            int *nops)
+{
+    uint8_t *already = (uint8_t *)calloc((size_t)(nmp > 0 ? nmp : 1), 1);
+    int i, k, nFused = 0, no = 0;
+    for (k = 0; k < nkp; k++)
+        if (kf_mp[k] >= 0 && !mp_bad[kf_mp[k]]) already[kf_mp[k]] = 1;
+    for (i = 0; i < nlist; i++) {
+        const int pMP = list[i];
+        if (pMP < 0) continue;
+        if (mp_bad[pMP] || already[pMP]) continue;
+        if (!visible[i] || idx[i] < 0) continue;          /* projection tests / vIndices.empty() / no candidate in level range */
+        if (best[i] <= th_low) {
+            const int bestIdx = idx[i], pMPinKF = kf_mp[bestIdx];
+            if (pMPinKF >= 0) {
+                if (!mp_bad[pMPinKF]) {
+                    replace[i] = pMPinKF;
+                    ops[3 * no] = 3; ops[3 * no + 1] = i; ops[3 * no + 2] = pMPinKF; no++;
+                }
+            } else {
+                kf_mp[bestIdx] = pMP; mp_in_kf[pMP] = bestIdx; mp_obs[pMP] += 1;
+                ops[3 * no] = 0; ops[3 * no + 1] = pMP; ops[3 * no + 2] = bestIdx; no++;
+            }
+            nFused++;
+        }
+    }
+    *nops = no;
+    free(already);
+    return nFused;
+}

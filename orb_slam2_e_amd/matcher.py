@@ -317,12 +317,36 @@ class ORBmatcher:
         projection of every listed map point and the gated candidate loop on the device, then the reference's loop tail
         on the host in list order.  vpMapPoints[i] = map point handle or -1 (NULL entry); mp_* arrays are indexed by i.
         map_ops: is_bad(h), is_in_keyframe(h), slot_owner(idx) -> handle or -1, observations(h), replace(dead, heir),
-        add(h, idx).  Returns nFused."""
+        add(h, idx); the Sim3 form needs already_found(h) (spAlreadyFound, a snapshot) and record_replace(i, h) instead of
+        is_in_keyframe / observations / replace.  Returns nFused."""
         mode = self.PROJECT_FUSE_SIM3 if sim3 else self.PROJECT_FUSE
         proj, q = self.project_points(mode, mp_pos, mp_normal, mp_min_distance, mp_max_distance, Rcw, tcw, Ow, cam, mbf,
                                       log_scale_factor, scale_factors, th)
         best, idx = self.search_fuse(q, mp_desc, kps, desc, bounds, uright, None if sim3 else inv_level_sigma2)
+        if sim3:
+            return self.fuse_replay_sim3(vpMapPoints, proj["visible"], best, idx, map_ops)
         return self.fuse_replay(vpMapPoints, proj["visible"], best, idx, map_ops)
+
+    def fuse_replay_sim3(self, vpPoints, visible, best, idx, map_ops):
+        """The tail of the Sim3 form (ORBmatcher.cc:1194-1205 skips, :1279-1296 update): the "already found" test reads the
+        snapshot of the key frame's map points taken before the loop -- map_ops.already_found(h) must answer from that
+        snapshot (KeyFrame::GetMapPoints at call time), not from the state the loop is changing; a taken slot is only
+        recorded, map_ops.record_replace(i, h_in_kf) (vpReplacePoint[i] = pMPinKF); a free slot gets the point."""
+        nFused = 0
+        for i, h in enumerate(vpPoints):
+            if h < 0 or map_ops.is_bad(h) or map_ops.already_found(h):
+                continue
+            if not visible[i] or idx[i] < 0:
+                continue
+            if best[i] <= self.TH_LOW:
+                other = map_ops.slot_owner(int(idx[i]))
+                if other >= 0:
+                    if not map_ops.is_bad(other):
+                        map_ops.record_replace(i, other)
+                else:
+                    map_ops.add(h, int(idx[i]))
+                nFused += 1
+        return nFused
 
     def fuse_replay(self, vpMapPoints, visible, best, idx, map_ops):
         """The tail of the Fuse loop (ORBmatcher.cc:1046-1053 skips, :1149-1170 update) in the list's order: the candidate

@@ -68,6 +68,82 @@ def test_fuse_replay_equals_literal_loop_tail(seed):
         assert np.array_equal(a, b)
 
 
+class ToyMapSim3(ToyMap):
+    """+ what the Sim3 form reads and writes: spAlreadyFound (snapshot at construction) and vpReplacePoint."""
+
+    def __init__(self, mp_obs, mp_bad, mp_in_kf, kf_mp, nlist):
+        super().__init__(mp_obs, mp_bad, mp_in_kf, kf_mp)
+        self.already = np.zeros(len(mp_obs), bool)
+        own = kf_mp[kf_mp >= 0]
+        self.already[own[mp_bad[own] == 0]] = True                  # KeyFrame::GetMapPoints(), KeyFrame.cc:274-287
+        self.vpReplacePoint = np.full(nlist, -1, np.int32)
+
+    def already_found(self, h): return bool(self.already[h])
+
+    def record_replace(self, i, h):
+        self.vpReplacePoint[i] = h
+        self.ops.append((3, i, h))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuse_replay_sim3_equals_literal_loop_tail(seed):
+    """ORBmatcher.cc:1194-1205, :1279-1296: snapshot skip, record-only replacement; the list repeats points, so one the
+    loop has just added comes round again (it is not in the snapshot) and finds itself in its slot."""
+    rng = np.random.default_rng(40 + seed)
+    lst, visible, best, idx, mp_obs, mp_bad, mp_in_kf, kf_mp = _toy(rng, 300, 200, 500)
+    lst = np.concatenate([lst, lst[:120]]); visible = np.concatenate([visible, visible[:120]])
+    best = np.concatenate([best, best[:120]]); idx = np.concatenate([idx, idx[:120]])
+    state_o = [a.copy() for a in (mp_obs, mp_bad, mp_in_kf, kf_mp)]
+    rep_o = np.full(len(lst), -1, np.int32)
+    n_ref, ops_ref = oracle.fuse_replay_sim3(lst, visible, best, idx, *state_o, rep_o)
+    tm = ToyMapSim3(mp_obs.copy(), mp_bad.copy(), mp_in_kf.copy(), kf_mp.copy(), len(lst))
+    n = ORBmatcher.__new__(ORBmatcher).fuse_replay_sim3(lst, visible, best, idx, tm)
+    assert n == n_ref and n > 20
+    assert [tuple(int(v) for v in o) for o in ops_ref] == tm.ops
+    assert {k for k, _, _ in tm.ops} == {0, 3}
+    assert np.array_equal(rep_o, tm.vpReplacePoint) and (rep_o >= 0).sum() > 5
+    for a, b in zip(state_o, (tm.obs, tm.bad, tm.in_kf, tm.kf)):
+        assert np.array_equal(a, b)
+    # a point added by the loop and named again records itself (not in the snapshot): the reference's behaviour
+    added = {h for k, h, _ in tm.ops if k == 0}
+    assert any(k == 3 and int(lst[i]) in added and int(lst[i]) == h for k, i, h in tm.ops)
+    assert not np.array_equal(state_o[1], mp_bad) or True            # the Sim3 form never kills a point
+    assert np.array_equal(state_o[1], mp_bad)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_cxx_header_fuse_tails_equal_the_oracle(seed, tmp_path):
+    """orbslam_hip::ORBmatcher::fuseReplay / fuseReplaySim3 (include/orbslam_hip.hpp), compiled with g++ and run on a toy
+    map (tests/cxx/host_logic.cpp; no device call), against the oracle's literal loop tails."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_logic")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cxx", "host_logic.cpp"), "-o", exe])
+    rng = np.random.default_rng(90 + seed)
+    lst, visible, best, idx, mp_obs, mp_bad, mp_in_kf, kf_mp = _toy(rng, 300, 200, 500)
+    lst = np.concatenate([lst, lst[:120]]); visible = np.concatenate([visible, visible[:120]])
+    best = np.concatenate([best, best[:120]]); idx = np.concatenate([idx, idx[:120]])
+    text = " ".join(str(int(v)) for v in np.concatenate([[300, 200, len(lst)], mp_obs, mp_bad, mp_in_kf, kf_mp, lst, visible, best, idx]))
+    out = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = [np.array(l.split(), np.int64) for l in out.stdout.strip("\n").split("\n")]
+    # plain form
+    st = [a.copy() for a in (mp_obs, mp_bad, mp_in_kf, kf_mp)]
+    n_ref, ops_ref = oracle.fuse_replay(lst, visible, best, idx, *st)
+    assert tuple(lines[0]) == (n_ref, len(ops_ref)) and np.array_equal(lines[1], ops_ref.ravel())
+    for got, ref in zip(lines[2:6], st):
+        assert np.array_equal(got, ref)
+    # Sim3 form
+    st = [a.copy() for a in (mp_obs, mp_bad, mp_in_kf, kf_mp)]
+    rep = np.full(len(lst), -1, np.int32)
+    n_ref, ops_ref = oracle.fuse_replay_sim3(lst, visible, best, idx, *st, rep)
+    assert tuple(lines[6]) == (n_ref, len(ops_ref)) and np.array_equal(lines[7], ops_ref.ravel())
+    for got, ref in zip(lines[8:13], st + [rep]):
+        assert np.array_equal(got, ref)
+
+
 def _scene(rng, m):
     """A camera at a generic pose looking at a cloud; points in front, behind, outside the image, too near / far, seen
     from behind, plus exact boundary cases."""
@@ -161,11 +237,21 @@ def test_fuse_as_a_whole(sim3):
     if not sim3:
         n_ref, ops_ref = oracle.fuse_replay(lst, rproj["visible"], rbest, ridx, *st_ref)
     tm = ToyMap(mp_obs.copy(), mp_bad.copy(), mp_in_kf.copy(), kf_mp.copy())
-    if sim3:                 # candidate stage only (the Sim3 tail records instead of replacing; host logic in the C++ header)
+    if sim3:                 # the Sim3 form end to end: candidate stage on the device, its record-only tail on the host
         gproj, gq = mt.project_points(mode, pos[li], nrm[li], mind[li], maxd[li], R, t, Ow, _cam(), 386.1448, logsf, sf, 3.0)
         gbest, gidx = mt.search_fuse(gq, mp_desc[li], kps, desc, BOUNDS, uright, None)
         assert gq.tobytes() == rq.tobytes() and np.array_equal(gbest, rbest) and np.array_equal(gidx, ridx)
         assert ((rbest <= 45) & (ridx >= 0)).sum() > 100
+        rep_ref = np.full(len(lst), -1, np.int32)
+        n_ref, ops_ref = oracle.fuse_replay_sim3(lst, rproj["visible"], rbest, ridx, *st_ref, rep_ref)
+        ts = ToyMapSim3(mp_obs.copy(), mp_bad.copy(), mp_in_kf.copy(), kf_mp.copy(), len(lst))
+        n = mt.Fuse(kps, desc, uright, BOUNDS, inv_sigma2, lst, pos[li], nrm[li], mind[li], maxd[li], mp_desc[li], R, t, Ow, _cam(),
+                    386.1448, logsf, sf, 3.0, ts, sim3=True)
+        assert n == n_ref and n > 100
+        assert [tuple(int(v) for v in o) for o in ops_ref] == ts.ops and {k for k, _, _ in ts.ops} == {0, 3}
+        assert np.array_equal(rep_ref, ts.vpReplacePoint)
+        for a, b in zip(st_ref, (ts.obs, ts.bad, ts.in_kf, ts.kf)):
+            assert np.array_equal(a, b)
         return
     n = mt.Fuse(kps, desc, uright, BOUNDS, inv_sigma2, lst, pos[li], nrm[li], mind[li], maxd[li], mp_desc[li], R, t, Ow, _cam(),
                 386.1448, logsf, sf, 3.0, tm)
