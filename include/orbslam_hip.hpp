@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <utility>
@@ -725,6 +726,144 @@ private:
     fem_model *mModel = nullptr;
     int mStatus = ORBX_OK;
     bool mTrialReady = false;
+};
+
+// The FEM side of Optimizer::PoseOptimizationNR (src/Optimizer.cc:478-834) as one compiled sequence:
+//   FEA2 fea2(mnId, 3500, 0.495, 0.5, 0.577350269, nElType)                       :480
+//   fea2.Compute(1)                                                               :723   -> Compute()
+//   4 x { optimizer.initializeOptimization(0); optimizer.optimize(10); classify } :733-790 -> Optimize()
+// and, inside every Levenberg iteration of optimize(), g2o's trial loop with this fork's hook
+// (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:63-232; the hook :159-199) -> Iteration() / Hook().
+// What g2o computes -- the reprojection chi2, the linear solve, the vertex estimates, push / pop -- stays g2o's and
+// comes in through `Problem` (a g2o::SparseOptimizer + BlockSolver in the real build, a scripted stand-in in the tests):
+//   void   initializeOptimization(int round)          optimizer.initializeOptimization(0)              Optimizer.cc:738
+//   double activeRobustChi2()                         computeActiveErrors() + activeRobustChi2()       levenberg.cpp:80-99
+//   void   buildSystem()                              _solver->buildSystem()                           :102
+//   double computeLambdaInit()                        :242-256
+//   void   push(), pop(), discardTop()                _optimizer->push() / pop() / discardTop()        :123, 222, 216
+//   bool   solveAndUpdate(double lambda)              setLambda, solve, update(x), restoreDiagonal     :130-146 (-> ok2)
+//   double computeScale(double lambda)                :258-267
+//   void   pointEstimates(std::vector<double> &xyz)   GetPointCoordinates(pFEA2->vVertices)            :293-311
+//   bool   terminate()                                _optimizer->terminate()
+//   void   classifyOutliers(int round)                the inlier / outlier pass after each round       Optimizer.cc:752-790
+class PoseOptimizationNR_fem {
+public:
+    struct Trial { float sE, nsE; double tempChi, currentChi, rho, lambda; int qmax, accepted; };
+    enum SolverResult { Terminate = 2, OK = 1, Fail = -1 };   // OptimizationAlgorithm::SolverResult
+
+    explicit PoseOptimizationNR_fem(int nElType) : fea2(3500, 0.495f, 0.5f, 0.577350269f, nElType) {}
+
+    // fea2.Compute(1), Optimizer.cc:723 (its numeric half: the PCL meshing in front stays the reference's), and the
+    // state of the hook parked on the device: u0, the Dirichlet list, the optimiser's nVertices point vertices and
+    // vNewPointsBase (derived[nDerived][4] = {2 | 3, i0, i1, i2}; nVertices + nDerived = top-layer nodes).
+    bool Compute(const std::vector<float> &topXYZ, const std::vector<int32_t> &faces, int nVertices,
+                 const std::vector<int32_t> &derived = std::vector<int32_t>())
+    {
+        if (!fea2.Compute(topXYZ, faces)) return false;
+        mStatus = fem_trial_setup(fea2.model(), fea2.u0.data(), fea2.vDir.data(), (int)fea2.vDir.size(), 100000000.0f, nVertices,
+                                  derived.empty() ? nullptr : derived.data(), (int)derived.size() / 4);
+        mNV = nVertices;
+        return mStatus == ORBX_OK;
+    }
+
+    // The hook, levenberg.cpp:159-199: GetPointCoordinates + Set_uf + ComputeDisplacement + ComputeForces +
+    // ComputeStrainEnergy + NormalizeStrainEnergy in one device call, then g2o's weighting, verbatim.
+    double Hook(const std::vector<double> &vertexXYZ, int qmax, double tempChi, double &currentChi, float &sE, float &nsE)
+    {
+        sE = 0.0f; nsE = 0.0f;
+        mStatus = fem_trial_energy(fea2.model(), vertexXYZ.data(), nullptr, &sE, &nsE);     // :164-171
+        float w_rE = 1.0;                                                                    // :184
+        float w_sE = 5.0;                                                                    // :185
+        if (qmax == 0) {                                                                     // :186-193
+            w_rE = 1.0;
+            w_sE = 2.0;
+            currentChi += nsE;
+        }
+        return w_rE * tempChi + w_sE * nsE;                                                  // :198
+    }
+
+    // One Levenberg iteration = OptimizationAlgorithmLevenberg::solve(iteration), levenberg.cpp:63-232, bInFEA set.
+    template <class Problem>
+    SolverResult Iteration(Problem &g2o, int iteration, std::vector<Trial> *log = nullptr)
+    {
+        double currentChi = g2o.activeRobustChi2();            // :80-97
+        double tempChi = currentChi;
+        const double iniChi = currentChi;
+        g2o.buildSystem();                                     // :102
+        if (iteration == 0) {                                  // :109-114
+            mLambda = g2o.computeLambdaInit();
+            mNi = 2;
+            mNBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        std::vector<double> pts;
+        do {
+            g2o.push();                                        // :123
+            const bool ok2 = g2o.solveAndUpdate(mLambda);      // :130-146
+            tempChi = g2o.activeRobustChi2();                  // :148-157
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            float sE, nsE;
+            g2o.pointEstimates(pts);
+            if ((int)pts.size() != 3 * mNV) { mStatus = ORBX_ERR_ARG; return Fail; }
+            tempChi = Hook(pts, qmax, tempChi, currentChi, sE, nsE);   // :159-199
+            if (mStatus != ORBX_OK) return Fail;
+            rho = (currentChi - tempChi);                      // :201
+            double scale = g2o.computeScale(mLambda);
+            scale += 1e-3;
+            rho /= scale;
+            const bool good = rho > 0 && std::isfinite(tempChi);
+            if (good) {                                        // :207-217
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = (std::min)(alpha, mGoodStepUpperScale);
+                const double scaleFactor = (std::max)(mGoodStepLowerScale, alpha);
+                mLambda *= scaleFactor;
+                mNi = 2;
+                currentChi = tempChi;
+                g2o.discardTop();
+            } else {                                           // :218-223
+                mLambda *= mNi;
+                mNi *= 2;
+                g2o.pop();
+            }
+            if (log) log->push_back(Trial{sE, nsE, tempChi, currentChi, rho, mLambda, qmax, good ? 1 : 0});
+            qmax++;
+        } while (rho < 0 && qmax < mMaxTrialsAfterFailure && !g2o.terminate());   // :226
+        if (qmax == mMaxTrialsAfterFailure || rho == 0) return Terminate;           // :228-229
+        if ((iniChi - currentChi) * 1e3 < iniChi) mNBad++;                           // :232-235 (the stop criterion added in ORB-SLAM2's g2o)
+        else mNBad = 0;
+        if (mNBad >= 3) return Terminate;
+        return OK;
+    }
+
+    // The four rounds of Optimizer.cc:733-790: its[] = {10, 10, 10, 10}; SparseOptimizer::optimize's loop stops at the
+    // first result that is not OK.  Returns the number of Levenberg iterations run.
+    template <class Problem>
+    int Optimize(Problem &g2o, std::vector<Trial> *log = nullptr, std::vector<int> *results = nullptr)
+    {
+        static const int its[4] = {10, 10, 10, 10};            // :730
+        int total = 0;
+        for (int round = 0; round < 4; ++round) {
+            g2o.initializeOptimization(round);                 // :738
+            for (int i = 0; i < its[round] && !g2o.terminate(); ++i) {
+                const SolverResult r = Iteration(g2o, i, log);
+                ++total;
+                if (results) results->push_back((int)r);
+                if (r != OK) break;
+            }
+            g2o.classifyOutliers(round);                       // :752-790
+        }
+        return total;
+    }
+
+    FEA2 fea2;
+    int status() const { return mStatus == ORBX_OK ? fea2.status() : mStatus; }
+    double lambda() const { return mLambda; }
+
+private:
+    int mStatus = ORBX_OK, mNV = 0;
+    double mLambda = -1., mNi = 2., mGoodStepLowerScale = 1. / 3., mGoodStepUpperScale = 2. / 3.;   // levenberg.cpp:48-56
+    int mNBad = 0, mMaxTrialsAfterFailure = 10;                                                     // :50
 };
 
 } // namespace orbslam_hip

@@ -639,3 +639,76 @@ def fuse_replay_sim3(vpPoints, visible, best, idx, mp_obs, mp_bad, mp_in_kf, kf_
     n = L.oracle_fuse_replay_sim3(_p(lst), len(lst), _p(vis), _p(b), _p(ix), int(th_low), len(mp_obs), len(kf_mp), _p(mp_obs),
                                   _p(mp_bad), _p(mp_in_kf), _p(kf_mp), _p(vpReplacePoint), _p(ops), C.byref(nops))
     return n, ops[:nops.value].copy()
+
+
+def pose_optimization_nr_fem_sequence(K, u0, ids, derived, script, Klarge=100000000.0):
+    """The FEM side of Optimizer::PoseOptimizationNR after fea2.Compute(1) (src/Optimizer.cc:733-790), literally: four
+    rounds of optimizer.optimize(10) (SparseOptimizer::optimize, sparse_optimizer.cpp:453-470: stop at the first result
+    that is not OK), each iteration = OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:63-232)
+    with this fork's hook (:159-199) evaluated by the oracle's Set_uf / ComputeDisplacement / ComputeForces /
+    ComputeStrainEnergy / NormalizeStrainEnergy.  What g2o computes comes from `script` (the same one the C++ harness
+    reads): pts[T][nv][3], chi[T], scale[T], ok2[T] consumed one per trial, iterChi[I] one per iteration, lambdaInit.
+    K: the assembled matrix after ImposeDirichletEncastre_K (dense f32).  Returns (trials, results): trials = list of
+    (sE, nsE, tempChi, currentChi, rho, lambda, qmax, accepted)."""
+    pts, chi, scale, ok2, iterChi = script["pts"], script["chi"], script["scale"], script["ok2"], script["iterChi"]
+    T, I = len(chi), len(iterChi)
+    t, it = -1, 0
+    lam, ni, nBad = -1.0, 2.0, 0                           # levenberg.cpp:47-55
+    lower, upper, max_trials = 1.0 / 3.0, 2.0 / 3.0, 10
+    trials, results = [], []
+    exhausted = False
+    for rnd in range(4):                                   # Optimizer.cc:733, its = {10, 10, 10, 10}
+        for iteration in range(10):
+            if exhausted or it >= I:
+                exhausted = True
+                break
+            currentChi = float(iterChi[it]); it += 1       # :97
+            iniChi = currentChi
+            if iteration == 0:                             # :109-114
+                lam, ni, nBad = float(script["lambdaInit"]), 2.0, 0
+            rho, qmax = 0.0, 0
+            while True:
+                if t + 1 >= T:
+                    exhausted = True
+                else:
+                    t += 1
+                tempChi = float(chi[t])                    # :157
+                if not ok2[t]:
+                    tempChi = float(np.finfo(np.float64).max)
+                a = fem_trial_displacement(pts[t], derived, u0, ids, Klarge)       # GetPointCoordinates, Set_uf, ComputeDisplacement
+                f = fem_matvec_dense(K, a)                                         # ComputeForces
+                sE, nsE = fem_strain_energy(a, f)                                  # ComputeStrainEnergy, NormalizeStrainEnergy
+                w_rE, w_sE = np.float32(1.0), np.float32(5.0)                      # :184-185 (float)
+                if qmax == 0:                                                      # :186-193
+                    w_rE, w_sE = np.float32(1.0), np.float32(2.0)
+                    currentChi += float(np.float32(nsE))
+                tempChi = float(w_rE) * tempChi + float(np.float32(w_sE * np.float32(nsE)))   # :198: float * double + float * float
+                rho = currentChi - tempChi
+                sc = float(scale[t]) + 1e-3
+                rho /= sc
+                good = rho > 0 and np.isfinite(tempChi)
+                if good:                                   # :207-217
+                    alpha = 1.0 - (2 * rho - 1) ** 3
+                    alpha = min(alpha, upper)
+                    lam *= max(lower, alpha)
+                    ni = 2.0
+                    currentChi = tempChi
+                else:
+                    lam *= ni
+                    ni *= 2
+                trials.append((float(sE), float(nsE), tempChi, currentChi, rho, lam, qmax, int(good)))
+                qmax += 1
+                if not (rho < 0 and qmax < max_trials and not exhausted):
+                    break
+            if qmax == max_trials or rho == 0:
+                results.append(2)
+                break
+            if (iniChi - currentChi) * 1e3 < iniChi:
+                nBad += 1
+            else:
+                nBad = 0
+            if nBad >= 3:
+                results.append(2)
+                break
+            results.append(1)
+    return trials, results

@@ -498,3 +498,76 @@ def test_256_meshes_200_iterations_resident_vs_oracle(ncell):
         ox, _, orel = oracle.fem_cg(rp, col, val, b[m], iters, 0.0)
         assert np.abs(x[m] - ox).max() <= RTOL * np.abs(ox).max(), m
         assert abs(rel[m] - orel) <= 1e-6 * orel + 1e-12
+
+
+@pytest.mark.parametrize("name,nder", [("min", 0), ("median", 12), ("p90", 40), ("large", 0)])
+def test_pose_optimization_nr_fem_sequence(name, nder, tmp_path):
+    """F12: the FEM side of Optimizer::PoseOptimizationNR as the compiled sequence orbslam_hip::PoseOptimizationNR_fem
+    (include/orbslam_hip.hpp; g++-built harness tests/cxx/pose_nr_fem.cpp over the C-ABI) -- fea2.Compute(1), the hook's
+    state parked on the device, 4 x optimize(10) with g2o's trial loop and this fork's hook (tempChi = w_rE chi2 + w_sE nsE,
+    w_sE = 2 on the first trial of an iteration, else 5) -- against the oracle's literal sequence on the reference's own
+    surface meshes.  g2o's numbers (trial estimates, reprojection chi2, scale, solver failures) come from one script both
+    sides read.  Energies 1e-5 relative; accept / reject decisions, trial counts, results per iteration equal."""
+    import subprocess
+    import struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "orb_slam2_e_amd")
+    exe = str(tmp_path / "pose_nr_fem")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cxx", "pose_nr_fem.cpp"),
+                           "-o", exe, "-L", libdir, "-lorbslam_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    top, tris = _fixture(name)
+    tris = _clean(top, tris)
+    rng = np.random.default_rng(len(top))
+    ntop = len(top)
+    nv = ntop - nder
+    der = []
+    for d in range(nder):
+        hi = nv + d if d % 5 == 4 else nv
+        der.append([2, *rng.integers(0, hi, 2), 0] if d % 2 == 0 else [3, *rng.integers(0, hi, 3)])
+    der = np.array(der, np.int32).reshape(-1, 4)
+    # the oracle's Compute(1): second layer, assembly, Dirichlet K
+    nodes = oracle.fem_second_layer(top, 0.5)
+    elems = extrude_elems(tris, ntop)
+    K = oracle.fem_assemble_dense(2, nodes, elems)
+    ids = np.arange(ntop, 2 * ntop, dtype=np.int32)
+    K = oracle.fem_dirichlet_K(K, ids)
+    u0 = nodes.ravel()
+    # g2o's side, scripted
+    T, I = 400, 40
+    amp = 0.004 * (0.985 ** np.arange(T)) * (1 + 0.5 * np.sin(np.arange(T)))
+    pts = top[None, :nv].astype(np.float64) + rng.normal(0, 1, (T, nv, 3)) * amp[:, None, None]
+    a0 = oracle.fem_trial_displacement(pts[0], der, u0, ids)
+    nsE0 = float(oracle.fem_strain_energy(a0, oracle.fem_matvec_dense(K, a0))[1])
+    c0 = 20 * nsE0
+    script = {"pts": pts, "chi": c0 * (0.9 + 0.2 * rng.random(T)), "scale": c0 * 0.1 * rng.uniform(0.5, 2, T),
+              "ok2": (np.arange(T) % 17 != 5).astype(np.int32), "iterChi": c0 * (1.0 + 0.1 * rng.random(I)), "lambdaInit": 1e-5 * c0}
+    trials, results = oracle.pose_optimization_nr_fem_sequence(K, u0, ids, der, script)
+    assert len(trials) < T and len(results) <= I
+    sp = str(tmp_path / "script.bin"); op = str(tmp_path / "out.bin")
+    with open(sp, "wb") as f:
+        f.write(np.array([2, ntop, len(tris), nv, len(der), T, I], np.int32).tobytes())
+        f.write(np.array([script["lambdaInit"]], np.float64).tobytes())
+        f.write(np.ascontiguousarray(top, np.float32).tobytes()); f.write(np.ascontiguousarray(tris, np.int32).tobytes())
+        f.write(der.tobytes()); f.write(pts.tobytes())
+        f.write(script["chi"].astype(np.float64).tobytes()); f.write(script["scale"].astype(np.float64).tobytes())
+        f.write(script["ok2"].tobytes()); f.write(script["iterChi"].astype(np.float64).tobytes())
+    out = subprocess.run([exe, sp, op], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+    assert out.stdout.strip().endswith("exhausted: 0")
+    raw = open(op, "rb").read()
+    nt, nit = struct.unpack("<ii", raw[:8])
+    rec = np.dtype([("sE", "<f4"), ("nsE", "<f4"), ("tempChi", "<f8"), ("currentChi", "<f8"), ("rho", "<f8"), ("lam", "<f8"), ("qmax", "<i4"), ("acc", "<i4")])
+    got = np.frombuffer(raw[8:8 + nt * rec.itemsize], rec)
+    gres = np.frombuffer(raw[8 + nt * rec.itemsize:], np.int32)
+    ref = np.array(trials, dtype=[("sE", "<f8"), ("nsE", "<f8"), ("tempChi", "<f8"), ("currentChi", "<f8"), ("rho", "<f8"), ("lam", "<f8"), ("qmax", "<i4"), ("acc", "<i4")])
+    assert min(abs(r) for r in ref["rho"][np.isfinite(ref["rho"])]) > 1e-3          # no decision hangs on the tolerance
+    assert nt == len(trials) and nit == len(results) and np.array_equal(gres, results)
+    assert np.array_equal(got["qmax"], ref["qmax"]) and np.array_equal(got["acc"], ref["acc"])
+    assert 0 < ref["acc"].sum() < nt and ref["qmax"].max() >= 1 and 1 in results     # accepted and rejected trials, retries
+    ok = ref["tempChi"] < 1e300
+    assert (~ok).sum() >= 1                                                         # a failed linear solve was in the script
+    for fld in ("sE", "nsE"):
+        assert np.all(np.abs(got[fld] - ref[fld]) <= RTOL * np.abs(ref[fld])), fld
+    for fld in ("tempChi", "currentChi", "lam"):
+        assert np.all(np.abs(got[fld][ok] - ref[fld][ok]) <= RTOL * np.abs(ref[fld][ok])), fld
+    assert np.all(np.abs(got["rho"][ok] - ref["rho"][ok]) <= 1e-4 * np.maximum(np.abs(ref["rho"][ok]), 1e-2))
