@@ -84,6 +84,23 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs);
 int fem_get_ke(fem_model *m, int mesh, int elem, float *ke /* (3*npe)^2 */);
 int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr /*ndof+1*/, int32_t *col /*nnz*/, float *val /*nnz*/);
 
+/* What fem_create / fem_create_batch work out on the host before their first device call -- the symbolic phase (CSR pattern
+ * of 3 x 3 node blocks in the reference's scatter order), the chunking of rows over workgroups, the node-block tables of the
+ * SpMV and the chunk table of the compute-unit-resident CG -- WITHOUT touching the device: no GPU is needed.  Introspection /
+ * test aid (the CPU tests and the host sanitizer build, tools/asan_host.sh, drive the host code through it).
+ * uniform_copies > 0: fem_create's layout (nmesh must be 1: that many meshes sharing the one topology); 0: fem_create_batch's
+ * (nmesh meshes of their own sizes, concatenated in global numbering).  Every output array may be NULL; sizes: rowptr[ndof + 1],
+ * lcol[nnz], diag[ndof] (position of each row's diagonal entry), bp[ndof / 3 + 1] (blocks before a block row), bcol3[nnz / 9]
+ * (first column of a block), rcd[4 nrcd] = {first block row, block rows, first block, blocks} per chunk of the resident CG and
+ * rcfirst[meshes + 1] (both only if info->resident), chunk_mesh[nchunk_tot] (batch layout only). */
+typedef struct {
+    int32_t ndof, nblk, spb, spmv_lds, fused_lds, nchunk_tot, nchunk_s_tot, resident, resident_big, resident_lds, nrcd, maxel;
+    int64_t nnz, ncontrib;
+} fem_plan_info;
+int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const int32_t *elems, int uniform_copies,
+             fem_plan_info *info, int32_t *rowptr, int32_t *lcol, int32_t *diag, int32_t *bp, int32_t *bcol3, int32_t *rcd,
+             int32_t *rcfirst, int32_t *chunk_mesh);
+
 /* ComputeDisplacement + ImposeDirichletEncastre_a (FEA2.cc:1799-1808,1648-1658):
  * a = uf - u0, then a[3*(id-1)+k] = 1/klarge.  Arrays [nmesh][ndof]. */
 int fem_displacement(fem_model *m, const float *uf, const float *u0, const int32_t *ids, int nids,
@@ -116,9 +133,10 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
  * The solver works on a block-major copy of the matrix values (3 x 3 node blocks kept together), made from the values
  * as they stand when fem_cg / fem_cg_setup is called: another 4 bytes per non-zero of device memory while a model has
  * been solved with, and changes of K (assembly, penalties) after that call are seen by the next call, not by
- * fem_cg_iterate.  Batches of 64 or more meshes of at most 14,336 dofs each run one mesh per compute unit with the
- * iteration vectors in LDS and registers (all iterations of a call in one launch); other models launch phase by
- * phase.  Both sum in fixed orders: a given model, right-hand side and iteration count give the same bits every run. */
+ * fem_cg_iterate.  Batches of 64 or more meshes of at most 14,288 dofs each (what 160 KB of LDS hold: (n + 6,192) x 8
+ * bytes with the search direction alone in LDS; up to 7,168 dofs also K p stays there) run one mesh per compute unit
+ * with the iteration vectors in LDS and registers: fem_cg_iterate(n) is ONE launch of n iterations, fem_cg launches
+ * slices of 25 iterations between its convergence tests.  Other models launch phase by phase.  Both sum in fixed orders: a given model, right-hand side and iteration count give the same bits every run. */
 int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int *iters_done, double *relres);
 
 /* Resident variants for timing: upload the right-hand side and reset the solver

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
     if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
 }
 
-// Batches of meshes that fit a compute unit: ALL iterations of a mesh's CG in one launch, one 1024-thread workgroup per mesh
+// Batches of meshes that fit a compute unit: ALL iterations of a mesh's CG in one launch, one 512-thread (CGR_T) workgroup per mesh
 // (one per CU: the batch of 256 fills the chip).  What an iteration needs besides the matrix stays on the CU: p and Ap in LDS
 // (16 bytes per dof), x, r and 1/diag in the registers of the thread that owns the row, the scalars in the workgroup.  HBM
 // then streams the block-major values and ONE column index per 3 x 3 block, once per iteration, and nothing else: no vector
@@ -702,7 +702,8 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
 // A wave takes chunks of <= CGR_CB blocks = whole block rows (host table: first block row, block rows, first block, blocks),
 // a lane a block; the three row sums of a block are parked in the wave's own LDS slice and summed per row by one lane, in
 // block order; no workgroup barrier inside the product.  Three barriers per iteration.
-// BIG: meshes of up to 14,336 dofs (8 bytes of LDS per dof for p): Ap and x live in the mesh's slice of the batch vectors instead
+// BIG: meshes of up to 14,288 dofs -- what (n + 3 CGR_CB CGR_W + 6 CGR_W) x 8 B <= 160 KB of LDS leaves for p (plan_model; the register
+// tiling CGR_MAXROWS_BIG would take 14,336) --: Ap and x live in the mesh's slice of the batch vectors instead
 // (written and read by the same compute unit: with 1/diag + 48 bytes per dof and iteration beside the matrix's ~175), r in registers.
 constexpr int CGR_T = 512, CGR_W = CGR_T / 64, CGR_NB = 4, CGR_CB = 64 * CGR_NB, CGR_MAXROWS = 7168, CGR_MAXROWS_BIG = 14336, CGR_MIN_MESHES = 64;
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -988,6 +989,7 @@ struct fem_model {
     int *d_tr_derived = nullptr, *d_tr_ids = nullptr;
     int cg_it = 0;
     // device
+    char *d_tables = nullptr;   // ONE block: node coordinates and every index table below (interior pointers; create_model)
     float *d_nodes = nullptr, *d_ke = nullptr, *d_vals = nullptr, *d_a = nullptr, *d_f = nullptr, *d_u = nullptr, *d_e = nullptr;
     int *d_elems = nullptr, *d_blk_row = nullptr, *d_bptr = nullptr, *d_cptr = nullptr, *d_contrib = nullptr;
     int *d_rowptr = nullptr, *d_lcol = nullptr, *d_diag = nullptr, *d_bcol3 = nullptr, *d_bp = nullptr;
@@ -1008,11 +1010,9 @@ namespace {
 
 void fem_free(fem_model *m)
 {
-    void *ptrs[] = {m->d_nodes, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_elems, m->d_blk_row, m->d_bptr,
-                    m->d_cptr, m->d_contrib, m->d_rowptr, m->d_lcol, m->d_diag, m->d_b, m->d_x, m->d_r,
+    void *ptrs[] = {m->d_tables, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids, m->d_cmesh, m->d_cmesh_s, m->d_minfo, m->d_minfo_s, m->d_nel_ptr, m->d_nel, m->d_contrib_loc,
-                    m->d_ke1, m->d_bcol3, m->d_bp, m->d_vals_b, m->d_rcd, m->d_rcfirst};
+                    m->d_tr_derived, m->d_tr_ids, m->d_ke1, m->d_vals_b};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -1174,13 +1174,23 @@ void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
     y.rowptr[ndof] = 9 * nblk;
 }
 
-// The rest of model construction: material constants, chunking, device arrays.  seg_nn == nullptr: uniform layout
-// (nmesh meshes of nn nodes sharing `y`); else the segmented layout over nseg meshes whose symbolic data `y` already
-// holds concatenated in global numbering (nmesh == 1, nn / ne = totals).
-int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, const int32_t *elems, int ne, unsigned int E, float nu,
-                 float fg, Symbolic &y, int nseg, const int *seg_nn, const int *seg_ne, fem_model **out)
+// Everything model construction computes on the host before its first device call: chunking, segment tables, the
+// node-block tables of the SpMV and the chunk table of the resident CG.  plan_model touches no device state (it also
+// serves fem_plan, which the CPU tests and the host sanitizer build drive without a GPU).
+struct HostPlan {
+    std::vector<int> cmesh, cmesh_s, bp, bcol3, rcfirst;
+    std::vector<int4> minfo, minfo_s, rcd;
+    bool resident = false, big = false;
+    size_t resident_lds = 0;
+    int maxrows = 0;
+};
+
+// seg_nn == nullptr: uniform layout (nmesh meshes of nn nodes sharing `y`); else the segmented layout over nseg meshes
+// whose symbolic data `y` already holds concatenated in global numbering (nmesh == 1, nn / ne = totals).  Fills the
+// host fields of `m` (sizes, material, chunk counts, h_* tables; y's row tables are moved into m) and `P`.
+int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, unsigned int E, float nu, float fg, Symbolic &y, int nseg,
+               const int *seg_nn, const int *seg_ne, HostPlan &P)
 {
-    fem_model *m = new fem_model();
     m->eltype = eltype; m->npe = npe; m->nd = 3 * npe; m->nmesh = nmesh; m->nn = nn; m->ne = ne; m->ndof = 3 * nn;
     m->nseg = seg_nn ? nseg : nmesh;
     m->E = E; m->nu = nu; m->fg = fg;
@@ -1200,8 +1210,6 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     m->nnzs = (m->nnz + 3) & ~(size_t)3;
     m->h_rowptr.swap(y.rowptr); m->h_lcol.swap(y.lcol); m->h_diag.swap(y.diag);
     // chunking: CG vector kernels RPB rows per workgroup, SpMV SPB rows; a chunk never crosses a mesh
-    std::vector<int> cmesh, cmesh_s;
-    std::vector<int4> minfo, minfo_s;
     size_t rows_of_blocks = 0;
     if (seg_nn) for (int k = 0; k < nseg; ++k) rows_of_blocks += (size_t)(3 * seg_nn[k] + 95) / 96;
     else rows_of_blocks = (size_t)nmesh * ((m->ndof + 95) / 96);
@@ -1226,8 +1234,8 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
             const int row0 = 3 * m->seg_node0[k], nrows = 3 * seg_nn[k];
             m->seg_nnz0[k + 1] = m->h_rowptr[row0 + nrows];
             const int nc = (nrows + RPB - 1) / RPB, ns = (nrows + SPB - 1) / SPB;
-            minfo.push_back(make_int4(row0, nrows, c0, nc)); minfo_s.push_back(make_int4(row0, nrows, s0, ns));
-            cmesh.insert(cmesh.end(), nc, k); cmesh_s.insert(cmesh_s.end(), ns, k);
+            P.minfo.push_back(make_int4(row0, nrows, c0, nc)); P.minfo_s.push_back(make_int4(row0, nrows, s0, ns));
+            P.cmesh.insert(P.cmesh.end(), nc, k); P.cmesh_s.insert(P.cmesh_s.end(), ns, k);
             c0 += nc; s0 += ns;
             scan_runs(row0, nrows);
         }
@@ -1236,59 +1244,28 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         scan_runs(0, m->ndof);
     }
     // k_fem_spmv parks three row sums per 3 x 3 block of a workgroup's run: maxrun / 9 blocks
-    if (maxrun / 3 * (int)sizeof(double) > 150 * 1024) { delete m; ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer"); }
+    if (maxrun / 3 * (int)sizeof(double) > 150 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "rows too long for the SpMV staging buffer");
     m->spmv_lds = (maxrun / 3 + 8) * (int)sizeof(double);
-
-    const size_t M = (size_t)nmesh;
-    int bad = 0;
     {   // K_e stays on the chip when the Gauss-point data of a node's elements fits LDS (it always does for real meshes)
         const int ngp = eltype == FEM_TET4 ? 1 : 8;
         const size_t lds = (size_t)y.maxel * (ngp * 3 * npe + ngp) * sizeof(float);
         m->fused_lds = lds <= 64 * 1024 ? (int)std::max(lds, (size_t)16) : 0;
     }
-    bad |= dalloc(&m->d_nodes, M * nn * 3) | dalloc(&m->d_elems, (size_t)ne * npe) | dalloc(&m->d_ke1, (size_t)m->nd * m->nd);
-    if (!m->fused_lds) bad |= dalloc(&m->d_ke, M * ne * m->nd * m->nd);
-    else bad |= dalloc(&m->d_nel_ptr, (size_t)nn + 1) | dalloc(&m->d_nel, y.nel.size()) | dalloc(&m->d_contrib_loc, y.contrib_loc.size());
-    bad |= dalloc(&m->d_vals, M * m->nnzs) | dalloc(&m->d_blk_row, (size_t)nblk);
-    bad |= dalloc(&m->d_bptr, (size_t)nn + 1) | dalloc(&m->d_cptr, (size_t)nblk + 1) | dalloc(&m->d_contrib, y.contrib.size());
-    bad |= dalloc(&m->d_rowptr, (size_t)m->ndof + 1) | dalloc(&m->d_lcol, m->nnzs) | dalloc(&m->d_diag, (size_t)m->ndof) |
-           dalloc(&m->d_bcol3, (size_t)m->nnz / 9 + 1) | dalloc(&m->d_bp, (size_t)m->ndof / 3 + 2);
-    if (seg_nn) bad |= dalloc(&m->d_cmesh, cmesh.size()) | dalloc(&m->d_cmesh_s, cmesh_s.size()) | dalloc(&m->d_minfo, (size_t)nseg) | dalloc(&m->d_minfo_s, (size_t)nseg);
-    if (bad || !(m->stream = stream_get())) {
-        fem_free(m); delete m;
-        ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
-    }
-    ORBX_HIP(hipMemcpy(m->d_nodes, nodes, sizeof(float) * M * nn * 3, hipMemcpyHostToDevice));
-    if (ne) ORBX_HIP(hipMemcpy(m->d_elems, elems, sizeof(int) * (size_t)ne * npe, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_blk_row, y.blk_row.data(), sizeof(int) * nblk, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_bptr, y.bptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_cptr, y.cptr.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice));
-    if (!y.contrib.empty()) ORBX_HIP(hipMemcpy(m->d_contrib, y.contrib.data(), sizeof(int) * y.contrib.size(), hipMemcpyHostToDevice));
-    if (m->fused_lds) {
-        ORBX_HIP(hipMemcpy(m->d_nel_ptr, y.nel_ptr.data(), sizeof(int) * (nn + 1), hipMemcpyHostToDevice));
-        if (!y.nel.empty()) ORBX_HIP(hipMemcpy(m->d_nel, y.nel.data(), sizeof(int) * y.nel.size(), hipMemcpyHostToDevice));
-        if (!y.contrib_loc.empty()) ORBX_HIP(hipMemcpy(m->d_contrib_loc, y.contrib_loc.data(), sizeof(int) * y.contrib_loc.size(), hipMemcpyHostToDevice));
-    }
-    ORBX_HIP(hipMemcpy(m->d_rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemset(m->d_lcol, 0, sizeof(int) * m->nnzs)); // the padding tail is read by the SpMV's last quad: valid columns
-    ORBX_HIP(hipMemcpy(m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, hipMemcpyHostToDevice));
     {   // node-block tables of k_fem_spmv: bp[I] = blocks before block row I, bcol3[q] = first column of block q
         const int nbr = m->ndof / 3;
-        std::vector<int> bp((size_t)nbr + 1, 0), bcol3((size_t)m->nnz / 9);
+        P.bp.assign((size_t)nbr + 1, 0); P.bcol3.assign((size_t)m->nnz / 9, 0);
         size_t q = 0;
         for (int I = 0; I < nbr; ++I) {
             const int k0 = m->h_rowptr[3 * I], nb = (m->h_rowptr[3 * I + 1] - k0) / 3;
-            bp[I] = (int)q;
-            for (int j = 0; j < nb && q < bcol3.size(); ++j) bcol3[q++] = m->h_lcol[k0 + 3 * j];
+            P.bp[I] = (int)q;
+            for (int j = 0; j < nb && q < P.bcol3.size(); ++j) P.bcol3[q++] = m->h_lcol[k0 + 3 * j];
         }
-        bp[nbr] = (int)q;
-        if (q != bcol3.size()) { fem_free(m); delete m; ORBX_FAIL(ORBX_ERR_ARG, "matrix pattern is not made of 3 x 3 node blocks"); }
-        ORBX_HIP(hipMemcpy(m->d_bcol3, bcol3.data(), sizeof(int) * bcol3.size(), hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(m->d_bp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice));
-        m->h_bp.swap(bp);
+        P.bp[nbr] = (int)q;
+        if (q != P.bcol3.size()) ORBX_FAIL(ORBX_ERR_ARG, "matrix pattern is not made of 3 x 3 node blocks");
+        m->h_bp = P.bp;
     }
     {   // k_fem_cg_resident: whole batches of meshes small enough for one compute unit each
-        std::vector<int4> rcd; std::vector<int> rcfirst(1, 0);
+        P.rcfirst.assign(1, 0);
         bool ok = m->nseg >= CGR_MIN_MESHES;
         int maxrows = 0;
         if (seg_nn) for (int k = 0; k < nseg; ++k) maxrows = std::max(maxrows, 3 * seg_nn[k]);
@@ -1303,40 +1280,170 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
                 int J = I;
                 while (J < I0 + nbr && m->h_bp[J + 1] - q0 <= CGR_CB && J - I < maxbr) ++J;
                 if (J == I) { ok = false; break; }       // a block row longer than a chunk
-                rcd.push_back(make_int4(I, J - I, q0, m->h_bp[J] - q0));
+                P.rcd.push_back(make_int4(I, J - I, q0, m->h_bp[J] - q0));
                 I = J;
             }
-            rcfirst.push_back((int)rcd.size());
+            P.rcfirst.push_back((int)P.rcd.size());
         };
         if (seg_nn) for (int k = 0; k < nseg && ok; ++k) chunks_of(m->seg_node0[k], seg_nn[k]);
         else if (ok) chunks_of(0, m->ndof / 3);
         ok = ok && maxrows > 0 && maxrows <= (big ? CGR_MAXROWS_BIG : CGR_MAXROWS) && lds <= 160 * 1024;
-        m->cgr_big = big;
-        if (ok) {
-            if (dalloc(&m->d_rcd, rcd.size()) || dalloc(&m->d_rcfirst, rcfirst.size())) { fem_free(m); delete m; ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed"); }
-            ORBX_HIP(hipMemcpy(m->d_rcd, rcd.data(), sizeof(int4) * rcd.size(), hipMemcpyHostToDevice));
-            ORBX_HIP(hipMemcpy(m->d_rcfirst, rcfirst.data(), sizeof(int) * rcfirst.size(), hipMemcpyHostToDevice));
-            ORBX_HIP(hipFuncSetAttribute(big ? reinterpret_cast<const void *>(k_fem_cg_resident<true>) : reinterpret_cast<const void *>(k_fem_cg_resident<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            m->cg_resident = true; m->cgr_lds = (int)lds; m->cgr_ldn = maxrows;
-        }
+        P.resident = ok; P.big = big; P.resident_lds = lds; P.maxrows = maxrows;
     }
-    ORBX_HIP(hipMemcpy(m->d_diag, m->h_diag.data(), sizeof(int) * m->ndof, hipMemcpyHostToDevice));
+    return ORBX_OK;
+}
+
+// Model construction: plan on the host, then ONE device block for all tables and the node coordinates, filled through ONE
+// pinned staging block by ONE copy on the model's stream (the first version issued about twenty blocking pageable copies;
+// the reference builds a new mesh on every PoseOptimizationNR call, Optimizer.cc:480, so this is per-frame work).
+int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, const int32_t *elems, int ne, unsigned int E, float nu,
+                 float fg, Symbolic &y, int nseg, const int *seg_nn, const int *seg_ne, fem_model **out)
+{
+    fem_model *m = new fem_model();
+    HostPlan P;
+    int rc = plan_model(m, eltype, npe, nmesh, nn, ne, E, nu, fg, y, nseg, seg_nn, seg_ne, P);
+    if (rc != ORBX_OK) { delete m; return rc; }
+    const int nblk = m->nblk;
+    const size_t M = (size_t)nmesh;
+    m->cgr_big = P.big;
+
+    // layout of the table block: 256-byte aligned pieces
+    struct Piece { void **dst; const void *src; size_t bytes, room, off; };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    auto piece = [&](auto **dst, const void *src, size_t bytes, size_t room = 0) {
+        room = std::max(room, bytes);
+        pieces.push_back(Piece{reinterpret_cast<void **>(dst), src, bytes, room, total});
+        total += (std::max(room, (size_t)1) + 255) & ~(size_t)255;
+    };
+    piece(&m->d_nodes, nodes, sizeof(float) * M * nn * 3);
+    piece(&m->d_elems, elems, sizeof(int) * (size_t)ne * npe);
+    piece(&m->d_blk_row, y.blk_row.data(), sizeof(int) * (size_t)nblk);
+    piece(&m->d_bptr, y.bptr.data(), sizeof(int) * ((size_t)nn + 1));
+    piece(&m->d_cptr, y.cptr.data(), sizeof(int) * ((size_t)nblk + 1));
+    piece(&m->d_contrib, y.contrib.data(), sizeof(int) * y.contrib.size());
+    if (m->fused_lds) {
+        piece(&m->d_nel_ptr, y.nel_ptr.data(), sizeof(int) * ((size_t)nn + 1));
+        piece(&m->d_nel, y.nel.data(), sizeof(int) * y.nel.size());
+        piece(&m->d_contrib_loc, y.contrib_loc.data(), sizeof(int) * y.contrib_loc.size());
+    }
+    piece(&m->d_rowptr, m->h_rowptr.data(), sizeof(int) * ((size_t)m->ndof + 1));
+    piece(&m->d_lcol, m->h_lcol.data(), sizeof(int) * m->nnz, sizeof(int) * m->nnzs);   // the padding tail is read by the SpMV's last quad: zeros = valid columns
+    piece(&m->d_diag, m->h_diag.data(), sizeof(int) * (size_t)m->ndof);
+    piece(&m->d_bcol3, P.bcol3.data(), sizeof(int) * P.bcol3.size(), sizeof(int) * (P.bcol3.size() + 1));
+    piece(&m->d_bp, P.bp.data(), sizeof(int) * P.bp.size(), sizeof(int) * (P.bp.size() + 1));
     if (seg_nn) {
-        ORBX_HIP(hipMemcpy(m->d_cmesh, cmesh.data(), sizeof(int) * cmesh.size(), hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(m->d_cmesh_s, cmesh_s.data(), sizeof(int) * cmesh_s.size(), hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(m->d_minfo, minfo.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(m->d_minfo_s, minfo_s.data(), sizeof(int4) * nseg, hipMemcpyHostToDevice));
+        piece(&m->d_cmesh, P.cmesh.data(), sizeof(int) * P.cmesh.size());
+        piece(&m->d_cmesh_s, P.cmesh_s.data(), sizeof(int) * P.cmesh_s.size());
+        piece(&m->d_minfo, P.minfo.data(), sizeof(int4) * (size_t)nseg);
+        piece(&m->d_minfo_s, P.minfo_s.data(), sizeof(int4) * (size_t)nseg);
     }
+    if (P.resident) {
+        piece(&m->d_rcd, P.rcd.data(), sizeof(int4) * P.rcd.size());
+        piece(&m->d_rcfirst, P.rcfirst.data(), sizeof(int) * P.rcfirst.size());
+    }
+
+    int bad = 0;
+    bad |= dalloc(&m->d_tables, total) | dalloc(&m->d_ke1, (size_t)m->nd * m->nd);
+    if (!m->fused_lds) bad |= dalloc(&m->d_ke, M * ne * m->nd * m->nd);
+    bad |= dalloc(&m->d_vals, M * m->nnzs);
+    char *stage = bad ? nullptr : static_cast<char *>(g_pin_cache.get(total));
+    if (bad || !stage || !(m->stream = stream_get())) {
+        g_pin_cache.put(stage);
+        fem_free(m); delete m;
+        ORBX_FAIL(ORBX_ERR_HIP, "device allocation failed");
+    }
+    for (const Piece &pc : pieces) {
+        *pc.dst = m->d_tables + pc.off;
+        if (pc.bytes) memcpy(stage + pc.off, pc.src, pc.bytes);
+        if (pc.room > pc.bytes) memset(stage + pc.off + pc.bytes, 0, pc.room - pc.bytes);
+    }
+    hipError_t e = hipMemcpyAsync(m->d_tables, stage, total, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);   // the staging block goes back to the cache
+    g_pin_cache.put(stage);
+    if (e == hipSuccess && P.resident)
+        e = hipFuncSetAttribute(P.big ? reinterpret_cast<const void *>(k_fem_cg_resident<true>) : reinterpret_cast<const void *>(k_fem_cg_resident<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
+    if (e == hipSuccess && m->spmv_lds > 48 * 1024)
+        for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
+                               reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds);
+    if (e != hipSuccess) {
+        fem_free(m); delete m;
+        return orbx::set_error(ORBX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
+    }
+    if (P.resident) { m->cg_resident = true; m->cgr_lds = (int)P.resident_lds; m->cgr_ldn = P.maxrows; }
     static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
     for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
     if (m->nseg >= CGS_MIN_MESHES) { m->prof.names[3] = "k_fem_cg_step"; m->prof.names[4] = nullptr; }   // one launch does both
     if (m->cg_resident) m->prof.names[5] = "k_fem_cg_resident";
-    if (m->spmv_lds > 48 * 1024)
-        for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
-                               reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
-            ORBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, m->spmv_lds));
     *out = m;
+    return ORBX_OK;
+}
+
+// The symbolic phase of a batch of meshes with their own topologies: per mesh (independent: a few host threads), then
+// concatenated in global node / element / dof / non-zero numbering.  gelems receives the elements in global node ids.
+int build_symbolic_batch(int npe, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const int32_t *elems,
+                         const std::vector<long long> &node0, const std::vector<long long> &elem0, Symbolic &y, std::vector<int32_t> &gelems)
+{
+    std::vector<Symbolic> ys(nmesh);
+    {
+        const int nthr = std::max(1, std::min(nmesh, std::min(16, (int)std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t)
+            pool.emplace_back([&, t]() {
+                for (int k = t; k < nmesh; k += nthr) build_symbolic(npe, mesh_nn[k], mesh_ne[k], elems + elem0[k] * npe, ys[k]);
+            });
+        for (std::thread &th : pool) th.join();
+    }
+    gelems.assign((size_t)elem0[nmesh] * npe, 0);
+    y.bptr.assign(1, 0);
+    y.cptr.assign(1, 0);
+    y.rowptr.clear();
+    long long blk0 = 0;
+    for (int k = 0; k < nmesh; ++k) {
+        const Symbolic &z = ys[k];
+        const int nd0 = (int)node0[k], el0 = (int)elem0[k], nz0 = (int)(9 * blk0), c0 = y.cptr.back();
+        if (9 * (blk0 + z.nblk) >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 non-zeros");
+        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i) gelems[i] = elems[i] + nd0;
+        for (int v : z.blk_row) y.blk_row.push_back(v + nd0);
+        for (size_t i = 1; i < z.bptr.size(); ++i) y.bptr.push_back(z.bptr[i] + (int)blk0);
+        for (size_t i = 1; i < z.cptr.size(); ++i) y.cptr.push_back(z.cptr[i] + c0);
+        for (int v : z.contrib) y.contrib.push_back(v + (el0 << 6));
+        y.contrib_loc.insert(y.contrib_loc.end(), z.contrib_loc.begin(), z.contrib_loc.end());   // local element numbers: unchanged
+        {
+            const int n0 = y.nel_ptr.empty() ? 0 : y.nel_ptr.back();
+            if (y.nel_ptr.empty()) y.nel_ptr.push_back(0);
+            for (size_t i = 1; i < z.nel_ptr.size(); ++i) y.nel_ptr.push_back(z.nel_ptr[i] + n0);
+            for (int v : z.nel) y.nel.push_back(v + el0);
+            y.maxel = std::max(y.maxel, z.maxel);
+        }
+        for (size_t i = 0; i + 1 < z.rowptr.size(); ++i) y.rowptr.push_back(z.rowptr[i] + nz0);
+        for (int v : z.lcol) y.lcol.push_back(v + 3 * nd0);
+        for (int v : z.diag) y.diag.push_back(v + nz0);
+        blk0 += z.nblk;
+    }
+    y.rowptr.push_back((int)(9 * blk0));
+    y.nblk = (int)blk0;
+    return ORBX_OK;
+}
+
+// argument checks shared by fem_create_batch and fem_plan
+int check_batch(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const int32_t *elems, int &npe,
+                std::vector<long long> &node0, std::vector<long long> &elem0)
+{
+    npe = eltype == FEM_C3D8 ? 8 : eltype == FEM_C3D6 ? 6 : eltype == FEM_TET4 ? 4 : 0;
+    if (!npe) ORBX_FAIL(ORBX_ERR_ARG, "unknown element type");
+    node0.assign(nmesh + 1, 0); elem0.assign(nmesh + 1, 0);
+    for (int k = 0; k < nmesh; ++k) {
+        if (mesh_nn[k] < 2 || mesh_ne[k] < 0) ORBX_FAIL(ORBX_ERR_ARG, "mesh with fewer than two nodes (FEA2.cc:1386: assembly refuses Ksize <= 3)");
+        node0[k + 1] = node0[k] + mesh_nn[k]; elem0[k + 1] = elem0[k] + mesh_ne[k];
+    }
+    if (elem0[nmesh] >= (1ll << 25)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "too many elements");
+    if (3 * node0[nmesh] >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 dofs");
+    for (int k = 0; k < nmesh; ++k)
+        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i)
+            if (elems[i] < 0 || elems[i] >= mesh_nn[k]) ORBX_FAIL(ORBX_ERR_ARG, "element node id out of range");
     return ORBX_OK;
 }
 
@@ -1375,63 +1482,58 @@ int fem_create_batch(int eltype, int nmesh, const int32_t *mesh_nn, const int32_
                      unsigned int E, float nu, float fg, fem_model **out)
 {
     if (!nodes || !elems || !out || !mesh_nn || !mesh_ne || nmesh < 1) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
-    const int npe = eltype == FEM_C3D8 ? 8 : eltype == FEM_C3D6 ? 6 : eltype == FEM_TET4 ? 4 : 0;
-    if (!npe) ORBX_FAIL(ORBX_ERR_ARG, "unknown element type");
-    std::vector<long long> node0(nmesh + 1, 0), elem0(nmesh + 1, 0);
-    for (int k = 0; k < nmesh; ++k) {
-        if (mesh_nn[k] < 2 || mesh_ne[k] < 0) ORBX_FAIL(ORBX_ERR_ARG, "mesh with fewer than two nodes (FEA2.cc:1386: assembly refuses Ksize <= 3)");
-        node0[k + 1] = node0[k] + mesh_nn[k]; elem0[k + 1] = elem0[k] + mesh_ne[k];
-    }
-    const long long nn = node0[nmesh], ne = elem0[nmesh];
-    if (ne >= (1ll << 25)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "too many elements");
-    if (3 * nn >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 dofs");
-    for (int k = 0; k < nmesh; ++k)
-        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i)
-            if (elems[i] < 0 || elems[i] >= mesh_nn[k]) ORBX_FAIL(ORBX_ERR_ARG, "element node id out of range");
+    int npe = 0;
+    std::vector<long long> node0, elem0;
+    int rc = check_batch(eltype, nmesh, mesh_nn, mesh_ne, elems, npe, node0, elem0);
+    if (rc != ORBX_OK) return rc;
     ORBX_NEED_DEVICE();
-    // symbolic phase per mesh (independent: a few host threads), then concatenation in global numbering
-    std::vector<Symbolic> ys(nmesh);
-    {
-        const int nthr = std::max(1, std::min(nmesh, std::min(16, (int)std::thread::hardware_concurrency())));
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthr; ++t)
-            pool.emplace_back([&, t]() {
-                for (int k = t; k < nmesh; k += nthr) build_symbolic(npe, mesh_nn[k], mesh_ne[k], elems + elem0[k] * npe, ys[k]);
-            });
-        for (std::thread &th : pool) th.join();
-    }
     Symbolic y;
-    std::vector<int32_t> gelems((size_t)ne * npe);
-    y.bptr.assign(1, 0);
-    y.cptr.assign(1, 0);
-    y.rowptr.clear();
-    long long blk0 = 0;
-    for (int k = 0; k < nmesh; ++k) {
-        const Symbolic &z = ys[k];
-        const int nd0 = (int)node0[k], el0 = (int)elem0[k], nz0 = (int)(9 * blk0), c0 = y.cptr.back();
-        if (9 * (blk0 + z.nblk) >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 non-zeros");
-        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i) gelems[i] = elems[i] + nd0;
-        for (int v : z.blk_row) y.blk_row.push_back(v + nd0);
-        for (size_t i = 1; i < z.bptr.size(); ++i) y.bptr.push_back(z.bptr[i] + (int)blk0);
-        for (size_t i = 1; i < z.cptr.size(); ++i) y.cptr.push_back(z.cptr[i] + c0);
-        for (int v : z.contrib) y.contrib.push_back(v + (el0 << 6));
-        y.contrib_loc.insert(y.contrib_loc.end(), z.contrib_loc.begin(), z.contrib_loc.end());   // local element numbers: unchanged
-        {
-            const int n0 = y.nel_ptr.empty() ? 0 : y.nel_ptr.back();
-            if (y.nel_ptr.empty()) y.nel_ptr.push_back(0);
-            for (size_t i = 1; i < z.nel_ptr.size(); ++i) y.nel_ptr.push_back(z.nel_ptr[i] + n0);
-            for (int v : z.nel) y.nel.push_back(v + el0);
-            y.maxel = std::max(y.maxel, z.maxel);
-        }
-        for (size_t i = 0; i + 1 < z.rowptr.size(); ++i) y.rowptr.push_back(z.rowptr[i] + nz0);
-        for (int v : z.lcol) y.lcol.push_back(v + 3 * nd0);
-        for (int v : z.diag) y.diag.push_back(v + nz0);
-        blk0 += z.nblk;
-    }
-    y.rowptr.push_back((int)(9 * blk0));
-    y.nblk = (int)blk0;
+    std::vector<int32_t> gelems;
+    rc = build_symbolic_batch(npe, nmesh, mesh_nn, mesh_ne, elems, node0, elem0, y, gelems);
+    if (rc != ORBX_OK) return rc;
     std::vector<int> snn(mesh_nn, mesh_nn + nmesh), sne(mesh_ne, mesh_ne + nmesh);
-    return create_model(eltype, npe, nodes, 1, (int)nn, gelems.data(), (int)ne, E, nu, fg, y, nmesh, snn.data(), sne.data(), out);
+    return create_model(eltype, npe, nodes, 1, (int)node0[nmesh], gelems.data(), (int)elem0[nmesh], E, nu, fg, y, nmesh, snn.data(), sne.data(), out);
+}
+
+int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const int32_t *elems, int uniform_copies,
+             fem_plan_info *info, int32_t *rowptr, int32_t *lcol, int32_t *diag, int32_t *bp, int32_t *bcol3, int32_t *rcd, int32_t *rcfirst,
+             int32_t *chunk_mesh)
+{
+    if (!elems || !mesh_nn || !mesh_ne || !info || nmesh < 1 || uniform_copies < 0 || (uniform_copies && nmesh != 1))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    int npe = 0;
+    std::vector<long long> node0, elem0;
+    int rc = check_batch(eltype, nmesh, mesh_nn, mesh_ne, elems, npe, node0, elem0);
+    if (rc != ORBX_OK) return rc;
+    fem_model m;
+    HostPlan P;
+    Symbolic y;
+    if (uniform_copies) {     // fem_create's layout: `uniform_copies` meshes sharing the one topology
+        if ((long long)uniform_copies * 3 * mesh_nn[0] >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 dofs");
+        build_symbolic(npe, mesh_nn[0], mesh_ne[0], elems, y);
+        rc = plan_model(&m, eltype, npe, uniform_copies, mesh_nn[0], mesh_ne[0], 3500, 0.495f, 0.577350269f, y, 0, nullptr, nullptr, P);
+    } else {                  // fem_create_batch's
+        std::vector<int32_t> gelems;
+        rc = build_symbolic_batch(npe, nmesh, mesh_nn, mesh_ne, elems, node0, elem0, y, gelems);
+        if (rc != ORBX_OK) return rc;
+        std::vector<int> snn(mesh_nn, mesh_nn + nmesh), sne(mesh_ne, mesh_ne + nmesh);
+        rc = plan_model(&m, eltype, npe, 1, (int)node0[nmesh], (int)elem0[nmesh], 3500, 0.495f, 0.577350269f, y, nmesh, snn.data(), sne.data(), P);
+    }
+    if (rc != ORBX_OK) return rc;
+    memset(info, 0, sizeof(*info));
+    info->ndof = m.ndof; info->nblk = m.nblk; info->nnz = (int64_t)m.nnz; info->spb = m.spb; info->spmv_lds = m.spmv_lds;
+    info->fused_lds = m.fused_lds; info->nchunk_tot = m.nchunk_tot; info->nchunk_s_tot = m.nchunk_s_tot;
+    info->resident = P.resident ? 1 : 0; info->resident_big = P.big ? 1 : 0; info->resident_lds = (int32_t)P.resident_lds;
+    info->nrcd = P.resident ? (int32_t)P.rcd.size() : 0; info->ncontrib = (int64_t)y.contrib.size(); info->maxel = y.maxel;
+    if (rowptr) memcpy(rowptr, m.h_rowptr.data(), sizeof(int) * m.h_rowptr.size());
+    if (lcol) memcpy(lcol, m.h_lcol.data(), sizeof(int) * m.h_lcol.size());
+    if (diag) memcpy(diag, m.h_diag.data(), sizeof(int) * m.h_diag.size());
+    if (bp) memcpy(bp, P.bp.data(), sizeof(int) * P.bp.size());
+    if (bcol3) memcpy(bcol3, P.bcol3.data(), sizeof(int) * P.bcol3.size());
+    if (rcd && P.resident) memcpy(rcd, P.rcd.data(), sizeof(int4) * P.rcd.size());
+    if (rcfirst && P.resident) memcpy(rcfirst, P.rcfirst.data(), sizeof(int) * P.rcfirst.size());
+    if (chunk_mesh && !uniform_copies) memcpy(chunk_mesh, P.cmesh.data(), sizeof(int) * P.cmesh.size());
+    return ORBX_OK;
 }
 
 int fem_batch_offsets(const fem_model *m, int32_t *node0, int32_t *elem0, int32_t *nnz0)

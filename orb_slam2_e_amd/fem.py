@@ -248,3 +248,33 @@ class FEA2Batch(FEA2):
 
     def trial_setup(self, *a, **k):
         raise NotImplementedError("the LM hook works on one mesh per model")
+
+
+class _PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("ndof", "nblk", "spb", "spmv_lds", "fused_lds", "nchunk_tot", "nchunk_s_tot", "resident",
+                                         "resident_big", "resident_lds", "nrcd", "maxel")] + [("nnz", C.c_int64), ("ncontrib", C.c_int64)]
+
+
+def plan(elems_list, nn_list, nElType, uniform_copies=0):
+    """fem_plan: the host-side planning of fem_create (uniform_copies > 0, one mesh) / fem_create_batch (0) without any
+    device call.  Returns a dict: the info fields + rowptr, lcol, diag, bp, bcol3, rcd[nrcd, 4], rcfirst, chunk_mesh."""
+    L = lib()
+    npe = _NPE[nElType]
+    elems_list = [np.ascontiguousarray(e, np.int32).reshape(-1, npe) for e in elems_list]
+    nn = np.ascontiguousarray(nn_list, np.int32); ne = np.array([len(e) for e in elems_list], np.int32)
+    elems = np.ascontiguousarray(np.concatenate(elems_list), np.int32) if len(elems_list) else np.zeros((0, npe), np.int32)
+    L.fem_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 8
+    info = _PlanInfo()
+    args = (nElType, len(nn), _p(nn), _p(ne), _p(elems), int(uniform_copies))
+    check(L.fem_plan(*args, C.byref(info), *([None] * 8)))
+    out = {n: getattr(info, n) for n, _ in _PlanInfo._fields_}
+    nmesh = uniform_copies if uniform_copies else len(nn)
+    arr = {"rowptr": np.zeros(info.ndof + 1, np.int32), "lcol": np.zeros(info.nnz, np.int32), "diag": np.zeros(info.ndof, np.int32),
+           "bp": np.zeros(info.ndof // 3 + 1, np.int32), "bcol3": np.zeros(info.nnz // 9, np.int32),
+           "rcd": np.zeros((max(info.nrcd, 1), 4), np.int32), "rcfirst": np.zeros((1 if uniform_copies else len(nn)) + 1, np.int32),
+           "chunk_mesh": np.zeros(max(info.nchunk_tot, 1), np.int32)}
+    check(L.fem_plan(*args, C.byref(info), *[_p(arr[k]) for k in ("rowptr", "lcol", "diag", "bp", "bcol3", "rcd", "rcfirst", "chunk_mesh")]))
+    arr["rcd"] = arr["rcd"][:info.nrcd]
+    out.update(arr)
+    out["nmesh"] = nmesh
+    return out

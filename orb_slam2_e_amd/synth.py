@@ -128,6 +128,23 @@ def synth_tet_mesh(ncell=12, seed=11, jitter=0.1):
     return nodes.astype(np.float32), tets.astype(np.int32), fixed.astype(np.int32), load
 
 
+def synth_tet_chain(nn, seed=5):
+    """A mesh with exactly `nn` nodes (any nn >= 4): nodes on a helix, tets (i, i+1, i+2, i+3) -- a banded matrix of 7 node
+    blocks per row; for probing size limits that grids cannot hit.  Returns nodes, tets (positively oriented), fixed dofs
+    (the first three nodes), load (unit pull on the last node)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(nn) * 0.9
+    nodes = np.stack([np.cos(t), np.sin(t), 0.35 * t], 1) + rng.uniform(-0.02, 0.02, (nn, 3))
+    tets = np.stack([np.arange(nn - 3) + k for k in range(4)], 1)
+    p = nodes[tets]
+    vol = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0])
+    flip = vol < 0
+    tets[flip] = tets[flip][:, [1, 0, 2, 3]]
+    fixed = np.arange(9, dtype=np.int32)
+    load = np.zeros(3 * nn); load[-1] = 1.0
+    return nodes.astype(np.float32), tets.astype(np.int32), fixed, load
+
+
 def synth_tet_batch(nmesh, ncell=12, seed=11):
     """nmesh meshes sharing the Kuhn topology, each with its own jitter (distinct matrices)."""
     base, tets, fixed, load = synth_tet_mesh(ncell, seed)

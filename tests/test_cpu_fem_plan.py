@@ -1,0 +1,128 @@
+"""The host half of fem_create / fem_create_batch (symbolic CSR of 3 x 3 node blocks, chunk tables, the resident CG's
+chunk table) through fem_plan -- no device call, so it runs without a GPU (and, rebuilt host-only under ASan / UBSan by
+tools/asan_host.sh, is what the sanitizers see).  The pattern is checked against a numpy construction from the element
+list (MatrixAssemblyC3D8/6's scatter, FEA2.cc:1379-1624: entry (3 I + r, 3 J + c) exists iff nodes I, J share an element)."""
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_e_amd.fem import FEM_C3D6, FEM_C3D8, FEM_TET4, extrude_elems, plan
+from orb_slam2_e_amd.synth import synth_tet_batch_distinct, synth_tet_mesh
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _pattern(elems, nn):
+    """rowptr, lcol of the block pattern: node I's neighbours = itself + all nodes sharing an element, ascending."""
+    nbr = [set([i]) for i in range(nn)]
+    for e in elems:
+        for a in e:
+            nbr[a].update(int(b) for b in e)
+    rowptr, lcol = [0], []
+    for i in range(nn):
+        cols = [3 * j + c for j in sorted(nbr[i]) for c in range(3)]
+        for r in range(3):
+            lcol += cols
+            rowptr.append(len(lcol))
+    return np.array(rowptr, np.int32), np.array(lcol, np.int32)
+
+
+def _check_tables(p, rowptr, lcol, mesh_rows):
+    assert p["ndof"] == len(rowptr) - 1 and p["nnz"] == len(lcol) == 9 * p["nblk"]
+    assert np.array_equal(p["rowptr"], rowptr) and np.array_equal(p["lcol"], lcol)
+    rows = np.arange(p["ndof"])
+    assert np.array_equal(p["lcol"][p["diag"]], rows)                       # every row's diagonal position
+    assert np.all((p["diag"] >= rowptr[:-1]) & (p["diag"] < rowptr[1:]))
+    # node-block tables: bp = blocks before a block row, bcol3 = a block's first column
+    nb = np.diff(rowptr)[0::3] // 3
+    assert np.array_equal(p["bp"], np.concatenate([[0], np.cumsum(nb)]))
+    first = np.concatenate([lcol[rowptr[3 * i]:rowptr[3 * i + 1]:3] for i in range(p["ndof"] // 3)])
+    assert np.array_equal(p["bcol3"], first)
+    # chunks of the resident CG: every block row of every mesh exactly once, in order, at most 256 blocks per chunk
+    if p["resident"]:
+        rcd, rcf = p["rcd"], p["rcfirst"]
+        assert rcf[0] == 0 and rcf[-1] == len(rcd) and len(rcf) == len(mesh_rows) + 1
+        for k, (row0, nrows) in enumerate(mesh_rows):
+            c = rcd[rcf[k]:rcf[k + 1]]
+            assert c[0, 0] == row0 // 3 and c[-1, 0] + c[-1, 1] == (row0 + nrows) // 3
+            assert np.array_equal(c[1:, 0], c[:-1, 0] + c[:-1, 1])
+            assert np.array_equal(c[:, 2], p["bp"][c[:, 0]]) and np.array_equal(c[:, 2] + c[:, 3], p["bp"][c[:, 0] + c[:, 1]])
+            assert c[:, 3].max() <= 256 and c[:, 1].min() >= 1 and c[:, 1].max() <= (21 if p["resident_big"] else 63)
+    else:
+        assert p["nrcd"] == 0
+
+
+@pytest.mark.parametrize("name,eltype", [("min", FEM_C3D6), ("median", FEM_C3D6), ("p90", FEM_C3D6), ("median", FEM_C3D8)])
+def test_plan_of_the_references_own_meshes(name, eltype):
+    m = np.load(os.path.join(GOLD, f"fem_mesh_{name}.npz"))
+    top, tris = m["points"], m["triangles"]
+    if eltype == FEM_C3D8:
+        faces = np.array([[a, b, c, a] for a, b, c in tris], np.int32)      # degenerate quads: repeated node ids in an element
+    else:
+        faces = tris
+    elems = extrude_elems(faces, len(top))
+    nn = 2 * len(top)
+    p = plan([elems], [nn], eltype, uniform_copies=1)
+    rowptr, lcol = _pattern(elems, nn)
+    _check_tables(p, rowptr, lcol, [(0, 3 * nn)])
+    assert not p["resident"] and p["nchunk_tot"] == (3 * nn + 255) // 256
+    assert p["ncontrib"] == len(elems) * elems.shape[1] ** 2 and p["fused_lds"] > 0
+    p64 = plan([elems], [nn], eltype, uniform_copies=64)                       # 64 copies: one compute unit each
+    assert p64["resident"] and not p64["resident_big"] and p64["nchunk_tot"] == 64 * p["nchunk_tot"]
+    _check_tables(p64, rowptr, lcol, [(0, 3 * nn)])
+
+
+def test_plan_of_config3_and_the_lds_limits():
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
+    p = plan([tets], [len(nodes)], FEM_TET4, uniform_copies=256)
+    assert (p["ndof"], p["nnz"]) == (6591, 261477) and p["resident"] and not p["resident_big"]
+    rowptr, lcol = _pattern(tets, len(nodes))
+    _check_tables(p, rowptr, lcol, [(0, 6591)])
+    # (2 n + 3 * 8 * 256 + 48) * 8 <= 160 KB with p and Ap in LDS, n + ... with p alone: the documented limits
+    for ncell, resident, big in ((13, True, True), (15, True, True), (16, False, True)):
+        nd, tt, _, _ = synth_tet_mesh(ncell=ncell)
+        q = plan([tt], [len(nd)], FEM_TET4, uniform_copies=64)
+        assert (bool(q["resident"]), bool(q["resident_big"])) == (resident, big), (ncell, q["ndof"])
+        assert not resident or q["resident_lds"] <= 160 * 1024
+    assert not plan([tets], [len(nodes)], FEM_TET4, uniform_copies=63)["resident"]      # fewer than 64 meshes: launch per phase
+
+
+@pytest.mark.parametrize("nn,resident", [(4762, True), (4763, False)])
+def test_resident_limit_is_the_lds_formula(nn, resident):
+    """include/fem_hip.h: at most 14,288 dofs per mesh on a compute unit, (n + 6,192) x 8 B <= 160 KB -- 14,286 dofs
+    (4,762 nodes) run resident with p alone in LDS, 14,289 dofs take the launch-per-phase path."""
+    from orb_slam2_e_amd.synth import synth_tet_chain
+    nodes, tets, fixed, load = synth_tet_chain(nn)
+    q = plan([tets], [nn], FEM_TET4, uniform_copies=64)
+    assert bool(q["resident"]) == resident and q["ndof"] == 3 * nn
+    if resident:
+        assert q["resident_big"] and q["resident_lds"] == (3 * nn + 3 * 8 * 256 + 48) * 8 <= 160 * 1024
+
+
+def test_plan_of_a_batch_with_its_own_topologies():
+    nodes_l, tets_l, _, _ = synth_tet_batch_distinct(70, base=4)
+    nn = [len(n) for n in nodes_l]
+    p = plan(tets_l, nn, FEM_TET4)
+    rps, lcs, rows, off = [np.zeros(1, np.int32)], [], [], 0
+    for t, n in zip(tets_l, nn):
+        rp, lc = _pattern(t, n)
+        rps.append(rp[1:] + rps[-1][-1]); lcs.append(lc + 3 * off); rows.append((3 * off, 3 * n)); off += n
+    _check_tables(p, np.concatenate(rps), np.concatenate(lcs), rows)
+    assert p["resident"]
+    # a chunk of the vector kernels never crosses a mesh
+    cm = p["chunk_mesh"]
+    assert len(cm) == p["nchunk_tot"] == sum((3 * n + 255) // 256 for n in nn)
+    assert np.array_equal(cm, np.repeat(np.arange(70), [(3 * n + 255) // 256 for n in nn]))
+
+
+def test_plan_rejects_what_create_rejects():
+    from orb_slam2_e_amd import OrbxError
+    with pytest.raises(OrbxError):
+        plan([np.array([[0, 1, 2, 9]], np.int32)], [4], FEM_TET4, uniform_copies=1)        # node id out of range
+    with pytest.raises(OrbxError):
+        plan([np.zeros((0, 4), np.int32)], [1], FEM_TET4, uniform_copies=1)                 # Ksize <= 3
+    with pytest.raises(OrbxError):
+        plan([np.array([[0, 1, 2, 3]], np.int32)] * 2, [4, 4], FEM_TET4, uniform_copies=2)  # copies only of ONE mesh
+    p = plan([np.zeros((0, 4), np.int32)], [5], FEM_TET4, uniform_copies=1)                 # no elements: the identity pattern
+    assert p["nnz"] == 45 and np.array_equal(p["lcol"].reshape(5, 3, 3)[:, 0, :], np.arange(15).reshape(5, 3))

@@ -571,3 +571,29 @@ def test_pose_optimization_nr_fem_sequence(name, nder, tmp_path):
     for fld in ("tempChi", "currentChi", "lam"):
         assert np.all(np.abs(got[fld][ok] - ref[fld][ok]) <= RTOL * np.abs(ref[fld][ok])), fld
     assert np.all(np.abs(got["rho"][ok] - ref["rho"][ok]) <= 1e-4 * np.maximum(np.abs(ref["rho"][ok]), 1e-2))
+
+
+@pytest.mark.parametrize("nn,resident", [(4762, True), (4763, False)])
+def test_resident_cg_at_the_lds_boundary(nn, resident):
+    """The documented limit of the compute-unit-resident CG (include/fem_hip.h: 14,288 dofs = what 160 KB of LDS hold
+    beside the staging slices): 64 meshes of 14,286 dofs run in k_fem_cg_resident, 64 of 14,289 launch phase by phase --
+    which kernels ran is read from the profiler's names -- and both give the oracle's iterate."""
+    from orb_slam2_e_amd.synth import synth_tet_chain
+    nm, iters = 64, 30
+    base, tets, fixed, load = synth_tet_chain(nn)
+    nodes = np.stack([synth_tet_chain(nn, seed=5 + m)[0] for m in range(nm)])
+    fea = FEA2(nodes, tets, FEM_TET4)
+    assert fea.Ksize == 3 * nn
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    b = np.tile(load, (nm, 1)); b[:, fixed] = 0
+    fea.profile(True)
+    fea.cg_setup(b); fea.cg_iterate(iters)
+    x, rel = fea.cg_result()
+    prof = fea.profile_read()
+    ran_resident = bool(prof.get("k_fem_cg_resident", (0, 0))[1])
+    assert ran_resident == resident and bool(prof["k_fem_spmv"][1]) == (not resident)
+    for m in (0, nm - 1):
+        rp, col, val = fea.csr(m)
+        ox, _, orel = oracle.fem_cg(rp, col, val, b[m], iters, 0.0)
+        assert np.abs(x[m] - ox).max() <= RTOL * np.abs(ox).max(), m
