@@ -359,6 +359,14 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
                          int32_t *best_dev, int32_t *second_dev, int32_t *idx_dev,
                          int32_t *match12_dev, int32_t *nmatch_dev, void *stream);
 
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:245-260, PosInGrid :397-407) as the whole-loop searches lay a frame out: the
+ * keypoints that fall inside the 64 x 48 grid (and are not skipped), ordered by (cell = col * 48 + row, keypoint index) --
+ * the order in which GetFeaturesInArea visits a window.  Host only, no device call (introspection / test aid: the CPU
+ * tests and the host sanitizer build check the counting sort through it).  perm[n] (first *nsorted entries valid),
+ * cell_off[64 * 48 + 1]; both may be NULL. */
+int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
+                      float max_x, float max_y, int32_t *perm, int32_t *cell_off, int32_t *nsorted);
+
 /* Which kernel the all-pairs matchers (orbm_match_batch_dev, orbm_match_bruteforce) launch.  Both produce the same
  * integers.  ORBM_ALLPAIRS_AUTO (default): the matrix-core kernel (FP4 MFMA computes the selection keys, 3.5x
  * faster at 2000 x 2000) for sets up to 32768 rows, the XOR + popcount kernel above that; ORBM_ALLPAIRS_POPCOUNT:

@@ -223,6 +223,13 @@ class Grid:
             self.L.oracle_grid_free(self.h)
             self.h = None
 
+    def tables(self):
+        """(cell_off[64 * 48 + 1], keypoint indices cell by cell): mGrid flattened."""
+        off = np.zeros(64 * 48 + 1, np.int32); items = np.zeros(max(len(self.xy), 1), np.int32)
+        self.L.oracle_grid_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.oracle_grid_tables(self.h, _p(off), _p(items))
+        return off, items[:off[-1]].copy()
+
     def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
         out = np.zeros(len(self.xy) + 1, np.int32)
         n = self.L.oracle_grid_features_in_area(self.h, _p(self.xy), _p(self.octave), x, y, r,

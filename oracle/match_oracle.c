@@ -156,6 +156,13 @@ oracle_grid *oracle_grid_build(const float *xy, int n, float minX, float minY, f
     free(cnt); free(cell);
     return g;
 }
+/* mGrid as flat tables: cell_off[COLS*ROWS + 1] and the keypoint indices cell by cell (col * ROWS + row), insertion order inside a cell */
+void oracle_grid_tables(const oracle_grid *g, int *cell_off, int *items)
+{
+    const int NC = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    memcpy(cell_off, g->cell_off, sizeof(int) * (NC + 1));
+    if (g->cell_off[NC]) memcpy(items, g->cell_items, sizeof(int) * g->cell_off[NC]);
+}
 void oracle_grid_free(oracle_grid *g) { if (g) { free(g->cell_off); free(g->cell_items); free(g); } }
 
 /* Frame::GetFeaturesInArea, Frame.cc:342-395.  Result order: column-major

@@ -43,10 +43,12 @@ def _one_hip_runtime():
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(SO_PATH):
+        # ORBX_LIB: another build of the SAME sources (tools/asan_host.sh: the host-only ASan / UBSan build)
+        path = os.environ.get("ORBX_LIB") or SO_PATH
+        if path == SO_PATH and not os.path.exists(SO_PATH):
             build()
         _one_hip_runtime()
-        _LIB = C.CDLL(SO_PATH)
+        _LIB = C.CDLL(path)
         _LIB.orbx_last_error.restype = C.c_char_p
     return _LIB
 

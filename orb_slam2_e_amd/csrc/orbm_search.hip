@@ -825,6 +825,21 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
 
 extern "C" {
 
+int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
+                      float max_x, float max_y, int32_t *perm, int32_t *cell_off, int32_t *nsorted)
+{
+    if (n < 0 || (n && !kps) || !nsorted || !(max_x > min_x) || !(max_y > min_y)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    if (n > 65535) ORBX_FAIL(ORBX_ERR_CAPACITY, "more than 65,535 keypoints per frame");
+    SortedFrame sf;
+    std::vector<uint8_t> nodesc((size_t)32 * (n ? n : 1), 0);
+    sort_frame(kps, nodesc.data(), n, skip, uright, min_x, min_y, max_x, max_y, sf);
+    *nsorted = (int)sf.perm.size();
+    if (perm) memcpy(perm, sf.perm.data(), sizeof(int) * sf.perm.size());
+    if (cell_off) memcpy(cell_off, sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
+    return ORBX_OK;
+}
+
+
 int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps,
                        const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
                        float max_x, float max_y, int init_dist, int32_t *best, int32_t *best_level, int32_t *second,
