@@ -260,6 +260,43 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
     return out
 
 
+def fem_compute1_bench():
+    """What Optimizer::PoseOptimizationNR pays per call on the FEM side (Optimizer.cc:480, :723; FEA2::Compute(1), FEA2.cc:80-121,
+    its numeric half) at the reference's own mesh sizes -- the four surface meshes of tests/golden as prism models: fem_create
+    (symbolic phase on the host + ONE staged upload), fem_assemble, the Dirichlet penalty and fem_trial_setup, each timed on
+    its own with a synchronisation behind it, and one LM trial (levenberg.cpp:159-175) on the resident state."""
+    from orb_slam2_e_amd.fem import FEA2, FEM_C3D6, extrude_elems, second_layer
+    out = {}
+    for name in ("min", "median", "p90", "large"):
+        m = np.load(os.path.join(ROOT, "tests", "golden", f"fem_mesh_{name}.npz"))
+        top, tris = m["points"], m["triangles"]
+        p = top[tris]
+        tris = tris[~((p[:, 0] == p[:, 1]).all(1) | (p[:, 0] == p[:, 2]).all(1) | (p[:, 1] == p[:, 2]).all(1))]
+        nodes = second_layer(top, 0.5); elems = extrude_elems(tris, len(top))
+        ids = np.arange(len(top), 2 * len(top), dtype=np.int32)
+        u0 = nodes.ravel()
+        reps = 30
+        acc = np.zeros(5)
+        fea = None
+        for r in range(reps + 3):
+            t = [time.perf_counter()]
+            fea = FEA2(nodes, elems, FEM_C3D6); t.append(time.perf_counter())
+            fea.MatrixAssembly(); t.append(time.perf_counter())          # (every one of these calls ends with a wait for the model's stream)
+            fea.ImposeDirichletEncastre_K(ids); t.append(time.perf_counter())
+            fea.trial_setup(u0, ids, len(top), None); t.append(time.perf_counter())
+            if r >= 3:
+                acc[:4] += np.diff(t)
+        pts = top.astype(np.float64) + 0.003
+        fea.trial_energy(pts)
+        t0 = time.perf_counter()
+        for _ in range(100): fea.trial_energy(pts)
+        acc[4] = (time.perf_counter() - t0) / 100 * reps
+        ms = acc / reps * 1e3
+        out[name] = {"Ksize": int(fea.Ksize), "elements": int(len(elems)), "create_ms": ms[0], "assemble_ms": ms[1], "dirichlet_ms": ms[2],
+                     "trial_setup_ms": ms[3], "compute1_ms": float(ms[:4].sum()), "lm_trial_ms": ms[4]}
+    return out
+
+
 def load_fem_traffic():
     """HBM bytes per 200-iteration launch of the batched CG legs (tools/fem_traffic.py over separate FETCH_SIZE / WRITE_SIZE passes)."""
     f = os.path.join(ROOT, "profiles", "r03_fem_traffic.json")
@@ -666,6 +703,8 @@ def main():
     fem_csr = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"orbx_bench_fem_csr_{os.getpid()}.npz")
     if not args.no_fem:
         fem = fem_bench(rank, world, dist, torch, dev, cdev, nmesh=args.fem_meshes, csr_out=fem_csr)
+        if rank == 0:
+            fem["compute1_per_frame"] = fem_compute1_bench()
 
     if rank == 0:
         total_frames = world * BATCH * args.steps
