@@ -101,6 +101,10 @@ int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_
              fem_plan_info *info, int32_t *rowptr, int32_t *lcol, int32_t *diag, int32_t *bp, int32_t *bcol3, int32_t *rcd,
              int32_t *rcfirst, int32_t *chunk_mesh);
 
+/* Cross-check of the symbolic phase (host only): the linear-pass formulation fem_create uses against the first, list-based
+ * one, table by table (block pattern, contribution lists in scatter order, element lists).  ORBX_OK when identical. */
+int fem_plan_selfcheck(int eltype, int nn, const int32_t *elems, int ne);
+
 /* ComputeDisplacement + ImposeDirichletEncastre_a (FEA2.cc:1799-1808,1648-1658):
  * a = uf - u0, then a[3*(id-1)+k] = 1/klarge.  Arrays [nmesh][ndof]. */
 int fem_displacement(fem_model *m, const float *uf, const float *u0, const int32_t *ids, int nids,

@@ -1102,7 +1102,8 @@ struct Symbolic {
     std::vector<int> nel_ptr, nel, contrib_loc; // elements holding each node (ascending); contrib with the element as its index in the row node's list
     int nblk = 0, maxel = 0;
 };
-void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
+// The first formulation (adjacency lists, binary searches): kept as the cross-check of build_symbolic (fem_plan_selfcheck).
+void build_symbolic_simple(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
 {
     std::vector<std::vector<int>> adj(nn);
     for (int i = 0; i < nn; ++i) adj[i].push_back(i);
@@ -1168,6 +1169,99 @@ void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
                     const int col = 3 * y.bcol[y.bptr[I] + jb] + c;
                     y.lcol[start + 3 * jb + c] = col;
                     if (col == row) y.diag[row] = start + 3 * jb + c;
+                }
+        }
+    }
+    y.rowptr[ndof] = 9 * nblk;
+}
+
+// Symbolic phase in linear passes over flat arrays (it runs once per fem_create, i.e. once per PoseOptimizationNR call,
+// and was 90 % of Compute(1) at the reference's mesh sizes in its first formulation): (1) node -> elements in CSR form by
+// counting; (2) per node I: its neighbours gathered from its elements through a stamp array, sorted (a handful of entries),
+// their positions parked in a scratch array; the contributions of block row I -- every (e, li, lj) with elems[e][li] == I
+// -- are produced right there in ascending (e, li, lj) order = the reference's scatter order, counted per block and laid
+// out behind the row's prefix.  No per-node containers, no searches.
+void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
+{
+    // (1) elements holding each node, ascending, once each (an element may repeat a node id: degenerate faces)
+    y.nel_ptr.assign((size_t)nn + 1, 0);
+    for (int e = 0; e < ne; ++e)
+        for (int a = 0; a < npe; ++a) {
+            const int I = elems[e * npe + a];
+            bool seen = false;
+            for (int a2 = 0; a2 < a; ++a2) seen |= elems[e * npe + a2] == I;
+            if (!seen) y.nel_ptr[I + 1]++;
+        }
+    y.maxel = 0;
+    for (int i = 0; i < nn; ++i) { y.maxel = std::max(y.maxel, y.nel_ptr[i + 1]); y.nel_ptr[i + 1] += y.nel_ptr[i]; }
+    y.nel.assign((size_t)y.nel_ptr[nn], 0);
+    {
+        std::vector<int> fill(y.nel_ptr.begin(), y.nel_ptr.end() - 1);
+        for (int e = 0; e < ne; ++e)
+            for (int a = 0; a < npe; ++a) {
+                const int I = elems[e * npe + a];
+                bool seen = false;
+                for (int a2 = 0; a2 < a; ++a2) seen |= elems[e * npe + a2] == I;
+                if (!seen) y.nel[fill[I]++] = e;
+            }
+    }
+    // (2) block rows
+    y.bptr.assign((size_t)nn + 1, 0); y.bcol.clear(); y.blk_row.clear(); y.cptr.assign(1, 0); y.contrib.clear(); y.contrib_loc.clear();
+    y.bcol.reserve((size_t)nn * 16); y.blk_row.reserve((size_t)nn * 16);
+    y.contrib.reserve((size_t)ne * npe * npe); y.contrib_loc.reserve((size_t)ne * npe * npe);
+    std::vector<int> stamp((size_t)nn, -1), pos((size_t)nn, 0), nb, cnt, start;
+    for (int I = 0; I < nn; ++I) {
+        nb.clear();
+        nb.push_back(I); stamp[I] = I;
+        for (int k = y.nel_ptr[I]; k < y.nel_ptr[I + 1]; ++k) {
+            const int32_t *el = elems + (size_t)y.nel[k] * npe;
+            for (int b = 0; b < npe; ++b)
+                if (stamp[el[b]] != I) { stamp[el[b]] = I; nb.push_back(el[b]); }
+        }
+        std::sort(nb.begin(), nb.end());
+        const int b0 = (int)y.bcol.size(), nbI = (int)nb.size();
+        for (int j = 0; j < nbI; ++j) { pos[nb[j]] = j; y.bcol.push_back(nb[j]); y.blk_row.push_back(I); }
+        y.bptr[I + 1] = b0 + nbI;
+        // contributions of the row: count per block, then fill in (e, li, lj) order
+        cnt.assign((size_t)nbI, 0);
+        for (int k = y.nel_ptr[I]; k < y.nel_ptr[I + 1]; ++k) {
+            const int32_t *el = elems + (size_t)y.nel[k] * npe;
+            for (int a = 0; a < npe; ++a)
+                if (el[a] == I)
+                    for (int b = 0; b < npe; ++b) cnt[pos[el[b]]]++;
+        }
+        const int c0 = y.cptr.back();
+        start.assign((size_t)nbI, 0);
+        int run = c0;
+        for (int j = 0; j < nbI; ++j) { start[j] = run; run += cnt[j]; y.cptr.push_back(run); }
+        y.contrib.resize((size_t)run); y.contrib_loc.resize((size_t)run);
+        for (int k = y.nel_ptr[I]; k < y.nel_ptr[I + 1]; ++k) {
+            const int e = y.nel[k], loc = k - y.nel_ptr[I];
+            const int32_t *el = elems + (size_t)e * npe;
+            for (int a = 0; a < npe; ++a)
+                if (el[a] == I)
+                    for (int b = 0; b < npe; ++b) {
+                        const int at = start[pos[el[b]]]++;
+                        y.contrib[at] = (e << 6) | (a << 3) | b;
+                        y.contrib_loc[at] = (loc << 6) | (a << 3) | b;
+                    }
+        }
+    }
+    const int nblk = y.nblk = (int)y.bcol.size();
+    const int ndof = 3 * nn;
+    y.rowptr.assign((size_t)ndof + 1, 0);
+    y.lcol.assign((size_t)9 * nblk, 0);
+    y.diag.assign((size_t)ndof, 0);
+    for (int I = 0; I < nn; ++I) {
+        const int nbI = y.bptr[I + 1] - y.bptr[I];
+        for (int r = 0; r < 3; ++r) {
+            const int row = 3 * I + r, st = 9 * y.bptr[I] + r * 3 * nbI;
+            y.rowptr[row] = st;
+            for (int jb = 0; jb < nbI; ++jb)
+                for (int c = 0; c < 3; ++c) {
+                    const int col = 3 * y.bcol[y.bptr[I] + jb] + c;
+                    y.lcol[st + 3 * jb + c] = col;
+                    if (col == row) y.diag[row] = st + 3 * jb + c;
                 }
         }
     }
@@ -1493,6 +1587,22 @@ int fem_create_batch(int eltype, int nmesh, const int32_t *mesh_nn, const int32_
     if (rc != ORBX_OK) return rc;
     std::vector<int> snn(mesh_nn, mesh_nn + nmesh), sne(mesh_ne, mesh_ne + nmesh);
     return create_model(eltype, npe, nodes, 1, (int)node0[nmesh], gelems.data(), (int)elem0[nmesh], E, nu, fg, y, nmesh, snn.data(), sne.data(), out);
+}
+
+int fem_plan_selfcheck(int eltype, int nn, const int32_t *elems, int ne)
+{
+    const int npe = eltype == FEM_C3D8 ? 8 : eltype == FEM_C3D6 ? 6 : eltype == FEM_TET4 ? 4 : 0;
+    if (!npe || !elems || nn < 1 || ne < 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    for (int i = 0; i < ne * npe; ++i)
+        if (elems[i] < 0 || elems[i] >= nn) ORBX_FAIL(ORBX_ERR_ARG, "element node id out of range");
+    Symbolic a, b;
+    build_symbolic(npe, nn, ne, elems, a);
+    build_symbolic_simple(npe, nn, ne, elems, b);
+    const bool same = a.nblk == b.nblk && a.maxel == b.maxel && a.bptr == b.bptr && a.bcol == b.bcol && a.blk_row == b.blk_row &&
+                      a.cptr == b.cptr && a.contrib == b.contrib && a.contrib_loc == b.contrib_loc && a.nel_ptr == b.nel_ptr &&
+                      a.nel == b.nel && a.rowptr == b.rowptr && a.lcol == b.lcol && a.diag == b.diag;
+    if (!same) ORBX_FAIL(ORBX_ERR_HIP, "the two formulations of the symbolic phase disagree");
+    return ORBX_OK;
 }
 
 int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const int32_t *elems, int uniform_copies,

@@ -126,3 +126,27 @@ def test_plan_rejects_what_create_rejects():
         plan([np.array([[0, 1, 2, 3]], np.int32)] * 2, [4, 4], FEM_TET4, uniform_copies=2)  # copies only of ONE mesh
     p = plan([np.zeros((0, 4), np.int32)], [5], FEM_TET4, uniform_copies=1)                 # no elements: the identity pattern
     assert p["nnz"] == 45 and np.array_equal(p["lcol"].reshape(5, 3, 3)[:, 0, :], np.arange(15).reshape(5, 3))
+
+
+def test_symbolic_phase_two_formulations_agree():
+    """fem_plan_selfcheck: the linear-pass symbolic phase fem_create uses == the first, list-based formulation, every table
+    (block pattern, contribution lists in the reference's scatter order, per-node element lists) -- on the reference's
+    meshes as prisms and degenerate hexahedra (repeated node ids), grids of tets, random element soups, an empty mesh."""
+    import ctypes as C
+    from orb_slam2_e_amd._lib import check, lib
+    L = lib()
+    L.fem_plan_selfcheck.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    def run(eltype, nn, elems):
+        elems = np.ascontiguousarray(elems, np.int32)
+        check(L.fem_plan_selfcheck(eltype, nn, elems.ctypes.data_as(C.c_void_p), len(elems)))
+    for name in ("min", "median", "p90", "large"):
+        m = np.load(os.path.join(GOLD, f"fem_mesh_{name}.npz"))
+        top, tris = m["points"], m["triangles"]
+        run(FEM_C3D6, 2 * len(top), extrude_elems(tris, len(top)))
+        run(FEM_C3D8, 2 * len(top), extrude_elems(np.array([[a, b, c, a] for a, b, c in tris], np.int32), len(top)))
+    nodes, tets, _, _ = synth_tet_mesh(ncell=12)
+    run(FEM_TET4, len(nodes), tets)
+    rng = np.random.default_rng(0)
+    for npe, et in ((4, FEM_TET4), (6, FEM_C3D6), (8, FEM_C3D8)):
+        run(et, 50, rng.integers(0, 50, (300, npe)))          # soup: repeated ids inside elements, isolated nodes
+    run(FEM_TET4, 7, np.zeros((0, 4), np.int32))

@@ -570,7 +570,11 @@ def test_pose_optimization_nr_fem_sequence(name, nder, tmp_path):
         assert np.all(np.abs(got[fld] - ref[fld]) <= RTOL * np.abs(ref[fld])), fld
     for fld in ("tempChi", "currentChi", "lam"):
         assert np.all(np.abs(got[fld][ok] - ref[fld][ok]) <= RTOL * np.abs(ref[fld][ok])), fld
-    assert np.all(np.abs(got["rho"][ok] - ref["rho"][ok]) <= 1e-4 * np.maximum(np.abs(ref["rho"][ok]), 1e-2))
+    # rho = (currentChi - tempChi) / scale is a difference of two sums that each carry the energies' 1e-5: its error is bounded
+    # by that of its terms over the scale (trial k reads script entry k), not by its own size
+    sc = script["scale"][:nt] + 1e-3
+    bound = 4 * RTOL * (np.abs(ref["tempChi"]) + np.abs(ref["currentChi"])) / sc
+    assert np.all(np.abs(got["rho"][ok] - ref["rho"][ok]) <= bound[ok])
 
 
 @pytest.mark.parametrize("nn,resident", [(4762, True), (4763, False)])
