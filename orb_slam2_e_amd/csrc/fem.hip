@@ -1490,35 +1490,46 @@ int build_symbolic_batch(int npe, int nmesh, const int32_t *mesh_nn, const int32
             });
         for (std::thread &th : pool) th.join();
     }
-    gelems.assign((size_t)elem0[nmesh] * npe, 0);
-    y.bptr.assign(1, 0);
-    y.cptr.assign(1, 0);
-    y.rowptr.clear();
-    long long blk0 = 0;
+    // offsets of every mesh's slice in every concatenated table, then the slices filled side by side
+    std::vector<long long> blk0(nmesh + 1, 0), con0(nmesh + 1, 0), nel0(nmesh + 1, 0);
     for (int k = 0; k < nmesh; ++k) {
-        const Symbolic &z = ys[k];
-        const int nd0 = (int)node0[k], el0 = (int)elem0[k], nz0 = (int)(9 * blk0), c0 = y.cptr.back();
-        if (9 * (blk0 + z.nblk) >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 non-zeros");
-        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i) gelems[i] = elems[i] + nd0;
-        for (int v : z.blk_row) y.blk_row.push_back(v + nd0);
-        for (size_t i = 1; i < z.bptr.size(); ++i) y.bptr.push_back(z.bptr[i] + (int)blk0);
-        for (size_t i = 1; i < z.cptr.size(); ++i) y.cptr.push_back(z.cptr[i] + c0);
-        for (int v : z.contrib) y.contrib.push_back(v + (el0 << 6));
-        y.contrib_loc.insert(y.contrib_loc.end(), z.contrib_loc.begin(), z.contrib_loc.end());   // local element numbers: unchanged
-        {
-            const int n0 = y.nel_ptr.empty() ? 0 : y.nel_ptr.back();
-            if (y.nel_ptr.empty()) y.nel_ptr.push_back(0);
-            for (size_t i = 1; i < z.nel_ptr.size(); ++i) y.nel_ptr.push_back(z.nel_ptr[i] + n0);
-            for (int v : z.nel) y.nel.push_back(v + el0);
-            y.maxel = std::max(y.maxel, z.maxel);
-        }
-        for (size_t i = 0; i + 1 < z.rowptr.size(); ++i) y.rowptr.push_back(z.rowptr[i] + nz0);
-        for (int v : z.lcol) y.lcol.push_back(v + 3 * nd0);
-        for (int v : z.diag) y.diag.push_back(v + nz0);
-        blk0 += z.nblk;
+        blk0[k + 1] = blk0[k] + ys[k].nblk;
+        con0[k + 1] = con0[k] + (long long)ys[k].contrib.size();
+        nel0[k + 1] = nel0[k] + (long long)ys[k].nel.size();
+        y.maxel = std::max(y.maxel, ys[k].maxel);
     }
-    y.rowptr.push_back((int)(9 * blk0));
-    y.nblk = (int)blk0;
+    if (9 * blk0[nmesh] >= (1ll << 31) || con0[nmesh] >= (1ll << 31)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "batch exceeds 2^31 non-zeros");
+    const long long nnt = node0[nmesh], nbt = blk0[nmesh];
+    gelems.assign((size_t)elem0[nmesh] * npe, 0);
+    y.blk_row.assign((size_t)nbt, 0); y.bptr.assign((size_t)nnt + 1, 0); y.cptr.assign((size_t)nbt + 1, 0);
+    y.contrib.assign((size_t)con0[nmesh], 0); y.contrib_loc.assign((size_t)con0[nmesh], 0);
+    y.nel_ptr.assign((size_t)nnt + 1, 0); y.nel.assign((size_t)nel0[nmesh], 0);
+    y.rowptr.assign((size_t)3 * nnt + 1, 0); y.lcol.assign((size_t)9 * nbt, 0); y.diag.assign((size_t)3 * nnt, 0);
+    auto place = [&](int k) {
+        const Symbolic &z = ys[k];
+        const int nd0 = (int)node0[k], el0 = (int)elem0[k], b0 = (int)blk0[k], nz0 = 9 * b0, c0 = (int)con0[k], n0 = (int)nel0[k];
+        for (long long i = elem0[k] * npe; i < elem0[k + 1] * npe; ++i) gelems[i] = elems[i] + nd0;
+        for (size_t i = 0; i < z.blk_row.size(); ++i) y.blk_row[b0 + i] = z.blk_row[i] + nd0;
+        for (size_t i = 1; i < z.bptr.size(); ++i) y.bptr[nd0 + i] = z.bptr[i] + b0;
+        for (size_t i = 1; i < z.cptr.size(); ++i) y.cptr[b0 + i] = z.cptr[i] + c0;
+        for (size_t i = 0; i < z.contrib.size(); ++i) y.contrib[c0 + i] = z.contrib[i] + (el0 << 6);
+        std::copy(z.contrib_loc.begin(), z.contrib_loc.end(), y.contrib_loc.begin() + c0);   // local element numbers: unchanged
+        for (size_t i = 1; i < z.nel_ptr.size(); ++i) y.nel_ptr[nd0 + i] = z.nel_ptr[i] + n0;
+        for (size_t i = 0; i < z.nel.size(); ++i) y.nel[n0 + i] = z.nel[i] + el0;
+        for (size_t i = 0; i + 1 < z.rowptr.size(); ++i) y.rowptr[3 * (size_t)nd0 + i] = z.rowptr[i] + nz0;
+        for (size_t i = 0; i < z.lcol.size(); ++i) y.lcol[(size_t)nz0 + i] = z.lcol[i] + 3 * nd0;
+        for (size_t i = 0; i < z.diag.size(); ++i) y.diag[3 * (size_t)nd0 + i] = z.diag[i] + nz0;
+    };
+    {
+        const int nthr = std::max(1, std::min(nmesh, std::min(16, (int)std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t)
+            pool.emplace_back([&, t]() { for (int k = t; k < nmesh; k += nthr) place(k); });
+        for (std::thread &th : pool) th.join();
+    }
+    const long long blk0_total = nbt;
+    y.rowptr[(size_t)3 * nnt] = (int)(9 * blk0_total);
+    y.nblk = (int)blk0_total;
     return ORBX_OK;
 }
 
