@@ -367,6 +367,11 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
 int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
                       float max_x, float max_y, int32_t *perm, int32_t *cell_off, int32_t *nsorted);
 
+/* Test aid: on != 0 makes the whole-loop projection searches use the one-wave sequential resolver (k_resolve) instead of the
+ * parallel fixed-point resolver (k_resolve_par), which otherwise only takes over when the latter does not converge.  Both
+ * give the reference loop's result.  Process-wide; returns the previous setting. */
+int orbm_debug_force_sequential_resolver(int on);
+
 /* Which kernel the all-pairs matchers (orbm_match_batch_dev, orbm_match_bruteforce) launch.  Both produce the same
  * integers.  ORBM_ALLPAIRS_AUTO (default): the matrix-core kernel (FP4 MFMA computes the selection keys, 3.5x
  * faster at 2000 x 2000) for sets up to 32768 rows, the XOR + popcount kernel above that; ORBM_ALLPAIRS_POPCOUNT:

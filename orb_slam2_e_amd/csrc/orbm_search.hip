@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -331,6 +332,198 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
         for (int j = lane; j < nq; j += 64) out_a[j] = s_c[j];              // vnMatches12 by sorted position
     }
     if (lane == 0) { if (seg) atomicAdd(nmatches, nm); else *nmatches = nm; }
+}
+
+// The projection family's sequential loop as a parallel fixed point, with the rotation check of k_rotation<0> as its tail: ONE
+// workgroup of 1024 threads, every query evaluated in every iteration.
+//
+// In the reference's loop (ORBmatcher.cc:69-130, :1588-1660, ...) query i skips the keypoints an EARLIER query j < i was matched
+// to (if j's point blocks the slot: `takes`), and nothing else couples the queries.  Let first[s] be the smallest index of a
+// query whose accepted match takes slot s.  Given `first`, query i's selection is a function of it alone: candidates with
+// first[s] < i are skipped.  Iterate: all queries select against first_k, their claims give first_{k+1}.  Query 0 never skips
+// anything, so it is final after one iteration; once every j < i is final, i is final one iteration later: the iteration reaches
+// the sequential loop's result after at most as many iterations as the longest chain "j's match changes what i selects", and a
+// state whose claims reproduce themselves is that result (by the same induction).  Real frames have chains of a few queries
+// (a window holds a handful of keypoints); the one-wave batch walk of k_resolve took 32 dependent batches for 2,000 queries.
+// If the claims still change after RES_MAXIT iterations the kernel says so (*converged = 0) and the host repeats the call on
+// k_resolve: the result never depends on how the chains fall.
+constexpr int RES_T = 1024, RES_QREG = 2, RES_MAXIT = 48;
+__global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restrict__ ent, const unsigned *__restrict__ top,
+                                                       const int *__restrict__ lbeg, const int *__restrict__ lend, int nq, int ns,
+                                                       const uint8_t *__restrict__ takes, int th, float nnratio, int accept_mode,
+                                                       const float *__restrict__ qangle, const float *__restrict__ kangle,
+                                                       const int *__restrict__ perm, int check, int *__restrict__ match_q,
+                                                       int *__restrict__ match_kp, int *__restrict__ nmatches, int *__restrict__ converged)
+{
+    extern __shared__ __align__(16) int sm[];
+    int *f_cur = sm, *f_nxt = sm + ns;     // first[s] of the last / of this iteration (INT_MAX: nobody takes s)
+    __shared__ int s_changed, s_nm, hist[HISTO_LENGTH], keep[3], removed;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < ns; j += RES_T) { f_cur[j] = INT_MAX; f_nxt[j] = INT_MAX; }
+    if (tid == 0) { s_changed = 0; s_nm = 0; removed = 0; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    const bool need2 = accept_mode != ACCEPT_BEST;
+    // the first RES_QREG queries of a thread keep their short lists in registers
+    unsigned tpr[RES_QREG][TOPK];
+    int br[RES_QREG], er[RES_QREG], tkr[RES_QREG];
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r) {
+        const int i = tid + r * RES_T;
+        br[r] = er[r] = 0; tkr[r] = 1;
+#pragma unroll
+        for (int k = 0; k < TOPK; ++k) tpr[r][k] = 0xffffffffu;
+        if (i < nq) {
+            const uint4 t0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i], t1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1];
+            tpr[r][0] = t0.x; tpr[r][1] = t0.y; tpr[r][2] = t0.z; tpr[r][3] = t0.w;
+            tpr[r][4] = t1.x; tpr[r][5] = t1.y; tpr[r][6] = t1.z; tpr[r][7] = t1.w;
+            br[r] = lbeg[i]; er[r] = lend[i]; tkr[r] = takes[i];
+        }
+    }
+    // query i's accepted candidate against `first` (or -1): the selection of k_resolve<0>, eligibility = first[sp] >= i
+    auto select = [&](int i, const unsigned (&tp)[TOPK], int b, int e, const int *first) -> int {
+        int sp1 = -1, sp2 = -1, best = INT_MAX, second = INT_MAX, l1 = -1, l2 = -1, found = 0;
+        int st[TOPK];
+#pragma unroll
+        for (int r = 0; r < TOPK; ++r) st[r] = first[tp[r] == 0xffffffffu ? 0 : (tp[r] & 0xffffu)];
+#pragma unroll
+        for (int r = 0; r < TOPK; ++r) {
+            const unsigned en = tp[r];
+            if (en != 0xffffffffu && found < 2 && st[r] >= i) {
+                const int sp = en & 0xffffu, dist = (int)(en >> 20);
+                if (found == 0) { sp1 = sp; best = dist; l1 = (en >> 16) & 15; }
+                else { sp2 = sp; second = dist; l2 = (en >> 16) & 15; }
+                ++found;
+            }
+        }
+        if (found < (need2 ? 2 : 1) && e - b > TOPK) { // the short list ran dry: the whole list
+            unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
+            for (int k = b; k < e; ++k) {
+                const unsigned en = ent[k];
+                if (en != 0xffffffffu && first[en & 0xffffu] >= i) {
+                    const unsigned key = ((en >> 20) << 16) | (unsigned)(k - b);
+                    const unsigned hi = max(k1, key);
+                    k2 = min(k2, hi);
+                    k1 = min(k1, key);
+                }
+            }
+            sp1 = sp2 = -1; best = second = INT_MAX; l1 = l2 = -1;
+            if (k1 != 0xffffffffu) { const unsigned en = ent[b + (k1 & 0xffffu)]; sp1 = en & 0xffffu; l1 = (en >> 16) & 15; best = (int)(k1 >> 16); }
+            if (k2 != 0xffffffffu) { const unsigned en = ent[b + (k2 & 0xffffu)]; sp2 = en & 0xffffu; l2 = (en >> 16) & 15; second = (int)(k2 >> 16); }
+        }
+        if (!need2) sp2 = -1;
+        bool acc = sp1 >= 0 && best <= th;
+        const int sec = sp2 >= 0 ? second : 256;     // initial bestDist2 = 256 when there is no second candidate (:79-81)
+        if (accept_mode == ACCEPT_RATIO_SAME_LEVEL && l1 == l2 && (float)best > nnratio * (float)sec) acc = false; // :121
+        if (accept_mode == ACCEPT_RATIO && !((float)best < nnratio * (float)sec)) acc = false;                    // :431, :801
+        return acc ? sp1 : -1;
+    };
+    auto select_global = [&](int i, const int *first) -> int {
+        unsigned tp[TOPK];
+        const uint4 t0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i], t1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1];
+        tp[0] = t0.x; tp[1] = t0.y; tp[2] = t0.z; tp[3] = t0.w; tp[4] = t1.x; tp[5] = t1.y; tp[6] = t1.z; tp[7] = t1.w;
+        return select(i, tp, lbeg[i], lend[i], first);
+    };
+    __syncthreads();
+    int selr[RES_QREG];
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r) selr[r] = -2;
+    bool done = false;
+    int it = 0;
+    // (queries beyond RES_QREG x RES_T keep their last selection in match_q, which this kernel owns until its tail)
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) match_q[i] = -2;
+    for (; it < RES_MAXIT; ++it) {
+        bool changed = false;
+#pragma unroll
+        for (int r = 0; r < RES_QREG; ++r) {
+            const int i = tid + r * RES_T;
+            if (i < nq) {
+                const int sel = select(i, tpr[r], br[r], er[r], f_cur);
+                const int claim = sel >= 0 && tkr[r] ? sel : -1, was = selr[r] >= 0 && tkr[r] ? selr[r] : -1;
+                changed |= claim != was || (selr[r] == -2);
+                selr[r] = sel;
+                if (claim >= 0) atomicMin(&f_nxt[claim], i);
+            }
+        }
+        for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
+            const int sel = select_global(i, f_cur), prev = match_q[i], tk = takes[i];
+            const int claim = sel >= 0 && tk ? sel : -1, was = prev >= 0 && tk ? prev : -1;
+            changed |= claim != was || prev == -2;
+            match_q[i] = sel;
+            if (claim >= 0) atomicMin(&f_nxt[claim], i);
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        done = s_changed == 0;
+        __syncthreads();
+        if (done) break;
+        if (tid == 0) s_changed = 0;
+        for (int j = tid; j < ns; j += RES_T) f_cur[j] = INT_MAX;     // becomes the next iteration's claim table
+        int *t = f_cur; f_cur = f_nxt; f_nxt = t;
+        __syncthreads();
+    }
+    if (!done) {            // chains longer than RES_MAXIT: the host repeats the call on the sequential kernel
+        if (tid == 0) *converged = 0;
+        return;
+    }
+    // ---- tail: match_kp = the LAST accepted query of a slot (:125), the rotation histogram, ComputeThreeMaxima, rejection
+    int *s_a = f_nxt;       // (f_nxt holds this iteration's claims = f_cur's content: no longer needed)
+    for (int j = tid; j < ns; j += RES_T) s_a[j] = -1;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto bin_of = [&](int i, int sp) {
+        float rot = qangle[i] - kangle[sp];
+        if (rot < 0.0f) rot += 360.0f;
+        const int bin = (int)roundf(rot * factor);
+        return bin == HISTO_LENGTH ? 0 : bin;
+    };
+    int binr[RES_QREG], nacc = 0;
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r) {
+        const int i = tid + r * RES_T;
+        binr[r] = -1;
+        if (i < nq && selr[r] >= 0) {
+            atomicMax(&s_a[selr[r]], i);
+            ++nacc;
+            if (check) { binr[r] = bin_of(i, selr[r]); atomicAdd(&hist[binr[r]], 1); }
+        }
+    }
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
+        const int sel = match_q[i];
+        if (sel >= 0) {
+            atomicMax(&s_a[sel], i);
+            ++nacc;
+            if (check) atomicAdd(&hist[bin_of(i, sel)], 1);
+        }
+    }
+    if (nacc) atomicAdd(&s_nm, nacc);
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+    }
+    for (int j = tid; j < ns; j += RES_T) match_kp[perm[j]] = s_a[j];
+    __syncthreads();
+    auto finish = [&](int i, int sp, int bin) {
+        if (check && sp >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2]) { match_kp[perm[sp]] = -2; atomicAdd(&removed, 1); }
+        match_q[i] = sp >= 0 ? perm[sp] : -1;
+    };
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r)
+        if (tid + r * RES_T < nq) finish(tid + r * RES_T, selr[r], binr[r]);
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
+        const int sp = match_q[i];
+        finish(i, sp, check && sp >= 0 ? bin_of(i, sp) : -1);
+    }
+    __syncthreads();
+    if (tid == 0) *nmatches = s_nm - removed;
 }
 
 // Window search without coupling between queries = Frame::GetFeaturesInArea (src/Frame.cc:342-395)
@@ -638,6 +831,8 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
     if (tid == 0) *nmatches -= removed;
 }
 
+std::atomic<int> g_force_sequential{0};   // orbm_debug_force_sequential_resolver: tests run both resolvers
+
 struct SortedFrame {
     std::vector<SeqKp> kp;
     std::vector<int> cell_off; // [COLS*ROWS + 1] runs of the sorted array per grid cell (col * ROWS + row)
@@ -702,6 +897,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     if (!lds_attr_set) { // the largest request either instantiation can make
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     // Window lists: their lengths are known only on the device.  First attempt: every query fills its own region of
@@ -709,9 +905,12 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     // back with the results and the call is repeated on the exact path (count, scan, fill), whose total also travels
     // with the results -- the host never waits in the middle of a call.
     constexpr int WIN_STRIDE = 256;
-    bool exact = false;
+    bool exact = false, sized = false;
     size_t ent_need = cand_off ? (size_t)cand_off[nq] : (size_t)nq * WIN_STRIDE;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    // the projection family (one segment, MODE 0) resolves as a parallel fixed point (k_resolve_par, rotation check fused); if its
+    // dependency chains are longer than the kernel iterates, the call is repeated on the one-wave sequential resolver
+    bool sequential = mode != 0 || seg != nullptr || g_force_sequential.load(std::memory_order_relaxed) != 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
         w.used = 0;
         // staged inputs (same offsets on both sides), then device-only arrays, then the result block
         const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * ns),
@@ -725,7 +924,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                      o_lend = w.carve(sizeof(int) * nq),
                      o_state = w.carve(sizeof(int) * (size_t)std::max(ns, nq));
         const size_t o_res = w.used;
-        const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(2 * sizeof(int));
+        const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(3 * sizeof(int));
         const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
         if (w.reserve(total_bytes, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
         if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
@@ -755,7 +954,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         // to (segments: the host adds the 1 back), the overflow flag is CLEARED to 0 by a list that does not fit
         {
             const size_t f0 = seg ? o_state : o_mk;
-            ORBX_HIP(hipMemsetAsync(w.d<char>(f0), 0xff, o_nm + 2 * sizeof(int) - f0, st));
+            ORBX_HIP(hipMemsetAsync(w.d<char>(f0), 0xff, o_nm + 3 * sizeof(int) - f0, st));   // (+ the "converged" flag of k_resolve_par)
         }
 
         const WinQuery *dq = w.d<WinQuery>(o_q);
@@ -778,7 +977,8 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                                init_dist, w.d<int>(o_cnt), (const int *)nullptr, (unsigned *)nullptr, 0, (int *)nullptr, (int *)nullptr,
                                (int *)nullptr, (unsigned *)nullptr);
             hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_cnt), nq, doff, dnm + 1);
-            if (attempt == 1) { // the total is needed to size the buffer: the one host wait of this (rare) path
+            if (!sized) { // the total is needed to size the buffer: the one host wait of this (rare) path
+                sized = true;
                 int total = 0;
                 ORBX_HIP(hipMemcpyAsync(&total, dnm + 1, sizeof(int), hipMemcpyDeviceToHost, st));
                 ORBX_HIP(hipStreamSynchronize(st));
@@ -790,7 +990,11 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         }
         const int *dseg = seg ? w.d<int>(o_seg) : nullptr;
         const dim3 gr(seg ? nseg : 1);
-        if (mode == 0) {
+        if (!sequential) {
+            hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(RES_T), sizeof(int) * 2 * (size_t)ns, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend,
+                               nq, ns, (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, (const float *)w.d<float>(o_qang),
+                               (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<int>(o_mq), w.d<int>(o_mk), dnm, dnm + 2);
+        } else if (mode == 0) {
             hipLaunchKernelGGL(k_resolve<0>, gr, dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend, nq, ns,
                                (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, w.d<int>(o_acc), w.d<int>(o_state), dnm, dseg);
             hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
@@ -812,6 +1016,11 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
             exact = true;
             continue;
         }
+        if (!sequential) {
+            int conv = 0;
+            memcpy(&conv, w.pin + (o_nm - o_res) + 2 * sizeof(int), sizeof(int));
+            if (conv == 0) { sequential = true; continue; }
+        }
         memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
         if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
         memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
@@ -824,6 +1033,11 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
 } // namespace
 
 extern "C" {
+
+int orbm_debug_force_sequential_resolver(int on)
+{
+    return g_force_sequential.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
 
 int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
                       float max_x, float max_y, int32_t *perm, int32_t *cell_off, int32_t *nsorted)

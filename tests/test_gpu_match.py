@@ -278,7 +278,7 @@ def test_distinctive_descriptors_batch():
 
 @pytest.mark.parametrize("seed,th,ratio_lvl,ori,stereo", [(0, 95, False, True, False), (1, 95, True, False, True),
                                                           (2, 60, False, True, True), (3, 45, False, False, False)])
-def test_search_projection_whole_loop(seed, th, ratio_lvl, ori, stereo):
+def test_search_projection_whole_loop(seed, th, ratio_lvl, ori, stereo, resolver):
     """orbm_search_projection vs the literal sequential loops (in-loop assignment + rotation check)."""
     q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(seed, stereo=stereo)
     m = ORBmatcher(0.8 if ratio_lvl else 0.6, ori)
@@ -293,7 +293,7 @@ def test_search_projection_whole_loop(seed, th, ratio_lvl, ori, stereo):
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
 
 
-def test_search_projection_edge_cases():
+def test_search_projection_edge_cases(resolver):
     from orb_slam2_e_amd import KP_DTYPE
     m = ORBmatcher(0.6, True)
     q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(5, n=300, nq=100, hot=20)
@@ -412,7 +412,7 @@ def test_fuse_candidate_loop(seed, stereo, gate):
         assert not np.array_equal(free[1], ref[1])
 
 
-def test_search_by_sim3_agreement():
+def test_search_by_sim3_agreement(resolver):
     """SearchBySim3 = two window searches + the mutual-agreement check, against the oracle composition."""
     from orb_slam2_e_amd import KP_DTYPE
     rng = np.random.default_rng(4)

@@ -12,7 +12,7 @@ from orb_slam2_e_amd.extractor import KP_DTYPE
 
 
 @pytest.mark.parametrize("crowd", [40, 700])
-def test_projection_loop_small_and_overflowing_lists(crowd):
+def test_projection_loop_small_and_overflowing_lists(crowd, resolver):
     rng = np.random.default_rng(crowd)
     n, nq = 1500, 900
     kps = np.zeros(n, KP_DTYPE)
@@ -36,3 +36,29 @@ def test_projection_loop_small_and_overflowing_lists(crowd):
         for g, r in zip(got, ref):
             assert np.array_equal(g, r)
     assert got[2] > 100
+
+
+@pytest.mark.parametrize("nk,nq", [(100, 300), (12, 3000), (2000, 2000)])
+def test_projection_loop_long_dependency_chains(nk, nq):
+    """Every query looks at the SAME window: query k can only take what the k - 1 before it left, a dependency chain as long
+    as the window has keypoints (nk = 100: longer than k_resolve_par iterates, so the call falls back to the sequential
+    resolver by itself; nk = 12: a short chain among 3,000 queries, more than two per thread; 2000 x 2000 in one window:
+    lists overflow AND chains are long).  All must equal the literal loop."""
+    rng = np.random.default_rng(nk)
+    kps = np.zeros(nk, KP_DTYPE)
+    kps["x"] = rng.uniform(300, 340, nk); kps["y"] = rng.uniform(200, 240, nk)
+    kps["octave"] = rng.integers(0, 3, nk); kps["angle"] = rng.uniform(0, 360, nk)
+    desc = rng.integers(0, 256, (nk, 32), dtype=np.uint8)
+    q = np.zeros(nq, ORBmatcher.WQ_DTYPE)
+    q["u"] = 320; q["v"] = 220; q["r"] = 60.0; q["min_level"] = -1; q["max_level"] = -1; q["xr"] = 320
+    src = rng.integers(0, nk, nq)
+    qd = desc[src] ^ np.packbits(rng.random((nq, 256)) < 0.1, axis=1, bitorder="little")
+    qa = ((kps["angle"][src] + 3.0) % 360).astype(np.float32)
+    takes = (rng.random(nq) < 0.9).astype(np.uint8)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    m = ORBmatcher(0.9, True)
+    got = m.search_projection(q, qd, qa, takes, kps, desc, bounds, np.zeros(nk, np.uint8), None, 256)
+    ref = oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, np.zeros(nk, np.uint8), None, 256, 0.9, False, True)
+    assert ref[2] >= min(nk, nq) // 2
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
