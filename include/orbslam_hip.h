@@ -371,6 +371,9 @@ int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, cons
  * parallel fixed-point resolver (k_resolve_par), which otherwise only takes over when the latter does not converge.  Both
  * give the reference loop's result.  Process-wide; returns the previous setting. */
 int orbm_debug_force_sequential_resolver(int on);
+/* Iterations the parallel resolver needed in the last whole-loop projection search of this process (-1: it gave up after
+ * its iteration limit and the sequential resolver produced the result). */
+int orbm_debug_last_resolver_iterations(void);
 
 /* Which kernel the all-pairs matchers (orbm_match_batch_dev, orbm_match_bruteforce) launch.  Both produce the same
  * integers.  ORBM_ALLPAIRS_AUTO (default): the matrix-core kernel (FP4 MFMA computes the selection keys, 3.5x

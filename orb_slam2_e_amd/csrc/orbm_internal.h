@@ -55,6 +55,7 @@ struct Workspace {
     unsigned *ent = nullptr;
     size_t dev_cap = 0, pin_cap = 0, ent_cap = 0, used = 0;
     hipStream_t st = nullptr;
+    unsigned gen = 0;    // call counter: flags a kernel raises are this number (a fresh arena is zeroed, 0 is never a generation)
     int reserve(size_t dev_bytes, size_t pin_bytes); // discards the contents
     int reserve_entries(size_t n);
     size_t carve(size_t bytes) { const size_t o = used; used += (bytes + 255) & ~(size_t)255; return o; }

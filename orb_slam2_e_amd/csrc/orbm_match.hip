@@ -484,6 +484,7 @@ int Workspace::reserve(size_t dev_bytes, size_t pin_bytes)
         dev = nullptr; dev_cap = 0;
         const size_t want = std::max(dev_bytes + dev_bytes / 2, (size_t)1 << 20);
         if (hipMalloc((void **)&dev, want) != hipSuccess) { dev = nullptr; return -1; }
+        if (hipMemsetAsync(dev, 0, want, st) != hipSuccess) return -1;    // flags are generation numbers >= 1: stale memory must not look like one
         dev_cap = want;
     }
     if (pin_bytes > pin_cap) {

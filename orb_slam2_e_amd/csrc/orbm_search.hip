@@ -99,9 +99,10 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
                                                  const int *__restrict__ cell_off, GridParams gp, int has_uright, int init_dist,
                                                  int *__restrict__ cnt, const int *__restrict__ off, unsigned *__restrict__ ent,
                                                  int stride, int *__restrict__ lbeg, int *__restrict__ lend,
-                                                 int *__restrict__ overflow, unsigned *__restrict__ top)
+                                                 int *__restrict__ overflow, unsigned *__restrict__ top, int gen)
 {
-    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // (the query index is the same in all lanes: said so, the query record, its cell range and the runs' bounds become scalar loads)
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (MT / 64) + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (i >= nq) return;
     const int obase = FILL == 2 ? i * stride : (FILL == 1 ? off[i] : 0), ocap = FILL == 2 ? stride : INT_MAX;
     const WinQuery w = q[i];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
     if (FILL) {
         if (FILL == 2 && lane == 0) {
             lbeg[i] = obase; lend[i] = obase + min(c, ocap);
-            if (c > ocap) atomicAnd(overflow, 0);   // preset to -1 by the host's fill: 0 = some list did not fit
+            if (c > ocap) *overflow = gen;          // this call's generation number: some list did not fit (no preset needed)
         }
         __threadfence_block();
         wave_topk(ent, obase, min(c, ocap), lane, top + (size_t)i * TOPK);
@@ -353,38 +354,55 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
                                                        const uint8_t *__restrict__ takes, int th, float nnratio, int accept_mode,
                                                        const float *__restrict__ qangle, const float *__restrict__ kangle,
                                                        const int *__restrict__ perm, int check, int *__restrict__ match_q,
-                                                       int *__restrict__ match_kp, int *__restrict__ nmatches, int *__restrict__ converged)
+                                                       int *__restrict__ match_kp, int n, const int *__restrict__ flags, int gen,
+                                                       int *__restrict__ host_q, int *__restrict__ host_kp, int *__restrict__ host_nm)
 {
+    // host_*: the call's result block in PINNED HOST memory.  The kernel's last phase writes the results there itself (posted
+    // writes over PCIe, each element once): a device-to-host copy behind the kernel cost the call its 5 us plus ~9 us of
+    // hand-over between the compute queue and the copy engine.  match_q / match_kp stay the device-side working copies.
     extern __shared__ __align__(16) int sm[];
     int *f_cur = sm, *f_nxt = sm + ns;     // first[s] of the last / of this iteration (INT_MAX: nobody takes s)
+    int *s_perm = sm + 2 * ns;             // what the tail gathers by sorted position sits in LDS before the iterations end:
+    float *s_kang = reinterpret_cast<float *>(sm + 3 * ns);   // the kernel is one workgroup of dependent round trips
     __shared__ int s_changed, s_nm, hist[HISTO_LENGTH], keep[3], removed;
     const int tid = threadIdx.x;
-    for (int j = tid; j < ns; j += RES_T) { f_cur[j] = INT_MAX; f_nxt[j] = INT_MAX; }
-    if (tid == 0) { s_changed = 0; s_nm = 0; removed = 0; }
-    if (tid < HISTO_LENGTH) hist[tid] = 0;
     const bool need2 = accept_mode != ACCEPT_BEST;
-    // the first RES_QREG queries of a thread keep their short lists in registers
+    // everything that does not depend on the iterations is requested up front: the first RES_QREG queries of a thread keep
+    // their short lists (and their angles) in registers, the permutation and the keypoint angles go to LDS, every slot of the
+    // result is preset (keypoints outside the grid included: no fill by the host)
     unsigned tpr[RES_QREG][TOPK];
     int br[RES_QREG], er[RES_QREG], tkr[RES_QREG];
+    float qar[RES_QREG];
 #pragma unroll
     for (int r = 0; r < RES_QREG; ++r) {
         const int i = tid + r * RES_T;
-        br[r] = er[r] = 0; tkr[r] = 1;
+        br[r] = er[r] = 0; tkr[r] = 1; qar[r] = 0.f;
 #pragma unroll
         for (int k = 0; k < TOPK; ++k) tpr[r][k] = 0xffffffffu;
         if (i < nq) {
             const uint4 t0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i], t1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1];
             tpr[r][0] = t0.x; tpr[r][1] = t0.y; tpr[r][2] = t0.z; tpr[r][3] = t0.w;
             tpr[r][4] = t1.x; tpr[r][5] = t1.y; tpr[r][6] = t1.z; tpr[r][7] = t1.w;
-            br[r] = lbeg[i]; er[r] = lend[i]; tkr[r] = takes[i];
+            br[r] = lbeg[i]; er[r] = lend[i]; tkr[r] = takes[i]; qar[r] = qangle[i];
         }
     }
+    for (int j = tid; j < ns; j += RES_T) { f_cur[j] = INT_MAX; f_nxt[j] = INT_MAX; s_perm[j] = perm[j]; s_kang[j] = kangle[j]; }
+    for (int j = tid; j < n; j += RES_T) match_kp[j] = -1;
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) match_q[i] = -2;   // queries beyond the registers keep their last selection here
+    if (tid == 0) { s_changed = 0; s_nm = 0; removed = 0; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
     // query i's accepted candidate against `first` (or -1): the selection of k_resolve<0>, eligibility = first[sp] >= i
     auto select = [&](int i, const unsigned (&tp)[TOPK], int b, int e, const int *first) -> int {
         int sp1 = -1, sp2 = -1, best = INT_MAX, second = INT_MAX, l1 = -1, l2 = -1, found = 0;
         int st[TOPK];
 #pragma unroll
         for (int r = 0; r < TOPK; ++r) st[r] = first[tp[r] == 0xffffffffu ? 0 : (tp[r] & 0xffffu)];
+        if (!need2) {       // "best only" (wave-uniform): the first eligible entry of the sorted short list, a select chain
+            unsigned en1 = 0xffffffffu;
+#pragma unroll
+            for (int r = TOPK - 1; r >= 0; --r) en1 = (tp[r] != 0xffffffffu && st[r] >= i) ? tp[r] : en1;
+            if (en1 != 0xffffffffu || e - b <= TOPK) return en1 != 0xffffffffu && (int)(en1 >> 20) <= th ? (int)(en1 & 0xffffu) : -1;
+        }
 #pragma unroll
         for (int r = 0; r < TOPK; ++r) {
             const unsigned en = tp[r];
@@ -429,8 +447,6 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
     for (int r = 0; r < RES_QREG; ++r) selr[r] = -2;
     bool done = false;
     int it = 0;
-    // (queries beyond RES_QREG x RES_T keep their last selection in match_q, which this kernel owns until its tail)
-    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) match_q[i] = -2;
     for (; it < RES_MAXIT; ++it) {
         bool changed = false;
 #pragma unroll
@@ -461,17 +477,19 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
         int *t = f_cur; f_cur = f_nxt; f_nxt = t;
         __syncthreads();
     }
+    if (tid == 0) host_nm[1] = flags[1];      // "a list outgrew its region" as k_win_wave left it
     if (!done) {            // chains longer than RES_MAXIT: the host repeats the call on the sequential kernel
-        if (tid == 0) *converged = 0;
+        if (tid == 0) host_nm[2] = 0;
         return;
     }
+    if (tid == 0) { host_nm[2] = gen; host_nm[3] = it + 1; }   // reached the fixed point (+ the number of iterations it took)
     // ---- tail: match_kp = the LAST accepted query of a slot (:125), the rotation histogram, ComputeThreeMaxima, rejection
     int *s_a = f_nxt;       // (f_nxt holds this iteration's claims = f_cur's content: no longer needed)
     for (int j = tid; j < ns; j += RES_T) s_a[j] = -1;
     __syncthreads();
     const float factor = 1.0f / HISTO_LENGTH;
-    auto bin_of = [&](int i, int sp) {
-        float rot = qangle[i] - kangle[sp];
+    auto bin_of = [&](float qa, int sp) {
+        float rot = qa - s_kang[sp];
         if (rot < 0.0f) rot += 360.0f;
         const int bin = (int)roundf(rot * factor);
         return bin == HISTO_LENGTH ? 0 : bin;
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
         if (i < nq && selr[r] >= 0) {
             atomicMax(&s_a[selr[r]], i);
             ++nacc;
-            if (check) { binr[r] = bin_of(i, selr[r]); atomicAdd(&hist[binr[r]], 1); }
+            if (check) { binr[r] = bin_of(qar[r], selr[r]); atomicAdd(&hist[binr[r]], 1); }
         }
     }
     for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
         if (sel >= 0) {
             atomicMax(&s_a[sel], i);
             ++nacc;
-            if (check) atomicAdd(&hist[bin_of(i, sel)], 1);
+            if (check) atomicAdd(&hist[bin_of(qangle[i], sel)], 1);
         }
     }
     if (nacc) atomicAdd(&s_nm, nacc);
@@ -509,21 +527,23 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
     }
-    for (int j = tid; j < ns; j += RES_T) match_kp[perm[j]] = s_a[j];
+    for (int j = tid; j < ns; j += RES_T)
+        if (s_a[j] >= 0) match_kp[s_perm[j]] = s_a[j];        // (the other slots keep their preset -1)
     __syncthreads();
     auto finish = [&](int i, int sp, int bin) {
-        if (check && sp >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2]) { match_kp[perm[sp]] = -2; atomicAdd(&removed, 1); }
-        match_q[i] = sp >= 0 ? perm[sp] : -1;
+        if (check && sp >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2]) { match_kp[s_perm[sp]] = -2; atomicAdd(&removed, 1); }
+        host_q[i] = sp >= 0 ? s_perm[sp] : -1;
     };
 #pragma unroll
     for (int r = 0; r < RES_QREG; ++r)
         if (tid + r * RES_T < nq) finish(tid + r * RES_T, selr[r], binr[r]);
     for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
         const int sp = match_q[i];
-        finish(i, sp, check && sp >= 0 ? bin_of(i, sp) : -1);
+        finish(i, sp, check && sp >= 0 ? bin_of(qangle[i], sp) : -1);
     }
     __syncthreads();
-    if (tid == 0) *nmatches = s_nm - removed;
+    for (int j = tid; j < n; j += RES_T) host_kp[j] = match_kp[j];
+    if (tid == 0) host_nm[0] = s_nm - removed;
 }
 
 // Window search without coupling between queries = Frame::GetFeaturesInArea (src/Frame.cc:342-395)
@@ -540,7 +560,7 @@ __global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q,
                                                  int *__restrict__ best_o, int *__restrict__ bl_o, int *__restrict__ second_o,
                                                  int *__restrict__ sl_o, int *__restrict__ idx_o)
 {
-    const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (MT / 64) + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (i >= nq) return;
     const WinQuery w = q[i];
     unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, e1 = 0, e2 = 0; // e = octave << 16 | sorted position
@@ -831,6 +851,7 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
     if (tid == 0) *nmatches -= removed;
 }
 
+std::atomic<int> g_last_iterations{0};    // iterations of the last k_resolve_par (-1: it gave up and k_resolve ran)
 std::atomic<int> g_force_sequential{0};   // orbm_debug_force_sequential_resolver: tests run both resolvers
 
 struct SortedFrame {
@@ -897,7 +918,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     if (!lds_attr_set) { // the largest request either instantiation can make
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));   // (it also has static LDS)
         lds_attr_set = true;
     }
     // Window lists: their lengths are known only on the device.  First attempt: every query fills its own region of
@@ -924,7 +945,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                      o_lend = w.carve(sizeof(int) * nq),
                      o_state = w.carve(sizeof(int) * (size_t)std::max(ns, nq));
         const size_t o_res = w.used;
-        const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(3 * sizeof(int));
+        const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(4 * sizeof(int));
         const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
         if (w.reserve(total_bytes, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
         if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
@@ -952,9 +973,12 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         // segments write back touched slots of the state only, so it is preset to -1 as well (the span in between, match_q, is
         // rewritten in full anyway); and the two counters START AT -1: the match count is overwritten (one workgroup) or added
         // to (segments: the host adds the 1 back), the overflow flag is CLEARED to 0 by a list that does not fit
-        {
+        // (k_resolve_par writes every slot and its count itself; the two flags behind the count -- "a list outgrew its region",
+        // "the fixed point was reached" -- are raised by writing this call's generation number, so nothing needs a preset there)
+        const int gen = (int)(w.gen = (w.gen % 0x7ffffffe) + 1);
+        if (sequential) {
             const size_t f0 = seg ? o_state : o_mk;
-            ORBX_HIP(hipMemsetAsync(w.d<char>(f0), 0xff, o_nm + 3 * sizeof(int) - f0, st));   // (+ the "converged" flag of k_resolve_par)
+            ORBX_HIP(hipMemsetAsync(w.d<char>(f0), 0xff, o_nm + sizeof(int) - f0, st));
         }
 
         const WinQuery *dq = w.d<WinQuery>(o_q);
@@ -971,11 +995,11 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         } else if (!exact) {
             lbeg = w.d<int>(o_cnt); lend = w.d<int>(o_lend);
             hipLaunchKernelGGL(k_win_wave<2>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
-                               init_dist, (int *)nullptr, (const int *)nullptr, w.ent, WIN_STRIDE, w.d<int>(o_cnt), w.d<int>(o_lend), dnm + 1, dtop);
+                               init_dist, (int *)nullptr, (const int *)nullptr, w.ent, WIN_STRIDE, w.d<int>(o_cnt), w.d<int>(o_lend), dnm + 1, dtop, gen);
         } else {
             hipLaunchKernelGGL(k_win_wave<0>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
                                init_dist, w.d<int>(o_cnt), (const int *)nullptr, (unsigned *)nullptr, 0, (int *)nullptr, (int *)nullptr,
-                               (int *)nullptr, (unsigned *)nullptr);
+                               (int *)nullptr, (unsigned *)nullptr, gen);
             hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_cnt), nq, doff, dnm + 1);
             if (!sized) { // the total is needed to size the buffer: the one host wait of this (rare) path
                 sized = true;
@@ -986,14 +1010,15 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                 if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
             }
             hipLaunchKernelGGL(k_win_wave<1>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
-                               init_dist, (int *)nullptr, (const int *)doff, w.ent, 0, (int *)nullptr, (int *)nullptr, (int *)nullptr, dtop);
+                               init_dist, (int *)nullptr, (const int *)doff, w.ent, 0, (int *)nullptr, (int *)nullptr, (int *)nullptr, dtop, gen);
         }
         const int *dseg = seg ? w.d<int>(o_seg) : nullptr;
         const dim3 gr(seg ? nseg : 1);
         if (!sequential) {
-            hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(RES_T), sizeof(int) * 2 * (size_t)ns, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend,
+            hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(RES_T), sizeof(int) * 4 * (size_t)ns, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend,
                                nq, ns, (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, (const float *)w.d<float>(o_qang),
-                               (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<int>(o_mq), w.d<int>(o_mk), dnm, dnm + 2);
+                               (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<int>(o_mq), w.d<int>(o_mk), n, (const int *)dnm, gen,
+                               reinterpret_cast<int *>(w.pin + (o_mq - o_res)), reinterpret_cast<int *>(w.pin + (o_mk - o_res)), reinterpret_cast<int *>(w.pin + (o_nm - o_res)));
         } else if (mode == 0) {
             hipLaunchKernelGGL(k_resolve<0>, gr, dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend, nq, ns,
                                (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, w.d<int>(o_acc), w.d<int>(o_state), dnm, dseg);
@@ -1008,18 +1033,20 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                                w.d<int>(o_mq), w.d<int>(o_mk), dnm);
         }
         ORBX_HIP(hipGetLastError());
-        ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));
+        if (sequential) ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));   // (k_resolve_par wrote the block itself)
         ORBX_HIP(hipStreamSynchronize(st));
         int flag = 0;
         memcpy(&flag, w.pin + (o_nm - o_res) + sizeof(int), sizeof(int));
-        if (!cand_off && !exact && flag == 0) { // a window list outgrew its region: once more on the exact path
+        if (!cand_off && !exact && flag == gen) { // a window list outgrew its region: once more on the exact path
             exact = true;
             continue;
         }
         if (!sequential) {
             int conv = 0;
             memcpy(&conv, w.pin + (o_nm - o_res) + 2 * sizeof(int), sizeof(int));
-            if (conv == 0) { sequential = true; continue; }
+            if (conv != gen) { sequential = true; g_last_iterations.store(-1, std::memory_order_relaxed); continue; }
+            memcpy(&conv, w.pin + (o_nm - o_res) + 3 * sizeof(int), sizeof(int));
+            g_last_iterations.store(conv, std::memory_order_relaxed);
         }
         memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
         if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
@@ -1038,6 +1065,8 @@ int orbm_debug_force_sequential_resolver(int on)
 {
     return g_force_sequential.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
+
+int orbm_debug_last_resolver_iterations(void) { return g_last_iterations.load(std::memory_order_relaxed); }
 
 int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
                       float max_x, float max_y, int32_t *perm, int32_t *cell_off, int32_t *nsorted)

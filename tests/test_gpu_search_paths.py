@@ -57,8 +57,8 @@ def test_projection_loop_long_dependency_chains(nk, nq):
     takes = (rng.random(nq) < 0.9).astype(np.uint8)
     bounds = (0.0, 0.0, 640.0, 480.0)
     m = ORBmatcher(0.9, True)
-    got = m.search_projection(q, qd, qa, takes, kps, desc, bounds, np.zeros(nk, np.uint8), None, 256)
-    ref = oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, np.zeros(nk, np.uint8), None, 256, 0.9, False, True)
+    got = m.search_projection(q, qd, qa, takes, kps, desc, bounds, np.zeros(nk, np.uint8), None, 255)
+    ref = oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, np.zeros(nk, np.uint8), None, 255, 0.9, False, True)
     assert ref[2] >= min(nk, nq) // 2
     for g, r in zip(got, ref):
         assert np.array_equal(g, r)

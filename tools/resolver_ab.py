@@ -22,4 +22,6 @@ for name, kw in (("2000 x 2000, one query per keypoint", dict(n=2000, nq=2000, h
             for _ in range(100): f()
             res.setdefault(label, []).append((time.perf_counter() - t0) / 100 * 1e3)
     L.orbm_debug_force_sequential_resolver(0)
+    f()
+    print("  iterations of the fixed point:", L.orbm_debug_last_resolver_iterations())
     print(name, {k: [round(x, 4) for x in v] for k, v in res.items()}, flush=True)
