@@ -1923,9 +1923,10 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
     double *h_points = reinterpret_cast<double *>(m->h_tr_pin);
     float *h_a = reinterpret_cast<float *>(m->h_tr_pin + pbytes), *h_e = h_a + (size_t)m->nmesh * m->ndof;
     memcpy(h_points, points, pbytes);
-    ORBX_HIP(hipMemcpyAsync(m->d_tr_points, h_points, pbytes, hipMemcpyHostToDevice, st));
+    // the kernels read the estimates from, and write the two energies into, the pinned block themselves (it is mapped into the
+    // device's address space): a copy-engine transfer on either side of five short kernels costs more than they do (common.h)
     const int gx = m->tr_nder ? 1 : (3 * m->tr_npoints + 255) / 256;
-    hipLaunchKernelGGL(k_fem_trial_top, dim3(gx > 0 ? gx : 1, m->nmesh), dim3(256), 0, st, m->d_tr_points, m->tr_npoints,
+    hipLaunchKernelGGL(k_fem_trial_top, dim3(gx > 0 ? gx : 1, m->nmesh), dim3(256), 0, st, (const double *)h_points, m->tr_npoints,
                        m->d_tr_derived, m->tr_nder, m->tr_seq, m->d_tr_top);
     hipLaunchKernelGGL(k_fem_trial_a, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_tr_top, m->d_tr_u0, nTop, m->d_a);
     if (m->tr_nids)
@@ -1933,11 +1934,10 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
                            m->d_tr_ids, m->tr_nids, m->tr_klarge);
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
                        m->nnzs, m->ndof, m->d_a, m->d_f);
-    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nmesh,
+    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, h_e, h_e + m->nmesh,
                        (const int4 *)nullptr);
     ORBX_HIP(hipGetLastError());
     if (a_out) ORBX_HIP(hipMemcpyAsync(h_a, m->d_a, abytes, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipMemcpyAsync(h_e, m->d_e, sizeof(float) * 2 * m->nmesh, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));
     if (a_out) memcpy(a_out, h_a, abytes);
     if (sE) memcpy(sE, h_e, sizeof(float) * m->nmesh);

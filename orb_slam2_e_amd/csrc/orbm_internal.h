@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/orbslam_hip.h"
+#include "common.h"
 
 namespace orbm_detail {
 
@@ -102,11 +103,11 @@ struct StagedCall {
     {
         if (w.reserve(w.used, staged > res_bytes ? staged : res_bytes)) return -1;
         for (const In &i : ins) memcpy(w.pin + i.off, i.src, i.bytes);
-        return staged && hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, w.st) != hipSuccess ? -1 : 0;
+        return orbx::stage_in(w.dev, w.pin, staged, w.st) != hipSuccess ? -1 : 0;
     }
     int download()
     {
-        if (res_bytes && hipMemcpyAsync(w.pin, w.dev + res_off, res_bytes, hipMemcpyDeviceToHost, w.st) != hipSuccess) return -1;
+        if (orbx::stage_out(w.pin, w.dev + res_off, res_bytes, w.st) != hipSuccess) return -1;
         return hipStreamSynchronize(w.st) == hipSuccess ? 0 : -1;
     }
 };

@@ -968,7 +968,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
             if (ncand) memcpy(w.h<char>(o_cand), cand_idx, sizeof(int) * ncand);
         }
         if (seg) memcpy(w.h<char>(o_seg), seg, sizeof(int) * (size_t)(nseg + 1));
-        ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
+        ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
         // ONE fill for everything that needs a preset (a launch each was 3-4 us of a 0.1-ms call): match_kp = -1 (slot untouched);
         // segments write back touched slots of the state only, so it is preset to -1 as well (the span in between, match_q, is
         // rewritten in full anyway); and the two counters START AT -1: the match count is overwritten (one workgroup) or added
@@ -1033,7 +1033,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                                w.d<int>(o_mq), w.d<int>(o_mk), dnm);
         }
         ORBX_HIP(hipGetLastError());
-        if (sequential) ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));   // (k_resolve_par wrote the block itself)
+        if (sequential) ORBX_HIP(orbx::stage_out(w.pin, w.dev + o_res, res_bytes, st));   // (k_resolve_par wrote the block itself)
         ORBX_HIP(hipStreamSynchronize(st));
         int flag = 0;
         memcpy(&flag, w.pin + (o_nm - o_res) + sizeof(int), sizeof(int));
@@ -1113,14 +1113,14 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
         memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
     }
     memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
-    ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, w.st));
+    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, w.st));
     int *ob = w.d<int>(o_res);
     hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, w.st, (const WinQuery *)w.d<WinQuery>(o_q),
                        (const uint4 *)w.d<uint4>(o_a), nq, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
                        (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, uright ? 1 : 0, init_dist, (const float *)nullptr, 0, ob, ob + nq,
                        ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(w.pin, ob, sizeof(int) * 5 * (size_t)nq, hipMemcpyDeviceToHost, w.st));
+    ORBX_HIP(orbx::stage_out(w.pin, ob, (sizeof(int) * 5 * (size_t)nq + 15) & ~(size_t)15, w.st));
     ORBX_HIP(hipStreamSynchronize(w.st));
     const int *r = w.h<int>(0);
     memcpy(best, r, sizeof(int) * nq); memcpy(best_level, r + nq, sizeof(int) * nq);
@@ -1170,7 +1170,7 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
     memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
     memcpy(w.h<char>(o_sc), scale_factors, sizeof(float) * nlevels);
     hipStream_t st = w.st;
-    ORBX_HIP(hipMemcpyAsync(w.dev, w.pin, staged, hipMemcpyHostToDevice, st));
+    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
     ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * n, st));
     ORBX_HIP(hipMemsetAsync(w.d<char>(o_nm), 0, sizeof(int), st));
     MapCam mc;
@@ -1191,7 +1191,7 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
     hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, st, (const int *)ob, (const int *)(ob + 4 * m), (const int *)(ob + 2 * m),
                        (const int *)(ob + m), (const int *)(ob + 3 * m), m, th_reloc, nnratio, w.d<int>(o_mk), w.d<int>(o_nm));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(w.pin, w.dev + o_res, res_bytes, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(orbx::stage_out(w.pin, w.dev + o_res, res_bytes, st));
     ORBX_HIP(hipStreamSynchronize(st));
     memcpy(matched_mp, w.pin + (o_mk - o_res), sizeof(int) * n);
     if (nmatches) memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));

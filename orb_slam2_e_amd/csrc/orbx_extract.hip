@@ -1566,6 +1566,17 @@ void resize_axis(int dn, int sn, std::vector<int> &ofs, std::vector<int> &c0, st
     }
 }
 
+// One frame's results into the caller's pinned block: {count, 0, 0, 0}, the keypoint records, the descriptors -- written by the
+// queue that produced them (posted writes over PCIe), 16 bytes per lane.
+__global__ __launch_bounds__(256) void k_result_out(const int *__restrict__ counts, const uint4 *__restrict__ kps, const uint4 *__restrict__ desc,
+                                                    int kps16, int desc16, uint4 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) out[0] = make_uint4((unsigned)counts[0], 0u, 0u, 0u);
+    if (i < kps16) out[1 + i] = kps[i];
+    else if (i < kps16 + desc16) out[1 + i] = desc[i - kps16];
+}
+
 std::mutex g_reg_mu;
 std::vector<orbx_extractor *> g_reg;   // live handles (orbx_create .. orbx_destroy)
 
@@ -1891,7 +1902,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ORBX_HIP(hipMalloc(&ex->d_knode, sizeof(unsigned short) * ex->keys_per_frame * B));
     ORBX_HIP(hipMalloc(&ex->d_kq, ex->keys_per_frame * B));
     ORBX_HIP(hipMalloc(&ex->d_sel, sizeof(uint32_t) * ((size_t)ex->sel_per_frame * B + DESC_KPB)));   // k_describe reads whole chunks of 16 slots
-    ORBX_HIP(hipMalloc(&ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B));
+    ORBX_HIP(hipMalloc(&ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B + 16));   // (+ 16: k_result_out reads whole 16-byte pieces)
     ORBX_HIP(hipMalloc(&ex->d_desc, (size_t)32 * ex->kcap * B));
     ORBX_HIP(hipMemcpy(ex->d_lv, ex->lv, sizeof(LevelInfo) * MAXL, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_cells, ex->cells.data(), sizeof(CellInfo) * ex->cells.size(), hipMemcpyHostToDevice));
@@ -2120,31 +2131,35 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     if (!image || width <= 0 || height <= 0) { *n = 0; return ORBX_OK; } // empty image: outputs untouched (:1054)
     // ORBextractor::operator() on one host image is latency-bound: stage the image and the results through pinned
     // buffers so that the call is one H2D, the kernel chain, one D2H and a single stream synchronisation
-    const size_t in_bytes = (size_t)stride * height;
+    const size_t in_bytes = (size_t)stride * height, in_room = (in_bytes + 255) & ~(size_t)255;   // 16-byte pieces on both sides
     int rc = orbx_reserve(ex, width, height, 1);
     if (rc != ORBX_OK) return rc;
-    const size_t out_bytes = 16 + (sizeof(orbx_keypoint) + 32) * (size_t)ex->kcap;
-    if (in_bytes + out_bytes > ex->pin_bytes) {
+    const size_t kp_bytes = (sizeof(orbx_keypoint) * (size_t)ex->kcap + 15) & ~(size_t)15, de_bytes = (size_t)32 * ex->kcap;
+    const size_t out_bytes = 16 + kp_bytes + de_bytes;
+    if (in_room + out_bytes > ex->pin_bytes) {
         if (ex->h_pin) (void)hipHostFree(ex->h_pin);
         ex->h_pin = nullptr; ex->pin_bytes = 0;
-        ORBX_HIP(hipHostMalloc((void **)&ex->h_pin, in_bytes + out_bytes, hipHostMallocDefault));
-        ex->pin_bytes = in_bytes + out_bytes;
+        ORBX_HIP(hipHostMalloc((void **)&ex->h_pin, in_room + out_bytes, hipHostMallocDefault));
+        ex->pin_bytes = in_room + out_bytes;
     }
-    if (in_bytes > ex->in_bytes) {
+    if (in_room > ex->in_bytes) {
         if (ex->d_in) ORBX_HIP(hipFree(ex->d_in));
         ex->d_in = nullptr;
-        ORBX_HIP(hipMalloc(&ex->d_in, in_bytes));
-        ex->in_bytes = in_bytes;
+        ORBX_HIP(hipMalloc(&ex->d_in, in_room));
+        ex->in_bytes = in_room;
     }
     hipStream_t st = ex->stream;
     memcpy(ex->h_pin, image, in_bytes);
-    ORBX_HIP(hipMemcpyAsync(ex->d_in, ex->h_pin, in_bytes, hipMemcpyHostToDevice, st));
+    // image in and results out by the compute queue itself (common.h: stage_in / stage_out): no hand-over to the copy engine
+    // in front of and behind the twelve kernels of a frame
+    ORBX_HIP(orbx::stage_in(ex->d_in, ex->h_pin, in_room, st));
     rc = orbx_extract_batch(ex, ex->d_in, 1, width, height, stride, in_bytes, 1, st);
     if (rc != ORBX_OK) return rc;
-    uint8_t *o = ex->h_pin + in_bytes;
-    ORBX_HIP(hipMemcpyAsync(o, ex->d_counts, sizeof(int), hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipMemcpyAsync(o + 16, ex->d_kps, sizeof(orbx_keypoint) * ex->kcap, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipMemcpyAsync(o + 16 + sizeof(orbx_keypoint) * ex->kcap, ex->d_desc, (size_t)32 * ex->kcap, hipMemcpyDeviceToHost, st));
+    uint8_t *o = ex->h_pin + in_room;
+    hipLaunchKernelGGL(k_result_out, dim3((unsigned)(((kp_bytes + de_bytes) / 16 + 255) / 256)), dim3(256), 0, st, (const int *)ex->d_counts,
+                       reinterpret_cast<const uint4 *>(ex->d_kps), reinterpret_cast<const uint4 *>(ex->d_desc), (int)(kp_bytes / 16),
+                       (int)(de_bytes / 16), reinterpret_cast<uint4 *>(o));
+    ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(st));
     int cnt = 0;
     memcpy(&cnt, o, sizeof(int));
@@ -2152,7 +2167,7 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "keypoint buffer too small");
     if (cnt > 0) {
         if (kps) memcpy(kps, o + 16, sizeof(orbx_keypoint) * cnt);
-        if (desc) memcpy(desc, o + 16 + sizeof(orbx_keypoint) * ex->kcap, (size_t)32 * cnt);
+        if (desc) memcpy(desc, o + 16 + kp_bytes, (size_t)32 * cnt);
     }
     return ORBX_OK;
 }
