@@ -11,5 +11,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_IN
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc4.log 2>&1
 find $OUT -name "*.csv" | head -20
+# texture addresser / L1 pass (k_describe, k_fem_spmv are bound there): optional as well
+rocprofv3 --pmc TA_TA_BUSY_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc6 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc6.log 2>&1 || true
 # matrix-core pass (the all-pairs matcher): optional, a missing counter must not lose the passes above
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 --output-format csv -d $OUT/pmc5 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc5.log 2>&1 || true
