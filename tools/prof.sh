@@ -12,6 +12,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $GRAFT_RE
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc4.log 2>&1
 find $OUT -name "*.csv" | head -20
 # texture addresser / L1 pass (k_describe, k_fem_spmv are bound there): optional as well
-rocprofv3 --pmc TA_TA_BUSY_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc6 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc6.log 2>&1 || true
+# (a request for more counters than one pass can hold aborts rocprofv3 and leaves the child hanging: few counters per pass, every pass under `timeout`)
+timeout -k 10 300 rocprofv3 --pmc TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc6 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc6.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $OUT/pmc7 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc7.log 2>&1 || true
 # matrix-core pass (the all-pairs matcher): optional, a missing counter must not lose the passes above
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 --output-format csv -d $OUT/pmc5 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc5.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 --output-format csv -d $OUT/pmc5 -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc5.log 2>&1 || true
