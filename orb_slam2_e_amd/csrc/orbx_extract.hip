@@ -1678,7 +1678,7 @@ int orbx_destroy(orbx_extractor *ex)
     if (ex->reader_ev) (void)hipEventDestroy(ex->reader_ev);
     free_workspace(ex);
     if (ex->d_in) (void)hipFree(ex->d_in);
-    void *stp[] = {ex->d_st_key, ex->d_st_rk, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
+    void *stp[] = {ex->d_st_key, ex->d_st_rk, ex->d_st_rowoff, ex->d_st_items, ex->d_uright, ex->d_depth, ex->d_st_scale, ex->d_st_sad, ex->d_st_nvalid};
     for (void *q : stp)
         if (q) (void)hipFree(q);
     if (ex->h_pin) (void)hipHostFree(ex->h_pin);

@@ -99,6 +99,7 @@ struct orbx_extractor {
     size_t pin_bytes = 0;
     unsigned *d_st_key = nullptr;
     void *d_st_rk = nullptr; // row bands of the right keypoints (orbx_stereo.hip)
+    int *d_st_rowoff = nullptr, *d_st_items = nullptr; // vRowIndices as a CSR table per frame
     float *d_uright = nullptr, *d_depth = nullptr, *d_st_scale = nullptr;
     int *d_st_sad = nullptr, *d_st_nvalid = nullptr;
     int st_batch = 0;

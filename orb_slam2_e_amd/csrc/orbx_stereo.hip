@@ -1,8 +1,8 @@
 // orbx_stereo.hip -- Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the
 // device-resident results of a left and a right orbx_extractor.
 //
-//   k_stereo_prep     row band of every right keypoint (:537-554)
-//   k_stereo_hamming  row-band / octave / disparity gating + best Hamming match (:556-610)
+//   k_stereo_rows     vRowIndices: per image row the right keypoints whose band covers it (:537-554), a CSR table per frame
+//   k_stereo_hamming  the row's candidates: octave / disparity gating + best Hamming match (:556-610)
 //   k_stereo_refine   11x11 L1 correlation over 11 shifts on the left keypoint's
 //                     pyramid level, parabola sub-pixel fit, depth (:612-683)
 //   k_stereo_median   median cut 1.5*1.4*median of the correlation distances (:687-700)
@@ -30,45 +30,84 @@ __device__ __forceinline__ int hamming256(const uint4 &a0, const uint4 &a1, cons
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// Row band of every right keypoint (vRowIndices, :537-554): r = 2 * scale[octave], rows floor(y - r) .. ceil(y + r).
-__global__ __launch_bounds__(ST_T) void k_stereo_prep(const orbx_keypoint *__restrict__ kpR, const int *__restrict__ cntR, int cap,
-                                                      const float *__restrict__ scaleFactors, RightKp *__restrict__ rk)
+// vRowIndices (:537-554): for every image row the right keypoints whose band r = 2 * scale[octave], rows floor(y - r) ..
+// ceil(y + r), covers it -- as a CSR table per frame, built by ONE workgroup per frame: row counts in LDS (atomics: the
+// order inside a row's list is irrelevant, the matcher's key minimum reproduces "first index wins"), scan, fill.  A left
+// keypoint then looks at its own row's list only (~50 candidates of 2,000: scanning all right keypoints per left keypoint
+// made the row-band match 26 % of a 64-pair batch).
+constexpr int ROWS_T = 1024, ROWS_MAX = 4096;   // (orbx_reserve limits an image side to 4,000 px)
+__global__ __launch_bounds__(ROWS_T) void k_stereo_rows(const orbx_keypoint *__restrict__ kpR, const int *__restrict__ cntR, int cap,
+                                                        const float *__restrict__ scaleFactors, int nRows, int items_cap,
+                                                        RightKp *__restrict__ rk, int *__restrict__ rowoff, int *__restrict__ items)
 {
-    const int f = blockIdx.y, j = blockIdx.x * ST_T + threadIdx.x;
-    if (j >= min(cntR[f], cap)) return;
-    const orbx_keypoint k = kpR[(size_t)f * cap + j];
-    const float r = 2.0f * scaleFactors[k.octave]; // :546
-    RightKp o;
-    o.maxr = (short)(int)ceilf(k.y + r);
-    o.minr = (short)(int)floorf(k.y - r);
-    o.octave = k.octave; o.x = k.x;
-    rk[(size_t)f * cap + j] = o;
+    __shared__ int cnt[ROWS_MAX + 1];
+    __shared__ int wsum[ROWS_T / 64];
+    const int f = blockIdx.x, tid = threadIdx.x, Nr = min(cntR[f], cap);
+    for (int r = tid; r <= nRows; r += ROWS_T) cnt[r] = 0;
+    __syncthreads();
+    for (int j = tid; j < Nr; j += ROWS_T) {
+        const orbx_keypoint k = kpR[(size_t)f * cap + j];
+        const float r = 2.0f * scaleFactors[k.octave]; // :546
+        RightKp o;
+        o.maxr = (short)(int)ceilf(k.y + r);
+        o.minr = (short)(int)floorf(k.y - r);
+        o.octave = k.octave; o.x = k.x;
+        rk[(size_t)f * cap + j] = o;
+        for (int y = max((int)o.minr, 0); y <= min((int)o.maxr, nRows - 1); ++y) atomicAdd(&cnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0 .. nRows] in place: contiguous chunks per thread, wave scan, one hop across waves
+    const int per = (nRows + 1 + ROWS_T - 1) / ROWS_T, lo = min(tid * per, nRows + 1), hi = min(lo + per, nRows + 1);
+    int sum = 0;
+    for (int r = lo; r < hi; ++r) sum += cnt[r];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((tid & 63) >= o) incl += t; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    int *ro = rowoff + (size_t)f * (nRows + 1);
+    for (int r = lo; r < hi; ++r) { const int c = cnt[r]; cnt[r] = base; ro[r] = base; base += c; }   // cnt becomes the fill cursor
+    __syncthreads();
+    int *it = items + (size_t)f * items_cap;
+    for (int j = tid; j < Nr; j += ROWS_T) {
+        const RightKp o = rk[(size_t)f * cap + j];
+        for (int y = max((int)o.minr, 0); y <= min((int)o.maxr, nRows - 1); ++y) {
+            const int pos = atomicAdd(&cnt[y], 1);
+            if (pos < items_cap) it[pos] = j;
+        }
+    }
 }
 
-// One wave per left keypoint (4 per workgroup): the lanes stride over the right keypoints' row bands; the few
-// that pass the row / octave / disparity gates get a Hamming distance; wave minimum of dist << 16 | iR.
+// One wave per left keypoint (4 per workgroup): the lanes stride over vRowIndices[row of the keypoint]; the candidates that
+// pass the octave / disparity gates get a Hamming distance; wave minimum of dist << 16 | iR.
 __global__ __launch_bounds__(ST_T) void k_stereo_hamming(const orbx_keypoint *__restrict__ kpL, const uint8_t *__restrict__ dL,
                                                          const int *__restrict__ cntL, const RightKp *__restrict__ rkR,
-                                                         const uint8_t *__restrict__ dR, const int *__restrict__ cntR,
+                                                         const uint8_t *__restrict__ dR, const int *__restrict__ rowoff,
+                                                         const int *__restrict__ items, int items_cap,
                                                          int cap, int nRows, float maxD, unsigned *__restrict__ best_key)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int iL = blockIdx.x * (ST_T / 64) + (threadIdx.x >> 6);
-    const int N = min(cntL[f], cap), Nr = min(cntR[f], cap);
+    const int N = min(cntL[f], cap);
     if (iL >= N) return;
     const orbx_keypoint k = kpL[(size_t)f * cap + iL];
     const uint4 *A = reinterpret_cast<const uint4 *>(dL + ((size_t)f * cap + iL) * 32);
     const uint4 a0 = A[0], a1 = A[1];
     const int levelL = k.octave;
-    int row = (int)k.y;                    // vRowIndices[vL], :569
+    const int row = (int)k.y;              // vRowIndices[vL], :569
     const float minU = k.x - maxD;         // :574
     const float maxU = k.x - 0.0f;         // :575 (minD = 0)
     unsigned key = 95u << 16;              // bestDist = TH_HIGH, bestIdxR = 0 (:580-581)
     if (!(row < 0 || row >= nRows || maxU < 0)) { // else no candidates (:571-578)
         const RightKp *rk = rkR + (size_t)f * cap;
-        for (int j = lane; j < Nr; j += 64) {
+        const int *ro = rowoff + (size_t)f * (nRows + 1), *it = items + (size_t)f * items_cap;
+        const int k0 = ro[row], k1 = min(ro[row + 1], items_cap);
+        for (int q = k0 + lane; q < k1; q += 64) {
+            const int j = it[q];
             const RightKp r = rk[j];
-            if (row >= r.minr && row <= r.maxr && r.octave >= levelL - 1 && r.octave <= levelL + 1 && r.x >= minU && r.x <= maxU) {
+            if (r.octave >= levelL - 1 && r.octave <= levelL + 1 && r.x >= minU && r.x <= maxU) {
                 const uint4 *Bp = reinterpret_cast<const uint4 *>(dR + ((size_t)f * cap + j) * 32);
                 const unsigned k2 = ((unsigned)hamming256(a0, a1, Bp[0], Bp[1]) << 16) | (unsigned)j;
                 key = k2 < key ? k2 : key; // dist<bestDist in iR order == min over (dist, iR), :598-602
@@ -92,6 +131,7 @@ __global__ __launch_bounds__(256) void k_stereo_refine(const orbx_keypoint *__re
 {
     __shared__ uint8_t s_l[4][11 * 11];
     __shared__ uint8_t s_r[4][11 * 21];
+    __shared__ int s_p[4][121];
     const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int iL = blockIdx.x * 4 + wv;
     const int N = min(cntL[f], cap);
@@ -124,17 +164,33 @@ __global__ __launch_bounds__(256) void k_stereo_refine(const orbx_keypoint *__re
                 }
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
-                // lanes 0..10: L1 distance for incR = lane - 5 (IL, IR minus their centre pixels, :625-645)
+                // L1 distance for incR = s - 5 (IL, IR minus their centre pixels, :625-645): the 121 (shift s, row dy) row sums over
+                // the lanes (two per lane; integers: any summation order), then lanes 0..10 add up their shift's eleven rows
+                // (one lane per shift walking all 121 pixels kept 53 of 64 lanes idle for ~700 instructions)
+                {
+                    const int cL = s_l[wv][5 * 11 + 5];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int t = lane + 64 * h;
+                        if (t < 121) {
+                            const int sft = t / 11, dy = t - 11 * sft, cR = s_r[wv][5 * 21 + 5 + sft];
+                            int acc = 0;
+#pragma unroll
+                            for (int dx = 0; dx < 11; ++dx) {
+                                const int d = ((int)s_l[wv][dy * 11 + dx] - cL) - ((int)s_r[wv][dy * 21 + sft + dx] - cR);
+                                acc += d < 0 ? -d : d;
+                            }
+                            s_p[wv][t] = acc;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
                 float dist = 0.0f;
                 if (lane < 11) {
-                    const int cL = s_l[wv][5 * 11 + 5], cR = s_r[wv][5 * 21 + 5 + lane];
                     int acc = 0;
-                    for (int dy = 0; dy < 11; ++dy)
-                        for (int dx = 0; dx < 11; ++dx) {
-                            const int a = (int)s_l[wv][dy * 11 + dx] - cL, b = (int)s_r[wv][dy * 21 + lane + dx] - cR;
-                            const int d = a - b;
-                            acc += d < 0 ? -d : d;
-                        }
+#pragma unroll
+                    for (int dy = 0; dy < 11; ++dy) acc += s_p[wv][lane * 11 + dy];
                     dist = (float)acc;
                 }
                 float vd[11];
@@ -250,10 +306,15 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
     ORBX_NEED_DEVICE();
     hipStream_t st = stream_ ? (hipStream_t)stream_ : left->stream;
     const int B = left->last_batch, cap = left->kcap;
+    if (left->lv[0].h > ROWS_MAX) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 4,096 image rows");
+    // a right keypoint's band: floor(y - r) .. ceil(y + r), r = 2 * scale[octave] -> at most 2 ceil(r) + 3 rows
+    const int items_cap = cap * (2 * (int)ceilf(2.0f * left->scale[left->nlevels - 1]) + 3);
     if (!left->d_st_key || left->st_batch < B) {
-        if (left->d_st_key) { (void)hipFree(left->d_st_rk); (void)hipFree(left->d_st_key); (void)hipFree(left->d_uright); (void)hipFree(left->d_depth); (void)hipFree(left->d_st_sad); (void)hipFree(left->d_st_scale); (void)hipFree(left->d_st_nvalid); }
+        if (left->d_st_key) { (void)hipFree(left->d_st_rk); (void)hipFree(left->d_st_rowoff); (void)hipFree(left->d_st_items); (void)hipFree(left->d_st_key); (void)hipFree(left->d_uright); (void)hipFree(left->d_depth); (void)hipFree(left->d_st_sad); (void)hipFree(left->d_st_scale); (void)hipFree(left->d_st_nvalid); }
         ORBX_HIP(hipMalloc(&left->d_st_key, sizeof(unsigned) * (size_t)cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_st_rk, sizeof(RightKp) * (size_t)cap * left->batch));
+        ORBX_HIP(hipMalloc(&left->d_st_rowoff, sizeof(int) * (size_t)(ROWS_MAX + 1) * left->batch));   // (any image height the handle is given later)
+        ORBX_HIP(hipMalloc(&left->d_st_items, sizeof(int) * (size_t)items_cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_uright, sizeof(float) * (size_t)cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_depth, sizeof(float) * (size_t)cap * left->batch));
         ORBX_HIP(hipMalloc(&left->d_st_sad, sizeof(int) * (size_t)cap * left->batch));
@@ -270,11 +331,11 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
     left->st_stream = st;
     const float maxD = mbf / mb; // :557-559
     const int nRows = left->lv[0].h;
-    hipLaunchKernelGGL(k_stereo_prep, dim3((cap + ST_T - 1) / ST_T, B), dim3(ST_T), 0, st, right->d_kps, right->d_counts, cap,
-                       left->d_st_scale, (RightKp *)left->d_st_rk);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(B), dim3(ROWS_T), 0, st, right->d_kps, right->d_counts, cap, left->d_st_scale, nRows, items_cap,
+                       (RightKp *)left->d_st_rk, left->d_st_rowoff, left->d_st_items);
     hipLaunchKernelGGL(k_stereo_hamming, dim3((cap + ST_T / 64 - 1) / (ST_T / 64), B), dim3(ST_T), 0, st, left->d_kps, left->d_desc,
-                       left->d_counts, (const RightKp *)left->d_st_rk, right->d_desc, right->d_counts, cap, nRows, maxD,
-                       left->d_st_key);
+                       left->d_counts, (const RightKp *)left->d_st_rk, right->d_desc, (const int *)left->d_st_rowoff,
+                       (const int *)left->d_st_items, items_cap, cap, nRows, maxD, left->d_st_key);
     hipLaunchKernelGGL(k_stereo_refine, dim3((cap + 3) / 4, B), dim3(256), 0, st, left->d_kps, left->d_counts, right->d_kps,
                        cap, left->d_st_key, left->d_pyr, right->d_pyr, left->frame_bytes, left->d_lv, left->d_st_scale,
                        left->d_st_scale + MAXL, maxD, mbf, left->d_uright, left->d_depth, left->d_st_sad);

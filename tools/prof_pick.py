@@ -42,13 +42,14 @@ lines = ["| kernel | launches | grid (threads) | avg us | " + " | ".join(names) 
 keep = [k for k in dur if k.startswith("k_")]
 for k in sorted(keep, key=lambda k: -dur[k][0] * (7 if k in PER_LEVEL else 1)):
     lines.append(f"| {k} | {dur[k][1]} | {dur[k][2]} | {dur[k][0]:.1f} | " + " | ".join(f"{ctr[k][c]:.4g}" if c in ctr[k] else "" for c in names) + " |")
-lines += ["", "Derived (per launch; 1024 SIMDs, 256 CUs; GRBM_GUI_ACTIVE = the launch's clocks):", "",
+lines += ["", "Derived (per launch; 1024 SIMDs, 256 CUs; clocks = GRBM_GUI_ACTIVE / 8, the counter being summed over the 8 XCDs):", "",
           "| kernel | VALU issue fraction (SQ_INSTS_VALU x 4 / (1024 x clocks)) | TA busy fraction (TA_TA_BUSY_sum / (256 x clocks)) | L1 accesses per wave-wide VMEM instruction | L1 -> L2 read requests per L1 access |", "|---|---|---|---|---|"]
 for k in sorted(keep, key=lambda k: -dur[k][0]):
     c = ctr[k]
     clk = c.get("GRBM_GUI_ACTIVE")
     if not clk:
         continue
+    clk /= 8.0          # the counter is accumulated over the 8 XCDs (k_fast_cells: 1.61e6 for an 80-us launch = 8 x 2.5 GHz)
     vm = c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)
     f = lambda x: f"{x:.3f}" if x is not None else ""
     lines.append(f"| {k} | {f(c['SQ_INSTS_VALU'] * 4 / (1024 * clk)) if 'SQ_INSTS_VALU' in c else ''} | "
