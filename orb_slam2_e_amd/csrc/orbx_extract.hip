@@ -1682,6 +1682,7 @@ int orbx_destroy(orbx_extractor *ex)
     for (void *q : stp)
         if (q) (void)hipFree(q);
     if (ex->h_pin) (void)hipHostFree(ex->h_pin);
+    if (ex->h_st_pin) (void)hipHostFree(ex->h_st_pin);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
     return ORBX_OK;

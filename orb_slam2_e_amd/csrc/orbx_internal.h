@@ -100,6 +100,7 @@ struct orbx_extractor {
     unsigned *d_st_key = nullptr;
     void *d_st_rk = nullptr; // row bands of the right keypoints (orbx_stereo.hip)
     int *d_st_rowoff = nullptr, *d_st_items = nullptr; // vRowIndices as a CSR table per frame
+    uint8_t *h_st_pin = nullptr; size_t st_pin_bytes = 0; // pinned block of orbx_stereo_download
     float *d_uright = nullptr, *d_depth = nullptr, *d_st_scale = nullptr;
     int *d_st_sad = nullptr, *d_st_nvalid = nullptr;
     int st_batch = 0;

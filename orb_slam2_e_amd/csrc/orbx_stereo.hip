@@ -292,6 +292,15 @@ __global__ __launch_bounds__(MED_T) void k_stereo_median(const int *__restrict__
         if (sd[i] >= 0 && !((float)sd[i] < thDist)) { uRight[(size_t)f * cap + i] = -1.0f; depth[(size_t)f * cap + i] = -1.0f; }
 }
 
+// one frame's count, mvuRight and mvDepth into the caller's pinned block
+__global__ __launch_bounds__(256) void k_stereo_out(const int *__restrict__ count, const float *__restrict__ u, const float *__restrict__ d, int cap,
+                                                    int *__restrict__ out_n, float *__restrict__ out_u, float *__restrict__ out_d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *out_n = *count;
+    if (i < cap) { out_u[i] = u[i]; out_d[i] = d[i]; }
+}
+
 } // namespace
 
 extern "C" {
@@ -348,16 +357,29 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
 int orbx_stereo_download(orbx_extractor *left, int frame, float *uRight, float *depth, int cap, int *n)
 {
     if (!left || !left->d_uright || frame < 0 || frame >= left->last_batch || !n) ORBX_FAIL(ORBX_ERR_ARG, "no stereo results");
-    hipStream_t st = left->st_stream;   // the copies wait for the stereo match's stream only
-    int cnt = 0;
-    ORBX_HIP(hipMemcpyAsync(&cnt, left->d_counts + frame, sizeof(int), hipMemcpyDeviceToHost, st));
+    hipStream_t st = left->st_stream;   // queued behind the stereo match on ITS stream, one wait for that stream only
+    // {count, mvuRight[kcap], mvDepth[kcap]} of the frame into a pinned block by the compute queue itself (common.h: no
+    // hand-over to the copy engine), ONE synchronisation
+    const size_t vec = (sizeof(float) * (size_t)left->kcap + 15) & ~(size_t)15, need = 16 + 2 * vec;
+    if (need > left->st_pin_bytes) {
+        if (left->h_st_pin) (void)hipHostFree(left->h_st_pin);
+        left->h_st_pin = nullptr; left->st_pin_bytes = 0;
+        ORBX_HIP(hipHostMalloc((void **)&left->h_st_pin, need, hipHostMallocDefault));
+        left->st_pin_bytes = need;
+    }
+    hipLaunchKernelGGL(k_stereo_out, dim3((unsigned)((left->kcap + 255) / 256)), dim3(256), 0, st, (const int *)left->d_counts + frame,
+                       (const float *)left->d_uright + (size_t)frame * left->kcap, (const float *)left->d_depth + (size_t)frame * left->kcap,
+                       left->kcap, reinterpret_cast<int *>(left->h_st_pin), reinterpret_cast<float *>(left->h_st_pin + 16),
+                       reinterpret_cast<float *>(left->h_st_pin + 16 + vec));
+    ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(st));
+    int cnt = 0;
+    memcpy(&cnt, left->h_st_pin, sizeof(int));
     *n = cnt;
     if (cnt > cap) ORBX_FAIL(ORBX_ERR_CAPACITY, "buffer too small");
     if (cnt > 0) {
-        if (uRight) ORBX_HIP(hipMemcpyAsync(uRight, left->d_uright + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
-        if (depth) ORBX_HIP(hipMemcpyAsync(depth, left->d_depth + (size_t)frame * left->kcap, sizeof(float) * cnt, hipMemcpyDeviceToHost, st));
-        ORBX_HIP(hipStreamSynchronize(st));
+        if (uRight) memcpy(uRight, left->h_st_pin + 16, sizeof(float) * cnt);
+        if (depth) memcpy(depth, left->h_st_pin + 16 + vec, sizeof(float) * cnt);
     }
     return ORBX_OK;
 }
