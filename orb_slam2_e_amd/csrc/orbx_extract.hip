@@ -1963,9 +1963,18 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         const LevelInfo &l0 = ex->lv[0];
         const int aligned = (((uintptr_t)d_img | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
         pf.start(0, st);
-        if (aligned && l0.w % 8 == 0 && l0.w >= 64) {
-            const int rows = l0.h + 2 * EDGE, pp = l0.w / 8, nleft = PADX / 4 - ((PADX - EDGE) >> 2);
-            const int nb = nleft + ((PADX + l0.w + EDGE - 1) >> 2) - ((PADX + l0.w) >> 2) + 1;
+        // the linear form splits a piece index p into (row, piece) with the reciprocal inv = ceil(2^32 / d): exact while
+        // p (inv d - 2^32) < 2^32 for every p < rows d -- holds with room for any size orbx_reserve accepts (sides <= 4,000 px:
+        // 2 M x 500), checked here all the same so that a larger limit one day cannot shift pixels by a row unnoticed
+        auto recip_exact = [](uint64_t count, uint64_t d) {
+            const uint64_t inv = (0x100000000ull + d - 1) / d;
+            return count == 0 || (count - 1) * (inv * d - 0x100000000ull) < 0x100000000ull;
+        };
+        const int rows0 = l0.h + 2 * EDGE, pp0 = l0.w / 8, nleft0 = PADX / 4 - ((PADX - EDGE) >> 2);
+        const int nb0 = nleft0 + ((PADX + l0.w + EDGE - 1) >> 2) - ((PADX + l0.w) >> 2) + 1;
+        if (aligned && l0.w % 8 == 0 && l0.w >= 64 && recip_exact((uint64_t)rows0 * pp0, (uint64_t)pp0) && recip_exact((uint64_t)rows0 * nb0, (uint64_t)nb0)) {
+            const int rows = rows0, pp = pp0, nleft = nleft0;
+            const int nb = nb0;
             const int nblk_int = (rows * pp + 255) / 256, nblk_b = (rows * nb + 63) / 64;
             hipLaunchKernelGGL(k_pyr_level0_lin, dim3(nblk_int + nblk_b, 1, batch), dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr,
                                ex->frame_bytes, l0, pp, (unsigned)((0x100000000ull + pp - 1) / pp), nblk_int, nb,
