@@ -333,11 +333,15 @@ __global__ __launch_bounds__(MT) void k_match_cands(const uint4 *__restrict__ A,
 }
 
 // SearchForTriangulation inner loop (ORBmatcher.cc:892-990) + CheckDistEpipolarLine
-// (:341-358): one query per lane over its BoW-node candidate list, in member order.
+// (:341-358): every query over its BoW-node candidate list (16 lanes per query, see the kernel).
 // `dist>bestDist` is non-strict in the reference, so a later candidate with an equal
 // distance replaces the earlier one; vbMatched2 is never set there, so queries are
 // independent.
 struct TriParams { float F12[9]; float ex, ey; int only_stereo; };
+// 16 lanes per query, four queries per wave: the candidates of a query (its BoW node's members in frame 2, ~30) are taken 16 at a
+// time.  The reference keeps the LAST candidate among those of smallest distance that pass the gates (`dist > bestDist` is
+// non-strict, and the gates do not depend on bestDist), i.e. the minimum of dist << 16 | (0xffff - position in the list).
+// (One lane per query walking its list alone was a 68-us chain of dependent loads for 2,000 queries on 32 waves.)
 __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__restrict__ kps1, const uint4 *__restrict__ A, int nA,
                                                      const orbx_keypoint *__restrict__ kps2, const uint4 *__restrict__ B,
                                                      const int *__restrict__ off, const int *__restrict__ cidx,
@@ -346,9 +350,10 @@ __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__rest
                                                      TriParams tp, const float *__restrict__ scale2, const float *__restrict__ sigma2,
                                                      int *__restrict__ match12, int *__restrict__ bestdist)
 {
-    const int i = blockIdx.x * MT + threadIdx.x;
-    if (i >= nA) return;
-    int bestDist = 45, bestIdx2 = -1; // TH_LOW
+    const int i = (blockIdx.x * MT + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (i >= nA) return;                       // (whole 16-lane groups leave together)
+    unsigned key = 0xffffffffu;
+    int k0 = 0;
     if (!hasmp1[i] && !(tp.only_stereo && !stereo1[i])) {
         const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
         const orbx_keypoint kp1 = kps1[i];
@@ -358,13 +363,15 @@ __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__rest
         const float c = kp1.x * tp.F12[2] + kp1.y * tp.F12[5] + tp.F12[8];
         const float den = a * a + b * b;
         const bool st1 = stereo1[i] != 0;
-        for (int k = off[i]; k < off[i + 1]; ++k) {
+        k0 = off[i];
+        const int k1 = off[i + 1];
+        for (int k = k0 + sub; k < k1; k += 16) {
             const int j = cidx[k];
             if (hasmp2[j]) continue;
             const bool st2 = stereo2[j] != 0;
             if (tp.only_stereo && !st2) continue;
             const int dist = popc256(a0, a1, B[2 * j], B[2 * j + 1]);
-            if (dist > 45 || dist > bestDist) continue;
+            if (dist > 45) continue;           // TH_LOW
             const orbx_keypoint kp2 = kps2[j];
             if (!st1 && !st2) {
                 const float distex = tp.ex - kp2.x, distey = tp.ey - kp2.y;
@@ -373,11 +380,19 @@ __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__rest
             const float num = a * kp2.x + b * kp2.y + c;
             if (den == 0) continue;
             const float dsqr = num * num / den;
-            if ((double)dsqr < 3.84 * (double)sigma2[kp2.octave]) { bestIdx2 = j; bestDist = dist; }
+            if ((double)dsqr < 3.84 * (double)sigma2[kp2.octave]) {
+                const unsigned k2 = ((unsigned)dist << 16) | (0xffffu - (unsigned)min(k - k0, 0xffff));
+                key = k2 < key ? k2 : key;
+            }
         }
     }
-    match12[i] = bestIdx2;
-    bestdist[i] = bestDist;
+#pragma unroll
+    for (int o = 8; o; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    if (sub == 0) {
+        const bool hit = key != 0xffffffffu;
+        match12[i] = hit ? cidx[k0 + (int)(0xffffu - (key & 0xffffu))] : -1;
+        bestdist[i] = hit ? (int)(key >> 16) : 45;
+    }
 }
 
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:305-370), one wave per map
@@ -748,6 +763,8 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
         if (cand_idx[k] < 0 || cand_idx[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "candidate index out of range");
     for (int i = 0; i < n1; ++i)
         if (cand_off[i] > cand_off[i + 1] || cand_off[i] < 0) ORBX_FAIL(ORBX_ERR_ARG, "candidate offsets not monotone");
+    for (int i = 0; i < n1; ++i)
+        if (cand_off[i + 1] - cand_off[i] > 65535) ORBX_FAIL(ORBX_ERR_CAPACITY, "more than 65,535 candidates for one keypoint (the tie rule's position field)");
     for (int j = 0; j < n2; ++j)
         if (kps2[j].octave < 0 || kps2[j].octave >= nlevels) ORBX_FAIL(ORBX_ERR_ARG, "octave out of range");
     StagedCall sc;
@@ -762,7 +779,7 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
     for (int i = 0; i < 9; ++i) tp.F12[i] = F12[i];
     tp.ex = ex; tp.ey = ey; tp.only_stereo = only_stereo ? 1 : 0;
     int *ob = sc.d<int>(o_o);
-    hipLaunchKernelGGL(k_match_triang, dim3((n1 + MT - 1) / MT), dim3(MT), 0, sc.stream(), sc.d<const orbx_keypoint>(o_k1),
+    hipLaunchKernelGGL(k_match_triang, dim3((unsigned)(((size_t)n1 * 16 + MT - 1) / MT)), dim3(MT), 0, sc.stream(), sc.d<const orbx_keypoint>(o_k1),
                        sc.d<const uint4>(o_a), n1, sc.d<const orbx_keypoint>(o_k2), sc.d<const uint4>(o_b), sc.d<const int>(o_off),
                        sc.d<const int>(o_ci), sc.d<const uint8_t>(o_m1), sc.d<const uint8_t>(o_m2), sc.d<const uint8_t>(o_s1),
                        sc.d<const uint8_t>(o_s2), tp, sc.d<const float>(o_sc), sc.d<const float>(o_sg), ob, ob + n1);
