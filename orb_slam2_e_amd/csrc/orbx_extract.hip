@@ -1253,6 +1253,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     }
 }
 
+// (Measured in round 3 and dropped: k_octree and k_blur as ONE launch -- both follow k_fast_cells / the pyramid and precede k_describe,
+// neither needs the other.  66-68 us for the pair instead of 54 + 27 alone, bit-exact, and the pipelined step 3 % SLOWER: the fused
+// kernel allocates the octree's 121 VGPRs and 30 KB of LDS for every blur workgroup too.  Even the refactoring that made the two
+// bodies callable from one kernel -- arguments through structs, the blur's LDS as a dynamic block -- cost the step 5.5 % with every
+// kernel's own time unchanged (0.2737 against 0.2587 ms, three A/B rounds on one box, tools/ab.sh): with static LDS the compiler
+// knows k_blur's occupancy limit and schedules for it.  What a kernel pins while it runs is what the other contexts pay for.)
+
 // ----------------------------------------------------- orientation + rBRIEF
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 {
