@@ -1628,7 +1628,7 @@ void reader_done(orbx_extractor *ex, hipStream_t st)
 extern "C" {
 
 const char *orbx_last_error(void) { return orbx::last_error().c_str(); }
-int orbx_abi_version(void) { return 110; } // 110: + orbm_project_points, fem_create_batch, fem_batch_offsets (additions only)
+int orbx_abi_version(void) { return 120; } // 120: + fem_plan, fem_plan_selfcheck, orbm_sorted_frame, orbx_stereo_download_batch, orbm_debug_* (additions only); 110: + orbm_project_points, fem_create_batch, fem_batch_offsets
 
 int orbx_create(const orbx_params *prm, orbx_extractor **out)
 {
