@@ -140,16 +140,18 @@ def _worker_buckets(rank, world, port, out, nctx, ge, nsteps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nctx,ge,nsteps,full,partial", [(1, 3, 4, 1, 1), (2, 3, 7, 2, 1), (3, 1, 5, 5, 0), (2, 4, 3, 0, 2)])
-def test_bucketed_gather(tmp_path, nctx, ge, nsteps, full, partial):
+@pytest.mark.parametrize("world,nctx,ge,nsteps,full,partial", [(2, 1, 3, 4, 1, 1), (2, 2, 3, 7, 2, 1), (2, 3, 1, 5, 5, 0), (2, 2, 4, 3, 0, 2),
+                                                                (8, 3, 4, 14, 3, 2)])
+def test_bucketed_gather(tmp_path, world, nctx, ge, nsteps, full, partial):
     """`--gather-every ge`: a context's records travel in buckets of ge steps, partial buckets leave on flush();
-    every (step, rank) record arrives exactly once with the right bytes."""
+    every (step, rank) record arrives exactly once with the right bytes.  The last case is BASELINE config 4's shape:
+    8 ranks, the bench's three contexts and four steps per gather."""
     out = str(tmp_path / "b.pkl")
-    mp.spawn(_worker_buckets, args=(2, _free_port(), out, nctx, ge, nsteps), nprocs=2, join=True)
+    mp.spawn(_worker_buckets, args=(world, _free_port(), out, nctx, ge, nsteps), nprocs=world, join=True)
     got, gathers, before_flush = pickle.load(open(out, "rb"))
     assert gathers == full + partial
-    assert before_flush == 2 * ge * full          # what arrived before the flush came in full buckets
-    assert sorted((k, r) for k, r, _ in got) == [(k, r) for k in range(nsteps) for r in range(2)]
+    assert before_flush == world * ge * full      # what arrived before the flush came in full buckets
+    assert sorted((k, r) for k, r, _ in got) == [(k, r) for k in range(nsteps) for r in range(world)]
     for k, r, rec in got:
         assert np.array_equal(rec, _pattern(r, k, 1000)), (k, r)
 
