@@ -330,7 +330,11 @@ def matcher_loops_bench():
     d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
     fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
     m = ORBmatcher(0.6, True)
-    return {"search_by_projection_2000x2000_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
+    from orb_slam2_e_amd.synth import synth_initialization_case
+    ik1, id1, ik2, id2, iprev, ibounds = synth_initialization_case(0)
+    mi = ORBmatcher(0.9, True)
+    return {"search_for_initialization_2000x2200_ms": ms(lambda: mi.SearchForInitialization(ik1, id1, ik2, id2, iprev, ibounds, 100), 30),
+            "search_by_projection_2000x2000_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
             "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
             "search_window_2000x2000_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
 

@@ -213,6 +213,23 @@ def synth_keyframe_pair_case(kps1, desc1, kps2, desc2, seed=0, nwords=90, fx=718
     return fv1, fv2, has1, has2, s1, s2, F12, ex, ey
 
 
+def synth_initialization_case(seed=0, n1=2000, n2=2200):
+    """Two frames for ORBmatcher::SearchForInitialization: frame 2's keypoints are frame 1's, moved by a few pixels, with
+    slightly perturbed descriptors.  Returns (kps1, desc1, kps2, desc2, vbPrevMatched, bounds)."""
+    from .extractor import KP_DTYPE
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    k1 = np.zeros(n1, KP_DTYPE)
+    k1["x"] = rng.uniform(0, 640, n1); k1["y"] = rng.uniform(0, 480, n1)
+    k1["octave"] = rng.choice(8, n1, p=[0.5, 0.15, 0.1, 0.08, 0.07, 0.05, 0.03, 0.02]); k1["angle"] = rng.uniform(0, 360, n1)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    src = rng.integers(0, n1, n2)
+    k2 = k1[src].copy()
+    k2["x"] += rng.normal(0, 6, n2); k2["y"] += rng.normal(0, 6, n2)
+    d2 = d1[src] ^ np.packbits(rng.random((n2, 256)) < 0.03, axis=1, bitorder="little")
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    return k1, d1, k2, d2, prev, (0.0, 0.0, 640.0, 480.0)
+
+
 def synth_projection_case(seed, n=2000, nq=3000, hot=400, stereo=False):
     """Many queries aim at few keypoints, so the in-loop assignment matters."""
     from .extractor import KP_DTYPE
