@@ -925,7 +925,8 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     // WIN_STRIDE entries in one pass (no count, no scan, no host wait); if a list does not fit, the overflow flag comes
     // back with the results and the call is repeated on the exact path (count, scan, fill), whose total also travels
     // with the results -- the host never waits in the middle of a call.
-    constexpr int WIN_STRIDE = 256;
+    // (SearchForInitialization's windows are 200 px wide: a few hundred candidates each, where the projection searches see tens)
+    const int WIN_STRIDE = mode == 1 ? 1024 : 256;
     bool exact = false, sized = false;
     size_t ent_need = cand_off ? (size_t)cand_off[nq] : (size_t)nq * WIN_STRIDE;
     // the projection family (one segment, MODE 0) resolves as a parallel fixed point (k_resolve_par, rotation check fused); if its
