@@ -371,6 +371,85 @@ __global__ void k_fem_trial_a(const float *__restrict__ top, const float *__rest
     a[(size_t)mesh * ndof + i] = (i < 3 * nTop ? top[(size_t)mesh * 3 * nTop + i] : u) - u;
 }
 
+// The hook's five steps as TWO launches (they were five, 4-5 us each, for 40 trials per frame).
+// (1) k_fem_trial_a_fused, ONE workgroup per mesh: the vertex estimates -> float top layer (read straight from the caller's
+// pinned block), the derived mid-edge / barycentre nodes (FEA2.cc:1746-1775; in the reference's order when one builds on
+// another), a = uf - u0, the Dirichlet entries of ImposeDirichletEncastre_a -- the steps wait for each other at workgroup
+// barriers instead of at kernel boundaries.
+constexpr int TRIAL_T = 1024;
+__global__ __launch_bounds__(TRIAL_T) void k_fem_trial_a_fused(const double *__restrict__ points, int npoints, const int *__restrict__ derived,
+                                                               int nder, int sequential, float *__restrict__ top, const float *__restrict__ u0,
+                                                               float *__restrict__ a, const int *__restrict__ ids, int nids, float klarge)
+{
+    const int mesh = blockIdx.x, nTop = npoints + nder, ndof = 6 * nTop, tid = threadIdx.x;
+    float *t = top + (size_t)mesh * nTop * 3;
+    const double *p = points + (size_t)mesh * npoints * 3;
+    for (int i = tid; i < 3 * npoints; i += TRIAL_T) t[i] = (float)p[i];
+    __syncthreads();
+    if (nder) {
+        if (sequential) {
+            if (tid == 0)
+                for (int d = 0; d < nder; ++d) {
+                    const int *e = derived + 4 * d;
+                    for (int k = 0; k < 3; ++k)
+                        t[3 * (npoints + d) + k] = e[0] == 2 ? (t[3 * e[1] + k] + t[3 * e[2] + k]) / 2
+                                                             : (t[3 * e[1] + k] + t[3 * e[2] + k] + t[3 * e[3] + k]) / 3;
+                }
+        } else {
+            for (int i = tid; i < 3 * nder; i += TRIAL_T) {
+                const int d = i / 3, k = i - 3 * d;
+                const int *e = derived + 4 * d;
+                t[3 * (npoints + d) + k] = e[0] == 2 ? (t[3 * e[1] + k] + t[3 * e[2] + k]) / 2
+                                                     : (t[3 * e[1] + k] + t[3 * e[2] + k] + t[3 * e[3] + k]) / 3;
+            }
+        }
+        __syncthreads();
+    }
+    float *am = a + (size_t)mesh * ndof;
+    for (int i = tid; i < ndof; i += TRIAL_T) {
+        const float u = u0[i];
+        am[i] = (i < 3 * nTop ? t[i] : u) - u;
+    }
+    __syncthreads();
+    for (int q = tid; q < nids * 3; q += TRIAL_T) am[3 * (ids[q / 3] - 1) + q % 3] = 1 / klarge;
+}
+// (2) k_fem_matvec_energy: f = K a as k_fem_matvec (a thread per row, ascending columns), and the workgroup that finishes LAST
+// (a counter per mesh, which it resets) runs k_fem_energy's reduction -- the same 256 threads, strides and summation order, so
+// sE / nsE have the bits the two separate kernels give -- and writes them where the caller wants them (the pinned block).
+__global__ __launch_bounds__(256) void k_fem_matvec_energy(const float *__restrict__ vals, const int *__restrict__ lcol,
+                                                           const int *__restrict__ rowptr, size_t nnz, int ndof, const float *__restrict__ a,
+                                                           float *__restrict__ f, unsigned *__restrict__ done, float *__restrict__ sE,
+                                                           float *__restrict__ nsE)
+{
+    __shared__ double sh[4];
+    __shared__ int s_last;
+    const int r = blockIdx.x * 256 + threadIdx.x, mesh = blockIdx.y;
+    const float *am = a + (size_t)mesh * ndof;
+    float *fm = f + (size_t)mesh * ndof;
+    if (r < ndof) {
+        const float *v = vals + (size_t)mesh * nnz;
+        float s = 0.0f;
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s += v[k] * am[lcol[k]];
+        fm[r] = s;
+    }
+    __threadfence();                      // this workgroup's rows of f are visible device-wide before it is counted
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&done[mesh], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double s = 0;
+    for (int i = threadIdx.x; i < ndof; i += 256) s += (double)am[i] * (double)__builtin_nontemporal_load(fm + i);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        float e = (float)s;
+        if (e < 0.0f) e = -e;
+        if (sE) sE[mesh] = e;
+        if (nsE) nsE[mesh] = e / (float)(ndof / 3);
+        done[mesh] = 0;                   // ready for the next trial
+    }
+}
+
 // ------------------------------------------------------------------------ CG
 struct CgScal { double rz[2]; double bb; double rr; };
 
@@ -987,6 +1066,7 @@ struct fem_model {
     size_t h_tr_pin_bytes = 0;
     float *d_tr_top = nullptr, *d_tr_u0 = nullptr;
     int *d_tr_derived = nullptr, *d_tr_ids = nullptr;
+    unsigned *d_tr_done = nullptr;   // per mesh: workgroups of k_fem_matvec_energy that have finished
     int cg_it = 0;
     // device
     char *d_tables = nullptr;   // ONE block: node coordinates and every index table below (interior pointers; create_model)
@@ -1012,7 +1092,7 @@ void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_tables, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids, m->d_ke1, m->d_vals_b};
+                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -1891,13 +1971,15 @@ int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids,
             if (derived[4 * d + k] >= npoints) seq = 1; // built on an earlier derived node: keep the reference's order
         }
     }
-    void *old[] = {m->d_tr_points, m->d_tr_top, m->d_tr_u0, m->d_tr_derived, m->d_tr_ids};
+    void *old[] = {m->d_tr_points, m->d_tr_top, m->d_tr_u0, m->d_tr_derived, m->d_tr_ids, m->d_tr_done};
     for (void *q : old)
         if (q) dfree(q);
-    m->d_tr_points = nullptr; m->d_tr_top = m->d_tr_u0 = nullptr; m->d_tr_derived = m->d_tr_ids = nullptr;
+    m->d_tr_points = nullptr; m->d_tr_top = m->d_tr_u0 = nullptr; m->d_tr_derived = m->d_tr_ids = nullptr; m->d_tr_done = nullptr;
     if (ensure_vecs(m) || dalloc(&m->d_tr_points, (size_t)m->nmesh * npoints * 3) || dalloc(&m->d_tr_top, (size_t)m->nmesh * nTop * 3) ||
-        dalloc(&m->d_tr_u0, (size_t)m->ndof) || dalloc(&m->d_tr_derived, (size_t)4 * nder) || dalloc(&m->d_tr_ids, (size_t)nids))
+        dalloc(&m->d_tr_u0, (size_t)m->ndof) || dalloc(&m->d_tr_derived, (size_t)4 * nder) || dalloc(&m->d_tr_ids, (size_t)nids) ||
+        dalloc(&m->d_tr_done, (size_t)m->nmesh))
         ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
+    ORBX_HIP(hipMemset(m->d_tr_done, 0, sizeof(unsigned) * m->nmesh));
     ORBX_HIP(hipMemcpy(m->d_tr_u0, u0, sizeof(float) * m->ndof, hipMemcpyHostToDevice));
     if (nder) ORBX_HIP(hipMemcpy(m->d_tr_derived, derived, sizeof(int) * 4 * nder, hipMemcpyHostToDevice));
     if (nids) ORBX_HIP(hipMemcpy(m->d_tr_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
@@ -1918,24 +2000,16 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
 {
     if (!m || !m->trial_ready || !points) ORBX_FAIL(ORBX_ERR_ARG, "call fem_trial_setup first");
     hipStream_t st = m->stream;
-    const int nTop = m->tr_npoints + m->tr_nder;
     const size_t pbytes = sizeof(double) * (size_t)m->nmesh * m->tr_npoints * 3, abytes = sizeof(float) * (size_t)m->nmesh * m->ndof;
     double *h_points = reinterpret_cast<double *>(m->h_tr_pin);
     float *h_a = reinterpret_cast<float *>(m->h_tr_pin + pbytes), *h_e = h_a + (size_t)m->nmesh * m->ndof;
     memcpy(h_points, points, pbytes);
     // the kernels read the estimates from, and write the two energies into, the pinned block themselves (it is mapped into the
-    // device's address space): a copy-engine transfer on either side of five short kernels costs more than they do (common.h)
-    const int gx = m->tr_nder ? 1 : (3 * m->tr_npoints + 255) / 256;
-    hipLaunchKernelGGL(k_fem_trial_top, dim3(gx > 0 ? gx : 1, m->nmesh), dim3(256), 0, st, (const double *)h_points, m->tr_npoints,
-                       m->d_tr_derived, m->tr_nder, m->tr_seq, m->d_tr_top);
-    hipLaunchKernelGGL(k_fem_trial_a, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_tr_top, m->d_tr_u0, nTop, m->d_a);
-    if (m->tr_nids)
-        hipLaunchKernelGGL(k_fem_displacement_dir, dim3((m->tr_nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_a, m->ndof,
-                           m->d_tr_ids, m->tr_nids, m->tr_klarge);
-    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
-                       m->nnzs, m->ndof, m->d_a, m->d_f);
-    hipLaunchKernelGGL(k_fem_energy, dim3(m->nmesh), dim3(256), 0, st, m->d_a, m->d_f, m->ndof, h_e, h_e + m->nmesh,
-                       (const int4 *)nullptr);
+    // device's address space): a copy-engine transfer on either side of two short kernels costs more than they do (common.h)
+    hipLaunchKernelGGL(k_fem_trial_a_fused, dim3(m->nmesh), dim3(TRIAL_T), 0, st, (const double *)h_points, m->tr_npoints, m->d_tr_derived,
+                       m->tr_nder, m->tr_seq, m->d_tr_top, m->d_tr_u0, m->d_a, m->d_tr_ids, m->tr_nids, m->tr_klarge);
+    hipLaunchKernelGGL(k_fem_matvec_energy, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
+                       m->nnzs, m->ndof, m->d_a, m->d_f, m->d_tr_done, h_e, h_e + m->nmesh);
     ORBX_HIP(hipGetLastError());
     if (a_out) ORBX_HIP(hipMemcpyAsync(h_a, m->d_a, abytes, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));

@@ -145,13 +145,14 @@ class FEA2:
         self._L.fem_trial_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
         check(self._L.fem_trial_setup(self._h, _p(u0), _p(ids), len(ids), Klarge, npoints, _p(der), len(der)))
 
-    def trial_energy(self, points):
+    def trial_energy(self, points, want_a=True):
         """Set_uf + ComputeDisplacement + ComputeForces + ComputeStrainEnergy + NormalizeStrainEnergy
-        for the optimiser's current vertex estimates (double).  Returns (a, sE, nsE)."""
+        for the optimiser's current vertex estimates (double).  Returns (a, sE, nsE); want_a=False: what the hook itself
+        reads back -- the two energies only (a is None)."""
         pts = np.ascontiguousarray(points, np.float64).reshape(self.nmesh, self._npoints, 3)
-        a = np.zeros((self.nmesh, self.Ksize), np.float32)
+        a = np.zeros((self.nmesh, self.Ksize), np.float32) if want_a else None
         sE = np.zeros(self.nmesh, np.float32); nsE = np.zeros(self.nmesh, np.float32)
-        check(self._L.fem_trial_energy(self._h, _p(pts), _p(a), _p(sE), _p(nsE)))
+        check(self._L.fem_trial_energy(self._h, _p(pts), _p(a) if want_a else None, _p(sE), _p(nsE)))
         return a, sE, nsE
 
     def solve_cg(self, b, iters=200, tol=0.0):
