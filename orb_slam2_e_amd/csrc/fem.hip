@@ -256,19 +256,36 @@ __global__ void k_fem_eliminate(float *__restrict__ vals, const int *__restrict_
         if (fixed[r] || fixed[lcol[k]]) vals[(size_t)mesh * nnz + k] = lcol[k] == r ? 1.0f : 0.0f;
 }
 
-// f = K*a in float, one thread per row, ascending column order (= the dense row
-// sum of MultiplyMatricesEigen with exact zeros skipped).
-__global__ void k_fem_matvec(const float *__restrict__ vals, const int *__restrict__ lcol,
-                             const int *__restrict__ rowptr, size_t nnz, int ndof, const float *__restrict__ a,
-                             float *__restrict__ f)
+// f = K*a in float, ascending column order per row (= the dense row sum of MultiplyMatricesEigen with exact zeros skipped, and the
+// oracle's left-to-right sum, bit for bit).  16 lanes per row: they fetch 16 entries of the row side by side -- value, column,
+// a[column] -- and lane 0 of the group adds the 16 products IN ORDER, the products handed down the group one lane per step
+// (DPP row_shl:1).  The order of the additions is the reference's; only the memory round trips run side by side.  (One thread
+// walking its row alone waited for memory at every entry: 34 us for 3,756 rows of ~117 entries, most of an LM trial.)
+// Entries past the row's end contribute +0.0f, which leaves a float sum that started at +0.0f unchanged (it can never be -0.0f).
+__device__ __forceinline__ float fem_row_sum16(const float *__restrict__ v, const int *__restrict__ lcol, const float *__restrict__ am,
+                                               int k0, int k1, int sub)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y;
-    if (r >= ndof) return;
-    const float *v = vals + (size_t)mesh * nnz;
-    const float *am = a + (size_t)mesh * ndof;
     float s = 0.0f;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s += v[k] * am[lcol[k]];
-    f[(size_t)mesh * ndof + r] = s;
+    for (int kb = k0; kb < k1; kb += 16) {
+        const int k = kb + sub;
+        float p = 0.0f;
+        if (k < k1) p = v[k] * am[lcol[k]];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            s += p;                                                                                   // lane 0: + product j of the chunk
+            p = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x101, 0xf, 0xf, true));   // row_shl:1
+        }
+    }
+    return s;   // valid in lane 0 of the 16-lane group
+}
+__global__ __launch_bounds__(256) void k_fem_matvec(const float *__restrict__ vals, const int *__restrict__ lcol,
+                                                    const int *__restrict__ rowptr, size_t nnz, int ndof, const float *__restrict__ a,
+                                                    float *__restrict__ f)
+{
+    const int r = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15, mesh = blockIdx.y;
+    if (r >= ndof) return;
+    const float s = fem_row_sum16(vals + (size_t)mesh * nnz, lcol, a + (size_t)mesh * ndof, rowptr[r], rowptr[r + 1], sub);
+    if (sub == 0) f[(size_t)mesh * ndof + r] = s;
 }
 
 // alpha = rz / p.Ap and beta = rz' / rz of a mesh that has nothing left to do (zero load, or a residual that reached exactly 0
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(TRIAL_T) void k_fem_trial_a_fused(const double *__r
     __syncthreads();
     for (int q = tid; q < nids * 3; q += TRIAL_T) am[3 * (ids[q / 3] - 1) + q % 3] = 1 / klarge;
 }
-// (2) k_fem_matvec_energy: f = K a as k_fem_matvec (a thread per row, ascending columns), and the workgroup that finishes LAST
+// (2) k_fem_matvec_energy: f = K a as k_fem_matvec (16 lanes per row, the additions in ascending column order), and the workgroup that finishes LAST
 // (a counter per mesh, which it resets) runs k_fem_energy's reduction -- the same 256 threads, strides and summation order, so
 // sE / nsE have the bits the two separate kernels give -- and writes them where the caller wants them (the pinned block).
 __global__ __launch_bounds__(256) void k_fem_matvec_energy(const float *__restrict__ vals, const int *__restrict__ lcol,
@@ -423,14 +440,12 @@ __global__ __launch_bounds__(256) void k_fem_matvec_energy(const float *__restri
 {
     __shared__ double sh[4];
     __shared__ int s_last;
-    const int r = blockIdx.x * 256 + threadIdx.x, mesh = blockIdx.y;
+    const int r = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15, mesh = blockIdx.y;
     const float *am = a + (size_t)mesh * ndof;
     float *fm = f + (size_t)mesh * ndof;
     if (r < ndof) {
-        const float *v = vals + (size_t)mesh * nnz;
-        float s = 0.0f;
-        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s += v[k] * am[lcol[k]];
-        fm[r] = s;
+        const float s = fem_row_sum16(vals + (size_t)mesh * nnz, lcol, am, rowptr[r], rowptr[r + 1], sub);
+        if (sub == 0) fm[r] = s;
     }
     __threadfence();                      // this workgroup's rows of f are visible device-wide before it is counted
     __syncthreads();
@@ -1929,7 +1944,7 @@ int fem_matvec(fem_model *m, const float *a, float *f)
     if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
+    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 15) / 16, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_lcol,
                        m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     ORBX_HIP(hipStreamSynchronize(m->stream));
     ORBX_HIP(hipMemcpy(f, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
@@ -1942,7 +1957,7 @@ int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE)
     if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 127) / 128, m->nmesh), dim3(128), 0, m->stream, m->d_vals, m->d_lcol,
+    hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 15) / 16, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_lcol,
                        m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     hipLaunchKernelGGL(k_fem_energy, dim3(m->nseg), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nseg,
                        (const int4 *)m->d_minfo);
@@ -2008,7 +2023,7 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
     // device's address space): a copy-engine transfer on either side of two short kernels costs more than they do (common.h)
     hipLaunchKernelGGL(k_fem_trial_a_fused, dim3(m->nmesh), dim3(TRIAL_T), 0, st, (const double *)h_points, m->tr_npoints, m->d_tr_derived,
                        m->tr_nder, m->tr_seq, m->d_tr_top, m->d_tr_u0, m->d_a, m->d_tr_ids, m->tr_nids, m->tr_klarge);
-    hipLaunchKernelGGL(k_fem_matvec_energy, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
+    hipLaunchKernelGGL(k_fem_matvec_energy, dim3((m->ndof + 15) / 16, m->nmesh), dim3(256), 0, st, m->d_vals, m->d_lcol, m->d_rowptr,
                        m->nnzs, m->ndof, m->d_a, m->d_f, m->d_tr_done, h_e, h_e + m->nmesh);
     ORBX_HIP(hipGetLastError());
     if (a_out) ORBX_HIP(hipMemcpyAsync(h_a, m->d_a, abytes, hipMemcpyDeviceToHost, st));
