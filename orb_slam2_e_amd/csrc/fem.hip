@@ -1842,13 +1842,17 @@ int fem_dirichlet_penalty(fem_model *m, const int32_t *ids, int nids, float klar
     for (int i = 0; i < nids; ++i)
         if (ids[i] - 1 < 0 || ids[i] - 1 >= m->nn) ORBX_FAIL(ORBX_ERR_ARG, "Dirichlet id out of range (reference would write out of bounds)");
     if (nids == 0) return ORBX_OK;
-    int *d_ids = nullptr;
-    if (dalloc(&d_ids, (size_t)nids)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(d_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
+    // the id list through a pinned block that the kernel reads itself (it is mapped into the device's address space): no
+    // device allocation, no blocking pageable copy in front of a 3-us kernel
+    const size_t bytes = sizeof(int) * (size_t)nids;
+    int *h_ids = static_cast<int *>(g_pin_cache.get(bytes));
+    if (!h_ids) ORBX_FAIL(ORBX_ERR_HIP, "pinned allocation failed");
+    memcpy(h_ids, ids, bytes);
     hipLaunchKernelGGL(k_fem_penalty, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->nnzs,
-                       m->d_diag, d_ids, nids, klarge);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
-    dfree(d_ids);
+                       m->d_diag, (const int *)h_ids, nids, klarge);
+    const hipError_t e = hipStreamSynchronize(m->stream);
+    g_pin_cache.put(h_ids);
+    ORBX_HIP(e);
     m->cg_ready = false;
     return ORBX_OK;
 }
@@ -1991,13 +1995,25 @@ int fem_trial_setup(fem_model *m, const float *u0, const int32_t *ids, int nids,
         if (q) dfree(q);
     m->d_tr_points = nullptr; m->d_tr_top = m->d_tr_u0 = nullptr; m->d_tr_derived = m->d_tr_ids = nullptr; m->d_tr_done = nullptr;
     if (ensure_vecs(m) || dalloc(&m->d_tr_points, (size_t)m->nmesh * npoints * 3) || dalloc(&m->d_tr_top, (size_t)m->nmesh * nTop * 3) ||
-        dalloc(&m->d_tr_u0, (size_t)m->ndof) || dalloc(&m->d_tr_derived, (size_t)4 * nder) || dalloc(&m->d_tr_ids, (size_t)nids) ||
+        dalloc(&m->d_tr_u0, (size_t)m->ndof + 4) || dalloc(&m->d_tr_derived, (size_t)4 * nder + 4) || dalloc(&m->d_tr_ids, (size_t)nids + 4) ||
         dalloc(&m->d_tr_done, (size_t)m->nmesh))
         ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemset(m->d_tr_done, 0, sizeof(unsigned) * m->nmesh));
-    ORBX_HIP(hipMemcpy(m->d_tr_u0, u0, sizeof(float) * m->ndof, hipMemcpyHostToDevice));
-    if (nder) ORBX_HIP(hipMemcpy(m->d_tr_derived, derived, sizeof(int) * 4 * nder, hipMemcpyHostToDevice));
-    if (nids) ORBX_HIP(hipMemcpy(m->d_tr_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
+    {   // u0, the derived-node table and the Dirichlet list through ONE pinned block, copied by the compute queue (common.h)
+        const size_t b0 = (sizeof(float) * (size_t)m->ndof + 15) & ~(size_t)15, b1 = (sizeof(int) * 4 * (size_t)nder + 15) & ~(size_t)15,
+                     b2 = (sizeof(int) * (size_t)nids + 15) & ~(size_t)15;
+        char *h = static_cast<char *>(g_pin_cache.get(b0 + b1 + b2));
+        if (!h) ORBX_FAIL(ORBX_ERR_HIP, "pinned allocation failed");
+        memcpy(h, u0, sizeof(float) * m->ndof);
+        if (nder) memcpy(h + b0, derived, sizeof(int) * 4 * nder);
+        if (nids) memcpy(h + b0 + b1, ids, sizeof(int) * nids);
+        hipError_t e = orbx::stage_in(m->d_tr_u0, h, b0, m->stream);
+        if (e == hipSuccess && nder) e = orbx::stage_in(m->d_tr_derived, h + b0, b1, m->stream);
+        if (e == hipSuccess && nids) e = orbx::stage_in(m->d_tr_ids, h + b0 + b1, b2, m->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(m->d_tr_done, 0, sizeof(unsigned) * m->nmesh, m->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+        g_pin_cache.put(h);
+        ORBX_HIP(e);
+    }
     m->tr_npoints = npoints; m->tr_nder = nder; m->tr_nids = nids; m->tr_seq = seq; m->tr_klarge = klarge;
     const size_t pin_bytes = sizeof(double) * (size_t)m->nmesh * npoints * 3 + sizeof(float) * (size_t)m->nmesh * (m->ndof + 2);
     if (pin_bytes > m->h_tr_pin_bytes) {
