@@ -176,6 +176,18 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
                                     "GBps": resident_bytes / (res[0] / iters * 1e-3) / 1e9, "p_only_in_lds": bool(big)} if resident else None),
                       "displacements_gathered": None if xall is None else list(xall.shape),
                       "kernel_ms_per_launch_untimed_pass": split}
+        if nm > 1:
+            # north_star names "the FEM SpMV": k_fem_spmv by itself on the same resident matrix and vectors (the launch-per-phase
+            # kernel; the batches' CG runs in k_fem_cg_resident, which contains the same product), 50 launches under HIP events
+            fea.profile(4)
+            fea.spmv_repeat(50)
+            fea.cg_result()
+            sp = fea.profile_read()["k_fem_spmv"]
+            if sp[1]:
+                sms = sp[0] / sp[1]
+                out[label]["spmv_alone"] = {"kernel": "k_fem_spmv", "launch_ms": sms, "block_form_bytes_per_launch": block_bytes,
+                                            "GBps": block_bytes / (sms * 1e-3) / 1e9, "frac_of_8000": block_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            fea.profile(0)
         # the checker, outside the timed region, on every rank: the iterate the TIMED launches left (the single mesh; the first,
         # the largest and the last mesh of each batch -- the batches' 200 iterations ran in k_fem_cg_resident) against the
         # oracle's CG on the mesh's exported CSR, 1e-5 relative on the nodal displacements (north_star)
