@@ -1880,7 +1880,16 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     // (Since the keys of levels up to 2048 candidates live in registers, the LDS slots only serve larger levels' arrays -- but giving
     // them up (kcap = 0, 28 KB per workgroup) made the step 1 % SLOWER: measured 0.266 against 0.263 ms; kept.)
     ex->oct_kcap = 1536;
-    if (ex->keys_per_frame >= ((size_t)1 << 20)) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates per frame"); // k_octree packs size << 11 | seq
+    {   // k_octree ranks nodes by size << 12 | creation seq: a LEVEL may hold at most 2^20 - 1 candidates (its capacity is a quarter of
+        // its FAST zone: 3x3 strict NMS); per-frame offsets are ints
+        size_t worst = 0;
+        for (int l = 0; l < nl; l++) {
+            const size_t next = l + 1 < nl ? (size_t)ex->lv[l + 1].key_base : ex->keys_per_frame;
+            worst = std::max(worst, next - (size_t)ex->lv[l].key_base);
+        }
+        if (worst >= ((size_t)1 << 20) || ex->keys_per_frame >= ((size_t)1 << 31) || ex->cands_per_frame >= ((size_t)1 << 31))
+            ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^20 FAST candidates in one pyramid level");
+    }
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 

@@ -288,3 +288,21 @@ def test_reserve_sizes_the_workspace_up_front():
     kps, desc = ex(img)
     _kp_equal(kps, okps)
     assert np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("w,h,nfeat", [(1920, 1080, 2000), (1920, 1080, 5000), (3999, 501, 3000)])
+def test_full_hd_and_wide_frames_bit_exact(w, h, nfeat):
+    """Sizes beyond the bench's: the candidate capacity limit is per pyramid level (2^20 - 1, a quarter of the level's FAST
+    zone), so 1920 x 1080 fits (3840 x 2160 does not and must be refused, not mangled)."""
+    import oracle
+    from orb_slam2_e_amd import ORBextractor, OrbxError
+    from orb_slam2_e_amd.synth import synth_frame
+    prm = (nfeat, 1.2, 8, 20, 7)
+    img = synth_frame(7, w, h)
+    k, d = ORBextractor(*prm)(img)
+    ok_, od = oracle.OrbOracle(*prm).extract(img)
+    assert len(k) == len(ok_) >= nfeat - 20 and np.array_equal(d, od) and np.array_equal(k.view(np.uint8), ok_.view(np.uint8))
+    if w == 1920 and nfeat == 2000:
+        with pytest.raises(OrbxError) as e:
+            ORBextractor(*prm)(np.zeros((2160, 3840), np.uint8))
+        assert e.value.code == -5
