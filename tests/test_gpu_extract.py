@@ -292,8 +292,8 @@ def test_reserve_sizes_the_workspace_up_front():
 
 @pytest.mark.parametrize("w,h,nfeat", [(1920, 1080, 2000), (1920, 1080, 5000), (3999, 501, 3000)])
 def test_full_hd_and_wide_frames_bit_exact(w, h, nfeat):
-    """Sizes beyond the bench's: the candidate capacity limit is per pyramid level (2^20 - 1, a quarter of the level's FAST
-    zone), so 1920 x 1080 fits (3840 x 2160 does not and must be refused, not mangled)."""
+    """Sizes beyond the bench's: the candidate capacity limit is per pyramid level (2^21 - 1 slots, a good quarter of the level's
+    FAST zone), so 1920 x 1080 fits (3840 x 2160, 2.1 M slots at level 0, does not and must be refused, not mangled)."""
     import oracle
     from orb_slam2_e_amd import ORBextractor, OrbxError
     from orb_slam2_e_amd.synth import synth_frame
