@@ -1003,17 +1003,33 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             // larger (size, creation seq) key.  Keys (size << kshift | seq, seq < NC <= 2^kshift; 0 for the others) are packed first so that
             // the S x S comparison reads one LDS dword per four nodes (it was 45 % of the kernel as a scalar loop).
             unsigned *okey = reinterpret_cast<unsigned *>(ebase); // free until the splits are numbered below
-            for (int s = tid; s < ((S + 3) & ~3); s += OCT_T) okey[s] = (s < S && cn[s] > 1) ? ((unsigned)cn[s] << kshift) | cs[s] : 0u;
-            __syncthreads();
-            for (int s = tid; s < S; s += OCT_T) {
-                const unsigned k0 = okey[s];
-                if (k0) {
-                    int r = 0;
-                    for (int s2 = 0; s2 < S; s2 += 4) {
-                        const uint4 k4 = *reinterpret_cast<const uint4 *>(okey + s2);
-                        r += (k4.x > k0) + (k4.y > k0) + (k4.z > k0) + (k4.w > k0);
+            if (kshift) {
+                for (int s = tid; s < ((S + 3) & ~3); s += OCT_T) okey[s] = (s < S && cn[s] > 1) ? ((unsigned)cn[s] << kshift) | cs[s] : 0u;
+                __syncthreads();
+                for (int s = tid; s < S; s += OCT_T) {
+                    const unsigned k0 = okey[s];
+                    if (k0) {
+                        int r = 0;
+                        for (int s2 = 0; s2 < S; s2 += 4) {
+                            const uint4 k4 = *reinterpret_cast<const uint4 *>(okey + s2);
+                            r += (k4.x > k0) + (k4.y > k0) + (k4.z > k0) + (k4.w > k0);
+                        }
+                        order[r] = (unsigned short)s;
                     }
-                    order[r] = (unsigned short)s;
+                }
+            } else {
+                // a level with 2^21 candidate slots or more (frames beyond ~8 M pixels): size and sequence do not fit one dword,
+                // the pairs are compared as they are (the plain loop the packed keys replaced: slower, exact)
+                for (int s = tid; s < S; s += OCT_T) {
+                    const int c0 = cn[s], q0 = cs[s];
+                    if (c0 > 1) {
+                        int r = 0;
+                        for (int s2 = 0; s2 < S; ++s2) {
+                            const int c2 = cn[s2];
+                            r += c2 > 1 && (c2 > c0 || (c2 == c0 && (int)cs[s2] > q0));
+                        }
+                        order[r] = (unsigned short)s;
+                    }
                 }
             }
             __syncthreads(); // okey (= ebase) is rewritten below
@@ -1880,17 +1896,19 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     // (Since the keys of levels up to 2048 candidates live in registers, the LDS slots only serve larger levels' arrays -- but giving
     // them up (kcap = 0, 28 KB per workgroup) made the step 1 % SLOWER: measured 0.266 against 0.263 ms; kept.)
     ex->oct_kcap = 1536;
-    {   // k_octree ranks nodes by size << kshift | creation seq (seq < NC <= 2^kshift, kshift = 11 up to a per-level quota of 2,037
-        // features, else 12): a LEVEL may hold fewer than 2^(32 - kshift) candidates (its capacity is a quarter of its FAST zone:
-        // 3 x 3 strict NMS) -- 2^21 with the usual quotas, which a 3840 x 2160 level 0 just fits; per-frame offsets are ints
+    {   // k_octree ranks nodes by size << kshift | creation seq in one dword where that fits (seq < NC <= 2^kshift, kshift = 11 up to
+        // a per-level quota of 2,037 features, else 12; a level's candidate slots -- a good quarter of its FAST zone: 3 x 3 strict
+        // NMS -- below 2^(32 - kshift)), and by the plain pair otherwise (kshift = 0: frames beyond ~8 M pixels, e.g. 3840 x 2160).
+        // What remains a limit: 24 bits for a candidate's index within its level, int offsets per frame.
         size_t worst = 0;
         for (int l = 0; l < nl; l++) {
             const size_t next = l + 1 < nl ? (size_t)ex->lv[l + 1].key_base : ex->keys_per_frame;
             worst = std::max(worst, next - (size_t)ex->lv[l].key_base);
         }
-        const int kshift = ex->NC <= 2048 ? 11 : 12;
-        if (worst >= ((size_t)1 << (32 - kshift)) || ex->keys_per_frame >= ((size_t)1 << 31) || ex->cands_per_frame >= ((size_t)1 << 31))
-            ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "too many FAST candidate slots in one pyramid level (2^21 with per-level quotas up to 2,037 features, else 2^20)");
+        const int ks = ex->NC <= 2048 ? 11 : 12;
+        ex->oct_kshift = worst < ((size_t)1 << (32 - ks)) ? ks : 0;
+        if (worst >= ((size_t)1 << 24) || ex->keys_per_frame >= ((size_t)1 << 31) || ex->cands_per_frame >= ((size_t)1 << 31))
+            ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^24 FAST candidate slots in one pyramid level");
     }
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
@@ -2045,7 +2063,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
                        ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
                        ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
-                       ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap, ex->NC <= 2048 ? 11 : 12);
+                       ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap, ex->oct_kshift);
     pf.stop(3, st);
     pf.start(4, st);
     {

@@ -75,7 +75,7 @@ struct orbx_extractor {
     std::vector<orbx_detail::BlurTile> tiles;
     size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
     int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
-    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, queue_bytes = 0, oct_lds = 0, oct_kcap = 0;
+    int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, queue_bytes = 0, oct_lds = 0, oct_kcap = 0, oct_kshift = 11;
 
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr; // the stream the last batch was queued on (the handle's own or the caller's): downloads wait for it only

@@ -290,10 +290,11 @@ def test_reserve_sizes_the_workspace_up_front():
     assert np.array_equal(desc, odesc)
 
 
-@pytest.mark.parametrize("w,h,nfeat", [(1920, 1080, 2000), (1920, 1080, 5000), (3999, 501, 3000)])
-def test_full_hd_and_wide_frames_bit_exact(w, h, nfeat):
-    """Sizes beyond the bench's: the candidate capacity limit is per pyramid level (2^21 - 1 slots, a good quarter of the level's
-    FAST zone), so 1920 x 1080 fits (3840 x 2160, 2.1 M slots at level 0, does not and must be refused, not mangled)."""
+@pytest.mark.parametrize("w,h,nfeat", [(1920, 1080, 2000), (1920, 1080, 5000), (3999, 501, 3000), (3840, 2160, 4000)])
+def test_full_hd_and_4k_frames_bit_exact(w, h, nfeat):
+    """Sizes beyond the bench's.  k_octree ranks nodes by a packed (size, creation seq) key while a level has fewer than 2^21
+    candidate slots (a good quarter of its FAST zone); a 3840 x 2160 level 0 has 2.1 M and takes the unpacked comparison.
+    4000 x 4000 exceeds the octree's LDS node pool and must be refused, not mangled."""
     import oracle
     from orb_slam2_e_amd import ORBextractor, OrbxError
     from orb_slam2_e_amd.synth import synth_frame
@@ -304,5 +305,5 @@ def test_full_hd_and_wide_frames_bit_exact(w, h, nfeat):
     assert len(k) == len(ok_) >= nfeat - 20 and np.array_equal(d, od) and np.array_equal(k.view(np.uint8), ok_.view(np.uint8))
     if w == 1920 and nfeat == 2000:
         with pytest.raises(OrbxError) as e:
-            ORBextractor(*prm)(np.zeros((2160, 3840), np.uint8))
+            ORBextractor(8000, 1.2, 8, 20, 7)(np.zeros((4000, 4000), np.uint8))
         assert e.value.code == -5
