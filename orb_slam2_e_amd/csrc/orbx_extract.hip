@@ -1680,7 +1680,10 @@ int orbx_create(const orbx_params *prm, orbx_extractor **out)
         }
     if (prm->blur_variant == 1) { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 49; ex->taps[3] = 55; }
     else { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 48; ex->taps[3] = 56; }
+    // DistributeOctTree returns at most N + 3 keypoints for a quota N >= 1 (the last split may overshoot by three) -- and up to
+    // four for N = 0: the single initial node is split before the first "enough nodes" test (ORBextractor.cc:575-669)
     ex->kcap = prm->nfeatures + 3 * nl;
+    for (int l = 0; l < nl; l++) ex->kcap += ex->nfeat[l] == 0 ? 1 : 0;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         g_reg.push_back(ex);

@@ -307,3 +307,17 @@ def test_full_hd_and_4k_frames_bit_exact(w, h, nfeat):
         with pytest.raises(OrbxError) as e:
             ORBextractor(8000, 1.2, 8, 20, 7)(np.zeros((4000, 4000), np.uint8))
         assert e.value.code == -5
+
+
+@pytest.mark.parametrize("nfeat", [1, 3, 5, 10])
+def test_tiny_feature_counts(nfeat):
+    """Per-level quotas of 0 and 1: DistributeOctTree still splits its initial node once, so a level returns up to four
+    keypoints (ORBextractor.cc:575-669) and the frame more than nfeatures + 3 nlevels."""
+    import oracle
+    from orb_slam2_e_amd import ORBextractor
+    from orb_slam2_e_amd.synth import synth_frame
+    prm = (nfeat, 1.2, 8, 20, 7)
+    img = synth_frame(3, 640, 480)
+    k, d = ORBextractor(*prm)(img)
+    ok_, od = oracle.OrbOracle(*prm).extract(img)
+    assert len(k) == len(ok_) > nfeat and np.array_equal(d, od) and np.array_equal(k.view(np.uint8), ok_.view(np.uint8))
