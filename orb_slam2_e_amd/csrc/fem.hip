@@ -118,6 +118,21 @@ __device__ __forceinline__ void fem_gauss_point(const float *P, int gp, const Fe
     }
 }
 
+// (B^T D B)[i][j] at ONE Gauss point, the literal six-term chains of FEA2.cc:1295-1303.  g: that point's gradients [3][NPE].
+template <int NPE>
+__device__ __forceinline__ float fem_ke_gp(const float *g, const FemConst &fc, int ni, int ci, int nj, int cj)
+{
+    const float gxi = g[ni], gyi = g[NPE + ni], gzi = g[2 * NPE + ni];
+    const float gxj = g[nj], gyj = g[NPE + nj], gzj = g[2 * NPE + nj];
+    float Bi[6], Bj[6], BtD[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { Bi[m] = bmat(m, ci, gxi, gyi, gzi); Bj[m] = bmat(m, cj, gxj, gyj, gzj); }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        BtD[k] = Bi[0] * fc.D[k] + Bi[1] * fc.D[6 + k] + Bi[2] * fc.D[12 + k] + Bi[3] * fc.D[18 + k] + Bi[4] * fc.D[24 + k] + Bi[5] * fc.D[30 + k];
+    return BtD[0] * Bj[0] + BtD[1] * Bj[1] + BtD[2] * Bj[2] + BtD[3] * Bj[3] + BtD[4] * Bj[4] + BtD[5] * Bj[5];
+}
+
 // K_e[i][j] = sum over the Gauss points of (B^T D B)[i][j] * Jac, accumulated in Gauss-point order (FEA2.cc:1295-1306).
 // G: [NGP][3][NPE] (one element), JAC: [NGP].
 template <int NPE, int NGP>
@@ -125,20 +140,30 @@ __device__ __forceinline__ float fem_ke_entry(const float *G, const float *JAC, 
 {
     const int ni = i / 3, ci = i - 3 * ni, nj = j / 3, cj = j - 3 * nj;
     float acc = 0.0f;
-    for (int gp = 0; gp < NGP; ++gp) {
-        const float *g = G + gp * 3 * NPE;
-        const float gxi = g[ni], gyi = g[NPE + ni], gzi = g[2 * NPE + ni];
-        const float gxj = g[nj], gyj = g[NPE + nj], gzj = g[2 * NPE + nj];
-        float Bi[6], Bj[6], BtD[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) { Bi[m] = bmat(m, ci, gxi, gyi, gzi); Bj[m] = bmat(m, cj, gxj, gyj, gzj); }
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            BtD[k] = Bi[0] * fc.D[k] + Bi[1] * fc.D[6 + k] + Bi[2] * fc.D[12 + k] + Bi[3] * fc.D[18 + k] + Bi[4] * fc.D[24 + k] + Bi[5] * fc.D[30 + k];
-        const float aux = BtD[0] * Bj[0] + BtD[1] * Bj[1] + BtD[2] * Bj[2] + BtD[3] * Bj[3] + BtD[4] * Bj[4] + BtD[5] * Bj[5];
-        acc += aux * JAC[gp];
-    }
+    for (int gp = 0; gp < NGP; ++gp) acc += fem_ke_gp<NPE>(G + gp * 3 * NPE, fc, ni, ci, nj, cj) * JAC[gp];
     return acc;
+}
+
+// The nine (B_i^T D B_j)[m][n] of a node pair at one Gauss point with only the terms that are not structurally zero: B has
+// three non-zeros per column and D (isotropic: FEA2.cc:56-62) a dense 3 x 3 corner and a diagonal, so of the literal 72
+// products per entry 2 to 3 pairs survive.  The sums keep the literal order (k ascending), and what is left out is exact:
+// every dropped product has a structural +0 factor and -- g, h and g D finite, which the caller guarantees -- is +-0, and
+// x + (+-0) = x for every x != 0; where a whole chain is zero only the SIGN of that zero could differ, and the accumulations
+// this feeds start from +0.0f, (+0) + (+-0) = +0.  (g = node i's gradient, h = node j's.)
+__device__ __forceinline__ void fem_block_gp(float gx, float gy, float gz, float hx, float hy, float hz, const FemConst &fc, float aux[9])
+{
+    const float a0 = gx * fc.D[0], a1 = gx * fc.D[1], a2 = gx * fc.D[2], a3 = gy * fc.D[21], a4 = gz * fc.D[28];      // B_i column 0: [gx 0 0 gy gz 0]
+    aux[0] = a0 * hx + a3 * hy + a4 * hz;
+    aux[1] = a1 * hy + a3 * hx;
+    aux[2] = a2 * hz + a4 * hx;
+    const float b0 = gy * fc.D[6], b1 = gy * fc.D[7], b2 = gy * fc.D[8], b3 = gx * fc.D[21], b5 = gz * fc.D[35];      // column 1: [0 gy 0 gx 0 gz]
+    aux[3] = b0 * hx + b3 * hy;
+    aux[4] = b1 * hy + b3 * hx + b5 * hz;
+    aux[5] = b2 * hz + b5 * hy;
+    const float c0 = gz * fc.D[12], c1 = gz * fc.D[13], c2 = gz * fc.D[14], c4 = gx * fc.D[28], c5 = gy * fc.D[35];   // column 2: [0 0 gz 0 gx gy]
+    aux[6] = c0 * hx + c4 * hz;
+    aux[7] = c1 * hy + c5 * hz;
+    aux[8] = c2 * hz + c4 * hx + c5 * hy;
 }
 
 // One 64-lane workgroup per element (the K_e accessor and the two-kernel assembly): lanes 0..NGP-1 evaluate one Gauss
@@ -212,6 +237,80 @@ __global__ __launch_bounds__(256) void k_fem_assemble_fused(const float *__restr
             const int el = pk >> 6, li = (pk >> 3) & 7, lj = pk & 7;
             v += fem_ke_entry<NPE, NGP>(G + (size_t)el * GSZ, JAC + el * NGP, fc, 3 * li + m, 3 * lj + n);
         }
+        vals[(size_t)mesh * nnz + rowptr[3 * I + m] + 3 * bl + n] = v;
+    }
+}
+
+// The same assembly with the work of a block row shared (the default; k_fem_assemble_fused is kept for a D that is not
+// isotropic).  k_fem_assemble_fused forms every K_e entry by itself -- two B columns picked with selects, the 6 x 6 product
+// with D, ~360 instructions per entry, 2.2 G wave-instructions per 256 config-3 meshes.  Here a thread takes one
+// CONTRIBUTION (element, local i, local j) of the row and forms its nine entries together from the six gradient components
+// (fem_block_gp: 66 flops per Gauss point for all nine), parks them in LDS, and then a thread per scalar of the row's blocks
+// adds its contributions up in the reference's scatter order, exactly as before.  An element whose gradients are not finite
+// or large enough for g D to overflow (the reference's degenerate prisms: NaN / Inf patterns must come out the same) takes
+// the literal chains (fem_ke_gp) instead, flagged per (element, Gauss point) in phase 1.
+#ifndef FEM_ROWS_T
+#define FEM_ROWS_T 64
+#endif
+constexpr int ROWS_T = FEM_ROWS_T;
+template <int NPE, int ELT>
+__global__ __launch_bounds__(ROWS_T) void k_fem_assemble_rows(const float *__restrict__ nodes, int nn, const int *__restrict__ elems,
+                                                           FemConst fc, float glimit, const int *__restrict__ bptr,
+                                                           const int *__restrict__ cptr, const int *__restrict__ contrib_loc,
+                                                           const int *__restrict__ nel_ptr, const int *__restrict__ nel,
+                                                           const int *__restrict__ rowptr, float *__restrict__ vals, size_t nnz)
+{
+    constexpr int NGP = ELT == FEM_TET4 ? 1 : 8;
+    constexpr int GSZ = NGP * 3 * NPE;
+    extern __shared__ float s_fem[];                   // [nelI][GSZ] gradients, [nelI][NGP] weights, [nelI][NGP] flags, [ncI][9] entries
+    const int I = blockIdx.x, mesh = blockIdx.y, tid = threadIdx.x;
+    const int e0 = nel_ptr[I], nelI = nel_ptr[I + 1] - e0;
+    float *G = s_fem, *JAC = s_fem + (size_t)nelI * GSZ, *SAFE = JAC + nelI * NGP, *CV = SAFE + nelI * NGP;
+    for (int t = tid; t < nelI * NGP; t += ROWS_T) {
+        const int el = t / NGP, gp = t - el * NGP, e = nel[e0 + el];
+        float P[NPE * 3];
+#pragma unroll
+        for (int n = 0; n < NPE; ++n) {
+            const float *q = nodes + ((size_t)mesh * nn + elems[e * NPE + n]) * 3;
+            P[3 * n] = q[0]; P[3 * n + 1] = q[1]; P[3 * n + 2] = q[2];
+        }
+        float jac, g[3 * NPE];
+        fem_gauss_point<NPE, ELT, NPE>(P, gp, fc, g, jac);
+        bool safe = true;
+#pragma unroll
+        for (int k = 0; k < 3 * NPE; ++k) { G[(size_t)el * GSZ + gp * 3 * NPE + k] = g[k]; safe = safe && fabsf(g[k]) < glimit; }
+        JAC[t] = jac;
+        SAFE[t] = safe ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    const int b0 = bptr[I], nb = bptr[I + 1] - b0, cbase = cptr[b0], ncI = cptr[b0 + nb] - cbase;
+    for (int t = tid; t < ncI; t += ROWS_T) {
+        const int pk = contrib_loc[cbase + t];
+        const int el = pk >> 6, li = (pk >> 3) & 7, lj = pk & 7;
+        float acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
+        for (int gp = 0; gp < NGP; ++gp) {
+            const float *g = G + (size_t)el * GSZ + gp * 3 * NPE;
+            const float w = JAC[el * NGP + gp];
+            float aux[9];
+            if (SAFE[el * NGP + gp] != 0.0f) {
+                fem_block_gp(g[li], g[NPE + li], g[2 * NPE + li], g[lj], g[NPE + lj], g[2 * NPE + lj], fc, aux);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) aux[k] = fem_ke_gp<NPE>(g, fc, li, k / 3, lj, k % 3);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += aux[k] * w;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) CV[t * 9 + k] = acc[k];
+    }
+    __syncthreads();
+    for (int t = tid; t < nb * 9; t += ROWS_T) {
+        const int bl = t / 9, mn = t - 9 * bl, m = mn / 3, n = mn - 3 * m, b = b0 + bl;
+        float v = 0.0f;
+        for (int c = cptr[b] - cbase; c < cptr[b + 1] - cbase; ++c) v += CV[c * 9 + mn];
         vals[(size_t)mesh * nnz + rowptr[3 * I + m] + 3 * bl + n] = v;
     }
 }
@@ -1069,6 +1168,8 @@ struct fem_model {
     std::vector<int> seg_node0, seg_elem0, seg_nnz0; // [nseg + 1]
     int *d_nel_ptr = nullptr, *d_nel = nullptr, *d_contrib_loc = nullptr; // fused assembly: elements per node, contributions by local element
     int fused_lds = 0;                                                      // LDS bytes of k_fem_assemble_fused (0: two-kernel assembly)
+    int rows_lds = 0;                                                       // LDS bytes of k_fem_assemble_rows (0: D not isotropic / does not fit)
+    float glimit = 0.0f;                                                    // gradients below this keep g D finite (k_fem_assemble_rows)
     float *d_ke1 = nullptr;                                                 // one K_e for the accessor
     int *d_cmesh = nullptr, *d_cmesh_s = nullptr;
     int4 *d_minfo = nullptr, *d_minfo_s = nullptr;
@@ -1439,6 +1540,21 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
         const int ngp = eltype == FEM_TET4 ? 1 : 8;
         const size_t lds = (size_t)y.maxel * (ngp * 3 * npe + ngp) * sizeof(float);
         m->fused_lds = lds <= 64 * 1024 ? (int)std::max(lds, (size_t)16) : 0;
+        // k_fem_assemble_rows: one more flag per Gauss point and nine floats per contribution of the fullest block row; it
+        // leaves out the products with D's structural zeros, so D must have them
+        size_t maxcon = 0;
+        for (int I = 0; I < m->nn; ++I) maxcon = std::max(maxcon, (size_t)(y.cptr[y.bptr[I + 1]] - y.cptr[y.bptr[I]]));
+        const size_t lds_rows = (size_t)y.maxel * (ngp * 3 * npe + 2 * ngp) * sizeof(float) + maxcon * 9 * sizeof(float);
+        bool iso = true;
+        float dmax = 0.0f;
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                const float d = m->fc.D[6 * r + c];
+                if (!((r < 3 && c < 3) || r == c) && d != 0.0f) iso = false;
+                dmax = std::max(dmax, fabsf(d));
+            }
+        m->glimit = !(dmax <= 3.0e38f) ? 0.0f : (dmax > 1.0f ? 8.0e37f / dmax : 8.0e37f);   // NaN / Inf in D: nothing is "safe"
+        m->rows_lds = (m->fused_lds && iso && lds_rows <= 64 * 1024) ? (int)std::max(lds_rows, (size_t)16) : 0;
     }
     {   // node-block tables of k_fem_spmv: bp[I] = blocks before block row I, bcol3[q] = first column of block q
         const int nbr = m->ndof / 3;
@@ -1799,6 +1915,15 @@ int fem_assemble(fem_model *m)
         const dim3 g(m->nn, m->nmesh);
 #define ORBX_FUSED(NPE, ELT)                                                                                                    \
         do {                                                                                                                    \
+            if (m->rows_lds) {                                                                                                  \
+                if (m->rows_lds > 48 * 1024)                                                                                    \
+                    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_assemble_rows<NPE, ELT>),                 \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, m->rows_lds));                     \
+                hipLaunchKernelGGL((k_fem_assemble_rows<NPE, ELT>), g, dim3(ROWS_T), m->rows_lds, st, m->d_nodes, m->nn,           \
+                                   m->d_elems, m->fc, m->glimit, m->d_bptr, m->d_cptr, m->d_contrib_loc, m->d_nel_ptr,          \
+                                   m->d_nel, m->d_rowptr, m->d_vals, m->nnzs);                                                  \
+                break;                                                                                                          \
+            }                                                                                                                   \
             if (m->fused_lds > 48 * 1024)                                                                                       \
                 ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_assemble_fused<NPE, ELT>),                    \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, m->fused_lds));                        \

@@ -601,3 +601,38 @@ def test_resident_cg_at_the_lds_boundary(nn, resident):
         rp, col, val = fea.csr(m)
         ox, _, orel = oracle.fem_cg(rp, col, val, b[m], iters, 0.0)
         assert np.abs(x[m] - ox).max() <= RTOL * np.abs(ox).max(), m
+
+
+@pytest.mark.parametrize("eltype,code", [(FEM_TET4, 4), (FEM_C3D6, 2), (FEM_C3D8, 1)])
+@pytest.mark.parametrize("scale", [1.0, 1e-16, 1e-21, 1e-33, 3e18])
+def test_assembly_shared_rows_zero_signs_and_overflowing_gradients(eltype, code, scale):
+    """k_fem_assemble_rows leaves out the products with the structural zeros of B and D, and hands an (element, Gauss point)
+    whose gradients could overflow g D (or are not finite) to the literal chains.  An axis-aligned mesh without jitter has
+    exact-zero gradient components -- whole chains are zero and only their SIGN could differ: K must equal the oracle's
+    literal loops bit for bit, zero signs included.  Shrinking the coordinates drives the gradients up: 1e-16 keeps them
+    finite with finite products, 1e-21 makes the entries overflow to Inf inside the fast path (same Inf / NaN pattern
+    required), 1e-33 puts g D beyond FLT_MAX and therefore every element on the literal path; 3e18 makes them tiny."""
+    if eltype == FEM_TET4:
+        nodes, elems, _, _ = synth_tet_mesh(3, jitter=0.0)
+        nodes = nodes.astype(np.float32)
+    else:
+        g = np.arange(4, dtype=np.float32)
+        X, Y = np.meshgrid(g, g, indexing="ij")
+        top = np.stack([X.ravel(), Y.ravel(), np.zeros(16, np.float32)], 1).astype(np.float32)
+        nid = lambda i, j: i * 4 + j
+        if eltype == FEM_C3D8:
+            faces = np.array([[nid(i, j), nid(i + 1, j), nid(i + 1, j + 1), nid(i, j + 1)] for i in range(3) for j in range(3)], np.int32)
+        else:
+            faces = np.array([[nid(i, j), nid(i + 1, j), nid(i + 1, j + 1)] for i in range(3) for j in range(3)] +
+                             [[nid(i, j), nid(i + 1, j + 1), nid(i, j + 1)] for i in range(3) for j in range(3)], np.int32)
+        nodes = second_layer(top, 0.5)
+        elems = extrude_elems(faces, len(top))
+    nodes = (nodes.astype(np.float64) * scale).astype(np.float32)
+    fea = FEA2(nodes, elems, eltype)
+    fea.MatrixAssembly()
+    K, ref = fea.K_dense(), oracle.fem_assemble_dense(code, nodes, elems)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(K), nan)
+    assert np.array_equal(K.view(np.uint32)[~nan], ref.view(np.uint32)[~nan])
+    if scale == 1.0:
+        assert (ref == 0).sum() > ref.size // 4 and np.isfinite(ref).all()
