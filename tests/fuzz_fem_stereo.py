@@ -11,7 +11,25 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n):
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
+    if kind == 3:
+        # tetrahedra (config 3's element): a small Kuhn grid with random jitter, a few nodes collapsed onto a neighbour (zero-volume
+        # elements: Inf / NaN gradients) and, now and then, coordinates scaled until entries overflow
+        from orb_slam2_e_amd.synth import synth_tet_mesh
+        dims = tuple(int(v) for v in rng.integers(1, 5, 3))
+        nodes, elems, _, _ = synth_tet_mesh(dims, int(rng.integers(0, 1 << 30)), jitter=float(rng.uniform(0, 0.4)))
+        for k in rng.choice(len(nodes), int(rng.integers(0, 3)), replace=False):
+            nodes[k] = nodes[(k + 1) % len(nodes)]
+        nodes = (nodes.astype(np.float64) * float(rng.choice([1.0, 1.0, 1e-16, 1e-21, 1e-30, 1e15]))).astype(np.float32)
+        elems = elems[rng.permutation(len(elems))]
+        E = int(rng.integers(100, 100000)); nu = float(rng.uniform(0.05, 0.499))
+        fea = FEA2(nodes, elems, FEM_TET4, E=E, nu=nu)
+        fea.MatrixAssembly()
+        K, ref = fea.K_dense(), oracle.fem_assemble_dense(4, nodes, elems, E, nu)
+        nan = np.isnan(ref)
+        if not (np.array_equal(np.isnan(K), nan) and np.array_equal(K.view(np.uint32)[~nan], ref.view(np.uint32)[~nan])):
+            bad += 1; print("MISMATCH fem tet", case, dims, E, nu, flush=True)
+        continue
     g = int(rng.integers(3, 12))
     X, Y = np.meshgrid(np.arange(g, dtype=np.float32), np.arange(g, dtype=np.float32), indexing="ij")
     top = np.stack([X.ravel() + rng.normal(0, 0.15, g * g), Y.ravel() + rng.normal(0, 0.15, g * g), rng.normal(0, 0.3, g * g)], 1).astype(np.float32)
