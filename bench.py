@@ -136,7 +136,8 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         fea.eliminate_dofs(fixed)
         fea.cg_setup(b)
         fea.profile(True)
-        fea.cg_iterate(20); fea.cg_result()           # warm + per-kernel split (untimed pass, all kinds)
+        fea.cg_iterate(iters); fea.cg_result()        # warm + per-kernel split (untimed pass, all kinds): the same length as the timed
+                                                      # pass -- the first full-length launch after a set-up runs ~6 % longer than the next ones
         split = {k: v[0] / max(v[1], 1) for k, v in fea.profile_read().items() if v[1]}
         fea.cg_setup(b)
         fea.profile((4 | 32) if nm > 1 else 0)        # timed region: events around k_fem_spmv / k_fem_cg_resident only (batch);
