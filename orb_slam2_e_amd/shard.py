@@ -66,13 +66,15 @@ class ShardedPipeline:
     rehearsal the payload is staged through the CPU)."""
 
     def __init__(self, rank, world, rec_bytes, ncontexts, gather_every, compute, pack, make_context=None,
-                 stream_ctx=None, on_receive=None, send_device="cpu", coll_device="cpu", enable_gather=True):
+                 stream_ctx=None, on_receive=None, send_device="cpu", coll_device="cpu", enable_gather=True,
+                 gather_single_rank=False):
         self.rank, self.world, self.rec_bytes = rank, world, rec_bytes
         self.GE = max(1, int(gather_every))
         self.compute, self.pack = compute, pack
         self.stream_ctx = stream_ctx or (lambda ctx: contextlib.nullcontext())
         self.on_receive = on_receive
-        self.do_gather = world > 1 and enable_gather
+        # gather_single_rank: run the collective with one rank too (tests: the RCCL call path on a one-GPU box)
+        self.do_gather = (world > 1 or gather_single_rank) and enable_gather
         self.send_device, self.coll_device = torch.device(send_device), torch.device(coll_device)
         self.ctxs = []
         for i in range(max(1, ncontexts)):
