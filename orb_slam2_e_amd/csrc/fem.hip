@@ -346,13 +346,29 @@ __global__ void k_fem_penalty(float *__restrict__ vals, size_t nnz, const int *_
     vals[(size_t)mesh * nnz + diag_idx[d]] = klarge;
 }
 
-__global__ void k_fem_eliminate(float *__restrict__ vals, const int *__restrict__ lcol, const int *__restrict__ rowptr,
-                                size_t nnz, int ndof, const uint8_t *__restrict__ fixed)
+// One thread per 3 x 3 block q (block row I = blk_row[q], first column bcol3[q]): a block none of whose three rows and
+// three columns is fixed -- nearly all of them -- costs two table reads and six flag bytes and leaves the values alone.
+// (One thread per ROW walking its ~40 entries read a column index per non-zero at a 160-byte stride: 0.49 ms per 256 config-3
+// meshes, now 0.05.)
+__global__ __launch_bounds__(256) void k_fem_eliminate(float *__restrict__ vals, const int *__restrict__ blk_row,
+                                                       const int *__restrict__ bcol3, const int *__restrict__ bp,
+                                                       const int *__restrict__ rowptr, int nblk, size_t nnz,
+                                                       const uint8_t *__restrict__ fixed)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, mesh = blockIdx.y;
-    if (r >= ndof) return;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
-        if (fixed[r] || fixed[lcol[k]]) vals[(size_t)mesh * nnz + k] = lcol[k] == r ? 1.0f : 0.0f;
+    const int q = blockIdx.x * 256 + threadIdx.x, mesh = blockIdx.y;
+    if (q >= nblk) return;
+    const int I = blk_row[q], c0 = bcol3[q];
+    const unsigned fr = fixed[3 * I] | (fixed[3 * I + 1] << 1) | (fixed[3 * I + 2] << 2);
+    const unsigned fc = fixed[c0] | (fixed[c0 + 1] << 1) | (fixed[c0 + 2] << 2);
+    if (!(fr | fc)) return;
+    const int j = q - bp[I];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float *row = vals + (size_t)mesh * nnz + rowptr[3 * I + i] + 3 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (((fr >> i) | (fc >> c)) & 1u) row[c] = c0 + c == 3 * I + i ? 1.0f : 0.0f;
+    }
 }
 
 // f = K*a in float, ascending column order per row (= the dense row sum of MultiplyMatricesEigen with exact zeros skipped, and the
@@ -649,16 +665,24 @@ template <int N> __device__ __forceinline__ double dpp_shl_f64(double v)
 // (build_symbolic: the rows 3I, 3I+1, 3I+2 hold the same columns, in triples 3c, 3c+1, 3c+2), block q of block row I
 // (q = bp[I] + j) keeps its nine values together, row-major, at 9 q.  One thread per row.
 __global__ __launch_bounds__(256) void k_fem_to_blocks(const float *__restrict__ vals, float *__restrict__ vals_b,
-                                                       const int *__restrict__ rowptr, const int *__restrict__ bp, int nrows, size_t nnz)
+                                                       const int *__restrict__ rowptr, const int *__restrict__ bp,
+                                                       const int *__restrict__ blk_row, int nblk, size_t nnz)
 {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= nrows) return;
-    const int I = row / 3, i = row - 3 * I, nb = bp[I + 1] - bp[I];
-    const float *src = vals + (size_t)blockIdx.y * nnz + rowptr[row];
-    float *dst = vals_b + (size_t)blockIdx.y * nnz + 9 * (size_t)bp[I] + 3 * i;
-    for (int j = 0; j < nb; ++j) {
-        dst[9 * j] = src[3 * j]; dst[9 * j + 1] = src[3 * j + 1]; dst[9 * j + 2] = src[3 * j + 2];
+    // one thread per block: three 12-byte pieces in (consecutive blocks of a block row read consecutive memory in each of its
+    // three rows), 36 contiguous bytes out (one thread per ROW copying its ~14 triples at a 160-byte stride in and a 36-byte
+    // stride out took 0.29 ms per 256 config-3 meshes; 268 MB in and out)
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nblk) return;
+    const int I = blk_row[q], j = q - bp[I];
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float *src = vals + (size_t)blockIdx.y * nnz + rowptr[3 * I + i] + 3 * j;
+        v[3 * i] = src[0]; v[3 * i + 1] = src[1]; v[3 * i + 2] = src[2];
     }
+    float *dst = vals_b + (size_t)blockIdx.y * nnz + 9 * (size_t)q;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[k] = v[k];
 }
 
 // Ap = K p on the block-major values, workgroup = SPB consecutive rows (a multiple of 3: whole block rows) of one mesh =
@@ -1993,8 +2017,8 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
     uint8_t *d_fixed = nullptr;
     if (dalloc(&d_fixed, (size_t)m->ndof)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     ORBX_HIP(hipMemcpy(d_fixed, fixed.data(), m->ndof, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fem_eliminate, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals,
-                       m->d_lcol, m->d_rowptr, m->nnzs, m->ndof, d_fixed);
+    hipLaunchKernelGGL(k_fem_eliminate, dim3((m->nblk + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals,
+                       m->d_blk_row, m->d_bcol3, m->d_bp, m->d_rowptr, m->nblk, m->nnzs, d_fixed);
     ORBX_HIP(hipStreamSynchronize(m->stream));
     dfree(d_fixed);
     m->cg_ready = false;
@@ -2182,8 +2206,8 @@ int fem_cg_setup(fem_model *m, const double *b)
     const size_t N = (size_t)m->nmesh * m->ndof;
     ORBX_HIP(hipMemcpy(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice));
     // the values as they stand now (assembled, penalties applied), block-major, for k_fem_spmv
-    hipLaunchKernelGGL(k_fem_to_blocks, dim3((m->ndof + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_vals_b, m->d_rowptr,
-                       m->d_bp, m->ndof, m->nnzs);
+    hipLaunchKernelGGL(k_fem_to_blocks, dim3((m->nblk + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_vals_b, m->d_rowptr,
+                       m->d_bp, m->d_blk_row, m->nblk, m->nnzs);
     hipLaunchKernelGGL(k_fem_cg_init, grid_cg(m), dim3(CGT), 0, m->stream, m->d_vals, m->d_diag, m->nnzs,
                        m->ndof, m->nchunk, m->d_b, m->d_x, m->d_r, m->d_p, m->d_dinv, m->d_part[0], m->d_part[1],
                        (const int *)m->d_cmesh, (const int4 *)m->d_minfo);
