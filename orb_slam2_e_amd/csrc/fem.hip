@@ -2,9 +2,11 @@
 //
 // Replaces the numeric core of FEA2 (Thirdparty/g2o/g2o/FEA/src/FEA2.cc):
 //   k_fem_ke        ComputeKeiC3D8 / ComputeKeiC3D6 (:1244-1376) + a linear tet
-//   k_fem_assemble  MatrixAssemblyC3D8/6 (:1379-1624) into CSR, gather form: every
-//                   matrix entry sums its element contributions in element order,
+//   k_fem_assemble_rows  MatrixAssemblyC3D8/6 (:1379-1624) into CSR with K_e formed on the chip, gather form:
+//                   every matrix entry sums its element contributions in element order,
 //                   so no atomics and the result equals the dense scatter-add
+//                   (k_fem_assemble_fused: entry by entry, for a D that is not isotropic;
+//                   k_fem_assemble: from K_e in HBM, when a node's elements do not fit LDS)
 //   k_fem_matvec    ComputeForces f = K*a (:1811-1816), float, row order
 //   k_fem_energy    ComputeStrainEnergy |a^T f| (:1877-1894)
 //   k_fem_spmv / k_fem_cg_update / k_fem_cg_dir: Jacobi-PCG on the resident
