@@ -76,7 +76,7 @@ def _worker(cpu, frames, reps, q, barrier):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--runs", type=int, default=128)
+    ap.add_argument("--runs", type=int, default=512)   # ~11 s of one core at 22 ms per frame (the brief: 10-30 s of CPU work)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--all-cores-frames", type=int, default=16, help="frames per worker in the all-cores pass")
     ap.add_argument("--legs", default="extract", help="comma list of extract, fem, stereo, loops")
