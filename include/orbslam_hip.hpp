@@ -71,6 +71,8 @@ public:
                     std::vector<uint8_t> &descriptors)
     {
         if (image.empty()) return; // :1054-1055: outputs untouched
+        mStatus = orbx_reserve(mHandle, image.cols, image.rows, 1);   // the capacity depends on the frame's aspect ratio (tiny quotas)
+        if (mStatus != ORBX_OK) { keypoints.clear(); descriptors.clear(); return; }
         const int cap = orbx_keypoint_capacity(mHandle);
         keypoints.resize(cap);
         descriptors.resize((size_t)cap * 32);

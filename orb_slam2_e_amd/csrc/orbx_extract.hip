@@ -1558,6 +1558,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 
 namespace {
 
+// slots of a level in the selected-keypoint array: DistributeOctTree's worst case (see orbx_create) + 1
+inline int level_slots(const LevelInfo &lv) { return std::max(lv.N + 4, 4 * lv.nIni); }
+
 void free_workspace(orbx_extractor *ex)
 {
     void *ptrs[] = {ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_blur_frag, ex->d_xt, ex->d_yt, ex->d_cell_count,
@@ -1681,9 +1684,12 @@ int orbx_create(const orbx_params *prm, orbx_extractor **out)
     if (prm->blur_variant == 1) { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 49; ex->taps[3] = 55; }
     else { ex->taps[0] = 18; ex->taps[1] = 34; ex->taps[2] = 48; ex->taps[3] = 56; }
     // DistributeOctTree returns at most N + 3 keypoints for a quota N >= 1 (the last split may overshoot by three) -- and up to
-    // four for N = 0: the single initial node is split before the first "enough nodes" test (ORBextractor.cc:575-669)
-    ex->kcap = prm->nfeatures + 3 * nl;
-    for (int l = 0; l < nl; l++) ex->kcap += ex->nfeat[l] == 0 ? 1 : 0;
+    // four per INITIAL node whatever N is: every initial node is split before the first "enough nodes" test
+    // (ORBextractor.cc:575-669).  The number of initial nodes is round(width / height) of the level (:543), known once the
+    // frame size is (orbx_reserve raises the capacity if 4 nIni exceeds N + 3 on some level: tiny quotas on wide frames)
+    ex->kcap_params = prm->nfeatures + 3 * nl;
+    for (int l = 0; l < nl; l++) ex->kcap_params += ex->nfeat[l] == 0 ? 1 : 0;
+    ex->kcap = ex->kcap_params;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         g_reg.push_back(ex);
@@ -1751,7 +1757,7 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     std::vector<int4> yt;
     ex->cells.clear(); ex->tiles.clear();
     size_t off = 0, cand_off = 0, key_off = 0;
-    int sel_off = 0, maxcw = 0, maxch = 0;
+    int sel_off = 0, maxcw = 0, maxch = 0, kneed = 0;
     ex->maxcells = 0;
     for (int l = 0; l < nl; l++) {
         LevelInfo &lv = ex->lv[l];
@@ -1815,7 +1821,8 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         lv.ncells = (int)ex->cells.size() - lv.cell_base;
         if (lv.ncells > ex->maxcells) ex->maxcells = lv.ncells;
         lv.sel_base = sel_off;
-        sel_off += lv.N + 4;
+        sel_off += level_slots(lv);
+        kneed += std::max(lv.N + 3, 4 * lv.nIni);
         // blur tiles
         for (int y0 = 0; y0 < lv.h; y0 += BLUR_TH)
             for (int x0 = 0; x0 < lv.w; x0 += BLUR_SW) {
@@ -1873,10 +1880,11 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->keys_per_frame = key_off;
     ex->cells_per_frame = (int)ex->cells.size();
     ex->sel_per_frame = sel_off;
+    ex->kcap = std::max(ex->kcap_params, kneed);
     int maxN = 0;
     for (int l = 0; l < nl; l++) {
         if (ex->lv[l].N > maxN) maxN = ex->lv[l].N;
-        if (ex->lv[l].nIni > maxN) maxN = ex->lv[l].nIni;
+        if (4 * ex->lv[l].nIni - 4 > maxN) maxN = 4 * ex->lv[l].nIni - 4;   // the first pass leaves up to 4 nIni nodes
     }
     ex->NC = (maxN + 8 + 3) & ~3; // multiple of 4: the node arrays stay 16-byte aligned (int4 reads in k_octree)
     // tile row = 5 spare bytes + the cell + the packed pre-test's right-hand dword; zone <= 63 (6-bit queue
@@ -2091,7 +2099,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
             const LevelInfo &lv = ex->lv[l];
             D.off[l] = lv.off; D.stride[l] = lv.stride; D.sel_base[l] = lv.sel_base; D.patch[l] = lv.patch; D.scale[l] = lv.scale;
             D.chunk_base[l] = nchunks;
-            nchunks += (lv.N + 4 + DESC_KPB - 1) / DESC_KPB;   // a level holds at most N + 3 keypoints (its slots: N + 4)
+            nchunks += (level_slots(lv) + DESC_KPB - 1) / DESC_KPB;   // a level holds at most max(N + 3, 4 nIni) keypoints
         }
         for (int l = nl; l <= MAXL; l++) D.chunk_base[l] = nchunks;
         hipLaunchKernelGGL(k_describe, dim3(nchunks, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, D, nl,

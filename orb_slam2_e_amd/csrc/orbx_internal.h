@@ -66,7 +66,8 @@ struct orbx_extractor {
     int resident_waves = 8192;              // CUs x 32 wave slots of the device the handle was created on
     int resize_nxi[orbx_detail::MAXL] = {};
     int resize_tailwin[orbx_detail::MAXL] = {}; // the tail tiles of k_pyr_resize may use 8-byte source windows at this level // interior workgroups per row group of k_pyr_resize (0: no fast path at this level)
-    int kcap; // nfeatures + 3*nlevels
+    int kcap; // keypoints per frame the result arrays hold: nfeatures + 3*nlevels, more on wide frames with tiny quotas (orbx_reserve)
+    int kcap_params = 0;
 
     // geometry of the reserved workspace
     int width = 0, height = 0, batch = 0;

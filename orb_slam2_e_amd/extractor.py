@@ -32,6 +32,7 @@ class ORBextractor:
         self.nlevels = nlevels
         self.capacity = self._L.orbx_keypoint_capacity(self._h)
         self._shape = None
+        self._reserved = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -75,6 +76,7 @@ class ORBextractor:
         assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (ORBextractor.cc:1058)"
         image = np.ascontiguousarray(image)
         h, w = image.shape
+        self._reserve(w, h, 1)
         kps = np.zeros(self.capacity, KP_DTYPE)
         desc = np.zeros((self.capacity, 32), np.uint8)
         n = C.c_int(0)
@@ -83,17 +85,27 @@ class ORBextractor:
         self._shape = (h, w)
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def _reserve(self, w, h, B):
+        """The workspace for this frame size; the keypoint capacity follows the size (orbx_reserve: 4 initial-node children per
+        level can exceed quota + 3 on wide frames with tiny quotas)."""
+        if self._reserved != (w, h, B):
+            check(self._L.orbx_reserve(self._h, w, h, B))
+            self._reserved = (w, h, B)
+            self.capacity = self._L.orbx_keypoint_capacity(self._h)
+
     # ---- batch API
     def extract_batch(self, images):
         """images: [B,H,W] uint8 numpy array (host)."""
         images = np.ascontiguousarray(images, dtype=np.uint8)
         B, h, w = images.shape
+        self._reserve(w, h, B)
         check(self._L.orbx_extract_batch(self._h, _p(images), 0, w, h, w, C.c_size_t(w * h), B, None))
         self._shape = (h, w)
         self._last_B = B
 
     def extract_batch_device(self, dev_ptr, B, h, w, stream=None):
         """dev_ptr: device address of [B,H,W] uint8 (e.g. torch tensor .data_ptr())."""
+        self._reserve(w, h, B)
         check(self._L.orbx_extract_batch(self._h, C.c_void_p(dev_ptr), 1, w, h, w, C.c_size_t(w * h), B,
                                          C.c_void_p(stream) if stream else None))
         self._shape = (h, w)

@@ -321,3 +321,31 @@ def test_tiny_feature_counts(nfeat):
     k, d = ORBextractor(*prm)(img)
     ok_, od = oracle.OrbOracle(*prm).extract(img)
     assert len(k) == len(ok_) > nfeat and np.array_equal(d, od) and np.array_equal(k.view(np.uint8), ok_.view(np.uint8))
+
+
+@pytest.mark.parametrize("prm,size", [((108, 1.25, 8, 38, 25), (819, 320)), ((40, 1.2, 8, 20, 7), (1242, 375)),
+                                      ((12, 1.2, 4, 20, 7), (1242, 375)), ((2000, 1.2, 8, 20, 7), (1242, 375))])
+def test_small_quotas_on_wide_frames(prm, size):
+    """DistributeOctTree starts from round(width / height) nodes per level and splits every one of them before it first asks
+    whether there are enough (ORBextractor.cc:543, :575-669): a level returns up to 4 nIni keypoints whatever its quota, 16 per
+    level on a KITTI-shaped frame.  With small quotas that is more than nfeatures + 3 nlevels in total -- the capacity the
+    library reports follows the frame size (found by the differential fuzzer: 137 keypoints against a capacity of 132)."""
+    import oracle
+    from orb_slam2_e_amd import ORBextractor
+    from orb_slam2_e_amd.synth import synth_frame
+    img = synth_frame(1, *size)
+    ex = ORBextractor(*prm)
+    k, d = ex(img)
+    ok_, od = oracle.OrbOracle(*prm).extract(img)
+    assert len(k) == len(ok_) and np.array_equal(d, od) and np.array_equal(k.view(np.uint8), ok_.view(np.uint8))
+    assert ex.capacity >= len(k)
+    if prm[0] < 200:
+        assert len(k) > prm[0] + 3 * prm[2]
+    # the batch entry and a second frame size on the same handle
+    ex.extract_batch(np.stack([img, img[::-1].copy()]))
+    kb, db, cb = ex.download_batch()
+    assert cb[0] == len(k) and np.array_equal(db[0, :cb[0]], od)
+    img2 = synth_frame(2, 640, 480)
+    k2, d2 = ex(img2)
+    ok2, od2 = oracle.OrbOracle(*prm).extract(img2)
+    assert len(k2) == len(ok2) and np.array_equal(d2, od2)
