@@ -546,6 +546,215 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
     if (tid == 0) host_nm[0] = s_nm - removed;
 }
 
+// SearchForInitialization's loop (ORBmatcher.cc:626-696) as a parallel fixed point.  What couples its queries is
+// vMatchedDistance: query i leaves a candidate s out of BOTH its best and its second best when an EARLIER query that accepted s
+// did so at a distance <= dist(i, s) (:645-646); a later acceptor takes the keypoint from the earlier one (:678-682), and since
+// it can only accept s at a distance below the recorded one, vMatchedDistance[s] as query i sees it is M_i(s) = min { d_j : j < i,
+// query j accepted s }.  Given every query's accepted (slot, distance), every query's selection is a function of those alone;
+// iterate from "nobody has accepted anything": query 0 is final after one iteration, and once all j < i are final so is i one
+// iteration later -- a state that reproduces itself is the sequential loop's (the induction of k_resolve_par).  The acceptors
+// of a slot sit in a per-slot list of C entries (query << 9 | distance), rebuilt every iteration; a slot with more acceptors
+// than that, or chains longer than RES_MAXIT, end the kernel unconverged and the host repeats the call on k_resolve<1>.
+// Tail = k_rotation<1>: the match of a slot is its LAST acceptor (the steals), the histogram counts every acceptor, stolen
+// or not (:684-693: rotHist keeps them), only standing matches are removed (:704-708).
+__global__ __launch_bounds__(RES_T) void k_resolve_init_par(const unsigned *__restrict__ ent, const unsigned *__restrict__ top,
+                                                            const int *__restrict__ lbeg, const int *__restrict__ lend, int nq, int ns,
+                                                            int C, int th, float nnratio, const float *__restrict__ qangle,
+                                                            const float *__restrict__ kangle, const int *__restrict__ perm, int check,
+                                                            unsigned *__restrict__ sel_g, const int *__restrict__ flags, int gen,
+                                                            int *__restrict__ host_q, int *__restrict__ host_nm)
+{
+    extern __shared__ __align__(16) int sm[];
+    int *s_cnt = sm, *s_lst = sm + ns;                 // acceptors of slot s: s_lst[s * C .. + min(s_cnt[s], C))
+    int *s_perm = sm + (size_t)ns * (C + 1);
+    float *s_kang = reinterpret_cast<float *>(sm + (size_t)ns * (C + 2));
+    __shared__ int s_changed, s_over, s_nm, hist[HISTO_LENGTH], keep[3], removed;
+    const int tid = threadIdx.x;
+    unsigned tpr[RES_QREG][TOPK];
+    int br[RES_QREG], er[RES_QREG];
+    float qar[RES_QREG];
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r) {
+        const int i = tid + r * RES_T;
+        br[r] = er[r] = 0; qar[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < TOPK; ++k) tpr[r][k] = 0xffffffffu;
+        if (i < nq) {
+            const uint4 t0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i], t1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1];
+            tpr[r][0] = t0.x; tpr[r][1] = t0.y; tpr[r][2] = t0.z; tpr[r][3] = t0.w;
+            tpr[r][4] = t1.x; tpr[r][5] = t1.y; tpr[r][6] = t1.z; tpr[r][7] = t1.w;
+            br[r] = lbeg[i]; er[r] = lend[i]; qar[r] = qangle[i];
+        }
+    }
+    for (int j = tid; j < ns; j += RES_T) { s_cnt[j] = 0; s_perm[j] = perm[j]; s_kang[j] = kangle[j]; }
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) sel_g[i] = 0xfffffffeu;   // queries beyond the registers keep their selection here
+    if (tid == 0) { s_changed = 0; s_over = 0; s_nm = 0; removed = 0; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    // vMatchedDistance[sp] as query i sees it
+    auto matched_before = [&](int sp, int i) -> int {
+        const int c = min(s_cnt[sp], C);
+        int m = INT_MAX;
+        for (int k = 0; k < c; ++k) {
+            const int v = s_lst[sp * C + k];
+            if ((v >> 9) < i) m = min(m, v & 511);
+        }
+        return m;
+    };
+    // query i's accepted entry (dist << 20 | octave << 16 | sp) or 0xffffffff: the selection of k_resolve<1>
+    auto select = [&](int i, const unsigned (&tp)[TOPK], int b, int e) -> unsigned {
+        unsigned en1 = 0xffffffffu;
+        int best = INT_MAX, second = INT_MAX, found = 0;
+#pragma unroll
+        for (int r = 0; r < TOPK; ++r) {
+            const unsigned en = tp[r];
+            if (en != 0xffffffffu && found < 2) {
+                const int dist = (int)(en >> 20);
+                if (matched_before((int)(en & 0xffffu), i) > dist) {
+                    if (found == 0) { en1 = en; best = dist; } else second = dist;
+                    ++found;
+                }
+            }
+        }
+        if (found < 2 && e - b > TOPK) { // the short list ran dry: the whole list
+            unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
+            for (int k = b; k < e; ++k) {
+                const unsigned en = ent[k];
+                if (en != 0xffffffffu && matched_before((int)(en & 0xffffu), i) > (int)(en >> 20)) {
+                    const unsigned key = ((en >> 20) << 16) | (unsigned)(k - b);
+                    const unsigned hi = max(k1, key);
+                    k2 = min(k2, hi);
+                    k1 = min(k1, key);
+                }
+            }
+            en1 = 0xffffffffu; best = second = INT_MAX;
+            if (k1 != 0xffffffffu) { en1 = ent[b + (k1 & 0xffffu)]; best = (int)(k1 >> 16); }
+            if (k2 != 0xffffffffu) second = (int)(k2 >> 16);
+        }
+        const bool acc = en1 != 0xffffffffu && best <= th && (float)best < (float)second * nnratio;   // INT_MAX when alone (:637-638, :674-676)
+        return acc ? en1 : 0xffffffffu;
+    };
+    auto select_global = [&](int i) -> unsigned {
+        unsigned tp[TOPK];
+        const uint4 t0 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i], t1 = reinterpret_cast<const uint4 *>(top)[2 * (size_t)i + 1];
+        tp[0] = t0.x; tp[1] = t0.y; tp[2] = t0.z; tp[3] = t0.w; tp[4] = t1.x; tp[5] = t1.y; tp[6] = t1.z; tp[7] = t1.w;
+        return select(i, tp, lbeg[i], lend[i]);
+    };
+    auto claim = [&](int i, unsigned en) {
+        if (en == 0xffffffffu) return;
+        const int sp = (int)(en & 0xffffu), k = atomicAdd(&s_cnt[sp], 1);
+        if (k < C) s_lst[sp * C + k] = (i << 9) | (int)(en >> 20); else s_over = 1;
+    };
+    __syncthreads();
+    unsigned selr[RES_QREG];
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r) selr[r] = 0xfffffffeu;
+    bool done = false;
+    int it = 0;
+    for (; it < RES_MAXIT; ++it) {
+        bool changed = false;
+#pragma unroll
+        for (int r = 0; r < RES_QREG; ++r) {
+            const int i = tid + r * RES_T;
+            if (i < nq) {
+                const unsigned en = select(i, tpr[r], br[r], er[r]);
+                changed |= en != selr[r];
+                selr[r] = en;
+            }
+        }
+        for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
+            const unsigned en = select_global(i);
+            changed |= en != sel_g[i];
+            sel_g[i] = en;
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        done = s_changed == 0;
+        __syncthreads();
+        if (done) break;
+        if (tid == 0) s_changed = 0;
+        for (int j = tid; j < ns; j += RES_T) s_cnt[j] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RES_QREG; ++r)
+            if (tid + r * RES_T < nq) claim(tid + r * RES_T, selr[r]);
+        for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) claim(i, sel_g[i]);
+        __syncthreads();
+        if (s_over) break;
+    }
+    if (tid == 0) host_nm[1] = flags[1];      // "a list outgrew its region" as k_win_wave left it
+    if (!done) {            // a crowded slot or chains longer than RES_MAXIT: the host repeats the call on the sequential kernel
+        if (tid == 0) host_nm[2] = 0;
+        return;
+    }
+    if (tid == 0) { host_nm[2] = gen; host_nm[3] = it + 1; }
+    // ---- tail: the standing match of a slot is its last acceptor; rotation histogram over all acceptors; rejection
+    int *s_last = s_cnt;
+    for (int j = tid; j < ns; j += RES_T) s_last[j] = -1;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto bin_of = [&](float qa, int sp) {
+        float rot = qa - s_kang[sp];
+        if (rot < 0.0f) rot += 360.0f;
+        const int bin = (int)roundf(rot * factor);
+        return bin == HISTO_LENGTH ? 0 : bin;
+    };
+    int binr[RES_QREG];
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r) {
+        const int i = tid + r * RES_T;
+        binr[r] = -1;
+        if (i < nq && selr[r] != 0xffffffffu) {
+            const int sp = (int)(selr[r] & 0xffffu);
+            atomicMax(&s_last[sp], i);
+            if (check) { binr[r] = bin_of(qar[r], sp); atomicAdd(&hist[binr[r]], 1); }
+        }
+    }
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
+        const unsigned en = sel_g[i];
+        if (en != 0xffffffffu) {
+            atomicMax(&s_last[(int)(en & 0xffffu)], i);
+            if (check) atomicAdd(&hist[bin_of(qangle[i], (int)(en & 0xffffu))], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int sz = hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+    }
+    int nst = 0;
+    for (int j = tid; j < ns; j += RES_T) nst += s_last[j] >= 0;     // nmatches before the rotation check = slots that hold a match
+    if (nst) atomicAdd(&s_nm, nst);
+    __syncthreads();
+    auto finish = [&](int i, unsigned en, int bin) {
+        int out = -1;
+        if (en != 0xffffffffu) {
+            const int sp = (int)(en & 0xffffu);
+            if (s_last[sp] == i) {      // still standing
+                out = s_perm[sp];
+                if (check && bin != keep[0] && bin != keep[1] && bin != keep[2]) { out = -1; atomicAdd(&removed, 1); }
+            }
+        }
+        host_q[i] = out;
+    };
+#pragma unroll
+    for (int r = 0; r < RES_QREG; ++r)
+        if (tid + r * RES_T < nq) finish(tid + r * RES_T, selr[r], binr[r]);
+    for (int i = tid + RES_QREG * RES_T; i < nq; i += RES_T) {
+        const unsigned en = sel_g[i];
+        finish(i, en, check && en != 0xffffffffu ? bin_of(qangle[i], (int)(en & 0xffffu)) : -1);
+    }
+    __syncthreads();
+    if (tid == 0) host_nm[0] = s_nm - removed;
+}
+
 // Window search without coupling between queries = Frame::GetFeaturesInArea (src/Frame.cc:342-395)
 // fused with the best / second-best-with-levels loop of SearchByProjection (ORBmatcher.cc:69-118).
 // One wave per query walks the window's runs of the sorted keypoint array as k_win_wave does; every
@@ -919,6 +1128,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));   // (it also has static LDS)
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_init_par), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         lds_attr_set = true;
     }
     // Window lists: their lengths are known only on the device.  First attempt: every query fills its own region of
@@ -931,7 +1141,10 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     size_t ent_need = cand_off ? (size_t)cand_off[nq] : (size_t)nq * WIN_STRIDE;
     // the projection family (one segment, MODE 0) resolves as a parallel fixed point (k_resolve_par, rotation check fused); if its
     // dependency chains are longer than the kernel iterates, the call is repeated on the one-wave sequential resolver
-    bool sequential = mode != 0 || seg != nullptr || g_force_sequential.load(std::memory_order_relaxed) != 0;
+    // SearchForInitialization (MODE 1) likewise (k_resolve_init_par): its per-slot acceptor lists take C + 3 ints of LDS per keypoint
+    bool sequential = seg != nullptr || g_force_sequential.load(std::memory_order_relaxed) != 0;
+    const int init_c = std::min(7, (144 * 1024 / 4) / ns - 3);
+    if (mode == 1 && init_c < 2) sequential = true;
     for (int attempt = 0; attempt < 4; ++attempt) {
         w.used = 0;
         // staged inputs (same offsets on both sides), then device-only arrays, then the result block
@@ -1015,7 +1228,12 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         }
         const int *dseg = seg ? w.d<int>(o_seg) : nullptr;
         const dim3 gr(seg ? nseg : 1);
-        if (!sequential) {
+        if (!sequential && mode == 1) {
+            hipLaunchKernelGGL(k_resolve_init_par, dim3(1), dim3(RES_T), sizeof(int) * (size_t)(init_c + 3) * ns, st, (const unsigned *)w.ent,
+                               (const unsigned *)dtop, lbeg, lend, nq, ns, init_c, th, nnratio, (const float *)w.d<float>(o_qang),
+                               (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<unsigned>(o_acc), (const int *)dnm, gen,
+                               reinterpret_cast<int *>(w.pin + (o_mq - o_res)), reinterpret_cast<int *>(w.pin + (o_nm - o_res)));
+        } else if (!sequential) {
             hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(RES_T), sizeof(int) * 4 * (size_t)ns, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend,
                                nq, ns, (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, (const float *)w.d<float>(o_qang),
                                (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<int>(o_mq), w.d<int>(o_mk), n, (const int *)dnm, gen,

@@ -53,5 +53,38 @@ for case in range(n):
         print("MISMATCH case", case, "nk", nk, "nq", nq, "crowd", crowd, "th", th, "lvl", lvl, "ori", ori, "iterations", it, flush=True)
     if case % 20 == 19:
         print("...", case + 1, "cases,", bad, "mismatches", flush=True)
+# ORBmatcher::SearchForInitialization (k_resolve_init_par / k_resolve<1>): look-alike queries competing for the same keypoints
+# (steals, the matched-distance gate), random window sizes incl. ones whose lists outgrow their regions
+ifall, iiters = 0, []
+for case in range(max(1, n // 4)):
+    n1 = int(rng.integers(1, 3000)); n2 = int(rng.integers(1, 3000))
+    k1 = np.zeros(n1, KP_DTYPE)
+    k1["x"] = rng.uniform(0, 640, n1); k1["y"] = rng.uniform(0, 480, n1)
+    k1["octave"] = rng.choice(8, n1, p=[0.5, 0.15, 0.1, 0.08, 0.07, 0.05, 0.03, 0.02]); k1["angle"] = rng.uniform(0, 360, n1)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    nalike = int(rng.choice([0, n1 // 10, n1 // 3, n1])); protos = int(rng.choice([1, 3, 30]))
+    if nalike:
+        who = rng.choice(n1, nalike, replace=False)
+        d1[who] = d1[:protos][rng.integers(0, min(protos, n1), nalike)] ^ np.packbits(rng.random((nalike, 256)) < rng.choice([0.0, 0.01]), axis=1, bitorder="little")
+        if rng.random() < 0.5:     # ... and close together, so that they see the same windows
+            k1["x"][who] = rng.uniform(300, 340, nalike); k1["y"][who] = rng.uniform(200, 240, nalike); k1["octave"][who] = 0
+    src = rng.integers(0, n1, n2)
+    k2 = k1[src].copy()
+    k2["x"] += rng.normal(0, 6, n2); k2["y"] += rng.normal(0, 6, n2)
+    k2["angle"] = (k2["angle"] + rng.choice([20.0, 140.0, 250.0], n2, p=[0.7, 0.2, 0.1]) + rng.normal(0, 3, n2)) % 360
+    d2 = d1[src] ^ np.packbits(rng.random((n2, 256)) < rng.choice([0.0, 0.03, 0.08]), axis=1, bitorder="little")
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    window = int(rng.choice([10, 30, 100, 300, 700])); ratio = float(rng.choice([0.6, 0.9, 1.0])); ori = bool(rng.random() < 0.7)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    got = ORBmatcher(ratio, ori).SearchForInitialization(k1, d1, k2, d2, prev.copy(), bounds, window)
+    it = L.orbm_debug_last_resolver_iterations()
+    ifall += it < 0
+    if it > 0: iiters.append(it)
+    ref = oracle.search_for_initialization(k1, d1, k2, d2, prev.copy(), bounds, window, ratio, ori)
+    if not (got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])):
+        bad += 1
+        print("MISMATCH initialization case", case, "n1", n1, "n2", n2, "alike", nalike, protos, "window", window, "ratio", ratio, "ori", ori, "iterations", it, flush=True)
+print("initialization cases", max(1, n // 4), "| fallbacks", ifall, "| fixed-point iterations: median", int(np.median(iiters)) if iiters else 0, "max", max(iiters) if iiters else 0)
 print("cases", n, "mismatches", bad, "| fallbacks to the sequential resolver", fallbacks, "| fixed-point iterations: median", int(np.median(iters)) if iters else 0,
       "max", max(iters) if iters else 0)
+sys.exit(1 if bad else 0)

@@ -322,17 +322,21 @@ def test_search_projection_edge_cases(resolver):
     assert ref[2] > 5 and got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
-@pytest.mark.parametrize("seed,ratio,ori,window", [(0, 0.9, True, 100), (1, 0.9, False, 30), (2, 0.7, True, 100)])
-def test_search_for_initialization(seed, ratio, ori, window):
-    """ORBmatcher::SearchForInitialization whole (steal rule, vMatchedDistance gate, rotation check, prev update)."""
+@pytest.mark.parametrize("seed,ratio,ori,window,n1,alike", [(0, 0.9, True, 100, 2000, 3), (1, 0.9, False, 30, 2000, 3), (2, 0.7, True, 100, 2000, 3),
+                                                            (3, 0.95, True, 100, 2600, 40), (4, 1.0, False, 640, 1500, 1)])
+def test_search_for_initialization(seed, ratio, ori, window, n1, alike, resolver):
+    """ORBmatcher::SearchForInitialization whole (steal rule, vMatchedDistance gate, rotation check, prev update), on the parallel
+    fixed point (k_resolve_init_par) and on the one-wave sequential resolver.  n1 = 2600: more queries than the fixed point keeps in
+    registers; `alike` = 1: 600 look-alike queries after ONE keypoint each of frame 2 -- more acceptors than a slot's list holds,
+    the call repeats itself on the sequential resolver; window 640: every list outgrows its region (the exact path)."""
     from orb_slam2_e_amd import KP_DTYPE
     rng = np.random.default_rng(seed)
-    n1, n2 = 2000, 2200
+    n2 = 2200
     k1 = np.zeros(n1, KP_DTYPE)
     k1["x"] = rng.uniform(0, 640, n1); k1["y"] = rng.uniform(0, 480, n1)
     k1["octave"] = rng.choice(8, n1, p=[0.5, 0.15, 0.1, 0.08, 0.07, 0.05, 0.03, 0.02]); k1["angle"] = rng.uniform(0, 360, n1)
     d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
-    d1[rng.choice(n1, 600, replace=False)] = d1[:3][rng.integers(0, 3, 600)]         # look-alikes compete for the same F2 keypoints
+    d1[rng.choice(n1, 600, replace=False)] = d1[:alike][rng.integers(0, alike, 600)]  # look-alikes compete for the same F2 keypoints
     src = rng.integers(0, n1, n2)
     k2 = k1[src].copy()
     k2["x"] += rng.normal(0, 6, n2); k2["y"] += rng.normal(0, 6, n2)
