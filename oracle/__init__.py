@@ -108,10 +108,14 @@ class OrbOracle:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         h, w = img.shape
         cap = self.nfeatures + 3 * self.nlevels + 64
-        kps = np.zeros(cap, dtype=KP_DTYPE)
-        desc = np.zeros((cap, 32), dtype=np.uint8)
-        n = C.c_int(0)
-        rc = self.L.oracle_orb_extract(self.h, _p(img), w, h, w, _p(kps), _p(desc), cap, C.byref(n))
+        for _ in range(2):
+            kps = np.zeros(cap, dtype=KP_DTYPE)
+            desc = np.zeros((cap, 32), dtype=np.uint8)
+            n = C.c_int(0)
+            rc = self.L.oracle_orb_extract(self.h, _p(img), w, h, w, _p(kps), _p(desc), cap, C.byref(n))
+            if rc != -2:
+                break
+            cap = n.value       # more than quota + 3 per level: 4 keypoints per initial octree node (wide frames, tiny quotas)
         if rc != 0:
             raise RuntimeError(f"oracle_orb_extract rc={rc}")
         return kps[:n.value].copy(), desc[:n.value].copy()
