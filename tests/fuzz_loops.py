@@ -9,6 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import test_fuse_and_projection as tf
+import test_gpu_bow as tbow
 import test_gpu_match as tm
 from orb_slam2_e_amd._lib import lib
 
@@ -28,7 +29,33 @@ def with_resolver(fn, *a):
         L.orbm_debug_force_sequential_resolver(prev)
 
 
+def bow_case(irregular):
+    """DBoW2 descent on random vocabulary trees (regular k^L and k-means-like irregular ones): word, weight and the node at
+    levelsup of every feature against the oracle's literal descent, and the assembled BowVector / FeatureVector."""
+    import oracle
+    from orb_slam2_e_amd.vocabulary import ORBVocabulary, assemble_bow
+    if irregular:
+        off, ids, desc, word, weight, Lv = tbow._irregular_vocabulary(S(), int(rng.integers(1, 7)))
+    else:
+        k, Lv = [(4, 3), (5, 4), (7, 3), (10, 2), (10, 3), (12, 2), (4, 5)][int(rng.integers(0, 7))]   # (the generator wants k >= 4 and >= 50 words)
+        off, ids, desc, word, weight, Lv = tbow._synthetic_vocabulary(k, Lv, S())
+    leaves = np.where(word >= 0)[0]
+    nf = int(rng.integers(1, 3000))
+    feats = desc[rng.choice(leaves, nf)] ^ np.packbits(rng.random((nf, 256)) < rng.choice([0.0, 0.04, 0.3]), axis=1, bitorder="little")
+    levelsup = int(rng.integers(0, Lv + 3))
+    voc = ORBVocabulary(off, ids, desc, word, weight, Lv)
+    got = voc.descend(feats, levelsup)
+    ref = oracle.bow_descend(off, ids, desc, word, weight, Lv, feats, levelsup)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    gb, gf = voc.transform(feats, levelsup)
+    rb, rf = assemble_bow(*ref)
+    assert gb == rb and gf == rf
+
+
 CASES = [
+    ("bow descent, regular tree", lambda: bow_case(False)),
+    ("bow descent, irregular tree", lambda: bow_case(True)),
     ("triangulation inner loop", lambda: tm.test_search_for_triangulation_inner_loop(S(), B())),
     ("triangulation whole", lambda: tm.test_search_for_triangulation_whole_function(S(), B(), B())),
     ("window == grid + selection", lambda: tm.test_search_window_equals_grid_then_selection(S(), B(), int(rng.choice([256, 2**31 - 1])))),
