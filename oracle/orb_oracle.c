@@ -658,6 +658,13 @@ int oracle_orb_extract(oracle_orb *o, const uint8_t *img, int w, int h, int stri
     int level, total = 0, offset = 0, i;
     if (!img || w <= 0 || h <= 0) { if (n_out) *n_out = 0; return 0; } /* :1054 empty image: untouched */
     free_state(o);
+    /* a level narrower or lower than 56 px has no 30-px cell (nCols = (w - 26) / 30 = 0: the reference divides by it, :781-787;
+     * a level of 0 or 1 px cannot even be bordered): decided before the pyramid is built */
+    for (level = 0; level < o->nlevels; level++)
+        if (oracle_cvRound((float)w * o->mvInvScaleFactor[level]) < 56 || oracle_cvRound((float)h * o->mvInvScaleFactor[level]) < 56) {
+            if (n_out) *n_out = 0;
+            return -1;
+        }
     compute_pyramid(o, img, w, h, stride);
     for (level = 0; level < o->nlevels; level++)
         if (compute_level_keypoints(o, level) < 0) return -1;

@@ -16,6 +16,8 @@ for case in range(n):
     if rng.random() < 0.25:      # wide and tall frames: several initial octree nodes per level (or the reference's division by zero)
         w, h = (int(rng.integers(500, 1400)), int(rng.integers(110, 300))) if rng.random() < 0.7 else (int(rng.integers(150, 300)), int(rng.integers(300, 800)))
     nlev = int(rng.integers(1, 9)); sf = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0]))
+    if rng.random() < 0.15:      # unusual pyramids: nearly equal levels, very steep ones, more than eight levels
+        nlev = int(rng.integers(1, 17)); sf = float(rng.choice([1.03, 1.07, 1.15, 1.4, 1.7, 2.5, 3.0]))
     nfeat = int(rng.integers(100, 3500)) if rng.random() < 0.7 else int(rng.integers(1, 100))    # tiny quotas: 0 .. 3 per level
     ini = int(rng.integers(8, 40)); mn = int(rng.integers(3, ini + 1))
     kind = rng.integers(0, 4)
