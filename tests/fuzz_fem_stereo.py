@@ -58,9 +58,11 @@ for case in range(n):
         ok = np.array_equal(fea.ComputeForces(a)[0], oracle.fem_matvec_dense(K, a))
     if not ok:
         bad += 1; print("MISMATCH fem", case, kind, g, E, nu, flush=True)
-P = (1500, 1.2, 8, 20, 7)
 for case in range(max(4, n // 8)):
     w = int(rng.integers(400, 1300)); h = int(rng.integers(200, 500))
+    # the reference's stereo settings most of the time, otherwise any pyramid (the row band of a keypoint is +-2 scale[octave] rows)
+    P = (1500, 1.2, 8, 20, 7) if rng.random() < 0.5 else (int(rng.integers(50, 2500)), float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0])), int(rng.integers(1, 9)),
+                                                          int(rng.integers(8, 30)), int(rng.integers(3, 9)))
     left, right = synth_stereo_pair(int(rng.integers(0, 1000)), w=w, h=h, dmin=float(rng.uniform(0, 5)), dmax=float(rng.uniform(20, 90)))
     oL, oR = oracle.OrbOracle(*P), oracle.OrbOracle(*P)
     try:
@@ -75,8 +77,12 @@ for case in range(max(4, n // 8)):
     fx, bf = float(rng.uniform(300, 900)), float(rng.uniform(100, 500))
     mb = np.float32(bf) / np.float32(fx)
     ou, od, nd = oracle.stereo_matches(oL, oR, kL, dL, kR, dR, mb, np.float32(bf))
-    eL, eR = ORBextractor(*P), ORBextractor(*P)
-    eL(left); eR(right)
+    try:
+        eL, eR = ORBextractor(*P), ORBextractor(*P)
+        eL(left); eR(right)
+    except Exception as e:
+        if "error -5" in str(e): continue         # a documented capacity limit (one level with a quota above 2047)
+        raise
     gu, gd = ComputeStereoMatches(eL, eR, mb, np.float32(bf))
     if not (np.array_equal(gu.view(np.uint32), ou.view(np.uint32)) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))):
         bad += 1; print("MISMATCH stereo", case, w, h, fx, bf, flush=True)
