@@ -96,6 +96,7 @@ int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr /*ndof+1*/, int32_t *col
 typedef struct {
     int32_t ndof, nblk, spb, spmv_lds, fused_lds, nchunk_tot, nchunk_s_tot, resident, resident_big, resident_lds, nrcd, maxel;
     int64_t nnz, ncontrib;
+    int32_t rows_lds, reserved;   /* LDS bytes of the shared-row assembly (0: the entry-by-entry kernel assembles) */
 } fem_plan_info;
 int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_ne, const int32_t *elems, int uniform_copies,
              fem_plan_info *info, int32_t *rowptr, int32_t *lcol, int32_t *diag, int32_t *bp, int32_t *bcol3, int32_t *rcd,

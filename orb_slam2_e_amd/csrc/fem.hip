@@ -1880,7 +1880,7 @@ int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_
     if (rc != ORBX_OK) return rc;
     memset(info, 0, sizeof(*info));
     info->ndof = m.ndof; info->nblk = m.nblk; info->nnz = (int64_t)m.nnz; info->spb = m.spb; info->spmv_lds = m.spmv_lds;
-    info->fused_lds = m.fused_lds; info->nchunk_tot = m.nchunk_tot; info->nchunk_s_tot = m.nchunk_s_tot;
+    info->fused_lds = m.fused_lds; info->rows_lds = m.rows_lds; info->nchunk_tot = m.nchunk_tot; info->nchunk_s_tot = m.nchunk_s_tot;
     info->resident = P.resident ? 1 : 0; info->resident_big = P.big ? 1 : 0; info->resident_lds = (int32_t)P.resident_lds;
     info->nrcd = P.resident ? (int32_t)P.rcd.size() : 0; info->ncontrib = (int64_t)y.contrib.size(); info->maxel = y.maxel;
     if (rowptr) memcpy(rowptr, m.h_rowptr.data(), sizeof(int) * m.h_rowptr.size());

@@ -253,7 +253,8 @@ class FEA2Batch(FEA2):
 
 class _PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("ndof", "nblk", "spb", "spmv_lds", "fused_lds", "nchunk_tot", "nchunk_s_tot", "resident",
-                                         "resident_big", "resident_lds", "nrcd", "maxel")] + [("nnz", C.c_int64), ("ncontrib", C.c_int64)]
+                                         "resident_big", "resident_lds", "nrcd", "maxel")] + [("nnz", C.c_int64), ("ncontrib", C.c_int64),
+                                                                                                     ("rows_lds", C.c_int32), ("reserved", C.c_int32)]
 
 
 def plan(elems_list, nn_list, nElType, uniform_copies=0):

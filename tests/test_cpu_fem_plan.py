@@ -68,6 +68,8 @@ def test_plan_of_the_references_own_meshes(name, eltype):
     _check_tables(p, rowptr, lcol, [(0, 3 * nn)])
     assert not p["resident"] and p["nchunk_tot"] == (3 * nn + 255) // 256
     assert p["ncontrib"] == len(elems) * elems.shape[1] ** 2 and p["fused_lds"] > 0
+    # the shared-row assembly: the entry-by-entry kernel's LDS + a flag per Gauss point + nine floats per contribution of the fullest row
+    assert p["fused_lds"] < p["rows_lds"] <= 64 * 1024
     p64 = plan([elems], [nn], eltype, uniform_copies=64)                       # 64 copies: one compute unit each
     assert p64["resident"] and not p64["resident_big"] and p64["nchunk_tot"] == 64 * p["nchunk_tot"]
     _check_tables(p64, rowptr, lcol, [(0, 3 * nn)])
