@@ -138,12 +138,14 @@ def stereo_leg(args):
 
 def loops_leg(args):
     import oracle
-    from orb_slam2_e_amd.synth import synth_bow_case, synth_projection_case
+    from orb_slam2_e_amd.synth import synth_bow_case, synth_initialization_case, synth_projection_case
     _pin(sorted(os.sched_getaffinity(0))[0])
     q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(0, n=2000, nq=2000, hot=2000)
     d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
     ofv1 = oracle.feature_vector(node1, keep1); ofv2 = oracle.feature_vector(node2, keep2)
-    return {"kind": "port", "cores": 1, "unit": "ms per call", "sample": "the same inputs; " + PROTOCOL,
+    ik1, id1, ik2, id2, iprev, ibounds = synth_initialization_case(0)
+    return {"search_for_initialization_2000x2200_ms": _median_ms(lambda: oracle.search_for_initialization(ik1, id1, ik2, id2, iprev, ibounds, 100, 0.9, True)),
+            "kind": "port", "cores": 1, "unit": "ms per call", "sample": "the same inputs; " + PROTOCOL,
             "search_by_projection_2000x2000_ms": _median_ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True)),
             "search_by_bow_2000x2100_ms": _median_ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True))}
 
