@@ -54,6 +54,18 @@ for case in range(n):
     if not ok:
         bad += 1
         print("MISMATCH", case, params, (w, h), "kind", kind, len(kps), len(okps), flush=True)
+    if rng.random() < 0.15:      # the batch entry on the same handle: B frames of this size (B % 8 == 0 takes the XCD-aware mapping)
+        B = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 24]))
+        imgs = np.stack([img] + [np.roll(img, int(rng.integers(1, 40)) * (b + 1), axis=int(rng.integers(0, 2))) for b in range(B - 1)])
+        ex.extract_batch(imgs)
+        kb, db, cb = ex.download_batch()
+        for b in range(B):
+            rk, rd = (okps, odesc) if b == 0 else o.extract(imgs[b])
+            nb_ = int(cb[b])
+            if not (nb_ == len(rk) and np.array_equal(db[b, :nb_], rd) and kb[b, :nb_].tobytes() == rk.tobytes()):
+                bad += 1
+                print("MISMATCH batch", case, params, (w, h), "B", B, "frame", b, nb_, len(rk), flush=True)
+                break
 print("unsupported:", why)
 print("cases", n, "skipped (unsupported sizes)", skipped, "mismatches", bad)
 sys.exit(1 if bad else 0)
