@@ -318,7 +318,7 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
  * (bad keyframes already filtered by the caller, :325-331); best[i] = index (within
  * the point's rows) of the descriptor with the least median Hamming distance to the
  * others, first on ties, median = sorted row [int(0.5*(N-1))]; -1 if the point has
- * none.  At most 128 observations per point. */
+ * none.  At most 65,535 observations per point (above 128 a slower row-by-row path). */
 int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m, int32_t *best);
 
 /* DBoW2 vocabulary-tree descent = the Hamming-heavy half of Frame::ComputeBoW

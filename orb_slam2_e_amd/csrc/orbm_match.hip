@@ -408,6 +408,44 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint4 *__restrict__ de
     const int i = blockIdx.x, lane = threadIdx.x;
     const int o = off[i], N = off[i + 1] - o;
     if (N <= 0) { if (lane == 0) best[i] = -1; return; }
+    if (N > DD_MAXN) {
+        // A map point with more observations than the LDS matrix holds (long sessions: hundreds of keyframes see one point): row by
+        // row, the distances of row a from the descriptors in L2 (lane = column, 64 at a time) into a 257-bin histogram, its
+        // median = the first bin at which the running count reaches kth + 1.  N^2 / 64 wave iterations: rare, and bounded.
+        int *hist = reinterpret_cast<int *>(s_m);
+        const int kth = (int)(0.5 * (N - 1));
+        unsigned key = 0xffffffffu;
+        for (int a = 0; a < N; ++a) {
+            for (int k = lane; k < 320; k += 64) hist[k] = 0;
+            __syncthreads();
+            const uint4 a0 = desc[2 * (size_t)(o + a)], a1 = desc[2 * (size_t)(o + a) + 1];
+            for (int b = lane; b < N; b += 64) {
+                const int d = a == b ? 0 : popc256(a0, a1, desc[2 * (size_t)(o + b)], desc[2 * (size_t)(o + b) + 1]);
+                atomicAdd(&hist[d], 1);
+            }
+            __syncthreads();
+            int c[5], run = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { c[k] = hist[5 * lane + k]; run += c[k]; }
+            int incl = run;     // inclusive scan over the lanes
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft); if (lane >= sft) incl += v; }
+            const unsigned long long reach = __ballot(incl >= kth + 1);
+            const int owner = __ffsll((long long)reach) - 1;     // (the total is N >= kth + 1: some lane reaches it)
+            int med = 0;
+            if (lane == owner) {
+                int cum = incl - run;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { cum += c[k]; if (cum >= kth + 1) { med = 5 * lane + k; break; } }
+            }
+            med = __shfl(med, owner);
+            const unsigned k2 = ((unsigned)med << 16) | (unsigned)a;
+            key = k2 < key ? k2 : key;
+            __syncthreads();
+        }
+        if (lane == 0) best[i] = (int)(key & 0xffffu);
+        return;
+    }
     for (int k = lane; k < 2 * N; k += 64) s_d[k] = desc[2 * (size_t)o + k];
     __syncthreads();
     for (int p = lane; p < N * N; p += 64) {
@@ -634,7 +672,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m,
     if (off[0] != 0 || total < 0 || (total && !desc)) ORBX_FAIL(ORBX_ERR_ARG, "bad offsets");
     for (int i = 0; i < m; ++i) {
         if (off[i] > off[i + 1]) ORBX_FAIL(ORBX_ERR_ARG, "offsets not monotone");
-        if (off[i + 1] - off[i] > DD_MAXN) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 128 observations of one map point");
+        if (off[i + 1] - off[i] > 65535) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 65,535 observations of one map point");
     }
     StagedCall sc;
     const size_t o_d = sc.in(desc, (size_t)32 * total), o_off = sc.in(off, sizeof(int) * (m + 1)), o_o = sc.out(sizeof(int) * m);

@@ -266,7 +266,7 @@ def test_whole_map_search_by_projection(seed, th):
 
 def test_distinctive_descriptors_batch():
     rng = np.random.default_rng(5)
-    sizes = np.concatenate([[0, 1, 2, 3, 128], rng.integers(1, 60, 400)])
+    sizes = np.concatenate([[0, 1, 2, 3, 128, 129, 130, 333, 1000], rng.integers(1, 60, 400)])   # above 128: the row-by-row histogram path
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     base = rng.integers(0, 256, (len(sizes), 32), dtype=np.uint8)
     desc = np.concatenate([base[i] ^ np.packbits(rng.random((n, 256)) < 0.1, axis=1, bitorder="little") for i, n in enumerate(sizes) if n > 0])
