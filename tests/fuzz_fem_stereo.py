@@ -58,6 +58,37 @@ for case in range(n):
         ok = np.array_equal(fea.ComputeForces(a)[0], oracle.fem_matvec_dense(K, a))
     if not ok:
         bad += 1; print("MISMATCH fem", case, kind, g, E, nu, flush=True)
+    elif not np.isnan(K).any() and rng.random() < 0.5:
+        # the LM hook on this mesh (levenberg.cpp:159-175): penalties, resident set-up, trials -- a bit-exact, energies within 1e-5;
+        # the derived (mid-edge / barycentre) nodes of the C3D8 form on random earlier nodes
+        ntop = len(top)
+        ids = np.arange(ntop, 2 * ntop, dtype=np.int32)
+        fea.ImposeDirichletEncastre_K(ids)
+        oracle.fem_dirichlet_K(K, ids)
+        nder = int(rng.integers(0, min(30, ntop - 2))) if rng.random() < 0.5 else 0
+        npts = ntop - nder
+        der = None
+        if nder:
+            der = []
+            for d_ in range(nder):
+                hi = npts + d_ if d_ % 3 == 2 else npts
+                der.append([2, *rng.integers(0, hi, 2), 0] if rng.random() < 0.5 else [3, *rng.integers(0, hi, 3)])
+            der = np.array(der, np.int32)
+        u0 = nodes.ravel()
+        fea.trial_setup(u0, ids, npts, der)
+        for trial in range(2):
+            pts = top[:npts].astype(np.float64) + rng.normal(0, 0.01, (npts, 3))
+            a_, sE, nsE = fea.trial_energy(pts)
+            oa = oracle.fem_trial_displacement(pts, der, u0, ids)
+            of = oracle.fem_matvec_dense(K, oa)
+            osE, onsE = oracle.fem_strain_energy(oa, of)
+            # a^T f is a float sum with cancellation, and the reference forms it in Eigen (FEA2.cc:1877-1886: MultiplyMatricesEigen,
+            # summation order unspecified) where the oracle adds left to right: two orders may differ by the rounding of the sum
+            # itself, ~sqrt(n) eps sum|a_i f_i|, which on a random mesh can exceed 1e-5 of a strongly cancelled result
+            slack = 2e-6 * float(np.abs(oa.astype(np.float64) * of.astype(np.float64)).sum())
+            if not (np.array_equal(a_[0], oa) and abs(sE[0] - osE) <= max(1e-5 * abs(osE), slack) and
+                    abs(nsE[0] - onsE) <= max(1e-5 * abs(onsE), slack / (len(oa) // 3))):
+                bad += 1; print("MISMATCH LM trial", case, kind, g, nder, sE[0], osE, flush=True); break
 for case in range(max(4, n // 8)):
     w = int(rng.integers(400, 1300)); h = int(rng.integers(200, 500))
     # the reference's stereo settings most of the time, otherwise any pyramid (the row band of a keypoint is +-2 scale[octave] rows)
