@@ -75,6 +75,17 @@ int orbx_keypoint_capacity(const orbx_extractor *ex);
  * called implicitly by the extract calls). */
 int orbx_reserve(orbx_extractor *ex, int width, int height, int batch);
 
+/* What orbx_reserve decides about a frame size, computed on the host alone (no device needed): level sizes
+ * (ComputePyramid, ORBextractor.cc:1119-1121), quotas, DistributeOctTree's initial nodes round(W / H) per level (:543), the
+ * keypoint slots of a level = max(quota + 3, 4 nIni) + 1, the frame's keypoint capacity, the FAST cell count per level
+ * (:781-806) and the workspace / LDS budgets.  Same error codes as orbx_reserve for sizes it refuses. */
+typedef struct {
+    int32_t nlevels, keypoint_capacity, octree_nodes, cells_per_frame, sel_per_frame, fast_tile_stride, fast_lds, octree_lds, octree_kshift, reserved;
+    int64_t frame_bytes, cands_per_frame;
+    int32_t level_w[16], level_h[16], level_quota[16], level_nini[16], level_slots[16], level_cells[16];
+} orbx_plan_info;
+int orbx_plan(const orbx_params *params, int width, int height, orbx_plan_info *info);
+
 /* ORBextractor::operator()(image, mask, keypoints, descriptors) for ONE host image
  * (CV_8UC1, `stride` bytes per row).  Writes up to `cap` keypoints / 32-byte
  * descriptor rows; *n = count.  An empty image (NULL / 0 size) returns ORBX_OK

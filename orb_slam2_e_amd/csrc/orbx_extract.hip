@@ -1743,18 +1743,13 @@ int orbx_level_size(const orbx_extractor *ex, int level, int *w, int *h)
     return ORBX_OK;
 }
 
-int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
+// Everything orbx_reserve decides about a frame size on the HOST: level geometry, the FAST cell grid, the octree's initial nodes,
+// slot / node / result capacities, resize coefficient tables, blur tiles, LDS budgets.  No device call (orbx_plan runs it
+// without a GPU: the CPU tests and the host sanitizer pass check its capacities against the oracle's literal algorithm).
+static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int2> &xt, std::vector<int4> &yt)
 {
-    if (!ex || width <= 0 || height <= 0 || batch <= 0) ORBX_FAIL(ORBX_ERR_ARG, "bad reserve arguments");
-    ORBX_NEED_DEVICE();
-    if (ex->width == width && ex->height == height && ex->batch >= batch) return ORBX_OK;
-    if (!ex->stream) ORBX_HIP(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    free_workspace(ex);
-
     const int nl = ex->nlevels;
-    std::vector<int2> xt;
-    std::vector<int4> yt;
+    xt.clear(); yt.clear();
     ex->cells.clear(); ex->tiles.clear();
     size_t off = 0, cand_off = 0, key_off = 0;
     int sel_off = 0, maxcw = 0, maxch = 0, kneed = 0;
@@ -1924,6 +1919,24 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
+    return ORBX_OK;
+}
+
+int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
+{
+    if (!ex || width <= 0 || height <= 0 || batch <= 0) ORBX_FAIL(ORBX_ERR_ARG, "bad reserve arguments");
+    ORBX_NEED_DEVICE();
+    if (ex->width == width && ex->height == height && ex->batch >= batch) return ORBX_OK;
+    if (!ex->stream) ORBX_HIP(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    free_workspace(ex);
+    std::vector<int2> xt;
+    std::vector<int4> yt;
+    {
+        const int rc = plan_frame(ex, width, height, xt, yt);
+        if (rc != ORBX_OK) return rc;
+    }
+
     const size_t B = (size_t)batch;
     ORBX_HIP(hipMalloc(&ex->d_pyr, ex->frame_bytes * B));
     ORBX_HIP(hipMemset(ex->d_pyr, 0, ex->frame_bytes * B)); // the row padding outside the 19-px border is never written by k_pyr_resize
@@ -1977,6 +1990,30 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                                      hipFuncAttributeMaxDynamicSharedMemorySize, ex->oct_lds));
     ex->width = width; ex->height = height; ex->batch = batch;
     return ORBX_OK;
+}
+
+int orbx_plan(const orbx_params *prm, int width, int height, orbx_plan_info *info)
+{
+    if (!prm || !info || width <= 0 || height <= 0) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    orbx_extractor *ex = nullptr;
+    int rc = orbx_create(prm, &ex);
+    if (rc != ORBX_OK) return rc;
+    std::vector<int2> xt;
+    std::vector<int4> yt;
+    rc = plan_frame(ex, width, height, xt, yt);
+    if (rc == ORBX_OK) {
+        memset(info, 0, sizeof(*info));
+        info->nlevels = ex->nlevels; info->keypoint_capacity = ex->kcap; info->octree_nodes = ex->NC; info->cells_per_frame = ex->cells_per_frame;
+        info->sel_per_frame = ex->sel_per_frame; info->fast_tile_stride = ex->TS; info->fast_lds = ex->fast_lds; info->octree_lds = ex->oct_lds;
+        info->octree_kshift = ex->oct_kshift; info->frame_bytes = (int64_t)ex->frame_bytes; info->cands_per_frame = (int64_t)ex->cands_per_frame;
+        for (int l = 0; l < ex->nlevels; l++) {
+            const LevelInfo &lv = ex->lv[l];
+            info->level_w[l] = lv.w; info->level_h[l] = lv.h; info->level_quota[l] = lv.N; info->level_nini[l] = lv.nIni;
+            info->level_slots[l] = level_slots(lv); info->level_cells[l] = lv.ncells;
+        }
+    }
+    orbx_destroy(ex);
+    return rc;
 }
 
 int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device, int width, int height, int stride,

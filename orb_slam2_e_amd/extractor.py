@@ -167,6 +167,27 @@ class ORBextractor:
         return out[:n.value].copy()
 
 
+class _ExtractPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nlevels", "keypoint_capacity", "octree_nodes", "cells_per_frame", "sel_per_frame", "fast_tile_stride",
+                                         "fast_lds", "octree_lds", "octree_kshift", "reserved")] + \
+               [("frame_bytes", C.c_int64), ("cands_per_frame", C.c_int64)] + \
+               [(n, C.c_int32 * 16) for n in ("level_w", "level_h", "level_quota", "level_nini", "level_slots", "level_cells")]
+
+
+def plan(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height):
+    """orbx_plan: what orbx_reserve decides about a frame size, on the host alone (no GPU needed).  Returns a dict; the per-level
+    entries are lists of nlevels values."""
+    L = lib()
+    prm = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, 0)
+    info = _ExtractPlan()
+    check(L.orbx_plan(C.byref(prm), int(width), int(height), C.byref(info)))
+    out = {}
+    for n, t in _ExtractPlan._fields_:
+        v = getattr(info, n)
+        out[n] = list(v)[:info.nlevels] if n.startswith("level_") else v
+    return out
+
+
 def stereo_match_batch(left, right, mb, mbf, stream=None):
     """orbx_stereo_match on every frame of the last batch extracted on both handles (asynchronous on `stream`)."""
     L = left._L

@@ -1,0 +1,81 @@
+"""Host-side planning of the extractor (orbx_plan = the host half of orbx_reserve, no GPU): level geometry, quotas, initial
+octree nodes and -- what a differential fuzz run found wrong in round 3 -- the keypoint capacities, checked against what the
+oracle's literal ComputeKeyPointsOctTree / DistributeOctTree actually returns on random frames."""
+import numpy as np
+import pytest
+
+import oracle
+from orb_slam2_e_amd._lib import OrbxError
+from orb_slam2_e_amd.extractor import plan
+from orb_slam2_e_amd.synth import synth_frame
+
+
+def test_reference_settings_640x480():
+    p = plan(2000, 1.2, 8, 20, 7, 640, 480)
+    assert p["nlevels"] == 8 and p["keypoint_capacity"] == 2000 + 3 * 8
+    # level sizes, quotas, 815 cells per frame
+    assert list(zip(p["level_w"], p["level_h"])) == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+    assert p["level_quota"] == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert p["level_cells"] == [20 * 14, 16 * 12, 13 * 10, 11 * 8, 9 * 6, 7 * 5, 6 * 4, 4 * 3] and p["cells_per_frame"] == 815
+    assert p["level_nini"] == [1] * 8 and p["level_slots"] == [q + 4 for q in p["level_quota"]]
+    assert p["fast_tile_stride"] == 52 and 0 < p["fast_lds"] < 8 * 1024 and p["octree_lds"] <= 160 * 1024
+
+
+def test_kitti_shape_starts_from_several_octree_nodes():
+    p = plan(2000, 1.2, 8, 20, 7, 1242, 375)
+    assert p["level_nini"][0] == 4 and min(p["level_nini"]) >= 3
+    assert p["keypoint_capacity"] == 2024          # every quota is far above 4 nIni - 3
+    q = plan(40, 1.2, 8, 20, 7, 1242, 375)
+    assert q["level_quota"] == [9, 7, 6, 5, 4, 3, 3, 3]
+    assert q["level_slots"] == [16] * 8 and q["keypoint_capacity"] == 8 * 16      # 4 nIni = 16 keypoints per level whatever the quota
+
+
+def test_the_fuzzers_case():
+    """819 x 320, 108 features, scale 1.25: 137 keypoints where nfeatures + 3 nlevels is 132."""
+    prm = (108, 1.25, 8, 38, 25)
+    p = plan(*prm, 819, 320)
+    k, _ = oracle.OrbOracle(*prm).extract(synth_frame(1, 819, 320))
+    assert len(k) == 137 <= p["keypoint_capacity"]
+    per_level = np.bincount(k["octave"], minlength=8)
+    assert all(c <= s for c, s in zip(per_level, p["level_slots"])) and max(per_level[6:]) == 16 > p["level_quota"][6] + 3
+
+
+def test_capacities_hold_against_the_literal_algorithm_on_random_frames():
+    """The capacity rule is a claim about DistributeOctTree: at most max(quota + 3, 4 nIni) keypoints per level.  The oracle
+    IS that algorithm (list surgery and all): on random sizes, pyramids and quotas its per-level counts stay within the slots
+    orbx_plan reserves, its total within the reported capacity, and both agree on level sizes and on which frames cannot run."""
+    rng = np.random.default_rng(12)
+    ran = refused = 0
+    for case in range(60):
+        w, h = int(rng.integers(150, 1300)), int(rng.integers(110, 700))
+        prm = (int(rng.choice([1, 5, 20, 60, 300, 1500])), float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0])), int(rng.integers(1, 10)),
+               int(rng.integers(8, 30)), int(rng.integers(3, 8)))
+        img = synth_frame(int(rng.integers(0, 1000)), w, h) if rng.random() < 0.7 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        o = oracle.OrbOracle(*prm)
+        try:
+            k, _ = o.extract(img)
+        except RuntimeError:
+            k = None
+        try:
+            p = plan(*prm, w, h)
+        except OrbxError as e:
+            assert k is None or e.code == -5, (prm, w, h, str(e))     # -5: a documented capacity limit of the GPU path only
+            refused += 1
+            continue
+        assert k is not None, ("the library plans a frame the reference cannot run", prm, w, h)
+        ran += 1
+        assert [o.level_dims(l)[:2] for l in range(prm[2])] == list(zip(p["level_w"], p["level_h"]))
+        assert o.features_per_level() == p["level_quota"]
+        per_level = np.bincount(k["octave"], minlength=prm[2])
+        assert all(c <= max(q + 3, 4 * ni) < s + 1 for c, q, ni, s in zip(per_level, p["level_quota"], p["level_nini"], p["level_slots"])), (prm, w, h)
+        assert len(k) <= p["keypoint_capacity"]
+    assert ran >= 30 and refused >= 3
+
+
+@pytest.mark.parametrize("prm,size,code", [((2000, 1.2, 8, 20, 7), (100, 100), -1), ((2000, 1.2, 8, 20, 7), (200, 700), -5),
+                                            ((2000, 3.0, 8, 20, 7), (1314, 123), -1), ((9000, 1.2, 2, 20, 7), (640, 480), -5),
+                                            ((2000, 1.2, 8, 20, 7), (4100, 3000), -5)])
+def test_frames_that_cannot_run_are_refused_not_planned(prm, size, code):
+    with pytest.raises(OrbxError) as e:
+        plan(*prm, *size)
+    assert e.value.code == code

@@ -3,7 +3,7 @@
 # units compiled with the HOST side instrumented (-fno-gpu-sanitize: device code as usual; without a device every compute entry point
 # returns ORBX_ERR_NO_DEVICE) under AddressSanitizer + UndefinedBehaviorSanitizer, then the CPU tests that drive host
 # logic -- the symbolic CSR / chunk tables / resident-CG chunk table (fem_plan), the frame-grid counting sort
-# (orbm_sorted_frame), argument checks, the no-device paths of the workspace pool, the FeatureVector co-iteration and
+# (orbm_sorted_frame), the extractor's frame planning (orbx_plan), argument checks, the no-device paths of the workspace pool, the FeatureVector co-iteration and
 # the Fuse loop tails -- run against that build (ORBX_LIB).  usage: tools/asan_host.sh [pytest args]
 set -e
 cd "$(dirname "$0")/.."
@@ -19,5 +19,5 @@ $HIPCC --offload-arch=gfx950 -fno-gpu-sanitize -shared -fPIC -fsanitize=address,
 RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 echo "built $OUT/liborbslam_hip.so; runtime $RT"
 ORBX_LIB="$OUT/liborbslam_hip.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    python -m pytest tests/test_cpu_fem_plan.py tests/test_cpu_host_logic.py tests/test_fuse_and_projection.py tests/test_cpu_basics.py \
+    python -m pytest tests/test_cpu_fem_plan.py tests/test_cpu_extract_plan.py tests/test_cpu_host_logic.py tests/test_fuse_and_projection.py tests/test_cpu_basics.py \
     -q -m "not gpu" -p no:cacheprovider "$@"
