@@ -30,8 +30,19 @@ def build(force=False):
     so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "fem_oracle.c", "stereo_oracle.c", "orb_pattern_data.h",
                                              "Makefile")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+    stale = lambda: force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale():
+        # one builder at a time: the ranks of a multi-GPU bench run import this module together, and a rank must never load a
+        # library another rank is still writing (the first one in builds, the others find it up to date)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+                    force = False
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return so
 
 

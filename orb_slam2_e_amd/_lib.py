@@ -21,7 +21,14 @@ class OrbxError(RuntimeError):
 def build(force=False):
     csrc = os.path.join(_HERE, "csrc")
     args = ["make", "-C", csrc] + (["-B"] if force else [])
-    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    # one builder at a time (several ranks of one run may find the library missing together)
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(args, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     if not os.path.exists(SO_PATH):
         raise RuntimeError("liborbslam_hip.so was not produced by the build")
     return SO_PATH
