@@ -268,7 +268,13 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
                         }
                     }
                 }
-                if (found < (need2 ? 2 : 1) && e - b > TOPK) { // the short list ran dry: the whole list
+                bool scan = found < (need2 ? 2 : 1) && e - b > TOPK;   // the short list ran dry: the whole list ...
+                if (MODE == 1 && scan) {    // ... unless it cannot change the decision (see k_resolve_init_par)
+                    const int d7 = (int)(tp[TOPK - 1] >> 20);
+                    if (found == 0) scan = d7 <= th;
+                    else if (best > th || (float)best < (float)d7 * nnratio) { scan = false; second = d7; sp2 = -1; }
+                }
+                if (scan) {
                     unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
                     for (int k = b; k < e; ++k) {
                         const unsigned en = ent[k];
@@ -615,7 +621,17 @@ __global__ __launch_bounds__(RES_T) void k_resolve_init_par(const unsigned *__re
                 }
             }
         }
-        if (found < 2 && e - b > TOPK) { // the short list ran dry: the whole list
+        // The short list ran dry -- but the rest of the list (every entry's key is above the short list's last) is needed only if it
+        // can change the DECISION: with no eligible entry so far, a best beyond the last short-list distance d7 must still be <= th;
+        // with one, the second best is >= d7, so best < d7 * ratio already passes the ratio test (:674-676) whatever it is.  Most of a
+        // late query's short list is taken by earlier matches at small distances (:645-646), so this case is the common one.
+        bool scan = found < 2 && e - b > TOPK;
+        if (scan) {
+            const int d7 = (int)(tp[TOPK - 1] >> 20);
+            if (found == 0) scan = d7 <= th;
+            else if (best > th || (float)best < (float)d7 * nnratio) { scan = false; second = d7; }
+        }
+        if (scan) {
             unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
             for (int k = b; k < e; ++k) {
                 const unsigned en = ent[k];
