@@ -269,10 +269,12 @@ __global__ __launch_bounds__(64) void k_resolve(const unsigned *__restrict__ ent
                     }
                 }
                 bool scan = found < (need2 ? 2 : 1) && e - b > TOPK;   // the short list ran dry: the whole list ...
-                if (MODE == 1 && scan) {    // ... unless it cannot change the decision (see k_resolve_init_par)
+                if (scan) {    // ... unless it cannot change the decision (see k_resolve_init_par / k_resolve_par)
                     const int d7 = (int)(tp[TOPK - 1] >> 20);
+                    const bool passes = MODE == 1 ? (float)best < (float)d7 * nnratio
+                                                  : (accept_mode == ACCEPT_RATIO ? (float)best < nnratio * (float)d7 : !((float)best > nnratio * (float)d7));
                     if (found == 0) scan = d7 <= th;
-                    else if (best > th || (float)best < (float)d7 * nnratio) { scan = false; second = d7; sp2 = -1; }
+                    else if (best > th || passes) { scan = false; second = d7; sp2 = -1; l2 = -2; }
                 }
                 if (scan) {
                     unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
@@ -419,7 +421,18 @@ __global__ __launch_bounds__(RES_T) void k_resolve_par(const unsigned *__restric
                 ++found;
             }
         }
-        if (found < (need2 ? 2 : 1) && e - b > TOPK) { // the short list ran dry: the whole list
+        // the short list ran dry: the whole list -- unless it cannot change the decision (every entry beyond the short list is at
+        // least as far as its last one, d7: nothing eligible so far and d7 > th rejects; one eligible entry that passes its ratio
+        // test against d7, a lower bound of the second best (256 at most, the reference's initial bestDist2), passes)
+        bool scan = found < (need2 ? 2 : 1) && e - b > TOPK;
+        if (scan) {
+            const int d7 = (int)(tp[TOPK - 1] >> 20);
+            if (found == 0) scan = d7 <= th;
+            else if (best > th || (accept_mode == ACCEPT_RATIO ? (float)best < nnratio * (float)d7 : !((float)best > nnratio * (float)d7))) {
+                scan = false; sp2 = -1; second = d7; l2 = -2;     // (l2 = -2: never equal to l1, and the bound passes the same-level test anyway)
+            }
+        }
+        if (scan) {
             unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
             for (int k = b; k < e; ++k) {
                 const unsigned en = ent[k];
