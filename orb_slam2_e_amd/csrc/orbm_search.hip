@@ -1171,7 +1171,9 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     // the projection family (one segment, MODE 0) resolves as a parallel fixed point (k_resolve_par, rotation check fused); if its
     // dependency chains are longer than the kernel iterates, the call is repeated on the one-wave sequential resolver
     // SearchForInitialization (MODE 1) likewise (k_resolve_init_par): its per-slot acceptor lists take C + 3 ints of LDS per keypoint
-    bool sequential = seg != nullptr || g_force_sequential.load(std::memory_order_relaxed) != 0;
+    // (the BoW searches' segments -- one per vocabulary node, disjoint candidate sets -- only matter to the sequential resolver:
+    // the fixed point needs no partition, queries of different nodes simply never meet)
+    bool sequential = g_force_sequential.load(std::memory_order_relaxed) != 0;
     const int init_c = std::min(7, (144 * 1024 / 4) / ns - 3);
     if (mode == 1 && init_c < 2) sequential = true;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -1299,7 +1301,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
         if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
         memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
-        if (seg) *nmatches += 1;   // the segments added their counts to the preset -1
+        if (seg && sequential) *nmatches += 1;   // the segments added their counts to the preset -1
         break;
     }
     return ORBX_OK;

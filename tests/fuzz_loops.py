@@ -63,7 +63,7 @@ CASES = [
     ("projection loop", lambda: with_resolver(tm.test_search_projection_whole_loop, S(), int(rng.choice([60, 95, 100])), B(), B(), B())),
     ("initialization", lambda: with_resolver(tm.test_search_for_initialization, S(), float(rng.choice([0.7, 0.9, 1.0])), B(),
                                              int(rng.choice([30, 100, 300])), int(rng.choice([1200, 2000, 2600])), int(rng.choice([3, 10, 40])))),
-    ("bow loop", lambda: tm.test_search_by_bow_whole_loop(S(), B(), B(), float(rng.choice([0.6, 0.75, 0.9])))),
+    ("bow loop", lambda: with_resolver(tm.test_search_by_bow_whole_loop, S(), B(), B(), float(rng.choice([0.6, 0.75, 0.9])))),
     ("fuse candidate loop", lambda: tm.test_fuse_candidate_loop(S(), B(), B())),
     ("fuse replay tail", lambda: tf.test_fuse_replay_equals_literal_loop_tail(S())),
     ("fuse replay tail (Sim3)", lambda: tf.test_fuse_replay_sim3_equals_literal_loop_tail(S())),

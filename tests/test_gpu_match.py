@@ -352,8 +352,9 @@ def test_search_for_initialization(seed, ratio, ori, window, n1, alike, resolver
 
 
 @pytest.mark.parametrize("seed,kf_kf,ori,ratio", [(0, False, True, 0.7), (1, True, True, 0.75), (2, False, False, 0.6), (3, True, False, 0.9)])
-def test_search_by_bow_whole_loop(seed, kf_kf, ori, ratio):
-    """orbm_search_by_bow (+ the host co-iteration) vs the literal SearchByBoW loops."""
+def test_search_by_bow_whole_loop(seed, kf_kf, ori, ratio, resolver):
+    """orbm_search_by_bow (+ the host co-iteration) vs the literal SearchByBoW loops, on the parallel fixed point (all nodes in one
+    workgroup: queries of different nodes never meet) and on the sequential resolver (one workgroup per node)."""
     from orb_slam2_e_amd.vocabulary import feature_vector_arrays
     d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(seed)
     fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
