@@ -290,6 +290,7 @@ def fem_compute1_bench():
         u0 = nodes.ravel()
         reps = 30
         acc = np.zeros(5)
+        per_rep = []
         fea = None
         for r in range(reps + 3):
             t = [time.perf_counter()]
@@ -298,12 +299,10 @@ def fem_compute1_bench():
             fea.ImposeDirichletEncastre_K(ids); t.append(time.perf_counter())
             fea.trial_setup(u0, ids, len(top), None); t.append(time.perf_counter())
             if r >= 3:
-                acc[:4] += np.diff(t)
+                per_rep.append(np.diff(t))
         pts = top.astype(np.float64) + 0.003
-        for _ in range(10): fea.trial_energy(pts, want_a=False)
-        t0 = time.perf_counter()
-        for _ in range(100): fea.trial_energy(pts, want_a=False)     # as the hook: estimates in, the two energies out
-        acc[4] = (time.perf_counter() - t0) / 100 * reps
+        acc[:4] = np.median(np.array(per_rep), axis=0) * reps        # the median call of each phase (see best_batch_ms: power management)
+        acc[4] = best_batch_ms(lambda: fea.trial_energy(pts, want_a=False), 100, warm=10, batch=20) * 1e-3 * reps   # as the hook: estimates in, the two energies out
         ms = acc / reps * 1e3
         out[name] = {"Ksize": int(fea.Ksize), "elements": int(len(elems)), "create_ms": ms[0], "assemble_ms": ms[1], "dirichlet_ms": ms[2],
                      "trial_setup_ms": ms[3], "compute1_ms": float(ms[:4].sum()), "lm_trial_ms": ms[4]}
@@ -325,6 +324,20 @@ def load_traffic():
     return {}
 
 
+def best_batch_ms(f, reps, warm=5, batch=10):
+    """Per-call latency of f in ms: `warm` untimed calls, then reps calls in batches of `batch`; the BEST batch mean.  These legs
+    are single calls of 30-150 us issued from an otherwise idle process: the card's power management now and then runs a batch
+    at a fraction of its clocks (0.79 ms where 0.086 is the rule, seen in isolation), and a mean over everything reports that
+    instead of the call."""
+    for _ in range(warm): f()
+    best = float("inf")
+    for _ in range(max(3, reps // batch)):
+        t0 = time.perf_counter()
+        for _ in range(batch): f()
+        best = min(best, (time.perf_counter() - t0) / batch)
+    return best * 1e3
+
+
 def matcher_loops_bench():
     """Tracking-time matching: one call = one whole ORBmatcher loop, host arrays in and out
     (PCIe and the per-call host work included); the oracle's literal loops on the same inputs are timed by
@@ -333,11 +346,7 @@ def matcher_loops_bench():
     from orb_slam2_e_amd.synth import synth_bow_case, synth_projection_case
     from orb_slam2_e_amd.vocabulary import feature_vector_arrays
 
-    def ms(f, reps):
-        for _ in range(5): f()                      # the card idles (and clocks down) while the host times the CPU leg
-        t0 = time.perf_counter()
-        for _ in range(reps): f()
-        return (time.perf_counter() - t0) / reps * 1e3
+    ms = best_batch_ms                              # (the card idles -- and clocks down -- while the host times the CPU leg)
 
     q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(0, n=2000, nq=2000, hot=2000)
     d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
@@ -375,15 +384,12 @@ def stereo_bench():
 
     u, d = frame()
     reps = 50
-    t0 = time.perf_counter()
-    for _ in range(reps): frame()
-    t_all = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter()
-    for _ in range(reps): ComputeStereoMatches(eL, eR, mb, np.float32(bf))
-    t_st = (time.perf_counter() - t0) / reps
+    t_all = best_batch_ms(frame, reps) * 1e-3
+    t_st = best_batch_ms(lambda: ComputeStereoMatches(eL, eR, mb, np.float32(bf)), reps) * 1e-3
     pool.shutdown()
     out = {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "compute_stereo_matches_ms": t_st * 1e3,
            "threads": "left and right extraction on two host threads, as Frame.cc:78-81",
+           "timing": "per-call latencies of this leg, the matcher loops and the LM trial: best mean of 10-call batches (best_batch_ms); Compute(1) phases: medians of 30 calls",
            "stereo_pairs_per_s": 1.0 / t_all, "matched": int((u >= 0).sum())}
 
     # ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024) on the pair's own keypoints as two keyframes one KITTI
@@ -399,10 +405,7 @@ def stereo_bench():
     whole = lambda: m.SearchForTriangulation(kL, dL, fv1, has1, s1, kR, dR, fv2, has2, s2, F12, ex, ey, sf, sg, False)
     inner = lambda: m.match_triangulation(kL, dL, kR, dR, off, idx, has1, has2, s1, s2, F12, ex, ey, sf, sg, False)
     for name, fn in (("search_for_triangulation_ms", whole), ("search_for_triangulation_gated_loop_ms", inner)):
-        for _ in range(5): fn()
-        t0 = time.perf_counter()
-        for _ in range(reps): fn()
-        out[name] = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = best_batch_ms(fn, reps)
     out["search_for_triangulation"] = {"keypoints": [len(kL), len(kR)], "candidates": int(len(idx)), "matches": int(whole()[1])}
 
     # the same path with the batch as the unit: 64 resident pairs, left and right extract_batch on two handles and ONE
