@@ -139,16 +139,22 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         fea.cg_iterate(iters); fea.cg_result()        # warm + per-kernel split (untimed pass, all kinds): the same length as the timed
                                                       # pass -- the first full-length launch after a set-up runs ~6 % longer than the next ones
         split = {k: v[0] / max(v[1], 1) for k, v in fea.profile_read().items() if v[1]}
-        fea.cg_setup(b)
-        fea.profile((4 | 32) if nm > 1 else 0)        # timed region: events around k_fem_spmv / k_fem_cg_resident only (batch);
-        barrier()                                     # the single mesh replays a hipGraph (no events inside)
-        t0 = time.perf_counter()
-        fea.cg_iterate(iters)
-        x, rel = fea.cg_result()                       # synchronises
-        xall = gather_displacements(x, rank, world, cdev)   # N > 1: [world * nm, ndof] on rank 0
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0, world, cdev)
-        prof = fea.profile_read()
+        # the timed region, twice, the better one kept (a leg is ONE launch of 7-25 ms: a transient dip of the card's clocks would
+        # be the whole measurement; the iterations are deterministic, both passes leave the same x)
+        dt, prof = float("inf"), None
+        for attempt in range(2):
+            fea.cg_setup(b)
+            fea.profile((4 | 32) if nm > 1 else 0)        # events around k_fem_spmv / k_fem_cg_resident only (batch);
+            barrier()                                     # the single mesh replays a hipGraph (no events inside)
+            t0 = time.perf_counter()
+            fea.cg_iterate(iters)
+            x, rel = fea.cg_result()                       # synchronises
+            xall = gather_displacements(x, rank, world, cdev)   # N > 1: [world * nm, ndof] on rank 0
+            barrier()
+            dt_a = max_over_ranks(time.perf_counter() - t0, world, cdev)
+            prof_a = fea.profile_read()
+            if dt_a < dt:
+                dt, prof = dt_a, prof_a
         n, nnz = fea.Ksize, fea.nnz
         distinct = label == "batch_distinct_topologies"
         spmv_ms = prof["k_fem_spmv"][0] / max(prof["k_fem_spmv"][1], 1) if prof["k_fem_spmv"][1] else split.get("k_fem_spmv", 0.0)
