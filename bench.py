@@ -391,9 +391,17 @@ def stereo_bench():
     u, d = frame()
     reps = 50
     t_all = best_batch_ms(frame, reps) * 1e-3
+    # the same frame from ONE host thread: orbx_extract_pair enqueues both images' kernel chains before it waits for either
+    from orb_slam2_e_amd import extract_pair
+    def frame_one_call():
+        extract_pair(eL, eR, left, right)
+        return ComputeStereoMatches(eL, eR, mb, np.float32(bf))
+    u1, d1 = frame_one_call()
+    t_one = best_batch_ms(frame_one_call, reps) * 1e-3 if np.array_equal(u1, u) and np.array_equal(d1, d) else float("nan")
     t_st = best_batch_ms(lambda: ComputeStereoMatches(eL, eR, mb, np.float32(bf)), reps) * 1e-3
     pool.shutdown()
-    out = {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "compute_stereo_matches_ms": t_st * 1e3,
+    out = {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "stereo_frame_one_call_ms": t_one * 1e3,
+           "compute_stereo_matches_ms": t_st * 1e3,
            "threads": "left and right extraction on two host threads, as Frame.cc:78-81",
            "timing": "per-call latencies of this leg, the matcher loops and the LM trial: best mean of 10-call batches (best_batch_ms); Compute(1) phases: medians of 30 calls",
            "stereo_pairs_per_s": 1.0 / t_all, "matched": int((u >= 0).sum())}

@@ -93,6 +93,14 @@ int orbx_plan(const orbx_params *params, int width, int height, orbx_plan_info *
 int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride,
                  orbx_keypoint *kps, uint8_t *desc, int cap, int *n);
 
+/* The two images of a stereo frame (Frame.cc:78-81: ExtractORB on two threads, then join) in one call from one host thread:
+ * both kernel chains are enqueued on their handles' streams before the host waits for either, so they overlap on the
+ * device as the reference's threads overlap on the CPU.  Results as from two orbx_extract calls (left != right; same
+ * error behaviour).  Frame::ComputeStereoMatches = orbx_stereo_match on the two handles afterwards. */
+int orbx_extract_pair(orbx_extractor *left, const uint8_t *image_left, orbx_extractor *right, const uint8_t *image_right, int width,
+                      int height, int stride, orbx_keypoint *kps_left, uint8_t *desc_left, int cap_left, int *n_left,
+                      orbx_keypoint *kps_right, uint8_t *desc_right, int cap_right, int *n_right);
+
 /* Batch form: `batch` frames, frame f at images + f*frame_stride.  images_dev may
  * be a device pointer (is_device=1: inputs already resident in HBM) or host.
  * Results stay on the device until orbx_download / orbx_result_dev. Asynchronous

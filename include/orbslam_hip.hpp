@@ -85,6 +85,7 @@ public:
         mPyramidStale = true;
     }
 
+    void MarkPyramidStale() { mPyramidStale = true; }   // after a call that extracted through the handle (ExtractPair)
     int GetLevels() const { return mnLevels; }
     float GetScaleFactor() const { return mnLevels > 1 ? mvScaleFactor[1] : 1.0f; }
     std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
@@ -117,6 +118,28 @@ private:
     bool mPyramidStale = true;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
+
+// The two ExtractORB calls of a stereo frame (Frame.cc:78-81: two threads, then join) from one thread: both images' kernel chains
+// are enqueued before the host waits for either (orbx_extract_pair).  Outputs as from left(...) and right(...).
+inline int ExtractPair(ORBextractor &left, const ImageView &image_left, std::vector<KeyPoint> &keys_left, std::vector<uint8_t> &desc_left,
+                       ORBextractor &right, const ImageView &image_right, std::vector<KeyPoint> &keys_right, std::vector<uint8_t> &desc_right)
+{
+    if (image_left.empty() || image_right.empty() || image_left.cols != image_right.cols || image_left.rows != image_right.rows ||
+        image_left.step != image_right.step)
+        return ORBX_ERR_ARG;
+    int rc = orbx_reserve(left.handle(), image_left.cols, image_left.rows, 1);
+    if (rc == ORBX_OK) rc = orbx_reserve(right.handle(), image_right.cols, image_right.rows, 1);
+    if (rc != ORBX_OK) return rc;
+    const int capl = orbx_keypoint_capacity(left.handle()), capr = orbx_keypoint_capacity(right.handle());
+    keys_left.resize(capl); desc_left.resize((size_t)capl * 32); keys_right.resize(capr); desc_right.resize((size_t)capr * 32);
+    int nl = 0, nr = 0;
+    rc = orbx_extract_pair(left.handle(), image_left.data, right.handle(), image_right.data, image_left.cols, image_left.rows, image_left.step,
+                           keys_left.data(), desc_left.data(), capl, &nl, keys_right.data(), desc_right.data(), capr, &nr);
+    if (rc != ORBX_OK) nl = nr = 0;
+    keys_left.resize(nl); desc_left.resize((size_t)nl * 32); keys_right.resize(nr); desc_right.resize((size_t)nr * 32);
+    left.MarkPyramidStale(); right.MarkPyramidStale();
+    return rc;
+}
 
 // Frame::ComputeStereoMatches (src/Frame.cc:527-701) on the results the two
 // extractors still hold on the device after operator() ran on the left / right image.

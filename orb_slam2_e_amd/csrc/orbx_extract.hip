@@ -2218,11 +2218,11 @@ int orbx_download_batch(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, i
     return ORBX_OK;
 }
 
-int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride, orbx_keypoint *kps,
-                 uint8_t *desc, int cap, int *n)
+// One host image through the extractor, in two halves: everything up to the last launch (extract_enqueue), and the wait + the copy
+// out of the pinned block (extract_finish).  orbx_extract is one after the other; orbx_extract_pair enqueues the left and the right
+// image of a stereo frame on their two handles' streams before it waits for either.
+static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride)
 {
-    if (!ex || !n) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
-    if (!image || width <= 0 || height <= 0) { *n = 0; return ORBX_OK; } // empty image: outputs untouched (:1054)
     // ORBextractor::operator() on one host image is latency-bound: stage the image and the results through pinned
     // buffers so that the call is one H2D, the kernel chain, one D2H and a single stream synchronisation
     const size_t in_bytes = (size_t)stride * height, in_room = (in_bytes + 255) & ~(size_t)255;   // 16-byte pieces on both sides
@@ -2254,7 +2254,15 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
                        reinterpret_cast<const uint4 *>(ex->d_kps), reinterpret_cast<const uint4 *>(ex->d_desc), (int)(kp_bytes / 16),
                        (int)(de_bytes / 16), reinterpret_cast<uint4 *>(o));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipStreamSynchronize(st));
+    ex->pin_result_off = in_room;
+    return ORBX_OK;
+}
+
+static int extract_finish(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const size_t kp_bytes = (sizeof(orbx_keypoint) * (size_t)ex->kcap + 15) & ~(size_t)15;
+    const uint8_t *o = ex->h_pin + ex->pin_result_off;
     int cnt = 0;
     memcpy(&cnt, o, sizeof(int));
     *n = cnt;
@@ -2264,6 +2272,31 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
         if (desc) memcpy(desc, o + 16 + kp_bytes, (size_t)32 * cnt);
     }
     return ORBX_OK;
+}
+
+int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride, orbx_keypoint *kps,
+                 uint8_t *desc, int cap, int *n)
+{
+    if (!ex || !n) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
+    if (!image || width <= 0 || height <= 0) { *n = 0; return ORBX_OK; } // empty image: outputs untouched (:1054)
+    const int rc = extract_enqueue(ex, image, width, height, stride);
+    return rc != ORBX_OK ? rc : extract_finish(ex, kps, desc, cap, n);
+}
+
+int orbx_extract_pair(orbx_extractor *left, const uint8_t *image_left, orbx_extractor *right, const uint8_t *image_right, int width,
+                      int height, int stride, orbx_keypoint *kps_left, uint8_t *desc_left, int cap_left, int *n_left,
+                      orbx_keypoint *kps_right, uint8_t *desc_right, int cap_right, int *n_right)
+{
+    if (!left || !right || left == right || !n_left || !n_right || !image_left || !image_right || width <= 0 || height <= 0 || stride < width)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    // both chains are on their queues before the host waits for either: the two extractions of a stereo frame overlap on the
+    // device as they do on the reference's two threads (Frame.cc:78-81), without the threads
+    int rc = extract_enqueue(left, image_left, width, height, stride);
+    if (rc == ORBX_OK) rc = extract_enqueue(right, image_right, width, height, stride);
+    if (rc != ORBX_OK) { (void)hipStreamSynchronize(left->stream); return rc; }
+    rc = extract_finish(left, kps_left, desc_left, cap_left, n_left);
+    const int rc2 = extract_finish(right, kps_right, desc_right, cap_right, n_right);
+    return rc != ORBX_OK ? rc : rc2;
 }
 
 int orbx_result_dev(orbx_extractor *ex, const orbx_keypoint **kps, const uint8_t **desc, const int32_t **counts, int *capacity)

@@ -68,6 +68,7 @@ struct orbx_extractor {
     int resize_tailwin[orbx_detail::MAXL] = {}; // the tail tiles of k_pyr_resize may use 8-byte source windows at this level // interior workgroups per row group of k_pyr_resize (0: no fast path at this level)
     int kcap; // keypoints per frame the result arrays hold: nfeatures + 3*nlevels, more on wide frames with tiny quotas (orbx_reserve)
     int kcap_params = 0;
+    size_t pin_result_off = 0;   // where the last orbx_extract's result block starts in h_pin
 
     // geometry of the reserved workspace
     int width = 0, height = 0, batch = 0;

@@ -188,6 +188,24 @@ def plan(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height):
     return out
 
 
+def extract_pair(left, right, image_left, image_right):
+    """The two images of a stereo frame through their two extractors in ONE call from one host thread (orbx_extract_pair: both
+    kernel chains enqueued before the host waits; the reference runs them on two threads, Frame.cc:78-81).
+    Returns ((kpsL, descL), (kpsR, descR)) as two ORBextractor.__call__ would."""
+    il = np.ascontiguousarray(image_left); ir = np.ascontiguousarray(image_right)
+    assert il.dtype == np.uint8 and il.ndim == 2 and il.shape == ir.shape and ir.dtype == np.uint8
+    h, w = il.shape
+    left._reserve(w, h, 1); right._reserve(w, h, 1)
+    out = []
+    for e in (left, right):
+        out.append((np.zeros(e.capacity, KP_DTYPE), np.zeros((e.capacity, 32), np.uint8), C.c_int(0)))
+    (kl, dl, nl), (kr, dr, nr) = out
+    check(left._L.orbx_extract_pair(left._h, _p(il), right._h, _p(ir), w, h, il.strides[0], _p(kl), _p(dl), left.capacity, C.byref(nl),
+                                    _p(kr), _p(dr), right.capacity, C.byref(nr)))
+    left._shape = right._shape = (h, w)
+    return (kl[:nl.value].copy(), dl[:nl.value].copy()), (kr[:nr.value].copy(), dr[:nr.value].copy())
+
+
 def stereo_match_batch(left, right, mb, mbf, stream=None):
     """orbx_stereo_match on every frame of the last batch extracted on both handles (asynchronous on `stream`)."""
     L = left._L

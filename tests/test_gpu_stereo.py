@@ -136,3 +136,23 @@ def test_search_for_triangulation_on_the_pairs_own_keypoints():
         assert rn > (50 if only_stereo else 200), rn
         assert nm == rn and np.array_equal(m12, r12)
         assert np.array_equal(pairs[:, 0], np.nonzero(r12 >= 0)[0]) and np.array_equal(pairs[:, 1], r12[r12 >= 0])
+
+
+def test_stereo_frame_in_one_call_from_one_thread():
+    """orbx_extract_pair: both images of a stereo frame enqueued on their handles' streams before the host waits (the reference
+    uses two threads, Frame.cc:78-81).  Same keypoints, descriptors and stereo matches as two separate calls; a second pair of
+    another size on the same handles; the pyramids the stereo matcher reads are the pair's."""
+    from orb_slam2_e_amd import extract_pair
+    fx, bf = 718.856, 386.1448
+    mb = np.float32(bf) / np.float32(fx)
+    eL, eR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+    sL, sR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
+    for k, (w, h) in ((0, (1242, 375)), (3, (640, 480)), (1, (1242, 375))):
+        left, right = synth_stereo_pair(k, w=w, h=h)
+        (kl, dl), (kr, dr) = extract_pair(eL, eR, left, right)
+        rl, rr = sL(left), sR(right)
+        assert kl.tobytes() == rl[0].tobytes() and np.array_equal(dl, rl[1]) and kr.tobytes() == rr[0].tobytes() and np.array_equal(dr, rr[1])
+        u, d = ComputeStereoMatches(eL, eR, mb, np.float32(bf))
+        ru, rd = ComputeStereoMatches(sL, sR, mb, np.float32(bf))
+        assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(d.view(np.uint32), rd.view(np.uint32)) and (u >= 0).sum() > 200
+
