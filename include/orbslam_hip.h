@@ -332,6 +332,17 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
                              const float *scale_factors2, const float *level_sigma2, int nlevels, int32_t *match12,
                              int32_t *best_dist);
 
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024) as a whole: the FeatureVector co-iteration (:881-891,
+ * :1004-1012; a FeatureVector = nodes ascending, off[nn + 1], items, as for orbm_search_by_bow), the gated loop above, the
+ * rotation histogram + ComputeThreeMaxima + rejection when check_orientation (:992-1012).  match12[n1] = index in KF2 or
+ * -1; vMatchedPairs = its non-negative entries in index order (:1014-1021); *nmatches = their number. */
+int orbm_search_for_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const int32_t *nodes1, const int32_t *off1,
+                                  const int32_t *items1, int nn1, const uint8_t *has_mappoint1, const uint8_t *stereo1,
+                                  const orbx_keypoint *kps2, const uint8_t *desc2, int n2, const int32_t *nodes2, const int32_t *off2,
+                                  const int32_t *items2, int nn2, const uint8_t *has_mappoint2, const uint8_t *stereo2, int only_stereo,
+                                  const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2, int nlevels,
+                                  int check_orientation, int32_t *match12, int *nmatches);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:305-370) for a batch of m
  * map points: the observed descriptors of point i are rows off[i]..off[i+1) of desc
  * (bad keyframes already filtered by the caller, :325-331); best[i] = index (within

@@ -828,6 +828,82 @@ int orbm_match_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, in
     return ORBX_OK;
 }
 
+// The whole ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024) in one call: the FeatureVector co-iteration (:881-891,
+// :1004-1012: equal node ids -> every keypoint of the node in KF1 scans the node's members of KF2, in member order), the gated loop
+// on the device (orbm_match_triangulation), the rotation histogram, ComputeThreeMaxima and the rejection (:992-1012).  A
+// FeatureVector = (nodes ascending, off, items), as for orbm_search_by_bow.  match12[n1] = index in KF2 or -1; the pair list
+// vMatchedPairs is its non-negative entries in index order (:1014-1021).
+int orbm_search_for_triangulation(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const int32_t *nodes1, const int32_t *off1,
+                                  const int32_t *items1, int nn1, const uint8_t *has_mappoint1, const uint8_t *stereo1,
+                                  const orbx_keypoint *kps2, const uint8_t *desc2, int n2, const int32_t *nodes2, const int32_t *off2,
+                                  const int32_t *items2, int nn2, const uint8_t *has_mappoint2, const uint8_t *stereo2, int only_stereo,
+                                  const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2, int nlevels,
+                                  int check_orientation, int32_t *match12, int *nmatches)
+{
+    if (n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || !nmatches || (n1 && !match12) || (nn1 && (!nodes1 || !off1 || !items1)) ||
+        (nn2 && (!nodes2 || !off2 || !items2)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    *nmatches = 0;
+    if (n1 == 0) return ORBX_OK;
+    for (int a = 0; a < nn1; ++a)
+        for (int k = off1[a]; k < off1[a + 1]; ++k)
+            if (items1[k] < 0 || items1[k] >= n1) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
+    for (int b = 0; b < nn2; ++b)
+        for (int k = off2[b]; k < off2[b + 1]; ++k)
+            if (items2[k] < 0 || items2[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
+    std::vector<int32_t> cnt(n1, 0), start2(n1, 0), cand_off((size_t)n1 + 1, 0);
+    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int k = off1[a]; k < off1[a + 1]; ++k) { cnt[items1[k]] = off2[b + 1] - off2[b]; start2[items1[k]] = off2[b]; }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) ++a;     // lower_bound on the other map (:1004-1011)
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) ++b;
+        }
+    }
+    for (int i = 0; i < n1; ++i) {
+        if ((long long)cand_off[i] + cnt[i] > 0x7fffffffll) ORBX_FAIL(ORBX_ERR_CAPACITY, "candidate lists exceed 2^31 entries");
+        cand_off[i + 1] = cand_off[i] + cnt[i];
+    }
+    std::vector<int32_t> cand((size_t)std::max(cand_off[n1], 1));
+    for (int i = 0; i < n1; ++i)
+        if (cnt[i]) memcpy(&cand[cand_off[i]], items2 + start2[i], sizeof(int32_t) * (size_t)cnt[i]);
+    std::vector<int32_t> best((size_t)n1);
+    const int rc = orbm_match_triangulation(kps1, desc1, n1, kps2, desc2, n2, cand_off.data(), cand.data(), has_mappoint1, has_mappoint2,
+                                            stereo1, stereo2, only_stereo, F12, ex, ey, scale_factors2, level_sigma2, nlevels, match12, best.data());
+    if (rc != ORBX_OK) return rc;
+    if (check_orientation) {
+        constexpr int HL = 30;     // HISTO_LENGTH, ORBmatcher.cc:40
+        int hist[HL] = {0};
+        std::vector<int> bin((size_t)n1, -1);
+        const float factor = 1.0f / HL;
+        for (int i = 0; i < n1; ++i)
+            if (match12[i] >= 0) {
+                float rot = kps1[i].angle - kps2[match12[i]].angle;     // :994-1001
+                if (rot < 0.0f) rot += 360.0f;
+                int b = (int)roundf(rot * factor);
+                if (b == HL) b = 0;
+                bin[i] = b; hist[b]++;
+            }
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;      // ComputeThreeMaxima, :1802-1843
+        for (int i = 0; i < HL; i++) {
+            const int sz = hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < n1; ++i)
+            if (bin[i] >= 0 && bin[i] != ind1 && bin[i] != ind2 && bin[i] != ind3) match12[i] = -1;
+    }
+    int nm = 0;
+    for (int i = 0; i < n1; ++i) nm += match12[i] >= 0;
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
 int orbm_hamming_matrix(const uint8_t *A, int nA, const uint8_t *B, int nB, uint16_t *out)
 {
     if (nA < 0 || nB < 0 || (nA && !A) || (nB && !B) || ((nA && nB) && !out)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");

@@ -109,22 +109,24 @@ class ORBmatcher:
         """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024): FeatureVector co-iteration into per-keypoint
         candidate lists (host), the gated loop on the device, rotation histogram + ComputeThreeMaxima + pair list (host).
         fv = (nodes ascending, off, items).  Returns (vMatchedPairs as an (m, 2) array, nmatches, vMatches12)."""
-        n1 = len(kps1)
-        cand_off, cand_idx = self.feature_vector_candidates(n1, fv1, fv2)
-        m12, _ = self.match_triangulation(kps1, desc1, kps2, desc2, cand_off, cand_idx, has_mp1, has_mp2, stereo1, stereo2, F12, ex, ey,
-                                          scale_factors2, level_sigma2, bOnlyStereo)
-        if self.mbCheckOrientation:
-            hit = np.nonzero(m12 >= 0)[0]
-            rot = np.asarray(kps1["angle"], np.float32)[hit] - np.asarray(kps2["angle"], np.float32)[m12[hit]]
-            rot = np.where(rot < 0, rot + np.float32(360.0), rot).astype(np.float32)
-            v = rot * np.float32(1.0 / self.HISTO_LENGTH)
-            bins = (np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))).astype(np.int64)       # round(): half away from zero
-            bins[bins == self.HISTO_LENGTH] = 0
-            hist = np.bincount(bins, minlength=self.HISTO_LENGTH)
-            keep = self.ComputeThreeMaxima(hist)
-            m12[hit[~np.isin(bins, keep)]] = -1
+        n1, n2 = len(kps1), len(kps2)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        (nd1, of1, it1), (nd2, of2, it2) = (tuple(i32(a) for a in fv) for fv in (fv1, fv2))
+        h1, h2, s1, s2 = u8(has_mp1), u8(has_mp2), u8(stereo1), u8(stereo2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
+        m12 = np.full(n1, -1, np.int32); nm = C.c_int(0)
+        self._L.orbm_search_for_triangulation.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] * 2 +
+                                                          [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        check(self._L.orbm_search_for_triangulation(_p(k1), _p(d1), n1, _p(nd1), _p(of1), _p(it1), len(nd1), _p(h1), _p(s1),
+                                                    _p(k2), _p(d2), n2, _p(nd2), _p(of2), _p(it2), len(nd2), _p(h2), _p(s2),
+                                                    int(bool(bOnlyStereo)), _p(F), float(ex), float(ey), _p(sf), _p(sg), len(sf),
+                                                    int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
         i1 = np.nonzero(m12 >= 0)[0]
-        return np.stack([i1, m12[i1]], 1), len(i1), m12
+        return np.stack([i1, m12[i1]], 1), nm.value, m12
 
     @staticmethod
     def feature_vector_candidates(n1, fv1, fv2):
