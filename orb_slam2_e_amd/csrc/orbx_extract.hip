@@ -1561,8 +1561,16 @@ namespace {
 // slots of a level in the selected-keypoint array: DistributeOctTree's worst case (see orbx_create) + 1
 inline int level_slots(const LevelInfo &lv) { return std::max(lv.N + 4, 4 * lv.nIni); }
 
+void drop_graph(orbx_extractor *ex)
+{
+    if (ex->g_exec) (void)hipGraphExecDestroy(ex->g_exec);
+    if (ex->g_graph) (void)hipGraphDestroy(ex->g_graph);
+    ex->g_exec = nullptr; ex->g_graph = nullptr; ex->g_w = ex->g_h = ex->g_stride = 0;
+}
+
 void free_workspace(orbx_extractor *ex)
 {
+    drop_graph(ex);
     void *ptrs[] = {ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_blur_frag, ex->d_xt, ex->d_yt, ex->d_cell_count,
                     ex->d_level_count, ex->d_level_ncand, ex->d_counts, ex->d_cands, ex->d_kpos, ex->d_sel,
                     ex->d_knode, ex->d_kq, ex->d_desc, ex->d_kps};
@@ -2221,7 +2229,7 @@ int orbx_download_batch(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, i
 // One host image through the extractor, in two halves: everything up to the last launch (extract_enqueue), and the wait + the copy
 // out of the pinned block (extract_finish).  orbx_extract is one after the other; orbx_extract_pair enqueues the left and the right
 // image of a stereo frame on their two handles' streams before it waits for either.
-static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride)
+static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride, bool as_graph = false)
 {
     // ORBextractor::operator() on one host image is latency-bound: stage the image and the results through pinned
     // buffers so that the call is one H2D, the kernel chain, one D2H and a single stream synchronisation
@@ -2231,12 +2239,14 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
     const size_t kp_bytes = (sizeof(orbx_keypoint) * (size_t)ex->kcap + 15) & ~(size_t)15, de_bytes = (size_t)32 * ex->kcap;
     const size_t out_bytes = 16 + kp_bytes + de_bytes;
     if (in_room + out_bytes > ex->pin_bytes) {
+        drop_graph(ex);
         if (ex->h_pin) (void)hipHostFree(ex->h_pin);
         ex->h_pin = nullptr; ex->pin_bytes = 0;
         ORBX_HIP(hipHostMalloc((void **)&ex->h_pin, in_room + out_bytes, hipHostMallocDefault));
         ex->pin_bytes = in_room + out_bytes;
     }
     if (in_room > ex->in_bytes) {
+        drop_graph(ex);
         if (ex->d_in) ORBX_HIP(hipFree(ex->d_in));
         ex->d_in = nullptr;
         ORBX_HIP(hipMalloc(&ex->d_in, in_room));
@@ -2244,18 +2254,48 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
     }
     hipStream_t st = ex->stream;
     memcpy(ex->h_pin, image, in_bytes);
+    ex->pin_result_off = in_room;
     // image in and results out by the compute queue itself (common.h: stage_in / stage_out): no hand-over to the copy engine
     // in front of and behind the twelve kernels of a frame
-    ORBX_HIP(orbx::stage_in(ex->d_in, ex->h_pin, in_room, st));
-    rc = orbx_extract_batch(ex, ex->d_in, 1, width, height, stride, in_bytes, 1, st);
-    if (rc != ORBX_OK) return rc;
-    uint8_t *o = ex->h_pin + in_room;
-    hipLaunchKernelGGL(k_result_out, dim3((unsigned)(((kp_bytes + de_bytes) / 16 + 255) / 256)), dim3(256), 0, st, (const int *)ex->d_counts,
-                       reinterpret_cast<const uint4 *>(ex->d_kps), reinterpret_cast<const uint4 *>(ex->d_desc), (int)(kp_bytes / 16),
-                       (int)(de_bytes / 16), reinterpret_cast<uint4 *>(o));
-    ORBX_HIP(hipGetLastError());
-    ex->pin_result_off = in_room;
-    return ORBX_OK;
+    auto enqueue = [&]() -> int {
+        ORBX_HIP(orbx::stage_in(ex->d_in, ex->h_pin, in_room, st));
+        const int rc2 = orbx_extract_batch(ex, ex->d_in, 1, width, height, stride, in_bytes, 1, st);
+        if (rc2 != ORBX_OK) return rc2;
+        uint8_t *o = ex->h_pin + in_room;
+        hipLaunchKernelGGL(k_result_out, dim3((unsigned)(((kp_bytes + de_bytes) / 16 + 255) / 256)), dim3(256), 0, st, (const int *)ex->d_counts,
+                           reinterpret_cast<const uint4 *>(ex->d_kps), reinterpret_cast<const uint4 *>(ex->d_desc), (int)(kp_bytes / 16),
+                           (int)(de_bytes / 16), reinterpret_cast<uint4 *>(o));
+        ORBX_HIP(hipGetLastError());
+        return ORBX_OK;
+    };
+    // As a graph (orbx_extract_pair): the fourteen launches of a frame cost the host ~0.1 ms to enqueue, which is what the SECOND
+    // image of a stereo frame waits for; one graph launch per image lets the two chains run side by side on the device.  Captured
+    // on the second call of a frame size (the first has done every one-time set-up), only while nothing in the chain depends on
+    // the call (no per-kernel profiling events, no pending reader to wait for); any failure falls back to plain launches for good.
+    const bool can = as_graph && ex->prof.mask == 0 && !ex->reader_pending && !ex->g_failed;
+    if (can && ex->g_exec && ex->g_w == width && ex->g_h == height && ex->g_stride == stride) {
+        ORBX_HIP(hipGraphLaunch(ex->g_exec, st));
+        ex->last_batch = 1; ex->last_stream = st;
+        return ORBX_OK;
+    }
+    const bool second = ex->g_seen_w == width && ex->g_seen_h == height && ex->g_seen_stride == stride;
+    ex->g_seen_w = width; ex->g_seen_h = height; ex->g_seen_stride = stride;
+    if (can && second && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        rc = enqueue();
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(st, &g);
+        hipGraphExec_t x = nullptr;
+        if (rc == ORBX_OK && e == hipSuccess && g && hipGraphInstantiate(&x, g, nullptr, nullptr, 0) == hipSuccess) {
+            drop_graph(ex);
+            ex->g_graph = g; ex->g_exec = x; ex->g_w = width; ex->g_h = height; ex->g_stride = stride;
+            ORBX_HIP(hipGraphLaunch(ex->g_exec, st));
+            return ORBX_OK;
+        }
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        ex->g_failed = true;        // nothing of the captured chain has run: enqueue it plainly
+    }
+    return enqueue();
 }
 
 static int extract_finish(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int cap, int *n)
@@ -2291,8 +2331,8 @@ int orbx_extract_pair(orbx_extractor *left, const uint8_t *image_left, orbx_extr
         ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     // both chains are on their queues before the host waits for either: the two extractions of a stereo frame overlap on the
     // device as they do on the reference's two threads (Frame.cc:78-81), without the threads
-    int rc = extract_enqueue(left, image_left, width, height, stride);
-    if (rc == ORBX_OK) rc = extract_enqueue(right, image_right, width, height, stride);
+    int rc = extract_enqueue(left, image_left, width, height, stride, true);
+    if (rc == ORBX_OK) rc = extract_enqueue(right, image_right, width, height, stride, true);
     if (rc != ORBX_OK) { (void)hipStreamSynchronize(left->stream); return rc; }
     rc = extract_finish(left, kps_left, desc_left, cap_left, n_left);
     const int rc2 = extract_finish(right, kps_right, desc_right, cap_right, n_right);

@@ -69,6 +69,12 @@ struct orbx_extractor {
     int kcap; // keypoints per frame the result arrays hold: nfeatures + 3*nlevels, more on wide frames with tiny quotas (orbx_reserve)
     int kcap_params = 0;
     size_t pin_result_off = 0;   // where the last orbx_extract's result block starts in h_pin
+    // orbx_extract_pair: one frame's launch chain (image staging, the kernels, the result block) as a graph, captured on the second
+    // call of a frame size and replayed from then on (dropped with the workspace, the pinned block or the input buffer)
+    hipGraph_t g_graph = nullptr;
+    hipGraphExec_t g_exec = nullptr;
+    int g_w = 0, g_h = 0, g_stride = 0, g_seen_w = 0, g_seen_h = 0, g_seen_stride = 0;
+    bool g_failed = false;
 
     // geometry of the reserved workspace
     int width = 0, height = 0, batch = 0;

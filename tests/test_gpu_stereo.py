@@ -155,4 +155,22 @@ def test_stereo_frame_in_one_call_from_one_thread():
         u, d = ComputeStereoMatches(eL, eR, mb, np.float32(bf))
         ru, rd = ComputeStereoMatches(sL, sR, mb, np.float32(bf))
         assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(d.view(np.uint32), rd.view(np.uint32)) and (u >= 0).sum() > 200
+    # the same size again and again with other images: from its second call of a size the pair call replays the frame's launch
+    # chain as a graph -- the replay must read the NEW images and leave the same results as plain launches
+    for k in (5, 6, 7, 8, 5):
+        left, right = synth_stereo_pair(k, w=1242, h=375)
+        (kl, dl), (kr, dr) = extract_pair(eL, eR, left, right)
+        rl, rr = sL(left), sR(right)
+        assert kl.tobytes() == rl[0].tobytes() and np.array_equal(dl, rl[1]) and kr.tobytes() == rr[0].tobytes() and np.array_equal(dr, rr[1])
+        u, d = ComputeStereoMatches(eL, eR, mb, np.float32(bf))
+        ru, rd = ComputeStereoMatches(sL, sR, mb, np.float32(bf))
+        assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    # plain calls on the handles that hold a graph, profiling switched on (no replay then), and back
+    assert eL(left)[0].tobytes() == rl[0].tobytes()
+    eL._L.orbx_profile_enable(eL._h, -1)
+    (kl, dl), (kr, dr) = extract_pair(eL, eR, left, right)
+    eL._L.orbx_profile_enable(eL._h, 0)
+    assert kl.tobytes() == rl[0].tobytes() and np.array_equal(dr, rr[1])
+    (kl, dl), (kr, dr) = extract_pair(eL, eR, right, left)
+    assert kl.tobytes() == rr[0].tobytes() and kr.tobytes() == rl[0].tobytes()
 
