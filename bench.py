@@ -431,20 +431,23 @@ def stereo_bench():
     dr = torch.from_numpy(np.stack([pairs[k % 4][1] for k in range(Bp)])).cuda()
     from orb_slam2_e_amd import stereo_download_batch, stereo_match_batch
     ts = torch.cuda.Stream(); st = ts.cuda_stream
+    ts2 = torch.cuda.Stream(); st2 = ts2.cuda_stream
     bL, bR = ORBextractor(*PARAMS), ORBextractor(*PARAMS)
     Hs, Ws = pairs[0][0].shape
 
     def batch_step():
+        # left and right extraction on two streams (they overlap as the pipeline contexts of the frames/s leg do), the matcher
+        # on the left one: the library orders it behind the right extraction, and the next right extraction behind it, by events
         bL.extract_batch_device(dl.data_ptr(), Bp, Hs, Ws, st)
-        bR.extract_batch_device(dr.data_ptr(), Bp, Hs, Ws, st)
+        bR.extract_batch_device(dr.data_ptr(), Bp, Hs, Ws, st2)
         stereo_match_batch(bL, bR, mb, np.float32(bf), st)
 
     for _ in range(3): batch_step()
-    ts.synchronize()
+    ts.synchronize(); ts2.synchronize()
     nb = 20
     t0 = time.perf_counter()
     for _ in range(nb): batch_step()
-    ts.synchronize()
+    ts.synchronize(); ts2.synchronize()
     t_b = (time.perf_counter() - t0) / nb
     U, D, cnt = stereo_download_batch(bL)
     # outside the timed region: the batch's first four frames are the four distinct pairs -- against the oracle
@@ -458,7 +461,7 @@ def stereo_bench():
         ok = ok and n == len(okL) and np.array_equal(U[f, :n].view(np.uint32), ou.view(np.uint32)) and \
             np.array_equal(D[f, :n].view(np.uint32), od.view(np.uint32))
     out["batch"] = {"pairs": Bp, "ms_per_batch": t_b * 1e3, "pairs_per_s": Bp / t_b, "verified": bool(ok),
-                    "what": "64 resident 1242x375 pairs: left + right extract_batch and one orbx_stereo_match over all frames on one stream"}
+                    "what": "64 resident 1242x375 pairs: left and right extract_batch on two streams, one orbx_stereo_match over all frames on the left one (ordered by events inside the library)"}
     return out
 
 

@@ -2253,6 +2253,10 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
         ex->in_bytes = in_room;
     }
     hipStream_t st = ex->stream;
+    if (ex->reader_pending) {   // a consumer on another stream (the stereo matcher, a *_dev matcher call) still reads the last results
+        if (ex->reader_stream != st) ORBX_HIP(hipStreamWaitEvent(st, ex->reader_ev, 0));
+        ex->reader_pending = false;
+    }
     memcpy(ex->h_pin, image, in_bytes);
     ex->pin_result_off = in_room;
     // image in and results out by the compute queue itself (common.h: stage_in / stage_out): no hand-over to the copy engine
@@ -2271,8 +2275,9 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
     // As a graph (orbx_extract_pair): the fourteen launches of a frame cost the host ~0.1 ms to enqueue, which is what the SECOND
     // image of a stereo frame waits for; one graph launch per image lets the two chains run side by side on the device.  Captured
     // on the second call of a frame size (the first has done every one-time set-up), only while nothing in the chain depends on
-    // the call (no per-kernel profiling events, no pending reader to wait for); any failure falls back to plain launches for good.
-    const bool can = as_graph && ex->prof.mask == 0 && !ex->reader_pending && !ex->g_failed;
+    // the call (no per-kernel profiling events; a pending reader of the last results is waited for in front of the chain); any
+    // failure falls back to plain launches for good.
+    const bool can = as_graph && ex->prof.mask == 0 && !ex->g_failed;
     if (can && ex->g_exec && ex->g_w == width && ex->g_h == height && ex->g_stride == stride) {
         ORBX_HIP(hipGraphLaunch(ex->g_exec, st));
         ex->last_batch = 1; ex->last_stream = st;

@@ -334,9 +334,15 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
         ORBX_HIP(hipMemcpy(left->d_st_scale, sc, sizeof(sc), hipMemcpyHostToDevice));
         left->st_batch = left->batch;
     }
-    // streams: results of both extractors must be complete before matching
-    if (st != left->last_stream) ORBX_HIP(hipStreamSynchronize(left->last_stream));
-    if (st != right->last_stream) ORBX_HIP(hipStreamSynchronize(right->last_stream));
+    // streams: the results of both extractors must be complete before the matching starts -- ordered on the device (an event
+    // recorded behind each extraction that ran on another stream), the host does not wait
+    for (orbx_extractor *e : {left, right})
+        if (st != e->last_stream && hipStreamQuery(e->last_stream) != hipSuccess) {   // (an idle stream has nothing to wait for: the
+            (void)hipGetLastError();                                                  // usual case after two orbx_extract calls)
+            if (!e->order_ev) ORBX_HIP(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+            ORBX_HIP(hipEventRecord(e->order_ev, e->last_stream));
+            ORBX_HIP(hipStreamWaitEvent(st, e->order_ev, 0));
+        }
     left->st_stream = st;
     const float maxD = mbf / mb; // :557-559
     const int nRows = left->lv[0].h;
@@ -351,6 +357,10 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
     hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(MED_T), 0, st, left->d_counts, cap, left->d_st_sad, left->d_uright,
                        left->d_depth, left->d_st_nvalid);
     ORBX_HIP(hipGetLastError());
+    // ... and the next extraction on a handle whose own stream is another one must not overwrite what these kernels still read
+    // (keypoints, descriptors, pyramids): it waits for this point of `st` (orbx_extract_batch, reader_pending)
+    for (orbx_extractor *e : {left, right})
+        if (st != e->last_stream) orbx_detail::reader_done(e, st);
     return ORBX_OK;
 }
 
