@@ -104,6 +104,19 @@ int main(int argc, char **argv)
     if (nst < 20) { printf("FAIL stereo matches %d\n", nst); return 1; }
     for (size_t i = 0; i < uR.size(); ++i)
         if (uR[i] >= 0 && !(depth[i] > 0.f)) { printf("FAIL stereo depth\n"); return 1; }
+    {   // the same stereo frame through ExtractPair, three times (the second call captures each image's launch chain as a graph,
+        // the third replays it): same keypoints, descriptors and stereo matches as the two separate calls above
+        ORBextractor pl(1000, 1.2f, 8, 20, 7), pr(1000, 1.2f, 8, 20, 7);
+        for (int rep = 0; rep < 3; ++rep) {
+            std::vector<KeyPoint> kl2, kr2; std::vector<uint8_t> dl2, dr2;
+            if (ExtractPair(pl, ImageView{img.data(), W, H, W}, kl2, dl2, pr, ImageView{imgR.data(), W, H, W}, kr2, dr2) != ORBX_OK ||
+                kl2.size() != kps.size() || kr2.size() != kr.size() || memcmp(dl2.data(), desc.data(), desc.size()) || memcmp(dr2.data(), dr.data(), dr.size()) ||
+                memcmp(kl2.data(), kps.data(), sizeof(KeyPoint) * kps.size())) { printf("FAIL ExtractPair rep %d\n", rep); return 1; }
+            std::vector<float> u2, d2;
+            if (ComputeStereoMatches(pl, pr, 0.5f, 400.f, u2, d2) != ORBX_OK || u2.size() != uR.size() || memcmp(u2.data(), uR.data(), sizeof(float) * uR.size()) ||
+                memcmp(d2.data(), depth.data(), sizeof(float) * depth.size())) { printf("FAIL stereo after ExtractPair rep %d\n", rep); return 1; }
+        }
+    }
     // whole-loop searches on the frame against itself: every keypoint must find itself
     ORBmatcher::FrameView F;
     F.mvKeysUn = kps.data(); F.mDescriptors = desc.data(); F.N = n; F.mnMinX = 0.f; F.mnMinY = 0.f; F.mnMaxX = (float)W; F.mnMaxY = (float)H;
