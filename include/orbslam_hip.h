@@ -188,8 +188,8 @@ int orbm_match_candidates(const uint8_t *A, int nA, const uint8_t *B, int nB,
  * (already holds an observed MapPoint, :87-89); uright (may be NULL) enables the
  * stereo check |xr - uRight[j]| <= r of :91-96.  init_dist: 256 or INT32_MAX.
  * Outputs per query: best / second distance, their octaves, arg-best (-1 if none).
- * Callers whose loop assigns matches as it goes (e.g. :126 F.mvpMapPoints[bestIdx]=pMP)
- * resolve the rare conflicts in a host post-pass. */
+ * Queries are independent here; the loops that assign matches as they go (e.g. :126
+ * F.mvpMapPoints[bestIdx]=pMP) are orbm_search_projection and the whole-function entries below. */
 typedef struct orbm_window_query {
     float u, v, r, xr;
     int32_t min_level, max_level;
@@ -396,6 +396,102 @@ int orbm_match_batch_dev(const uint8_t *desc_dev, const int32_t *counts_dev, int
  * cell_off[64 * 48 + 1]; both may be NULL. */
 int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
                       float max_x, float max_y, int32_t *perm, int32_t *cell_off, int32_t *nsorted);
+
+/* ------------------------------------------------------------------ resident frames
+ * A Frame / KeyFrame as the searches need it, kept in HBM between calls: Frame::AssignFeaturesToGrid (src/Frame.cc:245-260)
+ * runs once, on the device, when the handle is made -- as the reference builds mGrid once in the Frame constructor -- and
+ * every search of that frame (Tracking::TrackWithMotionModel calls SearchByProjection twice, then SearchLocalPoints;
+ * src/Tracking.cc) reads the same sorted keypoints, descriptors and cell table.  kps = mvKeysUn, desc = mDescriptors,
+ * uright = mvuRight (NULL: monocular, all -1), (min_x .. max_y) = mnMinX .. mnMaxY.  At most 8,192 keypoints.
+ * orbm_frame_from_extractor takes keypoints and descriptors of frame `frame` of the extractor's last call where they are, in
+ * HBM (no trip over PCIe): xy_undistorted (n x 2 floats, or NULL when the camera has no distortion: mvKeysUn = mvKeys,
+ * Frame.cc:270-275) replaces the keypoint coordinates, uright comes from the host or, with uright_from_stereo, from the
+ * last orbx_stereo_match on this (left) handle.  A handle is immutable and may be searched from several threads at once;
+ * what changes between calls (which keypoints already hold a map point) is an argument of each search. */
+typedef struct orbm_frame orbm_frame;
+int orbm_frame_create(const orbx_keypoint *kps, const uint8_t *desc, int n, const float *uright, float min_x, float min_y,
+                      float max_x, float max_y, orbm_frame **out);
+int orbm_frame_from_extractor(orbx_extractor *ex, int frame, const float *xy_undistorted, const float *uright, int uright_from_stereo,
+                              float min_x, float min_y, float max_x, float max_y, orbm_frame **out);
+int orbm_frame_destroy(orbm_frame *frame);
+/* n = keypoints, nsorted = those inside the grid */
+int orbm_frame_size(const orbm_frame *frame, int *n, int *nsorted);
+/* introspection (tests): the device-built order as orbm_sorted_frame returns it: perm[nsorted], cell_off[64 * 48 + 1] */
+int orbm_frame_layout(const orbm_frame *frame, int32_t *perm, int32_t *cell_off);
+
+/* The host-array searches above, on a resident frame (same results; `skip` / `occupied` by keypoint index as there). */
+int orbm_frame_search_window(const orbm_frame *frame, const orbm_window_query *queries, const uint8_t *qdesc, int nq, const uint8_t *skip,
+                             int init_dist, int32_t *best, int32_t *best_level, int32_t *second, int32_t *second_level, int32_t *idx);
+int orbm_frame_search_fuse(const orbm_frame *frame, const orbm_window_query *queries, const uint8_t *qdesc, int nq,
+                           const float *inv_level_sigma2, int nlevels, int32_t *best, int32_t *idx);
+int orbm_frame_search_projection(const orbm_frame *frame, const orbm_window_query *queries, const uint8_t *qdesc, const float *qangle,
+                                 const uint8_t *qtakes, int nq, const uint8_t *occupied, int th_accept, float nnratio, int ratio_same_level,
+                                 int check_orientation, int32_t *match_kp, int32_t *match_q, int *nmatches);
+int orbm_frame_search_for_initialization(const orbm_frame *frame2, const orbx_keypoint *kps2, const orbx_keypoint *kps1, const uint8_t *desc1,
+                                         int n1, float *prev_matched, int window_size, float nnratio, int check_orientation,
+                                         int32_t *matches12, int *nmatches);
+int orbm_frame_search_by_projection_map(const orbm_frame *frame, const uint8_t *has_mappoint, const float *mp_pos, const float *mp_normal,
+                                        const float *mp_min_dist, const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw,
+                                        const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels, float th,
+                                        float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj);
+
+/* ------------------------------------------- the SearchByProjection forms and SearchBySim3 as WHOLE functions
+ * Projection prefix, candidate search, in-loop assignment, acceptance and rotation check in one call, nothing in between
+ * returns to the host.  The pointer graph is passed flat: entry i of the vector the reference walks (LastFrame.mvpMapPoints,
+ * pKF->GetMapPointMatches(), vpPoints) becomes
+ *   valid[i]         what the reference's pointer tests leave: non-NULL and not an outlier (:1555-1558) / not bad and not in
+ *                    sAlreadyFound (:1697-1700) / not bad and not in spAlreadyFound (:516-517) / non-NULL, not already
+ *                    matched, not bad (:1352-1358)
+ *   pos[i][3]        MapPoint::GetWorldPos          desc[i][32]   MapPoint::GetDescriptor
+ *   normal[i][3]     GetNormal (Sim3 form)          min_distance / max_distance[i]   mfMinDistance / mfMaxDistance (the 0.8 /
+ *                                                   1.2 of Get{Min,Max}DistanceInvariance are applied by the library)
+ *   takes[i]         Observations() > 0 (Cur/Last form: :1603-1605; NULL = every assignment blocks its slot)
+ *   octave[i]        LastFrame.mvKeys[i].octave (Cur/Last form)
+ *   angle[i]         mvKeysUn[i].angle of the source keypoint (rotation check)
+ * Arrays a form does not read may be NULL.  orbm_view = calibration + scale pyramid of the searched frame (fx .. cy, mb, mbf,
+ * mfLogScaleFactor, mvScaleFactors); the image bounds are the frame handle's.  Poses are 4 x 4 row-major floats as cv::Mat
+ * mTcw holds them; cv::Mat arithmetic on them (Rcw, tcw, twc, tlc, Ow, the Sim3 decomposition) is done by the library in the
+ * reference's order.  occupied[j] (by keypoint index, NULL = none): the slot is taken before the call -- mvpMapPoints[j] with
+ * Observations() > 0 (:1603-1605), mvpMapPoints[j] != NULL (:1741-1742), vpMatched[j] != NULL (:574-575).
+ * Outputs as orbm_search_projection: match_kp[n] (entry index, -1 untouched, -2 cleared by the rotation check), match_q[entries],
+ * *nmatches; queries_out (optional, test aid) = the GetFeaturesInArea query formed per entry (r < 0: skipped before the search). */
+typedef struct orbm_points {
+    int32_t n;
+    const uint8_t *valid;
+    const float *pos, *normal, *min_distance, *max_distance;
+    const uint8_t *desc, *takes;
+    const int32_t *octave;
+    const float *angle;
+} orbm_points;
+typedef struct orbm_view {
+    float fx, fy, cx, cy, mb, mbf, log_scale_factor;
+    int32_t nlevels;
+    const float *scale_factors;
+} orbm_view;
+/* SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)   src/ORBmatcher.cc:1529-1671
+ * (th_high = TH_HIGH).  THE per-frame matcher call of Tracking::TrackWithMotionModel. */
+int orbm_search_by_projection_last(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const float *Tlw, const orbm_points *last,
+                                   const uint8_t *occupied, float th, int mono, int th_high, int check_orientation, int32_t *match_kp,
+                                   int32_t *match_q, int *nmatches, orbm_window_query *queries_out);
+/* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist)
+ * src/ORBmatcher.cc:1673-1800 (relocalisation refinement). */
+int orbm_search_by_projection_keyframe(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const orbm_points *kf,
+                                       const uint8_t *occupied, float th, int orb_dist, int check_orientation, int32_t *match_kp,
+                                       int32_t *match_q, int *nmatches, orbm_window_query *queries_out);
+/* SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+ * src/ORBmatcher.cc:491-604 (loop closing; th_low = TH_LOW).  Scw 4 x 4. */
+int orbm_search_by_projection_sim3(const orbm_frame *kf, const orbm_view *view, const float *Scw, const orbm_points *points,
+                                   const uint8_t *occupied, int th, int th_low, int32_t *match_kp, int32_t *match_q, int *nmatches,
+                                   orbm_window_query *queries_out);
+/* SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)   src/ORBmatcher.cc:1303-1527: both projections, both window searches
+ * (levels [l-1, l], best from INT_MAX, <= th_high = TH_HIGH) and the agreement check.  points1 / points2 have one entry per
+ * keypoint of kf1 / kf2 (valid folds vbAlreadyMatched1 / 2 in); T1w / T2w = the key frames' poses, R12 3 x 3, t12 3.
+ * vnMatch1 / vnMatch2 (optional) as the reference's locals; match12[i1] = idx2 where both directions agree, else -1 (the entries
+ * of vpMatches12 the reference overwrites, :1513-1521); *nfound. */
+int orbm_search_by_sim3(const orbm_frame *kf1, const orbm_frame *kf2, const orbm_view *view, const float *T1w, const float *T2w, float s12,
+                        const float *R12, const float *t12, const orbm_points *points1, const orbm_points *points2, float th, int th_high,
+                        int32_t *vnMatch1, int32_t *vnMatch2, int32_t *match12, int *nfound, orbm_window_query *q12_out,
+                        orbm_window_query *q21_out);
 
 /* Test aid: on != 0 makes the whole-loop projection searches use the one-wave sequential resolver (k_resolve) instead of the
  * parallel fixed-point resolver (k_resolve_par), which otherwise only takes over when the latter does not converge.  Both

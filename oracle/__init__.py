@@ -734,3 +734,131 @@ def pose_optimization_nr_fem_sequence(K, u0, ids, derived, script, Klarge=100000
                 break
             results.append(1)
     return trials, results
+
+
+# ---- the four projection searches as whole functions (projection prefix included) ---------------------------------
+
+def _frame_arrays(kps, desc):
+    xy = np.ascontiguousarray(np.stack([kps["x"], kps["y"]], 1), np.float32)
+    return (xy, np.ascontiguousarray(kps["octave"], np.int32), np.ascontiguousarray(kps["angle"], np.float32),
+            np.ascontiguousarray(desc, np.uint8))
+
+
+_f32 = lambda a: np.ascontiguousarray(a, np.float32)
+_u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+_opt = lambda a: _p(a) if a is not None else None
+
+
+def camera_centre(T):
+    """Ow = -Rcw.t() * tcw of a 4 x 4 pose in cv::Mat float arithmetic (ORBmatcher.cc:1542, :1679)."""
+    L = lib(); T = _f32(T).reshape(16); o = np.zeros(3, np.float32)
+    L.oracle_camera_centre.argtypes = [C.c_void_p, C.c_void_p]
+    L.oracle_camera_centre(_p(T), _p(o))
+    return o
+
+
+def decompose_sim3(Scw):
+    """Scw -> (Rcw, tcw, Ow) as ORBmatcher.cc:500-504 decomposes it."""
+    L = lib(); S = _f32(Scw).reshape(16)
+    R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); o = np.zeros(3, np.float32)
+    L.oracle_decompose_sim3.argtypes = [C.c_void_p] * 4
+    L.oracle_decompose_sim3(_p(S), _p(R), _p(t), _p(o))
+    return R.reshape(3, 3), t, o
+
+
+def sim3_transforms(s12, R12, t12):
+    """sR12, sR21, t21 of ORBmatcher.cc:1320-1323."""
+    L = lib(); R = _f32(R12).reshape(9); t = _f32(t12).reshape(3)
+    a = np.zeros(9, np.float32); b = np.zeros(9, np.float32); c = np.zeros(3, np.float32)
+    L.oracle_sim3_transforms.argtypes = [C.c_float] + [C.c_void_p] * 5
+    L.oracle_sim3_transforms(float(s12), _p(R), _p(t), _p(a), _p(b), _p(c))
+    return a.reshape(3, 3), b.reshape(3, 3), c
+
+
+def motion_direction(Tcw, Tlw, mb, mono):
+    L = lib(); a = _f32(Tcw).reshape(16); b = _f32(Tlw).reshape(16)
+    f = C.c_int(0); k = C.c_int(0)
+    L.oracle_motion_direction.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_motion_direction(_p(a), _p(b), float(mb), int(bool(mono)), C.byref(f), C.byref(k))
+    return bool(f.value), bool(k.value)
+
+
+def search_by_projection_last(kps, desc, uright, occupied, bounds, cam4, mb, mbf, Tcw, scale_factors, Tlw, valid, pos, mp_desc,
+                              takes, last_octave, last_angle, th, mono, th_high=95, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), ORBmatcher.cc:1529-1671, literally.
+    Returns (match_kp, match_q, nmatches, queries)."""
+    L = lib()
+    xy, octv, ang, d = _frame_arrays(kps, desc)
+    ur = _f32(uright) if uright is not None else None
+    oc = _u8(occupied) if occupied is not None else None
+    b4, c4, sc = _f32(bounds), _f32(cam4), _f32(scale_factors)
+    Tc, Tl = _f32(Tcw).reshape(16), _f32(Tlw).reshape(16)
+    va, ps, md, tk = _u8(valid), _f32(pos), _u8(mp_desc), _u8(takes)
+    lo, la = np.ascontiguousarray(last_octave, np.int32), _f32(last_angle)
+    nl = len(va)
+    mk = np.zeros(len(xy), np.int32); mq = np.zeros(nl, np.int32); q = np.zeros(nl, WQ_DTYPE)
+    L.oracle_search_by_projection_last.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_float] + \
+        [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3
+    nm = L.oracle_search_by_projection_last(_p(xy), _p(octv), _p(ang), _p(d), len(xy), _opt(ur), _opt(oc), _p(b4), _p(c4),
+                                            float(mb), float(mbf), _p(Tc), _p(sc), _p(Tl), nl, _p(va), _p(ps), _p(md), _p(tk),
+                                            _p(lo), _p(la), float(th), int(bool(mono)), int(th_high), int(bool(check_orientation)),
+                                            _p(mk), _p(mq), _p(q))
+    return mk, mq, nm, q
+
+
+def search_by_projection_kf(kps, desc, occupied, bounds, cam4, Tcw, scale_factors, log_scale_factor, valid, pos, min_distance,
+                            max_distance, mp_desc, kf_angle, th, orb_dist, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1673-1800, literally."""
+    L = lib()
+    xy, octv, ang, d = _frame_arrays(kps, desc)
+    oc = _u8(occupied) if occupied is not None else None
+    b4, c4, sc, Tc = _f32(bounds), _f32(cam4), _f32(scale_factors), _f32(Tcw).reshape(16)
+    va, ps, mn, mx, md, ka = _u8(valid), _f32(pos), _f32(min_distance), _f32(max_distance), _u8(mp_desc), _f32(kf_angle)
+    nk = len(va)
+    mk = np.zeros(len(xy), np.int32); mq = np.zeros(nk, np.int32); q = np.zeros(nk, WQ_DTYPE)
+    L.oracle_search_by_projection_kf.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_int] + \
+        [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 3
+    nm = L.oracle_search_by_projection_kf(_p(xy), _p(octv), _p(ang), _p(d), len(xy), _opt(oc), _p(b4), _p(c4), _p(Tc), _p(sc),
+                                          len(sc), float(log_scale_factor), nk, _p(va), _p(ps), _p(mn), _p(mx), _p(md), _p(ka),
+                                          float(th), int(orb_dist), int(bool(check_orientation)), _p(mk), _p(mq), _p(q))
+    return mk, mq, nm, q
+
+
+def search_by_projection_sim3(kps, desc, occupied, bounds, cam4, Scw, scale_factors, log_scale_factor, valid, pos, normal,
+                              min_distance, max_distance, mp_desc, th, th_low=45):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), ORBmatcher.cc:491-604, literally."""
+    L = lib()
+    xy, octv, _, d = _frame_arrays(kps, desc)
+    oc = _u8(occupied) if occupied is not None else None
+    b4, c4, sc, S = _f32(bounds), _f32(cam4), _f32(scale_factors), _f32(Scw).reshape(16)
+    va, ps, nr, mn, mx, md = _u8(valid), _f32(pos), _f32(normal), _f32(min_distance), _f32(max_distance), _u8(mp_desc)
+    npt = len(va)
+    mk = np.zeros(len(xy), np.int32); mq = np.zeros(npt, np.int32); q = np.zeros(npt, WQ_DTYPE)
+    L.oracle_search_by_projection_sim3.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_int] + \
+        [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 3
+    nm = L.oracle_search_by_projection_sim3(_p(xy), _p(octv), _p(d), len(xy), _opt(oc), _p(b4), _p(c4), _p(S), _p(sc), len(sc),
+                                            float(log_scale_factor), npt, _p(va), _p(ps), _p(nr), _p(mn), _p(mx), _p(md), int(th),
+                                            int(th_low), _p(mk), _p(mq), _p(q))
+    return mk, mq, nm, q
+
+
+def search_by_sim3_whole(kps1, desc1, kps2, desc2, bounds, cam4, scale_factors, log_scale_factor, T1w, T2w, s12, R12, t12,
+                         valid1, pos1, mind1, maxd1, mp_desc1, valid2, pos2, mind2, maxd2, mp_desc2, th, th_high=95):
+    """ORBmatcher::SearchBySim3, ORBmatcher.cc:1303-1527, literally (projections included).
+    Returns (match12, nFound, vnMatch1, vnMatch2, q12, q21)."""
+    L = lib()
+    xy1, o1, _, d1 = _frame_arrays(kps1, desc1); xy2, o2, _, d2 = _frame_arrays(kps2, desc2)
+    b4, c4, sc = _f32(bounds), _f32(cam4), _f32(scale_factors)
+    T1, T2, R, t = _f32(T1w).reshape(16), _f32(T2w).reshape(16), _f32(R12).reshape(9), _f32(t12).reshape(3)
+    v1, p1, a1, b1, m1 = _u8(valid1), _f32(pos1), _f32(mind1), _f32(maxd1), _u8(mp_desc1)
+    v2, p2, a2, b2, m2 = _u8(valid2), _f32(pos2), _f32(mind2), _f32(maxd2), _u8(mp_desc2)
+    n1, n2 = len(xy1), len(xy2)
+    vn1 = np.zeros(n1, np.int32); vn2 = np.zeros(n2, np.int32); m12 = np.zeros(n1, np.int32)
+    q12 = np.zeros(n1, WQ_DTYPE); q21 = np.zeros(n2, WQ_DTYPE)
+    L.oracle_search_by_sim3.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + \
+        [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 12 + [C.c_float, C.c_int] + [C.c_void_p] * 5
+    nf = L.oracle_search_by_sim3(_p(xy1), _p(o1), _p(d1), n1, _p(xy2), _p(o2), _p(d2), n2, _p(b4), _p(c4), _p(sc), len(sc),
+                                 float(log_scale_factor), _p(T1), _p(T2), float(s12), _p(R), _p(t), _p(v1), _p(p1), _p(a1), _p(b1),
+                                 _p(m1), _p(v2), _p(p2), _p(a2), _p(b2), _p(m2), float(th), int(th_high), _p(vn1), _p(vn2),
+                                 _p(m12), _p(q12), _p(q21))
+    return m12, nf, vn1, vn2, q12, q21

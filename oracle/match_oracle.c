@@ -897,3 +897,412 @@ int oracle_fuse_replay_sim3(const int *list, int nlist, const int *visible, cons
     free(already);
     return nFused;
 }
+
+/* ================================================================================================================
+ * The four SearchByProjection / SearchBySim3 forms AS WHOLE FUNCTIONS, projection prefix included -- literal loop
+ * restatements of src/ORBmatcher.cc:1529-1671 (CurrentFrame, LastFrame), :1673-1800 (CurrentFrame, KeyFrame), :491-604
+ * (KeyFrame, Scw) and :1303-1527 (SearchBySim3).  The pointer graph is passed flat: entry i of a frame's / key frame's /
+ * list's map-point vector becomes valid[i] (what the reference's pointer tests leave: non-NULL, not an outlier / not bad /
+ * not in the "already found" set), its world position, descriptor (MapPoint::GetDescriptor), mfMinDistance / mfMaxDistance,
+ * normal, and takes[i] = Observations() > 0.  cv::Mat arithmetic (OpenCV 3.4, CV_32F; parity unpinned like the other OpenCV
+ * primitives), as in oracle_project_points:
+ *   A * b (+ c)          gemm's 3 x 3 special case: t = a0 b0 + a1 b1 + a2 b2 in float, left to right,
+ *                        d = float(double(t) * alpha + double(c) * beta)   (c = 0, beta = 0 without a third operand)
+ *   -A.t() * b           the transposed matrix materialised, then the product with alpha = -1
+ *   s * A, A / s         convertTo with a FLOAT scale: a * float(s) + 0.0f, a * float(1.0 / s) + 0.0f
+ *   A - B                float subtraction;  cv::norm = float(sqrt(double sum of squares));  Mat::dot = double sum of
+ *                        double products.
+ * Every function can return the GetFeaturesInArea query it forms per entry (qout, r < 0 = entry skipped before the search)
+ * so that a device prefix is compared at float-bit level. */
+static void cvm_gemm3(const float *A, const float *b, double alpha, const float *c, double beta, float *d)
+{
+    int k;
+    float out[3];
+    for (k = 0; k < 3; k++) {
+        const float t = A[3 * k] * b[0] + A[3 * k + 1] * b[1] + A[3 * k + 2] * b[2];
+        out[k] = (float)(t * alpha + (c ? c[k] : 0.0f) * beta);
+    }
+    d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+}
+static void cvm_transpose3(const float *A, float *At)
+{
+    int r, c;
+    for (r = 0; r < 3; r++) for (c = 0; c < 3; c++) At[3 * r + c] = A[3 * c + r];
+}
+static void cvm_scale(const float *A, int n, double s, float *out) /* convertTo(.., alpha = s): cvtScale with float(alpha), float(0) */
+{
+    const float a = (float)s, b = (float)0.0;
+    int i;
+    for (i = 0; i < n; i++) out[i] = A[i] * a + b;
+}
+static void cvm_pose_parts(const float *T16, float *R, float *t) /* mTcw.rowRange(0,3).colRange(0,3), .col(3) */
+{
+    int r, c;
+    for (r = 0; r < 3; r++) { for (c = 0; c < 3; c++) R[3 * r + c] = T16[4 * r + c]; t[r] = T16[4 * r + 3]; }
+}
+static float cvm_norm3(const float *a) /* cv::norm(NORM_L2) of a 3 x 1 CV_32F */
+{
+    double s = 0;
+    int k;
+    for (k = 0; k < 3; k++) s += (double)a[k] * a[k];
+    return (float)sqrt(s);
+}
+/* -R.t() * t: Ow / twc (ORBmatcher.cc:1542, :1679, :504) */
+static void cvm_neg_Rt_t(const float *R, const float *t, float *out)
+{
+    float Rt[9];
+    cvm_transpose3(R, Rt);
+    cvm_gemm3(Rt, t, -1.0, NULL, 0.0, out);
+}
+void oracle_camera_centre(const float *T16, float *Ow)
+{
+    float R[9], t[3];
+    cvm_pose_parts(T16, R, t);
+    cvm_neg_Rt_t(R, t, Ow);
+}
+/* Scw -> Rcw, tcw, Ow as ORBmatcher.cc:500-504 (and :1186-1192) decompose it */
+void oracle_decompose_sim3(const float *S16, float *Rcw, float *tcw, float *Ow)
+{
+    float sR[9], st[3], scw;
+    double dot = 0;
+    int k;
+    cvm_pose_parts(S16, sR, st);
+    for (k = 0; k < 3; k++) dot += (double)sR[k] * sR[k];          /* sRcw.row(0).dot(sRcw.row(0)) */
+    scw = (float)sqrt(dot);
+    cvm_scale(sR, 9, 1. / scw, Rcw);                               /* operator / (Mat, double): alpha = 1./s */
+    cvm_scale(st, 3, 1. / scw, tcw);
+    cvm_neg_Rt_t(Rcw, tcw, Ow);
+}
+
+/* bForward / bBackward of ORBmatcher.cc:1540-1550 */
+void oracle_motion_direction(const float *Tcw16, const float *Tlw16, float mb, int bMono, int *bForward, int *bBackward)
+{
+    float Rcw[9], tcw[3], Rlw[9], tlw[3], twc[3], tlc[3];
+    cvm_pose_parts(Tcw16, Rcw, tcw);
+    cvm_pose_parts(Tlw16, Rlw, tlw);
+    cvm_neg_Rt_t(Rcw, tcw, twc);
+    cvm_gemm3(Rlw, twc, 1.0, tlw, 1.0, tlc);
+    *bForward = tlc[2] > mb && !bMono;
+    *bBackward = -tlc[2] > mb && !bMono;
+}
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono),
+ * src/ORBmatcher.cc:1529-1671.  Current frame: mvKeysUn (kxy, koct, kangle), mDescriptors, mvuRight (NULL = all -1),
+ * occupied[j] = "mvpMapPoints[j] holds a point with Observations() > 0" before the call (:1603-1605), grid bounds4 =
+ * mnMinX, mnMinY, mnMaxX, mnMaxY, cam4 = fx, fy, cx, cy.  Last frame, per keypoint i: valid[i] = mvpMapPoints[i] &&
+ * !mvbOutlier[i], pos / mp_desc / takes of that point, last_octave[i] = mvKeys[i].octave, last_angle[i] = mvKeysUn[i].angle.
+ * match_kp[j] = i whose point ends in slot j (-1 untouched, -2 set to NULL by the rotation check), match_q[i] = bestIdx2
+ * of an accepted i (before the rotation check) or -1.  Returns nmatches. */
+int oracle_search_by_projection_last(const float *kxy, const int *koct, const float *kangle, const uint8_t *kdesc, int n,
+                                     const float *uright, const uint8_t *occupied, const float *bounds4, const float *cam4,
+                                     float mb, float mbf, const float *Tcw16, const float *scaleFactors, const float *Tlw16, int nl,
+                                     const uint8_t *valid, const float *pos, const uint8_t *mp_desc, const uint8_t *takes,
+                                     const int *last_octave, const float *last_angle, float th, int bMono, int th_high,
+                                     int check_orientation, int *match_kp, int *match_q, oracle_wquery *qout)
+{
+    const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const float mnMinX = bounds4[0], mnMinY = bounds4[1], mnMaxX = bounds4[2], mnMaxY = bounds4[3];
+    oracle_grid *g = oracle_grid_build(kxy, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+    int *cand = (int *)malloc(sizeof(int) * (n + 1));
+    uint8_t *blocked = (uint8_t *)malloc(n + 1);
+    int *qbin = (int *)malloc(sizeof(int) * (nl + 1));
+    int hist[HISTO_LENGTH] = {0};
+    float Rcw[9], tcw[3];
+    int bForward, bBackward, i, k, nmatches = 0;
+    cvm_pose_parts(Tcw16, Rcw, tcw);
+    oracle_motion_direction(Tcw16, Tlw16, mb, bMono, &bForward, &bBackward);
+    for (k = 0; k < n; k++) { blocked[k] = occupied ? occupied[k] : 0; match_kp[k] = -1; }
+    for (i = 0; i < nl; i++) {
+        float x3Dc[3], xc, yc, invzc, u, v, radius;
+        int nLastOctave, nc, bestDist = 256, bestIdx2 = -1;
+        const oracle_wquery none = {0.f, 0.f, -1.f, 0.f, 0, -1};
+        match_q[i] = -1; qbin[i] = -1;
+        if (qout) qout[i] = none;
+        if (!valid[i]) continue;
+        cvm_gemm3(Rcw, pos + 3 * i, 1.0, tcw, 1.0, x3Dc);
+        xc = x3Dc[0]; yc = x3Dc[1];
+        invzc = 1.0 / x3Dc[2];
+        if (invzc < 0) continue;
+        u = fx * xc * invzc + cx;
+        v = fy * yc * invzc + cy;
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        nLastOctave = last_octave[i];
+        radius = th * scaleFactors[nLastOctave];
+        {
+            const int minLevel = bForward ? nLastOctave : (bBackward ? 0 : nLastOctave - 1);
+            const int maxLevel = bForward ? -1 : (bBackward ? nLastOctave : nLastOctave + 1);
+            nc = oracle_grid_features_in_area(g, kxy, koct, u, v, radius, minLevel, maxLevel, cand, n + 1);
+            if (qout) { const oracle_wquery w = {u, v, radius, u - mbf * invzc, minLevel, maxLevel}; qout[i] = w; }
+        }
+        if (nc == 0) continue;
+        for (k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            int dist;
+            if (blocked[i2]) continue;
+            if (uright && uright[i2] > 0) {
+                const float ur = u - mbf * invzc;
+                const float er = fabsf(ur - uright[i2]);
+                if (er > radius) continue;
+            }
+            dist = oracle_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= th_high) {
+            match_kp[bestIdx2] = i;                    /* CurrentFrame.mvpMapPoints[bestIdx2] = pMP */
+            match_q[i] = bestIdx2;
+            if (takes[i]) blocked[bestIdx2] = 1;
+            nmatches++;
+            if (check_orientation) { qbin[i] = rot_bin(last_angle[i], kangle[bestIdx2]); hist[qbin[i]]++; }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (i = 0; i < nl; i++)
+            if (qbin[i] >= 0 && qbin[i] != ind1 && qbin[i] != ind2 && qbin[i] != ind3) { match_kp[match_q[i]] = -2; nmatches--; }
+    }
+    free(cand); free(blocked); free(qbin);
+    oracle_grid_free(g);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
+ * const int ORBdist), src/ORBmatcher.cc:1673-1800.  No depth test (:1706-1713 project whatever the sign of z), no stereo test;
+ * occupied[j] = CurrentFrame.mvpMapPoints[j] != NULL before the call (:1741-1742), every assignment blocks its slot.
+ * Key frame entry i: valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP), pos, mfMinDistance / mfMaxDistance, descriptor,
+ * kf_angle[i] = pKF->mvKeysUn[i].angle. */
+int oracle_search_by_projection_kf(const float *kxy, const int *koct, const float *kangle, const uint8_t *kdesc, int n,
+                                   const uint8_t *occupied, const float *bounds4, const float *cam4, const float *Tcw16,
+                                   const float *scaleFactors, int nLevels, float logScaleFactor, int nk, const uint8_t *valid,
+                                   const float *pos, const float *mfMinDistance, const float *mfMaxDistance, const uint8_t *mp_desc,
+                                   const float *kf_angle, float th, int ORBdist, int check_orientation, int *match_kp, int *match_q,
+                                   oracle_wquery *qout)
+{
+    const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const float mnMinX = bounds4[0], mnMinY = bounds4[1], mnMaxX = bounds4[2], mnMaxY = bounds4[3];
+    oracle_grid *g = oracle_grid_build(kxy, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+    int *cand = (int *)malloc(sizeof(int) * (n + 1));
+    uint8_t *blocked = (uint8_t *)malloc(n + 1);
+    int *qbin = (int *)malloc(sizeof(int) * (nk + 1));
+    int hist[HISTO_LENGTH] = {0};
+    float Rcw[9], tcw[3], Ow[3];
+    int i, k, nmatches = 0;
+    cvm_pose_parts(Tcw16, Rcw, tcw);
+    cvm_neg_Rt_t(Rcw, tcw, Ow);
+    for (k = 0; k < n; k++) { blocked[k] = occupied ? occupied[k] : 0; match_kp[k] = -1; }
+    for (i = 0; i < nk; i++) {
+        float x3Dc[3], PO[3], xc, yc, invzc, u, v, dist3D, maxDistance, minDistance, radius;
+        int nPredictedLevel, nc, bestDist = 256, bestIdx2 = -1;
+        const oracle_wquery none = {0.f, 0.f, -1.f, 0.f, 0, -1};
+        match_q[i] = -1; qbin[i] = -1;
+        if (qout) qout[i] = none;
+        if (!valid[i]) continue;
+        cvm_gemm3(Rcw, pos + 3 * i, 1.0, tcw, 1.0, x3Dc);
+        xc = x3Dc[0]; yc = x3Dc[1];
+        invzc = 1.0 / x3Dc[2];
+        u = fx * xc * invzc + cx;
+        v = fy * yc * invzc + cy;
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        for (k = 0; k < 3; k++) PO[k] = pos[3 * i + k] - Ow[k];
+        dist3D = cvm_norm3(PO);
+        maxDistance = 1.2f * mfMaxDistance[i];
+        minDistance = 0.8f * mfMinDistance[i];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        nPredictedLevel = oracle_predict_scale(mfMaxDistance[i], dist3D, logScaleFactor, nLevels);
+        radius = th * scaleFactors[nPredictedLevel];
+        nc = oracle_grid_features_in_area(g, kxy, koct, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, cand, n + 1);
+        if (qout) { const oracle_wquery w = {u, v, radius, 0.f, nPredictedLevel - 1, nPredictedLevel + 1}; qout[i] = w; }
+        if (nc == 0) continue;
+        for (k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            int dist;
+            if (blocked[i2]) continue;
+            dist = oracle_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            match_kp[bestIdx2] = i;
+            match_q[i] = bestIdx2;
+            blocked[bestIdx2] = 1;
+            nmatches++;
+            if (check_orientation) { qbin[i] = rot_bin(kf_angle[i], kangle[bestIdx2]); hist[qbin[i]]++; }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (i = 0; i < nk; i++)
+            if (qbin[i] >= 0 && qbin[i] != ind1 && qbin[i] != ind2 && qbin[i] != ind3) { match_kp[match_q[i]] = -2; nmatches--; }
+    }
+    free(cand); free(blocked); free(qbin);
+    oracle_grid_free(g);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched,
+ * int th), src/ORBmatcher.cc:491-604.  Key frame: mvKeysUn, mDescriptors, grid (KeyFrame::GetFeaturesInArea, KeyFrame.cc:613-652:
+ * no level argument, the loop filters :580-583), occupied[j] = vpMatched[j] != NULL before the call.  List entry i: valid[i] =
+ * !isBad() && !spAlreadyFound.count(pMP).  match_kp[j] = list entry written to vpMatched[j] (-1 untouched). */
+int oracle_search_by_projection_sim3(const float *kxy, const int *koct, const uint8_t *kdesc, int n, const uint8_t *occupied,
+                                     const float *bounds4, const float *cam4, const float *Scw16, const float *scaleFactors,
+                                     int nLevels, float logScaleFactor, int np, const uint8_t *valid, const float *pos,
+                                     const float *nrm, const float *mfMinDistance, const float *mfMaxDistance, const uint8_t *mp_desc,
+                                     int th, int th_low, int *match_kp, int *match_q, oracle_wquery *qout)
+{
+    const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const float mnMinX = bounds4[0], mnMinY = bounds4[1], mnMaxX = bounds4[2], mnMaxY = bounds4[3];
+    oracle_grid *g = oracle_grid_build(kxy, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+    int *cand = (int *)malloc(sizeof(int) * (n + 1));
+    uint8_t *blocked = (uint8_t *)malloc(n + 1);
+    float Rcw[9], tcw[3], Ow[3];
+    int iMP, k, nmatches = 0;
+    oracle_decompose_sim3(Scw16, Rcw, tcw, Ow);
+    for (k = 0; k < n; k++) { blocked[k] = occupied ? occupied[k] : 0; match_kp[k] = -1; }
+    for (iMP = 0; iMP < np; iMP++) {
+        const float *p3Dw = pos + 3 * iMP, *Pn = nrm + 3 * iMP;
+        float p3Dc[3], PO[3], invz, x, y, u, v, maxDistance, minDistance, dist, radius;
+        double dot = 0;
+        int nPredictedLevel, nc, bestDist = 256, bestIdx = -1;
+        const oracle_wquery none = {0.f, 0.f, -1.f, 0.f, 0, -1};
+        match_q[iMP] = -1;
+        if (qout) qout[iMP] = none;
+        if (!valid[iMP]) continue;
+        cvm_gemm3(Rcw, p3Dw, 1.0, tcw, 1.0, p3Dc);
+        if (p3Dc[2] < 0.0) continue;
+        invz = 1 / p3Dc[2];
+        x = p3Dc[0] * invz;
+        y = p3Dc[1] * invz;
+        u = fx * x + cx;
+        v = fy * y + cy;
+        if (!(u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY)) continue;   /* KeyFrame::IsInImage */
+        maxDistance = 1.2f * mfMaxDistance[iMP];
+        minDistance = 0.8f * mfMinDistance[iMP];
+        for (k = 0; k < 3; k++) PO[k] = p3Dw[k] - Ow[k];
+        dist = cvm_norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        for (k = 0; k < 3; k++) dot += (double)PO[k] * Pn[k];
+        if (dot < 0.5 * dist) continue;
+        nPredictedLevel = oracle_predict_scale(mfMaxDistance[iMP], dist, logScaleFactor, nLevels);
+        radius = th * scaleFactors[nPredictedLevel];
+        nc = oracle_grid_features_in_area(g, kxy, koct, u, v, radius, -1, -1, cand, n + 1);
+        if (qout) { const oracle_wquery w = {u, v, radius, 0.f, nPredictedLevel - 1, nPredictedLevel}; qout[iMP] = w; }
+        if (nc == 0) continue;
+        for (k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            int d;
+            if (blocked[idx]) continue;
+            if (koct[idx] < nPredictedLevel - 1 || koct[idx] > nPredictedLevel) continue;
+            d = oracle_descriptor_distance(mp_desc + 32 * (size_t)iMP, kdesc + 32 * (size_t)idx);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= th_low) {
+            match_kp[bestIdx] = iMP;      /* vpMatched[bestIdx] = pMP */
+            match_q[iMP] = bestIdx;
+            blocked[bestIdx] = 1;
+            nmatches++;
+        }
+    }
+    free(cand); free(blocked);
+    oracle_grid_free(g);
+    return nmatches;
+}
+
+/* One direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1348-1428 with (Ra, ta) = (R1w, t1w), (sRb, tb) = (sR21, t21),
+ * searched in key frame 2; :1430-1507 the other way round).  vnMatch[i] = bestIdx or -1. */
+static void sim3_direction(const float *Ra, const float *ta, const float *sRb, const float *tb, int na, const uint8_t *valid,
+                           const float *pos, const float *mfMinDistance, const float *mfMaxDistance, const uint8_t *mp_desc,
+                           const oracle_grid *g, const float *kxy, const int *koct, const uint8_t *kdesc, int n,
+                           const float *bounds4, const float *cam4, const float *scaleFactors, int nLevels, float logScaleFactor,
+                           float th, int th_high, int *vnMatch, oracle_wquery *qout)
+{
+    const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const float mnMinX = bounds4[0], mnMinY = bounds4[1], mnMaxX = bounds4[2], mnMaxY = bounds4[3];
+    int *cand = (int *)malloc(sizeof(int) * (n + 1));
+    int i, k;
+    for (i = 0; i < na; i++) {
+        float pa[3], pb[3], invz, x, y, u, v, maxDistance, minDistance, dist3D, radius;
+        int nPredictedLevel, nc, bestDist = INT_MAX, bestIdx = -1;
+        const oracle_wquery none = {0.f, 0.f, -1.f, 0.f, 0, -1};
+        vnMatch[i] = -1;
+        if (qout) qout[i] = none;
+        if (!valid[i]) continue;
+        cvm_gemm3(Ra, pos + 3 * i, 1.0, ta, 1.0, pa);
+        cvm_gemm3(sRb, pa, 1.0, tb, 1.0, pb);
+        if (pb[2] < 0.0) continue;
+        invz = 1.0 / pb[2];
+        x = pb[0] * invz;
+        y = pb[1] * invz;
+        u = fx * x + cx;
+        v = fy * y + cy;
+        if (!(u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY)) continue;
+        maxDistance = 1.2f * mfMaxDistance[i];
+        minDistance = 0.8f * mfMinDistance[i];
+        dist3D = cvm_norm3(pb);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        nPredictedLevel = oracle_predict_scale(mfMaxDistance[i], dist3D, logScaleFactor, nLevels);
+        radius = th * scaleFactors[nPredictedLevel];
+        nc = oracle_grid_features_in_area(g, kxy, koct, u, v, radius, -1, -1, cand, n + 1);
+        if (qout) { const oracle_wquery w = {u, v, radius, 0.f, nPredictedLevel - 1, nPredictedLevel}; qout[i] = w; }
+        if (nc == 0) continue;
+        for (k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            int d;
+            if (koct[idx] < nPredictedLevel - 1 || koct[idx] > nPredictedLevel) continue;
+            d = oracle_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)idx);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= th_high) vnMatch[i] = bestIdx;
+    }
+    free(cand);
+}
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1303-1527.  Both key frames share
+ * the calibration and the image bounds (static members).  valid1[i] = vpMapPoints1[i] && !vbAlreadyMatched1[i] && !isBad()
+ * (:1352-1358), valid2 likewise (:1434-1440; vbAlreadyMatched2 comes from GetIndexInKeyFrame, :1338-1341).  T1w / T2w:
+ * GetRotation / GetTranslation of the two key frames as 4 x 4 poses.  match12[i1] = idx2 where both directions agree (the
+ * entries the reference overwrites in vpMatches12, :1513-1521), else -1.  Returns nFound. */
+int oracle_search_by_sim3(const float *kxy1, const int *koct1, const uint8_t *kdesc1, int n1, const float *kxy2, const int *koct2,
+                          const uint8_t *kdesc2, int n2, const float *bounds4, const float *cam4, const float *scaleFactors,
+                          int nLevels, float logScaleFactor, const float *T1w16, const float *T2w16, float s12, const float *R12,
+                          const float *t12, const uint8_t *valid1, const float *pos1, const float *mind1, const float *maxd1,
+                          const uint8_t *desc_mp1, const uint8_t *valid2, const float *pos2, const float *mind2, const float *maxd2,
+                          const uint8_t *desc_mp2, float th, int th_high, int *vnMatch1, int *vnMatch2, int *match12,
+                          oracle_wquery *q12, oracle_wquery *q21)
+{
+    float R1w[9], t1w[3], R2w[9], t2w[3], sR12[9], R12t[9], sR21[9], t21[3];
+    oracle_grid *g1 = oracle_grid_build(kxy1, n1, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    oracle_grid *g2 = oracle_grid_build(kxy2, n2, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    int i1, nFound = 0;
+    cvm_pose_parts(T1w16, R1w, t1w);
+    cvm_pose_parts(T2w16, R2w, t2w);
+    cvm_scale(R12, 9, s12, sR12);                 /* sR12 = s12 * R12 */
+    cvm_transpose3(R12, R12t);
+    cvm_scale(R12t, 9, 1.0 / s12, sR21);          /* sR21 = (1.0 / s12) * R12.t() */
+    cvm_gemm3(sR21, t12, -1.0, NULL, 0.0, t21);   /* t21 = -sR21 * t12 */
+    sim3_direction(R1w, t1w, sR21, t21, n1, valid1, pos1, mind1, maxd1, desc_mp1, g2, kxy2, koct2, kdesc2, n2, bounds4, cam4,
+                   scaleFactors, nLevels, logScaleFactor, th, th_high, vnMatch1, q12);
+    sim3_direction(R2w, t2w, sR12, t12, n2, valid2, pos2, mind2, maxd2, desc_mp2, g1, kxy1, koct1, kdesc1, n1, bounds4, cam4,
+                   scaleFactors, nLevels, logScaleFactor, th, th_high, vnMatch2, q21);
+    for (i1 = 0; i1 < n1; i1++) {
+        const int idx2 = vnMatch1[i1];
+        match12[i1] = -1;
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+        }
+    }
+    oracle_grid_free(g1); oracle_grid_free(g2);
+    return nFound;
+}
+
+/* Transforms of SearchBySim3 (:1320-1323) for a caller that hands them to a device prefix: sR12, sR21, t21. */
+void oracle_sim3_transforms(float s12, const float *R12, const float *t12, float *sR12, float *sR21, float *t21)
+{
+    float R12t[9];
+    cvm_scale(R12, 9, s12, sR12);
+    cvm_transpose3(R12, R12t);
+    cvm_scale(R12t, 9, 1.0 / s12, sR21);
+    cvm_gemm3(sR21, t12, -1.0, NULL, 0.0, t21);
+}

@@ -6,4 +6,4 @@ reference's ORBextractor / ORBmatcher / FEA2 interfaces used by tests and bench.
 """
 from ._lib import OrbxError, build, lib  # noqa: F401
 from .extractor import KP_DTYPE, ComputeStereoMatches, ORBextractor, extract_pair, stereo_download_batch, stereo_match_batch  # noqa: F401
-from .matcher import ORBmatcher  # noqa: F401
+from .matcher import Frame, ORBmatcher, Points, View  # noqa: F401

@@ -22,6 +22,9 @@ constexpr int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64; // include/Frame.h:37-
 // insertion order inside a cell); 0xffffffff = not in the grid / skipped.
 struct WinKp { float x, y, uright; int octave; unsigned order; };
 struct WinQuery { float u, v, r, xr; int min_level, max_level; };
+// Sorted keypoint record of the windowed searches: position sp in the array = rank in GetFeaturesInArea order.
+struct SeqKp { float x, y, uright; int octave; };
+struct GridParams { float min_x, min_y, inv_w, inv_h; };
 static_assert(sizeof(WinQuery) == sizeof(orbm_window_query), "query layout");
 
 __device__ __forceinline__ int popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)

@@ -31,10 +31,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
 #include "orbm_internal.h"
+#include "orbx_internal.h"
 
 using namespace orbm_detail;
 
@@ -44,12 +46,9 @@ constexpr int SEQ_MAXN = 8192;     // keypoints per frame the resolver's LDS sta
 constexpr int HISTO_LENGTH = 30;   // ORBmatcher.cc:40
 enum { ACCEPT_BEST = 0, ACCEPT_RATIO_SAME_LEVEL = 1, ACCEPT_RATIO = 2 };
 
-// Sorted keypoint record: position sp in this array = rank in GetFeaturesInArea order.
-struct SeqKp { float x, y, uright; int octave; };
 
 constexpr int TOPK = 8; // best candidates per query kept sorted for the resolver
 
-struct GridParams { float min_x, min_y, inv_w, inv_h; };
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
@@ -96,7 +95,7 @@ __device__ __forceinline__ void wave_topk(const unsigned *__restrict__ ent, int 
 template <int FILL>
 __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
                                                  const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
-                                                 const int *__restrict__ cell_off, GridParams gp, int has_uright, int init_dist,
+                                                 const int *__restrict__ cell_off, const uint8_t *__restrict__ occ, GridParams gp, int has_uright, int init_dist,
                                                  int *__restrict__ cnt, const int *__restrict__ off, unsigned *__restrict__ ent,
                                                  int stride, int *__restrict__ lbeg, int *__restrict__ lend,
                                                  int *__restrict__ overflow, unsigned *__restrict__ top, int gen)
@@ -125,6 +124,7 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
                 bool ok = k < k1;
                 SeqKp p = {0.f, 0.f, 0.f, 0};
                 if (ok) p = kp[k];
+                if (occ && ok) ok = occ[k] == 0;   // the slot holds a point from the start (e.g. ORBmatcher.cc:87-89): never a candidate
                 if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
                 const float distx = p.x - w.u, disty = p.y - w.v;
                 ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(RES_T) void k_resolve_init_par(const unsigned *__re
 // keypoint index (-1).
 __global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q, const uint4 *__restrict__ A, int nq,
                                                  const SeqKp *__restrict__ kp, const uint4 *__restrict__ B,
-                                                 const int *__restrict__ cell_off, const int *__restrict__ perm, GridParams gp,
+                                                 const int *__restrict__ cell_off, const int *__restrict__ perm, const uint8_t *__restrict__ occ, GridParams gp,
                                                  int has_uright, int init_dist, const float *__restrict__ inv_sigma2, int fuse_gate,
                                                  int *__restrict__ best_o, int *__restrict__ bl_o, int *__restrict__ second_o,
                                                  int *__restrict__ sl_o, int *__restrict__ idx_o)
@@ -819,6 +819,7 @@ __global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q,
                 bool ok = k < r1;
                 SeqKp p = {0.f, 0.f, 0.f, 0};
                 if (ok) p = kp[k];
+                if (occ && ok) ok = occ[k] == 0;
                 if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
                 const float distx = p.x - w.u, disty = p.y - w.v;
                 ok = ok && fabsf(distx) < w.r && fabsf(disty) < w.r;
@@ -1089,6 +1090,218 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
     if (tid == 0) *nmatches -= removed;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A frame resident in HBM (orbm_frame): Frame::AssignFeaturesToGrid (src/Frame.cc:245-260, PosInGrid :397-407) on the device.
+// ONE workgroup lays the keypoints out in (cell, index) order -- the order Frame::GetFeaturesInArea visits a window in --
+//   1. cell of every keypoint (the reference's float arithmetic), cell histogram in LDS;
+//   2. exclusive scan of the histogram = cell_off;
+//   3. rank of a keypoint inside its cell = keypoints of the same cell with a smaller index: per 64-keypoint chunk the
+//      lanes compare cells pairwise (all waves), then one wave walks the chunks in order with a running count per cell;
+//   4. gather: position, level, right coordinate, angle, descriptor, permutation.
+// Keypoints come as cv::KeyPoint records (mvKeysUn; or the extractor's device results, optionally with the undistorted
+// coordinates beside them), n from the host or from the extractor's count array.
+constexpr int FB_T = 1024, FB_MAXN = SEQ_MAXN, FB_NC = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+struct FrameHdr { int n, ns; };
+constexpr size_t FB_LDS = sizeof(int) * (2 * (size_t)FB_NC + 2) + (size_t)FB_MAXN * (2 + 2 + 1 + 1);
+
+__global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__restrict__ kps, const uint4 *__restrict__ desc_raw,
+                                                      const float2 *__restrict__ xy_un, const float *__restrict__ uright_raw,
+                                                      const int *__restrict__ n_dev, int n_host, GridParams gp, SeqKp *__restrict__ kp,
+                                                      uint4 *__restrict__ desc, float *__restrict__ angle, int *__restrict__ perm,
+                                                      int *__restrict__ cell_off, FrameHdr *__restrict__ hdr)
+{
+    extern __shared__ __align__(16) unsigned char fb_sm[];
+    int *s_off = reinterpret_cast<int *>(fb_sm);                 // [FB_NC + 1] histogram, then exclusive scan
+    int *s_run = s_off + FB_NC + 1;                              // [FB_NC + 1] keypoints of the cell placed so far (last entry: scan carry)
+    unsigned short *s_cell = reinterpret_cast<unsigned short *>(s_run + FB_NC + 1);   // [n] cell or 0xffff
+    unsigned short *s_pos = s_cell + FB_MAXN;                    // [n] sorted position
+    unsigned char *s_low = reinterpret_cast<unsigned char *>(s_pos + FB_MAXN), *s_tot = s_low + FB_MAXN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(n_dev ? *n_dev : n_host, FB_MAXN);
+    for (int c = tid; c <= FB_NC; c += FB_T) { s_off[c] = 0; s_run[c] = 0; }
+    __syncthreads();
+    for (int j = tid; j < n; j += FB_T) {
+        const float x = xy_un ? xy_un[j].x : kps[j].x, y = xy_un ? xy_un[j].y : kps[j].y;
+        const int px = (int)roundf((x - gp.min_x) * gp.inv_w), py = (int)roundf((y - gp.min_y) * gp.inv_h);
+        const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
+        const int c = in ? px * FRAME_GRID_ROWS + py : 0xffff;
+        s_cell[j] = (unsigned short)c;
+        if (in) atomicAdd(&s_off[c], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of FB_NC counts: 3 per thread, wave scan, wave totals through s_run's spare slots
+        constexpr int PER = FB_NC / FB_T;
+        static_assert(FB_NC % FB_T == 0, "cells per thread");
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { v[k] = s_off[tid * PER + k]; sum += v[k]; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        __shared__ int wsum[FB_T / 64];
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int run = base + inc - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { s_off[tid * PER + k] = run; run += v[k]; }
+        if (tid == FB_T - 1) s_off[FB_NC] = run;
+    }
+    __syncthreads();
+    for (int c = tid; c <= FB_NC; c += FB_T) cell_off[c] = s_off[c];
+    // rank inside the chunk: lanes of one cell, in lane order
+    const int nchunk = (n + 63) / 64;
+    for (int ch = wave; ch < nchunk; ch += FB_T / 64) {
+        const int j = ch * 64 + lane;
+        const int c = j < n ? (int)s_cell[j] : 0xffff;
+        int low = 0, tot = 0;
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) {
+            const int cl = __shfl(c, l);
+            const int same = cl == c;
+            tot += same;
+            low += same && l < lane;
+        }
+        if (j < n) { s_low[j] = (unsigned char)low; s_tot[j] = (unsigned char)(tot - 1); }   // (tot - 1 <= 63 fits a byte)
+    }
+    __syncthreads();
+    if (wave == 0) {        // chunks in index order: the running count of a cell is what the earlier chunks put there
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int j = ch * 64 + lane;
+            const int c = j < n ? (int)s_cell[j] : 0xffff;
+            int base = 0;
+            if (c != 0xffff) base = s_run[c];
+            if (c != 0xffff) {
+                s_pos[j] = (unsigned short)(s_off[c] + base + s_low[j]);
+                if (s_low[j] == s_tot[j]) s_run[c] = base + s_tot[j] + 1;    // the cell's last lane of the chunk
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += FB_T) {
+        if (s_cell[j] == 0xffff) continue;
+        const int sp = s_pos[j];
+        const orbx_keypoint k = kps[j];
+        SeqKp o;
+        o.x = xy_un ? xy_un[j].x : k.x; o.y = xy_un ? xy_un[j].y : k.y;
+        o.uright = uright_raw ? uright_raw[j] : -1.0f;
+        o.octave = k.octave;
+        kp[sp] = o; angle[sp] = k.angle; perm[sp] = j;
+        desc[2 * sp] = desc_raw[2 * j]; desc[2 * sp + 1] = desc_raw[2 * j + 1];
+    }
+    if (tid == 0) { hdr->n = n; hdr->ns = s_off[FB_NC]; }
+}
+
+// The projection prefixes of the remaining SearchByProjection forms and of SearchBySim3, one thread per list entry, in the
+// reference's float / double order op by op (cv::Mat arithmetic as k_project_points restates it):
+//   FORM_LAST   SearchByProjection(CurrentFrame, LastFrame, th, bMono)            src/ORBmatcher.cc:1557-1591
+//   FORM_KF     SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) :1702-1735  (no depth test, as the reference)
+//   FORM_SIM3   SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)             :518-563    (pose = the decomposed Scw)
+//   FORM_PAIR   one direction of SearchBySim3                                     :1360-1396 / :1442-1478 (two transforms)
+// Output: the GetFeaturesInArea query of every entry (r < 0: the entry is skipped before the search).
+enum { FORM_LAST = 0, FORM_KF = 1, FORM_SIM3 = 2, FORM_PAIR = 3 };
+struct FormCam {
+    float fx, fy, cx, cy, min_x, max_x, min_y, max_y, mbf, log_scale, th;
+    float R[9], t[3], Ow[3];      // Rcw, tcw, Ow  (FORM_PAIR: Ra, ta = first transform)
+    float R2[9], t2[3];           // FORM_PAIR: the second transform (sR21, t21 / sR12, t12)
+    int nlevels, form, forward, backward;
+};
+
+__device__ __forceinline__ float gemm_row(const float *R, int r, float b0, float b1, float b2, float t)
+{
+    return (float)((double)(R[3 * r] * b0 + R[3 * r + 1] * b1 + R[3 * r + 2] * b2) + (double)t);
+}
+
+__global__ __launch_bounds__(MT) void k_project_form(const uint8_t *__restrict__ valid, const float *__restrict__ pos,
+                                                     const float *__restrict__ nrm, const float *__restrict__ mind,
+                                                     const float *__restrict__ maxd, const int *__restrict__ octave, int m, FormCam cam,
+                                                     const float *__restrict__ scale, WinQuery *__restrict__ q)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i >= m) return;
+    WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
+    if (valid[i]) {
+        const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+        float X = gemm_row(cam.R, 0, P0, P1, P2, cam.t[0]), Y = gemm_row(cam.R, 1, P0, P1, P2, cam.t[1]),
+              Z = gemm_row(cam.R, 2, P0, P1, P2, cam.t[2]);
+        if (cam.form == FORM_LAST) {
+            const float invzc = (float)(1.0 / (double)Z);                          // :1565
+            bool ok = !(invzc < 0);
+            const float u = cam.fx * X * invzc + cam.cx, v = cam.fy * Y * invzc + cam.cy;
+            ok = ok && !(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y);
+            if (ok) {
+                const int oct = octave[i];
+                w.u = u; w.v = v; w.r = cam.th * scale[oct]; w.xr = u - cam.mbf * invzc;
+                w.min_level = cam.forward ? oct : (cam.backward ? 0 : oct - 1);     // :1586-1591
+                w.max_level = cam.forward ? -1 : (cam.backward ? oct : oct + 1);
+            }
+        } else if (cam.form == FORM_KF) {
+            const float invzc = (float)(1.0 / (double)Z);                          // :1711
+            const float u = cam.fx * X * invzc + cam.cx, v = cam.fy * Y * invzc + cam.cy;
+            bool ok = !(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y);
+            const float PO0 = P0 - cam.Ow[0], PO1 = P1 - cam.Ow[1], PO2 = P2 - cam.Ow[2];
+            const float dist3D = (float)sqrt((double)PO0 * (double)PO0 + (double)PO1 * (double)PO1 + (double)PO2 * (double)PO2);
+            const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+            ok = ok && !(dist3D < minDistance || dist3D > maxDistance);
+            if (ok) {
+                const float ratio = maxd[i] / dist3D;
+                int level = (int)ceilf((float)log((double)ratio) / cam.log_scale);
+                if (level < 0) level = 0; else if (level >= cam.nlevels) level = cam.nlevels - 1;
+                w.u = u; w.v = v; w.r = cam.th * scale[level]; w.min_level = level - 1; w.max_level = level + 1;
+            }
+        } else {
+            if (cam.form == FORM_PAIR) {     // p3Dc2 = sR21 * (R1w * p3Dw + t1w) + t21
+                const float a0 = X, a1 = Y, a2 = Z;
+                X = gemm_row(cam.R2, 0, a0, a1, a2, cam.t2[0]); Y = gemm_row(cam.R2, 1, a0, a1, a2, cam.t2[1]);
+                Z = gemm_row(cam.R2, 2, a0, a1, a2, cam.t2[2]);
+            }
+            bool ok = !(Z < 0.0f);
+            const float invz = cam.form == FORM_SIM3 ? 1 / Z : (float)(1.0 / (double)Z);      // :531 / :1367
+            const float x = X * invz, y = Y * invz;
+            const float u = cam.fx * x + cam.cx, v = cam.fy * y + cam.cy;
+            ok = ok && (u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y);  // KeyFrame::IsInImage
+            const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+            float dist;
+            if (cam.form == FORM_SIM3) {
+                const float PO0 = P0 - cam.Ow[0], PO1 = P1 - cam.Ow[1], PO2 = P2 - cam.Ow[2];
+                dist = (float)sqrt((double)PO0 * (double)PO0 + (double)PO1 * (double)PO1 + (double)PO2 * (double)PO2);
+                ok = ok && !(dist < minDistance || dist > maxDistance);
+                const double dot = (double)PO0 * (double)nrm[3 * i] + (double)PO1 * (double)nrm[3 * i + 1] + (double)PO2 * (double)nrm[3 * i + 2];
+                ok = ok && !(dot < 0.5 * (double)dist);
+            } else {
+                dist = (float)sqrt((double)X * (double)X + (double)Y * (double)Y + (double)Z * (double)Z);   // cv::norm(p3Dc2)
+                ok = ok && !(dist < minDistance || dist > maxDistance);
+            }
+            if (ok) {
+                const float ratio = maxd[i] / dist;
+                int level = (int)ceilf((float)log((double)ratio) / cam.log_scale);
+                if (level < 0) level = 0; else if (level >= cam.nlevels) level = cam.nlevels - 1;
+                w.u = u; w.v = v; w.r = cam.th * scale[level]; w.min_level = level - 1; w.max_level = level;
+            }
+        }
+    }
+    q[i] = w;
+}
+
+// SearchBySim3's acceptance and agreement check (src/ORBmatcher.cc:1426-1429, :1505-1507, :1509-1524) over the two window searches.
+__global__ __launch_bounds__(MT) void k_sim3_agree(const int *__restrict__ best1, const int *__restrict__ idx1, int n1,
+                                                   const int *__restrict__ best2, const int *__restrict__ idx2, int n2, int th_high,
+                                                   int *__restrict__ vn1, int *__restrict__ vn2, int *__restrict__ m12, int *__restrict__ nfound)
+{
+    const int i = blockIdx.x * MT + threadIdx.x;
+    if (i < n2) vn2[i] = idx2[i] >= 0 && best2[i] <= th_high ? idx2[i] : -1;
+    bool found = false;
+    if (i < n1) {
+        const int a = idx1[i] >= 0 && best1[i] <= th_high ? idx1[i] : -1;
+        vn1[i] = a;
+        if (a >= 0 && a < n2) found = (idx2[a] >= 0 && best2[a] <= th_high ? idx2[a] : -1) == i;
+        m12[i] = found ? a : -1;
+    }
+    const unsigned long long b = __ballot(found);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nfound, __popcll(b));
+}
+
 std::atomic<int> g_last_iterations{0};    // iterations of the last k_resolve_par (-1: it gave up and k_resolve ran)
 std::atomic<int> g_force_sequential{0};   // orbm_debug_force_sequential_resolver: tests run both resolvers
 
@@ -1101,7 +1314,7 @@ struct SortedFrame {
     std::vector<uint8_t> desc;
 };
 
-// Keypoints in the grid and not excluded, ordered by (cell, index).
+// Keypoints in the grid (and not excluded by `skip`), ordered by (cell, index).
 void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x,
                 float min_y, float max_x, float max_y, SortedFrame &sf)
 {
@@ -1131,21 +1344,194 @@ void sort_frame(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint
     sf.kp.resize(ns); sf.perm.resize(ns); sf.angle.resize(ns); sf.desc.resize(32 * ns);
 }
 
+// What the search kernels read of a frame, wherever it lives.
+struct FrameView {
+    const SeqKp *kp; const uint4 *desc; const float *angle; const int *perm; const int *cell_off;
+    GridParams gp;
+};
+
+} // namespace
+
+// A frame resident in HBM: the sorted keypoint records, descriptors, angles, the permutation and the cell table of
+// k_frame_build in ONE device block (recycled through a pool: a frame per image must not cost a hipMalloc), plus a host
+// copy of the permutation (the per-call occupancy masks are given by keypoint index and staged in sorted order).
+// Read-only after creation: any number of searches, from any thread, may use it at once.
+struct orbm_frame {
+    int n = 0, ns = 0, cap = 0, has_uright = 0;
+    float min_x = 0, min_y = 0, max_x = 0, max_y = 0;
+    GridParams gp = {0.f, 0.f, 0.f, 0.f};
+    char *block = nullptr;
+    SeqKp *kp = nullptr; uint4 *desc = nullptr; float *angle = nullptr; int *perm = nullptr, *cell_off = nullptr;
+    FrameHdr *hdr = nullptr;
+    std::vector<int> perm_host;
+};
+
+namespace {
+
+std::mutex g_frame_mu;
+std::vector<std::pair<int, char *>> g_frame_pool;     // (capacity, block) of destroyed frames
+
+size_t frame_block_bytes(int cap)
+{
+    return 256 + ((sizeof(SeqKp) + 32 + 4 + 4) * (size_t)cap + 255) / 256 * 256 + sizeof(int) * (FB_NC + 1);
+}
+
+int frame_alloc(orbm_frame *f, int n)
+{
+    const int cap = std::max(2048, (n + 1023) / 1024 * 1024);
+    {
+        std::lock_guard<std::mutex> lk(g_frame_mu);
+        for (size_t i = 0; i < g_frame_pool.size(); ++i)
+            if (g_frame_pool[i].first == cap) {
+                f->block = g_frame_pool[i].second;
+                g_frame_pool.erase(g_frame_pool.begin() + (long)i);
+                break;
+            }
+    }
+    if (!f->block && hipMalloc((void **)&f->block, frame_block_bytes(cap)) != hipSuccess) { f->block = nullptr; return -1; }
+    f->cap = cap;
+    char *p = f->block;
+    f->hdr = reinterpret_cast<FrameHdr *>(p); p += 256;
+    f->desc = reinterpret_cast<uint4 *>(p); p += (size_t)32 * cap;
+    f->kp = reinterpret_cast<SeqKp *>(p); p += sizeof(SeqKp) * (size_t)cap;
+    f->angle = reinterpret_cast<float *>(p); p += sizeof(float) * (size_t)cap;
+    f->perm = reinterpret_cast<int *>(p);
+    f->cell_off = reinterpret_cast<int *>(f->block + frame_block_bytes(cap) - sizeof(int) * (FB_NC + 1));
+    return 0;
+}
+
+void frame_release(orbm_frame *f)
+{
+    if (f->block) {
+        std::lock_guard<std::mutex> lk(g_frame_mu);
+        if (g_frame_pool.size() < 64) { g_frame_pool.emplace_back(f->cap, f->block); f->block = nullptr; }
+    }
+    if (f->block) (void)hipFree(f->block);
+    delete f;
+}
+
+// k_frame_build on `st` from device-resident inputs, then the header and the permutation back to the host (one small
+// block through the pinned arena of the leased workspace `w`, whose first pin_need bytes must be free for it).
+int frame_build(orbm_frame *f, Workspace &w, const orbx_keypoint *d_kps, const uint4 *d_desc, const float2 *d_xy, const float *d_ur,
+                const int *d_n, int n_host, int n_bound)
+{
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_frame_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipStream_t st = w.st;
+    hipLaunchKernelGGL(k_frame_build, dim3(1), dim3(FB_T), FB_LDS, st, d_kps, d_desc, d_xy, d_ur, d_n, n_host, f->gp, f->kp, f->desc,
+                       f->angle, f->perm, f->cell_off, f->hdr);
+    ORBX_HIP(hipGetLastError());
+    // results: hdr (256-byte slot) + perm[n_bound], staged out through the arena's tail
+    const size_t bytes = (256 + sizeof(int) * (size_t)n_bound + 15) & ~(size_t)15;
+    char *pin = w.pin + w.pin_cap - ((bytes + 255) & ~(size_t)255);
+    ORBX_HIP(hipMemcpyAsync(pin, f->hdr, sizeof(FrameHdr), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(pin + 256, f->perm, sizeof(int) * (size_t)n_bound, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    FrameHdr h;
+    memcpy(&h, pin, sizeof(h));
+    f->n = h.n; f->ns = h.ns;
+    f->perm_host.assign(reinterpret_cast<const int *>(pin + 256), reinterpret_cast<const int *>(pin + 256) + h.ns);
+    return ORBX_OK;
+}
+
+// The frame of a call: sorted on the host and staged with the call's inputs (the host-array entry points), or resident.
+struct FrameSrc {
+    const SortedFrame *host = nullptr;
+    const orbm_frame *res = nullptr;
+    size_t o_k = 0, o_b = 0, o_kang = 0, o_perm = 0, o_cell = 0;
+    explicit FrameSrc(const SortedFrame &sf) : host(&sf) {}
+    explicit FrameSrc(const orbm_frame *f) : res(f) {}
+    int ns() const { return host ? (int)host->perm.size() : res->ns; }
+    const int *perm() const { return host ? host->perm.data() : res->perm_host.data(); }
+    GridParams gp() const { return host ? host->gp : res->gp; }
+    void carve(Workspace &w)
+    {
+        if (!host) return;
+        const size_t m = ns() ? (size_t)ns() : 1;
+        o_k = w.carve(sizeof(SeqKp) * m); o_b = w.carve(32 * m); o_kang = w.carve(sizeof(float) * m); o_perm = w.carve(sizeof(int) * m);
+        o_cell = w.carve(sizeof(int) * (FRAME_GRID_COLS * FRAME_GRID_ROWS + 1));
+    }
+    void fill(Workspace &w) const
+    {
+        if (!host) return;
+        const size_t m = (size_t)ns();
+        if (!host->kp.empty()) memcpy(w.h<char>(o_k), host->kp.data(), sizeof(SeqKp) * m);
+        if (!host->cell_off.empty()) memcpy(w.h<char>(o_cell), host->cell_off.data(), sizeof(int) * host->cell_off.size());
+        memcpy(w.h<char>(o_b), host->desc.data(), 32 * m);
+        memcpy(w.h<char>(o_kang), host->angle.data(), sizeof(float) * m);
+        memcpy(w.h<char>(o_perm), host->perm.data(), sizeof(int) * m);
+    }
+    FrameView view(const Workspace &w) const
+    {
+        if (host) return {w.d<SeqKp>(o_k), w.d<uint4>(o_b), w.d<float>(o_kang), w.d<int>(o_perm), w.d<int>(o_cell), host->gp};
+        return {res->kp, res->desc, res->angle, res->perm, res->cell_off, res->gp};
+    }
+    // occupancy by keypoint index -> by sorted position
+    void fill_occ(uint8_t *dst, const uint8_t *occupied) const
+    {
+        const int m = ns();
+        const int *pm = perm();
+        for (int s = 0; s < m; ++s) dst[s] = occupied[pm[s]];
+    }
+};
+
+// A list of map points as the whole-function searches take it (orbm_points), staged with a call, and the prefix kernel that
+// turns it into window queries on the device.
+struct PointsPrefix {
+    const orbm_points *pts = nullptr;
+    FormCam cam;
+    const float *scale = nullptr;
+    size_t o_valid = 0, o_pos = 0, o_nrm = 0, o_min = 0, o_max = 0, o_oct = 0, o_sc = 0;
+    void carve(Workspace &w)
+    {
+        const size_t m = pts->n ? (size_t)pts->n : 1;
+        o_valid = w.carve(m); o_pos = w.carve(sizeof(float) * 3 * m);
+        o_nrm = w.carve(pts->normal ? sizeof(float) * 3 * m : 1);
+        o_min = w.carve(pts->min_distance ? sizeof(float) * m : 1); o_max = w.carve(pts->max_distance ? sizeof(float) * m : 1);
+        o_oct = w.carve(pts->octave ? sizeof(int) * m : 1);
+        o_sc = w.carve(sizeof(float) * cam.nlevels);
+    }
+    void fill(Workspace &w) const
+    {
+        const size_t m = (size_t)pts->n;
+        memcpy(w.h<char>(o_valid), pts->valid, m);
+        memcpy(w.h<char>(o_pos), pts->pos, sizeof(float) * 3 * m);
+        if (pts->normal) memcpy(w.h<char>(o_nrm), pts->normal, sizeof(float) * 3 * m);
+        if (pts->min_distance) memcpy(w.h<char>(o_min), pts->min_distance, sizeof(float) * m);
+        if (pts->max_distance) memcpy(w.h<char>(o_max), pts->max_distance, sizeof(float) * m);
+        if (pts->octave) memcpy(w.h<char>(o_oct), pts->octave, sizeof(int) * m);
+        memcpy(w.h<char>(o_sc), scale, sizeof(float) * cam.nlevels);
+    }
+    void launch(const Workspace &w, WinQuery *dq, hipStream_t st) const
+    {
+        if (!pts->n) return;
+        hipLaunchKernelGGL(k_project_form, dim3((pts->n + MT - 1) / MT), dim3(MT), 0, st, (const uint8_t *)w.d<uint8_t>(o_valid),
+                           (const float *)w.d<float>(o_pos), (const float *)w.d<float>(o_nrm), (const float *)w.d<float>(o_min),
+                           (const float *)w.d<float>(o_max), (const int *)w.d<int>(o_oct), pts->n, cam, (const float *)w.d<float>(o_sc), dq);
+    }
+};
+
 // Shared driver.  mode 0: projection family / BoW lists; mode 1: SearchForInitialization.
 // Inputs are staged in the workspace's pinned arena and uploaded with one copy; results
-// come back with one copy.  Everything runs on the workspace's stream.
-int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes, int nq,
-                   const SortedFrame &sf, int n, int has_uright, int th, float nnratio, int accept_mode, int check,
-                   int32_t *match_kp, int32_t *match_q, int *nmatches, const int32_t *cand_off = nullptr,
+// come back with one copy.  Everything runs on the workspace's stream.  The window queries come from the host (`queries`)
+// or from `prefix` on the device (then queries_out, if given, receives them).
+int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes,
+                   int nq, FrameSrc &fs, int n, const uint8_t *occupied, int has_uright, int th, float nnratio, int accept_mode, int check,
+                   int32_t *match_kp, int32_t *match_q, int *nmatches, WinQuery *queries_out = nullptr, const int32_t *cand_off = nullptr,
                    const int32_t *cand_beg = nullptr, const int32_t *cand_idx = nullptr, int ncand = 0,
                    const int32_t *seg = nullptr, int nseg = 0)
 {
-    const int ns = (int)sf.perm.size();
+    const int ns = fs.ns();
     if (ns > SEQ_MAXN || nq > 65536) ORBX_FAIL(ORBX_ERR_CAPACITY, "frame too large for the sequential resolver");
     for (int j = 0; j < n && mode == 0; ++j) match_kp[j] = -1;
     for (int i = 0; i < nq; ++i) match_q[i] = -1;
     *nmatches = 0;
-    if (nq == 0 || ns == 0) return ORBX_OK;
+    const bool windows = queries || prefix;
+    if (queries_out) for (int i = 0; i < nq; ++i) queries_out[i] = {0.f, 0.f, -1.f, 0.f, 0, -1};
+    if (nq == 0 || (ns == 0 && !queries_out)) return ORBX_OK;
     const size_t lds = sizeof(int) * (3 * (size_t)ns + (mode == 1 ? nq : 0)) + 16;
     if (lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_CAPACITY, "resolver state exceeds LDS");
     if (mode != 0) { seg = nullptr; nseg = 0; }
@@ -1174,45 +1560,44 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
     // (the BoW searches' segments -- one per vocabulary node, disjoint candidate sets -- only matter to the sequential resolver:
     // the fixed point needs no partition, queries of different nodes simply never meet)
     bool sequential = g_force_sequential.load(std::memory_order_relaxed) != 0;
-    const int init_c = std::min(7, (144 * 1024 / 4) / ns - 3);
+    const int init_c = ns ? std::min(7, (144 * 1024 / 4) / ns - 3) : 7;
     if (mode == 1 && init_c < 2) sequential = true;
     for (int attempt = 0; attempt < 4; ++attempt) {
         w.used = 0;
         // staged inputs (same offsets on both sides), then device-only arrays, then the result block
-        const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * ns),
-                     o_b = w.carve((size_t)32 * ns), o_kang = w.carve(sizeof(float) * ns), o_qang = w.carve(sizeof(float) * nq),
-                     o_perm = w.carve(sizeof(int) * ns), o_tk = w.carve(nq), o_off = w.carve(sizeof(int) * (nq + 1)),
+        const size_t o_qh = w.carve(queries ? sizeof(WinQuery) * nq : 1), o_a = w.carve((size_t)32 * nq);
+        fs.carve(w);
+        const size_t o_qang = w.carve(sizeof(float) * nq), o_tk = w.carve(nq), o_occ = w.carve(occupied && ns ? (size_t)ns : 1),
+                     o_off = w.carve(sizeof(int) * (nq + 1)),
                      o_cbeg = w.carve(sizeof(int) * (size_t)nq), o_cand = w.carve(sizeof(int) * (size_t)(ncand ? ncand : 1)),
-                     o_cell = w.carve(sizeof(int) * (FRAME_GRID_COLS * FRAME_GRID_ROWS + 1)),
                      o_seg = w.carve(sizeof(int) * (size_t)(nseg + 1));
+        if (prefix) prefix->carve(w);
         const size_t staged = w.used;
+        const size_t o_qd = w.carve(queries ? 1 : sizeof(WinQuery) * nq);
+        const size_t o_q = queries ? o_qh : o_qd;
         const size_t o_top = w.carve(sizeof(unsigned) * TOPK * (size_t)nq), o_cnt = w.carve(sizeof(int) * nq), o_acc = w.carve(sizeof(int) * nq),
                      o_lend = w.carve(sizeof(int) * nq),
-                     o_state = w.carve(sizeof(int) * (size_t)std::max(ns, nq));
+                     o_state = w.carve(sizeof(int) * (size_t)std::max(std::max(ns, nq), 1));
         const size_t o_res = w.used;
         const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(4 * sizeof(int));
         const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
-        if (w.reserve(total_bytes, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        if (w.reserve(total_bytes, std::max(staged, res_bytes) + (queries_out ? sizeof(WinQuery) * nq + 256 : 0))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
         if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
         hipStream_t st = w.st;
 
-        if (queries) {
-            memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
-            memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
-            memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
-        }
+        if (queries) memcpy(w.h<char>(o_qh), queries, sizeof(WinQuery) * nq);
         memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
-        memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
-        memcpy(w.h<char>(o_kang), sf.angle.data(), sizeof(float) * ns);
+        fs.fill(w);
         if (qangle) memcpy(w.h<char>(o_qang), qangle, sizeof(float) * nq); else memset(w.h<char>(o_qang), 0, sizeof(float) * nq);
-        memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
         if (qtakes) memcpy(w.h<char>(o_tk), qtakes, nq); else memset(w.h<char>(o_tk), 1, nq);
+        if (occupied && ns) fs.fill_occ(w.h<uint8_t>(o_occ), occupied);
         if (cand_off) {
             memcpy(w.h<char>(o_off), cand_off, sizeof(int) * (nq + 1));
             memcpy(w.h<char>(o_cbeg), cand_beg, sizeof(int) * (size_t)nq);
             if (ncand) memcpy(w.h<char>(o_cand), cand_idx, sizeof(int) * ncand);
         }
         if (seg) memcpy(w.h<char>(o_seg), seg, sizeof(int) * (size_t)(nseg + 1));
+        if (prefix) prefix->fill(w);
         ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
         // ONE fill for everything that needs a preset (a launch each was 3-4 us of a 0.1-ms call): match_kp = -1 (slot untouched);
         // segments write back touched slots of the state only, so it is preset to -1 as well (the span in between, match_q, is
@@ -1226,23 +1611,30 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
             ORBX_HIP(hipMemsetAsync(w.d<char>(f0), 0xff, o_nm + sizeof(int) - f0, st));
         }
 
-        const WinQuery *dq = w.d<WinQuery>(o_q);
-        const uint4 *da = w.d<uint4>(o_a), *db = w.d<uint4>(o_b);
-        const SeqKp *dk = w.d<SeqKp>(o_k);
+        const FrameView fv = fs.view(w);
+        WinQuery *dq = w.d<WinQuery>(o_q);
+        if (prefix) prefix->launch(w, dq, st);
+        if (queries_out) {
+            ORBX_HIP(hipMemcpyAsync(w.pin + w.pin_cap - ((sizeof(WinQuery) * nq + 255) & ~(size_t)255), dq, sizeof(WinQuery) * nq, hipMemcpyDeviceToHost, st));
+            if (ns == 0) { ORBX_HIP(hipStreamSynchronize(st)); memcpy(queries_out, w.pin + w.pin_cap - ((sizeof(WinQuery) * nq + 255) & ~(size_t)255), sizeof(WinQuery) * nq); return ORBX_OK; }
+        }
+        const uint4 *da = w.d<uint4>(o_a), *db = fv.desc;
+        const SeqKp *dk = fv.kp;
+        const uint8_t *docc = occupied ? w.d<uint8_t>(o_occ) : nullptr;
         int *doff = w.d<int>(o_off), *dnm = w.d<int>(o_nm);
         const int init_dist = mode == 0 ? 256 : INT_MAX;
         const dim3 g((nq + MT / 64 - 1) / (MT / 64)); // one wave per query
         unsigned *dtop = w.d<unsigned>(o_top);
         const int *lbeg = doff, *lend = doff + 1; // CSR lists; the strided path has its own bounds
-        if (cand_off) { // explicit candidate lists
+        if (!windows) { // explicit candidate lists
             hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, st, da, nq, db, (const int *)doff, (const int *)w.d<int>(o_cbeg),
                                (const int *)w.d<int>(o_cand), w.ent, dtop);
         } else if (!exact) {
             lbeg = w.d<int>(o_cnt); lend = w.d<int>(o_lend);
-            hipLaunchKernelGGL(k_win_wave<2>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+            hipLaunchKernelGGL(k_win_wave<2>, g, dim3(MT), 0, st, (const WinQuery *)dq, da, nq, dk, db, fv.cell_off, docc, fv.gp, has_uright,
                                init_dist, (int *)nullptr, (const int *)nullptr, w.ent, WIN_STRIDE, w.d<int>(o_cnt), w.d<int>(o_lend), dnm + 1, dtop, gen);
         } else {
-            hipLaunchKernelGGL(k_win_wave<0>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+            hipLaunchKernelGGL(k_win_wave<0>, g, dim3(MT), 0, st, (const WinQuery *)dq, da, nq, dk, db, fv.cell_off, docc, fv.gp, has_uright,
                                init_dist, w.d<int>(o_cnt), (const int *)nullptr, (unsigned *)nullptr, 0, (int *)nullptr, (int *)nullptr,
                                (int *)nullptr, (unsigned *)nullptr, gen);
             hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_cnt), nq, doff, dnm + 1);
@@ -1254,7 +1646,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
                 ent_need = (size_t)total;
                 if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
             }
-            hipLaunchKernelGGL(k_win_wave<1>, g, dim3(MT), 0, st, dq, da, nq, dk, db, (const int *)w.d<int>(o_cell), sf.gp, has_uright,
+            hipLaunchKernelGGL(k_win_wave<1>, g, dim3(MT), 0, st, (const WinQuery *)dq, da, nq, dk, db, fv.cell_off, docc, fv.gp, has_uright,
                                init_dist, (int *)nullptr, (const int *)doff, w.ent, 0, (int *)nullptr, (int *)nullptr, (int *)nullptr, dtop, gen);
         }
         const int *dseg = seg ? w.d<int>(o_seg) : nullptr;
@@ -1262,24 +1654,24 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         if (!sequential && mode == 1) {
             hipLaunchKernelGGL(k_resolve_init_par, dim3(1), dim3(RES_T), sizeof(int) * (size_t)(init_c + 3) * ns, st, (const unsigned *)w.ent,
                                (const unsigned *)dtop, lbeg, lend, nq, ns, init_c, th, nnratio, (const float *)w.d<float>(o_qang),
-                               (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<unsigned>(o_acc), (const int *)dnm, gen,
+                               fv.angle, fv.perm, check, w.d<unsigned>(o_acc), (const int *)dnm, gen,
                                reinterpret_cast<int *>(w.pin + (o_mq - o_res)), reinterpret_cast<int *>(w.pin + (o_nm - o_res)));
         } else if (!sequential) {
             hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(RES_T), sizeof(int) * 4 * (size_t)ns, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend,
                                nq, ns, (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, (const float *)w.d<float>(o_qang),
-                               (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check, w.d<int>(o_mq), w.d<int>(o_mk), n, (const int *)dnm, gen,
+                               fv.angle, fv.perm, check, w.d<int>(o_mq), w.d<int>(o_mk), n, (const int *)dnm, gen,
                                reinterpret_cast<int *>(w.pin + (o_mq - o_res)), reinterpret_cast<int *>(w.pin + (o_mk - o_res)), reinterpret_cast<int *>(w.pin + (o_nm - o_res)));
         } else if (mode == 0) {
             hipLaunchKernelGGL(k_resolve<0>, gr, dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend, nq, ns,
                                (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, accept_mode, w.d<int>(o_acc), w.d<int>(o_state), dnm, dseg);
             hipLaunchKernelGGL(k_rotation<0>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
-                               (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
+                               (const float *)w.d<float>(o_qang), fv.angle, fv.perm, check,
                                w.d<int>(o_mq), w.d<int>(o_mk), dnm);
         } else {
             hipLaunchKernelGGL(k_resolve<1>, gr, dim3(64), lds, st, (const unsigned *)w.ent, (const unsigned *)dtop, lbeg, lend, nq, ns,
                                (const uint8_t *)w.d<uint8_t>(o_tk), th, nnratio, 0, w.d<int>(o_acc), w.d<int>(o_state), dnm, dseg);
             hipLaunchKernelGGL(k_rotation<1>, dim3(1), dim3(MT), 0, st, (const int *)w.d<int>(o_acc), (const int *)w.d<int>(o_state), nq, ns,
-                               (const float *)w.d<float>(o_qang), (const float *)w.d<float>(o_kang), (const int *)w.d<int>(o_perm), check,
+                               (const float *)w.d<float>(o_qang), fv.angle, fv.perm, check,
                                w.d<int>(o_mq), w.d<int>(o_mk), dnm);
         }
         ORBX_HIP(hipGetLastError());
@@ -1287,7 +1679,7 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         ORBX_HIP(hipStreamSynchronize(st));
         int flag = 0;
         memcpy(&flag, w.pin + (o_nm - o_res) + sizeof(int), sizeof(int));
-        if (!cand_off && !exact && flag == gen) { // a window list outgrew its region: once more on the exact path
+        if (windows && !exact && flag == gen) { // a window list outgrew its region: once more on the exact path
             exact = true;
             continue;
         }
@@ -1301,10 +1693,180 @@ int run_sequential(int mode, const WinQuery *queries, const uint8_t *qdesc, cons
         memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
         if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
         memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
+        if (queries_out) memcpy(queries_out, w.pin + w.pin_cap - ((sizeof(WinQuery) * nq + 255) & ~(size_t)255), sizeof(WinQuery) * nq);
         if (seg && sequential) *nmatches += 1;   // the segments added their counts to the preset -1
         break;
     }
     return ORBX_OK;
+}
+
+// ---- cv::Mat float arithmetic of the pose handling in front of the projection loops, on the host (a handful of operations
+// per call; -ffp-contract=off keeps them unfused).  OpenCV 3.4 semantics restated (gemm's 3 x 3 special case: float row
+// sum left to right, then float(double(sum) * alpha + double(c) * beta); scaling by a FLOAT factor with a + 0.0f).
+void pose_parts(const float *T16, float *R, float *t)
+{
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T16[4 * r + c]; t[r] = T16[4 * r + 3]; }
+}
+void gemm3(const float *A, const float *b, double alpha, const float *c, double beta, float *d)
+{
+    float out[3];
+    for (int k = 0; k < 3; ++k) {
+        const float t = A[3 * k] * b[0] + A[3 * k + 1] * b[1] + A[3 * k + 2] * b[2];
+        out[k] = (float)((double)t * alpha + (double)(c ? c[k] : 0.0f) * beta);
+    }
+    d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+}
+void transpose3(const float *A, float *At)
+{
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) At[3 * r + c] = A[3 * c + r];
+}
+void scale_mat(const float *A, int n, double s, float *out)
+{
+    const float a = (float)s, b = (float)0.0;
+    for (int i = 0; i < n; ++i) out[i] = A[i] * a + b;
+}
+void neg_Rt_t(const float *R, const float *t, float *out)   // -R.t() * t  (ORBmatcher.cc:1542, :1679, :504)
+{
+    float Rt[9];
+    transpose3(R, Rt);
+    gemm3(Rt, t, -1.0, nullptr, 0.0, out);
+}
+
+void form_cam_common(FormCam &c, const orbm_view *v, const orbm_frame *f, int form, float th)
+{
+    memset(&c, 0, sizeof(c));
+    c.fx = v->fx; c.fy = v->fy; c.cx = v->cx; c.cy = v->cy;
+    c.min_x = f->min_x; c.max_x = f->max_x; c.min_y = f->min_y; c.max_y = f->max_y;
+    c.mbf = v->mbf; c.log_scale = v->log_scale_factor; c.th = th; c.nlevels = v->nlevels; c.form = form;
+}
+
+bool bad_view(const orbm_view *v) { return !v || !v->scale_factors || v->nlevels < 1 || v->nlevels > 16; }
+bool bad_points(const orbm_points *p, bool need_range, bool need_normal, bool need_octave, int nlevels)
+{
+    if (!p || p->n < 0 || p->n > 65536) return true;
+    if (p->n == 0) return false;
+    if (!p->valid || !p->pos || !p->desc) return true;
+    if (need_range && (!p->min_distance || !p->max_distance)) return true;
+    if (need_normal && !p->normal) return true;
+    if (need_octave) {
+        if (!p->octave) return true;
+        for (int i = 0; i < p->n; ++i)
+            if (p->valid[i] && (p->octave[i] < 0 || p->octave[i] >= nlevels)) return true;
+    }
+    return false;
+}
+
+// One window search without coupling (k_win_best) for device-resident queries: returns into ob[5][nq] (best, best level, second,
+// second level, idx).
+void launch_win_best(hipStream_t st, const WinQuery *dq, const uint4 *da, int nq, const FrameView &fv, const uint8_t *docc, int has_uright,
+                     int init_dist, const float *inv_sigma2, int fuse_gate, int *ob)
+{
+    hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, st, dq, da, nq, fv.kp, fv.desc, fv.cell_off, fv.perm, docc,
+                       fv.gp, has_uright, init_dist, inv_sigma2, fuse_gate, ob, ob + nq, ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
+}
+
+int search_window_core(FrameSrc &fs, const orbm_window_query *queries, const uint8_t *qdesc, int nq, const uint8_t *skip, int has_uright,
+                       int init_dist, const float *inv_level_sigma2, int nlevels, int fuse_gate, int32_t *best, int32_t *best_level,
+                       int32_t *second, int32_t *second_level, int32_t *idx)
+{
+    const int ns = fs.ns();
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq);
+    fs.carve(w);
+    const size_t o_occ = w.carve(skip && ns ? (size_t)ns : 1), o_sg = w.carve(inv_level_sigma2 ? sizeof(float) * nlevels : 1);
+    const size_t staged = w.used;
+    const size_t o_res = w.carve(sizeof(int) * 5 * (size_t)nq);
+    if (w.reserve(w.used, std::max(staged, sizeof(int) * 5 * (size_t)nq + 16))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
+    memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
+    fs.fill(w);
+    if (skip && ns) fs.fill_occ(w.h<uint8_t>(o_occ), skip);
+    if (inv_level_sigma2) memcpy(w.h<char>(o_sg), inv_level_sigma2, sizeof(float) * nlevels);
+    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, w.st));
+    int *ob = w.d<int>(o_res);
+    launch_win_best(w.st, w.d<WinQuery>(o_q), w.d<uint4>(o_a), nq, fs.view(w), skip && ns ? w.d<uint8_t>(o_occ) : nullptr, has_uright, init_dist,
+                    inv_level_sigma2 ? w.d<float>(o_sg) : nullptr, fuse_gate, ob);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(orbx::stage_out(w.pin, ob, (sizeof(int) * 5 * (size_t)nq + 15) & ~(size_t)15, w.st));
+    ORBX_HIP(hipStreamSynchronize(w.st));
+    const int *r = w.h<int>(0);
+    if (best) memcpy(best, r, sizeof(int) * nq);
+    if (best_level) memcpy(best_level, r + nq, sizeof(int) * nq);
+    if (second) memcpy(second, r + 2 * nq, sizeof(int) * nq);
+    if (second_level) memcpy(second_level, r + 3 * nq, sizeof(int) * nq);
+    if (idx) memcpy(idx, r + 4 * nq, sizeof(int) * nq);
+    return ORBX_OK;
+}
+
+int search_map_core(FrameSrc &fs, int n, const uint8_t *has_mappoint, const float *mp_pos, const float *mp_normal, const float *mp_min_dist,
+                    const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw, const double *tcw, const orbm_camera *cam,
+                    const float *scale_factors, int nlevels, float th, float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches,
+                    float *proj)
+{
+    const int ns = fs.ns();
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    const size_t o_pos = w.carve(sizeof(float) * 3 * m), o_nrm = w.carve(sizeof(float) * 3 * m), o_min = w.carve(sizeof(float) * m),
+                 o_max = w.carve(sizeof(float) * m), o_md = w.carve((size_t)32 * m);
+    fs.carve(w);
+    const size_t o_occ = w.carve(has_mappoint && ns ? (size_t)ns : 1), o_sc = w.carve(sizeof(float) * nlevels);
+    const size_t staged = w.used;
+    const size_t o_q = w.carve(sizeof(WinQuery) * m), o_o = w.carve(sizeof(int) * 5 * (size_t)m);
+    const size_t o_res = w.used;
+    const size_t o_mk = w.carve(sizeof(int) * n), o_nm = w.carve(sizeof(int)), o_proj = w.carve(sizeof(float) * 4 * m);
+    const size_t res_bytes = w.used - o_res;
+    if (w.reserve(w.used, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    memcpy(w.h<char>(o_pos), mp_pos, sizeof(float) * 3 * m); memcpy(w.h<char>(o_nrm), mp_normal, sizeof(float) * 3 * m);
+    memcpy(w.h<char>(o_min), mp_min_dist, sizeof(float) * m); memcpy(w.h<char>(o_max), mp_max_dist, sizeof(float) * m);
+    memcpy(w.h<char>(o_md), mp_desc, (size_t)32 * m);
+    fs.fill(w);
+    if (has_mappoint && ns) fs.fill_occ(w.h<uint8_t>(o_occ), has_mappoint);
+    memcpy(w.h<char>(o_sc), scale_factors, sizeof(float) * nlevels);
+    hipStream_t st = w.st;
+    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
+    ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * n, st));
+    ORBX_HIP(hipMemsetAsync(w.d<char>(o_nm), 0, sizeof(int), st));
+    MapCam mc;
+    mc.fx = cam->fx; mc.fy = cam->fy; mc.cx = cam->cx; mc.cy = cam->cy;
+    mc.bminx = cam->min_x; mc.bmaxx = cam->max_x; mc.bminy = cam->min_y; mc.bmaxy = cam->max_y;
+    for (int i = 0; i < 9; ++i) mc.R[i] = Rcw[i];
+    for (int i = 0; i < 3; ++i) mc.t[i] = tcw[i];
+    mc.th = th; mc.nlevels = nlevels;
+    int *ob = w.d<int>(o_o);
+    const dim3 g((m + MT - 1) / MT);
+    hipLaunchKernelGGL(k_map_frustum, g, dim3(MT), 0, st, (const float *)w.d<float>(o_pos), (const float *)w.d<float>(o_nrm),
+                       (const float *)w.d<float>(o_min), (const float *)w.d<float>(o_max), m, mc, (const float *)w.d<float>(o_sc),
+                       w.d<WinQuery>(o_q), w.d<float>(o_proj));
+    launch_win_best(st, w.d<WinQuery>(o_q), w.d<uint4>(o_md), m, fs.view(w), has_mappoint && ns ? w.d<uint8_t>(o_occ) : nullptr, 0, INT_MAX,
+                    nullptr, 0, ob);
+    hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, st, (const int *)ob, (const int *)(ob + 4 * m), (const int *)(ob + 2 * m),
+                       (const int *)(ob + m), (const int *)(ob + 3 * m), m, th_reloc, nnratio, w.d<int>(o_mk), w.d<int>(o_nm));
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(orbx::stage_out(w.pin, w.dev + o_res, res_bytes, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(matched_mp, w.pin + (o_mk - o_res), sizeof(int) * n);
+    if (nmatches) memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
+    if (proj) memcpy(proj, w.pin + (o_proj - o_res), sizeof(float) * 4 * m);
+    return ORBX_OK;
+}
+
+int search_init_core(FrameSrc &fs, int n2, const orbx_keypoint *kps1, const uint8_t *desc1, int n1, float *prev_matched, int window_size,
+                     float nnratio, int check_orientation, int32_t *matches12, int *nmatches)
+{
+    // queries: level-0 keypoints of F1 around their previous match (:619-626); others get an empty window
+    std::vector<WinQuery> q(n1 ? n1 : 1);
+    std::vector<float> ang(n1 ? n1 : 1);
+    for (int i = 0; i < n1; ++i) {
+        const bool use = !(kps1[i].octave > 0);
+        q[i] = {prev_matched[2 * i], prev_matched[2 * i + 1], use ? (float)window_size : -1.0f, 0.f, kps1[i].octave, kps1[i].octave};
+        ang[i] = kps1[i].angle;
+    }
+    std::vector<int32_t> dummy(n2 ? n2 : 1);
+    return run_sequential(1, q.data(), nullptr, desc1, ang.data(), nullptr, n1, fs, n2, nullptr, 0, 45 /* TH_LOW, :38 */, nnratio, 0,
+                          check_orientation, dummy.data(), matches12, nmatches);
 }
 
 } // namespace
@@ -1332,6 +1894,107 @@ int orbm_sorted_frame(const orbx_keypoint *kps, int n, const uint8_t *skip, cons
     return ORBX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ resident frames
+
+int orbm_frame_create(const orbx_keypoint *kps, const uint8_t *desc, int n, const float *uright, float min_x, float min_y, float max_x,
+                      float max_y, orbm_frame **out)
+{
+    if (!out || n < 0 || (n && (!kps || !desc)) || !(max_x > min_x) || !(max_y > min_y)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    if (n > FB_MAXN) ORBX_FAIL(ORBX_ERR_CAPACITY, "more than 8,192 keypoints in a resident frame");
+    ORBX_NEED_DEVICE();
+    orbm_frame *f = new orbm_frame();
+    f->min_x = min_x; f->min_y = min_y; f->max_x = max_x; f->max_y = max_y; f->has_uright = uright ? 1 : 0;
+    f->gp = {min_x, min_y, (float)FRAME_GRID_COLS / (max_x - min_x), (float)FRAME_GRID_ROWS / (max_y - min_y)};
+    if (frame_alloc(f, n)) { frame_release(f); ORBX_FAIL(ORBX_ERR_HIP, "frame allocation failed"); }
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    const size_t m = n ? (size_t)n : 1;
+    const size_t o_k = w.carve(sizeof(orbx_keypoint) * m), o_d = w.carve(32 * m), o_u = w.carve(sizeof(float) * m);
+    const size_t staged = w.used;
+    if (w.reserve(staged, staged + sizeof(int) * m + 1024)) { frame_release(f); ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed"); }
+    if (n) {
+        memcpy(w.h<char>(o_k), kps, sizeof(orbx_keypoint) * m);
+        memcpy(w.h<char>(o_d), desc, 32 * m);
+        if (uright) memcpy(w.h<char>(o_u), uright, sizeof(float) * m);
+    }
+    int rc = orbx::stage_in(w.dev, w.pin, staged, w.st) == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
+    if (rc == ORBX_OK)
+        rc = frame_build(f, w, w.d<orbx_keypoint>(o_k), w.d<uint4>(o_d), nullptr, uright ? w.d<float>(o_u) : nullptr, nullptr, n, n ? n : 1);
+    if (rc != ORBX_OK) { frame_release(f); return rc; }
+    *out = f;
+    return ORBX_OK;
+}
+
+int orbm_frame_from_extractor(orbx_extractor *ex, int frame, const float *xy_undistorted, const float *uright, int uright_from_stereo,
+                              float min_x, float min_y, float max_x, float max_y, orbm_frame **out)
+{
+    if (!out || !ex || frame < 0 || frame >= ex->last_batch || !(max_x > min_x) || !(max_y > min_y) || (uright && uright_from_stereo))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    if (ex->kcap > FB_MAXN) ORBX_FAIL(ORBX_ERR_CAPACITY, "more than 8,192 keypoints in a resident frame");
+    if (uright_from_stereo && (!ex->d_uright || frame >= ex->st_batch)) ORBX_FAIL(ORBX_ERR_ARG, "no stereo match on this handle");
+    ORBX_NEED_DEVICE();
+    const int cap = ex->kcap;
+    orbm_frame *f = new orbm_frame();
+    f->min_x = min_x; f->min_y = min_y; f->max_x = max_x; f->max_y = max_y; f->has_uright = (uright || uright_from_stereo) ? 1 : 0;
+    f->gp = {min_x, min_y, (float)FRAME_GRID_COLS / (max_x - min_x), (float)FRAME_GRID_ROWS / (max_y - min_y)};
+    if (frame_alloc(f, cap)) { frame_release(f); ORBX_FAIL(ORBX_ERR_HIP, "frame allocation failed"); }
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    const size_t o_xy = w.carve(xy_undistorted ? sizeof(float) * 2 * (size_t)cap : 1), o_u = w.carve(uright ? sizeof(float) * (size_t)cap : 1);
+    const size_t staged = w.used;
+    if (w.reserve(staged, staged + sizeof(int) * (size_t)cap + 1024)) { frame_release(f); ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed"); }
+    // the caller's arrays hold n entries, n = the frame's count: known here only after the extraction has finished -- it has, for
+    // the caller to hold undistorted coordinates -- so read it back first in that case
+    int n_known = -1;
+    const int *d_n = ex->d_counts + frame;
+    const uint8_t *d_desc = ex->d_desc + (size_t)frame * cap * 32;
+    orbx_extractor *producer = orbx_detail::order_after_producer(d_desc, w.st);
+    int rc = ORBX_OK;
+    if (xy_undistorted || uright) {
+        if (hipMemcpyAsync(&n_known, d_n, sizeof(int), hipMemcpyDeviceToHost, w.st) != hipSuccess || hipStreamSynchronize(w.st) != hipSuccess) rc = ORBX_ERR_HIP;
+        if (rc == ORBX_OK && (n_known < 0 || n_known > cap)) rc = ORBX_ERR_HIP;
+        if (rc == ORBX_OK) {
+            if (xy_undistorted) memcpy(w.h<char>(o_xy), xy_undistorted, sizeof(float) * 2 * (size_t)n_known);
+            if (uright) memcpy(w.h<char>(o_u), uright, sizeof(float) * (size_t)n_known);
+            if (orbx::stage_in(w.dev, w.pin, staged, w.st) != hipSuccess) rc = ORBX_ERR_HIP;
+        }
+    }
+    if (rc == ORBX_OK)
+        rc = frame_build(f, w, ex->d_kps + (size_t)frame * cap, reinterpret_cast<const uint4 *>(d_desc),
+                         xy_undistorted ? w.d<float2>(o_xy) : nullptr,
+                         uright ? w.d<float>(o_u) : (uright_from_stereo ? ex->d_uright + (size_t)frame * cap : nullptr), d_n, 0, cap);
+    (void)producer;      // frame_build has waited for the stream: nothing of this call still reads the extractor's buffers
+    if (rc != ORBX_OK) { frame_release(f); if (rc == ORBX_ERR_HIP) ORBX_FAIL(ORBX_ERR_HIP, "building the frame failed"); return rc; }
+    *out = f;
+    return ORBX_OK;
+}
+
+int orbm_frame_destroy(orbm_frame *f)
+{
+    if (!f) return ORBX_OK;
+    frame_release(f);
+    return ORBX_OK;
+}
+
+int orbm_frame_size(const orbm_frame *f, int *n, int *nsorted)
+{
+    if (!f) ORBX_FAIL(ORBX_ERR_ARG, "null frame");
+    if (n) *n = f->n;
+    if (nsorted) *nsorted = f->ns;
+    return ORBX_OK;
+}
+
+int orbm_frame_layout(const orbm_frame *f, int32_t *perm, int32_t *cell_off)
+{
+    if (!f) ORBX_FAIL(ORBX_ERR_ARG, "null frame");
+    if (perm) memcpy(perm, f->perm_host.data(), sizeof(int) * f->perm_host.size());
+    if (cell_off) ORBX_HIP(hipMemcpy(cell_off, f->cell_off, sizeof(int) * (FB_NC + 1), hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ window searches
 
 int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, int nq, const orbx_keypoint *kps,
                        const uint8_t *desc, int n, const uint8_t *skip, const float *uright, float min_x, float min_y,
@@ -1344,39 +2007,20 @@ int orbm_search_window(const orbm_window_query *queries, const uint8_t *qdesc, i
     ORBX_NEED_DEVICE();
     if (nq == 0) return ORBX_OK;
     SortedFrame sf;
-    sort_frame(kps, desc, n, skip, uright, min_x, min_y, max_x, max_y, sf);
-    const int ns = (int)sf.perm.size();
-    WorkspaceLease lease;
-    Workspace &w = *lease.w;
-    w.used = 0;
-    const size_t o_q = w.carve(sizeof(WinQuery) * nq), o_a = w.carve((size_t)32 * nq), o_k = w.carve(sizeof(SeqKp) * (ns ? ns : 1)),
-                 o_b = w.carve((size_t)32 * (ns ? ns : 1)), o_perm = w.carve(sizeof(int) * (ns ? ns : 1)),
-                 o_cell = w.carve(sizeof(int) * sf.cell_off.size());
-    const size_t staged = w.used;
-    const size_t o_res = w.carve(sizeof(int) * 5 * (size_t)nq);
-    if (w.reserve(w.used, std::max(staged, sizeof(int) * 5 * (size_t)nq))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
-    memcpy(w.h<char>(o_q), queries, sizeof(WinQuery) * nq);
-    memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
-    if (ns) {
-        memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
-        memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
-        memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
-    }
-    memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
-    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, w.st));
-    int *ob = w.d<int>(o_res);
-    hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, w.st, (const WinQuery *)w.d<WinQuery>(o_q),
-                       (const uint4 *)w.d<uint4>(o_a), nq, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
-                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, uright ? 1 : 0, init_dist, (const float *)nullptr, 0, ob, ob + nq,
-                       ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
-    ORBX_HIP(hipGetLastError());
-    ORBX_HIP(orbx::stage_out(w.pin, ob, (sizeof(int) * 5 * (size_t)nq + 15) & ~(size_t)15, w.st));
-    ORBX_HIP(hipStreamSynchronize(w.st));
-    const int *r = w.h<int>(0);
-    memcpy(best, r, sizeof(int) * nq); memcpy(best_level, r + nq, sizeof(int) * nq);
-    memcpy(second, r + 2 * nq, sizeof(int) * nq); memcpy(second_level, r + 3 * nq, sizeof(int) * nq);
-    memcpy(idx, r + 4 * nq, sizeof(int) * nq);
-    return ORBX_OK;
+    sort_frame(kps, desc, n, nullptr, uright, min_x, min_y, max_x, max_y, sf);
+    FrameSrc fs(sf);
+    return search_window_core(fs, queries, qdesc, nq, skip, uright ? 1 : 0, init_dist, nullptr, 0, 0, best, best_level, second, second_level, idx);
+}
+
+int orbm_frame_search_window(const orbm_frame *frame, const orbm_window_query *queries, const uint8_t *qdesc, int nq, const uint8_t *skip,
+                             int init_dist, int32_t *best, int32_t *best_level, int32_t *second, int32_t *second_level, int32_t *idx)
+{
+    if (!frame || nq < 0 || (nq && (!queries || !qdesc || !best || !best_level || !second || !second_level || !idx)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (nq == 0) return ORBX_OK;
+    FrameSrc fs(frame);
+    return search_window_core(fs, queries, qdesc, nq, skip, frame->has_uright, init_dist, nullptr, 0, 0, best, best_level, second, second_level, idx);
 }
 
 int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc, int n, const uint8_t *has_mappoint,
@@ -1394,59 +2038,28 @@ int orbm_search_by_projection_map(const orbx_keypoint *kps, const uint8_t *desc,
     if (nmatches) *nmatches = 0;
     if (n == 0 || m == 0) return ORBX_OK;
     SortedFrame sf;
-    sort_frame(kps, desc, n, has_mappoint, nullptr, cam->grid_min_x, cam->grid_min_y, cam->grid_max_x, cam->grid_max_y, sf);
-    const int ns = (int)sf.perm.size();
-    WorkspaceLease lease;
-    Workspace &w = *lease.w;
-    w.used = 0;
-    const size_t o_pos = w.carve(sizeof(float) * 3 * m), o_nrm = w.carve(sizeof(float) * 3 * m), o_min = w.carve(sizeof(float) * m),
-                 o_max = w.carve(sizeof(float) * m), o_md = w.carve((size_t)32 * m), o_k = w.carve(sizeof(SeqKp) * (ns ? ns : 1)),
-                 o_b = w.carve((size_t)32 * (ns ? ns : 1)), o_perm = w.carve(sizeof(int) * (ns ? ns : 1)),
-                 o_cell = w.carve(sizeof(int) * sf.cell_off.size()), o_sc = w.carve(sizeof(float) * nlevels);
-    const size_t staged = w.used;
-    const size_t o_q = w.carve(sizeof(WinQuery) * m), o_o = w.carve(sizeof(int) * 5 * (size_t)m);
-    const size_t o_res = w.used;
-    const size_t o_mk = w.carve(sizeof(int) * n), o_nm = w.carve(sizeof(int)), o_proj = w.carve(sizeof(float) * 4 * m);
-    const size_t res_bytes = w.used - o_res;
-    if (w.reserve(w.used, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
-    memcpy(w.h<char>(o_pos), mp_pos, sizeof(float) * 3 * m); memcpy(w.h<char>(o_nrm), mp_normal, sizeof(float) * 3 * m);
-    memcpy(w.h<char>(o_min), mp_min_dist, sizeof(float) * m); memcpy(w.h<char>(o_max), mp_max_dist, sizeof(float) * m);
-    memcpy(w.h<char>(o_md), mp_desc, (size_t)32 * m);
-    if (ns) {
-        memcpy(w.h<char>(o_k), sf.kp.data(), sizeof(SeqKp) * ns);
-        memcpy(w.h<char>(o_b), sf.desc.data(), (size_t)32 * ns);
-        memcpy(w.h<char>(o_perm), sf.perm.data(), sizeof(int) * ns);
-    }
-    memcpy(w.h<char>(o_cell), sf.cell_off.data(), sizeof(int) * sf.cell_off.size());
-    memcpy(w.h<char>(o_sc), scale_factors, sizeof(float) * nlevels);
-    hipStream_t st = w.st;
-    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
-    ORBX_HIP(hipMemsetAsync(w.d<char>(o_mk), 0xff, sizeof(int) * n, st));
-    ORBX_HIP(hipMemsetAsync(w.d<char>(o_nm), 0, sizeof(int), st));
-    MapCam mc;
-    mc.fx = cam->fx; mc.fy = cam->fy; mc.cx = cam->cx; mc.cy = cam->cy;
-    mc.bminx = cam->min_x; mc.bmaxx = cam->max_x; mc.bminy = cam->min_y; mc.bmaxy = cam->max_y;
-    for (int i = 0; i < 9; ++i) mc.R[i] = Rcw[i];
-    for (int i = 0; i < 3; ++i) mc.t[i] = tcw[i];
-    mc.th = th; mc.nlevels = nlevels;
-    int *ob = w.d<int>(o_o);
-    const dim3 g((m + MT - 1) / MT);
-    hipLaunchKernelGGL(k_map_frustum, g, dim3(MT), 0, st, (const float *)w.d<float>(o_pos), (const float *)w.d<float>(o_nrm),
-                       (const float *)w.d<float>(o_min), (const float *)w.d<float>(o_max), m, mc, (const float *)w.d<float>(o_sc),
-                       w.d<WinQuery>(o_q), w.d<float>(o_proj));
-    hipLaunchKernelGGL(k_win_best, dim3((m + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, st, (const WinQuery *)w.d<WinQuery>(o_q),
-                       (const uint4 *)w.d<uint4>(o_md), m, (const SeqKp *)w.d<SeqKp>(o_k), (const uint4 *)w.d<uint4>(o_b),
-                       (const int *)w.d<int>(o_cell), (const int *)w.d<int>(o_perm), sf.gp, 0, INT_MAX, (const float *)nullptr, 0, ob, ob + m, ob + 2 * m,
-                       ob + 3 * m, ob + 4 * m);
-    hipLaunchKernelGGL(k_reloc_accept, g, dim3(MT), 0, st, (const int *)ob, (const int *)(ob + 4 * m), (const int *)(ob + 2 * m),
-                       (const int *)(ob + m), (const int *)(ob + 3 * m), m, th_reloc, nnratio, w.d<int>(o_mk), w.d<int>(o_nm));
-    ORBX_HIP(hipGetLastError());
-    ORBX_HIP(orbx::stage_out(w.pin, w.dev + o_res, res_bytes, st));
-    ORBX_HIP(hipStreamSynchronize(st));
-    memcpy(matched_mp, w.pin + (o_mk - o_res), sizeof(int) * n);
-    if (nmatches) memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
-    if (proj) memcpy(proj, w.pin + (o_proj - o_res), sizeof(float) * 4 * m);
-    return ORBX_OK;
+    sort_frame(kps, desc, n, nullptr, nullptr, cam->grid_min_x, cam->grid_min_y, cam->grid_max_x, cam->grid_max_y, sf);
+    FrameSrc fs(sf);
+    return search_map_core(fs, n, has_mappoint, mp_pos, mp_normal, mp_min_dist, mp_max_dist, mp_desc, m, Rcw, tcw, cam, scale_factors, nlevels,
+                           th, nnratio, th_reloc, matched_mp, nmatches, proj);
+}
+
+int orbm_frame_search_by_projection_map(const orbm_frame *frame, const uint8_t *has_mappoint, const float *mp_pos, const float *mp_normal,
+                                        const float *mp_min_dist, const float *mp_max_dist, const uint8_t *mp_desc, int m, const double *Rcw,
+                                        const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels, float th,
+                                        float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj)
+{
+    if (!frame || m < 0 || nlevels < 1 || nlevels > 64 || !cam || !Rcw || !tcw || !scale_factors || !matched_mp ||
+        (m && (!mp_pos || !mp_normal || !mp_min_dist || !mp_max_dist || !mp_desc)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    const int n = frame->n;
+    for (int j = 0; j < n; ++j) matched_mp[j] = -1;
+    if (nmatches) *nmatches = 0;
+    if (n == 0 || m == 0) return ORBX_OK;
+    FrameSrc fs(frame);
+    return search_map_core(fs, n, has_mappoint, mp_pos, mp_normal, mp_min_dist, mp_max_dist, mp_desc, m, Rcw, tcw, cam, scale_factors, nlevels,
+                           th, nnratio, th_reloc, matched_mp, nmatches, proj);
 }
 
 int orbm_project_points(int mode, const float *mp_pos, const float *mp_normal, const float *mp_min_distance,
@@ -1497,24 +2110,19 @@ int orbm_search_fuse(const orbm_window_query *queries, const uint8_t *qdesc, int
     SortedFrame sf;
     sort_frame(kps, desc, n, nullptr, uright, min_x, min_y, max_x, max_y, sf);
     if (!uright) for (SeqKp &k : sf.kp) k.uright = -1.0f;
-    const int ns = (int)sf.perm.size();
-    StagedCall sc;
-    const size_t o_q = sc.in(queries, sizeof(WinQuery) * nq), o_a = sc.in(qdesc, (size_t)32 * nq),
-                 o_k = sc.in(sf.kp.data(), sizeof(SeqKp) * ns), o_b = sc.in(sf.desc.data(), (size_t)32 * ns),
-                 o_perm = sc.in(sf.perm.data(), sizeof(int) * ns), o_cell = sc.in(sf.cell_off.data(), sizeof(int) * sf.cell_off.size()),
-                 o_sg = sc.in(inv_level_sigma2, sizeof(float) * (inv_level_sigma2 ? nlevels : 0)), o_o = sc.out(sizeof(int) * 5 * (size_t)nq);
-    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
-    int *ob = sc.d<int>(o_o);
-    hipLaunchKernelGGL(k_win_best, dim3((nq + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, sc.stream(), sc.d<const WinQuery>(o_q),
-                       sc.d<const uint4>(o_a), nq, sc.d<const SeqKp>(o_k), sc.d<const uint4>(o_b), sc.d<const int>(o_cell),
-                       sc.d<const int>(o_perm), sf.gp, uright ? 1 : 0, 256, inv_level_sigma2 ? sc.d<const float>(o_sg) : (const float *)nullptr,
-                       1, ob, ob + nq, ob + 2 * nq, ob + 3 * nq, ob + 4 * nq);
-    ORBX_HIP(hipGetLastError());
-    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
-    const int *r = sc.r<int>(o_o);
-    memcpy(best, r, sizeof(int) * nq);
-    memcpy(idx, r + 4 * nq, sizeof(int) * nq);
-    return ORBX_OK;
+    FrameSrc fs(sf);
+    return search_window_core(fs, queries, qdesc, nq, nullptr, uright ? 1 : 0, 256, inv_level_sigma2, nlevels, 1, best, nullptr, nullptr, nullptr, idx);
+}
+
+int orbm_frame_search_fuse(const orbm_frame *frame, const orbm_window_query *queries, const uint8_t *qdesc, int nq,
+                           const float *inv_level_sigma2, int nlevels, int32_t *best, int32_t *idx)
+{
+    if (!frame || nq < 0 || (nq && (!queries || !qdesc || !best || !idx)) || (inv_level_sigma2 && (nlevels < 1 || nlevels > 16)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    if (nq == 0) return ORBX_OK;
+    FrameSrc fs(frame);
+    return search_window_core(fs, queries, qdesc, nq, nullptr, frame->has_uright, 256, inv_level_sigma2, nlevels, 1, best, nullptr, nullptr, nullptr, idx);
 }
 
 int orbm_search_projection(const orbm_window_query *queries, const uint8_t *qdesc, const float *qangle, const uint8_t *qtakes,
@@ -1527,10 +2135,24 @@ int orbm_search_projection(const orbm_window_query *queries, const uint8_t *qdes
         ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
     SortedFrame sf;
-    sort_frame(kps, desc, n, occupied, uright, min_x, min_y, max_x, max_y, sf);
-    return run_sequential(0, reinterpret_cast<const WinQuery *>(queries), qdesc, qangle, qtakes, nq, sf, n, uright ? 1 : 0,
+    sort_frame(kps, desc, n, nullptr, uright, min_x, min_y, max_x, max_y, sf);
+    FrameSrc fs(sf);
+    return run_sequential(0, reinterpret_cast<const WinQuery *>(queries), nullptr, qdesc, qangle, qtakes, nq, fs, n, occupied, uright ? 1 : 0,
                           th_accept, nnratio, ratio_same_level ? ACCEPT_RATIO_SAME_LEVEL : ACCEPT_BEST, check_orientation, match_kp,
                           match_q, nmatches);
+}
+
+int orbm_frame_search_projection(const orbm_frame *frame, const orbm_window_query *queries, const uint8_t *qdesc, const float *qangle,
+                                 const uint8_t *qtakes, int nq, const uint8_t *occupied, int th_accept, float nnratio, int ratio_same_level,
+                                 int check_orientation, int32_t *match_kp, int32_t *match_q, int *nmatches)
+{
+    if (!frame || nq < 0 || (nq && (!queries || !qdesc || !match_q)) || (frame->n && !match_kp) || !nmatches || (check_orientation && nq && !qangle))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    FrameSrc fs(frame);
+    return run_sequential(0, reinterpret_cast<const WinQuery *>(queries), nullptr, qdesc, qangle, qtakes, nq, fs, frame->n, occupied,
+                          frame->has_uright, th_accept, nnratio, ratio_same_level ? ACCEPT_RATIO_SAME_LEVEL : ACCEPT_BEST, check_orientation,
+                          match_kp, match_q, nmatches);
 }
 
 int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *desc1, int n1, const orbx_keypoint *kps2,
@@ -1544,19 +2166,25 @@ int orbm_search_for_initialization(const orbx_keypoint *kps1, const uint8_t *des
     ORBX_NEED_DEVICE();
     SortedFrame sf;
     sort_frame(kps2, desc2, n2, nullptr, nullptr, min_x, min_y, max_x, max_y, sf);
-    // queries: level-0 keypoints of F1 around their previous match (:619-626); others get an empty window
-    std::vector<WinQuery> q(n1 ? n1 : 1);
-    std::vector<float> ang(n1 ? n1 : 1);
-    for (int i = 0; i < n1; ++i) {
-        const bool use = !(kps1[i].octave > 0);
-        q[i] = {prev_matched[2 * i], prev_matched[2 * i + 1], use ? (float)window_size : -1.0f, 0.f, kps1[i].octave, kps1[i].octave};
-        ang[i] = kps1[i].angle;
-    }
-    std::vector<int32_t> dummy(n2 ? n2 : 1);
-    const int rc = run_sequential(1, q.data(), desc1, ang.data(), nullptr, n1, sf, n2, 0, 45 /* TH_LOW, :38 */, nnratio, 0,
-                                  check_orientation, dummy.data(), matches12, nmatches);
+    FrameSrc fs(sf);
+    const int rc = search_init_core(fs, n2, kps1, desc1, n1, prev_matched, window_size, nnratio, check_orientation, matches12, nmatches);
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < n1; ++i) // :715-718
+        if (matches12[i] >= 0) { prev_matched[2 * i] = kps2[matches12[i]].x; prev_matched[2 * i + 1] = kps2[matches12[i]].y; }
+    return ORBX_OK;
+}
+
+int orbm_frame_search_for_initialization(const orbm_frame *frame2, const orbx_keypoint *kps2, const orbx_keypoint *kps1, const uint8_t *desc1,
+                                         int n1, float *prev_matched, int window_size, float nnratio, int check_orientation,
+                                         int32_t *matches12, int *nmatches)
+{
+    if (!frame2 || n1 < 0 || (frame2->n && !kps2) || (n1 && (!kps1 || !desc1 || !prev_matched || !matches12)) || !nmatches)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    FrameSrc fs(frame2);
+    const int rc = search_init_core(fs, frame2->n, kps1, desc1, n1, prev_matched, window_size, nnratio, check_orientation, matches12, nmatches);
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < n1; ++i)
         if (matches12[i] >= 0) { prev_matched[2 * i] = kps2[matches12[i]].x; prev_matched[2 * i + 1] = kps2[matches12[i]].y; }
     return ORBX_OK;
 }
@@ -1616,13 +2244,154 @@ int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t
     std::vector<float> qa(nq);
     for (int i = 0; i < nq; ++i) { memcpy(&qd[32 * (size_t)i], desc1 + 32 * (size_t)qidx[i], 32); qa[i] = angle1 ? angle1[qidx[i]] : 0.f; }
     std::vector<int32_t> mk(n2), mq(nq);
+    FrameSrc fs(sf);
     // bestDist1 < TH_LOW (:799) == bestDist1 <= TH_LOW - 1
-    const int rc = run_sequential(0, nullptr, qd.data(), qa.data(), nullptr, nq, sf, n2, 0, strict_th ? th - 1 : th, nnratio,
-                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, cand_off.data(), cand_beg.data(), cand.data(),
+    const int rc = run_sequential(0, nullptr, nullptr, qd.data(), qa.data(), nullptr, nq, fs, n2, nullptr, 0, strict_th ? th - 1 : th, nnratio,
+                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, nullptr, cand_off.data(), cand_beg.data(), cand.data(),
                                   (int)cand.size(), disjoint ? seg.data() : nullptr, disjoint ? (int)seg.size() - 1 : 0);
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < nq; ++i) // every accepted query blocks its candidate, so slot mq[i] still names i unless rejected
         if (mq[i] >= 0 && mk[mq[i]] == i) { match12[qidx[i]] = mq[i]; if (match21) match21[mq[i]] = qidx[i]; }
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------- the projection searches as whole functions, on resident frames
+
+int orbm_search_by_projection_last(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const float *Tlw, const orbm_points *last,
+                                   const uint8_t *occupied, float th, int mono, int th_high, int check_orientation, int32_t *match_kp,
+                                   int32_t *match_q, int *nmatches, orbm_window_query *queries_out)
+{
+    if (!cur || bad_view(view) || !Tcw || !Tlw || bad_points(last, false, false, true, view->nlevels) || !nmatches ||
+        (last->n && !match_q) || (cur->n && !match_kp) || (check_orientation && last->n && !last->angle))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    PointsPrefix px;
+    px.pts = last; px.scale = view->scale_factors;
+    form_cam_common(px.cam, view, cur, FORM_LAST, th);
+    float Rlw[9], tlw[3], twc[3], tlc[3];
+    pose_parts(Tcw, px.cam.R, px.cam.t);                    // Rcw, tcw (:1539-1540)
+    pose_parts(Tlw, Rlw, tlw);
+    neg_Rt_t(px.cam.R, px.cam.t, twc);                      // twc = -Rcw.t() * tcw (:1542)
+    gemm3(Rlw, twc, 1.0, tlw, 1.0, tlc);                    // tlc = Rlw * twc + tlw (:1547)
+    px.cam.forward = tlc[2] > view->mb && !mono;            // :1549-1550
+    px.cam.backward = -tlc[2] > view->mb && !mono;
+    FrameSrc fs(cur);
+    return run_sequential(0, nullptr, &px, last->desc, last->angle, last->takes, last->n, fs, cur->n, occupied, cur->has_uright, th_high, 0.f,
+                          ACCEPT_BEST, check_orientation, match_kp, match_q, nmatches, reinterpret_cast<WinQuery *>(queries_out));
+}
+
+int orbm_search_by_projection_keyframe(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const orbm_points *kf,
+                                       const uint8_t *occupied, float th, int orb_dist, int check_orientation, int32_t *match_kp,
+                                       int32_t *match_q, int *nmatches, orbm_window_query *queries_out)
+{
+    if (!cur || bad_view(view) || !Tcw || bad_points(kf, true, false, false, view->nlevels) || !nmatches || (kf->n && !match_q) ||
+        (cur->n && !match_kp) || (check_orientation && kf->n && !kf->angle))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    PointsPrefix px;
+    px.pts = kf; px.scale = view->scale_factors;
+    form_cam_common(px.cam, view, cur, FORM_KF, th);
+    pose_parts(Tcw, px.cam.R, px.cam.t);
+    neg_Rt_t(px.cam.R, px.cam.t, px.cam.Ow);                // Ow = -Rcw.t() * tcw (:1679)
+    FrameSrc fs(cur);
+    // no stereo test in this form, every assignment blocks its slot (:1741-1742)
+    return run_sequential(0, nullptr, &px, kf->desc, kf->angle, nullptr, kf->n, fs, cur->n, occupied, 0, orb_dist, 0.f, ACCEPT_BEST,
+                          check_orientation, match_kp, match_q, nmatches, reinterpret_cast<WinQuery *>(queries_out));
+}
+
+int orbm_search_by_projection_sim3(const orbm_frame *kf, const orbm_view *view, const float *Scw, const orbm_points *points,
+                                   const uint8_t *occupied, int th, int th_low, int32_t *match_kp, int32_t *match_q, int *nmatches,
+                                   orbm_window_query *queries_out)
+{
+    if (!kf || bad_view(view) || !Scw || bad_points(points, true, true, false, view->nlevels) || !nmatches || (points->n && !match_q) ||
+        (kf->n && !match_kp))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    PointsPrefix px;
+    px.pts = points; px.scale = view->scale_factors;
+    form_cam_common(px.cam, view, kf, FORM_SIM3, (float)th);
+    {   // :499-504: sRcw, scw = sqrt(sRcw.row(0).dot(sRcw.row(0))), Rcw = sRcw / scw, tcw = Scw.col(3) / scw, Ow = -Rcw.t() * tcw
+        float sR[9], st[3];
+        pose_parts(Scw, sR, st);
+        double dot = 0;
+        for (int k = 0; k < 3; ++k) dot += (double)sR[k] * (double)sR[k];
+        const float scw = (float)sqrt(dot);
+        scale_mat(sR, 9, 1. / scw, px.cam.R);
+        scale_mat(st, 3, 1. / scw, px.cam.t);
+        neg_Rt_t(px.cam.R, px.cam.t, px.cam.Ow);
+    }
+    FrameSrc fs(kf);
+    return run_sequential(0, nullptr, &px, points->desc, nullptr, nullptr, points->n, fs, kf->n, occupied, 0, th_low, 0.f, ACCEPT_BEST, 0,
+                          match_kp, match_q, nmatches, reinterpret_cast<WinQuery *>(queries_out));
+}
+
+int orbm_search_by_sim3(const orbm_frame *kf1, const orbm_frame *kf2, const orbm_view *view, const float *T1w, const float *T2w, float s12,
+                        const float *R12, const float *t12, const orbm_points *points1, const orbm_points *points2, float th, int th_high,
+                        int32_t *vnMatch1, int32_t *vnMatch2, int32_t *match12, int *nfound, orbm_window_query *q12_out,
+                        orbm_window_query *q21_out)
+{
+    if (!kf1 || !kf2 || bad_view(view) || !T1w || !T2w || !R12 || !t12 || bad_points(points1, true, false, false, view->nlevels) ||
+        bad_points(points2, true, false, false, view->nlevels) || !nfound || points1->n != kf1->n || points2->n != kf2->n ||
+        (kf1->n && !match12))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    const int n1 = kf1->n, n2 = kf2->n;
+    for (int i = 0; i < n1; ++i) { match12[i] = -1; if (vnMatch1) vnMatch1[i] = -1; }
+    for (int i = 0; i < n2 && vnMatch2; ++i) vnMatch2[i] = -1;
+    *nfound = 0;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    PointsPrefix p12, p21;
+    p12.pts = points1; p21.pts = points2; p12.scale = p21.scale = view->scale_factors;
+    form_cam_common(p12.cam, view, kf2, FORM_PAIR, th);       // KF1's points into KF2 (:1348-1428)
+    form_cam_common(p21.cam, view, kf1, FORM_PAIR, th);       // and back (:1430-1507)
+    pose_parts(T1w, p12.cam.R, p12.cam.t);
+    pose_parts(T2w, p21.cam.R, p21.cam.t);
+    {   // :1320-1323: sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t(), t21 = -sR21 * t12
+        float R12t[9];
+        scale_mat(R12, 9, (double)s12, p21.cam.R2);
+        memcpy(p21.cam.t2, t12, sizeof(float) * 3);
+        transpose3(R12, R12t);
+        scale_mat(R12t, 9, 1.0 / (double)s12, p12.cam.R2);
+        gemm3(p12.cam.R2, t12, -1.0, nullptr, 0.0, p12.cam.t2);
+    }
+    WorkspaceLease lease;
+    Workspace &w = *lease.w;
+    w.used = 0;
+    p12.carve(w); p21.carve(w);
+    const size_t o_a1 = w.carve((size_t)32 * n1), o_a2 = w.carve((size_t)32 * n2);
+    const size_t staged = w.used;
+    const size_t o_q12 = w.carve(sizeof(WinQuery) * n1), o_q21 = w.carve(sizeof(WinQuery) * n2), o_b1 = w.carve(sizeof(int) * 5 * (size_t)n1),
+                 o_b2 = w.carve(sizeof(int) * 5 * (size_t)n2);
+    const size_t o_res = w.used;
+    const size_t o_v1 = w.carve(sizeof(int) * n1), o_v2 = w.carve(sizeof(int) * n2), o_m = w.carve(sizeof(int) * n1), o_nf = w.carve(sizeof(int));
+    const size_t o_qo1 = w.carve(q12_out ? sizeof(WinQuery) * n1 : 1), o_qo2 = w.carve(q21_out ? sizeof(WinQuery) * n2 : 1);
+    const size_t res_bytes = w.used - o_res;
+    if (w.reserve(w.used, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    p12.fill(w); p21.fill(w);
+    memcpy(w.h<char>(o_a1), points1->desc, (size_t)32 * n1);
+    memcpy(w.h<char>(o_a2), points2->desc, (size_t)32 * n2);
+    hipStream_t st = w.st;
+    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
+    ORBX_HIP(hipMemsetAsync(w.d<char>(o_nf), 0, sizeof(int), st));
+    p12.launch(w, w.d<WinQuery>(o_q12), st);
+    p21.launch(w, w.d<WinQuery>(o_q21), st);
+    FrameSrc f1(kf1), f2(kf2);
+    int *b1 = w.d<int>(o_b1), *b2 = w.d<int>(o_b2);
+    launch_win_best(st, w.d<WinQuery>(o_q12), w.d<uint4>(o_a1), n1, f2.view(w), nullptr, 0, INT_MAX, nullptr, 0, b1);
+    launch_win_best(st, w.d<WinQuery>(o_q21), w.d<uint4>(o_a2), n2, f1.view(w), nullptr, 0, INT_MAX, nullptr, 0, b2);
+    hipLaunchKernelGGL(k_sim3_agree, dim3((std::max(n1, n2) + MT - 1) / MT), dim3(MT), 0, st, (const int *)b1, (const int *)(b1 + 4 * n1), n1,
+                       (const int *)b2, (const int *)(b2 + 4 * n2), n2, th_high, w.d<int>(o_v1), w.d<int>(o_v2), w.d<int>(o_m), w.d<int>(o_nf));
+    ORBX_HIP(hipGetLastError());
+    if (q12_out) ORBX_HIP(hipMemcpyAsync(w.d<char>(o_qo1), w.d<char>(o_q12), sizeof(WinQuery) * n1, hipMemcpyDeviceToDevice, st));
+    if (q21_out) ORBX_HIP(hipMemcpyAsync(w.d<char>(o_qo2), w.d<char>(o_q21), sizeof(WinQuery) * n2, hipMemcpyDeviceToDevice, st));
+    ORBX_HIP(orbx::stage_out(w.pin, w.dev + o_res, res_bytes, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    if (vnMatch1) memcpy(vnMatch1, w.pin + (o_v1 - o_res), sizeof(int) * n1);
+    if (vnMatch2) memcpy(vnMatch2, w.pin + (o_v2 - o_res), sizeof(int) * n2);
+    memcpy(match12, w.pin + (o_m - o_res), sizeof(int) * n1);
+    memcpy(nfound, w.pin + (o_nf - o_res), sizeof(int));
+    if (q12_out) memcpy(q12_out, w.pin + (o_qo1 - o_res), sizeof(WinQuery) * n1);
+    if (q21_out) memcpy(q21_out, w.pin + (o_qo2 - o_res), sizeof(WinQuery) * n2);
     return ORBX_OK;
 }
 

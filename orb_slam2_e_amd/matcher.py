@@ -380,3 +380,187 @@ class ORBmatcher:
         best = np.zeros(len(o) - 1, np.int32)
         check(L.orbm_distinctive_descriptors(_p(d), _p(o), len(o) - 1, _p(best)))
         return best
+
+    # ---------------------------------------------------------------- searches on a resident frame (orbm_frame)
+    def frame_search_window(self, frame, queries, qdesc, skip=None, init_dist=256):
+        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+        nq = len(q)
+        outs = [np.zeros(nq, np.int32) for _ in range(5)]
+        sk = np.ascontiguousarray(skip, np.uint8) if skip is not None else None
+        self._L.orbm_frame_search_window.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        check(self._L.orbm_frame_search_window(frame._h, _p(q), _p(qd), nq, _p(sk) if sk is not None else None, int(init_dist),
+                                               *[_p(o) for o in outs]))
+        return tuple(outs)
+
+    def frame_search_fuse(self, frame, queries, qdesc, inv_level_sigma2=None):
+        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+        sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if inv_level_sigma2 is not None else None
+        best = np.zeros(len(q), np.int32); idx = np.zeros(len(q), np.int32)
+        self._L.orbm_frame_search_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        check(self._L.orbm_frame_search_fuse(frame._h, _p(q), _p(qd), len(q), _p(sg) if sg is not None else None,
+                                             len(sg) if sg is not None else 0, _p(best), _p(idx)))
+        return best, idx
+
+    def frame_search_projection(self, frame, queries, qdesc, qangle, qtakes, occupied=None, th_accept=None, ratio_same_level=False):
+        """orbm_search_projection on a resident frame -> (match_kp, match_q, nmatches)."""
+        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+        qa = np.ascontiguousarray(qangle, np.float32) if qangle is not None else None
+        qt = np.ascontiguousarray(qtakes, np.uint8) if qtakes is not None else None
+        oc = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else None
+        nq = len(q)
+        mk = np.zeros(max(frame.n, 1), np.int32); mq = np.zeros(nq, np.int32); nm = C.c_int(0)
+        opt = lambda a: _p(a) if a is not None else None
+        self._L.orbm_frame_search_projection.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int] + \
+                                                        [C.c_void_p] * 3
+        check(self._L.orbm_frame_search_projection(frame._h, _p(q), _p(qd), opt(qa), opt(qt), nq, opt(oc),
+                                                   self.TH_HIGH if th_accept is None else int(th_accept), C.c_float(self.mfNNratio),
+                                                   int(ratio_same_level), int(self.mbCheckOrientation), _p(mk), _p(mq), C.byref(nm)))
+        return mk[:frame.n], mq, nm.value
+
+    def frame_search_for_initialization(self, frame2, kps2, kps1, desc1, vbPrevMatched, windowSize=10):
+        k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2); d1 = np.ascontiguousarray(desc1, np.uint8)
+        pv = np.array(vbPrevMatched, np.float32, copy=True).reshape(-1, 2)
+        m12 = np.zeros(len(k1), np.int32); nm = C.c_int(0)
+        self._L.orbm_frame_search_for_initialization.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                                                                    C.c_void_p, C.c_void_p]
+        check(self._L.orbm_frame_search_for_initialization(frame2._h, _p(k2), _p(k1), _p(d1), len(k1), _p(pv), int(windowSize),
+                                                           C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
+        return m12, pv, nm.value
+
+    def frame_search_by_projection_map(self, frame, has_mp, mp_pos, mp_normal, mp_min_dist, mp_max_dist, mp_desc, Rcw, tcw, cam,
+                                       scale_factors, th=1.0):
+        hm = np.ascontiguousarray(has_mp, np.uint8)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, nrm, mn, mx = f32(mp_pos), f32(mp_normal), f32(mp_min_dist), f32(mp_max_dist)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        R = np.ascontiguousarray(Rcw, np.float64).reshape(9); t = np.ascontiguousarray(tcw, np.float64).reshape(3)
+        cam = np.ascontiguousarray(cam, self.CAM_DTYPE).reshape(1)
+        sc = f32(scale_factors)
+        m = len(pos)
+        matched = np.zeros(max(frame.n, 1), np.int32); proj = np.zeros((m, 4), np.float32); nm = C.c_int(0)
+        self._L.orbm_frame_search_by_projection_map.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + \
+                                                               [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 3
+        check(self._L.orbm_frame_search_by_projection_map(frame._h, _p(hm), _p(pos), _p(nrm), _p(mn), _p(mx), _p(md), m, _p(R), _p(t),
+                                                          _p(cam), _p(sc), len(sc), th, C.c_float(self.mfNNratio), self.TH_RELOC,
+                                                          _p(matched), C.byref(nm), _p(proj)))
+        return matched[:frame.n], nm.value, proj
+
+    # ---------------------------------------------------------------- the projection searches as whole functions
+    def SearchByProjectionLast(self, cur, view, Tcw, Tlw, last, occupied, th, bMono, want_queries=False):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1529-1671) in one call: cur = resident
+        current frame, view = View(...), last = Points(valid, pos, desc, takes, octave, angle) per keypoint of the last frame,
+        occupied[j] = mvpMapPoints[j] holds an observed point.  Returns (match_kp, match_q, nmatches[, queries])."""
+        return self._whole(self._L.orbm_search_by_projection_last, cur, view, [Tcw, Tlw], last, occupied,
+                           [C.c_float(th), int(bool(bMono)), self.TH_HIGH, int(self.mbCheckOrientation)], want_queries)
+
+    def SearchByProjectionKeyFrame(self, cur, view, Tcw, kf, occupied, th, ORBdist, want_queries=False):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1673-1800)."""
+        return self._whole(self._L.orbm_search_by_projection_keyframe, cur, view, [Tcw], kf, occupied,
+                           [C.c_float(th), int(ORBdist), int(self.mbCheckOrientation)], want_queries)
+
+    def SearchByProjectionSim3(self, kf, view, Scw, points, occupied, th, want_queries=False):
+        """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:491-604)."""
+        return self._whole(self._L.orbm_search_by_projection_sim3, kf, view, [Scw], points, occupied, [int(th), self.TH_LOW], want_queries)
+
+    def _whole(self, fn, frame, view, poses, pts, occupied, scalars, want_queries):
+        mats = [np.ascontiguousarray(T, np.float32).reshape(16) for T in poses]
+        oc = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else None
+        mk = np.zeros(max(frame.n, 1), np.int32); mq = np.zeros(max(pts.n, 1), np.int32); nm = C.c_int(0)
+        q = np.zeros(max(pts.n, 1), self.WQ_DTYPE) if want_queries else None
+        fn.argtypes = None
+        check(fn(frame._h, C.byref(view.c), *[_p(m) for m in mats], C.byref(pts.c), _p(oc) if oc is not None else None, *scalars,
+                 _p(mk), _p(mq), C.byref(nm), _p(q) if q is not None else None))
+        out = (mk[:frame.n], mq[:pts.n], nm.value)
+        return out + (q[:pts.n],) if want_queries else out
+
+    def SearchBySim3Whole(self, kf1, kf2, view, T1w, T2w, s12, R12, t12, points1, points2, th, want_queries=False):
+        """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1303-1527) in one call.  Returns (match12, nFound, vnMatch1, vnMatch2[, q12, q21])."""
+        f32 = lambda a, k: np.ascontiguousarray(a, np.float32).reshape(k)
+        T1, T2, R, t = f32(T1w, 16), f32(T2w, 16), f32(R12, 9), f32(t12, 3)
+        n1, n2 = kf1.n, kf2.n
+        v1 = np.zeros(max(n1, 1), np.int32); v2 = np.zeros(max(n2, 1), np.int32); m12 = np.zeros(max(n1, 1), np.int32); nf = C.c_int(0)
+        q12 = np.zeros(max(n1, 1), self.WQ_DTYPE) if want_queries else None; q21 = np.zeros(max(n2, 1), self.WQ_DTYPE) if want_queries else None
+        fn = self._L.orbm_search_by_sim3
+        fn.argtypes = None
+        check(fn(kf1._h, kf2._h, C.byref(view.c), _p(T1), _p(T2), C.c_float(s12), _p(R), _p(t), C.byref(points1.c), C.byref(points2.c),
+                 C.c_float(th), self.TH_HIGH, _p(v1), _p(v2), _p(m12), C.byref(nf), _p(q12) if want_queries else None,
+                 _p(q21) if want_queries else None))
+        out = (m12[:n1], nf.value, v1[:n1], v2[:n2])
+        return out + (q12[:n1], q21[:n2]) if want_queries else out
+
+
+class _CPoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("valid", C.c_void_p), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_distance", C.c_void_p),
+                ("max_distance", C.c_void_p), ("desc", C.c_void_p), ("takes", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
+
+
+class _CView(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mb", C.c_float), ("mbf", C.c_float),
+                ("log_scale_factor", C.c_float), ("nlevels", C.c_int32), ("scale_factors", C.c_void_p)]
+
+
+class Points:
+    """orbm_points: the flat form of a vector<MapPoint*> (see include/orbslam_hip.h)."""
+
+    def __init__(self, valid, pos, desc, normal=None, min_distance=None, max_distance=None, takes=None, octave=None, angle=None):
+        f32 = lambda a: np.ascontiguousarray(a, np.float32) if a is not None else None
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8) if a is not None else None
+        self._keep = dict(valid=u8(valid), pos=f32(pos), normal=f32(normal), min_distance=f32(min_distance),
+                          max_distance=f32(max_distance), desc=u8(desc), takes=u8(takes),
+                          octave=np.ascontiguousarray(octave, np.int32) if octave is not None else None, angle=f32(angle))
+        self.n = len(self._keep["valid"])
+        self.c = _CPoints(self.n, *[(_p(self._keep[k]) if self._keep[k] is not None else None)
+                                    for k in ("valid", "pos", "normal", "min_distance", "max_distance", "desc", "takes", "octave", "angle")])
+
+
+class View:
+    """orbm_view: calibration and scale pyramid of the searched frame."""
+
+    def __init__(self, fx, fy, cx, cy, mb, mbf, log_scale_factor, scale_factors):
+        self._sc = np.ascontiguousarray(scale_factors, np.float32)
+        self.c = _CView(fx, fy, cx, cy, mb, mbf, log_scale_factor, len(self._sc), _p(self._sc))
+
+
+class Frame:
+    """orbm_frame: a Frame / KeyFrame resident in HBM (grid built once, on the device)."""
+
+    def __init__(self, kps=None, desc=None, bounds=(0.0, 0.0, 640.0, 480.0), uright=None, _handle=None):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.bounds = tuple(float(b) for b in bounds)
+        if _handle is not None:
+            self._h = _handle
+        else:
+            k = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
+            ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+            self._L.orbm_frame_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                  C.c_void_p]
+            check(self._L.orbm_frame_create(_p(k), _p(d), len(k), _p(ur) if ur is not None else None, *self.bounds, C.byref(self._h)))
+        n = C.c_int(0); ns = C.c_int(0)
+        check(self._L.orbm_frame_size(self._h, C.byref(n), C.byref(ns)))
+        self.n, self.ns = n.value, ns.value
+
+    @classmethod
+    def from_extractor(cls, ex, frame=0, bounds=(0.0, 0.0, 640.0, 480.0), xy_undistorted=None, uright=None, uright_from_stereo=False):
+        L = lib()
+        h = C.c_void_p()
+        xy = np.ascontiguousarray(xy_undistorted, np.float32) if xy_undistorted is not None else None
+        ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
+        L.orbm_frame_from_extractor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                C.c_float, C.c_void_p]
+        check(L.orbm_frame_from_extractor(ex._h, int(frame), _p(xy) if xy is not None else None, _p(ur) if ur is not None else None,
+                                          int(bool(uright_from_stereo)), *[float(b) for b in bounds], C.byref(h)))
+        return cls(bounds=bounds, _handle=h)
+
+    def layout(self):
+        perm = np.zeros(max(self.ns, 1), np.int32); cell_off = np.zeros(64 * 48 + 1, np.int32)
+        check(self._L.orbm_frame_layout(self._h, _p(perm), _p(cell_off)))
+        return perm[:self.ns], cell_off
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbm_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

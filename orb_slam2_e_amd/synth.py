@@ -274,3 +274,120 @@ def synth_bow_case(seed, n1=2000, n2=2100, nnodes=90):
     valid1 = (rng.random(n1) < 0.8).astype(np.uint8); valid2 = (rng.random(n2) < 0.85).astype(np.uint8)
     keep1 = rng.random(n1) < 0.97; keep2 = rng.random(n2) < 0.97                   # stop words never enter the FeatureVector
     return d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2
+
+
+# ---- scenes for the projection searches as whole functions (ORBmatcher.cc:491-604, :1303-1527, :1529-1800) ----------
+
+SCENE_CAM = dict(fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, mbf=40.0)   # TUM1-like pinhole, 640 x 480
+
+
+def _rot(rng, deg):
+    """Small random rotation (Rodrigues), float64."""
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    a = np.deg2rad(deg) * rng.uniform(0.3, 1.0)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+
+def _pose(R, t):
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+def synth_view_frame(rng, T, pts, mp_desc, n, nlevels=8, scale=1.2, stereo=False, noise=1.5, flip=0.04, mp_angle=None, turn=(0.0,)):
+    """A frame that sees the map: n keypoints, most of them noisy projections of map points (descriptor = the point's with
+    a few bits flipped), the rest clutter.  Returns (kps, desc, uright or None, src = map point behind each keypoint or -1)."""
+    from .extractor import KP_DTYPE
+    c = SCENE_CAM
+    Pc = pts @ T[:3, :3].T.astype(np.float64) + T[:3, 3].astype(np.float64)
+    z = Pc[:, 2]
+    u = c["fx"] * Pc[:, 0] / z + c["cx"]; v = c["fy"] * Pc[:, 1] / z + c["cy"]
+    vis = np.nonzero((z > 0.3) & (u > -20) & (u < 660) & (v > -20) & (v < 500))[0]
+    nsee = min(len(vis), int(0.8 * n))
+    src = np.full(n, -1, np.int64)
+    src[:nsee] = rng.choice(vis, nsee, replace=len(vis) < nsee)
+    rng.shuffle(src)
+    kps = np.zeros(n, KP_DTYPE)
+    seen = src >= 0
+    kps["x"] = np.where(seen, u[src] + rng.normal(0, noise, n), rng.uniform(-5, 645, n))
+    kps["y"] = np.where(seen, v[src] + rng.normal(0, noise, n), rng.uniform(-5, 485, n))
+    lvl = np.clip(np.round(np.log(np.clip(8.0 / np.maximum(z[src], 0.3), 1e-3, None)) / np.log(scale) + rng.normal(0, 0.8, n)), 0, nlevels - 1)
+    kps["octave"] = np.where(seen, lvl, rng.integers(0, nlevels, n)).astype(np.int32)
+    kps["angle"] = rng.uniform(0, 360, n)
+    if mp_angle is not None:     # a seen point's keypoint: the point's own angle turned by one of a few common amounts
+        kps["angle"] = np.where(seen, (mp_angle[src] + rng.choice(turn, n) + rng.normal(0, 2, n)) % 360, kps["angle"])
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    fl = np.packbits(rng.random((n, 256)) < flip, axis=1, bitorder="little")
+    desc[seen] = mp_desc[src[seen]] ^ fl[seen]
+    ur = None
+    if stereo:
+        ur = np.where(seen & (rng.random(n) < 0.7), kps["x"] - c["mbf"] / np.maximum(z[src], 0.3) + rng.normal(0, 0.7, n), -1.0).astype(np.float32)
+    return kps, desc, ur, src
+
+
+def synth_tracking_scene(seed, n=2000, nmp=2500, stereo=False, motion="none", nlevels=8, scale=1.2):
+    """One scene for the four whole-function searches.  Returns a dict:
+    cam (fx, fy, cx, cy), mb, mbf, bounds, scale_factors, log_scale_factor;
+    map: pos, normal, mind, maxd, desc (nmp points, a fifth of them near-duplicates of others so that list entries compete
+    for the same keypoint; some behind the camera, out of range or seen from behind);
+    cur: Tcw, kps, desc, uright, src; last: Tlw + per-keypoint arrays (valid, mp index, takes, octave, angle);
+    kf2: a second view (T2w, kps, desc, src) for the key-frame forms; Scw / (s12, R12, t12) for the Sim3 forms."""
+    rng = np.random.default_rng(seed)
+    c = SCENE_CAM
+    sf = (scale ** np.arange(nlevels)).astype(np.float32)
+    for i in range(1, nlevels):
+        sf[i] = np.float32(sf[i - 1] * np.float32(scale))
+    mb = np.float32(c["mbf"]) / np.float32(c["fx"])
+    Rcw = _rot(rng, 8); tcw = rng.normal(0, 0.3, 3)
+    Tcw = _pose(Rcw, tcw)
+    # map points: a slab in front of the current camera, plus outliers
+    Pc = np.stack([rng.uniform(-0.68, 0.68, nmp), rng.uniform(-0.52, 0.52, nmp), np.ones(nmp)], 1) * rng.uniform(0.8, 12, (nmp, 1))
+    far = rng.random(nmp) < 0.08
+    Pc[far] *= [2.5, 2.5, 1.0]                             # outside the image
+    Pc[rng.random(nmp) < 0.05, 2] *= -1                    # behind the camera
+    Pc[rng.integers(0, nmp)] = [0.3, -0.2, 0.0]            # z = 0: the projection divides by zero
+    dup = rng.choice(nmp, nmp // 5, replace=False)
+    Pc[dup] = Pc[rng.integers(0, nmp, len(dup))] + rng.normal(0, 0.01, (len(dup), 3))
+    pos = ((Pc - tcw) @ Rcw).astype(np.float32)            # world = Rcw^T (Pc - tcw)
+    Ow = -Rcw.T @ tcw
+    dvec = pos.astype(np.float64) - Ow
+    dist = np.linalg.norm(dvec, axis=1)
+    lvl0 = rng.integers(0, nlevels, nmp)
+    maxd = (dist * rng.uniform(0.6, 1.6, nmp) * sf[lvl0]).astype(np.float32)
+    mind = (maxd / sf[nlevels - 1]).astype(np.float32)
+    nrm = dvec / np.maximum(dist[:, None], 1e-6) + rng.normal(0, 0.5, (nmp, 3))     # mean viewing direction, camera -> point
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    mp_desc = rng.integers(0, 256, (nmp, 32), dtype=np.uint8)
+    mp_desc[dup] = mp_desc[rng.integers(0, nmp, len(dup))] ^ np.packbits(rng.random((len(dup), 256)) < 0.02, axis=1, bitorder="little")
+    mp_angle = rng.uniform(0, 360, nmp)
+    kps, desc, ur, src = synth_view_frame(rng, Tcw, pos.astype(np.float64), mp_desc, n, nlevels, scale, stereo, mp_angle=mp_angle)
+    # last frame: the camera a few baselines behind / ahead along z (forward / backward motion), or almost in place
+    dz = {"forward": 3.0, "backward": -3.0, "none": 0.2}[motion] * float(mb)
+    Rlc = _rot(rng, 2)
+    Tlw = _pose(Rlc @ Rcw, Rlc @ tcw + np.array([0.0, 0.0, dz]))
+    nl = n
+    lmp = rng.integers(0, nmp, nl)
+    take = rng.random(nl) < 0.75
+    pick = src[rng.integers(0, n, int(take.sum()))]
+    lmp[take] = np.where(pick >= 0, pick, lmp[take])
+    lval = (rng.random(nl) < 0.8).astype(np.uint8)
+    ltakes = (rng.random(nl) < 0.8).astype(np.uint8)
+    loct = np.clip(lvl0[lmp] + rng.integers(-1, 2, nl), 0, nlevels - 1).astype(np.int32)
+    lang = ((mp_angle[lmp] + rng.choice([12.0, 100.0, 215.0, 320.0], nl, p=[0.6, 0.25, 0.1, 0.05]) + rng.normal(0, 2, nl)) % 360).astype(np.float32)
+    occ = (rng.random(n) < 0.05).astype(np.uint8)
+    # a second key frame looking at the same map from the side, and the similarity between the two
+    R2 = _rot(rng, 10) @ Rcw; t2 = _rot(rng, 5) @ tcw + rng.normal(0, 0.25, 3)
+    T2w = _pose(R2, t2)
+    k2, d2, _, src2 = synth_view_frame(rng, T2w, pos.astype(np.float64), mp_desc, n + 100, nlevels, scale, False, mp_angle=mp_angle,
+                                       turn=(15.0, 15.0, 15.0, 110.0, 110.0, 250.0, 333.0))
+    T12 = Tcw.astype(np.float64) @ np.linalg.inv(T2w.astype(np.float64))
+    s12 = np.float32(rng.uniform(0.9, 1.1))
+    R12 = (T12[:3, :3] @ _rot(rng, 0.5)).astype(np.float32); t12 = (T12[:3, 3] + rng.normal(0, 0.02, 3)).astype(np.float32)
+    sw = np.float32(rng.uniform(0.8, 1.25))
+    Scw = Tcw.copy(); Scw[:3, :] *= sw
+    return dict(cam=(np.float32(c["fx"]), np.float32(c["fy"]), np.float32(c["cx"]), np.float32(c["cy"])), mb=mb, mbf=np.float32(c["mbf"]),
+                bounds=(0.0, 0.0, 640.0, 480.0), scale_factors=sf, log_scale_factor=np.float32(np.log(np.float32(scale))), nlevels=nlevels,
+                pos=pos, normal=nrm, mind=mind, maxd=maxd, mp_desc=mp_desc,
+                Tcw=Tcw, kps=kps, desc=desc, uright=ur, src=src, occupied=occ,
+                Tlw=Tlw, last_mp=lmp, last_valid=lval, last_takes=ltakes, last_octave=loct, last_angle=lang,
+                T2w=T2w, kps2=k2, desc2=d2, src2=src2, s12=s12, R12=R12, t12=t12, Scw=Scw)

@@ -1,0 +1,266 @@
+"""The SearchByProjection forms and SearchBySim3 as whole functions on resident frames (orbm_frame): projection prefix,
+window search, in-loop assignment, acceptance and rotation check in one call, against the literal loop restatements of
+oracle/match_oracle.c (src/ORBmatcher.cc:1529-1671, :1673-1800, :491-604, :1303-1527).  Queries are compared as float bits,
+match arrays as integers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from orb_slam2_e_amd import Frame, ORBextractor, ORBmatcher, Points, View
+from orb_slam2_e_amd.extractor import KP_DTYPE
+from orb_slam2_e_amd.synth import synth_frame, synth_initialization_case, synth_projection_case, synth_tracking_scene
+
+
+def _view(s):
+    return View(*s["cam"], s["mb"], s["mbf"], s["log_scale_factor"], s["scale_factors"])
+
+
+def _same_queries(got, ref):
+    """window queries equal as bits (u, v, r, xr) and integers (levels); skipped entries carry r < 0 on both sides"""
+    skip_g, skip_r = got["r"] < 0, ref["r"] < 0
+    assert np.array_equal(skip_g, skip_r)
+    k = ~skip_r
+    for f in ("u", "v", "r"):
+        assert np.array_equal(got[f][k].view(np.uint32), ref[f][k].view(np.uint32)), f
+    assert np.array_equal(got["min_level"][k], ref["min_level"][k]) and np.array_equal(got["max_level"][k], ref["max_level"][k])
+    return k
+
+
+# --------------------------------------------------------------------------------------------------- the handle itself
+
+@pytest.mark.parametrize("case", ["random", "outside", "one cell", "empty", "single", "8192"])
+def test_frame_layout_equals_host_sort(case):
+    """k_frame_build = Frame::AssignFeaturesToGrid as the host counting sort lays a frame out (orbm_sorted_frame)."""
+    import ctypes as C
+    from orb_slam2_e_amd._lib import lib
+    rng = np.random.default_rng(5)
+    n = {"random": 2000, "outside": 1500, "one cell": 700, "empty": 0, "single": 1, "8192": 8192}[case]
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(0, 640, n); kps["y"] = rng.uniform(0, 480, n)
+    if case == "outside":
+        kps["x"] = rng.uniform(-80, 720, n); kps["y"] = rng.uniform(-60, 540, n)
+    if case == "one cell":
+        kps["x"] = rng.uniform(100, 104, n); kps["y"] = rng.uniform(100, 104, n)
+    kps["octave"] = rng.integers(0, 8, n); kps["angle"] = rng.uniform(0, 360, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    f = Frame(kps, desc, bounds)
+    perm, cell_off = f.layout()
+    L = lib()
+    rp = np.zeros(max(n, 1), np.int32); rc = np.zeros(64 * 48 + 1, np.int32); ns = C.c_int(0)
+    L.orbm_sorted_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.orbm_sorted_frame(kps.ctypes.data_as(C.c_void_p), n, None, None, *bounds, rp.ctypes.data_as(C.c_void_p),
+                               rc.ctypes.data_as(C.c_void_p), C.byref(ns)) == 0
+    assert f.n == n and f.ns == ns.value
+    assert np.array_equal(perm, rp[:ns.value]) and np.array_equal(cell_off, rc)
+    f.close()
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_handle_searches_equal_host_array_searches(stereo, resolver):
+    """Every search that takes host arrays gives the same result through a resident frame."""
+    q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(3, n=2000, nq=2500, hot=600, stereo=stereo)
+    m = ORBmatcher(0.7, True)
+    f = Frame(kps, desc, bounds, ur)
+    for same_level in (False, True):
+        a = m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, ratio_same_level=same_level)
+        b = m.frame_search_projection(f, q, qd, qa, takes, occ, 95, ratio_same_level=same_level)
+        r = oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.7, same_level, True)
+        for x, y, z in zip(a, b, r):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+    a = m.search_window(q, qd, kps, desc, bounds, occ, ur)
+    b = m.frame_search_window(f, q, qd, occ)
+    r = oracle.search_window(q, qd, kps, desc, bounds, occ, ur)
+    for x, y, z in zip(a, b, r):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    sg = (1.0 / (1.2 ** np.arange(8)) ** 2).astype(np.float32)
+    a = m.search_fuse(q, qd, kps, desc, bounds, ur, sg)
+    b = m.frame_search_fuse(f, q, qd, sg)
+    r = oracle.search_fuse(q, qd, kps, desc, bounds, ur, sg)
+    for x, y, z in zip(a, b, r):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    f.close()
+
+
+def test_handle_search_for_initialization():
+    k1, d1, k2, d2, prev, bounds = synth_initialization_case(1)
+    m = ORBmatcher(0.9, True)
+    f2 = Frame(k2, d2, bounds)
+    a = m.SearchForInitialization(k1, d1, k2, d2, prev, bounds, 100)
+    b = m.frame_search_for_initialization(f2, k2, k1, d1, prev, 100)
+    r = oracle.search_for_initialization(k1, d1, k2, d2, prev, bounds, 100, 0.9, True)
+    for x, y, z in zip(a, b, r):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    f2.close()
+
+
+# ------------------------------------------------------------------------------------------- the four whole functions
+
+@pytest.mark.parametrize("motion", ["none", "forward", "backward"])
+@pytest.mark.parametrize("stereo", [False, True])
+def test_search_by_projection_last_frame(stereo, motion, resolver):
+    """SearchByProjection(CurrentFrame, LastFrame, th, bMono) at 2000 entries x 2000 keypoints, mono / stereo, the three
+    level-range branches (forward / backward / neither; a mono call never takes the first two)."""
+    s = synth_tracking_scene(11 + 2 * stereo, stereo=stereo, motion=motion)
+    lm = s["last_mp"]
+    m = ORBmatcher(0.9, True)
+    cur = Frame(s["kps"], s["desc"], s["bounds"], s["uright"])
+    last = Points(s["last_valid"], s["pos"][lm], s["mp_desc"][lm], takes=s["last_takes"], octave=s["last_octave"], angle=s["last_angle"])
+    for th, mono in ((7.0, not stereo), (15.0, not stereo), (7.0, True)):
+        fwd, bwd = oracle.motion_direction(s["Tcw"], s["Tlw"], s["mb"], mono)
+        assert (fwd, bwd) == ((motion == "forward") and not mono, (motion == "backward") and not mono)
+        ref = oracle.search_by_projection_last(s["kps"], s["desc"], s["uright"], s["occupied"], s["bounds"], s["cam"], s["mb"], s["mbf"],
+                                               s["Tcw"], s["scale_factors"], s["Tlw"], s["last_valid"], s["pos"][lm], s["mp_desc"][lm],
+                                               s["last_takes"], s["last_octave"], s["last_angle"], th, mono)
+        got = m.SearchByProjectionLast(cur, _view(s), s["Tcw"], s["Tlw"], last, s["occupied"], th, mono, want_queries=True)
+        k = _same_queries(got[3], ref[3])
+        assert np.array_equal(got[3]["xr"][k].view(np.uint32), ref[3]["xr"][k].view(np.uint32))
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+        assert ref[2] > 100 and (ref[0] == -2).any() and k.sum() > 1000
+    cur.close()
+
+
+def test_search_by_projection_last_without_query_output_and_empty_inputs():
+    s = synth_tracking_scene(5)
+    lm = s["last_mp"]
+    m = ORBmatcher(0.9, False)
+    cur = Frame(s["kps"], s["desc"], s["bounds"])
+    last = Points(s["last_valid"], s["pos"][lm], s["mp_desc"][lm], takes=s["last_takes"], octave=s["last_octave"], angle=s["last_angle"])
+    ref = oracle.search_by_projection_last(s["kps"], s["desc"], None, None, s["bounds"], s["cam"], s["mb"], s["mbf"], s["Tcw"],
+                                           s["scale_factors"], s["Tlw"], s["last_valid"], s["pos"][lm], s["mp_desc"][lm], s["last_takes"],
+                                           s["last_octave"], s["last_angle"], 7.0, True, check_orientation=False)
+    got = m.SearchByProjectionLast(cur, _view(s), s["Tcw"], s["Tlw"], last, None, 7.0, True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    # nothing valid: no matches, every slot untouched
+    none = Points(np.zeros(len(lm), np.uint8), s["pos"][lm], s["mp_desc"][lm], takes=s["last_takes"], octave=s["last_octave"], angle=s["last_angle"])
+    got = m.SearchByProjectionLast(cur, _view(s), s["Tcw"], s["Tlw"], none, None, 7.0, True)
+    assert got[2] == 0 and (got[0] == -1).all() and (got[1] == -1).all()
+    # an empty frame
+    e = Frame(np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8), s["bounds"])
+    got = m.SearchByProjectionLast(e, _view(s), s["Tcw"], s["Tlw"], last, None, 7.0, True, want_queries=True)
+    assert got[2] == 0 and len(got[0]) == 0 and (got[1] == -1).all()
+    ref = oracle.search_by_projection_last(np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8), None, None, s["bounds"], s["cam"], s["mb"],
+                                           s["mbf"], s["Tcw"], s["scale_factors"], s["Tlw"], s["last_valid"], s["pos"][lm], s["mp_desc"][lm],
+                                           s["last_takes"], s["last_octave"], s["last_angle"], 7.0, True)
+    _same_queries(got[3], ref[3])
+    e.close(); cur.close()
+
+
+@pytest.mark.parametrize("seed", [2, 9])
+def test_search_by_projection_keyframe(seed, resolver):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): no depth test, levels l-1 .. l+1, every match blocks."""
+    s = synth_tracking_scene(seed, stereo=True)          # the frame has right coordinates: this form must ignore them
+    rng = np.random.default_rng(seed)
+    valid = ((rng.random(len(s["kps2"])) < 0.8) & (s["src2"] >= 0)).astype(np.uint8)
+    mp = np.maximum(s["src2"], 0)
+    # entries without a map point still carry data (never read); a few valid entries behind the camera
+    m = ORBmatcher(0.9, True)
+    cur = Frame(s["kps"], s["desc"], s["bounds"], s["uright"])
+    kf = Points(valid, s["pos"][mp], s["mp_desc"][mp], min_distance=s["mind"][mp], max_distance=s["maxd"][mp], angle=s["kps2"]["angle"])
+    occ = (s["occupied"] | (rng.random(len(s["kps"])) < 0.1)).astype(np.uint8)
+    for th, dist in ((10.0, 100), (3.0, 64)):
+        ref = oracle.search_by_projection_kf(s["kps"], s["desc"], occ, s["bounds"], s["cam"], s["Tcw"], s["scale_factors"],
+                                             s["log_scale_factor"], valid, s["pos"][mp], s["mind"][mp], s["maxd"][mp], s["mp_desc"][mp],
+                                             s["kps2"]["angle"], th, dist)
+        got = m.SearchByProjectionKeyFrame(cur, _view(s), s["Tcw"], kf, occ, th, dist, want_queries=True)
+        _same_queries(got[3], ref[3])
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    assert ref[2] > 30
+    cur.close()
+
+
+@pytest.mark.parametrize("seed", [2, 4])
+def test_search_by_projection_sim3(seed, resolver):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): Sim3 decomposition, viewing-angle test, levels l-1 .. l."""
+    s = synth_tracking_scene(seed)
+    rng = np.random.default_rng(seed)
+    npnt = len(s["pos"])
+    valid = (rng.random(npnt) < 0.9).astype(np.uint8)
+    occ = (rng.random(len(s["kps"])) < 0.15).astype(np.uint8)
+    m = ORBmatcher(0.75, True)
+    kf = Frame(s["kps"], s["desc"], s["bounds"])
+    pts = Points(valid, s["pos"], s["mp_desc"], normal=s["normal"], min_distance=s["mind"], max_distance=s["maxd"])
+    for th in (10, 3):
+        ref = oracle.search_by_projection_sim3(s["kps"], s["desc"], occ, s["bounds"], s["cam"], s["Scw"], s["scale_factors"],
+                                               s["log_scale_factor"], valid, s["pos"], s["normal"], s["mind"], s["maxd"], s["mp_desc"], th)
+        got = m.SearchByProjectionSim3(kf, _view(s), s["Scw"], pts, occ, th, want_queries=True)
+        _same_queries(got[3], ref[3])
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    assert ref[2] > 20
+    kf.close()
+
+
+@pytest.mark.parametrize("seed", [2, 6])
+def test_search_by_sim3_whole(seed):
+    """SearchBySim3 with both projection passes on the device."""
+    s = synth_tracking_scene(seed)
+    rng = np.random.default_rng(seed)
+    v1 = ((s["src"] >= 0) & (rng.random(len(s["kps"])) < 0.85)).astype(np.uint8); mp1 = np.maximum(s["src"], 0)
+    v2 = ((s["src2"] >= 0) & (rng.random(len(s["kps2"])) < 0.85)).astype(np.uint8); mp2 = np.maximum(s["src2"], 0)
+    m = ORBmatcher(0.75, True)
+    k1 = Frame(s["kps"], s["desc"], s["bounds"]); k2 = Frame(s["kps2"], s["desc2"], s["bounds"])
+    p1 = Points(v1, s["pos"][mp1], s["mp_desc"][mp1], min_distance=s["mind"][mp1], max_distance=s["maxd"][mp1])
+    p2 = Points(v2, s["pos"][mp2], s["mp_desc"][mp2], min_distance=s["mind"][mp2], max_distance=s["maxd"][mp2])
+    ref = oracle.search_by_sim3_whole(s["kps"], s["desc"], s["kps2"], s["desc2"], s["bounds"], s["cam"], s["scale_factors"],
+                                      s["log_scale_factor"], s["Tcw"], s["T2w"], s["s12"], s["R12"], s["t12"], v1, s["pos"][mp1],
+                                      s["mind"][mp1], s["maxd"][mp1], s["mp_desc"][mp1], v2, s["pos"][mp2], s["mind"][mp2],
+                                      s["maxd"][mp2], s["mp_desc"][mp2], 7.5)
+    got = m.SearchBySim3Whole(k1, k2, _view(s), s["Tcw"], s["T2w"], s["s12"], s["R12"], s["t12"], p1, p2, 7.5, want_queries=True)
+    _same_queries(got[4], ref[4]); _same_queries(got[5], ref[5])
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and ref[1] > 20
+    k1.close(); k2.close()
+
+
+# -------------------------------------------------------------------------------- extractor -> resident frame -> searches
+
+def test_track_with_motion_model_sequence_uploads_the_frame_once():
+    """The shape of Tracking::TrackWithMotionModel (src/Tracking.cc): extract, then SearchByProjection(Cur, Last, th), again with
+    2 th, on ONE resident frame made straight from the extractor's device results -- against the same calls on host arrays."""
+    prm = (1000, 1.2, 8, 20, 7)
+    ex = ORBextractor(*prm)
+    kps, desc = ex(synth_frame(3))
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    f = Frame.from_extractor(ex, 0, bounds)
+    g = Frame(kps, desc, bounds)
+    assert f.n == len(kps) == g.n and f.ns == g.ns
+    pf, cf = f.layout(); pg, cg = g.layout()
+    assert np.array_equal(pf, pg) and np.array_equal(cf, cg)
+    # a scene whose current frame is this extraction: map points behind the keypoints
+    s = synth_tracking_scene(21, n=len(kps))
+    rng = np.random.default_rng(0)
+    nl = len(kps)
+    # last-frame entries aim at the real keypoints: place each point on the ray of a keypoint
+    src = rng.integers(0, len(kps), nl)
+    fx, fy, cx, cy = [np.float64(v) for v in s["cam"]]
+    z = rng.uniform(1, 8, nl)
+    Pc = np.stack([(kps["x"][src] + rng.normal(0, 1.5, nl) - cx) / fx * z, (kps["y"][src] + rng.normal(0, 1.5, nl) - cy) / fy * z, z], 1)
+    R = s["Tcw"][:3, :3].astype(np.float64); t = s["Tcw"][:3, 3].astype(np.float64)
+    pos = ((Pc - t) @ R).astype(np.float32)
+    mpd = desc[src] ^ np.packbits(rng.random((nl, 256)) < 0.04, axis=1, bitorder="little")
+    valid = (rng.random(nl) < 0.85).astype(np.uint8); takes = (rng.random(nl) < 0.8).astype(np.uint8)
+    loct = kps["octave"][src].astype(np.int32); lang = ((kps["angle"][src] + 20.0) % 360).astype(np.float32)
+    last = Points(valid, pos, mpd, takes=takes, octave=loct, angle=lang)
+    m = ORBmatcher(0.9, True)
+    for th in (7.0, 14.0):
+        ref = oracle.search_by_projection_last(kps, desc, None, None, bounds, s["cam"], s["mb"], s["mbf"], s["Tcw"], s["scale_factors"],
+                                               s["Tlw"], valid, pos, mpd, takes, loct, lang, th, True)
+        for fr in (f, g):
+            got = m.SearchByProjectionLast(fr, _view(s), s["Tcw"], s["Tlw"], last, None, th, True)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+        assert ref[2] > 200
+    # undistorted coordinates beside the extractor's keypoints (a camera with distortion: mvKeysUn != mvKeys)
+    xy = np.stack([kps["x"] + 0.37, kps["y"] - 0.21], 1).astype(np.float32)
+    ku = kps.copy(); ku["x"] = xy[:, 0]; ku["y"] = xy[:, 1]
+    fu = Frame.from_extractor(ex, 0, bounds, xy_undistorted=xy)
+    gu = Frame(ku, desc, bounds)
+    assert np.array_equal(fu.layout()[0], gu.layout()[0])
+    ref = oracle.search_by_projection_last(ku, desc, None, None, bounds, s["cam"], s["mb"], s["mbf"], s["Tcw"], s["scale_factors"],
+                                           s["Tlw"], valid, pos, mpd, takes, loct, lang, 7.0, True)
+    got = m.SearchByProjectionLast(fu, _view(s), s["Tcw"], s["Tlw"], last, None, 7.0, True)
+    assert np.array_equal(got[0], ref[0]) and got[2] == ref[2]
+    for fr in (f, g, fu, gu):
+        fr.close()
