@@ -361,10 +361,30 @@ def matcher_loops_bench():
     from orb_slam2_e_amd.synth import synth_initialization_case
     ik1, id1, ik2, id2, iprev, ibounds = synth_initialization_case(0)
     mi = ORBmatcher(0.9, True)
-    return {"search_for_initialization_2000x2200_ms": ms(lambda: mi.SearchForInitialization(ik1, id1, ik2, id2, iprev, ibounds, 100), 30),
-            "search_by_projection_2000x2000_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
-            "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
-            "search_window_2000x2000_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
+    # the same searches on a frame that stays in HBM between calls (orbm_frame: grid built once per frame, on the device), and
+    # the per-frame call of Tracking::TrackWithMotionModel as ONE whole function (projection prefix + search + resolver)
+    from orb_slam2_e_amd import Frame, Points, View
+    from orb_slam2_e_amd.synth import synth_tracking_scene
+    fr = Frame(kps, desc, bounds, ur)
+    sc = synth_tracking_scene(11)
+    lm = sc["last_mp"]
+    cur = Frame(sc["kps"], sc["desc"], sc["bounds"])
+    view = View(*sc["cam"], sc["mb"], sc["mbf"], sc["log_scale_factor"], sc["scale_factors"])
+    last = Points(sc["last_valid"], sc["pos"][lm], sc["mp_desc"][lm], takes=sc["last_takes"], octave=sc["last_octave"], angle=sc["last_angle"])
+    npnt = len(sc["pos"])
+    pts = Points(np.ones(npnt, np.uint8), sc["pos"], sc["mp_desc"], normal=sc["normal"], min_distance=sc["mind"], max_distance=sc["maxd"],
+                 takes=np.ones(npnt, np.uint8))
+    out = {"search_for_initialization_2000x2200_ms": ms(lambda: mi.SearchForInitialization(ik1, id1, ik2, id2, iprev, ibounds, 100), 30),
+           "search_by_projection_2000x2000_ms": ms(lambda: m.frame_search_projection(fr, q, qd, qa, takes, occ, 95), 100),
+           "search_by_projection_2000x2000_host_arrays_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
+           "search_by_projection_last_frame_whole_2000x2000_ms": ms(lambda: m.SearchByProjectionLast(cur, view, sc["Tcw"], sc["Tlw"], last, sc["occupied"], 7.0, True), 100),
+           "search_local_points_whole_2500x2000_ms": ms(lambda: m.SearchByProjectionPoints(cur, view, sc["Tcw"], pts, sc["occupied"], 1.0), 100),
+           "frame_create_2000_ms": ms(lambda: Frame(kps, desc, bounds, ur).close(), 50),
+           "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
+           "search_window_2000x2000_ms": ms(lambda: m.frame_search_window(fr, q, qd, occ), 100),
+           "search_window_2000x2000_host_arrays_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
+    fr.close(); cur.close()
+    return out
 
 
 def stereo_bench():

@@ -414,6 +414,12 @@ int orbm_frame_create(const orbx_keypoint *kps, const uint8_t *desc, int n, cons
 int orbm_frame_from_extractor(orbx_extractor *ex, int frame, const float *xy_undistorted, const float *uright, int uright_from_stereo,
                               float min_x, float min_y, float max_x, float max_y, orbm_frame **out);
 int orbm_frame_destroy(orbm_frame *frame);
+/* A second handle on the same device data whose SEARCHES use other bounds: a KeyFrame keeps the Frame's grid (mGrid and
+ * mfGridElementWidthInv / HeightInv are copied, src/KeyFrame.cc:36) but stores mnMinX .. mnMaxY as int (include/KeyFrame.h:201-204), and
+ * KeyFrame::GetFeaturesInArea / IsInImage (src/KeyFrame.cc:613-657) compute with those -- on a camera with distortion the Frame's
+ * bounds are fractional and the two differ.  The KeyFrame made from a Frame takes orbm_frame_alias(frame, (int)mnMinX, ...); no copy,
+ * no device work; either handle may be destroyed first. */
+int orbm_frame_alias(const orbm_frame *frame, float min_x, float min_y, float max_x, float max_y, orbm_frame **out);
 /* n = keypoints, nsorted = those inside the grid */
 int orbm_frame_size(const orbm_frame *frame, int *n, int *nsorted);
 /* introspection (tests): the device-built order as orbm_sorted_frame returns it: perm[nsorted], cell_off[64 * 48 + 1] */
@@ -468,6 +474,16 @@ typedef struct orbm_view {
     int32_t nlevels;
     const float *scale_factors;
 } orbm_view;
+/* Tracking::SearchLocalPoints' data plane (src/Tracking.cc): Frame::isInFrustum(pMP, viewing_cos_limit = 0.5) for every listed
+ * point (src/Frame.cc:284-340, with MapPoint::PredictScale) chained into SearchByProjection(Frame &F, const vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:46-132: RadiusByViewingCos, levels [l-1, l], stereo test, best / second with levels, <= th_high = TH_HIGH,
+ * ratio test on equal levels).  valid[i] = the point is not bad and was not already matched in this frame (mnLastFrameSeen);
+ * takes[i] = Observations() > 0; occupied[j] = mvpMapPoints[j] holds an observed point (:87-89).  projected_out (optional) =
+ * what isInFrustum leaves in the MapPoint (mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos) for the
+ * caller's IncreaseVisible bookkeeping. */
+int orbm_search_by_projection_points(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const orbm_points *points,
+                                     const uint8_t *occupied, float th, float viewing_cos_limit, int th_high, float nnratio, int32_t *match_kp,
+                                     int32_t *match_q, int *nmatches, orbm_projected_point *projected_out, orbm_window_query *queries_out);
 /* SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)   src/ORBmatcher.cc:1529-1671
  * (th_high = TH_HIGH).  THE per-frame matcher call of Tracking::TrackWithMotionModel. */
 int orbm_search_by_projection_last(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const float *Tlw, const orbm_points *last,

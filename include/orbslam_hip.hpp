@@ -430,6 +430,128 @@ public:
         return nFound;
     }
 
+    // ---- resident frames and the projection searches as whole functions ----------------------------------------------------
+    // A Frame / KeyFrame kept in HBM between searches (orbm_frame): Frame::AssignFeaturesToGrid runs once, on the device.
+    // Holds no reference to the arrays it was made from.  Movable, not copyable; any number of searches may read it at once.
+    class ResidentFrame {
+    public:
+        ResidentFrame() = default;
+        explicit ResidentFrame(const FrameView &F) { mStatus = orbm_frame_create(F.mvKeysUn, F.mDescriptors, F.N, F.mvuRight, F.mnMinX, F.mnMinY, F.mnMaxX, F.mnMaxY, &mH); sync(); }
+        // straight from the extractor's device results (no trip over PCIe): xyUndistorted = mvKeysUn coordinates (x0, y0, ...) or
+        // null when the camera has no distortion; uRight from the host or from the last ComputeStereoMatches on `ex`
+        ResidentFrame(ORBextractor &ex, const float *xyUndistorted, const float *uRight, bool uRightFromStereo, float mnMinX, float mnMinY,
+                      float mnMaxX, float mnMaxY)
+        {
+            mStatus = orbm_frame_from_extractor(ex.handle(), 0, xyUndistorted, uRight, uRightFromStereo, mnMinX, mnMinY, mnMaxX, mnMaxY, &mH);
+            sync();
+        }
+        ResidentFrame(ResidentFrame &&o) noexcept : mH(o.mH), N(o.N), mStatus(o.mStatus) { o.mH = nullptr; }
+        ResidentFrame &operator=(ResidentFrame &&o) noexcept { if (this != &o) { reset(); mH = o.mH; N = o.N; mStatus = o.mStatus; o.mH = nullptr; } return *this; }
+        ResidentFrame(const ResidentFrame &) = delete;
+        ResidentFrame &operator=(const ResidentFrame &) = delete;
+        ~ResidentFrame() { reset(); }
+        void reset() { if (mH) orbm_frame_destroy(mH); mH = nullptr; }
+        const orbm_frame *handle() const { return mH; }
+        int status() const { return mStatus; }
+        int N = 0;
+    private:
+        void sync() { if (mStatus == ORBX_OK) orbm_frame_size(mH, &N, nullptr); else mH = nullptr; }
+        orbm_frame *mH = nullptr;
+        int mStatus = ORBX_OK;
+    };
+    // The flat form of a vector<MapPoint*> (orbm_points; see include/orbslam_hip.h for which form reads what): the binding fills it
+    // in one pass over the pointer vector.
+    struct PointList {
+        std::vector<uint8_t> valid, desc, takes;
+        std::vector<float> pos, normal, minDistance, maxDistance, angle;
+        std::vector<int32_t> octave;
+        void resize(size_t n, bool withRange, bool withNormal, bool withOctave)
+        {
+            valid.assign(n, 0); desc.resize(32 * n); takes.assign(n, 1); pos.resize(3 * n); angle.assign(n, 0.f);
+            if (withRange) { minDistance.resize(n); maxDistance.resize(n); }
+            if (withNormal) normal.resize(3 * n);
+            if (withOctave) octave.assign(n, 0);
+        }
+        orbm_points view() const
+        {
+            orbm_points p;
+            p.n = (int32_t)valid.size(); p.valid = valid.data(); p.pos = pos.data(); p.normal = normal.empty() ? nullptr : normal.data();
+            p.min_distance = minDistance.empty() ? nullptr : minDistance.data(); p.max_distance = maxDistance.empty() ? nullptr : maxDistance.data();
+            p.desc = desc.data(); p.takes = takes.empty() ? nullptr : takes.data(); p.octave = octave.empty() ? nullptr : octave.data();
+            p.angle = angle.empty() ? nullptr : angle.data();
+            return p;
+        }
+    };
+    // Calibration + scale pyramid of the searched frame (Frame::fx .. mbf, mfLogScaleFactor, mvScaleFactors).
+    struct Calibration {
+        float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0, mfLogScaleFactor = 0;
+        std::vector<float> mvScaleFactors;
+        orbm_view view() const { return orbm_view{fx, fy, cx, cy, mb, mbf, mfLogScaleFactor, (int32_t)mvScaleFactors.size(), mvScaleFactors.data()}; }
+    };
+    // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) (ORBmatcher.cc:1529-1671),
+    // whole.  Tcw / Tlw = mTcw of the two frames (4 x 4, row-major).  slotOwner[j] = entry of `last` whose point ends in
+    // CurrentFrame.mvpMapPoints[j] (-1 untouched, -2 set to NULL by the rotation check); returns nmatches.
+    int SearchByProjection(const ResidentFrame &Cur, const Calibration &K, const float *Tcw, const float *Tlw, const PointList &last,
+                           const std::vector<uint8_t> &occupied, float th, bool bMono, std::vector<int32_t> &slotOwner)
+    {
+        const orbm_points p = last.view(); const orbm_view v = K.view();
+        slotOwner.assign(Cur.N, -1); mScratch.resize(p.n);
+        int nm = 0;
+        mStatus = orbm_search_by_projection_last(Cur.handle(), &v, Tcw, Tlw, &p, occupied.empty() ? nullptr : occupied.data(), th, bMono, TH_HIGH,
+                                                 mbCheckOrientation, slotOwner.data(), mScratch.data(), &nm, nullptr);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+    // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist) (:1673-1800), whole.
+    int SearchByProjection(const ResidentFrame &Cur, const Calibration &K, const float *Tcw, const PointList &kf,
+                           const std::vector<uint8_t> &occupied, float th, int ORBdist, std::vector<int32_t> &slotOwner)
+    {
+        const orbm_points p = kf.view(); const orbm_view v = K.view();
+        slotOwner.assign(Cur.N, -1); mScratch.resize(p.n);
+        int nm = 0;
+        mStatus = orbm_search_by_projection_keyframe(Cur.handle(), &v, Tcw, &p, occupied.empty() ? nullptr : occupied.data(), th, ORBdist,
+                                                     mbCheckOrientation, slotOwner.data(), mScratch.data(), &nm, nullptr);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+    // SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+    // (:491-604), whole.  slotOwner[j] = list entry written to vpMatched[j] or -1.
+    int SearchByProjection(const ResidentFrame &KF, const Calibration &K, const float *Scw, const PointList &points,
+                           const std::vector<uint8_t> &occupied, int th, std::vector<int32_t> &slotOwner)
+    {
+        const orbm_points p = points.view(); const orbm_view v = K.view();
+        slotOwner.assign(KF.N, -1); mScratch.resize(p.n);
+        int nm = 0;
+        mStatus = orbm_search_by_projection_sim3(KF.handle(), &v, Scw, &p, occupied.empty() ? nullptr : occupied.data(), th, TH_LOW,
+                                                 slotOwner.data(), mScratch.data(), &nm, nullptr);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+    // Tracking::SearchLocalPoints' data plane: isInFrustum for every listed point + SearchByProjection(Frame&, vector<MapPoint*>&, th)
+    // (:46-132), whole.  projected[i] = what isInFrustum leaves in the MapPoint.
+    int SearchLocalPoints(const ResidentFrame &Cur, const Calibration &K, const float *Tcw, const PointList &points,
+                          const std::vector<uint8_t> &occupied, float th, std::vector<int32_t> &slotOwner,
+                          std::vector<orbm_projected_point> *projected = nullptr)
+    {
+        const orbm_points p = points.view(); const orbm_view v = K.view();
+        slotOwner.assign(Cur.N, -1); mScratch.resize(p.n);
+        if (projected) projected->resize(p.n);
+        int nm = 0;
+        mStatus = orbm_search_by_projection_points(Cur.handle(), &v, Tcw, &p, occupied.empty() ? nullptr : occupied.data(), th, 0.5f, TH_HIGH,
+                                                   mfNNratio, slotOwner.data(), mScratch.data(), &nm, projected ? projected->data() : nullptr, nullptr);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+    // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (:1303-1527), whole: vnMatches12[i1] = idx2 where both directions
+    // agree (the entries of vpMatches12 the reference overwrites), else -1; returns nFound.
+    int SearchBySim3(const ResidentFrame &KF1, const ResidentFrame &KF2, const Calibration &K, const float *T1w, const float *T2w, float s12,
+                     const float *R12, const float *t12, const PointList &points1, const PointList &points2, float th,
+                     std::vector<int32_t> &vnMatches12)
+    {
+        const orbm_points p1 = points1.view(), p2 = points2.view(); const orbm_view v = K.view();
+        vnMatches12.assign(KF1.N, -1);
+        int nf = 0;
+        mStatus = orbm_search_by_sim3(KF1.handle(), KF2.handle(), &v, T1w, T2w, s12, R12, t12, &p1, &p2, th, TH_HIGH, nullptr, nullptr,
+                                      vnMatches12.data(), &nf, nullptr, nullptr);
+        return mStatus == ORBX_OK ? nf : 0;
+    }
+
     // DBoW2::FeatureVector flattened in std::map order.
     struct FeatureVector {
         std::vector<int32_t> nodes, off, items;
@@ -578,6 +700,7 @@ protected:
     float mfNNratio;
     bool mbCheckOrientation;
     int mStatus = ORBX_OK;
+    std::vector<int32_t> mScratch;     // per-entry output of the whole-function searches (not re-entrant per OBJECT; instances are stack-local, as in the reference)
 };
 
 // ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:31) as the

@@ -825,7 +825,7 @@ def search_by_projection_kf(kps, desc, occupied, bounds, cam4, Tcw, scale_factor
 
 
 def search_by_projection_sim3(kps, desc, occupied, bounds, cam4, Scw, scale_factors, log_scale_factor, valid, pos, normal,
-                              min_distance, max_distance, mp_desc, th, th_low=45):
+                              min_distance, max_distance, mp_desc, th, th_low=45, kf_bounds=None):
     """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), ORBmatcher.cc:491-604, literally."""
     L = lib()
     xy, octv, _, d = _frame_arrays(kps, desc)
@@ -835,15 +835,16 @@ def search_by_projection_sim3(kps, desc, occupied, bounds, cam4, Scw, scale_fact
     npt = len(va)
     mk = np.zeros(len(xy), np.int32); mq = np.zeros(npt, np.int32); q = np.zeros(npt, WQ_DTYPE)
     L.oracle_search_by_projection_sim3.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_int] + \
-        [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 3
+        [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+    kb = _f32(kf_bounds) if kf_bounds is not None else None
     nm = L.oracle_search_by_projection_sim3(_p(xy), _p(octv), _p(d), len(xy), _opt(oc), _p(b4), _p(c4), _p(S), _p(sc), len(sc),
                                             float(log_scale_factor), npt, _p(va), _p(ps), _p(nr), _p(mn), _p(mx), _p(md), int(th),
-                                            int(th_low), _p(mk), _p(mq), _p(q))
+                                            int(th_low), _p(mk), _p(mq), _p(q), _opt(kb))
     return mk, mq, nm, q
 
 
 def search_by_sim3_whole(kps1, desc1, kps2, desc2, bounds, cam4, scale_factors, log_scale_factor, T1w, T2w, s12, R12, t12,
-                         valid1, pos1, mind1, maxd1, mp_desc1, valid2, pos2, mind2, maxd2, mp_desc2, th, th_high=95):
+                         valid1, pos1, mind1, maxd1, mp_desc1, valid2, pos2, mind2, maxd2, mp_desc2, th, th_high=95, kf_bounds=None):
     """ORBmatcher::SearchBySim3, ORBmatcher.cc:1303-1527, literally (projections included).
     Returns (match12, nFound, vnMatch1, vnMatch2, q12, q21)."""
     L = lib()
@@ -856,9 +857,10 @@ def search_by_sim3_whole(kps1, desc1, kps2, desc2, bounds, cam4, scale_factors, 
     vn1 = np.zeros(n1, np.int32); vn2 = np.zeros(n2, np.int32); m12 = np.zeros(n1, np.int32)
     q12 = np.zeros(n1, WQ_DTYPE); q21 = np.zeros(n2, WQ_DTYPE)
     L.oracle_search_by_sim3.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + \
-        [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 12 + [C.c_float, C.c_int] + [C.c_void_p] * 5
+        [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 12 + [C.c_float, C.c_int] + [C.c_void_p] * 6
+    kb = _f32(kf_bounds) if kf_bounds is not None else None
     nf = L.oracle_search_by_sim3(_p(xy1), _p(o1), _p(d1), n1, _p(xy2), _p(o2), _p(d2), n2, _p(b4), _p(c4), _p(sc), len(sc),
                                  float(log_scale_factor), _p(T1), _p(T2), float(s12), _p(R), _p(t), _p(v1), _p(p1), _p(a1), _p(b1),
                                  _p(m1), _p(v2), _p(p2), _p(a2), _p(b2), _p(m2), float(th), int(th_high), _p(vn1), _p(vn2),
-                                 _p(m12), _p(q12), _p(q21))
+                                 _p(m12), _p(q12), _p(q21), _opt(kb))
     return m12, nf, vn1, vn2, q12, q21

@@ -136,6 +136,17 @@ def stereo_leg(args):
             "stereo_frame_ms": all_ms, "compute_stereo_matches_ms": sm_ms}
 
 
+def _whole_last_ms(oracle):
+    """SearchByProjection(CurrentFrame, LastFrame, th, bMono) as the literal loop, projection included (grid build inside, as the
+    reference's Frame constructor pays it once per frame -- timed apart below would flatter the CPU)."""
+    from orb_slam2_e_amd.synth import synth_tracking_scene
+    s = synth_tracking_scene(11)
+    lm = s["last_mp"]
+    return _median_ms(lambda: oracle.search_by_projection_last(s["kps"], s["desc"], None, s["occupied"], s["bounds"], s["cam"], s["mb"], s["mbf"],
+                                                               s["Tcw"], s["scale_factors"], s["Tlw"], s["last_valid"], s["pos"][lm],
+                                                               s["mp_desc"][lm], s["last_takes"], s["last_octave"], s["last_angle"], 7.0, True))
+
+
 def loops_leg(args):
     import oracle
     from orb_slam2_e_amd.synth import synth_bow_case, synth_initialization_case, synth_projection_case
@@ -147,7 +158,8 @@ def loops_leg(args):
     return {"search_for_initialization_2000x2200_ms": _median_ms(lambda: oracle.search_for_initialization(ik1, id1, ik2, id2, iprev, ibounds, 100, 0.9, True)),
             "kind": "port", "cores": 1, "unit": "ms per call", "sample": "the same inputs; " + PROTOCOL,
             "search_by_projection_2000x2000_ms": _median_ms(lambda: oracle.search_projection_seq(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95, 0.6, False, True)),
-            "search_by_bow_2000x2100_ms": _median_ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True))}
+            "search_by_bow_2000x2100_ms": _median_ms(lambda: oracle.search_by_bow(ofv1, valid1, d1, a1, ofv2, None, d2, a2, False, 0.6, True)),
+            "search_by_projection_last_frame_whole_2000x2000_ms": _whole_last_ms(oracle)}
 
 
 def extract_leg(args):

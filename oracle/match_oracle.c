@@ -1149,16 +1149,20 @@ int oracle_search_by_projection_sim3(const float *kxy, const int *koct, const ui
                                      const float *bounds4, const float *cam4, const float *Scw16, const float *scaleFactors,
                                      int nLevels, float logScaleFactor, int np, const uint8_t *valid, const float *pos,
                                      const float *nrm, const float *mfMinDistance, const float *mfMaxDistance, const uint8_t *mp_desc,
-                                     int th, int th_low, int *match_kp, int *match_q, oracle_wquery *qout)
+                                     int th, int th_low, int *match_kp, int *match_q, oracle_wquery *qout, const float *kf_bounds4)
 {
+    /* kf_bounds4 (may be NULL): the KeyFrame's own int-valued mnMinX .. mnMaxY (include/KeyFrame.h:201-204) used by its
+     * GetFeaturesInArea / IsInImage, while mGrid and the cell pitch are the Frame's (bounds4; src/KeyFrame.cc:36,44) */
     const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
-    const float mnMinX = bounds4[0], mnMinY = bounds4[1], mnMaxX = bounds4[2], mnMaxY = bounds4[3];
-    oracle_grid *g = oracle_grid_build(kxy, n, mnMinX, mnMinY, mnMaxX, mnMaxY);
+    const float *kb = kf_bounds4 ? kf_bounds4 : bounds4;
+    const float mnMinX = kb[0], mnMinY = kb[1], mnMaxX = kb[2], mnMaxY = kb[3];
+    oracle_grid *g = oracle_grid_build(kxy, n, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
     int *cand = (int *)malloc(sizeof(int) * (n + 1));
     uint8_t *blocked = (uint8_t *)malloc(n + 1);
     float Rcw[9], tcw[3], Ow[3];
     int iMP, k, nmatches = 0;
     oracle_decompose_sim3(Scw16, Rcw, tcw, Ow);
+    g->minX = mnMinX; g->minY = mnMinY;            /* the queries' arithmetic; cell membership stays as built */
     for (k = 0; k < n; k++) { blocked[k] = occupied ? occupied[k] : 0; match_kp[k] = -1; }
     for (iMP = 0; iMP < np; iMP++) {
         const float *p3Dw = pos + 3 * iMP, *Pn = nrm + 3 * iMP;
@@ -1269,12 +1273,13 @@ int oracle_search_by_sim3(const float *kxy1, const int *koct1, const uint8_t *kd
                           const float *t12, const uint8_t *valid1, const float *pos1, const float *mind1, const float *maxd1,
                           const uint8_t *desc_mp1, const uint8_t *valid2, const float *pos2, const float *mind2, const float *maxd2,
                           const uint8_t *desc_mp2, float th, int th_high, int *vnMatch1, int *vnMatch2, int *match12,
-                          oracle_wquery *q12, oracle_wquery *q21)
+                          oracle_wquery *q12, oracle_wquery *q21, const float *kf_bounds4)
 {
     float R1w[9], t1w[3], R2w[9], t2w[3], sR12[9], R12t[9], sR21[9], t21[3];
     oracle_grid *g1 = oracle_grid_build(kxy1, n1, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
     oracle_grid *g2 = oracle_grid_build(kxy2, n2, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
     int i1, nFound = 0;
+    if (kf_bounds4) { g1->minX = g2->minX = kf_bounds4[0]; g1->minY = g2->minY = kf_bounds4[1]; bounds4 = kf_bounds4; }   /* as in the form above */
     cvm_pose_parts(T1w16, R1w, t1w);
     cvm_pose_parts(T2w16, R2w, t2w);
     cvm_scale(R12, 9, s12, sR12);                 /* sR12 = s12 * R12 */

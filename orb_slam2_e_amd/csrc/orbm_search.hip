@@ -50,18 +50,44 @@ enum { ACCEPT_BEST = 0, ACCEPT_RATIO_SAME_LEVEL = 1, ACCEPT_RATIO = 2 };
 constexpr int TOPK = 8; // best candidates per query kept sorted for the resolver
 
 
+// Minimum over the wave, in every lane: a butterfly inside each row of 16 lanes on the DPP path (no LDS crossbar round trips),
+// then the four row results through scalar registers.  All 64 lanes must be active.
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1, 0, 3, 2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2, 3, 0, 1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
 }
 
 // The TOPK entries of a list with the smallest (distance, position) keys, in that
 // order -- all the sequential resolver normally needs.  Run by the wave that has just written the list
-// (its own stores are visible to it after the workgroup-scope fence).
+// (its own stores are visible to it after the workgroup-scope fence).  Lists of up to 256 entries -- a window's usual few tens --
+// are read ONCE, four entries per lane, and the rounds run on registers (every round used to re-read the list: eight dependent
+// trips to L1 / L2 per query).
 __device__ __forceinline__ void wave_topk(const unsigned *__restrict__ ent, int b, int len, int lane, unsigned *__restrict__ top_i)
 {
+    if (len <= 256) {
+        unsigned key[4], en[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = lane + 64 * r;
+            en[r] = p < len ? ent[b + p] : 0xffffffffu;
+            key[r] = en[r] != 0xffffffffu ? ((en[r] >> 20) << 16) | (unsigned)p : 0xffffffffu;
+        }
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            const unsigned g = wave_min_u32(min(min(key[0], key[1]), min(key[2], key[3])));
+            if (g == 0xffffffffu) { if (lane == 0) top_i[t] = 0xffffffffu; continue; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (key[r] == g) { top_i[t] = en[r]; key[r] = 0xffffffffu; }     // keys are unique: one lane, one slot
+        }
+        return;
+    }
     unsigned prev = 0;
     bool done = false;
     for (int r = 0; r < TOPK; ++r) {
@@ -875,6 +901,22 @@ __global__ __launch_bounds__(MT) void k_win_best(const WinQuery *__restrict__ q,
 // float / double arithmetic (fixed op order, no contraction), producing the
 // GetFeaturesInArea query of :162-163; k_win_best does the search; then the
 // TH_RELOC / same-level ratio acceptance (:205-216) with "last map point wins".
+// The upload of a call's staged inputs (orbx::stage_in: pinned host memory read by the compute queue) folded into the call's first
+// kernel: blocks [0, nblocks) of the launch copy 16 bytes per thread, the others do the kernel's own work and read THEIR inputs --
+// which nothing else needs on the device -- straight from the pinned block.  One launch less per call.
+struct StageJob { const uint4 *src; uint4 *dst; size_t n16; int nblocks; };
+__device__ __forceinline__ bool stage_block(const StageJob &job)
+{
+    if ((int)blockIdx.x >= job.nblocks) return false;
+    const size_t i = (size_t)blockIdx.x * MT + threadIdx.x;
+    if (i < job.n16) job.dst[i] = job.src[i];
+    return true;
+}
+inline StageJob stage_job(void *dev, const void *pin, size_t bytes)
+{
+    return {static_cast<const uint4 *>(pin), static_cast<uint4 *>(dev), bytes / 16, (int)((bytes / 16 + MT - 1) / MT)};
+}
+
 struct MapCam { float fx, fy, cx, cy; int bminx, bmaxx, bminy, bmaxy; double R[9], t[3]; float th; int nlevels; };
 
 __global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ pos, const float *__restrict__ nrm,
@@ -938,12 +980,13 @@ __global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ po
 // rounded float of the double logarithm (what glibc's logf returns except in vanishingly rare cases).
 struct ProjectCam { float fx, fy, cx, cy, min_x, max_x, min_y, max_y, mbf, cos_limit, log_scale, th; float R[9], t[3], Ow[3]; int nlevels, mode; };
 
-__global__ __launch_bounds__(MT) void k_project_points(const float *__restrict__ pos, const float *__restrict__ nrm,
+__global__ __launch_bounds__(MT) void k_project_points(const uint8_t *__restrict__ valid, const float *__restrict__ pos, const float *__restrict__ nrm,
                                                        const float *__restrict__ mind, const float *__restrict__ maxd, int m,
                                                        ProjectCam cam, const float *__restrict__ scale,
-                                                       orbm_projected_point *__restrict__ out, WinQuery *__restrict__ q)
+                                                       orbm_projected_point *__restrict__ out, WinQuery *__restrict__ q, StageJob job)
 {
-    const int i = blockIdx.x * MT + threadIdx.x;
+    if (stage_block(job)) return;
+    const int i = (blockIdx.x - job.nblocks) * MT + threadIdx.x;
     if (i >= m) return;
     orbm_projected_point o = {0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};
     WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
@@ -952,7 +995,7 @@ __global__ __launch_bounds__(MT) void k_project_points(const float *__restrict__
     const float PcX = (float)((double)(R[0] * P0 + R[1] * P1 + R[2] * P2) + (double)cam.t[0]);
     const float PcY = (float)((double)(R[3] * P0 + R[4] * P1 + R[5] * P2) + (double)cam.t[1]);
     const float PcZ = (float)((double)(R[6] * P0 + R[7] * P1 + R[8] * P2) + (double)cam.t[2]);
-    bool ok = !(PcZ < 0.0f);
+    bool ok = !(PcZ < 0.0f) && (!valid || valid[i]);
     float invz, u, v;
     if (cam.mode == 0) {
         invz = 1.0f / PcZ;                                  // Frame.cc:302-304
@@ -1216,9 +1259,10 @@ __device__ __forceinline__ float gemm_row(const float *R, int r, float b0, float
 __global__ __launch_bounds__(MT) void k_project_form(const uint8_t *__restrict__ valid, const float *__restrict__ pos,
                                                      const float *__restrict__ nrm, const float *__restrict__ mind,
                                                      const float *__restrict__ maxd, const int *__restrict__ octave, int m, FormCam cam,
-                                                     const float *__restrict__ scale, WinQuery *__restrict__ q)
+                                                     const float *__restrict__ scale, WinQuery *__restrict__ q, StageJob job)
 {
-    const int i = blockIdx.x * MT + threadIdx.x;
+    if (stage_block(job)) return;
+    const int i = (blockIdx.x - job.nblocks) * MT + threadIdx.x;
     if (i >= m) return;
     WinQuery w = {0.f, 0.f, -1.f, 0.f, 0, -1}; // r < 0: no candidates
     if (valid[i]) {
@@ -1358,9 +1402,10 @@ struct FrameView {
 // Read-only after creation: any number of searches, from any thread, may use it at once.
 struct orbm_frame {
     int n = 0, ns = 0, cap = 0, has_uright = 0;
-    float min_x = 0, min_y = 0, max_x = 0, max_y = 0;
-    GridParams gp = {0.f, 0.f, 0.f, 0.f};
+    float min_x = 0, min_y = 0, max_x = 0, max_y = 0;       // the bounds the SEARCHES use (cell range of a window, image tests)
+    GridParams gp = {0.f, 0.f, 0.f, 0.f};                   // ... with the cell pitch the grid was built with
     char *block = nullptr;
+    std::atomic<int> *refs = nullptr;                       // handles sharing the block (orbm_frame_alias)
     SeqKp *kp = nullptr; uint4 *desc = nullptr; float *angle = nullptr; int *perm = nullptr, *cell_off = nullptr;
     FrameHdr *hdr = nullptr;
     std::vector<int> perm_host;
@@ -1374,6 +1419,18 @@ std::vector<std::pair<int, char *>> g_frame_pool;     // (capacity, block) of de
 size_t frame_block_bytes(int cap)
 {
     return 256 + ((sizeof(SeqKp) + 32 + 4 + 4) * (size_t)cap + 255) / 256 * 256 + sizeof(int) * (FB_NC + 1);
+}
+
+void frame_pointers(orbm_frame *f)
+{
+    const int cap = f->cap;
+    char *p = f->block;
+    f->hdr = reinterpret_cast<FrameHdr *>(p); p += 256;
+    f->desc = reinterpret_cast<uint4 *>(p); p += (size_t)32 * cap;
+    f->kp = reinterpret_cast<SeqKp *>(p); p += sizeof(SeqKp) * (size_t)cap;
+    f->angle = reinterpret_cast<float *>(p); p += sizeof(float) * (size_t)cap;
+    f->perm = reinterpret_cast<int *>(p);
+    f->cell_off = reinterpret_cast<int *>(f->block + frame_block_bytes(cap) - sizeof(int) * (FB_NC + 1));
 }
 
 int frame_alloc(orbm_frame *f, int n)
@@ -1390,23 +1447,21 @@ int frame_alloc(orbm_frame *f, int n)
     }
     if (!f->block && hipMalloc((void **)&f->block, frame_block_bytes(cap)) != hipSuccess) { f->block = nullptr; return -1; }
     f->cap = cap;
-    char *p = f->block;
-    f->hdr = reinterpret_cast<FrameHdr *>(p); p += 256;
-    f->desc = reinterpret_cast<uint4 *>(p); p += (size_t)32 * cap;
-    f->kp = reinterpret_cast<SeqKp *>(p); p += sizeof(SeqKp) * (size_t)cap;
-    f->angle = reinterpret_cast<float *>(p); p += sizeof(float) * (size_t)cap;
-    f->perm = reinterpret_cast<int *>(p);
-    f->cell_off = reinterpret_cast<int *>(f->block + frame_block_bytes(cap) - sizeof(int) * (FB_NC + 1));
+    f->refs = new std::atomic<int>(1);
+    frame_pointers(f);
     return 0;
 }
 
 void frame_release(orbm_frame *f)
 {
-    if (f->block) {
-        std::lock_guard<std::mutex> lk(g_frame_mu);
-        if (g_frame_pool.size() < 64) { g_frame_pool.emplace_back(f->cap, f->block); f->block = nullptr; }
+    if (f->block && f->refs && f->refs->fetch_sub(1) == 1) {      // the last handle on the block
+        delete f->refs;
+        {
+            std::lock_guard<std::mutex> lk(g_frame_mu);
+            if (g_frame_pool.size() < 64) { g_frame_pool.emplace_back(f->cap, f->block); f->block = nullptr; }
+        }
+        if (f->block) (void)hipFree(f->block);
     }
-    if (f->block) (void)hipFree(f->block);
     delete f;
 }
 
@@ -1484,6 +1539,11 @@ struct PointsPrefix {
     const orbm_points *pts = nullptr;
     FormCam cam;
     const float *scale = nullptr;
+    bool frustum = false;        // Frame::isInFrustum + the window of SearchByProjection(Frame&, vector<MapPoint*>&, th): k_project_points, mode 0
+    ProjectCam pcam;
+    orbm_projected_point *proj_host = nullptr;   // optional: the projections back to the caller
+    size_t o_proj = 0;
+    void carve_scratch(Workspace &w) { if (frustum) o_proj = w.carve(sizeof(orbm_projected_point) * (size_t)(pts->n ? pts->n : 1)); }
     size_t o_valid = 0, o_pos = 0, o_nrm = 0, o_min = 0, o_max = 0, o_oct = 0, o_sc = 0;
     void carve(Workspace &w)
     {
@@ -1505,12 +1565,20 @@ struct PointsPrefix {
         if (pts->octave) memcpy(w.h<char>(o_oct), pts->octave, sizeof(int) * m);
         memcpy(w.h<char>(o_sc), scale, sizeof(float) * cam.nlevels);
     }
-    void launch(const Workspace &w, WinQuery *dq, hipStream_t st) const
+    // the prefix's inputs are read where the host staged them (pinned memory); `job` = the call's upload, done by the same launch
+    void launch(const Workspace &w, WinQuery *dq, hipStream_t st, StageJob job = StageJob{nullptr, nullptr, 0, 0}) const
     {
-        if (!pts->n) return;
-        hipLaunchKernelGGL(k_project_form, dim3((pts->n + MT - 1) / MT), dim3(MT), 0, st, (const uint8_t *)w.d<uint8_t>(o_valid),
-                           (const float *)w.d<float>(o_pos), (const float *)w.d<float>(o_nrm), (const float *)w.d<float>(o_min),
-                           (const float *)w.d<float>(o_max), (const int *)w.d<int>(o_oct), pts->n, cam, (const float *)w.d<float>(o_sc), dq);
+        const int nb = (pts->n + MT - 1) / MT + job.nblocks;
+        if (!nb) return;
+        if (frustum) {
+            hipLaunchKernelGGL(k_project_points, dim3(nb), dim3(MT), 0, st, (const uint8_t *)w.h<uint8_t>(o_valid),
+                               (const float *)w.h<float>(o_pos), (const float *)w.h<float>(o_nrm), (const float *)w.h<float>(o_min),
+                               (const float *)w.h<float>(o_max), pts->n, pcam, (const float *)w.h<float>(o_sc), w.d<orbm_projected_point>(o_proj), dq, job);
+            return;
+        }
+        hipLaunchKernelGGL(k_project_form, dim3(nb), dim3(MT), 0, st, (const uint8_t *)w.h<uint8_t>(o_valid),
+                           (const float *)w.h<float>(o_pos), (const float *)w.h<float>(o_nrm), (const float *)w.h<float>(o_min),
+                           (const float *)w.h<float>(o_max), (const int *)w.h<int>(o_oct), pts->n, cam, (const float *)w.h<float>(o_sc), dq, job);
     }
 };
 
@@ -1531,7 +1599,7 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
     *nmatches = 0;
     const bool windows = queries || prefix;
     if (queries_out) for (int i = 0; i < nq; ++i) queries_out[i] = {0.f, 0.f, -1.f, 0.f, 0, -1};
-    if (nq == 0 || (ns == 0 && !queries_out)) return ORBX_OK;
+    if (nq == 0 || (ns == 0 && !queries_out && !(prefix && prefix->proj_host))) return ORBX_OK;
     const size_t lds = sizeof(int) * (3 * (size_t)ns + (mode == 1 ? nq : 0)) + 16;
     if (lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_CAPACITY, "resolver state exceeds LDS");
     if (mode != 0) { seg = nullptr; nseg = 0; }
@@ -1571,8 +1639,10 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
                      o_off = w.carve(sizeof(int) * (nq + 1)),
                      o_cbeg = w.carve(sizeof(int) * (size_t)nq), o_cand = w.carve(sizeof(int) * (size_t)(ncand ? ncand : 1)),
                      o_seg = w.carve(sizeof(int) * (size_t)(nseg + 1));
-        if (prefix) prefix->carve(w);
         const size_t staged = w.used;
+        if (prefix) prefix->carve(w);              // read by the prefix kernel where they are staged: not part of the upload
+        const size_t pin_in = w.used;
+        if (prefix) prefix->carve_scratch(w);
         const size_t o_qd = w.carve(queries ? 1 : sizeof(WinQuery) * nq);
         const size_t o_q = queries ? o_qh : o_qd;
         const size_t o_top = w.carve(sizeof(unsigned) * TOPK * (size_t)nq), o_cnt = w.carve(sizeof(int) * nq), o_acc = w.carve(sizeof(int) * nq),
@@ -1581,7 +1651,11 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
         const size_t o_res = w.used;
         const size_t o_mq = w.carve(sizeof(int) * nq), o_mk = w.carve(sizeof(int) * (size_t)(n ? n : 1)), o_nm = w.carve(4 * sizeof(int));
         const size_t total_bytes = w.used, res_bytes = total_bytes - o_res;
-        if (w.reserve(total_bytes, std::max(staged, res_bytes) + (queries_out ? sizeof(WinQuery) * nq + 256 : 0))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        // optional outputs that are not part of the result block travel through the tail of the pinned arena
+        const size_t tq_bytes = queries_out ? (sizeof(WinQuery) * nq + 255) & ~(size_t)255 : 0;
+        const size_t tp_bytes = prefix && prefix->frustum && prefix->proj_host ? (sizeof(orbm_projected_point) * (size_t)nq + 255) & ~(size_t)255 : 0;
+        if (w.reserve(total_bytes, std::max(pin_in, res_bytes) + tq_bytes + tp_bytes)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+        char *tq_pin = w.pin + w.pin_cap - tq_bytes, *tp_pin = tq_pin - tp_bytes;
         if (w.reserve_entries(ent_need)) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
         hipStream_t st = w.st;
 
@@ -1598,7 +1672,8 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
         }
         if (seg) memcpy(w.h<char>(o_seg), seg, sizeof(int) * (size_t)(nseg + 1));
         if (prefix) prefix->fill(w);
-        ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
+        const bool fused_upload = prefix && orbx::stage_ok(w.dev, w.pin, staged);
+        if (!fused_upload) ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
         // ONE fill for everything that needs a preset (a launch each was 3-4 us of a 0.1-ms call): match_kp = -1 (slot untouched);
         // segments write back touched slots of the state only, so it is preset to -1 as well (the span in between, match_q, is
         // rewritten in full anyway); and the two counters START AT -1: the match count is overwritten (one workgroup) or added
@@ -1613,10 +1688,14 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
 
         const FrameView fv = fs.view(w);
         WinQuery *dq = w.d<WinQuery>(o_q);
-        if (prefix) prefix->launch(w, dq, st);
-        if (queries_out) {
-            ORBX_HIP(hipMemcpyAsync(w.pin + w.pin_cap - ((sizeof(WinQuery) * nq + 255) & ~(size_t)255), dq, sizeof(WinQuery) * nq, hipMemcpyDeviceToHost, st));
-            if (ns == 0) { ORBX_HIP(hipStreamSynchronize(st)); memcpy(queries_out, w.pin + w.pin_cap - ((sizeof(WinQuery) * nq + 255) & ~(size_t)255), sizeof(WinQuery) * nq); return ORBX_OK; }
+        if (prefix) prefix->launch(w, dq, st, fused_upload ? stage_job(w.dev, w.pin, staged) : StageJob{nullptr, nullptr, 0, 0});
+        if (tq_bytes) ORBX_HIP(hipMemcpyAsync(tq_pin, dq, sizeof(WinQuery) * nq, hipMemcpyDeviceToHost, st));
+        if (tp_bytes) ORBX_HIP(hipMemcpyAsync(tp_pin, w.d<char>(prefix->o_proj), sizeof(orbm_projected_point) * (size_t)nq, hipMemcpyDeviceToHost, st));
+        if (ns == 0) {      // nothing to search: the prefix's outputs are the whole result
+            ORBX_HIP(hipStreamSynchronize(st));
+            if (tq_bytes) memcpy(queries_out, tq_pin, sizeof(WinQuery) * nq);
+            if (tp_bytes) memcpy(prefix->proj_host, tp_pin, sizeof(orbm_projected_point) * (size_t)nq);
+            return ORBX_OK;
         }
         const uint4 *da = w.d<uint4>(o_a), *db = fv.desc;
         const SeqKp *dk = fv.kp;
@@ -1693,7 +1772,8 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
         memcpy(match_q, w.pin + (o_mq - o_res), sizeof(int) * nq);
         if (mode == 0 && n) memcpy(match_kp, w.pin + (o_mk - o_res), sizeof(int) * n);
         memcpy(nmatches, w.pin + (o_nm - o_res), sizeof(int));
-        if (queries_out) memcpy(queries_out, w.pin + w.pin_cap - ((sizeof(WinQuery) * nq + 255) & ~(size_t)255), sizeof(WinQuery) * nq);
+        if (tq_bytes) memcpy(queries_out, tq_pin, sizeof(WinQuery) * nq);
+        if (tp_bytes) memcpy(prefix->proj_host, tp_pin, sizeof(orbm_projected_point) * (size_t)nq);
         if (seg && sequential) *nmatches += 1;   // the segments added their counts to the preset -1
         break;
     }
@@ -1978,6 +2058,21 @@ int orbm_frame_destroy(orbm_frame *f)
     return ORBX_OK;
 }
 
+int orbm_frame_alias(const orbm_frame *src, float min_x, float min_y, float max_x, float max_y, orbm_frame **out)
+{
+    if (!src || !out || !(max_x > min_x) || !(max_y > min_y)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    orbm_frame *f = new orbm_frame();
+    f->n = src->n; f->ns = src->ns; f->cap = src->cap; f->has_uright = src->has_uright;
+    f->min_x = min_x; f->min_y = min_y; f->max_x = max_x; f->max_y = max_y;
+    f->gp = {min_x, min_y, src->gp.inv_w, src->gp.inv_h};        // KeyFrame: int bounds, the Frame's mfGridElement*Inv (KeyFrame.cc:36,44)
+    f->block = src->block; f->refs = src->refs;
+    f->refs->fetch_add(1);
+    frame_pointers(f);
+    f->perm_host = src->perm_host;
+    *out = f;
+    return ORBX_OK;
+}
+
 int orbm_frame_size(const orbm_frame *f, int *n, int *nsorted)
 {
     if (!f) ORBX_FAIL(ORBX_ERR_ARG, "null frame");
@@ -2086,9 +2181,9 @@ int orbm_project_points(int mode, const float *mp_pos, const float *mp_normal, c
     for (int i = 0; i < 9; ++i) pc.R[i] = Rcw[i];
     for (int i = 0; i < 3; ++i) { pc.t[i] = tcw[i]; pc.Ow[i] = Ow[i]; }
     pc.nlevels = nlevels; pc.mode = mode;
-    hipLaunchKernelGGL(k_project_points, dim3((m + MT - 1) / MT), dim3(MT), 0, sc.stream(), sc.d<const float>(o_pos),
+    hipLaunchKernelGGL(k_project_points, dim3((m + MT - 1) / MT), dim3(MT), 0, sc.stream(), (const uint8_t *)nullptr, sc.d<const float>(o_pos),
                        sc.d<const float>(o_nrm), sc.d<const float>(o_min), sc.d<const float>(o_max), m, pc, sc.d<const float>(o_sc),
-                       sc.d<orbm_projected_point>(o_out), sc.d<WinQuery>(o_q));
+                       sc.d<orbm_projected_point>(o_out), sc.d<WinQuery>(o_q), StageJob{nullptr, nullptr, 0, 0});
     ORBX_HIP(hipGetLastError());
     if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
     memcpy(out, sc.r<orbm_projected_point>(o_out), sizeof(orbm_projected_point) * (size_t)m);
@@ -2257,6 +2352,30 @@ int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t
 
 // ------------------------------------------------------- the projection searches as whole functions, on resident frames
 
+int orbm_search_by_projection_points(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const orbm_points *points,
+                                     const uint8_t *occupied, float th, float viewing_cos_limit, int th_high, float nnratio, int32_t *match_kp,
+                                     int32_t *match_q, int *nmatches, orbm_projected_point *projected_out, orbm_window_query *queries_out)
+{
+    if (!cur || bad_view(view) || !Tcw || bad_points(points, true, true, false, view->nlevels) || !nmatches || (points->n && !match_q) ||
+        (cur->n && !match_kp))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    ORBX_NEED_DEVICE();
+    PointsPrefix px;
+    px.pts = points; px.scale = view->scale_factors; px.frustum = true; px.proj_host = projected_out;
+    px.cam.nlevels = view->nlevels;
+    ProjectCam &pc = px.pcam;
+    pc.fx = view->fx; pc.fy = view->fy; pc.cx = view->cx; pc.cy = view->cy;
+    pc.min_x = cur->min_x; pc.max_x = cur->max_x; pc.min_y = cur->min_y; pc.max_y = cur->max_y;
+    pc.mbf = view->mbf; pc.cos_limit = viewing_cos_limit; pc.log_scale = view->log_scale_factor; pc.th = th;
+    pose_parts(Tcw, pc.R, pc.t);
+    neg_Rt_t(pc.R, pc.t, pc.Ow);                 // mOw = -mRcw.t() * mtcw (Frame::UpdatePoseMatrices, src/Frame.cc:236-242)
+    pc.nlevels = view->nlevels; pc.mode = ORBM_PROJECT_FRUSTUM;
+    if (projected_out) for (int i = 0; i < points->n; ++i) projected_out[i] = {0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};
+    FrameSrc fs(cur);
+    return run_sequential(0, nullptr, &px, points->desc, nullptr, points->takes, points->n, fs, cur->n, occupied, cur->has_uright, th_high,
+                          nnratio, ACCEPT_RATIO_SAME_LEVEL, 0, match_kp, match_q, nmatches, reinterpret_cast<WinQuery *>(queries_out));
+}
+
 int orbm_search_by_projection_last(const orbm_frame *cur, const orbm_view *view, const float *Tcw, const float *Tlw, const orbm_points *last,
                                    const uint8_t *occupied, float th, int mono, int th_high, int check_orientation, int32_t *match_kp,
                                    int32_t *match_q, int *nmatches, orbm_window_query *queries_out)
@@ -2357,23 +2476,24 @@ int orbm_search_by_sim3(const orbm_frame *kf1, const orbm_frame *kf2, const orbm
     WorkspaceLease lease;
     Workspace &w = *lease.w;
     w.used = 0;
-    p12.carve(w); p21.carve(w);
     const size_t o_a1 = w.carve((size_t)32 * n1), o_a2 = w.carve((size_t)32 * n2);
     const size_t staged = w.used;
+    p12.carve(w); p21.carve(w);                    // read by the prefix kernels from the pinned block
+    const size_t pin_in = w.used;
     const size_t o_q12 = w.carve(sizeof(WinQuery) * n1), o_q21 = w.carve(sizeof(WinQuery) * n2), o_b1 = w.carve(sizeof(int) * 5 * (size_t)n1),
                  o_b2 = w.carve(sizeof(int) * 5 * (size_t)n2);
     const size_t o_res = w.used;
     const size_t o_v1 = w.carve(sizeof(int) * n1), o_v2 = w.carve(sizeof(int) * n2), o_m = w.carve(sizeof(int) * n1), o_nf = w.carve(sizeof(int));
     const size_t o_qo1 = w.carve(q12_out ? sizeof(WinQuery) * n1 : 1), o_qo2 = w.carve(q21_out ? sizeof(WinQuery) * n2 : 1);
     const size_t res_bytes = w.used - o_res;
-    if (w.reserve(w.used, std::max(staged, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
+    if (w.reserve(w.used, std::max(pin_in, res_bytes))) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation failed");
     p12.fill(w); p21.fill(w);
     memcpy(w.h<char>(o_a1), points1->desc, (size_t)32 * n1);
     memcpy(w.h<char>(o_a2), points2->desc, (size_t)32 * n2);
     hipStream_t st = w.st;
-    ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st));
     ORBX_HIP(hipMemsetAsync(w.d<char>(o_nf), 0, sizeof(int), st));
-    p12.launch(w, w.d<WinQuery>(o_q12), st);
+    if (orbx::stage_ok(w.dev, w.pin, staged)) p12.launch(w, w.d<WinQuery>(o_q12), st, stage_job(w.dev, w.pin, staged));
+    else { ORBX_HIP(orbx::stage_in(w.dev, w.pin, staged, st)); p12.launch(w, w.d<WinQuery>(o_q12), st); }
     p21.launch(w, w.d<WinQuery>(o_q21), st);
     FrameSrc f1(kf1), f2(kf2);
     int *b1 = w.d<int>(o_b1), *b2 = w.d<int>(o_b2);

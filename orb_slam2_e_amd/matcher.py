@@ -453,6 +453,20 @@ class ORBmatcher:
         return self._whole(self._L.orbm_search_by_projection_last, cur, view, [Tcw, Tlw], last, occupied,
                            [C.c_float(th), int(bool(bMono)), self.TH_HIGH, int(self.mbCheckOrientation)], want_queries)
 
+    def SearchByProjectionPoints(self, cur, view, Tcw, points, occupied, th=1.0, viewing_cos_limit=0.5):
+        """Tracking::SearchLocalPoints' data plane: Frame::isInFrustum for every listed point chained into
+        SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:46-132) on a resident frame.
+        Returns (match_kp, match_q, nmatches, projected[PROJ_DTYPE], queries)."""
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        oc = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else None
+        mk = np.zeros(max(cur.n, 1), np.int32); mq = np.zeros(max(points.n, 1), np.int32); nm = C.c_int(0)
+        proj = np.zeros(max(points.n, 1), self.PROJ_DTYPE); q = np.zeros(max(points.n, 1), self.WQ_DTYPE)
+        fn = self._L.orbm_search_by_projection_points
+        fn.argtypes = None
+        check(fn(cur._h, C.byref(view.c), _p(T), C.byref(points.c), _p(oc) if oc is not None else None, C.c_float(th),
+                 C.c_float(viewing_cos_limit), self.TH_HIGH, C.c_float(self.mfNNratio), _p(mk), _p(mq), C.byref(nm), _p(proj), _p(q)))
+        return mk[:cur.n], mq[:points.n], nm.value, proj[:points.n], q[:points.n]
+
     def SearchByProjectionKeyFrame(self, cur, view, Tcw, kf, occupied, th, ORBdist, want_queries=False):
         """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1673-1800)."""
         return self._whole(self._L.orbm_search_by_projection_keyframe, cur, view, [Tcw], kf, occupied,
@@ -551,6 +565,13 @@ class Frame:
         check(L.orbm_frame_from_extractor(ex._h, int(frame), _p(xy) if xy is not None else None, _p(ur) if ur is not None else None,
                                           int(bool(uright_from_stereo)), *[float(b) for b in bounds], C.byref(h)))
         return cls(bounds=bounds, _handle=h)
+
+    def alias(self, bounds):
+        """orbm_frame_alias: the same device data searched with other bounds (a KeyFrame's int-valued mnMinX .. mnMaxY)."""
+        h = C.c_void_p()
+        self._L.orbm_frame_alias.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        check(self._L.orbm_frame_alias(self._h, *[float(b) for b in bounds], C.byref(h)))
+        return Frame(bounds=bounds, _handle=h)
 
     def layout(self):
         perm = np.zeros(max(self.ns, 1), np.int32); cell_off = np.zeros(64 * 48 + 1, np.int32)

@@ -145,6 +145,49 @@ int main(int argc, char **argv)
         for (int i = 0; i < n; ++i) selfp += owner[i] == i;
         if (m.status() != ORBX_OK || np != n || selfp != n) { printf("FAIL SearchByProjection %d %d of %d\n", np, selfp, n); return 1; }
     }
+    {   // Tracking::TrackWithMotionModel's shape on a frame that stays in HBM: the frame handle is made from the extractor's device
+        // results (`ex` last extracted `img`), every keypoint is given a map point on its own ray, identity pose:
+        // SearchByProjection(Cur, Last, th, mono) must hand every keypoint its own point, for th and 2 th, and equal the
+        // handle made from the host arrays
+        ORBmatcher::ResidentFrame cur(ex, nullptr, nullptr, false, 0.f, 0.f, (float)W, (float)H), cur2(F);
+        if (cur.status() != ORBX_OK || cur2.status() != ORBX_OK || cur.N != n || cur2.N != n) { printf("FAIL ResidentFrame %d %d\n", cur.status(), cur.N); return 1; }
+        ORBmatcher::Calibration K;
+        K.fx = 500.f; K.fy = 500.f; K.cx = 320.f; K.cy = 240.f; K.mbf = 40.f; K.mb = 0.08f; K.mfLogScaleFactor = logf(1.2f);
+        K.mvScaleFactors.resize(8);
+        for (int l = 0; l < 8; ++l) K.mvScaleFactors[l] = l ? K.mvScaleFactors[l - 1] * 1.2f : 1.0f;
+        ORBmatcher::PointList last;
+        last.resize(n, false, false, true);
+        for (int i = 0; i < n; ++i) {
+            const float z = 2.0f + (float)(i % 7);
+            last.valid[i] = 1; last.octave[i] = kps[i].octave; last.angle[i] = kps[i].angle;
+            last.pos[3 * i] = (kps[i].x - K.cx) / K.fx * z; last.pos[3 * i + 1] = (kps[i].y - K.cy) / K.fy * z; last.pos[3 * i + 2] = z;
+            std::copy(&desc[(size_t)32 * i], &desc[(size_t)32 * i] + 32, &last.desc[(size_t)32 * i]);
+        }
+        const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int rep = 0; rep < 2; ++rep) {
+            std::vector<int32_t> ownerA, ownerB;
+            const int na = m.SearchByProjection(cur, K, I4, I4, last, std::vector<uint8_t>(), rep ? 14.0f : 7.0f, true, ownerA);
+            const int nb2 = m.SearchByProjection(cur2, K, I4, I4, last, std::vector<uint8_t>(), rep ? 14.0f : 7.0f, true, ownerB);
+            int selfa = 0;
+            for (int i = 0; i < n; ++i) selfa += ownerA[i] == i;
+            if (m.status() != ORBX_OK || na != nb2 || ownerA != ownerB || selfa < n * 95 / 100 || na < selfa) { printf("FAIL whole SearchByProjection(Cur, Last) %d %d self %d of %d\n", na, nb2, selfa, n); return 1; }
+        }
+        // SearchLocalPoints: the same points with ranges and normals that pass isInFrustum
+        ORBmatcher::PointList loc = last;
+        loc.minDistance.resize(n); loc.maxDistance.resize(n); loc.normal.resize((size_t)3 * n); loc.octave.clear();
+        for (int i = 0; i < n; ++i) {
+            const float d = sqrtf(loc.pos[3 * i] * loc.pos[3 * i] + loc.pos[3 * i + 1] * loc.pos[3 * i + 1] + loc.pos[3 * i + 2] * loc.pos[3 * i + 2]);
+            loc.maxDistance[i] = d * K.mvScaleFactors[kps[i].octave]; loc.minDistance[i] = loc.maxDistance[i] / K.mvScaleFactors[7];
+            for (int k = 0; k < 3; ++k) loc.normal[3 * i + k] = loc.pos[3 * i + k] / d;
+        }
+        std::vector<int32_t> ownerL;
+        std::vector<orbm_projected_point> proj;
+        ORBmatcher ml(0.8f, true);
+        const int nlp = ml.SearchLocalPoints(cur, K, I4, loc, std::vector<uint8_t>(), 1.0f, ownerL, &proj);
+        int selfl = 0, vis = 0;
+        for (int i = 0; i < n; ++i) { selfl += ownerL[i] == i; vis += proj[i].visible; }
+        if (ml.status() != ORBX_OK || vis < n * 9 / 10 || selfl < vis * 8 / 10 || nlp < selfl) { printf("FAIL SearchLocalPoints %d self %d visible %d of %d\n", nlp, selfl, vis, n); return 1; }
+    }
     {
         std::vector<int32_t> node(n);
         for (int i = 0; i < n; ++i) node[i] = (desc[(size_t)32 * i] & 31) * 3 + 1;   // a stand-in vocabulary node per feature

@@ -149,6 +149,34 @@ def test_search_by_projection_last_without_query_output_and_empty_inputs():
     e.close(); cur.close()
 
 
+@pytest.mark.parametrize("stereo", [False, True])
+@pytest.mark.parametrize("th", [1.0, 3.0])
+def test_search_local_points(stereo, th, resolver):
+    """isInFrustum for all local map points chained into SearchByProjection(Frame&, vector<MapPoint*>&, th): equal to the oracle's
+    projection followed by its literal loop (levels [l-1, l], stereo test, same-level ratio test)."""
+    s = synth_tracking_scene(31 + stereo, stereo=stereo)
+    rng = np.random.default_rng(1)
+    npnt = len(s["pos"])
+    valid = (rng.random(npnt) < 0.9).astype(np.uint8)
+    takes = (rng.random(npnt) < 0.8).astype(np.uint8)
+    m = ORBmatcher(0.8, True)       # (this form has no rotation check whatever the flag)
+    cur = Frame(s["kps"], s["desc"], s["bounds"], s["uright"])
+    pts = Points(valid, s["pos"], s["mp_desc"], normal=s["normal"], min_distance=s["mind"], max_distance=s["maxd"], takes=takes)
+    got = m.SearchByProjectionPoints(cur, _view(s), s["Tcw"], pts, s["occupied"], th)
+    Ow = oracle.camera_centre(s["Tcw"])
+    rproj, rq = oracle.project_points(0, s["pos"], s["normal"], s["mind"], s["maxd"], s["Tcw"][:3, :3], s["Tcw"][:3, 3], Ow, s["cam"],
+                                      s["bounds"], s["mbf"], 0.5, s["log_scale_factor"], s["scale_factors"], th)
+    rq = rq.copy(); rq["r"][valid == 0] = -1.0
+    rproj = rproj.copy(); rproj[valid == 0] = np.zeros(1, rproj.dtype); rproj["level"][valid == 0] = -1
+    ref = oracle.search_projection_seq(rq, s["mp_desc"], np.zeros(npnt, np.float32), takes, s["kps"], s["desc"], s["bounds"], s["occupied"],
+                                       s["uright"], 95, 0.8, True, False)
+    k = _same_queries(got[4], rq)
+    assert np.array_equal(got[4]["xr"][k].view(np.uint32), rq["xr"][k].view(np.uint32))
+    assert got[3].tobytes() == rproj.tobytes()
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2] and ref[2] > 100
+    cur.close()
+
+
 @pytest.mark.parametrize("seed", [2, 9])
 def test_search_by_projection_keyframe(seed, resolver):
     """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): no depth test, levels l-1 .. l+1, every match blocks."""
@@ -264,3 +292,39 @@ def test_track_with_motion_model_sequence_uploads_the_frame_once():
     assert np.array_equal(got[0], ref[0]) and got[2] == ref[2]
     for fr in (f, g, fu, gu):
         fr.close()
+
+
+def test_keyframe_forms_use_the_keyframes_int_bounds():
+    """A camera with distortion: the Frame's bounds are fractional, the KeyFrame made from it keeps the Frame's grid but searches with
+    int-valued bounds (include/KeyFrame.h:201-204, src/KeyFrame.cc:36,44,613-657) -- orbm_frame_alias."""
+    s = synth_tracking_scene(8)
+    rng = np.random.default_rng(8)
+    fb = (-27.3, -19.6, 667.4, 501.8)
+    kb = tuple(float(int(b)) for b in fb)
+    m = ORBmatcher(0.75, True)
+    fr = Frame(s["kps"], s["desc"], fb); kf = fr.alias(kb)
+    fr2 = Frame(s["kps2"], s["desc2"], fb); kf2 = fr2.alias(kb)
+    fr.close(); fr2.close()                         # the aliases keep the device data alive
+    npnt = len(s["pos"])
+    valid = np.ones(npnt, np.uint8)
+    occ = (rng.random(len(s["kps"])) < 0.1).astype(np.uint8)
+    pts = Points(valid, s["pos"], s["mp_desc"], normal=s["normal"], min_distance=s["mind"], max_distance=s["maxd"])
+    ref = oracle.search_by_projection_sim3(s["kps"], s["desc"], occ, fb, s["cam"], s["Scw"], s["scale_factors"], s["log_scale_factor"], valid,
+                                           s["pos"], s["normal"], s["mind"], s["maxd"], s["mp_desc"], 10, kf_bounds=kb)
+    plain = oracle.search_by_projection_sim3(s["kps"], s["desc"], occ, fb, s["cam"], s["Scw"], s["scale_factors"], s["log_scale_factor"], valid,
+                                             s["pos"], s["normal"], s["mind"], s["maxd"], s["mp_desc"], 10)
+    got = m.SearchByProjectionSim3(kf, _view(s), s["Scw"], pts, occ, 10, want_queries=True)
+    _same_queries(got[3], ref[3])
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2] and ref[2] > 20
+    v1 = (s["src"] >= 0).astype(np.uint8); mp1 = np.maximum(s["src"], 0)
+    v2 = (s["src2"] >= 0).astype(np.uint8); mp2 = np.maximum(s["src2"], 0)
+    p1 = Points(v1, s["pos"][mp1], s["mp_desc"][mp1], min_distance=s["mind"][mp1], max_distance=s["maxd"][mp1])
+    p2 = Points(v2, s["pos"][mp2], s["mp_desc"][mp2], min_distance=s["mind"][mp2], max_distance=s["maxd"][mp2])
+    r9 = oracle.search_by_sim3_whole(s["kps"], s["desc"], s["kps2"], s["desc2"], fb, s["cam"], s["scale_factors"], s["log_scale_factor"],
+                                     s["Tcw"], s["T2w"], s["s12"], s["R12"], s["t12"], v1, s["pos"][mp1], s["mind"][mp1], s["maxd"][mp1],
+                                     s["mp_desc"][mp1], v2, s["pos"][mp2], s["mind"][mp2], s["maxd"][mp2], s["mp_desc"][mp2], 7.5, kf_bounds=kb)
+    g9 = m.SearchBySim3Whole(kf, kf2, _view(s), s["Tcw"], s["T2w"], s["s12"], s["R12"], s["t12"], p1, p2, 7.5)
+    assert np.array_equal(g9[0], r9[0]) and g9[1] == r9[1] and np.array_equal(g9[2], r9[2]) and np.array_equal(g9[3], r9[3])
+    # (whether the two sets of bounds give different answers on this scene is not asserted: the quirk bites at cell borders only)
+    del plain
+    kf.close(); kf2.close()
