@@ -52,6 +52,12 @@ typedef struct orbx_params {
     int32_t min_th_fast;   /* arg 5 */
     int32_t blur_variant;  /* 0: 7-tap 8.8 kernel {18,34,48,56,48,34,18} (sum 256, canonical);
                               1: {18,34,49,55,49,34,18} (taps rounded individually) */
+    int32_t trig_variant;  /* cos / sin of the keypoint angle in computeOrbDescriptor (ORBextractor.cc:111-113: a float argument under
+                              `using namespace std`, i.e. cosf / sinf):
+                              0: cosf / sinf as glibc >= 2.28 computes them (any current Linux; bit-exact restatement, checked over
+                                 every float in [0, 2 pi] by tools/trig/trig_variant_count.c);
+                              1: the correctly rounded float of the double-precision cos / sin (differs from 0 by one ulp at 0.36 % /
+                                 0.83 % of the angles: DESIGN 4.2) */
 } orbx_params;
 
 typedef struct orbx_extractor orbx_extractor;

@@ -48,7 +48,7 @@ public:
 
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
     {
-        orbx_params p = {nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, 0};
+        orbx_params p = {nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, /*blur_variant*/ 0, /*trig_variant*/ 0};
         mStatus = orbx_create(&p, &mHandle);
         if (mStatus == ORBX_OK) {
             mnLevels = nlevels;

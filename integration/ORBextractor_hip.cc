@@ -15,7 +15,7 @@ namespace ORB_SLAM2 {
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mHip(nullptr)
 {
-    orbx_params p = {nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, /*blur_variant*/ 0};
+    orbx_params p = {nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, /*blur_variant*/ 0, /*trig_variant*/ 0};
     if (orbx_create(&p, &mHip) != ORBX_OK) { mHip = nullptr; return; }       // orbx_last_error() has the text
     mvScaleFactor.resize(nlevels);      orbx_get_scale_factors(mHip, mvScaleFactor.data());
     mvInvScaleFactor.resize(nlevels);   orbx_get_inv_scale_factors(mHip, mvInvScaleFactor.data());

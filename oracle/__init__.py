@@ -105,6 +105,11 @@ class OrbOracle:
         assert t.shape == (7,)
         self.L.oracle_orb_set_blur_taps(self.h, _p(t))
 
+    def set_trig_variant(self, v):
+        """0: the C library's cosf / sinf, as the reference calls them (default); 1: the rounded double-precision values."""
+        self.L.oracle_orb_set_trig_variant.argtypes = [C.c_void_p, C.c_int]
+        self.L.oracle_orb_set_trig_variant(self.h, int(v))
+
     def features_per_level(self):
         return [self.L.oracle_orb_features_per_level(self.h, l) for l in range(self.nlevels)]
 

@@ -47,6 +47,7 @@ typedef struct {
     int mnFeaturesPerLevel[MAX_LEVELS];
     int umax[HALF_PATCH_SIZE + 1];
     int blur_taps[7];
+    int trig_variant; /* 0: the C library's cosf / sinf (glibc >= 2.28 for the documented results); 1: (float)cos((double)x) */
     /* per-call state (mvImagePyramid analogue) */
     int lw[MAX_LEVELS], lh[MAX_LEVELS], lstride[MAX_LEVELS];
     uint8_t *padded[MAX_LEVELS]; /* (lw+38) x (lh+38), stride lstride */
@@ -522,6 +523,7 @@ static void free_state(oracle_orb *o)
 void oracle_orb_destroy(oracle_orb *o) { if (o) { free_state(o); free(o); } }
 
 void oracle_orb_set_blur_taps(oracle_orb *o, const int *taps7) { memcpy(o->blur_taps, taps7, 7 * sizeof(int)); }
+void oracle_orb_set_trig_variant(oracle_orb *o, int v) { o->trig_variant = v; }
 
 /* ORBextractor::ComputePyramid, ORBextractor.cc:1115-1140 */
 static void compute_pyramid(oracle_orb *o, const uint8_t *img, int w, int h, int stride)
@@ -563,13 +565,15 @@ static float ic_angle(const uint8_t *image, int step, float ptx, float pty, cons
     return oracle_fastAtan2((float)m_01, (float)m_10);
 }
 
-/* computeOrbDescriptor, ORBextractor.cc:107-147.  cos/sin: correctly rounded
- * float of the double-precision value. */
-void oracle_orb_descriptor(const uint8_t *img, int step, float ptx, float pty, float angle_deg, uint8_t *desc)
+/* computeOrbDescriptor, ORBextractor.cc:107-147.  `cos(angle)` / `sin(angle)` with a float argument under `using namespace std`
+ * are the float overloads: trig_variant 0 calls the C library's cosf / sinf as the reference does (their values are a property of
+ * the library: glibc >= 2.28 here, whose FMA and generic builds agree on [0, 2 pi] -- tools/trig/trig_variant_count.c);
+ * variant 1 = the correctly rounded float of the double-precision value. */
+void oracle_orb_descriptor(const uint8_t *img, int step, float ptx, float pty, float angle_deg, uint8_t *desc, int trig_variant)
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float angle = angle_deg * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    float a = trig_variant == 0 ? cosf(angle) : (float)cos((double)angle), b = trig_variant == 0 ? sinf(angle) : (float)sin((double)angle);
     const uint8_t *center = img + (ptrdiff_t)oracle_cvRound(pty) * step + oracle_cvRound(ptx);
     const signed char *pat = oracle_orb_pattern;
     int i, k;
@@ -681,7 +685,7 @@ int oracle_orb_extract(oracle_orb *o, const uint8_t *img, int w, int h, int stri
         oracle_gauss7(inner, lw, lh, pst, o->blurred[level], lw, o->blur_taps);
         for (i = 0; i < nk; i++) {
             oracle_keypoint kp = o->lkps[level][i];
-            oracle_orb_descriptor(o->blurred[level], lw, kp.x, kp.y, kp.angle, desc + (size_t)(offset + i) * 32);
+            oracle_orb_descriptor(o->blurred[level], lw, kp.x, kp.y, kp.angle, desc + (size_t)(offset + i) * 32, o->trig_variant);
             if (level != 0) { float scale = o->mvScaleFactor[level]; kp.x *= scale; kp.y *= scale; }
             kps[offset + i] = kp;
         }

@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
                                                   const uint32_t *__restrict__ sel_all, int sel_per_frame,
                                                   const int *__restrict__ level_count,
                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                                  int *__restrict__ counts, int cap)
+                                                  int *__restrict__ counts, int cap, int trig_variant)
 {
     __shared__ uint32_t s_coff[DESC_KPB];   // patch centre, byte offset inside the frame's pyramid
     __shared__ int s_valid[DESC_KPB], s_out[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
@@ -1478,7 +1478,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const float angle = orbx_fast_atan2((float)s_m01[tid], (float)s_m10[tid]);
         const float factorPI = (float)(3.14159265358979323846 / 180.f);
         float a, b;
-        orbx_sincos_f32(angle * factorPI, &b, &a); // a = cos, b = sin
+        if (trig_variant == 0) orbx_sincos_glibc_f32(angle * factorPI, &b, &a); // a = cos, b = sin
+        else orbx_sincos_f32(angle * factorPI, &b, &a);
         s_angle[tid] = angle; s_cos[tid] = a; s_sin[tid] = b;
     }
     __syncthreads();
@@ -1655,12 +1656,13 @@ void reader_done(orbx_extractor *ex, hipStream_t st)
 extern "C" {
 
 const char *orbx_last_error(void) { return orbx::last_error().c_str(); }
-int orbx_abi_version(void) { return 120; } // 120: + fem_plan, fem_plan_selfcheck, orbm_sorted_frame, orbx_stereo_download_batch, orbm_debug_* (additions only); 110: + orbm_project_points, fem_create_batch, fem_batch_offsets
+int orbx_abi_version(void) { return 130; } // 130: + orbm_frame_*, the whole-function searches, orbx_params.trig_variant (a struct field: rebuild callers); 120: + fem_plan, fem_plan_selfcheck, orbm_sorted_frame, orbx_stereo_download_batch, orbm_debug_* (additions only); 110: + orbm_project_points, fem_create_batch, fem_batch_offsets
 
 int orbx_create(const orbx_params *prm, orbx_extractor **out)
 {
     if (!prm || !out) ORBX_FAIL(ORBX_ERR_ARG, "null argument");
-    if (prm->nlevels < 1 || prm->nlevels > MAXL || prm->nfeatures < 0 || !(prm->scale_factor > 1.0f))
+    if (prm->nlevels < 1 || prm->nlevels > MAXL || prm->nfeatures < 0 || !(prm->scale_factor > 1.0f) || prm->blur_variant < 0 ||
+        prm->blur_variant > 1 || prm->trig_variant < 0 || prm->trig_variant > 1)
         ORBX_FAIL(ORBX_ERR_ARG, "bad extractor parameters");
     orbx_extractor *ex = new orbx_extractor();
     ex->prm = *prm;
@@ -2148,7 +2150,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         }
         for (int l = nl; l <= MAXL; l++) D.chunk_base[l] = nchunks;
         hipLaunchKernelGGL(k_describe, dim3(nchunks, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, D, nl,
-                           ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps, ex->d_desc, ex->d_counts, ex->kcap);
+                           ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps, ex->d_desc, ex->d_counts, ex->kcap, ex->prm.trig_variant);
     }
     pf.stop(5, st);
     ORBX_HIP(hipGetLastError());

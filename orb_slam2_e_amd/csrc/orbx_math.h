@@ -70,4 +70,49 @@ ORBX_HD void orbx_sincos_f32(float xf, float *sn, float *cs)
     *cs = (float)co;
 }
 
+// cosf / sinf of a float angle in [0, 2*pi] as glibc >= 2.28 computes them (sysdeps/ieee754/flt-32/s_cosf.c, s_sinf.c: the ARM
+// optimized-routines algorithm -- argument in double, quadrant by a scaled float-to-int conversion, degree-8 / degree-7 polynomials in
+// double, one rounding to float).  This is what `cos(angle)` / `sin(angle)` of computeOrbDescriptor (src/ORBextractor.cc:112-113, float
+// argument under `using namespace std`) call on a current Linux.  A fixed sequence of double multiplies and adds: tools/trig/
+// trig_variant_count.c checks the same sequence bit for bit against the C library over every float in [0, 2 pi] (it also holds with
+// every a + b c fused: the FMA build glibc selects on CPUs with FMA returns the same floats).
+ORBX_HD float orbx_glibc_poly_f32(double x, double x2, int alt, int n)
+{
+    const double sg = alt ? -1.0 : 1.0;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double t1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * -0x1.555545995a603p-3;
+        return (float)(s + x7 * t1);
+    }
+    const double x4 = x2 * x2;
+    const double t2 = sg * -0x1.6c087e89a359dp-10 + x2 * (sg * 0x1.99343027bf8c3p-16);
+    const double t1 = sg * 0x1p0 + x2 * (sg * -0x1.ffffffd0c621cp-2);
+    const double x6 = x4 * x2;
+    const double c = t1 + x4 * (sg * 0x1.55553e1068f19p-5);
+    return (float)(c + x6 * t2);
+}
+ORBX_HD void orbx_sincos_glibc_f32(float y, float *sn, float *cs)
+{
+    double x = (double)y;
+    union { float f; unsigned u; } v;
+    v.f = y;
+    const unsigned top = (v.u >> 20) & 0x7ffu;
+    if (top < 0x3f4u) {                                   // |y| < pi / 4 (abstop12(0x1.921FB6p-1f))
+        const double x2 = x * x;
+        if (top < 0x398u) { *sn = y; *cs = 1.0f; return; }   // |y| < 2^-12
+        *sn = orbx_glibc_poly_f32(x, x2, 0, 0);
+        *cs = orbx_glibc_poly_f32(x, x2, 0, 1);
+        return;
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;           // 2 / pi * 2^24
+    const int n = ((int)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const double s = ((n + 1) & 2) ? -1.0 : 1.0;          // sign[n & 3] = {1, -1, -1, 1}
+    const int alt = (n & 2) != 0;
+    *sn = orbx_glibc_poly_f32(x * s, x * x, alt, n);
+    *cs = orbx_glibc_poly_f32(x * s, x * x, alt, n ^ 1);
+}
+
 #endif // ORBX_MATH_H

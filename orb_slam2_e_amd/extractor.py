@@ -16,7 +16,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 class _Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
-                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_variant", C.c_int32)]
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_variant", C.c_int32), ("trig_variant", C.c_int32)]
 
 
 def _p(a):
@@ -24,10 +24,10 @@ def _p(a):
 
 
 class ORBextractor:
-    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, blur_variant=0):
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, blur_variant=0, trig_variant=0):
         self._L = lib()
         self._h = C.c_void_p()
-        prm = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, blur_variant)
+        prm = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, blur_variant, trig_variant)
         check(self._L.orbx_create(C.byref(prm), C.byref(self._h)))
         self.nlevels = nlevels
         self.capacity = self._L.orbx_keypoint_capacity(self._h)

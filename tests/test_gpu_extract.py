@@ -229,6 +229,27 @@ def test_blur_variant_1():
     assert np.array_equal(desc, odesc)
 
 
+def test_trig_variant_1():
+    """cos / sin of the keypoint angle as the rounded double-precision values (the default is the C library's cosf / sinf, which
+    every other test here exercises): still bit-exact against the oracle evaluated the same way."""
+    descs = []
+    for v in (0, 1):
+        n_diff = 0
+        for k in (1, 2, 3):
+            img = synth_frame(k)
+            o = oracle.OrbOracle(*PARAMS)
+            o.set_trig_variant(v)
+            okps, odesc = o.extract(img)
+            ex = ORBextractor(*PARAMS, trig_variant=v)
+            kps, desc = ex(img)
+            _kp_equal(kps, okps)
+            assert np.array_equal(desc, odesc)
+            descs.append(desc)
+    # the two variants give the same keypoints and (nearly) the same descriptors: one ulp in a or b rarely moves a sampling point
+    same = sum(int((a != b).any(axis=1).sum()) for a, b in zip(descs[:3], descs[3:]))
+    assert same <= 6, same
+
+
 def test_download_batch_equals_per_frame_download():
     imgs = np.stack([synth_frame(20 + k) for k in range(3)])
     ex = ORBextractor(*PARAMS)
