@@ -507,6 +507,8 @@ def main():
     ap.add_argument("--match-kernel", choices=["auto", "popcount"], default="auto",
                     help="all-pairs matcher: auto = FP4 matrix-core kernel (default), popcount = XOR + v_bcnt kernel; same results")
     ap.add_argument("--fem-meshes", type=int, default=256)
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: leave the ranks' CPU placement to the scheduler")
+    ap.add_argument("--no-gather-sweep", action="store_true", help="N > 1: skip the short timed regions at other --gather-every values")
     ap.add_argument("--launch-timeout", type=float, default=None, help="--gpus N > 1 started without a launcher: seconds the N ranks may run")
     args = ap.parse_args()
 
@@ -519,6 +521,8 @@ def main():
     if launch.should_spawn(args.gpus):
         sys.exit(launch.run_parent(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout))
     world = launch.check_world(args.gpus)    # a launcher's WORLD_SIZE must be what --gpus says
+    # one rank, one set of cores -- before anything touches the GPU (the HIP runtime's threads inherit the mask)
+    affinity = None if args.no_pin else launch.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), world)
 
     import torch
     import torch.distributed as dist
@@ -681,6 +685,12 @@ def main():
 
     # ---- dominant kernel's launch times (HIP events on the launch stream, recorded in the timed region)
     kern = read_profiles()
+    # N > 1: the same steps at other gather cadences, short regions after the headline one (a single multi-GPU run then tunes
+    # --gather-every; the headline keeps the value it was started with)
+    sweep = None
+    if world > 1 and pipe.do_gather and not args.no_gather_sweep:
+        from orb_slam2_e_amd.shard import gather_sweep
+        sweep = gather_sweep(pipe, sync, world, cdev, values=tuple(sorted({1, 4, 16, GE})))
     for c in ctxs:
         L.orbx_profile_enable(c.ex._h, 0)
     L.orbm_profile_enable(0)
@@ -803,6 +813,7 @@ def main():
                        "parallelism": (f"frames sharded {BATCH}/rank, results gathered on rank 0 ({GE} steps per "
                                         f"{'gloo' if rehearse else 'RCCL'} gather)") if world > 1 else "single GPU",
                        "dist_backend": (args.dist_backend if world > 1 else None),
+                       "rank0_cpu_affinity": affinity,
                        "mean_keypoints_per_frame": float(counts.float().mean().item()),
                        "mean_matches_per_frame": float(nmatch.float().mean().item())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -848,6 +859,9 @@ def main():
             out["roofline"]["alone"] = {"launch_ms": alone_ms, "frac": alg / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if dom in tr and tr[dom].get("valu_wave_insts_per_launch"):
                 out["roofline"]["alone"]["valu_frac"] = tr[dom]["valu_wave_insts_per_launch"] / (alone_ms * 1e-3) / 1e9 / VALU_PEAK_GINST
+        if sweep is not None:
+            out["gather_sweep"] = {"ms_per_step_by_gather_every": sweep, "gather_every_of_value": GE,
+                                   "note": "24-step regions after the headline one, same steps, MAX over ranks"}
         if host_io is not None:
             out["host_io"] = host_io
         if fem is not None:
@@ -859,8 +873,10 @@ def main():
             out["stereo"] = stereo_bench()
             if out["verified"] is not None:
                 out["verified"] = bool(out["verified"] and out["stereo"]["batch"]["verified"])
-        if not args.no_cpu_baseline and world == 1:
-            legs = ["extract"] + ([] if args.no_fem else ["fem", "stereo", "loops"])
+        if not args.no_cpu_baseline:
+            # (N > 1: rank 0 times the extract + match leg alone -- the others wait at the closing barrier; the FEM / stereo / loop
+            # baselines belong to the N = 1 line)
+            legs = ["extract"] + ([] if (args.no_fem or world > 1) else ["fem", "stereo", "loops"])
             cb = cpu_baseline_child(legs, fem_csr if os.path.exists(fem_csr) else None)
             out["cpu_baseline"] = cb.get("extract_match", cb)
             if "fem" in cb and fem is not None: out["fem"]["cpu_baseline"] = cb["fem"]

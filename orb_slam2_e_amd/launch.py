@@ -146,3 +146,71 @@ def run_parent(script, argv, gpus, timeout=None, env=None, out=None, err=None):
         err.write(f"bench: asked for --gpus {gpus}, the result line says n_gpus = {res.get('n_gpus')}\n")
         return 4
     return 0
+
+
+# ---- one rank, one set of cores ---------------------------------------------------------------------------------------------
+# A rank's step is ~17 kernel launches per 0.26 ms from one host thread; eight ranks left to the scheduler migrate across sockets
+# and share cores with each other's HIP helper threads.  Each rank pins itself -- before it touches the GPU, so that the runtime's
+# threads inherit the mask -- to its share of the CPUs local to ITS GPU (PCI locality from sysfs), or to a contiguous share of the
+# CPUs it may use when the topology cannot be read.
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_local_cpus(index, sysfs="/sys"):
+    """CPUs on the NUMA node of HIP device `index` (KFD topology order), or None when it cannot be told."""
+    try:
+        nodes = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for n in sorted(os.listdir(nodes), key=int):
+            props = dict(line.split()[:2] for line in open(os.path.join(nodes, n, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        p = gpus[index]
+        loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        return _parse_cpulist(open(os.path.join(sysfs, "bus/pci/devices", bdf, "local_cpulist")).read()) or None
+    except Exception:
+        return None
+
+
+def rank_cpu_mask(local_rank, world, avail, local_cpus_of=None):
+    """CPUs for rank `local_rank` of `world` on this node.  avail: CPUs this process may use; local_cpus_of(r): CPUs near rank r's
+    GPU or None.  Ranks whose GPUs share a locality split it evenly, in rank order; without locality: a contiguous split of avail.
+    Every rank gets at least one CPU; masks of different ranks are disjoint whenever there are at least `world` CPUs."""
+    avail = sorted(avail)
+    if world <= 1 or not avail:
+        return avail
+    near = [local_cpus_of(r) if local_cpus_of else None for r in range(world)]
+    if all(n for n in near):
+        mine = sorted(set(near[local_rank]) & set(avail))
+        peers = [r for r in range(world) if sorted(set(near[r]) & set(avail)) == mine]
+        if mine and len(mine) >= len(peers):
+            per = len(mine) // len(peers)
+            i = peers.index(local_rank)
+            return mine[i * per:(i + 1) * per]
+    per = max(1, len(avail) // world)
+    lo = (local_rank * per) % len(avail)
+    return avail[lo:lo + per]
+
+
+def pin_rank(local_rank, world):
+    """Pins the calling process (call before the first GPU call); returns what it did, for the bench line."""
+    if world <= 1:
+        return None
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        mask = rank_cpu_mask(local_rank, world, avail, gpu_local_cpus)
+        os.sched_setaffinity(0, mask)
+        numa = gpu_local_cpus(local_rank) is not None
+        return {"cpus": "%d-%d" % (mask[0], mask[-1]) if mask == list(range(mask[0], mask[-1] + 1)) else ",".join(map(str, mask)),
+                "n": len(mask), "from": "GPU-local CPUs (sysfs)" if numa else "contiguous share"}
+    except Exception as e:       # never fatal: an unpinned rank is slower, not wrong
+        return {"error": str(e)}

@@ -124,6 +124,42 @@ class ShardedPipeline:
         for c in self.ctxs:
             self.gather_bucket(c)
 
+    def set_gather_every(self, gather_every, sync=None):
+        """Changes the bucket size between timed regions (all ranks, same value): flushes, waits (`sync`: the caller's
+        barrier + device synchronisation -- the buffers of a collective still in flight must not be released), then re-makes
+        the send / receive buffers for the new size."""
+        self.flush()
+        if sync is not None:
+            sync()
+        self.GE = max(1, int(gather_every))
+        if not self.do_gather:
+            return
+        for c in self.ctxs:
+            c.send = torch.empty(self.GE * self.rec_bytes, dtype=torch.uint8, device=self.send_device)
+            if self.rank == 0:
+                c.recv = [torch.empty(self.GE * self.rec_bytes, dtype=torch.uint8, device=self.coll_device) for _ in range(self.world)]
+
+
+def gather_sweep(pipe, sync, world, coll_device, values=(1, 4, 16), warm=6, steps=24, clock=None):
+    """Short timed regions at several bucket sizes (after the headline region, which keeps its own setting): ms per step, MAX
+    over ranks, per value -- one multi-GPU run then shows which cadence this node wants.  Restores the pipeline's setting."""
+    import time
+    clock = clock or time.perf_counter
+    keep = pipe.GE
+    out = {}
+    for ge in values:
+        pipe.set_gather_every(ge, sync)
+        for k in range(warm):
+            pipe.step(k)
+        sync()
+        t0 = clock()
+        for k in range(steps):
+            pipe.step(k)
+        sync()
+        out[str(ge)] = max_over_ranks(clock() - t0, world, coll_device) / steps * 1e3
+    pipe.set_gather_every(keep, sync)
+    return out
+
 
 def max_over_ranks(seconds, world, device="cpu"):
     """The timed region's duration as the driver wants it: MAX over ranks."""

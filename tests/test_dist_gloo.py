@@ -176,3 +176,53 @@ def test_fem_displacement_gather(tmp_path):
     assert np.array_equal(allx, ref)
     from orb_slam2_e_amd.shard import gather_displacements
     assert np.array_equal(gather_displacements(ref, 0, 1), ref)     # N = 1: no collective
+
+
+def _worker_sweep(rank, world, port, out):
+    _init(rank, world, port)
+    from orb_slam2_e_amd.shard import ShardedPipeline, gather_sweep
+    rec_bytes = 512
+    got = []
+    state = {}
+
+    def compute(c, k):
+        state[c.index] = torch.from_numpy(_pattern(rank, k, rec_bytes))
+
+    def pack(c, dst):
+        dst.copy_(state[c.index])
+
+    pipe = ShardedPipeline(rank, world, rec_bytes, 3, 4, compute, pack, on_receive=lambda k, r, rec: got.append((pipe.GE, k, r, rec.numpy().copy())))
+
+    def sync():
+        pipe.flush()
+        dist.barrier()
+
+    for k in range(5):                     # a partial bucket is pending when the sweep starts
+        pipe.step(k)
+    ticks = iter(range(1000))
+    sweep = gather_sweep(pipe, sync, world, "cpu", values=(1, 4, 16), warm=2, steps=7, clock=lambda: float(next(ticks)))
+    assert pipe.GE == 4 and all(c.nfill == 0 for c in pipe.ctxs)
+    assert all(c.send.numel() == 4 * rec_bytes for c in pipe.ctxs)
+    assert sorted(sweep) == ["1", "16", "4"] and all(abs(v - 1e3 / 7) < 1e-9 for v in sweep.values())    # one clock tick per region
+    pipe.step(99); pipe.flush()
+    dist.barrier()
+    if rank == 0:
+        with open(out, "wb") as f:
+            pickle.dump(got, f)
+    dist.destroy_process_group()
+
+
+def test_gather_sweep_at_world_8(tmp_path):
+    """BASELINE config 4's shape: after the headline region the bench re-runs short regions at --gather-every 1 / 4 / 16 and puts
+    the cadence back; every record of every region arrives once, with the right bytes, under the bucket size in force."""
+    out = str(tmp_path / "s.pkl")
+    mp.spawn(_worker_sweep, args=(8, _free_port(), out), nprocs=8, join=True)
+    got = pickle.load(open(out, "rb"))
+    by_ge = {}
+    for ge, k, r, rec in got:
+        assert np.array_equal(rec, _pattern(r, k, 512)), (ge, k, r)
+        by_ge.setdefault(ge, []).append((k, r))
+    # headline setting: steps 0..4 (their last partial bucket leaves in the first set_gather_every) and step 99
+    assert sorted(by_ge[4]) == sorted([(k, r) for k in list(range(5)) + list(range(2)) + list(range(7)) + [99] for r in range(8)])
+    for ge in (1, 16):
+        assert sorted(by_ge[ge]) == sorted([(k, r) for k in list(range(2)) + list(range(7)) for r in range(8)])

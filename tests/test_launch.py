@@ -116,3 +116,27 @@ def test_bench_gpus2_spawns_two_ranks_and_fails_loudly_without_gpus():
     assert r.returncode != 0
     assert "needs GPU" in r.stderr and "[rank " in r.stderr
     assert not r.stdout.strip()
+
+
+def test_rank_cpu_masks():
+    """bench.py pins every rank before it touches the GPU: masks are disjoint, non-empty, inside what the process may use, and
+    follow the GPUs' locality when sysfs tells it (ranks behind one socket share that socket's CPUs evenly)."""
+    from orb_slam2_e_amd import launch
+    avail = list(range(384))
+    near = lambda r: list(range(0, 96)) + list(range(192, 288)) if r < 4 else list(range(96, 192)) + list(range(288, 384))
+    masks = [launch.rank_cpu_mask(r, 8, avail, near) for r in range(8)]
+    assert all(len(m) == 48 for m in masks)
+    assert len(set().union(*map(set, masks))) == 384
+    assert all(set(masks[r]) <= set(near(r)) for r in range(8))
+    # no topology: contiguous shares; fewer CPUs than ranks: everybody still gets one
+    masks = [launch.rank_cpu_mask(r, 8, list(range(16)), None) for r in range(8)]
+    assert masks == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert all(len(launch.rank_cpu_mask(r, 8, [3, 5, 9], None)) == 1 for r in range(8))
+    # a restricted process (cgroup / taskset): locality is intersected with what is allowed; a rank whose GPU's CPUs are all
+    # outside falls back to the contiguous share
+    masks = [launch.rank_cpu_mask(r, 2, list(range(0, 8)), lambda r: list(range(4 * r, 4 * r + 4))) for r in range(2)]
+    assert masks == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert launch.rank_cpu_mask(1, 2, [0, 1], lambda r: [100, 101]) == [1]
+    assert launch.rank_cpu_mask(0, 1, [4, 5], None) == [4, 5]
+    assert launch._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert launch.pin_rank(0, 1) is None
