@@ -164,9 +164,40 @@ def _parse_cpulist(text):
     return cpus
 
 
+def _drm_local_cpus(index, sysfs):
+    """The AMD render nodes' PCI functions in bus order (the order the runtime enumerates the GPUs of one node in), the index-th one's
+    local_cpulist.  Readable without privileges, unlike the KFD topology's per-node properties."""
+    drm = os.path.join(sysfs, "class/drm")
+    devs = set()
+    for name in os.listdir(drm):
+        if not name.startswith("renderD"):
+            continue
+        dev = os.path.realpath(os.path.join(drm, name, "device"))
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip().lower() != "0x1002":
+                continue
+        except OSError:
+            continue
+        devs.add(dev)
+    dev = sorted(devs, key=os.path.basename)[index]
+    return _parse_cpulist(open(os.path.join(dev, "local_cpulist")).read()) or None
+
+
 def gpu_local_cpus(index, sysfs="/sys"):
-    """CPUs on the NUMA node of HIP device `index` (KFD topology order), or None when it cannot be told."""
+    """CPUs on the NUMA node of HIP device `index` (KFD topology order; else the render nodes in PCI bus order), or None when it
+    cannot be told."""
     try:
+        return _kfd_local_cpus(index, sysfs)
+    except Exception:
+        pass
+    try:
+        return _drm_local_cpus(index, sysfs)
+    except Exception:
+        return None
+
+
+def _kfd_local_cpus(index, sysfs):
+    if True:
         nodes = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
         gpus = []
         for n in sorted(os.listdir(nodes), key=int):
@@ -177,8 +208,6 @@ def gpu_local_cpus(index, sysfs="/sys"):
         loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
         bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
         return _parse_cpulist(open(os.path.join(sysfs, "bus/pci/devices", bdf, "local_cpulist")).read()) or None
-    except Exception:
-        return None
 
 
 def rank_cpu_mask(local_rank, world, avail, local_cpus_of=None):

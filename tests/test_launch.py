@@ -140,3 +140,27 @@ def test_rank_cpu_masks():
     assert launch.rank_cpu_mask(0, 1, [4, 5], None) == [4, 5]
     assert launch._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert launch.pin_rank(0, 1) is None
+
+
+def test_gpu_locality_from_a_fake_sysfs(tmp_path):
+    """Both sources of a GPU's local CPUs, on a made-up /sys: the KFD topology (location_id -> PCI function) and, when its per-node
+    files are unreadable (they are for unprivileged users on the GPU boxes), the AMD render nodes in bus order."""
+    from orb_slam2_e_amd import launch
+    sys_ = tmp_path / "sys"
+    for i, (bdf, cpus) in enumerate([("0000:05:00.0", "0-3"), ("0000:85:00.0", "4-7")]):
+        d = sys_ / "bus/pci/devices" / bdf
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(cpus + "\n"); (d / "vendor").write_text("0x1002\n")
+        r = sys_ / "class/drm" / f"renderD{128 + i}"
+        r.mkdir(parents=True)
+        (r / "device").symlink_to(d)
+    other = sys_ / "bus/pci/devices/0000:01:00.0"; other.mkdir(parents=True)
+    (other / "local_cpulist").write_text("0-7\n"); (other / "vendor").write_text("0x1a03\n")
+    r = sys_ / "class/drm/renderD130"; r.mkdir(parents=True); (r / "device").symlink_to(other)      # a BMC's VGA: not a GPU of ours
+    assert launch.gpu_local_cpus(0, str(sys_)) == [0, 1, 2, 3] and launch.gpu_local_cpus(1, str(sys_)) == [4, 5, 6, 7]
+    assert launch.gpu_local_cpus(2, str(sys_)) is None
+    nodes = sys_ / "class/kfd/kfd/topology/nodes"
+    for n, (simd, loc) in enumerate([(0, 0), (256, 0x8500), (256, 0x0500)]):       # KFD order differs from bus order here: it wins
+        (nodes / str(n)).mkdir(parents=True)
+        (nodes / str(n) / "properties").write_text(f"cpu_cores_count 8\nsimd_count {simd}\ndomain 0\nlocation_id {loc}\n")
+    assert launch.gpu_local_cpus(0, str(sys_)) == [4, 5, 6, 7] and launch.gpu_local_cpus(1, str(sys_)) == [0, 1, 2, 3]
