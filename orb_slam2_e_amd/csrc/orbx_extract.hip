@@ -1183,7 +1183,7 @@ constexpr int BLUR_IROW = 144;                                                 /
 // result can exceed 255.  Otherwise the first product starts from 0 and nothing saturates.
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                              size_t frame_bytes, const LevelInfo *__restrict__ L,
+                                              size_t frame_bytes, size_t blur_frame_bytes, const LevelInfo *__restrict__ L,
                                               const BlurTile *__restrict__ tiles, int ntiles,
                                               const uint4 *__restrict__ frag, int seed2)
 {
@@ -1258,13 +1258,15 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // rows out as 16-byte pieces: 6 per row
+    // rows out as 16-byte pieces, 6 per row, into the strip layout (orbx_internal.h): piece c of a row is one row of strip
+    // (PADX + x) / 16 -- a lane's piece and the pieces of the rows above and below it in the same strip are contiguous
+    uint8_t *const bdst = blur + (size_t)f * blur_frame_bytes + bt.boff;
 #pragma unroll
     for (int s = 0; s < (BLUR_TH * (BLUR_SW / 16) + 63) / 64; ++s) {
-        const int i = lane + 64 * s, row = i / (BLUR_SW / 16), c = i - row * (BLUR_SW / 16);
+        const int i = lane + 64 * s, c = i / BLUR_TH, row = i - c * BLUR_TH;   // rows fastest: four neighbouring lanes = 64 contiguous bytes of a strip
         const int x = bt.x0 + 16 * c, y = bt.y0 + row;
-        if (row < BLUR_TH && y < lv.h && x < lv.w)
-            *reinterpret_cast<uint4 *>(blur + base + (size_t)(y + EDGE) * lv.stride + x) =
+        if (c < BLUR_SW / 16 && y < lv.h && x < lv.w)
+            *reinterpret_cast<uint4 *>(bdst + (uint32_t)(((PADX + x) >> 4) * bt.bcol + (y + EDGE) * 16)) =
                 *reinterpret_cast<const uint4 *>(st + row * BLUR_LROW + 16 * c);
     }
 }
@@ -1353,10 +1355,11 @@ constexpr int DESC_KPB = 16, DESC_PD = 1;
 // chunk_base[level] <= item < chunk_base[level + 1]: 16 consecutive entries of that level's selected-keypoint slots.
 struct DescLevels {
     int off[MAXL], stride[MAXL], sel_base[MAXL], patch[MAXL], chunk_base[MAXL + 1];
+    int boff[MAXL], bcol[MAXL];   // the level in the blurred buffer's strip layout
     float scale[MAXL];
 };
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
-                                                  size_t frame_bytes, const DescLevels D, int nlevels,
+                                                  size_t frame_bytes, size_t blur_frame_bytes, const DescLevels D, int nlevels,
                                                   const uint32_t *__restrict__ sel_all, int sel_per_frame,
                                                   const int *__restrict__ level_count,
                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
@@ -1365,8 +1368,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ uint32_t s_coff[DESC_KPB];   // patch centre, byte offset inside the frame's pyramid
     __shared__ int s_valid[DESC_KPB], s_out[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
     __shared__ uint32_t s_pk[DESC_KPB];
+    __shared__ uint32_t s_boff[DESC_KPB];   // blurred window: byte offset of (strip of its first aligned piece, first aligned row) in the frame's strips
+    __shared__ int s_bx[DESC_KPB];          // bits 0-3 (x - 18) mod 16: bit 3 = which half of the strip the first piece is, bits 0-2 = shift inside it; bits 4-5: (y - 18) mod 4
     __shared__ float s_angle[DESC_KPB], s_cos[DESC_KPB], s_sin[DESC_KPB];
-    __shared__ uint32_t s_patch[4][37 * 10 + 14];
+    __shared__ uint32_t s_patch[4][40 * 12 + 4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     ORBX_PH_INIT(1);
     int f, item;
@@ -1397,34 +1402,47 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_out[tid] = first + j;
         s_pk[tid] = pk;
         s_coff[tid] = (uint32_t)(D.off[level] + (y + EDGE) * stride + PADX + x);
+        const int X = PADX + x - 18;                 // window origin in the padded row (>= PADX - 2)
+        const int Y = y + EDGE - 18;                 // window's first row in the padded level
+        s_boff[tid] = (uint32_t)(D.boff[level] + (X >> 4) * D.bcol[level] + (Y & ~3) * 16);
+        s_bx[tid] = (X & 15) | ((Y & 3) << 4);
     }
     __syncthreads();
     ORBX_PH(8, tid == 0);    // keypoint lookup
     if (!s_valid[0]) return; // a level's slots fill from 0: nothing in this chunk
-    const uint8_t *const fpyr = pyr + (size_t)f * frame_bytes, *const fblur = blur + (size_t)f * frame_bytes;
+    const uint8_t *const fpyr = pyr + (size_t)f * frame_bytes, *const fblur = blur + (size_t)f * blur_frame_bytes;
     // IC_Angle (:77-104): every lane owns 4 dwords of the 31x31 window (fixed per lane, so are
     // their weights) and reads them straight from the unblurred level; two dot4 per dword.
     // No branches on "slot in use": an unused slot reads the window of slot 0 (in use, see above) and its results are
     // dropped, so the loads of all four keypoints of a wave are in flight together.
     uint32_t *patch = s_patch[wv];
-    // The 37x37 blurred window of steered BRIEF (|offset| <= 18) is staged in LDS as 37 rows of 10 dwords starting at
-    // (x-18, y-18); every lane owns six fixed dwords of it (dword jj*64 + lane).  The windows are loaded PD keypoints
-    // ahead of their use, the first ones together with the moment windows: they depend on the keypoint's position only
-    constexpr int PR = 18, PW = 10, PD = DESC_PD, NPL = 3; // patch radius; row = 10 dwords = bytes x-18 .. x+21; prefetch distance; loads per lane
-    // lane d (+ 64 jj) owns the 8-byte piece d % 5 of row d / 5: three 8-byte loads per window instead of six dwords
-    uint32_t poff[NPL]; int pslot[NPL];
+    // The 37x37 blurred window of steered BRIEF (|offset| <= 18) is staged in LDS as 40 rows of 12 dwords: the 8-byte ALIGNED pieces
+    // that cover columns x-18 .. x+18 (six per row; the window starts (x - 18) mod 8 bytes into the first), from the 4-ALIGNED row at
+    // or above y-18.  Aligned pieces never straddle a strip of the blurred buffer, and in a strip consecutive rows are 16 bytes
+    // apart: four lanes that take the same piece of four consecutive aligned rows read one 64-byte span -- the unit the texture
+    // addresser works in -- so a wave-wide load is 16 of those instead of ~35 (row-major: the four lanes of a group sat in two rows).
+    // Every lane owns four fixed pieces (piece d + 64 jj: row d % 40, column d / 40); which strip a column falls into depends on
+    // whether the window starts in the first or the second half of its strip -- two offset sets per lane, chosen per keypoint by a
+    // wave-uniform select.  The windows are loaded PD keypoints ahead of their use, the first ones together with the moment
+    // windows: they depend on the keypoint's position only
+    constexpr int PR = 18, PW = 12, PROWS = 40, PD = DESC_PD, NPL = 4; // patch radius; LDS row = 12 dwords; staged rows; prefetch distance; loads per lane
+    const int bcol = D.bcol[level];
+    uint32_t poffA[NPL], poffB[NPL]; int pslot[NPL];
 #pragma unroll
     for (int jj = 0; jj < NPL; ++jj) {
-        const int d = lane + 64 * jj, dd = min(d, (2 * PR + 1) * 5 - 1);   // pieces past the window repeat its last one
-        poff[jj] = (uint32_t)(__mul24(dd / 5, stride) + 8 * (dd % 5));
-        pslot[jj] = 2 * dd;
+        const int d = lane + 64 * jj, dd = min(d, PROWS * 6 - 1);   // pieces past the window repeat its last one
+        const int col = dd / PROWS, row = dd - PROWS * col;
+        poffA[jj] = (uint32_t)(row * 16 + __mul24((8 * col) >> 4, bcol) + ((8 * col) & 15));
+        poffB[jj] = (uint32_t)(row * 16 + __mul24((8 + 8 * col) >> 4, bcol) + ((8 + 8 * col) & 15) - 8);   // (the base below already carries the 8)
+        pslot[jj] = row * PW + 2 * col;
     }
     uint2 nxt[PD][NPL];
     auto load_patch = [&](int j, uint2 (&r)[NPL]) {   // unused slots read slot 0's window (no branch in front of a load)
         const int kp = wv * (DESC_KPB / 4) + j, kpv = s_valid[kp] ? kp : 0;
-        const uint8_t *win = fblur + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_coff[kpv]) - PR - (ptrdiff_t)PR * stride; // (x-18, y-18)
+        const int bx = __builtin_amdgcn_readfirstlane(s_bx[kpv]);
+        const uint8_t *win = fblur + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_boff[kpv]) + (bx & 8);   // first aligned piece of row y-18
 #pragma unroll
-        for (int jj = 0; jj < NPL; ++jj) __builtin_memcpy(&r[jj], win + poff[jj], 8);
+        for (int jj = 0; jj < NPL; ++jj) __builtin_memcpy(&r[jj], win + ((bx & 8) ? poffB[jj] : poffA[jj]), 8);
     };
     // IC_Angle window, 31 rows x 32 bytes from (x-15, y-15): lane d (+ 64 jj) owns the 8-byte piece d % 4 of row d / 4 (dwords
     // 2 (d % 4) and + 1 of that row): two 8-byte loads per keypoint instead of four dwords; pieces past row 30 re-read row 0 with
@@ -1507,7 +1525,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         if (j + PD < DESC_KPB / 4) load_patch(j + PD, nxt[j % PD]);
         if (!s_valid[kp]) continue;
         // patch centre, minus what the magic-number bits add: (0x400000 * 40 + 0x4B400000) mod 2^32
-        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + PR * (PW * 4) + PR;
+        const int bxs = __builtin_amdgcn_readfirstlane(s_bx[kp]);
+        const uint8_t *pc = reinterpret_cast<const uint8_t *>(patch) + (PR + (bxs >> 4)) * (PW * 4) + PR + (bxs & 7);
         const f32x2 ab = {a, b}, ba = {b, a}, magic = {12582912.0f, 12582912.0f};
         unsigned nib = 0, tv[8];
 #pragma unroll
@@ -1763,6 +1782,7 @@ static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int
     ex->cells.clear(); ex->tiles.clear();
     size_t off = 0, cand_off = 0, key_off = 0;
     int sel_off = 0, maxcw = 0, maxch = 0, kneed = 0;
+    size_t boff_run = 0;
     ex->maxcells = 0;
     for (int l = 0; l < nl; l++) {
         LevelInfo &lv = ex->lv[l];
@@ -1775,6 +1795,10 @@ static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int
         lv.off = (int)off;
         off += (size_t)lv.stride * (lv.h + 2 * EDGE);
         off = (off + 255) & ~(size_t)255;
+        // the same level in the blurred buffer's strip layout: stride / 16 strips of ((rows + 7) & ~7) x 16 bytes
+        ex->bcol[l] = ((lv.h + 2 * EDGE + 7) & ~7) * 16;
+        ex->boff[l] = (int)boff_run;
+        boff_run += (size_t)(lv.stride / 16) * ex->bcol[l];
         lv.scale = ex->scale[l];
         lv.patch = (int)(31 * ex->scale[l]); // :845
         lv.N = ex->nfeat[l];
@@ -1832,6 +1856,7 @@ static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int
         for (int y0 = 0; y0 < lv.h; y0 += BLUR_TH)
             for (int x0 = 0; x0 < lv.w; x0 += BLUR_SW) {
                 BlurTile t; t.x0 = (short)x0; t.y0 = (short)y0; t.w = (short)lv.w; t.h = (short)lv.h; t.off = lv.off; t.stride = lv.stride;
+                t.boff = ex->boff[l]; t.bcol = ex->bcol[l]; t.pad[0] = t.pad[1] = 0;
                 ex->tiles.push_back(t);
             }
         // resize tables from level l-1
@@ -1881,6 +1906,7 @@ static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int
         }
     }
     ex->frame_bytes = off;
+    ex->blur_frame_bytes = (boff_run + 255) & ~(size_t)255;
     ex->cands_per_frame = cand_off;
     ex->keys_per_frame = key_off;
     ex->cells_per_frame = (int)ex->cells.size();
@@ -1950,8 +1976,8 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     const size_t B = (size_t)batch;
     ORBX_HIP(hipMalloc(&ex->d_pyr, ex->frame_bytes * B));
     ORBX_HIP(hipMemset(ex->d_pyr, 0, ex->frame_bytes * B)); // the row padding outside the 19-px border is never written by k_pyr_resize
-    ORBX_HIP(hipMalloc(&ex->d_blur, ex->frame_bytes * B));
-    ORBX_HIP(hipMemset(ex->d_blur, 0, ex->frame_bytes * B));
+    ORBX_HIP(hipMalloc(&ex->d_blur, ex->blur_frame_bytes * B));
+    ORBX_HIP(hipMemset(ex->d_blur, 0, ex->blur_frame_bytes * B));
     ORBX_HIP(hipMalloc(&ex->d_lv, sizeof(LevelInfo) * MAXL));
     {
         int dev = 0, ncu = 0;
@@ -2130,10 +2156,10 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         const int S = 2 * (ex->taps[0] + ex->taps[1] + ex->taps[2]) + ex->taps[3], nt = (int)ex->tiles.size();
         const dim3 grid((unsigned)((nt + 3) / 4), batch);
         if (S > 256)
-            hipLaunchKernelGGL(k_blur<true>, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->d_lv, ex->d_tiles, nt,
+            hipLaunchKernelGGL(k_blur<true>, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->blur_frame_bytes, ex->d_lv, ex->d_tiles, nt,
                                ex->d_blur_frag, 128 * S * S + 32768);
         else
-            hipLaunchKernelGGL(k_blur<false>, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->d_lv, ex->d_tiles, nt,
+            hipLaunchKernelGGL(k_blur<false>, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->blur_frame_bytes, ex->d_lv, ex->d_tiles, nt,
                                ex->d_blur_frag, S * (128 + 128 * S) + 32768);
     }
     pf.stop(4, st);
@@ -2145,11 +2171,12 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         for (int l = 0; l < nl; l++) {
             const LevelInfo &lv = ex->lv[l];
             D.off[l] = lv.off; D.stride[l] = lv.stride; D.sel_base[l] = lv.sel_base; D.patch[l] = lv.patch; D.scale[l] = lv.scale;
+            D.boff[l] = ex->boff[l]; D.bcol[l] = ex->bcol[l];
             D.chunk_base[l] = nchunks;
             nchunks += (level_slots(lv) + DESC_KPB - 1) / DESC_KPB;   // a level holds at most max(N + 3, 4 nIni) keypoints
         }
         for (int l = nl; l <= MAXL; l++) D.chunk_base[l] = nchunks;
-        hipLaunchKernelGGL(k_describe, dim3(nchunks, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, D, nl,
+        hipLaunchKernelGGL(k_describe, dim3(nchunks, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->blur_frame_bytes, D, nl,
                            ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps, ex->d_desc, ex->d_counts, ex->kcap, ex->prm.trig_variant);
     }
     pf.stop(5, st);
@@ -2386,7 +2413,24 @@ int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, uint8_t *out, i
 int orbx_pyramid_level_padded(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride)
 { return copy_level(ex, ex ? ex->d_pyr : nullptr, frame, level, out, out_stride, 1); }
 int orbx_debug_blurred_level(orbx_extractor *ex, int frame, int level, uint8_t *out, int out_stride)
-{ return copy_level(ex, ex ? ex->d_blur : nullptr, frame, level, out, out_stride, 0); }
+{
+    // the blurred buffer is laid out in strips (orbx_internal.h): the level's strips come over whole and are put back into rows here
+    if (!ex || !ex->d_blur || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->nlevels || !out)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad frame/level");
+    const LevelInfo &lv = ex->lv[level];
+    if (out_stride < lv.w) ORBX_FAIL(ORBX_ERR_ARG, "out_stride too small");
+    const int nstrips = lv.stride / 16, bcol = ex->bcol[level];
+    std::vector<uint8_t> strips((size_t)nstrips * bcol);
+    ORBX_HIP(hipMemcpyAsync(strips.data(), ex->d_blur + (size_t)frame * ex->blur_frame_bytes + ex->boff[level], strips.size(),
+                            hipMemcpyDeviceToHost, ex->last_stream));
+    ORBX_HIP(hipStreamSynchronize(ex->last_stream));
+    for (int y = 0; y < lv.h; ++y)
+        for (int x = 0; x < lv.w; ++x) {
+            const int X = PADX + x;
+            out[(size_t)y * out_stride + x] = strips[(size_t)(X >> 4) * bcol + (size_t)(y + EDGE) * 16 + (X & 15)];
+        }
+    return ORBX_OK;
+}
 
 int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, float *xyr, int cap, int *n)
 {

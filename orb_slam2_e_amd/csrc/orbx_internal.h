@@ -53,7 +53,7 @@ struct alignas(16) CellInfo : FastCell {
 
 // a blur tile strip with what k_blur needs of its level: 16 bytes, one scalar load (a tile record pointing into the level
 // table was two dependent loads, the first a per-lane one, in front of the window loads)
-struct alignas(16) BlurTile { short x0, y0, w, h; int off, stride; };
+struct alignas(16) BlurTile { short x0, y0, w, h; int off, stride; int boff, bcol; int pad[2]; };   // boff / bcol: the level in the blurred buffer's strip layout
 
 } // namespace orbx_detail
 
@@ -82,6 +82,12 @@ struct orbx_extractor {
     std::vector<orbx_detail::CellInfo> cells;
     std::vector<orbx_detail::BlurTile> tiles;
     size_t frame_bytes = 0, cands_per_frame = 0, keys_per_frame = 0;
+    // the blurred pyramid (private to k_blur -> k_describe) in STRIPS: a level is lv.stride / 16 column strips of 16 px, a strip's rows
+    // one after the other (16 bytes apart), bcol = rows x 16 bytes per strip with the row count rounded up to 8 -- a 128-byte line holds
+    // 8 rows x 16 px, and the 37 x 37 window of a descriptor spans a dozen lines instead of 37-74 (k_describe is bound by the texture
+    // addresser's line count)
+    size_t blur_frame_bytes = 0;
+    int boff[orbx_detail::MAXL] = {}, bcol[orbx_detail::MAXL] = {};
     int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
     int TS = 0, tile_bytes = 0, SS = 0, sc_bytes = 0, fast_lds = 0, queue_bytes = 0, oct_lds = 0, oct_kcap = 0, oct_kshift = 11;
 
