@@ -328,3 +328,55 @@ def test_keyframe_forms_use_the_keyframes_int_bounds():
     # (whether the two sets of bounds give different answers on this scene is not asserted: the quirk bites at cell borders only)
     del plain
     kf.close(); kf2.close()
+
+
+def test_stereo_frame_handle_takes_uright_from_the_device():
+    """A stereo frame: both extractions, Frame::ComputeStereoMatches on the device, and the resident frame made from the LEFT
+    extractor's device results with mvuRight taken where orbx_stereo_match left it -- equal to the handle made from the host arrays,
+    in layout and in a stereo-checked SearchByProjection(Cur, Last); frames of a batch are addressed by index."""
+    from orb_slam2_e_amd import ComputeStereoMatches
+    from orb_slam2_e_amd.synth import synth_stereo_pair
+    prm = (1200, 1.2, 8, 20, 7)
+    left, right = synth_stereo_pair(1, 640, 480)
+    eL, eR = ORBextractor(*prm), ORBextractor(*prm)
+    kps, desc = eL(left); eR(right)
+    mbf = np.float32(40.0); mb = mbf / np.float32(500.0)
+    ur, depth = ComputeStereoMatches(eL, eR, mb, mbf)
+    assert (ur >= 0).sum() > 100
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    f_dev = Frame.from_extractor(eL, 0, bounds, uright_from_stereo=True)
+    f_host = Frame(kps, desc, bounds, ur)
+    f_mix = Frame.from_extractor(eL, 0, bounds, uright=ur)
+    for f in (f_dev, f_mix):
+        assert f.n == f_host.n and np.array_equal(f.layout()[0], f_host.layout()[0])
+    s = synth_tracking_scene(33, n=len(kps), stereo=True, motion="forward")
+    rng = np.random.default_rng(3)
+    nl = len(kps)
+    src = rng.integers(0, len(kps), nl)
+    fx, fy, cx, cy = [np.float64(v) for v in s["cam"]]
+    z = np.where(ur[src] > 0, np.float64(mbf) / np.maximum(kps["x"][src] - ur[src], 0.5), rng.uniform(1, 8, nl))   # consistent with the right coordinate where there is one
+    Pc = np.stack([(kps["x"][src] + rng.normal(0, 1.0, nl) - cx) / fx * z, (kps["y"][src] + rng.normal(0, 1.0, nl) - cy) / fy * z, z], 1)
+    R = s["Tcw"][:3, :3].astype(np.float64); t = s["Tcw"][:3, 3].astype(np.float64)
+    pos = ((Pc - t) @ R).astype(np.float32)
+    mpd = desc[src] ^ np.packbits(rng.random((nl, 256)) < 0.04, axis=1, bitorder="little")
+    valid = np.ones(nl, np.uint8); takes = np.ones(nl, np.uint8)
+    loct = kps["octave"][src].astype(np.int32); lang = kps["angle"][src].astype(np.float32)
+    last = Points(valid, pos, mpd, takes=takes, octave=loct, angle=lang)
+    m = ORBmatcher(0.9, True)
+    ref = oracle.search_by_projection_last(kps, desc, ur, None, bounds, s["cam"], s["mb"], s["mbf"], s["Tcw"], s["scale_factors"], s["Tlw"],
+                                           valid, pos, mpd, takes, loct, lang, 7.0, False)
+    nost = oracle.search_by_projection_last(kps, desc, None, None, bounds, s["cam"], s["mb"], s["mbf"], s["Tcw"], s["scale_factors"], s["Tlw"],
+                                            valid, pos, mpd, takes, loct, lang, 7.0, False)
+    assert not np.array_equal(ref[0], nost[0])          # the stereo check does decide something on this input
+    for f in (f_dev, f_host, f_mix):
+        got = m.SearchByProjectionLast(f, _view(s), s["Tcw"], s["Tlw"], last, None, 7.0, False)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2] and ref[2] > 100
+        f.close()
+    # a batch: frame 2 of three
+    imgs = np.stack([synth_frame(40 + k) for k in range(3)])
+    eb = ORBextractor(*prm)
+    eb.extract_batch(imgs)
+    k2, d2 = eb.download(2)
+    fb = Frame.from_extractor(eb, 2, bounds); fh = Frame(k2, d2, bounds)
+    assert fb.n == len(k2) and np.array_equal(fb.layout()[0], fh.layout()[0]) and np.array_equal(fb.layout()[1], fh.layout()[1])
+    fb.close(); fh.close()
