@@ -68,6 +68,18 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 // (its own stores are visible to it after the workgroup-scope fence).  Lists of up to 256 entries -- a window's usual few tens --
 // are read ONCE, four entries per lane, and the rounds run on registers (every round used to re-read the list: eight dependent
 // trips to L1 / L2 per query).
+// the rounds on registers: every lane holds up to four (key, entry) pairs, keys unique (0xffffffff: none)
+__device__ __forceinline__ void wave_topk_regs(unsigned (&key)[4], const unsigned (&en)[4], int lane, unsigned *__restrict__ top_i)
+{
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        const unsigned g = wave_min_u32(min(min(key[0], key[1]), min(key[2], key[3])));
+        if (g == 0xffffffffu) { if (lane == 0) top_i[t] = 0xffffffffu; continue; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (key[r] == g) { top_i[t] = en[r]; key[r] = 0xffffffffu; }     // keys are unique: one lane, one slot
+    }
+}
 __device__ __forceinline__ void wave_topk(const unsigned *__restrict__ ent, int b, int len, int lane, unsigned *__restrict__ top_i)
 {
     if (len <= 256) {
@@ -78,14 +90,7 @@ __device__ __forceinline__ void wave_topk(const unsigned *__restrict__ ent, int 
             en[r] = p < len ? ent[b + p] : 0xffffffffu;
             key[r] = en[r] != 0xffffffffu ? ((en[r] >> 20) << 16) | (unsigned)p : 0xffffffffu;
         }
-#pragma unroll
-        for (int t = 0; t < TOPK; ++t) {
-            const unsigned g = wave_min_u32(min(min(key[0], key[1]), min(key[2], key[3])));
-            if (g == 0xffffffffu) { if (lane == 0) top_i[t] = 0xffffffffu; continue; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (key[r] == g) { top_i[t] = en[r]; key[r] = 0xffffffffu; }     // keys are unique: one lane, one slot
-        }
+        wave_topk_regs(key, en, lane, top_i);
         return;
     }
     unsigned prev = 0;
@@ -137,6 +142,10 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
     const int nMinCellY = (int)fmaxf(0.f, floorf((w.v - gp.min_y - w.r) * gp.inv_h));
     const int nMaxCellY = (int)fminf((float)FRAME_GRID_ROWS - 1, ceilf((w.v - gp.min_y + w.r) * gp.inv_h));
     const bool none = !(w.r >= 0.f) || nMinCellX >= FRAME_GRID_COLS || nMaxCellX < 0 || nMinCellY >= FRAME_GRID_ROWS || nMaxCellY < 0;
+    // FILL = 2: the entries a lane produces also stay in its registers (one per 64-candidate step, up to four steps): the short list is
+    // then built without reading the list back (a fence and a memory round trip at the end of every wave's life)
+    unsigned rkey[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ren[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    int step = 0;
     if (!none) {
         const bool check_levels = (w.min_level > 0) || (w.max_level >= 0);
         uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
@@ -149,7 +158,11 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
                 const int k = kb + lane;
                 bool ok = k < k1;
                 SeqKp p = {0.f, 0.f, 0.f, 0};
-                if (ok) p = kp[k];
+                uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+                if (ok) {
+                    p = kp[k];
+                    if (FILL) { b0 = B[2 * k]; b1 = B[2 * k + 1]; }    // with the keypoint, not behind its tests: one memory round trip less per step
+                }
                 if (occ && ok) ok = occ[k] == 0;   // the slot holds a point from the start (e.g. ORBmatcher.cc:87-89): never a candidate
                 if (check_levels) ok = ok && !(p.octave < w.min_level) && !(w.max_level >= 0 && p.octave > w.max_level);
                 const float distx = p.x - w.u, disty = p.y - w.v;
@@ -157,10 +170,17 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
                 if (has_uright && p.uright > 0) ok = ok && !(fabsf(w.xr - p.uright) > w.r);
                 const unsigned long long bal = __ballot(ok);
                 if (FILL && ok && c + __popcll(bal & lt) < ocap) {
-                    const int dist = popc256(a0, a1, B[2 * k], B[2 * k + 1]);
-                    out[c + __popcll(bal & lt)] = dist < init_dist ? ((unsigned)dist << 20) | ((unsigned)p.octave << 16) | (unsigned)k : 0xffffffffu;
+                    const int dist = popc256(a0, a1, b0, b1), pos = c + __popcll(bal & lt);
+                    const unsigned en = dist < init_dist ? ((unsigned)dist << 20) | ((unsigned)p.octave << 16) | (unsigned)k : 0xffffffffu;
+                    out[pos] = en;
+                    if (FILL == 2 && en != 0xffffffffu) {
+                        const unsigned key = ((unsigned)dist << 16) | (unsigned)pos;
+                        if (step == 0) { rkey[0] = key; ren[0] = en; } else if (step == 1) { rkey[1] = key; ren[1] = en; }
+                        else if (step == 2) { rkey[2] = key; ren[2] = en; } else if (step == 3) { rkey[3] = key; ren[3] = en; }
+                    }
                 }
                 c += __popcll(bal);
+                ++step;
             }
         }
     }
@@ -170,8 +190,12 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
             lbeg[i] = obase; lend[i] = obase + min(c, ocap);
             if (c > ocap) *overflow = gen;          // this call's generation number: some list did not fit (no preset needed)
         }
-        __threadfence_block();
-        wave_topk(ent, obase, min(c, ocap), lane, top + (size_t)i * TOPK);
+        if (FILL == 2 && step <= 4) {
+            wave_topk_regs(rkey, ren, lane, top + (size_t)i * TOPK);
+        } else {
+            __threadfence_block();
+            wave_topk(ent, obase, min(c, ocap), lane, top + (size_t)i * TOPK);
+        }
     }
 }
 
