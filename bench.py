@@ -335,7 +335,7 @@ def load_fem_traffic():
 
 def load_traffic():
     """HBM bytes / VALU instruction counts per launch from the committed PMC passes (newest round first)."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
             return json.load(open(f))
