@@ -49,7 +49,10 @@ __device__ __forceinline__ int reflect101(int p, int n)
 // so every thread produces 4 pixels (one dword store) in PYR_ROWS rows and keeps
 // all of their loads in flight at once.  The 19-px REFLECT_101 border is
 // recomputed through the reflected coordinate instead of copied afterwards.
-constexpr int PYR_ROWS = 4;
+// Rows per thread, round 4 (same-box A/B of the pipelined step, three rounds each): 4 -> 0.2495 ms, 6 -> 0.2474, 8 -> 0.2447-0.2471,
+// 10 -> 0.2536, 16 -> 0.2568.  A resize launch alone is no faster with 8 (8.7 against 8.1 us: half the waves, each twice as long) -- but
+// the chain then holds half the wave slots while it waits for memory, and the other contexts' kernels get them.
+constexpr int PYR_ROWS = 8;
 
 #ifdef ORBX_PHASE_TIMING
 // development aid (never in the product build): shader-clock time per kernel phase, one record per workgroup (plain
