@@ -64,3 +64,23 @@ def check(rc):
     if rc != 0:
         raise OrbxError(rc, lib().orbx_last_error().decode())
     return rc
+
+
+_from_buffer, _addressof, _void_p = C.c_char.from_buffer, C.addressof, C.c_void_p
+
+
+def ptr(a):
+    """Address of a numpy array's data as c_void_p.  `a.ctypes.data_as(c_void_p)` costs ~3 us a piece -- with seven arrays a call
+    that is more than a 50-us search; the buffer protocol gives the same address in ~0.4 us.  Read-only and empty arrays (which
+    the writable-buffer request refuses) take the slow way."""
+    try:
+        return _void_p(_addressof(_from_buffer(a)))
+    except (TypeError, ValueError, BufferError):
+        return a.ctypes.data_as(_void_p)
+
+
+def bind(fn, argtypes):
+    """Sets a C function's argtypes once (assigning them costs ~1.5 us, so not per call)."""
+    if fn.argtypes is None:
+        fn.argtypes = argtypes
+    return fn

@@ -542,6 +542,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     (void)queue_bytes;
     int c, f;
     xcd_frame_item(f, c);
+    c = cells_per_frame - 1 - c;   // dispatch order: the small levels' cells (most survivors, longest waves) first, level 0 last -- a shorter tail
     const int lane = threadIdx.x;
     ORBX_PH_INIT(0);
     const FastCell ci = cells[c];   // everything the wave needs about its cell: no second dependent table read

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import bind, check, lib, ptr as _p
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -19,8 +19,6 @@ class _Params(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_variant", C.c_int32), ("trig_variant", C.c_int32)]
 
 
-def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
 
 
 class ORBextractor:
@@ -209,7 +207,7 @@ def extract_pair(left, right, image_left, image_right):
 def stereo_match_batch(left, right, mb, mbf, stream=None):
     """orbx_stereo_match on every frame of the last batch extracted on both handles (asynchronous on `stream`)."""
     L = left._L
-    L.orbx_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    bind(L.orbx_stereo_match, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p])
     check(L.orbx_stereo_match(left._h, right._h, mb, mbf, C.c_void_p(stream) if stream else None))
 
 
@@ -226,7 +224,7 @@ def ComputeStereoMatches(left, right, mb, mbf, frame=0):
     ORBextractor objects (left / right images extracted with the same parameters).
     Returns (mvuRight, mvDepth) for `frame`; -1 where unmatched."""
     L = left._L
-    L.orbx_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    bind(L.orbx_stereo_match, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p])
     check(L.orbx_stereo_match(left._h, right._h, mb, mbf, None))
     u = np.zeros(left.capacity, np.float32); d = np.zeros(left.capacity, np.float32)
     n = C.c_int(0)

@@ -10,30 +10,28 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import bind, check, lib, ptr as _p
 
 FEM_C3D8, FEM_C3D6, FEM_TET4 = 1, 2, 4
 _NPE = {FEM_C3D8: 8, FEM_C3D6: 6, FEM_TET4: 4}
 _BOUND = False
 
 
-def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
 
 
 def _bind(L):
     global _BOUND
     if _BOUND:
         return
-    L.fem_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_float,
-                             C.c_float, C.c_void_p]
-    L.fem_second_layer.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
-    L.fem_dirichlet_penalty.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
-    L.fem_dirichlet_eliminate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    L.fem_displacement.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
-    L.fem_cg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
-    L.fem_cg_iterate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    L.fem_spmv_repeat.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    bind(L.fem_create, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_float,
+                             C.c_float, C.c_void_p])
+    bind(L.fem_second_layer, [C.c_void_p, C.c_int, C.c_float, C.c_void_p])
+    bind(L.fem_dirichlet_penalty, [C.c_void_p, C.c_void_p, C.c_int, C.c_float])
+    bind(L.fem_dirichlet_eliminate, [C.c_void_p, C.c_void_p, C.c_int])
+    bind(L.fem_displacement, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p])
+    bind(L.fem_cg, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p])
+    bind(L.fem_cg_iterate, [C.c_void_p, C.c_int, C.c_void_p])
+    bind(L.fem_spmv_repeat, [C.c_void_p, C.c_int, C.c_void_p])
     for n in ("fem_destroy", "fem_assemble"):
         getattr(L, n).argtypes = [C.c_void_p]
     _BOUND = True
@@ -142,7 +140,7 @@ class FEA2:
         ids = np.ascontiguousarray(ids, np.int32)
         der = np.ascontiguousarray(derived if derived is not None else np.zeros((0, 4)), np.int32).reshape(-1, 4)
         self._npoints = npoints
-        self._L.fem_trial_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
+        bind(self._L.fem_trial_setup, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int])
         check(self._L.fem_trial_setup(self._h, _p(u0), _p(ids), len(ids), Klarge, npoints, _p(der), len(der)))
 
     def trial_energy(self, points, want_a=True):
@@ -205,8 +203,8 @@ class FEA2Batch(FEA2):
         nodes = np.ascontiguousarray(np.concatenate(nodes_list), np.float32)
         elems = np.ascontiguousarray(np.concatenate(elems_list), np.int32)
         self._h = C.c_void_p()
-        self._L.fem_create_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_float,
-                                             C.c_float, C.c_void_p]
+        bind(self._L.fem_create_batch, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_float,
+                                             C.c_float, C.c_void_p])
         check(self._L.fem_create_batch(nElType, self.nseg, _p(nn), _p(ne), _p(nodes), _p(elems), int(E), nu, fg, C.byref(self._h)))
         nm, nd, nnz = C.c_int(), C.c_int(), C.c_int64()
         check(self._L.fem_sizes(self._h, C.byref(nm), C.byref(nd), C.byref(nnz)))
@@ -265,7 +263,7 @@ def plan(elems_list, nn_list, nElType, uniform_copies=0):
     elems_list = [np.ascontiguousarray(e, np.int32).reshape(-1, npe) for e in elems_list]
     nn = np.ascontiguousarray(nn_list, np.int32); ne = np.array([len(e) for e in elems_list], np.int32)
     elems = np.ascontiguousarray(np.concatenate(elems_list), np.int32) if len(elems_list) else np.zeros((0, npe), np.int32)
-    L.fem_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 8
+    bind(L.fem_plan, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 8)
     info = _PlanInfo()
     args = (nElType, len(nn), _p(nn), _p(ne), _p(elems), int(uniform_copies))
     check(L.fem_plan(*args, C.byref(info), *([None] * 8)))

@@ -7,11 +7,9 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import bind, check, lib, ptr as _p
 
 
-def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
 
 
 class ORBmatcher:
@@ -95,10 +93,10 @@ class ORBmatcher:
         sc = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
         n1 = len(kps1)
         m12 = np.zeros(n1, np.int32); bd = np.zeros(n1, np.int32)
-        self._L.orbm_match_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+        bind(self._L.orbm_match_triangulation, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
-                                                     C.c_int, C.c_void_p, C.c_void_p]
+                                                     C.c_int, C.c_void_p, C.c_void_p])
         check(self._L.orbm_match_triangulation(_p(kps1), _p(d1), n1, _p(kps2), _p(d2), len(kps2), _p(off), _p(ci), _p(m1),
                                                _p(m2), _p(s1), _p(s2), 1 if bOnlyStereo else 0, _p(F), ex, ey, _p(sc),
                                                _p(sg), len(sc), _p(m12), _p(bd)))
@@ -119,8 +117,8 @@ class ORBmatcher:
         F = np.ascontiguousarray(F12, np.float32).reshape(9)
         sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
         m12 = np.full(n1, -1, np.int32); nm = C.c_int(0)
-        self._L.orbm_search_for_triangulation.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] * 2 +
-                                                          [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        bind(self._L.orbm_search_for_triangulation, ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] * 2 +
+                                                          [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]))
         check(self._L.orbm_search_for_triangulation(_p(k1), _p(d1), n1, _p(nd1), _p(of1), _p(it1), len(nd1), _p(h1), _p(s1),
                                                     _p(k2), _p(d2), n2, _p(nd2), _p(of2), _p(it2), len(nd2), _p(h2), _p(s2),
                                                     int(bool(bOnlyStereo)), _p(F), float(ex), float(ey), _p(sf), _p(sg), len(sf),
@@ -170,8 +168,8 @@ class ORBmatcher:
         outs = [np.zeros(nq, np.int32) for _ in range(5)]
         sk = np.ascontiguousarray(skip, np.uint8) if skip is not None else None
         ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
-        self._L.orbm_search_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                               C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 5
+        bind(self._L.orbm_search_window, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 5)
         check(self._L.orbm_search_window(_p(q), _p(qd), nq, _p(kps), _p(d), len(kps), _p(sk) if sk is not None else None,
                                          _p(ur) if ur is not None else None, *[float(b) for b in bounds], init_dist,
                                          *[_p(o) for o in outs]))
@@ -191,9 +189,9 @@ class ORBmatcher:
         nq, n = len(q), len(kps)
         mk = np.zeros(n, np.int32); mq = np.zeros(nq, np.int32); nm = C.c_int(0)
         opt = lambda a: _p(a) if a is not None else None
-        self._L.orbm_search_projection.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+        bind(self._L.orbm_search_projection, [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+                                                   C.c_void_p, C.c_void_p, C.c_void_p])
         check(self._L.orbm_search_projection(_p(q), _p(qd), opt(qa), opt(qt), nq, _p(kps), _p(d), n, opt(oc), opt(ur),
                                              *[float(b) for b in bounds], self.TH_HIGH if th_accept is None else int(th_accept),
                                              C.c_float(self.mfNNratio), int(ratio_same_level), int(self.mbCheckOrientation),
@@ -207,8 +205,8 @@ class ORBmatcher:
         ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
         sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if inv_level_sigma2 is not None else None
         best = np.zeros(len(q), np.int32); idx = np.zeros(len(q), np.int32)
-        self._L.orbm_search_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                             C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        bind(self._L.orbm_search_fuse, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
         check(self._L.orbm_search_fuse(_p(q), _p(qd), len(q), _p(kps), _p(d), len(kps), _p(ur) if ur is not None else None,
                                        _p(sg) if sg is not None else None, len(sg) if sg is not None else 0,
                                        *[float(b) for b in bounds], _p(best), _p(idx)))
@@ -234,9 +232,9 @@ class ORBmatcher:
         d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
         pv = np.array(vbPrevMatched, np.float32, copy=True).reshape(-1, 2)
         m12 = np.zeros(len(k1), np.int32); nm = C.c_int(0)
-        self._L.orbm_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+        bind(self._L.orbm_search_for_initialization, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int,
-                                                           C.c_void_p, C.c_void_p]
+                                                           C.c_void_p, C.c_void_p])
         check(self._L.orbm_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(pv),
                                                      *[float(b) for b in bounds], int(windowSize), C.c_float(self.mfNNratio),
                                                      int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
@@ -255,9 +253,9 @@ class ORBmatcher:
         v2 = np.ascontiguousarray(valid2, np.uint8) if kf_kf else None
         n1, n2 = len(d1), len(d2)
         m12 = np.zeros(n1, np.int32); m21 = np.zeros(n2, np.int32); nm = C.c_int(0)
-        self._L.orbm_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+        bind(self._L.orbm_search_by_bow, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                               C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                                               C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
         check(self._L.orbm_search_by_bow(_p(nodes1), _p(off1), _p(it1), len(nodes1), _p(v1), _p(d1), _p(a1), n1,
                                          _p(nodes2), _p(off2), _p(it2), len(nodes2), _p(v2) if v2 is not None else None, _p(d2),
                                          _p(a2), n2, self.TH_LOW, int(kf_kf), C.c_float(self.mfNNratio),
@@ -281,10 +279,10 @@ class ORBmatcher:
         sc = f32(scale_factors)
         n, m = len(kps), len(pos)
         matched = np.zeros(n, np.int32); proj = np.zeros((m, 4), np.float32); nm = C.c_int(0)
-        self._L.orbm_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+        bind(self._L.orbm_search_by_projection_map, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
-                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+                                                          C.c_void_p, C.c_void_p, C.c_void_p])
         check(self._L.orbm_search_by_projection_map(_p(kps), _p(d), n, _p(hm), _p(pos), _p(nrm), _p(mn), _p(mx), _p(md), m,
                                                     _p(R), _p(t), _p(cam), _p(sc), len(sc), th, C.c_float(self.mfNNratio),
                                                     self.TH_RELOC, _p(matched), C.byref(nm), _p(proj)))
@@ -306,8 +304,8 @@ class ORBmatcher:
         sc = f32(scale_factors)
         m = len(pos)
         out = np.zeros(m, self.PROJ_DTYPE); q = np.zeros(m, self.WQ_DTYPE)
-        self._L.orbm_project_points.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] * 3 + \
-                                               [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        bind(self._L.orbm_project_points, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] * 3 + \
+                                               [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p])
         check(self._L.orbm_project_points(int(mode), _p(pos), _p(nrm), _p(mn), _p(mx), m, _p(R), _p(t), _p(O), _p(cam), float(mbf),
                                           float(viewing_cos_limit), float(log_scale_factor), _p(sc), len(sc), float(th), _p(out), _p(q)))
         return out, q
@@ -387,7 +385,7 @@ class ORBmatcher:
         nq = len(q)
         outs = [np.zeros(nq, np.int32) for _ in range(5)]
         sk = np.ascontiguousarray(skip, np.uint8) if skip is not None else None
-        self._L.orbm_frame_search_window.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        bind(self._L.orbm_frame_search_window, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5)
         check(self._L.orbm_frame_search_window(frame._h, _p(q), _p(qd), nq, _p(sk) if sk is not None else None, int(init_dist),
                                                *[_p(o) for o in outs]))
         return tuple(outs)
@@ -396,7 +394,7 @@ class ORBmatcher:
         q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
         sg = np.ascontiguousarray(inv_level_sigma2, np.float32) if inv_level_sigma2 is not None else None
         best = np.zeros(len(q), np.int32); idx = np.zeros(len(q), np.int32)
-        self._L.orbm_frame_search_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        bind(self._L.orbm_frame_search_fuse, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
         check(self._L.orbm_frame_search_fuse(frame._h, _p(q), _p(qd), len(q), _p(sg) if sg is not None else None,
                                              len(sg) if sg is not None else 0, _p(best), _p(idx)))
         return best, idx
@@ -410,8 +408,8 @@ class ORBmatcher:
         nq = len(q)
         mk = np.zeros(max(frame.n, 1), np.int32); mq = np.zeros(nq, np.int32); nm = C.c_int(0)
         opt = lambda a: _p(a) if a is not None else None
-        self._L.orbm_frame_search_projection.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int] + \
-                                                        [C.c_void_p] * 3
+        bind(self._L.orbm_frame_search_projection, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int] + \
+                                                        [C.c_void_p] * 3)
         check(self._L.orbm_frame_search_projection(frame._h, _p(q), _p(qd), opt(qa), opt(qt), nq, opt(oc),
                                                    self.TH_HIGH if th_accept is None else int(th_accept), C.c_float(self.mfNNratio),
                                                    int(ratio_same_level), int(self.mbCheckOrientation), _p(mk), _p(mq), C.byref(nm)))
@@ -421,8 +419,8 @@ class ORBmatcher:
         k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2); d1 = np.ascontiguousarray(desc1, np.uint8)
         pv = np.array(vbPrevMatched, np.float32, copy=True).reshape(-1, 2)
         m12 = np.zeros(len(k1), np.int32); nm = C.c_int(0)
-        self._L.orbm_frame_search_for_initialization.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int,
-                                                                                    C.c_void_p, C.c_void_p]
+        bind(self._L.orbm_frame_search_for_initialization, [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                                                                    C.c_void_p, C.c_void_p])
         check(self._L.orbm_frame_search_for_initialization(frame2._h, _p(k2), _p(k1), _p(d1), len(k1), _p(pv), int(windowSize),
                                                            C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
         return m12, pv, nm.value
@@ -438,8 +436,8 @@ class ORBmatcher:
         sc = f32(scale_factors)
         m = len(pos)
         matched = np.zeros(max(frame.n, 1), np.int32); proj = np.zeros((m, 4), np.float32); nm = C.c_int(0)
-        self._L.orbm_frame_search_by_projection_map.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + \
-                                                               [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 3
+        bind(self._L.orbm_frame_search_by_projection_map, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + \
+                                                               [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 3)
         check(self._L.orbm_frame_search_by_projection_map(frame._h, _p(hm), _p(pos), _p(nrm), _p(mn), _p(mx), _p(md), m, _p(R), _p(t),
                                                           _p(cam), _p(sc), len(sc), th, C.c_float(self.mfNNratio), self.TH_RELOC,
                                                           _p(matched), C.byref(nm), _p(proj)))
@@ -547,8 +545,8 @@ class Frame:
         else:
             k = np.ascontiguousarray(kps); d = np.ascontiguousarray(desc, np.uint8)
             ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
-            self._L.orbm_frame_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
-                                                  C.c_void_p]
+            bind(self._L.orbm_frame_create, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                  C.c_void_p])
             check(self._L.orbm_frame_create(_p(k), _p(d), len(k), _p(ur) if ur is not None else None, *self.bounds, C.byref(self._h)))
         n = C.c_int(0); ns = C.c_int(0)
         check(self._L.orbm_frame_size(self._h, C.byref(n), C.byref(ns)))
@@ -560,8 +558,8 @@ class Frame:
         h = C.c_void_p()
         xy = np.ascontiguousarray(xy_undistorted, np.float32) if xy_undistorted is not None else None
         ur = np.ascontiguousarray(uright, np.float32) if uright is not None else None
-        L.orbm_frame_from_extractor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
-                                                C.c_float, C.c_void_p]
+        bind(L.orbm_frame_from_extractor, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                C.c_float, C.c_void_p])
         check(L.orbm_frame_from_extractor(ex._h, int(frame), _p(xy) if xy is not None else None, _p(ur) if ur is not None else None,
                                           int(bool(uright_from_stereo)), *[float(b) for b in bounds], C.byref(h)))
         return cls(bounds=bounds, _handle=h)
@@ -569,7 +567,7 @@ class Frame:
     def alias(self, bounds):
         """orbm_frame_alias: the same device data searched with other bounds (a KeyFrame's int-valued mnMinX .. mnMaxY)."""
         h = C.c_void_p()
-        self._L.orbm_frame_alias.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        bind(self._L.orbm_frame_alias, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p])
         check(self._L.orbm_frame_alias(self._h, *[float(b) for b in bounds], C.byref(h)))
         return Frame(bounds=bounds, _handle=h)
 

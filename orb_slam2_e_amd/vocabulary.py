@@ -7,11 +7,9 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import bind, check, lib, ptr as _p
 
 
-def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
 
 
 class ORBVocabulary:
@@ -36,7 +34,7 @@ class ORBVocabulary:
         f = np.ascontiguousarray(features, np.uint8)
         n = len(f)
         word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); w = np.zeros(n, np.float64)
-        self._L.orbm_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        bind(self._L.orbm_bow_transform, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
         check(self._L.orbm_bow_transform(self._h, _p(f), n, levelsup, _p(word), _p(node), _p(w)))
         return word, node, w
 
