@@ -71,12 +71,14 @@ _from_buffer, _addressof, _void_p = C.c_char.from_buffer, C.addressof, C.c_void_
 
 def ptr(a):
     """Address of a numpy array's data as c_void_p.  `a.ctypes.data_as(c_void_p)` costs ~3 us a piece -- with seven arrays a call
-    that is more than a 50-us search; the buffer protocol gives the same address in ~0.4 us.  Read-only and empty arrays (which
+    that is more than a 50-us search; the buffer protocol gives the same address in ~0.4 us (the array is kept alive by the returned object, as data_as does).  Read-only and empty arrays (which
     the writable-buffer request refuses) take the slow way."""
     try:
-        return _void_p(_addressof(_from_buffer(a)))
+        v = _void_p(_addressof(_from_buffer(a)))
     except (TypeError, ValueError, BufferError):
         return a.ctypes.data_as(_void_p)
+    v._array = a        # as data_as does: the pointer keeps its array alive (callers pass temporaries)
+    return v
 
 
 def bind(fn, argtypes):

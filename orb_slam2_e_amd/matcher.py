@@ -401,18 +401,19 @@ class ORBmatcher:
 
     def frame_search_projection(self, frame, queries, qdesc, qangle, qtakes, occupied=None, th_accept=None, ratio_same_level=False):
         """orbm_search_projection on a resident frame -> (match_kp, match_q, nmatches)."""
-        q = np.ascontiguousarray(queries, self.WQ_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
-        qa = np.ascontiguousarray(qangle, np.float32) if qangle is not None else None
-        qt = np.ascontiguousarray(qtakes, np.uint8) if qtakes is not None else None
-        oc = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else None
+        asc = np.ascontiguousarray
+        q = asc(queries, self.WQ_DTYPE); qd = asc(qdesc, np.uint8)
+        qa = asc(qangle, np.float32) if qangle is not None else None     # (locals: a converted copy must outlive the call)
+        qt = asc(qtakes, np.uint8) if qtakes is not None else None
+        oc = asc(occupied, np.uint8) if occupied is not None else None
         nq = len(q)
         mk = np.zeros(max(frame.n, 1), np.int32); mq = np.zeros(nq, np.int32); nm = C.c_int(0)
-        opt = lambda a: _p(a) if a is not None else None
-        bind(self._L.orbm_frame_search_projection, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int] + \
-                                                        [C.c_void_p] * 3)
-        check(self._L.orbm_frame_search_projection(frame._h, _p(q), _p(qd), opt(qa), opt(qt), nq, opt(oc),
-                                                   self.TH_HIGH if th_accept is None else int(th_accept), C.c_float(self.mfNNratio),
-                                                   int(ratio_same_level), int(self.mbCheckOrientation), _p(mk), _p(mq), C.byref(nm)))
+        fn = bind(self._L.orbm_frame_search_projection, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int] +
+                  [C.c_void_p] * 3)
+        check(fn(frame._h, _p(q), _p(qd), _p(qa) if qa is not None else None, _p(qt) if qt is not None else None, nq,
+                 _p(oc) if oc is not None else None,
+                 self.TH_HIGH if th_accept is None else int(th_accept), self.mfNNratio, int(ratio_same_level),
+                 int(self.mbCheckOrientation), _p(mk), _p(mq), C.byref(nm)))
         return mk[:frame.n], mq, nm.value
 
     def frame_search_for_initialization(self, frame2, kps2, kps1, desc1, vbPrevMatched, windowSize=10):
