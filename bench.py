@@ -386,6 +386,15 @@ def matcher_loops_bench():
     npnt = len(sc["pos"])
     pts = Points(np.ones(npnt, np.uint8), sc["pos"], sc["mp_desc"], normal=sc["normal"], min_distance=sc["mind"], max_distance=sc["maxd"],
                  takes=np.ones(npnt, np.uint8))
+    # SearchByBoW with both frames resident: positions do not matter to it, any keypoints carrying the case's angles will do
+    from orb_slam2_e_amd import KP_DTYPE
+    brng = np.random.default_rng(5)
+
+    def bow_frame(d, a):
+        k = np.zeros(len(d), KP_DTYPE)
+        k["x"] = brng.uniform(0, 640, len(d)); k["y"] = brng.uniform(0, 480, len(d)); k["angle"] = a
+        return Frame(k, d, (0.0, 0.0, 640.0, 480.0))
+    bf1, bf2 = bow_frame(d1, a1), bow_frame(d2, a2)
     out = {"search_for_initialization_2000x2200_ms": ms(lambda: mi.SearchForInitialization(ik1, id1, ik2, id2, iprev, ibounds, 100), 30),
            "search_by_projection_2000x2000_ms": ms(lambda: m.frame_search_projection(fr, q, qd, qa, takes, occ, 95), 100),
            "search_by_projection_2000x2000_host_arrays_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
@@ -393,9 +402,10 @@ def matcher_loops_bench():
            "search_local_points_whole_2500x2000_ms": ms(lambda: m.SearchByProjectionPoints(cur, view, sc["Tcw"], pts, sc["occupied"], 1.0), 100),
            "frame_create_2000_ms": ms(lambda: Frame(kps, desc, bounds, ur).close(), 50),
            "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
+           "search_by_bow_2000x2100_resident_ms": ms(lambda: m.frame_search_by_bow(bf1, fv1, valid1, bf2, fv2, None, False), 50),
            "search_window_2000x2000_ms": ms(lambda: m.frame_search_window(fr, q, qd, occ), 100),
            "search_window_2000x2000_host_arrays_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
-    fr.close(); cur.close()
+    fr.close(); cur.close(); bf1.close(); bf2.close()
     return out
 
 

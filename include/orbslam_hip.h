@@ -447,6 +447,15 @@ int orbm_frame_search_by_projection_map(const orbm_frame *frame, const uint8_t *
                                         const double *tcw, const orbm_camera *cam, const float *scale_factors, int nlevels, float th,
                                         float nnratio, int th_reloc, int32_t *matched_mp, int *nmatches, float *proj);
 
+/* orbm_search_by_bow on two resident frames: descriptors and angles stay in HBM -- the first frame's queries are gathered on the
+ * device, the second frame's features are addressed by index whether they lie inside its grid or not -- and the call uploads the
+ * feature-vector lists only.  The frames' keypoint counts stand for n1 / n2 (valid1[n1], valid2[n2] or NULL, match12[n1],
+ * match21[n2] or NULL); arguments and results otherwise as for orbm_search_by_bow. */
+int orbm_frame_search_by_bow(const orbm_frame *frame1, const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1,
+                             const uint8_t *valid1, const orbm_frame *frame2, const int32_t *nodes2, const int32_t *off2,
+                             const int32_t *items2, int nn2, const uint8_t *valid2, int th, int strict_th, float nnratio,
+                             int check_orientation, int32_t *match12, int32_t *match21, int *nmatches);
+
 /* ------------------------------------------- the SearchByProjection forms and SearchBySim3 as WHOLE functions
  * Projection prefix, candidate search, in-loop assignment, acceptance and rotation check in one call, nothing in between
  * returns to the host.  The pointer graph is passed flat: entry i of the vector the reference walks (LastFrame.mvpMapPoints,

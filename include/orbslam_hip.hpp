@@ -600,6 +600,19 @@ public:
         return mStatus == ORBX_OK ? nm : 0;
     }
 
+    // The same on two resident frames: nothing but the feature-vector lists travels with the call.
+    int SearchByBoW(const FeatureVector &fv1, const std::vector<uint8_t> &valid1, const ResidentFrame &KF1, const FeatureVector &fv2,
+                    const std::vector<uint8_t> *valid2, const ResidentFrame &F2, std::vector<int32_t> &vnMatches12)
+    {
+        vnMatches12.assign(KF1.N, -1);
+        int nm = 0;
+        mStatus = orbm_frame_search_by_bow(KF1.handle(), fv1.nodes.data(), fv1.off.data(), fv1.items.data(), (int)fv1.nodes.size(),
+                                           valid1.data(), F2.handle(), fv2.nodes.data(), fv2.off.data(), fv2.items.data(),
+                                           (int)fv2.nodes.size(), valid2 ? valid2->data() : nullptr, TH_LOW, valid2 ? 1 : 0, mfNNratio,
+                                           mbCheckOrientation, vnMatches12.data(), nullptr, &nm);
+        return mStatus == ORBX_OK ? nm : 0;
+    }
+
     // ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024).  The FeatureVector co-iteration builds the candidate
     // list of every keypoint of KF1 (the members of the same vocabulary node in KF2, in member order), the device
     // runs the loop with its epipolar gates, the rotation histogram and the pair list are finished here.

@@ -202,14 +202,19 @@ __global__ __launch_bounds__(MT) void k_win_wave(const WinQuery *__restrict__ q,
 // Entries for explicit candidate lists (BoW-node members in member order), one wave per
 // query: entry = dist << 20 | candidate index; a distance of 256 can never be selected.  Query i's candidates are
 // cand[cbeg[i] .. cbeg[i] + off[i+1] - off[i]): the queries of one node share one copy of the node's member list.
+// qmap (queries taken from a resident frame): query i is the feature at sorted position qmap[i] of that frame -- A and qang_src are the
+// frame's arrays, and the query's angle is set down in qang_dst[i] for the rotation check.
 __global__ __launch_bounds__(MT) void k_list_fill(const uint4 *__restrict__ A, int nq, const uint4 *__restrict__ B,
                                                   const int *__restrict__ off, const int *__restrict__ cbeg,
                                                   const int *__restrict__ cand, unsigned *__restrict__ ent,
-                                                  unsigned *__restrict__ top)
+                                                  unsigned *__restrict__ top, const int *__restrict__ qmap,
+                                                  const float *__restrict__ qang_src, float *__restrict__ qang_dst)
 {
     const int i = blockIdx.x * (MT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nq) return;
-    const uint4 a0 = A[2 * i], a1 = A[2 * i + 1];
+    const int qi = qmap ? qmap[i] : i;
+    if (qmap && lane == 0) qang_dst[i] = qang_src[qi];
+    const uint4 a0 = A[2 * qi], a1 = A[2 * qi + 1];
     const int shift = cbeg[i] - off[i];
     for (int k = off[i] + lane; k < off[i + 1]; k += 64) {
         const int j = cand[k + shift];
@@ -1165,6 +1170,8 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
 //   3. rank of a keypoint inside its cell = keypoints of the same cell with a smaller index: per 64-keypoint chunk the
 //      lanes compare cells pairwise (all waves), then one wave walks the chunks in order with a running count per cell;
 //   4. gather: position, level, right coordinate, angle, descriptor, permutation.
+// Keypoints outside the grid (Frame::PosInGrid false: no window search ever returns them) follow the sorted part at positions
+// ns .. n-1 in index order: the searches over explicit candidate lists (SearchByBoW) address features by index, grid or not.
 // Keypoints come as cv::KeyPoint records (mvKeysUn; or the extractor's device results, optionally with the undistorted
 // coordinates beside them), n from the host or from the extractor's count array.
 constexpr int FB_T = 1024, FB_MAXN = SEQ_MAXN, FB_NC = FRAME_GRID_COLS * FRAME_GRID_ROWS;
@@ -1191,7 +1198,7 @@ __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__res
         const float x = xy_un ? xy_un[j].x : kps[j].x, y = xy_un ? xy_un[j].y : kps[j].y;
         const int px = (int)roundf((x - gp.min_x) * gp.inv_w), py = (int)roundf((y - gp.min_y) * gp.inv_h);
         const bool in = !(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS);
-        const int c = in ? px * FRAME_GRID_ROWS + py : 0xffff;
+        const int c = in ? px * FRAME_GRID_ROWS + py : FB_NC;   // FB_NC: outside the grid -- kept behind the sorted part, in index order
         s_cell[j] = (unsigned short)c;
         if (in) atomicAdd(&s_off[c], 1);
     }
@@ -1247,7 +1254,6 @@ __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__res
     }
     __syncthreads();
     for (int j = tid; j < n; j += FB_T) {
-        if (s_cell[j] == 0xffff) continue;
         const int sp = s_pos[j];
         const orbx_keypoint k = kps[j];
         SeqKp o;
@@ -1432,7 +1438,8 @@ struct orbm_frame {
     std::atomic<int> *refs = nullptr;                       // handles sharing the block (orbm_frame_alias)
     SeqKp *kp = nullptr; uint4 *desc = nullptr; float *angle = nullptr; int *perm = nullptr, *cell_off = nullptr;
     FrameHdr *hdr = nullptr;
-    std::vector<int> perm_host;
+    std::vector<int> perm_host;                             // [n]: keypoint index at sorted position (the first ns: inside the grid)
+    std::vector<int> inv_host;                              // [n]: sorted position of keypoint index
 };
 
 namespace {
@@ -1512,7 +1519,14 @@ int frame_build(orbm_frame *f, Workspace &w, const orbx_keypoint *d_kps, const u
     FrameHdr h;
     memcpy(&h, pin, sizeof(h));
     f->n = h.n; f->ns = h.ns;
-    f->perm_host.assign(reinterpret_cast<const int *>(pin + 256), reinterpret_cast<const int *>(pin + 256) + h.ns);
+    if (h.n < 0 || h.n > n_bound || h.ns < 0 || h.ns > h.n) ORBX_FAIL(ORBX_ERR_HIP, "frame header out of range");
+    f->perm_host.assign(reinterpret_cast<const int *>(pin + 256), reinterpret_cast<const int *>(pin + 256) + h.n);
+    f->inv_host.assign((size_t)h.n, 0);
+    for (int sp = 0; sp < h.n; ++sp) {
+        const int j = f->perm_host[sp];
+        if (j < 0 || j >= h.n) ORBX_FAIL(ORBX_ERR_HIP, "frame permutation out of range");
+        f->inv_host[j] = sp;
+    }
     return ORBX_OK;
 }
 
@@ -1521,9 +1535,10 @@ struct FrameSrc {
     const SortedFrame *host = nullptr;
     const orbm_frame *res = nullptr;
     size_t o_k = 0, o_b = 0, o_kang = 0, o_perm = 0, o_cell = 0;
+    bool all_positions = false;     // resident frame addressed by explicit candidate lists: the positions behind the grid's count too
     explicit FrameSrc(const SortedFrame &sf) : host(&sf) {}
-    explicit FrameSrc(const orbm_frame *f) : res(f) {}
-    int ns() const { return host ? (int)host->perm.size() : res->ns; }
+    explicit FrameSrc(const orbm_frame *f, bool all = false) : res(f), all_positions(all) {}
+    int ns() const { return host ? (int)host->perm.size() : (all_positions ? res->n : res->ns); }
     const int *perm() const { return host ? host->perm.data() : res->perm_host.data(); }
     GridParams gp() const { return host ? host->gp : res->gp; }
     void carve(Workspace &w)
@@ -1614,8 +1629,10 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
                    int nq, FrameSrc &fs, int n, const uint8_t *occupied, int has_uright, int th, float nnratio, int accept_mode, int check,
                    int32_t *match_kp, int32_t *match_q, int *nmatches, WinQuery *queries_out = nullptr, const int32_t *cand_off = nullptr,
                    const int32_t *cand_beg = nullptr, const int32_t *cand_idx = nullptr, int ncand = 0,
-                   const int32_t *seg = nullptr, int nseg = 0)
+                   const int32_t *seg = nullptr, int nseg = 0, const orbm_frame *qframe = nullptr, const int32_t *qsrc = nullptr)
 {
+    // qframe / qsrc (explicit candidate lists only): query i = the feature at sorted position qsrc[i] of the resident frame qframe;
+    // qdesc and qangle are not read
     const int ns = fs.ns();
     if (ns > SEQ_MAXN || nq > 65536) ORBX_FAIL(ORBX_ERR_CAPACITY, "frame too large for the sequential resolver");
     for (int j = 0; j < n && mode == 0; ++j) match_kp[j] = -1;
@@ -1657,7 +1674,7 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
     for (int attempt = 0; attempt < 4; ++attempt) {
         w.used = 0;
         // staged inputs (same offsets on both sides), then device-only arrays, then the result block
-        const size_t o_qh = w.carve(queries ? sizeof(WinQuery) * nq : 1), o_a = w.carve((size_t)32 * nq);
+        const size_t o_qh = w.carve(queries ? sizeof(WinQuery) * nq : 1), o_a = w.carve(qframe ? sizeof(int) * (size_t)nq : (size_t)32 * nq);
         fs.carve(w);
         const size_t o_qang = w.carve(sizeof(float) * nq), o_tk = w.carve(nq), o_occ = w.carve(occupied && ns ? (size_t)ns : 1),
                      o_off = w.carve(sizeof(int) * (nq + 1)),
@@ -1684,9 +1701,12 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
         hipStream_t st = w.st;
 
         if (queries) memcpy(w.h<char>(o_qh), queries, sizeof(WinQuery) * nq);
-        memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
+        if (qframe) memcpy(w.h<char>(o_a), qsrc, sizeof(int) * (size_t)nq);
+        else memcpy(w.h<char>(o_a), qdesc, (size_t)32 * nq);
         fs.fill(w);
-        if (qangle) memcpy(w.h<char>(o_qang), qangle, sizeof(float) * nq); else memset(w.h<char>(o_qang), 0, sizeof(float) * nq);
+        if (!qframe) {   // (from a resident frame: k_list_fill sets the angles down)
+            if (qangle) memcpy(w.h<char>(o_qang), qangle, sizeof(float) * nq); else memset(w.h<char>(o_qang), 0, sizeof(float) * nq);
+        }
         if (qtakes) memcpy(w.h<char>(o_tk), qtakes, nq); else memset(w.h<char>(o_tk), 1, nq);
         if (occupied && ns) fs.fill_occ(w.h<uint8_t>(o_occ), occupied);
         if (cand_off) {
@@ -1730,8 +1750,10 @@ int run_sequential(int mode, const WinQuery *queries, PointsPrefix *prefix, cons
         unsigned *dtop = w.d<unsigned>(o_top);
         const int *lbeg = doff, *lend = doff + 1; // CSR lists; the strided path has its own bounds
         if (!windows) { // explicit candidate lists
-            hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, st, da, nq, db, (const int *)doff, (const int *)w.d<int>(o_cbeg),
-                               (const int *)w.d<int>(o_cand), w.ent, dtop);
+            hipLaunchKernelGGL(k_list_fill, g, dim3(MT), 0, st, qframe ? (const uint4 *)qframe->desc : da, nq, db, (const int *)doff,
+                               (const int *)w.d<int>(o_cbeg), (const int *)w.d<int>(o_cand), w.ent, dtop,
+                               qframe ? (const int *)w.d<int>(o_a) : (const int *)nullptr, qframe ? (const float *)qframe->angle : (const float *)nullptr,
+                               w.d<float>(o_qang));
         } else if (!exact) {
             lbeg = w.d<int>(o_cnt); lend = w.d<int>(o_lend);
             hipLaunchKernelGGL(k_win_wave<2>, g, dim3(MT), 0, st, (const WinQuery *)dq, da, nq, dk, db, fv.cell_off, docc, fv.gp, has_uright,
@@ -2092,7 +2114,7 @@ int orbm_frame_alias(const orbm_frame *src, float min_x, float min_y, float max_
     f->block = src->block; f->refs = src->refs;
     f->refs->fetch_add(1);
     frame_pointers(f);
-    f->perm_host = src->perm_host;
+    f->perm_host = src->perm_host; f->inv_host = src->inv_host;
     *out = f;
     return ORBX_OK;
 }
@@ -2108,7 +2130,7 @@ int orbm_frame_size(const orbm_frame *f, int *n, int *nsorted)
 int orbm_frame_layout(const orbm_frame *f, int32_t *perm, int32_t *cell_off)
 {
     if (!f) ORBX_FAIL(ORBX_ERR_ARG, "null frame");
-    if (perm) memcpy(perm, f->perm_host.data(), sizeof(int) * f->perm_host.size());
+    if (perm) memcpy(perm, f->perm_host.data(), sizeof(int) * (size_t)f->ns);
     if (cell_off) ORBX_HIP(hipMemcpy(cell_off, f->cell_off, sizeof(int) * (FB_NC + 1), hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
@@ -2308,6 +2330,58 @@ int orbm_frame_search_for_initialization(const orbm_frame *frame2, const orbx_ke
     return ORBX_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+// The co-iteration of the two FeatureVectors (ORBmatcher.cc:384-456 / :745-828: equal keys: visit; else lower_bound on the other
+// map) as lists: every valid feature of a common node is a query whose candidates are that node's valid members in the other set, one
+// copy per node.  inv2: candidate numbers are positions in a resident frame instead of feature indices.
+struct BowLists {
+    std::vector<int32_t> qidx, cand_off, cand_beg, cand, seg;
+    bool disjoint = true;   // a feature sits in one node of a FeatureVector; arrays that break this resolve as one segment
+};
+void bow_lists(const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1, const uint8_t *valid1, const int32_t *nodes2,
+               const int32_t *off2, const int32_t *items2, int nn2, const uint8_t *valid2, int n2, const int *inv2, BowLists &L)
+{
+    L.cand_off.assign(1, 0); L.seg.assign(1, 0);
+    std::vector<uint8_t> seen(n2 ? n2 : 1, 0);
+    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
+        if (nodes1[a] == nodes2[b]) {
+            const size_t c0 = L.cand.size();
+            for (int k = off2[b]; k < off2[b + 1]; ++k) { L.disjoint = L.disjoint && !seen[items2[k]]; seen[items2[k]] = 1; }
+            for (int k = off2[b]; k < off2[b + 1]; ++k)
+                if (!valid2 || valid2[items2[k]]) L.cand.push_back(inv2 ? inv2[items2[k]] : items2[k]);
+            const int32_t len = (int32_t)(L.cand.size() - c0);
+            bool any = false;
+            for (int k = off1[a]; k < off1[a + 1]; ++k) { // every query of the node: the same members, one copy
+                if (!valid1[items1[k]]) continue;
+                any = true;
+                L.qidx.push_back(items1[k]);
+                L.cand_beg.push_back((int32_t)c0);
+                L.cand_off.push_back(L.cand_off.back() + len);
+            }
+            if (!any) L.cand.resize(c0);
+            else L.seg.push_back((int32_t)L.qidx.size());   // one segment per node
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) ++a;
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) ++b;
+        }
+    }
+}
+int bow_check_items(const int32_t *off, const int32_t *items, int nn, int n)
+{
+    for (int k = 0; k < (nn ? off[nn] : 0); ++k)
+        if (items[k] < 0 || items[k] >= n) return -1;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
 int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1, const uint8_t *valid1,
                        const uint8_t *desc1, const float *angle1, int n1, const int32_t *nodes2, const int32_t *off2,
                        const int32_t *items2, int nn2, const uint8_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
@@ -2318,59 +2392,60 @@ int orbm_search_by_bow(const int32_t *nodes1, const int32_t *off1, const int32_t
         (nn1 && (!nodes1 || !off1 || !items1)) || (nn2 && (!nodes2 || !off2 || !items2)) || !nmatches ||
         (check_orientation && n1 && n2 && (!angle1 || !angle2)))
         ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
-    for (int k = 0; k < (nn1 ? off1[nn1] : 0); ++k)
-        if (items1[k] < 0 || items1[k] >= n1) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
-    for (int k = 0; k < (nn2 ? off2[nn2] : 0); ++k)
-        if (items2[k] < 0 || items2[k] >= n2) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
+    if (bow_check_items(off1, items1, nn1, n1) || bow_check_items(off2, items2, nn2, n2)) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
     ORBX_NEED_DEVICE();
     for (int i = 0; i < n1; ++i) match12[i] = -1;
     if (match21) for (int j = 0; j < n2; ++j) match21[j] = -1;
     *nmatches = 0;
-    // the co-iteration of :384-456 / :745-828 (equal keys: visit; else lower_bound on the other map), as lists
-    std::vector<int32_t> qidx, cand_off(1, 0), cand_beg, cand, seg(1, 0);
-    std::vector<uint8_t> seen(n2 ? n2 : 1, 0);
-    bool disjoint = true; // a feature sits in one node of a FeatureVector; arrays that break this resolve as one segment
-    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
-        if (nodes1[a] == nodes2[b]) {
-            const size_t c0 = cand.size();
-            for (int k = off2[b]; k < off2[b + 1]; ++k) { disjoint = disjoint && !seen[items2[k]]; seen[items2[k]] = 1; }
-            for (int k = off2[b]; k < off2[b + 1]; ++k)
-                if (!valid2 || valid2[items2[k]]) cand.push_back(items2[k]);
-            const int32_t len = (int32_t)(cand.size() - c0);
-            bool any = false;
-            for (int k = off1[a]; k < off1[a + 1]; ++k) { // every query of the node: the same members, one copy
-                if (!valid1[items1[k]]) continue;
-                any = true;
-                qidx.push_back(items1[k]);
-                cand_beg.push_back((int32_t)c0);
-                cand_off.push_back(cand_off.back() + len);
-            }
-            if (!any) cand.resize(c0);
-            else seg.push_back((int32_t)qidx.size());   // one segment per node
-            ++a; ++b;
-        } else if (nodes1[a] < nodes2[b]) {
-            while (a < nn1 && nodes1[a] < nodes2[b]) ++a;
-        } else {
-            while (b < nn2 && nodes2[b] < nodes1[a]) ++b;
-        }
-    }
-    const int nq = (int)qidx.size();
+    BowLists L;
+    bow_lists(nodes1, off1, items1, nn1, valid1, nodes2, off2, items2, nn2, valid2, n2, nullptr, L);
+    const int nq = (int)L.qidx.size();
     if (nq == 0 || n2 == 0) return ORBX_OK;
     SortedFrame sf; // the second set as it is: position = feature index
     sf.perm.resize(n2); sf.angle.resize(n2); sf.desc.assign(desc2, desc2 + (size_t)32 * n2);
     for (int j = 0; j < n2; ++j) { sf.perm[j] = j; sf.angle[j] = angle2 ? angle2[j] : 0.f; }
     std::vector<uint8_t> qd((size_t)32 * nq);
     std::vector<float> qa(nq);
-    for (int i = 0; i < nq; ++i) { memcpy(&qd[32 * (size_t)i], desc1 + 32 * (size_t)qidx[i], 32); qa[i] = angle1 ? angle1[qidx[i]] : 0.f; }
+    for (int i = 0; i < nq; ++i) { memcpy(&qd[32 * (size_t)i], desc1 + 32 * (size_t)L.qidx[i], 32); qa[i] = angle1 ? angle1[L.qidx[i]] : 0.f; }
     std::vector<int32_t> mk(n2), mq(nq);
     FrameSrc fs(sf);
     // bestDist1 < TH_LOW (:799) == bestDist1 <= TH_LOW - 1
     const int rc = run_sequential(0, nullptr, nullptr, qd.data(), qa.data(), nullptr, nq, fs, n2, nullptr, 0, strict_th ? th - 1 : th, nnratio,
-                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, nullptr, cand_off.data(), cand_beg.data(), cand.data(),
-                                  (int)cand.size(), disjoint ? seg.data() : nullptr, disjoint ? (int)seg.size() - 1 : 0);
+                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, nullptr, L.cand_off.data(), L.cand_beg.data(), L.cand.data(),
+                                  (int)L.cand.size(), L.disjoint ? L.seg.data() : nullptr, L.disjoint ? (int)L.seg.size() - 1 : 0);
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < nq; ++i) // every accepted query blocks its candidate, so slot mq[i] still names i unless rejected
-        if (mq[i] >= 0 && mk[mq[i]] == i) { match12[qidx[i]] = mq[i]; if (match21) match21[mq[i]] = qidx[i]; }
+        if (mq[i] >= 0 && mk[mq[i]] == i) { match12[L.qidx[i]] = mq[i]; if (match21) match21[mq[i]] = L.qidx[i]; }
+    return ORBX_OK;
+}
+
+int orbm_frame_search_by_bow(const orbm_frame *frame1, const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1,
+                             const uint8_t *valid1, const orbm_frame *frame2, const int32_t *nodes2, const int32_t *off2,
+                             const int32_t *items2, int nn2, const uint8_t *valid2, int th, int strict_th, float nnratio,
+                             int check_orientation, int32_t *match12, int32_t *match21, int *nmatches)
+{
+    if (!frame1 || !frame2 || nn1 < 0 || nn2 < 0 || (frame1->n && (!match12 || !valid1)) || (nn1 && (!nodes1 || !off1 || !items1)) ||
+        (nn2 && (!nodes2 || !off2 || !items2)) || !nmatches)
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    const int n1 = frame1->n, n2 = frame2->n;
+    if (bow_check_items(off1, items1, nn1, n1) || bow_check_items(off2, items2, nn2, n2)) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
+    ORBX_NEED_DEVICE();
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    if (match21) for (int j = 0; j < n2; ++j) match21[j] = -1;
+    *nmatches = 0;
+    BowLists L;
+    bow_lists(nodes1, off1, items1, nn1, valid1, nodes2, off2, items2, nn2, valid2, n2, frame2->inv_host.data(), L);
+    const int nq = (int)L.qidx.size();
+    if (nq == 0 || n2 == 0) return ORBX_OK;
+    std::vector<int32_t> qsrc(nq), mk(n2), mq(nq);
+    for (int i = 0; i < nq; ++i) qsrc[i] = frame1->inv_host[L.qidx[i]];
+    FrameSrc fs(frame2, true);
+    const int rc = run_sequential(0, nullptr, nullptr, nullptr, nullptr, nullptr, nq, fs, n2, nullptr, 0, strict_th ? th - 1 : th, nnratio,
+                                  ACCEPT_RATIO, check_orientation, mk.data(), mq.data(), nmatches, nullptr, L.cand_off.data(), L.cand_beg.data(), L.cand.data(),
+                                  (int)L.cand.size(), L.disjoint ? L.seg.data() : nullptr, L.disjoint ? (int)L.seg.size() - 1 : 0, frame1, qsrc.data());
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < nq; ++i)
+        if (mq[i] >= 0 && mk[mq[i]] == i) { match12[L.qidx[i]] = mq[i]; if (match21) match21[mq[i]] = L.qidx[i]; }
     return ORBX_OK;
 }
 

@@ -444,6 +444,21 @@ class ORBmatcher:
                                                           _p(matched), C.byref(nm), _p(proj)))
         return matched[:frame.n], nm.value, proj
 
+    def frame_search_by_bow(self, frame1, fv1, valid1, frame2, fv2, valid2=None, kf_kf=False):
+        """SearchByBoW on two resident frames (orbm_frame_search_by_bow): fv = feature_vector_arrays(...) of each side.
+        Returns (match12, match21, nmatches)."""
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        nodes1, off1, it1 = [i32(a) for a in fv1]; nodes2, off2, it2 = [i32(a) for a in fv2]
+        v1 = np.ascontiguousarray(valid1, np.uint8)
+        v2 = np.ascontiguousarray(valid2, np.uint8) if kf_kf else None
+        m12 = np.zeros(max(frame1.n, 1), np.int32); m21 = np.zeros(max(frame2.n, 1), np.int32); nm = C.c_int(0)
+        fn = bind(self._L.orbm_frame_search_by_bow, [C.c_void_p] * 4 + [C.c_int, C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p] +
+                  [C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 3)
+        check(fn(frame1._h, _p(nodes1), _p(off1), _p(it1), len(nodes1), _p(v1), frame2._h, _p(nodes2), _p(off2), _p(it2), len(nodes2),
+                 _p(v2) if v2 is not None else None, self.TH_LOW, int(kf_kf), self.mfNNratio, int(self.mbCheckOrientation),
+                 _p(m12), _p(m21), C.byref(nm)))
+        return m12[:frame1.n], m21[:frame2.n], nm.value
+
     # ---------------------------------------------------------------- the projection searches as whole functions
     def SearchByProjectionLast(self, cur, view, Tcw, Tlw, last, occupied, th, bMono, want_queries=False):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1529-1671) in one call: cur = resident

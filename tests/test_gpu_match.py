@@ -369,6 +369,51 @@ def test_search_by_bow_whole_loop(seed, kf_kf, ori, ratio, resolver):
     assert taken > 0
 
 
+@pytest.mark.parametrize("seed,kf_kf,ori,ratio", [(0, False, True, 0.7), (1, True, True, 0.75), (3, True, False, 0.9)])
+def test_search_by_bow_on_resident_frames(seed, kf_kf, ori, ratio, resolver):
+    """orbm_frame_search_by_bow: both frames resident, queries gathered on the device, features addressed by index -- including the
+    ones that lie outside the frame's grid (Frame::PosInGrid false), which no window search returns but SearchByBoW must see."""
+    from orb_slam2_e_amd import KP_DTYPE, Frame
+    from orb_slam2_e_amd.vocabulary import feature_vector_arrays
+    d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(seed)
+    rng = np.random.default_rng(100 + seed)
+    bounds = (-3.5, -2.25, 645.5, 483.0)
+
+    def keypoints(angles):
+        n = len(angles)
+        k = np.zeros(n, KP_DTYPE)
+        k["x"] = rng.uniform(0, 640, n); k["y"] = rng.uniform(0, 480, n); k["octave"] = rng.integers(0, 8, n); k["angle"] = angles
+        out = rng.choice(n, 40, replace=False)                       # undistorted past the corner-based bounds
+        k["x"][out[:20]] = rng.choice([-9.0, 652.0], 20); k["y"][out[20:]] = rng.choice([-7.5, 490.0], 20)
+        return k
+    k1, k2 = keypoints(a1), keypoints(a2)
+    f1, f2 = Frame(k1, d1, bounds), Frame(k2, d2, bounds)
+    assert f1.layout()[0].size < len(k1) and f2.layout()[0].size < len(k2)      # some keypoints are outside the grid
+    fv1 = feature_vector_arrays(node1, keep1); fv2 = feature_vector_arrays(node2, keep2)
+    m = ORBmatcher(ratio, ori)
+    got = m.frame_search_by_bow(f1, fv1, valid1, f2, fv2, valid2, kf_kf)
+    host = m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, kf_kf)
+    ref = oracle.search_by_bow(oracle.feature_vector(node1, keep1), valid1, d1, a1, oracle.feature_vector(node2, keep2),
+                               valid2 if kf_kf else None, d2, a2, kf_kf, ratio, ori)
+    assert ref[2] > 300
+    for r in (host, got):
+        assert r[2] == ref[2] and np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1])
+    # the frames still serve window searches: a query over everything never returns an outside keypoint
+    q = np.zeros(1, ORBmatcher.WQ_DTYPE); q["u"] = 320; q["v"] = 240; q["r"] = 2000; q["min_level"] = -1; q["max_level"] = -1
+    outside = np.setdiff1d(np.arange(len(k2)), f2.layout()[0])
+    qo = np.repeat(q, len(outside))
+    mk, mq, nm = ORBmatcher(1.0, False).frame_search_projection(f2, qo, d2[outside], a2[outside], None, None, 256)
+    assert len(outside) >= 30 and (mq >= 0).any() and not np.isin(mq[mq >= 0], outside).any()   # their own descriptors do not find them
+    # empty feature vectors / an empty first frame
+    e = (np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    g0 = m.frame_search_by_bow(f1, e, valid1, f2, fv2, valid2, kf_kf)
+    assert g0[2] == 0 and (g0[0] == -1).all() and (g0[1] == -1).all()
+    f0 = Frame(k1[:0], d1[:0], bounds)
+    g1 = m.frame_search_by_bow(f0, e, valid1[:0], f2, fv2, valid2, kf_kf)
+    assert g1[2] == 0 and len(g1[0]) == 0
+    for f in (f0, f1, f2): f.close()
+
+
 def test_matcher_calls_are_reentrant_across_threads():
     """Tracking, LocalMapping and LoopClosing call ORBmatcher concurrently: the host-array entry
     points lease separate workspaces, so concurrent calls must return what sequential calls return."""
