@@ -463,6 +463,15 @@ def stereo_bench():
     for name, fn in (("search_for_triangulation_ms", whole), ("search_for_triangulation_gated_loop_ms", inner)):
         out[name] = best_batch_ms(fn, reps)
     out["search_for_triangulation"] = {"keypoints": [len(kL), len(kR)], "candidates": int(len(idx)), "matches": int(whole()[1])}
+    # ... and with the two keyframes resident in HBM (stereo = the frame's right coordinate; lists shared per node)
+    from orb_slam2_e_amd import Frame
+    tb = (0.0, 0.0, float(left.shape[1]), float(left.shape[0]))
+    fL = Frame(kL, dL, tb, np.where(np.asarray(s1, bool), 1.0, -1.0).astype(np.float32))
+    fR = Frame(kR, dR, tb, np.where(np.asarray(s2, bool), 1.0, -1.0).astype(np.float32))
+    resident = lambda: m.frame_search_for_triangulation(fL, fv1, has1, fR, fv2, has2, F12, ex, ey, sf, sg, False)
+    out["search_for_triangulation_resident_ms"] = best_batch_ms(resident, reps)
+    out["search_for_triangulation"]["resident_equal"] = bool(np.array_equal(resident()[2], whole()[2]))
+    fL.close(); fR.close()
 
     # the same path with the batch as the unit: 64 resident pairs, left and right extract_batch on two handles and ONE
     # orbx_stereo_match over all frames, everything queued on one stream

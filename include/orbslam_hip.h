@@ -456,6 +456,16 @@ int orbm_frame_search_by_bow(const orbm_frame *frame1, const int32_t *nodes1, co
                              const int32_t *items2, int nn2, const uint8_t *valid2, int th, int strict_th, float nnratio,
                              int check_orientation, int32_t *match12, int32_t *match21, int *nmatches);
 
+/* orbm_search_for_triangulation on two resident keyframes: a keypoint is "stereo" where the frame's right coordinate is >= 0
+ * (mvuRight, as given to orbm_frame_create / taken from ComputeStereoMatches); the call uploads the feature-vector lists and the two
+ * "owns a MapPoint" masks, and the rotation histogram runs on angle differences formed on the device.  Positions are the frames'
+ * (mvKeysUn) coordinates.  has_mappoint1[n1], has_mappoint2[n2], match12[n1]; otherwise as orbm_search_for_triangulation. */
+int orbm_frame_search_for_triangulation(const orbm_frame *kf1, const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1,
+                                        const uint8_t *has_mappoint1, const orbm_frame *kf2, const int32_t *nodes2, const int32_t *off2,
+                                        const int32_t *items2, int nn2, const uint8_t *has_mappoint2, int only_stereo, const float *F12,
+                                        float ex, float ey, const float *scale_factors2, const float *level_sigma2, int nlevels,
+                                        int check_orientation, int32_t *match12, int *nmatches);
+
 /* ------------------------------------------- the SearchByProjection forms and SearchBySim3 as WHOLE functions
  * Projection prefix, candidate search, in-loop assignment, acceptance and rotation check in one call, nothing in between
  * returns to the host.  The pointer graph is passed flat: entry i of the vector the reference walks (LastFrame.mvpMapPoints,

@@ -613,6 +613,27 @@ public:
         return mStatus == ORBX_OK ? nm : 0;
     }
 
+    // SearchForTriangulation on two resident keyframes (stereo = the frame's right coordinate >= 0): the lists and the two
+    // "owns a MapPoint" masks are all that travels.
+    int SearchForTriangulation(const ResidentFrame &KF1, const FeatureVector &fv1, const std::vector<uint8_t> &hasMP1,
+                               const ResidentFrame &KF2, const FeatureVector &fv2, const std::vector<uint8_t> &hasMP2, const float F12[9],
+                               float ex, float ey, bool bOnlyStereo, const std::vector<float> &scaleFactors2,
+                               const std::vector<float> &levelSigma2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs)
+    {
+        vMatchedPairs.clear();
+        std::vector<int32_t> m12(KF1.N > 0 ? KF1.N : 1, -1);
+        int nm = 0;
+        mStatus = orbm_frame_search_for_triangulation(KF1.handle(), fv1.nodes.data(), fv1.off.data(), fv1.items.data(), (int)fv1.nodes.size(),
+                                                      hasMP1.data(), KF2.handle(), fv2.nodes.data(), fv2.off.data(), fv2.items.data(),
+                                                      (int)fv2.nodes.size(), hasMP2.data(), bOnlyStereo ? 1 : 0, F12, ex, ey,
+                                                      scaleFactors2.data(), levelSigma2.data(), (int)scaleFactors2.size(),
+                                                      mbCheckOrientation, m12.data(), &nm);
+        if (mStatus != ORBX_OK) return 0;
+        for (int i = 0; i < KF1.N; ++i)
+            if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);
+        return (int)vMatchedPairs.size();
+    }
+
     // ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024).  The FeatureVector co-iteration builds the candidate
     // list of every keypoint of KF1 (the members of the same vocabulary node in KF2, in member order), the device
     // runs the loop with its epipolar gates, the rotation histogram and the pair list are finished here.

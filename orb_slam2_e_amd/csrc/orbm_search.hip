@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(MT) void k_rotation(const int *__restrict__ acc_sp,
 // Keypoints come as cv::KeyPoint records (mvKeysUn; or the extractor's device results, optionally with the undistorted
 // coordinates beside them), n from the host or from the extractor's count array.
 constexpr int FB_T = 1024, FB_MAXN = SEQ_MAXN, FB_NC = FRAME_GRID_COLS * FRAME_GRID_ROWS;
-struct FrameHdr { int n, ns; };
+struct FrameHdr { int n, ns, min_octave, max_octave; };
 constexpr size_t FB_LDS = sizeof(int) * (2 * (size_t)FB_NC + 2) + (size_t)FB_MAXN * (2 + 2 + 1 + 1);
 
 __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__restrict__ kps, const uint4 *__restrict__ desc_raw,
@@ -1192,6 +1192,8 @@ __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__res
     unsigned char *s_low = reinterpret_cast<unsigned char *>(s_pos + FB_MAXN), *s_tot = s_low + FB_MAXN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(n_dev ? *n_dev : n_host, FB_MAXN);
+    __shared__ int s_omin, s_omax;     // octave range of the keypoints (the searches index per-level tables with it)
+    if (tid == 0) { s_omin = INT_MAX; s_omax = INT_MIN; }
     for (int c = tid; c <= FB_NC; c += FB_T) { s_off[c] = 0; s_run[c] = 0; }
     __syncthreads();
     for (int j = tid; j < n; j += FB_T) {
@@ -1253,9 +1255,11 @@ __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__res
         }
     }
     __syncthreads();
+    int omin = INT_MAX, omax = INT_MIN;
     for (int j = tid; j < n; j += FB_T) {
         const int sp = s_pos[j];
         const orbx_keypoint k = kps[j];
+        omin = min(omin, k.octave); omax = max(omax, k.octave);
         SeqKp o;
         o.x = xy_un ? xy_un[j].x : k.x; o.y = xy_un ? xy_un[j].y : k.y;
         o.uright = uright_raw ? uright_raw[j] : -1.0f;
@@ -1263,7 +1267,71 @@ __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__res
         kp[sp] = o; angle[sp] = k.angle; perm[sp] = j;
         desc[2 * sp] = desc_raw[2 * j]; desc[2 * sp + 1] = desc_raw[2 * j + 1];
     }
-    if (tid == 0) { hdr->n = n; hdr->ns = s_off[FB_NC]; }
+    if (omin <= omax) { atomicMin(&s_omin, omin); atomicMax(&s_omax, omax); }
+    __syncthreads();
+    if (tid == 0) { hdr->n = n; hdr->ns = s_off[FB_NC]; hdr->min_octave = s_omin; hdr->max_octave = s_omax; }
+}
+
+// ORBmatcher::SearchForTriangulation's gated loop (src/ORBmatcher.cc:892-990 with CheckDistEpipolarLine :341-358) on two resident
+// frames: 16 lanes per keypoint of KF1, taken in KF1's sorted order (s -> feature i = perm1[s]); its candidates = the members of its
+// vocabulary node in KF2, one copy per node, given as positions in KF2's arrays.  "Stereo" = the frame's right coordinate >= 0
+// (mvuRight[idx] >= 0, :911 / :931).  The reference keeps the LAST candidate among those of smallest distance that pass the gates
+// (`dist > bestDist` is non-strict): the minimum of dist << 16 | (0xffff - position in the list).  Out, by feature index of KF1:
+// match12 = feature index in KF2 or -1; rot = angle1 - angle2 of the pair (:994), for the host's histogram.
+struct TriForm { float F12[9]; float ex, ey; int only_stereo; };
+__global__ __launch_bounds__(MT) void k_triang_frames(const SeqKp *__restrict__ kp1, const uint4 *__restrict__ A, const float *__restrict__ ang1,
+                                                      const int *__restrict__ perm1, int n1, const SeqKp *__restrict__ kp2,
+                                                      const uint4 *__restrict__ B, const float *__restrict__ ang2, const int *__restrict__ perm2,
+                                                      const int *__restrict__ cbeg, const int *__restrict__ clen, const int *__restrict__ cand,
+                                                      const uint8_t *__restrict__ hasmp1, const uint8_t *__restrict__ hasmp2, TriForm tp,
+                                                      const float *__restrict__ scale2, const float *__restrict__ sigma2,
+                                                      int *__restrict__ match12, float *__restrict__ rot)
+{
+    const int s = (blockIdx.x * MT + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (s >= n1) return;                       // (whole 16-lane groups leave together)
+    const int i = perm1[s];
+    const SeqKp k1 = kp1[s];
+    const bool st1 = k1.uright >= 0;
+    unsigned key = 0xffffffffu;
+    int k0 = 0;
+    if (!hasmp1[i] && !(tp.only_stereo && !st1)) {
+        const uint4 a0 = A[2 * s], a1 = A[2 * s + 1];
+        // epipolar line in the second image l = x1' F12 = [a b c]
+        const float a = k1.x * tp.F12[0] + k1.y * tp.F12[3] + tp.F12[6];
+        const float b = k1.x * tp.F12[1] + k1.y * tp.F12[4] + tp.F12[7];
+        const float c = k1.x * tp.F12[2] + k1.y * tp.F12[5] + tp.F12[8];
+        const float den = a * a + b * b;
+        k0 = cbeg[i];
+        const int kend = k0 + clen[i];
+        for (int k = k0 + sub; k < kend; k += 16) {
+            const int p = cand[k];
+            if (hasmp2[perm2[p]]) continue;
+            const SeqKp k2 = kp2[p];
+            const bool st2 = k2.uright >= 0;
+            if (tp.only_stereo && !st2) continue;
+            const int dist = popc256(a0, a1, B[2 * p], B[2 * p + 1]);
+            if (dist > 45) continue;           // TH_LOW
+            if (!st1 && !st2) {
+                const float distex = tp.ex - k2.x, distey = tp.ey - k2.y;
+                if (distex * distex + distey * distey < 100 * scale2[k2.octave]) continue;
+            }
+            const float num = a * k2.x + b * k2.y + c;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if ((double)dsqr < 3.84 * (double)sigma2[k2.octave]) {
+                const unsigned kk = ((unsigned)dist << 16) | (0xffffu - (unsigned)min(k - k0, 0xffff));
+                key = kk < key ? kk : key;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    if (sub == 0) {
+        const bool hit = key != 0xffffffffu;
+        const int p = hit ? cand[k0 + (int)(0xffffu - (key & 0xffffu))] : 0;
+        match12[i] = hit ? perm2[p] : -1;
+        rot[i] = hit ? ang1[s] - ang2[p] : 0.0f;
+    }
 }
 
 // The projection prefixes of the remaining SearchByProjection forms and of SearchBySim3, one thread per list entry, in the
@@ -1432,6 +1500,7 @@ struct FrameView {
 // Read-only after creation: any number of searches, from any thread, may use it at once.
 struct orbm_frame {
     int n = 0, ns = 0, cap = 0, has_uright = 0;
+    int min_octave = 0, max_octave = -1;                    // over the keypoints (empty frame: 0, -1)
     float min_x = 0, min_y = 0, max_x = 0, max_y = 0;       // the bounds the SEARCHES use (cell range of a window, image tests)
     GridParams gp = {0.f, 0.f, 0.f, 0.f};                   // ... with the cell pitch the grid was built with
     char *block = nullptr;
@@ -1519,6 +1588,7 @@ int frame_build(orbm_frame *f, Workspace &w, const orbx_keypoint *d_kps, const u
     FrameHdr h;
     memcpy(&h, pin, sizeof(h));
     f->n = h.n; f->ns = h.ns;
+    f->min_octave = h.n ? h.min_octave : 0; f->max_octave = h.n ? h.max_octave : -1;
     if (h.n < 0 || h.n > n_bound || h.ns < 0 || h.ns > h.n) ORBX_FAIL(ORBX_ERR_HIP, "frame header out of range");
     f->perm_host.assign(reinterpret_cast<const int *>(pin + 256), reinterpret_cast<const int *>(pin + 256) + h.n);
     f->inv_host.assign((size_t)h.n, 0);
@@ -2109,6 +2179,7 @@ int orbm_frame_alias(const orbm_frame *src, float min_x, float min_y, float max_
     if (!src || !out || !(max_x > min_x) || !(max_y > min_y)) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     orbm_frame *f = new orbm_frame();
     f->n = src->n; f->ns = src->ns; f->cap = src->cap; f->has_uright = src->has_uright;
+    f->min_octave = src->min_octave; f->max_octave = src->max_octave;
     f->min_x = min_x; f->min_y = min_y; f->max_x = max_x; f->max_y = max_y;
     f->gp = {min_x, min_y, src->gp.inv_w, src->gp.inv_h};        // KeyFrame: int bounds, the Frame's mfGridElement*Inv (KeyFrame.cc:36,44)
     f->block = src->block; f->refs = src->refs;
@@ -2446,6 +2517,89 @@ int orbm_frame_search_by_bow(const orbm_frame *frame1, const int32_t *nodes1, co
     if (rc != ORBX_OK) return rc;
     for (int i = 0; i < nq; ++i)
         if (mq[i] >= 0 && mk[mq[i]] == i) { match12[L.qidx[i]] = mq[i]; if (match21) match21[mq[i]] = L.qidx[i]; }
+    return ORBX_OK;
+}
+
+int orbm_frame_search_for_triangulation(const orbm_frame *kf1, const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1,
+                                        const uint8_t *has_mappoint1, const orbm_frame *kf2, const int32_t *nodes2, const int32_t *off2,
+                                        const int32_t *items2, int nn2, const uint8_t *has_mappoint2, int only_stereo, const float *F12,
+                                        float ex, float ey, const float *scale_factors2, const float *level_sigma2, int nlevels,
+                                        int check_orientation, int32_t *match12, int *nmatches)
+{
+    if (!kf1 || !kf2 || nn1 < 0 || nn2 < 0 || nlevels < 1 || !nmatches || !F12 || !scale_factors2 || !level_sigma2 ||
+        (kf1->n && (!match12 || !has_mappoint1)) || (kf2->n && !has_mappoint2) || (nn1 && (!nodes1 || !off1 || !items1)) ||
+        (nn2 && (!nodes2 || !off2 || !items2)))
+        ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    const int n1 = kf1->n, n2 = kf2->n;
+    if (bow_check_items(off1, items1, nn1, n1) || bow_check_items(off2, items2, nn2, n2)) ORBX_FAIL(ORBX_ERR_ARG, "feature index out of range");
+    if (n2 && (kf2->min_octave < 0 || kf2->max_octave >= nlevels)) ORBX_FAIL(ORBX_ERR_ARG, "octave out of range");
+    *nmatches = 0;
+    if (n1 == 0) return ORBX_OK;
+    ORBX_NEED_DEVICE();
+    // the co-iteration of :881-891 / :1004-1012: every keypoint of a common node in KF1 scans the node's members of KF2, in member
+    // order -- the member lists once, as positions in KF2's arrays
+    const int nit2 = nn2 ? off2[nn2] : 0;
+    std::vector<int32_t> cbeg((size_t)n1, 0), clen((size_t)n1, 0), cand((size_t)std::max(nit2, 1));
+    for (int k = 0; k < nit2; ++k) cand[k] = kf2->inv_host[items2[k]];
+    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
+        if (nodes1[a] == nodes2[b]) {
+            if (off2[b + 1] - off2[b] > 65535) ORBX_FAIL(ORBX_ERR_CAPACITY, "more than 65,535 candidates for one keypoint (the tie rule's position field)");
+            for (int k = off1[a]; k < off1[a + 1]; ++k) { cbeg[items1[k]] = off2[b]; clen[items1[k]] = off2[b + 1] - off2[b]; }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) ++a;
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) ++b;
+        }
+    }
+    StagedCall sc;
+    const size_t o_cb = sc.in(cbeg.data(), sizeof(int) * (size_t)n1), o_cl = sc.in(clen.data(), sizeof(int) * (size_t)n1),
+                 o_ca = sc.in(cand.data(), sizeof(int) * cand.size()), o_m1 = sc.in(has_mappoint1, (size_t)n1),
+                 o_m2 = sc.in(has_mappoint2, (size_t)n2), o_sc = sc.in(scale_factors2, sizeof(float) * (size_t)nlevels),
+                 o_sg = sc.in(level_sigma2, sizeof(float) * (size_t)nlevels), o_o = sc.out(sizeof(int) * 2 * (size_t)n1);
+    if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
+    TriForm tp;
+    for (int i = 0; i < 9; ++i) tp.F12[i] = F12[i];
+    tp.ex = ex; tp.ey = ey; tp.only_stereo = only_stereo ? 1 : 0;
+    int *om = sc.d<int>(o_o);
+    hipLaunchKernelGGL(k_triang_frames, dim3((unsigned)(((size_t)n1 * 16 + MT - 1) / MT)), dim3(MT), 0, sc.stream(), (const SeqKp *)kf1->kp,
+                       (const uint4 *)kf1->desc, (const float *)kf1->angle, (const int *)kf1->perm, n1, (const SeqKp *)kf2->kp,
+                       (const uint4 *)kf2->desc, (const float *)kf2->angle, (const int *)kf2->perm, sc.d<const int>(o_cb),
+                       sc.d<const int>(o_cl), sc.d<const int>(o_ca), sc.d<const uint8_t>(o_m1), sc.d<const uint8_t>(o_m2), tp,
+                       sc.d<const float>(o_sc), sc.d<const float>(o_sg), om, reinterpret_cast<float *>(om + n1));
+    ORBX_HIP(hipGetLastError());
+    if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
+    memcpy(match12, sc.r<int>(o_o), sizeof(int) * (size_t)n1);
+    if (check_orientation) {
+        const float *rot = reinterpret_cast<const float *>(sc.r<int>(o_o) + n1);
+        constexpr int HL = 30;     // HISTO_LENGTH, ORBmatcher.cc:40
+        int hist[HL] = {0};
+        std::vector<int> bin((size_t)n1, -1);
+        const float factor = 1.0f / HL;
+        for (int i = 0; i < n1; ++i)
+            if (match12[i] >= 0) {
+                float r = rot[i];                                      // :994-1001
+                if (r < 0.0f) r += 360.0f;
+                int b = (int)roundf(r * factor);
+                if (b == HL) b = 0;
+                if (b < 0 || b > HL) ORBX_FAIL(ORBX_ERR_ARG, "keypoint angles outside [0, 360)");   // (the reference asserts)
+                bin[i] = b; hist[b]++;
+            }
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;      // ComputeThreeMaxima, :1802-1843
+        for (int i = 0; i < HL; i++) {
+            const int sz = hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < n1; ++i)
+            if (bin[i] >= 0 && bin[i] != ind1 && bin[i] != ind2 && bin[i] != ind3) match12[i] = -1;
+    }
+    int nm = 0;
+    for (int i = 0; i < n1; ++i) nm += match12[i] >= 0;
+    *nmatches = nm;
     return ORBX_OK;
 }
 

@@ -459,6 +459,25 @@ class ORBmatcher:
                  _p(m12), _p(m21), C.byref(nm)))
         return m12[:frame1.n], m21[:frame2.n], nm.value
 
+    def frame_search_for_triangulation(self, kf1, fv1, has_mp1, kf2, fv2, has_mp2, F12, ex, ey, scale_factors2, level_sigma2,
+                                       bOnlyStereo=False):
+        """SearchForTriangulation on two resident keyframes (orbm_frame_search_for_triangulation).
+        Returns (vMatchedPairs as an (m, 2) array, nmatches, vMatches12)."""
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        (nd1, of1, it1), (nd2, of2, it2) = (tuple(i32(a) for a in fv) for fv in (fv1, fv2))
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2, np.float32)
+        m12 = np.full(max(kf1.n, 1), -1, np.int32); nm = C.c_int(0)
+        fn = bind(self._L.orbm_frame_search_for_triangulation, [C.c_void_p] * 4 + [C.c_int, C.c_void_p] + [C.c_void_p] * 4 +
+                  [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        check(fn(kf1._h, _p(nd1), _p(of1), _p(it1), len(nd1), _p(h1), kf2._h, _p(nd2), _p(of2), _p(it2), len(nd2), _p(h2),
+                 int(bool(bOnlyStereo)), _p(F), float(ex), float(ey), _p(sf), _p(sg), len(sf), int(self.mbCheckOrientation), _p(m12),
+                 C.byref(nm)))
+        m12 = m12[:kf1.n]
+        i1 = np.nonzero(m12 >= 0)[0]
+        return np.stack([i1, m12[i1]], 1), nm.value, m12
+
     # ---------------------------------------------------------------- the projection searches as whole functions
     def SearchByProjectionLast(self, cur, view, Tcw, Tlw, last, occupied, th, bMono, want_queries=False):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1529-1671) in one call: cur = resident

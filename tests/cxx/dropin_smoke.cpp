@@ -199,6 +199,11 @@ int main(int argc, char **argv)
         int selfb = 0;
         for (int i = 0; i < n; ++i) selfb += m12b[i] == i;
         if (mb.status() != ORBX_OK || nb != selfb || selfb < n * 8 / 10) { printf("FAIL SearchByBoW %d %d of %d\n", nb, selfb, n); return 1; }
+        // the same with both frames resident
+        ORBmatcher::ResidentFrame rf(F);
+        std::vector<int32_t> m12r;
+        const int nbr = mb.SearchByBoW(fv, valid, rf, fv, nullptr, rf, m12r);
+        if (rf.status() != ORBX_OK || mb.status() != ORBX_OK || nbr != nb || m12r != m12b) { printf("FAIL SearchByBoW on resident frames %d vs %d\n", nbr, nb); return 1; }
     }
     {
         // SearchForTriangulation of the frame against itself with a skew-symmetric F12 = [t]x (x^T [t]x x = 0: every keypoint
@@ -219,6 +224,10 @@ int main(int argc, char **argv)
         int good = 0;
         for (const auto &pr : pairs) good += node[pr.first] == node[pr.second] && popcount_row(&desc[32 * pr.first], &desc[32 * pr.second]) == 0;
         if (mt.status() != ORBX_OK || nt != n || (int)pairs.size() != n || good != n) { printf("FAIL SearchForTriangulation %d %zu %d of %d\n", nt, pairs.size(), good, n); return 1; }
+        ORBmatcher::ResidentFrame rf(F);
+        std::vector<std::pair<size_t, size_t>> pairs_r;
+        const int ntr = mt.SearchForTriangulation(rf, fv, none, rf, fv, none, F12, t3[0] / t3[2], t3[1] / t3[2], false, sf, sg, pairs_r);
+        if (rf.status() != ORBX_OK || mt.status() != ORBX_OK || ntr != nt || pairs_r != pairs) { printf("FAIL SearchForTriangulation on resident frames %d vs %d\n", ntr, nt); return 1; }
         // ComputeDistinctiveDescriptors: three copies of a descriptor and one outlier -> one of the copies (the first)
         std::vector<uint8_t> obs(4 * 32);
         for (int r = 0; r < 4; ++r) memcpy(&obs[32 * r], &desc[(size_t)32 * (r == 1 ? 7 : 3)], 32);

@@ -189,6 +189,45 @@ def test_search_for_triangulation_whole_function(seed, only_stereo, ori):
         assert rn < (oracle.search_for_triangulation(k1, d1, fv1, mp1, s1, k2, d2, fv2, mp2, s2, F12, ex, ey, sf, sg, only_stereo, False)[1])
 
 
+@pytest.mark.parametrize("seed,only_stereo,ori", [(0, False, True), (1, True, True), (2, False, False), (3, False, True)])
+def test_search_for_triangulation_on_resident_frames(seed, only_stereo, ori):
+    """orbm_frame_search_for_triangulation: both keyframes resident (sorted by cell, stereo = right coordinate >= 0, some keypoints
+    outside the grid), member lists shared per node, angle differences formed on the device -- equal to the host-array call and to
+    the oracle's literal function."""
+    from orb_slam2_e_amd import Frame
+    (k1, d1, k2, d2, _, _, mp1, mp2, s1, s2, F12, ex, ey, sf, sg), _ = _triangulation_case(seed, only_stereo)
+    rng = np.random.default_rng(100 + seed)
+    n = len(k1)
+    node1 = rng.integers(0, 45, n) * 3 + 7
+    node2 = np.where(rng.random(n) < 0.9, node1, rng.integers(0, 50, n) * 3 + 7)
+    node2[node2 == node1[0]] += 1 if seed == 3 else 0
+    k1["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k2["angle"] = np.where(rng.random(n) < 0.8, (k1["angle"] + rng.normal(0, 4, n)) % 360, rng.uniform(0, 360, n)).astype(np.float32)
+    keep1 = rng.random(n) < 0.95; keep2 = rng.random(n) < 0.95
+    fv1, fv2 = oracle.feature_vector(node1, keep1), oracle.feature_vector(node2, keep2)
+    bounds = (float(np.percentile(k1["x"], 5)), float(np.percentile(k1["y"], 5)), float(np.percentile(k1["x"], 95)),
+              float(np.percentile(k1["y"], 95)))                       # tighter than the keypoints' extent: the rim is outside the grid
+    ur1 = np.where(s1, 5.0, -1.0).astype(np.float32); ur2 = np.where(s2, 5.0, -1.0).astype(np.float32)
+    f1, f2 = Frame(k1, d1, bounds, ur1), Frame(k2, d2, bounds, ur2)
+    assert f1.layout()[0].size < n and f2.layout()[0].size < n
+    m = ORBmatcher(0.6, ori)
+    pairs, nm, m12 = m.frame_search_for_triangulation(f1, fv1, mp1, f2, fv2, mp2, F12, ex, ey, sf, sg, only_stereo)
+    r12, rn = oracle.search_for_triangulation(k1, d1, fv1, mp1, s1, k2, d2, fv2, mp2, s2, F12, ex, ey, sf, sg, only_stereo, ori)
+    assert rn > (10 if only_stereo else 60)
+    assert nm == rn and np.array_equal(m12, r12)
+    assert np.array_equal(pairs[:, 0], np.nonzero(r12 >= 0)[0]) and np.array_equal(pairs[:, 1], r12[r12 >= 0])
+    # mono frames (no right coordinates): everything is "not stereo"
+    g1, g2 = Frame(k1, d1, bounds), Frame(k2, d2, bounds)
+    z = np.zeros(n, bool)
+    _, nm0, m0 = m.frame_search_for_triangulation(g1, fv1, mp1, g2, fv2, mp2, F12, ex, ey, sf, sg, False)
+    r0, rn0 = oracle.search_for_triangulation(k1, d1, fv1, mp1, z, k2, d2, fv2, mp2, z, F12, ex, ey, sf, sg, False, ori)
+    assert nm0 == rn0 and np.array_equal(m0, r0)
+    # a level table shorter than the frame's octaves is refused, not read past
+    with pytest.raises(Exception):
+        m.frame_search_for_triangulation(f1, fv1, mp1, f2, fv2, mp2, F12, ex, ey, sf[:3], sg[:3], only_stereo)
+    for f in (f1, f2, g1, g2): f.close()
+
+
 @pytest.mark.parametrize("seed,stereo,init", [(0, False, 256), (1, True, 256), (2, False, 2**31 - 1)])
 def test_search_window_equals_grid_then_selection(seed, stereo, init):
     """orbm_search_window vs GetFeaturesInArea (grid order) + the SearchByProjection loop."""
