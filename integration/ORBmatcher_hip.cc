@@ -62,13 +62,6 @@ struct FlatFeatVec {
     }
 };
 
-static vector<float> AnglesOf(const vector<cv::KeyPoint> &kps)
-{
-    vector<float> a(kps.size());
-    for (size_t i = 0; i < kps.size(); ++i) a[i] = kps[i].angle;
-    return a;
-}
-
 // ---- single pair (src/ORBmatcher.cc:1848-1864).  Kept for the odd caller; loops over pairs belong in the batched entries
 // (orbm_hamming_matrix, orbm_distinctive_descriptors for MapPoint::ComputeDistinctiveDescriptors).
 int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
@@ -240,12 +233,11 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPoi
     const FlatFeatVec f1(pKF->mFeatVec), f2(F.mFeatVec);
     vector<uint8_t> valid1(pKF->N, 0);
     for (int i = 0; i < pKF->N; ++i) valid1[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();       // :395-399
-    const vector<float> a1 = AnglesOf(pKF->mvKeysUn), a2 = AnglesOf(F.mvKeysUn);
     vector<int32_t> match12(pKF->N > 0 ? pKF->N : 1);
-    int nmatches = 0;
-    if (orbm_search_by_bow(f1.nodes.data(), f1.off.data(), f1.items.data(), (int)f1.nodes.size(), valid1.data(), pKF->mDescriptors.data, a1.data(),
-                           pKF->N, f2.nodes.data(), f2.off.data(), f2.items.data(), (int)f2.nodes.size(), nullptr, F.mDescriptors.data, a2.data(), F.N,
-                           TH_LOW, /*strict_th=*/0, mfNNratio, mbCheckOrientation, match12.data(), nullptr, &nmatches) != ORBX_OK)
+    int nmatches = 0;                 // both frames are resident: the feature vectors and the mask are all that travels
+    if (orbm_frame_search_by_bow(pKF->mpHipFrame.get(), f1.nodes.data(), f1.off.data(), f1.items.data(), (int)f1.nodes.size(), valid1.data(),
+                                 F.mpHipFrame.get(), f2.nodes.data(), f2.off.data(), f2.items.data(), (int)f2.nodes.size(), nullptr,
+                                 TH_LOW, /*strict_th=*/0, mfNNratio, mbCheckOrientation, match12.data(), nullptr, &nmatches) != ORBX_OK)
         return 0;
     for (int i = 0; i < pKF->N; ++i)
         if (match12[i] >= 0) vpMapPointMatches[match12[i]] = vpMapPointsKF[i];                          // :433
@@ -261,12 +253,11 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &v
     vector<uint8_t> valid1(pKF1->N, 0), valid2(pKF2->N, 0);
     for (int i = 0; i < pKF1->N; ++i) valid1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();         // :763-767
     for (int i = 0; i < pKF2->N; ++i) valid2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();         // :782-786
-    const vector<float> a1 = AnglesOf(pKF1->mvKeysUn), a2 = AnglesOf(pKF2->mvKeysUn);
     vector<int32_t> match12(pKF1->N > 0 ? pKF1->N : 1);
     int nmatches = 0;
-    if (orbm_search_by_bow(f1.nodes.data(), f1.off.data(), f1.items.data(), (int)f1.nodes.size(), valid1.data(), pKF1->mDescriptors.data, a1.data(),
-                           pKF1->N, f2.nodes.data(), f2.off.data(), f2.items.data(), (int)f2.nodes.size(), valid2.data(), pKF2->mDescriptors.data,
-                           a2.data(), pKF2->N, TH_LOW, /*strict_th=*/1, mfNNratio, mbCheckOrientation, match12.data(), nullptr, &nmatches) != ORBX_OK)
+    if (orbm_frame_search_by_bow(pKF1->mpHipFrame.get(), f1.nodes.data(), f1.off.data(), f1.items.data(), (int)f1.nodes.size(), valid1.data(),
+                                 pKF2->mpHipFrame.get(), f2.nodes.data(), f2.off.data(), f2.items.data(), (int)f2.nodes.size(), valid2.data(),
+                                 TH_LOW, /*strict_th=*/1, mfNNratio, mbCheckOrientation, match12.data(), nullptr, &nmatches) != ORBX_OK)
         return 0;
     for (int i = 0; i < pKF1->N; ++i)
         if (match12[i] >= 0) vpMatches12[i] = vpMapPoints2[match12[i]];                                 // :803
@@ -299,19 +290,18 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
     const FlatFeatVec f1(pKF1->mFeatVec), f2(pKF2->mFeatVec);
     const int n1 = pKF1->N, n2 = pKF2->N;
-    vector<uint8_t> has1(n1, 0), has2(n2, 0), st1(n1, 0), st2(n2, 0);
-    for (int i = 0; i < n1; ++i) { has1[i] = pKF1->GetMapPoint(i) != NULL; st1[i] = pKF1->mvuRight[i] >= 0; }     // :900-907
-    for (int i = 0; i < n2; ++i) { has2[i] = pKF2->GetMapPoint(i) != NULL; st2[i] = pKF2->mvuRight[i] >= 0; }     // :921-927
+    vector<uint8_t> has1(n1, 0), has2(n2, 0);      // "stereo" (mvuRight >= 0, :911 / :931) is read from the resident frames
+    for (int i = 0; i < n1; ++i) has1[i] = pKF1->GetMapPoint(i) != NULL;                                           // :900-907
+    for (int i = 0; i < n2; ++i) has2[i] = pKF2->GetMapPoint(i) != NULL;                                           // :921-927
     float F[9];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F[3 * r + c] = F12.at<float>(r, c);
     vector<int32_t> match12(n1 > 0 ? n1 : 1);
     int nmatches = 0;
-    if (orbm_search_for_triangulation(reinterpret_cast<const orbx_keypoint *>(pKF1->mvKeysUn.data()), pKF1->mDescriptors.data, n1, f1.nodes.data(),
-                                      f1.off.data(), f1.items.data(), (int)f1.nodes.size(), has1.data(), st1.data(),
-                                      reinterpret_cast<const orbx_keypoint *>(pKF2->mvKeysUn.data()), pKF2->mDescriptors.data, n2, f2.nodes.data(),
-                                      f2.off.data(), f2.items.data(), (int)f2.nodes.size(), has2.data(), st2.data(), bOnlyStereo, F, ex, ey,
-                                      pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(), pKF2->mnScaleLevels, mbCheckOrientation,
-                                      match12.data(), &nmatches) != ORBX_OK)
+    if (orbm_frame_search_for_triangulation(pKF1->mpHipFrame.get(), f1.nodes.data(), f1.off.data(), f1.items.data(), (int)f1.nodes.size(),
+                                            has1.data(), pKF2->mpHipFrame.get(), f2.nodes.data(), f2.off.data(), f2.items.data(),
+                                            (int)f2.nodes.size(), has2.data(), bOnlyStereo, F, ex, ey, pKF2->mvScaleFactors.data(),
+                                            pKF2->mvLevelSigma2.data(), pKF2->mnScaleLevels, mbCheckOrientation, match12.data(),
+                                            &nmatches) != ORBX_OK)
         return 0;
     vMatchedPairs.clear();
     vMatchedPairs.reserve(nmatches);
