@@ -30,8 +30,11 @@ sys.path.insert(0, ROOT)
 W, H, BATCH = 640, 480, 64
 PARAMS = (2000, 1.2, 8, 20, 7)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Integer VALU issue rate: one wave64 instruction per 4 clocks per SIMD (tools/ubench/valu.hip), 1024 SIMDs, 2.4 GHz
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0
+# Vector-instruction issue ceiling of the whole chip, MEASURED (tools/ubench/mfma_overlap.hip, round 4: 3,072 waves of dependent
+# v_med3 / v_min / v_add on 1,024 SIMDs, 590 M wave64 instructions in 0.843 ms): a SIMD issues one wave64 VALU instruction per
+# ~2.3 clocks when several waves have one ready, and the clock settles at 1.5-1.6 GHz under that load -- 1.46 ns per instruction
+# and SIMD.  (Rounds 1-3 priced against 1024 x 2.4 GHz / 4 = 614: one instruction per 4 clocks is what ONE wave sustains.)
+VALU_PEAK_GINST = 700.0
 # MI355X_MICROARCH.md, Matrix cores: FP4 (v_mfma_f32_32x32x64_f8f6f4) dense peak; the all-pairs matcher runs on it
 MFMA_FP4_PEAK_TFLOPS = 10000.0
 # SURVEY 8(d) algorithmic bytes per 640x480 frame, by stage
