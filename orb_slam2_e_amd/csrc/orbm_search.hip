@@ -2415,6 +2415,8 @@ struct BowLists {
 void bow_lists(const int32_t *nodes1, const int32_t *off1, const int32_t *items1, int nn1, const uint8_t *valid1, const int32_t *nodes2,
                const int32_t *off2, const int32_t *items2, int nn2, const uint8_t *valid2, int n2, const int *inv2, BowLists &L)
 {
+    const size_t m1 = nn1 ? (size_t)off1[nn1] : 0, m2 = nn2 ? (size_t)off2[nn2] : 0;
+    L.qidx.reserve(m1); L.cand_beg.reserve(m1); L.cand_off.reserve(m1 + 1); L.cand.reserve(m2); L.seg.reserve((size_t)std::min(nn1, nn2) + 1);
     L.cand_off.assign(1, 0); L.seg.assign(1, 0);
     std::vector<uint8_t> seen(n2 ? n2 : 1, 0);
     for (int a = 0, b = 0; a < nn1 && b < nn2;) {
