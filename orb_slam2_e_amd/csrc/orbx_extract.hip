@@ -465,7 +465,7 @@ __device__ __forceinline__ uint32_t fast_pretest4(const uint8_t *p, uint32_t th2
 }
 // dark and bright both possible over all eight pairs cannot be a corner -> 0
 __device__ __forceinline__ uint32_t fast_resolve(uint32_t code) { return code & ~((code & (code >> 1) & 0x01010101u) * 3u); }
-constexpr unsigned FAST_PAIRS_A = 0x11u, FAST_PAIRS_B = 0xeeu;   // compass pairs 0/8 and 4/12 first, the other six on what is left
+constexpr unsigned FAST_PAIRS_A = 0x11u;   // compass pairs 0/8 and 4/12 on every pixel; the other six on what is left, pixel by pixel
 
 // cornerScore<16>: (largest arc-minimum of e_k over the 16 circular 9-arcs) - 1
 // where e = d (dark) or -d (bright), d_k = v - p_k; it is a corner at threshold th iff that
@@ -517,8 +517,9 @@ __device__ __forceinline__ uint32_t fast_arc_best_packed(const uint32_t X[8])
 // (2a) every pixel, 4 adjacent pixels per lane on packed u16: the opposite-pair pre-test on the two compass
 // pairs only (0/8 and 4/12: the vertical pair needs no byte shuffling across dwords); the 4-pixel groups that still
 // hold a possible corner (18 % of them at level 0, 67 % at level 7 on the synthetic frames) are compacted in raster
-// order into an LDS group queue; (2b) the other six pairs on the queued groups only, survivors (4 % ... 28 % of the
-// pixels) compacted in raster order into the pixel queue; (3) survivors only: arc score -> score map (0 below
+// order into an LDS group queue; (2b) the queued groups' live pixels go to the pixel queue, and the other six pairs are tested
+// with a lane per pixel (a group-wise test on packed halves worked on all four pixels of a group of which one or two were
+// alive), survivors (4 % ... 28 % of the pixels) compacted in place; (3) survivors only: arc score -> score map (0 below
 // the pass's threshold, which is all the non-max test needs: a neighbour that is no corner at this threshold scores
 // less than any corner); (4) 3x3 strict NMS; (5) ordered emission.
 // TS / SS (tile and score-map strides) are compile-time so that the 16 circle
@@ -607,33 +608,58 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             }
             __syncthreads();
             ORBX_PH(1, lane == 0);   // stage A
-            // (2b) the other six pairs on the queued groups, survivors -> queue entries y<<6 | x | polarity<<12
-            int nq = 0;
+            // (2b) the other six pairs, per PIXEL: of a queued group's four pixels one or two are still alive, and a lane that tests a
+            // whole group on packed halves works on all four (151 instructions per 64 groups against 61 + 45 per 64 pixels).
+            // First the queued groups' alive pixels (compass code != 0, inside the zone) go to the pixel queue in raster order, entry
+            // y<<6 | x | compass code<<12 ...
+            int np = 0;
             for (int q0 = 0; q0 < ngq; q0 += 64) {
                 uint32_t code = 0;
                 int ent = 0;
                 if (q0 + lane < ngq) {
                     const uint32_t e = gqueue[q0 + lane];
                     const int y = (e >> 2) & 63, gx = (e >> 10) & 63;
-                    code = fast_resolve(fast_pretest4<TS, FAST_PAIRS_B>(tile + __mul24(y + 3, TS) + 4 * (g0 + gx), th2) & e & 0x03030303u);
-                    ent = (y << 6) + 4 * (g0 + gx) - zc0;                  // zone x of the group's pixel 0: 4 gx
-                    code &= 0xffffffffu >> (8 * max(0, 4 * gx + 4 - zw));   // pixels at zone x >= zw are outside
+                    ent = (y << 6) + 4 * gx;                                                   // zone x of the group's pixel 0
+                    code = e & 0x03030303u & (0xffffffffu >> (8 * max(0, 4 * gx + 4 - zw)));   // pixels at zone x >= zw are outside
                 }
                 if (__ballot(code != 0)) {
-                    // survivors of this lane: bytes 0..3 are 0/1/2 -> one bit per pixel, n = how many
+                    // alive pixels of this lane: bytes 0..3 are 0..3 -> one bit per pixel, n = how many
                     const uint32_t nz = (code | (code >> 1)) & 0x01010101u;
                     const int n = __popc(nz);
                     const unsigned long long c0 = __ballot(n & 1), c1 = __ballot(n & 2), c2 = __ballot(n & 4);
-                    int pos = nq + mask_rank(c0) + 2 * mask_rank(c1) + 4 * mask_rank(c2);
+                    int pos = np + mask_rank(c0) + 2 * mask_rank(c1) + 4 * mask_rank(c2);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { // branch-free: rejected pixels go to the lane's dump slot
-                        const int pol = (code >> (8 * j)) & 3;
-                        unsigned short *dst = pol ? queue + pos : dump + lane;
-                        *dst = (unsigned short)((ent + j) | (pol << 12));
-                        pos += pol != 0;
+                    for (int j = 0; j < 4; ++j) { // branch-free: dead pixels go to the lane's dump slot
+                        const int ac = (code >> (8 * j)) & 3;
+                        unsigned short *dst = ac ? queue + pos : dump + lane;
+                        *dst = (unsigned short)((ent + j) | (ac << 12));
+                        pos += ac != 0;
                     }
-                    nq += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
+                    np += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
                 }
+            }
+            // ... then a lane per pixel: max over the six pairs of min(p_k, p_k+8) and min of their max, the two threshold tests, ANDed with
+            // the compass code; both polarities possible over all eight pairs cannot be a corner.  Survivors are compacted IN PLACE
+            // (entry y<<6 | x | polarity<<12): a write lands at or below the position its lane read in this round, and the wave reads
+            // before it writes.
+            int nq = 0;
+            for (int q0 = 0; q0 < np; q0 += 64) {
+                int pol = 0, ent = 0;
+                if (q0 + lane < np) {
+                    const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63, ac = e >> 12;
+                    ent = e & 0xfff;
+                    const uint8_t *t = t0 + y * TS + x;
+                    const int v = t[0];
+                    const int a1 = t[3 * TS + 1], b1 = t[-3 * TS - 1], a2 = t[2 * TS + 2], b2 = t[-2 * TS - 2], a3 = t[TS + 3], b3 = t[-TS - 3];
+                    const int a5 = t[-TS + 3], b5 = t[TS - 3], a6 = t[-2 * TS + 2], b6 = t[2 * TS - 2], a7 = t[-3 * TS + 1], b7 = t[3 * TS - 1];
+                    const int lo = max(max(max(min(a1, b1), min(a2, b2)), min(a3, b3)), max(max(min(a5, b5), min(a6, b6)), min(a7, b7)));
+                    const int hi = min(min(min(max(a1, b1), max(a2, b2)), max(a3, b3)), min(min(max(a5, b5), max(a6, b6)), max(a7, b7)));
+                    const bool dark = (ac & 1) && v > lo + th, bright = (ac & 2) && hi > v + th;
+                    pol = dark == bright ? 0 : dark ? 1 : 2;
+                }
+                const unsigned long long bm = __ballot(pol != 0);
+                if (pol) queue[nq + mask_rank(bm)] = (unsigned short)(ent | (pol << 12));
+                nq += __popcll(bm);
             }
             __syncthreads();
             ORBX_PH(2, lane == 0);   // stage B
