@@ -521,7 +521,7 @@ __device__ __forceinline__ uint32_t fast_arc_best_packed(const uint32_t X[8])
 // with a lane per pixel (a group-wise test on packed halves worked on all four pixels of a group of which one or two were
 // alive), survivors (4 % ... 28 % of the pixels) compacted in place; (3) survivors only: arc score -> score map (0 below
 // the pass's threshold, which is all the non-max test needs: a neighbour that is no corner at this threshold scores
-// less than any corner); (4) 3x3 strict NMS; (5) ordered emission.
+// less than any corner); (4) 3x3 strict NMS and ordered emission, one loop.
 // TS / SS (tile and score-map strides) are compile-time so that the 16 circle
 // offsets fold into ds_read immediates.
 template <int TS, int SS>
@@ -690,11 +690,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             }
             __syncthreads();
             ORBX_PH(3, lane == 0);   // zero + arc score
-            // (4) 3x3 strict non-max suppression on the survivors
-            unsigned long long mx = 0;
-            int it = 0;
-            for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
+            // (4) 3x3 strict non-max suppression on the survivors and (5) emission in queue (= raster) order, pass by pass of 64
+            for (int q0 = 0; q0 < nq; q0 += 64) {
                 bool ismax = false;
+                uint32_t word = 0;
                 if (q0 + lane < nq) {
                     const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
                     const uint8_t *q = sc + (y + 1) * SS + x + 1;
@@ -703,21 +702,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     // branches: eight LDS bytes, three v_max3, one compare
                     const int m = max(max(max(q[-1], q[1]), max(q[-SS - 1], q[-SS])), max(max(q[-SS + 1], q[SS - 1]), max(q[SS], q[SS + 1])));
                     ismax = s > m;
+                    word = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | (uint32_t)s;
                 }
-                mx |= (unsigned long long)ismax << it;
-            }
-            // (5) emission in queue (= raster) order
-            it = 0;
-            for (int q0 = 0; q0 < nq; q0 += 64, ++it) {
-                const bool flag = (mx >> it) & 1ull;
-                const unsigned long long b = __ballot(flag);
-                if (flag) {
-                    const int e = queue[q0 + lane], x = e & 63, y = (e >> 6) & 63;
-                    const int pos = total + __popcll(b & lt);
-                    const uint32_t s = sc[(y + 1) * SS + x + 1];
-                    if (pos < ci.cap)
-                        out[pos] = ((uint32_t)(ci.dy + y + 3) << 20) | ((uint32_t)(ci.dx + x + 3) << 8) | s;
-                }
+                const unsigned long long b = __ballot(ismax);
+                const int pos = total + __popcll(b & lt);
+                if (ismax && pos < ci.cap) out[pos] = word;
                 total += __popcll(b);
             }
             ORBX_PH(4, lane == 0);   // NMS + emission
