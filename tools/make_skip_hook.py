@@ -4,6 +4,9 @@ applies the edits in place, writes `git diff` of csrc/ to the patch file and res
 with a clean orb_slam2_e_amd/csrc."""
 import subprocess, sys
 
+if subprocess.run(["git", "diff", "--quiet", "--", "orb_slam2_e_amd/csrc"]).returncode != 0:
+    sys.exit("orb_slam2_e_amd/csrc has uncommitted changes: this script restores it from git when it is done -- commit or stash first")
+
 def edit(path, pairs):
     s = open(path).read()
     for old, new in pairs:
