@@ -174,6 +174,14 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)   // (a[23
     asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+// a[23:0] * b[23:0], low 32 bits, as ONE full-rate instruction: the compiler folds __mul24 of values whose range it cannot see back into
+// v_mul_lo_u32 (quarter rate)
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ uint32_t resize_vertical(int r0, int r1, uint32_t bs0, uint32_t bs1)
 {
     const uint32_t t0 = mulhi_u24(bs0, (uint32_t)r0 & 0xfffff0u);
@@ -1232,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         const int i = lane + 64 * s4, row = i >> 3, pc = i & 7;
         const int yin = min(bt.y0 - 3 + row, lv.h + EDGE - 1), xo = min(PADX + bt.x0 - 16 + 16 * pc, lv.stride - 16);
         *reinterpret_cast<uint4 *>(wn + row * BLUR_IROW + 16 * pc) =
-            *reinterpret_cast<const uint4 *>(pyr + (base - PADX) + (uint32_t)((yin + EDGE) * lv.stride + xo));
+            *reinterpret_cast<const uint4 *>(pyr + (base - PADX) + (uint32_t)(__mul24(yin + EDGE, lv.stride) + xo));   // (24-bit factors: a full-rate multiply)
     }
     asm volatile("" : "+v"(f1.x), "+v"(f1.y), "+v"(f1.z), "+v"(f1.w), "+v"(f2.x), "+v"(f2.y), "+v"(f2.z), "+v"(f2.w));   // pins the loads above this point
     const blur_v4i b1 = {(int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w}, b2 = {(int)f2.x, (int)f2.y, (int)f2.z, (int)f2.w};
@@ -1285,8 +1293,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         const int i = lane + 64 * s, c = i / BLUR_TH, row = i - c * BLUR_TH;   // rows fastest: four neighbouring lanes = 64 contiguous bytes of a strip
         const int x = bt.x0 + 16 * c, y = bt.y0 + row;
         if (c < BLUR_SW / 16 && y < lv.h && x < lv.w)
-            *reinterpret_cast<uint4 *>(bdst + (uint32_t)(((PADX + x) >> 4) * bt.bcol + (y + EDGE) * 16)) =
-                *reinterpret_cast<const uint4 *>(st + row * BLUR_LROW + 16 * c);
+            *reinterpret_cast<uint4 *>(bdst + (uint32_t)(__mul24((PADX + x) >> 4, bt.bcol) + (y + EDGE) * 16)) =
+                *reinterpret_cast<const uint4 *>(st + mul_u24((uint32_t)row, BLUR_LROW) + 16 * c);
     }
 }
 
@@ -1453,7 +1461,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int col = dd / PROWS, row = dd - PROWS * col;
         poffA[jj] = (uint32_t)(row * 16 + __mul24((8 * col) >> 4, bcol) + ((8 * col) & 15));
         poffB[jj] = (uint32_t)(row * 16 + __mul24((8 + 8 * col) >> 4, bcol) + ((8 + 8 * col) & 15) - 8);   // (the base below already carries the 8)
-        pslot[jj] = row * PW + 2 * col;
+        pslot[jj] = (int)mul_u24((uint32_t)row, PW) + 2 * col;
     }
     uint2 nxt[PD][NPL];
     auto load_patch = [&](int j, uint2 (&r)[NPL]) {   // unused slots read slot 0's window (no branch in front of a load)
