@@ -172,13 +172,16 @@ __global__ __launch_bounds__(64 * MSEG) void k_match_sets(const uint8_t *__restr
 // (1 - 2t) and query bit q to -(1 - 2q) / 2, sum_k a_k b_k = hamming - 128, and +-1 / +-0.5 are exact FP4
 // (E2M1) values, so v_mfma_f32_32x32x64_f8f6f4 computes 32 x 32 distances from four K = 64 steps at the FP4
 // rate (8 x the K of the bf16 form per cycle) with exact small-integer f32 sums.  The accumulator is seeded
-// with 128 + j * 2^-15 (j = train index of the row), so every output element IS the selection key
-// dist + j / 32768: at most 9 + 15 significant bits, exact in f32, positive, and ordered like its bit
-// pattern -- the (smallest, second smallest) update of k_match_sets runs on it unchanged, two VALU
-// instructions per pair instead of 8 xor + 8 bcnt + pack + 2.  The K order inside a step is whatever the
-// hardware uses: both operands are expanded by the same function of (lane half, step), and a dot product
-// does not care.  Train rows sit on M (the 16 accumulator registers of a lane), queries on N (the lane),
-// so a lane folds its registers into the running pair of its own query with no cross-lane traffic.
+// with 128 + r * 2^-15 (r = the row inside its 32-row tile), and the tile's first row * 2^-15 is added to what
+// leaves the tile, so the values that compete ARE the selection keys dist + j / 32768 (j = train index): at
+// most 9 + 15 significant bits, exact in f32, positive, and ordered like their bit patterns.  The K order inside
+// a step is whatever the hardware uses: both operands are expanded by the same function of (lane half,
+// step), and a dot product does not care.  Train rows sit on M (the 16 accumulator registers of a lane),
+// queries on N (the lane), so a lane folds its registers into the running pair of its own query with no
+// cross-lane traffic -- and it folds ONE key per MFMA result, the smallest of its 16 (five v_min3_u32 and
+// three more): the pair (smallest key, second smallest GROUP minimum) differs from (smallest, second smallest)
+// only by what the winner's own group hides, 15 keys that the finishing lane recomputes with popcounts at the
+// very end (group_rest_min).  40 fold instructions per train tile and wave instead of 128.
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -222,7 +225,7 @@ __device__ __forceinline__ void merge_pairs(unsigned &m1, unsigned &m2, unsigned
 }
 
 // One 32-row train tile against the XQ query tiles of the wave: expand, 4 x XQ MFMAs, fold the keys.
-__device__ __forceinline__ void mfma_tile(const uint4 &x, const v16f &c, const v8i (&bq)[XQ][4], unsigned (&k1)[XQ], unsigned (&k2)[XQ])
+__device__ __forceinline__ void mfma_tile(const uint4 &x, const v16f &c, float tilebase, const v8i (&bq)[XQ][4], unsigned (&k1)[XQ], unsigned (&k2)[XQ])
 {
     const v8i a0 = expand_fp4<FP4_TRAIN>(x.x), a1 = expand_fp4<FP4_TRAIN>(x.y), a2 = expand_fp4<FP4_TRAIN>(x.z),
               a3 = expand_fp4<FP4_TRAIN>(x.w);
@@ -232,9 +235,36 @@ __device__ __forceinline__ void mfma_tile(const uint4 &x, const v16f &c, const v
         acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[q][1], acc, 4, 4, 0, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a2, bq[q][2], acc, 4, 4, 0, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a3, bq[q][3], acc, 4, 4, 0, 0, 0, 0);
+        // ONE key per MFMA result enters the running pair: the smallest of the lane's 16 (v_min3_u32 on the bit patterns: positive
+        // floats order like integers) -- 10 instructions instead of 32.  The pair then holds the smallest key and the second smallest
+        // GROUP minimum; what the groups hide is only the rest of the winner's own group, and that is looked at once, at the very end
+        // (group_rest_min).
+        unsigned u[16];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) key_update_f(acc[g], k1[q], k2[q]);
+        for (int g = 0; g < 16; ++g) u[g] = __float_as_uint(acc[g]);
+        const unsigned t0 = min(min(u[0], u[1]), u[2]), t1 = min(min(u[3], u[4]), u[5]), t2 = min(min(u[6], u[7]), u[8]),
+                       t3 = min(min(u[9], u[10]), u[11]), t4 = min(min(u[12], u[13]), u[14]);
+        const unsigned m = min(min(min(t0, t1), t2), min(min(t3, t4), u[15]));
+        key_update_f(__uint_as_float(m) + tilebase, k1[q], k2[q]);   // the tile's first row joins the index part here: once per result, not per accumulator
     }
+}
+
+// The keys of the other rows of the winner's group -- the 16 rows of tile idx / 32 that share its lane half: 8 a + 4 h + b, a, b = 0..3,
+// h = bit 2 of the row -- against query descriptor (a0, a1): the smallest of them (XKEY_INF if there is none below nB).
+__device__ __forceinline__ unsigned group_rest_min(const uint4 &a0, const uint4 &a1, const uint4 *__restrict__ B, int idx, int nB)
+{
+    const int base = (idx & ~31) + (idx & 4);
+    unsigned m = XKEY_INF;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = base + 8 * a + b, jc = min(j, nB - 1);
+            const int dist = popc256(a0, a1, B[2 * jc], B[2 * jc + 1]);
+            const unsigned key = __float_as_uint((float)dist + (float)j * XIDX);
+            m = (j != idx && j < nB && key < m) ? key : m;
+        }
+    return m;
 }
 
 // Workgroup = XW waves x (XQ * 32 = 128 queries); wave `seg` scans the train tiles seg, seg + XW, ... .
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(64 * XW) void k_match_sets_mfma(const uint8_t *__re
     // accumulator register g of this lane is train row (g & 3) + 8 * (g >> 2) + 4 * h of the tile
     v16f c;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) c[g] = 128.0f + (float)(seg * 32 + (g & 3) + 8 * (g >> 2) + 4 * h) * XIDX;
+    for (int g = 0; g < 16; ++g) c[g] = 128.0f + (float)((g & 3) + 8 * (g >> 2) + 4 * h) * XIDX;     // the row inside its tile
     // full tiles first (no row test anywhere in that loop), then the one ragged tile, which belongs to one wave
     const int nfull = nB >> 5;
     uint4 nx = make_uint4(0, 0, 0, 0);
@@ -274,17 +304,14 @@ __global__ __launch_bounds__(64 * XW) void k_match_sets_mfma(const uint8_t *__re
     for (int t = seg; t < nfull; t += XW) {
         const uint4 x = nx;
         if (t + XW < nfull) nx = B[2 * ((t + XW) * 32 + r) + h];                // in flight during this tile
-        mfma_tile(x, c, bq, k1, k2);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) c[g] += (float)(32 * XW) * XIDX;          // XW tiles further
+        mfma_tile(x, c, (float)(32 * t) * XIDX, bq, k1, k2);
     }
     if ((nB & 31) && (nfull % XW) == seg) {
-        // c of this wave stands at tile seg + XW * (its full tiles) = nfull
         const uint4 x = B[2 * min(nfull * 32 + r, nB - 1) + h];
 #pragma unroll
         for (int g = 0; g < 16; ++g)
             if (nfull * 32 + (g & 3) + 8 * (g >> 2) + 4 * h >= nB) c[g] = __uint_as_float(XKEY_INF);   // rows past the set never win
-        mfma_tile(x, c, bq, k1, k2);
+        mfma_tile(x, c, (float)(32 * nfull) * XIDX, bq, k1, k2);
     }
     // fold the two lane halves (rows 4h.. of every tile), then the four waves
 #pragma unroll
@@ -300,9 +327,14 @@ __global__ __launch_bounds__(64 * XW) void k_match_sets_mfma(const uint8_t *__re
         unsigned m1 = sk[0][qt][0][r], m2 = sk[0][qt][1][r];
 #pragma unroll
         for (int g = 1; g < XW; ++g) merge_pairs(m1, m2, sk[g][qt][0][r], sk[g][qt][1][r]);
-        const float f1 = __uint_as_float(m1), f2 = __uint_as_float(m2);
+        const float f1 = __uint_as_float(m1);
         const int d1 = (int)f1;
         const int best = nB > 0 ? d1 : INT_MAX, idx = nB > 0 ? (int)((f1 - (float)d1) * 32768.0f) : -1;
+        if (nB > 1) {   // m2 = the second smallest group minimum so far: the rest of the winner's group may hold something smaller
+            const unsigned gm = group_rest_min(A[2 * i], A[2 * i + 1], B, idx, nB);
+            m2 = gm < m2 ? gm : m2;
+        }
+        const float f2 = __uint_as_float(m2);
         const int second = nB > 1 ? (int)f2 : INT_MAX;
         const size_t o = (size_t)p * cap + i;
         if (best_o) best_o[o] = best;
