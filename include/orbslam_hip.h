@@ -543,10 +543,12 @@ int orbm_debug_force_sequential_resolver(int on);
 int orbm_debug_last_resolver_iterations(void);
 
 /* Which kernel the all-pairs matchers (orbm_match_batch_dev, orbm_match_bruteforce) launch.  Both produce the same
- * integers.  ORBM_ALLPAIRS_AUTO (default): the matrix-core kernel (FP4 MFMA computes the selection keys, 3.5x
- * faster at 2000 x 2000) for sets up to 32768 rows, the XOR + popcount kernel above that; ORBM_ALLPAIRS_POPCOUNT:
- * always the wavefront popcount + LDS-reduction kernel BASELINE.json's north_star describes; ORBM_ALLPAIRS_MFMA:
- * as AUTO.  Process-wide; returns the previous setting, or a negative status for an unknown value. */
+ * integers.  ORBM_ALLPAIRS_AUTO (default): a matrix-core kernel (FP4 MFMA computes the selection keys, 4x
+ * faster at 2000 x 2000; train tiles expanded once per workgroup and shared through LDS) for sets up to 32768 rows, the
+ * XOR + popcount kernel above that; ORBM_ALLPAIRS_POPCOUNT: always the wavefront popcount + LDS-reduction kernel
+ * BASELINE.json's north_star describes; ORBM_ALLPAIRS_MFMA: the matrix-core kernel that splits the train tiles over a
+ * workgroup's waves (a little faster alone, more vector instructions).  Process-wide; returns the previous setting, or a
+ * negative status for an unknown value. */
 enum { ORBM_ALLPAIRS_AUTO = 0, ORBM_ALLPAIRS_POPCOUNT = 1, ORBM_ALLPAIRS_MFMA = 2 };
 int orbm_set_allpairs_kernel(int kind);
 

@@ -31,7 +31,7 @@ def rand_sets(nA, nB):
 
 
 for case in range(n):
-    kern = ORBmatcher.ALLPAIRS_POPCOUNT if rng.random() < 0.4 else ORBmatcher.ALLPAIRS_AUTO
+    kern = [ORBmatcher.ALLPAIRS_POPCOUNT, ORBmatcher.ALLPAIRS_MFMA, ORBmatcher.ALLPAIRS_AUTO][int(rng.choice(3, p=[0.3, 0.3, 0.4]))]
     prev = ORBmatcher.set_allpairs_kernel(kern)
     try:
         big = rng.random() < 0.1

@@ -23,10 +23,10 @@ def test_known_answers():
     assert ORBmatcher.DescriptorDistance(z, one) == 1
 
 
-@pytest.fixture(params=["matrix cores", "popcount"])
+@pytest.fixture(params=["matrix cores", "matrix cores, tiles split over waves", "popcount"])
 def allpairs_kernel(request):
-    """Both all-pairs kernels behind orbm_match_bruteforce / orbm_match_batch_dev must give the same integers."""
-    prev = ORBmatcher.set_allpairs_kernel(ORBmatcher.ALLPAIRS_POPCOUNT if request.param == "popcount" else ORBmatcher.ALLPAIRS_AUTO)
+    """All three all-pairs kernels behind orbm_match_bruteforce / orbm_match_batch_dev must give the same integers."""
+    prev = ORBmatcher.set_allpairs_kernel({"popcount": ORBmatcher.ALLPAIRS_POPCOUNT, "matrix cores": ORBmatcher.ALLPAIRS_AUTO}.get(request.param, ORBmatcher.ALLPAIRS_MFMA))
     yield request.param
     ORBmatcher.set_allpairs_kernel(prev)
 
