@@ -736,7 +736,7 @@ static void launch_match_sets(hipStream_t st, const uint8_t *desc, const int *co
                               int th, float nnratio, int *best, int *second, int *idx, int *match12, int *nmatch)
 {
     // Two matrix-core kernels, bit-identical results.  AUTO: train tiles shared by a workgroup through LDS (fewer vector instructions:
-    // 6.1 M against 9.4 M per 64-pair launch; 39 us alone against 37, but the pipelined step is 0.9 % faster with it and a 20-step
+    // 7.5 M against 9.4 M per 64-pair launch; 39 us alone against 37, but the pipelined step is 0.9 % faster with it and a 20-step
     // region 3 %: what a kernel issues is what the other contexts' kernels wait behind).  ORBM_ALLPAIRS_MFMA: the kernel that splits
     // the train tiles over a workgroup's waves.
     const int kind = g_allpairs_kind.load(std::memory_order_relaxed);
