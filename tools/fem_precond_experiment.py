@@ -2,7 +2,13 @@
 fem_cg runs) and under 3 x 3 node-block Jacobi (VERDICT r03 item 7 asked for it).  CPU only (the oracle's assembly + scipy), float64
 vectors on the float matrix like the device CG.  Result (round 4): 1274 vs 1116 iterations -- 12 % fewer, against 9 instead of 3
 preconditioner values per node in a kernel whose registers are spoken for; not built.  Incomplete factorisation without fill breaks
-down on this matrix (near-incompressible material)."""
+down on this matrix (near-incompressible material).
+Second experiment (end of round 4): Jacobi + an additive coarse correction Z Ac^-1 Z^T with Z = the rigid-body modes (3 translations,
+optionally 3 rotations) of g^3 geometric aggregates.  Iterations to 1e-8: 2^3 aggregates 784 / 470 (24 / 48 coarse dofs), 3^3: 616 / 345
+(81 / 162), 4^3: 521 / 284 (192 / 384) against 1274 -- 2.7x fewer with a 48 x 48 coarse inverse (18 KB) and ~12 % more work per
+iteration (48 dot products over the residual, a 48 x 48 product, 6 multiply-adds per row; no more matrix traffic).  That meets what the
+review asked of a preconditioner; it needs a deterministic segmented reduction and three more barriers in k_fem_cg_resident, a setup
+kernel for Ac = Z^T K Z, the same algorithm in the oracle, and all three CG paths -- the first thing to build next."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
@@ -40,3 +46,37 @@ try:
     x3,it3=pcg(A,b,lambda r:ilu.solve(r))
     print("ilu(0)-ish iters",it3)
 except Exception as e: print(e)
+
+
+# ---- second experiment: additive two-level preconditioner, rigid-body modes of geometric aggregates
+nn = n // 3
+P = np.asarray(nodes, np.float64).reshape(nn, 3)
+free = np.ones(n, bool); free[fixed] = False
+def coarse(g, rot):
+    lo = P.min(0); hi = P.max(0) + 1e-9
+    idx = np.minimum(((P - lo) / (hi - lo) * g).astype(int), g - 1)
+    agg = idx[:, 0] * g * g + idx[:, 1] * g + idx[:, 2]
+    rows, cols, vals, k = [], [], [], 0
+    for a in range(g ** 3):
+        m = np.nonzero(agg == a)[0]
+        if len(m) == 0: continue
+        q = P[m] - P[m].mean(0)
+        modes = [np.eye(3)[t][None, :].repeat(len(m), 0) for t in range(3)]
+        if rot:
+            z0 = np.zeros(len(m))
+            modes += [np.stack([z0, -q[:, 2], q[:, 1]], 1), np.stack([q[:, 2], z0, -q[:, 0]], 1), np.stack([-q[:, 1], q[:, 0], z0], 1)]
+        for v in modes:
+            for t in range(3):
+                rows += (3 * m + t).tolist(); cols += [k] * len(m); vals += v[:, t].tolist()
+            k += 1
+    Z = sp.diags(free.astype(float)) @ sp.csr_matrix((vals, (rows, cols)), shape=(n, k))   # eliminated dofs stay out of the coarse space
+    Ac = (Z.T @ A @ Z).toarray()
+    keep = np.abs(np.diag(Ac)) > 1e-12 * np.abs(np.diag(Ac)).max()
+    Z = Z[:, keep]
+    return Z, np.linalg.inv(Ac[np.ix_(keep, keep)])
+for g in (2, 3, 4):
+    for rot in (False, True):
+        Z, Aci = coarse(g, rot)
+        xk, itk = pcg(A, b, lambda r: r / d + Z @ (Aci @ (Z.T @ r)))
+        print("aggregates %d^3, rotations %s: %d coarse dofs, %d iterations (%.2fx fewer), solution differs by %.1e" %
+              (g, rot, Z.shape[1], itk, it1 / itk, np.abs(x1 - xk).max() / np.abs(x1).max()))
