@@ -394,3 +394,27 @@ def test_feature_vector_candidates_equal_the_literal_co_iteration():
         assert off[0] == 0 and off[-1] == len(idx)
         for i in range(n1):
             assert list(idx[off[i]:off[i + 1]]) == lists[i], (trial, i)
+
+
+def test_array_pointer_helper_and_kernel_switch():
+    """_lib.ptr gives the address ctypes' data_as gives (writable, read-only, empty, strided, structured arrays) and keeps its array alive;
+    orbm_set_allpairs_kernel knows three kernels and returns the previous setting (host-only: no device needed)."""
+    import ctypes as C, gc, weakref
+    from orb_slam2_e_amd._lib import lib, ptr
+    from orb_slam2_e_amd import KP_DTYPE, ORBmatcher
+    a = np.arange(100, dtype=np.int32)
+    ro = np.arange(7.0); ro.flags.writeable = False
+    for arr in (a, ro, np.zeros(0, np.uint8), a[::3], np.zeros(5, KP_DTYPE)):
+        assert ptr(arr).value == (arr.ctypes.data or None) or (arr.size == 0 and ptr(arr).value in (None, arr.ctypes.data))
+
+    class Arr(np.ndarray):
+        pass
+    t = np.zeros(10).view(Arr); w = weakref.ref(t); p = ptr(t); del t; gc.collect()
+    assert w() is not None
+    del p; gc.collect()
+    assert w() is None
+    L = lib()
+    prev = ORBmatcher.set_allpairs_kernel(ORBmatcher.ALLPAIRS_MFMA)
+    assert ORBmatcher.set_allpairs_kernel(ORBmatcher.ALLPAIRS_POPCOUNT) == ORBmatcher.ALLPAIRS_MFMA
+    assert L.orbm_set_allpairs_kernel(7) < 0                              # unknown kind: refused, setting unchanged
+    assert ORBmatcher.set_allpairs_kernel(prev) == ORBmatcher.ALLPAIRS_POPCOUNT
