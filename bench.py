@@ -843,7 +843,7 @@ def main():
                                  "rectangles and discs + per-frame noise; frame i is matched against frame i+1 mod 64",
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
                        "preconditioning_steps": PRECONDITION_STEPS,   # untimed, in front of the W warm-up steps: clock conditioning
-                       "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma (FP4 matrix cores)",
+                       "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma_shared (FP4 matrix cores, train tiles shared through LDS)",
                        "parallelism": (f"frames sharded {BATCH}/rank, results gathered on rank 0 ({GE} steps per "
                                         f"{'gloo' if rehearse else 'RCCL'} gather)") if world > 1 else "single GPU",
                        "dist_backend": (args.dist_backend if world > 1 else None),
