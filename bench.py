@@ -866,10 +866,10 @@ def main():
         pair_flops = 512.0 * float((nk[qa.cpu().long()] * nk[qb.cpu().long()]).sum())
         mm_ms = split_ms.get("k_match_sets_mfma", 0.0)
         if mm_ms > 0 and args.match_kernel != "popcount":
-            out["matcher_mfma"] = {"kernel": "k_match_sets_mfma", "bound": "mfma", "achieved": pair_flops / (mm_ms * 1e-3) / 1e12,
+            out["matcher_mfma"] = {"kernel": "k_match_sets_mfma_shared", "bound": "mfma", "achieved": pair_flops / (mm_ms * 1e-3) / 1e12,
                                    "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pair_flops / (mm_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                                    "flops_per_launch": pair_flops, "launch_ms_untimed_pass": mm_ms,
-                                   "note": "FP4 MFMA computes the selection keys; the top-2 fold (2 VALU instructions per pair) bounds it"}
+                                   "note": "FP4 MFMA computes the selection keys; one key per MFMA result enters the running pair, the winner's group is finished with popcounts; bounded by matrix time + LDS round trips at two waves per SIMD"}
         if dom == "k_match_sets_mfma" and args.match_kernel != "popcount":
             tf = pair_flops / (avg_launch_ms * 1e-3) / 1e12
             out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
