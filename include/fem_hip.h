@@ -144,6 +144,19 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
  * slices of 25 iterations between its convergence tests.  Other models launch phase by phase.  Both sum in fixed orders: a given model, right-hand side and iteration count give the same bits every run. */
 int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int *iters_done, double *relres);
 
+/* Preconditioner of fem_cg / fem_cg_setup (default FEM_PRECOND_JACOBI: z = r / diag).  FEM_PRECOND_TWO_LEVEL adds a coarse correction,
+ * z = r / diag + Z Ac^-1 Z^T r: Z = the six rigid-body modes (translations, rotations about the centroid) of 2 x 2 x 2 geometric
+ * aggregates of each mesh's nodes (split at the midpoint of the bounding box per axis) -- 48 coarse dofs per mesh --, Ac = Z^T K Z,
+ * rows of Z at dofs named in fem_dirichlet_penalty / fem_dirichlet_eliminate since the last fem_assemble are zero.  Point-Jacobi
+ * leaves the smooth error of a near-incompressible solid (nu -> 0.5) to thousands of iterations; the coarse term removes it:
+ * 1,274 -> 470 iterations to ||r|| <= 1e-8 ||b|| on BASELINE config 3's mesh.  Costs 48 matrix-vector products and a 48 x 48
+ * inverse per mesh in fem_cg_setup and a few per cent per iteration.  No reference counterpart (neither has the CG): the oracle's
+ * oracle_fem_cg_two_level is the definition.  Takes effect at the next fem_cg / fem_cg_setup. */
+enum { FEM_PRECOND_JACOBI = 0, FEM_PRECOND_TWO_LEVEL = 1 };
+int fem_cg_preconditioner(fem_model *m, int kind);
+/* Z^T K Z of one mesh as the last fem_cg_setup formed it (48 x 48, row-major); introspection for the tests. */
+int fem_cg_coarse_matrix(fem_model *m, int mesh, double *Ac);
+
 /* Resident variants for timing: upload the right-hand side and reset the solver
  * state; run n iterations asynchronously on `stream` (no host sync, no
  * convergence test); read the iterate back. */

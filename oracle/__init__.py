@@ -368,6 +368,44 @@ def fem_cg(rp, col, val, b, iters, tol=0.0):
     return x, it, rel.value
 
 
+def fem_cg_two_level(rp, col, val, b, iters, nodes, cmask=None, tol=0.0):
+    """CG with the two-level preconditioner (Jacobi + rigid-body modes of 2 x 2 x 2 aggregates); see fem_oracle.c."""
+    L = lib()
+    b = np.ascontiguousarray(b, np.float64)
+    nodes = np.ascontiguousarray(nodes, np.float32)
+    cm = np.zeros(len(b), np.uint8) if cmask is None else np.ascontiguousarray(cmask, np.uint8)
+    L.oracle_fem_cg_two_level.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    x = np.zeros_like(b); rel = C.c_double()
+    it = L.oracle_fem_cg_two_level(len(b), _p(rp), _p(col), _p(val), _p(b), _p(x), iters, tol, C.byref(rel), _p(nodes), _p(cm))
+    return x, it, rel.value
+
+
+def fem_coarse_matrix(rp, col, val, nodes, cmask=None):
+    L = lib()
+    n = len(rp) - 1
+    nodes = np.ascontiguousarray(nodes, np.float32)
+    cm = np.zeros(n, np.uint8) if cmask is None else np.ascontiguousarray(cmask, np.uint8)
+    Ac = np.zeros((48, 48), np.float64)
+    L.oracle_fem_coarse_matrix(n, _p(rp), _p(col), _p(val), _p(nodes), _p(cm), _p(Ac))
+    return Ac
+
+
+def fem_coarse_inverse(Ac):
+    L = lib()
+    a = np.array(Ac, np.float64, order="C", copy=True)
+    L.oracle_fem_coarse_inverse(_p(a))
+    return a
+
+
+def fem_coarse_space(nodes):
+    L = lib()
+    nodes = np.ascontiguousarray(nodes, np.float32).reshape(-1, 3)
+    agg = np.zeros(len(nodes), np.int32); q = np.zeros((len(nodes), 3), np.float32)
+    L.oracle_fem_coarse_space(len(nodes), _p(nodes), _p(agg), _p(q))
+    return agg, q
+
+
 def fem_csr_matvec(rp, col, val, x):
     L = lib()
     x = np.ascontiguousarray(x, np.float64)

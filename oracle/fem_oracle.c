@@ -331,6 +331,172 @@ int oracle_fem_cg(int n, const int *rowptr, const int *col, const float *val, co
     return it;
 }
 
+/* ---- Two-level preconditioner of the CG (no reference counterpart: this is the definition, as for the CG itself).
+ * M^-1 = D^-1 + Z Ac^-1 Z^T, Ac = Z^T K Z, Z = the six rigid-body modes (three translations, three rotations about the
+ * aggregate's centroid) of 2 x 2 x 2 geometric aggregates of the nodes: 48 coarse dofs.  A node's aggregate: per axis, bit =
+ * (double)P > 0.5 * ((double)lo + (double)hi) with lo / hi the float extremes of that coordinate; aggregate = 4 bx + 2 by + bz.
+ * q = (float)((double)P - centroid), centroid = double sum in node order / count.  Rows of constrained dofs (cmask != 0) are zero
+ * in Z.  Ac is symmetrised, coarse dofs whose diagonal is <= 1e-12 of the largest are dropped (row and column zero in the
+ * inverse), the inverse comes from a Cholesky factorisation in double and is symmetrised again. */
+#define CZ_NA 8
+#define CZ_NC 48
+void oracle_fem_coarse_space(int nn, const float *nodes, int *agg, float *q)
+{
+    double mid[3], cen[CZ_NA][3];
+    int cnt[CZ_NA], i, k, a;
+    for (k = 0; k < 3; k++) {
+        float lo = nodes[k], hi = nodes[k];
+        for (i = 1; i < nn; i++) { float v = nodes[3 * i + k]; if (v < lo) lo = v; if (v > hi) hi = v; }
+        mid[k] = 0.5 * ((double)lo + (double)hi);
+    }
+    for (a = 0; a < CZ_NA; a++) { cnt[a] = 0; cen[a][0] = cen[a][1] = cen[a][2] = 0; }
+    for (i = 0; i < nn; i++) {
+        a = 0;
+        for (k = 0; k < 3; k++) a = 2 * a + ((double)nodes[3 * i + k] > mid[k] ? 1 : 0);
+        agg[i] = a; cnt[a]++;
+        for (k = 0; k < 3; k++) cen[a][k] += (double)nodes[3 * i + k];
+    }
+    for (a = 0; a < CZ_NA; a++) for (k = 0; k < 3; k++) if (cnt[a]) cen[a][k] /= (double)cnt[a];
+    for (i = 0; i < nn; i++) for (k = 0; k < 3; k++) q[3 * i + k] = (float)((double)nodes[3 * i + k] - cen[agg[i]][k]);
+}
+/* w = Z^T r */
+static void cz_restrict(int nn, const int *agg, const float *q, const uint8_t *cmask, const double *r, double *w)
+{
+    int i, k;
+    for (k = 0; k < CZ_NC; k++) w[k] = 0;
+    for (i = 0; i < nn; i++) {
+        double *wa = w + 6 * agg[i];
+        const double r0 = cmask[3 * i] ? 0.0 : r[3 * i], r1 = cmask[3 * i + 1] ? 0.0 : r[3 * i + 1], r2 = cmask[3 * i + 2] ? 0.0 : r[3 * i + 2];
+        const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
+        wa[0] += r0; wa[1] += r1; wa[2] += r2;
+        wa[3] += q1 * r2 - q2 * r1; wa[4] += q2 * r0 - q0 * r2; wa[5] += q0 * r1 - q1 * r0;   /* q x r */
+    }
+}
+/* c = Z v */
+static void cz_prolong(int nn, const int *agg, const float *q, const uint8_t *cmask, const double *v, double *c)
+{
+    int i;
+    for (i = 0; i < nn; i++) {
+        const double *va = v + 6 * agg[i];
+        const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
+        c[3 * i] = cmask[3 * i] ? 0.0 : va[0] + (va[4] * q2 - va[5] * q1);            /* v + omega x q */
+        c[3 * i + 1] = cmask[3 * i + 1] ? 0.0 : va[1] + (va[5] * q0 - va[3] * q2);
+        c[3 * i + 2] = cmask[3 * i + 2] ? 0.0 : va[2] + (va[3] * q1 - va[4] * q0);
+    }
+}
+/* inverse of the symmetrised coarse matrix with the dropped dofs zeroed; a[] is overwritten */
+void oracle_fem_coarse_inverse(double *a /*48 x 48, in: Ac, out: inverse*/)
+{
+    double L[CZ_NC][CZ_NC], inv[CZ_NC][CZ_NC], y[CZ_NC], dmax = 0;
+    int keep[CZ_NC], i, j, k;
+    for (i = 0; i < CZ_NC; i++) for (j = 0; j < i; j++) { double s = 0.5 * (a[i * CZ_NC + j] + a[j * CZ_NC + i]); a[i * CZ_NC + j] = a[j * CZ_NC + i] = s; }
+    for (i = 0; i < CZ_NC; i++) if (a[i * CZ_NC + i] > dmax) dmax = a[i * CZ_NC + i];
+    for (i = 0; i < CZ_NC; i++) keep[i] = a[i * CZ_NC + i] > 1e-12 * dmax;
+    for (i = 0; i < CZ_NC; i++) for (j = 0; j < CZ_NC; j++) L[i][j] = 0;
+    for (j = 0; j < CZ_NC; j++) {
+        double s;
+        if (!keep[j]) continue;
+        s = a[j * CZ_NC + j];
+        for (k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+        if (!(s > 0)) { keep[j] = 0; for (k = 0; k < j; k++) L[j][k] = 0; continue; }   /* numerically dependent: dropped too */
+        L[j][j] = sqrt(s);
+        for (i = j + 1; i < CZ_NC; i++) {
+            if (!keep[i]) continue;
+            s = a[i * CZ_NC + j];
+            for (k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            L[i][j] = s / L[j][j];
+        }
+    }
+    for (k = 0; k < CZ_NC; k++) {                 /* column k of the inverse: L y = e_k, L^T x = y */
+        for (i = 0; i < CZ_NC; i++) inv[i][k] = 0;
+        if (!keep[k]) continue;
+        for (i = 0; i < CZ_NC; i++) {
+            double s = (i == k) ? 1.0 : 0.0;
+            if (!keep[i]) { y[i] = 0; continue; }
+            for (j = 0; j < i; j++) s -= L[i][j] * y[j];
+            y[i] = s / L[i][i];
+        }
+        for (i = CZ_NC - 1; i >= 0; i--) {
+            double s = y[i];
+            if (!keep[i]) continue;
+            for (j = i + 1; j < CZ_NC; j++) s -= L[j][i] * inv[j][k];
+            inv[i][k] = s / L[i][i];
+        }
+    }
+    for (i = 0; i < CZ_NC; i++) for (j = 0; j <= i; j++) a[i * CZ_NC + j] = a[j * CZ_NC + i] = 0.5 * (inv[i][j] + inv[j][i]);
+}
+/* The coarse matrix Z^T K Z of a float CSR matrix (column k = Z^T (K (Z e_k))); exported for the tests. */
+void oracle_fem_coarse_matrix(int n, const int *rowptr, const int *col, const float *val, const float *nodes, const uint8_t *cmask,
+                              double *Ac /*48 x 48*/)
+{
+    const int nn = n / 3;
+    int *agg = (int *)malloc(sizeof(int) * nn), i, k, kk;
+    float *q = (float *)malloc(sizeof(float) * 3 * nn);
+    double *z = (double *)malloc(sizeof(double) * n), *y = (double *)malloc(sizeof(double) * n), e[CZ_NC], w[CZ_NC];
+    oracle_fem_coarse_space(nn, nodes, agg, q);
+    for (k = 0; k < CZ_NC; k++) {
+        for (kk = 0; kk < CZ_NC; kk++) e[kk] = kk == k;
+        cz_prolong(nn, agg, q, cmask, e, z);
+        for (i = 0; i < n; i++) { double s = 0; for (kk = rowptr[i]; kk < rowptr[i + 1]; kk++) s += (double)val[kk] * z[col[kk]]; y[i] = s; }
+        cz_restrict(nn, agg, q, cmask, y, w);
+        for (kk = 0; kk < CZ_NC; kk++) Ac[kk * CZ_NC + k] = w[kk];
+    }
+    free(agg); free(q); free(z); free(y);
+}
+/* CG as oracle_fem_cg with z = r/diag + Z Ac^-1 Z^T r; r.z is formed as r.(r/diag) + (Z^T r).(Ac^-1 Z^T r). */
+int oracle_fem_cg_two_level(int n, const int *rowptr, const int *col, const float *val, const double *b, double *x,
+                            int iters, double tol, double *relres, const float *nodes, const uint8_t *cmask)
+{
+    const int nn = n / 3;
+    double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n), *c = (double *)malloc(sizeof(double) * n);
+    double *p = (double *)malloc(sizeof(double) * n), *Ap = (double *)malloc(sizeof(double) * n);
+    double *dinv = (double *)malloc(sizeof(double) * n), Aci[CZ_NC * CZ_NC], w[CZ_NC], v[CZ_NC];
+    int *agg = (int *)malloc(sizeof(int) * nn);
+    float *q = (float *)malloc(sizeof(float) * 3 * nn);
+    double rz = 0, bb = 0, rr, wv;
+    int i, k, j, it = 0;
+    oracle_fem_coarse_space(nn, nodes, agg, q);
+    oracle_fem_coarse_matrix(n, rowptr, col, val, nodes, cmask, Aci);
+    oracle_fem_coarse_inverse(Aci);
+    for (i = 0; i < n; i++) {
+        double d = 1.0;
+        for (k = rowptr[i]; k < rowptr[i + 1]; k++) if (col[k] == i) d = (double)val[k];
+        dinv[i] = 1.0 / d;
+        x[i] = 0; r[i] = b[i]; z[i] = r[i] * dinv[i];
+        rz += r[i] * z[i]; bb += b[i] * b[i];
+    }
+    cz_restrict(nn, agg, q, cmask, r, w);
+    for (k = 0, wv = 0; k < CZ_NC; k++) { double s = 0; for (j = 0; j < CZ_NC; j++) s += Aci[k * CZ_NC + j] * w[j]; v[k] = s; wv += w[k] * s; }
+    cz_prolong(nn, agg, q, cmask, v, c);
+    rz += wv;
+    for (i = 0; i < n; i++) p[i] = z[i] + c[i];
+    rr = bb;
+    while (it < iters && !(sqrt(rr) <= tol * sqrt(bb))) {
+        double pAp = 0, alpha, beta, rz2 = 0;
+        for (i = 0; i < n; i++) {
+            double s = 0;
+            for (k = rowptr[i]; k < rowptr[i + 1]; k++) s += (double)val[k] * p[col[k]];
+            Ap[i] = s; pAp += p[i] * s;
+        }
+        alpha = pAp > 0.0 ? rz / pAp : 0.0;
+        rr = 0;
+        for (i = 0; i < n; i++) {
+            x[i] += alpha * p[i]; r[i] -= alpha * Ap[i];
+            z[i] = r[i] * dinv[i]; rz2 += r[i] * z[i]; rr += r[i] * r[i];
+        }
+        cz_restrict(nn, agg, q, cmask, r, w);
+        for (k = 0, wv = 0; k < CZ_NC; k++) { double s = 0; for (j = 0; j < CZ_NC; j++) s += Aci[k * CZ_NC + j] * w[j]; v[k] = s; wv += w[k] * s; }
+        cz_prolong(nn, agg, q, cmask, v, c);
+        rz2 += wv;
+        beta = rz > 0.0 ? rz2 / rz : 0.0; rz = rz2;
+        for (i = 0; i < n; i++) p[i] = (z[i] + c[i]) + beta * p[i];
+        it++;
+    }
+    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0;
+    free(r); free(z); free(c); free(p); free(Ap); free(dinv); free(agg); free(q);
+    return it;
+}
+
 /* CSR y = A*x in double (float values), for residual checks. */
 void oracle_fem_csr_matvec(int n, const int *rowptr, const int *col, const float *val, const double *x, double *y)
 {

@@ -160,6 +160,16 @@ class FEA2:
         return x, done.value, rel
 
     # resident / timing API
+    def cg_preconditioner(self, kind):
+        """fem_cg_preconditioner: "jacobi" (default) or "two_level" (Jacobi + rigid-body modes of 2 x 2 x 2 aggregates)."""
+        k = {"jacobi": 0, "two_level": 1}.get(kind, kind)
+        check(bind(self._L.fem_cg_preconditioner, [C.c_void_p, C.c_int])(self._h, int(k)))
+
+    def cg_coarse_matrix(self, mesh=0):
+        Ac = np.zeros((48, 48), np.float64)
+        check(bind(self._L.fem_cg_coarse_matrix, [C.c_void_p, C.c_int, C.c_void_p])(self._h, mesh, _p(Ac)))
+        return Ac
+
     def cg_setup(self, b):
         b = self._vec(b, np.float64)
         check(self._L.fem_cg_setup(self._h, _p(b)))

@@ -1,0 +1,106 @@
+"""GPU parity of the CG's two-level preconditioner (fem_cg_preconditioner(FEM_PRECOND_TWO_LEVEL): Jacobi + the rigid-body modes of
+2 x 2 x 2 aggregates, include/fem_hip.h) against oracle_fem_cg_two_level on the exported CSR of the same mesh.  Neither has a
+reference counterpart (the reference's only solve is a dead dense inverse, FEA2.cc:1661-1691): the oracle is the definition.
+Displacements within 1e-5 relative (north_star), the coarse matrix Z^T K Z within 1e-10 of its largest entry, relative residuals
+after a fixed number of iterations within 1e-6."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from orb_slam2_e_amd.fem import FEA2, FEA2Batch, FEM_TET4
+from orb_slam2_e_amd.synth import synth_tet_batch, synth_tet_batch_distinct, synth_tet_mesh
+
+RTOL = 1e-5
+
+
+def _mask(n, fixed):
+    m = np.zeros(n, np.uint8); m[fixed] = 1
+    return m
+
+
+def _check(x, rel, ox, orel, what):
+    assert np.abs(x - ox).max() <= RTOL * np.abs(ox).max(), what
+    assert abs(rel - orel) <= 1e-6 * orel + 1e-12, what
+
+
+@pytest.mark.parametrize("ncell", [3, 6, 12])
+def test_single_mesh_two_level(ncell):
+    """One mesh (launch per phase, hipGraph replay of 50 iterations): the coarse matrix, 120 iterations, and the solve to 1e-10 --
+    same iteration count as the oracle to within the 25-iteration test cadence, and far fewer than Jacobi needs."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=ncell)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    b = load.copy(); b[fixed] = 0
+    xj, itj, relj = fea.solve_cg(b, iters=20000, tol=1e-10)
+    fea.cg_preconditioner("two_level")
+    rp, col, val = fea.csr(0)
+    mask = _mask(len(b), fixed)
+    x, done, rel = fea.solve_cg(b, iters=120, tol=0.0)
+    Ac = fea.cg_coarse_matrix(0)
+    oAc = oracle.fem_coarse_matrix(rp, col, val, nodes, mask)
+    assert np.abs(Ac - oAc).max() <= 1e-10 * np.abs(oAc).max()
+    ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b, 120, nodes, mask)
+    assert done == 120
+    _check(x[0], rel[0], ox, orel, "120 iterations")
+    x, it, rel = fea.solve_cg(b, iters=20000, tol=1e-10)
+    ox, oit, orel = oracle.fem_cg_two_level(rp, col, val, b, 20000, nodes, mask, tol=1e-10)
+    assert rel[0] <= 1e-10 and oit <= it < oit + 25 and it < 0.7 * itj, (it, oit, itj)
+    assert np.abs(x[0] - ox).max() <= RTOL * np.abs(ox).max()
+    assert np.abs(x[0] - xj[0]).max() <= RTOL * np.abs(xj[0]).max()
+    # back to Jacobi: bit-identical to the run before the preconditioner was ever switched on
+    fea.cg_preconditioner("jacobi")
+    xj2, itj2, relj2 = fea.solve_cg(b, iters=20000, tol=1e-10)
+    assert itj2 == itj and np.array_equal(xj2, xj) and np.array_equal(relj2, relj)
+
+
+@pytest.mark.parametrize("nmesh,ncell,iters", [(5, 4, 60), (20, 3, 40), (64, 5, 61), (70, 12, 30), (64, 14, 25)])
+def test_uniform_batch_two_level(nmesh, ncell, iters):
+    """Batches of one topology with their own coordinates (so their own aggregates' centroids and coarse matrices): below and above
+    the fused-step threshold, and the sizes that run resident on the compute units under Jacobi."""
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=ncell)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    fea.cg_preconditioner("two_level")
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    x, done, rel = fea.solve_cg(b, iters=iters, tol=0.0)
+    assert done == iters
+    mask = _mask(b.shape[1], fixed)
+    for m in sorted({0, nmesh // 2, nmesh - 1}):
+        rp, col, val = fea.csr(m)
+        oAc = oracle.fem_coarse_matrix(rp, col, val, nodes[m], mask)
+        assert np.abs(fea.cg_coarse_matrix(m) - oAc).max() <= 1e-10 * np.abs(oAc).max()
+        ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[m], iters, nodes[m], mask)
+        _check(x[m], rel[m], ox, orel, m)
+    assert not np.array_equal(x[0], x[1])
+    # the same iterations in three calls: bit-identical
+    fea.cg_setup(b)
+    fea.cg_iterate(1); fea.cg_iterate(iters - 8); fea.cg_iterate(7)
+    x2, rel2 = fea.cg_result()
+    assert np.array_equal(x2, x) and np.array_equal(rel2, rel)
+
+
+@pytest.mark.parametrize("n,base", [(7, 4), (72, 5)])
+def test_segmented_batch_two_level(n, base):
+    """Meshes of their own sizes and topologies concatenated (fem_create_batch): aggregates, coarse matrices and the coarse dot
+    products are per mesh."""
+    nodes_l, tets_l, fixed_l, load_l = synth_tet_batch_distinct(n, base=base)
+    fb = FEA2Batch(nodes_l, tets_l, FEM_TET4)
+    fb.MatrixAssembly()
+    fixed = np.concatenate([fb.dof0[k] + fx for k, fx in enumerate(fixed_l)]).astype(np.int32)
+    fb.eliminate_dofs(fixed)
+    fb.cg_preconditioner("two_level")
+    b = np.concatenate(load_l); b[fixed] = 0
+    x, done, rel = fb.solve_cg(b, iters=50, tol=0.0)
+    assert done == 50 and len(rel) == n
+    for k in range(0, n, 1 if n < 10 else 9):
+        rp, col, val = fb.csr(k)
+        d0, d1 = fb.dof0[k], fb.dof0[k + 1]
+        mask = _mask(d1 - d0, fixed_l[k])
+        oAc = oracle.fem_coarse_matrix(rp, col, val, nodes_l[k], mask)
+        assert np.abs(fb.cg_coarse_matrix(k) - oAc).max() <= 1e-10 * np.abs(oAc).max()
+        ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[d0:d1], 50, nodes_l[k], mask)
+        _check(x[0, d0:d1], rel[k], ox, orel, k)
