@@ -825,7 +825,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
 // Ac^-1 w, so the vector kernels keep their sums and the coarse part adds a 48-term dot product.
 // Data, per mesh: cz[] = one float4 per node in AGGREGATE order {q = node - centroid of its aggregate, bits: node | constrained dofs
 // << 28} (a constrained dof has a zero row in Z), czptr[9] = where each aggregate's nodes start, aci[48][48] = the symmetric inverse.
-constexpr int CZ_NA = 8, CZ_NC = 6 * CZ_NA, CZ_T = 256;
+constexpr int CZ_NA = 8, CZ_NC = 6 * CZ_NA, CZ_T = 256, CZR_U = 5;   // CZR_U x 64: the largest aggregate k_fem_cg_resident takes
 struct CzNode { double q0, q1, q2; int node; bool m0, m1, m2; };
 __device__ __forceinline__ CzNode cz_node(const float4 e)
 {
@@ -1012,21 +1012,46 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
 // tiling CGR_MAXROWS_BIG would take 14,336) --: Ap and x live in the mesh's slice of the batch vectors instead
 // (written and read by the same compute unit: with 1/diag + 48 bytes per dof and iteration beside the matrix's ~175), r in registers.
 constexpr int CGR_T = 512, CGR_W = CGR_T / 64, CGR_NB = 4, CGR_CB = 64 * CGR_NB, CGR_MAXROWS = 7168, CGR_MAXROWS_BIG = 14336, CGR_MIN_MESHES = 64;
+// Sum over the wave, the same value in every lane, in a fixed order: four DPP row_shr steps leave each row of 16 lanes' total in its
+// last lane, the four row totals are read into scalars and added row 0 .. 3.  No LDS round trips: the xor butterfly through
+// ds_bpermute (12 of them per f64 sum, each step waiting for the last) was 2 us of the 5 the coarse correction added per iteration.
+template <int N> __device__ __forceinline__ double dpp_shr_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x110 + N, 0xf, 0xf, true);         // row_shr:N, 0 from beyond the row
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x110 + N, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_shr_f64<1>(v);
+    v += dpp_shr_f64<2>(v);
+    v += dpp_shr_f64<4>(v);
+    v += dpp_shr_f64<8>(v);
+    return ((readlane_f64(v, 15) + readlane_f64(v, 31)) + readlane_f64(v, 47)) + readlane_f64(v, 63);
 }
-template <bool BIG>
+// COARSE (not with BIG): the two-level preconditioner inside the launch.  Wave a owns aggregate a (CGR_W = CZ_NA): after the update
+// r is parked in Ap's LDS slots (K p is no longer needed), wave a sums its aggregate's six modes from there (lane-strided, xor
+// butterflies) and forms ITS six columns' share of v = Ac^-1 w -- lane k holds Ac^-1[k][6a .. 6a+5] in registers for the whole launch --,
+// every wave then adds the eight shares in wave order, has w.v for beta, and writes Z v for its aggregate's nodes over r in LDS,
+// which the direction update adds.  Five barriers per iteration instead of three; no vector leaves the compute unit.
+template <bool BIG, bool COARSE>
 __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restrict__ vals_b, const int *__restrict__ bcol3,
                                                            const int *__restrict__ bp, const int4 *__restrict__ rcd,
                                                            const int *__restrict__ rcfirst, size_t nnzs, int ndof, int ldn,
                                                            int niter, CgScal *__restrict__ sc, double *__restrict__ p,
                                                            const double *__restrict__ dinv, double *__restrict__ x,
                                                            double *__restrict__ r, double *__restrict__ Apg,
-                                                           const int4 *__restrict__ minfo)
+                                                           const int4 *__restrict__ minfo, const float4 *__restrict__ cz,
+                                                           const int *__restrict__ czptr, const double *__restrict__ aci)
 {
+    static_assert(!(BIG && COARSE) && CGR_W == CZ_NA && CZR_U == 5, "the coarse correction needs r in LDS and a wave per aggregate");
     extern __shared__ __align__(16) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mesh = blockIdx.x;
@@ -1049,6 +1074,16 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         if (u * CGR_T + tid < nrows) p_s[i] = p[row0 + i];
     }
     double rz = sc[mesh].rz[0], rr = sc[mesh].rr;   // both rz slots hold the current value between launches of this kernel
+    // COARSE: this wave's aggregate (its nodes in cz[zp0 .. zp1)), lane k's six entries of the inverse, the scratch (in wave 0's
+    // slice of the product's partials, idle between the barriers that use it): eight shares of v, then w
+    const float4 *lz = COARSE ? cz + row0 / 3 : nullptr;
+    const int zp0 = COARSE ? czptr[9 * mesh + wave] : 0, zp1 = COARSE ? czptr[9 * mesh + wave + 1] : 0;
+    double *cz_share = lds + NV * ldn, *cz_w = cz_share + CZ_NA * CZ_NC;
+    double ac6[COARSE ? 6 : 1];
+    if constexpr (COARSE) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) ac6[m] = aci[(size_t)mesh * (CZ_NC * CZ_NC) + (6 * wave + m) * CZ_NC + min(lane, CZ_NC - 1)];
+    }
     // a chunk's loads: its descriptor (wave-uniform), per lane two blocks (clamped: lanes past the chunk repeat its last
     // block) and the block-row pointer of block row `lane`
     float nva[CGR_NB][9]; int nca[CGR_NB], nbpl; int4 nd;
@@ -1174,15 +1209,67 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
                     rv[u] = ri;
                     s1 += ri * (ri * dv[u]);
                     s2 += ri * ri;
+                    if constexpr (COARSE) Ap_s[i] = ri;   // K p has been used: its slot carries r to the restriction
                 }
             }
         }
         s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
         if (lane == 0) { shi[CGR_W + wave] = s1; shi[2 * CGR_W + wave] = s2; }
+        // COARSE: the wave's aggregate -- at most CZR_U x 64 nodes (plan: larger aggregates go phase by phase; config 3 has 275) -- is
+        // requested before the barrier, all entries at once (a loop of unknown length around a load would also make the compiler wait
+        // for ALL outstanding loads, the next chunk's matrix blocks included, wherever it loses count)
+        float4 ce[COARSE ? CZR_U : 1];
+        if constexpr (COARSE) {
+            int zl = lane;
+            asm volatile("" : "+v"(zl));   // per iteration: hoisted out of the loop these twenty registers would be spilled
+#pragma unroll
+            for (int u = 0; u < CZR_U; ++u) ce[u] = lz[max(min(zp0 + zl + 64 * u, zp1 - 1), 0)];
+        }
         __syncthreads();
         double rz2 = 0; rr = 0;
 #pragma unroll
         for (int w = 0; w < CGR_W; ++w) { rz2 += shi[CGR_W + w]; rr += shi[2 * CGR_W + w]; }
+        if constexpr (COARSE) {
+            double w6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < CZR_U; ++u) {
+                const CzNode n = cz_node(ce[u]);
+                const double *rs = Ap_s + 3 * n.node;
+                const bool in = zp0 + lane + 64 * u < zp1;
+                const double r0 = n.m0 || !in ? 0.0 : rs[0], r1 = n.m1 || !in ? 0.0 : rs[1], r2 = n.m2 || !in ? 0.0 : rs[2];
+                CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+            }
+            double share = 0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); share += ac6[m] * w6[m]; }
+            if (lane < CZ_NC) cz_share[wave * CZ_NC + lane] = share;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) if (lane == m) cz_w[6 * wave + m] = w6[m];
+            __syncthreads();                            // every aggregate's w and share of v
+            double v = 0;
+#pragma unroll
+            for (int a = 0; a < CZ_NA; ++a) v += cz_share[a * CZ_NC + min(lane, CZ_NC - 1)];
+            rz2 += wave_sum_f64(lane < CZ_NC ? cz_w[lane] * v : 0.0);
+            double va[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) va[m] = readlane_f64(v, 6 * wave + m);
+            auto prolong = [&](const CzNode n) {
+                double *cs = Ap_s + 3 * n.node;
+                cs[0] = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
+                cs[1] = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
+                cs[2] = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
+            };
+            {   // the same entries again (cache-resident now; kept in registers across the barrier they would be spilled)
+                int zl = lane;
+                asm volatile("" : "+v"(zl));
+#pragma unroll
+                for (int u = 0; u < CZR_U; ++u) ce[u] = lz[max(min(zp0 + zl + 64 * u, zp1 - 1), 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < CZR_U; ++u)
+                if (zp0 + lane + 64 * u < zp1) prolong(cz_node(ce[u]));
+            __syncthreads();                            // Z v complete
+        }
         const double beta = cg_ratio(rz2, rz);
         rz = rz2;
         if constexpr (BIG) {
@@ -1195,7 +1282,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
 #pragma unroll
             for (int u = 0; u < CGR_U; ++u) {
                 const int i = u * CGR_T + tid;
-                if (i < nrows) p_s[i] = rv[u] * dv[u] + beta * p_s[i];   // r/diag: the same product as in the sum above
+                if (i < nrows) p_s[i] = COARSE ? (rv[u] * dv[u] + Ap_s[i]) + beta * p_s[i] : rv[u] * dv[u] + beta * p_s[i];   // r/diag: the same product as in the sum above
             }
         }
         __syncthreads();                                // the new p is complete before anyone gathers from it
@@ -1317,6 +1404,11 @@ struct fem_model {
     double *d_aci = nullptr, *d_cw = nullptr, *d_cv = nullptr, *d_cwv = nullptr;
     std::vector<double> h_ac;   // Z^T K Z as the device formed it (fem_cg_coarse_matrix)
     bool coarse() const { return precond == FEM_PRECOND_TWO_LEVEL; }
+    // the whole solve in one launch per call; the two-level form needs r in LDS, which the one-vector (BIG) layout has no room for:
+    // those meshes go phase by phase
+    // (nor for an aggregate of more than CZR_U x 64 nodes: cz_max_agg, known after fem_cg_setup)
+    int cz_max_agg = 0;
+    bool resident_now() const { return cg_resident && !(coarse() && (cgr_big || cz_max_agg > 64 * 5)); }
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
     hipGraphExec_t cg_graph = nullptr; // GRAPH_ITERS CG iterations captured once (launch-bound single-mesh case)
@@ -1380,6 +1472,7 @@ int build_coarse_space(fem_model *m, std::vector<float4> &cz, std::vector<int> &
     if (hipMemcpy(nodes.data(), m->d_nodes, sizeof(float) * 3 * NN, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     cz.assign(NN, float4{0, 0, 0, 0});
     czptr.assign(9 * (size_t)m->nseg, 0);
+    m->cz_max_agg = 0;
     std::vector<int> agg;
     for (int sgi = 0; sgi < m->nseg; ++sgi) {
         const size_t node0 = m->segmented() ? (size_t)m->seg_node0[sgi] : (size_t)sgi * m->nn;
@@ -1400,6 +1493,7 @@ int build_coarse_space(fem_model *m, std::vector<float4> &cz, std::vector<int> &
             for (int k = 0; k < 3; ++k) cen[a][k] += (double)P[3 * i + k];
         }
         int *ptr = czptr.data() + 9 * (size_t)sgi, fill[CZ_NA];
+        for (int a = 0; a < CZ_NA; ++a) m->cz_max_agg = std::max(m->cz_max_agg, count[a]);
         for (int a = 0; a < CZ_NA; ++a) {
             ptr[a + 1] = ptr[a] + count[a]; fill[a] = ptr[a];
             if (count[a]) for (int k = 0; k < 3; ++k) cen[a][k] /= (double)count[a];
@@ -1538,12 +1632,14 @@ void launch_iter(fem_model *m, hipStream_t st)
 // n iterations of the batch: one launch where a mesh fits a compute unit (k_fem_cg_resident), else launch by launch
 void run_iters(fem_model *m, int n, hipStream_t st)
 {
-    if (m->cg_resident && !m->coarse()) {
+    if (m->resident_now()) {
         if (n <= 0) return;
         m->prof.start(5, st);
-        hipLaunchKernelGGL(m->cgr_big ? k_fem_cg_resident<true> : k_fem_cg_resident<false>, dim3(m->nseg), dim3(CGR_T), m->cgr_lds, st,
+        const auto kern = m->cgr_big ? k_fem_cg_resident<true, false> : m->coarse() ? k_fem_cg_resident<false, true> : k_fem_cg_resident<false, false>;
+        hipLaunchKernelGGL(kern, dim3(m->nseg), dim3(CGR_T), m->cgr_lds, st,
                            m->d_vals_b, m->d_bcol3, m->d_bp, (const int4 *)m->d_rcd, (const int *)m->d_rcfirst, m->nnzs, m->ndof,
-                           m->cgr_ldn, n, m->d_sc, m->d_p, m->d_dinv, m->d_x, m->d_r, m->d_Ap, (const int4 *)m->d_minfo);
+                           m->cgr_ldn, n, m->d_sc, m->d_p, m->d_dinv, m->d_x, m->d_r, m->d_Ap, (const int4 *)m->d_minfo,
+                           (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_aci);
         m->prof.stop(5, st);
         m->cg_it += 2 * ((n + 1) / 2);   // both rz slots are current after the launch: keep the parity of the other path even
         return;
@@ -1925,9 +2021,13 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     hipError_t e = hipMemcpyAsync(m->d_tables, stage, total, hipMemcpyHostToDevice, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);   // the staging block goes back to the cache
     g_pin_cache.put(stage);
-    if (e == hipSuccess && P.resident)
-        e = hipFuncSetAttribute(P.big ? reinterpret_cast<const void *>(k_fem_cg_resident<true>) : reinterpret_cast<const void *>(k_fem_cg_resident<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
+    if (e == hipSuccess && P.resident) {
+        if (P.big)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cg_resident<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
+        else
+            for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<false, false>), reinterpret_cast<const void *>(k_fem_cg_resident<false, true>)})
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
+    }
     if (e == hipSuccess && m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
                                reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
@@ -2488,7 +2588,7 @@ int fem_cg_iterate(fem_model *m, int n, void *stream)
     if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     m->cg_stream = st;
-    if (m->cg_resident && !m->coarse()) { run_iters(m, n, st); ORBX_HIP(hipGetLastError()); return ORBX_OK; }
+    if (m->resident_now()) { run_iters(m, n, st); ORBX_HIP(hipGetLastError()); return ORBX_OK; }
     int i = 0;
     // Small batches are launch-bound (3 short kernels per iteration): replay a captured
     // hipGraph of GRAPH_ITERS iterations.  Graph nodes carry no timing events, so this
