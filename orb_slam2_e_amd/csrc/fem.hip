@@ -901,6 +901,170 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_prolong(const float4 *__restric
     }
 }
 
+// The coarse space of one mesh per workgroup (fem_cg_setup, once per set of constrained dofs): bounding box (block min / max),
+// aggregate = 4 bx + 2 by + bz with bit = coordinate > midpoint (in double), the nodes of each aggregate in node order (counting
+// pass, then placement by wave ballots -- stable), centroids as double sums over those lists IN LIST ORDER (one thread per aggregate
+// and axis: the oracle's sums, bit for bit), q = (float)(node - centroid).  cmask: constrained dofs (numbered like the rows: per
+// mesh when the layout is uniform, globally when segmented), or nullptr.
+__global__ __launch_bounds__(CZ_T) void k_fem_cz_build(const float *__restrict__ nodes, const uint8_t *__restrict__ cmask, int mask_global,
+                                                       float4 *__restrict__ cz, int *__restrict__ czptr, int *__restrict__ maxagg,
+                                                       int ndof, const int4 *__restrict__ minfo)
+{
+    __shared__ float s_lo[3][CZ_T / 64], s_hi[3][CZ_T / 64];
+    __shared__ int s_cnt[CZ_T / 64][CZ_NA], s_base[CZ_NA], s_ptr[CZ_NA + 1];
+    __shared__ double s_cen[CZ_NA][3];
+    const int mesh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
+    const int cnt = (minfo ? minfo[mesh].y : ndof) / 3;
+    const float *P = nodes + row0;                       // 3 floats per node, as the rows
+    float4 *lz = cz + row0 / 3;
+    const uint8_t *mk = cmask ? cmask + (mask_global ? row0 : 0) : nullptr;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = P[k]; hi[k] = P[k]; }
+    for (int i = tid; i < cnt; i += CZ_T)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float v = P[3 * i + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+        if (lane == 0) { s_lo[k][wave] = lo[k]; s_hi[k][wave] = hi[k]; }
+    }
+    __syncthreads();
+    double mid[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float l = s_lo[k][0], h = s_hi[k][0];
+        for (int w = 1; w < CZ_T / 64; ++w) { l = fminf(l, s_lo[k][w]); h = fmaxf(h, s_hi[k][w]); }
+        mid[k] = 0.5 * ((double)l + (double)h);
+    }
+    auto agg_of = [&](int i) { return 4 * ((double)P[3 * i] > mid[0]) + 2 * ((double)P[3 * i + 1] > mid[1]) + ((double)P[3 * i + 2] > mid[2]); };
+    // counting pass
+    int c8[CZ_NA] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < cnt; i += CZ_T) {
+        const int a = agg_of(i);
+#pragma unroll
+        for (int b = 0; b < CZ_NA; ++b) c8[b] += a == b;
+    }
+#pragma unroll
+    for (int b = 0; b < CZ_NA; ++b) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c8[b] += __shfl_xor(c8[b], off);
+        if (lane == 0) s_cnt[wave][b] = c8[b];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, mx = 0;
+        for (int b = 0; b < CZ_NA; ++b) {
+            int t = 0;
+            for (int w = 0; w < CZ_T / 64; ++w) t += s_cnt[w][b];
+            s_ptr[b] = run; s_base[b] = run; run += t; mx = max(mx, t);
+            czptr[9 * mesh + b] = s_ptr[b];
+        }
+        s_ptr[CZ_NA] = run; czptr[9 * mesh + CZ_NA] = run;
+        atomicMax(maxagg, mx);
+    }
+    __syncthreads();
+    // placement, a tile of CZ_T consecutive nodes at a time: rank inside the wave by ballot, waves in order, tiles in order
+    for (int base = 0; base < cnt; base += CZ_T) {
+        const int i = base + tid, a = i < cnt ? agg_of(i) : -1;
+        int rank = 0;
+#pragma unroll
+        for (int b = 0; b < CZ_NA; ++b) {
+            const unsigned long long bal = __ballot(a == b);
+            if (a == b) rank = __popcll(bal & ((1ull << lane) - 1));
+            if (lane == 0) s_cnt[wave][b] = __popcll(bal);
+        }
+        __syncthreads();
+        if (a >= 0) {
+            int pos = s_base[a] + rank;
+            for (int w = 0; w < wave; ++w) pos += s_cnt[w][a];
+            unsigned bits = (unsigned)i;
+            if (mk) bits |= (unsigned)(mk[3 * i] != 0) << 28 | (unsigned)(mk[3 * i + 1] != 0) << 29 | (unsigned)(mk[3 * i + 2] != 0) << 30;
+            lz[pos].w = __uint_as_float(bits);
+        }
+        __syncthreads();
+        if (tid < CZ_NA) { int t = 0; for (int w = 0; w < CZ_T / 64; ++w) t += s_cnt[w][tid]; s_base[tid] += t; }
+        __syncthreads();
+    }
+    __threadfence_block();
+    // centroids: thread (a, k) adds its aggregate's coordinate k in list order
+    if (tid < 3 * CZ_NA) {
+        const int a = tid / 3, k = tid - 3 * a, p0 = s_ptr[a], p1 = s_ptr[a + 1];
+        double sum = 0;
+        for (int p = p0; p < p1; ++p) sum += (double)P[3 * (int)(__float_as_uint(lz[p].w) & 0x0fffffffu) + k];
+        s_cen[a][k] = p1 > p0 ? sum / (double)(p1 - p0) : 0.0;
+    }
+    __syncthreads();
+    for (int p = tid; p < cnt; p += CZ_T) {
+        int a = 0;
+#pragma unroll
+        for (int b = 1; b < CZ_NA; ++b) a += p >= s_ptr[b];
+        const int i = (int)(__float_as_uint(lz[p].w) & 0x0fffffffu);
+        lz[p].x = (float)((double)P[3 * i] - s_cen[a][0]);
+        lz[p].y = (float)((double)P[3 * i + 1] - s_cen[a][1]);
+        lz[p].z = (float)((double)P[3 * i + 2] - s_cen[a][2]);
+    }
+}
+
+// aci = inverse of the symmetrised coarse matrix ac (48 x 48, one wave per mesh, everything in LDS): Cholesky column by column
+// (lane i owns row i), then lane c solves L y = e_c and L^T x = y for column c, and the result is symmetrised again.  A coarse dof
+// whose diagonal is <= 1e-12 of the largest (an aggregate without a free dof) or whose pivot is not positive is dropped: zero row
+// and column in the inverse.  The operation order of the oracle's oracle_fem_coarse_inverse.
+__global__ __launch_bounds__(64) void k_fem_cz_invert(const double *__restrict__ ac, double *__restrict__ aci)
+{
+    constexpr int N = CZ_NC;
+    __shared__ double A[N * N], L[N * N], X[N * N];   // A doubles as y of the triangular solves
+    __shared__ int keep[N];
+    const int mesh = blockIdx.x, l = threadIdx.x, i = min(l, N - 1);
+    const double *G = ac + (size_t)mesh * N * N;
+    for (int j = 0; j < N; ++j) { A[i * N + j] = 0.5 * (G[i * N + j] + G[j * N + i]); L[i * N + j] = 0; X[i * N + j] = 0; }
+    double dmax = l < N ? G[i * N + i] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
+    if (l < N) keep[i] = G[i * N + i] > 1e-12 * dmax;
+    __syncthreads();
+    for (int j = 0; j < N; ++j) {
+        if (keep[j]) {                                   // uniform
+            double d = A[j * N + j];
+            for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+            if (!(d > 0)) {
+                __syncthreads();
+                if (l < j) L[j * N + l] = 0;
+                if (l == j) keep[j] = 0;
+            } else {
+                const double ljj = sqrt(d);
+                if (l < N && l > j && keep[l]) {
+                    double t = A[l * N + j];
+                    for (int k = 0; k < j; ++k) t -= L[l * N + k] * L[j * N + k];
+                    L[l * N + j] = t / ljj;
+                }
+                if (l == j) L[j * N + j] = ljj;
+            }
+        }
+        __syncthreads();
+    }
+    if (l < N && keep[l]) {
+        const int c = l;
+        for (int r = 0; r < N; ++r) {
+            if (!keep[r]) { A[r * N + c] = 0; continue; }
+            double t = r == c ? 1.0 : 0.0;
+            for (int j = 0; j < r; ++j) t -= L[r * N + j] * A[j * N + c];
+            A[r * N + c] = t / L[r * N + r];
+        }
+        for (int r = N - 1; r >= 0; --r) {
+            if (!keep[r]) continue;
+            double t = A[r * N + c];
+            for (int j = r + 1; j < N; ++j) t -= L[j * N + r] * X[j * N + c];
+            X[r * N + c] = t / L[r * N + r];
+        }
+    }
+    __syncthreads();
+    if (l < N)
+        for (int j = 0; j < N; ++j) aci[(size_t)mesh * N * N + j * N + l] = 0.5 * (X[j * N + l] + X[l * N + j]);
+}
+
 // Batches: the vector half of an iteration in one launch, one 1024-thread workgroup per mesh.  alpha and beta are per
 // mesh, so a mesh's workgroup needs nobody else: pAp = p.Ap; alpha = rz / pAp; x += alpha p; r -= alpha Ap; rz' = r.(r/diag) and
 // rr = r.r summed by the workgroup (thread-strided partials, wave butterflies, the waves in order: fixed order, no
@@ -1400,9 +1564,9 @@ struct fem_model {
     // (k_fem_cz_*), the inverse coarse matrices and the coarse vectors w, v (48 per mesh) and w.v
     int precond = 0;
     std::vector<uint8_t> h_cmask;
-    float4 *d_cz = nullptr; int *d_czptr = nullptr;
-    double *d_aci = nullptr, *d_cw = nullptr, *d_cv = nullptr, *d_cwv = nullptr;
-    std::vector<double> h_ac;   // Z^T K Z as the device formed it (fem_cg_coarse_matrix)
+    float4 *d_cz = nullptr; int *d_czptr = nullptr, *d_czmax = nullptr; uint8_t *d_cmask = nullptr;
+    double *d_ac = nullptr, *d_aci = nullptr, *d_cw = nullptr, *d_cv = nullptr, *d_cwv = nullptr;
+    bool cz_space_valid = false;   // the coarse space depends on the nodes (fixed) and on the constrained dofs
     bool coarse() const { return precond == FEM_PRECOND_TWO_LEVEL; }
     // the whole solve in one launch per call; the two-level form needs r in LDS, which the one-vector (BIG) layout has no room for:
     // those meshes go phase by phase
@@ -1421,7 +1585,7 @@ void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_tables, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_czptr, m->d_aci, m->d_cw, m->d_cv, m->d_cwv};
+                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_czptr, m->d_ac, m->d_aci, m->d_cw, m->d_cv, m->d_cwv, m->d_czmax, m->d_cmask};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -1462,128 +1626,39 @@ void launch_spmv(fem_model *m, hipStream_t st)
                        (const int *)m->d_cmesh_s, (const int4 *)m->d_minfo_s);
 }
 
-// The coarse space of every mesh of the model (host, once per fem_cg_setup): aggregates by the midpoint of the bounding box per
-// axis (bit = coordinate > midpoint, in double), centroids as double sums in node order, q rounded to float once -- restriction and
-// prolongation read the same q, so the preconditioner is symmetric whatever the rounding.
-int build_coarse_space(fem_model *m, std::vector<float4> &cz, std::vector<int> &czptr)
-{
-    const size_t NN = (size_t)m->nmesh * m->nn;
-    std::vector<float> nodes(3 * NN);
-    if (hipMemcpy(nodes.data(), m->d_nodes, sizeof(float) * 3 * NN, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    cz.assign(NN, float4{0, 0, 0, 0});
-    czptr.assign(9 * (size_t)m->nseg, 0);
-    m->cz_max_agg = 0;
-    std::vector<int> agg;
-    for (int sgi = 0; sgi < m->nseg; ++sgi) {
-        const size_t node0 = m->segmented() ? (size_t)m->seg_node0[sgi] : (size_t)sgi * m->nn;
-        const int cnt = m->segmented() ? m->seg_node0[sgi + 1] - m->seg_node0[sgi] : m->nn;
-        const float *P = nodes.data() + 3 * node0;
-        const uint8_t *mask = m->h_cmask.empty() ? nullptr : m->h_cmask.data() + (m->segmented() ? 3 * node0 : 0);
-        double mid[3], cen[CZ_NA][3] = {};
-        int count[CZ_NA] = {};
-        for (int k = 0; k < 3; ++k) {
-            float lo = P[k], hi = P[k];
-            for (int i = 1; i < cnt; ++i) { lo = std::min(lo, P[3 * i + k]); hi = std::max(hi, P[3 * i + k]); }
-            mid[k] = 0.5 * ((double)lo + (double)hi);
-        }
-        agg.resize(cnt);
-        for (int i = 0; i < cnt; ++i) {
-            const int a = 4 * ((double)P[3 * i] > mid[0]) + 2 * ((double)P[3 * i + 1] > mid[1]) + ((double)P[3 * i + 2] > mid[2]);
-            agg[i] = a; ++count[a];
-            for (int k = 0; k < 3; ++k) cen[a][k] += (double)P[3 * i + k];
-        }
-        int *ptr = czptr.data() + 9 * (size_t)sgi, fill[CZ_NA];
-        for (int a = 0; a < CZ_NA; ++a) m->cz_max_agg = std::max(m->cz_max_agg, count[a]);
-        for (int a = 0; a < CZ_NA; ++a) {
-            ptr[a + 1] = ptr[a] + count[a]; fill[a] = ptr[a];
-            if (count[a]) for (int k = 0; k < 3; ++k) cen[a][k] /= (double)count[a];
-        }
-        for (int i = 0; i < cnt; ++i) {
-            const int a = agg[i];
-            unsigned bits = (unsigned)i;
-            if (mask) bits |= (unsigned)(mask[3 * i] != 0) << 28 | (unsigned)(mask[3 * i + 1] != 0) << 29 | (unsigned)(mask[3 * i + 2] != 0) << 30;
-            float wbits; memcpy(&wbits, &bits, 4);
-            cz[node0 + fill[a]++] = float4{(float)((double)P[3 * i] - cen[a][0]), (float)((double)P[3 * i + 1] - cen[a][1]),
-                                           (float)((double)P[3 * i + 2] - cen[a][2]), wbits};
-        }
-    }
-    return 0;
-}
-
-// In place: the inverse of the symmetrised 48 x 48 coarse matrix by Cholesky in double.  A coarse dof whose diagonal is <= 1e-12 of
-// the largest (an aggregate without a free dof), or whose pivot is not positive, is dropped: zero row and column in the inverse.
-void coarse_inverse(double *A)
-{
-    constexpr int N = CZ_NC;
-    std::vector<double> Lm(N * N, 0.0), X(N * N, 0.0);
-    bool keep[N];
-    double dmax = 0;
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < i; ++j) A[i * N + j] = A[j * N + i] = 0.5 * (A[i * N + j] + A[j * N + i]);
-    for (int i = 0; i < N; ++i) dmax = std::max(dmax, A[i * N + i]);
-    for (int i = 0; i < N; ++i) keep[i] = A[i * N + i] > 1e-12 * dmax;
-    auto L = [&](int i, int j) -> double & { return Lm[i * N + j]; };
-    for (int j = 0; j < N; ++j) {
-        if (!keep[j]) continue;
-        double d = A[j * N + j];
-        for (int k = 0; k < j; ++k) d -= L(j, k) * L(j, k);
-        if (!(d > 0)) { keep[j] = false; for (int k = 0; k < j; ++k) L(j, k) = 0; continue; }
-        L(j, j) = sqrt(d);
-        for (int i = j + 1; i < N; ++i) {
-            if (!keep[i]) continue;
-            double t = A[i * N + j];
-            for (int k = 0; k < j; ++k) t -= L(i, k) * L(j, k);
-            L(i, j) = t / L(j, j);
-        }
-    }
-    double y[N];
-    for (int c = 0; c < N; ++c) {   // column c: L y = e_c, then L^T x = y
-        if (!keep[c]) continue;
-        for (int i = 0; i < N; ++i) {
-            if (!keep[i]) { y[i] = 0; continue; }
-            double t = i == c ? 1.0 : 0.0;
-            for (int j = 0; j < i; ++j) t -= L(i, j) * y[j];
-            y[i] = t / L(i, i);
-        }
-        for (int i = N - 1; i >= 0; --i) {
-            if (!keep[i]) continue;
-            double t = y[i];
-            for (int j = i + 1; j < N; ++j) t -= L(j, i) * X[j * N + c];
-            X[i * N + c] = t / L(i, i);
-        }
-    }
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j <= i; ++j) A[i * N + j] = A[j * N + i] = 0.5 * (X[i * N + j] + X[j * N + i]);
-}
-
-// Coarse space, Ac = Z^T K Z column by column (Z e_k through the product kernel of the CG, restricted again: 48 products, once per
-// fem_cg_setup) and its inverse (host: 48^3 / 3 flops per mesh).  Needs the block-major values (k_fem_to_blocks) in place.
+// Coarse space (k_fem_cz_build, again only after the constrained dofs changed), Ac = Z^T K Z column by column (Z e_k through the
+// product kernel of the CG, restricted again: 48 products, once per fem_cg_setup) and its inverse (k_fem_cz_invert): all on the
+// model's stream, nothing comes back to the host but the size of the largest aggregate.  Needs the block-major values
+// (k_fem_to_blocks) in place.
 int setup_coarse(fem_model *m)
 {
-    std::vector<float4> cz; std::vector<int> czptr;
-    if (build_coarse_space(m, cz, czptr)) return -1;
-    const size_t NC2 = (size_t)CZ_NC * CZ_NC;
-    if (!m->d_cz && (dalloc(&m->d_cz, cz.size()) || dalloc(&m->d_czptr, czptr.size()) || dalloc(&m->d_aci, NC2 * m->nseg) ||
-                     dalloc(&m->d_cw, (size_t)CZ_NC * m->nseg) || dalloc(&m->d_cv, (size_t)CZ_NC * m->nseg) || dalloc(&m->d_cwv, (size_t)m->nseg)))
+    const size_t NN = (size_t)m->nmesh * m->nn, NC2 = (size_t)CZ_NC * CZ_NC;
+    if (!m->d_cz && (dalloc(&m->d_cz, NN) || dalloc(&m->d_czptr, 9 * (size_t)m->nseg) || dalloc(&m->d_ac, NC2 * m->nseg) ||
+                     dalloc(&m->d_aci, NC2 * m->nseg) || dalloc(&m->d_cw, (size_t)CZ_NC * m->nseg) || dalloc(&m->d_cv, (size_t)CZ_NC * m->nseg) ||
+                     dalloc(&m->d_cwv, (size_t)m->nseg) || dalloc(&m->d_czmax, 1) || dalloc(&m->d_cmask, (size_t)m->ndof)))
         return -1;
-    if (hipMemcpy(m->d_cz, cz.data(), sizeof(float4) * cz.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(m->d_czptr, czptr.data(), sizeof(int) * czptr.size(), hipMemcpyHostToDevice) != hipSuccess)
-        return -1;
+    if (!m->cz_space_valid) {
+        if (!m->h_cmask.empty() && hipMemcpyAsync(m->d_cmask, m->h_cmask.data(), m->h_cmask.size(), hipMemcpyHostToDevice, m->stream) != hipSuccess) return -1;
+        if (hipMemsetAsync(m->d_czmax, 0, sizeof(int), m->stream) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_fem_cz_build, dim3(m->nseg), dim3(CZ_T), 0, m->stream, (const float *)m->d_nodes,
+                           m->h_cmask.empty() ? (const uint8_t *)nullptr : (const uint8_t *)m->d_cmask, m->segmented() ? 1 : 0, m->d_cz, m->d_czptr,
+                           m->d_czmax, m->ndof, (const int4 *)m->d_minfo);
+    }
     const dim3 g(CZ_NA, m->nseg);
     for (int k = 0; k < CZ_NC; ++k) {
         hipLaunchKernelGGL(k_fem_cz_prolong, g, dim3(CZ_T), 0, m->stream, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)nullptr, k,
                            m->d_p, 0, m->ndof, (const int4 *)m->d_minfo);
         launch_spmv(m, m->stream);
         hipLaunchKernelGGL(k_fem_cz_restrict, g, dim3(CZ_T), 0, m->stream, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_Ap,
-                           m->d_aci, (int)NC2, CZ_NC, k, m->ndof, (const int4 *)m->d_minfo);
+                           m->d_ac, (int)NC2, CZ_NC, k, m->ndof, (const int4 *)m->d_minfo);
     }
-    m->h_ac.resize(NC2 * m->nseg);
-    if (hipMemcpyAsync(m->h_ac.data(), m->d_aci, sizeof(double) * m->h_ac.size(), hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-        hipStreamSynchronize(m->stream) != hipSuccess)
-        return -1;
-    std::vector<double> inv(m->h_ac);
-    for (int sgi = 0; sgi < m->nseg; ++sgi) coarse_inverse(inv.data() + NC2 * sgi);
-    if (hipMemcpy(m->d_aci, inv.data(), sizeof(double) * inv.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_fem_cz_invert, dim3(m->nseg), dim3(64), 0, m->stream, (const double *)m->d_ac, m->d_aci);
+    if (!m->cz_space_valid) {
+        if (hipMemcpyAsync(&m->cz_max_agg, m->d_czmax, sizeof(int), hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            return -1;
+        m->cz_space_valid = true;
+    }
     return 0;
 }
 
@@ -2318,6 +2393,7 @@ int fem_assemble(fem_model *m)
     m->assembled = true;
     m->cg_ready = false;
     m->h_cmask.clear();   // a fresh K has no constrained dofs
+    m->cz_space_valid = false;
     return ORBX_OK;
 }
 
@@ -2341,6 +2417,7 @@ int fem_dirichlet_penalty(fem_model *m, const int32_t *ids, int nids, float klar
     m->h_cmask.resize(m->ndof, 0);
     for (int i = 0; i < nids; ++i)
         for (int k = 0; k < 3; ++k) m->h_cmask[3 * (ids[i] - 1) + k] = 1;
+    m->cz_space_valid = false;
     m->cg_ready = false;
     return ORBX_OK;
 }
@@ -2362,6 +2439,7 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
     dfree(d_fixed);
     m->h_cmask.resize(m->ndof, 0);
     for (int i = 0; i < m->ndof; ++i) m->h_cmask[i] |= fixed[i];
+    m->cz_space_valid = false;
     m->cg_ready = false;
     return ORBX_OK;
 }
@@ -2579,7 +2657,7 @@ int fem_cg_coarse_matrix(fem_model *m, int mesh, double *Ac)
 {
     if (!m || !Ac || mesh < 0 || mesh >= m->nseg) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     if (!m->coarse() || !m->cg_ready) ORBX_FAIL(ORBX_ERR_ARG, "no two-level preconditioner set up (fem_cg_preconditioner, fem_cg_setup)");
-    memcpy(Ac, m->h_ac.data() + (size_t)CZ_NC * CZ_NC * mesh, sizeof(double) * CZ_NC * CZ_NC);
+    ORBX_HIP(hipMemcpy(Ac, m->d_ac + (size_t)CZ_NC * CZ_NC * mesh, sizeof(double) * CZ_NC * CZ_NC, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

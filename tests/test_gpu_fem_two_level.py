@@ -104,3 +104,78 @@ def test_segmented_batch_two_level(n, base):
         assert np.abs(fb.cg_coarse_matrix(k) - oAc).max() <= 1e-10 * np.abs(oAc).max()
         ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[d0:d1], 50, nodes_l[k], mask)
         _check(x[0, d0:d1], rel[k], ox, orel, k)
+
+
+def test_two_level_with_penalty_dirichlet():
+    """The reference's own boundary condition (ImposeDirichletEncastre_K, FEA2.cc:1628-1643: Klarge on the diagonal of node id - 1):
+    the dofs it names leave the coarse space exactly as eliminated dofs do.  The penalised matrix is badly scaled (1e8 beside
+    ~1e3): what is compared is the coarse matrix and a fixed number of iterations."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=5)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    ids = (np.unique(np.asarray(fixed) // 3) + 1).astype(np.int32)      # 1-based ids, as the reference passes them
+    fea.ImposeDirichletEncastre_K(ids)
+    fea.cg_preconditioner("two_level")
+    b = load.copy()
+    x, done, rel = fea.solve_cg(b, iters=80, tol=0.0)
+    rp, col, val = fea.csr(0)
+    mask = np.zeros(len(b), np.uint8)
+    for k in range(3):
+        mask[3 * (ids - 1) + k] = 1
+    oAc = oracle.fem_coarse_matrix(rp, col, val, nodes, mask)
+    assert np.abs(fea.cg_coarse_matrix(0) - oAc).max() <= 1e-10 * np.abs(oAc).max()
+    ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b, 80, nodes, mask)
+    _check(x[0], rel[0], ox, orel, "penalty")
+    # a new assembly forgets the constrained dofs: the coarse space is rebuilt without them
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed[: len(fixed) // 2])
+    x, done, rel = fea.solve_cg(b, iters=10, tol=0.0)
+    rp, col, val = fea.csr(0)
+    oAc = oracle.fem_coarse_matrix(rp, col, val, nodes, _mask(len(b), fixed[: len(fixed) // 2]))
+    assert np.abs(fea.cg_coarse_matrix(0) - oAc).max() <= 1e-10 * np.abs(oAc).max()
+
+
+def test_two_level_lopsided_aggregates_leave_the_resident_kernel():
+    """A batch whose meshes would run resident (64 meshes, 6,591 dofs) but whose nodes crowd into one half of the bounding box: an
+    aggregate of more than 320 nodes does not fit the resident kernel's registers, the solve goes phase by phase -- same numbers."""
+    nmesh = 64
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=12)
+    nodes = np.array(nodes, np.float32, copy=True)
+    nodes[..., 0] = np.float32(10.0) * (nodes[..., 0] / nodes[..., 0].max()) ** 4     # x crowded towards 0: five of six nodes below the midpoint
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    fea.cg_preconditioner("two_level")
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    fea.profile(True)
+    x, done, rel = fea.solve_cg(b, iters=30, tol=0.0)
+    prof = fea.profile_read()
+    assert prof["k_fem_spmv"][1] >= 30 and not prof.get("k_fem_cg_resident", (0, 0))[1]
+    mask = _mask(b.shape[1], fixed)
+    agg, _ = oracle.fem_coarse_space(nodes[0])
+    assert np.bincount(agg, minlength=8).max() > 320
+    for m in (0, nmesh - 1):
+        rp, col, val = fea.csr(m)
+        ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[m], 30, nodes[m], mask)
+        _check(x[m], rel[m], ox, orel, m)
+
+
+def test_two_level_resident_kernel_is_the_one_that_runs():
+    """Config 3's batch under the two-level preconditioner: one launch of k_fem_cg_resident per call, no product kernel after the
+    48 of the set-up."""
+    nmesh = 64
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=12)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    fea.cg_preconditioner("two_level")
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    fea.cg_setup(b)
+    fea.profile(True)
+    fea.cg_iterate(40)
+    x, rel = fea.cg_result()
+    prof = fea.profile_read()
+    assert prof["k_fem_cg_resident"][1] == 1 and not prof["k_fem_spmv"][1]
+    rp, col, val = fea.csr(5)
+    ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[5], 40, nodes[5], _mask(b.shape[1], fixed))
+    _check(x[5], rel[5], ox, orel, 5)
