@@ -424,6 +424,30 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return t;
 }
 
+// Sum over the wave, the same value in every lane, in a fixed order: four DPP row_shr steps leave each row of 16 lanes' total in its
+// last lane, the four row totals are read into scalars and added row 0 .. 3.  No LDS round trips: the xor butterfly through
+// ds_bpermute (12 of them per f64 sum, each step waiting for the last) was 2 us of the 5 the coarse correction added per iteration.
+template <int N> __device__ __forceinline__ double dpp_shr_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x110 + N, 0xf, 0xf, true);         // row_shr:N, 0 from beyond the row
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x110 + N, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_shr_f64<1>(v);
+    v += dpp_shr_f64<2>(v);
+    v += dpp_shr_f64<4>(v);
+    v += dpp_shr_f64<8>(v);
+    return ((readlane_f64(v, 15) + readlane_f64(v, 31)) + readlane_f64(v, 47)) + readlane_f64(v, 63);
+}
 // Sum of n per-workgroup partials in a fixed order, the same value in every lane: lane l
 // adds part[l], part[l+64], ... and a xor butterfly joins the 64 lane sums.  (A serial
 // loop over the partials was 5 of the 8 us of k_fem_cg_update on one 6.6k-dof mesh.)
@@ -1072,17 +1096,65 @@ __global__ __launch_bounds__(64) void k_fem_cz_invert(const double *__restrict__
 // flight together (one memory round trip per block and phase).  A single mesh (the reference's own use, one mesh per
 // PoseOptimizationNR call) keeps the two launches above: there one workgroup is one CU's bandwidth, ~100 are the chip's.
 constexpr int CGS_T = 1024, CGS_U = 10, CGS_MIN_MESHES = 16;
+// COARSE: the two-level preconditioner inside the same launch.  After the update (r is in the batch vector) the sixteen waves sum
+// the aggregates' modes from r -- waves a and a + 8 take alternate groups of 64 nodes of aggregate a's list, partials in wave order --,
+// wave 0 forms v = Ac^-1 w and w.v, the waves write Z v for their nodes into Ap's slots (K p has been used), and the direction
+// update adds it: three more workgroup barriers, 16 bytes per dof more through the compute unit's caches, no more launches.
+template <bool COARSE>
 __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal *__restrict__ sc, double *__restrict__ p,
-                                                       const double *__restrict__ Ap, const double *__restrict__ dinv,
+                                                       double *__restrict__ Ap, const double *__restrict__ dinv,
                                                        double *__restrict__ x, double *__restrict__ r,
-                                                       const int4 *__restrict__ minfo)
+                                                       const int4 *__restrict__ minfo, const float4 *__restrict__ cz,
+                                                       const int *__restrict__ czptr, const double *__restrict__ aci)
 {
     __shared__ double sh[CGS_T / 64];
+    __shared__ double s_w[2][CZ_NC], s_v[CZ_NC + 1];
     const int mesh = blockIdx.x;
     const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
     const int nrows = minfo ? minfo[mesh].y : ndof;
     const double rz = sc[mesh].rz[cur];
     double s1 = 0, s2 = 0;
+    // z = r/diag + Z Ac^-1 Z^T r: leaves Z v in Ap[row0 ...] and returns w.v.  Called by all threads after r has been stored.
+    auto coarse = [&]() -> double {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, a = wave & 7, half = wave >> 3;
+        const float4 *lz = cz + row0 / 3;
+        const int zp0 = czptr[9 * mesh + a], zp1 = czptr[9 * mesh + a + 1];
+        const double *rm = r + row0;
+        double *cm = Ap + row0;
+        __syncthreads();                                   // r complete
+        double w6[6] = {0, 0, 0, 0, 0, 0};
+        for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
+            const CzNode n = cz_node(lz[q]);
+            const double r0 = n.m0 ? 0.0 : rm[3 * n.node], r1 = n.m1 ? 0.0 : rm[3 * n.node + 1], r2 = n.m2 ? 0.0 : rm[3 * n.node + 2];
+            CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); if (lane == m) s_w[half][6 * a + m] = w6[m]; }
+        __syncthreads();
+        if (wave == 0) {
+            const int k = min(lane, CZ_NC - 1);
+            const double *A = aci + (size_t)mesh * (CZ_NC * CZ_NC);
+            double v = 0;
+            for (int j = 0; j < CZ_NC; ++j) v += A[j * CZ_NC + k] * (s_w[0][j] + s_w[1][j]);
+            const double t = wave_sum_f64(lane < CZ_NC ? (s_w[0][k] + s_w[1][k]) * v : 0.0);
+            if (lane < CZ_NC) s_v[k] = v;
+            if (lane == 0) s_v[CZ_NC] = t;
+        }
+        __syncthreads();
+        double va[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) va[m] = s_v[6 * a + m];
+        for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
+            const CzNode n = cz_node(lz[q]);
+            double *cs = cm + 3 * n.node;
+            cs[0] = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
+            cs[1] = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
+            cs[2] = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
+        }
+        const double wv = s_v[CZ_NC];
+        __syncthreads();                                   // Z v complete
+        return wv;
+    };
     if (nrows <= CGS_U * CGS_T) {
         // the whole mesh in one block: p and r/diag stay in registers across the reduction -- 5 vector reads and 3 writes
         double pv[CGS_U], zv[CGS_U];
@@ -1112,12 +1184,14 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
                 }
             }
         }
-        const double rz2 = block_sum(s1, sh), rr = block_sum(s2, sh);
+        double rz2 = block_sum(s1, sh);
+        const double rr = block_sum(s2, sh);
+        if constexpr (COARSE) rz2 += coarse();
         const double beta = cg_ratio(rz2, rz);
 #pragma unroll
         for (int u = 0; u < CGS_U; ++u) {
             const int i = u * CGS_T + (int)threadIdx.x;
-            if (i < nrows) p[row0 + i] = zv[u] + beta * pv[u];
+            if (i < nrows) p[row0 + i] = COARSE ? (zv[u] + Ap[row0 + i]) + beta * pv[u] : zv[u] + beta * pv[u];
         }
         if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
         return;
@@ -1145,19 +1219,22 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
             }
         }
     }
-    const double rz2 = block_sum(s1, sh), rr = block_sum(s2, sh);
+    double rz2 = block_sum(s1, sh);
+    const double rr = block_sum(s2, sh);
+    if constexpr (COARSE) rz2 += coarse();
     const double beta = cg_ratio(rz2, rz);
     for (int base = 0; base < nrows; base += CGS_U * CGS_T) {   // r[g]: this thread's own stores of the first phase
-        double pv[CGS_U], rv[CGS_U], dv[CGS_U];
+        double pv[CGS_U], rv[CGS_U], dv[CGS_U], cv[COARSE ? CGS_U : 1];
 #pragma unroll
         for (int u = 0; u < CGS_U; ++u) {
             const size_t g = row0 + min(base + u * CGS_T + (int)threadIdx.x, nrows - 1);
             pv[u] = p[g]; rv[u] = r[g]; dv[u] = dinv[g];
+            if constexpr (COARSE) cv[u] = Ap[g];
         }
 #pragma unroll
         for (int u = 0; u < CGS_U; ++u) {
             const int i = base + u * CGS_T + (int)threadIdx.x;
-            if (i < nrows) p[row0 + i] = rv[u] * dv[u] + beta * pv[u];
+            if (i < nrows) p[row0 + i] = COARSE ? (rv[u] * dv[u] + cv[u]) + beta * pv[u] : rv[u] * dv[u] + beta * pv[u];
         }
     }
     if (threadIdx.x == 0) { sc[mesh].rz[cur ^ 1] = rz2; sc[mesh].rr = rr; }
@@ -1176,30 +1253,6 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
 // tiling CGR_MAXROWS_BIG would take 14,336) --: Ap and x live in the mesh's slice of the batch vectors instead
 // (written and read by the same compute unit: with 1/diag + 48 bytes per dof and iteration beside the matrix's ~175), r in registers.
 constexpr int CGR_T = 512, CGR_W = CGR_T / 64, CGR_NB = 4, CGR_CB = 64 * CGR_NB, CGR_MAXROWS = 7168, CGR_MAXROWS_BIG = 14336, CGR_MIN_MESHES = 64;
-// Sum over the wave, the same value in every lane, in a fixed order: four DPP row_shr steps leave each row of 16 lanes' total in its
-// last lane, the four row totals are read into scalars and added row 0 .. 3.  No LDS round trips: the xor butterfly through
-// ds_bpermute (12 of them per f64 sum, each step waiting for the last) was 2 us of the 5 the coarse correction added per iteration.
-template <int N> __device__ __forceinline__ double dpp_shr_f64(double v)
-{
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x110 + N, 0xf, 0xf, true);         // row_shr:N, 0 from beyond the row
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x110 + N, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l)
-{
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-    v += dpp_shr_f64<1>(v);
-    v += dpp_shr_f64<2>(v);
-    v += dpp_shr_f64<4>(v);
-    v += dpp_shr_f64<8>(v);
-    return ((readlane_f64(v, 15) + readlane_f64(v, 31)) + readlane_f64(v, 47)) + readlane_f64(v, 63);
-}
 // COARSE (not with BIG): the two-level preconditioner inside the launch.  Wave a owns aggregate a (CGR_W = CZ_NA): after the update
 // r is parked in Ap's LDS slots (K p is no longer needed), wave a sums its aggregate's six modes from there (lane-strided, xor
 // butterflies) and forms ITS six columns' share of v = Ac^-1 w -- lane k holds Ac^-1[k][6a .. 6a+5] in registers for the whole launch --,
@@ -1619,7 +1672,7 @@ inline dim3 grid_spmv(const fem_model *m) { return m->segmented() ? dim3(m->nchu
 
 void launch_spmv(fem_model *m, hipStream_t st)
 {
-    const bool pap = m->nseg < CGS_MIN_MESHES || m->coarse();   // the per-mesh k_fem_cg_step forms p.Ap itself
+    const bool pap = m->nseg < CGS_MIN_MESHES;   // the per-mesh k_fem_cg_step forms p.Ap itself
     hipLaunchKernelGGL(m->spb == 48 ? (pap ? k_fem_spmv<48, true> : k_fem_spmv<48, false>) : (pap ? k_fem_spmv<96, true> : k_fem_spmv<96, false>),
                        grid_spmv(m), dim3(CGT), m->spmv_lds, st,
                        m->d_vals_b, m->d_bcol3, m->d_bp, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
@@ -1682,10 +1735,11 @@ void launch_iter(fem_model *m, hipStream_t st)
     m->prof.start(2, st);
     launch_spmv(m, st);
     m->prof.stop(2, st);
-    if (m->nseg >= CGS_MIN_MESHES && !m->coarse()) {
+    if (m->nseg >= CGS_MIN_MESHES) {
         m->prof.start(3, st);
-        hipLaunchKernelGGL(k_fem_cg_step, dim3(m->nseg), dim3(CGS_T), 0, st, m->ndof, cur, m->d_sc, m->d_p, m->d_Ap, m->d_dinv, m->d_x,
-                           m->d_r, (const int4 *)m->d_minfo);
+        hipLaunchKernelGGL(m->coarse() ? k_fem_cg_step<true> : k_fem_cg_step<false>, dim3(m->nseg), dim3(CGS_T), 0, st, m->ndof, cur, m->d_sc,
+                           m->d_p, m->d_Ap, m->d_dinv, m->d_x, m->d_r, (const int4 *)m->d_minfo, (const float4 *)m->d_cz, (const int *)m->d_czptr,
+                           (const double *)m->d_aci);
         m->prof.stop(3, st);
         m->cg_it++;
         return;

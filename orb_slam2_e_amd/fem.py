@@ -185,6 +185,12 @@ class FEA2:
         check(self._L.fem_cg_result(self._h, _p(x), _p(rel)))
         return x, rel
 
+    def cg_relres(self):
+        """||r|| / ||b|| per mesh after the iterations run so far (synchronises; the iterate stays on the device)."""
+        rel = np.zeros(getattr(self, "nseg", self.nmesh), np.float64)
+        check(self._L.fem_cg_result(self._h, None, _p(rel)))
+        return rel
+
     def profile(self, on):
         """on: False/0 = off, True = every kernel kind, int = bit mask of kinds
         (k_fem_ke 1, k_fem_assemble 2, k_fem_spmv 4, k_fem_cg_update 8, k_fem_cg_dir 16)."""

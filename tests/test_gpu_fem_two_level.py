@@ -56,10 +56,11 @@ def test_single_mesh_two_level(ncell):
     assert itj2 == itj and np.array_equal(xj2, xj) and np.array_equal(relj2, relj)
 
 
-@pytest.mark.parametrize("nmesh,ncell,iters", [(5, 4, 60), (20, 3, 40), (64, 5, 61), (70, 12, 30), (64, 14, 25)])
+@pytest.mark.parametrize("nmesh,ncell,iters", [(5, 4, 60), (20, 3, 40), (64, 5, 61), (70, 12, 30), (64, 14, 25), (16, 15, 20)])
 def test_uniform_batch_two_level(nmesh, ncell, iters):
     """Batches of one topology with their own coordinates (so their own aggregates' centroids and coarse matrices): below and above
-    the fused-step threshold, and the sizes that run resident on the compute units under Jacobi."""
+    the fused-step threshold (k_fem_cg_step<true>: ncell = 14 in its registers-only form, ncell = 15 -- 12,288 dofs -- in the general
+    one), and the sizes that run resident on the compute units (k_fem_cg_resident<false, true>)."""
     nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=ncell)
     fea = FEA2(nodes, tets, FEM_TET4)
     fea.MatrixAssembly()
@@ -83,7 +84,7 @@ def test_uniform_batch_two_level(nmesh, ncell, iters):
     assert np.array_equal(x2, x) and np.array_equal(rel2, rel)
 
 
-@pytest.mark.parametrize("n,base", [(7, 4), (72, 5)])
+@pytest.mark.parametrize("n,base", [(7, 4), (72, 5), (64, 12)])
 def test_segmented_batch_two_level(n, base):
     """Meshes of their own sizes and topologies concatenated (fem_create_batch): aggregates, coarse matrices and the coarse dot
     products are per mesh."""
