@@ -1,6 +1,8 @@
 """Differential fuzz of the batched CG (uniform and segmented batches on both sides of the 16- and 64-mesh thresholds and of
 the 7,168-dof LDS limit of k_fem_cg_resident): fixed iteration counts against the oracle's CG on the exported CSR, 1e-5
-(solution and recurrence residual alike: seed 48 has a case with x equal to 3e-11 and the residuals 1.4e-6 apart)."""
+(solution and recurrence residual alike: seed 48 has a case with x equal to 3e-11 and the residuals 1.4e-6 apart).  Every other
+case runs under the two-level preconditioner (fem_cg_preconditioner) against oracle_fem_cg_two_level, coordinates of some of them
+warped so that aggregates are lopsided or empty."""
 import sys
 import numpy as np
 import oracle
@@ -17,37 +19,51 @@ for case in range(n):
     lo, hi = (11, 15) if big else (2, 9)
     iters = int(rng.integers(1, 60))
     seg = rng.random() < 0.5
+    two = case % 2 == 1
+    warp = two and rng.random() < 0.4        # crowd the nodes along x: lopsided aggregates (beyond 320 nodes the resident kernel is not used)
+    def shape(nodes):
+        if not warp: return nodes
+        nodes = np.array(nodes, np.float32, copy=True); t = nodes[..., 0] - nodes[..., 0].min()
+        nodes[..., 0] = (t.max() * (t / t.max()) ** 3).astype(np.float32)
+        return nodes
+    def ocg(rp, col, val, bb, nodes, fixed_local):
+        if not two: return oracle.fem_cg(rp, col, val, bb, iters, 0.0)
+        mk = np.zeros(len(bb), np.uint8); mk[fixed_local] = 1
+        return oracle.fem_cg_two_level(rp, col, val, bb, iters, nodes, mk)
     if seg:
         dims = [tuple(int(v) for v in rng.integers(lo, hi + 1, 3)) for _ in range(nm)]
         meshes = [synth_tet_mesh(d, 1000 * case + k) for k, d in enumerate(dims)]
+        meshes = [(shape(m[0]),) + tuple(m[1:]) for m in meshes]
         fea = FEA2Batch([m[0] for m in meshes], [m[1] for m in meshes], FEM_TET4)
         fixed = np.concatenate([fea.dof0[k] + m[2] for k, m in enumerate(meshes)]).astype(np.int32)
         b = np.concatenate([m[3] for m in meshes]); b[fixed] = 0
         fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
+        if two: fea.cg_preconditioner("two_level")
         x, done, rel = fea.solve_cg(b, iters=iters, tol=0.0)
         pick = sorted(set([0, nm - 1, int(rng.integers(0, nm))]))
         ok = done == iters
         for k in pick:
             rp, col, val = fea.csr(k); d0, d1 = fea.dof0[k], fea.dof0[k + 1]
-            ox, _, orel = oracle.fem_cg(rp, col, val, b[d0:d1], iters, 0.0)
+            ox, _, orel = ocg(rp, col, val, b[d0:d1], meshes[k][0], meshes[k][2])
             okk = np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max() and abs(rel[k] - orel) <= RTOL * orel + 1e-12
             if not okk: print("   mesh", k, "dims", dims[k], "x diff", np.abs(x[0, d0:d1] - ox).max() / np.abs(ox).max(), "relres", rel[k], "oracle", orel, flush=True)
             ok = ok and okk
-        desc = f"segmented nm={nm} dims {dims[0]}.. iters={iters}"
+        desc = f"segmented nm={nm} dims {dims[0]}.. iters={iters} two_level={two} warp={warp}"
     else:
         d = tuple(int(v) for v in rng.integers(lo, hi + 1, 3))
         base = synth_tet_mesh(d, 1000 * case)
-        nodes = np.stack([base[0] + rng.normal(0, 0.01, base[0].shape).astype(np.float32) for _ in range(nm)])
+        nodes = shape(np.stack([base[0] + rng.normal(0, 0.01, base[0].shape).astype(np.float32) for _ in range(nm)]))
         fea = FEA2(nodes, base[1], FEM_TET4)
         b = np.tile(base[3], (nm, 1)) * rng.uniform(0.5, 2.0, (nm, 1)); b[:, base[2]] = 0
         fea.MatrixAssembly(); fea.eliminate_dofs(base[2])
+        if two: fea.cg_preconditioner("two_level")
         x, done, rel = fea.solve_cg(b, iters=iters, tol=0.0)
         ok = done == iters
         for k in sorted(set([0, nm - 1, int(rng.integers(0, nm))])):
             rp, col, val = fea.csr(k)
-            ox, _, orel = oracle.fem_cg(rp, col, val, b[k], iters, 0.0)
+            ox, _, orel = ocg(rp, col, val, b[k], nodes[k], base[2])
             ok = ok and np.abs(x[k] - ox).max() <= RTOL * np.abs(ox).max() and abs(rel[k] - orel) <= RTOL * orel + 1e-12
-        desc = f"uniform nm={nm} dims {d} iters={iters}"
+        desc = f"uniform nm={nm} dims {d} iters={iters} two_level={two} warp={warp}"
     if not ok:
         bad += 1; print("MISMATCH cg", case, desc, flush=True)
     del fea
