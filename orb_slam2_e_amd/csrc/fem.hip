@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
                                                            const int4 *__restrict__ minfo, const float4 *__restrict__ cz,
                                                            const int *__restrict__ czptr, const double *__restrict__ aci)
 {
-    static_assert(!(BIG && COARSE) && CGR_W == CZ_NA && CZR_U == 5, "the coarse correction needs r in LDS and a wave per aggregate");
+    static_assert(CGR_W == CZ_NA && CZR_U == 5, "the coarse correction takes a wave per aggregate");
     extern __shared__ __align__(16) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mesh = blockIdx.x;
@@ -1298,10 +1298,12 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
     const float4 *lz = COARSE ? cz + row0 / 3 : nullptr;
     const int zp0 = COARSE ? czptr[9 * mesh + wave] : 0, zp1 = COARSE ? czptr[9 * mesh + wave + 1] : 0;
     double *cz_share = lds + NV * ldn, *cz_w = cz_share + CZ_NA * CZ_NC;
-    double ac6[COARSE ? 6 : 1];
-    if constexpr (COARSE) {
+    // (BIG: no registers to spare -- the six entries are read again in every iteration, from L2)
+    const double *acl = COARSE ? aci + (size_t)mesh * (CZ_NC * CZ_NC) + (6 * wave) * CZ_NC + min(lane, CZ_NC - 1) : nullptr;
+    double ac6[COARSE && !BIG ? 6 : 1];
+    if constexpr (COARSE && !BIG) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) ac6[m] = aci[(size_t)mesh * (CZ_NC * CZ_NC) + (6 * wave + m) * CZ_NC + min(lane, CZ_NC - 1)];
+        for (int m = 0; m < 6; ++m) ac6[m] = acl[m * CZ_NC];
     }
     // a chunk's loads: its descriptor (wave-uniform), per lane two blocks (clamped: lanes past the chunk repeat its last
     // block) and the block-row pointer of block row `lane`
@@ -1414,6 +1416,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
                         rv[u] = ri;
                         s1 += ri * (ri * dd[u]);
                         s2 += ri * ri;
+                        if constexpr (COARSE) ag[i] = ri;   // K p has been used: its slot (in the batch vector) carries r to the restriction
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -1437,8 +1440,8 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         // COARSE: the wave's aggregate -- at most CZR_U x 64 nodes (plan: larger aggregates go phase by phase; config 3 has 275) -- is
         // requested before the barrier, all entries at once (a loop of unknown length around a load would also make the compiler wait
         // for ALL outstanding loads, the next chunk's matrix blocks included, wherever it loses count)
-        float4 ce[COARSE ? CZR_U : 1];
-        if constexpr (COARSE) {
+        float4 ce[COARSE && !BIG ? CZR_U : 1];
+        if constexpr (COARSE && !BIG) {
             int zl = lane;
             asm volatile("" : "+v"(zl));   // per iteration: hoisted out of the loop these twenty registers would be spilled
 #pragma unroll
@@ -1450,17 +1453,28 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
         for (int w = 0; w < CGR_W; ++w) { rz2 += shi[CGR_W + w]; rr += shi[2 * CGR_W + w]; }
         if constexpr (COARSE) {
             double w6[6] = {0, 0, 0, 0, 0, 0};
+            if constexpr (BIG) {
+                // aggregates of up to 600 nodes: a loop, r from the batch vector (this compute unit wrote it: its caches hold it)
+                for (int q = zp0 + lane; q < zp1; q += 64) {
+                    const CzNode n = cz_node(lz[q]);
+                    const double *rs = ag + 3 * n.node;
+                    const double g0 = rs[0], g1 = rs[1], g2 = rs[2];
+                    const double r0 = n.m0 ? 0.0 : g0, r1 = n.m1 ? 0.0 : g1, r2 = n.m2 ? 0.0 : g2;
+                    CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+                }
+            } else {
 #pragma unroll
-            for (int u = 0; u < CZR_U; ++u) {
-                const CzNode n = cz_node(ce[u]);
-                const double *rs = Ap_s + 3 * n.node;
-                const bool in = zp0 + lane + 64 * u < zp1;
-                const double r0 = n.m0 || !in ? 0.0 : rs[0], r1 = n.m1 || !in ? 0.0 : rs[1], r2 = n.m2 || !in ? 0.0 : rs[2];
-                CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+                for (int u = 0; u < CZR_U; ++u) {
+                    const CzNode n = cz_node(ce[u]);
+                    const double *rs = Ap_s + 3 * n.node;
+                    const bool in = zp0 + lane + 64 * u < zp1;
+                    const double r0 = n.m0 || !in ? 0.0 : rs[0], r1 = n.m1 || !in ? 0.0 : rs[1], r2 = n.m2 || !in ? 0.0 : rs[2];
+                    CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+                }
             }
             double share = 0;
 #pragma unroll
-            for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); share += ac6[m] * w6[m]; }
+            for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); share += (BIG ? acl[m * CZ_NC] : ac6[m]) * w6[m]; }
             if (lane < CZ_NC) cz_share[wave * CZ_NC + lane] = share;
 #pragma unroll
             for (int m = 0; m < 6; ++m) if (lane == m) cz_w[6 * wave + m] = w6[m];
@@ -1473,25 +1487,43 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
 #pragma unroll
             for (int m = 0; m < 6; ++m) va[m] = readlane_f64(v, 6 * wave + m);
             auto prolong = [&](const CzNode n) {
-                double *cs = Ap_s + 3 * n.node;
+                double *cs = (BIG ? ag : Ap_s) + 3 * n.node;
                 cs[0] = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
                 cs[1] = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
                 cs[2] = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
             };
-            {   // the same entries again (cache-resident now; kept in registers across the barrier they would be spilled)
-                int zl = lane;
-                asm volatile("" : "+v"(zl));
+            if constexpr (BIG) {
+                for (int q = zp0 + lane; q < zp1; q += 64) prolong(cz_node(lz[q]));
+            } else {
+                {   // the same entries again (cache-resident now; kept in registers across the barrier they would be spilled)
+                    int zl = lane;
+                    asm volatile("" : "+v"(zl));
 #pragma unroll
-                for (int u = 0; u < CZR_U; ++u) ce[u] = lz[max(min(zp0 + zl + 64 * u, zp1 - 1), 0)];
+                    for (int u = 0; u < CZR_U; ++u) ce[u] = lz[max(min(zp0 + zl + 64 * u, zp1 - 1), 0)];
+                }
+#pragma unroll
+                for (int u = 0; u < CZR_U; ++u)
+                    if (zp0 + lane + 64 * u < zp1) prolong(cz_node(ce[u]));
             }
-#pragma unroll
-            for (int u = 0; u < CZR_U; ++u)
-                if (zp0 + lane + 64 * u < zp1) prolong(cz_node(ce[u]));
             __syncthreads();                            // Z v complete
         }
         const double beta = cg_ratio(rz2, rz);
         rz = rz2;
-        if constexpr (BIG) {
+        if constexpr (BIG && COARSE) {
+            // Z v from the batch vector, fourteen rows at a time (as the update reads K p)
+#pragma unroll
+            for (int sb = 0; sb < CGR_U; sb += 14) {
+                double cv[14];
+#pragma unroll
+                for (int v = 0; v < 14; ++v) cv[v] = ag[min((sb + v) * CGR_T + tv, nrows - 1)];
+#pragma unroll
+                for (int v = 0; v < 14; ++v) {
+                    const int u = sb + v, i = u * CGR_T + tv;
+                    if (i < nrows) p_s[i] = (rv[u] * dd[u] + cv[v]) + beta * p_s[i];
+                }
+                asm volatile("" ::: "memory");
+            }
+        } else if constexpr (BIG) {
 #pragma unroll
             for (int u = 0; u < CGR_U; ++u) {
                 const int i = u * CGR_T + tv;
@@ -1627,7 +1659,7 @@ struct fem_model {
     // those meshes go phase by phase
     // (nor for an aggregate of more than CZR_U x 64 nodes: cz_max_agg, known after fem_cg_setup)
     int cz_max_agg = 0;
-    bool resident_now() const { return cg_resident && !(coarse() && (cgr_big || cz_max_agg > 64 * 5)); }
+    bool resident_now() const { return cg_resident && !(coarse() && !cgr_big && cz_max_agg > 64 * 5); }
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
     hipGraphExec_t cg_graph = nullptr; // GRAPH_ITERS CG iterations captured once (launch-bound single-mesh case)
@@ -1766,7 +1798,8 @@ void run_iters(fem_model *m, int n, hipStream_t st)
     if (m->resident_now()) {
         if (n <= 0) return;
         m->prof.start(5, st);
-        const auto kern = m->cgr_big ? k_fem_cg_resident<true, false> : m->coarse() ? k_fem_cg_resident<false, true> : k_fem_cg_resident<false, false>;
+        const auto kern = m->cgr_big ? (m->coarse() ? k_fem_cg_resident<true, true> : k_fem_cg_resident<true, false>)
+                                     : (m->coarse() ? k_fem_cg_resident<false, true> : k_fem_cg_resident<false, false>);
         hipLaunchKernelGGL(kern, dim3(m->nseg), dim3(CGR_T), m->cgr_lds, st,
                            m->d_vals_b, m->d_bcol3, m->d_bp, (const int4 *)m->d_rcd, (const int *)m->d_rcfirst, m->nnzs, m->ndof,
                            m->cgr_ldn, n, m->d_sc, m->d_p, m->d_dinv, m->d_x, m->d_r, m->d_Ap, (const int4 *)m->d_minfo,
@@ -2154,7 +2187,8 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
     g_pin_cache.put(stage);
     if (e == hipSuccess && P.resident) {
         if (P.big)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cg_resident<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
+            for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<true, false>), reinterpret_cast<const void *>(k_fem_cg_resident<true, true>)})
+                { if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds); }
         else
             for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<false, false>), reinterpret_cast<const void *>(k_fem_cg_resident<false, true>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
