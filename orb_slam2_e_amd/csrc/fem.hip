@@ -1487,13 +1487,29 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
 #pragma unroll
             for (int m = 0; m < 6; ++m) va[m] = readlane_f64(v, 6 * wave + m);
             auto prolong = [&](const CzNode n) {
-                double *cs = (BIG ? ag : Ap_s) + 3 * n.node;
+                double *cs = Ap_s + 3 * n.node;
                 cs[0] = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
                 cs[1] = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
                 cs[2] = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
             };
             if constexpr (BIG) {
-                for (int q = zp0 + lane; q < zp1; q += 64) prolong(cz_node(lz[q]));
+                // no second vector in LDS to pass Z v through, and 28 more loads per thread from the batch vector cost 20 us (the
+                // allocator spills around them): the owners form r/diag + beta p first, then each wave adds Z v for its aggregate's
+                // nodes into p in LDS -- (r/diag + beta p) + Z v, the other forms' (r/diag + Z v) + beta p to within rounding
+                const double beta = cg_ratio(rz2, rz);
+#pragma unroll
+                for (int u = 0; u < CGR_U; ++u) {
+                    const int i = u * CGR_T + tv;
+                    if (i < nrows) p_s[i] = rv[u] * dd[u] + beta * p_s[i];
+                }
+                __syncthreads();
+                for (int q = zp0 + lane; q < zp1; q += 64) {
+                    const CzNode n = cz_node(lz[q]);
+                    double *ps = p_s + 3 * n.node;
+                    if (!n.m0) ps[0] += va[0] + (va[4] * n.q2 - va[5] * n.q1);
+                    if (!n.m1) ps[1] += va[1] + (va[5] * n.q0 - va[3] * n.q2);
+                    if (!n.m2) ps[2] += va[2] + (va[3] * n.q1 - va[4] * n.q0);
+                }
             } else {
                 {   // the same entries again (cache-resident now; kept in registers across the barrier they would be spilled)
                     int zl = lane;
@@ -1505,24 +1521,12 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
                 for (int u = 0; u < CZR_U; ++u)
                     if (zp0 + lane + 64 * u < zp1) prolong(cz_node(ce[u]));
             }
-            __syncthreads();                            // Z v complete
+            if constexpr (!BIG) __syncthreads();        // Z v complete
         }
         const double beta = cg_ratio(rz2, rz);
         rz = rz2;
         if constexpr (BIG && COARSE) {
-            // Z v from the batch vector, fourteen rows at a time (as the update reads K p)
-#pragma unroll
-            for (int sb = 0; sb < CGR_U; sb += 14) {
-                double cv[14];
-#pragma unroll
-                for (int v = 0; v < 14; ++v) cv[v] = ag[min((sb + v) * CGR_T + tv, nrows - 1)];
-#pragma unroll
-                for (int v = 0; v < 14; ++v) {
-                    const int u = sb + v, i = u * CGR_T + tv;
-                    if (i < nrows) p_s[i] = (rv[u] * dd[u] + cv[v]) + beta * p_s[i];
-                }
-                asm volatile("" ::: "memory");
-            }
+            // (done inside the coarse section)
         } else if constexpr (BIG) {
 #pragma unroll
             for (int u = 0; u < CGR_U; ++u) {
