@@ -1098,6 +1098,63 @@ __global__ __launch_bounds__(64) void k_fem_cz_invert(const double *__restrict__
 // flight together (one memory round trip per block and phase).  A single mesh (the reference's own use, one mesh per
 // PoseOptimizationNR call) keeps the two launches above: there one workgroup is one CU's bandwidth, ~100 are the chip's.
 constexpr int CGS_T = 1024, CGS_U = 10, CGS_MIN_MESHES = 16;
+// The coarse correction of one mesh by one 1024-thread workgroup (all threads call it; rm = the mesh's slice of the vector to
+// restrict, complete before the call or at its first barrier; cm = where Z v goes): waves a and a + 8 take alternate groups of 64
+// nodes of aggregate a's list, partials in wave order; wave 0 forms v = Ac^-1 w and w.v; the waves write (or add) Z v for their
+// nodes.  Returns w.v.  Ends with a barrier: Z v is complete.
+__device__ __forceinline__ double cz_apply_block(const float4 *__restrict__ lz, const int *__restrict__ ptr9, const double *__restrict__ A,
+                                                 const double *rm, double *cm, bool accumulate, double (*s_w)[CZ_NC], double *s_v)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, a = wave & 7, half = wave >> 3;
+    const int zp0 = ptr9[a], zp1 = ptr9[a + 1];
+    __syncthreads();                                   // the vector is complete
+    double w6[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
+        const CzNode n = cz_node(lz[q]);
+        const double r0 = n.m0 ? 0.0 : rm[3 * n.node], r1 = n.m1 ? 0.0 : rm[3 * n.node + 1], r2 = n.m2 ? 0.0 : rm[3 * n.node + 2];
+        CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); if (lane == m) s_w[half][6 * a + m] = w6[m]; }
+    __syncthreads();
+    if (wave == 0) {
+        const int k = min(lane, CZ_NC - 1);
+        double v = 0;
+        for (int j = 0; j < CZ_NC; ++j) v += A[j * CZ_NC + k] * (s_w[0][j] + s_w[1][j]);
+        const double t = wave_sum_f64(lane < CZ_NC ? (s_w[0][k] + s_w[1][k]) * v : 0.0);
+        if (lane < CZ_NC) s_v[k] = v;
+        if (lane == 0) s_v[CZ_NC] = t;
+    }
+    __syncthreads();
+    double va[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) va[m] = s_v[6 * a + m];
+    for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
+        const CzNode n = cz_node(lz[q]);
+        double *cs = cm + 3 * n.node;
+        const double c0 = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
+        const double c1 = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
+        const double c2 = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
+        if (accumulate) { cs[0] += c0; cs[1] += c1; cs[2] += c2; }
+        else { cs[0] = c0; cs[1] = c1; cs[2] = c2; }
+    }
+    const double wv = s_v[CZ_NC];
+    __syncthreads();                                   // Z v complete
+    return wv;
+}
+// The same as a launch of its own: restriction, coarse solve and prolongation of few meshes in ONE launch instead of three (a single
+// mesh is launch-bound: six launches per iteration became four, 12.8 -> 10.4 ms to 1e-8 on config 3's mesh)
+__global__ __launch_bounds__(1024) void k_fem_cz_apply(const float4 *__restrict__ cz, const int *__restrict__ czptr, const double *__restrict__ aci,
+                                                       const double *src, double *out, int accumulate, double *__restrict__ wv, int ndof,
+                                                       const int4 *__restrict__ minfo)
+{
+    __shared__ double s_w[2][CZ_NC], s_v[CZ_NC + 1];
+    const int mesh = blockIdx.x;
+    const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
+    const double t = cz_apply_block(cz + row0 / 3, czptr + 9 * mesh, aci + (size_t)mesh * (CZ_NC * CZ_NC), src + row0, out + row0, accumulate != 0, s_w, s_v);
+    if (threadIdx.x == 0) wv[mesh] = t;
+}
+
 // COARSE: the two-level preconditioner inside the same launch.  After the update (r is in the batch vector) the sixteen waves sum
 // the aggregates' modes from r -- waves a and a + 8 take alternate groups of 64 nodes of aggregate a's list, partials in wave order --,
 // wave 0 forms v = Ac^-1 w and w.v, the waves write Z v for their nodes into Ap's slots (K p has been used), and the direction
@@ -1118,44 +1175,7 @@ __global__ __launch_bounds__(CGS_T) void k_fem_cg_step(int ndof, int cur, CgScal
     double s1 = 0, s2 = 0;
     // z = r/diag + Z Ac^-1 Z^T r: leaves Z v in Ap[row0 ...] and returns w.v.  Called by all threads after r has been stored.
     auto coarse = [&]() -> double {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, a = wave & 7, half = wave >> 3;
-        const float4 *lz = cz + row0 / 3;
-        const int zp0 = czptr[9 * mesh + a], zp1 = czptr[9 * mesh + a + 1];
-        const double *rm = r + row0;
-        double *cm = Ap + row0;
-        __syncthreads();                                   // r complete
-        double w6[6] = {0, 0, 0, 0, 0, 0};
-        for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
-            const CzNode n = cz_node(lz[q]);
-            const double r0 = n.m0 ? 0.0 : rm[3 * n.node], r1 = n.m1 ? 0.0 : rm[3 * n.node + 1], r2 = n.m2 ? 0.0 : rm[3 * n.node + 2];
-            CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
-        }
-#pragma unroll
-        for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); if (lane == m) s_w[half][6 * a + m] = w6[m]; }
-        __syncthreads();
-        if (wave == 0) {
-            const int k = min(lane, CZ_NC - 1);
-            const double *A = aci + (size_t)mesh * (CZ_NC * CZ_NC);
-            double v = 0;
-            for (int j = 0; j < CZ_NC; ++j) v += A[j * CZ_NC + k] * (s_w[0][j] + s_w[1][j]);
-            const double t = wave_sum_f64(lane < CZ_NC ? (s_w[0][k] + s_w[1][k]) * v : 0.0);
-            if (lane < CZ_NC) s_v[k] = v;
-            if (lane == 0) s_v[CZ_NC] = t;
-        }
-        __syncthreads();
-        double va[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) va[m] = s_v[6 * a + m];
-        for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
-            const CzNode n = cz_node(lz[q]);
-            double *cs = cm + 3 * n.node;
-            cs[0] = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
-            cs[1] = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
-            cs[2] = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
-        }
-        const double wv = s_v[CZ_NC];
-        __syncthreads();                                   // Z v complete
-        return wv;
+        return cz_apply_block(cz + row0 / 3, czptr + 9 * mesh, aci + (size_t)mesh * (CZ_NC * CZ_NC), r + row0, Ap + row0, false, s_w, s_v);
     };
     if (nrows <= CGS_U * CGS_T) {
         // the whole mesh in one block: p and r/diag stay in registers across the reduction -- 5 vector reads and 3 writes
@@ -1270,7 +1290,7 @@ __global__ __launch_bounds__(CGR_T) void k_fem_cg_resident(const float *__restri
                                                            const int4 *__restrict__ minfo, const float4 *__restrict__ cz,
                                                            const int *__restrict__ czptr, const double *__restrict__ aci)
 {
-    static_assert(CGR_W == CZ_NA && CZR_U == 5, "the coarse correction takes a wave per aggregate");
+    static_assert(CGS_MIN_MESHES == 16 && CGR_W == CZ_NA && CZR_U == 5, "the coarse correction takes a wave per aggregate");
     extern __shared__ __align__(16) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mesh = blockIdx.x;
@@ -1659,6 +1679,17 @@ struct fem_model {
     double *d_ac = nullptr, *d_aci = nullptr, *d_cw = nullptr, *d_cv = nullptr, *d_cwv = nullptr;
     bool cz_space_valid = false;   // the coarse space depends on the nodes (fixed) and on the constrained dofs
     bool coarse() const { return precond == FEM_PRECOND_TWO_LEVEL; }
+    void name_kernel_kinds()
+    {
+        static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
+        for (int i = 0; i < 5; ++i) prof.names[i] = names[i];
+        if (fused_step()) { prof.names[3] = "k_fem_cg_step"; prof.names[4] = nullptr; }   // one launch does both
+        prof.names[5] = cg_resident ? "k_fem_cg_resident" : nullptr;
+        prof.names[6] = coarse() ? "k_fem_cz_*" : nullptr;
+    }
+    // the vector half of an iteration as ONE per-mesh workgroup (k_fem_cg_step): batches of 16 meshes and more (a single mesh under
+    // the two-level preconditioner was tried there too, to save launches: one compute unit's bandwidth, 12.8 -> 14.1 ms to 1e-8)
+    bool fused_step() const { return nseg >= 16; }
     // the whole solve in one launch per call; the two-level form needs r in LDS, which the one-vector (BIG) layout has no room for:
     // those meshes go phase by phase
     // (nor for an aggregate of more than CZR_U x 64 nodes: cz_max_agg, known after fem_cg_setup)
@@ -1710,7 +1741,7 @@ inline dim3 grid_spmv(const fem_model *m) { return m->segmented() ? dim3(m->nchu
 
 void launch_spmv(fem_model *m, hipStream_t st)
 {
-    const bool pap = m->nseg < CGS_MIN_MESHES;   // the per-mesh k_fem_cg_step forms p.Ap itself
+    const bool pap = !m->fused_step();   // the per-mesh k_fem_cg_step forms p.Ap itself
     hipLaunchKernelGGL(m->spb == 48 ? (pap ? k_fem_spmv<48, true> : k_fem_spmv<48, false>) : (pap ? k_fem_spmv<96, true> : k_fem_spmv<96, false>),
                        grid_spmv(m), dim3(CGT), m->spmv_lds, st,
                        m->d_vals_b, m->d_bcol3, m->d_bp, m->nnzs, m->ndof, m->nchunk_s, m->d_p, m->d_Ap, m->d_part[0],
@@ -1758,6 +1789,12 @@ void coarse_correction(fem_model *m, hipStream_t st, const double *src, double *
 {
     const dim3 g(CZ_NA, m->nseg);
     m->prof.start(6, st);
+    if ((size_t)m->nmesh * m->nn <= (size_t)m->nseg * 65536) {   // one workgroup per mesh does all three steps
+        hipLaunchKernelGGL(k_fem_cz_apply, dim3(m->nseg), dim3(1024), 0, st, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_aci,
+                           src, out, accumulate, m->d_cwv, m->ndof, (const int4 *)m->d_minfo);
+        m->prof.stop(6, st);
+        return;
+    }
     hipLaunchKernelGGL(k_fem_cz_restrict, g, dim3(CZ_T), 0, st, (const float4 *)m->d_cz, (const int *)m->d_czptr, src, m->d_cw, CZ_NC, 1, 0,
                        m->ndof, (const int4 *)m->d_minfo);
     hipLaunchKernelGGL(k_fem_cz_solve, dim3(m->nseg), dim3(64), 0, st, (const double *)m->d_aci, (const double *)m->d_cw, m->d_cv, m->d_cwv);
@@ -1773,7 +1810,7 @@ void launch_iter(fem_model *m, hipStream_t st)
     m->prof.start(2, st);
     launch_spmv(m, st);
     m->prof.stop(2, st);
-    if (m->nseg >= CGS_MIN_MESHES) {
+    if (m->fused_step()) {
         m->prof.start(3, st);
         hipLaunchKernelGGL(m->coarse() ? k_fem_cg_step<true> : k_fem_cg_step<false>, dim3(m->nseg), dim3(CGS_T), 0, st, m->ndof, cur, m->d_sc,
                            m->d_p, m->d_Ap, m->d_dinv, m->d_x, m->d_r, (const int4 *)m->d_minfo, (const float4 *)m->d_cz, (const int *)m->d_czptr,
@@ -2206,10 +2243,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         return orbx::set_error(ORBX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
     }
     if (P.resident) { m->cg_resident = true; m->cgr_lds = (int)P.resident_lds; m->cgr_ldn = P.maxrows; }
-    static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
-    for (int i = 0; i < 5; ++i) m->prof.names[i] = names[i];
-    if (m->nseg >= CGS_MIN_MESHES) { m->prof.names[3] = "k_fem_cg_step"; m->prof.names[4] = nullptr; }   // one launch does both
-    if (m->cg_resident) m->prof.names[5] = "k_fem_cg_resident";
+    m->name_kernel_kinds();
     *out = m;
     return ORBX_OK;
 }
@@ -2742,7 +2776,7 @@ int fem_cg_preconditioner(fem_model *m, int kind)
         m->precond = kind;
         m->cg_ready = false;
         if (m->cg_graph) { (void)hipGraphExecDestroy(m->cg_graph); m->cg_graph = nullptr; }   // the captured iteration has another shape
-        m->prof.names[6] = m->coarse() ? "k_fem_cz_*" : nullptr;
+        m->name_kernel_kinds();
     }
     return ORBX_OK;
 }

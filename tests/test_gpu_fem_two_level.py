@@ -180,3 +180,22 @@ def test_two_level_resident_kernel_is_the_one_that_runs():
     rp, col, val = fea.csr(5)
     ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[5], 40, nodes[5], _mask(b.shape[1], fixed))
     _check(x[5], rel[5], ox, orel, 5)
+
+
+def test_two_level_one_large_mesh_takes_the_three_kernel_coarse_path():
+    """Meshes of more than 65,536 nodes restrict, solve and prolong in three launches (k_fem_cz_restrict with a workgroup per
+    aggregate, k_fem_cz_solve, k_fem_cz_prolong) instead of one workgroup per mesh: 74,088 nodes, 12 iterations."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=41)
+    assert len(nodes) > 65536
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    fea.cg_preconditioner("two_level")
+    b = load.copy(); b[fixed] = 0
+    x, done, rel = fea.solve_cg(b, iters=12, tol=0.0)
+    rp, col, val = fea.csr(0)
+    mask = _mask(len(b), fixed)
+    oAc = oracle.fem_coarse_matrix(rp, col, val, nodes, mask)
+    assert np.abs(fea.cg_coarse_matrix(0) - oAc).max() <= 1e-10 * np.abs(oAc).max()
+    ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b, 12, nodes, mask)
+    _check(x[0], rel[0], ox, orel, "large mesh")
