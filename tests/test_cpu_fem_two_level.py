@@ -1,0 +1,73 @@
+"""CPU checks of the oracle's two-level preconditioned CG (oracle/fem_oracle.c: oracle_fem_cg_two_level and its pieces), the
+definition the device's fem_cg_preconditioner(FEM_PRECOND_TWO_LEVEL) is tested against: first-principles properties, no GPU."""
+import numpy as np
+
+import oracle
+from orb_slam2_e_amd.synth import synth_tet_mesh
+
+
+def _system(ncell, eliminate=True):
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=ncell)
+    K = oracle.fem_assemble_dense(4, nodes, tets)
+    rp, col, val = oracle.fem_dense_to_csr(K)
+    mask = np.zeros(len(load), np.uint8)
+    b = load.copy()
+    if eliminate:
+        mask[fixed] = 1
+        oracle.fem_csr_eliminate(rp, col, val, mask)
+        b[fixed] = 0
+    return nodes, K, rp, col, val, mask, b
+
+
+def test_aggregates_partition_the_nodes_and_q_is_centred():
+    nodes = synth_tet_mesh(ncell=5)[0]
+    agg, q = oracle.fem_coarse_space(nodes)
+    assert agg.min() == 0 and agg.max() == 7 and len(np.unique(agg)) == 8
+    P = np.asarray(nodes, np.float64).reshape(-1, 3)
+    mid = 0.5 * (P.min(0) + P.max(0))
+    assert np.array_equal(agg, 4 * (P[:, 0] > mid[0]) + 2 * (P[:, 1] > mid[1]) + (P[:, 2] > mid[2]))
+    for a in range(8):
+        assert np.abs(q[agg == a].astype(np.float64).sum(0)).max() < 1e-4 * np.abs(P).max()      # q = node - centroid of its aggregate
+
+
+def test_coarse_matrix_is_zt_k_z_and_rigid_motions_of_the_free_body_cost_nothing():
+    nodes, K, rp, col, val, mask, b = _system(4, eliminate=False)
+    Ac = oracle.fem_coarse_matrix(rp, col, val, nodes)
+    agg, q = oracle.fem_coarse_space(nodes)
+    n = len(b)
+    Z = np.zeros((n, 48))
+    for i in range(n // 3):
+        a = 6 * agg[i]; x, y, z = q[i].astype(np.float64)
+        Z[3 * i:3 * i + 3, a:a + 3] = np.eye(3)
+        Z[3 * i:3 * i + 3, a + 3:a + 6] = [[0, z, -y], [-z, 0, x], [y, -x, 0]]      # v + omega x q
+    ref = Z.T @ K.astype(np.float64) @ Z
+    assert np.abs(Ac - ref).max() <= 1e-9 * np.abs(ref).max()
+    # the same translation on every aggregate is a rigid translation of the whole (unconstrained) body: no strain energy
+    t = np.tile(np.r_[1.0, 0, 0, 0, 0, 0], 8)
+    assert abs(t @ Ac @ t) <= 1e-6 * np.abs(np.diag(Ac)).max()
+
+
+def test_coarse_inverse_inverts_and_drops_dead_and_dependent_dofs():
+    rng = np.random.default_rng(3)
+    B = rng.normal(size=(48, 48)); A = B @ B.T + 48 * np.eye(48)
+    Ai = oracle.fem_coarse_inverse(A)
+    assert np.abs(Ai @ A - np.eye(48)).max() < 1e-10 and np.array_equal(Ai, Ai.T)
+    # a coarse dof with a zero row (aggregate without a free dof) and one that repeats another (collinear free nodes): both dropped
+    A2 = A.copy(); A2[5, :] = 0; A2[:, 5] = 0
+    A2[11, :] = A2[10, :]; A2[:, 11] = A2[:, 10]; A2[11, 11] = A2[10, 10]
+    Ai2 = oracle.fem_coarse_inverse(A2)
+    assert not Ai2[5].any() and not Ai2[:, 5].any() and not Ai2[11].any() and not Ai2[:, 11].any()
+    keep = np.ones(48, bool); keep[[5, 11]] = False
+    assert np.abs(Ai2[np.ix_(keep, keep)] @ A2[np.ix_(keep, keep)] - np.eye(46)).max() < 1e-9
+
+
+def test_two_level_cg_reaches_the_same_solution_in_far_fewer_iterations():
+    nodes, K, rp, col, val, mask, b = _system(6)
+    xj, itj, relj = oracle.fem_cg(rp, col, val, b, 20000, 1e-10)
+    xt, itt, relt = oracle.fem_cg_two_level(rp, col, val, b, 20000, nodes, mask, 1e-10)
+    assert relj <= 1e-10 and relt <= 1e-10 and itt < 0.6 * itj
+    assert np.abs(xt - xj).max() <= 1e-7 * np.abs(xj).max()
+    r = b - oracle.fem_csr_matvec(rp, col, val, xt)
+    assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
+    # constrained dofs stay where the elimination put them: out of the coarse space, the iterate there is b / 1 = 0
+    assert not xt[mask.astype(bool)].any()
