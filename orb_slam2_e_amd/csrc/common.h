@@ -125,6 +125,20 @@ inline hipError_t stage_out(void *pin, const void *dev, size_t bytes, hipStream_
     return hipGetLastError();
 }
 
+// Inclusive scan of one int per lane over the wave: DPP row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes (lanes without a source add
+// 0), then the last lane of row 0 (2) broadcast into row 1 (3) and lane 31 into rows 2 and 3: six register-to-register steps instead of
+// six ds_bpermute round trips through LDS (__shfl_up), each of which the next step waits for.
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
+    return v;
+}
+
 } // namespace orbx
 
 #define ORBX_FAIL(code, msg) return orbx::set_error((code), (msg), __FILE__, __LINE__)

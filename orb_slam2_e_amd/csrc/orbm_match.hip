@@ -579,9 +579,7 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint4 *__restrict__ de
             int c[5], run = 0;
 #pragma unroll
             for (int k = 0; k < 5; ++k) { c[k] = hist[5 * lane + k]; run += c[k]; }
-            int incl = run;     // inclusive scan over the lanes
-#pragma unroll
-            for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft); if (lane >= sft) incl += v; }
+            const int incl = orbx::wave_incl_scan(run);     // inclusive scan over the lanes
             const unsigned long long reach = __ballot(incl >= kth + 1);
             const int owner = __ffsll((long long)reach) - 1;     // (the total is N >= kth + 1: some lane reaches it)
             int med = 0;

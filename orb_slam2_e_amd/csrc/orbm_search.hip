@@ -1211,9 +1211,7 @@ __global__ __launch_bounds__(FB_T) void k_frame_build(const orbx_keypoint *__res
         int v[PER], sum = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) { v[k] = s_off[tid * PER + k]; sum += v[k]; }
-        int inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        const int inc = orbx::wave_incl_scan(sum);
         __shared__ int wsum[FB_T / 64];
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();

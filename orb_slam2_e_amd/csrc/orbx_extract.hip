@@ -741,19 +741,8 @@ __device__ void block_excl_scan2(int *a, int *b, int n, int *part, int &ta, int 
     const int lo = min(tid * per, n), hi = min(lo + per, n);
     int sa = 0, sb = 0;
     for (int i = lo; i < hi; ++i) { sa += a[i]; if (b) sb += b[i]; }
-    // inclusive over the wave: DPP row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes (lanes without a source add 0), then the last
-    // lane of row 0 (2) broadcast into row 1 (3) and lane 31 into rows 2 and 3 -- six register-to-register steps where six
-    // ds_bpermute round trips through LDS stood (this kernel is a chain of ~20 such scans, each waited for)
-    auto wave_scan = [](int v) {
-        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
-        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
-        return v;
-    };
-    const int ia = wave_scan(sa), ib = b ? wave_scan(sb) : 0;
+    // inclusive over the wave (this kernel is a chain of ~20 such scans, each waited for)
+    const int ia = orbx::wave_incl_scan(sa), ib = b ? orbx::wave_incl_scan(sb) : 0;
     if (lane == 63) { part[w] = ia; part[OCT_T / 64 + w] = ib; }
     __syncthreads();
     int ba = 0, bb = 0, ga = 0, gb = 0;

@@ -60,9 +60,7 @@ __global__ __launch_bounds__(ROWS_T) void k_stereo_rows(const orbx_keypoint *__r
     const int per = (nRows + 1 + ROWS_T - 1) / ROWS_T, lo = min(tid * per, nRows + 1), hi = min(lo + per, nRows + 1);
     int sum = 0;
     for (int r = lo; r < hi; ++r) sum += cnt[r];
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((tid & 63) >= o) incl += t; }
+    const int incl = orbx::wave_incl_scan(sum);
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
     int base = incl - sum;
@@ -237,9 +235,7 @@ __device__ __forceinline__ void med_pick(int *hist, int *sel, int tid)
         int h[4], s = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) { h[u] = hist[4 * tid + u]; s += h[u]; }
-        int incl = s;                                 // inclusive scan of the lanes' sums
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+        const int incl = orbx::wave_incl_scan(s);     // inclusive scan of the lanes' sums
         int pre = incl - s;
         if (k >= pre && k < incl) {                   // exactly one lane
 #pragma unroll
