@@ -411,19 +411,6 @@ __global__ __launch_bounds__(256) void k_fem_matvec(const float *__restrict__ va
 // (K is positive definite after the Dirichlet elimination, so p.Ap > 0 for p != 0).  The oracle's CG has the same guard.
 __device__ __forceinline__ double cg_ratio(double num, double den) { return den > 0.0 ? num / den : 0.0; }
 
-__device__ __forceinline__ double block_sum(double v, double *sh)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[w] = v;
-    __syncthreads();
-    double t = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
-    return t;
-}
-
 // Sum over the wave, the same value in every lane, in a fixed order: four DPP row_shr steps leave each row of 16 lanes' total in its
 // last lane, the four row totals are read into scalars and added row 0 .. 3.  No LDS round trips: the xor butterfly through
 // ds_bpermute (12 of them per f64 sum, each step waiting for the last) was 2 us of the 5 the coarse correction added per iteration.
@@ -448,16 +435,26 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     v += dpp_shr_f64<8>(v);
     return ((readlane_f64(v, 15) + readlane_f64(v, 31)) + readlane_f64(v, 47)) + readlane_f64(v, 63);
 }
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+    v = wave_sum_f64(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+
 // Sum of n per-workgroup partials in a fixed order, the same value in every lane: lane l
-// adds part[l], part[l+64], ... and a xor butterfly joins the 64 lane sums.  (A serial
+// adds part[l], part[l+64], ... and wave_sum_f64 joins the 64 lane sums.  (A serial
 // loop over the partials was 5 of the 8 us of k_fem_cg_update on one 6.6k-dof mesh.)
 __device__ __forceinline__ double chunk_sum(const double *__restrict__ part, int n)
 {
     double v = 0;
     for (int c = threadIdx.x & 63; c < n; c += 64) v += part[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    return wave_sum_f64(v);
 }
 
 // sE = |a^T f|, nsE = sE / int(Ksize/3): one block per mesh.
