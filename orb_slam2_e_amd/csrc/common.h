@@ -139,6 +139,24 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
+// Minimum over each row of 16 lanes, in every lane of the row: four DPP rotations (row_ror 8 / 4 / 2 / 1) instead of four
+// ds_bpermute round trips (__shfl_xor).  wave_min_u32: the four row minima joined through scalars, the same value in all 64 lanes.
+__device__ __forceinline__ unsigned row_min_u32(unsigned v)
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = row_min_u32(v);
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
 } // namespace orbx
 
 #define ORBX_FAIL(code, msg) return orbx::set_error((code), (msg), __FILE__, __LINE__)

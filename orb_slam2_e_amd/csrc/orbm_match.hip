@@ -538,8 +538,7 @@ __global__ __launch_bounds__(MT) void k_match_triang(const orbx_keypoint *__rest
             }
         }
     }
-#pragma unroll
-    for (int o = 8; o; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    key = orbx::row_min_u32(key);
     if (sub == 0) {
         const bool hit = key != 0xffffffffu;
         match12[i] = hit ? cidx[k0 + (int)(0xffffu - (key & 0xffffu))] : -1;
@@ -616,8 +615,7 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint4 *__restrict__ de
         const unsigned k2 = ((unsigned)lo << 16) | (unsigned)a;
         key = k2 < key ? k2 : key;
     }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned other = __shfl_xor(key, sft); key = other < key ? other : key; }
+    key = orbx::wave_min_u32(key);
     if (lane == 0) best[i] = (int)(key & 0xffffu);
 }
 
@@ -650,8 +648,7 @@ __global__ __launch_bounds__(MT) void k_bow_transform(const int *__restrict__ ch
                 key = min(key, (d << 16) | (unsigned)(k - c0));
             }
         }
-#pragma unroll
-        for (int w = 8; w; w >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, w, 16));
+        key = orbx::row_min_u32(key);
         final_id = child_ids[c0 + (int)(key & 0xffffu)];
         if (level == nid_level) nid = final_id;
     } while (child_off[final_id + 1] > child_off[final_id]);

@@ -1322,8 +1322,7 @@ __global__ __launch_bounds__(MT) void k_triang_frames(const SeqKp *__restrict__ 
             }
         }
     }
-#pragma unroll
-    for (int o = 8; o; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    key = orbx::row_min_u32(key);
     if (sub == 0) {
         const bool hit = key != 0xffffffffu;
         const int p = hit ? cand[k0 + (int)(0xffffu - (key & 0xffffu))] : 0;

@@ -112,8 +112,7 @@ __global__ __launch_bounds__(ST_T) void k_stereo_hamming(const orbx_keypoint *__
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    key = orbx::wave_min_u32(key);
     if (lane == 0) best_key[(size_t)f * cap + iL] = key;
 }
 
