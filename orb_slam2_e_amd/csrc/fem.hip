@@ -928,8 +928,8 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_prolong(const float4 *__restric
 // and axis: the oracle's sums, bit for bit), q = (float)(node - centroid).  cmask: constrained dofs (numbered like the rows: per
 // mesh when the layout is uniform, globally when segmented), or nullptr.
 __global__ __launch_bounds__(CZ_T) void k_fem_cz_build(const float *__restrict__ nodes, const uint8_t *__restrict__ cmask, int mask_global,
-                                                       float4 *__restrict__ cz, int *__restrict__ czptr, int *__restrict__ maxagg,
-                                                       int ndof, const int4 *__restrict__ minfo)
+                                                       float4 *__restrict__ cz, float4 *__restrict__ cznode,
+                                                       int *__restrict__ czptr, int *__restrict__ maxagg, int ndof, const int4 *__restrict__ minfo)
 {
     __shared__ float s_lo[3][CZ_T / 64], s_hi[3][CZ_T / 64];
     __shared__ int s_cnt[CZ_T / 64][CZ_NA], s_base[CZ_NA], s_ptr[CZ_NA + 1];
@@ -1023,9 +1023,108 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_build(const float *__restrict__
 #pragma unroll
         for (int b = 1; b < CZ_NA; ++b) a += p >= s_ptr[b];
         const int i = (int)(__float_as_uint(lz[p].w) & 0x0fffffffu);
-        lz[p].x = (float)((double)P[3 * i] - s_cen[a][0]);
-        lz[p].y = (float)((double)P[3 * i + 1] - s_cen[a][1]);
-        lz[p].z = (float)((double)P[3 * i + 2] - s_cen[a][2]);
+        const float q0 = (float)((double)P[3 * i] - s_cen[a][0]), q1 = (float)((double)P[3 * i + 1] - s_cen[a][1]), q2 = (float)((double)P[3 * i + 2] - s_cen[a][2]);
+        lz[p].x = q0; lz[p].y = q1; lz[p].z = q2;
+        // the same by node: {q, aggregate | constrained dofs << 28} (k_fem_cz_kz looks a block's column node up)
+        cznode[row0 / 3 + i] = float4{q0, q1, q2, __uint_as_float((unsigned)a | (__float_as_uint(lz[p].w) & 0x70000000u))};
+    }
+}
+
+// Z^T K Z six columns at a time.  Pass b (one launch each of the two kernels below per aggregate b) takes the six modes of aggregate b:
+// k_fem_cz_kz streams K once (a workgroup = the blocks of KZ_SPB consecutive rows, a lane a block, as the product kernel), forms
+// K_IJ G_J (3 x 6; G_J = [I | -[q_J]x], rows of constrained dofs zero) for the blocks whose column node J is in aggregate b -- G_J
+// from the node table, no vectors --, sums them per row in block order and writes Y = K Z_b (6 doubles per row);
+// k_fem_cz_restrict6 forms Z_a^T Y for every aggregate a: the 48 x 6 columns 6b .. 6b+5 of Ac.  Eight streams of K instead of the
+// 48 products of single columns (prolong, product, restrict: 4.3 -> 1.7 ms of fem_cg_setup on 256 config-3 meshes).
+constexpr int KZ_SPB = 24;   // rows per workgroup: 8 block rows, ~110-220 blocks, 16-32 KB of LDS (18 sums per block) -- the product
+                             // kernel's 96 rows would be 70 KB: two workgroups per compute unit, 158 us per pass instead of 98
+__global__ __launch_bounds__(CGT) void k_fem_cz_kz(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
+                                                   size_t nnzs, int ndof, const float4 *__restrict__ cznode, int b, double *__restrict__ Y)
+{
+    // uniform layout: mesh = blockIdx.y, tables numbered from 0; segmented: launched as ONE system in global numbering (block rows
+    // are independent of each other: a workgroup's rows may straddle two meshes)
+    extern __shared__ __align__(16) double part[];   // [blocks of the run][18]: entry 6 t + m = row t of the block, mode m
+    __shared__ int s_bp[KZ_SPB / 3 + 1];
+    const int tid = threadIdx.x, mesh = blockIdx.y;
+    const int r0 = blockIdx.x * KZ_SPB, r1 = min(r0 + KZ_SPB, ndof);
+    const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
+    if (tid <= (r1 - r0) / 3) s_bp[tid] = bp[r0 / 3 + tid] - q0;
+    const float *v = vals_b + (size_t)mesh * nnzs + 9 * (size_t)q0;
+    const int *bc = bcol3 + q0;
+    const size_t vbase = (size_t)mesh * ndof;
+    const float4 *nqm = cznode + vbase / 3;
+    for (int q = tid; q < nq; q += CGT) {
+        const float4 e = nqm[bc[q] / 3];
+        const unsigned bits = __float_as_uint(e.w);
+        double *dst = part + 18 * q;
+        if ((int)(bits & 0xfu) == b) {       // one block in eight: the other seven do not even read their values
+            float va[9];
+            __builtin_memcpy(va, v + 9 * q, 36);
+            const bool m0 = (bits >> 28 & 1) != 0, m1 = (bits >> 29 & 1) != 0, m2 = (bits >> 30 & 1) != 0;
+            const double x = e.x, y = e.y, z = e.z;
+            // G_J, row by dof of J: translations e_m; rotations about e_0, e_1, e_2: (0, -z, y), (z, 0, -x), (-y, x, 0) in the columns
+            const double g0[6] = {m0 ? 0.0 : 1.0, 0, 0, 0, m0 ? 0.0 : z, m0 ? 0.0 : -y};
+            const double g1[6] = {0, m1 ? 0.0 : 1.0, 0, m1 ? 0.0 : -z, 0, m1 ? 0.0 : x};
+            const double g2[6] = {0, 0, m2 ? 0.0 : 1.0, m2 ? 0.0 : y, m2 ? 0.0 : -x, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int m = 0; m < 6; ++m)
+                    dst[6 * t + m] = ((double)va[3 * t] * g0[m] + (double)va[3 * t + 1] * g1[m]) + (double)va[3 * t + 2] * g2[m];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) dst[k] = 0.0;
+        }
+    }
+    __syncthreads();
+    const int nbr = (r1 - r0) / 3;
+    for (int idx = tid; idx < 18 * nbr; idx += CGT) {
+        const int I = idx / 18, tm = idx - 18 * I, b0 = s_bp[I], nb = s_bp[I + 1] - b0;
+        double sum = 0;
+        for (int j = 0; j < nb; ++j) sum += part[18 * (b0 + j) + tm];
+        Y[(vbase + r0 + 3 * I) * 6 + tm] = sum;      // rows 3I .. 3I+2 of the run, six modes each: entry 6 t + m again
+    }
+}
+// ac[mesh][(6 a + m') * 48 + 6 b + m] = (Z_a^T Y)[m'][m]: a workgroup per (aggregate a, mesh), thread-strided partials, DPP wave sums,
+// the four waves added in order
+__global__ __launch_bounds__(CZ_T) void k_fem_cz_restrict6(const float4 *__restrict__ cz, const int *__restrict__ czptr,
+                                                           const double *__restrict__ Y, int b, double *__restrict__ ac, int ndof,
+                                                           const int4 *__restrict__ minfo)
+{
+    __shared__ double sh[CZ_T / 64][36];
+    const int a = blockIdx.x, mesh = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
+    const float4 *lz = cz + row0 / 3;
+    const double *Ym = Y + row0 * 6;
+    const int p0 = czptr[9 * mesh + a], p1 = czptr[9 * mesh + a + 1];
+    double W[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) W[i][m] = 0;
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += CZ_T) {
+        const CzNode n = cz_node(lz[p]);
+        const double *yn = Ym + 18 * (size_t)n.node;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const double r0 = n.m0 ? 0.0 : yn[m], r1 = n.m1 ? 0.0 : yn[6 + m], r2 = n.m2 ? 0.0 : yn[12 + m];
+            W[0][m] += r0; W[1][m] += r1; W[2][m] += r2;
+            W[3][m] += n.q1 * r2 - n.q2 * r1; W[4][m] += n.q2 * r0 - n.q0 * r2; W[5][m] += n.q0 * r1 - n.q1 * r0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const double t = wave_sum_f64(W[i][m]);
+            if (lane == 0) sh[wave][6 * i + m] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        double t = 0;
+        for (int w = 0; w < CZ_T / 64; ++w) t += sh[w][threadIdx.x];
+        const int i = threadIdx.x / 6, m = threadIdx.x - 6 * i;
+        ac[(size_t)mesh * (CZ_NC * CZ_NC) + (size_t)(6 * a + i) * CZ_NC + 6 * b + m] = t;
     }
 }
 
@@ -1672,7 +1771,9 @@ struct fem_model {
     // (k_fem_cz_*), the inverse coarse matrices and the coarse vectors w, v (48 per mesh) and w.v
     int precond = 0;
     std::vector<uint8_t> h_cmask;
-    float4 *d_cz = nullptr; int *d_czptr = nullptr, *d_czmax = nullptr; uint8_t *d_cmask = nullptr;
+    float4 *d_cz = nullptr, *d_cznode = nullptr; int *d_czptr = nullptr, *d_czmax = nullptr; uint8_t *d_cmask = nullptr;
+    double *d_cy = nullptr;   // K Z_b, six doubles per row (k_fem_cz_kz)
+    int kz_lds = 0;           // its LDS bytes: 18 doubles per block of the fullest KZ_SPB rows
     double *d_ac = nullptr, *d_aci = nullptr, *d_cw = nullptr, *d_cv = nullptr, *d_cwv = nullptr;
     bool cz_space_valid = false;   // the coarse space depends on the nodes (fixed) and on the constrained dofs
     bool coarse() const { return precond == FEM_PRECOND_TWO_LEVEL; }
@@ -1704,7 +1805,7 @@ void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_tables, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_czptr, m->d_ac, m->d_aci, m->d_cw, m->d_cv, m->d_cwv, m->d_czmax, m->d_cmask};
+                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_cznode, m->d_cy, m->d_czptr, m->d_ac, m->d_aci, m->d_cw, m->d_cv, m->d_cwv, m->d_czmax, m->d_cmask};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -1752,7 +1853,8 @@ void launch_spmv(fem_model *m, hipStream_t st)
 int setup_coarse(fem_model *m)
 {
     const size_t NN = (size_t)m->nmesh * m->nn, NC2 = (size_t)CZ_NC * CZ_NC;
-    if (!m->d_cz && (dalloc(&m->d_cz, NN) || dalloc(&m->d_czptr, 9 * (size_t)m->nseg) || dalloc(&m->d_ac, NC2 * m->nseg) ||
+    if (!m->d_cz && (dalloc(&m->d_cz, NN) || dalloc(&m->d_cznode, NN) || dalloc(&m->d_cy, 6 * (size_t)m->nmesh * m->ndof) ||
+                     dalloc(&m->d_czptr, 9 * (size_t)m->nseg) || dalloc(&m->d_ac, NC2 * m->nseg) ||
                      dalloc(&m->d_aci, NC2 * m->nseg) || dalloc(&m->d_cw, (size_t)CZ_NC * m->nseg) || dalloc(&m->d_cv, (size_t)CZ_NC * m->nseg) ||
                      dalloc(&m->d_cwv, (size_t)m->nseg) || dalloc(&m->d_czmax, 1) || dalloc(&m->d_cmask, (size_t)m->ndof)))
         return -1;
@@ -1760,16 +1862,15 @@ int setup_coarse(fem_model *m)
         if (!m->h_cmask.empty() && hipMemcpyAsync(m->d_cmask, m->h_cmask.data(), m->h_cmask.size(), hipMemcpyHostToDevice, m->stream) != hipSuccess) return -1;
         if (hipMemsetAsync(m->d_czmax, 0, sizeof(int), m->stream) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_fem_cz_build, dim3(m->nseg), dim3(CZ_T), 0, m->stream, (const float *)m->d_nodes,
-                           m->h_cmask.empty() ? (const uint8_t *)nullptr : (const uint8_t *)m->d_cmask, m->segmented() ? 1 : 0, m->d_cz, m->d_czptr,
-                           m->d_czmax, m->ndof, (const int4 *)m->d_minfo);
+                           m->h_cmask.empty() ? (const uint8_t *)nullptr : (const uint8_t *)m->d_cmask, m->segmented() ? 1 : 0, m->d_cz, m->d_cznode,
+                           m->d_czptr, m->d_czmax, m->ndof, (const int4 *)m->d_minfo);
     }
     const dim3 g(CZ_NA, m->nseg);
-    for (int k = 0; k < CZ_NC; ++k) {
-        hipLaunchKernelGGL(k_fem_cz_prolong, g, dim3(CZ_T), 0, m->stream, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)nullptr, k,
-                           m->d_p, 0, m->ndof, (const int4 *)m->d_minfo);
-        launch_spmv(m, m->stream);
-        hipLaunchKernelGGL(k_fem_cz_restrict, g, dim3(CZ_T), 0, m->stream, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_Ap,
-                           m->d_ac, (int)NC2, CZ_NC, k, m->ndof, (const int4 *)m->d_minfo);
+    for (int b = 0; b < CZ_NA; ++b) {
+        hipLaunchKernelGGL(k_fem_cz_kz, dim3((m->ndof + KZ_SPB - 1) / KZ_SPB, m->nmesh), dim3(CGT), m->kz_lds, m->stream, (const float *)m->d_vals_b,
+                           (const int *)m->d_bcol3, (const int *)m->d_bp, m->nnzs, m->ndof, (const float4 *)m->d_cznode, b, m->d_cy);
+        hipLaunchKernelGGL(k_fem_cz_restrict6, g, dim3(CZ_T), 0, m->stream, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_cy, b,
+                           m->d_ac, m->ndof, (const int4 *)m->d_minfo);
     }
     hipLaunchKernelGGL(k_fem_cz_invert, dim3(m->nseg), dim3(64), 0, m->stream, (const double *)m->d_ac, m->d_aci);
     if (!m->cz_space_valid) {
@@ -2125,6 +2226,9 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
         P.bp[nbr] = (int)q;
         if (q != P.bcol3.size()) ORBX_FAIL(ORBX_ERR_ARG, "matrix pattern is not made of 3 x 3 node blocks");
         m->h_bp = P.bp;
+        int mb = 0;   // k_fem_cz_kz: 18 doubles per block of the fullest KZ_SPB rows (a quarter of the product kernel's bound times six: fits)
+        for (int I = 0; I < nbr; I += KZ_SPB / 3) mb = std::max(mb, P.bp[std::min(I + KZ_SPB / 3, nbr)] - P.bp[I]);
+        m->kz_lds = (mb + 1) * 18 * (int)sizeof(double);
     }
     {   // k_fem_cg_resident: whole batches of meshes small enough for one compute unit each
         P.rcfirst.assign(1, 0);
@@ -2231,6 +2335,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
             for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<false, false>), reinterpret_cast<const void *>(k_fem_cg_resident<false, true>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
     }
+    if (e == hipSuccess && m->kz_lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cz_kz), hipFuncAttributeMaxDynamicSharedMemorySize, m->kz_lds);
     if (e == hipSuccess && m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
                                reinterpret_cast<const void *>(k_fem_spmv<96, true>), reinterpret_cast<const void *>(k_fem_spmv<96, false>)})
