@@ -859,11 +859,11 @@ __device__ __forceinline__ CzNode cz_node(const float4 e)
         s[0] += r0; s[1] += r1; s[2] += r2;                                                                                       \
         s[3] += n.q1 * r2 - n.q2 * r1; s[4] += n.q2 * r0 - n.q0 * r2; s[5] += n.q0 * r1 - n.q1 * r0;                              \
     } while (0)
-// out[mesh * mstride + (6 a + m) * estride + off] = (Z^T src)[6 a + m]: a workgroup per (aggregate, mesh), thread-strided partials
-// and the block sum in its fixed order
+// The three steps of the coarse correction as launches of their own, for meshes of more than 65,536 nodes (smaller ones: k_fem_cz_apply).
+// w[mesh][6 a + m] = (Z^T src)[6 a + m]: a workgroup per (aggregate, mesh), thread-strided partials and the block sum in its fixed order
 __global__ __launch_bounds__(CZ_T) void k_fem_cz_restrict(const float4 *__restrict__ cz, const int *__restrict__ czptr,
-                                                          const double *__restrict__ src, double *__restrict__ out, int mstride,
-                                                          int estride, int off, int ndof, const int4 *__restrict__ minfo)
+                                                          const double *__restrict__ src, double *__restrict__ out, int ndof,
+                                                          const int4 *__restrict__ minfo)
 {
     __shared__ double sh[CZ_T / 64];
     const int a = blockIdx.x, mesh = blockIdx.y;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_restrict(const float4 *__restri
     for (int m = 0; m < 6; ++m) s[m] = block_sum(s[m], sh);
     if (threadIdx.x == 0)
 #pragma unroll
-        for (int m = 0; m < 6; ++m) out[(size_t)mesh * mstride + (size_t)(6 * a + m) * estride + off] = s[m];
+        for (int m = 0; m < 6; ++m) out[(size_t)mesh * CZ_NC + 6 * a + m] = s[m];
 }
 // v = Ac^-1 w and w.v, one wave per mesh (the inverse is symmetric: lane k reads column k, consecutive lanes consecutive memory)
 __global__ __launch_bounds__(64) void k_fem_cz_solve(const double *__restrict__ aci, const double *__restrict__ w, double *__restrict__ v,
@@ -892,15 +892,14 @@ __global__ __launch_bounds__(64) void k_fem_cz_solve(const double *__restrict__ 
     double s = 0;
     for (int j = 0; j < CZ_NC; ++j) s += A[j * CZ_NC + k] * wm[j];
     double t = (int)threadIdx.x < CZ_NC ? wm[k] * s : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    t = wave_sum_f64(t);
     if ((int)threadIdx.x < CZ_NC) v[(size_t)mesh * CZ_NC + k] = s;
     if (threadIdx.x == 0) wv[mesh] = t;
 }
-// out (=, or += when `accumulate`) Z v: v + omega x q per node, 0 at constrained dofs; unit >= 0: v = the unit vector e_unit (the
-// columns of Z, for Ac = Z^T K Z).  Every node is in exactly one aggregate, so `=` writes the whole vector.
+// out (=, or += when `accumulate`) Z v: v + omega x q per node, 0 at constrained dofs.  Every node is in exactly one aggregate, so
+// `=` writes the whole vector.
 __global__ __launch_bounds__(CZ_T) void k_fem_cz_prolong(const float4 *__restrict__ cz, const int *__restrict__ czptr,
-                                                         const double *__restrict__ v, int unit, double *__restrict__ out,
+                                                         const double *__restrict__ v, double *__restrict__ out,
                                                          int accumulate, int ndof, const int4 *__restrict__ minfo)
 {
     const int a = blockIdx.x, mesh = blockIdx.y;
@@ -910,7 +909,7 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_prolong(const float4 *__restric
     const int p0 = czptr[9 * mesh + a], p1 = czptr[9 * mesh + a + 1];
     double va[6];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) va[m] = unit >= 0 ? (unit == 6 * a + m ? 1.0 : 0.0) : v[(size_t)mesh * CZ_NC + 6 * a + m];
+    for (int m = 0; m < 6; ++m) va[m] = v[(size_t)mesh * CZ_NC + 6 * a + m];
     for (int p = p0 + (int)threadIdx.x; p < p1; p += CZ_T) {
         const CzNode n = cz_node(lz[p]);
         const double c0 = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
@@ -1893,11 +1892,11 @@ void coarse_correction(fem_model *m, hipStream_t st, const double *src, double *
         m->prof.stop(6, st);
         return;
     }
-    hipLaunchKernelGGL(k_fem_cz_restrict, g, dim3(CZ_T), 0, st, (const float4 *)m->d_cz, (const int *)m->d_czptr, src, m->d_cw, CZ_NC, 1, 0,
-                       m->ndof, (const int4 *)m->d_minfo);
+    hipLaunchKernelGGL(k_fem_cz_restrict, g, dim3(CZ_T), 0, st, (const float4 *)m->d_cz, (const int *)m->d_czptr, src, m->d_cw, m->ndof,
+                       (const int4 *)m->d_minfo);
     hipLaunchKernelGGL(k_fem_cz_solve, dim3(m->nseg), dim3(64), 0, st, (const double *)m->d_aci, (const double *)m->d_cw, m->d_cv, m->d_cwv);
-    hipLaunchKernelGGL(k_fem_cz_prolong, g, dim3(CZ_T), 0, st, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_cv, -1,
-                       out, accumulate, m->ndof, (const int4 *)m->d_minfo);
+    hipLaunchKernelGGL(k_fem_cz_prolong, g, dim3(CZ_T), 0, st, (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_cv, out,
+                       accumulate, m->ndof, (const int4 *)m->d_minfo);
     m->prof.stop(6, st);
 }
 
