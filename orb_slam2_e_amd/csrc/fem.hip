@@ -1204,10 +1204,25 @@ __device__ __forceinline__ double cz_apply_block(const float4 *__restrict__ lz, 
     const int zp0 = ptr9[a], zp1 = ptr9[a + 1];
     __syncthreads();                                   // the vector is complete
     double w6[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
-        const CzNode n = cz_node(lz[q]);
-        const double r0 = n.m0 ? 0.0 : rm[3 * n.node], r1 = n.m1 ? 0.0 : rm[3 * n.node + 1], r2 = n.m2 ? 0.0 : rm[3 * n.node + 2];
-        CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+    // four groups of 64 nodes at a time: their entries requested together, then their r -- two round trips per four groups (config
+    // 3's 275 nodes per aggregate: two in all) where a plain loop makes two per group
+    constexpr int U = 4;
+    for (int q0 = zp0 + 64 * half + lane; q0 - lane < zp1; q0 += 128 * U) {
+        float4 e[U]; double g[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = lz[min(q0 + 128 * u, zp1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double *rs = rm + 3 * (int)(__float_as_uint(e[u].w) & 0x0fffffffu);
+            g[u][0] = rs[0]; g[u][1] = rs[1]; g[u][2] = rs[2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const CzNode n = cz_node(e[u]);
+            const bool in = q0 + 128 * u < zp1;
+            const double r0 = n.m0 || !in ? 0.0 : g[u][0], r1 = n.m1 || !in ? 0.0 : g[u][1], r2 = n.m2 || !in ? 0.0 : g[u][2];
+            CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+        }
     }
 #pragma unroll
     for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); if (lane == m) s_w[half][6 * a + m] = w6[m]; }
@@ -1224,14 +1239,21 @@ __device__ __forceinline__ double cz_apply_block(const float4 *__restrict__ lz, 
     double va[6];
 #pragma unroll
     for (int m = 0; m < 6; ++m) va[m] = s_v[6 * a + m];
-    for (int q = zp0 + 64 * half + lane; q < zp1; q += 128) {
-        const CzNode n = cz_node(lz[q]);
-        double *cs = cm + 3 * n.node;
-        const double c0 = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
-        const double c1 = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
-        const double c2 = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
-        if (accumulate) { cs[0] += c0; cs[1] += c1; cs[2] += c2; }
-        else { cs[0] = c0; cs[1] = c1; cs[2] = c2; }
+    for (int q0 = zp0 + 64 * half + lane; q0 - lane < zp1; q0 += 128 * U) {
+        float4 e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = lz[min(q0 + 128 * u, zp1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + 128 * u >= zp1) continue;
+            const CzNode n = cz_node(e[u]);
+            double *cs = cm + 3 * n.node;
+            const double c0 = n.m0 ? 0.0 : va[0] + (va[4] * n.q2 - va[5] * n.q1);
+            const double c1 = n.m1 ? 0.0 : va[1] + (va[5] * n.q0 - va[3] * n.q2);
+            const double c2 = n.m2 ? 0.0 : va[2] + (va[3] * n.q1 - va[4] * n.q0);
+            if (accumulate) { cs[0] += c0; cs[1] += c1; cs[2] += c2; }
+            else { cs[0] = c0; cs[1] = c1; cs[2] = c2; }
+        }
     }
     const double wv = s_v[CZ_NC];
     __syncthreads();                                   // Z v complete
@@ -2890,17 +2912,16 @@ int fem_cg_coarse_matrix(fem_model *m, int mesh, double *Ac)
     return ORBX_OK;
 }
 
-int fem_cg_iterate(fem_model *m, int n, void *stream)
+// n iterations on st: one resident launch, or launch by launch -- small batches replay a captured hipGraph
+static int cg_iterate_on(fem_model *m, int n, hipStream_t st)
 {
-    if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
-    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-    m->cg_stream = st;
     if (m->resident_now()) { run_iters(m, n, st); ORBX_HIP(hipGetLastError()); return ORBX_OK; }
     int i = 0;
-    // Small batches are launch-bound (3 short kernels per iteration): replay a captured
+    // Small batches are launch-bound (3-4 short kernels per iteration): replay a captured
     // hipGraph of GRAPH_ITERS iterations.  Graph nodes carry no timing events, so this
-    // path is taken only while per-kernel profiling is off.
-    constexpr int GRAPH_ITERS = 50; // even: the rz[] parity returns to its start
+    // path is taken only while per-kernel profiling is off.  24: even (the rz[] parity returns to its start), and what a slice of 25
+    // iterations between two convergence tests (fem_cg) holds beside the one plain iteration that restores the parity
+    constexpr int GRAPH_ITERS = 24;
     if (m->prof.mask == 0 && m->nmesh * (size_t)m->ndof <= (size_t)1 << 20) {
         if ((m->cg_it & 1) && n > 0) { launch_iter(m, st); ++i; }
         while (n - i >= GRAPH_ITERS) {
@@ -2922,6 +2943,14 @@ int fem_cg_iterate(fem_model *m, int n, void *stream)
     for (; i < n; ++i) launch_iter(m, st);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
+}
+
+int fem_cg_iterate(fem_model *m, int n, void *stream)
+{
+    if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    m->cg_stream = st;
+    return cg_iterate_on(m, n, st);
 }
 
 int fem_spmv_repeat(fem_model *m, int n, void *stream)
@@ -2968,7 +2997,8 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
             if (all) break;
         }
         const int n = iters - done < 25 ? iters - done : 25;
-        run_iters(m, n, m->stream);
+        rc = cg_iterate_on(m, n, m->stream);
+        if (rc != ORBX_OK) return rc;
         done += n;
     }
     ORBX_HIP(hipGetLastError());
