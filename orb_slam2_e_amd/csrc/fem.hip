@@ -1817,6 +1817,7 @@ struct fem_model {
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
     hipGraphExec_t cg_graph = nullptr; // GRAPH_ITERS CG iterations captured once (launch-bound single-mesh case)
+    bool cg_graph_failed = false;
     orbx::KernelProfiler prof;
 };
 
@@ -2924,16 +2925,21 @@ static int cg_iterate_on(fem_model *m, int n, hipStream_t st)
     constexpr int GRAPH_ITERS = 24;
     if (m->prof.mask == 0 && m->nmesh * (size_t)m->ndof <= (size_t)1 << 20) {
         if ((m->cg_it & 1) && n > 0) { launch_iter(m, st); ++i; }
-        while (n - i >= GRAPH_ITERS) {
+        while (n - i >= GRAPH_ITERS && !m->cg_graph_failed) {
             if (!m->cg_graph) {
+                // a capture can be invalidated from outside (another thread's copy on the legacy stream synchronises with this one):
+                // then this model launches kernel by kernel from now on -- same results, more host time
                 hipGraph_t g = nullptr;
                 const int it0 = m->cg_it;
-                ORBX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                for (int k = 0; k < GRAPH_ITERS; ++k) launch_iter(m, st);
-                ORBX_HIP(hipStreamEndCapture(st, &g));
-                m->cg_it = it0; // capture executed nothing
-                ORBX_HIP(hipGraphInstantiate(&m->cg_graph, g, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(g);
+                bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    for (int k = 0; k < GRAPH_ITERS; ++k) launch_iter(m, st);
+                    ok = hipStreamEndCapture(st, &g) == hipSuccess && g != nullptr;
+                    m->cg_it = it0; // capture executed nothing
+                }
+                if (ok) ok = hipGraphInstantiate(&m->cg_graph, g, nullptr, nullptr, 0) == hipSuccess;
+                if (g) (void)hipGraphDestroy(g);
+                if (!ok) { (void)hipGetLastError(); m->cg_graph = nullptr; m->cg_graph_failed = true; break; }
             }
             ORBX_HIP(hipGraphLaunch(m->cg_graph, st));
             m->cg_it += GRAPH_ITERS;
@@ -2997,8 +3003,7 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
             if (all) break;
         }
         const int n = iters - done < 25 ? iters - done : 25;
-        rc = cg_iterate_on(m, n, m->stream);
-        if (rc != ORBX_OK) return rc;
+        run_iters(m, n, m->stream);
         done += n;
     }
     ORBX_HIP(hipGetLastError());
