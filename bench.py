@@ -148,7 +148,7 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         for attempt in range(2):
             fea.cg_setup(b)
             fea.profile((4 | 32) if nm > 1 else 0)        # events around k_fem_spmv / k_fem_cg_resident only (batch);
-            barrier()                                     # the single mesh replays a hipGraph (no events inside)
+            barrier()                                     # (the single mesh launches phase by phase)
             t0 = time.perf_counter()
             fea.cg_iterate(iters)
             x, rel = fea.cg_result()                       # synchronises

@@ -1816,8 +1816,6 @@ struct fem_model {
     bool resident_now() const { return cg_resident && !(coarse() && !cgr_big && cz_max_agg > 64 * 5); }
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
-    hipGraphExec_t cg_graph = nullptr; // GRAPH_ITERS CG iterations captured once (launch-bound single-mesh case)
-    bool cg_graph_failed = false;
     orbx::KernelProfiler prof;
 };
 
@@ -1832,7 +1830,6 @@ void fem_free(fem_model *m)
     for (void *q : ptrs)
         if (q) dfree(q);
     g_pin_cache.put(m->h_tr_pin);
-    if (m->cg_graph) (void)hipGraphExecDestroy(m->cg_graph);
     stream_put(m->stream);
 }
 
@@ -2899,7 +2896,6 @@ int fem_cg_preconditioner(fem_model *m, int kind)
     if (kind != m->precond) {
         m->precond = kind;
         m->cg_ready = false;
-        if (m->cg_graph) { (void)hipGraphExecDestroy(m->cg_graph); m->cg_graph = nullptr; }   // the captured iteration has another shape
         m->name_kernel_kinds();
     }
     return ORBX_OK;
@@ -2913,50 +2909,18 @@ int fem_cg_coarse_matrix(fem_model *m, int mesh, double *Ac)
     return ORBX_OK;
 }
 
-// n iterations on st: one resident launch, or launch by launch -- small batches replay a captured hipGraph
-static int cg_iterate_on(fem_model *m, int n, hipStream_t st)
-{
-    if (m->resident_now()) { run_iters(m, n, st); ORBX_HIP(hipGetLastError()); return ORBX_OK; }
-    int i = 0;
-    // Small batches are launch-bound (3-4 short kernels per iteration): replay a captured
-    // hipGraph of GRAPH_ITERS iterations.  Graph nodes carry no timing events, so this
-    // path is taken only while per-kernel profiling is off.  24: even (the rz[] parity returns to its start), and what a slice of 25
-    // iterations between two convergence tests (fem_cg) holds beside the one plain iteration that restores the parity
-    constexpr int GRAPH_ITERS = 24;
-    if (m->prof.mask == 0 && m->nmesh * (size_t)m->ndof <= (size_t)1 << 20) {
-        if ((m->cg_it & 1) && n > 0) { launch_iter(m, st); ++i; }
-        while (n - i >= GRAPH_ITERS && !m->cg_graph_failed) {
-            if (!m->cg_graph) {
-                // a capture can be invalidated from outside (another thread's copy on the legacy stream synchronises with this one):
-                // then this model launches kernel by kernel from now on -- same results, more host time
-                hipGraph_t g = nullptr;
-                const int it0 = m->cg_it;
-                bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-                if (ok) {
-                    for (int k = 0; k < GRAPH_ITERS; ++k) launch_iter(m, st);
-                    ok = hipStreamEndCapture(st, &g) == hipSuccess && g != nullptr;
-                    m->cg_it = it0; // capture executed nothing
-                }
-                if (ok) ok = hipGraphInstantiate(&m->cg_graph, g, nullptr, nullptr, 0) == hipSuccess;
-                if (g) (void)hipGraphDestroy(g);
-                if (!ok) { (void)hipGetLastError(); m->cg_graph = nullptr; m->cg_graph_failed = true; break; }
-            }
-            ORBX_HIP(hipGraphLaunch(m->cg_graph, st));
-            m->cg_it += GRAPH_ITERS;
-            i += GRAPH_ITERS;
-        }
-    }
-    for (; i < n; ++i) launch_iter(m, st);
-    ORBX_HIP(hipGetLastError());
-    return ORBX_OK;
-}
-
+// (Until round 4 small batches replayed a captured hipGraph of 50 iterations here.  While ANY stream captures, another thread's copy
+// on the legacy stream fails -- "would make the legacy stream depend on a capturing blocking stream", also with the capture on a
+// non-blocking stream of its own -- and invalidates the capture: tests/stress_threads.py.  The replay was worth 2 % on a single
+// mesh (97 k against 99-102 k iterations/s): the kernels run back to back either way.  Taken out.)
 int fem_cg_iterate(fem_model *m, int n, void *stream)
 {
     if (!m || !m->cg_ready || n < 0) ORBX_FAIL(ORBX_ERR_ARG, "call fem_cg_setup first");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     m->cg_stream = st;
-    return cg_iterate_on(m, n, st);
+    run_iters(m, n, st);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
 }
 
 int fem_spmv_repeat(fem_model *m, int n, void *stream)

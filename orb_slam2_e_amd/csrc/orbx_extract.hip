@@ -2329,7 +2329,11 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
     // on the second call of a frame size (the first has done every one-time set-up), only while nothing in the chain depends on
     // the call (no per-kernel profiling events; a pending reader of the last results is waited for in front of the chain); any
     // failure falls back to plain launches for good.
-    const bool can = as_graph && ex->prof.mask == 0 && !ex->g_failed;
+    // ORBX_NO_GRAPHS=1 switches the capture off: while a stream captures (once per frame size, ~0.2 ms), a copy on the legacy stream
+    // from ANY other thread fails with hipErrorStreamCaptureImplicit (tests/stress_threads.py met it in the FEM solver's former graph)
+    // -- a host that cannot make its first two pairs before its other threads call into the library should set it.
+    static const bool graphs_allowed = getenv("ORBX_NO_GRAPHS") == nullptr;
+    const bool can = as_graph && graphs_allowed && ex->prof.mask == 0 && !ex->g_failed;
     if (can && ex->g_exec && ex->g_w == width && ex->g_h == height && ex->g_stride == stride) {
         ORBX_HIP(hipGraphLaunch(ex->g_exec, st));
         ex->last_batch = 1; ex->last_stream = st;

@@ -62,13 +62,20 @@ def make_jobs(k):
         fea = FEA2(tn, tt, FEM_TET4); fea.MatrixAssembly(); fea.eliminate_dofs(tfixed)
         return fea.solve_cg(tb[None], iters=40)
 
+    def fem_cg_two_level():
+        fea = FEA2(tn, tt, FEM_TET4); fea.MatrixAssembly(); fea.eliminate_dofs(tfixed)
+        fea.cg_preconditioner("two_level")
+        x = fea.solve_cg(tb[None], iters=40)
+        fea.cg_setup(tb[None]); fea.cg_iterate(50)          # the captured graph of the launch-per-phase path, under other threads' copies
+        return x + fea.cg_result()
+
     return [("extract", lambda: ex(img)), ("stereo", stereo),
             ("projection", lambda: ORBmatcher(0.6, True).search_projection(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], 95)),
             ("window", lambda: ORBmatcher().search_window(c[0], c[1], c[4], c[5], c[6], c[7], c[8])),
             ("bruteforce", lambda: ORBmatcher().match_bruteforce(c[1][:700], c[5])),
             ("bow", lambda: ORBmatcher(0.7, True).SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False)),
             ("initialization", lambda: ORBmatcher(0.9, True).SearchForInitialization(ik1, id1, ik2, id2, iprev, ib, 100)),
-            ("fem LM trial", fem_lm), ("fem CG", fem_cg)]
+            ("fem LM trial", fem_lm), ("fem CG", fem_cg), ("fem CG two-level", fem_cg_two_level)]
 
 
 jobs = [make_jobs(k) for k in range(nthreads)]

@@ -27,7 +27,7 @@ def _check(x, rel, ox, orel, what):
 
 @pytest.mark.parametrize("ncell", [3, 6, 12])
 def test_single_mesh_two_level(ncell):
-    """One mesh (launch per phase, hipGraph replay of 50 iterations): the coarse matrix, 120 iterations, and the solve to 1e-10 --
+    """One mesh (launch per phase): the coarse matrix, 120 iterations, and the solve to 1e-10 --
     same iteration count as the oracle to within the 25-iteration test cadence, and far fewer than Jacobi needs."""
     nodes, tets, fixed, load = synth_tet_mesh(ncell=ncell)
     fea = FEA2(nodes, tets, FEM_TET4)
