@@ -10,6 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from orb_slam2_e_amd import ComputeStereoMatches, ORBextractor, ORBmatcher
+from orb_slam2_e_amd.extractor import extract_pair
 from orb_slam2_e_amd.fem import FEA2, FEM_C3D6, FEM_TET4, extrude_elems, second_layer
 from orb_slam2_e_amd.synth import synth_bow_case, synth_frame, synth_initialization_case, synth_projection_case, synth_stereo_pair, synth_tet_mesh
 from orb_slam2_e_amd.vocabulary import feature_vector_arrays
@@ -53,6 +54,13 @@ def make_jobs(k):
         eL(left); eR(right)
         return ComputeStereoMatches(eL, eR, mb, np.float32(386.1448))
 
+    pL, pR = ORBextractor(*P), ORBextractor(*P)
+    extract_pair(pL, pR, left, right); extract_pair(pL, pR, left, right)   # the second pair of a size captures its hipGraph: before the
+                                                                           # threads start, replays only from here on
+
+    def pair():
+        return extract_pair(pL, pR, left, right)
+
     def fem_lm():
         fea = FEA2(nodes, elems, FEM_C3D6); fea.MatrixAssembly(); fea.ImposeDirichletEncastre_K(ids)
         fea.trial_setup(nodes.ravel(), ids, len(top), None)
@@ -75,7 +83,7 @@ def make_jobs(k):
             ("bruteforce", lambda: ORBmatcher().match_bruteforce(c[1][:700], c[5])),
             ("bow", lambda: ORBmatcher(0.7, True).SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False)),
             ("initialization", lambda: ORBmatcher(0.9, True).SearchForInitialization(ik1, id1, ik2, id2, iprev, ib, 100)),
-            ("fem LM trial", fem_lm), ("fem CG", fem_cg), ("fem CG two-level", fem_cg_two_level)]
+            ("fem LM trial", fem_lm), ("fem CG", fem_cg), ("fem CG two-level", fem_cg_two_level), ("pair", pair)]
 
 
 jobs = [make_jobs(k) for k in range(nthreads)]
