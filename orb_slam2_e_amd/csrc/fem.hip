@@ -2872,7 +2872,7 @@ int fem_cg_setup(fem_model *m, const double *b)
     if (!m || !m->assembled || !b) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
     if (ensure_cg(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
-    ORBX_HIP(hipMemcpy(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpyAsync(m->d_b, b, sizeof(double) * N, hipMemcpyHostToDevice, m->stream));   // on the model's stream: a copy on the legacy stream waits for every other thread's work
     // the values as they stand now (assembled, penalties applied), block-major, for k_fem_spmv
     hipLaunchKernelGGL(k_fem_to_blocks, dim3((m->nblk + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_vals_b, m->d_rowptr,
                        m->d_bp, m->d_blk_row, m->nblk, m->nnzs);
@@ -2960,8 +2960,8 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
     int done = 0;
     while (done < iters) {
         if (tol > 0) { // convergence test on the device-side scalars, every 25 iterations
+            ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, m->stream));
             ORBX_HIP(hipStreamSynchronize(m->stream));
-            ORBX_HIP(hipMemcpy(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost));
             bool all = true;
             for (int i = 0; i < m->nseg; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb));
             if (all) break;
