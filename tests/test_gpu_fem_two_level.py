@@ -199,3 +199,37 @@ def test_two_level_one_large_mesh_takes_the_three_kernel_coarse_path():
     assert np.abs(fea.cg_coarse_matrix(0) - oAc).max() <= 1e-10 * np.abs(oAc).max()
     ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b, 12, nodes, mask)
     _check(x[0], rel[0], ox, orel, "large mesh")
+
+
+@pytest.mark.parametrize("nmesh", [1, 20, 64])
+def test_two_level_freezes_a_mesh_without_load_and_stays_finite_past_convergence(nmesh):
+    """As test_gpu_fem.py's guards, under the two-level preconditioner: a mesh with a zero right-hand side (w = Z^T r = 0, r.z = 0)
+    is frozen -- x == 0, no NaN -- in all three forms (launch per phase, fused step, resident), and 400 iterations on an 81-dof mesh
+    (whose aggregates hold 1-4 nodes each: most rotations are dropped as dependent) stay finite and at the solution."""
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=3)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    fea.cg_preconditioner("two_level")
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    dead = nmesh // 3
+    b[dead] = 0
+    x, done, rel = fea.solve_cg(b, iters=30, tol=0.0)
+    assert np.isfinite(x).all() and np.isfinite(rel).all()
+    assert not x[dead].any() and rel[dead] == 0
+    mask = _mask(b.shape[1], fixed)
+    for m in sorted({0, nmesh - 1} - {dead}):
+        rp, col, val = fea.csr(m)
+        ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[m], 30, nodes[m], mask)
+        _check(x[m], rel[m], ox, orel, m)
+    nodes, tets, fixed, load = synth_tet_batch(nmesh, ncell=2)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    fea.cg_preconditioner("two_level")
+    b = np.tile(load, (nmesh, 1)); b[:, fixed] = 0
+    x, done, rel = fea.solve_cg(b, iters=400, tol=0.0)
+    assert np.isfinite(x).all() and np.isfinite(rel).all() and rel.max() < 1e-9
+    rp, col, val = fea.csr(0)
+    r = b[0] - oracle.fem_csr_matvec(rp, col, val, x[0])
+    assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b[0])
