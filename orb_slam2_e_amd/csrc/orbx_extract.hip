@@ -71,6 +71,23 @@ __device__ unsigned long long g_phase_rec[4 * 65536 * 16];   // per workgroup: 8
 #define ORBX_PHA(i, cond) do {} while (0)
 #endif
 
+// XCD-aware (frame, item) mapping for grids of (nitems, nframes) workgroups (speed only,
+// never correctness): workgroups are dealt round-robin over the 8 XCDs in dispatch
+// order (x fastest), each XCD has its own L2; handing every XCD whole frames lets the
+// halos / patches of one frame hit in one L2 instead of being fetched by all eight.
+__device__ __forceinline__ void xcd_frame_item(int &frame, int &item)
+{
+    const int nb = gridDim.x, B = gridDim.y, id = blockIdx.x + nb * blockIdx.y;
+    if ((B & 7) == 0) {
+        const int x = id & 7, s = id >> 3;
+        frame = (s / nb) * 8 + x;
+        item = s % nb;
+    } else {
+        frame = blockIdx.y;
+        item = blockIdx.x;
+    }
+}
+
 // Level 0: copyMakeBorder(image, temp, 19,19,19,19, BORDER_REFLECT_101), ORBextractor.cc:1135.
 __global__ __launch_bounds__(64) void k_pyr_level0(const uint8_t *__restrict__ img, int img_stride,
                                                    size_t img_frame_stride, uint8_t *__restrict__ pyr,
@@ -122,15 +139,17 @@ __global__ __launch_bounds__(64) void k_pyr_level0_lin(const uint8_t *__restrict
                                                        uint8_t *__restrict__ pyr, size_t frame_bytes, LevelInfo lv, int pp,
                                                        unsigned inv_pp, int nblk_int, int nb, unsigned inv_nb, int nleft)
 {
-    const int f = blockIdx.z, lane = threadIdx.x, rows = lv.h + 2 * EDGE;
+    int f, bx;
+    xcd_frame_item(f, bx);          // grid (workgroups per frame, frames): a frame's pyramid is made by one XCD, launch after launch
+    const int lane = threadIdx.x, rows = lv.h + 2 * EDGE;
     const uint8_t *src = img + (size_t)f * img_frame_stride;
     uint8_t *dst = pyr + (size_t)f * frame_bytes + lv.off;
-    if ((int)blockIdx.x < nblk_int) {
+    if (bx < nblk_int) {
         uint2 v[4];
         int row[4], pc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int p = min((int)blockIdx.x * 256 + u * 64 + lane, rows * pp - 1);   // past the end: the last piece again
+            const int p = min(bx * 256 + u * 64 + lane, rows * pp - 1);   // past the end: the last piece again
             row[u] = (int)(((unsigned long long)(unsigned)p * inv_pp) >> 32);
             pc[u] = p - row[u] * pp;
             __builtin_memcpy(&v[u], src + (uint32_t)(reflect101(row[u] - EDGE, lv.h) * img_stride + 8 * pc[u]), 8);
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(64) void k_pyr_level0_lin(const uint8_t *__restrict
         for (int u = 0; u < 4; ++u)
             *reinterpret_cast<uint2 *>(dst + (uint32_t)(row[u] * lv.stride + PADX + 8 * pc[u])) = v[u];
     } else {
-        const int q = ((int)blockIdx.x - nblk_int) * 64 + lane;
+        const int q = (bx - nblk_int) * 64 + lane;
         if (q >= rows * nb) return;
         const int row = (int)(((unsigned long long)(unsigned)q * inv_nb) >> 32), k = q - row * nb;
         const int xw = k < nleft ? ((PADX - EDGE) >> 2) + k : ((PADX + lv.w) >> 2) + (k - nleft);   // dword of the padded row
@@ -201,24 +220,26 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
                                                    LevelInfo dst, const int2 *__restrict__ xt,
                                                    const int4 *__restrict__ yt, int nff, int nint, int nrg, int ntail, int tw_shift, int ntw, int rpw, int tail_window)
 {
-    const int f = blockIdx.z, tid = threadIdx.x;
+    int f, bx;
+    xcd_frame_item(f, bx);
+    const int tid = threadIdx.x;
     ORBX_PH_INIT(2);
 #ifdef ORBX_PHASE_TIMING
-    if (tid == 0) { ph_rec[12] = dst.w; ph_rec[11] = ((int)blockIdx.x < nff * ((nrg + rpw - 1) / rpw)) ? 1 : 0; }
+    if (tid == 0) { ph_rec[12] = dst.w; ph_rec[11] = (bx < nff * ((nrg + rpw - 1) / rpw)) ? 1 : 0; }
 #endif
     const int xlo = (PADX - EDGE) >> 2, xhi = (PADX + dst.w + EDGE - 1) >> 2; // first / last dword that holds border or image bytes
     const int nrgw = (nrg + rpw - 1) / rpw;   // a full wave takes rpw consecutive row groups, one after the other
-    const bool fast = (int)blockIdx.x < nff * nrgw;
+    const bool fast = bx < nff * nrgw;
     int xw, rowg;
     if (fast) {
-        const int rw = (int)blockIdx.x / nff;
-        const int g = ((int)blockIdx.x - rw * nff) * 64 + tid;
+        const int rw = bx / nff;
+        const int g = (bx - rw * nff) * 64 + tid;
         if (g >= nint) return;   // the last wave of a row may be partly filled (nint = interior groups the full-wave path takes)
         xw = PADX / 4 + g;
         rowg = rw * rpw;
     } else {
         // tail tile: 2^tw_shift groups x 64 >> tw_shift row groups; ntw > 1 (a tail wider than a wave) only with tw_shift = 6
-        const int tb = (int)blockIdx.x - nff * nrgw, tr = tb / ntw;
+        const int tb = bx - nff * nrgw, tr = tb / ntw;
         const int col = ((tb - tr * ntw) << tw_shift) + (tid & ((1 << tw_shift) - 1));
         rowg = (tr << (6 - tw_shift)) + (tid >> tw_shift);
         if (col >= ntail) return;
@@ -354,23 +375,6 @@ __global__ __launch_bounds__(64) void k_pyr_resize(uint8_t *__restrict__ pyr, si
     }
     ORBX_PH(2, tid == 0);
     ORBX_PH_END(tid == 0);
-}
-
-// XCD-aware (frame, item) mapping for grids of (nitems, nframes) workgroups (speed only,
-// never correctness): workgroups are dealt round-robin over the 8 XCDs in dispatch
-// order (x fastest), each XCD has its own L2; handing every XCD whole frames lets the
-// halos / patches of one frame hit in one L2 instead of being fetched by all eight.
-__device__ __forceinline__ void xcd_frame_item(int &frame, int &item)
-{
-    const int nb = gridDim.x, B = gridDim.y, id = blockIdx.x + nb * blockIdx.y;
-    if ((B & 7) == 0) {
-        const int x = id & 7, s = id >> 3;
-        frame = (s / nb) * 8 + x;
-        item = s % nb;
-    } else {
-        frame = blockIdx.y;
-        item = blockIdx.x;
-    }
 }
 
 // Dword load at any byte address: gfx950 under amdhsa runs in unaligned-access mode (the compiler itself turns an
@@ -2119,7 +2123,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
             const int rows = rows0, pp = pp0, nleft = nleft0;
             const int nb = nb0;
             const int nblk_int = (rows * pp + 255) / 256, nblk_b = (rows * nb + 63) / 64;
-            hipLaunchKernelGGL(k_pyr_level0_lin, dim3(nblk_int + nblk_b, 1, batch), dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr,
+            hipLaunchKernelGGL(k_pyr_level0_lin, dim3(nblk_int + nblk_b, batch), dim3(64), 0, st, d_img, stride, frame_stride, ex->d_pyr,
                                ex->frame_bytes, l0, pp, (unsigned)((0x100000000ull + pp - 1) / pp), nblk_int, nb,
                                (unsigned)((0x100000000ull + nb - 1) / nb), nleft);
         } else {
@@ -2146,7 +2150,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         const int ntailw = ntw * ((nrg + rpt - 1) / rpt);
         int rpw = 1;
         while (rpw < 2 && (size_t)(nff * ((nrg + rpw - 1) / rpw) + ntailw) * batch > (size_t)ex->resident_waves) ++rpw;
-        dim3 g(nff * ((nrg + rpw - 1) / rpw) + ntailw, 1, batch);
+        dim3 g(nff * ((nrg + rpw - 1) / rpw) + ntailw, batch);
         pf.start(1, st);
         hipLaunchKernelGGL(k_pyr_resize, g, dim3(64), 0, st, ex->d_pyr, ex->frame_bytes, ex->lv[l - 1], lv,
                            ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nint, nrg, ntail, tw_shift, ntw, rpw, ex->resize_tailwin[l]);
