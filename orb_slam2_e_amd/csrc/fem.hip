@@ -2681,7 +2681,7 @@ int fem_dirichlet_eliminate(fem_model *m, const int32_t *dofs, int ndofs)
     }
     uint8_t *d_fixed = nullptr;
     if (dalloc(&d_fixed, (size_t)m->ndof)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-    ORBX_HIP(hipMemcpy(d_fixed, fixed.data(), m->ndof, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpyAsync(d_fixed, fixed.data(), m->ndof, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_fem_eliminate, dim3((m->nblk + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_vals,
                        m->d_blk_row, m->d_bcol3, m->d_bp, m->d_rowptr, m->nblk, m->nnzs, d_fixed);
     ORBX_HIP(hipStreamSynchronize(m->stream));
@@ -2726,12 +2726,12 @@ int fem_get_csr(fem_model *m, int mesh, int32_t *rowptr, int32_t *col, float *va
         const int k0 = m->seg_nnz0[mesh], k1 = m->seg_nnz0[mesh + 1];
         if (rowptr) for (int r = 0; r <= nrows; ++r) rowptr[r] = m->h_rowptr[row0 + r] - k0;
         if (col) for (int k = k0; k < k1; ++k) col[k - k0] = m->h_lcol[k] - row0;
-        if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + k0, sizeof(float) * (size_t)(k1 - k0), hipMemcpyDeviceToHost));
+        if (val) { ORBX_HIP(hipMemcpyAsync(val, m->d_vals + k0, sizeof(float) * (size_t)(k1 - k0), hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
         return ORBX_OK;
     }
     if (rowptr) memcpy(rowptr, m->h_rowptr.data(), sizeof(int) * (m->ndof + 1));
     if (col) memcpy(col, m->h_lcol.data(), sizeof(int) * m->nnz);
-    if (val) ORBX_HIP(hipMemcpy(val, m->d_vals + (size_t)mesh * m->nnzs, sizeof(float) * m->nnz, hipMemcpyDeviceToHost));
+    if (val) { ORBX_HIP(hipMemcpyAsync(val, m->d_vals + (size_t)mesh * m->nnzs, sizeof(float) * m->nnz, hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
     return ORBX_OK;
 }
 
@@ -2742,20 +2742,20 @@ int fem_displacement(fem_model *m, const float *uf, const float *u0, const int32
         if (ids[i] - 1 < 0 || ids[i] - 1 >= m->nn) ORBX_FAIL(ORBX_ERR_ARG, "Dirichlet id out of range");
     if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
-    ORBX_HIP(hipMemcpy(m->d_a, uf, sizeof(float) * N, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(m->d_u, u0, sizeof(float) * N, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpyAsync(m->d_a, uf, sizeof(float) * N, hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP(hipMemcpyAsync(m->d_u, u0, sizeof(float) * N, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_fem_displacement, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, m->stream, m->d_a, m->d_u, m->d_f, N);
     if (nids) {
         int *d_ids = nullptr;
         if (dalloc(&d_ids, (size_t)nids)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
-        ORBX_HIP(hipMemcpy(d_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpyAsync(d_ids, ids, sizeof(int) * nids, hipMemcpyHostToDevice, m->stream));
         hipLaunchKernelGGL(k_fem_displacement_dir, dim3((nids * 3 + 255) / 256, m->nmesh), dim3(256), 0, m->stream, m->d_f,
                            m->ndof, d_ids, nids, klarge);
         ORBX_HIP(hipStreamSynchronize(m->stream));
         dfree(d_ids);
     }
     ORBX_HIP(hipStreamSynchronize(m->stream));
-    ORBX_HIP(hipMemcpy(a, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
+    { ORBX_HIP(hipMemcpyAsync(a, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
     return ORBX_OK;
 }
 
@@ -2764,11 +2764,11 @@ int fem_matvec(fem_model *m, const float *a, float *f)
     if (!m || !m->assembled || !a || !f) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
     if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
-    ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpyAsync(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 15) / 16, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_lcol,
                        m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     ORBX_HIP(hipStreamSynchronize(m->stream));
-    ORBX_HIP(hipMemcpy(f, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost));
+    { ORBX_HIP(hipMemcpyAsync(f, m->d_f, sizeof(float) * N, hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
     return ORBX_OK;
 }
 
@@ -2777,14 +2777,14 @@ int fem_strain_energy(fem_model *m, const float *a, float *sE, float *nsE)
     if (!m || !m->assembled || !a) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments / not assembled");
     if (ensure_vecs(m)) ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     const size_t N = (size_t)m->nmesh * m->ndof;
-    ORBX_HIP(hipMemcpy(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpyAsync(m->d_a, a, sizeof(float) * N, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_fem_matvec, dim3((m->ndof + 15) / 16, m->nmesh), dim3(256), 0, m->stream, m->d_vals, m->d_lcol,
                        m->d_rowptr, m->nnzs, m->ndof, m->d_a, m->d_f);
     hipLaunchKernelGGL(k_fem_energy, dim3(m->nseg), dim3(256), 0, m->stream, m->d_a, m->d_f, m->ndof, m->d_e, m->d_e + m->nseg,
                        (const int4 *)m->d_minfo);
     ORBX_HIP(hipStreamSynchronize(m->stream));
-    if (sE) ORBX_HIP(hipMemcpy(sE, m->d_e, sizeof(float) * m->nseg, hipMemcpyDeviceToHost));
-    if (nsE) ORBX_HIP(hipMemcpy(nsE, m->d_e + m->nseg, sizeof(float) * m->nseg, hipMemcpyDeviceToHost));
+    if (sE) { ORBX_HIP(hipMemcpyAsync(sE, m->d_e, sizeof(float) * m->nseg, hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
+    if (nsE) { ORBX_HIP(hipMemcpyAsync(nsE, m->d_e + m->nseg, sizeof(float) * m->nseg, hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
     return ORBX_OK;
 }
 
@@ -2905,7 +2905,7 @@ int fem_cg_coarse_matrix(fem_model *m, int mesh, double *Ac)
 {
     if (!m || !Ac || mesh < 0 || mesh >= m->nseg) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     if (!m->coarse() || !m->cg_ready) ORBX_FAIL(ORBX_ERR_ARG, "no two-level preconditioner set up (fem_cg_preconditioner, fem_cg_setup)");
-    ORBX_HIP(hipMemcpy(Ac, m->d_ac + (size_t)CZ_NC * CZ_NC * mesh, sizeof(double) * CZ_NC * CZ_NC, hipMemcpyDeviceToHost));
+    { ORBX_HIP(hipMemcpyAsync(Ac, m->d_ac + (size_t)CZ_NC * CZ_NC * mesh, sizeof(double) * CZ_NC * CZ_NC, hipMemcpyDeviceToHost, m->stream)); ORBX_HIP(hipStreamSynchronize(m->stream)); }
     return ORBX_OK;
 }
 
