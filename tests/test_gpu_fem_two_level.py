@@ -233,3 +233,25 @@ def test_two_level_freezes_a_mesh_without_load_and_stays_finite_past_convergence
     rp, col, val = fea.csr(0)
     r = b[0] - oracle.fem_csr_matvec(rp, col, val, x[0])
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b[0])
+
+
+def test_two_level_api_errors_are_loud():
+    """Argument errors of the two entry points come back as OrbxError, not as silence: an unknown preconditioner, the coarse matrix
+    before any set-up, under Jacobi, and for a mesh that does not exist."""
+    from orb_slam2_e_amd._lib import OrbxError
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=3)
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly()
+    fea.eliminate_dofs(fixed)
+    with pytest.raises(OrbxError):
+        fea.cg_preconditioner(7)
+    with pytest.raises(OrbxError):
+        fea.cg_coarse_matrix(0)                       # Jacobi: there is none
+    fea.cg_preconditioner("two_level")
+    with pytest.raises(OrbxError):
+        fea.cg_coarse_matrix(0)                       # no fem_cg_setup yet
+    b = load.copy(); b[fixed] = 0
+    fea.solve_cg(b, iters=5)
+    assert fea.cg_coarse_matrix(0).shape == (48, 48)
+    with pytest.raises(OrbxError):
+        fea.cg_coarse_matrix(1)
