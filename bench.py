@@ -142,10 +142,12 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         fea.cg_iterate(iters); fea.cg_result()        # warm + per-kernel split (untimed pass, all kinds): the same length as the timed
                                                       # pass -- the first full-length launch after a set-up runs ~6 % longer than the next ones
         split = {k: v[0] / max(v[1], 1) for k, v in fea.profile_read().items() if v[1]}
-        # the timed region, twice, the better one kept (a leg is ONE launch of 7-25 ms: a transient dip of the card's clocks would
-        # be the whole measurement; the iterations are deterministic, both passes leave the same x)
-        dt, prof = float("inf"), None
-        for attempt in range(2):
+        # the timed region, three times: a leg is ONE launch of 7-25 ms, so a transient dip of the card's clocks would be the whole
+        # measurement.  The MEDIAN pass is what the line reports (`ms_per_iter`, `cg_mesh_iters_per_s`, the resident kernel's
+        # roofline); the best pass stands beside it as `*_best` (rounds 2-4 reported the better of two passes alone).  The
+        # iterations are deterministic, every pass leaves the same x.
+        passes = []
+        for attempt in range(3):
             fea.cg_setup(b)
             fea.profile((4 | 32) if nm > 1 else 0)        # events around k_fem_spmv / k_fem_cg_resident only (batch);
             barrier()                                     # (the single mesh launches phase by phase)
@@ -155,9 +157,10 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
             xall = gather_displacements(x, rank, world, cdev)   # N > 1: [world * nm, ndof] on rank 0
             barrier()
             dt_a = max_over_ranks(time.perf_counter() - t0, world, cdev)
-            prof_a = fea.profile_read()
-            if dt_a < dt:
-                dt, prof = dt_a, prof_a
+            passes.append((dt_a, fea.profile_read()))
+        passes.sort(key=lambda q: q[0])
+        dt, prof = passes[1]
+        dt_best = passes[0][0]
         n, nnz = fea.Ksize, fea.nnz
         distinct = label == "batch_distinct_topologies"
         spmv_ms = prof["k_fem_spmv"][0] / max(prof["k_fem_spmv"][1], 1) if prof["k_fem_spmv"][1] else split.get("k_fem_spmv", 0.0)
@@ -178,6 +181,8 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
         out[label] = {"meshes_per_gpu": nm, "n_dof": n, "nnz": nnz, "cg_iters": iters, "create_ms": t_create * 1e3, "synth_ms_host_numpy": t_synth * 1e3,
                       "spmv_grid_threads": grid_threads,
                       "cg_mesh_iters_per_s": world * nm * iters / dt, "ms_per_iter": dt / iters * 1e3,
+                      "cg_mesh_iters_per_s_best": world * nm * iters / dt_best, "ms_per_iter_best": dt_best / iters * 1e3,
+                      "timed_passes": "3; the median pass is reported, the best beside it as *_best",
                       "assemble_ms": t_asm * 1e3, "relres_after": float(rel.max()),
                       "spmv_avg_launch_ms": spmv_ms, "spmv_alg_bytes_per_launch": spmv_bytes, "spmv_block_form_bytes_per_launch": block_bytes,
                       "spmv_GBps": spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
@@ -333,41 +338,58 @@ def fem_compute1_bench():
             if r >= 3:
                 per_rep.append(np.diff(t))
         pts = top.astype(np.float64) + 0.003
-        acc[:4] = np.median(np.array(per_rep), axis=0) * reps        # the median call of each phase (see best_batch_ms: power management)
-        acc[4] = best_batch_ms(lambda: fea.trial_energy(pts, want_a=False), 100, warm=10, batch=20) * 1e-3 * reps   # as the hook: estimates in, the two energies out
+        acc[:4] = np.median(np.array(per_rep), axis=0) * reps        # the median call of each phase
+        trial_med, trial_best = batch_ms(lambda: fea.trial_energy(pts, want_a=False), 100, warm=10, batch=20)   # as the hook: estimates in, the two energies out
+        acc[4] = trial_med * 1e-3 * reps
         ms = acc / reps * 1e3
         out[name] = {"Ksize": int(fea.Ksize), "elements": int(len(elems)), "create_ms": ms[0], "assemble_ms": ms[1], "dirichlet_ms": ms[2],
-                     "trial_setup_ms": ms[3], "compute1_ms": float(ms[:4].sum()), "lm_trial_ms": ms[4]}
+                     "trial_setup_ms": ms[3], "compute1_ms": float(ms[:4].sum()), "lm_trial_ms": ms[4], "lm_trial_ms_best": trial_best}
     return out
+
+
+def _newest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round number present (the passes are re-made on every round's final library)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        r = int(re.match(r"r(\d\d)_", os.path.basename(f)).group(1))
+        if best is None or r > best[0]:
+            best = (r, f)
+    return best[1] if best else None
 
 
 def load_fem_traffic():
     """HBM bytes per 200-iteration launch of the batched CG legs (tools/fem_traffic.py over separate FETCH_SIZE / WRITE_SIZE passes)."""
-    f = os.path.join(ROOT, "profiles", "r03_fem_traffic.json")
-    return json.load(open(f)) if os.path.exists(f) else {}
+    f = _newest_profile("fem_traffic.json")
+    return json.load(open(f)) if f else {}
 
 
 def load_traffic():
-    """HBM bytes / VALU instruction counts per launch from the committed PMC passes (newest round first)."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        f = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(f):
-            return json.load(open(f))
-    return {}
+    """HBM bytes / VALU instruction counts per launch from the committed PMC passes (newest round)."""
+    f = _newest_profile("traffic.json")
+    return json.load(open(f)) if f else {}
 
 
-def best_batch_ms(f, reps, warm=5, batch=10):
-    """Per-call latency of f in ms: `warm` untimed calls, then reps calls in batches of `batch`; the BEST batch mean.  These legs
-    are single calls of 30-150 us issued from an otherwise idle process: the card's power management now and then runs a batch
-    at a fraction of its clocks (0.79 ms where 0.086 is the rule, seen in isolation), and a mean over everything reports that
-    instead of the call."""
+def batch_ms(f, reps, warm=5, batch=10):
+    """Per-call latency of f in ms: `warm` untimed calls, then reps calls in batches of `batch`.  Returns (median, best) of the
+    batch means.  These legs are single calls of 30-150 us issued from an otherwise idle process: the card's power management now
+    and then runs a batch at a fraction of its clocks (0.79 ms where 0.086 is the rule, seen in isolation) -- the MEDIAN batch is
+    what the line reports under the plain key, the best batch beside it as `<key>_best` (rounds 1-4 reported the best alone)."""
     for _ in range(warm): f()
-    best = float("inf")
+    t = []
     for _ in range(max(3, reps // batch)):
         t0 = time.perf_counter()
         for _ in range(batch): f()
-        best = min(best, (time.perf_counter() - t0) / batch)
-    return best * 1e3
+        t.append((time.perf_counter() - t0) / batch)
+    return float(np.median(t)) * 1e3, min(t) * 1e3
+
+
+def put_ms(out, key, f, reps, warm=5, batch=10):
+    """out[key] = median batch mean of f in ms, out[key + '_best'] = best batch mean."""
+    assert key.endswith("_ms")
+    out[key], out[key + "_best"] = batch_ms(f, reps, warm, batch)
+    return out[key]
 
 
 def matcher_loops_bench():
@@ -377,8 +399,6 @@ def matcher_loops_bench():
     from orb_slam2_e_amd.matcher import ORBmatcher
     from orb_slam2_e_amd.synth import synth_bow_case, synth_projection_case
     from orb_slam2_e_amd.vocabulary import feature_vector_arrays
-
-    ms = best_batch_ms                              # (the card idles -- and clocks down -- while the host times the CPU leg)
 
     q, qd, qa, takes, kps, desc, bounds, occ, ur = synth_projection_case(0, n=2000, nq=2000, hot=2000)
     d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2 = synth_bow_case(0)
@@ -409,17 +429,103 @@ def matcher_loops_bench():
         k["x"] = brng.uniform(0, 640, len(d)); k["y"] = brng.uniform(0, 480, len(d)); k["angle"] = a
         return Frame(k, d, (0.0, 0.0, 640.0, 480.0))
     bf1, bf2 = bow_frame(d1, a1), bow_frame(d2, a2)
-    out = {"search_for_initialization_2000x2200_ms": ms(lambda: mi.SearchForInitialization(ik1, id1, ik2, id2, iprev, ibounds, 100), 30),
-           "search_by_projection_2000x2000_ms": ms(lambda: m.frame_search_projection(fr, q, qd, qa, takes, occ, 95), 100),
-           "search_by_projection_2000x2000_host_arrays_ms": ms(lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
-           "search_by_projection_last_frame_whole_2000x2000_ms": ms(lambda: m.SearchByProjectionLast(cur, view, sc["Tcw"], sc["Tlw"], last, sc["occupied"], 7.0, True), 100),
-           "search_local_points_whole_2500x2000_ms": ms(lambda: m.SearchByProjectionPoints(cur, view, sc["Tcw"], pts, sc["occupied"], 1.0), 100),
-           "frame_create_2000_ms": ms(lambda: Frame(kps, desc, bounds, ur).close(), 50),
-           "search_by_bow_2000x2100_ms": ms(lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
-           "search_by_bow_2000x2100_resident_ms": ms(lambda: m.frame_search_by_bow(bf1, fv1, valid1, bf2, fv2, None, False), 50),
-           "search_window_2000x2000_ms": ms(lambda: m.frame_search_window(fr, q, qd, occ), 100),
-           "search_window_2000x2000_host_arrays_ms": ms(lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)}
+    out = {"timing": "per call: median of the means of 10-call batches; `_best` = the best batch (the only figure of rounds 1-4)"}
+    for key, f, reps in (
+            ("search_for_initialization_2000x2200_ms", lambda: mi.SearchForInitialization(ik1, id1, ik2, id2, iprev, ibounds, 100), 30),
+            ("search_by_projection_2000x2000_ms", lambda: m.frame_search_projection(fr, q, qd, qa, takes, occ, 95), 100),
+            ("search_by_projection_2000x2000_host_arrays_ms", lambda: m.search_projection(q, qd, qa, takes, kps, desc, bounds, occ, ur, 95), 50),
+            ("search_by_projection_last_frame_whole_2000x2000_ms", lambda: m.SearchByProjectionLast(cur, view, sc["Tcw"], sc["Tlw"], last, sc["occupied"], 7.0, True), 100),
+            ("search_local_points_whole_2500x2000_ms", lambda: m.SearchByProjectionPoints(cur, view, sc["Tcw"], pts, sc["occupied"], 1.0), 100),
+            ("frame_create_2000_ms", lambda: Frame(kps, desc, bounds, ur).close(), 50),
+            ("search_by_bow_2000x2100_ms", lambda: m.SearchByBoW(fv1, valid1, d1, a1, fv2, valid2, d2, a2, False), 50),
+            ("search_by_bow_2000x2100_resident_ms", lambda: m.frame_search_by_bow(bf1, fv1, valid1, bf2, fv2, None, False), 50),
+            ("search_window_2000x2000_ms", lambda: m.frame_search_window(fr, q, qd, occ), 100),
+            ("search_window_2000x2000_host_arrays_ms", lambda: m.search_window(q, qd, kps, desc, bounds, occ, ur), 50)):
+        put_ms(out, key, f, reps)
     fr.close(); cur.close(); bf1.close(); bf2.close()
+    return out
+
+
+BOW_K, BOW_L, BOW_SETS, BOW_CAP = 10, 6, 64, 2000     # ORBvoc's shape (k = 10, L = 6: 1,111,111 nodes), 64 frames x 2000 descriptors
+
+
+def bow_case():
+    """The vocabulary and the descriptor sets of the bow_transform leg (the CPU baseline child builds the same)."""
+    from orb_slam2_e_amd.synth import synth_vocabulary, synth_vocabulary_features
+    voc = synth_vocabulary(BOW_K, BOW_L, seed=0)
+    feats = synth_vocabulary_features(voc, BOW_SETS * BOW_CAP, seed=1).reshape(BOW_SETS, BOW_CAP, 32)
+    return voc, feats
+
+
+def distinctive_case(m=2000, seed=3):
+    """m map points with 2..40 observations each (MapPoint::ComputeDistinctiveDescriptors' input, MapPoint.cc:305-370)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(2, 41, m)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    desc = np.repeat(base, sizes, axis=0) ^ np.packbits(rng.random((int(off[-1]), 256)) < 0.1, axis=1, bitorder="little")
+    return desc, off
+
+
+def bow_bench(torch, dev):
+    """SURVEY 8(f) rank 2 at the reference's real vocabulary shape: DBoW2 transform's tree descent (TemplatedVocabulary.h:1218-1262,
+    levelsup = 4 as Frame.cc:415) of 64 x 2000 resident descriptors through a k = 10, L = 6 tree (35.6 MB of node descriptors --
+    the gather pattern of ORBvoc.txt, which is missing from the reference mount), one launch; and rank 4,
+    ComputeDistinctiveDescriptors over 2000 map points, one call on host arrays."""
+    import oracle
+    from orb_slam2_e_amd.matcher import ORBmatcher
+    from orb_slam2_e_amd.vocabulary import ORBVocabulary
+    voc, feats = bow_case()
+    t0 = time.perf_counter()
+    v = ORBVocabulary(*voc)
+    create_ms = (time.perf_counter() - t0) * 1e3
+    d_f = torch.from_numpy(feats).to(dev)
+    d_cnt = torch.full((BOW_SETS,), BOW_CAP, dtype=torch.int32, device=dev)
+    d_w = torch.full((BOW_SETS, BOW_CAP), -7, dtype=torch.int32, device=dev); d_n = torch.full_like(d_w, -7)
+    ts = torch.cuda.Stream(device=dev)
+    run = lambda: v.descend_batch_device(d_f.data_ptr(), d_cnt.data_ptr(), BOW_CAP, BOW_SETS, 4, d_w.data_ptr(), d_n.data_ptr(), ts.cuda_stream)
+    reps = 50
+    with torch.cuda.stream(ts):
+        for _ in range(5): run()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:                    # events on the stream the kernel is launched on
+            a.record(ts); run(); b.record(ts)
+    ts.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in ev])
+    # whole-batch wall time, back to back without events
+    t0 = time.perf_counter()
+    for _ in range(reps): run()
+    ts.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    nd = BOW_SETS * BOW_CAP
+    alg = nd * (BOW_L * BOW_K * 32 + 32 + 8)        # every level's children descriptors + the feature + word id and node id out
+    avg = float(t.mean())
+    # the checker, outside the timed region: all 128,000 descents against the oracle
+    ref = oracle.bow_descend(*voc, feats.reshape(-1, 32), 4)
+    ok = bool(np.array_equal(d_w.cpu().numpy().ravel(), ref[0]) and np.array_equal(d_n.cpu().numpy().ravel(), ref[1]))
+    out = {"vocabulary": {"k": BOW_K, "L": BOW_L, "nodes": int(len(voc[3])), "words": int((voc[3] >= 0).sum()), "node_descriptor_bytes": int(voc[2].nbytes),
+                          "what": "synthetic complete tree in ORBvoc's shape (orb_slam2_e_amd/synth.py: synth_vocabulary); ORBvoc.txt itself is not in the reference mount",
+                          "create_ms": create_ms},
+           "descriptors": nd, "sets": BOW_SETS, "levelsup": 4, "launch_ms_avg": avg, "launch_ms_median": float(np.median(t)), "wall_ms_per_batch": wall_ms,
+           "descriptors_per_s": nd / (wall_ms * 1e-3), "verified": ok,
+           "roofline": {"bound": "hbm", "kernel": "k_bow_transform", "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg, "alg_bytes_per_launch": alg,
+                        "note": "algorithmic bytes per descriptor = L x k x 32 B of children descriptors + 32 B feature + 8 B out (1,960 B); the kernel "
+                                "also reads a 16-byte record per child (its own children's range, node id, word id: +960 B). The whole tree "
+                                "(35.6 + 17.8 MB) fits the 256-MiB Infinity Cache: a gather bound by round-trip latency x levels, not by HBM"}}
+    tr = load_traffic().get("k_bow_transform")
+    if tr:
+        out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]; out["roofline"]["traffic_source"] = tr["source"]
+    put_ms(out, "transform_2000_host_arrays_ms", lambda: v.descend(feats[0], 4), 50)
+    desc, off = distinctive_case()
+    got = ORBmatcher.distinctive_descriptors(desc, off)
+    dd = {"map_points": int(len(off) - 1), "observations": int(off[-1]), "verified": bool(np.array_equal(got, oracle.distinctive_descriptors(desc, off))),
+          "alg_bytes_per_call": int(off[-1]) * 32 + (len(off) - 1) * 4,
+          "what": "MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:305-370) for 2000 map points of 2..40 observations in one call, host arrays in and out"}
+    put_ms(dd, "call_ms", lambda: ORBmatcher.distinctive_descriptors(desc, off), 50)
+    out["distinctive_descriptors"] = dd
+    out["verified"] = bool(ok and dd["verified"])
+    del v
     return out
 
 
@@ -446,20 +552,21 @@ def stereo_bench():
 
     u, d = frame()
     reps = 50
-    t_all = best_batch_ms(frame, reps) * 1e-3
+    t_all, t_all_best = (x * 1e-3 for x in batch_ms(frame, reps))
     # the same frame from ONE host thread: orbx_extract_pair enqueues both images' kernel chains before it waits for either
     from orb_slam2_e_amd import extract_pair
     def frame_one_call():
         extract_pair(eL, eR, left, right)
         return ComputeStereoMatches(eL, eR, mb, np.float32(bf))
     u1, d1 = frame_one_call()
-    t_one = best_batch_ms(frame_one_call, reps) * 1e-3 if np.array_equal(u1, u) and np.array_equal(d1, d) else float("nan")
-    t_st = best_batch_ms(lambda: ComputeStereoMatches(eL, eR, mb, np.float32(bf)), reps) * 1e-3
+    t_one, t_one_best = (x * 1e-3 for x in batch_ms(frame_one_call, reps)) if np.array_equal(u1, u) and np.array_equal(d1, d) else (float("nan"),) * 2
+    t_st, t_st_best = (x * 1e-3 for x in batch_ms(lambda: ComputeStereoMatches(eL, eR, mb, np.float32(bf)), reps))
     pool.shutdown()
     out = {"pair": "1242x375, 2000 features per image", "stereo_frame_ms": t_all * 1e3, "stereo_frame_one_call_ms": t_one * 1e3,
            "compute_stereo_matches_ms": t_st * 1e3,
+           "stereo_frame_ms_best": t_all_best * 1e3, "stereo_frame_one_call_ms_best": t_one_best * 1e3, "compute_stereo_matches_ms_best": t_st_best * 1e3,
            "threads": "left and right extraction on two host threads, as Frame.cc:78-81",
-           "timing": "per-call latencies of this leg, the matcher loops and the LM trial: best mean of 10-call batches (best_batch_ms); Compute(1) phases: medians of 30 calls",
+           "timing": "per-call latencies of this leg, the matcher loops and the LM trial: MEDIAN of the means of 10-call batches, `_best` = the best batch (batch_ms); Compute(1) phases: medians of 30 calls",
            "stereo_pairs_per_s": 1.0 / t_all, "matched": int((u >= 0).sum())}
 
     # ORBmatcher::SearchForTriangulation (ORBmatcher.cc:858-1024) on the pair's own keypoints as two keyframes one KITTI
@@ -475,7 +582,7 @@ def stereo_bench():
     whole = lambda: m.SearchForTriangulation(kL, dL, fv1, has1, s1, kR, dR, fv2, has2, s2, F12, ex, ey, sf, sg, False)
     inner = lambda: m.match_triangulation(kL, dL, kR, dR, off, idx, has1, has2, s1, s2, F12, ex, ey, sf, sg, False)
     for name, fn in (("search_for_triangulation_ms", whole), ("search_for_triangulation_gated_loop_ms", inner)):
-        out[name] = best_batch_ms(fn, reps)
+        put_ms(out, name, fn, reps)
     out["search_for_triangulation"] = {"keypoints": [len(kL), len(kR)], "candidates": int(len(idx)), "matches": int(whole()[1])}
     # ... and with the two keyframes resident in HBM (stereo = the frame's right coordinate; lists shared per node)
     from orb_slam2_e_amd import Frame
@@ -483,7 +590,7 @@ def stereo_bench():
     fL = Frame(kL, dL, tb, np.where(np.asarray(s1, bool), 1.0, -1.0).astype(np.float32))
     fR = Frame(kR, dR, tb, np.where(np.asarray(s2, bool), 1.0, -1.0).astype(np.float32))
     resident = lambda: m.frame_search_for_triangulation(fL, fv1, has1, fR, fv2, has2, F12, ex, ey, sf, sg, False)
-    out["search_for_triangulation_resident_ms"] = best_batch_ms(resident, reps)
+    put_ms(out, "search_for_triangulation_resident_ms", resident, reps)
     out["search_for_triangulation"]["resident_equal"] = bool(np.array_equal(resident()[2], whole()[2]))
     fL.close(); fR.close()
 
@@ -530,7 +637,7 @@ def stereo_bench():
     return out
 
 
-PRECONDITION_STEPS = 300   # untimed steps in front of the warm-up (see the timed region in main())
+PRECONDITION_STEPS = 300   # untimed steps in front of the SECOND timed region (ms_per_step_conditioned; see main())
 
 
 def main():
@@ -706,18 +813,9 @@ def main():
             L.orbx_profile_enable(c.ex._h, (1 << KINDS.index(dom)) if dom in KINDS else 0)
         L.orbm_profile_enable(1 if dom == "k_match_sets_mfma" else 0)
 
-    # the W warm-up steps run exactly as the timed ones do (pipelined, same events) and directly before them: the
-    # one-step-at-a-time profiling pass above leaves the card nearly idle, and a timed region that starts from
-    # there spends its first steps getting back to the steady state
+    # The contract's region: W warm-up steps, run exactly as the timed ones (pipelined, same events), then EXACTLY K timed steps
+    # between barriers -- nothing else in front.  `value` / `ms_per_step` come from here (= `ms_per_step_unconditioned`).
     enable_dominant()
-    # clock conditioning (untimed; reported as config.preconditioning_steps): the passes above leave the card nearly idle, and
-    # from there it takes tens of milliseconds of load to reach the clocks it then sustains -- a 20-step timed region is
-    # 5-6 ms.  Measured on one box, 20 timed steps: 0.280-0.289 ms per step after W = 2 or 10 warm-up steps alone,
-    # 0.261-0.269 ms after 200 (the 200-step figure is 0.255-0.266).  So the same pipelined steps run for PRECONDITION_STEPS
-    # (~80 ms) first, then the W warm-up steps the caller asked for, then the K timed ones.
-    for k in range(PRECONDITION_STEPS):
-        step(k)
-    sync()
     for k in range(args.warmup):
         step(k)
     sync()
@@ -727,9 +825,24 @@ def main():
         step(k)
     sync()
     dt = max_over_ranks(time.perf_counter() - t0, world, cdev)
+    kern = read_profiles()          # the dominant kernel's launch times of THIS region (HIP events on the launch stream)
+    # Beside it, reported and never `value`: the same K steps after clock conditioning.  The passes above leave the card nearly
+    # idle, and from there it takes tens of milliseconds of load to reach the clocks it then sustains -- a 20-step region is
+    # 5-6 ms.  Measured on one box, 20 timed steps: 0.280-0.289 ms per step after W = 2 or 10 warm-up steps alone, 0.261-0.269 ms
+    # after 200 more.  So PRECONDITION_STEPS (~80 ms) of the same pipelined steps, W warm-ups again, and K timed steps:
+    # `ms_per_step_conditioned` (rounds 3-4 reported THIS figure as `value`; the driver's --warmup could not see the preamble).
+    for k in range(PRECONDITION_STEPS):
+        step(k)
+    sync()
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    sync()
+    dt_cond = max_over_ranks(time.perf_counter() - t0, world, cdev)
 
-    # ---- dominant kernel's launch times (HIP events on the launch stream, recorded in the timed region)
-    kern = read_profiles()
     # N > 1: the same steps at other gather cadences, short regions after the headline one (a single multi-GPU run then tunes
     # --gather-every; the headline keeps the value it was started with)
     sweep = None
@@ -843,6 +956,9 @@ def main():
             "metric": "frames/s ORB extract+match (640x480, 2000 feat)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_unconditioned": dt / args.steps * 1e3,     # = ms_per_step: the K steps directly behind the W warm-ups
+            "ms_per_step_conditioned": dt_cond / args.steps * 1e3,  # the same K steps after PRECONDITION_STEPS more untimed ones (never `value`)
+            "value_conditioned": total_frames / dt_cond,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "verified": verified,
             "config": {"workload": (f"{world}xMI355X: {world * BATCH}-frame batch sharded {BATCH}/GPU, " if world > 1 else
@@ -853,7 +969,8 @@ def main():
                        "frames": "synth_sequence: each GPU's 64 frames are one camera pan (2, 1) px per frame over its own scene of "
                                  "rectangles and discs + per-frame noise; frame i is matched against frame i+1 mod 64",
                        "frames_per_gpu": BATCH, "global_batch": world * BATCH, "pipeline_contexts": len(ctxs),
-                       "preconditioning_steps": PRECONDITION_STEPS,   # untimed, in front of the W warm-up steps: clock conditioning
+                       "preconditioning_steps": 0,                    # in front of the region `value` is timed on: none since round 5
+                       "preconditioning_steps_of_ms_per_step_conditioned": PRECONDITION_STEPS,
                        "allpairs_kernel": "k_match_sets (popcount)" if args.match_kernel == "popcount" else "k_match_sets_mfma_shared (FP4 matrix cores, train tiles shared through LDS)",
                        "parallelism": (f"frames sharded {BATCH}/rank, results gathered on rank 0 ({GE} steps per "
                                         f"{'gloo' if rehearse else 'RCCL'} gather)") if world > 1 else "single GPU",
@@ -915,18 +1032,20 @@ def main():
                 out["verified"] = bool(verified and fem["verified"])
         if not args.no_fem:
             out["matcher_loops"] = matcher_loops_bench()
+            out["bow_transform"] = bow_bench(torch, dev)
             out["stereo"] = stereo_bench()
             if out["verified"] is not None:
-                out["verified"] = bool(out["verified"] and out["stereo"]["batch"]["verified"])
+                out["verified"] = bool(out["verified"] and out["stereo"]["batch"]["verified"] and out["bow_transform"]["verified"])
         if not args.no_cpu_baseline:
             # (N > 1: rank 0 times the extract + match leg alone -- the others wait at the closing barrier; the FEM / stereo / loop
             # baselines belong to the N = 1 line)
-            legs = ["extract"] + ([] if (args.no_fem or world > 1) else ["fem", "stereo", "loops"])
+            legs = ["extract"] + ([] if (args.no_fem or world > 1) else ["fem", "stereo", "loops", "bow"])
             cb = cpu_baseline_child(legs, fem_csr if os.path.exists(fem_csr) else None)
             out["cpu_baseline"] = cb.get("extract_match", cb)
             if "fem" in cb and fem is not None: out["fem"]["cpu_baseline"] = cb["fem"]
             if "stereo" in cb and "stereo" in out: out["stereo"]["cpu_baseline"] = cb["stereo"]
             if "matcher_loops" in cb and "matcher_loops" in out: out["matcher_loops"]["cpu_baseline"] = cb["matcher_loops"]
+            if "bow_transform" in cb and "bow_transform" in out: out["bow_transform"]["cpu_baseline"] = cb["bow_transform"]
         if os.path.exists(fem_csr):
             os.unlink(fem_csr)
         print(json.dumps(out), flush=True)

@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--runs", type=int, default=512)   # ~11 s of one core at 22 ms per frame (the brief: 10-30 s of CPU work)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--all-cores-frames", type=int, default=16, help="frames per worker in the all-cores pass")
-    ap.add_argument("--legs", default="extract", help="comma list of extract, fem, stereo, loops")
+    ap.add_argument("--legs", default="extract", help="comma list of extract, fem, stereo, loops, bow")
     ap.add_argument("--fem-csr", default=None, help=".npz with rp, col, val, b of the single config-3 mesh (written by bench.py)")
     ap.add_argument("--fem-iters", type=int, default=200)
     args = ap.parse_args()
@@ -93,6 +93,8 @@ def main():
         result["stereo"] = stereo_leg(args)
     if "loops" in legs:
         result["matcher_loops"] = loops_leg(args)
+    if "bow" in legs:
+        result["bow_transform"] = bow_leg(args)
     print(json.dumps(result), flush=True)
 
 
@@ -134,6 +136,23 @@ def stereo_leg(args):
     sm_ms = _median_ms(lambda: oracle.stereo_matches(oL, oR, st["kL"], st["dL"], st["kR"], st["dR"], mb, np.float32(bf)))
     return {"kind": "port", "cores": 1, "unit": "ms per pair", "sample": "the same 1242x375 pair; " + PROTOCOL,
             "stereo_frame_ms": all_ms, "compute_stereo_matches_ms": sm_ms}
+
+
+def bow_leg(args):
+    """The DBoW2 descent of bench.py's bow_transform leg (same synthetic k = 10, L = 6 tree, the first 10 of its 64 descriptor sets:
+    20,000 descents per run) and the distinctive-descriptor call on the same 2000 map points."""
+    import oracle
+    sys.path.insert(0, ROOT)
+    from bench import bow_case, distinctive_case
+    _pin(sorted(os.sched_getaffinity(0))[0])
+    voc, feats = bow_case()
+    f = feats[:10].reshape(-1, 32)
+    ms = _median_ms(lambda: oracle.bow_descend(*voc, f, 4))
+    desc, off = distinctive_case()
+    dms = _median_ms(lambda: oracle.distinctive_descriptors(desc, off))
+    return {"value": len(f) / (ms * 1e-3), "unit": "descriptors/s", "cores": 1, "kind": "port",
+            "sample": f"oracle_bow_transform on {len(f)} descriptors (10 of the leg's 64 sets), the same tree; " + PROTOCOL,
+            "ms_per_2000_descriptors": ms * 2000 / len(f), "distinctive_descriptors_call_ms": dms}
 
 
 def _whole_last_ms(oracle):

@@ -62,6 +62,7 @@ struct Workspace {
     unsigned gen = 0;    // call counter: flags a kernel raises are this number (a fresh arena is zeroed, 0 is never a generation)
     int reserve(size_t dev_bytes, size_t pin_bytes); // discards the contents
     int reserve_entries(size_t n);
+    hipStream_t own_stream() { if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr; return st; }   // nullptr = failed (never hand out the legacy stream)
     size_t carve(size_t bytes) { const size_t o = used; used += (bytes + 255) & ~(size_t)255; return o; }
     template <typename T> T *d(size_t off) const { return reinterpret_cast<T *>(dev + off); }
     template <typename T> T *h(size_t off) const { return reinterpret_cast<T *>(pin + off); }

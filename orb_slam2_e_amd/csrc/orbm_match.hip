@@ -619,41 +619,51 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint4 *__restrict__ de
     if (lane == 0) best[i] = (int)(key & 0xffffu);
 }
 
-// DBoW2 vocabulary-tree descent (TemplatedVocabulary.h:1218-1262): one feature per
-// lane, at every level the Hamming distance to all children of the current node,
-// strict '<' so the first child wins ties; records the node at level L - levelsup
-// (the FeatureVector key) and the leaf's word id.
-__global__ __launch_bounds__(MT) void k_bow_transform(const int *__restrict__ child_off, const int *__restrict__ child_ids,
-                                                      const uint4 *__restrict__ node_desc, const int *__restrict__ node_word,
+// DBoW2 vocabulary-tree descent (TemplatedVocabulary.h:1218-1262): at every level the Hamming distance to all children of
+// the current node, strict '<' so the first child wins ties; records the node at level L - levelsup (the FeatureVector key)
+// and the leaf's word id.
+// The tree is stored by CHILD SLOT, not by node: slot s = the s-th entry of the reference's concatenated children lists, so the
+// children of any node are one contiguous run [c0, c1) of 32-byte descriptors (slot_desc) and of 16-byte records
+// {c0, c1 of the child's own children, node id, word id} (slot_rec).  A level is then ONE memory round trip: every lane asks for
+// its child's descriptor and record together, the row minimum picks the child, the winner's record comes from its lane.  (Indexed
+// by node -- child_off[id] -> child_ids[k] -> node_desc[id], three dependent gathers per level -- the 35-MB tree of ORBvoc
+// (k = 10, L = 6) cost 18 round trips per descriptor instead of 6.)
+__global__ __launch_bounds__(MT) void k_bow_transform(const uint4 *__restrict__ slot_desc, const int4 *__restrict__ slot_rec, int root_c1,
                                                       int nid_level, const uint4 *__restrict__ feat, const int *__restrict__ counts,
                                                       int cap, int n_single, int *__restrict__ word_id, int *__restrict__ node_id)
 {
-    // 16 lanes per feature: at every level the children of the current node are scored 16 at a time, one per lane,
-    // and the group minimum of dist << 16 | position picks the first closest child (strict d < best_d, :1246-1254)
+    // 16 lanes (one DPP row) per feature: the children of the current node are scored 16 at a time, one per lane, and the row
+    // minimum of dist << 16 | position picks the first closest child (strict d < best_d, :1246-1254)
     const int set = blockIdx.y, i = blockIdx.x * (MT / 16) + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     const int n = counts ? min(max(counts[set], 0), cap) : n_single;
     if (i >= n) return;
     const size_t o = (size_t)set * cap + i;
     const uint4 a0 = feat[2 * o], a1 = feat[2 * o + 1];
-    int final_id = 0, level = 0, nid = 0;
+    const int row_base = (int)(threadIdx.x & 63u & ~15u);
+    int c0 = 0, c1 = root_c1, level = 0, nid = 0, word = -1;
     do {
-        const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
         ++level;
         unsigned key = 0xffffffffu;
+        int4 mine = make_int4(0, 0, 0, -1);
         for (int kb = c0; kb < c1; kb += 16) {
             const int k = kb + sub;
             if (k < c1) {
-                const int id = child_ids[k];
-                const unsigned d = (unsigned)popc256(a0, a1, node_desc[2 * id], node_desc[2 * id + 1]);
-                key = min(key, (d << 16) | (unsigned)(k - c0));
+                const int4 r = slot_rec[k];
+                const unsigned d = (unsigned)popc256(a0, a1, slot_desc[2 * (size_t)k], slot_desc[2 * (size_t)k + 1]);
+                const unsigned key2 = (d << 16) | (unsigned)(k - c0);
+                if (key2 < key) { key = key2; mine = r; }
             }
         }
-        key = orbx::row_min_u32(key);
-        final_id = child_ids[c0 + (int)(key & 0xffffu)];
-        if (level == nid_level) nid = final_id;
-    } while (child_off[final_id + 1] > child_off[final_id]);
+        // the winner's position is kb - c0 + sub with kb - c0 a multiple of 16: its lane of the row is position & 15
+        const int src = (row_base + (int)(orbx::row_min_u32(key) & 15u)) << 2;
+        c0 = __builtin_amdgcn_ds_bpermute(src, mine.x);
+        c1 = __builtin_amdgcn_ds_bpermute(src, mine.y);
+        const int id = __builtin_amdgcn_ds_bpermute(src, mine.z);
+        word = __builtin_amdgcn_ds_bpermute(src, mine.w);
+        if (level == nid_level) nid = id;
+    } while (c1 > c0);
     if (sub == 0) {
-        word_id[o] = node_word[final_id];
+        word_id[o] = word;
         node_id[o] = nid;
     }
 }
@@ -841,8 +851,9 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int m,
 
 struct orbm_vocabulary {
     int nnodes = 0, L = 0;
-    int *d_off = nullptr, *d_ids = nullptr, *d_word = nullptr;
-    uint8_t *d_desc = nullptr;
+    int root_c1 = 0;            // the root's children are slots [0, root_c1)
+    uint8_t *d_slot_desc = nullptr;   // [nnodes - 1][32]: descriptor of the node in child slot s (k_bow_transform)
+    int4 *d_slot_rec = nullptr;       // [nnodes - 1]: {c0, c1 (that node's own children), node id, word id}
     std::vector<double> weight; // per word id (host: the BowVector is assembled by the caller)
     std::vector<int> word_of_node;
 };
@@ -876,15 +887,27 @@ int orbm_vocab_create(const int32_t *child_off, const int32_t *child_ids, const 
     ORBX_NEED_DEVICE();
     orbm_vocabulary *v = new orbm_vocabulary();
     v->nnodes = nnodes; v->L = L;
-    if (hipMalloc(&v->d_off, sizeof(int) * (nnodes + 1)) != hipSuccess || hipMalloc(&v->d_ids, sizeof(int) * (nch ? nch : 1)) != hipSuccess ||
-        hipMalloc(&v->d_word, sizeof(int) * nnodes) != hipSuccess || hipMalloc(&v->d_desc, (size_t)32 * nnodes) != hipSuccess) {
-        delete v;
+    v->root_c1 = child_off[1];
+    std::vector<uint8_t> sdesc((size_t)32 * nch);
+    std::vector<int4> srec((size_t)nch);
+    for (int k = 0; k < nch; ++k) {     // slot k holds node child_ids[k]
+        const int id = child_ids[k];
+        memcpy(&sdesc[(size_t)32 * k], node_desc + (size_t)32 * id, 32);
+        srec[k] = make_int4(child_off[id], child_off[id + 1], id, node_word[id]);
+    }
+    if (hipMalloc((void **)&v->d_slot_desc, (size_t)32 * nch) != hipSuccess || hipMalloc((void **)&v->d_slot_rec, sizeof(int4) * (size_t)nch) != hipSuccess) {
+        (void)orbm_vocab_destroy(v);
         ORBX_FAIL(ORBX_ERR_HIP, "hipMalloc failed");
     }
-    ORBX_HIP(hipMemcpy(v->d_off, child_off, sizeof(int) * (nnodes + 1), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(v->d_ids, child_ids, sizeof(int) * nch, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(v->d_word, node_word, sizeof(int) * nnodes, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(v->d_desc, node_desc, (size_t)32 * nnodes, hipMemcpyHostToDevice));
+    {   // on a leased workspace's stream, waited for there (35 + 18 MB for ORBvoc: pageable source, staged by the runtime) -- never
+        // the legacy stream, whose blocking copies wait for every other thread's work and fail while any thread captures a graph
+        orbm_detail::WorkspaceLease lease;
+        const hipStream_t st = lease.w->own_stream();
+        hipError_t e = st ? hipMemcpyAsync(v->d_slot_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice, st) : hipErrorInvalidResourceHandle;
+        if (e == hipSuccess) e = hipMemcpyAsync(v->d_slot_rec, srec.data(), sizeof(int4) * srec.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)orbm_vocab_destroy(v); ORBX_FAIL(ORBX_ERR_HIP, hipGetErrorString(e)); }
+    }
     v->word_of_node.assign(node_word, node_word + nnodes);
     int nwords = 0;
     for (int i = 0; i < nnodes; ++i) nwords = std::max(nwords, node_word[i] + 1);
@@ -898,7 +921,8 @@ int orbm_vocab_create(const int32_t *child_off, const int32_t *child_ids, const 
 int orbm_vocab_destroy(orbm_vocabulary *v)
 {
     if (!v) return ORBX_OK;
-    (void)hipFree(v->d_off); (void)hipFree(v->d_ids); (void)hipFree(v->d_word); (void)hipFree(v->d_desc);
+    if (v->d_slot_desc) (void)hipFree(v->d_slot_desc);
+    if (v->d_slot_rec) (void)hipFree(v->d_slot_rec);
     delete v;
     return ORBX_OK;
 }
@@ -913,8 +937,8 @@ int orbm_bow_transform(orbm_vocabulary *v, const uint8_t *features, int n, int l
     const size_t o_f = sc.in(features, (size_t)32 * n), o_o = sc.out(sizeof(int) * 2 * (size_t)n);
     if (sc.upload()) ORBX_FAIL(ORBX_ERR_HIP, "workspace allocation / upload failed");
     int *ob = sc.d<int>(o_o);
-    hipLaunchKernelGGL(k_bow_transform, dim3((n + MT / 16 - 1) / (MT / 16), 1), dim3(MT), 0, sc.stream(), v->d_off, v->d_ids,
-                       (const uint4 *)v->d_desc, v->d_word, v->L - levelsup, sc.d<const uint4>(o_f), (const int *)nullptr, n, n, ob, ob + n);
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + MT / 16 - 1) / (MT / 16), 1), dim3(MT), 0, sc.stream(), (const uint4 *)v->d_slot_desc,
+                       (const int4 *)v->d_slot_rec, v->root_c1, v->L - levelsup, sc.d<const uint4>(o_f), (const int *)nullptr, n, n, ob, ob + n);
     ORBX_HIP(hipGetLastError());
     if (sc.download()) ORBX_FAIL(ORBX_ERR_HIP, "download failed");
     memcpy(word_id, sc.r<int>(o_o), sizeof(int) * n);
@@ -931,8 +955,8 @@ int orbm_bow_transform_batch_dev(orbm_vocabulary *v, const uint8_t *desc_dev, co
 {
     if (!v || !desc_dev || !counts_dev || cap <= 0 || nsets <= 0 || !word_id_dev || !node_id_dev) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
-    hipLaunchKernelGGL(k_bow_transform, dim3((cap + MT / 16 - 1) / (MT / 16), nsets), dim3(MT), 0, (hipStream_t)stream, v->d_off, v->d_ids,
-                       (const uint4 *)v->d_desc, v->d_word, v->L - levelsup, (const uint4 *)desc_dev, counts_dev, cap, 0,
+    hipLaunchKernelGGL(k_bow_transform, dim3((cap + MT / 16 - 1) / (MT / 16), nsets), dim3(MT), 0, (hipStream_t)stream, (const uint4 *)v->d_slot_desc,
+                       (const int4 *)v->d_slot_rec, v->root_c1, v->L - levelsup, (const uint4 *)desc_dev, counts_dev, cap, 0,
                        word_id_dev, node_id_dev);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

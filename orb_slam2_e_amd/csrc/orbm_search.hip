@@ -2199,7 +2199,13 @@ int orbm_frame_layout(const orbm_frame *f, int32_t *perm, int32_t *cell_off)
 {
     if (!f) ORBX_FAIL(ORBX_ERR_ARG, "null frame");
     if (perm) memcpy(perm, f->perm_host.data(), sizeof(int) * (size_t)f->ns);
-    if (cell_off) ORBX_HIP(hipMemcpy(cell_off, f->cell_off, sizeof(int) * (FB_NC + 1), hipMemcpyDeviceToHost));
+    if (cell_off) {   // (debug accessor; on a leased stream like every other call)
+        WorkspaceLease lease;
+        const hipStream_t st = lease.w->own_stream();
+        if (!st) ORBX_FAIL(ORBX_ERR_HIP, "hipStreamCreate failed");
+        ORBX_HIP(hipMemcpyAsync(cell_off, f->cell_off, sizeof(int) * (FB_NC + 1), hipMemcpyDeviceToHost, st));
+        ORBX_HIP(hipStreamSynchronize(st));
+    }
     return ORBX_OK;
 }
 

@@ -2000,11 +2000,13 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
         if (rc != ORBX_OK) return rc;
     }
 
+    // every fill and upload below runs on the handle's own stream and is waited for there: a blocking copy on the legacy stream
+    // would wait for every other thread's work and fails outright while any thread captures a graph (hipErrorStreamCaptureImplicit)
     const size_t B = (size_t)batch;
     ORBX_HIP(hipMalloc(&ex->d_pyr, ex->frame_bytes * B));
-    ORBX_HIP(hipMemset(ex->d_pyr, 0, ex->frame_bytes * B)); // the row padding outside the 19-px border is never written by k_pyr_resize
+    ORBX_HIP(hipMemsetAsync(ex->d_pyr, 0, ex->frame_bytes * B, ex->stream)); // the row padding outside the 19-px border is never written by k_pyr_resize
     ORBX_HIP(hipMalloc(&ex->d_blur, ex->blur_frame_bytes * B));
-    ORBX_HIP(hipMemset(ex->d_blur, 0, ex->blur_frame_bytes * B));
+    ORBX_HIP(hipMemsetAsync(ex->d_blur, 0, ex->blur_frame_bytes * B, ex->stream));
     ORBX_HIP(hipMalloc(&ex->d_lv, sizeof(LevelInfo) * MAXL));
     {
         int dev = 0, ncu = 0;
@@ -2028,9 +2030,9 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     ORBX_HIP(hipMalloc(&ex->d_sel, sizeof(uint32_t) * ((size_t)ex->sel_per_frame * B + DESC_KPB)));   // k_describe reads whole chunks of 16 slots
     ORBX_HIP(hipMalloc(&ex->d_kps, sizeof(orbx_keypoint) * ex->kcap * B + 16));   // (+ 16: k_result_out reads whole 16-byte pieces)
     ORBX_HIP(hipMalloc(&ex->d_desc, (size_t)32 * ex->kcap * B));
-    ORBX_HIP(hipMemcpy(ex->d_lv, ex->lv, sizeof(LevelInfo) * MAXL, hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(ex->d_cells, ex->cells.data(), sizeof(CellInfo) * ex->cells.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(ex->d_tiles, ex->tiles.data(), sizeof(BlurTile) * ex->tiles.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpyAsync(ex->d_lv, ex->lv, sizeof(LevelInfo) * MAXL, hipMemcpyHostToDevice, ex->stream));
+    ORBX_HIP(hipMemcpyAsync(ex->d_cells, ex->cells.data(), sizeof(CellInfo) * ex->cells.size(), hipMemcpyHostToDevice, ex->stream));
+    ORBX_HIP(hipMemcpyAsync(ex->d_tiles, ex->tiles.data(), sizeof(BlurTile) * ex->tiles.size(), hipMemcpyHostToDevice, ex->stream));
     {
         // Toeplitz fragments of k_blur, per lane (r = lane & 31, h = lane >> 5), byte j of the 16-byte operand:
         // first product: input column 16h + j feeds output column r with tap (16h + j) - r - 1;
@@ -2044,10 +2046,12 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
                 fr[lane][1][j] = (uint8_t)(d2 >= 0 && d2 < 7 ? T[d2] : 0);
             }
         ORBX_HIP(hipMalloc(&ex->d_blur_frag, sizeof(fr)));
-        ORBX_HIP(hipMemcpy(ex->d_blur_frag, fr, sizeof(fr), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpyAsync(ex->d_blur_frag, fr, sizeof(fr), hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipStreamSynchronize(ex->stream));   // fr lives in this scope
     }
-    if (!xt.empty()) ORBX_HIP(hipMemcpy(ex->d_xt, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
-    if (!yt.empty()) ORBX_HIP(hipMemcpy(ex->d_yt, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
+    if (!xt.empty()) ORBX_HIP(hipMemcpyAsync(ex->d_xt, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice, ex->stream));
+    if (!yt.empty()) ORBX_HIP(hipMemcpyAsync(ex->d_yt, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
     if (ex->oct_lds > 48 * 1024)
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, ex->oct_lds));
@@ -2229,7 +2233,11 @@ int orbx_debug_phases(unsigned long long *out, int reset)   // out: 2 x 65536 x 
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_rec), sizeof(unsigned long long) * 4 * 65536 * 16) != hipSuccess) return -1;
     if (reset) {
         void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 4 * 65536 * 16) != hipSuccess) return -1;
+        hipStream_t st = nullptr;   // (a stream of its own: nothing in this library touches the legacy stream)
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_rec)) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1;
+        const bool ok = hipMemsetAsync(p, 0, sizeof(unsigned long long) * 4 * 65536 * 16, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        (void)hipStreamDestroy(st);
+        if (!ok) return -1;
     }
     return 0;
 }

@@ -326,7 +326,8 @@ int orbx_stereo_match(orbx_extractor *left, orbx_extractor *right, float mb, flo
         ORBX_HIP(hipMalloc(&left->d_st_scale, sizeof(float) * 2 * MAXL));
         float sc[2 * MAXL];
         for (int i = 0; i < MAXL; ++i) { sc[i] = left->scale[i]; sc[MAXL + i] = left->inv_scale[i]; }
-        ORBX_HIP(hipMemcpy(left->d_st_scale, sc, sizeof(sc), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpyAsync(left->d_st_scale, sc, sizeof(sc), hipMemcpyHostToDevice, st));   // on the call's stream, never the legacy one
+        ORBX_HIP(hipStreamSynchronize(st));   // sc lives in this scope
         left->st_batch = left->batch;
     }
     // streams: the results of both extractors must be complete before the matching starts -- ordered on the device (an event

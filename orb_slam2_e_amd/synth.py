@@ -276,6 +276,46 @@ def synth_bow_case(seed, n1=2000, n2=2100, nnodes=90):
     return d1, a1, node1, keep1, valid1, d2, a2, node2, keep2, valid2
 
 
+def synth_vocabulary(k=10, L=6, seed=0, nstop=50, nties=64):
+    """A complete k-ary DBoW2 vocabulary tree of L levels in the shape of ORBvoc (k = 10, L = 6: 1,111,111 nodes, 10^6 words,
+    35 MB of node descriptors; the real file is missing from the reference mount, Vocabulary/ORBvoc.txt.tar.gz), nodes numbered
+    breadth-first as DBoW2 creates them (TemplatedVocabulary.h:560-640, HKmeansStep): the children of node g are g k + 1 .. g k + k.
+    A child is its parent with every bit flipped with probability 2^-min(depth, 5), so that the descent of a noisy leaf descriptor
+    is decided by a few bits at the deep levels; `nties` nodes get a sibling's descriptor (the first minimum must win,
+    TemplatedVocabulary.h:1240-1250), `nstop` words weight 0 (stop words).  Returns the flat arrays of orbm_vocab_create /
+    ORBVocabulary: (child_off, child_ids, node_desc, node_word, node_weight, L)."""
+    rng = np.random.default_rng(seed)
+    level_n = [k ** d for d in range(L + 1)]
+    n = sum(level_n); nint = n - level_n[L]
+    desc = np.empty((n, 32), np.uint8)
+    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    first = 0
+    for d in range(1, L + 1):
+        pf, cf, cn = first, first + level_n[d - 1], level_n[d]
+        flips = rng.integers(0, 256, (cn, 32), dtype=np.uint8)
+        for _ in range(min(d, 5) - 1):
+            flips &= rng.integers(0, 256, (cn, 32), dtype=np.uint8)
+        desc[cf:cf + cn] = np.repeat(desc[pf:cf], k, axis=0) ^ flips
+        first = cf
+    if nties and k > 3:
+        g = rng.choice(np.arange(nint), min(nties, nint), replace=False)      # parents whose child 3 repeats child 1
+        desc[g * k + 4] = desc[g * k + 2]
+    child_off = np.minimum(np.arange(n + 1, dtype=np.int64), nint) * k
+    child_ids = np.arange(1, n, dtype=np.int32)
+    word = np.full(n, -1, np.int32); word[nint:] = np.arange(level_n[L], dtype=np.int32)
+    weight = np.zeros(n, np.float64); weight[nint:] = rng.uniform(0.5, 8.0, level_n[L])
+    if nstop:
+        weight[nint + rng.choice(level_n[L], min(nstop, level_n[L]), replace=False)] = 0.0
+    return child_off.astype(np.int32), child_ids, desc, word, weight, L
+
+
+def synth_vocabulary_features(voc, n, seed=1, flip_p=0.04):
+    """n descriptors near random words of a synth_vocabulary tree (leaf descriptor with bits flipped with probability flip_p)."""
+    rng = np.random.default_rng(seed)
+    leaves = np.nonzero(voc[3] >= 0)[0]
+    return voc[2][rng.choice(leaves, n)] ^ np.packbits(rng.random((n, 256)) < flip_p, axis=1, bitorder="little")
+
+
 # ---- scenes for the projection searches as whole functions (ORBmatcher.cc:491-604, :1303-1527, :1529-1800) ----------
 
 SCENE_CAM = dict(fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, mbf=40.0)   # TUM1-like pinhole, 640 x 480

@@ -89,13 +89,15 @@ def save_vocabulary_text(path, child_off, child_ids, node_desc, node_word, node_
     """Writer in the layout of TemplatedVocabulary::saveToTextFile (:1425-1450), for tests: nodes must be numbered so
     that every parent precedes its children (breadth-first ids as DBoW2 creates them)."""
     n = len(node_word)
+    child_off = np.asarray(child_off); child_ids = np.asarray(child_ids)
     parent = np.zeros(n, np.int64)
-    for i in range(n):
-        parent[child_ids[child_off[i]:child_off[i + 1]]] = i
+    parent[child_ids] = np.repeat(np.arange(n), np.diff(child_off))
+    rows = np.empty((n - 1, 35), np.float64)
+    rows[:, 0] = parent[1:]; rows[:, 1] = np.asarray(node_word)[1:] >= 0
+    rows[:, 2:34] = np.asarray(node_desc)[1:]; rows[:, 34] = np.asarray(node_weight)[1:]
     with open(path, "w") as f:
         f.write(f"{k} {L}  {scoring} {weighting}\n")
-        for i in range(1, n):
-            f.write(f"{parent[i]} {1 if node_word[i] >= 0 else 0} " + " ".join(str(int(b)) for b in node_desc[i]) + f" {float(node_weight[i])!r}\n")
+        np.savetxt(f, rows, fmt=["%d"] * 34 + ["%.17g"])      # (%.17g round-trips a double; 13 s for ORBvoc's 1.1 M lines)
 
 
 def assemble_bow(word, node, w, scoring=0, weighting=0):

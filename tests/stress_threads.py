@@ -54,9 +54,8 @@ def make_jobs(k):
         eL(left); eR(right)
         return ComputeStereoMatches(eL, eR, mb, np.float32(386.1448))
 
-    pL, pR = ORBextractor(*P), ORBextractor(*P)
-    extract_pair(pL, pR, left, right); extract_pair(pL, pR, left, right)   # the second pair of a size captures its hipGraph: before the
-                                                                           # threads start, replays only from here on
+    pL, pR = ORBextractor(*P), ORBextractor(*P)      # first pair = workspace build, second = hipGraph capture, then replays: ALL of it
+                                                     # inside the threads (nothing is captured before they start)
 
     def pair():
         return extract_pair(pL, pR, left, right)
@@ -74,7 +73,7 @@ def make_jobs(k):
         fea = FEA2(tn, tt, FEM_TET4); fea.MatrixAssembly(); fea.eliminate_dofs(tfixed)
         fea.cg_preconditioner("two_level")
         x = fea.solve_cg(tb[None], iters=40)
-        fea.cg_setup(tb[None]); fea.cg_iterate(50)          # the captured graph of the launch-per-phase path, under other threads' copies
+        fea.cg_setup(tb[None]); fea.cg_iterate(50)          # the launch-per-phase path, under other threads' copies
         return x + fea.cg_result()
 
     return [("extract", lambda: ex(img)), ("stereo", stereo),
@@ -86,6 +85,78 @@ def make_jobs(k):
             ("fem LM trial", fem_lm), ("fem CG", fem_cg), ("fem CG two-level", fem_cg_two_level), ("pair", pair)]
 
 
+def collision_jobs():
+    """The collision the round-4 run found: while ONE thread captures a hipGraph (the second orbx_extract_pair of a frame size), a
+    blocking copy on the legacy stream from any other thread fails (hipErrorStreamCaptureImplicit) and kills the capture.  Every
+    one-time set-up of the library that used to make such copies runs here on other threads WHILE thread 0 captures over and over
+    (fresh handles each time: build, capture, replay): first-frame workspace builds, vocabulary uploads, first stereo calls, frame
+    layouts.  Each job returns a comparable result; any error return raises in the Python mirror."""
+    from orb_slam2_e_amd.matcher import Frame
+    from orb_slam2_e_amd.vocabulary import ORBVocabulary
+    from orb_slam2_e_amd.synth import synth_vocabulary
+    sizes = [(320, 240), (400, 296), (352, 288), (480, 272)]
+    imgs = {wh: (synth_frame(7, *wh), synth_frame(8, *wh)) for wh in sizes}
+    voc = synth_vocabulary(10, 3, seed=3)
+    feats = np.random.default_rng(5).integers(0, 256, (500, 32), dtype=np.uint8)
+    mb = np.float32(386.1448) / np.float32(718.856)
+    tick = [0, 0, 0, 0]
+
+    def nxt(i):
+        tick[i] += 1
+        return sizes[tick[i] % len(sizes)]
+
+    def capture():                                    # build + capture + replay on fresh handles
+        wh = nxt(0); a, b = ORBextractor(*P), ORBextractor(*P)
+        r = [extract_pair(a, b, *imgs[wh]) for _ in range(3)]
+        assert eq(r[0], r[1]) and eq(r[1], r[2]), "captured chain differs from the plain one"
+        return (wh, r[2])
+
+    def first_frame():                                # orbx_reserve: allocations, fills, table uploads
+        wh = nxt(1)
+        return (wh, ORBextractor(*P)(imgs[wh][0]))
+
+    def vocab():                                      # orbm_vocab_create's uploads + a descent
+        v = ORBVocabulary(*voc)
+        return v.descend(feats, 1)
+
+    def first_stereo():                               # orbx_stereo_match's first call on fresh handles + a frame's layout download
+        wh = nxt(2); a, b = ORBextractor(*P), ORBextractor(*P)
+        kl, dl = a(imgs[wh][0]); b(imgs[wh][1])
+        u, d = ComputeStereoMatches(a, b, mb, np.float32(386.1448))
+        f = Frame(kl, dl, bounds=(0.0, 0.0, float(wh[0]), float(wh[1])))
+        return (wh, u, d, f.layout())
+
+    return [capture, first_frame, vocab, first_stereo]
+
+
+def run_collision(seconds):
+    cj = collision_jobs()
+    ref = [{} for _ in cj]
+    for i, f in enumerate(cj):                        # single-threaded results per size
+        for _ in range(4):
+            r = f()
+            ref[i][repr(r[0]) if i != 2 else "v"] = r
+    errs, cnt = [], [0] * len(cj)
+    end = time.time() + seconds
+
+    def work(i):
+        try:
+            while time.time() < end:
+                r = cj[i]()
+                if not eq(r, ref[i][repr(r[0]) if i != 2 else "v"]):
+                    errs.append((i, "result differs from the single-threaded call")); return
+                cnt[i] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(cj))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    print("collision phase: captures", cnt[0], "first frames", cnt[1], "vocabulary uploads", cnt[2], "first stereo calls", cnt[3], "errors", errs[:5])
+    return errs
+
+
+collision_errors = run_collision(min(seconds, 4.0))
 jobs = [make_jobs(k) for k in range(nthreads)]
 want = [[f() for _, f in js] for js in jobs]           # single-threaded reference results
 errors, counts = [], [0] * nthreads
@@ -110,4 +181,4 @@ threads = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
 for t in threads: t.start()
 for t in threads: t.join()
 print("threads", nthreads, "seconds", seconds, "calls per thread", counts, "errors", errors[:5])
-sys.exit(1 if errors else 0)
+sys.exit(1 if errors or collision_errors else 0)

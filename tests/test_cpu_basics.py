@@ -418,3 +418,45 @@ def test_array_pointer_helper_and_kernel_switch():
     assert ORBmatcher.set_allpairs_kernel(ORBmatcher.ALLPAIRS_POPCOUNT) == ORBmatcher.ALLPAIRS_MFMA
     assert L.orbm_set_allpairs_kernel(7) < 0                              # unknown kind: refused, setting unchanged
     assert ORBmatcher.set_allpairs_kernel(prev) == ORBmatcher.ALLPAIRS_POPCOUNT
+
+
+def test_synthetic_vocabulary_in_orbvoc_shape_and_the_oracle_descent(tmp_path):
+    """orb_slam2_e_amd.synth.synth_vocabulary: a complete k-ary tree numbered breadth-first, as the bow_transform bench leg and the
+    GPU test use it at k = 10, L = 6.  Here at k = 10, L = 3: structure, the text round trip (vectorised writer), and the oracle's
+    descent (TemplatedVocabulary.h:1218-1262) against a literal Python walk -- a node's own descriptor reaches that node unless an
+    equal earlier sibling takes the tie."""
+    from orb_slam2_e_amd.synth import synth_vocabulary, synth_vocabulary_features
+    from orb_slam2_e_amd.vocabulary import load_vocabulary_text, save_vocabulary_text
+    k, L = 10, 3
+    off, ids, desc, word, weight, L_ = voc = synth_vocabulary(k, L, seed=2, nstop=7, nties=5)
+    n = 1 + 10 + 100 + 1000
+    assert L_ == L and len(word) == n and off[-1] == n - 1 and np.array_equal(ids, np.arange(1, n))
+    assert (word[:111] == -1).all() and np.array_equal(word[111:], np.arange(1000)) and (weight[111:] == 0).sum() == 7
+    assert all(np.array_equal(ids[off[g]:off[g + 1]], np.arange(g * k + 1, g * k + k + 1)) for g in range(111))
+    assert (np.diff(off)[111:] == 0).all()
+    path = str(tmp_path / "v.txt")
+    save_vocabulary_text(path, off, ids, desc, word, weight, k, L)
+    arrays, (k2, sc, wt) = load_vocabulary_text(path)
+    assert k2 == k and arrays[5] == L and (sc, wt) == (0, 0)
+    for a, b in zip(arrays[:2] + arrays[3:5], (off, ids, word, weight)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(arrays[2][1:], desc[1:])
+    feats = synth_vocabulary_features(voc, 300, seed=4)
+    feats[:50] = desc[np.random.default_rng(0).integers(111, n, 50)]      # exact leaf descriptors
+    feats[:5] = desc[np.nonzero((desc[2:-2] == desc[4:]).all(1))[0][:5] + 4]  # ... of nodes that repeat an earlier sibling
+    w_, nid_, wt_ = oracle.bow_descend(*voc, feats, 1)
+
+    def walk(f, nid_level):
+        node, lvl, nid = 0, 0, 0
+        while off[node + 1] > off[node]:
+            ch = ids[off[node]:off[node + 1]]
+            d = [oracle.descriptor_distance(f, desc[c]) for c in ch]
+            node = int(ch[int(np.argmin(d))])          # np.argmin: first minimum
+            lvl += 1
+            if lvl == nid_level:
+                nid = node
+        return word[node], nid, weight[node]
+    for i in range(0, 300, 7):
+        assert (w_[i], nid_[i], wt_[i]) == walk(feats[i], L - 1)
+    for i in range(50):                                 # exact leaf descriptors (ties at distance 0 between equal siblings included)
+        assert (w_[i], nid_[i], wt_[i]) == walk(feats[i], L - 1)

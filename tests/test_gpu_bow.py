@@ -135,3 +135,47 @@ def test_bow_batch_on_resident_descriptor_sets(levelsup):
         rw, rn, _ = oracle.bow_descend(off, ids, desc, word, weight, L, sets[s_, :cnt], levelsup)
         assert np.array_equal(w[s_, :cnt], rw) and np.array_equal(n[s_, :cnt], rn), f"set {s_}"
         assert (w[s_, cnt:] == -9).all() and (n[s_, cnt:] == -9).all()
+
+
+def test_bow_descent_orbvoc_shape(tmp_path):
+    """The reference's real vocabulary shape -- k = 10, L = 6: 1,111,111 nodes, 35.6 MB of node descriptors (Vocabulary/ORBvoc.txt
+    is missing from the reference mount) -- written in DBoW2's text layout, read back by the loader (TemplatedVocabulary.h:1338-1420),
+    and 64 x 2000 descriptors descended with levelsup = 4 (Frame.cc:415): host-array call and the resident batch form, word and
+    node ids bit-equal to the oracle; ties between equal siblings go to the first (:1246-1254)."""
+    import torch
+    from orb_slam2_e_amd.synth import synth_vocabulary, synth_vocabulary_features
+    voc = synth_vocabulary(10, 6, seed=0)
+    path = str(tmp_path / "ORBvoc_synth.txt")
+    save_vocabulary_text(path, *voc[:5], 10, 6)
+    v = ORBVocabulary.loadFromTextFile(path)
+    assert v.m_k == 10 and v.m_L == 6 and len(v.node_word) == 1111111 and int((v.node_word >= 0).sum()) == 10 ** 6
+    for a, b in zip((v.child_off, v.child_ids, v.node_word, v.node_weight), (voc[0], voc[1], voc[3], voc[4])):
+        assert np.array_equal(a, b)
+    assert np.array_equal(v.node_desc[1:], voc[2][1:])            # (the root has no line and no descriptor)
+    B, N = 64, 2000
+    feats = synth_vocabulary_features(voc, B * N, seed=1).reshape(B, N, 32)
+    # a few features that sit exactly between two equal siblings: copies of tied nodes
+    tied = np.nonzero((voc[2][2:-2] == voc[2][4:]).all(1))[0] + 2
+    assert len(tied) >= 32
+    feats[0, :32] = voc[2][tied[:32]]
+    ref = oracle.bow_descend(*voc, feats.reshape(-1, 32), 4)
+    assert len(np.unique(ref[1])) > 90 and len(np.unique(ref[0])) > 50000 and (ref[2] == 0).sum() > 0
+    got = v.descend(feats[3], 4)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r[3 * N:4 * N])
+    d_f = torch.from_numpy(feats).cuda()
+    cnt = np.full(B, N, np.int32); cnt[5] = 1234; cnt[9] = 0
+    d_c = torch.from_numpy(cnt).cuda()
+    d_w = torch.full((B, N), -7, dtype=torch.int32, device="cuda"); d_n = torch.full_like(d_w, -7)
+    s = torch.cuda.Stream()
+    v.descend_batch_device(d_f.data_ptr(), d_c.data_ptr(), N, B, 4, d_w.data_ptr(), d_n.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    w, nid = d_w.cpu().numpy(), d_n.cpu().numpy()
+    rw, rn = ref[0].reshape(B, N), ref[1].reshape(B, N)
+    for b in range(B):
+        assert np.array_equal(w[b, :cnt[b]], rw[b, :cnt[b]]) and np.array_equal(nid[b, :cnt[b]], rn[b, :cnt[b]])
+        assert (w[b, cnt[b]:] == -7).all() and (nid[b, cnt[b]:] == -7).all()      # rows past a set's count are not written
+    for lu in (0, 2, 6, 7):                                                        # other levels of the FeatureVector key
+        g = v.descend(feats[1, :500], lu)
+        r = oracle.bow_descend(*voc, feats[1, :500], lu)
+        assert all(np.array_equal(x, y) for x, y in zip(g, r))
