@@ -225,6 +225,9 @@ def fem_bench(rank, world, dist, torch, dev, cdev, nmesh=256, iters=200, csr_out
                 sms = sp[0] / sp[1]
                 out[label]["spmv_alone"] = {"kernel": "k_fem_spmv", "launch_ms": sms, "block_form_bytes_per_launch": block_bytes,
                                             "GBps": block_bytes / (sms * 1e-3) / 1e9, "frac_of_8000": block_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                trs = load_fem_traffic().get(label, {}).get("k_fem_spmv") if nmesh == 256 else None    # the PMC passes ran the 256-mesh batches
+                if trs:
+                    out[label]["spmv_alone"].update({"traffic": trs["hbm_bytes_per_launch"], "traffic_source": trs["source"]})
             fea.profile(0)
         # the checker, outside the timed region, on every rank: the iterate the TIMED launches left (the single mesh; the first,
         # the largest and the last mesh of each batch -- the batches' 200 iterations ran in k_fem_cg_resident) against the

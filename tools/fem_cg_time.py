@@ -23,3 +23,7 @@ fea.profile(True); fea.cg_setup(b); fea.cg_iterate(iters); fea.cg_result()
 for k, v in fea.profile_read().items():
     if v[1]:
         print(f"  {k}: {v[0] / v[1]:.4f} ms x {v[1]}")
+# k_fem_spmv by itself on the same resident matrix and vectors, as bench.py's `spmv_alone` (50 launches): the kernel north_star names
+fea.profile(4); fea.spmv_repeat(50); fea.cg_result()
+v = fea.profile_read()["k_fem_spmv"]
+print(f"  k_fem_spmv alone: {v[0] / max(v[1], 1):.4f} ms x {v[1]}")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Convert a few of the reference's committed surface meshes
 (output/PointClouds/pcr_t_f*.vtk: POINTS n float + POLYGONS m 4m) into small
-input fixtures for the C3D6 FEM parity tests.  These are data files of the
+input fixtures for the C3D6 FEM parity tests: four picked by size (fem_mesh_*.npz) and all 853 in one file (fem_meshes_all.npz).  These are data files of the
 reference (inputs only -- nothing in the reference tree records results for them,
 SURVEY 8c).  Run in the dev container; output: tests/golden/fem_mesh_*.npz."""
 import glob
@@ -41,3 +41,15 @@ for name, idx in targets.items():
     np.savez_compressed(os.path.join(OUT, f"fem_mesh_{name}.npz"), points=pts, triangles=tris,
                         source=os.path.basename(files[idx]))
     print(name, os.path.basename(files[idx]), pts.shape, tris.shape)
+
+# ... and ALL of them in one file (round 5): concatenated points / triangles with offsets, the frame number of each file name
+pts_l, tri_l, frame = [], [], []
+for f in files:
+    p_, t_ = read_vtk(f)
+    pts_l.append(p_); tri_l.append(t_)
+    frame.append(int(os.path.basename(f)[len("pcr_t_f"):-len(".vtk")]))
+pt_off = np.concatenate([[0], np.cumsum([len(p_) for p_ in pts_l])]).astype(np.int32)
+tri_off = np.concatenate([[0], np.cumsum([len(t_) for t_ in tri_l])]).astype(np.int32)
+np.savez_compressed(os.path.join(OUT, "fem_meshes_all.npz"), points=np.concatenate(pts_l), triangles=np.concatenate(tri_l),
+                    pt_off=pt_off, tri_off=tri_off, frame=np.array(frame, np.int32))
+print("all:", len(files), "meshes,", pt_off[-1], "points,", tri_off[-1], "triangles")
