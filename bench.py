@@ -350,6 +350,40 @@ def fem_compute1_bench():
     return out
 
 
+def fem_compute1_all_meshes(trials=40):
+    """The FEM side of one Optimizer::PoseOptimizationNR call on EVERY surface mesh the reference tree holds (853 dumps under
+    output/PointClouds, tests/golden/fem_meshes_all.npz; degenerate triangles removed), one call per mesh, cold: FEA2::Compute(1)'s
+    numeric half (create, assemble, Dirichlet penalty, hook set-up) + the 4 x 10 Levenberg trials' energy evaluations
+    (levenberg.cpp:159-199).  BASELINE.md's `timeD` medians (27-160 ms per file) time the reference's whole call INCLUDING its PCL
+    meshing (MLS + greedy triangulation, FEA2.cc:205-438), which is out of scope here: context, not a like-for-like baseline."""
+    from orb_slam2_e_amd.fem import FEA2, FEM_C3D6, extrude_elems, second_layer
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "fem_meshes_all.npz")))
+    c1, tr, npts = [], [], []
+    for k in range(len(z["frame"])):
+        top = z["points"][z["pt_off"][k]:z["pt_off"][k + 1]]; tris = z["triangles"][z["tri_off"][k]:z["tri_off"][k + 1]]
+        p = top[tris]
+        tris = tris[~((p[:, 0] == p[:, 1]).all(1) | (p[:, 0] == p[:, 2]).all(1) | (p[:, 1] == p[:, 2]).all(1))]
+        if not len(tris):
+            continue
+        nodes = second_layer(top, 0.5); elems = extrude_elems(tris, len(top))
+        ids = np.arange(len(top), 2 * len(top), dtype=np.int32)
+        u0 = nodes.ravel(); pts = top.astype(np.float64) + 0.003
+        t0 = time.perf_counter()
+        fea = FEA2(nodes, elems, FEM_C3D6); fea.MatrixAssembly(); fea.ImposeDirichletEncastre_K(ids); fea.trial_setup(u0, ids, len(top), None)
+        t1 = time.perf_counter()
+        for _ in range(trials):
+            fea.trial_energy(pts, want_a=False)
+        t2 = time.perf_counter()
+        c1.append((t1 - t0) * 1e3); tr.append((t2 - t1) * 1e3); npts.append(len(top))
+        del fea
+    c1, tr = np.array(c1), np.array(tr)
+    tot = c1 + tr
+    q = lambda a: {"median": float(np.median(a)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
+    return {"meshes": len(c1), "points_median": int(np.median(npts)), "points_max": int(max(npts)), "lm_trials_per_mesh": trials,
+            "compute1_ms": q(c1), "lm_trials_ms": q(tr), "fem_side_of_one_call_ms": q(tot), "all_meshes_s": float(tot.sum() * 1e-3),
+            "reference_timeD_ms_medians": "27.3 - 159.1 per log file (BASELINE.md 2): the reference's WHOLE PoseOptimizationNR incl. PCL meshing + g2o, hardware unstated -- context only"}
+
+
 def _newest_profile(suffix):
     """profiles/rNN_<suffix> of the highest round number present (the passes are re-made on every round's final library)."""
     import glob
@@ -944,6 +978,7 @@ def main():
         fem = fem_bench(rank, world, dist, torch, dev, cdev, nmesh=args.fem_meshes, csr_out=fem_csr)
         if rank == 0:
             fem["compute1_per_frame"] = fem_compute1_bench()
+            fem["compute1_all_reference_meshes"] = fem_compute1_all_meshes()
 
     if rank == 0:
         total_frames = world * BATCH * args.steps

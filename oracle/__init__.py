@@ -779,6 +779,32 @@ def pose_optimization_nr_fem_sequence(K, u0, ids, derived, script, Klarge=100000
     return trials, results
 
 
+LM_TRIAL_DTYPE = np.dtype([("sE", "<f4"), ("nsE", "<f4"), ("tempChi", "<f8"), ("currentChi", "<f8"), ("rho", "<f8"), ("lam", "<f8"),
+                           ("qmax", "<i4"), ("acc", "<i4")], align=True)
+
+
+def pose_optimization_nr(scene, K, u0, ids, derived=None, Klarge=100000000.0):
+    """oracle_pose_optimization_nr (oracle/pose_nr_oracle.c): Optimizer::PoseOptimizationNR's four rounds of optimize(10) as a
+    closed loop on the mini-g2o graph `scene` (tests/pose_nr_scene.py) with the oracle's FEM hook.  K: dense matrix after
+    ImposeDirichletEncastre_K.  Returns (trials[LM_TRIAL_DTYPE], results, R, t, X, inliers, outlier flags)."""
+    L = lib()
+    der = np.ascontiguousarray(derived if derived is not None else np.zeros((0, 4)), np.int32).reshape(-1, 4)
+    K = np.ascontiguousarray(K, np.float32); u0 = np.ascontiguousarray(u0, np.float32); ids = np.ascontiguousarray(ids, np.int32)
+    npts, nkf, ne = len(scene["X0"]), len(scene["kfR"]), len(scene["e_pt"])
+    assert LM_TRIAL_DTYPE.itemsize == 48
+    trials = np.zeros(400, LM_TRIAL_DTYPE); results = np.zeros(40, np.int32); nres = C.c_int(0)
+    R = np.zeros(9); t = np.zeros(3); X = np.zeros((npts, 3)); inl = C.c_int(0); out = np.zeros(npts, np.uint8)
+    L.oracle_pose_optimization_nr.argtypes = [C.c_int] * 3 + [C.c_void_p] * 11 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int, C.c_void_p, C.c_int,
+                                             C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    L.oracle_pose_optimization_nr.restype = C.c_int
+    nt = L.oracle_pose_optimization_nr(npts, nkf, ne, _p(scene["R0"]), _p(scene["t0"]), _p(scene["kfR"]), _p(scene["kft"]), _p(scene["X0"]),
+                                       _p(scene["e_pt"]), _p(scene["e_cam"]), _p(scene["e_obs"]), _p(scene["e_info"]), _p(scene["e_K"]),
+                                       _p(K), len(K), _p(u0), _p(ids), len(ids), _p(der), len(der), Klarge, _p(trials), len(trials),
+                                       _p(results), len(results), C.byref(nres), _p(R), _p(t), _p(X), C.byref(inl), _p(out))
+    assert nt >= 0, "trial log overflow"
+    return trials[:nt].copy(), results[:nres.value].copy(), R.reshape(3, 3), t, X, inl.value, out
+
+
 # ---- the four projection searches as whole functions (projection prefix included) ---------------------------------
 
 def _frame_arrays(kps, desc):

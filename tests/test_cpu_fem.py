@@ -167,3 +167,60 @@ def test_all_reference_meshes_fixture_matches_baseline_md():
         assert not (bad & ~degenerate).any()        # a triangle with three distinct points has a finite K_e; a degenerate one has a
         nan_meshes += bool(bad.any())               # zero Jacobian up to rounding: NaN (0 / 0) in most, entries of ~1e12 in a few
     assert nan_meshes > 3
+
+
+def _nr_case(name, **kw):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pose_nr_scene import make_scene
+    from orb_slam2_e_amd.fem import extrude_elems
+    m = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fem_mesh_{name}.npz"))
+    top, tris = m["points"], m["triangles"]
+    p = top[tris]
+    tris = tris[~((p[:, 0] == p[:, 1]).all(1) | (p[:, 0] == p[:, 2]).all(1) | (p[:, 1] == p[:, 2]).all(1))]
+    nodes = oracle.fem_second_layer(top, 0.5); elems = extrude_elems(tris, len(top))
+    ids = np.arange(len(top), 2 * len(top), dtype=np.int32)
+    return top, tris, nodes, elems, ids, make_scene(top, **kw)
+
+
+def test_pose_optimization_nr_oracle_without_fem_term_is_plain_levenberg():
+    """The closed-loop F12 oracle (oracle/pose_nr_oracle.c on the mini-g2o graph of oracle/mini_g2o.h) with K = 0: the hook adds
+    nothing, what remains is g2o's Levenberg on reprojection edges (levenberg.cpp:63-241) -- on a scene without deformation, noise
+    or outliers it must drive chi2 to ~0, recover the frame's pose, accept (nearly) every trial, keep every point an inlier."""
+    top, tris, nodes, elems, ids, sc = _nr_case("median", seed=3, deform=0.0, noise_px=0.0, outlier_frac=0.0, pose_err=(0.01, 0.02))
+    K0 = np.zeros((6 * len(top), 6 * len(top)), np.float32)
+    tr, res, R, t, X, inl, out = oracle.pose_optimization_nr(sc, K0, nodes.ravel(), ids)
+    assert (tr["nsE"] == 0).all() and inl == len(top) and not out.any()
+    acc = tr[tr["acc"] == 1]
+    assert len(acc) >= 4 and (np.diff(acc["currentChi"]) <= 1e-9).all()          # accepted steps never increase chi2
+    assert acc["currentChi"][0] > 0.1 and acc["currentChi"][-1] < 1e-12 * acc["currentChi"][0]
+    assert np.abs(R - sc["Rf"]).max() < 1e-9 and np.abs(t - sc["tf"]).max() < 1e-8 and np.abs(sc["R0"] - sc["Rf"]).max() > 1e-3
+    assert (tr["acc"] == 1).all() and (res == 1).all() and len(res) == 40    # 4 x 10 iterations, one accepted trial each
+    lam = tr["lam"]
+    assert ((lam[1:] / lam[:-1] >= 1 / 3 - 1e-12) & (lam[1:] / lam[:-1] <= 2 / 3 + 1e-12))[np.arange(1, 40) % 10 != 0].all()   # :207-214
+
+
+def test_pose_optimization_nr_oracle_closed_loop_with_the_fem_hook():
+    """... and with the reference's K (prism model of the same mesh, Dirichlet penalty): the hook's energies enter tempChi with
+    w = 2 on the first trial of an iteration and 5 on the retries, `currentChi += nsE` on the first (levenberg.cpp:184-198);
+    trials are rejected and retried with lambda x 2, 4, 8 ..; an iteration that exhausts 10 trials returns Terminate and ends its
+    round (sparse_optimizer.cpp:453-470); gross outliers are classified (Optimizer.cc:752-790)."""
+    top, tris, nodes, elems, ids, sc = _nr_case("median", seed=1, deform=0.003, noise_px=0.5, pose_err=(0.005, 0.01))
+    K = oracle.fem_dirichlet_K(oracle.fem_assemble_dense(2, nodes, elems), ids)
+    tr, res, R, t, X, inl, out = oracle.pose_optimization_nr(sc, K, nodes.ravel(), ids)
+    assert 20 < len(tr) <= 400 and 0 < tr["acc"].sum() < len(tr) and tr["qmax"].max() == 9 and set(res.tolist()) == {1, 2}
+    assert (tr["nsE"] > 0).all() and out.sum() >= 1
+    first = tr["qmax"] == 0
+    # tempChi - (reprojection chi2) = w nsE: on a first trial currentChi was raised by nsE before the comparison
+    rej = tr[(tr["acc"] == 0)]
+    assert (rej["rho"] <= 0).all() and (tr[tr["acc"] == 1]["rho"] > 0).all()
+    for k in range(1, len(tr)):
+        if tr["qmax"][k] > 0:                                                    # a retry: lambda of the rejected trial x its ni
+            assert tr["acc"][k - 1] == 0
+            if not tr["acc"][k]:
+                assert tr["lam"][k] == tr["lam"][k - 1] * 2.0 ** (tr["qmax"][k] + 1)
+    assert first.sum() == len(res)                                               # one first trial per Levenberg iteration
+    # deterministic
+    tr2 = oracle.pose_optimization_nr(sc, K, nodes.ravel(), ids)[0]
+    assert tr.tobytes() == tr2.tobytes()

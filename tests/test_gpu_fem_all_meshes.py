@@ -59,7 +59,7 @@ def test_all_853_raw_meshes_one_batch_nan_pattern_and_bits():
 
 def test_all_clean_meshes_batch_and_single_against_oracle():
     ms = _meshes(clean=True)
-    assert len(ms) >= 850
+    assert len(ms) == 844          # nine dumps hold degenerate triangles only
     nodes_l = [second_layer(top, 0.5) for _, top, _ in ms]
     elems_l = [extrude_elems(tris, len(top)) for _, top, tris in ms]
     batch = FEA2Batch(nodes_l, elems_l, FEM_C3D6)
@@ -74,7 +74,7 @@ def test_all_clean_meshes_batch_and_single_against_oracle():
     a_b = batch.ComputeDisplacement(uf, u0, gids)[0]
     f_b = batch.ComputeForces(a_b)[0]
     sE_b, nsE_b = batch.ComputeStrainEnergy(a_b)
-    finite = 0
+    finite, worst = 0, 0.0
     for k, (frame, top, tris) in enumerate(ms):
         d0, d1 = int(batch.dof0[k]), int(batch.dof0[k + 1])
         K = oracle.fem_assemble_dense(2, nodes_l[k], elems_l[k])
@@ -86,9 +86,18 @@ def test_all_clean_meshes_batch_and_single_against_oracle():
         assert _bits_equal(batch.K_dense(k), K), tag
         assert np.array_equal(a_b[d0:d1], a), tag
         assert _bits_equal(f_b[d0:d1], f), tag
+        # a^T f: the reference sums it in float (Eigen's packet order, FEA2.cc:1886), the oracle in float left to right, the device
+        # in double -- three roundings of one sum whose terms partly cancel.  The device must be within a float ulp or two of the
+        # exact sum, and within 1e-5 of the oracle's figure on the scale the float sum's own rounding lives on, sum |a_i f_i|
+        # (>= |sE|; on these meshes the oracle's left-to-right sum is itself up to 5.9e-5 of |sE| away from the exact one)
+        exact = abs(float(np.dot(a.astype(np.float64), f.astype(np.float64))))
+        scale = float(np.abs(a.astype(np.float64) * f.astype(np.float64)).sum())
+        nel = len(a) // 3
         if np.isfinite(sE):
             finite += 1
-            assert abs(sE_b[k] - sE) <= RTOL * abs(sE) and abs(nsE_b[k] - nsE) <= RTOL * abs(nsE), tag
+            assert abs(sE_b[k] - exact) <= 2.5e-7 * exact and abs(nsE_b[k] - exact / nel) <= 4e-7 * exact / nel, tag
+            assert abs(sE_b[k] - sE) <= RTOL * scale and abs(nsE_b[k] - nsE) <= RTOL * scale / nel, tag
+            worst = max(worst, abs(sE_b[k] - sE) / abs(sE))
         else:
             assert not np.isfinite(sE_b[k]), tag
         # ... and as a model of its own, the way PoseOptimizationNR builds one per call
@@ -98,5 +107,5 @@ def test_all_clean_meshes_batch_and_single_against_oracle():
         f1 = one.ComputeForces(a)[0]
         assert _bits_equal(f1, f), tag
         s1, n1 = one.ComputeStrainEnergy(a)
-        assert (abs(s1[0] - sE) <= RTOL * abs(sE) and abs(n1[0] - nsE) <= RTOL * abs(nsE)) if np.isfinite(sE) else not np.isfinite(s1[0]), tag
-    assert finite >= 800
+        assert (s1[0] == sE_b[k] and n1[0] == nsE_b[k]) if np.isfinite(sE) else not np.isfinite(s1[0]), tag      # one model or a batch: the same bits
+    assert finite >= 800 and worst < 1e-4          # measured: 5.9e-5 on the worst of the 844 (the float sum's own noise)
