@@ -711,7 +711,8 @@ def main():
         sys.exit(launch.run_parent(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout))
     world = launch.check_world(args.gpus)    # a launcher's WORLD_SIZE must be what --gpus says
     # one rank, one set of cores -- before anything touches the GPU (the HIP runtime's threads inherit the mask)
-    affinity = None if args.no_pin else launch.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), world)
+    _lr = int(os.environ.get("LOCAL_RANK", "0"))
+    affinity = None if args.no_pin else launch.pin_rank(_lr, world, dev_index=0 if args.dist_backend != "nccl" else _lr)   # (a gloo rehearsal puts every rank on GPU 0)
 
     import torch
     import torch.distributed as dist

@@ -37,6 +37,7 @@
 #include "common.h"
 #include "orbm_internal.h"
 #include "orbx_internal.h"
+#include "orbx_math.h"
 
 using namespace orbm_detail;
 
@@ -1005,8 +1006,9 @@ __global__ __launch_bounds__(MT) void k_map_frustum(const float *__restrict__ po
 //                    float(double(sum) + double(t));
 //   cv::norm(PO)   : sqrt of the double sum of squares, left to right, cast to float;
 //   PO.dot(Pn)     : double sum of double products, left to right.
-// std::log / std::ceil on a float argument are the float overloads (using namespace std): log as the correctly
-// rounded float of the double logarithm (what glibc's logf returns except in vanishingly rare cases).
+// std::log / std::ceil on a float argument are the float overloads (using namespace std): logf as glibc >= 2.27 evaluates it,
+// restated in orbx_math.h (orbx_logf_glibc_f32: equal to the library at every positive float, tools/trig/logf_count.c; it differs
+// from the rounded double logarithm at 416,909 floats -- at none of them by enough to move a level at scale factor 1.2).
 struct ProjectCam { float fx, fy, cx, cy, min_x, max_x, min_y, max_y, mbf, cos_limit, log_scale, th; float R[9], t[3], Ow[3]; int nlevels, mode; };
 
 __global__ __launch_bounds__(MT) void k_project_points(const uint8_t *__restrict__ valid, const float *__restrict__ pos, const float *__restrict__ nrm,
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(MT) void k_project_points(const uint8_t *__restrict
     }
     // PredictScale: ratio = mfMaxDistance / dist; ceil(log(ratio) / mfLogScaleFactor), clamped
     const float ratio = maxd[i] / dist;
-    const float lg = (float)log((double)ratio);
+    const float lg = orbx_logf_glibc_f32(ratio);        // log(float) = logf under the reference's headers; glibc's logf restated (orbx_math.h)
     int level = (int)ceilf(lg / cam.log_scale);
     if (level < 0) level = 0; else if (level >= cam.nlevels) level = cam.nlevels - 1;
     if (ok) {
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(MT) void k_project_form(const uint8_t *__restrict__
             ok = ok && !(dist3D < minDistance || dist3D > maxDistance);
             if (ok) {
                 const float ratio = maxd[i] / dist3D;
-                int level = (int)ceilf((float)log((double)ratio) / cam.log_scale);
+                int level = (int)ceilf(orbx_logf_glibc_f32(ratio) / cam.log_scale);
                 if (level < 0) level = 0; else if (level >= cam.nlevels) level = cam.nlevels - 1;
                 w.u = u; w.v = v; w.r = cam.th * scale[level]; w.min_level = level - 1; w.max_level = level + 1;
             }
@@ -1414,7 +1416,7 @@ __global__ __launch_bounds__(MT) void k_project_form(const uint8_t *__restrict__
             }
             if (ok) {
                 const float ratio = maxd[i] / dist;
-                int level = (int)ceilf((float)log((double)ratio) / cam.log_scale);
+                int level = (int)ceilf(orbx_logf_glibc_f32(ratio) / cam.log_scale);
                 if (level < 0) level = 0; else if (level >= cam.nlevels) level = cam.nlevels - 1;
                 w.u = u; w.v = v; w.r = cam.th * scale[level]; w.min_level = level - 1; w.max_level = level;
             }

@@ -115,4 +115,45 @@ ORBX_HD void orbx_sincos_glibc_f32(float y, float *sn, float *cs)
     *cs = orbx_glibc_poly_f32(x * s, x * x, alt, n ^ 1);
 }
 
+// glibc >= 2.27's logf (sysdeps/ieee754/flt-32/e_logf.c, the table-driven double-precision evaluation: 16 intervals of the mantissa,
+// z = x / 2^k, r = z invc - 1, log x = k ln 2 + logc + r + r^2 (A2 + A1 r + A0 r^2)), restated operation for operation.
+// Why: MapPoint::PredictScale (MapPoint.cc:448-480) computes ceil(log(ratio) / mfLogScaleFactor) with a FLOAT ratio, which under the
+// reference's headers is logf; logf is not correctly rounded everywhere, and where it differs from (float)log((double)x) the quotient
+// can land on the other side of an integer.  tools/trig/logf_count.c tries every positive float against the C library.
+ORBX_HD float orbx_logf_glibc_f32(float x)
+{
+    const double T[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
+        {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+        {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5}, {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3}, {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+        {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2, Ln2 = 0x1.62e42fefa39efp-1;
+    union { float f; unsigned u; } v;
+    v.f = x;
+    unsigned ix = v.u;
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {          // zero, subnormal, negative, inf, nan
+        if (ix * 2u == 0u) return -1.0f / 0.0f;
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return (x - x) / (x - x);   // nan (glibc: __math_invalidf)
+        v.f = x * 0x1p23f;                                         // subnormal: normalise
+        ix = v.u - (23u << 23);
+    }
+    const unsigned tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> (23 - 4)) % 16u);
+    const int k = (int)tmp >> 23;
+    v.u = ix - (tmp & (0x1ffu << 23));
+    const double invc = T[i][0], logc = T[i][1];
+    const double z = (double)v.f;
+    const double r = z * invc - 1;
+    const double y0 = logc + (double)k * Ln2;
+    const double r2 = r * r;
+    double y = A1 * r + A2;
+    y = A0 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
 #endif // ORBX_MATH_H

@@ -230,16 +230,46 @@ def rank_cpu_mask(local_rank, world, avail, local_cpus_of=None):
     return avail[lo:lo + per]
 
 
-def pin_rank(local_rank, world):
-    """Pins the calling process (call before the first GPU call); returns what it did, for the bench line."""
+def visible_device_index(index, env=None):
+    """Physical GPU behind HIP device `index` of this process: ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is
+    an alias on ROCm) renumber the devices a process sees; a list of plain indices is mapped through, anything else (UUIDs, an
+    index beyond the list) gives None = unknown."""
+    env = os.environ if env is None else env
+    phys = index
+    for name in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):    # HIP's filter applies on top of ROCr's
+        v = env.get(name)
+        if v is None or v.strip() == "":
+            continue
+        items = [x.strip() for x in v.split(",")]
+        if not all(x.isdigit() for x in items) or phys >= len(items):
+            return None
+        phys = int(items[phys])
+        if name != "ROCR_VISIBLE_DEVICES" and env.get("ROCR_VISIBLE_DEVICES") is None:
+            break
+    return phys
+
+
+def pin_rank(local_rank, world, dev_index=None):
+    """Pins the calling process (call before the first GPU call); returns what it did, for the bench line.  dev_index: the HIP
+    device this rank will use (default: local_rank).  Ranks that map one to one onto devices get the CPUs local to the PHYSICAL GPU
+    behind their device (visible-device lists mapped through); when ranks share a device (a gloo rehearsal: all on GPU 0) or the
+    physical GPU cannot be told, every rank gets a contiguous share of the CPUs instead."""
     if world <= 1:
         return None
     try:
         avail = sorted(os.sched_getaffinity(0))
-        mask = rank_cpu_mask(local_rank, world, avail, gpu_local_cpus)
+        dev_index = local_rank if dev_index is None else dev_index
+        local = None
+        if dev_index == local_rank:                                  # rank r <-> device r
+
+            def local(r):
+                p = visible_device_index(r)
+                return gpu_local_cpus(p) if p is not None else None
+        mask = rank_cpu_mask(local_rank, world, avail, local)
         os.sched_setaffinity(0, mask)
-        numa = gpu_local_cpus(local_rank) is not None
+        numa = local is not None and all(local(r) for r in range(world))      # (rank_cpu_mask uses the locality only if every rank has one)
         return {"cpus": "%d-%d" % (mask[0], mask[-1]) if mask == list(range(mask[0], mask[-1] + 1)) else ",".join(map(str, mask)),
-                "n": len(mask), "from": "GPU-local CPUs (sysfs)" if numa else "contiguous share"}
+                "n": len(mask), "from": "GPU-local CPUs (sysfs)" if numa else "contiguous share",
+                "gpu": {"hip_device": dev_index, "physical": visible_device_index(dev_index)}}
     except Exception as e:       # never fatal: an unpinned rank is slower, not wrong
         return {"error": str(e)}

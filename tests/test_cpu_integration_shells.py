@@ -98,3 +98,56 @@ def test_patch_applies_to_the_reference_tree(tmp_path):
     gen = subprocess.run(["python", os.path.join(ROOT, "tools", "make_reference_patch.py"), fresh], capture_output=True, text=True)
     assert gen.returncode == 0, gen.stderr
     assert open(fresh).read() == open(patch).read(), "integration/reference.patch is stale: run tools/make_reference_patch.py"
+
+
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference tree is only present in the development container")
+
+
+def _reference_sources(*dirs):
+    for d in dirs:
+        for base, _, names in os.walk(os.path.join(REF, d)):
+            for n in names:
+                if n.endswith((".cc", ".cpp", ".h", ".hpp")):
+                    yield os.path.join(base, n)
+
+
+@needs_reference
+def test_nobody_but_the_replaced_code_reads_mvImagePyramid():
+    """INTEGRATION.md 3a: ORBextractor::mvImagePyramid is filled on demand (SyncImagePyramid).  Its readers in the reference tree must
+    be ORBextractor.cc itself (replaced) and Frame::ComputeStereoMatches (Frame.cc:527-701, replaced by Frame_stereo_hip.cc) --
+    anything else would silently read stale levels."""
+    readers = {}
+    for f in _reference_sources("src", "include", "Examples"):
+        for k, line in enumerate(open(f, errors="replace"), 1):
+            if "mvImagePyramid" in _strip_comments(line):
+                readers.setdefault(os.path.relpath(f, REF), []).append(k)
+    assert set(readers) == {"src/ORBextractor.cc", "src/Frame.cc", "include/ORBextractor.h"}, readers
+    assert readers["include/ORBextractor.h"] and all(527 <= k <= 701 for k in readers["src/Frame.cc"]), readers
+    shell = open(os.path.join(ROOT, "integration", "Frame_stereo_hip.cc")).read()
+    assert "orbx_stereo_match" in shell and "mvImagePyramid" not in _strip_comments(shell)
+    assert "SyncImagePyramid" in open(os.path.join(ROOT, "integration", "ORBextractor_hip.cc")).read()
+    assert "SyncImagePyramid" in open(os.path.join(ROOT, "integration", "reference.patch")).read()
+    assert "SyncImagePyramid" in open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+
+@needs_reference
+def test_nobody_but_the_replaced_code_reads_FEA2_K_or_vvf():
+    """INTEGRATION.md 3a: FEA2::K / vvf stay empty behind the shell.  Outside FEA2.cc (whose numeric methods are replaced) and the
+    abandoned FEA.cc the only mention in the reference is the debug print of g2o's Levenberg hook, and that sits inside a comment."""
+    pat = re.compile(r"(->|\.)\s*(K|vvf)\b\s*(\[|\.size|\.push_back|=)")
+    live, commented = [], []
+    for f in _reference_sources("src", "include", "Thirdparty/g2o/g2o"):
+        rel = os.path.relpath(f, REF)
+        if "/FEA/" in rel:
+            continue
+        raw = open(f, errors="replace").read()
+        if pat.search(raw):
+            commented.append(rel)
+        if pat.search(_strip_comments(raw)):
+            live.append(rel)
+    assert live == [], live
+    assert commented == ["Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp"], commented
+    shell = _strip_comments(open(os.path.join(ROOT, "integration", "FEA2_hip.cc")).read())
+    assert not re.search(r"\bK\s*(\[|\.push_back|\.resize)", shell) and "vvf" not in shell     # the shell never fills them
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "`FEA2::K` and `FEA2::vvf` stay empty" in doc and "levenberg.cpp:173-181" in doc

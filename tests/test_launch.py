@@ -164,3 +164,23 @@ def test_gpu_locality_from_a_fake_sysfs(tmp_path):
         (nodes / str(n)).mkdir(parents=True)
         (nodes / str(n) / "properties").write_text(f"cpu_cores_count 8\nsimd_count {simd}\ndomain 0\nlocation_id {loc}\n")
     assert launch.gpu_local_cpus(0, str(sys_)) == [4, 5, 6, 7] and launch.gpu_local_cpus(1, str(sys_)) == [0, 1, 2, 3]
+
+
+def test_visible_device_lists_are_mapped_to_physical_gpus():
+    """pin_rank pins a rank to the CPUs of the GPU it really uses: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumber the
+    devices, and a gloo rehearsal (every rank on device 0) must not pretend to a locality."""
+    from orb_slam2_e_amd import launch
+    v = launch.visible_device_index
+    assert v(3, {}) == 3
+    assert v(1, {"HIP_VISIBLE_DEVICES": "4,6"}) == 6 and v(0, {"CUDA_VISIBLE_DEVICES": "5"}) == 5
+    assert v(1, {"ROCR_VISIBLE_DEVICES": "2,3,7"}) == 3
+    assert v(1, {"ROCR_VISIBLE_DEVICES": "2,3,7", "HIP_VISIBLE_DEVICES": "2,0"}) == 2      # HIP's list indexes ROCr's
+    assert v(2, {"HIP_VISIBLE_DEVICES": "0,1"}) is None and v(0, {"ROCR_VISIBLE_DEVICES": "GPU-abc"}) is None
+    import os
+    if len(os.sched_getaffinity(0)) >= 2:
+        before = os.sched_getaffinity(0)
+        try:
+            r = launch.pin_rank(1, 2, dev_index=0)          # rehearsal: rank 1 on device 0
+            assert r["from"] == "contiguous share" and r["gpu"] == {"hip_device": 0, "physical": launch.visible_device_index(0)}
+        finally:
+            os.sched_setaffinity(0, before)
