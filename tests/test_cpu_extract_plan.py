@@ -79,3 +79,19 @@ def test_frames_that_cannot_run_are_refused_not_planned(prm, size, code):
     with pytest.raises(OrbxError) as e:
         plan(*prm, *size)
     assert e.value.code == code
+
+
+def test_pin_tool_level_sizes_equal_the_plan():
+    """tools/pin_with_opencv.py computes the pyramid's level sizes by itself (it must run on a machine with cv2 and no ROCm): the
+    same sizes as orbx_plan for the frame shapes it dumps, without importing cv2."""
+    import ast
+    import os
+    import numpy as np
+    from orb_slam2_e_amd.extractor import plan
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pin_with_opencv.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "level_sizes")
+    ns = {"np": np}
+    exec(compile(ast.Module([fn], []), "level_sizes", "exec"), ns)
+    for w, h in ((640, 480), (1242, 375), (752, 480), (1241, 376)):
+        info = plan(2000, 1.2, 8, 20, 7, w, h)
+        assert ns["level_sizes"](w, h) == list(zip(info["level_w"], info["level_h"]))
