@@ -839,6 +839,349 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
     if (sg.chunk == 0 && threadIdx.x == 0) { sc[sg.mesh].rz[cur ^ 1] = rz2; sc[sg.mesh].rr = rr; }
 }
 
+// ---- ONE mesh, all iterations of a call in ONE launch, spread over the compute units of one XCD (k_fem_cg_xcd).
+// A single mesh cannot use k_fem_cg_resident's trick at speed (one compute unit's bandwidth: measured slower) and pays 3 launches of
+// ~3 us each per iteration on the launch-per-phase path.  Here P <= 32 workgroups of a 256-workgroup launch stay resident for the
+// whole call -- blockIdx % 8 == 0: workgroups are dealt round-robin over the XCDs, so these share one (for speed only: nothing below
+// relies on it).  The arithmetic is the launch-per-phase path's, chunk for chunk: workgroup `rank` owns the SpMV chunks [c0, c1)
+// (SPB rows each: same lanes, same LDS partials, same DPP sums as k_fem_spmv, same p.Ap partial per chunk) and the vector chunk
+// `rank` (RPB rows: k_fem_cg_update's and k_fem_cg_dir's formulas, one row per thread, same block sums); chunk partials are joined
+// in chunk_sum's order -- x, r, p and the scalars come out bit for bit.
+//   * the matrix never moves: a thread keeps the nine values and the column of its blocks (<= XG_MAXCH x XG_MAXQ) in registers
+//   * p lives in LDS, replicated: every workgroup keeps p (and 1/diag) over the column range [lo, hi) its blocks and rows touch and
+//     forms p = r/diag + beta p there itself, from the r its peers published -- p is never handed over
+//   * handed over per iteration: K p rows, r rows and three arrays of chunk partials, every value as a TAGGED 16-byte granule
+//     {value, tag, check}: one sc1 store by the producer, sc1 loads polled by the consumer until tag (= launch base + 2 it + phase) and
+//     check word match -- no counter, no store drain, no separate barrier: an iteration is TWO store -> load hops across the fabric.
+//     (A first version with two counter barriers per iteration -- stores, s_waitcnt, agent-scope add, poll, loads -- made ~8
+//     dependent fabric round trips of an iteration: 10.9 us on the 6,591-dof mesh, 7.1 on a 648-dof one; tools/ubench/xcd_barrier.hip
+//     prices the pieces: 1.2 us per barrier at P = 32, 2.3 us to stage 53 KB.)  MI355X_MICROARCH.md observes 16-byte sc1 granules
+//     untorn on gfx950 without promising it: the check word (value ^ tag ^ constant) turns a torn granule into "not there yet".
+//   * no write-after-read hazard without barriers: a slot is rewritten only by a workgroup that has since consumed data whose
+//     existence implies the slot's readers are done (K p rows and r rows: their consumer produced what the writer waited for; the
+//     chunk partials are double-buffered by iteration parity, and a workgroup two iterations ahead is impossible -- each phase needs
+//     every workgroup's partial of the phase before).
+// Every spin is bounded: a timeout raises the abort word, every workgroup leaves, and fem_cg_result / fem_cg report the failure.
+constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 32;
+constexpr unsigned XG_SPIN = 1u << 22, XG_KEY = 0x5bd1e995u;
+struct XgCtl { unsigned abort_flag, pad[31]; };
+typedef unsigned xg_u32x4 __attribute__((ext_vector_type(4)));
+// Two cache policies for the granules, chosen per launch by the participants themselves:
+//   SAME_XCD  every participant reads its XCC id at start and publishes it; if all are equal, the workgroups share ONE L2, which is
+//             then the point of coherence: plain stores (write-through L1 -> L2, the line stays in L2) and sc1 loads (past L1, served
+//             by L2) -- a hop is an L2 round trip (tools/ubench/xcd_barrier.hip, `plain-stores 1 stride 8`: 0 stale values in 20,000
+//             rounds; the same run across XCDs reads stale data at once, which is why this mode is only taken on the ids' evidence)
+//   otherwise sc0 sc1 on both sides (system scope: served by memory, never by an L2 line) -- correct for any placement, and three
+//             times slower per hop (16.4 us per iteration on the 6,591-dof mesh when it was the only mode)
+__device__ __forceinline__ void xg_put(char *gb, int slot, double v, unsigned tag, bool same_xcd)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    xg_u32x4 g;
+    g.x = (unsigned)b; g.y = (unsigned)(b >> 32); g.z = tag; g.w = g.x ^ g.y ^ tag ^ XG_KEY;
+    char *a = gb + 16 * (size_t)slot;
+    if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a), "v"(g) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a), "v"(g) : "memory");
+}
+__device__ __forceinline__ bool xg_ok(const xg_u32x4 g, unsigned tag) { return g.z == tag && g.w == (g.x ^ g.y ^ tag ^ XG_KEY); }
+__device__ __forceinline__ double xg_val(const xg_u32x4 g) { return __builtin_bit_cast(double, ((unsigned long long)g.y << 32) | g.x); }
+// Wave-wide poll of U granules per lane (slot < 0: nothing wanted) until every wanted one carries `tag`; false: timed out / aborted.
+template <int U>
+__device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[U], unsigned tag, double (&out)[U], XgCtl *ctl, unsigned where, bool same_xcd)
+{
+    bool pend[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { pend[u] = slot[u] >= 0; out[u] = 0; }
+    for (unsigned spins = 0;; ++spins) {
+        xg_u32x4 g[U];
+        // Hand-written loads: to the compiler a buffer-load builtin is a pure read of an unchanging address, and it hoisted all U of them
+        // out of this loop (neither the builtin's volatile bit nor a memory clobber in the loop stopped it) -- the bug of this kernel's
+        // first day: every wave but the one that had stored the granule itself spun on a register.  U loads in flight, one wait; the
+        // empty asm statements behind it tie every later use of g[u] to a point after the wait.
+        // (only what is still wanted is asked for again: the r rows of a range are there rounds before the last chunk partial is)
+        if (same_xcd) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(g[u]) :: "memory");
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pend[u] && xg_ok(g[u], tag)) { out[u] = xg_val(g[u]); pend[u] = false; }
+            any = any || pend[u];
+        }
+        if (!__any(any)) return true;
+        if (spins > XG_SPIN || ((spins & 1023u) == 1023u && __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (spins > XG_SPIN) {      // the first to time out says where (development aid: fem_debug_xcd reads the word)
+                unsigned expect = 0;
+                __hip_atomic_compare_exchange_strong(&ctl->abort_flag, &expect, where | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// Workgroup barrier for data that lives in LDS only: __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)` in front
+// of the s_barrier -- every barrier of an iteration then waited for the granule stores in flight to be acknowledged (the row puts behind
+// the product: 5,000 of an iteration's 21,000 clocks).  The waves of k_fem_cg_xcd exchange LDS contents only.
+__device__ __forceinline__ void xg_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Granule buffer of a model: K p rows | r rows | p.Ap partials x 2 parities | r.z partials x 2 | r.r partials x 2 | XCC ids
+struct XgLayout { int ap, r, pap, rz, rr, id, total; };
+__host__ __device__ inline XgLayout xg_layout(int ndof, int nchunk, int nchunk_s)
+{
+    XgLayout l;
+    l.ap = 0; l.r = ndof; l.pap = 2 * ndof; l.rz = l.pap + 2 * nchunk_s; l.rr = l.rz + 2 * nchunk; l.id = l.rr + 2 * nchunk; l.total = l.id + XG_MAXP;
+    return l;
+}
+template <int SPB>
+__global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
+                                                    int ndof, int nchunk, int nchunk_s, int niter, int cur, CgScal *__restrict__ sc,
+                                                    double *__restrict__ p, const double *__restrict__ dinv, double *__restrict__ x,
+                                                    double *__restrict__ r, void *__restrict__ gran, const int4 *__restrict__ plan, int P,
+                                                    int ldr, int ldq, XgCtl *__restrict__ ctl, unsigned base)
+{
+    static_assert(CGT == RPB, "one row of the vector chunk per thread");
+    if (blockIdx.x % XG_STRIDE != 0 || (int)(blockIdx.x / XG_STRIDE) >= P) return;
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double sh[XG_MAXCH][CGT / 64], shv[2][CGT / 64];
+    __shared__ int s_bp[XG_MAXCH][SPB / 3 + 1];
+    __shared__ int s_fail;
+    const int rank = blockIdx.x / XG_STRIDE, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int4 pl = plan[rank];
+    const int c0 = pl.x, nch = pl.y - pl.x, lo = pl.z, rng = pl.w - pl.z;
+    const XgLayout L = xg_layout(ndof, nchunk, nchunk_s);
+    char *gb = static_cast<char *>(gran);
+    double *p_s = lds, *d_s = lds + ldr, *part = lds + 2 * ldr;        // part: XG_MAXCH regions of 3 ldq doubles
+    // the blocks of this thread, for the whole launch
+    float va[XG_MAXCH][XG_MAXQ][9]; int ca[XG_MAXCH][XG_MAXQ]; int nqa[XG_MAXCH], r0a[XG_MAXCH], r1a[XG_MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < XG_MAXCH; ++ch) {
+        nqa[ch] = 0; r0a[ch] = r1a[ch] = 0;
+        if (ch < nch) {
+            const int r0 = (c0 + ch) * SPB, r1 = min(r0 + SPB, ndof);
+            const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
+            if (tid <= (r1 - r0) / 3) s_bp[ch][tid] = bp[r0 / 3 + tid] - q0;
+            nqa[ch] = nq; r0a[ch] = r0; r1a[ch] = r1;
+#pragma unroll
+            for (int u = 0; u < XG_MAXQ; ++u) {
+                const int qq = min(tid + u * CGT, nq - 1);
+                __builtin_memcpy(va[ch][u], vals_b + 9 * (size_t)(q0 + qq), 36);
+                ca[ch][u] = bcol3[q0 + qq] - lo;
+            }
+        }
+    }
+    for (int i = tid; i < rng; i += CGT)
+        if (lo + i < ndof) { p_s[i] = p[lo + i]; d_s[i] = dinv[lo + i]; }
+    if (tid == 0) s_fail = 0;
+    const int row = rank * RPB + tid;
+    const bool vec = rank < nchunk, has = vec && row < ndof;
+    double xv = has ? x[row] : 0, rv = has ? r[row] : 0;
+    const double dv = has ? dinv[row] : 0;
+    double rz = sc[0].rz[cur], rr = sc[0].rr;
+    // where the participants run: every one publishes its XCC id (system scope), every one reads all of them
+    bool fast;
+    {
+        if (tid == 0) xg_put(gb, L.id + rank, (double)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf), base, false);   // HW_REG_XCC_ID, bits 0-3
+        int slot[1]; double got[1];
+        slot[0] = lane < P ? L.id + lane : -1;
+        if (!xg_get<1>(gb, slot, base, got, ctl, 4u | (unsigned)rank << 8 | (unsigned)w << 16, false)) s_fail = 1;
+        const double mine = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(unsigned long long, got[0]) >> 32)) << 32) |
+                                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_bit_cast(unsigned long long, got[0])));   // rank 0's id
+        fast = !__any(lane < P && got[0] != mine);
+    }
+    __syncthreads();
+    if (s_fail) return;
+    const int sub = tid / LPR, sl = tid % LPR;
+    // the row groups of this thread (chunk ch, pass): LDS offset of the row's first partial, its blocks, its row -- fixed for the launch.
+    // Groups that do not exist (ch >= nch, rows past the chunk) read slot 0 of the partials and are never used.
+    constexpr int NPASS = (SPB + CGT / LPR - 1) / (CGT / LPR);
+    // goff: LDS index of the partials sl, sl + 8, sl + 16, sl + 24 of the row (past the row's end: `zero`, a double that stays 0.0, so the
+    // sum needs neither a mask nor a branch); gmore: the row has more than 32 blocks (wave-wide: anymore).
+    int goff[XG_MAXCH][NPASS][4], gbase[XG_MAXCH][NPASS], gnb[XG_MAXCH][NPASS], grow[XG_MAXCH][NPASS];
+    const int zero = 3 * XG_MAXCH * ldq;            // part[zero]: one spare double behind the chunks' regions
+    if (tid == 0) part[zero] = 0.0;
+    bool more = false;
+#pragma unroll
+    for (int ch = 0; ch < XG_MAXCH; ++ch)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            gbase[ch][pass] = zero; gnb[ch][pass] = 0; grow[ch][pass] = -1;
+            const int rw = r0a[ch] + pass * (CGT / LPR) + sub;
+            if (ch < nch && rw < r1a[ch]) {
+                const int I = (rw - r0a[ch]) / 3, i = rw - r0a[ch] - 3 * I, b0 = s_bp[ch][I];
+                gbase[ch][pass] = 3 * (ch * ldq + b0) + i; gnb[ch][pass] = s_bp[ch][I + 1] - b0; grow[ch][pass] = rw;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) goff[ch][pass][jj] = sl + LPR * jj < gnb[ch][pass] ? gbase[ch][pass] + 3 * (sl + LPR * jj) : zero;
+            more = more || gnb[ch][pass] > 4 * LPR;
+        }
+    const bool anymore = __any(more) != 0;
+    xg_sync();
+#ifdef XG_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define XG_T(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define XG_T(k) do { } while (0)
+#endif
+    for (int it = 0; it < niter; ++it) {
+        const unsigned tagA = base + 2u * (unsigned)it + 1u, tagB = tagA + 1u;
+        const int par = it & 1;
+        // ---- K p on the own chunks (k_fem_spmv, phase 1: a lane per block, three row sums parked in LDS)
+#pragma unroll
+        for (int ch = 0; ch < XG_MAXCH; ++ch) {
+            if (ch < nch && tid < nqa[ch]) {
+#pragma unroll
+                for (int u = 0; u < XG_MAXQ; ++u) {
+                    if (u > 0 && tid + u * CGT >= nqa[ch]) continue;   // (k_fem_spmv's lanes past the run repeat its last block: same values to the same slots)
+                    const int qq = tid + u * CGT;
+                    const double *pp = p_s + ca[ch][u];
+                    const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                    double *dst = part + 3 * (ch * ldq + qq);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        dst[i] = ((double)va[ch][u][3 * i] * p0 + (double)va[ch][u][3 * i + 1] * p1) + (double)va[ch][u][3 * i + 2] * p2;
+                }
+            }
+        }
+        xg_sync();
+        XG_T(0);   // SpMV phase 1
+        // (phase 2: 8 lanes per row, DPP row_shl sums in a fixed order; the chunk's partial of p.Ap)
+        // No branch, no mask and no loop in here: the <= 48 partials a thread adds are asked for together (a first version -- k_fem_spmv's
+        // loop over a row's blocks, under `if (row < r1)` -- compiled to 72 LDS reads each waited for behind its own branch: 11,000 of
+        // an iteration's 21,000 clocks; a second one with selects kept 48 loop-invariant lane masks in spilled scalar registers: 9,000).
+        // A lane adds the partials sl, sl + 8, .. of its row in that order; the slots past the row's end read a 0.0, and `+ 0.0` changes
+        // nothing (a sum that starts at +0.0 never is -0.0).  Rows of more than 32 blocks take the loop for the rest (wave-uniform test).
+        double acc[XG_MAXCH], srow[XG_MAXCH][NPASS];
+        {
+            double pv[XG_MAXCH][NPASS][4], pr[XG_MAXCH][NPASS];
+#pragma unroll
+            for (int ch = 0; ch < XG_MAXCH; ++ch)
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) pv[ch][pass][jj] = part[goff[ch][pass][jj]];
+                    pr[ch][pass] = p_s[max(grow[ch][pass], lo) - lo];
+                }
+#pragma unroll
+            for (int ch = 0; ch < XG_MAXCH; ++ch) {
+                acc[ch] = 0;
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    double sm = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) sm += pv[ch][pass][jj];
+                    if (anymore)
+                        for (int j = sl + 4 * LPR; j < gnb[ch][pass]; j += LPR) sm += part[gbase[ch][pass] + 3 * j];
+                    sm += dpp_shl_f64<4>(sm);
+                    sm += dpp_shl_f64<2>(sm);
+                    sm += dpp_shl_f64<1>(sm);
+                    srow[ch][pass] = sm;
+                    acc[ch] += grow[ch][pass] >= 0 && sl == 0 ? pr[ch][pass] * sm : 0.0;
+                }
+                acc[ch] = wave_sum_f64(acc[ch]);      // block_sum, all chunks behind one barrier
+            }
+        }
+        // (the rows go out behind the sums, not between them: a store is a hand-written asm statement with a memory clobber, and ten of
+        // them inside the loop above made ten chains of LDS reads run one after the other -- 10,600 of an iteration's 20,700 clocks)
+#pragma unroll
+        for (int ch = 0; ch < XG_MAXCH; ++ch)
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass)
+                if (grow[ch][pass] >= 0 && sl == 0) xg_put(gb, L.ap + grow[ch][pass], srow[ch][pass], tagA, fast);
+        if (lane == 0) {
+#pragma unroll
+            for (int ch = 0; ch < XG_MAXCH; ++ch) if (ch < nch) sh[ch][w] = acc[ch];
+        }
+        xg_sync();
+        if (tid == 0) {
+#pragma unroll
+            for (int ch = 0; ch < XG_MAXCH; ++ch)
+                if (ch < nch) {
+                    double t = 0;
+                    for (int i = 0; i < CGT / 64; ++i) t += sh[ch][i];
+                    xg_put(gb, L.pap + par * nchunk_s + c0 + ch, t, tagA, fast);
+                }
+        }
+        XG_T(1);   // SpMV phase 2 + partials out
+        // ---- alpha = rz / p.Ap; x += alpha p; r -= alpha K p; partials of r.(r/diag) and r.r (k_fem_cg_update)
+        double pAp, api;
+        {
+            int slot[4]; double got[4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) slot[u] = lane + 64 * u < nchunk_s ? L.pap + par * nchunk_s + lane + 64 * u : -1;
+            slot[3] = has ? L.ap + row : -1;
+            if (!xg_get<4>(gb, slot, tagA, got, ctl, 1u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+            double v = 0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) if (lane + 64 * u < nchunk_s) v += got[u];      // chunk_sum's order
+            pAp = wave_sum_f64(v);
+            api = got[3];
+        }
+        XG_T(2);   // hop A: the p.Ap partials and the own K p row
+        const double alpha = cg_ratio(rz, pAp);
+        if (vec) {
+            double s1 = 0, s2 = 0;
+            if (has) {
+                xv += alpha * p_s[row - lo];
+                const double ri = rv - alpha * api;
+                rv = ri;
+                s1 += ri * (ri * dv);
+                s2 += ri * ri;
+                xg_put(gb, L.r + row, ri, tagB, fast);
+            }
+            s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);       // two block_sums behind one barrier
+            if (lane == 0) { shv[0][w] = s1; shv[1][w] = s2; }
+        }
+        xg_sync();
+        if (s_fail) return;
+        if (vec && tid == 0) {
+            double t1 = 0, t2 = 0;
+            for (int i = 0; i < CGT / 64; ++i) { t1 += shv[0][i]; t2 += shv[1][i]; }
+            xg_put(gb, L.rz + par * nchunk + rank, t1, tagB, fast);
+            xg_put(gb, L.rr + par * nchunk + rank, t2, tagB, fast);
+        }
+        // ---- beta = rz_new / rz; p = r/diag + beta p over the own column range, from the r everybody published (k_fem_cg_dir)
+        XG_T(3);   // update + partials out
+        // one poll for the chunk partials and the first XG_SU x 256 rows of the range (ranges beyond that -- irregular numberings --
+        // take further rounds of rows only)
+        double rz2, beta;
+        {
+            int slot[2 + XG_SU]; double got[2 + XG_SU];
+            slot[0] = lane < nchunk ? L.rz + par * nchunk + lane : -1;
+            slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[2 + u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+            if (!xg_get<2 + XG_SU>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+            rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);       // chunk_sum with <= 32 partials: a lane per partial
+            rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
+            beta = cg_ratio(rz2, rz);
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; if (slot[2 + u] >= 0) p_s[i] = got[2 + u] * d_s[i] + beta * p_s[i]; }
+        }
+        for (int b0 = XG_SU * CGT; b0 < rng; b0 += XG_SU * CGT) {
+            int slot[XG_SU]; double got[XG_SU];
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; slot[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+            if (!xg_get<XG_SU>(gb, slot, tagB, got, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; if (slot[u] >= 0) p_s[i] = got[u] * d_s[i] + beta * p_s[i]; }
+        }
+        rz = rz2;
+        xg_sync();
+        XG_T(4);   // hop B: the r.z partials and the range's r rows; the new p
+        if (s_fail) return;
+    }
+#ifdef XG_TIMING
+    if (tid == 0 && rank < 4) for (int k = 0; k < 5; ++k) ctl->pad[1 + 5 * rank + k] = (unsigned)(tacc[k] / (unsigned long long)max(niter, 1));
+#endif
+    if (has) { x[row] = xv; r[row] = rv; p[row] = p_s[row - lo]; }
+    if (rank == 0 && tid == 0) { sc[0].rz[0] = rz; sc[0].rz[1] = rz; sc[0].rr = rr; }
+}
+
 // ---- Two-level preconditioner (fem_cg_preconditioner(FEM_PRECOND_TWO_LEVEL)): z = r/diag + Z Ac^-1 Z^T r with Z = the six rigid-body
 // modes (three translations, three rotations about the centroid) of 2 x 2 x 2 geometric aggregates of a mesh's nodes -- 48 coarse
 // dofs -- and Ac = Z^T K Z.  Point-Jacobi leaves the smooth, near-rigid error of a near-incompressible solid to thousands of
@@ -1785,6 +2128,10 @@ struct fem_model {
     // k_fem_cg_resident: chunk table {first block row, block rows, first block, blocks} and each mesh's chunk range
     int4 *d_rcd = nullptr; int *d_rcfirst = nullptr;
     bool cg_resident = false, cgr_big = false; int cgr_lds = 0, cgr_ldn = 0;
+    // k_fem_cg_xcd (one mesh): participants, LDS doubles per vector / blocks per chunk region, LDS bytes, the per-workgroup plan, the
+    // barrier block and how far its counter has been driven
+    bool cg_xcd = false; int xg_P = 0, xg_ldr = 0, xg_ldq = 0, xg_lds = 0; int4 *d_xg_plan = nullptr; XgCtl *d_xg_ctl = nullptr; unsigned xg_bar = 0;
+    char *d_xg_gran = nullptr;   // its tagged 16-byte granules (xg_layout)
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -1803,7 +2150,7 @@ struct fem_model {
         static const char *names[5] = {"k_fem_ke", "k_fem_assemble", "k_fem_spmv", "k_fem_cg_update", "k_fem_cg_dir"};
         for (int i = 0; i < 5; ++i) prof.names[i] = names[i];
         if (fused_step()) { prof.names[3] = "k_fem_cg_step"; prof.names[4] = nullptr; }   // one launch does both
-        prof.names[5] = cg_resident ? "k_fem_cg_resident" : nullptr;
+        prof.names[5] = cg_resident ? "k_fem_cg_resident" : (cg_xcd ? "k_fem_cg_xcd" : nullptr);
         prof.names[6] = coarse() ? "k_fem_cz_*" : nullptr;
     }
     // the vector half of an iteration as ONE per-mesh workgroup (k_fem_cg_step): batches of 16 meshes and more (a single mesh under
@@ -1814,6 +2161,8 @@ struct fem_model {
     // (nor for an aggregate of more than CZR_U x 64 nodes: cz_max_agg, known after fem_cg_setup)
     int cz_max_agg = 0;
     bool resident_now() const { return cg_resident && !(coarse() && !cgr_big && cz_max_agg > 64 * 5); }
+    // the one-XCD kernel: one mesh under point Jacobi (FEM_CG_XCD=0 keeps the launch-per-phase path, which it equals bit for bit)
+    bool xcd_now() const { const char *e = getenv("FEM_CG_XCD"); return cg_xcd && !coarse() && !(e && e[0] == '0'); }   // (read per call: the tests switch it)
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
     orbx::KernelProfiler prof;
@@ -1825,7 +2174,7 @@ void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_tables, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
-                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_cznode, m->d_cy, m->d_czptr, m->d_ac, m->d_aci, m->d_cw, m->d_cv, m->d_cwv, m->d_czmax, m->d_cmask};
+                    m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_cznode, m->d_cy, m->d_czptr, m->d_ac, m->d_aci, m->d_cw, m->d_cv, m->d_cwv, m->d_czmax, m->d_cmask, m->d_xg_ctl, m->d_xg_gran};
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -1847,7 +2196,8 @@ int ensure_cg(fem_model *m)
     if (m->d_b) return 0;
     if (dalloc(&m->d_b, N) || dalloc(&m->d_x, N) || dalloc(&m->d_r, N) || dalloc(&m->d_p, N) || dalloc(&m->d_Ap, N) ||
         dalloc(&m->d_dinv, N) || dalloc(&m->d_part[0], C) || dalloc(&m->d_part[1], C) || dalloc(&m->d_part[2], C) ||
-        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nseg) || dalloc(&m->d_vals_b, (size_t)m->nmesh * m->nnzs))
+        dalloc(&m->d_part[3], C) || dalloc(&m->d_sc, (size_t)m->nseg) || dalloc(&m->d_vals_b, (size_t)m->nmesh * m->nnzs) ||
+        (m->cg_xcd && (dalloc(&m->d_xg_ctl, (size_t)1) || dalloc(&m->d_xg_gran, (size_t)16 * xg_layout(m->ndof, m->nchunk, m->nchunk_s).total))))
         return -1;
     return 0;
 }
@@ -1964,6 +2314,17 @@ void run_iters(fem_model *m, int n, hipStream_t st)
                            (const float4 *)m->d_cz, (const int *)m->d_czptr, (const double *)m->d_aci);
         m->prof.stop(5, st);
         m->cg_it += 2 * ((n + 1) / 2);   // both rz slots are current after the launch: keep the parity of the other path even
+        return;
+    }
+    if (m->xcd_now()) {
+        if (n <= 0) return;
+        m->prof.start(5, st);
+        hipLaunchKernelGGL(m->spb == 48 ? k_fem_cg_xcd<48> : k_fem_cg_xcd<96>, dim3(XG_STRIDE * XG_MAXP), dim3(CGT), m->xg_lds, st, m->d_vals_b,
+                           m->d_bcol3, m->d_bp, m->ndof, m->nchunk, m->nchunk_s, n, m->cg_it & 1, m->d_sc, m->d_p, m->d_dinv, m->d_x, m->d_r,
+                           (void *)m->d_xg_gran, (const int4 *)m->d_xg_plan, m->xg_P, m->xg_ldr, m->xg_ldq, m->d_xg_ctl, m->xg_bar);
+        m->prof.stop(5, st);
+        m->xg_bar += 2u * (unsigned)n;                        // the granules' tags: two per iteration, never reused (fem_cg_setup clears the buffer)
+        m->cg_it = 2 * ((m->cg_it + n + 1) / 2);              // both rz slots are current after the launch
         return;
     }
     for (int i = 0; i < n; ++i) launch_iter(m, st);
@@ -2146,8 +2507,9 @@ void build_symbolic(int npe, int nn, int ne, const int32_t *elems, Symbolic &y)
 // serves fem_plan, which the CPU tests and the host sanitizer build drive without a GPU).
 struct HostPlan {
     std::vector<int> cmesh, cmesh_s, bp, bcol3, rcfirst;
-    std::vector<int4> minfo, minfo_s, rcd;
-    bool resident = false, big = false;
+    std::vector<int4> minfo, minfo_s, rcd, xg;   // xg: k_fem_cg_xcd's plan, {first SpMV chunk, end, first dof, end} per workgroup
+    bool resident = false, big = false, xcd = false;
+    int xg_P = 0, xg_ldr = 0, xg_ldq = 0; size_t xg_lds = 0;
     size_t resident_lds = 0;
     int maxrows = 0;
 };
@@ -2275,6 +2637,30 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
         ok = ok && maxrows > 0 && maxrows <= (big ? CGR_MAXROWS_BIG : CGR_MAXROWS) && lds <= 160 * 1024;
         P.resident = ok; P.big = big; P.resident_lds = lds; P.maxrows = maxrows;
     }
+    if (!seg_nn && nmesh == 1 && m->nchunk <= XG_MAXP) {   // k_fem_cg_xcd: ONE mesh, its chunks dealt in contiguous runs to <= 32 workgroups
+        const int kch = (m->nchunk_s + XG_MAXP - 1) / XG_MAXP, Ps = (m->nchunk_s + kch - 1) / kch, Pn = std::max(Ps, m->nchunk);
+        bool ok = kch <= XG_MAXCH;
+        int maxq = 0, maxr = 0;
+        for (int w = 0; w < Pn && ok; ++w) {
+            const int c0 = std::min(w * kch, m->nchunk_s), c1 = std::min(c0 + kch, m->nchunk_s);
+            int lo = m->ndof, hi = 0;
+            if (w < m->nchunk) { lo = std::min(lo, w * RPB); hi = std::max(hi, std::min(w * RPB + RPB, m->ndof)); }   // the own vector chunk's rows
+            for (int c = c0; c < c1; ++c) {
+                const int r0 = c * SPB, r1 = std::min(r0 + SPB, m->ndof), q0 = P.bp[r0 / 3], q1 = P.bp[r1 / 3];
+                maxq = std::max(maxq, q1 - q0);
+                lo = std::min(lo, r0); hi = std::max(hi, r1);                                                              // the own rows (p.Ap)
+                for (int q = q0; q < q1; ++q) { lo = std::min(lo, P.bcol3[q]); hi = std::max(hi, P.bcol3[q] + 3); }       // the columns
+            }
+            if (hi <= lo) { lo = 0; hi = 2; }
+            lo &= ~1; hi = (hi + 1) & ~1;                       // 16-byte pieces of r
+            maxr = std::max(maxr, hi - lo);
+            P.xg.push_back(make_int4(c0, c1, lo, hi));
+        }
+        const size_t lds = ((size_t)2 * maxr + (size_t)3 * XG_MAXCH * std::max(maxq, 1) + 2) * sizeof(double);   // (+ the zero slot)
+        ok = ok && maxq <= XG_MAXQ * CGT && lds <= 150 * 1024;
+        if (ok) { P.xcd = true; P.xg_P = Pn; P.xg_ldr = maxr; P.xg_ldq = std::max(maxq, 1); P.xg_lds = lds; }
+        else P.xg.clear();
+    }
     return ORBX_OK;
 }
 
@@ -2327,6 +2713,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         piece(&m->d_rcd, P.rcd.data(), sizeof(int4) * P.rcd.size());
         piece(&m->d_rcfirst, P.rcfirst.data(), sizeof(int) * P.rcfirst.size());
     }
+    if (P.xcd) piece(&m->d_xg_plan, P.xg.data(), sizeof(int4) * P.xg.size());
 
     int bad = 0;
     bad |= dalloc(&m->d_tables, total) | dalloc(&m->d_ke1, (size_t)m->nd * m->nd);
@@ -2354,6 +2741,9 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
             for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<false, false>), reinterpret_cast<const void *>(k_fem_cg_resident<false, true>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
     }
+    if (e == hipSuccess && P.xcd && P.xg_lds > 48 * 1024)
+        e = hipFuncSetAttribute(m->spb == 48 ? reinterpret_cast<const void *>(k_fem_cg_xcd<48>) : reinterpret_cast<const void *>(k_fem_cg_xcd<96>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.xg_lds);
     if (e == hipSuccess && m->kz_lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cz_kz), hipFuncAttributeMaxDynamicSharedMemorySize, m->kz_lds);
     if (e == hipSuccess && m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
@@ -2364,6 +2754,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         return orbx::set_error(ORBX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
     }
     if (P.resident) { m->cg_resident = true; m->cgr_lds = (int)P.resident_lds; m->cgr_ldn = P.maxrows; }
+    if (P.xcd) { m->cg_xcd = true; m->xg_P = P.xg_P; m->xg_ldr = P.xg_ldr; m->xg_ldq = P.xg_ldq; m->xg_lds = (int)P.xg_lds; }
     m->name_kernel_kinds();
     *out = m;
     return ORBX_OK;
@@ -2883,6 +3274,11 @@ int fem_cg_setup(fem_model *m, const double *b)
     if (m->coarse()) coarse_correction(m, m->stream, m->d_r, m->d_p, 1);   // p = z = r/diag + Z Ac^-1 Z^T r
     hipLaunchKernelGGL(k_fem_cg_init2, dim3(m->nseg), dim3(1), 0, m->stream, m->nchunk, m->d_part[0], m->d_part[1], m->d_sc,
                        (const int4 *)m->d_minfo, m->coarse() ? (const double *)m->d_cwv : nullptr);
+    if (m->d_xg_ctl) {
+        ORBX_HIP(hipMemsetAsync(m->d_xg_ctl, 0, sizeof(XgCtl), m->stream));
+        ORBX_HIP(hipMemsetAsync(m->d_xg_gran, 0, (size_t)16 * xg_layout(m->ndof, m->nchunk, m->nchunk_s).total, m->stream));
+        m->xg_bar = 0;
+    }
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(m->stream));
     m->cg_it = 0;
@@ -2944,7 +3340,10 @@ int fem_cg_result(fem_model *m, double *x, double *relres)
     std::vector<CgScal> sc(relres ? m->nseg : 0);
     if (x) ORBX_HIP(hipMemcpyAsync(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost, st));
     if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, st));
+    unsigned xg_abort = 0;   // k_fem_cg_xcd: a barrier that timed out (every workgroup left; the iterate is not to be used)
+    if (m->d_xg_ctl) ORBX_HIP(hipMemcpyAsync(&xg_abort, &m->d_xg_ctl->abort_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));
+    if (xg_abort) { m->cg_ready = false; ORBX_FAIL(ORBX_ERR_HIP, "k_fem_cg_xcd: a cross-workgroup barrier timed out (FEM_CG_XCD=0 selects the launch-per-phase path)"); }
     if (relres) {
         for (int i = 0; i < m->nseg; ++i) relres[i] = sc[i].bb > 0 ? sqrt(sc[i].rr / sc[i].bb) : 0.0;
     }
@@ -2973,6 +3372,29 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
     ORBX_HIP(hipGetLastError());
     if (iters_done) *iters_done = done;
     return fem_cg_result(m, x, relres);
+}
+
+// Development aid (not in include/fem_hip.h): the one-launch CG's plan and its granule buffer as it stands.
+int fem_debug_xcd(fem_model *m, int32_t *info8, int32_t *plan4, uint32_t *gran, int max_granules)
+{
+    if (!m || !info8) return -1;
+    const XgLayout L = xg_layout(m->ndof, m->nchunk, m->nchunk_s);
+    int v[8] = {m->cg_xcd, m->xg_P, m->xg_ldr, m->xg_ldq, m->xg_lds, L.total, m->nchunk, m->nchunk_s};
+    hipStream_t st = m->cg_stream ? m->cg_stream : m->stream;
+    if (m->cg_xcd && m->d_xg_ctl) { unsigned a = 0; if (hipMemcpyAsync(&a, &m->d_xg_ctl->abort_flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1; v[4] = (int)a; }   // (slot 4: the abort word)
+    memcpy(info8, v, sizeof(v));
+    if (!m->cg_xcd) return 0;
+    if (plan4 && hipMemcpyAsync(plan4, m->d_xg_plan, sizeof(int4) * m->xg_P, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (gran && m->d_xg_gran && hipMemcpyAsync(gran, m->d_xg_gran, (size_t)16 * std::min(max_granules, L.total), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
+}
+
+int fem_debug_xcd_timing(fem_model *m, uint32_t *out32)
+{
+    if (!m || !m->d_xg_ctl || !out32) return -1;
+    hipStream_t st = m->cg_stream ? m->cg_stream : m->stream;
+    if (hipMemcpyAsync(out32, m->d_xg_ctl, sizeof(XgCtl), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
 }
 
 int fem_profile_enable(fem_model *m, int on)

@@ -1,0 +1,105 @@
+"""GPU parity: the one-mesh CG as ONE launch over the compute units of one XCD (k_fem_cg_xcd: <= 32 resident workgroups, two
+hand-rolled barriers per iteration, the matrix in registers, p replicated in LDS) against the launch-per-phase path it replaces
+(k_fem_spmv + k_fem_cg_update + k_fem_cg_dir, selected with FEM_CG_XCD=0) -- BIT FOR BIT: the kernel keeps that path's chunk
+decomposition and summation orders -- and against the oracle's CG at 1e-5 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from orb_slam2_e_amd.fem import FEA2, FEM_TET4
+from orb_slam2_e_amd.synth import synth_tet_chain, synth_tet_mesh
+
+RTOL = 1e-5
+
+
+def _model(nodes, tets, fixed, load):
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
+    b = load.copy(); b[fixed] = 0
+    return fea, b[None]
+
+
+def _run(fea, b, slices, xcd):
+    os.environ["FEM_CG_XCD"] = "1" if xcd else "0"
+    try:
+        fea.profile(True)
+        fea.cg_setup(b)
+        for n in slices:
+            fea.cg_iterate(n)
+        x, rel = fea.cg_result()
+        return x, rel, fea.profile_read()
+    finally:
+        os.environ.pop("FEM_CG_XCD", None)
+
+
+@pytest.mark.parametrize("ncell,iters", [(12, 200), (2, 40), (5, 120), (9, 150), (11, 60)])
+def test_one_launch_equals_the_launch_per_phase_path_bit_for_bit(ncell, iters):
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=ncell)
+    fea, b = _model(nodes, tets, fixed, load)
+    xa, ra, pa = _run(fea, b, [iters], xcd=True)
+    xb, rb, pb = _run(fea, b, [iters], xcd=False)
+    assert pa["k_fem_cg_xcd"][1] == 1 and not pa["k_fem_spmv"][1]                 # ONE launch did all the iterations
+    assert pb["k_fem_spmv"][1] == iters and not pb.get("k_fem_cg_xcd", (0, 0))[1]
+    assert np.isfinite(xa).all() and xa.tobytes() == xb.tobytes() and ra.tobytes() == rb.tobytes()
+    rp, col, val = fea.csr(0)
+    ox, _, orel = oracle.fem_cg(rp, col, val, b[0], iters, 0.0)
+    assert np.abs(xa[0] - ox).max() <= RTOL * np.abs(ox).max()
+    assert abs(ra[0] - orel) <= 1e-6 * orel + 1e-12
+
+
+def test_split_launches_and_mixed_paths_continue_the_same_iteration():
+    """fem_cg_iterate in slices -- odd lengths, one path handing over to the other in the middle -- is the same sequence of
+    iterations: x after 7 + 1 + 30 + 12 equals x after 50, bit for bit, whichever path ran which slice."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
+    fea, b = _model(nodes, tets, fixed, load)
+    x50, r50, _ = _run(fea, b, [50], xcd=False)
+    xs, rs, _ = _run(fea, b, [7, 1, 30, 12], xcd=True)
+    assert xs.tobytes() == x50.tobytes() and rs.tobytes() == r50.tobytes()
+    fea.cg_setup(b)
+    for n, xcd in ((7, True), (1, False), (30, True), (3, False), (9, True)):
+        os.environ["FEM_CG_XCD"] = "1" if xcd else "0"
+        fea.cg_iterate(n)
+    os.environ.pop("FEM_CG_XCD", None)
+    xm, rm = fea.cg_result()
+    assert xm.tobytes() == x50.tobytes() and rm.tobytes() == r50.tobytes()
+
+
+@pytest.mark.parametrize("nn", [27, 2197, 2596, 2730, 2731, 3000])
+def test_sizes_around_the_kernels_limits(nn):
+    """Chains of tetrahedra of nn nodes: few chunks (fewer participants than 32), 7,788 dofs (the reference's largest mesh), the last
+    size the kernel takes (8,190 dofs: 32 vector chunks) and the first it does not (8,193: the launch-per-phase path runs by itself)."""
+    nodes, tets, fixed, load = synth_tet_chain(nn)
+    fea, b = _model(nodes, tets, fixed, load)
+    xa, ra, pa = _run(fea, b, [30], xcd=True)
+    xb, rb, pb = _run(fea, b, [30], xcd=False)
+    took = bool(pa.get("k_fem_cg_xcd", (0, 0))[1])
+    assert took == (3 * nn <= 8192)
+    assert xa.tobytes() == xb.tobytes() and ra.tobytes() == rb.tobytes()
+    rp, col, val = fea.csr(0)
+    ox, _, _ = oracle.fem_cg(rp, col, val, b[0], 30, 0.0)
+    assert np.abs(xa[0] - ox).max() <= RTOL * np.abs(ox).max()
+
+
+def test_solve_to_tolerance_and_two_level_keep_their_paths():
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
+    fea, b = _model(nodes, tets, fixed, load)
+    fea.profile(True)
+    x, done, rel = fea.solve_cg(b, iters=3000, tol=1e-8)          # slices of 25 between convergence tests: one launch each
+    prof = fea.profile_read()
+    assert rel[0] <= 1e-8 and done % 25 == 0 and prof["k_fem_cg_xcd"][1] == done // 25
+    os.environ["FEM_CG_XCD"] = "0"
+    try:
+        x0, done0, rel0 = fea.solve_cg(b, iters=3000, tol=1e-8)
+    finally:
+        os.environ.pop("FEM_CG_XCD", None)
+    assert done0 == done and x0.tobytes() == x.tobytes()
+    fea.cg_preconditioner("two_level")                             # the coarse correction is not in the one-launch kernel
+    fea.profile(True)
+    fea.cg_setup(b); fea.cg_iterate(20); fea.cg_result()
+    prof = fea.profile_read()
+    assert not prof.get("k_fem_cg_xcd", (0, 0))[1] and prof["k_fem_spmv"][1] == 20
+    fea.cg_preconditioner("jacobi")
