@@ -937,7 +937,8 @@ __host__ __device__ inline XgLayout xg_layout(int ndof, int nchunk, int nchunk_s
     l.ap = 0; l.r = ndof; l.pap = 2 * ndof; l.rz = l.pap + 2 * nchunk_s; l.rr = l.rz + 2 * nchunk; l.id = l.rr + 2 * nchunk; l.total = l.id + XG_MAXP;
     return l;
 }
-template <int SPB>
+// MC: the most SpMV chunks a workgroup owns (1, 3 or 6: small meshes do not pay for six chunks' worth of unrolled code)
+template <int SPB, int MC>
 __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
                                                     int ndof, int nchunk, int nchunk_s, int niter, int cur, CgScal *__restrict__ sc,
                                                     double *__restrict__ p, const double *__restrict__ dinv, double *__restrict__ x,
@@ -947,19 +948,19 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
     static_assert(CGT == RPB, "one row of the vector chunk per thread");
     if (blockIdx.x % XG_STRIDE != 0 || (int)(blockIdx.x / XG_STRIDE) >= P) return;
     extern __shared__ __align__(16) double lds[];
-    __shared__ double sh[XG_MAXCH][CGT / 64], shv[2][CGT / 64];
-    __shared__ int s_bp[XG_MAXCH][SPB / 3 + 1];
+    __shared__ double sh[MC][CGT / 64], shv[2][CGT / 64];
+    __shared__ int s_bp[MC][SPB / 3 + 1];
     __shared__ int s_fail;
     const int rank = blockIdx.x / XG_STRIDE, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int4 pl = plan[rank];
     const int c0 = pl.x, nch = pl.y - pl.x, lo = pl.z, rng = pl.w - pl.z;
     const XgLayout L = xg_layout(ndof, nchunk, nchunk_s);
     char *gb = static_cast<char *>(gran);
-    double *p_s = lds, *d_s = lds + ldr, *part = lds + 2 * ldr;        // part: XG_MAXCH regions of 3 ldq doubles
+    double *p_s = lds, *d_s = lds + ldr, *part = lds + 2 * ldr;        // part: MC regions of 3 ldq doubles
     // the blocks of this thread, for the whole launch
-    float va[XG_MAXCH][XG_MAXQ][9]; int ca[XG_MAXCH][XG_MAXQ]; int nqa[XG_MAXCH], r0a[XG_MAXCH], r1a[XG_MAXCH];
+    float va[MC][XG_MAXQ][9]; int ca[MC][XG_MAXQ]; int nqa[MC], r0a[MC], r1a[MC];
 #pragma unroll
-    for (int ch = 0; ch < XG_MAXCH; ++ch) {
+    for (int ch = 0; ch < MC; ++ch) {
         nqa[ch] = 0; r0a[ch] = r1a[ch] = 0;
         if (ch < nch) {
             const int r0 = (c0 + ch) * SPB, r1 = min(r0 + SPB, ndof);
@@ -1001,12 +1002,12 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
     constexpr int NPASS = (SPB + CGT / LPR - 1) / (CGT / LPR);
     // goff: LDS index of the partials sl, sl + 8, sl + 16, sl + 24 of the row (past the row's end: `zero`, a double that stays 0.0, so the
     // sum needs neither a mask nor a branch); gmore: the row has more than 32 blocks (wave-wide: anymore).
-    int goff[XG_MAXCH][NPASS][4], gbase[XG_MAXCH][NPASS], gnb[XG_MAXCH][NPASS], grow[XG_MAXCH][NPASS];
-    const int zero = 3 * XG_MAXCH * ldq;            // part[zero]: one spare double behind the chunks' regions
+    int goff[MC][NPASS][4], gbase[MC][NPASS], gnb[MC][NPASS], grow[MC][NPASS];
+    const int zero = 3 * MC * ldq;            // part[zero]: one spare double behind the chunks' regions
     if (tid == 0) part[zero] = 0.0;
     bool more = false;
 #pragma unroll
-    for (int ch = 0; ch < XG_MAXCH; ++ch)
+    for (int ch = 0; ch < MC; ++ch)
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             gbase[ch][pass] = zero; gnb[ch][pass] = 0; grow[ch][pass] = -1;
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
         const int par = it & 1;
         // ---- K p on the own chunks (k_fem_spmv, phase 1: a lane per block, three row sums parked in LDS)
 #pragma unroll
-        for (int ch = 0; ch < XG_MAXCH; ++ch) {
+        for (int ch = 0; ch < MC; ++ch) {
             if (ch < nch && tid < nqa[ch]) {
 #pragma unroll
                 for (int u = 0; u < XG_MAXQ; ++u) {
@@ -1055,11 +1056,11 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
         // an iteration's 21,000 clocks; a second one with selects kept 48 loop-invariant lane masks in spilled scalar registers: 9,000).
         // A lane adds the partials sl, sl + 8, .. of its row in that order; the slots past the row's end read a 0.0, and `+ 0.0` changes
         // nothing (a sum that starts at +0.0 never is -0.0).  Rows of more than 32 blocks take the loop for the rest (wave-uniform test).
-        double acc[XG_MAXCH], srow[XG_MAXCH][NPASS];
+        double acc[MC], srow[MC][NPASS];
         {
-            double pv[XG_MAXCH][NPASS][4], pr[XG_MAXCH][NPASS];
+            double pv[MC][NPASS][4], pr[MC][NPASS];
 #pragma unroll
-            for (int ch = 0; ch < XG_MAXCH; ++ch)
+            for (int ch = 0; ch < MC; ++ch)
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
                     pr[ch][pass] = p_s[max(grow[ch][pass], lo) - lo];
                 }
 #pragma unroll
-            for (int ch = 0; ch < XG_MAXCH; ++ch) {
+            for (int ch = 0; ch < MC; ++ch) {
                 acc[ch] = 0;
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
@@ -1088,18 +1089,18 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
         // (the rows go out behind the sums, not between them: a store is a hand-written asm statement with a memory clobber, and ten of
         // them inside the loop above made ten chains of LDS reads run one after the other -- 10,600 of an iteration's 20,700 clocks)
 #pragma unroll
-        for (int ch = 0; ch < XG_MAXCH; ++ch)
+        for (int ch = 0; ch < MC; ++ch)
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass)
                 if (grow[ch][pass] >= 0 && sl == 0) xg_put(gb, L.ap + grow[ch][pass], srow[ch][pass], tagA, fast);
         if (lane == 0) {
 #pragma unroll
-            for (int ch = 0; ch < XG_MAXCH; ++ch) if (ch < nch) sh[ch][w] = acc[ch];
+            for (int ch = 0; ch < MC; ++ch) if (ch < nch) sh[ch][w] = acc[ch];
         }
         xg_sync();
         if (tid == 0) {
 #pragma unroll
-            for (int ch = 0; ch < XG_MAXCH; ++ch)
+            for (int ch = 0; ch < MC; ++ch)
                 if (ch < nch) {
                     double t = 0;
                     for (int i = 0; i < CGT / 64; ++i) t += sh[ch][i];
@@ -2130,7 +2131,7 @@ struct fem_model {
     bool cg_resident = false, cgr_big = false; int cgr_lds = 0, cgr_ldn = 0;
     // k_fem_cg_xcd (one mesh): participants, LDS doubles per vector / blocks per chunk region, LDS bytes, the per-workgroup plan, the
     // barrier block and how far its counter has been driven
-    bool cg_xcd = false; int xg_P = 0, xg_ldr = 0, xg_ldq = 0, xg_lds = 0; int4 *d_xg_plan = nullptr; XgCtl *d_xg_ctl = nullptr; unsigned xg_bar = 0;
+    bool cg_xcd = false; int xg_P = 0, xg_ldr = 0, xg_ldq = 0, xg_lds = 0, xg_mc = 0; int4 *d_xg_plan = nullptr; XgCtl *d_xg_ctl = nullptr; unsigned xg_bar = 0;
     char *d_xg_gran = nullptr;   // its tagged 16-byte granules (xg_layout)
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -2270,6 +2271,13 @@ void coarse_correction(fem_model *m, hipStream_t st, const double *src, double *
     m->prof.stop(6, st);
 }
 
+// the variant of k_fem_cg_xcd a model runs: rows per SpMV chunk x chunks per workgroup
+inline const void *xg_kernel(int spb, int mc)
+{
+    if (spb == 48) return mc == 1 ? reinterpret_cast<const void *>(k_fem_cg_xcd<48, 1>) : mc == 3 ? reinterpret_cast<const void *>(k_fem_cg_xcd<48, 3>) : reinterpret_cast<const void *>(k_fem_cg_xcd<48, 6>);
+    return mc == 1 ? reinterpret_cast<const void *>(k_fem_cg_xcd<96, 1>) : mc == 3 ? reinterpret_cast<const void *>(k_fem_cg_xcd<96, 3>) : reinterpret_cast<const void *>(k_fem_cg_xcd<96, 6>);
+}
+
 void launch_iter(fem_model *m, hipStream_t st)
 {
     const dim3 g = grid_cg(m);
@@ -2319,9 +2327,14 @@ void run_iters(fem_model *m, int n, hipStream_t st)
     if (m->xcd_now()) {
         if (n <= 0) return;
         m->prof.start(5, st);
-        hipLaunchKernelGGL(m->spb == 48 ? k_fem_cg_xcd<48> : k_fem_cg_xcd<96>, dim3(XG_STRIDE * XG_MAXP), dim3(CGT), m->xg_lds, st, m->d_vals_b,
-                           m->d_bcol3, m->d_bp, m->ndof, m->nchunk, m->nchunk_s, n, m->cg_it & 1, m->d_sc, m->d_p, m->d_dinv, m->d_x, m->d_r,
-                           (void *)m->d_xg_gran, (const int4 *)m->d_xg_plan, m->xg_P, m->xg_ldr, m->xg_ldq, m->d_xg_ctl, m->xg_bar);
+        {
+            int cur = m->cg_it & 1;
+            void *gran = m->d_xg_gran;
+            const int4 *plan = m->d_xg_plan;
+            void *args[] = {&m->d_vals_b, &m->d_bcol3, &m->d_bp, &m->ndof, &m->nchunk, &m->nchunk_s, &n, &cur, &m->d_sc, &m->d_p, &m->d_dinv, &m->d_x,
+                            &m->d_r, &gran, &plan, &m->xg_P, &m->xg_ldr, &m->xg_ldq, &m->d_xg_ctl, &m->xg_bar};
+            (void)hipLaunchKernel(xg_kernel(m->spb, m->xg_mc), dim3(XG_STRIDE * XG_MAXP), dim3(CGT), args, (size_t)m->xg_lds, st);
+        }
         m->prof.stop(5, st);
         m->xg_bar += 2u * (unsigned)n;                        // the granules' tags: two per iteration, never reused (fem_cg_setup clears the buffer)
         m->cg_it = 2 * ((m->cg_it + n + 1) / 2);              // both rz slots are current after the launch
@@ -2509,7 +2522,7 @@ struct HostPlan {
     std::vector<int> cmesh, cmesh_s, bp, bcol3, rcfirst;
     std::vector<int4> minfo, minfo_s, rcd, xg;   // xg: k_fem_cg_xcd's plan, {first SpMV chunk, end, first dof, end} per workgroup
     bool resident = false, big = false, xcd = false;
-    int xg_P = 0, xg_ldr = 0, xg_ldq = 0; size_t xg_lds = 0;
+    int xg_P = 0, xg_ldr = 0, xg_ldq = 0, xg_mc = 0; size_t xg_lds = 0;
     size_t resident_lds = 0;
     int maxrows = 0;
 };
@@ -2656,9 +2669,10 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
             maxr = std::max(maxr, hi - lo);
             P.xg.push_back(make_int4(c0, c1, lo, hi));
         }
-        const size_t lds = ((size_t)2 * maxr + (size_t)3 * XG_MAXCH * std::max(maxq, 1) + 2) * sizeof(double);   // (+ the zero slot)
+        const int mc = kch <= 1 ? 1 : kch <= 3 ? 3 : XG_MAXCH;   // the kernel's template variants
+        const size_t lds = ((size_t)2 * maxr + (size_t)3 * mc * std::max(maxq, 1) + 2) * sizeof(double);   // (+ the zero slot)
         ok = ok && maxq <= XG_MAXQ * CGT && lds <= 150 * 1024;
-        if (ok) { P.xcd = true; P.xg_P = Pn; P.xg_ldr = maxr; P.xg_ldq = std::max(maxq, 1); P.xg_lds = lds; }
+        if (ok) { P.xcd = true; P.xg_P = Pn; P.xg_ldr = maxr; P.xg_ldq = std::max(maxq, 1); P.xg_lds = lds; P.xg_mc = mc; }
         else P.xg.clear();
     }
     return ORBX_OK;
@@ -2741,9 +2755,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
             for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<false, false>), reinterpret_cast<const void *>(k_fem_cg_resident<false, true>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
     }
-    if (e == hipSuccess && P.xcd && P.xg_lds > 48 * 1024)
-        e = hipFuncSetAttribute(m->spb == 48 ? reinterpret_cast<const void *>(k_fem_cg_xcd<48>) : reinterpret_cast<const void *>(k_fem_cg_xcd<96>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.xg_lds);
+    if (e == hipSuccess && P.xcd && P.xg_lds > 48 * 1024) e = hipFuncSetAttribute(xg_kernel(m->spb, P.xg_mc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.xg_lds);
     if (e == hipSuccess && m->kz_lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cz_kz), hipFuncAttributeMaxDynamicSharedMemorySize, m->kz_lds);
     if (e == hipSuccess && m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),
@@ -2754,7 +2766,7 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
         return orbx::set_error(ORBX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
     }
     if (P.resident) { m->cg_resident = true; m->cgr_lds = (int)P.resident_lds; m->cgr_ldn = P.maxrows; }
-    if (P.xcd) { m->cg_xcd = true; m->xg_P = P.xg_P; m->xg_ldr = P.xg_ldr; m->xg_ldq = P.xg_ldq; m->xg_lds = (int)P.xg_lds; }
+    if (P.xcd) { m->cg_xcd = true; m->xg_P = P.xg_P; m->xg_ldr = P.xg_ldr; m->xg_ldq = P.xg_ldq; m->xg_lds = (int)P.xg_lds; m->xg_mc = P.xg_mc; }
     m->name_kernel_kinds();
     *out = m;
     return ORBX_OK;
