@@ -17,6 +17,7 @@
 // whole batch (shared topology: they stay in L2); CG vectors x, r, p, Ap [M][n] f64.  SpMV streams
 // the values from HBM once per iteration; reductions are fixed-order (chunk partials
 // summed in index order), so results are run-to-run reproducible.
+#include <atomic>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -2133,6 +2134,7 @@ struct fem_model {
     // barrier block and how far its counter has been driven
     bool cg_xcd = false; int xg_P = 0, xg_ldr = 0, xg_ldq = 0, xg_lds = 0, xg_mc = 0; int4 *d_xg_plan = nullptr; XgCtl *d_xg_ctl = nullptr; unsigned xg_bar = 0;
     char *d_xg_gran = nullptr;   // its tagged 16-byte granules (xg_layout)
+    hipEvent_t xg_done = nullptr; bool xg_inflight = false;   // admission: see xg_admit
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -2171,11 +2173,39 @@ struct fem_model {
 
 namespace {
 
+// Admission of k_fem_cg_xcd launches.  A launch parks up to 32 workgroups that wait for EACH OTHER, and such a workgroup fills its compute
+// unit (512 registers per lane): the chip holds 256 of them.  More than XG_MAX_INFLIGHT launches at once (models solved from many host
+// threads, or queued on many streams) could leave every launch with some of its workgroups resident and none complete -- they would spin
+// until their timeouts.  So the library counts the launches it has in flight (an event behind each; settled when the model's next call
+// finds it complete, at fem_cg_result, or at destruction) and sends a call beyond the limit down the launch-per-phase path instead, which
+// gives the same bits.
+constexpr int XG_MAX_INFLIGHT = 6;
+std::atomic<int> g_xg_inflight{0};
+void xg_settle(fem_model *m, bool wait)
+{
+    if (!m->xg_inflight) return;
+    if (wait) (void)hipEventSynchronize(m->xg_done);
+    else if (hipEventQuery(m->xg_done) != hipSuccess) return;
+    m->xg_inflight = false;
+    g_xg_inflight.fetch_sub(1);
+}
+bool xg_admit(fem_model *m)
+{
+    xg_settle(m, false);
+    if (m->xg_inflight) return true;                    // this model's own earlier launch, same stream order: no new seat needed
+    if (g_xg_inflight.fetch_add(1) >= XG_MAX_INFLIGHT) { g_xg_inflight.fetch_sub(1); return false; }
+    if (!m->xg_done && hipEventCreateWithFlags(&m->xg_done, hipEventDisableTiming) != hipSuccess) { m->xg_done = nullptr; g_xg_inflight.fetch_sub(1); return false; }
+    m->xg_inflight = true;
+    return true;
+}
+
 void fem_free(fem_model *m)
 {
     void *ptrs[] = {m->d_tables, m->d_ke, m->d_vals, m->d_a, m->d_f, m->d_u, m->d_e, m->d_b, m->d_x, m->d_r,
                     m->d_p, m->d_Ap, m->d_dinv, m->d_part[0], m->d_part[1], m->d_part[2], m->d_part[3], m->d_sc, m->d_tr_points, m->d_tr_top, m->d_tr_u0,
                     m->d_tr_derived, m->d_tr_ids, m->d_tr_done, m->d_ke1, m->d_vals_b, m->d_cz, m->d_cznode, m->d_cy, m->d_czptr, m->d_ac, m->d_aci, m->d_cw, m->d_cv, m->d_cwv, m->d_czmax, m->d_cmask, m->d_xg_ctl, m->d_xg_gran};
+    xg_settle(m, true);
+    if (m->xg_done) (void)hipEventDestroy(m->xg_done);
     if (m->stream) (void)hipStreamSynchronize(m->stream); // blocks go back to the cache: nothing may still use them
     for (void *q : ptrs)
         if (q) dfree(q);
@@ -2324,8 +2354,7 @@ void run_iters(fem_model *m, int n, hipStream_t st)
         m->cg_it += 2 * ((n + 1) / 2);   // both rz slots are current after the launch: keep the parity of the other path even
         return;
     }
-    if (m->xcd_now()) {
-        if (n <= 0) return;
+    if (m->xcd_now() && n > 0 && xg_admit(m)) {
         m->prof.start(5, st);
         {
             int cur = m->cg_it & 1;
@@ -2336,6 +2365,7 @@ void run_iters(fem_model *m, int n, hipStream_t st)
             (void)hipLaunchKernel(xg_kernel(m->spb, m->xg_mc), dim3(XG_STRIDE * XG_MAXP), dim3(CGT), args, (size_t)m->xg_lds, st);
         }
         m->prof.stop(5, st);
+        (void)hipEventRecord(m->xg_done, st);
         m->xg_bar += 2u * (unsigned)n;                        // the granules' tags: two per iteration, never reused (fem_cg_setup clears the buffer)
         m->cg_it = 2 * ((m->cg_it + n + 1) / 2);              // both rz slots are current after the launch
         return;
@@ -3352,6 +3382,7 @@ int fem_cg_result(fem_model *m, double *x, double *relres)
     std::vector<CgScal> sc(relres ? m->nseg : 0);
     if (x) ORBX_HIP(hipMemcpyAsync(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost, st));
     if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, st));
+    xg_settle(m, true);
     unsigned xg_abort = 0;   // k_fem_cg_xcd: a barrier that timed out (every workgroup left; the iterate is not to be used)
     if (m->d_xg_ctl) ORBX_HIP(hipMemcpyAsync(&xg_abort, &m->d_xg_ctl->abort_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));

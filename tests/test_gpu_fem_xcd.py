@@ -103,3 +103,38 @@ def test_solve_to_tolerance_and_two_level_keep_their_paths():
     prof = fea.profile_read()
     assert not prof.get("k_fem_cg_xcd", (0, 0))[1] and prof["k_fem_spmv"][1] == 20
     fea.cg_preconditioner("jacobi")
+
+
+def test_many_models_solved_at_once_from_many_threads():
+    """Twelve threads, a model each, every one solving its own mesh over and over: more one-launch kernels than the chip can hold
+    complete sets of waiting workgroups for.  The library admits six at a time and sends the rest down the launch-per-phase path
+    (same bits), so nothing waits for a workgroup that cannot be scheduled: no barrier times out, every result is the
+    single-threaded one."""
+    import threading
+    models = []
+    for k in range(12):
+        nodes, tets, fixed, load = synth_tet_mesh(ncell=6 + k % 4, seed=20 + k)
+        fea, b = _model(nodes, tets, fixed, load)
+        models.append((fea, b))
+    os.environ["FEM_CG_XCD"] = "0"
+    want = []
+    for fea, b in models:
+        fea.cg_setup(b); fea.cg_iterate(80)
+        want.append(fea.cg_result()[0].tobytes())
+    os.environ.pop("FEM_CG_XCD", None)
+    errors = []
+
+    def work(k):
+        fea, b = models[k]
+        try:
+            for rep in range(15):
+                fea.cg_setup(b); fea.cg_iterate(30); fea.cg_iterate(50)
+                if fea.cg_result()[0].tobytes() != want[k]:
+                    errors.append((k, rep, "differs")); return
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(12)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors[:3]
