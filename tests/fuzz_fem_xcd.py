@@ -1,0 +1,65 @@
+"""Differential fuzz of the one-launch single-mesh CG (k_fem_cg_xcd): random box meshes (1 .. 14 cells per side, cubic or not, some
+with their node numbering shuffled -- column ranges as wide as the mesh) and chains of tetrahedra, random slicing of the iterations
+into launches with the launch-per-phase path taking some slices; x and the residuals must equal the launch-per-phase path BIT FOR BIT
+and, for up to 40 iterations, the oracle's CG at 1e-5 (the thin boxes and chains here are badly conditioned at nu = 0.495: past 50
+iterations of a CG that is not converging yet, device and oracle drift apart like any two roundings of it do -- 6e-5 at 60, 9e-3 at 88
+on a 1 x 2 x 7 box -- while the two device paths stay bit-identical; one-cell-thick boxes are compared between the paths only).  usage (GPU box): python tests/fuzz_fem_xcd.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+import oracle
+from orb_slam2_e_amd.fem import FEA2, FEM_TET4
+from orb_slam2_e_amd.synth import synth_tet_chain, synth_tet_mesh
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+RTOL = 1e-5
+bad = took = 0
+for case in range(n):
+    if rng.random() < 0.25:
+        nn = int(rng.integers(4, 2800))
+        nodes, tets, fixed, load = synth_tet_chain(nn, seed=case)
+        desc = f"chain nn={nn}"
+        well = nn >= 40
+    else:
+        d = tuple(int(v) for v in rng.integers(1, 15, 3))
+        if (d[0] + 1) * (d[1] + 1) * (d[2] + 1) > 3000: d = tuple(min(v, 12) for v in d)
+        nodes, tets, fixed, load = synth_tet_mesh(d, 7000 + case)
+        desc = f"grid {d}"
+        well = min(d) >= 2           # (one-cell-thick boxes: the oracle comparison is skipped, see above)
+        if rng.random() < 0.3:                       # shuffled numbering: every workgroup's column range is (nearly) the whole mesh
+            perm = rng.permutation(len(nodes)); inv = np.argsort(perm)
+            nodes = nodes[perm]; tets = inv[tets].astype(np.int32)
+            fd = np.zeros(3 * len(perm), bool); fd[fixed] = True
+            fixed = np.nonzero(fd.reshape(-1, 3)[perm].ravel())[0].astype(np.int32)
+            load = load.reshape(-1, 3)[perm].ravel()
+            desc += " shuffled"
+    fea = FEA2(nodes, tets, FEM_TET4)
+    fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
+    b = (load * rng.uniform(0.5, 2.0))[None].copy(); b[:, fixed] = 0
+    iters = int(rng.integers(1, 90))
+    cuts = sorted(set(int(v) for v in rng.integers(1, iters + 1, int(rng.integers(0, 4))))) + [iters]
+    slices = [b_ - a_ for a_, b_ in zip([0] + cuts[:-1], cuts) if b_ > a_]
+    os.environ["FEM_CG_XCD"] = "0"
+    fea.cg_setup(b); fea.cg_iterate(iters); x0, r0 = fea.cg_result()
+    fea.profile(True)
+    fea.cg_setup(b)
+    for s_ in slices:
+        os.environ["FEM_CG_XCD"] = "0" if rng.random() < 0.25 else "1"
+        fea.cg_iterate(s_)
+    x1, r1 = fea.cg_result()
+    os.environ.pop("FEM_CG_XCD", None)
+    took += bool(fea.profile_read().get("k_fem_cg_xcd", (0, 0))[1])
+    rp, col, val = fea.csr(0)
+    ox, _, orel = oracle.fem_cg(rp, col, val, b[0], iters, 0.0)
+    ok = x1.tobytes() == x0.tobytes() and r1.tobytes() == r0.tobytes() and np.isfinite(x1).all()
+    if iters <= 40 and well:
+        ok = ok and np.abs(x1[0] - ox).max() <= RTOL * max(np.abs(ox).max(), 1e-300) and abs(r1[0] - orel) <= RTOL * orel + 1e-7   # (at the convergence floor the recurrence residuals of two roundings differ: 6.9e-9 against 3.5e-9 seen)
+    if not ok:
+        bad += 1
+        print("MISMATCH", desc, "dofs", fea.Ksize, "iters", iters, "slices", slices, "| paths bit-equal:", x1.tobytes() == x0.tobytes(), r1.tobytes() == r0.tobytes(),
+              "| vs oracle x", np.abs(x1[0] - ox).max() / max(np.abs(ox).max(), 1e-300), "relres", r1[0], orel, flush=True)
+print("cases", n, "ran the one-launch kernel", took, "mismatches", bad)
+sys.exit(1 if bad else 0)

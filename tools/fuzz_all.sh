@@ -1,5 +1,5 @@
 #!/bin/bash
-# All nine differential fuzzers against the oracle, one line each (GPU box, repo root): tools/fuzz_all.sh <outfile> [seed0]
+# All ten differential fuzzers against the oracle, one line each (GPU box, repo root): tools/fuzz_all.sh <outfile> [seed0]
 # Counts sized for ~10 minutes in all; every fuzzer under its own timeout.
 OUT=${1:-gpurun_out/fuzz_all.log}; S=${2:-341}
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$GRAFT_REPO_ROOT
@@ -14,3 +14,4 @@ run fuzz_frames 6000 $((S+5))
 run fuzz_loops 400 $((S+6))
 run fuzz_fem_cg 200 $((S+7)) 400
 run fuzz_fem_stereo 150 $((S+8))
+run fuzz_fem_xcd 250 $((S+9))
