@@ -2984,6 +2984,26 @@ int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_
     return ORBX_OK;
 }
 
+int fem_plan_single_cg(int eltype, int nn, const int32_t *elems, int ne, int32_t *info6, int32_t *plan)
+{
+    if (!elems || !info6 || nn < 1 || ne < 1) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
+    int npe = 0;
+    std::vector<long long> node0, elem0;
+    const int32_t mnn[1] = {nn}, mne[1] = {ne};
+    int rc = check_batch(eltype, 1, mnn, mne, elems, npe, node0, elem0);
+    if (rc != ORBX_OK) return rc;
+    fem_model m;
+    HostPlan P;
+    Symbolic y;
+    build_symbolic(npe, nn, ne, elems, y);
+    rc = plan_model(&m, eltype, npe, 1, nn, ne, 3500, 0.495f, 0.577350269f, y, 0, nullptr, nullptr, P);
+    if (rc != ORBX_OK) return rc;
+    const int v[6] = {P.xcd ? 1 : 0, P.xg_P, P.xg_mc, (int)P.xg_lds, m.nchunk, m.nchunk_s};
+    memcpy(info6, v, sizeof(v));
+    if (plan && P.xcd) memcpy(plan, P.xg.data(), sizeof(int4) * P.xg.size());
+    return ORBX_OK;
+}
+
 int fem_batch_offsets(const fem_model *m, int32_t *node0, int32_t *elem0, int32_t *nnz0)
 {
     if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");

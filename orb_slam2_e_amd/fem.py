@@ -271,6 +271,18 @@ class _PlanInfo(C.Structure):
                                                                                                      ("rows_lds", C.c_int32), ("reserved", C.c_int32)]
 
 
+def plan_single_cg(elems, nn, nElType):
+    """fem_plan_single_cg: how the CG of ONE mesh of this topology will run (host only).  Returns a dict: eligible (the one-launch
+    kernel k_fem_cg_xcd), workgroups, chunks_per_workgroup, lds, nchunk, nchunk_s, plan[workgroups, 4]."""
+    L = lib()
+    e = np.ascontiguousarray(elems, np.int32).reshape(-1, _NPE[nElType])
+    info = np.zeros(6, np.int32); pl = np.zeros((32, 4), np.int32)
+    bind(L.fem_plan_single_cg, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
+    check(L.fem_plan_single_cg(nElType, int(nn), _p(e), len(e), _p(info), _p(pl)))
+    return {"eligible": bool(info[0]), "workgroups": int(info[1]), "chunks_per_workgroup": int(info[2]), "lds": int(info[3]),
+            "nchunk": int(info[4]), "nchunk_s": int(info[5]), "plan": pl[:info[1]].copy()}
+
+
 def plan(elems_list, nn_list, nElType, uniform_copies=0):
     """fem_plan: the host-side planning of fem_create (uniform_copies > 0, one mesh) / fem_create_batch (0) without any
     device call.  Returns a dict: the info fields + rowptr, lcol, diag, bp, bcol3, rcd[nrcd, 4], rcfirst, chunk_mesh."""

@@ -152,3 +152,39 @@ def test_symbolic_phase_two_formulations_agree():
     for npe, et in ((4, FEM_TET4), (6, FEM_C3D6), (8, FEM_C3D8)):
         run(et, 50, rng.integers(0, 50, (300, npe)))          # soup: repeated ids inside elements, isolated nodes
     run(FEM_TET4, 7, np.zeros((0, 4), np.int32))
+
+
+def test_single_mesh_cg_plan_covers_every_chunk_and_every_column():
+    """fem_plan_single_cg (host only): the plan of the one-launch CG kernel.  Every SpMV chunk belongs to exactly one workgroup, in
+    contiguous runs; every workgroup's column range holds its own rows, its vector chunk's rows and every column its blocks read
+    (checked against the CSR pattern of fem_plan), is even-aligned, and fits the LDS the plan asks for; meshes beyond 8,192 dofs
+    are not eligible; the kernel variant (1 / 3 / 6 chunks per workgroup) is the smallest that fits."""
+    from orb_slam2_e_amd.fem import FEM_TET4, plan, plan_single_cg
+    from orb_slam2_e_amd.synth import synth_tet_chain, synth_tet_mesh
+    for ncell, nn_chain in ((12, None), (2, None), (7, None), (None, 2596), (None, 2730), (None, 2731), (None, 27)):
+        nodes, tets, fixed, load = synth_tet_mesh(ncell) if ncell else synth_tet_chain(nn_chain)
+        nn = len(nodes)
+        sp = plan_single_cg(tets, nn, FEM_TET4)
+        assert sp["eligible"] == (3 * nn <= 8192), (nn, sp)
+        if not sp["eligible"]:
+            continue
+        full = plan([tets], [nn], FEM_TET4, uniform_copies=1)
+        spb, ndof = full["spb"], 3 * nn
+        assert sp["nchunk"] == (ndof + 255) // 256 and sp["nchunk_s"] == (ndof + spb - 1) // spb
+        P, pl = sp["workgroups"], sp["plan"]
+        assert 1 <= P <= 32 and P >= sp["nchunk"]
+        kch = max(int(c1 - c0) for c0, c1, _, _ in pl)
+        assert sp["chunks_per_workgroup"] == (1 if kch <= 1 else 3 if kch <= 3 else 6)
+        owned = np.concatenate([np.arange(c0, c1) for c0, c1, _, _ in pl])
+        assert np.array_equal(owned, np.arange(sp["nchunk_s"]))                       # every chunk once, in order
+        rowptr, lcol = full["rowptr"], full["lcol"]
+        for w, (c0, c1, lo, hi) in enumerate(pl):
+            assert lo % 2 == 0 and hi % 2 == 0 and 0 <= lo < hi <= ndof + 1
+            need = []
+            if c1 > c0:
+                r0, r1 = c0 * spb, min(c1 * spb, ndof)
+                need += [r0, r1 - 1, int(lcol[rowptr[r0]:rowptr[r1]].min()), int(lcol[rowptr[r0]:rowptr[r1]].max())]
+            if w < sp["nchunk"]:
+                need += [256 * w, min(256 * w + 256, ndof) - 1]
+            assert lo <= min(need) and max(need) < hi, (w, lo, hi, need)
+        assert sp["lds"] <= 150 * 1024 and sp["lds"] >= 16 * int((pl[:, 3] - pl[:, 2]).max())
