@@ -24,7 +24,7 @@ def _model(nodes, tets, fixed, load):
 
 
 def _run(fea, b, slices, xcd):
-    os.environ["FEM_CG_XCD"] = "1" if xcd else "0"
+    os.environ["FEM_CG_XCD"] = {True: "1", False: "0"}.get(xcd, xcd)
     try:
         fea.profile(True)
         fea.cg_setup(b)
@@ -138,3 +138,13 @@ def test_many_models_solved_at_once_from_many_threads():
     for t in ts: t.start()
     for t in ts: t.join()
     assert not errors, errors[:3]
+
+
+def test_system_scope_granules_give_the_same_bits():
+    """FEM_CG_XCD=safe: the kernel's fallback for participants that do NOT share an XCD (system-scope granules on both sides, served
+    by memory) -- never taken by itself so far, so forced here: same bits, more time per iteration."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
+    fea, b = _model(nodes, tets, fixed, load)
+    xs, rs, ps = _run(fea, b, [40, 25], xcd="safe")
+    xb, rb, pb = _run(fea, b, [65], xcd=False)
+    assert ps["k_fem_cg_xcd"][1] == 2 and xs.tobytes() == xb.tobytes() and rs.tobytes() == rb.tobytes()
