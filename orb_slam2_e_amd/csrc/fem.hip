@@ -840,350 +840,6 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_dir(int ndof, int nchunk, int cu
     if (sg.chunk == 0 && threadIdx.x == 0) { sc[sg.mesh].rz[cur ^ 1] = rz2; sc[sg.mesh].rr = rr; }
 }
 
-// ---- ONE mesh, all iterations of a call in ONE launch, spread over the compute units of one XCD (k_fem_cg_xcd).
-// A single mesh cannot use k_fem_cg_resident's trick at speed (one compute unit's bandwidth: measured slower) and pays 3 launches of
-// ~3 us each per iteration on the launch-per-phase path.  Here P <= 32 workgroups of a 256-workgroup launch stay resident for the
-// whole call -- blockIdx % 8 == 0: workgroups are dealt round-robin over the XCDs, so these share one (for speed only: nothing below
-// relies on it).  The arithmetic is the launch-per-phase path's, chunk for chunk: workgroup `rank` owns the SpMV chunks [c0, c1)
-// (SPB rows each: same lanes, same LDS partials, same DPP sums as k_fem_spmv, same p.Ap partial per chunk) and the vector chunk
-// `rank` (RPB rows: k_fem_cg_update's and k_fem_cg_dir's formulas, one row per thread, same block sums); chunk partials are joined
-// in chunk_sum's order -- x, r, p and the scalars come out bit for bit.
-//   * the matrix never moves: a thread keeps the nine values and the column of its blocks (<= XG_MAXCH x XG_MAXQ) in registers
-//   * p lives in LDS, replicated: every workgroup keeps p (and 1/diag) over the column range [lo, hi) its blocks and rows touch and
-//     forms p = r/diag + beta p there itself, from the r its peers published -- p is never handed over
-//   * handed over per iteration: K p rows, r rows and three arrays of chunk partials, every value as a TAGGED 16-byte granule
-//     {value, tag, check}: one sc1 store by the producer, sc1 loads polled by the consumer until tag (= launch base + 2 it + phase) and
-//     check word match -- no counter, no store drain, no separate barrier: an iteration is TWO store -> load hops across the fabric.
-//     (A first version with two counter barriers per iteration -- stores, s_waitcnt, agent-scope add, poll, loads -- made ~8
-//     dependent fabric round trips of an iteration: 10.9 us on the 6,591-dof mesh, 7.1 on a 648-dof one; tools/ubench/xcd_barrier.hip
-//     prices the pieces: 1.2 us per barrier at P = 32, 2.3 us to stage 53 KB.)  MI355X_MICROARCH.md observes 16-byte sc1 granules
-//     untorn on gfx950 without promising it: the check word (value ^ tag ^ constant) turns a torn granule into "not there yet".
-//   * no write-after-read hazard without barriers: a slot is rewritten only by a workgroup that has since consumed data whose
-//     existence implies the slot's readers are done (K p rows and r rows: their consumer produced what the writer waited for; the
-//     chunk partials are double-buffered by iteration parity, and a workgroup two iterations ahead is impossible -- each phase needs
-//     every workgroup's partial of the phase before).
-// Every spin is bounded: a timeout raises the abort word, every workgroup leaves, and fem_cg_result / fem_cg report the failure.
-constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 32;
-constexpr unsigned XG_SPIN = 1u << 22, XG_KEY = 0x5bd1e995u;
-struct XgCtl { unsigned abort_flag, pad[31]; };
-typedef unsigned xg_u32x4 __attribute__((ext_vector_type(4)));
-// Two cache policies for the granules, chosen per launch by the participants themselves:
-//   SAME_XCD  every participant reads its XCC id at start and publishes it; if all are equal, the workgroups share ONE L2, which is
-//             then the point of coherence: plain stores (write-through L1 -> L2, the line stays in L2) and sc1 loads (past L1, served
-//             by L2) -- a hop is an L2 round trip (tools/ubench/xcd_barrier.hip, `plain-stores 1 stride 8`: 0 stale values in 20,000
-//             rounds; the same run across XCDs reads stale data at once, which is why this mode is only taken on the ids' evidence)
-//   otherwise sc0 sc1 on both sides (system scope: served by memory, never by an L2 line) -- correct for any placement, and three
-//             times slower per hop (16.4 us per iteration on the 6,591-dof mesh when it was the only mode)
-__device__ __forceinline__ void xg_put(char *gb, int slot, double v, unsigned tag, bool same_xcd)
-{
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    xg_u32x4 g;
-    g.x = (unsigned)b; g.y = (unsigned)(b >> 32); g.z = tag; g.w = g.x ^ g.y ^ tag ^ XG_KEY;
-    char *a = gb + 16 * (size_t)slot;
-    if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a), "v"(g) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a), "v"(g) : "memory");
-}
-__device__ __forceinline__ bool xg_ok(const xg_u32x4 g, unsigned tag) { return g.z == tag && g.w == (g.x ^ g.y ^ tag ^ XG_KEY); }
-__device__ __forceinline__ double xg_val(const xg_u32x4 g) { return __builtin_bit_cast(double, ((unsigned long long)g.y << 32) | g.x); }
-// Wave-wide poll of U granules per lane (slot < 0: nothing wanted) until every wanted one carries `tag`; false: timed out / aborted.
-template <int U>
-__device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[U], unsigned tag, double (&out)[U], XgCtl *ctl, unsigned where, bool same_xcd)
-{
-    bool pend[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { pend[u] = slot[u] >= 0; out[u] = 0; }
-    for (unsigned spins = 0;; ++spins) {
-        xg_u32x4 g[U];
-        // Hand-written loads: to the compiler a buffer-load builtin is a pure read of an unchanging address, and it hoisted all U of them
-        // out of this loop (neither the builtin's volatile bit nor a memory clobber in the loop stopped it) -- the bug of this kernel's
-        // first day: every wave but the one that had stored the granule itself spun on a register.  U loads in flight, one wait; the
-        // empty asm statements behind it tie every later use of g[u] to a point after the wait.
-        // (only what is still wanted is asked for again: the r rows of a range are there rounds before the last chunk partial is)
-        if (same_xcd) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(g[u]) :: "memory");
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (pend[u] && xg_ok(g[u], tag)) { out[u] = xg_val(g[u]); pend[u] = false; }
-            any = any || pend[u];
-        }
-        if (!__any(any)) return true;
-        if (spins > XG_SPIN || ((spins & 1023u) == 1023u && __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            if (spins > XG_SPIN) {      // the first to time out says where (development aid: fem_debug_xcd reads the word)
-                unsigned expect = 0;
-                __hip_atomic_compare_exchange_strong(&ctl->abort_flag, &expect, where | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-// Workgroup barrier for data that lives in LDS only: __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)` in front
-// of the s_barrier -- every barrier of an iteration then waited for the granule stores in flight to be acknowledged (the row puts behind
-// the product: 5,000 of an iteration's 21,000 clocks).  The waves of k_fem_cg_xcd exchange LDS contents only.
-__device__ __forceinline__ void xg_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// Granule buffer of a model: K p rows | r rows | p.Ap partials x 2 parities | r.z partials x 2 | r.r partials x 2 | XCC ids
-struct XgLayout { int ap, r, pap, rz, rr, id, total; };
-__host__ __device__ inline XgLayout xg_layout(int ndof, int nchunk, int nchunk_s)
-{
-    XgLayout l;
-    l.ap = 0; l.r = ndof; l.pap = 2 * ndof; l.rz = l.pap + 2 * nchunk_s; l.rr = l.rz + 2 * nchunk; l.id = l.rr + 2 * nchunk; l.total = l.id + XG_MAXP;
-    return l;
-}
-// MC: the most SpMV chunks a workgroup owns (1, 3 or 6: small meshes do not pay for six chunks' worth of unrolled code)
-template <int SPB, int MC>
-__global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
-                                                    int ndof, int nchunk, int nchunk_s, int niter, int cur, CgScal *__restrict__ sc,
-                                                    double *__restrict__ p, const double *__restrict__ dinv, double *__restrict__ x,
-                                                    double *__restrict__ r, void *__restrict__ gran, const int4 *__restrict__ plan, int P,
-                                                    int ldr, int ldq, XgCtl *__restrict__ ctl, unsigned base)
-{
-    static_assert(CGT == RPB, "one row of the vector chunk per thread");
-    if (blockIdx.x % XG_STRIDE != 0 || (int)(blockIdx.x / XG_STRIDE) >= P) return;
-    extern __shared__ __align__(16) double lds[];
-    __shared__ double sh[MC][CGT / 64], shv[2][CGT / 64];
-    __shared__ int s_bp[MC][SPB / 3 + 1];
-    __shared__ int s_fail;
-    const int rank = blockIdx.x / XG_STRIDE, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int4 pl = plan[rank];
-    const int c0 = pl.x, nch = pl.y - pl.x, lo = pl.z, rng = pl.w - pl.z;
-    const XgLayout L = xg_layout(ndof, nchunk, nchunk_s);
-    char *gb = static_cast<char *>(gran);
-    double *p_s = lds, *d_s = lds + ldr, *part = lds + 2 * ldr;        // part: MC regions of 3 ldq doubles
-    // the blocks of this thread, for the whole launch
-    float va[MC][XG_MAXQ][9]; int ca[MC][XG_MAXQ]; int nqa[MC], r0a[MC], r1a[MC];
-#pragma unroll
-    for (int ch = 0; ch < MC; ++ch) {
-        nqa[ch] = 0; r0a[ch] = r1a[ch] = 0;
-        if (ch < nch) {
-            const int r0 = (c0 + ch) * SPB, r1 = min(r0 + SPB, ndof);
-            const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
-            if (tid <= (r1 - r0) / 3) s_bp[ch][tid] = bp[r0 / 3 + tid] - q0;
-            nqa[ch] = nq; r0a[ch] = r0; r1a[ch] = r1;
-#pragma unroll
-            for (int u = 0; u < XG_MAXQ; ++u) {
-                const int qq = min(tid + u * CGT, nq - 1);
-                __builtin_memcpy(va[ch][u], vals_b + 9 * (size_t)(q0 + qq), 36);
-                ca[ch][u] = bcol3[q0 + qq] - lo;
-            }
-        }
-    }
-    for (int i = tid; i < rng; i += CGT)
-        if (lo + i < ndof) { p_s[i] = p[lo + i]; d_s[i] = dinv[lo + i]; }
-    if (tid == 0) s_fail = 0;
-    const int row = rank * RPB + tid;
-    const bool vec = rank < nchunk, has = vec && row < ndof;
-    double xv = has ? x[row] : 0, rv = has ? r[row] : 0;
-    const double dv = has ? dinv[row] : 0;
-    double rz = sc[0].rz[cur & 1], rr = sc[0].rr;
-    // where the participants run: every one publishes its XCC id (system scope), every one reads all of them
-    bool fast;
-    {
-        if (tid == 0) xg_put(gb, L.id + rank, (double)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf), base, false);   // HW_REG_XCC_ID, bits 0-3
-        int slot[1]; double got[1];
-        slot[0] = lane < P ? L.id + lane : -1;
-        if (!xg_get<1>(gb, slot, base, got, ctl, 4u | (unsigned)rank << 8 | (unsigned)w << 16, false)) s_fail = 1;
-        const double mine = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(unsigned long long, got[0]) >> 32)) << 32) |
-                                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_bit_cast(unsigned long long, got[0])));   // rank 0's id
-        fast = !__any(lane < P && got[0] != mine) && !(cur & 2);
-    }
-    __syncthreads();
-    if (s_fail) return;
-    const int sub = tid / LPR, sl = tid % LPR;
-    // the row groups of this thread (chunk ch, pass): LDS offset of the row's first partial, its blocks, its row -- fixed for the launch.
-    // Groups that do not exist (ch >= nch, rows past the chunk) read slot 0 of the partials and are never used.
-    constexpr int NPASS = (SPB + CGT / LPR - 1) / (CGT / LPR);
-    // goff: LDS index of the partials sl, sl + 8, sl + 16, sl + 24 of the row (past the row's end: `zero`, a double that stays 0.0, so the
-    // sum needs neither a mask nor a branch); gmore: the row has more than 32 blocks (wave-wide: anymore).
-    int goff[MC][NPASS][4], gbase[MC][NPASS], gnb[MC][NPASS], grow[MC][NPASS];
-    const int zero = 3 * MC * ldq;            // part[zero]: one spare double behind the chunks' regions
-    if (tid == 0) part[zero] = 0.0;
-    bool more = false;
-#pragma unroll
-    for (int ch = 0; ch < MC; ++ch)
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            gbase[ch][pass] = zero; gnb[ch][pass] = 0; grow[ch][pass] = -1;
-            const int rw = r0a[ch] + pass * (CGT / LPR) + sub;
-            if (ch < nch && rw < r1a[ch]) {
-                const int I = (rw - r0a[ch]) / 3, i = rw - r0a[ch] - 3 * I, b0 = s_bp[ch][I];
-                gbase[ch][pass] = 3 * (ch * ldq + b0) + i; gnb[ch][pass] = s_bp[ch][I + 1] - b0; grow[ch][pass] = rw;
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) goff[ch][pass][jj] = sl + LPR * jj < gnb[ch][pass] ? gbase[ch][pass] + 3 * (sl + LPR * jj) : zero;
-            more = more || gnb[ch][pass] > 4 * LPR;
-        }
-    const bool anymore = __any(more) != 0;
-    xg_sync();
-#ifdef XG_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define XG_T(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
-#else
-#define XG_T(k) do { } while (0)
-#endif
-    for (int it = 0; it < niter; ++it) {
-        const unsigned tagA = base + 2u * (unsigned)it + 1u, tagB = tagA + 1u;
-        const int par = it & 1;
-        // ---- K p on the own chunks (k_fem_spmv, phase 1: a lane per block, three row sums parked in LDS)
-#pragma unroll
-        for (int ch = 0; ch < MC; ++ch) {
-            if (ch < nch && tid < nqa[ch]) {
-#pragma unroll
-                for (int u = 0; u < XG_MAXQ; ++u) {
-                    if (u > 0 && tid + u * CGT >= nqa[ch]) continue;   // (k_fem_spmv's lanes past the run repeat its last block: same values to the same slots)
-                    const int qq = tid + u * CGT;
-                    const double *pp = p_s + ca[ch][u];
-                    const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
-                    double *dst = part + 3 * (ch * ldq + qq);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        dst[i] = ((double)va[ch][u][3 * i] * p0 + (double)va[ch][u][3 * i + 1] * p1) + (double)va[ch][u][3 * i + 2] * p2;
-                }
-            }
-        }
-        xg_sync();
-        XG_T(0);   // SpMV phase 1
-        // (phase 2: 8 lanes per row, DPP row_shl sums in a fixed order; the chunk's partial of p.Ap)
-        // No branch, no mask and no loop in here: the <= 48 partials a thread adds are asked for together (a first version -- k_fem_spmv's
-        // loop over a row's blocks, under `if (row < r1)` -- compiled to 72 LDS reads each waited for behind its own branch: 11,000 of
-        // an iteration's 21,000 clocks; a second one with selects kept 48 loop-invariant lane masks in spilled scalar registers: 9,000).
-        // A lane adds the partials sl, sl + 8, .. of its row in that order; the slots past the row's end read a 0.0, and `+ 0.0` changes
-        // nothing (a sum that starts at +0.0 never is -0.0).  Rows of more than 32 blocks take the loop for the rest (wave-uniform test).
-        double acc[MC], srow[MC][NPASS];
-        {
-            double pv[MC][NPASS][4], pr[MC][NPASS];
-#pragma unroll
-            for (int ch = 0; ch < MC; ++ch)
-#pragma unroll
-                for (int pass = 0; pass < NPASS; ++pass) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) pv[ch][pass][jj] = part[goff[ch][pass][jj]];
-                    pr[ch][pass] = p_s[max(grow[ch][pass], lo) - lo];
-                }
-#pragma unroll
-            for (int ch = 0; ch < MC; ++ch) {
-                acc[ch] = 0;
-#pragma unroll
-                for (int pass = 0; pass < NPASS; ++pass) {
-                    double sm = 0;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) sm += pv[ch][pass][jj];
-                    if (anymore)
-                        for (int j = sl + 4 * LPR; j < gnb[ch][pass]; j += LPR) sm += part[gbase[ch][pass] + 3 * j];
-                    sm += dpp_shl_f64<4>(sm);
-                    sm += dpp_shl_f64<2>(sm);
-                    sm += dpp_shl_f64<1>(sm);
-                    srow[ch][pass] = sm;
-                    acc[ch] += grow[ch][pass] >= 0 && sl == 0 ? pr[ch][pass] * sm : 0.0;
-                }
-                acc[ch] = wave_sum_f64(acc[ch]);      // block_sum, all chunks behind one barrier
-            }
-        }
-        // (the rows go out behind the sums, not between them: a store is a hand-written asm statement with a memory clobber, and ten of
-        // them inside the loop above made ten chains of LDS reads run one after the other -- 10,600 of an iteration's 20,700 clocks)
-#pragma unroll
-        for (int ch = 0; ch < MC; ++ch)
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass)
-                if (grow[ch][pass] >= 0 && sl == 0) xg_put(gb, L.ap + grow[ch][pass], srow[ch][pass], tagA, fast);
-        if (lane == 0) {
-#pragma unroll
-            for (int ch = 0; ch < MC; ++ch) if (ch < nch) sh[ch][w] = acc[ch];
-        }
-        xg_sync();
-        if (tid == 0) {
-#pragma unroll
-            for (int ch = 0; ch < MC; ++ch)
-                if (ch < nch) {
-                    double t = 0;
-                    for (int i = 0; i < CGT / 64; ++i) t += sh[ch][i];
-                    xg_put(gb, L.pap + par * nchunk_s + c0 + ch, t, tagA, fast);
-                }
-        }
-        XG_T(1);   // SpMV phase 2 + partials out
-        // ---- alpha = rz / p.Ap; x += alpha p; r -= alpha K p; partials of r.(r/diag) and r.r (k_fem_cg_update)
-        double pAp, api;
-        {
-            int slot[4]; double got[4];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) slot[u] = lane + 64 * u < nchunk_s ? L.pap + par * nchunk_s + lane + 64 * u : -1;
-            slot[3] = has ? L.ap + row : -1;
-            if (!xg_get<4>(gb, slot, tagA, got, ctl, 1u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
-            double v = 0;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) if (lane + 64 * u < nchunk_s) v += got[u];      // chunk_sum's order
-            pAp = wave_sum_f64(v);
-            api = got[3];
-        }
-        XG_T(2);   // hop A: the p.Ap partials and the own K p row
-        const double alpha = cg_ratio(rz, pAp);
-        if (vec) {
-            double s1 = 0, s2 = 0;
-            if (has) {
-                xv += alpha * p_s[row - lo];
-                const double ri = rv - alpha * api;
-                rv = ri;
-                s1 += ri * (ri * dv);
-                s2 += ri * ri;
-                xg_put(gb, L.r + row, ri, tagB, fast);
-            }
-            s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);       // two block_sums behind one barrier
-            if (lane == 0) { shv[0][w] = s1; shv[1][w] = s2; }
-        }
-        xg_sync();
-        if (s_fail) return;
-        if (vec && tid == 0) {
-            double t1 = 0, t2 = 0;
-            for (int i = 0; i < CGT / 64; ++i) { t1 += shv[0][i]; t2 += shv[1][i]; }
-            xg_put(gb, L.rz + par * nchunk + rank, t1, tagB, fast);
-            xg_put(gb, L.rr + par * nchunk + rank, t2, tagB, fast);
-        }
-        // ---- beta = rz_new / rz; p = r/diag + beta p over the own column range, from the r everybody published (k_fem_cg_dir)
-        XG_T(3);   // update + partials out
-        // one poll for the chunk partials and the first XG_SU x 256 rows of the range (ranges beyond that -- irregular numberings --
-        // take further rounds of rows only)
-        double rz2, beta;
-        {
-            int slot[2 + XG_SU]; double got[2 + XG_SU];
-            slot[0] = lane < nchunk ? L.rz + par * nchunk + lane : -1;
-            slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
-#pragma unroll
-            for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[2 + u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
-            if (!xg_get<2 + XG_SU>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
-            rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);       // chunk_sum with <= 32 partials: a lane per partial
-            rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
-            beta = cg_ratio(rz2, rz);
-#pragma unroll
-            for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; if (slot[2 + u] >= 0) p_s[i] = got[2 + u] * d_s[i] + beta * p_s[i]; }
-        }
-        for (int b0 = XG_SU * CGT; b0 < rng; b0 += XG_SU * CGT) {
-            int slot[XG_SU]; double got[XG_SU];
-#pragma unroll
-            for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; slot[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
-            if (!xg_get<XG_SU>(gb, slot, tagB, got, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
-#pragma unroll
-            for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; if (slot[u] >= 0) p_s[i] = got[u] * d_s[i] + beta * p_s[i]; }
-        }
-        rz = rz2;
-        xg_sync();
-        XG_T(4);   // hop B: the r.z partials and the range's r rows; the new p
-        if (s_fail) return;
-    }
-#ifdef XG_TIMING
-    if (tid == 0 && rank < 4) for (int k = 0; k < 5; ++k) ctl->pad[1 + 5 * rank + k] = (unsigned)(tacc[k] / (unsigned long long)max(niter, 1));
-#endif
-    if (has) { x[row] = xv; r[row] = rv; p[row] = p_s[row - lo]; }
-    if (rank == 0 && tid == 0) { sc[0].rz[0] = rz; sc[0].rz[1] = rz; sc[0].rr = rr; }
-}
-
 // ---- Two-level preconditioner (fem_cg_preconditioner(FEM_PRECOND_TWO_LEVEL)): z = r/diag + Z Ac^-1 Z^T r with Z = the six rigid-body
 // modes (three translations, three rotations about the centroid) of 2 x 2 x 2 geometric aggregates of a mesh's nodes -- 48 coarse
 // dofs -- and Ac = Z^T K Z.  Point-Jacobi leaves the smooth, near-rigid error of a near-incompressible solid to thousands of
@@ -1615,6 +1271,494 @@ __global__ __launch_bounds__(1024) void k_fem_cz_apply(const float4 *__restrict_
     const size_t row0 = minfo ? (size_t)minfo[mesh].x : (size_t)mesh * ndof;
     const double t = cz_apply_block(cz + row0 / 3, czptr + 9 * mesh, aci + (size_t)mesh * (CZ_NC * CZ_NC), src + row0, out + row0, accumulate != 0, s_w, s_v);
     if (threadIdx.x == 0) wv[mesh] = t;
+}
+
+// ---- ONE mesh, all iterations of a call in ONE launch, spread over the compute units of one XCD (k_fem_cg_xcd).
+// A single mesh cannot use k_fem_cg_resident's trick at speed (one compute unit's bandwidth: measured slower) and pays 3 launches of
+// ~3 us each per iteration on the launch-per-phase path.  Here P <= 32 workgroups of a 256-workgroup launch stay resident for the
+// whole call -- blockIdx % 8 == 0: workgroups are dealt round-robin over the XCDs, so these share one (for speed only: nothing below
+// relies on it).  The arithmetic is the launch-per-phase path's, chunk for chunk: workgroup `rank` owns the SpMV chunks [c0, c1)
+// (SPB rows each: same lanes, same LDS partials, same DPP sums as k_fem_spmv, same p.Ap partial per chunk) and the vector chunk
+// `rank` (RPB rows: k_fem_cg_update's and k_fem_cg_dir's formulas, one row per thread, same block sums); chunk partials are joined
+// in chunk_sum's order -- x, r, p and the scalars come out bit for bit.
+//   * the matrix never moves: a thread keeps the nine values and the column of its blocks (<= XG_MAXCH x XG_MAXQ) in registers
+//   * p lives in LDS, replicated: every workgroup keeps p (and 1/diag) over the column range [lo, hi) its blocks and rows touch and
+//     forms p = r/diag + beta p there itself, from the r its peers published -- p is never handed over
+//   * handed over per iteration: K p rows, r rows and three arrays of chunk partials, every value as a TAGGED 16-byte granule
+//     {value, tag, check}: one sc1 store by the producer, sc1 loads polled by the consumer until tag (= launch base + 2 it + phase) and
+//     check word match -- no counter, no store drain, no separate barrier: an iteration is TWO store -> load hops across the fabric.
+//     (A first version with two counter barriers per iteration -- stores, s_waitcnt, agent-scope add, poll, loads -- made ~8
+//     dependent fabric round trips of an iteration: 10.9 us on the 6,591-dof mesh, 7.1 on a 648-dof one; tools/ubench/xcd_barrier.hip
+//     prices the pieces: 1.2 us per barrier at P = 32, 2.3 us to stage 53 KB.)  MI355X_MICROARCH.md observes 16-byte sc1 granules
+//     untorn on gfx950 without promising it: the check word (value ^ tag ^ constant) turns a torn granule into "not there yet".
+//   * no write-after-read hazard without barriers: a slot is rewritten only by a workgroup that has since consumed data whose
+//     existence implies the slot's readers are done (K p rows and r rows: their consumer produced what the writer waited for; the
+//     chunk partials are double-buffered by iteration parity, and a workgroup two iterations ahead is impossible -- each phase needs
+//     every workgroup's partial of the phase before).
+// Every spin is bounded: a timeout raises the abort word, every workgroup leaves, and fem_cg_result / fem_cg report the failure.
+constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 32;
+constexpr unsigned XG_SPIN = 1u << 22, XG_KEY = 0x5bd1e995u;
+struct XgCtl { unsigned abort_flag, pad[31]; };
+typedef unsigned xg_u32x4 __attribute__((ext_vector_type(4)));
+// Two cache policies for the granules, chosen per launch by the participants themselves:
+//   SAME_XCD  every participant reads its XCC id at start and publishes it; if all are equal, the workgroups share ONE L2, which is
+//             then the point of coherence: plain stores (write-through L1 -> L2, the line stays in L2) and sc1 loads (past L1, served
+//             by L2) -- a hop is an L2 round trip (tools/ubench/xcd_barrier.hip, `plain-stores 1 stride 8`: 0 stale values in 20,000
+//             rounds; the same run across XCDs reads stale data at once, which is why this mode is only taken on the ids' evidence)
+//   otherwise sc0 sc1 on both sides (system scope: served by memory, never by an L2 line) -- correct for any placement, and three
+//             times slower per hop (16.4 us per iteration on the 6,591-dof mesh when it was the only mode)
+__device__ __forceinline__ void xg_put(char *gb, int slot, double v, unsigned tag, bool same_xcd)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    xg_u32x4 g;
+    g.x = (unsigned)b; g.y = (unsigned)(b >> 32); g.z = tag; g.w = g.x ^ g.y ^ tag ^ XG_KEY;
+    char *a = gb + 16 * (size_t)slot;
+    if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a), "v"(g) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a), "v"(g) : "memory");
+}
+__device__ __forceinline__ bool xg_ok(const xg_u32x4 g, unsigned tag) { return g.z == tag && g.w == (g.x ^ g.y ^ tag ^ XG_KEY); }
+__device__ __forceinline__ double xg_val(const xg_u32x4 g) { return __builtin_bit_cast(double, ((unsigned long long)g.y << 32) | g.x); }
+// Wave-wide poll of U granules per lane (slot < 0: nothing wanted) until every wanted one carries `tag`; false: timed out / aborted.
+template <int U>
+__device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[U], unsigned tag, double (&out)[U], XgCtl *ctl, unsigned where, bool same_xcd)
+{
+    bool pend[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { pend[u] = slot[u] >= 0; out[u] = 0; }
+    for (unsigned spins = 0;; ++spins) {
+        xg_u32x4 g[U];
+        // Hand-written loads: to the compiler a buffer-load builtin is a pure read of an unchanging address, and it hoisted all U of them
+        // out of this loop (neither the builtin's volatile bit nor a memory clobber in the loop stopped it) -- the bug of this kernel's
+        // first day: every wave but the one that had stored the granule itself spun on a register.  U loads in flight, one wait; the
+        // empty asm statements behind it tie every later use of g[u] to a point after the wait.
+        // (only what is still wanted is asked for again: the r rows of a range are there rounds before the last chunk partial is)
+        if (same_xcd) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(g[u]) :: "memory");
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pend[u] && xg_ok(g[u], tag)) { out[u] = xg_val(g[u]); pend[u] = false; }
+            any = any || pend[u];
+        }
+        if (!__any(any)) return true;
+        if (spins > XG_SPIN || ((spins & 1023u) == 1023u && __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (spins > XG_SPIN) {      // the first to time out says where (development aid: fem_debug_xcd reads the word)
+                unsigned expect = 0;
+                __hip_atomic_compare_exchange_strong(&ctl->abort_flag, &expect, where | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// Workgroup barrier for data that lives in LDS only: __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)` in front
+// of the s_barrier -- every barrier of an iteration then waited for the granule stores in flight to be acknowledged (the row puts behind
+// the product: 5,000 of an iteration's 21,000 clocks).  The waves of k_fem_cg_xcd exchange LDS contents only.
+__device__ __forceinline__ void xg_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Granule buffer of a model: K p rows | r rows | p.Ap partials x 2 parities | r.z partials x 2 | r.r partials x 2 | XCC ids | the restriction's 2 x 48 sums x 2 parities
+struct XgLayout { int ap, r, pap, rz, rr, id, cw, total; };
+__host__ __device__ inline XgLayout xg_layout(int ndof, int nchunk, int nchunk_s)
+{
+    XgLayout l;
+    l.ap = 0; l.r = ndof; l.pap = 2 * ndof; l.rz = l.pap + 2 * nchunk_s; l.rr = l.rz + 2 * nchunk; l.id = l.rr + 2 * nchunk; l.cw = l.id + XG_MAXP; l.total = l.cw + 4 * 48;
+    return l;
+}
+// MC: the most SpMV chunks a workgroup owns (1, 3 or 6: small meshes do not pay for six chunks' worth of unrolled code).
+// COARSE: the two-level preconditioner inside the launch, as a THIRD hop per iteration.  Aggregate a belongs to workgroup a % P: with
+// the r.z partials it also polls the r rows of its aggregate's nodes (into LDS, in the aggregate list's order) and restricts them as
+// cz_apply_block does -- the two waves (a, a + 8) of that 1024-thread workgroup are two waves here, same lanes, same order: the same
+// twelve sums bit for bit --, and publishes them; every workgroup then polls the 96 sums, forms v = Ac^-1 w and w.v (cz_apply_block's
+// wave 0, word for word) and Z v row by row over its column range from the by-node table (a closed form per node: the same bits as
+// the list walk).  r.z = the partials + w.v, p = (r/diag + Z v) + beta p: k_fem_cg_dir's expressions.  Bit-identical to the
+// launch-per-phase two-level path of a single mesh (k_fem_cz_apply between k_fem_cg_update and k_fem_cg_dir).
+// (A first version had every workgroup stage ALL of r and run the whole correction itself: no third hop, 28 x 105 KB of granules per
+// iteration through one L2 and sixteen waves' work on four -- 22.9 us per iteration against the launch-per-phase path's 17.9.)
+template <int SPB, int MC, bool COARSE>
+__global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
+                                                    int ndof, int nchunk, int nchunk_s, int niter, int cur, CgScal *__restrict__ sc,
+                                                    double *__restrict__ p, const double *__restrict__ dinv, double *__restrict__ x,
+                                                    double *__restrict__ r, void *__restrict__ gran, const int4 *__restrict__ plan, int P,
+                                                    int ldr, int ldq, XgCtl *__restrict__ ctl, unsigned base, const float4 *__restrict__ cz,
+                                                    const int *__restrict__ czptr, const float4 *__restrict__ cznode, const double *__restrict__ aci, int lda)
+{
+    static_assert(CGT == RPB, "one row of the vector chunk per thread");
+    if (blockIdx.x % XG_STRIDE != 0 || (int)(blockIdx.x / XG_STRIDE) >= P) return;
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double sh[MC][CGT / 64], shv[2][CGT / 64];
+    __shared__ int s_bp[MC][SPB / 3 + 1];
+    __shared__ int s_fail;
+    const int rank = blockIdx.x / XG_STRIDE, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int4 pl = plan[rank];
+    const int c0 = pl.x, nch = pl.y - pl.x, lo = pl.z, rng = pl.w - pl.z;
+    const XgLayout L = xg_layout(ndof, nchunk, nchunk_s);
+    char *gb = static_cast<char *>(gran);
+    double *p_s = lds, *d_s = lds + ldr, *part = lds + 2 * ldr;        // part: MC regions of 3 ldq doubles (+ the zero slot, + 1 of padding)
+    // COARSE: the own aggregate's r, the coarse vectors, and per row of the column range what the prolongation needs (first coarse dof of the row's
+    // aggregate | component << 8 | constrained << 10; the two components of q the row's rotation term multiplies)
+    double *r_a = part + 3 * MC * ldq + 2, *s_w = r_a + lda, *s_v = s_w + 2 * CZ_NC;      // r_a: the own aggregate's r rows (3 per node, list order); s_w[2][48], s_v[48 + 1]
+    float2 *rq = reinterpret_cast<float2 *>(s_v + CZ_NC + 2);
+    int *rinfo = reinterpret_cast<int *>(rq + ldr);
+    double *a_s = reinterpret_cast<double *>(rinfo + ((ldr + 1) & ~1));   // Ac^-1 (48 x 48): read from memory by wave 0's solve it was 48 round trips, 14,000 clocks per iteration
+    // the blocks of this thread, for the whole launch
+    float va[MC][XG_MAXQ][9]; int ca[MC][XG_MAXQ]; int nqa[MC], r0a[MC], r1a[MC];
+#pragma unroll
+    for (int ch = 0; ch < MC; ++ch) {
+        nqa[ch] = 0; r0a[ch] = r1a[ch] = 0;
+        if (ch < nch) {
+            const int r0 = (c0 + ch) * SPB, r1 = min(r0 + SPB, ndof);
+            const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
+            if (tid <= (r1 - r0) / 3) s_bp[ch][tid] = bp[r0 / 3 + tid] - q0;
+            nqa[ch] = nq; r0a[ch] = r0; r1a[ch] = r1;
+#pragma unroll
+            for (int u = 0; u < XG_MAXQ; ++u) {
+                const int qq = min(tid + u * CGT, nq - 1);
+                __builtin_memcpy(va[ch][u], vals_b + 9 * (size_t)(q0 + qq), 36);
+                ca[ch][u] = bcol3[q0 + qq] - lo;
+            }
+        }
+    }
+    for (int i = tid; i < rng; i += CGT)
+        if (lo + i < ndof) { p_s[i] = p[lo + i]; d_s[i] = dinv[lo + i]; }
+    if (tid == 0) s_fail = 0;
+    if constexpr (COARSE) {
+        for (int i = tid; i < CZ_NC * CZ_NC; i += CGT) a_s[i] = aci[i];
+        for (int i = tid; i < rng; i += CGT)
+            if (lo + i < ndof) {
+                const int g = lo + i, n = g / 3, kk = g - 3 * n;
+                const float4 e = cznode[n];
+                const unsigned id = __float_as_uint(e.w);
+                const float q[3] = {e.x, e.y, e.z};
+                rinfo[i] = (int)(6u * (id & 0x0fffffffu)) | kk << 8 | (int)((id >> (28 + kk)) & 1u) << 10;
+                rq[i] = float2{q[(kk + 2) % 3], q[(kk + 1) % 3]};
+            }
+    }
+    const int row = rank * RPB + tid;
+    const bool vec = rank < nchunk, has = vec && row < ndof;
+    double xv = has ? x[row] : 0, rv = has ? r[row] : 0;
+    const double dv = has ? dinv[row] : 0;
+    double rz = sc[0].rz[cur & 1], rr = sc[0].rr;
+    // where the participants run: every one publishes its XCC id (system scope), every one reads all of them
+    bool fast;
+    {
+        if (tid == 0) xg_put(gb, L.id + rank, (double)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf), base, false);   // HW_REG_XCC_ID, bits 0-3
+        int slot[1]; double got[1];
+        slot[0] = lane < P ? L.id + lane : -1;
+        if (!xg_get<1>(gb, slot, base, got, ctl, 4u | (unsigned)rank << 8 | (unsigned)w << 16, false)) s_fail = 1;
+        const double mine = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(unsigned long long, got[0]) >> 32)) << 32) |
+                                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_bit_cast(unsigned long long, got[0])));   // rank 0's id
+        fast = !__any(lane < P && got[0] != mine) && !(cur & 2);
+    }
+    __syncthreads();
+    if (s_fail) return;
+    const int sub = tid / LPR, sl = tid % LPR;
+    // the row groups of this thread (chunk ch, pass): LDS offset of the row's first partial, its blocks, its row -- fixed for the launch.
+    // Groups that do not exist (ch >= nch, rows past the chunk) read slot 0 of the partials and are never used.
+    constexpr int NPASS = (SPB + CGT / LPR - 1) / (CGT / LPR);
+    // goff: LDS index of the partials sl, sl + 8, sl + 16, sl + 24 of the row (past the row's end: `zero`, a double that stays 0.0, so the
+    // sum needs neither a mask nor a branch); gmore: the row has more than 32 blocks (wave-wide: anymore).
+    int goff[MC][NPASS][4], gbase[MC][NPASS], gnb[MC][NPASS], grow[MC][NPASS];
+    const int zero = 3 * MC * ldq;            // part[zero]: one spare double behind the chunks' regions
+    if (tid == 0) part[zero] = 0.0;
+    bool more = false;
+#pragma unroll
+    for (int ch = 0; ch < MC; ++ch)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            gbase[ch][pass] = zero; gnb[ch][pass] = 0; grow[ch][pass] = -1;
+            const int rw = r0a[ch] + pass * (CGT / LPR) + sub;
+            if (ch < nch && rw < r1a[ch]) {
+                const int I = (rw - r0a[ch]) / 3, i = rw - r0a[ch] - 3 * I, b0 = s_bp[ch][I];
+                gbase[ch][pass] = 3 * (ch * ldq + b0) + i; gnb[ch][pass] = s_bp[ch][I + 1] - b0; grow[ch][pass] = rw;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) goff[ch][pass][jj] = sl + LPR * jj < gnb[ch][pass] ? gbase[ch][pass] + 3 * (sl + LPR * jj) : zero;
+            more = more || gnb[ch][pass] > 4 * LPR;
+        }
+    const bool anymore = __any(more) != 0;
+    xg_sync();
+#ifdef XG_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define XG_T(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define XG_T(k) do { } while (0)
+#endif
+    for (int it = 0; it < niter; ++it) {
+        const unsigned tagA = base + 3u * (unsigned)it + 1u, tagB = tagA + 1u, tagC = tagA + 2u;   // (tagC: the two-level form's third hop)
+        const int par = it & 1;
+        // ---- K p on the own chunks (k_fem_spmv, phase 1: a lane per block, three row sums parked in LDS)
+#pragma unroll
+        for (int ch = 0; ch < MC; ++ch) {
+            if (ch < nch && tid < nqa[ch]) {
+#pragma unroll
+                for (int u = 0; u < XG_MAXQ; ++u) {
+                    if (u > 0 && tid + u * CGT >= nqa[ch]) continue;   // (k_fem_spmv's lanes past the run repeat its last block: same values to the same slots)
+                    const int qq = tid + u * CGT;
+                    const double *pp = p_s + ca[ch][u];
+                    const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                    double *dst = part + 3 * (ch * ldq + qq);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        dst[i] = ((double)va[ch][u][3 * i] * p0 + (double)va[ch][u][3 * i + 1] * p1) + (double)va[ch][u][3 * i + 2] * p2;
+                }
+            }
+        }
+        xg_sync();
+        XG_T(0);   // SpMV phase 1
+        // (phase 2: 8 lanes per row, DPP row_shl sums in a fixed order; the chunk's partial of p.Ap)
+        // No branch, no mask and no loop in here: the <= 48 partials a thread adds are asked for together (a first version -- k_fem_spmv's
+        // loop over a row's blocks, under `if (row < r1)` -- compiled to 72 LDS reads each waited for behind its own branch: 11,000 of
+        // an iteration's 21,000 clocks; a second one with selects kept 48 loop-invariant lane masks in spilled scalar registers: 9,000).
+        // A lane adds the partials sl, sl + 8, .. of its row in that order; the slots past the row's end read a 0.0, and `+ 0.0` changes
+        // nothing (a sum that starts at +0.0 never is -0.0).  Rows of more than 32 blocks take the loop for the rest (wave-uniform test).
+        double acc[MC], srow[MC][NPASS];
+        {
+            double pv[MC][NPASS][4], pr[MC][NPASS];
+#pragma unroll
+            for (int ch = 0; ch < MC; ++ch)
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) pv[ch][pass][jj] = part[goff[ch][pass][jj]];
+                    pr[ch][pass] = p_s[max(grow[ch][pass], lo) - lo];
+                }
+#pragma unroll
+            for (int ch = 0; ch < MC; ++ch) {
+                acc[ch] = 0;
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    double sm = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) sm += pv[ch][pass][jj];
+                    if (anymore)
+                        for (int j = sl + 4 * LPR; j < gnb[ch][pass]; j += LPR) sm += part[gbase[ch][pass] + 3 * j];
+                    sm += dpp_shl_f64<4>(sm);
+                    sm += dpp_shl_f64<2>(sm);
+                    sm += dpp_shl_f64<1>(sm);
+                    srow[ch][pass] = sm;
+                    acc[ch] += grow[ch][pass] >= 0 && sl == 0 ? pr[ch][pass] * sm : 0.0;
+                }
+                acc[ch] = wave_sum_f64(acc[ch]);      // block_sum, all chunks behind one barrier
+            }
+        }
+        // (the rows go out behind the sums, not between them: a store is a hand-written asm statement with a memory clobber, and ten of
+        // them inside the loop above made ten chains of LDS reads run one after the other -- 10,600 of an iteration's 20,700 clocks)
+#pragma unroll
+        for (int ch = 0; ch < MC; ++ch)
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass)
+                if (grow[ch][pass] >= 0 && sl == 0) xg_put(gb, L.ap + grow[ch][pass], srow[ch][pass], tagA, fast);
+        if (lane == 0) {
+#pragma unroll
+            for (int ch = 0; ch < MC; ++ch) if (ch < nch) sh[ch][w] = acc[ch];
+        }
+        xg_sync();
+        if (tid == 0) {
+#pragma unroll
+            for (int ch = 0; ch < MC; ++ch)
+                if (ch < nch) {
+                    double t = 0;
+                    for (int i = 0; i < CGT / 64; ++i) t += sh[ch][i];
+                    xg_put(gb, L.pap + par * nchunk_s + c0 + ch, t, tagA, fast);
+                }
+        }
+        XG_T(1);   // SpMV phase 2 + partials out
+        // ---- alpha = rz / p.Ap; x += alpha p; r -= alpha K p; partials of r.(r/diag) and r.r (k_fem_cg_update)
+        double pAp, api;
+        {
+            int slot[4]; double got[4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) slot[u] = lane + 64 * u < nchunk_s ? L.pap + par * nchunk_s + lane + 64 * u : -1;
+            slot[3] = has ? L.ap + row : -1;
+            if (!xg_get<4>(gb, slot, tagA, got, ctl, 1u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+            double v = 0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) if (lane + 64 * u < nchunk_s) v += got[u];      // chunk_sum's order
+            pAp = wave_sum_f64(v);
+            api = got[3];
+        }
+        XG_T(2);   // hop A: the p.Ap partials and the own K p row
+        const double alpha = cg_ratio(rz, pAp);
+        if (vec) {
+            double s1 = 0, s2 = 0;
+            if (has) {
+                xv += alpha * p_s[row - lo];
+                const double ri = rv - alpha * api;
+                rv = ri;
+                s1 += ri * (ri * dv);
+                s2 += ri * ri;
+                xg_put(gb, L.r + row, ri, tagB, fast);
+            }
+            s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);       // two block_sums behind one barrier
+            if (lane == 0) { shv[0][w] = s1; shv[1][w] = s2; }
+        }
+        xg_sync();
+        if (s_fail) return;
+        if (vec && tid == 0) {
+            double t1 = 0, t2 = 0;
+            for (int i = 0; i < CGT / 64; ++i) { t1 += shv[0][i]; t2 += shv[1][i]; }
+            xg_put(gb, L.rz + par * nchunk + rank, t1, tagB, fast);
+            xg_put(gb, L.rr + par * nchunk + rank, t2, tagB, fast);
+        }
+        // ---- beta = rz_new / rz; p = r/diag + beta p over the own column range, from the r everybody published (k_fem_cg_dir)
+        XG_T(3);   // update + partials out
+        // one poll for the chunk partials and the first XG_SU x 256 rows of the range (ranges beyond that -- irregular numberings --
+        // take further rounds of rows only)
+        double rz2, beta;
+        if constexpr (!COARSE) {
+            int slot[2 + XG_SU]; double got[2 + XG_SU];
+            slot[0] = lane < nchunk ? L.rz + par * nchunk + lane : -1;
+            slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[2 + u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+            if (!xg_get<2 + XG_SU>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+            rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);       // chunk_sum with <= 32 partials: a lane per partial
+            rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
+            beta = cg_ratio(rz2, rz);
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; if (slot[2 + u] >= 0) p_s[i] = got[2 + u] * d_s[i] + beta * p_s[i]; }
+            for (int b0 = XG_SU * CGT; b0 < rng; b0 += XG_SU * CGT) {
+                int slot2[XG_SU]; double got2[XG_SU];
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; slot2[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+                if (!xg_get<XG_SU>(gb, slot2, tagB, got2, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; if (slot2[u] >= 0) p_s[i] = got2[u] * d_s[i] + beta * p_s[i]; }
+            }
+        } else {
+            constexpr int XG_SA = 4;                          // aggregate rows per thread and poll (<= 1,024 rows = 341 nodes; larger: more rounds)
+            // hop B: the chunk partials, the column range's r rows and -- aggregate owners -- the first rows of the own aggregate
+            const bool owner = rank < CZ_NA;                  // aggregate a = rank, rank + P, .. (P < 8: several per workgroup)
+            double rgot[XG_SU];
+            {
+                int slot[2 + XG_SU + XG_SA]; double got[2 + XG_SU + XG_SA];
+                slot[0] = lane < nchunk ? L.rz + par * nchunk + lane : -1;
+                slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[2 + u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+                const int zp0 = owner ? czptr[rank] : 0, na3 = owner ? 3 * (czptr[rank + 1] - zp0) : 0;
+#pragma unroll
+                for (int u = 0; u < XG_SA; ++u) {
+                    const int e = u * CGT + tid;
+                    slot[2 + XG_SU + u] = e < na3 ? L.r + 3 * (int)(__float_as_uint(cz[zp0 + e / 3].w) & 0x0fffffffu) + e % 3 : -1;
+                }
+                if (!xg_get<2 + XG_SU + XG_SA>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);
+                rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) rgot[u] = got[2 + u];
+#pragma unroll
+                for (int u = 0; u < XG_SA; ++u) { const int e = u * CGT + tid; if (e < na3) r_a[e] = got[2 + XG_SU + u]; }
+            }
+            XG_T(5);   // (two-level) hop B's poll
+            // restriction of the owned aggregates: cz_apply_block's waves (a, half = 0) and (a, half = 1) are waves 0 and 1 here
+            for (int ag = rank; ag < CZ_NA; ag += P) {
+                const int zp0 = czptr[ag], zp1 = czptr[ag + 1], na3 = 3 * (zp1 - zp0);
+                for (int e0 = (ag == rank ? XG_SA : 0) * CGT; e0 < na3; e0 += XG_SA * CGT) {       // what the first poll did not cover
+                    if (ag != rank && e0 == 0) xg_sync();                                          // (the previous aggregate's rows have been used)
+                    int slot[XG_SA]; double got[XG_SA];
+#pragma unroll
+                    for (int u = 0; u < XG_SA; ++u) {
+                        const int e = e0 + u * CGT + tid;
+                        slot[u] = e < na3 ? L.r + 3 * (int)(__float_as_uint(cz[zp0 + e / 3].w) & 0x0fffffffu) + e % 3 : -1;
+                    }
+                    if (!xg_get<XG_SA>(gb, slot, tagB, got, ctl, 5u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+#pragma unroll
+                    for (int u = 0; u < XG_SA; ++u) { const int e = e0 + u * CGT + tid; if (e < na3) r_a[e] = got[u]; }
+                }
+                xg_sync();                                    // the aggregate's rows are in LDS
+                if (w < 2) {
+                    const int half = w;
+                    double w6[6] = {0, 0, 0, 0, 0, 0};
+                    constexpr int U = 4;
+                    for (int q0 = zp0 + 64 * half + lane; q0 - lane < zp1; q0 += 128 * U) {
+                        float4 e[U]; double g[U][3];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) e[u] = cz[min(q0 + 128 * u, zp1 - 1)];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double *rs_ = r_a + 3 * (min(q0 + 128 * u, zp1 - 1) - zp0);
+                            g[u][0] = rs_[0]; g[u][1] = rs_[1]; g[u][2] = rs_[2];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const CzNode n = cz_node(e[u]);
+                            const bool in = q0 + 128 * u < zp1;
+                            const double r0 = n.m0 || !in ? 0.0 : g[u][0], r1 = n.m1 || !in ? 0.0 : g[u][1], r2 = n.m2 || !in ? 0.0 : g[u][2];
+                            CZ_RESTRICT_ADD(w6, n, r0, r1, r2);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); if (lane == m) xg_put(gb, L.cw + par * 2 * CZ_NC + half * CZ_NC + 6 * ag + m, w6[m], tagC, fast); }
+                }
+            }
+            XG_T(6);   // (two-level) restriction of the own aggregate + puts
+            // hop C: the 96 sums; v = Ac^-1 w and w.v as cz_apply_block's wave 0
+            if (w == 0) {
+                int slot[2]; double got[2];
+                slot[0] = lane < CZ_NC ? L.cw + par * 2 * CZ_NC + lane : -1;
+                slot[1] = lane < CZ_NC ? L.cw + par * 2 * CZ_NC + CZ_NC + lane : -1;
+                if (!xg_get<2>(gb, slot, tagC, got, ctl, 6u | (unsigned)rank << 8 | (unsigned)it << 20, fast)) s_fail = 1;
+                if (lane < CZ_NC) { s_w[lane] = got[0]; s_w[CZ_NC + lane] = got[1]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own LDS writes, read back below
+                const int kq = min(lane, CZ_NC - 1);
+                double v = 0;
+#pragma unroll 8
+                for (int j = 0; j < CZ_NC; ++j) v += a_s[j * CZ_NC + kq] * (s_w[j] + s_w[CZ_NC + j]);
+                const double t = wave_sum_f64(lane < CZ_NC ? (s_w[kq] + s_w[CZ_NC + kq]) * v : 0.0);
+                if (lane < CZ_NC) s_v[kq] = v;
+                if (lane == 0) s_v[CZ_NC] = t;
+            }
+            xg_sync();
+            XG_T(7);   // (two-level) hop C + coarse solve
+            rz2 += s_v[CZ_NC];                                // r.z = r.(r/diag) + w.v (k_fem_cg_dir)
+            beta = cg_ratio(rz2, rz);
+#pragma unroll
+            for (int u = 0; u < XG_SU; ++u) {
+                const int i = u * CGT + tid;
+                if (i < rng && lo + i < ndof) {
+                    const int info = rinfo[i], c6 = info & 0xff, kk = (info >> 8) & 3;
+                    const double *va = s_v + c6;                    // the six coarse dofs of the row's aggregate
+                    const float2 q = rq[i];
+                    const double czr = (info >> 10) & 1 ? 0.0 : va[kk] + (va[3 + (kk + 1) % 3] * (double)q.x - va[3 + (kk + 2) % 3] * (double)q.y);
+                    p_s[i] = (rgot[u] * d_s[i] + czr) + beta * p_s[i];
+                }
+            }
+            for (int b0 = XG_SU * CGT; b0 < rng; b0 += XG_SU * CGT) {      // ranges beyond 2,048 rows (irregular numberings)
+                int slot2[XG_SU]; double got2[XG_SU];
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; slot2[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+                if (!xg_get<XG_SU>(gb, slot2, tagB, got2, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) {
+                    const int i = b0 + u * CGT + tid;
+                    if (slot2[u] >= 0) {
+                        const int info = rinfo[i], c6 = info & 0xff, kk = (info >> 8) & 3;
+                        const double *va = s_v + c6;
+                        const float2 q = rq[i];
+                        const double czr = (info >> 10) & 1 ? 0.0 : va[kk] + (va[3 + (kk + 1) % 3] * (double)q.x - va[3 + (kk + 2) % 3] * (double)q.y);
+                        p_s[i] = (got2[u] * d_s[i] + czr) + beta * p_s[i];
+                    }
+                }
+            }
+        }
+        rz = rz2;
+        xg_sync();
+        XG_T(4);   // hop B: the r.z partials and the range's r rows; the new p
+        if (s_fail) return;
+    }
+#ifdef XG_TIMING
+    if (tid == 0 && rank < 3) for (int k = 0; k < 8; ++k) ctl->pad[1 + 8 * rank + k] = (unsigned)(tacc[k] / (unsigned long long)max(niter, 1));
+#endif
+    if (has) { x[row] = xv; r[row] = rv; p[row] = p_s[row - lo]; }
+    if (rank == 0 && tid == 0) { sc[0].rz[0] = rz; sc[0].rz[1] = rz; sc[0].rr = rr; }
 }
 
 // COARSE: the two-level preconditioner inside the same launch.  After the update (r is in the batch vector) the sixteen waves sum
@@ -2165,7 +2309,13 @@ struct fem_model {
     int cz_max_agg = 0;
     bool resident_now() const { return cg_resident && !(coarse() && !cgr_big && cz_max_agg > 64 * 5); }
     // the one-XCD kernel: one mesh under point Jacobi (FEM_CG_XCD=0 keeps the launch-per-phase path, which it equals bit for bit)
-    bool xcd_now() const { const char *e = getenv("FEM_CG_XCD"); return cg_xcd && !coarse() && !(e && e[0] == '0'); }   // (read per call: the tests switch it)
+    bool xcd_now() const   // (the switch is read per call: the tests flip it)
+    {
+        const char *e = getenv("FEM_CG_XCD");
+        if (!cg_xcd || (e && e[0] == '0')) return false;
+        // the two-level form also keeps an aggregate's r rows, the coarse vectors and a per-row table in LDS: it must fit beside the rest
+        return !coarse() || (size_t)xg_lds + (size_t)(3 * cz_max_agg + 200 + 48 * 48) * 8 + (size_t)xg_ldr * 12 <= 150 * 1024;
+    }
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
     orbx::KernelProfiler prof;
@@ -2302,10 +2452,20 @@ void coarse_correction(fem_model *m, hipStream_t st, const double *src, double *
 }
 
 // the variant of k_fem_cg_xcd a model runs: rows per SpMV chunk x chunks per workgroup
-inline const void *xg_kernel(int spb, int mc)
+inline const void *xg_kernel(int spb, int mc, bool coarse)
 {
-    if (spb == 48) return mc == 1 ? reinterpret_cast<const void *>(k_fem_cg_xcd<48, 1>) : mc == 3 ? reinterpret_cast<const void *>(k_fem_cg_xcd<48, 3>) : reinterpret_cast<const void *>(k_fem_cg_xcd<48, 6>);
-    return mc == 1 ? reinterpret_cast<const void *>(k_fem_cg_xcd<96, 1>) : mc == 3 ? reinterpret_cast<const void *>(k_fem_cg_xcd<96, 3>) : reinterpret_cast<const void *>(k_fem_cg_xcd<96, 6>);
+#define XG_K(S, M) (coarse ? reinterpret_cast<const void *>(k_fem_cg_xcd<S, M, true>) : reinterpret_cast<const void *>(k_fem_cg_xcd<S, M, false>))
+    (void)spb;   // 48 for every mesh the kernel takes (plan_model: a single mesh of <= 8,192 dofs is far below the 96-row threshold)
+    return mc == 1 ? XG_K(48, 1) : mc == 3 ? XG_K(48, 3) : XG_K(48, 6);
+#undef XG_K
+}
+// LDS bytes of the variant: the Jacobi layout, and behind it all of r, the coarse vectors and the prolongation's per-row table
+inline int xg_lda(const fem_model *m) { return (3 * std::max(m->cz_max_agg, 1) + 1) & ~1; }   // LDS doubles of an aggregate's r rows
+inline size_t xg_lds_bytes(const fem_model *m, bool coarse)
+{
+    size_t b = (size_t)m->xg_lds;
+    if (coarse) b += (size_t)(xg_lda(m) + 3 * CZ_NC + 2 + CZ_NC * CZ_NC) * sizeof(double) + (size_t)m->xg_ldr * (sizeof(float2) + sizeof(int)) + 32;
+    return b;
 }
 
 void launch_iter(fem_model *m, hipStream_t st)
@@ -2363,13 +2523,26 @@ void run_iters(fem_model *m, int n, hipStream_t st)
             int cur = (m->cg_it & 1) | (xe && xe[0] == 's' ? 2 : 0);
             void *gran = m->d_xg_gran;
             const int4 *plan = m->d_xg_plan;
+            const bool co = m->coarse();
+            const float4 *czl = co ? m->d_cz : nullptr, *czn = co ? m->d_cznode : nullptr;
+            const int *czp = co ? m->d_czptr : nullptr;
+            const double *aci = co ? m->d_aci : nullptr;
+            const size_t lds = xg_lds_bytes(m, co);
+            int lda = co ? xg_lda(m) : 0;
             void *args[] = {&m->d_vals_b, &m->d_bcol3, &m->d_bp, &m->ndof, &m->nchunk, &m->nchunk_s, &n, &cur, &m->d_sc, &m->d_p, &m->d_dinv, &m->d_x,
-                            &m->d_r, &gran, &plan, &m->xg_P, &m->xg_ldr, &m->xg_ldq, &m->d_xg_ctl, &m->xg_bar};
-            (void)hipLaunchKernel(xg_kernel(m->spb, m->xg_mc), dim3(XG_STRIDE * XG_MAXP), dim3(CGT), args, (size_t)m->xg_lds, st);
+                            &m->d_r, &gran, &plan, &m->xg_P, &m->xg_ldr, &m->xg_ldq, &m->d_xg_ctl, &m->xg_bar, &czl, &czp, &czn, &aci, &lda};
+            const void *fn = xg_kernel(m->spb, m->xg_mc, co);
+            {   // the limit belongs to the FUNCTION, not to the model: raised once per variant to what the hardware has (a per-model value
+                // would be lowered by the next smaller model, and the larger one's next launch would fail)
+                static std::atomic<unsigned> raised{0};
+                const unsigned bit = 1u << ((co ? 3 : 0) + (m->xg_mc == 1 ? 0 : m->xg_mc == 3 ? 1 : 2));
+                if (!(raised.load() & bit)) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); raised.fetch_or(bit); }   // (the kernel's static arrays take a few KB of the 160)
+            }
+            (void)hipLaunchKernel(fn, dim3(XG_STRIDE * XG_MAXP), dim3(CGT), args, lds, st);
         }
         m->prof.stop(5, st);
         (void)hipEventRecord(m->xg_done, st);
-        m->xg_bar += 2u * (unsigned)n;                        // the granules' tags: two per iteration, never reused (fem_cg_setup clears the buffer)
+        m->xg_bar += 3u * (unsigned)n;                        // the granules' tags: three per iteration, never reused (fem_cg_setup clears the buffer)
         m->cg_it = 2 * ((m->cg_it + n + 1) / 2);              // both rz slots are current after the launch
         return;
     }
@@ -2704,7 +2877,7 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
         }
         const int mc = kch <= 1 ? 1 : kch <= 3 ? 3 : XG_MAXCH;   // the kernel's template variants
         const size_t lds = ((size_t)2 * maxr + (size_t)3 * mc * std::max(maxq, 1) + 2) * sizeof(double);   // (+ the zero slot)
-        ok = ok && maxq <= XG_MAXQ * CGT && lds <= 150 * 1024;
+        ok = ok && SPB == 48 && maxq <= XG_MAXQ * CGT && lds <= 150 * 1024;
         if (ok) { P.xcd = true; P.xg_P = Pn; P.xg_ldr = maxr; P.xg_ldq = std::max(maxq, 1); P.xg_lds = lds; P.xg_mc = mc; }
         else P.xg.clear();
     }
@@ -2788,7 +2961,6 @@ int create_model(int eltype, int npe, const float *nodes, int nmesh, int nn, con
             for (const void *fn : {reinterpret_cast<const void *>(k_fem_cg_resident<false, false>), reinterpret_cast<const void *>(k_fem_cg_resident<false, true>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.resident_lds);
     }
-    if (e == hipSuccess && P.xcd && P.xg_lds > 48 * 1024) e = hipFuncSetAttribute(xg_kernel(m->spb, P.xg_mc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.xg_lds);
     if (e == hipSuccess && m->kz_lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fem_cz_kz), hipFuncAttributeMaxDynamicSharedMemorySize, m->kz_lds);
     if (e == hipSuccess && m->spmv_lds > 48 * 1024)
         for (const void *fn : {reinterpret_cast<const void *>(k_fem_spmv<48, true>), reinterpret_cast<const void *>(k_fem_spmv<48, false>),

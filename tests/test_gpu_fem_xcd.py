@@ -84,7 +84,7 @@ def test_sizes_around_the_kernels_limits(nn):
     assert np.abs(xa[0] - ox).max() <= RTOL * np.abs(ox).max()
 
 
-def test_solve_to_tolerance_and_two_level_keep_their_paths():
+def test_solve_to_tolerance_under_both_preconditioners():
     nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
     fea, b = _model(nodes, tets, fixed, load)
     fea.profile(True)
@@ -97,11 +97,12 @@ def test_solve_to_tolerance_and_two_level_keep_their_paths():
     finally:
         os.environ.pop("FEM_CG_XCD", None)
     assert done0 == done and x0.tobytes() == x.tobytes()
-    fea.cg_preconditioner("two_level")                             # the coarse correction is not in the one-launch kernel
+    fea.cg_preconditioner("two_level")                             # the coarse correction runs inside the one-launch kernel too
     fea.profile(True)
-    fea.cg_setup(b); fea.cg_iterate(20); fea.cg_result()
+    x2, done2, rel2 = fea.solve_cg(b, iters=3000, tol=1e-8)
     prof = fea.profile_read()
-    assert not prof.get("k_fem_cg_xcd", (0, 0))[1] and prof["k_fem_spmv"][1] == 20
+    assert rel2[0] <= 1e-8 and done2 < done // 2 and prof["k_fem_cg_xcd"][1] == done2 // 25 and not prof["k_fem_spmv"][1]
+    assert np.abs(x2 - x).max() <= 1e-6 * np.abs(x).max()
     fea.cg_preconditioner("jacobi")
 
 
@@ -148,3 +149,24 @@ def test_system_scope_granules_give_the_same_bits():
     xs, rs, ps = _run(fea, b, [40, 25], xcd="safe")
     xb, rb, pb = _run(fea, b, [65], xcd=False)
     assert ps["k_fem_cg_xcd"][1] == 2 and xs.tobytes() == xb.tobytes() and rs.tobytes() == rb.tobytes()
+
+
+@pytest.mark.parametrize("ncell,iters", [(12, 120), (5, 60), (3, 40), (9, 77)])
+def test_two_level_inside_the_launch_equals_the_launch_per_phase_path(ncell, iters):
+    """fem_cg_preconditioner(two_level) on one mesh: the coarse correction inside k_fem_cg_xcd (every workgroup stages all of r and
+    walks cz_apply_block's sixteen waves with its four) against the launch-per-phase path with k_fem_cz_apply between the update and
+    the direction kernel -- bit for bit, slices and mixed paths included -- and against the oracle's two-level CG at 1e-5."""
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=ncell)
+    fea, b = _model(nodes, tets, fixed, load)
+    fea.cg_preconditioner("two_level")
+    xa, ra, pa = _run(fea, b, [iters], xcd=True)
+    xb, rb, pb = _run(fea, b, [iters], xcd=False)
+    assert pa["k_fem_cg_xcd"][1] == 1 and not pa["k_fem_spmv"][1] and pb["k_fem_spmv"][1] == iters
+    assert np.isfinite(xa).all() and xa.tobytes() == xb.tobytes() and ra.tobytes() == rb.tobytes()
+    xs, rs, _ = _run(fea, b, [7, iters - 20, 13], xcd=True)
+    assert xs.tobytes() == xb.tobytes() and rs.tobytes() == rb.tobytes()
+    rp, col, val = fea.csr(0)
+    mk = np.zeros(fea.Ksize, np.uint8); mk[fixed] = 1
+    ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[0], iters, nodes, mk)
+    assert np.abs(xa[0] - ox).max() <= RTOL * np.abs(ox).max()
+    fea.cg_preconditioner("jacobi")
