@@ -106,7 +106,7 @@ int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_
  * k_fem_cg_xcd eligible (a single mesh of at most 8,192 dofs whose chunk tables fit), participating workgroups P (<= 32), chunks per
  * workgroup of the kernel variant (1, 3 or 6), its LDS bytes, vector chunks (256 rows), SpMV chunks (48 or 96 rows)}; plan[P][4] =
  * {first SpMV chunk, end, first dof, end of the column range whose p the workgroup keeps in LDS} per workgroup (may be NULL).  The
- * kernel gives the launch-per-phase path's results bit for bit (FEM_CG_XCD=0 selects that path); point-Jacobi preconditioner only. */
+ * kernel gives the launch-per-phase path's results bit for bit under either preconditioner (FEM_CG_XCD=0 selects that path). */
 int fem_plan_single_cg(int eltype, int nn, const int32_t *elems, int ne, int32_t *info6, int32_t *plan);
 
 /* Cross-check of the symbolic phase (host only): the linear-pass formulation fem_create uses against the first, list-based
@@ -148,7 +148,7 @@ int fem_trial_energy(fem_model *m, const double *points, float *a_out, float *sE
  * fem_cg_iterate.  Batches of 64 or more meshes of at most 14,288 dofs each (what 160 KB of LDS hold: (n + 6,192) x 8
  * bytes with the search direction alone in LDS; up to 7,168 dofs also K p stays there) run one mesh per compute unit
  * with the iteration vectors in LDS and registers: fem_cg_iterate(n) is ONE launch of n iterations, fem_cg launches
- * slices of 25 iterations between its convergence tests.  ONE mesh of at most 8,192 dofs under point Jacobi also runs
+ * slices of 25 iterations between its convergence tests.  ONE mesh of at most 8,192 dofs (either preconditioner) also runs
  * fem_cg_iterate(n) as one launch (k_fem_cg_xcd: <= 32 workgroups of one XCD stay resident and exchange tagged 16-byte
  * granules; fem_plan_single_cg tells); its results equal the launch-per-phase path's bit for bit, at most six such launches
  * are in flight per process (further calls take the other path), and should one of its bounded waits ever time out,
