@@ -11,8 +11,10 @@ T=${1:-r05}
 R=$GRAFT_REPO_ROOT
 $R/tools/prof_main.sh ${T}_main
 $R/tools/prof_default.sh ${T}_default
+find $R/gpurun_out/${T}_default -name "*kernel_trace.csv" -delete      # (the per-dispatch rows: only the stats are kept; gpurun returns 64 MiB at most)
 OUT=$R/gpurun_out/${T}_full; mkdir -p $OUT
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/trace.err; echo "full rc $?" )
+find $OUT -name "*kernel_trace.csv" -delete                             # (70,000 dispatches of the all-meshes FEM leg)
 $R/tools/prof_fem.sh ${T}_fem
 OUT=$R/gpurun_out/${T}_bow; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
