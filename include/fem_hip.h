@@ -103,9 +103,10 @@ int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_
              int32_t *rcfirst, int32_t *chunk_mesh);
 
 /* How fem_cg_iterate / fem_cg will run ONE mesh of this topology (host only, no GPU needed): info6 = {one-launch kernel
- * k_fem_cg_xcd eligible (a single mesh of at most 8,192 dofs whose chunk tables fit), participating workgroups P (<= 32), chunks per
+ * k_fem_cg_xcd eligible (a single mesh of at most 8,192 dofs whose chunk tables fit), participating workgroups P (<= 64), chunks per
  * workgroup of the kernel variant (1, 3 or 6), its LDS bytes, vector chunks (256 rows), SpMV chunks (48 or 96 rows)}; plan[P][4] =
- * {first SpMV chunk, end, first dof, end of the column range whose p the workgroup keeps in LDS} per workgroup (may be NULL).  The
+ * {first SpMV chunk, end | (own vector chunk + 1) << 16, first dof, end of the column range whose p the workgroup keeps in LDS} per
+ * workgroup (may be NULL; room for 64 entries).  The
  * kernel gives the launch-per-phase path's results bit for bit under either preconditioner (FEM_CG_XCD=0 selects that path). */
 int fem_plan_single_cg(int eltype, int nn, const int32_t *elems, int ne, int32_t *info6, int32_t *plan);
 

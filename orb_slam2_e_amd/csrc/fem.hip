@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(1024) void k_fem_cz_apply(const float4 *__restrict_
 //     chunk partials are double-buffered by iteration parity, and a workgroup two iterations ahead is impossible -- each phase needs
 //     every workgroup's partial of the phase before).
 // Every spin is bounded: a timeout raises the abort word, every workgroup leaves, and fem_cg_result / fem_cg report the failure.
-constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 32;
+constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 64;   // XG_MAXP: up to two workgroups per compute unit of the XCD (variants MC <= 3)
 constexpr unsigned XG_SPIN = 1u << 22, XG_KEY = 0x5bd1e995u;
 struct XgCtl { unsigned abort_flag, pad[31]; };
 typedef unsigned xg_u32x4 __attribute__((ext_vector_type(4)));
@@ -1382,7 +1382,7 @@ __host__ __device__ inline XgLayout xg_layout(int ndof, int nchunk, int nchunk_s
 // (A first version had every workgroup stage ALL of r and run the whole correction itself: no third hop, 28 x 105 KB of granules per
 // iteration through one L2 and sixteen waves' work on four -- 22.9 us per iteration against the launch-per-phase path's 17.9.)
 template <int SPB, int MC, bool COARSE>
-__global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
+__global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float *__restrict__ vals_b, const int *__restrict__ bcol3, const int *__restrict__ bp,
                                                     int ndof, int nchunk, int nchunk_s, int niter, int cur, CgScal *__restrict__ sc,
                                                     double *__restrict__ p, const double *__restrict__ dinv, double *__restrict__ x,
                                                     double *__restrict__ r, void *__restrict__ gran, const int4 *__restrict__ plan, int P,
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
     __shared__ int s_fail;
     const int rank = blockIdx.x / XG_STRIDE, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int4 pl = plan[rank];
-    const int c0 = pl.x, nch = pl.y - pl.x, lo = pl.z, rng = pl.w - pl.z;
+    const int c0 = pl.x, nch = (pl.y & 0xffff) - pl.x, vch = (pl.y >> 16) - 1, lo = pl.z, rng = pl.w - pl.z;   // vch: the own vector chunk, or -1
     const XgLayout L = xg_layout(ndof, nchunk, nchunk_s);
     char *gb = static_cast<char *>(gran);
     double *p_s = lds, *d_s = lds + ldr, *part = lds + 2 * ldr;        // part: MC regions of 3 ldq doubles (+ the zero slot, + 1 of padding)
@@ -1440,8 +1440,8 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
                 rq[i] = float2{q[(kk + 2) % 3], q[(kk + 1) % 3]};
             }
     }
-    const int row = rank * RPB + tid;
-    const bool vec = rank < nchunk, has = vec && row < ndof;
+    const int row = max(vch, 0) * RPB + tid;
+    const bool vec = vch >= 0, has = vec && row < ndof;
     double xv = has ? x[row] : 0, rv = has ? r[row] : 0;
     const double dv = has ? dinv[row] : 0;
     double rz = sc[0].rz[cur & 1], rr = sc[0].rr;
@@ -1604,8 +1604,8 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_xcd(const float *__restrict__ va
         if (vec && tid == 0) {
             double t1 = 0, t2 = 0;
             for (int i = 0; i < CGT / 64; ++i) { t1 += shv[0][i]; t2 += shv[1][i]; }
-            xg_put(gb, L.rz + par * nchunk + rank, t1, tagB, fast);
-            xg_put(gb, L.rr + par * nchunk + rank, t2, tagB, fast);
+            xg_put(gb, L.rz + par * nchunk + vch, t1, tagB, fast);
+            xg_put(gb, L.rr + par * nchunk + vch, t2, tagB, fast);
         }
         // ---- beta = rz_new / rz; p = r/diag + beta p over the own column range, from the r everybody published (k_fem_cg_dir)
         XG_T(3);   // update + partials out
@@ -2314,7 +2314,7 @@ struct fem_model {
         const char *e = getenv("FEM_CG_XCD");
         if (!cg_xcd || (e && e[0] == '0')) return false;
         // the two-level form also keeps an aggregate's r rows, the coarse vectors and a per-row table in LDS: it must fit beside the rest
-        return !coarse() || (size_t)xg_lds + (size_t)(3 * cz_max_agg + 200 + 48 * 48) * 8 + (size_t)xg_ldr * 12 <= 150 * 1024;
+        return !coarse() || (size_t)xg_lds + (size_t)(3 * cz_max_agg + 200 + 48 * 48) * 8 + (size_t)xg_ldr * 12 <= (size_t)(xg_P > 32 ? 78 : 150) * 1024;
     }
     hipStream_t stream = nullptr;
     hipStream_t cg_stream = nullptr; // the stream the last fem_cg_iterate ran on
@@ -2856,14 +2856,31 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
         ok = ok && maxrows > 0 && maxrows <= (big ? CGR_MAXROWS_BIG : CGR_MAXROWS) && lds <= 160 * 1024;
         P.resident = ok; P.big = big; P.resident_lds = lds; P.maxrows = maxrows;
     }
-    if (!seg_nn && nmesh == 1 && m->nchunk <= XG_MAXP) {   // k_fem_cg_xcd: ONE mesh, its chunks dealt in contiguous runs to <= 32 workgroups
-        const int kch = (m->nchunk_s + XG_MAXP - 1) / XG_MAXP, Ps = (m->nchunk_s + kch - 1) / kch, Pn = std::max(Ps, m->nchunk);
+    if (!seg_nn && nmesh == 1 && m->nchunk <= 32) {   // k_fem_cg_xcd: ONE mesh, its chunks dealt in contiguous runs to the workgroups of one XCD
+        // 32 workgroups (one per compute unit), or up to 64 (two per compute unit: the variants of <= 3 chunks per workgroup are
+        // compiled for two workgroups per compute unit -- two waves per SIMD hide each other's latencies) when that takes the chunks per
+        // workgroup from 4-6 to 2-3.  More than two per compute unit would leave workgroups waiting for a seat that the spinning ones hold.
+        int kch = (m->nchunk_s + 31) / 32;
+        if (kch > 3 && (m->nchunk_s + 63) / 64 <= 3) kch = (m->nchunk_s + 63) / 64;
+        const int Ps = (m->nchunk_s + kch - 1) / kch, Pn = std::max(Ps, m->nchunk);
         bool ok = kch <= XG_MAXCH;
         int maxq = 0, maxr = 0;
+        // vector chunk v (rows 256 v ..) goes to the workgroup whose SpMV rows hold its first row, so that a workgroup's column range
+        // stays one neighbourhood of the mesh; where two chunks would meet in one workgroup (runs longer than 256 rows): chunk v to workgroup v
+        std::vector<int> vec_of(Pn, -1);
+        {
+            bool clash = false;
+            for (int v = 0; v < m->nchunk; ++v) {
+                const int w = std::min((v * RPB) / (kch * SPB), Pn - 1);
+                clash = clash || vec_of[w] >= 0;
+                vec_of[w] = v;
+            }
+            if (clash) for (int w = 0; w < Pn; ++w) vec_of[w] = w < m->nchunk ? w : -1;
+        }
         for (int w = 0; w < Pn && ok; ++w) {
             const int c0 = std::min(w * kch, m->nchunk_s), c1 = std::min(c0 + kch, m->nchunk_s);
             int lo = m->ndof, hi = 0;
-            if (w < m->nchunk) { lo = std::min(lo, w * RPB); hi = std::max(hi, std::min(w * RPB + RPB, m->ndof)); }   // the own vector chunk's rows
+            if (vec_of[w] >= 0) { lo = std::min(lo, vec_of[w] * RPB); hi = std::max(hi, std::min(vec_of[w] * RPB + RPB, m->ndof)); }   // the own vector chunk's rows
             for (int c = c0; c < c1; ++c) {
                 const int r0 = c * SPB, r1 = std::min(r0 + SPB, m->ndof), q0 = P.bp[r0 / 3], q1 = P.bp[r1 / 3];
                 maxq = std::max(maxq, q1 - q0);
@@ -2873,11 +2890,11 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
             if (hi <= lo) { lo = 0; hi = 2; }
             lo &= ~1; hi = (hi + 1) & ~1;                       // 16-byte pieces of r
             maxr = std::max(maxr, hi - lo);
-            P.xg.push_back(make_int4(c0, c1, lo, hi));
+            P.xg.push_back(make_int4(c0, c1 | (vec_of[w] + 1) << 16, lo, hi));   // (end of the chunk run | (vector chunk + 1) << 16)
         }
         const int mc = kch <= 1 ? 1 : kch <= 3 ? 3 : XG_MAXCH;   // the kernel's template variants
         const size_t lds = ((size_t)2 * maxr + (size_t)3 * mc * std::max(maxq, 1) + 2) * sizeof(double);   // (+ the zero slot)
-        ok = ok && SPB == 48 && maxq <= XG_MAXQ * CGT && lds <= 150 * 1024;
+        ok = ok && SPB == 48 && maxq <= XG_MAXQ * CGT && lds <= (Pn > 32 ? 60 : 150) * 1024;   // (two per compute unit: 160 KB for both, the two-level form's extras included)
         if (ok) { P.xcd = true; P.xg_P = Pn; P.xg_ldr = maxr; P.xg_ldq = std::max(maxq, 1); P.xg_lds = lds; P.xg_mc = mc; }
         else P.xg.clear();
     }

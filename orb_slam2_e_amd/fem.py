@@ -273,14 +273,17 @@ class _PlanInfo(C.Structure):
 
 def plan_single_cg(elems, nn, nElType):
     """fem_plan_single_cg: how the CG of ONE mesh of this topology will run (host only).  Returns a dict: eligible (the one-launch
-    kernel k_fem_cg_xcd), workgroups, chunks_per_workgroup, lds, nchunk, nchunk_s, plan[workgroups, 4]."""
+    kernel k_fem_cg_xcd), workgroups, chunks_per_workgroup, lds, nchunk, nchunk_s, plan[workgroups, 4], vector_chunk[workgroups]."""
     L = lib()
     e = np.ascontiguousarray(elems, np.int32).reshape(-1, _NPE[nElType])
-    info = np.zeros(6, np.int32); pl = np.zeros((32, 4), np.int32)
+    info = np.zeros(6, np.int32); pl = np.zeros((64, 4), np.int32)
     bind(L.fem_plan_single_cg, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
     check(L.fem_plan_single_cg(nElType, int(nn), _p(e), len(e), _p(info), _p(pl)))
+    pl = pl[:info[1]].copy()
+    vec = (pl[:, 1] >> 16) - 1                      # the vector chunk (256 rows) a workgroup owns, or -1
+    pl[:, 1] &= 0xffff
     return {"eligible": bool(info[0]), "workgroups": int(info[1]), "chunks_per_workgroup": int(info[2]), "lds": int(info[3]),
-            "nchunk": int(info[4]), "nchunk_s": int(info[5]), "plan": pl[:info[1]].copy()}
+            "nchunk": int(info[4]), "nchunk_s": int(info[5]), "plan": pl, "vector_chunk": vec}
 
 
 def plan(elems_list, nn_list, nElType, uniform_copies=0):

@@ -172,9 +172,10 @@ def test_single_mesh_cg_plan_covers_every_chunk_and_every_column():
         spb, ndof = full["spb"], 3 * nn
         assert sp["nchunk"] == (ndof + 255) // 256 and sp["nchunk_s"] == (ndof + spb - 1) // spb
         P, pl = sp["workgroups"], sp["plan"]
-        assert 1 <= P <= 32 and P >= sp["nchunk"]
+        assert 1 <= P <= 64 and P >= sp["nchunk"] and (P <= 32 or sp["chunks_per_workgroup"] <= 3)
         kch = max(int(c1 - c0) for c0, c1, _, _ in pl)
         assert sp["chunks_per_workgroup"] == (1 if kch <= 1 else 3 if kch <= 3 else 6)
+        assert sorted(int(v) for v in sp["vector_chunk"] if v >= 0) == list(range(sp["nchunk"]))   # every vector chunk once
         owned = np.concatenate([np.arange(c0, c1) for c0, c1, _, _ in pl])
         assert np.array_equal(owned, np.arange(sp["nchunk_s"]))                       # every chunk once, in order
         rowptr, lcol = full["rowptr"], full["lcol"]
@@ -184,7 +185,8 @@ def test_single_mesh_cg_plan_covers_every_chunk_and_every_column():
             if c1 > c0:
                 r0, r1 = c0 * spb, min(c1 * spb, ndof)
                 need += [r0, r1 - 1, int(lcol[rowptr[r0]:rowptr[r1]].min()), int(lcol[rowptr[r0]:rowptr[r1]].max())]
-            if w < sp["nchunk"]:
-                need += [256 * w, min(256 * w + 256, ndof) - 1]
+            v = int(sp["vector_chunk"][w])
+            if v >= 0:
+                need += [256 * v, min(256 * v + 256, ndof) - 1]
             assert lo <= min(need) and max(need) < hi, (w, lo, hi, need)
         assert sp["lds"] <= 150 * 1024 and sp["lds"] >= 16 * int((pl[:, 3] - pl[:, 2]).max())

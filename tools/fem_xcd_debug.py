@@ -10,7 +10,7 @@ fea = FEA2(nodes, tets, FEM_TET4); fea.MatrixAssembly(); fea.eliminate_dofs(fixe
 b = load.copy()[None]; b[:, fixed] = 0
 fea.cg_setup(b)
 L = lib()
-info = np.zeros(8, np.int32); plan = np.zeros((32, 4), np.int32)
+info = np.zeros(8, np.int32); plan = np.zeros((64, 4), np.int32)
 L.fem_debug_xcd.argtypes = [C.c_void_p] * 4 + [C.c_int]
 L.fem_debug_xcd(fea._h, info.ctypes.data, plan.ctypes.data, None, 0)
 print("info cg_xcd,P,ldr,ldq,lds,total,nchunk,nchunk_s:", info.tolist()); print("plan", plan[:info[1]].tolist())
