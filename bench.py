@@ -553,6 +553,9 @@ def bow_bench(torch, dev):
     tr = load_traffic().get("k_bow_transform")
     if tr:
         out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]; out["roofline"]["traffic_source"] = tr["source"]
+        # `frac` above prices ALGORITHMIC bytes and exceeds 1: the tree's upper levels are served by L2 and the Infinity Cache.  What the
+        # memory side really delivers (counter bytes over the same launch time):
+        out["roofline"]["frac_of_counter_traffic"] = tr["hbm_bytes_per_launch"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
     put_ms(out, "transform_2000_host_arrays_ms", lambda: v.descend(feats[0], 4), 50)
     desc, off = distinctive_case()
     got = ORBmatcher.distinctive_descriptors(desc, off)
