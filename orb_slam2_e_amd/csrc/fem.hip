@@ -1298,7 +1298,11 @@ __global__ __launch_bounds__(1024) void k_fem_cz_apply(const float4 *__restrict_
 // Every spin is bounded: a timeout raises the abort word, every workgroup leaves, and fem_cg_result / fem_cg report the failure.
 constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 64;   // XG_MAXP: up to two workgroups per compute unit of the XCD (variants MC <= 3)
 constexpr unsigned XG_SPIN = 1u << 22, XG_KEY = 0x5bd1e995u;
+#ifdef XG_TIMING
+struct XgCtl { unsigned abort_flag, pad[31 + 8 * 64]; };   // development build: per-phase clocks of every workgroup behind the control words
+#else
 struct XgCtl { unsigned abort_flag, pad[31]; };
+#endif
 typedef unsigned xg_u32x4 __attribute__((ext_vector_type(4)));
 // Two cache policies for the granules, chosen per launch by the participants themselves:
 //   SAME_XCD  every participant reads its XCC id at start and publishes it; if all are equal, the workgroups share ONE L2, which is
@@ -1356,7 +1360,7 @@ __device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[U], uns
             }
             return false;
         }
-        __builtin_amdgcn_s_sleep(1);
+        // (no s_sleep between rounds: a round is one L2 round trip, ~1,000 clocks, and the 64 clocks of an s_sleep 1 were 1.7 % of an iteration)
     }
 }
 // Workgroup barrier for data that lives in LDS only: __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)` in front
@@ -1494,16 +1498,23 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         const unsigned tagA = base + 3u * (unsigned)it + 1u, tagB = tagA + 1u, tagC = tagA + 2u;   // (tagC: the two-level form's third hop)
         const int par = it & 1;
         // ---- K p on the own chunks (k_fem_spmv, phase 1: a lane per block, three row sums parked in LDS)
+        // No lane masks: the lanes past a chunk's run hold its LAST block (values and column were loaded with a clamped index) and store that
+        // block's three sums once more to the same slots, as k_fem_spmv's do; the tests left are workgroup-uniform (scalar branches), so
+        // the LDS reads of all the blocks are in flight together.  The values stay FLOATS in registers: the empty asm statement makes them
+        // "new" every iteration -- without it the compiler hoisted the 54 conversions out of the loop, kept 108 registers of doubles, spilled
+        // 18 of them and read those back from scratch one `s_waitcnt vmcnt(0)` at a time (which also waited for the previous phase's stores).
 #pragma unroll
         for (int ch = 0; ch < MC; ++ch) {
-            if (ch < nch && tid < nqa[ch]) {
+            if (ch < nch) {
 #pragma unroll
                 for (int u = 0; u < XG_MAXQ; ++u) {
-                    if (u > 0 && tid + u * CGT >= nqa[ch]) continue;   // (k_fem_spmv's lanes past the run repeat its last block: same values to the same slots)
-                    const int qq = tid + u * CGT;
+                    if (u > 0 && u * CGT >= nqa[ch]) continue;
+                    const int qq = min(tid + u * CGT, nqa[ch] - 1);
                     const double *pp = p_s + ca[ch][u];
                     const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
                     double *dst = part + 3 * (ch * ldq + qq);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(va[ch][u][i]));
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
                         dst[i] = ((double)va[ch][u][3 * i] * p0 + (double)va[ch][u][3 * i + 1] * p1) + (double)va[ch][u][3 * i + 2] * p2;
@@ -1548,6 +1559,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 acc[ch] = wave_sum_f64(acc[ch]);      // block_sum, all chunks behind one barrier
             }
         }
+        if constexpr (!COARSE) XG_T(5);
         // (the rows go out behind the sums, not between them: a store is a hand-written asm statement with a memory clobber, and ten of
         // them inside the loop above made ten chains of LDS reads run one after the other -- 10,600 of an iteration's 20,700 clocks)
 #pragma unroll
@@ -1559,15 +1571,14 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
 #pragma unroll
             for (int ch = 0; ch < MC; ++ch) if (ch < nch) sh[ch][w] = acc[ch];
         }
+        if constexpr (!COARSE) XG_T(6);
         xg_sync();
-        if (tid == 0) {
+        if constexpr (!COARSE) XG_T(7);
+        if (tid < nch) {                                  // a lane per chunk (one thread for all of them: three chains of reads and adds in a row)
+            double t = 0;
 #pragma unroll
-            for (int ch = 0; ch < MC; ++ch)
-                if (ch < nch) {
-                    double t = 0;
-                    for (int i = 0; i < CGT / 64; ++i) t += sh[ch][i];
-                    xg_put(gb, L.pap + par * nchunk_s + c0 + ch, t, tagA, fast);
-                }
+            for (int i = 0; i < CGT / 64; ++i) t += sh[tid][i];
+            xg_put(gb, L.pap + par * nchunk_s + c0 + tid, t, tagA, fast);
         }
         XG_T(1);   // SpMV phase 2 + partials out
         // ---- alpha = rz / p.Ap; x += alpha p; r -= alpha K p; partials of r.(r/diag) and r.r (k_fem_cg_update)
@@ -1601,11 +1612,11 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         }
         xg_sync();
         if (s_fail) return;
-        if (vec && tid == 0) {
-            double t1 = 0, t2 = 0;
-            for (int i = 0; i < CGT / 64; ++i) { t1 += shv[0][i]; t2 += shv[1][i]; }
-            xg_put(gb, L.rz + par * nchunk + vch, t1, tagB, fast);
-            xg_put(gb, L.rr + par * nchunk + vch, t2, tagB, fast);
+        if (vec && tid < 2) {                             // lane 0: the r.(r/diag) partial, lane 1: r.r
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < CGT / 64; ++i) t += shv[tid][i];
+            xg_put(gb, (tid ? L.rr : L.rz) + par * nchunk + vch, t, tagB, fast);
         }
         // ---- beta = rz_new / rz; p = r/diag + beta p over the own column range, from the r everybody published (k_fem_cg_dir)
         XG_T(3);   // update + partials out
@@ -1756,6 +1767,8 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
     }
 #ifdef XG_TIMING
     if (tid == 0 && rank < 3) for (int k = 0; k < 8; ++k) ctl->pad[1 + 8 * rank + k] = (unsigned)(tacc[k] / (unsigned long long)max(niter, 1));
+    if (tid == 0) for (int k = 0; k < 8; ++k) ctl->pad[31 + 8 * rank + k] = (unsigned)(tacc[k] / (unsigned long long)max(niter, 1));
+    if (tid == 0) ctl->pad[31 + 8 * rank + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID instead of the barrier's clocks
 #endif
     if (has) { x[row] = xv; r[row] = rv; p[row] = p_s[row - lo]; }
     if (rank == 0 && tid == 0) { sc[0].rz[0] = rz; sc[0].rz[1] = rz; sc[0].rr = rr; }
@@ -2860,25 +2873,55 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
         // 32 workgroups (one per compute unit), or up to 64 (two per compute unit: the variants of <= 3 chunks per workgroup are
         // compiled for two workgroups per compute unit -- two waves per SIMD hide each other's latencies) when that takes the chunks per
         // workgroup from 4-6 to 2-3.  More than two per compute unit would leave workgroups waiting for a seat that the spinning ones hold.
-        int kch = (m->nchunk_s + 31) / 32;
-        if (kch > 3 && (m->nchunk_s + 63) / 64 <= 3) kch = (m->nchunk_s + 63) / 64;
-        const int Ps = (m->nchunk_s + kch - 1) / kch, Pn = std::max(Ps, m->nchunk);
-        bool ok = kch <= XG_MAXCH;
+        // Two on a compute unit do not run alike: the SIMDs issue oldest-first, the workgroup that came second (in dispatch order: rank >=
+        // 32) gets the slots the first leaves -- measured 1.25-1.3x slower in every phase, its partner not at all -- and an iteration lasts
+        // as long as its slowest workgroup.  So the second-comers get the smaller share (2 chunks against 3, and no vector chunk where an
+        // older neighbour can take it), and the runs of the two kinds alternate along the rows so that every column range stays one
+        // neighbourhood of the mesh.  (Placement is the dispatcher's habit, not a promise: a different one costs speed, never results.)
+        const int N = m->nchunk_s;
+        struct Run { int c0, c1, rank; bool young; };
+        std::vector<Run> runs;
+        int kch = (N + 31) / 32;
+        if (kch > 3 && (N + 63) / 64 <= 3) {
+            const int so = N > 128 ? 3 : 2, sy = N > 160 ? 3 : 2;                  // chunks of a first-comer / of a second-comer
+            const int Y = std::min(32, (N - 32 * so + sy - 1) / sy), R = 32 + Y;
+            int c = 0, o = 0, y = 0;
+            for (int j = 0; j < R; ++j) {
+                const bool young = (j + 1) * Y / R > j * Y / R;                     // spread evenly; the last run is a second-comer's
+                const int n = std::min(young ? sy : so, N - c);
+                runs.push_back(Run{c, c + n, young ? 32 + y++ : o++, young});
+                c += n;
+            }
+            kch = so;
+            if (c != N) { runs.clear(); kch = XG_MAXCH + 1; }                       // (cannot happen: 32 so + Y sy >= N)
+        } else {
+            for (int j = 0, c = 0; c < N; ++j, c += kch) runs.push_back(Run{c, std::min(c + kch, N), j, false});
+        }
+        for (int w = (int)runs.size(); w < m->nchunk; ++w) runs.push_back(Run{N, N, w, false});   // (more vector chunks than runs: workgroups without rows)
+        const int Pn = (int)runs.size();
+        bool ok = kch <= XG_MAXCH && Pn > 0;
         int maxq = 0, maxr = 0;
-        // vector chunk v (rows 256 v ..) goes to the workgroup whose SpMV rows hold its first row, so that a workgroup's column range
-        // stays one neighbourhood of the mesh; where two chunks would meet in one workgroup (runs longer than 256 rows): chunk v to workgroup v
-        std::vector<int> vec_of(Pn, -1);
-        {
+        // vector chunk v (rows 256 v ..) goes to the workgroup whose SpMV rows hold its first row -- to the first-comer beside it if that one
+        // is a second-comer --, so that a workgroup's column range stays one neighbourhood of the mesh; where two chunks would meet in
+        // one workgroup (runs longer than 256 rows): chunk v to workgroup v
+        std::vector<int> vec_of(Pn, -1);                                            // by rank
+        if (ok) {
+            std::vector<int> run_of(std::max(N, 1), 0);
+            for (int j = 0; j < Pn; ++j) for (int c = runs[j].c0; c < runs[j].c1; ++c) run_of[c] = j;
             bool clash = false;
             for (int v = 0; v < m->nchunk; ++v) {
-                const int w = std::min((v * RPB) / (kch * SPB), Pn - 1);
-                clash = clash || vec_of[w] >= 0;
-                vec_of[w] = v;
+                const int j = run_of[std::min((v * RPB) / SPB, N - 1)];
+                const int cand[4] = {runs[j].young ? -1 : j, j > 0 && !runs[j - 1].young ? j - 1 : -1, j + 1 < Pn && !runs[j + 1].young ? j + 1 : -1, j};
+                int take = -1;
+                for (int k = 0; k < 4 && take < 0; ++k) if (cand[k] >= 0 && vec_of[runs[cand[k]].rank] < 0) take = cand[k];
+                clash = clash || take < 0;
+                if (take >= 0) vec_of[runs[take].rank] = v;
             }
             if (clash) for (int w = 0; w < Pn; ++w) vec_of[w] = w < m->nchunk ? w : -1;
         }
-        for (int w = 0; w < Pn && ok; ++w) {
-            const int c0 = std::min(w * kch, m->nchunk_s), c1 = std::min(c0 + kch, m->nchunk_s);
+        P.xg.assign(ok ? Pn : 0, make_int4(0, 0, 0, 0));
+        for (int j = 0; j < Pn && ok; ++j) {
+            const int w = runs[j].rank, c0 = runs[j].c0, c1 = runs[j].c1;
             int lo = m->ndof, hi = 0;
             if (vec_of[w] >= 0) { lo = std::min(lo, vec_of[w] * RPB); hi = std::max(hi, std::min(vec_of[w] * RPB + RPB, m->ndof)); }   // the own vector chunk's rows
             for (int c = c0; c < c1; ++c) {
@@ -2890,7 +2933,7 @@ int plan_model(fem_model *m, int eltype, int npe, int nmesh, int nn, int ne, uns
             if (hi <= lo) { lo = 0; hi = 2; }
             lo &= ~1; hi = (hi + 1) & ~1;                       // 16-byte pieces of r
             maxr = std::max(maxr, hi - lo);
-            P.xg.push_back(make_int4(c0, c1 | (vec_of[w] + 1) << 16, lo, hi));   // (end of the chunk run | (vector chunk + 1) << 16)
+            P.xg[w] = make_int4(c0, c1 | (vec_of[w] + 1) << 16, lo, hi);   // (end of the chunk run | (vector chunk + 1) << 16)
         }
         const int mc = kch <= 1 ? 1 : kch <= 3 ? 3 : XG_MAXCH;   // the kernel's template variants
         const size_t lds = ((size_t)2 * maxr + (size_t)3 * mc * std::max(maxq, 1) + 2) * sizeof(double);   // (+ the zero slot)

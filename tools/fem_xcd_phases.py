@@ -14,7 +14,7 @@ b = load.copy()[None]; b[:, fixed] = 0
 if len(sys.argv) > 3 and sys.argv[3] == "two_level": fea.cg_preconditioner("two_level")
 fea.cg_setup(b); fea.cg_iterate(iters); fea.cg_result()
 fea.cg_setup(b); fea.cg_iterate(iters); fea.cg_result()
-out = np.zeros(32, np.uint32)
+out = np.zeros(32 + 8 * 64, np.uint32)
 L = lib(); L.fem_debug_xcd_timing.argtypes = [C.c_void_p, C.c_void_p]
 assert L.fem_debug_xcd_timing(fea._h, out.ctypes.data) == 0
 names = ["spmv phase 1", "spmv phase 2 + puts", "hop A (poll pAp, Ap row)", "update + puts", "hop B + new p (two-level: the new p only)",
@@ -22,3 +22,8 @@ names = ["spmv phase 1", "spmv phase 2 + puts", "hop A (poll pAp, Ap row)", "upd
 for r in range(3):
     t = out[2 + 8 * r: 10 + 8 * r]
     print("rank", r, "clocks per iteration:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, t)), "| sum", int(t.sum()))
+if os.environ.get("XG_ALL"):
+    for r in range(64):
+        t = out[32 + 8 * r: 40 + 8 * r]
+        h = int(t[7])
+        if t.sum(): print("rank %2d" % r, " ".join("%5d" % int(v) for v in t[:7]), "| sum", int(t[:7].sum()), "| se %d sh %d cu %2d simd %d wave %2d" % ((h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15, (h >> 4) & 3, h & 15))
