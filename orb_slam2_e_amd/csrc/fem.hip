@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -435,6 +436,15 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     v += dpp_shr_f64<4>(v);
     v += dpp_shr_f64<8>(v);
     return ((readlane_f64(v, 15) + readlane_f64(v, 31)) + readlane_f64(v, 47)) + readlane_f64(v, 63);
+}
+// The same sum, bit for bit, of a v that is +0.0 in every lane but 0 and 8 of each row (k_fem_spmv's p.Ap terms: one lane in eight): the
+// four steps above reduce to  row total = (v[8] + v[0]) + 0.0  -- every other term of the scan adds a +0.0, which changes nothing but
+// the sign of a -0.0, and the one `+ 0.0` left does the same (x + (-x) rounds to +0.0, so no case tells the two apart).
+__device__ __forceinline__ double wave_sum_f64_lanes08(double v)
+{
+    v += dpp_shr_f64<8>(v);
+    v += 0.0;
+    return ((readlane_f64(v, 8) + readlane_f64(v, 24)) + readlane_f64(v, 40)) + readlane_f64(v, 56);
 }
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
@@ -1413,14 +1423,18 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
     double *a_s = reinterpret_cast<double *>(rinfo + ((ldr + 1) & ~1));   // Ac^-1 (48 x 48): read from memory by wave 0's solve it was 48 round trips, 14,000 clocks per iteration
     // the blocks of this thread, for the whole launch
     float va[MC][XG_MAXQ][9]; int ca[MC][XG_MAXQ]; int nqa[MC], r0a[MC], r1a[MC];
+    bool wide = false;                                    // some chunk of this workgroup has more than CGT blocks
 #pragma unroll
     for (int ch = 0; ch < MC; ++ch) {
         nqa[ch] = 0; r0a[ch] = r1a[ch] = 0;
+#pragma unroll
+        for (int u = 0; u < XG_MAXQ; ++u) ca[ch][u] = 0;
         if (ch < nch) {
             const int r0 = (c0 + ch) * SPB, r1 = min(r0 + SPB, ndof);
             const int q0 = bp[r0 / 3], nq = bp[r1 / 3] - q0;
             if (tid <= (r1 - r0) / 3) s_bp[ch][tid] = bp[r0 / 3 + tid] - q0;
             nqa[ch] = nq; r0a[ch] = r0; r1a[ch] = r1;
+            wide = wide || nq > CGT;
 #pragma unroll
             for (int u = 0; u < XG_MAXQ; ++u) {
                 const int qq = min(tid + u * CGT, nq - 1);
@@ -1471,7 +1485,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
     int goff[MC][NPASS][4], gbase[MC][NPASS], gnb[MC][NPASS], grow[MC][NPASS];
     const int zero = 3 * MC * ldq;            // part[zero]: one spare double behind the chunks' regions
     if (tid == 0) part[zero] = 0.0;
-    bool more = false;
+    bool more = false, more2 = false;
 #pragma unroll
     for (int ch = 0; ch < MC; ++ch)
 #pragma unroll
@@ -1485,8 +1499,10 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) goff[ch][pass][jj] = sl + LPR * jj < gnb[ch][pass] ? gbase[ch][pass] + 3 * (sl + LPR * jj) : zero;
             more = more || gnb[ch][pass] > 4 * LPR;
+            more2 = more2 || gnb[ch][pass] > 2 * LPR;
         }
     const bool anymore = __any(more) != 0;
+    const bool deep = __any(more2) != 0;              // some row of this wave has more than 16 blocks
     xg_sync();
 #ifdef XG_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -1503,6 +1519,15 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         // the LDS reads of all the blocks are in flight together.  The values stay FLOATS in registers: the empty asm statement makes them
         // "new" every iteration -- without it the compiler hoisted the 54 conversions out of the loop, kept 108 registers of doubles, spilled
         // 18 of them and read those back from scratch one `s_waitcnt vmcnt(0)` at a time (which also waited for the previous phase's stores).
+        double pin[MC][XG_MAXQ][3];
+#pragma unroll
+        for (int ch = 0; ch < MC; ++ch)                   // (all the reads first -- chunks that do not exist read p[0..2] --, so that no block waits for its own)
+#pragma unroll
+            for (int u = 0; u < XG_MAXQ; ++u) {
+                if (u > 0 && !wide) continue;
+                const double *pp = p_s + ca[ch][u];
+                pin[ch][u][0] = pp[0]; pin[ch][u][1] = pp[1]; pin[ch][u][2] = pp[2];
+            }
 #pragma unroll
         for (int ch = 0; ch < MC; ++ch) {
             if (ch < nch) {
@@ -1510,8 +1535,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 for (int u = 0; u < XG_MAXQ; ++u) {
                     if (u > 0 && u * CGT >= nqa[ch]) continue;
                     const int qq = min(tid + u * CGT, nqa[ch] - 1);
-                    const double *pp = p_s + ca[ch][u];
-                    const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                    const double p0 = pin[ch][u][0], p1 = pin[ch][u][1], p2 = pin[ch][u][2];
                     double *dst = part + 3 * (ch * ldq + qq);
 #pragma unroll
                     for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(va[ch][u][i]));
@@ -1530,14 +1554,15 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         // A lane adds the partials sl, sl + 8, .. of its row in that order; the slots past the row's end read a 0.0, and `+ 0.0` changes
         // nothing (a sum that starts at +0.0 never is -0.0).  Rows of more than 32 blocks take the loop for the rest (wave-uniform test).
         double acc[MC], srow[MC][NPASS];
-        {
-            double pv[MC][NPASS][4], pr[MC][NPASS];
+        auto row_sums = [&](auto nj_) {                   // NJ = 2: no row of this wave has more than 16 blocks, the partials 16.. are not asked for at all
+            constexpr int NJ = decltype(nj_)::value;
+            double pv[MC][NPASS][NJ], pr[MC][NPASS];
 #pragma unroll
             for (int ch = 0; ch < MC; ++ch)
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) pv[ch][pass][jj] = part[goff[ch][pass][jj]];
+                    for (int jj = 0; jj < NJ; ++jj) pv[ch][pass][jj] = part[goff[ch][pass][jj]];
                     pr[ch][pass] = p_s[max(grow[ch][pass], lo) - lo];
                 }
 #pragma unroll
@@ -1547,8 +1572,9 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 for (int pass = 0; pass < NPASS; ++pass) {
                     double sm = 0;
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) sm += pv[ch][pass][jj];
-                    if (anymore)
+                    for (int jj = 0; jj < NJ; ++jj) sm += pv[ch][pass][jj];
+                    // (NJ == 2: the two slots left out held +0.0, and sm -- a sum that began at +0.0 -- is never -0.0: adding them changed no bit)
+                    if (NJ == 4 && anymore)
                         for (int j = sl + 4 * LPR; j < gnb[ch][pass]; j += LPR) sm += part[gbase[ch][pass] + 3 * j];
                     sm += dpp_shl_f64<4>(sm);
                     sm += dpp_shl_f64<2>(sm);
@@ -1556,9 +1582,10 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                     srow[ch][pass] = sm;
                     acc[ch] += grow[ch][pass] >= 0 && sl == 0 ? pr[ch][pass] * sm : 0.0;
                 }
-                acc[ch] = wave_sum_f64(acc[ch]);      // block_sum, all chunks behind one barrier
+                acc[ch] = wave_sum_f64_lanes08(acc[ch]);      // block_sum, all chunks behind one barrier
             }
-        }
+        };
+        if (deep) row_sums(std::integral_constant<int, 4>{}); else row_sums(std::integral_constant<int, 2>{});
         if constexpr (!COARSE) XG_T(5);
         // (the rows go out behind the sums, not between them: a store is a hand-written asm statement with a memory clobber, and ten of
         // them inside the loop above made ten chains of LDS reads run one after the other -- 10,600 of an iteration's 20,700 clocks)
