@@ -1332,42 +1332,89 @@ __device__ __forceinline__ void xg_put(char *gb, int slot, double v, unsigned ta
 }
 __device__ __forceinline__ bool xg_ok(const xg_u32x4 g, unsigned tag) { return g.z == tag && g.w == (g.x ^ g.y ^ tag ^ XG_KEY); }
 __device__ __forceinline__ double xg_val(const xg_u32x4 g) { return __builtin_bit_cast(double, ((unsigned long long)g.y << 32) | g.x); }
-// Wave-wide poll of U granules per lane (slot < 0: nothing wanted) until every wanted one carries `tag`; false: timed out / aborted.
-template <int U>
-__device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[U], unsigned tag, double (&out)[U], XgCtl *ctl, unsigned where, bool same_xcd)
+// The U loads of a poll round and their wait as ONE asm statement per U.  Hand-written: to the compiler a buffer-load builtin is a pure
+// read of an unchanging address, and it hoisted all U of them out of the poll loop (neither the builtin's volatile bit nor a memory
+// clobber stopped it) -- the bug of this kernel's first day: every wave but the one that had stored the granule itself spun on a
+// register.  One statement: with a statement per load the compiler is free to copy a register a load has been issued into before the
+// wait (it did, once the loads became conditional: the copies held the registers' old contents).
+template <int U> struct XgLoad;
+template <> struct XgLoad<1> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[1], const char *(&a)[1], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(a[0]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(a[0]) : "memory");
+} };
+template <> struct XgLoad<2> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[2], const char *(&a)[2], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(a[0]), "v"(a[1]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(a[0]), "v"(a[1]) : "memory");
+} };
+template <> struct XgLoad<3> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[3], const char *(&a)[3], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off sc0 sc1\n\tglobal_load_dwordx4 %2, %5, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
+} };
+template <> struct XgLoad<4> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[4], const char *(&a)[4], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\tglobal_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+} };
+template <> struct XgLoad<8> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[8], const char *(&a)[8], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\tglobal_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\tglobal_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\tglobal_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\tglobal_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+} };
+template <> struct XgLoad<10> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[10], const char *(&a)[10], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %10, off sc1\n\tglobal_load_dwordx4 %1, %11, off sc1\n\tglobal_load_dwordx4 %2, %12, off sc1\n\tglobal_load_dwordx4 %3, %13, off sc1\n\tglobal_load_dwordx4 %4, %14, off sc1\n\tglobal_load_dwordx4 %5, %15, off sc1\n\tglobal_load_dwordx4 %6, %16, off sc1\n\tglobal_load_dwordx4 %7, %17, off sc1\n\tglobal_load_dwordx4 %8, %18, off sc1\n\tglobal_load_dwordx4 %9, %19, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %10, off sc0 sc1\n\tglobal_load_dwordx4 %1, %11, off sc0 sc1\n\tglobal_load_dwordx4 %2, %12, off sc0 sc1\n\tglobal_load_dwordx4 %3, %13, off sc0 sc1\n\tglobal_load_dwordx4 %4, %14, off sc0 sc1\n\tglobal_load_dwordx4 %5, %15, off sc0 sc1\n\tglobal_load_dwordx4 %6, %16, off sc0 sc1\n\tglobal_load_dwordx4 %7, %17, off sc0 sc1\n\tglobal_load_dwordx4 %8, %18, off sc0 sc1\n\tglobal_load_dwordx4 %9, %19, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]) : "memory");
+} };
+template <> struct XgLoad<14> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[14], const char *(&a)[14], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %14, off sc1\n\tglobal_load_dwordx4 %1, %15, off sc1\n\tglobal_load_dwordx4 %2, %16, off sc1\n\tglobal_load_dwordx4 %3, %17, off sc1\n\tglobal_load_dwordx4 %4, %18, off sc1\n\tglobal_load_dwordx4 %5, %19, off sc1\n\tglobal_load_dwordx4 %6, %20, off sc1\n\tglobal_load_dwordx4 %7, %21, off sc1\n\tglobal_load_dwordx4 %8, %22, off sc1\n\tglobal_load_dwordx4 %9, %23, off sc1\n\tglobal_load_dwordx4 %10, %24, off sc1\n\tglobal_load_dwordx4 %11, %25, off sc1\n\tglobal_load_dwordx4 %12, %26, off sc1\n\tglobal_load_dwordx4 %13, %27, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %14, off sc0 sc1\n\tglobal_load_dwordx4 %1, %15, off sc0 sc1\n\tglobal_load_dwordx4 %2, %16, off sc0 sc1\n\tglobal_load_dwordx4 %3, %17, off sc0 sc1\n\tglobal_load_dwordx4 %4, %18, off sc0 sc1\n\tglobal_load_dwordx4 %5, %19, off sc0 sc1\n\tglobal_load_dwordx4 %6, %20, off sc0 sc1\n\tglobal_load_dwordx4 %7, %21, off sc0 sc1\n\tglobal_load_dwordx4 %8, %22, off sc0 sc1\n\tglobal_load_dwordx4 %9, %23, off sc0 sc1\n\tglobal_load_dwordx4 %10, %24, off sc0 sc1\n\tglobal_load_dwordx4 %11, %25, off sc0 sc1\n\tglobal_load_dwordx4 %12, %26, off sc0 sc1\n\tglobal_load_dwordx4 %13, %27, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]) : "memory");
+} };
+// Wave-wide poll of UL + UR granules per lane (slot < 0: nothing wanted) until every wanted one carries `tag`; false: timed out / aborted.
+// The first UL slots are the LATE ones (chunk partials: the last thing their producers publish), the other UR the EARLY ones (rows).
+// A round is straight-line: the loads (a lane that wants nothing in a slot reads granule 0), one wait, the checks, one vote.  The early
+// group is asked for until the whole wave has all of it -- kept then, and the rounds after that load the late group only; nothing else is
+// remembered.  (A granule that carried the tag keeps it until this workgroup has moved on -- the hazard note above --, so a second read is
+// harmless.)  Two earlier forms: a "still wanted" flag per slot and lane, asking only for those, compiled to ~50 scalar mask operations
+// per slot and round (500 instructions per round of the ten-slot poll, against the ~1,000 clocks of the round trip itself); asking for
+// everything every round made the rounds as long as their bytes take through the compute unit's one load path (8 waves x 10 KB per
+// round at 64 B per clock): 6.7 us per iteration against 5.4.
+template <int UL, int UR>
+__device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[UL + UR], unsigned tag, double (&out)[UL + UR], XgCtl *ctl, unsigned where, bool same_xcd)
 {
-    bool pend[U];
+    constexpr int U = UL + UR;
+    const char *addr[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { pend[u] = slot[u] >= 0; out[u] = 0; }
+    for (int u = 0; u < U; ++u) { addr[u] = gb + 16 * (size_t)max(slot[u], 0); out[u] = 0.0; }
+    bool early = UR > 0;                                  // wave-uniform: the early group is still being asked for
     for (unsigned spins = 0;; ++spins) {
-        xg_u32x4 g[U];
-        // Hand-written loads: to the compiler a buffer-load builtin is a pure read of an unchanging address, and it hoisted all U of them
-        // out of this loop (neither the builtin's volatile bit nor a memory clobber in the loop stopped it) -- the bug of this kernel's
-        // first day: every wave but the one that had stored the granule itself spun on a register.  U loads in flight, one wait; the
-        // empty asm statements behind it tie every later use of g[u] to a point after the wait.
-        // (only what is still wanted is asked for again: the r rows of a range are there rounds before the last chunk partial is)
-        if (same_xcd) {
+        bool all = true;
+        if (early) {
+            xg_u32x4 g[U];
+            XgLoad<U>::run(g, addr, same_xcd);
+            bool allr = true;
 #pragma unroll
-            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
-        } else {
+            for (int u = UL; u < U; ++u) allr = allr && (slot[u] < 0 || xg_ok(g[u], tag));
+            if (__all(allr)) {
+                early = false;
 #pragma unroll
-            for (int u = 0; u < U; ++u) { g[u] = xg_u32x4{0u, 0u, 0u, 0u}; if (pend[u]) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(g[u]) : "v"(gb + 16 * (size_t)slot[u]) : "memory"); }
+                for (int u = UL; u < U; ++u) out[u] = slot[u] >= 0 ? xg_val(g[u]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) { all = all && (slot[u] < 0 || xg_ok(g[u], tag)); out[u] = slot[u] >= 0 ? xg_val(g[u]) : 0.0; }
+        } else if constexpr (UL > 0) {
+            xg_u32x4 g[UL];
+            const char *al[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) al[u] = addr[u];
+            XgLoad<UL>::run(g, al, same_xcd);
+#pragma unroll
+            for (int u = 0; u < UL; ++u) { all = all && (slot[u] < 0 || xg_ok(g[u], tag)); out[u] = slot[u] >= 0 ? xg_val(g[u]) : 0.0; }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(g[u]) :: "memory");
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (pend[u] && xg_ok(g[u], tag)) { out[u] = xg_val(g[u]); pend[u] = false; }
-            any = any || pend[u];
-        }
-        if (!__any(any)) return true;
+        if (!early && __all(all)) return true;
         if (spins > XG_SPIN || ((spins & 1023u) == 1023u && __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             if (spins > XG_SPIN) {      // the first to time out says where (development aid: fem_debug_xcd reads the word)
                 unsigned expect = 0;
                 __hip_atomic_compare_exchange_strong(&ctl->abort_flag, &expect, where | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) out[u] = 0.0;
             return false;
         }
         // (no s_sleep between rounds: a round is one L2 round trip, ~1,000 clocks, and the 64 clocks of an s_sleep 1 were 1.7 % of an iteration)
@@ -1469,7 +1516,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         if (tid == 0) xg_put(gb, L.id + rank, (double)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf), base, false);   // HW_REG_XCC_ID, bits 0-3
         int slot[1]; double got[1];
         slot[0] = lane < P ? L.id + lane : -1;
-        if (!xg_get<1>(gb, slot, base, got, ctl, 4u | (unsigned)rank << 8 | (unsigned)w << 16, false)) s_fail = 1;
+        if (!xg_get<1, 0>(gb, slot, base, got, ctl, 4u | (unsigned)rank << 8 | (unsigned)w << 16, false)) s_fail = 1;
         const double mine = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(unsigned long long, got[0]) >> 32)) << 32) |
                                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_bit_cast(unsigned long long, got[0])));   // rank 0's id
         fast = !__any(lane < P && got[0] != mine) && !(cur & 2);
@@ -1519,6 +1566,10 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         // the LDS reads of all the blocks are in flight together.  The values stay FLOATS in registers: the empty asm statement makes them
         // "new" every iteration -- without it the compiler hoisted the 54 conversions out of the loop, kept 108 registers of doubles, spilled
         // 18 of them and read those back from scratch one `s_waitcnt vmcnt(0)` at a time (which also waited for the previous phase's stores).
+#ifdef XG_EXP_P1X2
+        for (int rep_ = 0; rep_ < 2; ++rep_) {
+        if (rep_) asm volatile("" ::: "memory");
+#endif
         double pin[MC][XG_MAXQ][3];
 #pragma unroll
         for (int ch = 0; ch < MC; ++ch)                   // (all the reads first -- chunks that do not exist read p[0..2] --, so that no block waits for its own)
@@ -1545,6 +1596,9 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 }
             }
         }
+#ifdef XG_EXP_P1X2
+        }
+#endif
         xg_sync();
         XG_T(0);   // SpMV phase 1
         // (phase 2: 8 lanes per row, DPP row_shl sums in a fixed order; the chunk's partial of p.Ap)
@@ -1615,7 +1669,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
 #pragma unroll
             for (int u = 0; u < 3; ++u) slot[u] = lane + 64 * u < nchunk_s ? L.pap + par * nchunk_s + lane + 64 * u : -1;
             slot[3] = has ? L.ap + row : -1;
-            if (!xg_get<4>(gb, slot, tagA, got, ctl, 1u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+            if (!xg_get<3, 1>(gb, slot, tagA, got, ctl, 1u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
             double v = 0;
 #pragma unroll
             for (int u = 0; u < 3; ++u) if (lane + 64 * u < nchunk_s) v += got[u];      // chunk_sum's order
@@ -1656,7 +1710,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
             slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
 #pragma unroll
             for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[2 + u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
-            if (!xg_get<2 + XG_SU>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+            if (!xg_get<2, XG_SU>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
             rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);       // chunk_sum with <= 32 partials: a lane per partial
             rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
             beta = cg_ratio(rz2, rz);
@@ -1666,7 +1720,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 int slot2[XG_SU]; double got2[XG_SU];
 #pragma unroll
                 for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; slot2[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
-                if (!xg_get<XG_SU>(gb, slot2, tagB, got2, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                if (!xg_get<0, XG_SU>(gb, slot2, tagB, got2, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
 #pragma unroll
                 for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; if (slot2[u] >= 0) p_s[i] = got2[u] * d_s[i] + beta * p_s[i]; }
             }
@@ -1687,7 +1741,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                     const int e = u * CGT + tid;
                     slot[2 + XG_SU + u] = e < na3 ? L.r + 3 * (int)(__float_as_uint(cz[zp0 + e / 3].w) & 0x0fffffffu) + e % 3 : -1;
                 }
-                if (!xg_get<2 + XG_SU + XG_SA>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                if (!xg_get<2, XG_SU + XG_SA>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
                 rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);
                 rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
 #pragma unroll
@@ -1707,7 +1761,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                         const int e = e0 + u * CGT + tid;
                         slot[u] = e < na3 ? L.r + 3 * (int)(__float_as_uint(cz[zp0 + e / 3].w) & 0x0fffffffu) + e % 3 : -1;
                     }
-                    if (!xg_get<XG_SA>(gb, slot, tagB, got, ctl, 5u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                    if (!xg_get<0, XG_SA>(gb, slot, tagB, got, ctl, 5u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
 #pragma unroll
                     for (int u = 0; u < XG_SA; ++u) { const int e = e0 + u * CGT + tid; if (e < na3) r_a[e] = got[u]; }
                 }
@@ -1743,7 +1797,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 int slot[2]; double got[2];
                 slot[0] = lane < CZ_NC ? L.cw + par * 2 * CZ_NC + lane : -1;
                 slot[1] = lane < CZ_NC ? L.cw + par * 2 * CZ_NC + CZ_NC + lane : -1;
-                if (!xg_get<2>(gb, slot, tagC, got, ctl, 6u | (unsigned)rank << 8 | (unsigned)it << 20, fast)) s_fail = 1;
+                if (!xg_get<2, 0>(gb, slot, tagC, got, ctl, 6u | (unsigned)rank << 8 | (unsigned)it << 20, fast)) s_fail = 1;
                 if (lane < CZ_NC) { s_w[lane] = got[0]; s_w[CZ_NC + lane] = got[1]; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own LDS writes, read back below
                 const int kq = min(lane, CZ_NC - 1);
@@ -1773,7 +1827,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 int slot2[XG_SU]; double got2[XG_SU];
 #pragma unroll
                 for (int u = 0; u < XG_SU; ++u) { const int i = b0 + u * CGT + tid; slot2[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
-                if (!xg_get<XG_SU>(gb, slot2, tagB, got2, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                if (!xg_get<0, XG_SU>(gb, slot2, tagB, got2, ctl, 3u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
 #pragma unroll
                 for (int u = 0; u < XG_SU; ++u) {
                     const int i = b0 + u * CGT + tid;
