@@ -1326,9 +1326,9 @@ __device__ __forceinline__ void xg_put(char *gb, int slot, double v, unsigned ta
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     xg_u32x4 g;
     g.x = (unsigned)b; g.y = (unsigned)(b >> 32); g.z = tag; g.w = g.x ^ g.y ^ tag ^ XG_KEY;
-    char *a = gb + 16 * (size_t)slot;
-    if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a), "v"(g) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a), "v"(g) : "memory");
+    const unsigned a = 16u * (unsigned)slot;              // (base in scalar registers + a 32-bit byte offset: the buffer is far below 4 GB)
+    if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(a), "v"(g), "s"(gb) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(a), "v"(g), "s"(gb) : "memory");
 }
 __device__ __forceinline__ bool xg_ok(const xg_u32x4 g, unsigned tag) { return g.z == tag && g.w == (g.x ^ g.y ^ tag ^ XG_KEY); }
 __device__ __forceinline__ double xg_val(const xg_u32x4 g) { return __builtin_bit_cast(double, ((unsigned long long)g.y << 32) | g.x); }
@@ -1338,33 +1338,34 @@ __device__ __forceinline__ double xg_val(const xg_u32x4 g) { return __builtin_bi
 // register.  One statement: with a statement per load the compiler is free to copy a register a load has been issued into before the
 // wait (it did, once the loads became conditional: the copies held the registers' old contents).
 template <int U> struct XgLoad;
-template <> struct XgLoad<1> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[1], const char *(&a)[1], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(a[0]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(a[0]) : "memory");
+// (addresses: the granule buffer's base in scalar registers + a 32-bit byte offset per lane)
+template <> struct XgLoad<1> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[1], const char *gb, const unsigned (&a)[1], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(a[0]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(a[0]), "s"(gb) : "memory");
 } };
-template <> struct XgLoad<2> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[2], const char *(&a)[2], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(a[0]), "v"(a[1]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(a[0]), "v"(a[1]) : "memory");
+template <> struct XgLoad<2> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[2], const char *gb, const unsigned (&a)[2], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(a[0]), "v"(a[1]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %2, %4 sc0 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(a[0]), "v"(a[1]), "s"(gb) : "memory");
 } };
-template <> struct XgLoad<3> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[3], const char *(&a)[3], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off sc0 sc1\n\tglobal_load_dwordx4 %2, %5, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
+template <> struct XgLoad<3> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[3], const char *gb, const unsigned (&a)[3], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %3, %6 sc1\n\tglobal_load_dwordx4 %1, %4, %6 sc1\n\tglobal_load_dwordx4 %2, %5, %6 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %3, %6 sc0 sc1\n\tglobal_load_dwordx4 %1, %4, %6 sc0 sc1\n\tglobal_load_dwordx4 %2, %5, %6 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "s"(gb) : "memory");
 } };
-template <> struct XgLoad<4> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[4], const char *(&a)[4], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\tglobal_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+template <> struct XgLoad<4> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[4], const char *gb, const unsigned (&a)[4], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %4, %8 sc1\n\tglobal_load_dwordx4 %1, %5, %8 sc1\n\tglobal_load_dwordx4 %2, %6, %8 sc1\n\tglobal_load_dwordx4 %3, %7, %8 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %4, %8 sc0 sc1\n\tglobal_load_dwordx4 %1, %5, %8 sc0 sc1\n\tglobal_load_dwordx4 %2, %6, %8 sc0 sc1\n\tglobal_load_dwordx4 %3, %7, %8 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(gb) : "memory");
 } };
-template <> struct XgLoad<8> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[8], const char *(&a)[8], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\tglobal_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\tglobal_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\tglobal_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\tglobal_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+template <> struct XgLoad<6> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[6], const char *gb, const unsigned (&a)[6], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %6, %12 sc1\n\tglobal_load_dwordx4 %1, %7, %12 sc1\n\tglobal_load_dwordx4 %2, %8, %12 sc1\n\tglobal_load_dwordx4 %3, %9, %12 sc1\n\tglobal_load_dwordx4 %4, %10, %12 sc1\n\tglobal_load_dwordx4 %5, %11, %12 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %6, %12 sc0 sc1\n\tglobal_load_dwordx4 %1, %7, %12 sc0 sc1\n\tglobal_load_dwordx4 %2, %8, %12 sc0 sc1\n\tglobal_load_dwordx4 %3, %9, %12 sc0 sc1\n\tglobal_load_dwordx4 %4, %10, %12 sc0 sc1\n\tglobal_load_dwordx4 %5, %11, %12 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "s"(gb) : "memory");
 } };
-template <> struct XgLoad<10> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[10], const char *(&a)[10], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %10, off sc1\n\tglobal_load_dwordx4 %1, %11, off sc1\n\tglobal_load_dwordx4 %2, %12, off sc1\n\tglobal_load_dwordx4 %3, %13, off sc1\n\tglobal_load_dwordx4 %4, %14, off sc1\n\tglobal_load_dwordx4 %5, %15, off sc1\n\tglobal_load_dwordx4 %6, %16, off sc1\n\tglobal_load_dwordx4 %7, %17, off sc1\n\tglobal_load_dwordx4 %8, %18, off sc1\n\tglobal_load_dwordx4 %9, %19, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %10, off sc0 sc1\n\tglobal_load_dwordx4 %1, %11, off sc0 sc1\n\tglobal_load_dwordx4 %2, %12, off sc0 sc1\n\tglobal_load_dwordx4 %3, %13, off sc0 sc1\n\tglobal_load_dwordx4 %4, %14, off sc0 sc1\n\tglobal_load_dwordx4 %5, %15, off sc0 sc1\n\tglobal_load_dwordx4 %6, %16, off sc0 sc1\n\tglobal_load_dwordx4 %7, %17, off sc0 sc1\n\tglobal_load_dwordx4 %8, %18, off sc0 sc1\n\tglobal_load_dwordx4 %9, %19, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]) : "memory");
+template <> struct XgLoad<8> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[8], const char *gb, const unsigned (&a)[8], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %8, %16 sc1\n\tglobal_load_dwordx4 %1, %9, %16 sc1\n\tglobal_load_dwordx4 %2, %10, %16 sc1\n\tglobal_load_dwordx4 %3, %11, %16 sc1\n\tglobal_load_dwordx4 %4, %12, %16 sc1\n\tglobal_load_dwordx4 %5, %13, %16 sc1\n\tglobal_load_dwordx4 %6, %14, %16 sc1\n\tglobal_load_dwordx4 %7, %15, %16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %8, %16 sc0 sc1\n\tglobal_load_dwordx4 %1, %9, %16 sc0 sc1\n\tglobal_load_dwordx4 %2, %10, %16 sc0 sc1\n\tglobal_load_dwordx4 %3, %11, %16 sc0 sc1\n\tglobal_load_dwordx4 %4, %12, %16 sc0 sc1\n\tglobal_load_dwordx4 %5, %13, %16 sc0 sc1\n\tglobal_load_dwordx4 %6, %14, %16 sc0 sc1\n\tglobal_load_dwordx4 %7, %15, %16 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "s"(gb) : "memory");
 } };
-template <> struct XgLoad<14> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[14], const char *(&a)[14], bool same_xcd) {
-    if (same_xcd) asm volatile("global_load_dwordx4 %0, %14, off sc1\n\tglobal_load_dwordx4 %1, %15, off sc1\n\tglobal_load_dwordx4 %2, %16, off sc1\n\tglobal_load_dwordx4 %3, %17, off sc1\n\tglobal_load_dwordx4 %4, %18, off sc1\n\tglobal_load_dwordx4 %5, %19, off sc1\n\tglobal_load_dwordx4 %6, %20, off sc1\n\tglobal_load_dwordx4 %7, %21, off sc1\n\tglobal_load_dwordx4 %8, %22, off sc1\n\tglobal_load_dwordx4 %9, %23, off sc1\n\tglobal_load_dwordx4 %10, %24, off sc1\n\tglobal_load_dwordx4 %11, %25, off sc1\n\tglobal_load_dwordx4 %12, %26, off sc1\n\tglobal_load_dwordx4 %13, %27, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %14, off sc0 sc1\n\tglobal_load_dwordx4 %1, %15, off sc0 sc1\n\tglobal_load_dwordx4 %2, %16, off sc0 sc1\n\tglobal_load_dwordx4 %3, %17, off sc0 sc1\n\tglobal_load_dwordx4 %4, %18, off sc0 sc1\n\tglobal_load_dwordx4 %5, %19, off sc0 sc1\n\tglobal_load_dwordx4 %6, %20, off sc0 sc1\n\tglobal_load_dwordx4 %7, %21, off sc0 sc1\n\tglobal_load_dwordx4 %8, %22, off sc0 sc1\n\tglobal_load_dwordx4 %9, %23, off sc0 sc1\n\tglobal_load_dwordx4 %10, %24, off sc0 sc1\n\tglobal_load_dwordx4 %11, %25, off sc0 sc1\n\tglobal_load_dwordx4 %12, %26, off sc0 sc1\n\tglobal_load_dwordx4 %13, %27, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]) : "memory");
+template <> struct XgLoad<10> { static __device__ __forceinline__ void run(xg_u32x4 (&g)[10], const char *gb, const unsigned (&a)[10], bool same_xcd) {
+    if (same_xcd) asm volatile("global_load_dwordx4 %0, %10, %20 sc1\n\tglobal_load_dwordx4 %1, %11, %20 sc1\n\tglobal_load_dwordx4 %2, %12, %20 sc1\n\tglobal_load_dwordx4 %3, %13, %20 sc1\n\tglobal_load_dwordx4 %4, %14, %20 sc1\n\tglobal_load_dwordx4 %5, %15, %20 sc1\n\tglobal_load_dwordx4 %6, %16, %20 sc1\n\tglobal_load_dwordx4 %7, %17, %20 sc1\n\tglobal_load_dwordx4 %8, %18, %20 sc1\n\tglobal_load_dwordx4 %9, %19, %20 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "s"(gb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %10, %20 sc0 sc1\n\tglobal_load_dwordx4 %1, %11, %20 sc0 sc1\n\tglobal_load_dwordx4 %2, %12, %20 sc0 sc1\n\tglobal_load_dwordx4 %3, %13, %20 sc0 sc1\n\tglobal_load_dwordx4 %4, %14, %20 sc0 sc1\n\tglobal_load_dwordx4 %5, %15, %20 sc0 sc1\n\tglobal_load_dwordx4 %6, %16, %20 sc0 sc1\n\tglobal_load_dwordx4 %7, %17, %20 sc0 sc1\n\tglobal_load_dwordx4 %8, %18, %20 sc0 sc1\n\tglobal_load_dwordx4 %9, %19, %20 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&v"(g[8]), "=&v"(g[9]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "s"(gb) : "memory");
 } };
 // Wave-wide poll of UL + UR granules per lane (slot < 0: nothing wanted) until every wanted one carries `tag`; false: timed out / aborted.
 // The first UL slots are the LATE ones (chunk partials: the last thing their producers publish), the other UR the EARLY ones (rows).
@@ -1379,15 +1380,15 @@ template <int UL, int UR>
 __device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[UL + UR], unsigned tag, double (&out)[UL + UR], XgCtl *ctl, unsigned where, bool same_xcd)
 {
     constexpr int U = UL + UR;
-    const char *addr[U];
+    unsigned addr[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { addr[u] = gb + 16 * (size_t)max(slot[u], 0); out[u] = 0.0; }
+    for (int u = 0; u < U; ++u) { addr[u] = 16u * (unsigned)max(slot[u], 0); out[u] = 0.0; }
     bool early = UR > 0;                                  // wave-uniform: the early group is still being asked for
     for (unsigned spins = 0;; ++spins) {
         bool all = true;
         if (early) {
             xg_u32x4 g[U];
-            XgLoad<U>::run(g, addr, same_xcd);
+            XgLoad<U>::run(g, gb, addr, same_xcd);
             bool allr = true;
 #pragma unroll
             for (int u = UL; u < U; ++u) allr = allr && (slot[u] < 0 || xg_ok(g[u], tag));
@@ -1400,10 +1401,10 @@ __device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[UL + UR
             for (int u = 0; u < UL; ++u) { all = all && (slot[u] < 0 || xg_ok(g[u], tag)); out[u] = slot[u] >= 0 ? xg_val(g[u]) : 0.0; }
         } else if constexpr (UL > 0) {
             xg_u32x4 g[UL];
-            const char *al[UL];
+            unsigned al[UL];
 #pragma unroll
             for (int u = 0; u < UL; ++u) al[u] = addr[u];
-            XgLoad<UL>::run(g, al, same_xcd);
+            XgLoad<UL>::run(g, gb, al, same_xcd);
 #pragma unroll
             for (int u = 0; u < UL; ++u) { all = all && (slot[u] < 0 || xg_ok(g[u], tag)); out[u] = slot[u] >= 0 ? xg_val(g[u]) : 0.0; }
         }
@@ -1728,26 +1729,35 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
             constexpr int XG_SA = 4;                          // aggregate rows per thread and poll (<= 1,024 rows = 341 nodes; larger: more rounds)
             // hop B: the chunk partials, the column range's r rows and -- aggregate owners -- the first rows of the own aggregate
             const bool owner = rank < CZ_NA;                  // aggregate a = rank, rank + P, .. (P < 8: several per workgroup)
+            // An aggregate's owner asks for the partials and its aggregate's rows first and restricts -- every workgroup waits for those sums --
+            // and for the rows of its own column range afterwards, when they have long arrived; the others ask for partials and range at once.
             double rgot[XG_SU];
-            {
-                int slot[2 + XG_SU + XG_SA]; double got[2 + XG_SU + XG_SA];
+            if (owner) {
+                int slot[2 + XG_SA]; double got[2 + XG_SA];
+                slot[0] = lane < nchunk ? L.rz + par * nchunk + lane : -1;
+                slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
+                const int zp0 = czptr[rank], na3 = 3 * (czptr[rank + 1] - zp0);
+#pragma unroll
+                for (int u = 0; u < XG_SA; ++u) {
+                    const int e = u * CGT + tid;
+                    slot[2 + u] = e < na3 ? L.r + 3 * (int)(__float_as_uint(cz[zp0 + e / 3].w) & 0x0fffffffu) + e % 3 : -1;
+                }
+                if (!xg_get<2, XG_SA>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);
+                rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
+#pragma unroll
+                for (int u = 0; u < XG_SA; ++u) { const int e = u * CGT + tid; if (e < na3) r_a[e] = got[2 + u]; }
+            } else {
+                int slot[2 + XG_SU]; double got[2 + XG_SU];
                 slot[0] = lane < nchunk ? L.rz + par * nchunk + lane : -1;
                 slot[1] = lane < nchunk ? L.rr + par * nchunk + lane : -1;
 #pragma unroll
                 for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[2 + u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
-                const int zp0 = owner ? czptr[rank] : 0, na3 = owner ? 3 * (czptr[rank + 1] - zp0) : 0;
-#pragma unroll
-                for (int u = 0; u < XG_SA; ++u) {
-                    const int e = u * CGT + tid;
-                    slot[2 + XG_SU + u] = e < na3 ? L.r + 3 * (int)(__float_as_uint(cz[zp0 + e / 3].w) & 0x0fffffffu) + e % 3 : -1;
-                }
-                if (!xg_get<2, XG_SU + XG_SA>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
+                if (!xg_get<2, XG_SU>(gb, slot, tagB, got, ctl, 2u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
                 rz2 = wave_sum_f64(lane < nchunk ? got[0] : 0.0);
                 rr = wave_sum_f64(lane < nchunk ? got[1] : 0.0);
 #pragma unroll
                 for (int u = 0; u < XG_SU; ++u) rgot[u] = got[2 + u];
-#pragma unroll
-                for (int u = 0; u < XG_SA; ++u) { const int e = u * CGT + tid; if (e < na3) r_a[e] = got[2 + XG_SU + u]; }
             }
             XG_T(5);   // (two-level) hop B's poll
             // restriction of the owned aggregates: cz_apply_block's waves (a, half = 0) and (a, half = 1) are waves 0 and 1 here
@@ -1790,6 +1800,12 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
 #pragma unroll
                     for (int m = 0; m < 6; ++m) { w6[m] = wave_sum_f64(w6[m]); if (lane == m) xg_put(gb, L.cw + par * 2 * CZ_NC + half * CZ_NC + 6 * ag + m, w6[m], tagC, fast); }
                 }
+            }
+            if (owner) {                                      // (the column range's rows, behind the restriction)
+                int slot[XG_SU];
+#pragma unroll
+                for (int u = 0; u < XG_SU; ++u) { const int i = u * CGT + tid; slot[u] = i < rng && lo + i < ndof ? L.r + lo + i : -1; }
+                if (!xg_get<0, XG_SU>(gb, slot, tagB, rgot, ctl, 7u | (unsigned)rank << 8 | (unsigned)w << 16 | (unsigned)it << 20, fast)) s_fail = 1;
             }
             XG_T(6);   // (two-level) restriction of the own aggregate + puts
             // hop C: the 96 sums; v = Ac^-1 w and w.v as cz_apply_block's wave 0
