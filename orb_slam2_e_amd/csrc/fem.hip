@@ -1567,10 +1567,6 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
         // the LDS reads of all the blocks are in flight together.  The values stay FLOATS in registers: the empty asm statement makes them
         // "new" every iteration -- without it the compiler hoisted the 54 conversions out of the loop, kept 108 registers of doubles, spilled
         // 18 of them and read those back from scratch one `s_waitcnt vmcnt(0)` at a time (which also waited for the previous phase's stores).
-#ifdef XG_EXP_P1X2
-        for (int rep_ = 0; rep_ < 2; ++rep_) {
-        if (rep_) asm volatile("" ::: "memory");
-#endif
         double pin[MC][XG_MAXQ][3];
 #pragma unroll
         for (int ch = 0; ch < MC; ++ch)                   // (all the reads first -- chunks that do not exist read p[0..2] --, so that no block waits for its own)
@@ -1597,9 +1593,6 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
                 }
             }
         }
-#ifdef XG_EXP_P1X2
-        }
-#endif
         xg_sync();
         XG_T(0);   // SpMV phase 1
         // (phase 2: 8 lanes per row, DPP row_shl sums in a fixed order; the chunk's partial of p.Ap)
