@@ -970,9 +970,16 @@ def main():
             for _ in range(5): dst.copy_(src, non_blocking=True)
             torch.cuda.synchronize()
             bw[name] = 5 * (64 << 20) / (time.perf_counter() - t0) / 1e9
+        # (c) the live tracker's shape: ONE frame per call through ORBextractor::operator() -- host image in, keypoints and descriptors out
+        one = ORBextractor(2000, 1.2, 8, 20, 7)
+        for k in range(8): one(frames[k])
+        call_ms = batch_ms(lambda: one(frames[3]), 200, warm=10)
+        del one
         host_io = {"pcie_pinned_copy_GBps": bw, "frames_per_s_extract_only_sync_pageable": rate_sync, "frames_per_s_extract_only_pinned_pipelined": rate_pipe,
                    "bytes_per_frame": W * H + cap * 60 + 4,
-                   "note": "64 host u8 frames in over PCIe, all keypoints+descriptors+counts out; no match; never `value`"}
+                   "one_frame_operator_call_ms": call_ms[0], "one_frame_operator_call_ms_best": call_ms[1],
+                   "note": "64 host u8 frames in over PCIe, all keypoints+descriptors+counts out; no match; never `value`; one_frame_*: a "
+                           "single 640x480 frame per ORBextractor::operator() call (pyramid levels 1.. in one launch: k_pyr_chain)"}
         for c in ctxs:
             del c.pin_in, c.d_in, c.pin_kps, c.pin_desc, c.pin_cnt
 

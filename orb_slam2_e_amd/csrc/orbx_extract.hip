@@ -1183,6 +1183,176 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 // --------------------------------------------------------------------- blur
 
 
+// Levels 1 .. n-1 of the pyramid in ONE launch -- the form SMALL batches take (orbx_extract_batch: <= 2 frames, the live tracker's one frame
+// per call: 22 us against the seven dependent per-level launches' 52; in the pipelined 64-frame step it was slower than they are,
+// profiles/r04_notes.md, and is not used there).  A workgroup carries one spatial tile through all levels in LDS: it loads
+// its rectangle of level 0, computes from it its rectangle of level 1 (the same fixed-point arithmetic, 4 pixels per lane from an
+// 8-byte source window -- taken from three aligned LDS dwords), stores the part of the padded level 1 it owns (border pixels through
+// the reflected coordinate, as the per-level kernel does), computes level 2 from level 1, and so on.  The rectangles (host table,
+// plan_frame) are what the tile owns at a level plus what its deeper levels read: neighbours overlap by a few pixels per level and
+// recompute them (1.3-1.5 x the arithmetic of the exact chain), and nobody waits for anybody.
+__device__ __forceinline__ int chain_pitch(int nw) { return ((nw + 15) & ~15) + 16; }
+__global__ __launch_bounds__(256) void k_pyr_chain(uint8_t *__restrict__ pyr, size_t frame_bytes, const LevelInfo *__restrict__ L, int nlevels,
+                                                   const ChainTile *__restrict__ tiles, const uint4 *__restrict__ tabs,
+                                                   const int2 *__restrict__ tab_span, int ldsA, int ldsB)
+{
+    extern __shared__ __align__(16) uint8_t chain_lds[];
+    const int tid = threadIdx.x, f = blockIdx.y;
+    ORBX_PH_INIT(2);
+#ifdef ORBX_PHASE_TIMING
+    if (tid == 0) { ph_rec[12] = 0; ph_rec[11] = 1; ph_rec[1] = ph_rec[2] = ph_rec[3] = 0; }
+#endif
+    const ChainTile &T = tiles[blockIdx.x];
+    uint8_t *const fp = pyr + (size_t)f * frame_bytes;
+    // the tile's coefficient tables, prepared by the host as one block (plan_frame): for every level the rows {sy0 | sy1 << 16,
+    // b0 | b1 << 16} and then the columns {sx, a0 | a1 << 16} of its rectangle, source coordinates relative to the source rectangle.
+    // The rectangles and the levels' geometry are staged too (read per level through the scalar cache they were a dependent memory
+    // round trip at the top of every level)
+    uint4 *const s_rect = reinterpret_cast<uint4 *>(chain_lds + ldsA + ldsB);          // [MAXL] ChainRect, [MAXL] {w, h, stride, off}
+    int2 *const s_tab = reinterpret_cast<int2 *>(s_rect + 2 * MAXL);
+    const int2 span = tab_span[blockIdx.x];      // first 16-byte unit, units
+    if (tid < MAXL) s_rect[tid] = reinterpret_cast<const uint4 *>(&T)[tid];
+    else if (tid < 2 * MAXL) s_rect[tid] = *reinterpret_cast<const uint4 *>(&L[tid - MAXL]);
+    auto rect_at = [&](int l) {
+        uint4 v = s_rect[l];
+        v.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.x); v.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y);
+        v.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z); v.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w);
+        return __builtin_bit_cast(ChainRect, v);
+    };
+    struct Geo { int w, h, stride, off; };
+    auto geo_at = [&](int l) {
+        uint4 v = s_rect[MAXL + l];
+        Geo g;
+        g.w = __builtin_amdgcn_readfirstlane((int)v.x); g.h = __builtin_amdgcn_readfirstlane((int)v.y);
+        g.stride = __builtin_amdgcn_readfirstlane((int)v.z); g.off = __builtin_amdgcn_readfirstlane((int)v.w);
+        return g;
+    };
+    {   // level 0: the rectangle in 16-byte pieces (nx0 % 4 == 0: dword-aligned in memory; the columns past nw up to the pitch are read
+        // too: they lie inside the padded row), all of a lane's pieces in flight together; the tables travel meanwhile
+        const ChainRect r0 = T.r[0];
+        const LevelInfo l0 = L[0];
+        const int p16 = chain_pitch(r0.nw) >> 4, n = p16 * r0.nh;
+        const uint8_t *src = fp + l0.off + PADX + r0.nx0 + (size_t)(r0.ny0 + EDGE) * l0.stride;
+        for (int i = tid; i < span.y; i += 256) reinterpret_cast<uint4 *>(s_tab)[i] = tabs[span.x + i];
+        for (int i0 = tid; i0 < n; i0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(i0 + 256 * k, n - 1), row = i / p16, c = i - row * p16;
+                __builtin_memcpy(&v[k], src + (uint32_t)(row * l0.stride + 16 * c), 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + 256 * k < n) reinterpret_cast<uint4 *>(chain_lds)[i0 + 256 * k] = v[k];
+        }
+    }
+    __syncthreads();
+    int nytot = 0;
+    for (int l = 1; l < nlevels; ++l) nytot += rect_at(l).nh;
+    const int2 *const s_yt = s_tab, *const s_xt = s_tab + ((nytot + 1) & ~1);
+    ORBX_PH(0, tid == 0);    // tables + level 0 in LDS
+    int yo = 0, xo = 0;
+    ChainRect rp = rect_at(0);
+    for (int l = 1; l < nlevels; ++l) {
+        const ChainRect rc = rect_at(l);
+        const Geo lv = geo_at(l);
+        const uint8_t *src = chain_lds + ((l - 1) & 1 ? ldsA : 0);
+        uint8_t *dst = chain_lds + (l & 1 ? ldsA : 0);
+        const int pp = chain_pitch(rp.nw), pc = chain_pitch(rc.nw);
+        uint8_t *const gout = fp + lv.off;
+        // ---- compute the rectangle: lane = a group of 4 columns x a band of consecutive rows (G groups side by side, G a power of two,
+        // 256 / G bands).  A source row's horizontal pass (4 pixels) stays in registers: consecutive output rows share source rows
+        // (sy1 of one is sy0 of the next four times out of five), so a row is read and interpolated 1.2 times instead of 2.  A dword
+        // that the tile owns and that holds four interior pixels goes to memory straight from the registers.
+        const int ngrp = (rc.nw + 3) >> 2;
+        int gs = 0;
+        while ((1 << gs) < ngrp) ++gs;
+        const int g = tid & ((1 << gs) - 1), band = tid >> gs, nband = 256 >> gs;
+        const int rb = (rc.nh + nband - 1) / nband, r_lo = band * rb, r_hi = min(r_lo + rb, (int)rc.nh);
+        if (g < ngrp && r_lo < r_hi) {
+            const int2 *xg = s_xt + xo + 4 * g;
+            const int2 x0 = xg[0], x1 = xg[1], x2 = xg[2], x3 = xg[3];
+            const uint32_t coef[4] = {(uint32_t)x0.y, (uint32_t)x1.y, (uint32_t)x2.y, (uint32_t)x3.y};
+            const int col0 = x0.x, a4 = col0 >> 2, o = col0 & 3;
+            const uint32_t sel[4] = {0x0c010c00u, 0x0c010c00u + (uint32_t)(x1.x - col0) * 0x00010001u,
+                                     0x0c010c00u + (uint32_t)(x2.x - col0) * 0x00010001u, 0x0c010c00u + (uint32_t)(x3.x - col0) * 0x00010001u};
+            const int2 *yl = s_yt + yo;
+            struct H4 { int v[4]; };
+            auto horiz = [&](int srow) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(src + srow * pp) + a4;
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                const uint32_t wx = __builtin_amdgcn_alignbyte(d1, d0, o), wy = __builtin_amdgcn_alignbyte(d2, d1, o);
+                H4 h;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    h.v[b] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(wy, wx, sel[b])),
+                                                         __builtin_bit_cast(pyr_u16x2, coef[b]), 0u, false);
+                return h;
+            };
+            // the dword of this group in the padded row, and whether the tile stores it from here
+            const int gx = rc.nx0 + 4 * g, xw = (PADX + gx) >> 2;
+            const bool own_x = xw >= rc.oxw0 && xw < rc.oxw1 && gx + 3 < lv.w;
+            int prev = -1;
+            H4 hp = {{0, 0, 0, 0}};
+            for (int r = r_lo; r < r_hi; ++r) {
+                const int2 yy = yl[r];
+                const int s0 = yy.x & 0xffff, s1 = (int)((uint32_t)yy.x >> 16);
+                const H4 h0 = s0 == prev ? hp : horiz(s0);
+                const H4 h1 = s1 == s0 ? h0 : horiz(s1);
+                hp = h1; prev = s1;
+                const uint32_t bs0 = ((uint32_t)yy.y & 0xffffu) << 12, bs1 = ((uint32_t)yy.y >> 16) << 12;
+                uint32_t out = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) out |= resize_vertical(h0.v[b], h1.v[b], bs0, bs1) << (8 * b);
+                *reinterpret_cast<uint32_t *>(dst + r * pc + 4 * g) = out;
+                const int row = rc.ny0 + r + EDGE;
+                if (own_x && row >= rc.or0 && row < rc.or1) *reinterpret_cast<uint32_t *>(gout + (uint32_t)(row * lv.stride + 4 * xw)) = out;
+            }
+        }
+        __syncthreads();
+        ORBX_PHA(1, tid == 0);   // compute (all levels)
+        // ---- what is left of the tile's share of the padded level: the border (reflected coordinates) -- rows above / below the image
+        // in full, beside the image the dwords that are not four interior pixels.  Lane = a dword of the padded row
+        const int ndw = rc.oxw1 - rc.oxw0, nrow = rc.or1 - rc.or0;
+        const int ilo = PADX >> 2, ihi = (PADX + lv.w) >> 2;           // dwords [ilo, ihi) hold four interior pixels each
+        const bool side = rc.oxw0 < ilo || rc.oxw1 > ihi, cap = rc.or0 < EDGE || rc.or1 > lv.h + EDGE;
+        if (ndw > 0 && nrow > 0 && (side || cap)) {
+            int ws = 0;
+            while ((1 << ws) < ndw) ++ws;
+            const int c = tid & ((1 << ws) - 1), r1st = tid >> ws, wpass = 256 >> ws;
+            if (c < ndw) {
+                const int xw = rc.oxw0 + c, px0 = xw * 4 - PADX;
+                const bool interior = xw >= ilo && xw < ihi;
+                int cx[4]; uint32_t keep = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int px = min(max(px0 + b, -EDGE), lv.w + EDGE - 1);
+                    px = px < 0 ? -px : (px >= lv.w ? 2 * (lv.w - 1) - px : px);       // one fold is enough: |px| <= EDGE < w
+                    cx[b] = px - rc.nx0;
+                    keep |= (px0 + b >= -EDGE && px0 + b < lv.w + EDGE) ? 0xffu << (8 * b) : 0u;
+                }
+                for (int r = r1st; r < nrow; r += wpass) {
+                    const int row = rc.or0 + r, yy0 = row - EDGE;
+                    const bool inrow = yy0 >= 0 && yy0 < lv.h;
+                    if (interior && inrow) continue;                                   // stored from the registers above
+                    const int y = yy0 < 0 ? -yy0 : (yy0 >= lv.h ? 2 * (lv.h - 1) - yy0 : yy0);
+                    const uint8_t *sr = dst + (y - rc.ny0) * pc;
+                    uint32_t v;
+                    if (interior) v = *reinterpret_cast<const uint32_t *>(sr + cx[0]);   // nx0 % 4 == 0: an aligned dword
+                    else v = ((uint32_t)sr[cx[0]] | ((uint32_t)sr[cx[1]] << 8) | ((uint32_t)sr[cx[2]] << 16) | ((uint32_t)sr[cx[3]] << 24)) & keep;
+                    *reinterpret_cast<uint32_t *>(gout + (uint32_t)(row * lv.stride + 4 * xw)) = v;
+                }
+            }
+        }
+        // (no barrier here: the next level reads `dst`, which nobody writes any more, and writes the other buffer, which nobody
+        // reads any more -- its last readers passed the barrier above)
+        yo += rc.nh; xo += (rc.nw + 3) & ~3;
+        rp = rc;
+        ORBX_PHA(2, tid == 0);   // border stores (all levels; thread 0's share)
+    }
+    ORBX_PH_END(tid == 0);
+}
+
 // GaussianBlur(7x7, sigma 2, REFLECT_101) in 8.8 fixed point: horizontal 7 taps exact in
 // u16, vertical 7 taps exact in u32, min((v + 2^15) >> 16, 255).  The padded pyramid already holds the
 // reflected border, so no index clamping.
@@ -1618,12 +1788,12 @@ void drop_graph(orbx_extractor *ex)
 void free_workspace(orbx_extractor *ex)
 {
     drop_graph(ex);
-    void *ptrs[] = {ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_blur_frag, ex->d_xt, ex->d_yt, ex->d_cell_count,
+    void *ptrs[] = {ex->d_chain, ex->d_chain_tabs, ex->d_chain_span, ex->d_pyr, ex->d_blur, ex->d_lv, ex->d_cells, ex->d_tiles, ex->d_blur_frag, ex->d_xt, ex->d_yt, ex->d_cell_count,
                     ex->d_level_count, ex->d_level_ncand, ex->d_counts, ex->d_cands, ex->d_kpos, ex->d_sel,
                     ex->d_knode, ex->d_kq, ex->d_desc, ex->d_kps};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    ex->d_pyr = ex->d_blur = nullptr; ex->d_lv = nullptr; ex->d_cells = nullptr; ex->d_tiles = nullptr; ex->d_blur_frag = nullptr;
+    ex->d_chain = nullptr; ex->d_chain_tabs = nullptr; ex->d_chain_span = nullptr; ex->d_pyr = ex->d_blur = nullptr; ex->d_lv = nullptr; ex->d_cells = nullptr; ex->d_tiles = nullptr; ex->d_blur_frag = nullptr;
     ex->d_xt = nullptr; ex->d_yt = nullptr; ex->d_cell_count = ex->d_level_count = ex->d_level_ncand = ex->d_counts = nullptr;
     ex->d_cands = ex->d_kpos = ex->d_sel = nullptr; ex->d_knode = nullptr; ex->d_kq = ex->d_desc = nullptr; ex->d_kps = nullptr;
     ex->width = ex->height = ex->batch = 0;
@@ -1979,6 +2149,99 @@ static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int
         if (worst >= ((size_t)1 << 24) || ex->keys_per_frame >= ((size_t)1 << 31) || ex->cands_per_frame >= ((size_t)1 << 31))
             ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "more than 2^24 FAST candidate slots in one pyramid level");
     }
+    // ---- the pyramid chain in one launch (k_pyr_chain): tiles and their rectangles per level
+    ex->chain.clear(); ex->chain_tiles = 0; ex->chain_ldsA = ex->chain_ldsB = 0;
+    {
+        bool ok = nl >= 2 && nl <= MAXL;
+        for (int l = 1; l < nl && ok; ++l) ok = ex->resize_nxi[l] != 0 && ex->lv[l].w >= 8 && ex->lv[l].h >= 8;   // the 8-byte source window must hold at every level
+        const auto refl = [](int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p; return p; };
+        if (ok) {
+            const LevelInfo &l1 = ex->lv[1];
+            // tiles of 48 x 36 px at level 1 (15 x 11 of them on 640 x 480): one frame's launch 22.3 us; 96 x 72: 26.8, 32 x 36: 22.6 -- a
+            // workgroup's seven dependent levels are the floor, not the tile's area (ORBX_CHAIN_TW / _TH: development knobs)
+            const int ctw = getenv("ORBX_CHAIN_TW") ? std::max(16, atoi(getenv("ORBX_CHAIN_TW"))) : 48, cth = getenv("ORBX_CHAIN_TH") ? std::max(16, atoi(getenv("ORBX_CHAIN_TH"))) : 36;
+            const int nx = std::max(1, (l1.w + 2 * EDGE + ctw - 1) / ctw), ny = std::max(1, (l1.h + 2 * EDGE + cth - 1) / cth);
+            int maxA = 0, maxB = 0;
+            for (int j = 0; j < ny && ok; ++j)
+                for (int i = 0; i < nx && ok; ++i) {
+                    ChainTile T;
+                    memset(&T, 0, sizeof(T));
+                    int ax0 = 0, ax1 = -1, ay0 = 0, ay1 = -1;        // what the deeper level reads of this one (inner coordinates, inclusive; empty: ax1 < ax0)
+                    for (int l = nl - 1; l >= 0; --l) {
+                        const LevelInfo &lv = ex->lv[l];
+                        int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+                        ChainRect &rc = T.r[l];
+                        if (l >= 1) {
+                            // ownership follows the INNER image: tile i owns the columns [w i / nx, w (i + 1) / nx) (cut at multiples of 4, so
+                            // that the cuts are dword boundaries of the padded row), the first and last tile the 19-px border beside them --
+                            // the tiles of all levels then cover the same part of the scene and a level's rectangle is little more than what
+                            // the tile owns of it
+                            const int xlo = (PADX - EDGE) >> 2, xhi = (PADX + lv.w + EDGE - 1) >> 2, R = lv.h + 2 * EDGE;
+                            const auto bx = [&](int k) { return (int)((long long)k * lv.w / nx) & ~3; };
+                            const auto by = [&](int k) { return (int)((long long)k * lv.h / ny); };
+                            rc.oxw0 = (short)(i == 0 ? xlo : (PADX + bx(i)) >> 2); rc.oxw1 = (short)(i == nx - 1 ? xhi + 1 : (PADX + bx(i + 1)) >> 2);
+                            rc.or0 = (short)(j == 0 ? 0 : EDGE + by(j)); rc.or1 = (short)(j == ny - 1 ? R : EDGE + by(j + 1));
+                            for (int px = rc.oxw0 * 4 - PADX; px < rc.oxw1 * 4 - PADX; ++px) {
+                                if (px < -EDGE || px >= lv.w + EDGE) continue;
+                                const int x = refl(px, lv.w);
+                                x0 = std::min(x0, x); x1 = std::max(x1, x);
+                            }
+                            for (int row = rc.or0; row < rc.or1; ++row) {
+                                const int y = refl(row - EDGE, lv.h);
+                                y0 = std::min(y0, y); y1 = std::max(y1, y);
+                            }
+                            if (x1 < x0 || y1 < y0) { x0 = y0 = 1 << 30; x1 = y1 = -1; rc.oxw1 = rc.oxw0; rc.or1 = rc.or0; }   // owns nothing here
+                        }
+                        if (ax1 >= ax0) { x0 = std::min(x0, ax0); x1 = std::max(x1, ax1); y0 = std::min(y0, ay0); y1 = std::max(y1, ay1); }
+                        if (x1 < x0) { x0 = x1 = 0; y0 = y1 = 0; }      // nothing owned, nothing needed below: a 1 x 1 rectangle keeps the kernel uniform
+                        x0 &= ~3;
+                        rc.nx0 = (short)x0; rc.ny0 = (short)y0; rc.nw = (short)(x1 - x0 + 1); rc.nh = (short)(y1 - y0 + 1);
+                        if (rc.nw > 1024 || rc.nh > 4096) ok = false;
+                        const int bytes = (((rc.nw + 15) & ~15) + 16) * rc.nh + 16;
+                        if (l & 1) maxB = std::max(maxB, bytes); else maxA = std::max(maxA, bytes);
+                        if (l >= 1) {      // what computing this rectangle reads of level l - 1
+                            const int2 *xtab = &xt[lv.xtab];
+                            const int4 *ytab = &yt[lv.ytab];
+                            const int wsrc = ex->lv[l - 1].w;
+                            ax0 = xtab[x0].x; ax1 = std::min(xtab[std::min(x1, lv.w - 1)].x + 1, wsrc - 1);
+                            ay0 = std::min(ytab[y0].x, ytab[y0].y); ay1 = std::max(ytab[y1].x, ytab[y1].y);
+                        }
+                    }
+                    ex->chain.push_back(T);
+                }
+            maxA = (maxA + 15) & ~15; maxB = (maxB + 15) & ~15;
+            // the coefficient tables of every tile as one block of 16-byte units: per level the rows, then per level the columns
+            int maxT = 0;
+            ex->chain_tabs.clear(); ex->chain_span.clear();
+            for (const ChainTile &T : ex->chain) {
+                const size_t first = ex->chain_tabs.size();
+                std::vector<int2> rows;
+                for (int l = 1; l < nl; ++l)
+                    for (int r = 0; r < T.r[l].nh; ++r) {
+                        const int4 y = yt[ex->lv[l].ytab + T.r[l].ny0 + r];
+                        const int s0 = y.x - T.r[l - 1].ny0, s1 = y.y - T.r[l - 1].ny0;
+                        if (s0 < 0 || s1 < s0 || s1 > 65535 || y.z < 0 || y.z > 65535 || y.w < 0 || y.w > 65535) ok = false;
+                        rows.push_back(make_int2(s0 | (s1 << 16), y.z | (y.w << 16)));
+                    }
+                if (rows.size() & 1) rows.push_back(make_int2(0, 0));
+                for (size_t k = 0; k < rows.size(); k += 2)
+                    ex->chain_tabs.push_back(make_uint4((unsigned)rows[k].x, (unsigned)rows[k].y, (unsigned)rows[k + 1].x, (unsigned)rows[k + 1].y));
+                std::vector<int2> cols;
+                for (int l = 1; l < nl; ++l)
+                    for (int c = 0; c < ((T.r[l].nw + 3) & ~3); ++c) {
+                        int2 x = xt[ex->lv[l].xtab + std::min(T.r[l].nx0 + c, ex->lv[l].w - 1)];     // (columns past the level: junk nobody reads)
+                        x.x -= T.r[l - 1].nx0;
+                        cols.push_back(x);
+                    }
+                for (size_t k = 0; k < cols.size(); k += 2)      // (rounded-up widths are multiples of 4: an even count)
+                    ex->chain_tabs.push_back(make_uint4((unsigned)cols[k].x, (unsigned)cols[k].y, (unsigned)cols[k + 1].x, (unsigned)cols[k + 1].y));
+                ex->chain_span.push_back(make_int2((int)first, (int)(ex->chain_tabs.size() - first)));
+                maxT = std::max(maxT, (int)(ex->chain_tabs.size() - first) * 16);
+            }
+            if (ok && maxA + maxB + maxT <= 64 * 1024) { ex->chain_tiles = nx * ny; ex->chain_ldsA = maxA; ex->chain_ldsB = maxB; ex->chain_ldsT = maxT; }
+            else ex->chain.clear();
+        }
+    }
     ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
@@ -2016,6 +2279,16 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     }
     ORBX_HIP(hipMalloc(&ex->d_cells, sizeof(CellInfo) * ex->cells.size()));
     ORBX_HIP(hipMalloc(&ex->d_tiles, sizeof(BlurTile) * ex->tiles.size()));
+    if (ex->chain_tiles) {
+        ORBX_HIP(hipMalloc(&ex->d_chain, sizeof(ChainTile) * ex->chain.size()));
+        ORBX_HIP(hipMemcpyAsync(ex->d_chain, ex->chain.data(), sizeof(ChainTile) * ex->chain.size(), hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMalloc(&ex->d_chain_tabs, sizeof(uint4) * ex->chain_tabs.size()));
+        ORBX_HIP(hipMemcpyAsync(ex->d_chain_tabs, ex->chain_tabs.data(), sizeof(uint4) * ex->chain_tabs.size(), hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMalloc(&ex->d_chain_span, sizeof(int2) * ex->chain_span.size()));
+        ORBX_HIP(hipMemcpyAsync(ex->d_chain_span, ex->chain_span.data(), sizeof(int2) * ex->chain_span.size(), hipMemcpyHostToDevice, ex->stream));
+        if (ex->chain_ldsA + ex->chain_ldsB + ex->chain_ldsT > 48 * 1024)
+            ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pyr_chain), hipFuncAttributeMaxDynamicSharedMemorySize, ex->chain_ldsA + ex->chain_ldsB + ex->chain_ldsT));
+    }
 
     ORBX_HIP(hipMalloc(&ex->d_xt, sizeof(int2) * (xt.size() + 1)));
     ORBX_HIP(hipMalloc(&ex->d_yt, sizeof(int4) * (yt.size() + 1)));
@@ -2136,7 +2409,20 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         }
         pf.stop(0, st);
     }
-    for (int l = 1; l < nl; l++) {
+    // Small batches -- the live tracker's one frame per call -- take the levels 1.. in ONE launch (k_pyr_chain): seven dependent launches of
+    // a few microseconds each are 52 of one frame's 134 us of kernels.  Large batches keep the per-level launches (the one-launch form was
+    // slower in the pipelined 64-frame step, profiles/r04_notes.md).  ORBX_PYR_CHAIN_MAX_BATCH moves the limit (0: never; tests run both).
+    const char *cmb = getenv("ORBX_PYR_CHAIN_MAX_BATCH");            // (read per call: the tests flip it)
+    const int chain_max_batch = cmb ? atoi(cmb) : 2;
+    const bool use_chain = ex->chain_tiles > 0 && batch <= chain_max_batch;
+    if (use_chain) {
+        pf.start(1, st);
+        hipLaunchKernelGGL(k_pyr_chain, dim3(ex->chain_tiles, batch), dim3(256), ex->chain_ldsA + ex->chain_ldsB + ex->chain_ldsT + 2 * MAXL * 16, st, ex->d_pyr, ex->frame_bytes,
+                           (const LevelInfo *)ex->d_lv, nl, (const ChainTile *)ex->d_chain, (const uint4 *)ex->d_chain_tabs, (const int2 *)ex->d_chain_span,
+                           ex->chain_ldsA, ex->chain_ldsB);
+        pf.stop(1, st);
+    }
+    for (int l = 1; l < nl && !use_chain; l++) {
         const LevelInfo &lv = ex->lv[l];
         const int ngi = lv.w >> 2, xlo = (PADX - EDGE) >> 2, xhi = (PADX + lv.w + EDGE - 1) >> 2;
         // waves of 64 consecutive interior groups of a row group (8-byte-window path); a last, partly filled one when at least

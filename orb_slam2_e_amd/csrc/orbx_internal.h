@@ -51,6 +51,12 @@ struct alignas(16) CellInfo : FastCell {
     int pad;
 };
 
+// k_pyr_chain: what one workgroup computes of every pyramid level.  Level l >= 1: the inner rectangle [nx0, nx0 + nw) x [ny0, ny0 + nh)
+// it computes into LDS (what it owns of the padded level plus what its deeper levels read) and the dwords x rows of the padded level
+// it stores; level 0: the rectangle it loads.  nx0 is a multiple of 4 (LDS dwords line up with the padded row's dwords).
+struct ChainRect { short nx0, ny0, nw, nh, oxw0, oxw1, or0, or1; };
+struct alignas(16) ChainTile { ChainRect r[MAXL]; };
+
 // a blur tile strip with what k_blur needs of its level: 16 bytes, one scalar load (a tile record pointing into the level
 // table was two dependent loads, the first a per-lane one, in front of the window loads)
 struct alignas(16) BlurTile { short x0, y0, w, h; int off, stride; int boff, bcol; int pad[2]; };   // boff / bcol: the level in the blurred buffer's strip layout
@@ -86,6 +92,14 @@ struct orbx_extractor {
     // one after the other (16 bytes apart), bcol = rows x 16 bytes per strip with the row count rounded up to 8 -- a 128-byte line holds
     // 8 rows x 16 px, and the 37 x 37 window of a descriptor spans a dozen lines instead of 37-74 (k_describe is bound by the texture
     // addresser's line count)
+    // the pyramid chain in one launch (k_pyr_chain): tiles per frame, the two LDS buffers' sizes; 0 tiles = the per-level launches
+    std::vector<orbx_detail::ChainTile> chain;
+    std::vector<uint4> chain_tabs;          // every tile's coefficient tables (rows, then columns, per level), 16-byte units
+    std::vector<int2> chain_span;           // first unit, units of a tile
+    orbx_detail::ChainTile *d_chain = nullptr;
+    uint4 *d_chain_tabs = nullptr;
+    int2 *d_chain_span = nullptr;
+    int chain_tiles = 0, chain_ldsA = 0, chain_ldsB = 0, chain_ldsT = 0;
     size_t blur_frame_bytes = 0;
     int boff[orbx_detail::MAXL] = {}, bcol[orbx_detail::MAXL] = {};
     int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;

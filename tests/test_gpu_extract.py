@@ -370,3 +370,40 @@ def test_small_quotas_on_wide_frames(prm, size):
     k2, d2 = ex(img2)
     ok2, od2 = oracle.OrbOracle(*prm).extract(img2)
     assert len(k2) == len(ok2) and np.array_equal(d2, od2)
+
+
+@pytest.mark.parametrize("shape,params", [
+    ((480, 640), (2000, 1.2, 8, 20, 7)),
+    ((375, 1242), (2000, 1.2, 8, 20, 7)),     # KITTI-shaped
+    ((300, 400), (500, 1.5, 4, 30, 10)),      # 4 levels, scale 1.5
+    ((243, 317), (300, 1.2, 8, 20, 7)),       # odd sizes: widths that are no multiple of 4 at most levels
+    ((2160, 3840), (2000, 1.2, 8, 20, 7)),    # 4K: many tiles
+    ((200, 260), (200, 1.2, 5, 20, 7)),       # small: few tiles, shallow rectangles
+])
+def test_pyramid_in_one_launch_equals_the_per_level_launches(shape, params, monkeypatch):
+    """Small batches build levels 1.. in ONE launch (k_pyr_chain: a workgroup carries a tile through all levels in LDS, neighbours
+    recompute the overlap); large ones keep a launch per level.  Same padded levels byte for byte, same keypoints and descriptors --
+    one frame and a batch of three, each under both forms (ORBX_PYR_CHAIN_MAX_BATCH is read per call)."""
+    from orb_slam2_e_amd.synth import synth_frame
+    h, w = shape
+    frames = [np.ascontiguousarray(np.tile(synth_frame(k), ((h + 479) // 480, (w + 639) // 640))[:h, :w]) for k in range(3)]
+    rng = np.random.default_rng(5)
+    frames = [np.clip(f.astype(np.int16) + rng.integers(-3, 4, f.shape), 0, 255).astype(np.uint8) for f in frames]
+    out = {}
+    for form, limit in (("chain", "64"), ("levels", "0")):
+        monkeypatch.setenv("ORBX_PYR_CHAIN_MAX_BATCH", limit)
+        ex = ORBextractor(*params)
+        kps, desc = ex(frames[0])
+        one = [ex.pyramid_level(0, l, padded=True).copy() for l in range(params[2])]
+        ex.extract_batch(frames)
+        res = ex.download_batch()
+        three = [ex.pyramid_level(f, l, padded=True).copy() for f in range(3) for l in range(params[2])]
+        out[form] = (kps, desc, one, res, three)
+    a, b = out["chain"], out["levels"]
+    for x, y in zip(a[2] + a[4], b[2] + b[4]):
+        assert np.array_equal(x, y)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
+    (ka, da, ca), (kb, db, cb) = a[3], b[3]       # the batch: what lies behind a frame's count is not defined
+    assert np.array_equal(ca, cb)
+    for f in range(3):
+        assert ka[f, :ca[f]].tobytes() == kb[f, :cb[f]].tobytes() and np.array_equal(da[f, :ca[f]], db[f, :cb[f]])
