@@ -2595,13 +2595,6 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
         ORBX_HIP(hipHostMalloc((void **)&ex->h_pin, in_room + out_bytes, hipHostMallocDefault));
         ex->pin_bytes = in_room + out_bytes;
     }
-    if (in_room > ex->in_bytes) {
-        drop_graph(ex);
-        if (ex->d_in) ORBX_HIP(hipFree(ex->d_in));
-        ex->d_in = nullptr;
-        ORBX_HIP(hipMalloc(&ex->d_in, in_room));
-        ex->in_bytes = in_room;
-    }
     hipStream_t st = ex->stream;
     if (ex->reader_pending) {   // a consumer on another stream (the stereo matcher, a *_dev matcher call) still reads the last results
         if (ex->reader_stream != st) ORBX_HIP(hipStreamWaitEvent(st, ex->reader_ev, 0));
@@ -2609,11 +2602,12 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
     }
     memcpy(ex->h_pin, image, in_bytes);
     ex->pin_result_off = in_room;
-    // image in and results out by the compute queue itself (common.h: stage_in / stage_out): no hand-over to the copy engine
-    // in front of and behind the twelve kernels of a frame
+    // image in and results out by the compute queue itself (the kernels read / write the pinned block): no hand-over to the copy engine
+    // in front of and behind the kernels of a frame
     auto enqueue = [&]() -> int {
-        ORBX_HIP(orbx::stage_in(ex->d_in, ex->h_pin, in_room, st));
-        const int rc2 = orbx_extract_batch(ex, ex->d_in, 1, width, height, stride, in_bytes, 1, st);
+        // (level 0 reads the pinned image itself -- it is mapped into the device's address space --: 16 us instead of a staging copy + 7, and
+        // one launch less; 0.149 -> 0.146 ms per call)
+        const int rc2 = orbx_extract_batch(ex, ex->h_pin, 1, width, height, stride, in_bytes, 1, st);
         if (rc2 != ORBX_OK) return rc2;
         uint8_t *o = ex->h_pin + in_room;
         hipLaunchKernelGGL(k_result_out, dim3((unsigned)(((kp_bytes + de_bytes) / 16 + 255) / 256)), dim3(256), 0, st, (const int *)ex->d_counts,
