@@ -737,23 +737,24 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 // whole 256-thread block; totals returned through ta / tb.  Each thread owns a
 // contiguous chunk, wave-level shuffle scan, one cross-wave hop through LDS:
 // three barriers in all.
+template <int T>
 __device__ void block_excl_scan2(int *a, int *b, int n, int *part, int &ta, int &tb)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     __syncthreads();
-    const int per = (n + OCT_T - 1) / OCT_T;
+    const int per = (n + T - 1) / T;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
     int sa = 0, sb = 0;
     for (int i = lo; i < hi; ++i) { sa += a[i]; if (b) sb += b[i]; }
     // inclusive over the wave (this kernel is a chain of ~20 such scans, each waited for)
     const int ia = orbx::wave_incl_scan(sa), ib = b ? orbx::wave_incl_scan(sb) : 0;
-    if (lane == 63) { part[w] = ia; part[OCT_T / 64 + w] = ib; }
+    if (lane == 63) { part[w] = ia; part[T / 64 + w] = ib; }
     __syncthreads();
     int ba = 0, bb = 0, ga = 0, gb = 0;
 #pragma unroll
-    for (int i = 0; i < OCT_T / 64; ++i) {
-        if (i < w) { ba += part[i]; bb += part[OCT_T / 64 + i]; }
-        ga += part[i]; gb += part[OCT_T / 64 + i];
+    for (int i = 0; i < T / 64; ++i) {
+        if (i < w) { ba += part[i]; bb += part[T / 64 + i]; }
+        ga += part[i]; gb += part[T / 64 + i];
     }
     int ra = ba + ia - sa, rb = bb + ib - sb;
     for (int i = lo; i < hi; ++i) {
@@ -764,10 +765,11 @@ __device__ void block_excl_scan2(int *a, int *b, int n, int *part, int &ta, int 
     ta = ga; tb = gb;
     __syncthreads();
 }
+template <int T>
 __device__ int block_excl_scan(int *a, int n, int *part)
 {
     int ta, tb;
-    block_excl_scan2(a, nullptr, n, part, ta, tb);
+    block_excl_scan2<T>(a, nullptr, n, part, ta, tb);
     return ta;
 }
 
@@ -790,7 +792,8 @@ __device__ __forceinline__ void child_box(int x0, int x1, int y0, int y1, int q,
 // largest-first phase use creation order.
 // Keys (candidates) live in LDS when the level has at most `kcap` of them, else in
 // the per-frame HBM workspace (flat pointers serve both).
-__global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ L, const CellInfo *__restrict__ cells,
+template <int T, int KPT, int KB>
+__global__ __launch_bounds__(T) void k_octree(const LevelInfo *__restrict__ L, const CellInfo *__restrict__ cells,
                                                   const int *__restrict__ cell_count, int cells_per_frame,
                                                   const uint32_t *__restrict__ cands, size_t cands_per_frame,
                                                   uint32_t *__restrict__ kpos_all, unsigned short *__restrict__ knode_all,
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 {
     extern __shared__ __align__(16) unsigned char smem[];
     int *p = reinterpret_cast<int *>(smem);
-    int *part = p;          p += 2 * (OCT_T / 64);
+    int *part = p;          p += 2 * (T / 64);
     int *s_cell = p;        p += (maxcells + 1 + 3) & ~3;
     int *s_coff = p;        p += (maxcells + 1 + 3) & ~3; // each cell's slot in the candidate buffer
     int *bx[2] = {p, p + NC};  p += 2 * NC; // x0 | x1<<16
@@ -830,58 +833,58 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
 
     // gather the level's candidates in cell row-major order (vToDistributeKeys)
     // (cand_off goes to LDS too, so that the gather below has one dependent global load per candidate, not two)
-    for (int c = tid; c < lv.ncells; c += OCT_T) {
+    for (int c = tid; c < lv.ncells; c += T) {
         const int n = cell_count[(size_t)f * cells_per_frame + lv.cell_base + c];
         const CellInfo ci = cells[lv.cell_base + c];
         s_cell[c] = n < ci.cap ? n : ci.cap;
         s_coff[c] = ci.cand_off;
     }
-    const int M = block_excl_scan(s_cell, lv.ncells, part);
+    const int M = block_excl_scan<T>(s_cell, lv.ncells, part);
     if (tid == 0) s_cell[lv.ncells] = M;
     const bool in_lds = M <= kcap;
     uint32_t *kpos = in_lds ? l_kpos : kpos_all + (size_t)f * keys_per_frame + lv.key_base;
     unsigned short *knode = in_lds ? l_knode : knode_all + (size_t)f * keys_per_frame + lv.key_base;
     uint8_t *kq = in_lds ? l_kq : kq_all + (size_t)f * keys_per_frame + lv.key_base;
     uint32_t *kpos_out = kpos_all + (size_t)f * keys_per_frame + lv.key_base; // candidates stay readable for staged tests
-    for (int i = tid; i < NC; i += OCT_T) cnt[0][i] = 0;
+    for (int i = tid; i < NC; i += T) cnt[0][i] = 0;
     __syncthreads();
-    // Up to OCT_KPT x 256 candidates (every level of a usual frame) the keys never leave the registers: thread t owns the keys
+    // Up to KPT x 256 candidates (every level of a usual frame) the keys never leave the registers: thread t owns the keys
     // t, t + 256, ...; a key's packed position never changes and its node is rewritten by its owner only.  A round's two passes
     // over the keys were 60 % of a workgroup's life as loops over LDS / HBM arrays -- every iteration a chain of dependent
     // reads (node of the key -> state of the node) on a workgroup of four waves; with the keys in registers all of a thread's
     // node-state reads are in flight together.
-    const bool regs = M <= OCT_KPT * OCT_T;
-    uint32_t kp[OCT_KPT];
-    int kn[OCT_KPT], kqv[OCT_KPT];
+    const bool regs = M <= KPT * T;
+    uint32_t kp[KPT];
+    int kn[KPT], kqv[KPT];
     if (regs) {
         // cell of key k = largest c with s_cell[c] <= k: the bisections of a thread's keys run in lockstep, one LDS read of each
         // in flight per step (one after the other they were 8 x 9 dependent reads)
-        // (OCT_KB keys at a time here and in the passes below: batching all eight took 187 VGPRs, and what the kernel holds on
+        // (KB keys at a time here and in the passes below: batching all eight took 187 VGPRs, and what the kernel holds on
         // a CU for 60 us is what the other contexts' kernels cannot have -- the step lost 4 % to it)
 #pragma unroll
-        for (int u = 0; u < OCT_KPT; ++u) { kp[u] = 0; kn[u] = 0; kqv[u] = 0; }
+        for (int u = 0; u < KPT; ++u) { kp[u] = 0; kn[u] = 0; kqv[u] = 0; }
 #pragma unroll
-        for (int h = 0; h < OCT_KPT; h += OCT_KB) {
-            if (h * OCT_T >= M) break;
-            int lo[OCT_KB], hi[OCT_KB];
+        for (int h = 0; h < KPT; h += KB) {
+            if (h * T >= M) break;
+            int lo[KB], hi[KB];
 #pragma unroll
-            for (int v = 0; v < OCT_KB; ++v) { lo[v] = 0; hi[v] = lv.ncells; }
+            for (int v = 0; v < KB; ++v) { lo[v] = 0; hi[v] = lv.ncells; }
             for (int span = lv.ncells; span > 1; span = (span + 1) >> 1) {
 #pragma unroll
-                for (int v = 0; v < OCT_KB; ++v) {
+                for (int v = 0; v < KB; ++v) {
                     const int mid = (lo[v] + hi[v]) >> 1;
-                    if (hi[v] - lo[v] > 1) { if (s_cell[mid] <= min(tid + (h + v) * OCT_T, M - 1)) lo[v] = mid; else hi[v] = mid; }
+                    if (hi[v] - lo[v] > 1) { if (s_cell[mid] <= min(tid + (h + v) * T, M - 1)) lo[v] = mid; else hi[v] = mid; }
                 }
             }
 #pragma unroll
-            for (int v = 0; v < OCT_KB; ++v) {
-                const int k = tid + (h + v) * OCT_T;
+            for (int v = 0; v < KB; ++v) {
+                const int k = tid + (h + v) * T;
                 if (k < M) kp[h + v] = cands[(size_t)f * cands_per_frame + s_coff[lo[v]] + (k - s_cell[lo[v]])];
             }
         }
 #pragma unroll
-        for (int u = 0; u < OCT_KPT; ++u) {
-            const int k = tid + u * OCT_T;
+        for (int u = 0; u < KPT; ++u) {
+            const int k = tid + u * T;
             if (k < M) {
                 kpos_out[k] = kp[u];
                 const float x = (float)((kp[u] >> 8) & 0xfffu);
@@ -890,11 +893,11 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             }
         }
     } else
-    for (int k0 = tid; k0 < M; k0 += 4 * OCT_T) { // four candidates per thread in flight: the loads are a dependent chain each
+    for (int k0 = tid; k0 < M; k0 += 4 * T) { // four candidates per thread in flight: the loads are a dependent chain each
         uint32_t pk4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * OCT_T;
+            const int k = k0 + u * T;
             pk4[u] = 0;
             if (k < M) {
                 int lo = 0, hiC = lv.ncells; // largest c with s_cell[c] <= k
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * OCT_T;
+            const int k = k0 + u * T;
             if (k < M) {
                 const uint32_t pk = pk4[u];
                 kpos[k] = pk;
@@ -925,9 +928,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     if (tid == 0) ph_rec[11] = M;
 #endif
     // roots (:552-563), empty ones erased (:574-585)
-    for (int i = tid; i < lv.nIni; i += OCT_T) a1[i] = cnt[0][i] > 0 ? 1 : 0;
-    int S = block_excl_scan(a1, lv.nIni, part);
-    for (int i = tid; i < lv.nIni; i += OCT_T) {
+    for (int i = tid; i < lv.nIni; i += T) a1[i] = cnt[0][i] > 0 ? 1 : 0;
+    int S = block_excl_scan<T>(a1, lv.nIni, part);
+    for (int i = tid; i < lv.nIni; i += T) {
         if (cnt[0][i] > 0) {
             const int x0 = (int)(lv.hX * (float)i), x1 = (int)(lv.hX * (float)(i + 1));
             const int pos = a1[i];
@@ -939,9 +942,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     }
     if (regs) {
 #pragma unroll
-        for (int u = 0; u < OCT_KPT; ++u) { if (u * OCT_T >= M) break; kn[u] = tid + u * OCT_T < M ? a1[kn[u]] : 0; }
+        for (int u = 0; u < KPT; ++u) { if (u * T >= M) break; kn[u] = tid + u * T < M ? a1[kn[u]] : 0; }
     } else
-    for (int k = tid; k < M; k += OCT_T) knode[k] = (unsigned short)a1[knode[k]];
+    for (int k = tid; k < M; k += T) knode[k] = (unsigned short)a1[knode[k]];
     __syncthreads();
     ORBX_PHA(1, tid == 0);   // roots
     int cur = 1, mode = 1;
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     while (true) {
         int *cx = bx[cur], *cy = by[cur], *cn = cnt[cur];
         unsigned short *cs = seq[cur];
-        for (int s = tid; s < S; s += OCT_T) {
+        for (int s = tid; s < S; s += T) {
             cc[4 * s] = cc[4 * s + 1] = cc[4 * s + 2] = cc[4 * s + 3] = 0;
             split[s] = 0;
         }
@@ -957,15 +960,15 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         // children counts of every expandable node (DivideNode, :511-526)
         if (regs) {
 #pragma unroll
-            for (int h = 0; h < OCT_KPT; h += OCT_KB) {
-                if (h * OCT_T >= M) break;
-                int ncn[OCT_KB], ncx[OCT_KB], ncy[OCT_KB];   // the node's state, read for OCT_KB of the thread's keys at once
+            for (int h = 0; h < KPT; h += KB) {
+                if (h * T >= M) break;
+                int ncn[KB], ncx[KB], ncy[KB];   // the node's state, read for KB of the thread's keys at once
 #pragma unroll
-                for (int v = 0; v < OCT_KB; ++v) { ncn[v] = cn[kn[h + v]]; ncx[v] = cx[kn[h + v]]; ncy[v] = cy[kn[h + v]]; }
+                for (int v = 0; v < KB; ++v) { ncn[v] = cn[kn[h + v]]; ncx[v] = cx[kn[h + v]]; ncy[v] = cy[kn[h + v]]; }
 #pragma unroll
-                for (int v = 0; v < OCT_KB; ++v) {
+                for (int v = 0; v < KB; ++v) {
                     const int u = h + v;
-                    if (tid + u * OCT_T < M && ncn[v] > 1) {
+                    if (tid + u * T < M && ncn[v] > 1) {
                         const float x = (float)((kp[u] >> 8) & 0xfffu), y = (float)(kp[u] >> 20);
                         const int x0 = ncx[v] & 0xffff, x1 = ncx[v] >> 16, y0 = ncy[v] & 0xffff, y1 = ncy[v] >> 16;
                         const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2);
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
                 }
             }
         } else
-        for (int k = tid; k < M; k += OCT_T) {
+        for (int k = tid; k < M; k += T) {
             const int s = knode[k];
             if (cn[s] > 1) {
                 const uint32_t pk = kpos[k];
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         __syncthreads();
         ORBX_PHA(2, tid == 0);   // children counts (pass over the keys)
         // per node: non-empty / expandable children; scanned together with the candidate flag
-        for (int s = tid; s < S; s += OCT_T) {
+        for (int s = tid; s < S; s += T) {
             int a = 0, b = 0;
             const bool cand = cn[s] > 1;
             if (cand) {
@@ -1008,14 +1011,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             a2[s] = a | (b << 16);     // -> prefix of (non-empty, expandable) children in list order
         }
         int E, PE;
-        block_excl_scan2(a1, a2, S, part, E, PE);
+        block_excl_scan2<T>(a1, a2, S, part, E, PE);
         ORBX_PHA(3, tid == 0);   // node flags + scans
         if (E == 0) break;
         int F, Etot, nns;
         if (mode == 1) {
             // every expandable node splits, in list order (:606-665)
             F = PE & 0xffff; Etot = PE >> 16;
-            for (int s = tid; s < S; s += OCT_T) {
+            for (int s = tid; s < S; s += T) {
                 if (cn[s] > 1) {
                     split[s] = 1;
                     bstart[s] = F - ((a2[s] & 0xffff) + nne[s]); // children pushed to the front, last processed first
@@ -1031,9 +1034,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             // the S x S comparison reads one LDS dword per four nodes (it was 45 % of the kernel as a scalar loop).
             unsigned *okey = reinterpret_cast<unsigned *>(ebase); // free until the splits are numbered below
             if (kshift) {
-                for (int s = tid; s < ((S + 3) & ~3); s += OCT_T) okey[s] = (s < S && cn[s] > 1) ? ((unsigned)cn[s] << kshift) | cs[s] : 0u;
+                for (int s = tid; s < ((S + 3) & ~3); s += T) okey[s] = (s < S && cn[s] > 1) ? ((unsigned)cn[s] << kshift) | cs[s] : 0u;
                 __syncthreads();
-                for (int s = tid; s < S; s += OCT_T) {
+                for (int s = tid; s < S; s += T) {
                     const unsigned k0 = okey[s];
                     if (k0) {
                         int r = 0;
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             } else {
                 // a level with 2^21 candidate slots or more (frames beyond ~8 M pixels): size and sequence do not fit one dword,
                 // the pairs are compared as they are (the plain loop the packed keys replaced: slower, exact)
-                for (int s = tid; s < S; s += OCT_T) {
+                for (int s = tid; s < S; s += T) {
                     const int c0 = cn[s], q0 = cs[s];
                     if (c0 > 1) {
                         int r = 0;
@@ -1062,10 +1065,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             __syncthreads(); // okey (= ebase) is rewritten below
             if (tid == 0) s_nproc = E;
             __syncthreads();
-            for (int r = tid; r < E; r += OCT_T) a2[r] = nne[order[r]] | (eexp[order[r]] << 16);
+            for (int r = tid; r < E; r += T) a2[r] = nne[order[r]] | (eexp[order[r]] << 16);
             int dummy;
-            block_excl_scan2(a2, nullptr, E, part, PE, dummy);
-            for (int r = tid; r < E; r += OCT_T) // stop at the first split that reaches N leaves (:730-731)
+            block_excl_scan2<T>(a2, nullptr, E, part, PE, dummy);
+            for (int r = tid; r < E; r += T) // stop at the first split that reaches N leaves (:730-731)
                 if (S + (a2[r] & 0xffff) - r + nne[order[r]] - 1 >= N) atomicMin(&s_nproc, r + 1);
             __syncthreads();
             const int nproc = s_nproc;
@@ -1073,21 +1076,21 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
             const int lastr = nproc - 1, lasts = order[lastr];
             F = (a2[lastr] & 0xffff) + nne[lasts];
             Etot = (a2[lastr] >> 16) + eexp[lasts];
-            for (int r = tid; r < nproc; r += OCT_T) {
+            for (int r = tid; r < nproc; r += T) {
                 const int s = order[r];
                 split[s] = 1;
                 bstart[s] = F - ((a2[r] & 0xffff) + nne[s]);
                 ebase[s] = a2[r] >> 16;
             }
             __syncthreads();
-            for (int s = tid; s < S; s += OCT_T) a1[s] = split[s] ? 0 : 1;
-            nns = block_excl_scan(a1, S, part); // a1[s] = rank among the nodes that stay
+            for (int s = tid; s < S; s += T) a1[s] = split[s] ? 0 : 1;
+            nns = block_excl_scan<T>(a1, S, part); // a1[s] = rank among the nodes that stay
         }
         const int S2 = F + nns;
         int *nx = bx[cur ^ 1], *ny = by[cur ^ 1], *nn = cnt[cur ^ 1];
         unsigned short *ns = seq[cur ^ 1];
         ORBX_PHA(4, tid == 0);   // which nodes split (mode 1: all; mode 2: ranking, largest first)
-        for (int s = tid; s < S; s += OCT_T) {
+        for (int s = tid; s < S; s += T) {
             if (split[s]) {
                 const int x0 = cx[s] & 0xffff, x1 = cx[s] >> 16, y0 = cy[s] & 0xffff, y1 = cy[s] >> 16;
                 int e = ebase[s];
@@ -1113,25 +1116,25 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
         }
         if (regs) {
 #pragma unroll
-            for (int h = 0; h < OCT_KPT; h += OCT_KB) {
-                if (h * OCT_T >= M) break;
-                int nsp[OCT_KB], nbs[OCT_KB], na1[OCT_KB];
-                int4 ncc[OCT_KB];
+            for (int h = 0; h < KPT; h += KB) {
+                if (h * T >= M) break;
+                int nsp[KB], nbs[KB], na1[KB];
+                int4 ncc[KB];
 #pragma unroll
-                for (int v = 0; v < OCT_KB; ++v) {
+                for (int v = 0; v < KB; ++v) {
                     const int s = kn[h + v];
                     nsp[v] = split[s]; nbs[v] = bstart[s]; na1[v] = a1[s];
                     ncc[v] = *reinterpret_cast<const int4 *>(cc + 4 * s);
                 }
 #pragma unroll
-                for (int v = 0; v < OCT_KB; ++v) {
+                for (int v = 0; v < KB; ++v) {
                     const int u = h + v, q = kqv[u];
                     const int after = (q < 1 && ncc[v].y > 0) + (q < 2 && ncc[v].z > 0) + (q < 3 && ncc[v].w > 0);   // later non-empty children
-                    kn[u] = tid + u * OCT_T < M ? (nsp[v] ? nbs[v] + after : F + na1[v]) : 0;
+                    kn[u] = tid + u * T < M ? (nsp[v] ? nbs[v] + after : F + na1[v]) : 0;
                 }
             }
         } else
-        for (int k = tid; k < M; k += OCT_T) {
+        for (int k = tid; k < M; k += T) {
             const int s = knode[k];
             int pos;
             if (split[s]) {
@@ -1158,20 +1161,20 @@ __global__ __launch_bounds__(OCT_T) void k_octree(const LevelInfo *__restrict__ 
     __syncthreads();
     // best response per leaf, first candidate wins ties (:741-760)
     int *best = a2;
-    for (int s = tid; s < S; s += OCT_T) best[s] = 0;
+    for (int s = tid; s < S; s += T) best[s] = 0;
     __syncthreads();
     if (regs) {
 #pragma unroll
-        for (int u = 0; u < OCT_KPT; ++u)
-            if (tid + u * OCT_T < M)
-                atomicMax(reinterpret_cast<unsigned *>(&best[kn[u]]), ((kp[u] & 0xffu) << 24) | (0xffffffu - (unsigned)(tid + u * OCT_T)));
+        for (int u = 0; u < KPT; ++u)
+            if (tid + u * T < M)
+                atomicMax(reinterpret_cast<unsigned *>(&best[kn[u]]), ((kp[u] & 0xffu) << 24) | (0xffffffu - (unsigned)(tid + u * T)));
     } else
-    for (int k = tid; k < M; k += OCT_T)
+    for (int k = tid; k < M; k += T)
         atomicMax(reinterpret_cast<unsigned *>(&best[knode[k]]), ((kpos[k] & 0xffu) << 24) | (0xffffffu - (unsigned)k));
     __syncthreads();
     uint32_t *sel = sel_all + (size_t)f * sel_per_frame + lv.sel_base;
     const uint32_t *kfin = regs ? kpos_out : kpos;   // (register keys: the gather left the packed positions in the frame's workspace)
-    for (int s = tid; s < S; s += OCT_T) sel[s] = kfin[0xffffffu - ((unsigned)best[s] & 0xffffffu)];
+    for (int s = tid; s < S; s += T) sel[s] = kfin[0xffffffu - ((unsigned)best[s] & 0xffffffu)];
     if (tid == 0) {
         level_count[f * nlevels + l] = S;
         level_ncand[f * nlevels + l] = M;
@@ -2242,7 +2245,7 @@ static int plan_frame(orbx_extractor *ex, int width, int height, std::vector<int
             else ex->chain.clear();
         }
     }
-    ex->oct_lds = (int)sizeof(int) * (2 * (OCT_T / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
+    ex->oct_lds = (int)sizeof(int) * (2 * (OCT_TW / 64) + 2 * ((ex->maxcells + 1 + 3) & ~3) + 16 * ex->NC + ex->oct_kcap + (ex->oct_kcap + 1) / 2 + (ex->oct_kcap + 3) / 4) + 64;
     if (ex->oct_lds > 160 * 1024) ORBX_FAIL(ORBX_ERR_UNSUPPORTED, "octree node pool exceeds LDS");
 
     return ORBX_OK;
@@ -2325,9 +2328,12 @@ int orbx_reserve(orbx_extractor *ex, int width, int height, int batch)
     if (!xt.empty()) ORBX_HIP(hipMemcpyAsync(ex->d_xt, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice, ex->stream));
     if (!yt.empty()) ORBX_HIP(hipMemcpyAsync(ex->d_yt, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice, ex->stream));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    if (ex->oct_lds > 48 * 1024)
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree),
+    if (ex->oct_lds > 48 * 1024) {
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<OCT_T, OCT_KPT, OCT_KB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, ex->oct_lds));
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<OCT_TW, OCT_KPT * OCT_T / OCT_TW, OCT_KPT * OCT_T / OCT_TW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, ex->oct_lds));
+    }
     ex->width = width; ex->height = height; ex->batch = batch;
     return ORBX_OK;
 }
@@ -2461,10 +2467,21 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
                            ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
     pf.stop(2, st);
     pf.start(3, st);
-    hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
-                       ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
-                       ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
-                       ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap, ex->oct_kshift);
+    // Small batches: OCT_TW = 512 threads per (level, frame) -- a level's workgroup is the one frame's critical path, and its passes over
+    // keys and nodes are loops of dependent LDS reads that twice the threads make half as long: 43.6 -> 37.0 us for one frame (1,024
+    // threads: 36.5 -- what is left is the chain of scans and barriers).  Large batches fill the chip with 256-thread workgroups
+    // (ORBX_OCT_WIDE_MAX_BATCH moves the limit; tests run both).
+    const char *owb = getenv("ORBX_OCT_WIDE_MAX_BATCH");
+    if (batch <= (owb ? atoi(owb) : 2))
+        hipLaunchKernelGGL((k_octree<OCT_TW, OCT_KPT * OCT_T / OCT_TW, OCT_KPT * OCT_T / OCT_TW>), dim3(nl, batch), dim3(OCT_TW), ex->oct_lds, st, ex->d_lv, ex->d_cells,
+                           ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
+                           ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
+                           ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap, ex->oct_kshift);
+    else
+        hipLaunchKernelGGL((k_octree<OCT_T, OCT_KPT, OCT_KB>), dim3(nl, batch), dim3(OCT_T), ex->oct_lds, st, ex->d_lv, ex->d_cells,
+                           ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
+                           ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
+                           ex->d_level_ncand, nl, ex->NC, ex->maxcells, ex->oct_kcap, ex->oct_kshift);
     pf.stop(3, st);
     pf.start(4, st);
     {

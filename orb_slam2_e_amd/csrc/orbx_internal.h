@@ -15,7 +15,8 @@ constexpr int EDGE = 19;  // EDGE_THRESHOLD, ORBextractor.cc:74
 constexpr int PADX = 32;  // left pad (bytes) of every pyramid row
 constexpr int MAXL = 16;
 constexpr int MIN_BORDER = EDGE - 3; // minBorderX/Y, ORBextractor.cc:773
-constexpr int OCT_T = 256;           // threads of k_octree
+constexpr int OCT_T = 256;           // threads of k_octree (large batches)
+constexpr int OCT_TW = 512;          // ... of the wide variant small batches run (orbx_extract_batch): same 2,048 register-resident keys, 4 per thread
 constexpr int OCT_KPT = 8, OCT_KB = 4; // keys a k_octree thread keeps in registers (levels above OCT_KPT x OCT_T candidates: arrays); keys per batch of LDS reads
 constexpr int OCT_MAXN = 2047;       // largest per-level feature quota supported (node state of k_octree in LDS)
 

@@ -382,8 +382,9 @@ def test_small_quotas_on_wide_frames(prm, size):
 ])
 def test_pyramid_in_one_launch_equals_the_per_level_launches(shape, params, monkeypatch):
     """Small batches build levels 1.. in ONE launch (k_pyr_chain: a workgroup carries a tile through all levels in LDS, neighbours
-    recompute the overlap); large ones keep a launch per level.  Same padded levels byte for byte, same keypoints and descriptors --
-    one frame and a batch of three, each under both forms (ORBX_PYR_CHAIN_MAX_BATCH is read per call)."""
+    recompute the overlap) and run k_octree with 512 threads per (level, frame); large ones keep a launch per level and 256 threads.  Same
+    padded levels byte for byte, same keypoints and descriptors -- one frame and a batch of three, each under both forms (the two
+    environment switches are read per call)."""
     from orb_slam2_e_amd.synth import synth_frame
     h, w = shape
     frames = [np.ascontiguousarray(np.tile(synth_frame(k), ((h + 479) // 480, (w + 639) // 640))[:h, :w]) for k in range(3)]
@@ -392,6 +393,7 @@ def test_pyramid_in_one_launch_equals_the_per_level_launches(shape, params, monk
     out = {}
     for form, limit in (("chain", "64"), ("levels", "0")):
         monkeypatch.setenv("ORBX_PYR_CHAIN_MAX_BATCH", limit)
+        monkeypatch.setenv("ORBX_OCT_WIDE_MAX_BATCH", limit)    # ... and the 512-thread k_octree of small batches against the 256-thread one
         ex = ORBextractor(*params)
         kps, desc = ex(frames[0])
         one = [ex.pyramid_level(0, l, padded=True).copy() for l in range(params[2])]
