@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(T) void k_octree(const LevelInfo *__restrict__ L, c
 // --------------------------------------------------------------------- blur
 
 
-// Levels 1 .. n-1 of the pyramid in ONE launch -- the form SMALL batches take (orbx_extract_batch: <= 2 frames, the live tracker's one frame
+// Levels 1 .. n-1 of the pyramid in ONE launch -- the form SMALL batches take (orbx_extract_batch: <= 6 frames, the live tracker's one frame
 // per call: 22 us against the seven dependent per-level launches' 52; in the pipelined 64-frame step it was slower than they are,
 // profiles/r04_notes.md, and is not used there).  A workgroup carries one spatial tile through all levels in LDS: it loads
 // its rectangle of level 0, computes from it its rectangle of level 1 (the same fixed-point arithmetic, 4 pixels per lane from an
@@ -2415,11 +2415,11 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         }
         pf.stop(0, st);
     }
-    // Small batches -- the live tracker's one frame per call -- take the levels 1.. in ONE launch (k_pyr_chain): seven dependent launches of
+    // Small batches -- the live tracker's one frame per call, a camera rig's few -- take the levels 1.. in ONE launch (k_pyr_chain): seven dependent launches of
     // a few microseconds each are 52 of one frame's 134 us of kernels.  Large batches keep the per-level launches (the one-launch form was
     // slower in the pipelined 64-frame step, profiles/r04_notes.md).  ORBX_PYR_CHAIN_MAX_BATCH moves the limit (0: never; tests run both).
     const char *cmb = getenv("ORBX_PYR_CHAIN_MAX_BATCH");            // (read per call: the tests flip it)
-    const int chain_max_batch = cmb ? atoi(cmb) : 2;
+    const int chain_max_batch = cmb ? atoi(cmb) : 6;   // (tools/small_batch_sweep.py: ahead up to 6 frames per call, level at 8, behind from 16)
     const bool use_chain = ex->chain_tiles > 0 && batch <= chain_max_batch;
     if (use_chain) {
         pf.start(1, st);
@@ -2472,7 +2472,7 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
     // threads: 36.5 -- what is left is the chain of scans and barriers).  Large batches fill the chip with 256-thread workgroups
     // (ORBX_OCT_WIDE_MAX_BATCH moves the limit; tests run both).
     const char *owb = getenv("ORBX_OCT_WIDE_MAX_BATCH");
-    if (batch <= (owb ? atoi(owb) : 2))
+    if (batch <= (owb ? atoi(owb) : 6))
         hipLaunchKernelGGL((k_octree<OCT_TW, OCT_KPT * OCT_T / OCT_TW, OCT_KPT * OCT_T / OCT_TW>), dim3(nl, batch), dim3(OCT_TW), ex->oct_lds, st, ex->d_lv, ex->d_cells,
                            ex->d_cell_count, ex->cells_per_frame, ex->d_cands, ex->cands_per_frame, ex->d_kpos,
                            ex->d_knode, ex->d_kq, ex->keys_per_frame, ex->d_sel, ex->sel_per_frame, ex->d_level_count,
