@@ -2633,7 +2633,7 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
         ORBX_HIP(hipGetLastError());
         return ORBX_OK;
     };
-    // As a graph (orbx_extract_pair): the fourteen launches of a frame cost the host ~0.1 ms to enqueue, which is what the SECOND
+    // As a graph (orbx_extract_pair): the launches of a frame (fourteen when this was written, seven now) cost the host time to enqueue, which is what the SECOND
     // image of a stereo frame waits for; one graph launch per image lets the two chains run side by side on the device.  Captured
     // on the second call of a frame size (the first has done every one-time set-up), only while nothing in the chain depends on
     // the call (no per-kernel profiling events; a pending reader of the last results is waited for in front of the chain); any
