@@ -1,5 +1,5 @@
 import os, sys, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orb_slam2_e_amd.fem import FEA2, FEM_TET4
 from orb_slam2_e_amd.synth import synth_tet_mesh
