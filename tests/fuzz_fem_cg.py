@@ -13,6 +13,18 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 RTOL = 1e-5
 bad = 0
+
+
+def rel_ok(rel, orel, xd, ox, rp, col, val, bb):
+    """The two residual norms may differ by what the two iterates' difference explains, | ||r1|| - ||r2|| | <= ||A (x1 - x2)||, on top of
+    the 1e-5: on the warped, nearly incompressible meshes of the two-level cases CG does not converge in the iterations given (relres
+    0.36 after 58), the iterates agree to 1.5e-7 and their residuals to 2.5e-5 (seed 31207, cases 25 and 41)."""
+    from scipy.sparse import csr_matrix
+    A = csr_matrix((np.asarray(val, np.float64), col, rp), shape=(len(bb), len(bb)))
+    slack = np.linalg.norm(A @ (np.asarray(xd, np.float64) - ox)) / max(np.linalg.norm(bb), 1e-300)
+    return abs(rel - orel) <= RTOL * orel + 1e-12 + 2 * slack
+
+
 for case in range(n):
     nm = int(rng.choice([1, 3, 15, 16, 40, 63, 64, 65, 100, 130]))
     big = rng.random() < 0.3
@@ -45,7 +57,7 @@ for case in range(n):
         for k in pick:
             rp, col, val = fea.csr(k); d0, d1 = fea.dof0[k], fea.dof0[k + 1]
             ox, _, orel = ocg(rp, col, val, b[d0:d1], meshes[k][0], meshes[k][2])
-            okk = np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max() and abs(rel[k] - orel) <= RTOL * orel + 1e-12
+            okk = np.abs(x[0, d0:d1] - ox).max() <= RTOL * np.abs(ox).max() and rel_ok(rel[k], orel, x[0, d0:d1], ox, rp, col, val, b[d0:d1])
             if not okk: print("   mesh", k, "dims", dims[k], "x diff", np.abs(x[0, d0:d1] - ox).max() / np.abs(ox).max(), "relres", rel[k], "oracle", orel, flush=True)
             ok = ok and okk
         desc = f"segmented nm={nm} dims {dims[0]}.. iters={iters} two_level={two} warp={warp}"
@@ -62,7 +74,9 @@ for case in range(n):
         for k in sorted(set([0, nm - 1, int(rng.integers(0, nm))])):
             rp, col, val = fea.csr(k)
             ox, _, orel = ocg(rp, col, val, b[k], nodes[k], base[2])
-            ok = ok and np.abs(x[k] - ox).max() <= RTOL * np.abs(ox).max() and abs(rel[k] - orel) <= RTOL * orel + 1e-12
+            okk = np.abs(x[k] - ox).max() <= RTOL * np.abs(ox).max() and rel_ok(rel[k], orel, x[k], ox, rp, col, val, b[k])
+            if not okk: print("   mesh", k, "dims", d, "ndof", len(ox), "x diff", np.abs(x[k] - ox).max() / np.abs(ox).max(), "|x|max", np.abs(ox).max(), "relres", rel[k], "oracle", orel, flush=True)
+            ok = ok and okk
         desc = f"uniform nm={nm} dims {d} iters={iters} two_level={two} warp={warp}"
     if not ok:
         bad += 1; print("MISMATCH cg", case, desc, flush=True)
