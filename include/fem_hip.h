@@ -164,7 +164,7 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
  * leaves the smooth error of a near-incompressible solid (nu -> 0.5) to thousands of iterations; the coarse term removes it:
  * 1,274 -> 470 iterations to ||r|| <= 1e-8 ||b|| on BASELINE config 3's mesh.  Costs eight passes over the matrix and a 48 x 48
  * inverse per mesh in fem_cg_setup (0.24 ms for one 6,591-dof mesh, 1.7 ms for 256) and 6-13 per cent per iteration (batches that run on the compute units; k_fem_cg_resident).  Coarse dofs without a free fine dof, and modes that the modes before them
- * already span (Cholesky pivot <= 1e-8 of the diagonal: the rotations of an aggregate whose free nodes lie on a line), are dropped.  No reference counterpart (neither has the CG): the oracle's
+ * already span or nearly span (Cholesky pivot <= 1e-4 of the diagonal: the rotations of an aggregate whose free nodes lie on or near a line), are dropped.  No reference counterpart (neither has the CG): the oracle's
  * oracle_fem_cg_two_level is the definition.  Takes effect at the next fem_cg / fem_cg_setup. */
 enum { FEM_PRECOND_JACOBI = 0, FEM_PRECOND_TWO_LEVEL = 1 };
 int fem_cg_preconditioner(fem_model *m, int kind);

@@ -336,8 +336,8 @@ int oracle_fem_cg(int n, const int *rowptr, const int *col, const float *val, co
  * aggregate's centroid) of 2 x 2 x 2 geometric aggregates of the nodes: 48 coarse dofs.  A node's aggregate: per axis, bit =
  * (double)P > 0.5 * ((double)lo + (double)hi) with lo / hi the float extremes of that coordinate; aggregate = 4 bx + 2 by + bz.
  * q = (float)((double)P - centroid), centroid = double sum in node order / count.  Rows of constrained dofs (cmask != 0) are zero
- * in Z.  Ac is symmetrised, coarse dofs whose diagonal is <= 1e-12 of the largest, or whose Cholesky pivot is <= 1e-8 of their
- * diagonal (modes the earlier ones span), are dropped (row and column zero in the inverse), the inverse comes from the Cholesky
+ * in Z.  Ac is symmetrised, coarse dofs whose diagonal is <= 1e-12 of the largest, or whose Cholesky pivot is <= 1e-4 of their
+ * diagonal (modes the earlier ones span or nearly span: kept at 6e-7 one made the iteration a function of the last bits), are dropped (row and column zero in the inverse), the inverse comes from the Cholesky
  * factorisation in double and is symmetrised again. */
 #define CZ_NA 8
 #define CZ_NC 48
@@ -399,7 +399,7 @@ void oracle_fem_coarse_inverse(double *a /*48 x 48, in: Ac, out: inverse*/)
         if (!keep[j]) continue;
         s = a[j * CZ_NC + j];
         for (k = 0; k < j; k++) s -= L[j][k] * L[j][k];
-        if (!(s > 1e-8 * a[j * CZ_NC + j])) { keep[j] = 0; for (k = 0; k < j; k++) L[j][k] = 0; continue; }   /* spanned by the modes before it: dropped too */
+        if (!(s > 1e-4 * a[j * CZ_NC + j])) { keep[j] = 0; for (k = 0; k < j; k++) L[j][k] = 0; continue; }   /* spanned by the modes before it: dropped too */
         L[j][j] = sqrt(s);
         for (i = j + 1; i < CZ_NC; i++) {
             if (!keep[i]) continue;

@@ -1140,10 +1140,14 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_restrict6(const float4 *__restr
 
 // aci = inverse of the symmetrised coarse matrix ac (48 x 48, one wave per mesh, everything in LDS): Cholesky column by column
 // (lane i owns row i), then lane c solves L y = e_c and L^T x = y for column c, and the result is symmetrised again.  A coarse dof
-// whose diagonal is <= 1e-12 of the largest (an aggregate without a free dof) or whose pivot is <= 1e-8 of its diagonal (a mode that
-// the ones before it already span: the rotations of an aggregate whose free nodes lie on a line) is dropped: zero row and column in
-// the inverse.  A pivot test against 0 would keep or drop such a mode by the last bit of Ac, and a kept one makes the
-// preconditioner all but singular.  The operation order of the oracle's oracle_fem_coarse_inverse.
+// whose diagonal is <= 1e-12 of the largest (an aggregate without a free dof) or whose pivot is <= CZ_PIVOT_MIN = 1e-4 of its diagonal
+// (a mode that the ones before it span, or all but span: the rotations of an aggregate whose free nodes lie on or near a line) is
+// dropped: zero row and column in the inverse.  A pivot test against 0 would keep or drop such a mode by the last bit of Ac, and a
+// kept one makes the preconditioner all but singular: until round 5 the limit was 1e-8, and a warped 54-node mesh whose fifth
+// aggregate kept a rotation at 6e-7 (largest entry of the inverse 1.7e10) made the iteration a function of the last bits --
+// relres after 45 iterations 0.15 here, 0.29 in the oracle, 0.39 .. 5.5 with the inverse perturbed by 1e-15 (profiles/r05_notes.md).
+// The operation order of the oracle's oracle_fem_coarse_inverse.
+constexpr double CZ_PIVOT_MIN = 1e-4;
 __global__ __launch_bounds__(64) void k_fem_cz_invert(const double *__restrict__ ac, double *__restrict__ aci)
 {
     constexpr int N = CZ_NC;
@@ -1161,7 +1165,7 @@ __global__ __launch_bounds__(64) void k_fem_cz_invert(const double *__restrict__
         if (keep[j]) {                                   // uniform
             double d = A[j * N + j];
             for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
-            if (!(d > 1e-8 * A[j * N + j])) {
+            if (!(d > CZ_PIVOT_MIN * A[j * N + j])) {
                 __syncthreads();
                 if (l < j) L[j * N + l] = 0;
                 if (l == j) keep[j] = 0;

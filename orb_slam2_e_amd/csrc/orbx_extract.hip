@@ -1563,8 +1563,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
                                                   const uint32_t *__restrict__ sel_all, int sel_per_frame,
                                                   const int *__restrict__ level_count,
                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                                  int *__restrict__ counts, int cap, int trig_variant)
+                                                  int *__restrict__ counts, int cap, int trig_variant, uint32_t *__restrict__ mirror, int mirror_desc)
 {
+    // mirror (one frame per call only): the caller's pinned result block {count, 12 bytes | kps[cap] | desc[cap][32]} as dwords, desc at
+    // dword mirror_desc -- every record is stored there as well (posted writes), so that no copy kernel runs behind this one
     __shared__ uint32_t s_coff[DESC_KPB];   // patch centre, byte offset inside the frame's pyramid
     __shared__ int s_valid[DESC_KPB], s_out[DESC_KPB], s_m10[DESC_KPB], s_m01[DESC_KPB];
     __shared__ uint32_t s_pk[DESC_KPB];
@@ -1596,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     if (tid < DESC_KPB) {
         const int j = (item - D.chunk_base[level]) * DESC_KPB + tid;   // slot within the level
         const uint32_t pk = sel_all[(size_t)f * sel_per_frame + D.sel_base[level] + j];   // (slots past the level's count: never used)
-        if (item == 0 && tid == 0) counts[f] = total < cap ? total : cap;
+        if (item == 0 && tid == 0) { counts[f] = total < cap ? total : cap; if (mirror) mirror[0] = (uint32_t)(total < cap ? total : cap); }
         const int x = (int)((pk >> 8) & 0xfffu) + MIN_BORDER, y = (int)(pk >> 20) + MIN_BORDER;
         s_valid[tid] = j < mine && first + j < cap;
         s_out[tid] = first + j;
@@ -1755,6 +1757,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int kp0 = wv * (DESC_KPB / 4);
         const size_t o0 = (size_t)f * cap + s_out[kp0];
         if (lane < 32 && s_valid[kp0 + (lane >> 3)]) reinterpret_cast<uint32_t *>(desc + o0 * 32)[lane] = dacc;
+        if (mirror && lane < 32 && s_valid[kp0 + (lane >> 3)]) mirror[mirror_desc + o0 * 8 + lane] = dacc;
         if (lane < 28) {
             const int jk = lane / 7, fld = lane - 7 * jk, kp = kp0 + jk;
             if (s_valid[kp]) {
@@ -1765,6 +1768,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
                                      fld == 2 ? __float_as_uint((float)D.patch[level]) : fld == 3 ? __float_as_uint(s_angle[kp]) :
                                      fld == 4 ? __float_as_uint((float)(pk & 0xffu)) : fld == 5 ? (uint32_t)level : 0xffffffffu;
                 reinterpret_cast<uint32_t *>(kps + o0)[lane] = val;
+                if (mirror) mirror[4 + o0 * 7 + lane] = val;
             }
         }
     }
@@ -2511,7 +2515,8 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
         }
         for (int l = nl; l <= MAXL; l++) D.chunk_base[l] = nchunks;
         hipLaunchKernelGGL(k_describe, dim3(nchunks, batch), dim3(256), 0, st, ex->d_pyr, ex->d_blur, ex->frame_bytes, ex->blur_frame_bytes, D, nl,
-                           ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps, ex->d_desc, ex->d_counts, ex->kcap, ex->prm.trig_variant);
+                           ex->d_sel, ex->sel_per_frame, ex->d_level_count, ex->d_kps, ex->d_desc, ex->d_counts, ex->kcap, ex->prm.trig_variant,
+                           batch == 1 ? ex->mirror : (uint32_t *)nullptr, ex->mirror_desc);
     }
     pf.stop(5, st);
     ORBX_HIP(hipGetLastError());
@@ -2624,13 +2629,11 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
     auto enqueue = [&]() -> int {
         // (level 0 reads the pinned image itself -- it is mapped into the device's address space --: 16 us instead of a staging copy + 7, and
         // one launch less; 0.149 -> 0.146 ms per call)
+        // (the results: k_describe stores every record into the pinned block as well -- no copy kernel behind it)
+        ex->mirror = reinterpret_cast<uint32_t *>(ex->h_pin + in_room); ex->mirror_desc = (int)((16 + kp_bytes) / 4);
         const int rc2 = orbx_extract_batch(ex, ex->h_pin, 1, width, height, stride, in_bytes, 1, st);
+        ex->mirror = nullptr;
         if (rc2 != ORBX_OK) return rc2;
-        uint8_t *o = ex->h_pin + in_room;
-        hipLaunchKernelGGL(k_result_out, dim3((unsigned)(((kp_bytes + de_bytes) / 16 + 255) / 256)), dim3(256), 0, st, (const int *)ex->d_counts,
-                           reinterpret_cast<const uint4 *>(ex->d_kps), reinterpret_cast<const uint4 *>(ex->d_desc), (int)(kp_bytes / 16),
-                           (int)(de_bytes / 16), reinterpret_cast<uint4 *>(o));
-        ORBX_HIP(hipGetLastError());
         return ORBX_OK;
     };
     // As a graph (orbx_extract_pair): the launches of a frame (fourteen when this was written, seven now) cost the host time to enqueue, which is what the SECOND

@@ -101,6 +101,7 @@ struct orbx_extractor {
     uint4 *d_chain_tabs = nullptr;
     int2 *d_chain_span = nullptr;
     int chain_tiles = 0, chain_ldsA = 0, chain_ldsB = 0, chain_ldsT = 0;
+    uint32_t *mirror = nullptr; int mirror_desc = 0;   // set around the one-frame call's orbx_extract_batch: k_describe's second copy of the results (pinned host block)
     size_t blur_frame_bytes = 0;
     int boff[orbx_detail::MAXL] = {}, bcol[orbx_detail::MAXL] = {};
     int cells_per_frame = 0, sel_per_frame = 0, maxcells = 0, NC = 0;
