@@ -71,3 +71,22 @@ def test_two_level_cg_reaches_the_same_solution_in_far_fewer_iterations():
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
     # constrained dofs stay where the elimination put them: out of the coarse space, the iterate there is b / 1 = 0
     assert not xt[mask.astype(bool)].any()
+
+
+def test_coarse_inverse_drops_nearly_dependent_modes():
+    """oracle_fem_coarse_inverse: a coarse dof whose Cholesky pivot is <= 1e-4 of its diagonal -- a mode the earlier ones span or all but
+    span -- gets a zero row and column; on the kept dofs the result is the inverse of that block.  (Round 5's soak: a rotation kept at
+    6e-7 under the old 1e-8 limit made an inverse with entries of 1.7e10 and the iteration a function of the last bits.)"""
+    rng = np.random.default_rng(11)
+    V = rng.standard_normal((60, 48))
+    V[:, 20] = V[:, 3] + 2e-3 * rng.standard_normal(60)          # sin^2 of the angle to mode 3 ~ 4e-6: dropped
+    V[:, 33] = V[:, 5] - V[:, 7] + 0.2 * rng.standard_normal(60)  # ~ 1e-2: kept
+    V[:, 40] = 0                                                   # an aggregate without a free dof
+    Ac = V.T @ V
+    inv = oracle.fem_coarse_inverse(Ac.copy())
+    dropped = [20, 40]
+    keep = np.array([i for i in range(48) if i not in dropped])
+    assert np.all(inv[dropped] == 0) and np.all(inv[:, dropped] == 0)
+    sub = inv[np.ix_(keep, keep)]
+    assert np.abs(sub @ Ac[np.ix_(keep, keep)] - np.eye(len(keep))).max() < 1e-7
+    assert np.abs(sub - sub.T).max() == 0 and np.abs(inv).max() < 1e3
