@@ -54,8 +54,8 @@ for case in range(n):
     if not ok:
         bad += 1
         print("MISMATCH", case, params, (w, h), "kind", kind, len(kps), len(okps), flush=True)
-    if rng.random() < 0.15:      # the batch entry on the same handle: B frames of this size (B % 8 == 0 takes the XCD-aware mapping)
-        B = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 24]))
+    if rng.random() < 0.25:      # the batch entry on the same handle: B frames of this size (B % 8 == 0 takes the XCD-aware mapping)
+        B = int(rng.choice([1, 2, 3, 5, 6, 7, 8, 9, 16, 24]))   # (up to 6: the small-batch kernel forms, k_pyr_chain and the 512-thread k_octree)
         imgs = np.stack([img] + [np.roll(img, int(rng.integers(1, 40)) * (b + 1), axis=int(rng.integers(0, 2))) for b in range(B - 1)])
         ex.extract_batch(imgs)
         kb, db, cb = ex.download_batch()
