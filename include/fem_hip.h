@@ -102,6 +102,13 @@ int fem_plan(int eltype, int nmesh, const int32_t *mesh_nn, const int32_t *mesh_
              fem_plan_info *info, int32_t *rowptr, int32_t *lcol, int32_t *diag, int32_t *bp, int32_t *bcol3, int32_t *rcd,
              int32_t *rcfirst, int32_t *chunk_mesh);
 
+/* Diagnostic: how many k_fem_cg_xcd launches this model has made, and how many times one of them gave up and was made good.  The kernel's
+ * workgroups wait for each other, so every one of them needs a compute unit at the same time; when the chip is full of other streams' work
+ * a participant may not be scheduled for long (observed: seconds under three threads of 64-frame extraction batches).  A participant is
+ * waited for 2 ms; then the launch leaves x, r, p and the scalars untouched, the next fem_cg_result / convergence check runs the owed
+ * iterations on the launch-per-phase path (same bits), and the model's next 32 fem_cg_iterate calls (doubling while such events follow each other) stay on that path. */
+int fem_cg_one_launch_stats(fem_model *m, int64_t *launches, int64_t *recovered);
+
 /* How fem_cg_iterate / fem_cg will run ONE mesh of this topology (host only, no GPU needed): info6 = {one-launch kernel
  * k_fem_cg_xcd eligible (a single mesh of at most 8,192 dofs whose chunk tables fit), participating workgroups P (<= 64), chunks per
  * workgroup of the kernel variant (1, 3 or 6), its LDS bytes, vector chunks (256 rows), SpMV chunks (48 or 96 rows)}; plan[P][4] =

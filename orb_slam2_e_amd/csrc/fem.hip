@@ -1311,7 +1311,8 @@ __global__ __launch_bounds__(1024) void k_fem_cz_apply(const float4 *__restrict_
 //     every workgroup's partial of the phase before).
 // Every spin is bounded: a timeout raises the abort word, every workgroup leaves, and fem_cg_result / fem_cg report the failure.
 constexpr int XG_MAXCH = 6, XG_MAXQ = 2, XG_SU = 8, XG_STRIDE = 8, XG_MAXP = 64;   // XG_MAXP: up to two workgroups per compute unit of the XCD (variants MC <= 3)
-constexpr unsigned XG_SPIN = 1u << 22, XG_KEY = 0x5bd1e995u;
+constexpr unsigned XG_KEY = 0x5bd1e995u;
+constexpr unsigned long long XG_TIMEOUT = 200000ull;      // 2 ms of the 100-MHz wall clock (s_memrealtime): see xg_get
 #ifdef XG_TIMING
 struct XgCtl { unsigned abort_flag, pad[31 + 8 * 64]; };   // development build: per-phase clocks of every workgroup behind the control words
 #else
@@ -1388,6 +1389,7 @@ __device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[UL + UR
 #pragma unroll
     for (int u = 0; u < U; ++u) { addr[u] = 16u * (unsigned)max(slot[u], 0); out[u] = 0.0; }
     bool early = UR > 0;                                  // wave-uniform: the early group is still being asked for
+    unsigned long long t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         bool all = true;
         if (early) {
@@ -1413,8 +1415,19 @@ __device__ __forceinline__ bool xg_get(const char *gb, const int (&slot)[UL + UR
             for (int u = 0; u < UL; ++u) { all = all && (slot[u] < 0 || xg_ok(g[u], tag)); out[u] = slot[u] >= 0 ? xg_val(g[u]) : 0.0; }
         }
         if (!early && __all(all)) return true;
-        if (spins > XG_SPIN || ((spins & 1023u) == 1023u && __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            if (spins > XG_SPIN) {      // the first to time out says where (development aid: fem_debug_xcd reads the word)
+        // Bounded by wall time: a participant that has not been given a compute unit yet -- the chip full of other streams' work whose small
+        // workgroups keep taking the seats this kernel's large ones need: seen for seconds under three threads of 64-frame extraction
+        // batches -- is waited for 2 ms; then the launch gives up (nothing of it has reached x, r or p) and the host makes the iterations
+        // good on the launch-per-phase path (xg_recover).  (Until round 5 the bound was a spin count worth seconds, and the call failed.)
+        // (20 ms at first: 1,620 solves in 6 s beside that load, 10 % of the launches giving up; 2 ms: 2,160 solves, 12 %.)
+        bool late = false;
+        if ((spins & 63u) == 63u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            late = now - t0 > XG_TIMEOUT;
+        }
+        if (late || ((spins & 255u) == 255u && __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (late) {                 // the first to time out says where (development aid: fem_debug_xcd reads the word)
                 unsigned expect = 0;
                 __hip_atomic_compare_exchange_strong(&ctl->abort_flag, &expect, where | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1497,7 +1510,9 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
     }
     for (int i = tid; i < rng; i += CGT)
         if (lo + i < ndof) { p_s[i] = p[lo + i]; d_s[i] = dinv[lo + i]; }
-    if (tid == 0) s_fail = 0;
+    if (tid == 0) s_fail = __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier launch gave up: this one must not touch the state either
+    __syncthreads();
+    if (s_fail) return;
     if constexpr (COARSE) {
         for (int i = tid; i < CZ_NC * CZ_NC; i += CGT) a_s[i] = aci[i];
         for (int i = tid; i < rng; i += CGT)
@@ -1865,7 +1880,7 @@ __global__ __launch_bounds__(CGT, MC <= 3 ? 2 : 1) void k_fem_cg_xcd(const float
     if (tid == 0) ctl->pad[31 + 8 * rank + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID instead of the barrier's clocks
 #endif
     if (has) { x[row] = xv; r[row] = rv; p[row] = p_s[row - lo]; }
-    if (rank == 0 && tid == 0) { sc[0].rz[0] = rz; sc[0].rz[1] = rz; sc[0].rr = rr; }
+    if (rank == 0 && tid == 0) { sc[0].rz[0] = rz; sc[0].rz[1] = rz; sc[0].rr = rr; ctl->pad[0] = base + 3u * (unsigned)niter; }   // (pad[0]: the tag this launch ended at = it ran to its end, xg_recover)
 }
 
 // COARSE: the two-level preconditioner inside the same launch.  After the update (r is in the batch vector) the sixteen waves sum
@@ -2329,6 +2344,8 @@ hipStream_t stream_get()
         if (!g_stream_free.empty()) { hipStream_t s = g_stream_free.back(); g_stream_free.pop_back(); return s; }
     }
     hipStream_t s = nullptr;
+    // (a high-priority queue does not get k_fem_cg_xcd's workgroups seated sooner beside a saturating load on other streams: tried, 79 against 78
+    // launches of ~730 gave up either way, profiles/r05_notes.md)
     return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
 }
 void stream_put(hipStream_t s)
@@ -2386,6 +2403,9 @@ struct fem_model {
     bool cg_xcd = false; int xg_P = 0, xg_ldr = 0, xg_ldq = 0, xg_lds = 0, xg_mc = 0; int4 *d_xg_plan = nullptr; XgCtl *d_xg_ctl = nullptr; unsigned xg_bar = 0;
     char *d_xg_gran = nullptr;   // its tagged 16-byte granules (xg_layout)
     hipEvent_t xg_done = nullptr; bool xg_inflight = false;   // admission: see xg_admit
+    std::vector<std::pair<unsigned, int>> xg_pending;        // k_fem_cg_xcd launches since the last check of the abort word: {first tag, iterations}
+    int xg_cooldown = 0, xg_backoff = 0;                      // calls that stay on the launch-per-phase path after a recovery (doubling while recoveries follow each other)
+    long long xg_launches = 0, xg_recovered = 0;             // (fem_cg_one_launch_stats)
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr, *d_dinv = nullptr;
     double *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     CgScal *d_sc = nullptr;
@@ -2621,7 +2641,11 @@ void run_iters(fem_model *m, int n, hipStream_t st)
         m->cg_it += 2 * ((n + 1) / 2);   // both rz slots are current after the launch: keep the parity of the other path even
         return;
     }
-    if (m->xcd_now() && n > 0 && xg_admit(m)) {
+    if (m->xg_cooldown > 0 && n > 0) m->xg_cooldown--;
+    else if (m->xcd_now() && n > 0 && xg_admit(m)) {
+        // (the kernel starts from the even rz slot: should it give up, the state and the host's parity still agree -- see xg_recover)
+        if (m->cg_it & 1) { launch_iter(m, st); if (--n == 0) return; }
+        m->xg_pending.emplace_back(m->xg_bar, n); m->xg_launches++;
         m->prof.start(5, st);
         {
             // bit 0: which rz slot is current; bit 1: FEM_CG_XCD=safe -- system-scope granules whatever the placement (the mode the tests
@@ -2654,6 +2678,28 @@ void run_iters(fem_model *m, int n, hipStream_t st)
         return;
     }
     for (int i = 0; i < n; ++i) launch_iter(m, st);
+}
+
+// Behind a synchronisation of `st` that brought the two control words along: a one-launch call that gave up (a participant was not
+// scheduled in time) has changed nothing -- x, r, p and the scalars are written after the last iteration only, every later launch left
+// at its first instruction, and launch-per-phase calls in between ran from the state as it was, with the right rz slot (the kernel
+// always starts from the even one) -- so the iterations of the launches that did NOT run to their end (they say so: pad[0]) are simply
+// run now, launch by launch: CG does not care how its iterations are cut into calls (same bits).  The model then stays on the
+// launch-per-phase path for a while.
+int xg_recover(fem_model *m, hipStream_t st, const unsigned (&ctl2)[2])   // {abort word, the end tag of the last launch that ran to its end}
+{
+    int redo = 0;
+    for (const auto &l : m->xg_pending)
+        if ((int)(l.first + 3u * (unsigned)l.second - ctl2[1]) > 0) redo += l.second;   // (tags only grow between two fem_cg_setup calls)
+    const bool had = !m->xg_pending.empty();
+    m->xg_pending.clear();
+    if (!ctl2[0]) { if (had) m->xg_backoff = 0; return ORBX_OK; }
+    ORBX_HIP(hipMemsetAsync(&m->d_xg_ctl->abort_flag, 0, sizeof(unsigned), st));
+    m->xg_backoff = std::min(m->xg_backoff + 1, 7); m->xg_cooldown = 16 << m->xg_backoff; m->xg_recovered++;   // 32, 64 .. 2,048 calls on the launch-per-phase path
+    for (int i = 0; i < redo; ++i) launch_iter(m, st);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipStreamSynchronize(st));
+    return ORBX_OK;
 }
 
 // Symbolic phase of one mesh (host, once per topology): block pattern, contribution lists, CSR pattern.
@@ -3673,7 +3719,16 @@ int fem_cg_setup(fem_model *m, const double *b)
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipStreamSynchronize(m->stream));
     m->cg_it = 0;
+    m->xg_pending.clear();
     m->cg_ready = true;
+    return ORBX_OK;
+}
+
+int fem_cg_one_launch_stats(fem_model *m, int64_t *launches, int64_t *recovered)
+{
+    if (!m) ORBX_FAIL(ORBX_ERR_ARG, "null model");
+    if (launches) *launches = m->xg_launches;
+    if (recovered) *recovered = m->xg_recovered;
     return ORBX_OK;
 }
 
@@ -3729,13 +3784,21 @@ int fem_cg_result(fem_model *m, double *x, double *relres)
     // the copies wait for the stream the iterations ran on, not for the whole device
     hipStream_t st = m->cg_stream ? m->cg_stream : m->stream;
     std::vector<CgScal> sc(relres ? m->nseg : 0);
-    if (x) ORBX_HIP(hipMemcpyAsync(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost, st));
-    if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, st));
-    xg_settle(m, true);
-    unsigned xg_abort = 0;   // k_fem_cg_xcd: a barrier that timed out (every workgroup left; the iterate is not to be used)
-    if (m->d_xg_ctl) ORBX_HIP(hipMemcpyAsync(&xg_abort, &m->d_xg_ctl->abort_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipStreamSynchronize(st));
-    if (xg_abort) { m->cg_ready = false; ORBX_FAIL(ORBX_ERR_HIP, "k_fem_cg_xcd: a cross-workgroup barrier timed out (FEM_CG_XCD=0 selects the launch-per-phase path)"); }
+    // k_fem_cg_xcd launches since the last check: the two control words come along with the results; had a launch given up, the iterations
+    // are made good (xg_recover) and the results fetched again
+    const bool chk = m->d_xg_ctl && !m->xg_pending.empty();
+    unsigned ctl2[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+        if (chk && pass == 0) ORBX_HIP(hipMemcpyAsync(ctl2, m->d_xg_ctl, sizeof(ctl2), hipMemcpyDeviceToHost, st));
+        if (x) ORBX_HIP(hipMemcpyAsync(x, m->d_x, sizeof(double) * (size_t)m->nmesh * m->ndof, hipMemcpyDeviceToHost, st));
+        if (relres) ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, st));
+        xg_settle(m, true);
+        ORBX_HIP(hipStreamSynchronize(st));
+        if (!chk || pass == 1) break;
+        const int rc = xg_recover(m, st, ctl2);
+        if (rc != ORBX_OK) return rc;
+        if (!ctl2[0]) break;
+    }
     if (relres) {
         for (int i = 0; i < m->nseg; ++i) relres[i] = sc[i].bb > 0 ? sqrt(sc[i].rr / sc[i].bb) : 0.0;
     }
@@ -3751,8 +3814,19 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
     int done = 0;
     while (done < iters) {
         if (tol > 0) { // convergence test on the device-side scalars, every 25 iterations
+            const bool chk = m->d_xg_ctl && !m->xg_pending.empty();   // (a one-launch slice that gave up is made good before its residual is looked at)
+            unsigned ctl2[2] = {0, 0};
+            if (chk) ORBX_HIP(hipMemcpyAsync(ctl2, m->d_xg_ctl, sizeof(ctl2), hipMemcpyDeviceToHost, m->stream));
             ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, m->stream));
             ORBX_HIP(hipStreamSynchronize(m->stream));
+            if (chk) {
+                rc = xg_recover(m, m->stream, ctl2);
+                if (rc != ORBX_OK) return rc;
+                if (ctl2[0]) {
+                    ORBX_HIP(hipMemcpyAsync(sc.data(), m->d_sc, sizeof(CgScal) * m->nseg, hipMemcpyDeviceToHost, m->stream));
+                    ORBX_HIP(hipStreamSynchronize(m->stream));
+                }
+            }
             bool all = true;
             for (int i = 0; i < m->nseg; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb));
             if (all) break;

@@ -165,6 +165,12 @@ class FEA2:
         k = {"jacobi": 0, "two_level": 1}.get(kind, kind)
         check(bind(self._L.fem_cg_preconditioner, [C.c_void_p, C.c_int])(self._h, int(k)))
 
+    def one_launch_stats(self):
+        """(launches of the one-launch CG kernel, how many of them gave up and were made good on the launch-per-phase path)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(bind(self._L.fem_cg_one_launch_stats, [C.c_void_p, C.c_void_p, C.c_void_p])(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def cg_coarse_matrix(self, mesh=0):
         Ac = np.zeros((48, 48), np.float64)
         check(bind(self._L.fem_cg_coarse_matrix, [C.c_void_p, C.c_int, C.c_void_p])(self._h, mesh, _p(Ac)))

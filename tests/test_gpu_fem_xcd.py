@@ -170,3 +170,56 @@ def test_two_level_inside_the_launch_equals_the_launch_per_phase_path(ncell, ite
     ox, _, orel = oracle.fem_cg_two_level(rp, col, val, b[0], iters, nodes, mk)
     assert np.abs(xa[0] - ox).max() <= RTOL * np.abs(ox).max()
     fea.cg_preconditioner("jacobi")
+
+
+def test_one_launch_cg_beside_a_saturating_extraction_load():
+    """The kernel's workgroups wait for each other, so all of them must get a seat: here three threads keep the chip full with 64-frame
+    extraction batches while a fourth solves the 6,591-dof mesh over and over under both preconditioners.  A participant that is not
+    scheduled within 2 ms makes its launch give up (seen: the small workgroups of the other streams keep taking the seats); the host
+    then runs the owed iterations on the launch-per-phase path and stays there for a while.  Either way no call fails and every result
+    is the launch-per-phase path's, bit for bit -- also when one-launch and launch-per-phase slices mix inside one solve."""
+    import threading
+    from orb_slam2_e_amd import ORBextractor
+    from orb_slam2_e_amd.synth import synth_sequence
+    nodes, tets, fixed, load = synth_tet_mesh(ncell=12)
+    fea, b = _model(nodes, tets, fixed, load)
+    want = {}
+    for pre in ("jacobi", "two_level"):
+        fea.cg_preconditioner(pre)
+        os.environ["FEM_CG_XCD"] = "0"
+        fea.cg_setup(b); fea.cg_iterate(120)
+        want[pre] = fea.cg_result()[0].tobytes()
+        os.environ.pop("FEM_CG_XCD", None)
+    frames = synth_sequence(64)
+    stop = threading.Event()
+    errors, batches = [], [0, 0, 0]
+
+    def load_thread(k):
+        try:
+            ex = ORBextractor(2000, 1.2, 8, 20, 7)
+            while not stop.is_set():
+                ex.extract_batch(frames); ex.download_batch(); batches[k] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(("load", k, repr(e)))
+
+    ts = [threading.Thread(target=load_thread, args=(k,)) for k in range(3)]
+    for t in ts: t.start()
+    solves = 0
+    try:
+        import time
+        t0 = time.time()
+        while time.time() - t0 < 6.0 and not errors:
+            for pre in ("jacobi", "two_level"):
+                fea.cg_preconditioner(pre)
+                fea.cg_setup(b); fea.cg_iterate(49); fea.cg_iterate(71)       # (an odd slice: the next one starts from the odd rz slot)
+                got = fea.cg_result()[0].tobytes()
+                if got != want[pre]: errors.append(("cg", pre, "differs"))
+                solves += 1
+    finally:
+        stop.set()
+        for t in ts: t.join()
+        fea.cg_preconditioner("jacobi")
+    launches, recovered = fea.one_launch_stats()
+    print("solves", solves, "one-launch kernel launches", launches, "of which gave up and were made good", recovered, "extraction batches", batches)
+    assert not errors, errors[:3]
+    assert solves >= 6 and min(batches) >= 5 and launches >= 1, (solves, batches, launches)
