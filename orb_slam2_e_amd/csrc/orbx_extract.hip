@@ -2388,7 +2388,9 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
             ORBX_HIP(hipMalloc(&ex->d_in, need));
             ex->in_bytes = need;
         }
-        ORBX_HIP(hipMemcpyAsync(ex->d_in, images, need, hipMemcpyHostToDevice, st));
+        // (what is copied ends with the last pixel of the last row: a cv::Mat with a row pitch -- a region of interest at the bottom of its
+        // parent -- owns nothing behind it)
+        ORBX_HIP(hipMemcpyAsync(ex->d_in, images, need - (size_t)(stride - width), hipMemcpyHostToDevice, st));
         d_img = ex->d_in;
     }
     const int nl = ex->nlevels;
@@ -2605,6 +2607,7 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
 {
     // ORBextractor::operator() on one host image is latency-bound: stage the image and the results through pinned
     // buffers so that the call is one H2D, the kernel chain, one D2H and a single stream synchronisation
+    if (stride < width) ORBX_FAIL(ORBX_ERR_ARG, "row pitch smaller than the width");
     const size_t in_bytes = (size_t)stride * height, in_room = (in_bytes + 255) & ~(size_t)255;   // 16-byte pieces on both sides
     int rc = orbx_reserve(ex, width, height, 1);
     if (rc != ORBX_OK) return rc;
@@ -2622,7 +2625,7 @@ static int extract_enqueue(orbx_extractor *ex, const uint8_t *image, int width, 
         if (ex->reader_stream != st) ORBX_HIP(hipStreamWaitEvent(st, ex->reader_ev, 0));
         ex->reader_pending = false;
     }
-    memcpy(ex->h_pin, image, in_bytes);
+    memcpy(ex->h_pin, image, in_bytes - (size_t)(stride - width));   // (ends with the last row's last pixel: a region of interest owns nothing behind it)
     ex->pin_result_off = in_room;
     // image in and results out by the compute queue itself (the kernels read / write the pinned block): no hand-over to the copy engine
     // in front of and behind the kernels of a frame

@@ -409,3 +409,30 @@ def test_pyramid_in_one_launch_equals_the_per_level_launches(shape, params, monk
     assert np.array_equal(ca, cb)
     for f in range(3):
         assert ka[f, :ca[f]].tobytes() == kb[f, :cb[f]].tobytes() and np.array_equal(da[f, :ca[f]], db[f, :cb[f]])
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (375, 1242), (243, 317)])
+@pytest.mark.parametrize("pad", [4, 13, 64])
+def test_rows_with_a_pitch_larger_than_the_width(shape, pad):
+    """ORBextractor::operator() takes any cv::Mat (ORBextractor.cc:1056: _image.getMat()): rows `stride` bytes apart with stride > width
+    -- a region of interest, an aligned allocation.  Same keypoints and descriptors as the continuous copy, for pitches that keep the
+    rows dword-aligned and for one that does not; the bytes between the rows are never read as pixels (they are poisoned here), and
+    nothing is read behind the last row's last pixel (the buffer ends there)."""
+    import ctypes as C
+    from orb_slam2_e_amd._lib import check
+    from orb_slam2_e_amd.extractor import KP_DTYPE
+    h, w = shape
+    img = np.ascontiguousarray(np.tile(synth_frame(3), ((h + 479) // 480, (w + 639) // 640))[:h, :w])
+    ex = ORBextractor(*PARAMS)
+    k0, d0 = ex(img)
+    stride = w + pad
+    buf = np.full((h - 1) * stride + w, 0xA5, np.uint8)          # ends with the last pixel of the last row
+    for y in range(h):
+        buf[y * stride: y * stride + w] = img[y]
+    ex2 = ORBextractor(*PARAMS)
+    ex2._reserve(w, h, 1)
+    kps = np.zeros(ex2.capacity, KP_DTYPE); desc = np.zeros((ex2.capacity, 32), np.uint8); n = C.c_int(0)
+    for rep in range(2):       # (the second call of a size takes the cached path)
+        check(ex2._L.orbx_extract(ex2._h, buf.ctypes.data_as(C.c_void_p), w, h, stride, kps.ctypes.data_as(C.c_void_p),
+                                  desc.ctypes.data_as(C.c_void_p), ex2.capacity, C.byref(n)))
+        assert n.value == len(k0) and kps[:n.value].tobytes() == k0.tobytes() and np.array_equal(desc[:n.value], d0)
