@@ -72,7 +72,8 @@ class ORBextractor:
         if image is None or image.size == 0:
             return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (ORBextractor.cc:1058)"
-        image = np.ascontiguousarray(image)
+        if not (image.strides[1] == 1 and image.strides[0] >= image.shape[1]):   # rows with a pitch (a view of a wider array: a cv::Mat region of interest) go as they are
+            image = np.ascontiguousarray(image)
         h, w = image.shape
         self._reserve(w, h, 1)
         kps = np.zeros(self.capacity, KP_DTYPE)

@@ -35,9 +35,15 @@ for case in range(n):
         o = oracle.OrbOracle(*params)
     except Exception as e:
         print("oracle rejects", params, w, h, e); continue
+    view = img
+    if rng.random() < 0.3:       # the image as a region of interest of a wider, taller array: a row pitch (aligned or not), poisoned surroundings
+        padx, pady, offx, offy = int(rng.integers(1, 70)), int(rng.integers(0, 5)), int(rng.integers(0, 9)), int(rng.integers(0, 3))
+        big = np.full((h + pady + offy, w + padx + offx), 0x5A, np.uint8)
+        big[offy:offy + h, offx:offx + w] = img
+        view = big[offy:offy + h, offx:offx + w]
     try:
         ex = ORBextractor(*params)
-        kps, desc = ex(img)
+        kps, desc = ex(view)
     except Exception as e:
         # geometry the reference cannot run either (cell grid / nIni = 0) must be rejected by both
         if "error -5" in str(e):      # documented capacity limit (per-level quota above 2047, cell larger than the LDS tile)
