@@ -436,3 +436,26 @@ def test_rows_with_a_pitch_larger_than_the_width(shape, pad):
         check(ex2._L.orbx_extract(ex2._h, buf.ctypes.data_as(C.c_void_p), w, h, stride, kps.ctypes.data_as(C.c_void_p),
                                   desc.ctypes.data_as(C.c_void_p), ex2.capacity, C.byref(n)))
         assert n.value == len(k0) and kps[:n.value].tobytes() == k0.tobytes() and np.array_equal(desc[:n.value], d0)
+
+
+def test_one_handle_sizes_and_batches_in_turn():
+    """One ORBextractor serving frames of changing size and batches of changing length (orbx_reserve re-plans; the pair path's captured
+    graph, the small-batch kernel forms and the cached plan must all follow): every result equals a fresh handle's."""
+    rng = np.random.default_rng(9)
+    shapes = [(480, 640), (240, 320), (480, 640), (375, 1242), (480, 640)]
+    ex = ORBextractor(*PARAMS)
+    for step, (h, w) in enumerate(shapes):
+        img = np.ascontiguousarray(np.tile(synth_frame(step), ((h + 479) // 480, (w + 639) // 640))[:h, :w])
+        fresh = ORBextractor(*PARAMS)
+        k0, d0 = fresh(img)
+        k1, d1 = ex(img)
+        assert k1.tobytes() == k0.tobytes() and np.array_equal(d1, d0), (step, h, w)
+        B = int(rng.integers(2, 10))
+        frames = np.stack([np.roll(img, 7 * b, axis=1) for b in range(B)])
+        ex.extract_batch(frames); kb, db, cb = ex.download_batch()
+        fresh.extract_batch(frames); kf, df, cf = fresh.download_batch()
+        assert np.array_equal(cb, cf)
+        for b in range(B):
+            assert kb[b, :cb[b]].tobytes() == kf[b, :cf[b]].tobytes() and np.array_equal(db[b, :cb[b]], df[b, :cf[b]]), (step, B, b)
+        k2, d2 = ex(img)            # ... and back to one frame after the batch
+        assert k2.tobytes() == k0.tobytes() and np.array_equal(d2, d0)
