@@ -174,3 +174,25 @@ def test_stereo_frame_in_one_call_from_one_thread():
     (kl, dl), (kr, dr) = extract_pair(eL, eR, right, left)
     assert kl.tobytes() == rr[0].tobytes() and kr.tobytes() == rl[0].tobytes()
 
+
+
+def test_pair_call_follows_changing_sizes_and_single_calls():
+    """orbx_extract_pair replays a captured graph of a frame size from its third call on; a new size, a single-frame call or a batch on
+    either handle in between must not leave it replaying the old chain or writing into a released block: every pair result equals two
+    fresh single extractions."""
+    from orb_slam2_e_amd.extractor import extract_pair
+    from orb_slam2_e_amd.synth import synth_frame
+    left, right = ORBextractor(2000, 1.2, 8, 20, 7), ORBextractor(2000, 1.2, 8, 20, 7)
+    def frame(seed, h, w):
+        return np.ascontiguousarray(np.tile(synth_frame(seed), ((h + 479) // 480, (w + 639) // 640))[:h, :w])
+    plan = [(375, 1242)] * 4 + [(480, 640)] * 3 + [(375, 1242)] * 3 + [(720, 1280)] * 3 + [(480, 640)] * 2
+    for step, (h, w) in enumerate(plan):
+        il, ir = frame(2 * step, h, w), frame(2 * step + 1, h, w)
+        (kl, dl), (kr, dr) = extract_pair(left, right, il, ir)
+        for got_k, got_d, img in ((kl, dl, il), (kr, dr, ir)):
+            k0, d0 = ORBextractor(2000, 1.2, 8, 20, 7)(img)
+            assert got_k.tobytes() == k0.tobytes() and np.array_equal(got_d, d0), (step, h, w)
+        if step % 4 == 1:       # a single call and a batch on the left handle between two pair calls
+            k1, d1 = left(il)
+            assert k1.tobytes() == kl.tobytes()
+            left.extract_batch(np.stack([il, ir, il])); left.download_batch()
