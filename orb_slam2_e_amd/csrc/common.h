@@ -3,6 +3,7 @@
 #define ORBX_COMMON_H
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -70,6 +71,21 @@ struct KernelProfiler {
     void stop(int k, hipStream_t st)
     {
         if ((mask >> k) & 1u) rec(k | 0x100, st);
+    }
+    // A pair of events for hipExtLaunchKernelGGL to fill -- the kernel's own start and end, as rocprofv3 sees them -- instead of two
+    // hipEventRecord commands around the launch: those are queue packets of their own, and between them and a 70-us kernel of a
+    // three-stream mix lay 40 us that were not the kernel (bench.py's roofline: 0.113 ms per launch against the trace's 0.071).
+    bool pair(int k, hipEvent_t *a, hipEvent_t *b)
+    {
+        *a = *b = nullptr;
+        if (!((mask >> k) & 1u)) return false;
+        if (n + 4 >= MAXEV) flush();
+        for (int j = 0; j < 2; ++j) {
+            if (n == created) { (void)hipEventCreate(&ev[created]); ++created; }
+            kind[n] = j ? (k | 0x100) : k;
+            (j ? *b : *a) = ev[n++];
+        }
+        return true;
     }
     void flush()
     {

@@ -2458,20 +2458,17 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *images, int is_device,
                            ex->d_xt + lv.xtab, ex->d_yt + lv.ytab, nff, nint, nrg, ntail, tw_shift, ntw, rpw, ex->resize_tailwin[l]);
         pf.stop(1, st);
     }
-    pf.start(2, st);
-    if (ex->TS == 52)
-        hipLaunchKernelGGL((k_fast_cells<52, 40>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
-                           ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
-    else if (ex->TS == 64)
-        hipLaunchKernelGGL((k_fast_cells<64, 64>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
-                           ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
-    else
-        hipLaunchKernelGGL((k_fast_cells<80, 80>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, ex->d_pyr,
-                           ex->frame_bytes, ex->d_lv, ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands,
-                           ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes);
-    pf.stop(2, st);
+    {   // (profiled: the kernel's own start and end through hipExtLaunchKernelGGL -- see KernelProfiler::pair)
+        hipEvent_t e0, e1;
+        pf.pair(2, &e0, &e1);
+#define ORBX_FAST_LAUNCH(TS_, SS_) hipExtLaunchKernelGGL((k_fast_cells<TS_, SS_>), dim3(ex->cells_per_frame, batch), dim3(64), ex->fast_lds, st, e0, e1, 0, \
+            (const uint8_t *)ex->d_pyr, ex->frame_bytes, (const LevelInfo *)ex->d_lv, (const CellInfo *)ex->d_cells, ex->d_cell_count, ex->cells_per_frame, ex->d_cands, \
+            ex->cands_per_frame, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->tile_bytes, ex->sc_bytes, ex->queue_bytes)
+        if (ex->TS == 52) ORBX_FAST_LAUNCH(52, 40);
+        else if (ex->TS == 64) ORBX_FAST_LAUNCH(64, 64);
+        else ORBX_FAST_LAUNCH(80, 80);
+#undef ORBX_FAST_LAUNCH
+    }
     pf.start(3, st);
     // Small batches: OCT_TW = 512 threads per (level, frame) -- a level's workgroup is the one frame's critical path, and its passes over
     // keys and nodes are loops of dependent LDS reads that twice the threads make half as long: 43.6 -> 37.0 us for one frame (1,024

@@ -4,6 +4,7 @@
 #   main     tools/prof_main.sh     extract + match alone (one context): kernel trace + the PMC passes (FETCH_SIZE, WRITE_SIZE separately)
 #   default  tools/prof_default.sh  the pipelined three-context run without the other legs: per-kernel averages as the timed region sees them
 #   full     kernel trace of the driver's own command line (python3 bench.py --steps 20 --warmup 5)
+#   timed    tools/prof_timed.sh    2,000 steps, no other leg: per-kernel averages OF the timed region (bench.py's roofline events agree with them)
 #   fem      tools/prof_fem.sh      the three batched CG legs, one per process: k_fem_cg_resident and k_fem_spmv, trace + FETCH_SIZE + WRITE_SIZE
 #   bow      tools/bow_transform_prof.py: k_bow_transform, trace + FETCH_SIZE + WRITE_SIZE
 # Locally afterwards (tools/prof_r05_collect.sh <tag> <round>): summaries into profiles/.
@@ -15,6 +16,7 @@ find $R/gpurun_out/${T}_default -name "*kernel_trace.csv" -delete      # (the pe
 OUT=$R/gpurun_out/${T}_full; mkdir -p $OUT
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/trace.err; echo "full rc $?" )
 find $OUT -name "*kernel_trace.csv" -delete                             # (70,000 dispatches of the all-meshes FEM leg)
+$R/tools/prof_timed.sh ${T}_timed    # 2,000 pipelined steps and nothing else: the averages the bench line's event-timed roofline must agree with
 $R/tools/prof_fem.sh ${T}_fem
 OUT=$R/gpurun_out/${T}_bow; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R

@@ -7,6 +7,7 @@ cp $(find $G/${T}_main/trace -name "*kernel_stats.csv" | head -1) $P/${R}_main_b
 cp $(find $G/${T}_default/trace_default -name "*kernel_stats.csv" | head -1) $P/${R}_default_bench_kernel_stats.csv
 cp $(find $G/${T}_full/trace -name "*kernel_stats.csv" | head -1) $P/${R}_full_bench_kernel_stats.csv
 tail -1 $G/${T}_full/bench_line.json > $P/${R}_bench_line_under_rocprof.json
+if [ -d $G/${T}_timed ]; then cp $(find $G/${T}_timed/trace_timed -name "*kernel_stats.csv" | head -1) $P/${R}_timed_bench_kernel_stats.csv; grep '^{' $G/${T}_timed/trace_timed.log | tail -1 > $P/${R}_bench_line_timed_under_rocprof.json; fi
 python3 tools/fem_traffic.py $G/${T}_fem $P/${R}_fem_traffic.json > /dev/null
 for leg in batch batch_beyond_infinity_cache batch_distinct_topologies; do
   cp $(find $G/${T}_fem/$leg/trace -name "*kernel_stats.csv" | head -1) $P/${R}_fem_${leg}_kernel_stats.csv
