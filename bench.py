@@ -12,7 +12,8 @@ ratio filter) -> gather of the fixed-size result records on rank 0 (N>1 only).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 `roofline`: dominant kernel's algorithmic bytes / its mean launch time, timed
-with HIP events on the launch stream inside the timed region.  `cpu_baseline`:
+with HIP events on the launch stream inside the timed region (the events of the
+kernel's own start and end: hipExtLaunchKernelGGL inside the library).  `cpu_baseline`:
 the CPU oracle (single thread) on a bounded sample of the same workload.
 """
 import argparse
