@@ -505,7 +505,7 @@ def distinctive_case(m=2000, seed=3):
     return desc, off
 
 
-def bow_bench(torch, dev):
+def bow_bench(torch, dev, batch_only=False):
     """SURVEY 8(f) rank 2 at the reference's real vocabulary shape: DBoW2 transform's tree descent (TemplatedVocabulary.h:1218-1262,
     levelsup = 4 as Frame.cc:415) of 64 x 2000 resident descriptors through a k = 10, L = 6 tree (35.6 MB of node descriptors --
     the gather pattern of ORBvoc.txt, which is missing from the reference mount), one launch; and rank 4,
@@ -523,13 +523,22 @@ def bow_bench(torch, dev):
     ts = torch.cuda.Stream(device=dev)
     run = lambda: v.descend_batch_device(d_f.data_ptr(), d_cnt.data_ptr(), BOW_CAP, BOW_SETS, 4, d_w.data_ptr(), d_n.data_ptr(), ts.cuda_stream)
     reps = 50
+    from orb_slam2_e_amd._lib import lib
+    L = lib()
     with torch.cuda.stream(ts):
         for _ in range(5): run()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in ev:                    # events on the stream the kernel is launched on
-            a.record(ts); run(); b.record(ts)
-    ts.synchronize()
-    t = np.array([a.elapsed_time(b) for a, b in ev])
+        ts.synchronize()
+        # the kernel's own start and end events on the stream it is launched on (hipExtLaunchKernelGGL inside the library: two event
+        # records around a 20-us launch measured 30 us), one read per launch for the median
+        t = []
+        for _ in range(reps):
+            L.orbm_profile_enable(2)
+            run()
+            ms, nl = C.c_double(0), C.c_int64(0)
+            L.orbm_profile_read_bow(C.byref(ms), C.byref(nl))
+            t.append(ms.value / max(nl.value, 1))
+        L.orbm_profile_enable(0)
+    t = np.array(t)
     # whole-batch wall time, back to back without events
     t0 = time.perf_counter()
     for _ in range(reps): run()
@@ -557,6 +566,10 @@ def bow_bench(torch, dev):
         # `frac` above prices ALGORITHMIC bytes and exceeds 1: the tree's upper levels are served by L2 and the Infinity Cache.  What the
         # memory side really delivers (counter bytes over the same launch time):
         out["roofline"]["frac_of_counter_traffic"] = tr["hbm_bytes_per_launch"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if batch_only:      # (tools/bow_transform_prof.py: a trace in which every k_bow_transform launch is the 64 x 2000 one)
+        out["verified"] = bool(ok)
+        del v
+        return out
     put_ms(out, "transform_2000_host_arrays_ms", lambda: v.descend(feats[0], 4), 50)
     desc, off = distinctive_case()
     got = ORBmatcher.distinctive_descriptors(desc, off)

@@ -555,6 +555,8 @@ int orbm_set_allpairs_kernel(int kind);
 /* HIP-event timing of the all-pairs kernel launched through orbm_match_batch_dev. */
 int orbm_profile_enable(int on);
 int orbm_profile_read(double *total_ms, int64_t *launches);
+/* (orbm_profile_enable: bit 0 = the all-pairs matcher, bit 1 = orbm_bow_transform_batch_dev -- that kernel's own start and end events) */
+int orbm_profile_read_bow(double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

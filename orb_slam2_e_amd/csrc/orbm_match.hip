@@ -955,9 +955,11 @@ int orbm_bow_transform_batch_dev(orbm_vocabulary *v, const uint8_t *desc_dev, co
 {
     if (!v || !desc_dev || !counts_dev || cap <= 0 || nsets <= 0 || !word_id_dev || !node_id_dev) ORBX_FAIL(ORBX_ERR_ARG, "bad arguments");
     ORBX_NEED_DEVICE();
-    hipLaunchKernelGGL(k_bow_transform, dim3((cap + MT / 16 - 1) / (MT / 16), nsets), dim3(MT), 0, (hipStream_t)stream, (const uint4 *)v->d_slot_desc,
-                       (const int4 *)v->d_slot_rec, v->root_c1, v->L - levelsup, (const uint4 *)desc_dev, counts_dev, cap, 0,
-                       word_id_dev, node_id_dev);
+    hipEvent_t e0, e1;
+    g_prof.pair(1, &e0, &e1);                      // (orbm_profile_enable(2): the kernel's own start and end, as a kernel trace sees them)
+    hipExtLaunchKernelGGL(k_bow_transform, dim3((cap + MT / 16 - 1) / (MT / 16), nsets), dim3(MT), 0, (hipStream_t)stream, e0, e1, 0,
+                          (const uint4 *)v->d_slot_desc, (const int4 *)v->d_slot_rec, v->root_c1, v->L - levelsup, (const uint4 *)desc_dev, counts_dev, cap, 0,
+                          word_id_dev, node_id_dev);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
@@ -1105,11 +1107,11 @@ int orbm_set_allpairs_kernel(int kind)
     return g_allpairs_kind.exchange(kind);
 }
 
-int orbm_profile_enable(int on)
+int orbm_profile_enable(int on)      // bit 0: the all-pairs matcher's launches, bit 1: orbm_bow_transform_batch_dev's
 {
-    g_prof.names[0] = "k_match_sets_mfma";
+    g_prof.names[0] = "k_match_sets_mfma"; g_prof.names[1] = "k_bow_transform";
     g_prof.reset();
-    g_prof.mask = on ? 1u : 0u;
+    g_prof.mask = (unsigned)on & 3u;
     return ORBX_OK;
 }
 
@@ -1118,6 +1120,14 @@ int orbm_profile_read(double *total_ms, int64_t *launches)
     g_prof.flush();
     if (total_ms) *total_ms = g_prof.ms[0];
     if (launches) *launches = g_prof.launches[0];
+    return ORBX_OK;
+}
+
+int orbm_profile_read_bow(double *total_ms, int64_t *launches)
+{
+    g_prof.flush();
+    if (total_ms) *total_ms = g_prof.ms[1];
+    if (launches) *launches = g_prof.launches[1];
     return ORBX_OK;
 }
 

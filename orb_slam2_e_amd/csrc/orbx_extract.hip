@@ -1879,7 +1879,7 @@ void reader_done(orbx_extractor *ex, hipStream_t st)
 extern "C" {
 
 const char *orbx_last_error(void) { return orbx::last_error().c_str(); }
-int orbx_abi_version(void) { return 134; } // 134: + fem_cg_one_launch_stats (addition only); 133: + fem_plan_single_cg (addition only); 132: + fem_cg_preconditioner, fem_cg_coarse_matrix (additions only); 131: + orbm_frame_search_by_bow, orbm_frame_search_for_triangulation; ORBM_ALLPAIRS_MFMA now names the second matrix-core kernel (additions only); 130: + orbm_frame_*, the whole-function searches, orbx_params.trig_variant (a struct field: rebuild callers); 120: + fem_plan, fem_plan_selfcheck, orbm_sorted_frame, orbx_stereo_download_batch, orbm_debug_* (additions only); 110: + orbm_project_points, fem_create_batch, fem_batch_offsets
+int orbx_abi_version(void) { return 135; } // 135: + orbm_profile_read_bow (addition only); 134: + fem_cg_one_launch_stats (addition only); 133: + fem_plan_single_cg (addition only); 132: + fem_cg_preconditioner, fem_cg_coarse_matrix (additions only); 131: + orbm_frame_search_by_bow, orbm_frame_search_for_triangulation; ORBM_ALLPAIRS_MFMA now names the second matrix-core kernel (additions only); 130: + orbm_frame_*, the whole-function searches, orbx_params.trig_variant (a struct field: rebuild callers); 120: + fem_plan, fem_plan_selfcheck, orbm_sorted_frame, orbx_stereo_download_batch, orbm_debug_* (additions only); 110: + orbm_project_points, fem_create_batch, fem_batch_offsets
 
 int orbx_create(const orbx_params *prm, orbx_extractor **out)
 {

@@ -4,5 +4,5 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-out = bench.bow_bench(torch, torch.device("cuda", 0))
+out = bench.bow_bench(torch, torch.device("cuda", 0), batch_only=True)   # only the 64 x 2000 launches: the trace's average is theirs
 print(json.dumps({k: out[k] for k in ("launch_ms_avg", "launch_ms_median", "verified", "descriptors_per_s")}))

@@ -13,7 +13,7 @@ nodes, tets, fixed, load = synth_tet_batch(nm, ncell, seed=11)
 fea = FEA2(nodes, tets, FEM_TET4)
 fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
 b = np.tile(load, (nm, 1)); b[:, fixed] = 0
-fea.cg_setup(b); fea.cg_iterate(20); fea.cg_result()
+fea.cg_setup(b); fea.cg_iterate(iters); fea.cg_result()   # (warm-up of the same length: every launch in a trace of this tool is alike)
 for rep in range(3):
     fea.cg_setup(b)
     t0 = time.perf_counter(); fea.cg_iterate(iters); x, rel = fea.cg_result(); dt = time.perf_counter() - t0

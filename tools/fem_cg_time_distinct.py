@@ -13,7 +13,7 @@ fea = FEA2Batch(nodes_l, tets_l, FEM_TET4)
 fixed = np.concatenate([fea.dof0[k] + fx for k, fx in enumerate(fixed_l)]).astype(np.int32)
 b = np.concatenate(load_l)[None].copy(); b[:, fixed] = 0
 fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
-fea.cg_setup(b); fea.cg_iterate(20); fea.cg_result()
+fea.cg_setup(b); fea.cg_iterate(iters); fea.cg_result()   # (warm-up of the same length: every launch in a trace of this tool is alike)
 for rep in range(3):
     fea.cg_setup(b)
     t0 = time.perf_counter(); fea.cg_iterate(iters); x, rel = fea.cg_result(); dt = time.perf_counter() - t0
