@@ -459,3 +459,22 @@ def test_one_handle_sizes_and_batches_in_turn():
             assert kb[b, :cb[b]].tobytes() == kf[b, :cf[b]].tobytes() and np.array_equal(db[b, :cb[b]], df[b, :cf[b]]), (step, B, b)
         k2, d2 = ex(img)            # ... and back to one frame after the batch
         assert k2.tobytes() == k0.tobytes() and np.array_equal(d2, d0)
+
+
+def test_image_in_pinned_memory_is_read_in_place():
+    """An image that already lies in pinned host memory (a capture buffer allocated with hipHostMalloc) is not staged: the level-0 kernel
+    reads it where it is.  Same results as from pageable memory -- also as a region of interest of a larger pinned array."""
+    import torch
+    img = synth_frame(4)
+    ex = ORBextractor(*PARAMS)
+    k0, d0 = ex(img)
+    pin = torch.from_numpy(img).pin_memory().numpy()
+    assert pin.ctypes.data != img.ctypes.data
+    k1, d1 = ex(pin)
+    assert k1.tobytes() == k0.tobytes() and np.array_equal(d1, d0)
+    big = torch.full((500, 700), 0x33, dtype=torch.uint8).pin_memory().numpy()
+    big[7:487, 12:652] = img
+    k2, d2 = ex(big[7:487, 12:652])
+    assert k2.tobytes() == k0.tobytes() and np.array_equal(d2, d0)
+    k3, d3 = ex(img)           # ... and pageable again
+    assert k3.tobytes() == k0.tobytes()
