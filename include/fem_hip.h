@@ -172,7 +172,9 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
  * 1,274 -> 470 iterations to ||r|| <= 1e-8 ||b|| on BASELINE config 3's mesh.  Costs eight passes over the matrix and a 48 x 48
  * inverse per mesh in fem_cg_setup (0.24 ms for one 6,591-dof mesh, 1.7 ms for 256) and 6-13 per cent per iteration (batches that run on the compute units; k_fem_cg_resident).  Coarse dofs without a free fine dof, and modes that the modes before them
  * already span or nearly span (Cholesky pivot <= 1e-4 of the diagonal: the rotations of an aggregate whose free nodes lie on or near a line), are dropped.  No reference counterpart (neither has the CG): the oracle's
- * oracle_fem_cg_two_level is the definition.  Takes effect at the next fem_cg / fem_cg_setup. */
+ * oracle_fem_cg_two_level is the definition.  Takes effect at the next fem_cg / fem_cg_setup.  A dof whose diagonal entry is 0 -- a node that belongs to no element: K has a zero row and column there,
+ * as for the points no triangle uses in 800 of the reference's 853 surface meshes -- stays at 0 under either preconditioner and counts as
+ * constrained in the coarse space (until round 5: 1 / 0, every vector NaN). */
 enum { FEM_PRECOND_JACOBI = 0, FEM_PRECOND_TWO_LEVEL = 1 };
 int fem_cg_preconditioner(fem_model *m, int kind);
 /* Z^T K Z of one mesh as the last fem_cg_setup formed it (48 x 48, row-major); introspection for the tests. */

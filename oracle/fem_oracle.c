@@ -304,7 +304,7 @@ int oracle_fem_cg(int n, const int *rowptr, const int *col, const float *val, co
     for (i = 0; i < n; i++) {
         double d = 1.0;
         for (k = rowptr[i]; k < rowptr[i + 1]; k++) if (col[k] == i) d = (double)val[k];
-        dinv[i] = 1.0 / d;
+        dinv[i] = d != 0.0 ? 1.0 / d : 0.0;      /* a dof without a diagonal -- a node in no element: K has a zero row and column there -- stays at 0 */
         x[i] = 0; r[i] = b[i]; z[i] = r[i] * dinv[i]; p[i] = z[i];
         rz += r[i] * z[i]; bb += b[i] * b[i];
     }
@@ -456,13 +456,21 @@ int oracle_fem_cg_two_level(int n, const int *rowptr, const int *col, const floa
     float *q = (float *)malloc(sizeof(float) * 3 * nn);
     double rz = 0, bb = 0, rr, wv;
     int i, k, j, it = 0;
+    /* dofs without a diagonal (a node in no element) count as constrained: zero rows in Z, and they stay at 0 */
+    uint8_t *cm2 = (uint8_t *)malloc(n);
+    for (i = 0; i < n; i++) {
+        double d = 1.0;
+        for (k = rowptr[i]; k < rowptr[i + 1]; k++) if (col[k] == i) d = (double)val[k];
+        cm2[i] = (uint8_t)((cmask && cmask[i]) || d == 0.0);
+    }
+    cmask = cm2;
     oracle_fem_coarse_space(nn, nodes, agg, q);
     oracle_fem_coarse_matrix(n, rowptr, col, val, nodes, cmask, Aci);
     oracle_fem_coarse_inverse(Aci);
     for (i = 0; i < n; i++) {
         double d = 1.0;
         for (k = rowptr[i]; k < rowptr[i + 1]; k++) if (col[k] == i) d = (double)val[k];
-        dinv[i] = 1.0 / d;
+        dinv[i] = d != 0.0 ? 1.0 / d : 0.0;
         x[i] = 0; r[i] = b[i]; z[i] = r[i] * dinv[i];
         rz += r[i] * z[i]; bb += b[i] * b[i];
     }
@@ -494,7 +502,7 @@ int oracle_fem_cg_two_level(int n, const int *rowptr, const int *col, const floa
         it++;
     }
     if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0;
-    free(r); free(z); free(c); free(p); free(Ap); free(dinv); free(agg); free(q);
+    free(r); free(z); free(c); free(p); free(Ap); free(dinv); free(agg); free(q); free(cm2);
     return it;
 }
 

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(CGT) void k_fem_cg_init(const float *__restrict__ v
         if (row < sg.nrows) {
             const size_t g = (size_t)sg.row0 + row;
             const double d = (double)vals[sg.voff + diag_idx[sg.tab0 + row]];
-            const double di = 1.0 / d, bi = b[g];
+            const double di = d != 0.0 ? 1.0 / d : 0.0, bi = b[g];   // (no diagonal -- a node in no element, K has a zero row and column there: 800 of the reference's 853 meshes have such points --: the dof stays at 0)
             dinv[g] = di; x[g] = 0; r[g] = bi; p[g] = bi * di;
             s1 += bi * (bi * di); s2 += bi * bi;
         }
@@ -937,6 +937,12 @@ __global__ __launch_bounds__(CZ_T) void k_fem_cz_prolong(const float4 *__restric
 // pass, then placement by wave ballots -- stable), centroids as double sums over those lists IN LIST ORDER (one thread per aggregate
 // and axis: the oracle's sums, bit for bit), q = (float)(node - centroid).  cmask: constrained dofs (numbered like the rows: per
 // mesh when the layout is uniform, globally when segmented), or nullptr.
+// ... and such dofs count as constrained in the coarse space (zero rows in Z): the mask the caller's constraints gave, OR "no diagonal"
+__global__ void k_fem_mask_no_diagonal(const float *__restrict__ vals, const int *__restrict__ diag_idx, int ndof, uint8_t *__restrict__ cmask)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < ndof && vals[diag_idx[row]] == 0.0f) cmask[row] = 1;
+}
 __global__ __launch_bounds__(CZ_T) void k_fem_cz_build(const float *__restrict__ nodes, const uint8_t *__restrict__ cmask, int mask_global,
                                                        float4 *__restrict__ cz, float4 *__restrict__ cznode,
                                                        int *__restrict__ czptr, int *__restrict__ maxagg, int ndof, const int4 *__restrict__ minfo)
@@ -2536,10 +2542,12 @@ int setup_coarse(fem_model *m)
                      dalloc(&m->d_cwv, (size_t)m->nseg) || dalloc(&m->d_czmax, 1) || dalloc(&m->d_cmask, (size_t)m->ndof)))
         return -1;
     if (!m->cz_space_valid) {
-        if (!m->h_cmask.empty() && hipMemcpyAsync(m->d_cmask, m->h_cmask.data(), m->h_cmask.size(), hipMemcpyHostToDevice, m->stream) != hipSuccess) return -1;
+        if (m->h_cmask.empty()) { if (hipMemsetAsync(m->d_cmask, 0, (size_t)m->ndof, m->stream) != hipSuccess) return -1; }
+        else if (hipMemcpyAsync(m->d_cmask, m->h_cmask.data(), m->h_cmask.size(), hipMemcpyHostToDevice, m->stream) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_fem_mask_no_diagonal, dim3((m->ndof + 255) / 256), dim3(256), 0, m->stream, (const float *)m->d_vals, (const int *)m->d_diag, m->ndof, m->d_cmask);
         if (hipMemsetAsync(m->d_czmax, 0, sizeof(int), m->stream) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_fem_cz_build, dim3(m->nseg), dim3(CZ_T), 0, m->stream, (const float *)m->d_nodes,
-                           m->h_cmask.empty() ? (const uint8_t *)nullptr : (const uint8_t *)m->d_cmask, m->segmented() ? 1 : 0, m->d_cz, m->d_cznode,
+                           (const uint8_t *)m->d_cmask, m->segmented() ? 1 : 0, m->d_cz, m->d_cznode,
                            m->d_czptr, m->d_czmax, m->ndof, (const int4 *)m->d_minfo);
     }
     const dim3 g(CZ_NA, m->nseg);

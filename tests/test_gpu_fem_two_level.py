@@ -255,3 +255,40 @@ def test_two_level_api_errors_are_loud():
     assert fea.cg_coarse_matrix(0).shape == (48, 48)
     with pytest.raises(OrbxError):
         fea.cg_coarse_matrix(1)
+
+
+@pytest.mark.parametrize("nm", [1, 3, 70])
+def test_nodes_that_belong_to_no_element_stay_at_zero(nm):
+    """800 of the reference's 853 surface meshes have points that no triangle uses: K has a zero row and column for each of their dofs.
+    Such a dof has no diagonal to precondition with (1 / 0: every vector turned NaN, on the device and in the oracle alike) -- it stays
+    at 0 and counts as constrained in the coarse space; the rest of the system is solved as if those nodes were not there.  One mesh
+    (the one-launch kernel and the launch-per-phase path) and batches, both preconditioners, against the oracle and against the same
+    meshes without the extra nodes."""
+    import os
+    from orb_slam2_e_amd.fem import FEA2, FEM_TET4
+    from orb_slam2_e_amd.synth import synth_tet_mesh
+    nodes, tets, fixed, load = synth_tet_mesh(5)
+    rng = np.random.default_rng(4)
+    extra = np.array([[9.0, 9.0, 9.0], [-3.0, 1.0, 2.0], [0.5, 0.5, 7.0]], np.float32)
+    many = np.stack([np.vstack([nodes + rng.normal(0, 0.01, nodes.shape).astype(np.float32), extra]) for _ in range(nm)])
+    b = np.tile(np.concatenate([load, np.zeros(9)]), (nm, 1)); b[:, fixed] = 0
+    for pre in ("jacobi", "two_level"):
+        for xcd in (("1", "0") if nm == 1 else ("1",)):
+            os.environ["FEM_CG_XCD"] = xcd
+            try:
+                fea = FEA2(many, tets, FEM_TET4); fea.MatrixAssembly(); fea.eliminate_dofs(fixed)
+                fea.cg_preconditioner(pre)
+                x, done, rel = fea.solve_cg(b, iters=60, tol=0.0)
+            finally:
+                os.environ.pop("FEM_CG_XCD", None)
+            assert np.isfinite(x).all() and np.isfinite(rel).all() and np.all(x[:, len(load):] == 0)
+            ref = FEA2(many[:, :len(nodes)], tets, FEM_TET4); ref.MatrixAssembly(); ref.eliminate_dofs(fixed)
+            ref.cg_preconditioner(pre)
+            x0, _, rel0 = ref.solve_cg(b[:, :len(load)], iters=60, tol=0.0)
+            if pre == "jacobi":      # (the two-level form's aggregates are cut by the bounding box, which the extra nodes move)
+                assert np.abs(x[:, :len(load)] - x0).max() <= 1e-12 * np.abs(x0).max()
+            for k in sorted({0, nm - 1}):
+                rp, col, val = fea.csr(k)
+                mk = np.zeros(b.shape[1], np.uint8); mk[fixed] = 1
+                ox, _, orel = (oracle.fem_cg(rp, col, val, b[k], 60, 0.0) if pre == "jacobi" else oracle.fem_cg_two_level(rp, col, val, b[k], 60, many[k], mk))
+                assert np.abs(x[k] - ox).max() <= 1e-5 * np.abs(ox).max() and abs(rel[k] - orel) <= 1e-5 * orel
