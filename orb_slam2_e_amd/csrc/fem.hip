@@ -3836,7 +3836,7 @@ int fem_cg(fem_model *m, const double *b, double *x, int iters, double tol, int 
                 }
             }
             bool all = true;
-            for (int i = 0; i < m->nseg; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb));
+            for (int i = 0; i < m->nseg; ++i) all = all && (sqrt(sc[i].rr) <= tol * sqrt(sc[i].bb) || !(sc[i].rr == sc[i].rr));   // (a mesh whose residual is NaN -- non-finite K: degenerate elements -- will not converge: not waited for)
             if (all) break;
         }
         const int n = iters - done < 25 ? iters - done : 25;
