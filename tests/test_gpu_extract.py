@@ -110,6 +110,14 @@ def test_too_small_image_is_an_error():
     ((376, 1241), (2000, 1.2, 8, 12, 7)),     # KITTI 00-02 size (Examples/Stereo/KITTI00-02.yaml), odd width
     ((480, 640), (5000, 1.2, 8, 20, 7)),      # level-0 quota 1085: node state beyond 1024 leaves
     ((600, 800), (3000, 1.5, 3, 15, 5)),      # level-0 quota 1421
+    # THIS FORK's own settings (20 of its launch files: roslaunch/sHamlyn*.yaml, sHCULB_*.yaml, sEndoscope*.yaml, Examples/Stereo/EuRoC.yaml):
+    # 1200 features, scale 1.1, 6 levels, FAST 24 / 7 -- at the sizes their principal points suggest
+    ((360, 640), (1200, 1.1, 6, 24, 7)),      # Hamlyn (cx 327.9, cy 165.5)
+    ((480, 752), (1200, 1.1, 6, 24, 7)),      # EuRoC stereo as the fork sets it
+    ((1080, 1440), (1200, 1.1, 6, 24, 7)),    # HCULB (cx 770.2, cy 530.7)
+    ((576, 720), (1200, 1.1, 6, 24, 7)),      # endoscope, PAL frame
+    ((480, 640), (1200, 1.1, 6, 12, 7)),      # the two launch files with lower initial thresholds
+    ((480, 640), (1200, 1.1, 6, 9, 4)),
 ])
 def test_other_shapes_and_params(shape, params):
     img = synth_frame(3, w=shape[1], h=shape[0])
