@@ -7,14 +7,18 @@ from orb_slam2_e_amd import ORBextractor
 from orb_slam2_e_amd._lib import lib
 from orb_slam2_e_amd.synth import synth_frame
 
-ex = ORBextractor(2000, 1.2, 8, 20, 7)
-imgs = [synth_frame(k) for k in range(8)]
+# usage: single_frame_prof.py [w h nfeatures scale nlevels iniTh minTh]   (this fork's launch files: 640 360 1200 1.1 6 24 7)
+A = sys.argv[1:]
+W_, H_ = (int(A[0]), int(A[1])) if len(A) >= 2 else (640, 480)
+PRM = (int(A[2]), float(A[3]), int(A[4]), int(A[5]), int(A[6])) if len(A) >= 7 else (2000, 1.2, 8, 20, 7)
+ex = ORBextractor(*PRM)
+imgs = [synth_frame(k, w=W_, h=H_) for k in range(8)]
 for im in imgs: ex(im)
 t = []
 for r in range(200):
     t0 = time.perf_counter(); k, d = ex(imgs[r % 8]); t.append(time.perf_counter() - t0)
 t = np.array(t) * 1e3
-print("operator() 640x480, 2000 features: median %.3f ms  p90 %.3f ms  min %.3f ms  (%d keypoints)" % (np.median(t), np.percentile(t, 90), t.min(), len(k)))
+print("operator() %dx%d, %s: median" % (W_, H_, PRM) + " %.3f ms  p90 %.3f ms  min %.3f ms  (%d keypoints)" % (np.median(t), np.percentile(t, 90), t.min(), len(k)))
 L = lib()
 L.orbx_profile_enable(ex._h, -1)
 for r in range(50): ex(imgs[r % 8])
