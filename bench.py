@@ -989,7 +989,24 @@ def main():
         for k in range(8): one(frames[k])
         call_ms = batch_ms(lambda: one(frames[3]), 200, warm=10)
         del one
-        host_io = {"pcie_pinned_copy_GBps": bw, "frames_per_s_extract_only_sync_pageable": rate_sync, "frames_per_s_extract_only_pinned_pipelined": rate_pipe,
+        # (d) THIS fork's own settings (20 of its launch files: 1200 features, scale 1.1, 6 levels, FAST 24 / 7) at Hamlyn's frame size: one
+        # frame per call, and 64 resident frames per batch (extract only, one context, events-free wall time)
+        from orb_slam2_e_amd.synth import synth_frame
+        fk = ORBextractor(1200, 1.1, 6, 24, 7)
+        ff = np.stack([synth_frame(k, w=640, h=360) for k in range(BATCH)])
+        for k in range(8): fk(ff[k])
+        fork_call = batch_ms(lambda: fk(ff[3]), 200, warm=10)
+        d_ff = torch.from_numpy(ff).to(dev)
+        for _ in range(5): fk.extract_batch_device(d_ff.data_ptr(), BATCH, 360, 640)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50): fk.extract_batch_device(d_ff.data_ptr(), BATCH, 360, 640)
+        torch.cuda.synchronize()
+        fork_rate = 50 * BATCH / (time.perf_counter() - t0)
+        del fk, d_ff
+        fork = {"settings": "ORBextractor(1200, 1.1, 6, 24, 7), 640x360 (roslaunch/sHamlyn*.yaml)", "one_frame_operator_call_ms": fork_call[0],
+                "one_frame_operator_call_ms_best": fork_call[1], "frames_per_s_extract_only_resident_batches_of_64": fork_rate}
+        host_io = {"pcie_pinned_copy_GBps": bw, "fork_settings": fork, "frames_per_s_extract_only_sync_pageable": rate_sync, "frames_per_s_extract_only_pinned_pipelined": rate_pipe,
                    "bytes_per_frame": W * H + cap * 60 + 4,
                    "one_frame_operator_call_ms": call_ms[0], "one_frame_operator_call_ms_best": call_ms[1],
                    "note": "64 host u8 frames in over PCIe, all keypoints+descriptors+counts out; no match; never `value`; one_frame_*: a "
