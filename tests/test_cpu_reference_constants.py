@@ -112,3 +112,25 @@ def test_levenberg_hook_and_outlier_constants():
     g2o = _ours("oracle/mini_g2o.h")
     assert {float(v) for v in re.findall(r"> (5\.\d+)\)|<= (5\.\d+)\)", g2o) for v in v if v} == {5.991}
     assert "sqrt(5.991)" in g2o and re.search(r"sqrt\(5\.991\)", fn)
+
+
+def test_the_forks_own_extractor_settings():
+    """What this fork's launch files set (roslaunch/*.yaml, Examples/*/*.yaml): the tuple most of them share -- 1200 features, scale 1.1,
+    6 levels, FAST 24 / 7 -- is the one tests/test_gpu_extract.py and bench.py's `fork_settings` leg run; prisms (nElType 2) and the dead
+    inverse path (bUseInverse 0) are what the FEM tests assume."""
+    import collections
+    import glob
+    tuples, eltype, inverse = collections.Counter(), collections.Counter(), collections.Counter()
+    for f in glob.glob(os.path.join(REF, "roslaunch", "*.yaml")) + glob.glob(os.path.join(REF, "Examples", "*", "*.yaml")):
+        t = open(f, errors="replace").read()
+        g = {k: re.search(r"^ORBextractor\." + k + r":\s*([0-9.]+)", t, re.M) for k in ("nFeatures", "scaleFactor", "nLevels", "iniThFAST", "minThFAST")}
+        if all(g.values()):
+            tuples[tuple(float(v.group(1)) for v in g.values())] += 1
+        m = re.search(r"^RelocParam\.nElType:\s*(\d+)", t, re.M)
+        if m: eltype[int(m.group(1))] += 1
+        m = re.search(r"^RelocParam\.bUseInverse:\s*(\d+)", t, re.M)
+        if m: inverse[int(m.group(1))] += 1
+    assert tuples.most_common(1)[0][0] == (1200.0, 1.1, 6.0, 24.0, 7.0) and tuples.most_common(1)[0][1] >= 10
+    assert eltype.most_common(1)[0][0] == 2 and set(inverse) == {0}
+    src = _ours("tests/test_gpu_extract.py") + _ours("bench.py")
+    assert "(1200, 1.1, 6, 24, 7)" in src and "ORBextractor(1200, 1.1, 6, 24, 7)" in src
